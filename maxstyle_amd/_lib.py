@@ -1,0 +1,59 @@
+"""ctypes binding of libmaxstyle_hip.so (the C ABI declared in include/maxstyle_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing the import fails loudly, and every op
+refuses non-CUDA tensors.  Build with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C maxstyle_amd/csrc`."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmaxstyle_hip.so")
+
+c_f32p = ctypes.c_void_p   # raw device pointers travel as integers
+c_i64p = ctypes.c_void_p
+c_void = ctypes.c_void_p
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_size = ctypes.c_size_t
+
+# name -> (restype, argtypes): mirrors include/maxstyle_hip.h one to one (tests/test_abi.py checks both ways)
+SIGNATURES = {
+    "ms_version": (c_int, []),
+    "ms_last_error": (ctypes.c_char_p, []),
+    "ms_style_ws_bytes": (c_size, [c_int, c_int, c_int]),
+    "ms_style_moments": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_float, c_void, c_size, c_void]),
+    "ms_style_coeffs": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_int, c_int, c_void]),
+    "ms_style_apply": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_void]),
+    "ms_style_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p,
+                             c_int, c_int, c_int, c_float, c_void, c_size, c_void]),
+    "ms_style_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p,
+                             c_int, c_int, c_int, c_void, c_size, c_void]),
+    "ms_adam_step": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_float, c_float, c_float, c_float, c_int, c_void, c_void]),
+    "ms_counter_incr": (c_int, [c_void, c_void]),
+}
+
+
+class MaxStyleHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the MaxStyle HIP extension is not built. "
+            "Run `make -C maxstyle_amd/csrc` (or __graft_entry__.build()). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib.ms_last_error().decode(errors="replace")
+        raise MaxStyleHipError(f"{what} failed with status {status}: {msg}")

@@ -1,0 +1,409 @@
+// MaxStyle layer kernels for gfx950 (K1 forward, K2 backward, Adam on the style parameters).
+//
+// Reference semantics: /root/reference/src/advanced/maxstyle.py:140-189 (forward), autograd of it
+// (SURVEY.md A.2), torch.optim.Adam defaults.
+//
+// Data layout: x is NCHW fp32 contiguous; a "plane" is one (b,c) image of HW floats.  All kernels are
+// HBM-streaming: 16 B/lane coalesced loads, per-wave __shfl reductions, LDS only for the cross-wave
+// combine, fixed-order (deterministic) two-stage reductions, no float atomics.
+//
+//  forward  = moments_partial (1 read of x; register-resident two-pass variance per chunk)
+//           -> style_finalize (per channel: Chan-merge partials in fp64, batch std, mixing -> per-plane A,S)
+//           -> restyle        (read x, write y = A*(x-mu)/sig + S)
+//    algorithmic bytes: 8 B/element (the second read of x is served from L2/Infinity Cache when the tensor
+//    fits; the persistent single-read variant lives in ms_style_fused.hip)
+//  backward = restyle_bwd (read dy,x; write dx=dy*A/sig; partial S1=sum dy, S2=sum dy*xhat)
+//           -> style_bwd_finalize (d gamma, d beta, d lmda)
+#include <algorithm>
+#include "ms_common.h"
+#include "maxstyle_hip.h"
+
+namespace ms {
+
+constexpr int kStyleThreads = 256;
+
+struct PlanePartial { float n, mean, m2, pad; };
+
+// ---------------------------------------------------------------------------------------------
+// moments: grid (S, P). Block s of plane p owns elements [s*chunk, min(HW,(s+1)*chunk)).
+// VEC=4: float4 loads (needs HW%4==0 and 16-B aligned base); VEC=1: scalar loads (any shape).
+// NV = values of width VEC held per thread: chunk <= 256*VEC*NV.
+// ---------------------------------------------------------------------------------------------
+template <int VEC, int NV>
+__global__ __launch_bounds__(kStyleThreads) void moments_partial_kernel(const float* __restrict__ x, PlanePartial* __restrict__ part,
+                                                                       int HW, int chunk, int S) {
+  __shared__ float red[16];
+  const int p = blockIdx.y, s = blockIdx.x;
+  const int beg = s * chunk;
+  const int end = min(HW, beg + chunk);
+  const float* xp = x + (size_t)p * HW;
+  float v[NV][VEC];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = beg + (j * kStyleThreads + threadIdx.x) * VEC;
+    if (VEC == 4) {
+      if (i < end) {
+        const float4 t = *reinterpret_cast<const float4*>(xp + i);
+        v[j][0] = t.x; v[j][1] = t.y; v[j][2] = t.z; v[j][3] = t.w;
+      } else {
+        v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+      }
+    } else {
+      v[j][0] = (i < end) ? xp[i] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) sum += v[j][k];
+  }
+  const float n = (float)(end - beg);
+  const float mean = block_sum(sum, red) / n;
+  float m2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = beg + (j * kStyleThreads + threadIdx.x) * VEC;
+    if (i < end) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) { const float d = v[j][k] - mean; m2 += d * d; }
+    }
+  }
+  m2 = block_sum(m2, red);
+  if (threadIdx.x == 0) part[(size_t)p * S + s] = PlanePartial{n, mean, m2, 0.f};
+}
+
+__device__ __forceinline__ void merge_plane(const PlanePartial* part, int p, int S, int HW, float eps, float& mu, float& sig) {
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int s = 0; s < S; ++s) {
+    const PlanePartial q = part[(size_t)p * S + s];
+    chan_merge(n, mean, m2, (double)q.n, (double)q.mean, (double)q.m2);
+  }
+  mu = (float)mean;
+  const float var = (float)(m2 / (double)(HW - 1));   // unbiased, as torch.var default
+  sig = sqrtf(var + eps);
+}
+
+__global__ void moments_merge_kernel(const PlanePartial* __restrict__ part, float* __restrict__ mu, float* __restrict__ sig,
+                                     int P, int S, int HW, float eps) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float m, sg;
+  merge_plane(part, p, S, HW, eps, m, sg);
+  mu[p] = m; sig[p] = sg;
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: one block per channel c, thread b handles plane (b,c).
+//   merge partials -> mu,sig ; (first call) gamma_std[c]=std_b(sig), beta_std[c]=std_b(mu) (unbiased, fp64)
+//   lam=clamp(lmda[b],0,1); A = sig(1-lam)+sig[perm b]lam + gamma_noise*gamma_std ; S likewise with mu/beta.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void style_finalize_kernel(const PlanePartial* __restrict__ part, float* __restrict__ mu, float* __restrict__ sig,
+                                                              float* __restrict__ gamma_std, float* __restrict__ beta_std, int compute_std,
+                                                              const float* __restrict__ lmda, const float* __restrict__ gamma_noise,
+                                                              const float* __restrict__ beta_noise, const int64_t* __restrict__ perm,
+                                                              float* __restrict__ coefA, float* __restrict__ coefS,
+                                                              int B, int C, int S, int HW, float eps) {
+  __shared__ double redd[16];
+  extern __shared__ float sm[];     // [2*B]: mu_b, sig_b of this channel
+  float* smu = sm; float* ssig = sm + B;
+  const int c = blockIdx.x;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float m, sg;
+    if (part != nullptr) {
+      merge_plane(part, b * C + c, S, HW, eps, m, sg);
+      mu[b * C + c] = m; sig[b * C + c] = sg;
+    } else {
+      m = mu[b * C + c]; sg = sig[b * C + c];
+    }
+    smu[b] = m; ssig[b] = sg;
+  }
+  __syncthreads();
+  float gs, bs;
+  if (compute_std) {
+    double am = 0.0, as = 0.0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) { am += (double)smu[b]; as += (double)ssig[b]; }
+    const double mean_mu = block_sum_d(am, redd) / B;
+    const double mean_sg = block_sum_d(as, redd) / B;
+    double qm = 0.0, qs = 0.0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+      const double d1 = (double)smu[b] - mean_mu, d2 = (double)ssig[b] - mean_sg;
+      qm += d1 * d1; qs += d2 * d2;
+    }
+    qm = block_sum_d(qm, redd); qs = block_sum_d(qs, redd);
+    bs = (float)sqrt(qm / (double)(B - 1));
+    gs = (float)sqrt(qs / (double)(B - 1));
+    if (threadIdx.x == 0) { gamma_std[c] = gs; beta_std[c] = bs; }
+  } else {
+    gs = gamma_std[c]; bs = beta_std[c];
+  }
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float m = smu[b], sg = ssig[b];
+    float A = sg, Sh = m;
+    if (lmda != nullptr) {
+      const float lam = fminf(fmaxf(lmda[b], 0.f), 1.f);
+      const int pb = (int)perm[b];
+      A = sg * (1.f - lam) + ssig[pb] * lam;
+      Sh = m * (1.f - lam) + smu[pb] * lam;
+    }
+    if (gamma_noise != nullptr) {
+      A += gamma_noise[b * C + c] * gs;
+      Sh += beta_noise[b * C + c] * bs;
+    }
+    coefA[b * C + c] = A;
+    coefS[b * C + c] = Sh;
+  }
+}
+
+// y = A * ((x - mu) / sig) + S, grid (S, P) like the moments kernel.
+template <int VEC>
+__global__ __launch_bounds__(kStyleThreads) void restyle_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               const float* __restrict__ mu, const float* __restrict__ sig,
+                                                               const float* __restrict__ coefA, const float* __restrict__ coefS,
+                                                               int HW, int chunk) {
+  const int p = blockIdx.y;
+  const float m = mu[p], a = coefA[p] / sig[p], sh = coefS[p];
+  const int beg = blockIdx.x * chunk, end = min(HW, beg + chunk);
+  const float* xp = x + (size_t)p * HW;
+  float* yp = y + (size_t)p * HW;
+  for (int i = beg + threadIdx.x * VEC; i < end; i += kStyleThreads * VEC) {
+    if (VEC == 4) {
+      float4 t = *reinterpret_cast<const float4*>(xp + i);
+      t.x = a * (t.x - m) + sh; t.y = a * (t.y - m) + sh; t.z = a * (t.z - m) + sh; t.w = a * (t.w - m) + sh;
+      *reinterpret_cast<float4*>(yp + i) = t;
+    } else {
+      yp[i] = a * (xp[i] - m) + sh;
+    }
+  }
+}
+
+// backward: partial S1 = sum dy, S2 = sum dy*xhat; dx = dy * A/sig (optional)
+template <int VEC>
+__global__ __launch_bounds__(kStyleThreads) void restyle_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                                                                   const float* __restrict__ mu, const float* __restrict__ sig,
+                                                                   const float* __restrict__ coefA, float2* __restrict__ part,
+                                                                   int HW, int chunk, int S) {
+  __shared__ float red[16];
+  const int p = blockIdx.y;
+  const float m = mu[p], inv = 1.f / sig[p], a = coefA[p] * inv;
+  const int beg = blockIdx.x * chunk, end = min(HW, beg + chunk);
+  const float* xp = x + (size_t)p * HW;
+  const float* gp = dy + (size_t)p * HW;
+  float* dxp = dx ? dx + (size_t)p * HW : nullptr;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = beg + threadIdx.x * VEC; i < end; i += kStyleThreads * VEC) {
+    if (VEC == 4) {
+      const float4 g = *reinterpret_cast<const float4*>(gp + i);
+      const float4 t = *reinterpret_cast<const float4*>(xp + i);
+      s1 += (g.x + g.y) + (g.z + g.w);
+      s2 += g.x * ((t.x - m) * inv) + g.y * ((t.y - m) * inv) + g.z * ((t.z - m) * inv) + g.w * ((t.w - m) * inv);
+      if (dxp) *reinterpret_cast<float4*>(dxp + i) = make_float4(g.x * a, g.y * a, g.z * a, g.w * a);
+    } else {
+      const float g = gp[i];
+      s1 += g; s2 += g * ((xp[i] - m) * inv);
+      if (dxp) dxp[i] = g * a;
+    }
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) part[(size_t)p * S + blockIdx.x] = make_float2(s1, s2);
+}
+
+// one block per batch sample b; threads over channels.
+__global__ __launch_bounds__(256) void style_bwd_finalize_kernel(const float2* __restrict__ part, const float* __restrict__ mu, const float* __restrict__ sig,
+                                                                  const float* __restrict__ gamma_std, const float* __restrict__ beta_std,
+                                                                  const float* __restrict__ lmda, const int64_t* __restrict__ perm,
+                                                                  float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_lmda,
+                                                                  int B, int C, int S) {
+  __shared__ double redd[16];
+  const int b = blockIdx.x;
+  const int pb = perm ? (int)perm[b] : b;
+  double acc = 0.0;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int p = b * C + c;
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < S; ++s) { const float2 q = part[(size_t)p * S + s]; s1 += (double)q.x; s2 += (double)q.y; }
+    if (d_gamma) d_gamma[p] = (float)((double)gamma_std[c] * s2);
+    if (d_beta) d_beta[p] = (float)((double)beta_std[c] * s1);
+    const int q = pb * C + c;
+    acc += ((double)sig[q] - (double)sig[p]) * s2 + ((double)mu[q] - (double)mu[p]) * s1;
+  }
+  acc = block_sum_d(acc, redd);
+  if (threadIdx.x == 0 && d_lmda) {
+    const float l = lmda[b];
+    d_lmda[b] = (l >= 0.f && l <= 1.f) ? (float)acc : 0.f;   // clamp(): zero gradient outside [0,1]
+  }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
+                            float lr, float b1, float b2, float eps, int step, const int* __restrict__ step_dev) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = step_dev ? (*step_dev + 1) : step;
+  // torch.optim.Adam (single-tensor path): bias corrections in double on the host there; float pow here
+  const double bc1 = 1.0 - pow((double)b1, (double)t);
+  const double bc2 = 1.0 - pow((double)b2, (double)t);
+  const float gi = g[i];
+  const float mi = m[i] * b1 + gi * (1.f - b1);     // m.lerp_(g, 1-b1) == m + (g-m)(1-b1); same to 1 ulp
+  const float vi = v[i] * b2 + gi * gi * (1.f - b2);
+  m[i] = mi; v[i] = vi;
+  const float step_size = (float)((double)lr / bc1);
+  const float denom = sqrtf(vi) / (float)sqrt(bc2) + eps;
+  p[i] = p[i] - step_size * (mi / denom);
+}
+
+__global__ void incr_kernel(int* c) { if (threadIdx.x == 0 && blockIdx.x == 0) *c += 1; }
+
+struct Split { int chunk, S, nv; bool vec; };
+
+static Split choose_split(int P, int HW, bool vec_ok) {
+  // Largest register tile that still yields >= ~1024 blocks (256 CUs x 4): P*S >= 1024 when possible.
+  Split sp; sp.vec = vec_ok;
+  const int vec = vec_ok ? 4 : 1;
+  int nv = 8;
+  while (nv > 1) {
+    const int chunk = kStyleThreads * vec * nv;
+    const long blocks = (long)P * cdiv(HW, chunk);
+    if (blocks >= 1024) break;
+    nv >>= 1;
+  }
+  sp.nv = nv;
+  sp.chunk = kStyleThreads * vec * nv;
+  sp.S = cdiv(HW, sp.chunk);
+  return sp;
+}
+
+}  // namespace ms
+
+using namespace ms;
+
+extern "C" size_t ms_style_ws_bytes(int B, int C, int HW) {
+  // worst case split: scalar path, nv=1 -> chunk 256
+  const size_t P = (size_t)B * C;
+  const size_t S = (size_t)cdiv(HW, kStyleThreads);
+  return P * S * sizeof(PlanePartial) + 256;
+}
+
+static int launch_moments(const float* x, PlanePartial* part, int P, int HW, const Split& sp, hipStream_t st) {
+  dim3 grid(sp.S, P), block(kStyleThreads);
+#define MS_LAUNCH_MOM(V, N) hipLaunchKernelGGL((moments_partial_kernel<V, N>), grid, block, 0, st, x, part, HW, sp.chunk, sp.S)
+  if (sp.vec) {
+    switch (sp.nv) { case 8: MS_LAUNCH_MOM(4, 8); break; case 4: MS_LAUNCH_MOM(4, 4); break; case 2: MS_LAUNCH_MOM(4, 2); break; default: MS_LAUNCH_MOM(4, 1); }
+  } else {
+    switch (sp.nv) { case 8: MS_LAUNCH_MOM(1, 8); break; case 4: MS_LAUNCH_MOM(1, 4); break; case 2: MS_LAUNCH_MOM(1, 2); break; default: MS_LAUNCH_MOM(1, 1); }
+  }
+#undef MS_LAUNCH_MOM
+  return check_launch("moments_partial");
+}
+
+static int check_style_args(int B, int C, int HW, const void* ws, size_t ws_bytes) {
+  if (B < 1 || C < 1 || HW < 2) { set_error("ms_style: invalid shape B=%d C=%d HW=%d", B, C, HW); return MS_ERR_INVALID; }
+  if ((long)B * C > 2147483647L / 2 || (long)B * C > 65535L * 65535L) { set_error("ms_style: too many planes"); return MS_ERR_INVALID; }
+  if (ws == nullptr || ws_bytes < ms_style_ws_bytes(B, C, HW)) { set_error("ms_style: workspace too small (%zu < %zu)", ws_bytes, ms_style_ws_bytes(B, C, HW)); return MS_ERR_WORKSPACE; }
+  if (!aligned16(ws)) { set_error("ms_style: workspace must be 16-byte aligned"); return MS_ERR_ALIGN; }
+  return MS_OK;
+}
+
+// gridDim.y is limited to 65535: planes beyond that are processed in slabs.
+static constexpr int kMaxPlanesPerLaunch = 65535;
+
+extern "C" int ms_style_moments(const float* x, float* mu, float* sig, int planes, int HW, float eps, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_style_args(planes, 1, HW, ws, ws_bytes)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (HW % 4 == 0) && aligned16(x);
+  const Split sp = choose_split(planes, HW, vec);
+  PlanePartial* part = (PlanePartial*)ws;
+  for (int p0 = 0; p0 < planes; p0 += kMaxPlanesPerLaunch) {
+    const int np = std::min(kMaxPlanesPerLaunch, planes - p0);
+    if (int e = launch_moments(x + (size_t)p0 * HW, part + (size_t)p0 * sp.S, np, HW, sp, st)) return e;
+  }
+  hipLaunchKernelGGL(moments_merge_kernel, dim3(cdiv(planes, 256)), dim3(256), 0, st, part, mu, sig, planes, sp.S, HW, eps);
+  return check_launch("moments_merge");
+}
+
+extern "C" int ms_style_coeffs(float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std, const float* lmda,
+                               const float* gamma_noise, const float* beta_noise, const int64_t* perm, float* coefA, float* coefS,
+                               int B, int C, void* stream) {
+  if (B < 1 || C < 1) { set_error("ms_style_coeffs: invalid shape"); return MS_ERR_INVALID; }
+  if (compute_std && B < 2) { set_error("ms_style_coeffs: batch std needs B >= 2"); return MS_ERR_INVALID; }
+  if (lmda != nullptr && perm == nullptr) { set_error("ms_style_coeffs: mixing needs perm"); return MS_ERR_INVALID; }
+  if ((gamma_noise == nullptr) != (beta_noise == nullptr)) { set_error("ms_style_coeffs: gamma/beta noise must both be given"); return MS_ERR_INVALID; }
+  hipLaunchKernelGGL(style_finalize_kernel, dim3(C), dim3(256), 2 * B * sizeof(float), (hipStream_t)stream, (const PlanePartial*)nullptr, mu, sig,
+                     gamma_std, beta_std, compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, 0, 0, 0.f);
+  return check_launch("style_finalize");
+}
+
+extern "C" int ms_style_apply(const float* x, float* y, const float* mu, const float* sig, const float* coefA, const float* coefS,
+                              int planes, int HW, void* stream) {
+  if (planes < 1 || HW < 1) { set_error("ms_style_apply: invalid shape"); return MS_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (HW % 4 == 0) && aligned16(x) && aligned16(y);
+  const Split sp = choose_split(planes, HW, vec);
+  for (int p0 = 0; p0 < planes; p0 += kMaxPlanesPerLaunch) {
+    const int np = std::min(kMaxPlanesPerLaunch, planes - p0);
+    dim3 grid(sp.S, np), block(kStyleThreads);
+    const size_t off = (size_t)p0 * HW;
+    if (vec) hipLaunchKernelGGL(restyle_kernel<4>, grid, block, 0, st, x + off, y + off, mu + p0, sig + p0, coefA + p0, coefS + p0, HW, sp.chunk);
+    else hipLaunchKernelGGL(restyle_kernel<1>, grid, block, 0, st, x + off, y + off, mu + p0, sig + p0, coefA + p0, coefS + p0, HW, sp.chunk);
+  }
+  return check_launch("restyle");
+}
+
+extern "C" int ms_style_fwd(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+                            const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
+                            float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_style_args(B, C, HW, ws, ws_bytes)) return e;
+  if (compute_std && B < 2) { set_error("ms_style_fwd: batch std needs B >= 2"); return MS_ERR_INVALID; }
+  if (lmda != nullptr && perm == nullptr) { set_error("ms_style_fwd: mixing needs perm"); return MS_ERR_INVALID; }
+  if ((gamma_noise == nullptr) != (beta_noise == nullptr)) { set_error("ms_style_fwd: gamma/beta noise must both be given"); return MS_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  const int P = B * C;
+  const bool vec = (HW % 4 == 0) && aligned16(x);
+  const Split sp = choose_split(P, HW, vec);
+  PlanePartial* part = (PlanePartial*)ws;
+  for (int p0 = 0; p0 < P; p0 += kMaxPlanesPerLaunch) {
+    const int np = std::min(kMaxPlanesPerLaunch, P - p0);
+    if (int e = launch_moments(x + (size_t)p0 * HW, part + (size_t)p0 * sp.S, np, HW, sp, st)) return e;
+  }
+  hipLaunchKernelGGL(style_finalize_kernel, dim3(C), dim3(256), 2 * B * sizeof(float), st, (const PlanePartial*)part, mu, sig, gamma_std, beta_std,
+                     compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, sp.S, HW, eps);
+  if (int e = check_launch("style_finalize")) return e;
+  return ms_style_apply(x, y, mu, sig, coefA, coefS, P, HW, stream);
+}
+
+extern "C" int ms_style_bwd(const float* dy, const float* x, float* dx, const float* mu, const float* sig, const float* coefA,
+                            const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
+                            float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_style_args(B, C, HW, ws, ws_bytes)) return e;
+  if (d_lmda != nullptr && (lmda == nullptr || perm == nullptr)) { set_error("ms_style_bwd: d_lmda needs lmda and perm"); return MS_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  const int P = B * C;
+  const bool vec = (HW % 4 == 0) && aligned16(x) && aligned16(dy) && (dx == nullptr || aligned16(dx));
+  const Split sp = choose_split(P, HW, vec);
+  float2* part = (float2*)ws;
+  for (int p0 = 0; p0 < P; p0 += kMaxPlanesPerLaunch) {
+    const int np = std::min(kMaxPlanesPerLaunch, P - p0);
+    dim3 grid(sp.S, np), block(kStyleThreads);
+    const size_t off = (size_t)p0 * HW;
+    float* dxo = dx ? dx + off : nullptr;
+    if (vec) hipLaunchKernelGGL(restyle_bwd_kernel<4>, grid, block, 0, st, dy + off, x + off, dxo, mu + p0, sig + p0, coefA + p0, part + (size_t)p0 * sp.S, HW, sp.chunk, sp.S);
+    else hipLaunchKernelGGL(restyle_bwd_kernel<1>, grid, block, 0, st, dy + off, x + off, dxo, mu + p0, sig + p0, coefA + p0, part + (size_t)p0 * sp.S, HW, sp.chunk, sp.S);
+  }
+  if (int e = check_launch("restyle_bwd")) return e;
+  if (d_gamma || d_beta || d_lmda) {
+    hipLaunchKernelGGL(style_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, (const float2*)part, mu, sig, gamma_std, beta_std, lmda, perm,
+                       d_gamma, d_beta, d_lmda, B, C, sp.S);
+    return check_launch("style_bwd_finalize");
+  }
+  return MS_OK;
+}
+
+extern "C" int ms_adam_step(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2, float eps, int step,
+                            const int* step_dev, void* stream) {
+  if (n < 0 || (step_dev == nullptr && step < 1)) { set_error("ms_adam_step: invalid n/step"); return MS_ERR_INVALID; }
+  if (n == 0) return MS_OK;
+  hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, step, step_dev);
+  return check_launch("adam");
+}
+
+extern "C" int ms_counter_incr(int* counter, void* stream) {
+  hipLaunchKernelGGL(incr_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter);
+  return check_launch("incr");
+}

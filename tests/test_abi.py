@@ -1,0 +1,89 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/*.h declares
+(and nothing in the ctypes table is undeclared), and the host logic of the MaxStyle module mirrors the reference."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "maxstyle_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(ms_[a-z0-9_]+)\s*\(", text))
+
+
+def test_library_exports_every_declared_symbol():
+    import maxstyle_amd._lib as L
+    declared = _header_symbols()
+    assert declared, "no declarations parsed"
+    assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
+    out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (ms_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+    assert L.lib.ms_version() >= 100
+
+
+def test_missing_extension_fails_loudly(tmp_path, monkeypatch):
+    import importlib, maxstyle_amd._lib as L
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        L._load()
+
+
+def test_cpu_tensor_is_refused():
+    from maxstyle_amd import MaxStyle
+    torch.manual_seed(0)
+    m = MaxStyle(4, 3, p=1.5, use_gpu=False)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        m(torch.randn(4, 3, 8, 8))
+
+
+def test_maxstyle_host_contract():
+    """Constructor/attribute/parameter-order contract of maxstyle.py:14-139 (no GPU needed)."""
+    from maxstyle_amd import MaxStyle
+    torch.manual_seed(43)
+    m = MaxStyle(batch_size=4, num_feature=2, p=1.5, use_gpu=False)
+    assert [n for n, _ in m.named_parameters()] == ["gamma_noise", "beta_noise", "lmda"]
+    assert m.gamma_noise.shape == (4, 2, 1, 1) and m.lmda.shape == (4, 1, 1, 1)
+    assert m.perm.dtype == torch.int64 and not torch.equal(m.perm, torch.arange(4))
+    assert m.gamma_std is None and m.beta_std is None and m.data is None
+    assert "MaxStyle" in repr(m)
+    # identity short-cuts return the very same object (maxstyle.py:146-152)
+    x1 = torch.randn(4, 2, 1, 1)
+    assert m(x1) is x1
+    off = MaxStyle(4, 2, p=-1.0, use_gpu=False)   # rand_p >= p always: "not applied"
+    assert list(off.parameters()) == [] and repr(off) == "diffuse style not applied"
+    x = torch.randn(4, 2, 3, 3)
+    assert off(x) is x
+    assert float(off.lmda.abs().sum()) == 0.0
+    with pytest.raises(AssertionError, match="turn no_noise=False"):
+        MaxStyle(4, 2, p=1.5, no_noise=True, noise_learnable=True, use_gpu=False)
+    # reference quirk: a previously applied instance that redraws "not applied" raises TypeError in reset()
+    m.p = -1.0
+    with pytest.raises(TypeError):
+        m.reset()
+    # mix_learnable=False keeps lmda a Parameter without grad; mix_style=False makes it a plain zero tensor
+    m2 = MaxStyle(4, 2, p=1.5, mix_learnable=False, use_gpu=False)
+    assert isinstance(m2.lmda, torch.nn.Parameter) and not m2.lmda.requires_grad
+    m3 = MaxStyle(4, 2, p=1.5, mix_style=False, use_gpu=False)
+    assert not isinstance(m3.lmda, torch.nn.Parameter) and [n for n, _ in m3.named_parameters()] == ["gamma_noise", "beta_noise"]
+    with pytest.raises(ValueError):
+        MaxStyle(1, 2, use_gpu=False)     # the reference hangs forever here; we refuse
+
+
+def test_rng_draw_order_matches_reference_kat(golden_dir):
+    """Same torch.manual_seed -> same perm / rand_p / (CPU) noise draws as the reference's __main__ smoke."""
+    import numpy as np
+    from maxstyle_amd import MaxStyle
+    g = np.load(os.path.join(golden_dir, "kat_ramp.npz"))
+    torch.manual_seed(43)
+    m = MaxStyle(batch_size=4, num_feature=2, p=0.5, use_gpu=False)
+    np.testing.assert_array_equal(m.perm.numpy(), g["perm"])
+    np.testing.assert_allclose(m.rand_p.numpy(), g["rand_p"])
+    np.testing.assert_allclose(m.gamma_noise.detach().numpy(), g["gamma_noise0"])
+    np.testing.assert_allclose(m.beta_noise.detach().numpy(), g["beta_noise0"])
+    np.testing.assert_allclose(m.lmda.detach().numpy(), g["lmda0"])
