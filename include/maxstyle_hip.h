@@ -65,6 +65,66 @@ int ms_adam_step(float* p, const float* g, float* m, float* v, int n, float lr, 
                  const int* step_dev, void* stream);
 int ms_counter_incr(int* counter, void* stream);
 
+/* ---- convolution stack: src/models/ebm/encoder_decoder.py:22-74, 289-357, 423-482, 561-596, 634-680 -------- */
+
+/* Implicit-GEMM convolution on the exact-fp32 matrix cores.  Replaces nn.Conv2d(k=3,p=1,s=1|2), nn.Conv2d(k=1),
+ * nn.ConvTranspose2d(k=2,s=2) and (with transformed weights) their data-gradients.
+ *   in        [N,Cin,Hs,Ws]; in2 same shape (only for pro_mode 2)
+ *   w_packed  [ks*ks][cin_pad][cout_pad] fp32, cin_pad = roundup(Cin,4), cout_pad = roundup(gemm_cols,64), zero padded,
+ *             w_packed[ky*ks+kx][ci][co] = weight[co][ci][ky][kx]           (gemm_cols = Cout, or 4*Cout for epi_mode 2)
+ *   ks/stride (3,1) (3,2) (1,1) (2,2); padding = 1 for ks 3 else 0
+ *   fetch     0 normal | 1 nearest x2 up-sampling fused into the load | 2 zero-insertion x2 (stride-2 data-gradient)
+ *   pro_mode  0 none | 1 v = LeakyReLU_slope(pro_a[i]*v + pro_b[i]), i = n*pro_nstride + ci  (BatchNorm apply + activation
+ *             of the producer; pro_nstride = 0 per channel, = Cin per (n,c) plane)
+ *             | 2 v = pro_a[ci]*v + pro_b[ci]*in2 + pro_c[ci]   (BatchNorm backward apply)
+ *   epi_mode  0 out = acc + bias | 1 out += acc + bias | 2 ConvTranspose2d(k=2,s=2) pixel-shuffle store:
+ *             GEMM column (dy*2+dx)*Cout+co -> out[n,co,2y+dy,2x+dx] (needs ks=1)
+ *   stats     NULL or float4[Cout][ms_conv_stats_parts()] receiving per-workgroup (count, mean, M2, 0) of the outputs
+ *             for ms_bn_finalize (BatchNorm batch statistics; model_util.py:468-510). */
+size_t ms_conv_stats_bytes(int N, int Cout, int Hout, int Wout);
+int ms_conv_stats_parts(int N, int Hout, int Wout);
+int ms_conv2d(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
+              int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+              int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, float slope,
+              int epi_mode, float* stats, void* stream);
+
+/* Chan-merge of the per-workgroup statistics in fp64 -> coef4[c] = {scale=gamma*invstd, shift=beta-mean*scale, mean, invstd}
+ * (biased variance + eps: nn.BatchNorm2d training-mode normalisation with frozen affine). */
+int ms_bn_finalize(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, int C, void* stream);
+
+/* ---- streaming kernels around the convolutions ------------------------------------------------------------- */
+
+/* out = LeakyReLU_slope(coef4[c].scale*u + coef4[c].shift + res): BatchNorm apply + residual add + activation
+ * (encoder_decoder.py:62-64, 344-346; slope 0.2, or 0 for nn.ReLU).  res_mode 0 none | 1 same shape | 2 res is
+ * [N,C,H/2,W/2] and is nearest-up-sampled on the fly (conv1x1 commutes with nn.UpsamplingNearest2d). */
+int ms_bn_act(const float* u, const float* coef4, const float* res, int res_mode, float* out, int N, int C, int H, int W, float slope, void* stream);
+
+/* Backward through the activation + the two BatchNorm-backward reductions in one pass:
+ *   gout = gin * (r > 0 ? 1 : slope), r = ref (the saved activation output) or coef4.scale*u+coef4.shift when ref == NULL;
+ *   part2[c][ms_act_bwd_parts()] = per-workgroup {sum gout, sum gout*u}.  gout may alias gin. */
+int ms_act_bwd_parts(int N, int C, int HW);
+int ms_act_bwd_reduce(const float* gin, const float* ref, const float* u, const float* coef4, float* gout, float* part2,
+                      int N, int C, int HW, float slope, void* stream);
+
+/* native_batch_norm_backward (input gradient only, batch statistics): du = al*g + be*u + de, coef_out4[c] = {al,be,de,0}
+ * (SURVEY.md A.7).  count = N*H*W.  Feed coef_out4 to ms_conv2d(pro_mode=2) of the data-gradient convolution. */
+int ms_bn_bwd_coefs(const float* part2, int nparts, const float* coef4, double count, float* coef_out4, int C, void* stream);
+
+/* out[p,y,x] (+)= in[p,2y,2x]+in[p,2y,2x+1]+in[p,2y+1,2x]+in[p,2y+1,2x+1]: gradient of nn.UpsamplingNearest2d(2) */
+int ms_pool2_sum(const float* in, float* out, int planes, int Ho, int Wo, int accumulate, void* stream);
+
+/* Heads (1x1 conv with K <= 4 outputs from C <= 64 channels; w is [K][C]):
+ *   ms_head_fwd  out = sigmoid?(w h + b)         MyDecoder.final_conv + nn.Sigmoid (encoder_decoder.py:582,594)
+ *   ms_head_bwd  dh = w^T (dout * out*(1-out))   (apply_sigmoid=0: dh = w^T dout)
+ *   ms_head_ce   logits = w h + b; loss = loss_sign * cross_entropy_2D(logits, labels) (custom_loss.py:1043-1078: sum of
+ *                pixel NLL / (N*H*W)); writes loss_out[*loss_slot_dev or 0], dh = d loss / d h (NULL to skip) and the
+ *                logits (NULL to skip).  The inner loop uses loss_sign = -1 (advanced_triplet...py:555). */
+int ms_head_fwd(const float* h, const float* w, const float* b, float* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
+int ms_head_bwd(const float* dout, const float* out, const float* w, float* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
+size_t ms_head_ce_ws_bytes(int N, int HW);
+int ms_head_ce(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* logits, float* loss_out,
+               const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

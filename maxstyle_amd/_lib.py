@@ -30,6 +30,21 @@ SIGNATURES = {
                              c_int, c_int, c_int, c_void, c_size, c_void]),
     "ms_adam_step": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_float, c_float, c_float, c_float, c_int, c_void, c_void]),
     "ms_counter_incr": (c_int, [c_void, c_void]),
+    "ms_conv_stats_bytes": (c_size, [c_int, c_int, c_int, c_int]),
+    "ms_conv_stats_parts": (c_int, [c_int, c_int, c_int]),
+    "ms_conv2d": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                          c_int, c_f32p, c_f32p, c_f32p, c_int, c_float, c_int, c_f32p, c_void]),
+    "ms_bn_finalize": (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void]),
+    "ms_bn_act": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_int, c_int, c_int, c_float, c_void]),
+    "ms_act_bwd_parts": (c_int, [c_int, c_int, c_int]),
+    "ms_act_bwd_reduce": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_float, c_void]),
+    "ms_bn_bwd_coefs": (c_int, [c_f32p, c_int, c_f32p, ctypes.c_double, c_f32p, c_int, c_void]),
+    "ms_pool2_sum": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_void]),
+    "ms_head_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_void]),
+    "ms_head_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_void]),
+    "ms_head_ce_ws_bytes": (c_size, [c_int, c_int]),
+    "ms_head_ce": (c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_void, c_int, c_int, c_int, c_int, c_float,
+                           c_void, c_size, c_void]),
 }
 
 

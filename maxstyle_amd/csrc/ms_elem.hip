@@ -1,0 +1,340 @@
+// Streaming (HBM-bound) kernels around the convolutions: BatchNorm apply + residual + LeakyReLU, the backward
+// mask+reduction passes of BatchNorm in "batch statistics, frozen affine" mode, 2x2 sum pooling (gradient of nearest
+// up-sampling), and the two network heads (1x1 conv + sigmoid; 1x1 conv + log-softmax + NLL with fused backward).
+//
+// Reference ops replaced: nn.BatchNorm2d (train mode, track_running_stats=False; model_util.py:468-510),
+// nn.LeakyReLU(0.2)/nn.ReLU, residual add (encoder_decoder.py:62-64, 344-346), nn.UpsamplingNearest2d backward,
+// MyDecoder.final_conv + nn.Sigmoid (encoder_decoder.py:582,594), cross_entropy_2D (custom_loss.py:1043-1078).
+// All reductions are fixed-order two-stage (per-block partials, fp64 finalize): deterministic, no float atomics.
+#include <algorithm>
+#include "ms_common.h"
+#include "maxstyle_hip.h"
+
+namespace ms {
+
+constexpr int kElemThreads = 256;
+
+struct ElemSplit { int chunk, S; };
+static ElemSplit elem_split(int planes, int HW) {
+  // ~2048 blocks target, chunk multiple of 1024 elements (256 threads x float4)
+  int chunk = 1024;
+  while ((long)planes * cdiv(HW, chunk) > 4096 && chunk < 16384) chunk <<= 1;
+  return ElemSplit{chunk, cdiv(HW, chunk)};
+}
+
+// out = LeakyReLU_slope(sc[c]*u + sh[c] + res)   res: none | same shape | half resolution (nearest up-sampled on the fly)
+template <int RES /*0 none,1 same,2 half-res*/>
+__global__ __launch_bounds__(kElemThreads) void bn_act_kernel(const float* __restrict__ u, const float4* __restrict__ coef, const float* __restrict__ res,
+                                                              float* __restrict__ out, int C, int H, int W, int chunk, float slope) {
+  const int p = blockIdx.y, c = p % C;
+  const float4 cf = coef[c];
+  const int HW = H * W;
+  const int beg = blockIdx.x * chunk, end = min(HW, beg + chunk);
+  const float* up = u + (size_t)p * HW;
+  float* op = out + (size_t)p * HW;
+  const bool vec = (W % 4 == 0);
+  if (vec) {
+    const float* rp = (RES == 1) ? res + (size_t)p * HW : (RES == 2 ? res + (size_t)p * (HW / 4) : nullptr);
+    for (int i = beg + threadIdx.x * 4; i < end; i += kElemThreads * 4) {
+      float4 t = *reinterpret_cast<const float4*>(up + i);
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (RES == 1) r = *reinterpret_cast<const float4*>(rp + i);
+      if (RES == 2) {
+        const int y = i / W, x = i - y * W;            // x % 4 == 0
+        const float2 h = *reinterpret_cast<const float2*>(rp + (size_t)(y >> 1) * (W >> 1) + (x >> 1));
+        r = make_float4(h.x, h.x, h.y, h.y);
+      }
+      t.x = leaky(cf.x * t.x + cf.y + r.x, slope); t.y = leaky(cf.x * t.y + cf.y + r.y, slope);
+      t.z = leaky(cf.x * t.z + cf.y + r.z, slope); t.w = leaky(cf.x * t.w + cf.y + r.w, slope);
+      *reinterpret_cast<float4*>(op + i) = t;
+    }
+  } else {
+    for (int i = beg + threadIdx.x; i < end; i += kElemThreads) {
+      float r = 0.f;
+      if (RES == 1) r = res[(size_t)p * HW + i];
+      if (RES == 2) { const int y = i / W, x = i - y * W; r = res[(size_t)p * ((H / 2) * (W / 2)) + (size_t)(y >> 1) * (W >> 1) + (x >> 1)]; }
+      op[i] = leaky(cf.x * up[i] + cf.y + r, slope);
+    }
+  }
+}
+
+// g = gin * (ref > 0 ? 1 : slope); partial sums of g and g*u per (plane, chunk) -> part[c][n*S+s]
+//   MASK 0: ref = the materialised activation output (sign(out) == sign(pre-activation))
+//   MASK 1: ref = sc[c]*u + sh[c]  (activation whose output was never materialised: folded into the next conv's prologue)
+template <int MASK>
+__global__ __launch_bounds__(kElemThreads) void act_bwd_reduce_kernel(const float* __restrict__ gin, const float* __restrict__ ref, const float* __restrict__ u,
+                                                                      const float4* __restrict__ coef, float* __restrict__ gout, float2* __restrict__ part,
+                                                                      int C, int HW, int chunk, int S, int N, float slope) {
+  __shared__ float red[16];
+  const int p = blockIdx.y, c = p % C, n = p / C;
+  const float4 cf = coef[c];
+  const int beg = blockIdx.x * chunk, end = min(HW, beg + chunk);
+  const size_t base = (size_t)p * HW;
+  float s1 = 0.f, s2 = 0.f;
+  if (HW % 4 == 0) {
+    for (int i = beg + threadIdx.x * 4; i < end; i += kElemThreads * 4) {
+      const float4 g = *reinterpret_cast<const float4*>(gin + base + i);
+      const float4 uu = *reinterpret_cast<const float4*>(u + base + i);
+      float4 r;
+      if (MASK == 0) r = *reinterpret_cast<const float4*>(ref + base + i);
+      else r = make_float4(cf.x * uu.x + cf.y, cf.x * uu.y + cf.y, cf.x * uu.z + cf.y, cf.x * uu.w + cf.y);
+      float4 o;
+      o.x = g.x * (r.x > 0.f ? 1.f : slope); o.y = g.y * (r.y > 0.f ? 1.f : slope);
+      o.z = g.z * (r.z > 0.f ? 1.f : slope); o.w = g.w * (r.w > 0.f ? 1.f : slope);
+      *reinterpret_cast<float4*>(gout + base + i) = o;
+      s1 += (o.x + o.y) + (o.z + o.w);
+      s2 += (o.x * uu.x + o.y * uu.y) + (o.z * uu.z + o.w * uu.w);
+    }
+  } else {
+    for (int i = beg + threadIdx.x; i < end; i += kElemThreads) {
+      const float g = gin[base + i], uu = u[base + i];
+      const float r = (MASK == 0) ? ref[base + i] : (cf.x * uu + cf.y);
+      const float o = g * (r > 0.f ? 1.f : slope);
+      gout[base + i] = o;
+      s1 += o; s2 += o * uu;
+    }
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) part[(size_t)c * (N * S) + n * S + blockIdx.x] = make_float2(s1, s2);
+}
+
+// BatchNorm backward coefficients: du = sc*(g - mean(g) - uhat*mean(g*uhat)) = al*g + be*u + de
+__global__ __launch_bounds__(256) void bn_bwd_coefs_kernel(const float2* __restrict__ part, int nparts, const float4* __restrict__ coef, double count,
+                                                           float4* __restrict__ out) {
+  __shared__ double redd[16];
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) { const float2 q = part[(size_t)c * nparts + i]; s1 += (double)q.x; s2 += (double)q.y; }
+  s1 = block_sum_d(s1, redd);
+  s2 = block_sum_d(s2, redd);
+  if (threadIdx.x == 0) {
+    const float4 cf = coef[c];           // {sc, sh, mean, invstd}
+    const double mean = cf.z, invstd = cf.w, sc = cf.x;
+    const double c1 = s1 / count;
+    const double c2 = (s2 - mean * s1) * invstd / count;
+    const double be = -sc * c2 * invstd;
+    out[c] = make_float4((float)sc, (float)be, (float)(-sc * c1 - be * mean), 0.f);
+  }
+}
+
+// out[n,c,y,x] (+)= sum of the 2x2 block of in (gradient of nearest x2 up-sampling)
+__global__ __launch_bounds__(kElemThreads) void pool2_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int Ho, int Wo, int accumulate) {
+  const size_t total = (size_t)planes * Ho * Wo;
+  for (size_t i = (size_t)blockIdx.x * kElemThreads + threadIdx.x; i < total; i += (size_t)gridDim.x * kElemThreads) {
+    const int x = (int)(i % Wo);
+    const size_t t = i / Wo;
+    const int y = (int)(t % Ho);
+    const size_t p = t / Ho;
+    const float* ip = in + (p * 2 * Ho + 2 * y) * (size_t)(2 * Wo) + 2 * x;
+    const float2 a = *reinterpret_cast<const float2*>(ip);
+    const float2 b = *reinterpret_cast<const float2*>(ip + 2 * Wo);
+    const float v = (a.x + a.y) + (b.x + b.y);
+    out[i] = accumulate ? out[i] + v : v;
+  }
+}
+
+// ---- heads (few output channels: VALU dot products, HBM-bound on h) -------------------------------------
+constexpr int kMaxHeadC = 64, kMaxHeadK = 4;
+
+// out[n,k,i] = sigmoid(b[k] + sum_c w[k][c]*h[n,c,i])
+__global__ __launch_bounds__(kElemThreads) void head_sigmoid_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ b,
+                                                                    float* __restrict__ out, int C, int K, int HW, int apply_sigmoid) {
+  __shared__ float sw[kMaxHeadK * kMaxHeadC + kMaxHeadK];
+  for (int i = threadIdx.x; i < K * C; i += kElemThreads) sw[i] = w[i];
+  if (threadIdx.x < K) sw[kMaxHeadK * kMaxHeadC + threadIdx.x] = b ? b[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int n = blockIdx.y;
+  const float* hp = h + (size_t)n * C * HW;
+  for (int i = (blockIdx.x * kElemThreads + threadIdx.x) * 4; i < HW; i += gridDim.x * kElemThreads * 4) {
+    float4 acc[kMaxHeadK];
+#pragma unroll
+    for (int k = 0; k < kMaxHeadK; ++k) { const float bb = sw[kMaxHeadK * kMaxHeadC + k]; acc[k] = make_float4(bb, bb, bb, bb); }
+    for (int c = 0; c < C; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(hp + (size_t)c * HW + i);
+#pragma unroll
+      for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
+        const float ww = sw[k * C + c];
+        acc[k].x += ww * v.x; acc[k].y += ww * v.y; acc[k].z += ww * v.z; acc[k].w += ww * v.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
+      float4 o = acc[k];
+      if (apply_sigmoid) { o.x = 1.f / (1.f + expf(-o.x)); o.y = 1.f / (1.f + expf(-o.y)); o.z = 1.f / (1.f + expf(-o.z)); o.w = 1.f / (1.f + expf(-o.w)); }
+      *reinterpret_cast<float4*>(out + ((size_t)n * K + k) * HW + i) = o;
+    }
+  }
+}
+
+// dh[n,c,i] = sum_k w[k][c] * dout[n,k,i] * out(1-out)
+__global__ __launch_bounds__(kElemThreads) void head_sigmoid_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ w,
+                                                                        float* __restrict__ dh, int C, int K, int HW, int apply_sigmoid) {
+  __shared__ float sw[kMaxHeadK * kMaxHeadC];
+  for (int i = threadIdx.x; i < K * C; i += kElemThreads) sw[i] = w[i];
+  __syncthreads();
+  const int n = blockIdx.y;
+  for (int i = (blockIdx.x * kElemThreads + threadIdx.x) * 4; i < HW; i += gridDim.x * kElemThreads * 4) {
+    float4 d[kMaxHeadK];
+#pragma unroll
+    for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
+      const float4 g = *reinterpret_cast<const float4*>(dout + ((size_t)n * K + k) * HW + i);
+      if (apply_sigmoid) {
+        const float4 o = *reinterpret_cast<const float4*>(out + ((size_t)n * K + k) * HW + i);
+        d[k] = make_float4(g.x * (o.x * (1.f - o.x)), g.y * (o.y * (1.f - o.y)), g.z * (o.z * (1.f - o.z)), g.w * (o.w * (1.f - o.w)));
+      } else d[k] = g;
+    }
+    for (int c = 0; c < C; ++c) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < kMaxHeadK; ++k) if (k < K) { const float ww = sw[k * C + c]; a.x += ww * d[k].x; a.y += ww * d[k].y; a.z += ww * d[k].z; a.w += ww * d[k].w; }
+      *reinterpret_cast<float4*>(dh + ((size_t)n * C + c) * HW + i) = a;
+    }
+  }
+}
+
+// Segmentation head with fused loss and backward: logits = W h + b; logp = log_softmax; CE = -(1/M) sum logp[label];
+// the loop maximises CE (loss = -CE, advanced_triplet...py:555), so d loss/d logit_k = -(softmax_k - 1[k==label]) / M.
+// Writes dh = sum_k w[k][c]*dlogit_k, optional logits, and per-block partial sums of logp[label].
+__global__ __launch_bounds__(kElemThreads) void head_ce_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ b,
+                                                               const int64_t* __restrict__ labels, float* __restrict__ dh, float* __restrict__ logits_out,
+                                                               double* __restrict__ part, int C, int K, int HW, float grad_scale) {
+  __shared__ float sw[kMaxHeadK * kMaxHeadC + kMaxHeadK];
+  __shared__ double redd[16];
+  for (int i = threadIdx.x; i < K * C; i += kElemThreads) sw[i] = w[i];
+  if (threadIdx.x < K) sw[kMaxHeadK * kMaxHeadC + threadIdx.x] = b ? b[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int n = blockIdx.y;
+  const float* hp = h + (size_t)n * C * HW;
+  double picked = 0.0;
+  for (int i = blockIdx.x * kElemThreads + threadIdx.x; i < HW; i += gridDim.x * kElemThreads) {
+    float z[kMaxHeadK];
+#pragma unroll
+    for (int k = 0; k < kMaxHeadK; ++k) z[k] = sw[kMaxHeadK * kMaxHeadC + k];
+    for (int c = 0; c < C; ++c) {
+      const float v = hp[(size_t)c * HW + i];
+#pragma unroll
+      for (int k = 0; k < kMaxHeadK; ++k) if (k < K) z[k] += sw[k * C + c] * v;
+    }
+    float mx = z[0];
+#pragma unroll
+    for (int k = 1; k < kMaxHeadK; ++k) if (k < K) mx = fmaxf(mx, z[k]);
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxHeadK; ++k) if (k < K) se += expf(z[k] - mx);
+    const float lse = mx + logf(se);
+    const int lab = (int)labels[(size_t)n * HW + i];
+    float d[kMaxHeadK];
+#pragma unroll
+    for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
+      const float pk = expf(z[k] - lse);
+      if (k == lab) picked += (double)(z[k] - lse);
+      d[k] = grad_scale * (pk - (k == lab ? 1.f : 0.f));
+      if (logits_out) logits_out[((size_t)n * K + k) * HW + i] = z[k];
+    }
+    if (dh) {
+      for (int c = 0; c < C; ++c) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < kMaxHeadK; ++k) if (k < K) a += sw[k * C + c] * d[k];
+        dh[((size_t)n * C + c) * HW + i] = a;
+      }
+    }
+  }
+  picked = block_sum_d(picked, redd);
+  if (threadIdx.x == 0) part[(size_t)n * gridDim.x + blockIdx.x] = picked;
+}
+
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const double* __restrict__ part, int nparts, double scale, float* __restrict__ loss_out,
+                                                          const int* __restrict__ slot_dev) {
+  __shared__ double redd[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+  s = block_sum_d(s, redd);
+  if (threadIdx.x == 0) loss_out[slot_dev ? *slot_dev : 0] = (float)(s * scale);
+}
+
+}  // namespace ms
+
+using namespace ms;
+
+extern "C" int ms_bn_act(const float* u, const float* coef4, const float* res, int res_mode, float* out, int N, int C, int H, int W, float slope, void* stream) {
+  if (N < 1 || C < 1 || H < 1 || W < 1 || res_mode < 0 || res_mode > 2) { set_error("ms_bn_act: invalid argument"); return MS_ERR_INVALID; }
+  if (res_mode != 0 && res == nullptr) { set_error("ms_bn_act: residual missing"); return MS_ERR_INVALID; }
+  if (res_mode == 2 && ((H | W) & 1)) { set_error("ms_bn_act: half-resolution residual needs even H,W"); return MS_ERR_INVALID; }
+  if ((long)N * C > 65535) { set_error("ms_bn_act: too many planes"); return MS_ERR_INVALID; }
+  const ElemSplit sp = elem_split(N * C, H * W);
+  dim3 grid(sp.S, N * C), block(kElemThreads);
+  hipStream_t st = (hipStream_t)stream;
+  const float4* cf = (const float4*)coef4;
+  if (res_mode == 0) hipLaunchKernelGGL(bn_act_kernel<0>, grid, block, 0, st, u, cf, res, out, C, H, W, sp.chunk, slope);
+  else if (res_mode == 1) hipLaunchKernelGGL(bn_act_kernel<1>, grid, block, 0, st, u, cf, res, out, C, H, W, sp.chunk, slope);
+  else hipLaunchKernelGGL(bn_act_kernel<2>, grid, block, 0, st, u, cf, res, out, C, H, W, sp.chunk, slope);
+  return check_launch("bn_act");
+}
+
+extern "C" int ms_act_bwd_parts(int N, int C, int HW) { return N * elem_split(N * C, HW).S; }
+
+extern "C" int ms_act_bwd_reduce(const float* gin, const float* ref, const float* u, const float* coef4, float* gout, float* part2,
+                                 int N, int C, int HW, float slope, void* stream) {
+  if (N < 1 || C < 1 || HW < 1) { set_error("ms_act_bwd_reduce: invalid shape"); return MS_ERR_INVALID; }
+  if ((long)N * C > 65535) { set_error("ms_act_bwd_reduce: too many planes"); return MS_ERR_INVALID; }
+  const ElemSplit sp = elem_split(N * C, HW);
+  dim3 grid(sp.S, N * C), block(kElemThreads);
+  hipStream_t st = (hipStream_t)stream;
+  if (ref != nullptr) hipLaunchKernelGGL(act_bwd_reduce_kernel<0>, grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope);
+  else hipLaunchKernelGGL(act_bwd_reduce_kernel<1>, grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope);
+  return check_launch("act_bwd_reduce");
+}
+
+extern "C" int ms_bn_bwd_coefs(const float* part2, int nparts, const float* coef4, double count, float* coef_out4, int C, void* stream) {
+  if (C < 1 || nparts < 1 || count <= 0) { set_error("ms_bn_bwd_coefs: invalid argument"); return MS_ERR_INVALID; }
+  hipLaunchKernelGGL(bn_bwd_coefs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float2*)part2, nparts, (const float4*)coef4, count, (float4*)coef_out4);
+  return check_launch("bn_bwd_coefs");
+}
+
+extern "C" int ms_pool2_sum(const float* in, float* out, int planes, int Ho, int Wo, int accumulate, void* stream) {
+  if (planes < 1 || Ho < 1 || Wo < 1) { set_error("ms_pool2_sum: invalid shape"); return MS_ERR_INVALID; }
+  const size_t total = (size_t)planes * Ho * Wo;
+  const int blocks = (int)std::min<size_t>((total + kElemThreads - 1) / kElemThreads, 4096);
+  hipLaunchKernelGGL(pool2_sum_kernel, dim3(blocks), dim3(kElemThreads), 0, (hipStream_t)stream, in, out, planes, Ho, Wo, accumulate);
+  return check_launch("pool2_sum");
+}
+
+static int head_check(int N, int C, int K, int HW, const char* who) {
+  if (N < 1 || C < 1 || C > kMaxHeadC || K < 1 || K > kMaxHeadK || HW < 1) { set_error("%s: unsupported head shape C=%d (<=%d) K=%d (<=%d)", who, C, kMaxHeadC, K, kMaxHeadK); return MS_ERR_INVALID; }
+  if (N > 65535) { set_error("%s: batch too large", who); return MS_ERR_INVALID; }
+  return MS_OK;
+}
+
+extern "C" int ms_head_fwd(const float* h, const float* w, const float* b, float* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream) {
+  if (int e = head_check(N, C, K, HW, "ms_head_fwd")) return e;
+  if (HW % 4 != 0) { set_error("ms_head_fwd: H*W must be a multiple of 4"); return MS_ERR_INVALID; }
+  dim3 grid(std::min(cdiv(HW, kElemThreads * 4), 256), N);
+  hipLaunchKernelGGL(head_sigmoid_kernel, grid, dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, out, C, K, HW, apply_sigmoid);
+  return check_launch("head_fwd");
+}
+
+extern "C" int ms_head_bwd(const float* dout, const float* out, const float* w, float* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream) {
+  if (int e = head_check(N, C, K, HW, "ms_head_bwd")) return e;
+  if (HW % 4 != 0) { set_error("ms_head_bwd: H*W must be a multiple of 4"); return MS_ERR_INVALID; }
+  dim3 grid(std::min(cdiv(HW, kElemThreads * 4), 256), N);
+  hipLaunchKernelGGL(head_sigmoid_bwd_kernel, grid, dim3(kElemThreads), 0, (hipStream_t)stream, dout, out, w, dh, C, K, HW, apply_sigmoid);
+  return check_launch("head_bwd");
+}
+
+extern "C" size_t ms_head_ce_ws_bytes(int N, int HW) { return (size_t)N * std::min(cdiv(HW, kElemThreads), 256) * sizeof(double) + 64; }
+
+extern "C" int ms_head_ce(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* logits, float* loss_out,
+                          const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = head_check(N, C, K, HW, "ms_head_ce")) return e;
+  if (ws == nullptr || ws_bytes < ms_head_ce_ws_bytes(N, HW)) { set_error("ms_head_ce: workspace too small"); return MS_ERR_WORKSPACE; }
+  const int gx = std::min(cdiv(HW, kElemThreads), 256);
+  dim3 grid(gx, N);
+  const double M = (double)N * HW;
+  // loss = loss_sign * CE, CE = -(1/M) sum logp[label];  d loss / d logit_k = loss_sign * (p_k - 1[k==label]) / M
+  hipLaunchKernelGGL(head_ce_kernel, grid, dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, logits, (double*)ws, C, K, HW, (float)(loss_sign / M));
+  if (int e = check_launch("head_ce")) return e;
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, gx * N, -(double)loss_sign / M, loss_out, loss_slot_dev);
+  return check_launch("ce_finalize");
+}

@@ -89,3 +89,149 @@ def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8, step_dev=None):
     _need_cuda_f32(p, g, m, v)
     check(lib.ms_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, b1, b2, eps, int(step),
                            _ptr(step_dev), _stream()), "ms_adam_step")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# convolution stack
+# ---------------------------------------------------------------------------------------------------------
+FETCH_NORMAL, FETCH_UPS2, FETCH_ZINS2 = 0, 1, 2
+
+
+def _pack(w4):
+    """[Cout,Cin,k,k] -> [k*k][roundup(Cin,4)][roundup(Cout,64)] (zero padded), the layout ms_conv2d reads."""
+    Cout, Cin, k, _ = w4.shape
+    cin_pad = (Cin + 3) // 4 * 4
+    cout_pad = (Cout + 63) // 64 * 64
+    wp = torch.zeros(k * k, cin_pad, cout_pad, device=w4.device, dtype=torch.float32)
+    wp[:, :Cin, :Cout] = w4.detach().float().permute(2, 3, 1, 0).reshape(k * k, Cin, Cout)
+    return wp.contiguous()
+
+
+def pack_conv_weight(w):
+    """nn.Conv2d weight [Cout,Cin,k,k] for the forward convolution."""
+    return _pack(w)
+
+
+def pack_conv_weight_dgrad(w):
+    """Data-gradient of nn.Conv2d(k,p=k//2): a convolution of dY with the flipped, in/out-swapped kernel
+    (stride 1: as is; stride 2: on the zero-inserted dY, fetch=FETCH_ZINS2)."""
+    return _pack(w.detach().flip(2, 3).transpose(0, 1).contiguous())
+
+
+def pack_convT_weight(w):
+    """nn.ConvTranspose2d(k=2,s=2) weight [Cin,Cout,2,2] as a k=1 GEMM with 4*Cout columns: col=(dy*2+dx)*Cout+co."""
+    Cin, Cout = w.shape[:2]
+    g = w.detach().float().permute(2, 3, 1, 0).reshape(4 * Cout, Cin)     # [(dy,dx,co), ci]
+    return _pack(g.reshape(4 * Cout, Cin, 1, 1))
+
+
+def pack_convT_weight_dgrad(w):
+    """Data-gradient of ConvTranspose2d(k=2,s=2) = Conv2d(k=2,s=2,p=0) from Cout to Cin channels with kernel w[ci][co][dy][dx]."""
+    return _pack(w.detach())          # as a conv weight: [Cout'=Cin, Cin'=Cout, 2, 2]
+
+
+def conv_out_hw(Hs, Ws, ks, stride, fetch):
+    Hin, Win = (Hs, Ws) if fetch == FETCH_NORMAL else (2 * Hs, 2 * Ws)
+    pad = 1 if ks == 3 else 0
+    return (Hin + 2 * pad - ks) // stride + 1, (Win + 2 * pad - ks) // stride + 1
+
+
+def conv2d(x, wp, bias, Cout, ks, stride=1, fetch=FETCH_NORMAL, pro_mode=0, pro_a=None, pro_b=None, pro_c=None, pro_nstride=0,
+           slope=1.0, epi_mode=0, out=None, stats=None, in2=None):
+    """ms_conv2d wrapper. Returns out ([N,Cout,Hout,Wout], or [N,Cout,2H,2W] for the ConvTranspose epilogue)."""
+    _need_cuda_f32(x, wp, bias, pro_a, pro_b, pro_c, out, stats, in2)
+    N, Cin, Hs, Ws = x.shape
+    Ho, Wo = conv_out_hw(Hs, Ws, ks, stride, fetch)
+    if out is None:
+        shape = (N, Cout, 2 * Ho, 2 * Wo) if epi_mode == 2 else (N, Cout, Ho, Wo)
+        if epi_mode == 1:
+            raise ValueError("accumulate epilogue needs an existing `out`")
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    check(lib.ms_conv2d(x.data_ptr(), _ptr(in2), out.data_ptr(), wp.data_ptr(), _ptr(bias), N, Cin, Hs, Ws, Cout, ks, stride, fetch,
+                        pro_mode, _ptr(pro_a), _ptr(pro_b), _ptr(pro_c), pro_nstride, slope, epi_mode, _ptr(stats), _stream()), "ms_conv2d")
+    return out
+
+
+def conv_stats_buffer(N, Cout, Ho, Wo, device):
+    parts = lib.ms_conv_stats_parts(N, Ho, Wo)
+    return torch.empty(Cout, parts, 4, device=device, dtype=torch.float32), parts
+
+
+def bn_finalize(stats, nparts, gamma, beta, eps=1e-5, out=None):
+    C = gamma.numel()
+    coef = torch.empty(C, 4, device=gamma.device, dtype=torch.float32) if out is None else out
+    check(lib.ms_bn_finalize(stats.data_ptr(), nparts, gamma.data_ptr(), beta.data_ptr(), eps, coef.data_ptr(), C, _stream()), "ms_bn_finalize")
+    return coef
+
+
+def bn_act(u, coef4, res=None, res_mode=0, slope=0.2, out=None):
+    _need_cuda_f32(u, coef4, res, out)
+    N, C, H, W = u.shape
+    out = torch.empty_like(u) if out is None else out
+    check(lib.ms_bn_act(u.data_ptr(), coef4.data_ptr(), _ptr(res), res_mode, out.data_ptr(), N, C, H, W, slope, _stream()), "ms_bn_act")
+    return out
+
+
+def act_bwd_reduce(gin, ref, u, coef4, slope, gout=None, part=None):
+    _need_cuda_f32(gin, ref, u, coef4, gout, part)
+    N, C, H, W = u.shape
+    nparts = lib.ms_act_bwd_parts(N, C, H * W)
+    gout = torch.empty_like(gin) if gout is None else gout
+    part = torch.empty(C, nparts, 2, device=u.device, dtype=torch.float32) if part is None else part
+    check(lib.ms_act_bwd_reduce(gin.data_ptr(), _ptr(ref), u.data_ptr(), coef4.data_ptr(), gout.data_ptr(), part.data_ptr(), N, C, H * W, slope, _stream()),
+          "ms_act_bwd_reduce")
+    return gout, part, nparts
+
+
+def bn_bwd_coefs(part, nparts, coef4, count, out=None):
+    C = coef4.shape[0]
+    out = torch.empty(C, 4, device=coef4.device, dtype=torch.float32) if out is None else out
+    check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef4.data_ptr(), float(count), out.data_ptr(), C, _stream()), "ms_bn_bwd_coefs")
+    return out
+
+
+def pool2_sum(x, out=None, accumulate=False):
+    _need_cuda_f32(x, out)
+    N, C, H, W = x.shape
+    if out is None:
+        out = torch.empty(N, C, H // 2, W // 2, device=x.device, dtype=torch.float32)
+    check(lib.ms_pool2_sum(x.data_ptr(), out.data_ptr(), N * C, H // 2, W // 2, 1 if accumulate else 0, _stream()), "ms_pool2_sum")
+    return out
+
+
+def head_fwd(h, w, b, apply_sigmoid, out=None):
+    _need_cuda_f32(h, w, b, out)
+    N, C, H, W = h.shape
+    K = w.shape[0]
+    out = torch.empty(N, K, H, W, device=h.device, dtype=torch.float32) if out is None else out
+    check(lib.ms_head_fwd(h.data_ptr(), w.data_ptr(), _ptr(b), out.data_ptr(), N, C, K, H * W, 1 if apply_sigmoid else 0, _stream()), "ms_head_fwd")
+    return out
+
+
+def head_bwd(dout, out, w, C, apply_sigmoid, dh=None):
+    _need_cuda_f32(dout, out, w, dh)
+    N, K, H, W = dout.shape
+    dh = torch.empty(N, C, H, W, device=dout.device, dtype=torch.float32) if dh is None else dh
+    check(lib.ms_head_bwd(dout.data_ptr(), _ptr(out), w.data_ptr(), dh.data_ptr(), N, C, K, H * W, 1 if apply_sigmoid else 0, _stream()), "ms_head_bwd")
+    return dh
+
+
+def head_ce(h, w, b, labels, loss_sign=1.0, need_dh=True, need_logits=False, dh=None, logits=None, loss_out=None, loss_slot_dev=None):
+    """loss = loss_sign * cross_entropy_2D(w h + b, labels); returns (loss[1] device tensor, dh, logits)."""
+    _need_cuda_f32(h, w, b, dh, logits, loss_out)
+    if labels.dtype != torch.int64 or not labels.is_cuda or not labels.is_contiguous():
+        raise TypeError("labels must be a contiguous CUDA int64 tensor [N,H,W]")
+    N, C, H, W = h.shape
+    K = w.shape[0]
+    dev = h.device
+    if need_dh and dh is None:
+        dh = torch.empty_like(h)
+    if need_logits and logits is None:
+        logits = torch.empty(N, K, H, W, device=dev, dtype=torch.float32)
+    if loss_out is None:
+        loss_out = torch.empty(1, device=dev, dtype=torch.float32)
+    nbytes = lib.ms_head_ce_ws_bytes(N, H * W)
+    ws = workspace(nbytes, dev)
+    check(lib.ms_head_ce(h.data_ptr(), w.data_ptr(), _ptr(b), labels.data_ptr(), _ptr(dh if need_dh else None), _ptr(logits if need_logits else None),
+                         loss_out.data_ptr(), _ptr(loss_slot_dev), N, C, K, H * W, loss_sign, ws.data_ptr(), ws.numel(), _stream()), "ms_head_ce")
+    return loss_out, dh, logits
