@@ -74,9 +74,10 @@ int ms_counter_incr(int* counter, void* stream);
  *             w_packed[ky*ks+kx][ci][co] = weight[co][ci][ky][kx]           (gemm_cols = Cout, or 4*Cout for epi_mode 2)
  *   ks/stride (3,1) (3,2) (1,1) (2,2); padding = 1 for ks 3 else 0
  *   fetch     0 normal | 1 nearest x2 up-sampling fused into the load | 2 zero-insertion x2 (stride-2 data-gradient)
- *   pro_mode  0 none | 1 v = LeakyReLU_slope(pro_a[i]*v + pro_b[i]), i = n*pro_nstride + ci  (BatchNorm apply + activation
- *             of the producer; pro_nstride = 0 per channel, = Cin per (n,c) plane)
- *             | 2 v = pro_a[ci]*v + pro_b[ci]*in2 + pro_c[ci]   (BatchNorm backward apply)
+ *   pro_mode  0 none | 1 v = LeakyReLU_slope(pro_a[i]*v + pro_b[i]), i = (n*pro_nstride + ci)*pro_cstride  (BatchNorm apply +
+ *             activation of the producer; pro_nstride = 0 per channel, = Cin per (n,c) plane; pro_cstride = 4 reads the
+ *             interleaved coef4 records of ms_bn_finalize / ms_bn_bwd_coefs in place)
+ *             | 2 v = pro_a[i]*v + pro_b[i]*in2 + pro_c[i], i = ci*pro_cstride   (BatchNorm backward apply)
  *   epi_mode  0 out = acc + bias | 1 out += acc + bias | 2 ConvTranspose2d(k=2,s=2) pixel-shuffle store:
  *             GEMM column (dy*2+dx)*Cout+co -> out[n,co,2y+dy,2x+dx] (needs ks=1)
  *   stats     NULL or float4[Cout][ms_conv_stats_parts()] receiving per-workgroup (count, mean, M2, 0) of the outputs
@@ -85,7 +86,7 @@ size_t ms_conv_stats_bytes(int N, int Cout, int Hout, int Wout);
 int ms_conv_stats_parts(int N, int Hout, int Wout);
 int ms_conv2d(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
               int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
-              int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, float slope,
+              int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
               int epi_mode, float* stats, void* stream);
 
 /* Chan-merge of the per-workgroup statistics in fp64 -> coef4[c] = {scale=gamma*invstd, shift=beta-mean*scale, mean, invstd}

@@ -33,7 +33,7 @@ SIGNATURES = {
     "ms_conv_stats_bytes": (c_size, [c_int, c_int, c_int, c_int]),
     "ms_conv_stats_parts": (c_int, [c_int, c_int, c_int]),
     "ms_conv2d": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                          c_int, c_f32p, c_f32p, c_f32p, c_int, c_float, c_int, c_f32p, c_void]),
+                          c_int, c_f32p, c_f32p, c_f32p, c_int, c_int, c_float, c_int, c_f32p, c_void]),
     "ms_bn_finalize": (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void]),
     "ms_bn_act": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_int, c_int, c_int, c_float, c_void]),
     "ms_act_bwd_parts": (c_int, [c_int, c_int, c_int]),

@@ -35,7 +35,7 @@ struct ConvArgs {
   const float* pro_a; const float* pro_b; const float* pro_c;
   float* stats;                 // PlanePartial-like float4 [cout][nparts] or null
   int N, Cin, Hs, Ws, Hin, Win, Cout, Hout, Wout, cin_pad, cout_pad;
-  int pro_mode, pro_nstride; float slope;
+  int pro_mode, pro_nstride, pro_cstride; float slope;
   int epi_mode, tiles_x, tiles_y, cout_real;   // cout_real: ConvTranspose real channel count (epi shuffle)
 };
 
@@ -107,10 +107,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const size_t off = (size_t)ci * in_plane + (size_t)ys * a.Ws + xs;
         v = in_n[off];
         if (a.pro_mode == 1) {
-          const int pi = n * a.pro_nstride + ci;
+          const int pi = (n * a.pro_nstride + ci) * a.pro_cstride;
           v = leaky(a.pro_a[pi] * v + a.pro_b[pi], a.slope);
         } else if (a.pro_mode == 2) {
-          v = a.pro_a[ci] * v + a.pro_b[ci] * in2_n[off] + a.pro_c[ci];
+          const int pi = ci * a.pro_cstride;
+          v = a.pro_a[pi] * v + a.pro_b[pi] * in2_n[off] + a.pro_c[pi];
         }
       }
       const int q = (STRIDE == 1) ? xx : ((xx & 1) * HALFW + (xx >> 1));
@@ -350,7 +351,7 @@ extern "C" int ms_conv_stats_parts(int N, int Hout, int Wout) { return N * cdiv(
 
 extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                          int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
-                         int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, float slope,
+                         int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                          int epi_mode, float* stats, void* stream) {
   if (N < 1 || Cin < 1 || Cout < 1 || Hs < 1 || Ws < 1) { set_error("ms_conv2d: invalid shape"); return MS_ERR_INVALID; }
   if (pro_mode < 0 || pro_mode > 2 || epi_mode < 0 || epi_mode > 2 || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
@@ -369,7 +370,7 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
   const int gemm_cols = (epi_mode == 2) ? 4 * Cout : Cout;
   a.Cout = (epi_mode == 2) ? gemm_cols : Cout;
   a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (gemm_cols + 63) / 64 * 64;
-  a.pro_mode = pro_mode; a.pro_nstride = pro_nstride; a.slope = slope; a.epi_mode = epi_mode;
+  a.pro_mode = pro_mode; a.pro_nstride = pro_nstride; a.pro_cstride = pro_cstride < 1 ? 1 : pro_cstride; a.slope = slope; a.epi_mode = epi_mode;
   a.tiles_x = cdiv(a.Wout, TW); a.tiles_y = cdiv(a.Hout, TH);
   if (a.Hout < 1 || a.Wout < 1) { set_error("ms_conv2d: empty output"); return MS_ERR_INVALID; }
   if ((long)N > 65535 ) { set_error("ms_conv2d: batch too large for gridDim.z"); return MS_ERR_INVALID; }

@@ -1,0 +1,565 @@
+"""Fused inner adversarial style-optimisation loop on one MI355X.
+
+Replaces the body of `AdvancedTripletReconSegmentationModel.generate_max_style_image`
+(/root/reference/src/models/advanced_triplet_recon_segmentation_model.py:539-566): per inner step
+    encode(recon) -> segmentation decoder -> loss = -CE -> backward to {lmda, gamma_noise, beta_noise} -> Adam -> re-decode
+with hand-written HIP kernels only (no autograd, no ATen compute).  What makes it different from an op-for-op port:
+  * no weight gradients are ever formed (all network parameters are frozen inside the loop, :508-511) - the backward is
+    data-gradient only, written out by hand per block;
+  * BatchNorm (batch statistics, frozen affine; model_util.py:468-510) is split into a statistics epilogue of the producing
+    conv and an apply(+LeakyReLU) prologue of the consuming conv; its backward into one mask+reduce pass and a prologue of
+    the data-gradient conv, so "conv -> BN -> LeakyReLU" costs one write and one read of the activation;
+  * nn.UpsamplingNearest2d is never materialised (fused into the 3x3 conv's load; the 1x1 skip conv runs at low resolution);
+  * the style-independent decoder prefix (blocks before the first MaxStyle insertion) is computed once per call, not K+1 times;
+  * every buffer is allocated once per (shape, device); a step is a fixed sequence of kernel launches on one stream, so it is
+    captured into a HIP graph and replayed (no per-step host work, no allocator traffic, no empty_cache()).
+Host code is orchestration only; it raises if the HIP extension is missing (import of ._lib) - there is no CPU path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from ._lib import lib, check
+
+LEAKY = 0.2
+BN_EPS = 1e-5
+F32 = torch.float32
+
+
+@dataclass
+class NetSpec:
+    """FCN_16 (reduce=4) / FCN_64 (reduce=1): advanced_triplet...py:152-203."""
+    reduce: int = 4
+    image_ch: int = 1
+    num_classes: int = 4
+
+    @property
+    def widths(self):
+        r = self.reduce
+        return [64 // r, 128 // r, 256 // r, 512 // r]
+
+    @property
+    def code_ch(self):
+        return 512 // self.reduce
+
+    @property
+    def dec_chans(self):
+        r = self.reduce
+        return [(512 // r, 256 // r), (256 // r, 128 // r), (128 // r, 64 // r), (64 // r, 64 // r)]
+
+    @property
+    def channel_num(self):
+        r = self.reduce
+        return [512 // r, 256 // r, 128 // r, 64 // r, 64 // r, self.image_ch]
+
+
+class ConvW:
+    """Packed weights of one convolution: forward layout, data-gradient layout, bias."""
+
+    def __init__(self, w, b, kind="conv"):
+        self.kind = kind
+        if kind == "conv":
+            self.cout, self.cin, self.ks = w.shape[0], w.shape[1], w.shape[2]
+            self.wp = ops.pack_conv_weight(w)
+            self.dwp = ops.pack_conv_weight_dgrad(w)
+        else:  # ConvTranspose2d k2 s2: weight [Cin, Cout, 2, 2]
+            self.cin, self.cout, self.ks = w.shape[0], w.shape[1], 2
+            self.wp = ops.pack_convT_weight(w)
+            self.dwp = ops.pack_convT_weight_dgrad(w)
+        self.b = None if b is None else b.detach().float().contiguous()
+
+
+class BNW:
+    def __init__(self, sd, name):
+        self.gamma = sd[name + ".weight"].detach().float().contiguous()
+        self.beta = sd[name + ".bias"].detach().float().contiguous()
+
+
+class PackedNets:
+    """Device-resident, kernel-layout copies of the three sub-nets' frozen parameters (state_dict key layout of the
+    reference: SURVEY.md A.6, so reference checkpoints load unchanged)."""
+
+    def __init__(self, spec: NetSpec, enc_sd, seg_sd, dec_sd):
+        self.spec = spec
+        g = "general_encoder."
+        cv = lambda sd, n, kind="conv": ConvW(sd[n + ".weight"], sd.get(n + ".bias"), kind)
+        e = {}
+        e["inc0"] = cv(enc_sd, g + "inc.0"); e["inc1"] = BNW(enc_sd, g + "inc.1")
+        e["inc3"] = cv(enc_sd, g + "inc.3"); e["inc4"] = BNW(enc_sd, g + "inc.4")
+        for i in range(1, 5):
+            p = g + f"down{i}."
+            e[f"d{i}.down"] = cv(enc_sd, p + "down")
+            e[f"d{i}.c0"] = cv(enc_sd, p + "conv.0"); e[f"d{i}.bn1"] = BNW(enc_sd, p + "conv.1")
+            e[f"d{i}.c3"] = cv(enc_sd, p + "conv.3"); e[f"d{i}.bn4"] = BNW(enc_sd, p + "conv.4")
+            e[f"d{i}.ci"] = cv(enc_sd, p + "conv_input")
+        e["fc0"] = cv(enc_sd, g + "final_conv.0"); e["fc1"] = BNW(enc_sd, g + "final_conv.1")
+        e["cd0"] = cv(enc_sd, "code_decoupler.0"); e["cd1"] = BNW(enc_sd, "code_decoupler.1")
+        e["cd3"] = cv(enc_sd, "code_decoupler.3"); e["cd4"] = BNW(enc_sd, "code_decoupler.4")
+        self.enc = e
+
+        def dec(sd, conv_t):
+            d = {}
+            for i in range(1, 5):
+                p = f"up{i}."
+                if conv_t:
+                    d[f"u{i}.up"] = cv(sd, p + "up", "convT")
+                d[f"u{i}.c0"] = cv(sd, p + "conv.0"); d[f"u{i}.bn1"] = BNW(sd, p + "conv.1")
+                d[f"u{i}.c3"] = cv(sd, p + "conv.3"); d[f"u{i}.bn4"] = BNW(sd, p + "conv.4")
+                d[f"u{i}.ci"] = cv(sd, p + "conv_input")
+            w = sd["final_conv.weight"].detach().float()
+            d["head.w"] = w.reshape(w.shape[0], w.shape[1]).contiguous()
+            d["head.b"] = sd["final_conv.bias"].detach().float().contiguous()
+            return d
+        self.seg = dec(seg_sd, False)
+        self.dec = dec(dec_sd, True)
+
+
+class StyleSlot:
+    """Device state of one applied MaxStyle layer inside the engine (views into the flat parameter buffers)."""
+
+    def __init__(self, index, B, C):
+        self.index, self.B, self.C = index, B, C
+        self.mix_style = True
+        self.use_noise = True
+        self.learn_noise = True
+        self.learn_mix = True
+        self.eps = 1e-6
+        self.off = {}          # name -> (offset, n) into the flat buffers
+        self.have_std = False
+
+
+class InnerLoopEngine:
+    def __init__(self, spec: NetSpec, B: int, H: int, W: int, device, lr=0.1):
+        if H % 16 or W % 16:
+            raise ValueError("image height/width must be multiples of 16 (four stride-2 stages)")
+        self.spec, self.B, self.H, self.W, self.dev, self.lr = spec, B, H, W, torch.device(device), lr
+        self.buf: Dict[str, torch.Tensor] = {}
+        self.nets: Optional[PackedNets] = None
+        self.styles: Dict[int, StyleSlot] = {}
+        self.layers: List[int] = []
+        self.flat_p = self.flat_g = self.flat_m = self.flat_v = None
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.loss_buf = torch.zeros(64, dtype=F32, device=self.dev)
+        self._graph = None
+        self._prefix_valid = False
+        self.labels = None
+        self.code = None
+
+    # ------------------------------------------------------------------ buffers
+    def t(self, name, *shape, dtype=F32):
+        b = self.buf.get(name)
+        if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
+            if self._graph is not None:
+                raise RuntimeError(f"buffer {name} would be (re)allocated while a captured graph is live")
+            b = torch.empty(*shape, dtype=dtype, device=self.dev)
+            self.buf[name] = b
+        return b
+
+    def _st(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    # ------------------------------------------------------------------ kernel-call helpers (no allocation after warm-up)
+    def conv(self, name, x, cw: ConvW, cout=None, ks=None, stride=1, fetch=0, act=None, bnbwd=None, epi=0, out=None, stats=False, dgrad=False):
+        """act=(coef4, slope): BN-apply+LeakyReLU prologue; bnbwd=(bcoef4, u): BN-backward prologue. Returns (out, stats, parts)."""
+        N, Cin, Hs, Ws = x.shape
+        wp = cw.dwp if dgrad else cw.wp
+        ks = cw.ks if ks is None else ks
+        if cout is None:
+            cout = cw.cin if dgrad else cw.cout
+        Ho, Wo = ops.conv_out_hw(Hs, Ws, ks, stride, fetch)
+        if out is None:
+            out = self.t(name, N, cout, 2 * Ho, 2 * Wo) if epi == 2 else self.t(name, N, cout, Ho, Wo)
+        st = None
+        parts = 0
+        if stats:
+            parts = lib.ms_conv_stats_parts(N, Ho, Wo)
+            st = self.t(name + ".stats", cout, parts, 4)
+        pm, pa, pb, pc, in2 = 0, 0, 0, 0, None
+        slope = 1.0
+        if act is not None:
+            pm = 1
+            pa, pb, _ = ops.coef_ptrs(act[0])
+            slope = act[1]
+        elif bnbwd is not None:
+            pm = 2
+            pa, pb, pc = ops.coef_ptrs(bnbwd[0])
+            in2 = bnbwd[1]
+        bias = None if dgrad else cw.b
+        check(lib.ms_conv2d(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                            N, Cin, Hs, Ws, cout, ks, stride, fetch, pm, pa, pb, pc, 0, 4, slope, epi, 0 if st is None else st.data_ptr(), self._st()),
+              "ms_conv2d:" + name)
+        return out, st, parts
+
+    def bn_fin(self, name, st, parts, bn: BNW):
+        coef = self.t(name + ".coef", bn.gamma.numel(), 4)
+        check(lib.ms_bn_finalize(st.data_ptr(), parts, bn.gamma.data_ptr(), bn.beta.data_ptr(), BN_EPS, coef.data_ptr(), bn.gamma.numel(), self._st()), "ms_bn_finalize:" + name)
+        return coef
+
+    def bn_act(self, name, u, coef, res=None, res_mode=0, slope=LEAKY):
+        N, C, H, W = u.shape
+        out = self.t(name, N, C, H, W)
+        check(lib.ms_bn_act(u.data_ptr(), coef.data_ptr(), 0 if res is None else res.data_ptr(), res_mode, out.data_ptr(), N, C, H, W, slope, self._st()), "ms_bn_act:" + name)
+        return out
+
+    def act_bwd(self, name, gin, ref, u, coef, slope):
+        """In-place mask of gin + BN-backward reductions -> (g, bcoef4)."""
+        N, C, H, W = u.shape
+        nparts = lib.ms_act_bwd_parts(N, C, H * W)
+        part = self.t(name + ".part", C, nparts, 2)
+        check(lib.ms_act_bwd_reduce(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
+                                    N, C, H * W, slope, self._st()), "ms_act_bwd_reduce:" + name)
+        bc = self.t(name + ".bcoef", C, 4)
+        check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(N * H * W), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + name)
+        return gin, bc
+
+    def pool2(self, name, x, out=None, accumulate=False):
+        N, C, H, W = x.shape
+        if out is None:
+            out = self.t(name, N, C, H // 2, W // 2)
+        check(lib.ms_pool2_sum(x.data_ptr(), out.data_ptr(), N * C, H // 2, W // 2, 1 if accumulate else 0, self._st()), "ms_pool2_sum:" + name)
+        return out
+
+    # ------------------------------------------------------------------ residual blocks
+    def res_fwd(self, pfx, net, key, x, kind):
+        """encoder_decoder.py:22-74 (kind 'down') / :289-357 (kind 'convT' = up_type Conv2, 'nn' = up_type NN)."""
+        c0, c3, ci = net[key + ".c0"], net[key + ".c3"], net[key + ".ci"]
+        fetch = ops.FETCH_NORMAL
+        src = x
+        if kind == "convT":
+            src, _, _ = self.conv(pfx + ".xu", x, net[key + ".up"], cout=net[key + ".up"].cout, ks=1, epi=2)
+        elif kind == "down":
+            src, _, _ = self.conv(pfx + ".xd", x, net[key + ".down"], stride=2)
+        else:
+            fetch = ops.FETCH_UPS2
+        u1, st1, p1 = self.conv(pfx + ".u1", src, c0, fetch=fetch, stats=True)
+        cf1 = self.bn_fin(pfx + ".bn1", st1, p1, net[key + ".bn1"])
+        u2, st2, p2 = self.conv(pfx + ".u2", u1, c3, act=(cf1, LEAKY), stats=True)
+        cf2 = self.bn_fin(pfx + ".bn4", st2, p2, net[key + ".bn4"])
+        if kind == "nn":
+            s, _, _ = self.conv(pfx + ".s", x, ci)              # conv1x1 commutes with nearest up-sampling: low resolution
+            out = self.bn_act(pfx + ".out", u2, cf2, s, 2, LEAKY)
+        else:
+            s, _, _ = self.conv(pfx + ".s", src, ci)
+            out = self.bn_act(pfx + ".out", u2, cf2, s, 1, LEAKY)
+        return out
+
+    def res_bwd(self, pfx, net, key, dout, kind, need_dx=True):
+        """dout: gradient w.r.t. the block output (overwritten). Returns the gradient w.r.t. the block input."""
+        b = self.buf
+        c0, c3, ci = net[key + ".c0"], net[key + ".c3"], net[key + ".ci"]
+        g2, bc2 = self.act_bwd(pfx + ".bw2", dout, b[pfx + ".out"], b[pfx + ".u2"], b[pfx + ".bn4.coef"], LEAKY)
+        da1, _, _ = self.conv(pfx + ".da1", g2, c3, bnbwd=(bc2, b[pfx + ".u2"]), dgrad=True)
+        g1, bc1 = self.act_bwd(pfx + ".bw1", da1, None, b[pfx + ".u1"], b[pfx + ".bn1.coef"], LEAKY)
+        dsrc, _, _ = self.conv(pfx + ".dsrc", g1, c0, bnbwd=(bc1, b[pfx + ".u1"]), dgrad=True)     # at the (up-sampled / strided) resolution
+        if kind == "nn":
+            dx = self.pool2(pfx + ".dx", dsrc)
+            gs = self.pool2(pfx + ".gs", g2)
+            self.conv(pfx + ".dx", gs, ci, dgrad=True, epi=1, out=dx)
+            return dx
+        self.conv(pfx + ".dsrc", g2, ci, dgrad=True, epi=1, out=dsrc)
+        if not need_dx:
+            return dsrc
+        if kind == "convT":
+            dx, _, _ = self.conv(pfx + ".dx", dsrc, net[key + ".up"], ks=2, stride=2, dgrad=True)
+        else:
+            dx, _, _ = self.conv(pfx + ".dx", dsrc, net[key + ".down"], ks=3, stride=1, fetch=ops.FETCH_ZINS2, dgrad=True)
+        return dx
+
+    # ------------------------------------------------------------------ encoder + segmentation decoder + loss
+    def encode_fwd(self, image):
+        """MyEncoder.forward + code_decoupler (encoder_decoder.py:469-482, 673-680) in BN batch-stat mode."""
+        e = self.nets.enc
+        ua, st, p = self.conv("e.inc.ua", image, e["inc0"], stats=True)
+        cfa = self.bn_fin("e.inc.bn1", st, p, e["inc1"])
+        ub, st, p = self.conv("e.inc.ub", ua, e["inc3"], act=(cfa, LEAKY), stats=True)
+        cfb = self.bn_fin("e.inc.bn4", st, p, e["inc4"])
+        h = self.bn_act("e.inc.out", ub, cfb, None, 0, LEAKY)
+        for i in range(1, 5):
+            h = self.res_fwd(f"e.d{i}", e, f"d{i}", h, "down")
+        uf, st, p = self.conv("e.fc.u", h, e["fc0"], stats=True)
+        cff = self.bn_fin("e.fc.bn", st, p, e["fc1"])
+        z_i = self.bn_act("e.z_i", uf, cff, None, 0, 0.0)
+        u1, st, p = self.conv("e.cd.u1", z_i, e["cd0"], stats=True)
+        cf1 = self.bn_fin("e.cd.bn1", st, p, e["cd1"])
+        u2, st, p = self.conv("e.cd.u2", u1, e["cd3"], act=(cf1, LEAKY), stats=True)
+        cf2 = self.bn_fin("e.cd.bn4", st, p, e["cd4"])
+        z_s = self.bn_act("e.z_s", u2, cf2, None, 0, 0.0)
+        return z_i, z_s
+
+    def encode_bwd(self, dz_s):
+        e, b = self.nets.enc, self.buf
+        g, bc = self.act_bwd("e.cd.bw2", dz_s, b["e.z_s"], b["e.cd.u2"], b["e.cd.bn4.coef"], 0.0)
+        da, _, _ = self.conv("e.cd.da", g, e["cd3"], bnbwd=(bc, b["e.cd.u2"]), dgrad=True)
+        g, bc = self.act_bwd("e.cd.bw1", da, None, b["e.cd.u1"], b["e.cd.bn1.coef"], LEAKY)
+        dz_i, _, _ = self.conv("e.dz_i", g, e["cd0"], bnbwd=(bc, b["e.cd.u1"]), dgrad=True)
+        g, bc = self.act_bwd("e.fc.bw", dz_i, b["e.z_i"], b["e.fc.u"], b["e.fc.bn.coef"], 0.0)
+        dh, _, _ = self.conv("e.fc.dh", g, e["fc0"], bnbwd=(bc, b["e.fc.u"]), dgrad=True)
+        for i in range(4, 0, -1):
+            dh = self.res_bwd(f"e.d{i}", e, f"d{i}", dh, "down")
+        g, bc = self.act_bwd("e.inc.bw2", dh, b["e.inc.out"], b["e.inc.ub"], b["e.inc.bn4.coef"], LEAKY)
+        da, _, _ = self.conv("e.inc.da", g, e["inc3"], bnbwd=(bc, b["e.inc.ub"]), dgrad=True)
+        g, bc = self.act_bwd("e.inc.bw1", da, None, b["e.inc.ua"], b["e.inc.bn1.coef"], LEAKY)
+        dimg, _, _ = self.conv("e.dimage", g, e["inc0"], bnbwd=(bc, b["e.inc.ua"]), dgrad=True)
+        return dimg
+
+    def seg_fwd(self, z_s):
+        h = z_s
+        for i in range(1, 5):
+            h = self.res_fwd(f"s.u{i}", self.nets.seg, f"u{i}", h, "nn")
+        return h
+
+    def seg_loss(self, image, labels, need_grad=True, need_logits=False, loss_slot=None):
+        """encode -> segment -> loss = -cross_entropy_2D (advanced_triplet...py:547-558) [+ backward to the image]."""
+        z_i, z_s = self.encode_fwd(image)
+        h = self.seg_fwd(z_s)
+        N, C, H, W = h.shape
+        w, bias = self.nets.seg["head.w"], self.nets.seg["head.b"]
+        K = w.shape[0]
+        dh = self.t("s.dh", N, C, H, W) if need_grad else None
+        logits = self.t("s.logits", N, K, H, W) if need_logits else None
+        nbytes = lib.ms_head_ce_ws_bytes(N, H * W)
+        ws = self.t("s.ce_ws", max(nbytes, 64), dtype=torch.uint8)
+        check(lib.ms_head_ce(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), 0 if dh is None else dh.data_ptr(),
+                             0 if logits is None else logits.data_ptr(), self.loss_buf.data_ptr(), 0 if loss_slot is None else loss_slot.data_ptr(),
+                             N, C, K, H * W, -1.0, ws.data_ptr(), ws.numel(), self._st()), "ms_head_ce")
+        if not need_grad:
+            return None
+        d = dh
+        for i in range(4, 0, -1):
+            d = self.res_bwd(f"s.u{i}", self.nets.seg, f"u{i}", d, "nn")
+        return self.encode_bwd(d)
+
+    # ------------------------------------------------------------------ MaxStyle layers inside the decoder
+    def configure_styles(self, layers: Sequence[int], slots: Dict[int, StyleSlot]):
+        """layers: indexes where MaxStyle is inserted AND applied (rand_p < p), ascending order of use; slots: their state."""
+        self.layers = [i for i in layers if i in slots]
+        self.styles = slots
+        total = 0
+        for i in self.layers:
+            s = slots[i]
+            for nm, n in (("gamma_noise", s.B * s.C), ("beta_noise", s.B * s.C), ("lmda", s.B)):
+                s.off[nm] = (total, n)
+                total += n
+            s.have_std = False
+        self.nparam = total
+        self.flat_p = torch.zeros(max(total, 1), dtype=F32, device=self.dev)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.step_dev.zero_()
+        self._graph = None
+        self._prefix_valid = False
+        # learnable segments (merged where adjacent) for the Adam kernel
+        segs = []
+        for i in self.layers:
+            s = slots[i]
+            for nm in ("gamma_noise", "beta_noise", "lmda"):
+                learn = (s.learn_noise and s.use_noise) if nm != "lmda" else (s.learn_mix and s.mix_style)
+                if learn:
+                    o, n = s.off[nm]
+                    if segs and segs[-1][0] + segs[-1][1] == o:
+                        segs[-1] = (segs[-1][0], segs[-1][1] + n)
+                    else:
+                        segs.append((o, n))
+        self.learn_segments = segs
+
+    def param(self, i, name):
+        o, n = self.styles[i].off[name]
+        s = self.styles[i]
+        return self.flat_p[o:o + n].view(s.B, s.C if name != "lmda" else 1, 1, 1)
+
+    def grad(self, i, name):
+        o, n = self.styles[i].off[name]
+        s = self.styles[i]
+        return self.flat_g[o:o + n].view(s.B, s.C if name != "lmda" else 1, 1, 1)
+
+    def set_style_state(self, i, perm, lmda, gamma_noise, beta_noise):
+        s = self.styles[i]
+        s.perm = torch.as_tensor(perm).to(device=self.dev, dtype=torch.int64).contiguous()
+        self.param(i, "lmda").copy_(torch.as_tensor(lmda).to(self.dev, F32).view(s.B, 1, 1, 1))
+        self.param(i, "gamma_noise").copy_(torch.as_tensor(gamma_noise).to(self.dev, F32).view(s.B, s.C, 1, 1))
+        self.param(i, "beta_noise").copy_(torch.as_tensor(beta_noise).to(self.dev, F32).view(s.B, s.C, 1, 1))
+
+    def style_fwd(self, i, x):
+        s = self.styles[i]
+        B, C = x.shape[:2]
+        HW = x.shape[2] * x.shape[3]
+        if HW == 1 or B <= 1 or (not s.mix_style and not s.use_noise):
+            return x                                     # identity short-cuts of maxstyle.py:146-152
+        y = self.t(f"st{i}.y", *x.shape)
+        stats = self.t(f"st{i}.stats", 4, B, C)          # mu, sig, A, S
+        std = self.t(f"st{i}.std", 2, C)                 # gamma_std, beta_std (frozen after the first forward)
+        ws = self._style_ws(lib.ms_style_ws_bytes(B, C, HW))
+        po = lambda nm: self.flat_p.data_ptr() + 4 * s.off[nm][0]
+        check(lib.ms_style_fwd(x.data_ptr(), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), std[0].data_ptr(), std[1].data_ptr(),
+                               0 if s.have_std else 1, po("lmda") if s.mix_style else 0, po("gamma_noise") if s.use_noise else 0,
+                               po("beta_noise") if s.use_noise else 0, s.perm.data_ptr() if s.mix_style else 0,
+                               stats[2].data_ptr(), stats[3].data_ptr(), B, C, HW, s.eps, ws.data_ptr(), ws.numel(), self._st()), f"ms_style_fwd:{i}")
+        s.have_std = True
+        self.buf[f"st{i}.x"] = x
+        return y
+
+    def style_bwd(self, i, dy, need_dx):
+        s = self.styles[i]
+        x = self.buf.get(f"st{i}.x")
+        B, C = x.shape[:2]
+        HW = x.shape[2] * x.shape[3]
+        stats, std = self.buf[f"st{i}.stats"], self.buf[f"st{i}.std"]
+        dx = self.t(f"st{i}.dx", *x.shape) if need_dx else None
+        ws = self.buf["style.ws"]
+        go = lambda nm: self.flat_g.data_ptr() + 4 * s.off[nm][0]
+        po = lambda nm: self.flat_p.data_ptr() + 4 * s.off[nm][0]
+        check(lib.ms_style_bwd(dy.data_ptr(), x.data_ptr(), 0 if dx is None else dx.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+                               std[0].data_ptr(), std[1].data_ptr(), po("lmda") if s.mix_style else 0, s.perm.data_ptr() if s.mix_style else 0,
+                               go("gamma_noise") if s.use_noise else 0, go("beta_noise") if s.use_noise else 0, go("lmda") if s.mix_style else 0,
+                               B, C, HW, ws.data_ptr(), ws.numel(), self._st()), f"ms_style_bwd:{i}")
+        return dx
+
+    def _style_ws(self, nbytes):
+        b = self.buf.get("style.ws")
+        if b is None or b.numel() < nbytes:
+            if self._graph is not None:
+                raise RuntimeError("style workspace would grow while a captured graph is live")
+            b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=self.dev)
+            self.buf["style.ws"] = b
+        return b
+
+    def _is_identity(self, i, shape):
+        s = self.styles[i]
+        return shape[2] * shape[3] == 1 or shape[0] <= 1 or (not s.mix_style and not s.use_noise)
+
+    # ------------------------------------------------------------------ image decoder with MaxStyle (apply_max_style)
+    def decode(self, code):
+        """MyDecoder.apply_max_style (encoder_decoder.py:598-631); the blocks before the first inserted layer are cached."""
+        d = self.nets.dec
+        first = min(self.layers) if self.layers else 6
+        x = code
+        if 0 in self.layers:
+            x = self.style_fwd(0, x)
+        for i in range(1, 5):
+            if i <= first and self._prefix_valid:
+                x = self.buf[f"d.u{i}.out"]              # style-independent prefix: computed once per call
+            else:
+                x = self.res_fwd(f"d.u{i}", d, f"u{i}", x, "convT")
+            if i in self.layers:
+                x = self.style_fwd(i, x)
+        N, C, H, W = x.shape
+        K = d["head.w"].shape[0]
+        if first > 4 and self._prefix_valid:
+            img = self.buf["d.image"]
+        else:
+            img = self.t("d.image", N, K, H, W)
+            check(lib.ms_head_fwd(x.data_ptr(), d["head.w"].data_ptr(), d["head.b"].data_ptr(), img.data_ptr(), N, C, K, H * W, 1, self._st()), "ms_head_fwd")
+            self.buf["d.head_in"] = x
+        self._prefix_valid = True
+        if 5 in self.layers:
+            img = self.style_fwd(5, img)
+        return img
+
+    def decode_bwd(self, dimg):
+        """Backward of apply_max_style down to the first inserted layer; fills flat_g."""
+        d = self.nets.dec
+        first = min(self.layers)
+        g = dimg
+        if 5 in self.layers and not self._is_identity(5, self.buf["d.image"].shape):
+            g = self.style_bwd(5, g, need_dx=(first < 5))
+            if first == 5:
+                return
+        x = self.buf["d.head_in"]
+        N, C, H, W = x.shape
+        K = d["head.w"].shape[0]
+        dh = self.t("d.dh", N, C, H, W)
+        check(lib.ms_head_bwd(g.data_ptr(), self.buf["d.image"].data_ptr(), d["head.w"].data_ptr(), dh.data_ptr(), N, C, K, H * W, 1, self._st()), "ms_head_bwd")
+        g = dh
+        for i in range(4, 0, -1):
+            if i in self.layers and not self._is_identity(i, self.buf[f"d.u{i}.out"].shape):
+                g = self.style_bwd(i, g, need_dx=(first < i))
+                if first == i:
+                    return
+            g = self.res_bwd(f"d.u{i}", d, f"u{i}", g, "convT", need_dx=True)
+        if 0 in self.layers:
+            self.style_bwd(0, g, need_dx=False)
+
+    # ------------------------------------------------------------------ the loop
+    def adam(self):
+        for o, n in self.learn_segments:
+            b = 4 * o
+            check(lib.ms_adam_step(self.flat_p.data_ptr() + b, self.flat_g.data_ptr() + b, self.flat_m.data_ptr() + b, self.flat_v.data_ptr() + b, n,
+                                   self.lr, 0.9, 0.999, 1e-8, 0, self.step_dev.data_ptr(), self._st()), "ms_adam_step")
+        check(lib.ms_counter_incr(self.step_dev.data_ptr(), self._st()), "ms_counter_incr")
+
+    def step(self, image):
+        """One inner iteration i >= 1 of advanced_triplet...py:539-566. Returns the re-decoded image."""
+        dimg = self.seg_loss(image, self.labels, need_grad=True, loss_slot=self.step_dev)
+        self.decode_bwd(dimg)
+        self.adam()
+        return self.decode(self.code)
+
+    def step_grads(self, labels):
+        """Decode at the current parameters, evaluate loss and gradients (no Adam). For parity tests (teacher forcing)."""
+        self.labels = labels
+        img = self.decode(self.code)
+        self.flat_g.zero_()
+        dimg = self.seg_loss(img, labels, need_grad=True, loss_slot=None)
+        self.decode_bwd(dimg)
+        return img, self.loss_buf[0:1]
+
+    def set_nets(self, nets: PackedNets):
+        self.nets = nets
+        self._graph = None
+        self._prefix_valid = False
+
+    def run(self, code, labels, n_iter, use_graph=True):
+        """K inner steps; returns the final stylised image (a view of an engine buffer - clone to keep)."""
+        assert n_iter <= self.loss_buf.numel(), "n_iter exceeds the loss buffer"
+        self.code, self.labels = code, labels
+        self._prefix_valid = False
+        self.step_dev.zero_()
+        img = self.decode(code)
+        if n_iter <= 0 or not self.learn_segments:
+            return img
+        k0 = 0
+        if use_graph and self._graph is None and n_iter >= 2:
+            img = self.step(img)                         # eager warm-up: allocates every buffer
+            k0 = 1
+            try:
+                g = torch.cuda.CUDAGraph()
+                self._graph_in = img
+                with torch.cuda.graph(g):
+                    out = self.step(self._graph_in)
+                assert out.data_ptr() == self._graph_in.data_ptr(), "decode must write the image in place for replay"
+                self._graph = g
+                # the captured launches did not execute: replay below performs step k0+1
+            except Exception as ex:                      # capture unsupported: stay eager, say so once
+                self._graph = None
+                self.graph_error = repr(ex)
+                torch.cuda.synchronize()
+        for _ in range(k0, n_iter):
+            if self._graph is not None and use_graph:
+                self._graph.replay()
+            else:
+                img = self.step(img)
+        return img
+
+    def losses(self, n):
+        return self.loss_buf[:n]
+
+
+def slots_from_modules(style_modules: Dict[int, "torch.nn.Module"], device):
+    """Build engine StyleSlots from MaxStyle nn.Modules (applied ones only), keeping their drawn state."""
+    slots = {}
+    for i, m in style_modules.items():
+        if bool(m.rand_p >= m.p):
+            continue
+        s = StyleSlot(i, m.batch_size, m.num_feature)
+        s.mix_style = bool(m.mix_style)
+        s.use_noise = not bool(m.no_noise)
+        s.learn_noise = isinstance(m.gamma_noise, torch.nn.Parameter) and m.gamma_noise.requires_grad
+        s.learn_mix = isinstance(m.lmda, torch.nn.Parameter) and m.lmda.requires_grad
+        s.eps = float(m.eps)
+        slots[i] = s
+    return slots

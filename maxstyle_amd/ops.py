@@ -12,12 +12,20 @@ def _stream():
 
 
 def _ptr(t):
-    return 0 if t is None else t.data_ptr()
+    if t is None:
+        return 0
+    return t if isinstance(t, int) else t.data_ptr()
+
+
+def coef_ptrs(coef4):
+    """Raw pointers to columns 0,1,2 of an interleaved [C,4] coefficient record (use with pro_cstride=4)."""
+    p = coef4.data_ptr()
+    return p, p + 4, p + 8
 
 
 def _need_cuda_f32(*ts):
     for t in ts:
-        if t is None:
+        if t is None or isinstance(t, int):
             continue
         if not t.is_cuda:
             raise RuntimeError("maxstyle_amd ops run on the MI355X only: got a CPU tensor (there is no CPU fallback)")
@@ -137,7 +145,7 @@ def conv_out_hw(Hs, Ws, ks, stride, fetch):
 
 
 def conv2d(x, wp, bias, Cout, ks, stride=1, fetch=FETCH_NORMAL, pro_mode=0, pro_a=None, pro_b=None, pro_c=None, pro_nstride=0,
-           slope=1.0, epi_mode=0, out=None, stats=None, in2=None):
+           pro_cstride=1, slope=1.0, epi_mode=0, out=None, stats=None, in2=None):
     """ms_conv2d wrapper. Returns out ([N,Cout,Hout,Wout], or [N,Cout,2H,2W] for the ConvTranspose epilogue)."""
     _need_cuda_f32(x, wp, bias, pro_a, pro_b, pro_c, out, stats, in2)
     N, Cin, Hs, Ws = x.shape
@@ -148,7 +156,7 @@ def conv2d(x, wp, bias, Cout, ks, stride=1, fetch=FETCH_NORMAL, pro_mode=0, pro_
             raise ValueError("accumulate epilogue needs an existing `out`")
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
     check(lib.ms_conv2d(x.data_ptr(), _ptr(in2), out.data_ptr(), wp.data_ptr(), _ptr(bias), N, Cin, Hs, Ws, Cout, ks, stride, fetch,
-                        pro_mode, _ptr(pro_a), _ptr(pro_b), _ptr(pro_c), pro_nstride, slope, epi_mode, _ptr(stats), _stream()), "ms_conv2d")
+                        pro_mode, _ptr(pro_a), _ptr(pro_b), _ptr(pro_c), pro_nstride, pro_cstride, slope, epi_mode, _ptr(stats), _stream()), "ms_conv2d")
     return out
 
 

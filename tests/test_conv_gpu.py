@@ -100,7 +100,7 @@ def test_batch_stats_and_prologue(dev, N, C, H, W):
     coef = ops.bn_finalize(stats, parts, gamma.to(dev), beta.to(dev))
     assert rel(coef[:, 2], mean) < 1e-6
     assert rel(coef[:, 3], 1 / torch.sqrt(var + 1e-5)) < 1e-5
-    out = ops.conv2d(ug, ops.pack_conv_weight(w2.to(dev)), b2.to(dev), 16, 3, 1, pro_mode=1, pro_a=coef[:, 0].contiguous(), pro_b=coef[:, 1].contiguous(), slope=0.2)
+    out = ops.conv2d(ug, ops.pack_conv_weight(w2.to(dev)), b2.to(dev), 16, 3, 1, pro_mode=1, pro_a=ops.coef_ptrs(coef)[0], pro_b=ops.coef_ptrs(coef)[1], pro_cstride=4, slope=0.2)
     assert rel(out, ref) < 1e-5
     # materialised BN+residual+activation (same-res and half-res residual)
     res = _rand((N, C, H, W), 8); res_h = _rand((N, C, H // 2, W // 2), 9)
@@ -129,8 +129,8 @@ def test_bn_backward_chain(dev):
     assert rel(og, out) < 1e-5
     g, part, nparts = ops.act_bwd_reduce(dout.to(dev), og, ug, coef, 0.2)
     bc = ops.bn_bwd_coefs(part, nparts, coef, N * H * W)
-    da = ops.conv2d(g, ops.pack_conv_weight_dgrad(w.to(dev)), None, C, 3, 1, pro_mode=2, pro_a=bc[:, 0].contiguous(), pro_b=bc[:, 1].contiguous(),
-                    pro_c=bc[:, 2].contiguous(), in2=ug)
+    da = ops.conv2d(g, ops.pack_conv_weight_dgrad(w.to(dev)), None, C, 3, 1, pro_mode=2, pro_a=ops.coef_ptrs(bc)[0], pro_b=ops.coef_ptrs(bc)[1],
+                    pro_c=ops.coef_ptrs(bc)[2], pro_cstride=4, in2=ug)
     assert rel(da, ar.grad) < 2e-5
     # un-materialised activation: mask from coef*u+shift
     z2 = F.leaky_relu(F.batch_norm(u.detach(), None, None, gamma.double(), beta.double(), True, 0.0, 1e-5), 0.2)

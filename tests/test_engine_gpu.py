@@ -1,0 +1,185 @@
+"""The fused HIP inner loop (maxstyle_amd.engine) against the reference golden vectors and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from parity_util import rel, ref_params_at, style_names
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def build_engine(dev, spec_o, B, size, layers, style_seed=7, lr=0.1):
+    from maxstyle_amd import engine as E
+    from oracle import maxstyle_oracle as orc
+    W = orc.procedural_weights(spec_o, 0)
+    to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
+    spec = E.NetSpec(spec_o.reduce, spec_o.image_ch, spec_o.num_classes)
+    nets = E.PackedNets(spec, to(W["image_encoder"]), to(W["segmentation_decoder"]), to(W["image_decoder"]))
+    eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=lr)
+    eng.set_nets(nets)
+    img, lab = orc.synthetic_batch(B, size, spec_o.image_ch, spec_o.num_classes, 1234)
+    styles = {i: orc.random_style_state(B, spec_o.channel_num[i], style_seed + i) for i in layers}
+    slots = {i: E.StyleSlot(i, B, spec_o.channel_num[i]) for i in layers}
+    eng.configure_styles(layers, slots)
+    for i in layers:
+        st = styles[i]
+        eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
+    return eng, W, img, lab, styles
+
+
+def test_forward_taps_config1(golden_dir, dev):
+    """Every block of the un-styled decoder, the encoder and the segmentation decoder (BN batch-stat mode) vs the oracle."""
+    from oracle import maxstyle_oracle as orc
+    spec = orc.NetSpec(4, 1, 4)
+    eng, W, img, lab, _ = build_engine(dev, spec, 4, 128, [])
+    g = np.load(os.path.join(golden_dir, "loop_c1.npz"))
+    z_i = torch.from_numpy(g["z_i"])
+    with torch.no_grad():
+        taps = {}
+        h = z_i
+        for k in range(1, 5):
+            h = orc.res_up_block(W["image_decoder"], f"up{k}.", h, "Conv2", taps=taps)
+        recon = torch.sigmoid(torch.nn.functional.conv2d(h, W["image_decoder"]["final_conv.weight"], W["image_decoder"]["final_conv.bias"]))
+        et = {}
+        zi, zs = orc.encoder_forward(W["image_encoder"], recon, taps=et)
+        st = {}
+        logits = orc.decoder_forward(W["segmentation_decoder"], zs, "NN", taps=st)
+        ce = -orc.cross_entropy_2d(logits, lab)
+    out = eng.decode(z_i.to(dev))
+    for k in range(1, 5):
+        assert rel(eng.buf[f"d.u{k}.out"], taps[f"up{k}.out"]) < 2e-5, k
+    assert rel(out, recon) < 1e-5
+    eng.seg_loss(out, lab.to(dev), need_grad=False, need_logits=True)
+    assert rel(eng.buf["e.inc.out"], et["general_encoder.inc.out"]) < 2e-5
+    for k in range(1, 5):
+        assert rel(eng.buf[f"e.d{k}.out"], et[f"general_encoder.down{k}.out"]) < 3e-5, k
+    assert rel(eng.buf["e.z_i"], zi) < 3e-5 and rel(eng.buf["e.z_s"], zs) < 5e-5
+    for k in range(1, 5):
+        assert rel(eng.buf[f"s.u{k}.out"], st[f"up{k}.out"]) < 1e-4, k
+    assert rel(eng.buf["s.logits"], logits) < 1e-4
+    assert abs(float(eng.loss_buf[0]) - float(ce)) < 2e-5 * abs(float(ce))
+    # fixture samples taken from the reference itself
+    flat = eng.buf["s.logits"].reshape(-1).cpu()
+    idx = torch.linspace(0, flat.numel() - 1, 2048).long()
+    assert rel(flat[idx], g["tap.seg.logits.sample"]) < 1e-4
+
+
+def _teacher_forced(dev, g, g64, spec, B, size, layers, K, grad_tol=5e-2):
+    eng, W, img, lab, styles = build_engine(dev, spec, B, size, layers)
+    z_i = torch.from_numpy(g["z_i"]).to(dev) if "z_i" in g.files else None
+    if z_i is None:
+        from oracle import maxstyle_oracle as orc
+        with torch.no_grad():
+            z_i = orc.encoder_forward(W["image_encoder"], img)[0].to(dev)
+    eng.code = z_i
+    labd = lab.to(dev)
+    initial = {f"{i}.{n}": getattr(styles[i], n).numpy().copy() for i in layers for n in ("gamma_noise", "beta_noise", "lmda")}
+    for s in range(1, K + 1):
+        cur = ref_params_at(g, s - 1, layers, initial)
+        for n, val in cur.items():
+            i, nm = n.split(".")
+            eng.param(int(i), nm).copy_(torch.from_numpy(np.array(val)).to(dev))
+        eng._prefix_valid = False
+        _, loss = eng.step_grads(labd)
+        assert abs(float(loss) - g["losses"][s - 1]) < 3e-5 * abs(g["losses"][s - 1]), (s, float(loss), g["losses"][s - 1])
+        for n in style_names(layers):
+            i, nm = n.split(".")
+            got = eng.grad(int(i), nm)
+            ref = g[f"step{s}.grad.{n}"]
+            if s == 1 and g64 is not None:
+                noise = rel(ref, g64[f"step1.grad.{n}"])
+                assert rel(got, g64[f"step1.grad.{n}"]) < max(4 * noise, 2e-4), (s, n, noise)
+            else:
+                assert rel(got, ref) < grad_tol, (s, n)
+        if s == 1:
+            for i in layers:
+                assert rel(eng.buf[f"st{i}.std"][0], g[f"{i}.gamma_std"].ravel()) < 1e-5
+                assert rel(eng.buf[f"st{i}.std"][1], g[f"{i}.beta_std"].ravel()) < 1e-5
+            # Adam kernel: reference gradient in -> reference parameters out
+            for n in style_names(layers):
+                i, nm = n.split(".")
+                eng.grad(int(i), nm).copy_(torch.from_numpy(np.array(g[f"step1.grad.{n}"])).to(dev))
+            eng.step_dev.zero_()
+            eng.adam()
+            for n in style_names(layers):
+                i, nm = n.split(".")
+                assert rel(eng.param(int(i), nm), g[f"step1.param.{n}"]) < 1e-6, n
+    for n, val in ref_params_at(g, K, layers, initial).items():
+        i, nm = n.split(".")
+        eng.param(int(i), nm).copy_(torch.from_numpy(np.array(val)).to(dev))
+    out = eng.decode(z_i)
+    assert rel(out, g["image"]) < 2e-5
+    return eng, W, lab, out
+
+
+def test_loop_config1_teacher_forced(golden_dir, dev):
+    from oracle import maxstyle_oracle as orc
+    g = np.load(os.path.join(golden_dir, "loop_c1.npz")); g64 = np.load(os.path.join(golden_dir, "loop_c1_f64.npz"))
+    _teacher_forced(dev, g, g64, orc.NetSpec(4, 1, 4), 4, 128, [3], 1)
+
+
+def test_loop_k5_teacher_forced(golden_dir, dev):
+    from oracle import maxstyle_oracle as orc
+    g = np.load(os.path.join(golden_dir, "loop_c2small.npz")); g64 = np.load(os.path.join(golden_dir, "loop_c2small_f64.npz"))
+    eng, W, lab, out = _teacher_forced(dev, g, g64, orc.NetSpec(4, 1, 4), 4, 64, [3, 4, 5], 5)
+    # segmentation of the final stylised image: argmax labels + Dice equal to the reference's
+    eng.seg_loss(out, lab.to(dev), need_grad=False, need_logits=True)
+    pred = eng.buf["s.logits"].argmax(1).cpu()
+    assert float((pred.numpy() == g["final_pred"]).mean()) > 0.9995
+    np.testing.assert_allclose(orc.dice_per_class(pred, lab, 4), g["final_dice"], atol=1e-3)
+
+
+def test_loop_all_six_layers(golden_dir, dev):
+    from oracle import maxstyle_oracle as orc
+    g = np.load(os.path.join(golden_dir, "loop_all_layers.npz"))
+    _teacher_forced(dev, g, None, orc.NetSpec(4, 1, 4), 3, 64, [0, 1, 2, 3, 4, 5], 2, grad_tol=0.2)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_free_running_loop(golden_dir, dev, use_graph):
+    """run(K): eager and HIP-graph replay agree bit for bit; vs the reference trajectory only loosely (parity_util)."""
+    from oracle import maxstyle_oracle as orc
+    g = np.load(os.path.join(golden_dir, "loop_c2small.npz"))
+    eng, W, img, lab, styles = build_engine(dev, orc.NetSpec(4, 1, 4), 4, 64, [3, 4, 5])
+    z_i = torch.from_numpy(g["z_i"]).to(dev)
+    out = eng.run(z_i, lab.to(dev), 5, use_graph=use_graph).clone()
+    if use_graph:
+        assert eng._graph is not None, getattr(eng, "graph_error", "graph capture failed")
+    losses = eng.losses(5).cpu().numpy()
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-2)
+    assert rel(out, g["image"]) < 3e-2
+    eng.seg_loss(out, lab.to(dev), need_grad=False, need_logits=True)
+    pred = eng.buf["s.logits"].argmax(1).cpu()
+    np.testing.assert_allclose(orc.dice_per_class(pred, lab, 4), g["final_dice"], atol=2e-2)
+    if use_graph:
+        eng2, *_ = build_engine(dev, orc.NetSpec(4, 1, 4), 4, 64, [3, 4, 5])
+        ref = eng2.run(z_i, lab.to(dev), 5, use_graph=False)
+        assert torch.equal(ref, out), "graph replay must be bit-identical to eager launches"
+
+
+def test_fcn64_three_channel(dev):
+    """Prostate-shaped variant (FCN_64 widths, 3-channel image, 2 classes) at a small size: engine vs oracle fp64, one step."""
+    from oracle import maxstyle_oracle as orc
+    spec = orc.NetSpec(1, 3, 2)
+    B, size, layers = 2, 32, [3, 4, 5]
+    eng, W, img, lab, styles = build_engine(dev, spec, B, size, layers)
+    W64 = {k: {n: (t.double() if t.is_floating_point() else t) for n, t in sd.items()} for k, sd in W.items()}
+    with torch.no_grad():
+        z_i = orc.encoder_forward(W64["image_encoder"], img.double())[0]
+    st64 = {i: s.clone(torch.float64) for i, s in styles.items()}
+    recon, loss, grads = orc.inner_step_grads(W64, z_i, st64, layers, lab)
+    eng.code = z_i.float().to(dev)
+    img_g, loss_g = eng.step_grads(lab.to(dev))
+    assert rel(img_g, recon) < 1e-4
+    assert abs(float(loss_g) - loss) < 1e-4 * abs(loss)
+    for n, gr in grads.items():
+        i, nm = n.split(".")
+        assert rel(eng.grad(int(i), nm), gr) < 0.1, n
