@@ -153,8 +153,8 @@ class InnerLoopEngine:
     def t(self, name, *shape, dtype=F32):
         b = self.buf.get(name)
         if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
-            if self._graph is not None:
-                raise RuntimeError(f"buffer {name} would be (re)allocated while a captured graph is live")
+            if b is not None and self._graph is not None:
+                raise RuntimeError(f"buffer {name} would be re-allocated while a captured graph holds its address")
             b = torch.empty(*shape, dtype=dtype, device=self.dev)
             self.buf[name] = b
         return b
