@@ -1,0 +1,19 @@
+// Instantiations: 1x1 convolutions (skip paths, final_conv, ConvTranspose2d-as-GEMM and their data-gradients).
+#include "ms_conv_kernel.h"
+namespace ms {
+template <bool VEC, bool NARROW, bool IN2>
+static int k1_nt(const ConvArgs& a, int nt, hipStream_t st) {
+  switch (nt) {
+    case 1: return launch_conv<1, 1, FETCH_NORMAL, 1, VEC, NARROW, IN2>(a, st);
+    case 2: return launch_conv<1, 1, FETCH_NORMAL, 2, VEC, NARROW, IN2>(a, st);
+    default: return launch_conv<1, 1, FETCH_NORMAL, 4, VEC, NARROW, IN2>(a, st);
+  }
+}
+int conv_dispatch_k1s1(const ConvArgs& a, int nt, bool vec, bool narrow, bool in2, hipStream_t st) {
+  if (vec) {
+    if (narrow) return in2 ? k1_nt<true, true, true>(a, nt, st) : k1_nt<true, true, false>(a, nt, st);
+    return in2 ? k1_nt<true, false, true>(a, nt, st) : k1_nt<true, false, false>(a, nt, st);
+  }
+  return in2 ? k1_nt<false, false, true>(a, nt, st) : k1_nt<false, false, false>(a, nt, st);
+}
+}  // namespace ms

@@ -1,0 +1,390 @@
+// Implicit-GEMM convolution kernel template for gfx950 (exact-fp32 matrix cores, v_mfma_f32_16x16x4_f32).
+// See ms_conv.hip for what it replaces in the reference and for the dispatch; this header is included by the
+// translation units that instantiate slices of the template (parallel compilation).
+//
+// Workgroup = 4 waves = one output tile (8x32 pixels, or 16x16 for small feature maps) x 16*NT output channels.
+// K loop over chunks of CK input channels:
+//     global --(16-B loads of an aligned window, issued back to back)--> registers   [prefetch of chunk i+1]
+//     registers --(BatchNorm apply / BatchNorm backward prologue)--> LDS               [chunk i]
+//     LDS --ds_read_b32 fragments--> MFMA 16x16x4 (A = 16 pixels x 4 channels, B = 4 channels x 16 couts)
+// The loads of chunk i+1 are in flight while chunk i is multiplied, so a workgroup hides its own HBM/L2 latency
+// even at one workgroup per CU (deep layers: few tiles, long K).
+#pragma once
+#include "ms_common.h"
+
+namespace ms {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { FETCH_NORMAL = 0, FETCH_UPS2 = 1, FETCH_ZINS2 = 2 };
+
+struct ConvArgs {
+  const float* in; const float* in2; float* out; const float* w; const float* bias;
+  const float* pro_a; const float* pro_b; const float* pro_c;
+  float* stats;                 // float4 [cout][nparts] (count, mean, M2, 0) or null
+  int N, Cin, Hs, Ws, Hin, Win, Cout, Hout, Wout, cin_pad, cout_pad;
+  int pro_mode, pro_nstride, pro_cstride; float slope;
+  int epi_mode, tiles_x, tiles_y, cout_real;
+};
+
+template <int KS, int STRIDE, bool VEC, bool NARROW>
+struct Geo {
+  static constexpr int TW = NARROW ? 16 : 32;
+  static constexpr int TH = NARROW ? 16 : 8;
+  static constexpr int PAD = (KS == 3) ? 1 : 0;
+  static constexpr int PADL = VEC ? ((KS == 3) ? 4 : 0) : PAD;           // window starts PADL logical columns left of ox0*S
+  static constexpr int IH = (TH - 1) * STRIDE + KS;
+  static constexpr int WIN_W = VEC ? (TW * STRIDE + ((KS == 3) ? 8 : 0)) : ((TW - 1) * STRIDE + KS);
+  static constexpr int HALF = (WIN_W + 1) / 2;
+  static constexpr int RS = (STRIDE == 1) ? ((WIN_W + 3) / 4 * 4) : 2 * HALF;
+  static constexpr int BASE = IH * RS;
+  static constexpr int PS = BASE + ((16 - BASE % 32 + 32) % 32);           // plane stride == 16 (mod 32 banks)
+  static constexpr int CK = (STRIDE == 1) ? 16 : 8;
+  static constexpr int VW = VEC ? 4 : 1;
+  static constexpr int ROW_ITEMS = WIN_W / VW;                              // VEC: WIN_W % 4 == 0 by construction
+  static constexpr int ITEMS = CK * IH * ROW_ITEMS;
+  static constexpr int NI = (ITEMS + 255) / 256;
+  // LDS column of logical tap offset t = kx - PAD + PADL (added to the pixel's x inside the tile)
+  static constexpr int tap_col(int kx) {
+    const int t = kx - PAD + PADL;
+    return (STRIDE == 1) ? t : ((t & 1) * HALF + (t >> 1));
+  }
+};
+
+template <int NT> struct WGeo { static constexpr int WS = (NT == 1) ? 16 : NT * 16 + 16; };
+
+template <int KS, int STRIDE, int FETCH, int NT, bool VEC, bool NARROW, bool IN2>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+  using G = Geo<KS, STRIDE, VEC, NARROW>;
+  constexpr int CK = G::CK, PS = G::PS, RS = G::RS, IH = G::IH, PAD = G::PAD, PADL = G::PADL, HALF = G::HALF;
+  constexpr int TW = G::TW, TH = G::TH, VW = G::VW, ROW_ITEMS = G::ROW_ITEMS, ITEMS = G::ITEMS, NI = G::NI;
+  constexpr int WS = WGeo<NT>::WS;
+  constexpr int TAPS = KS * KS;
+  constexpr int COUT_TILE = 16 * NT;
+  constexpr int WITEMS = TAPS * CK * (COUT_TILE / 4);
+  constexpr int NWI = (WITEMS + 255) / 256;
+  static_assert(!VEC || FETCH == FETCH_NORMAL, "vector staging needs the plain fetch");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* in_lds = smem;                 // [CK][PS]
+  float* w_lds = smem + CK * PS;        // [TAPS][CK][WS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, k = lane >> 4;
+  const int tile = blockIdx.x;
+  const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+  const int co0 = blockIdx.y * COUT_TILE;
+  const int n = blockIdx.z;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 * STRIDE - PAD;
+  const int wx0 = ox0 * STRIDE - PADL;        // logical input column of window column 0
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const size_t in_plane = (size_t)a.Hs * a.Ws;
+  const float* in_n = a.in + (size_t)n * a.Cin * in_plane;
+  const float* in2_n = IN2 ? a.in2 + (size_t)n * a.Cin * in_plane : nullptr;
+
+  // ---- per-thread staging slots (fixed across chunks): item -> (channel c, row r, window column w) ----
+  int s_lds[NI];        // LDS float offset of the slot (or -1: no slot)
+  int s_goff[NI];       // global offset inside one channel plane (or -1: out of the image -> zeros)
+  int s_c[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int item = tid + j * 256;
+    s_lds[j] = -1; s_goff[j] = -1; s_c[j] = 0;
+    if (item < ITEMS) {
+      const int f = item % ROW_ITEMS;
+      const int row = item / ROW_ITEMS;
+      const int r = row % IH, c = row / IH;
+      const int w = f * VW;
+      const int Y = iy0 + r, X = wx0 + w;
+      bool ok = (Y >= 0) && (Y < a.Hin) && (X >= 0) && (X < a.Win);
+      int ys = Y, xs = X;
+      if (FETCH == FETCH_UPS2) { ys = Y >> 1; xs = X >> 1; }
+      if (FETCH == FETCH_ZINS2) { ok = ok && !((Y | X) & 1); ys = Y >> 1; xs = X >> 1; }
+      s_c[j] = c;
+      s_goff[j] = ok ? (ys * a.Ws + xs) : -1;
+      const int q = (STRIDE == 1) ? w : ((w & 1) * HALF + (w >> 1));
+      s_lds[j] = c * PS + r * RS + q;
+    }
+  }
+
+  float rin[NI][VW];
+  float rin2[IN2 ? NI : 1][VW];
+  float4 rw[NWI];
+
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int ci = c0 + s_c[j];
+      const bool ok = (s_lds[j] >= 0) && (s_goff[j] >= 0) && (ci < a.Cin);
+      const size_t off = ok ? ((size_t)ci * in_plane + (size_t)s_goff[j]) : 0;
+      if constexpr (VEC) {
+        const float4 v = ok ? *reinterpret_cast<const float4*>(in_n + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rin[j][0] = v.x; rin[j][1] = v.y; rin[j][2] = v.z; rin[j][3] = v.w;
+        if constexpr (IN2) {
+          const float4 u = ok ? *reinterpret_cast<const float4*>(in2_n + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          rin2[j][0] = u.x; rin2[j][1] = u.y; rin2[j][2] = u.z; rin2[j][3] = u.w;
+        }
+      } else {
+        rin[j][0] = ok ? in_n[off] : 0.f;
+        if constexpr (IN2) rin2[j][0] = ok ? in2_n[off] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NWI; ++j) {
+      const int idx = tid + j * 256;
+      const int j4 = idx % (COUT_TILE / 4);
+      const int row = idx / (COUT_TILE / 4);      // tap*CK + c
+      const int c = row % CK, tap = row / CK;
+      rw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < WITEMS && c0 + c < a.cin_pad)
+        rw[j] = *reinterpret_cast<const float4*>(a.w + ((size_t)tap * a.cin_pad + c0 + c) * a.cout_pad + co0 + j4 * 4);
+    }
+  };
+
+  auto store_chunk = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if (s_lds[j] < 0) continue;
+      const int ci = c0 + s_c[j];
+      const bool ok = (s_goff[j] >= 0) && (ci < a.Cin);
+      float v[VW];
+#pragma unroll
+      for (int e = 0; e < VW; ++e) v[e] = rin[j][e];
+      if (ok) {
+        if (a.pro_mode == 1) {
+          const int pi = (n * a.pro_nstride + ci) * a.pro_cstride;
+          const float pa = a.pro_a[pi], pb = a.pro_b[pi];
+#pragma unroll
+          for (int e = 0; e < VW; ++e) v[e] = leaky(pa * v[e] + pb, a.slope);
+        } else if constexpr (IN2) {
+          if (a.pro_mode == 2) {
+            const int pi = ci * a.pro_cstride;
+            const float pa = a.pro_a[pi], pb = a.pro_b[pi], pc = a.pro_c[pi];
+#pragma unroll
+            for (int e = 0; e < VW; ++e) v[e] = pa * v[e] + pb * rin2[j][e] + pc;
+          }
+        }
+      }
+      float* dst = in_lds + s_lds[j];
+      if constexpr (VEC) {
+        if constexpr (STRIDE == 1) {
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {          // de-interleave even / odd columns (w % 4 == 0 -> even half at dst, odd half at dst+HALF)
+          *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[2]);
+          *reinterpret_cast<float2*>(dst + HALF) = make_float2(v[1], v[3]);
+        }
+      } else {
+        dst[0] = v[0];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NWI; ++j) {
+      const int idx = tid + j * 256;
+      if (idx < WITEMS) {
+        const int j4 = idx % (COUT_TILE / 4);
+        const int row = idx / (COUT_TILE / 4);
+        *reinterpret_cast<float4*>(w_lds + row * WS + j4 * 4) = rw[j];
+      }
+    }
+  };
+
+  // M-tile i of this wave: NARROW: rows 4*wave+i, columns 0..15; else rows 2*wave+(i>>1), columns (i&1)*16..
+  const int a_lane = k * PS + m;
+  const int b_lane = k * WS + m;
+  auto mt_row = [&](int i) { return NARROW ? (wave * 4 + i) : (wave * 2 + (i >> 1)); };
+  auto mt_col = [&](int i) { return NARROW ? 0 : ((i & 1) * 16); };
+
+  auto compute = [&](int ncg) {
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int ky = tap / KS, kx = tap % KS;
+      const int tap_off = ky * RS + G::tap_col(kx);
+#pragma unroll
+      for (int cg = 0; cg < CK / 4; ++cg) {
+        if (cg < ncg) {
+          float bf[NT], af[4];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bf[j] = w_lds[b_lane + (tap * CK + cg * 4) * WS + j * 16];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[i] = in_lds[a_lane + cg * 4 * PS + tap_off + mt_row(i) * STRIDE * RS + mt_col(i)];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  load_chunk(0);
+  for (int c0 = 0; c0 < a.cin_pad; c0 += CK) {
+    __syncthreads();                       // every wave finished multiplying the previous chunk
+    store_chunk(c0);
+    __syncthreads();
+    if (c0 + CK < a.cin_pad) load_chunk(c0 + CK);     // in flight while this chunk is multiplied
+    const int ncg = min(CK / 4, (a.cin_pad - c0) / 4);
+    if (ncg == CK / 4) compute(CK / 4); else compute(ncg);
+  }
+
+  // ---- epilogue ----
+  // D layout (16x16): column (output channel) = lane&15, rows (pixels) = 4*(lane>>4) + reg
+  const int xq = 4 * k;
+  float bias_v[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int co = co0 + j * 16 + m;
+    int bidx = co;
+    if (a.epi_mode == 2) bidx = co % a.cout_real;
+    bias_v[j] = (a.bias != nullptr && co < ((a.epi_mode == 2) ? 4 * a.cout_real : a.Cout)) ? a.bias[bidx] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] += bias_v[j];
+
+  if (a.stats != nullptr) {
+    __syncthreads();
+    float* red = smem;                       // [4 waves][COUT_TILE]
+    float s[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) s[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = oy0 + mt_row(i);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int x = ox0 + mt_col(i) + xq + r;
+        const bool ok = (y < a.Hout) && (x < a.Wout);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) s[j] += ok ? acc[i][j][r] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      s[j] += __shfl_xor(s[j], 16, 64);
+      s[j] += __shfl_xor(s[j], 32, 64);
+      if (k == 0) red[wave * COUT_TILE + j * 16 + m] = s[j];
+    }
+    __syncthreads();
+    const float cnt = (float)(min(TH, a.Hout - oy0) * min(TW, a.Wout - ox0));
+    float mean[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int cc = j * 16 + m;
+      mean[j] = (red[cc] + red[COUT_TILE + cc] + red[2 * COUT_TILE + cc] + red[3 * COUT_TILE + cc]) / cnt;
+      s[j] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = oy0 + mt_row(i);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int x = ox0 + mt_col(i) + xq + r;
+        const bool ok = (y < a.Hout) && (x < a.Wout);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { const float d = acc[i][j][r] - mean[j]; s[j] += ok ? d * d : 0.f; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      s[j] += __shfl_xor(s[j], 16, 64);
+      s[j] += __shfl_xor(s[j], 32, 64);
+      if (k == 0) red[wave * COUT_TILE + j * 16 + m] = s[j];
+    }
+    __syncthreads();
+    if (wave == 0 && k == 0) {
+      const int nparts = a.N * a.tiles_x * a.tiles_y;
+      const int pidx = n * (a.tiles_x * a.tiles_y) + tile;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int cc = j * 16 + m;
+        const int co = co0 + cc;
+        if (co < a.Cout) {
+          const float m2 = red[cc] + red[COUT_TILE + cc] + red[2 * COUT_TILE + cc] + red[3 * COUT_TILE + cc];
+          reinterpret_cast<float4*>(a.stats)[(size_t)co * nparts + pidx] = make_float4(cnt, mean[j], m2, 0.f);
+        }
+      }
+    }
+  }
+
+  if (a.epi_mode == 2) {
+    // ConvTranspose2d k=2 s=2: GEMM column j = (dy*2+dx)*cout_real + co -> out[n,co,2y+dy,2x+dx]
+    const int Ho = 2 * a.Hout, Wo = 2 * a.Wout;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = co0 + j * 16 + m;
+      if (col >= 4 * a.cout_real) continue;
+      const int q = col / a.cout_real, co = col - q * a.cout_real;
+      const int dy = q >> 1, dx = q & 1;
+      float* op = a.out + ((size_t)n * a.cout_real + co) * Ho * Wo;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int y = oy0 + mt_row(i);
+        if (y >= a.Hout) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int x = ox0 + mt_col(i) + xq + r;
+          if (x < a.Wout) op[(size_t)(2 * y + dy) * Wo + 2 * x + dx] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
+
+  const bool vec_ok = (a.Wout % 4 == 0);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int co = co0 + j * 16 + m;
+    if (co >= a.Cout) continue;
+    float* op = a.out + ((size_t)n * a.Cout + co) * a.Hout * a.Wout;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = oy0 + mt_row(i);
+      if (y >= a.Hout) continue;
+      const int x = ox0 + mt_col(i) + xq;
+      float* o = op + (size_t)y * a.Wout + x;
+      if (vec_ok && x + 3 < a.Wout) {
+        float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (a.epi_mode == 1) { const float4 p = *reinterpret_cast<const float4*>(o); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+        *reinterpret_cast<float4*>(o) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (x + r < a.Wout) o[r] = (a.epi_mode == 1) ? (o[r] + acc[i][j][r]) : acc[i][j][r];
+      }
+    }
+  }
+}
+
+template <int KS, int STRIDE, int FETCH, int NT, bool VEC, bool NARROW, bool IN2>
+int launch_conv(const ConvArgs& a, hipStream_t st) {
+  using G = Geo<KS, STRIDE, VEC, NARROW>;
+  constexpr int lds_floats = G::CK * G::PS + KS * KS * G::CK * WGeo<NT>::WS;
+  constexpr int red_floats = 4 * 16 * NT;
+  constexpr size_t lds_bytes = sizeof(float) * (lds_floats > red_floats ? lds_floats : red_floats);
+  static bool attr_set = false;
+  if (!attr_set && lds_bytes > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    attr_set = true;
+  }
+  const int gemm_cols = (a.epi_mode == 2) ? 4 * a.cout_real : a.Cout;
+  dim3 grid(a.tiles_x * a.tiles_y, cdiv(gemm_cols, 16 * NT), a.N), block(256);
+  hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2>), grid, block, lds_bytes, st, a);
+  return check_launch("conv_mfma");
+}
+
+// dispatch entry points implemented in the ms_conv_inst*.hip translation units
+int conv_dispatch_k3s1(const ConvArgs& a, int fetch, int nt, bool vec, bool narrow, bool in2, hipStream_t st);
+int conv_dispatch_k1s1(const ConvArgs& a, int nt, bool vec, bool narrow, bool in2, hipStream_t st);
+int conv_dispatch_s2(const ConvArgs& a, int ks, int nt, bool vec, bool narrow, hipStream_t st);
+
+}  // namespace ms
