@@ -121,9 +121,9 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
   }
   hipStream_t st = (hipStream_t)stream;
   const bool use_in2 = (pro_mode == 2);
-  if (ks == 3 && stride == 1) return conv_dispatch_k3s1(a, fetch, nt, vec, narrow && vec, use_in2, st);
-  if (ks == 1) return conv_dispatch_k1s1(a, nt, vec, narrow && vec, use_in2, st);
-  return conv_dispatch_s2(a, ks, nt, vec, narrow && vec, st);
+  if (ks == 3 && stride == 1) return conv_dispatch_k3s1(a, fetch, nt, vec, narrow, use_in2, st);
+  if (ks == 1) return conv_dispatch_k1s1(a, nt, vec, narrow, use_in2, st);
+  return conv_dispatch_s2(a, ks, nt, vec, narrow, st);
 }
 
 extern "C" int ms_bn_finalize(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, int C, void* stream) {

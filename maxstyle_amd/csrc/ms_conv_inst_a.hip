@@ -14,6 +14,7 @@ int conv_dispatch_k3s1_plain(const ConvArgs& a, int nt, bool vec, bool narrow, b
     if (narrow) return in2 ? k3s1_nt<true, true, true>(a, nt, st) : k3s1_nt<true, true, false>(a, nt, st);
     return in2 ? k3s1_nt<true, false, true>(a, nt, st) : k3s1_nt<true, false, false>(a, nt, st);
   }
+  if (narrow) return in2 ? k3s1_nt<false, true, true>(a, nt, st) : k3s1_nt<false, true, false>(a, nt, st);
   return in2 ? k3s1_nt<false, false, true>(a, nt, st) : k3s1_nt<false, false, false>(a, nt, st);
 }
 }  // namespace ms

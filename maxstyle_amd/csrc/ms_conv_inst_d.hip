@@ -12,7 +12,7 @@ static int s2_nt(const ConvArgs& a, int nt, hipStream_t st) {
 template <int KS>
 static int s2_ks(const ConvArgs& a, int nt, bool vec, bool narrow, hipStream_t st) {
   if (vec) return narrow ? s2_nt<KS, true, true>(a, nt, st) : s2_nt<KS, true, false>(a, nt, st);
-  return s2_nt<KS, false, false>(a, nt, st);
+  return narrow ? s2_nt<KS, false, true>(a, nt, st) : s2_nt<KS, false, false>(a, nt, st);
 }
 int conv_dispatch_s2(const ConvArgs& a, int ks, int nt, bool vec, bool narrow, hipStream_t st) {
   return ks == 3 ? s2_ks<3>(a, nt, vec, narrow, st) : s2_ks<2>(a, nt, vec, narrow, st);

@@ -39,7 +39,7 @@ struct Geo {
   static constexpr int RS = (STRIDE == 1) ? ((WIN_W + 3) / 4 * 4) : 2 * HALF;
   static constexpr int BASE = IH * RS;
   static constexpr int PS = BASE + ((16 - BASE % 32 + 32) % 32);           // plane stride == 16 (mod 32 banks)
-  static constexpr int CK = (STRIDE == 1) ? 16 : 8;
+  static constexpr int CK = (STRIDE == 1 && VEC) ? 16 : 8;   // scalar fallback stages 4x more slots per channel: halve the chunk
   static constexpr int VW = VEC ? 4 : 1;
   static constexpr int ROW_ITEMS = WIN_W / VW;                              // VEC: WIN_W % 4 == 0 by construction
   static constexpr int ITEMS = CK * IH * ROW_ITEMS;
@@ -53,8 +53,11 @@ struct Geo {
 
 template <int NT> struct WGeo { static constexpr int WS = (NT == 1) ? 16 : NT * 16 + 16; };
 
+// waves per SIMD the register budget is sized for (a workgroup is 4 waves = 1 per SIMD): 4 -> <=128 VGPRs, 3 -> <=168, 2 -> <=256
+template <int NT, bool IN2> struct Occ { static constexpr int W = (NT == 1) ? (IN2 ? 3 : 4) : ((NT == 2) ? (IN2 ? 2 : 3) : 2); };
+
 template <int KS, int STRIDE, int FETCH, int NT, bool VEC, bool NARROW, bool IN2>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (Occ<NT, IN2>::W)) void conv_mfma_kernel(const ConvArgs a) {
   using G = Geo<KS, STRIDE, VEC, NARROW>;
   constexpr int CK = G::CK, PS = G::PS, RS = G::RS, IH = G::IH, PAD = G::PAD, PADL = G::PADL, HALF = G::HALF;
   constexpr int TW = G::TW, TH = G::TH, VW = G::VW, ROW_ITEMS = G::ROW_ITEMS, ITEMS = G::ITEMS, NI = G::NI;
@@ -89,13 +92,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const float* in2_n = IN2 ? a.in2 + (size_t)n * a.Cin * in_plane : nullptr;
 
   // ---- per-thread staging slots (fixed across chunks): item -> (channel c, row r, window column w) ----
-  int s_lds[NI];        // LDS float offset of the slot (or -1: no slot)
+  int s_lds[NI];        // (channel-in-chunk << 20) | LDS float offset of the slot, or -1: no slot
   int s_goff[NI];       // global offset inside one channel plane (or -1: out of the image -> zeros)
-  int s_c[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int item = tid + j * 256;
-    s_lds[j] = -1; s_goff[j] = -1; s_c[j] = 0;
+    s_lds[j] = -1; s_goff[j] = -1;
     if (item < ITEMS) {
       const int f = item % ROW_ITEMS;
       const int row = item / ROW_ITEMS;
@@ -106,10 +108,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       int ys = Y, xs = X;
       if (FETCH == FETCH_UPS2) { ys = Y >> 1; xs = X >> 1; }
       if (FETCH == FETCH_ZINS2) { ok = ok && !((Y | X) & 1); ys = Y >> 1; xs = X >> 1; }
-      s_c[j] = c;
       s_goff[j] = ok ? (ys * a.Ws + xs) : -1;
       const int q = (STRIDE == 1) ? w : ((w & 1) * HALF + (w >> 1));
-      s_lds[j] = c * PS + r * RS + q;
+      s_lds[j] = (c << 20) | (c * PS + r * RS + q);
     }
   }
 
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   auto load_chunk = [&](int c0) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int ci = c0 + s_c[j];
+      const int ci = c0 + (s_lds[j] >> 20);
       const bool ok = (s_lds[j] >= 0) && (s_goff[j] >= 0) && (ci < a.Cin);
       const size_t off = ok ? ((size_t)ci * in_plane + (size_t)s_goff[j]) : 0;
       if constexpr (VEC) {
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       if (s_lds[j] < 0) continue;
-      const int ci = c0 + s_c[j];
+      const int ci = c0 + (s_lds[j] >> 20);
       const bool ok = (s_goff[j] >= 0) && (ci < a.Cin);
       float v[VW];
 #pragma unroll
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
           }
         }
       }
-      float* dst = in_lds + s_lds[j];
+      float* dst = in_lds + (s_lds[j] & 0xFFFFF);
       if constexpr (VEC) {
         if constexpr (STRIDE == 1) {
           *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -201,18 +202,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   auto mt_col = [&](int i) { return NARROW ? 0 : ((i & 1) * 16); };
 
   auto compute = [&](int ncg) {
-#pragma unroll
+#pragma unroll 1
     for (int tap = 0; tap < TAPS; ++tap) {
-      const int ky = tap / KS, kx = tap % KS;
-      const int tap_off = ky * RS + G::tap_col(kx);
+      const int ky = tap / KS, kx = tap - ky * KS;
+      const int t = kx - PAD + PADL;
+      const int tap_off = ky * RS + ((STRIDE == 1) ? t : ((t & 1) * HALF + (t >> 1)));
+      const float* ap = in_lds + a_lane + tap_off;
+      const float* bp = w_lds + b_lane + tap * CK * WS;
 #pragma unroll
       for (int cg = 0; cg < CK / 4; ++cg) {
         if (cg < ncg) {
           float bf[NT], af[4];
 #pragma unroll
-          for (int j = 0; j < NT; ++j) bf[j] = w_lds[b_lane + (tap * CK + cg * 4) * WS + j * 16];
+          for (int j = 0; j < NT; ++j) bf[j] = bp[cg * 4 * WS + j * 16];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) af[i] = in_lds[a_lane + cg * 4 * PS + tap_off + mt_row(i) * STRIDE * RS + mt_col(i)];
+          for (int i = 0; i < 4; ++i) af[i] = ap[cg * 4 * PS + mt_row(i) * STRIDE * RS + mt_col(i)];
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
