@@ -68,7 +68,8 @@ static inline int tile_w(int Wout) { return narrow_tile(Wout) ? 16 : 32; }
 
 using namespace ms;
 
-extern "C" int ms_conv_stats_parts(int N, int Hout, int Wout) { return N * cdiv(Hout, tile_h(Wout)) * cdiv(Wout, tile_w(Wout)); }
+// one partial per WAVE (4 per workgroup tile): the conv epilogue needs no LDS and no barrier for the statistics
+extern "C" int ms_conv_stats_parts(int N, int Hout, int Wout) { return 4 * N * cdiv(Hout, tile_h(Wout)) * cdiv(Wout, tile_w(Wout)); }
 
 extern "C" size_t ms_conv_stats_bytes(int N, int Cout, int Hout, int Wout) {
   return (size_t)Cout * ms_conv_stats_parts(N, Hout, Wout) * sizeof(float4);
@@ -106,19 +107,19 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
   const bool narrow = narrow_tile(a.Wout);
   a.tiles_x = cdiv(a.Wout, tile_w(a.Wout)); a.tiles_y = cdiv(a.Hout, tile_h(a.Wout));
   const bool vec = (fetch == FETCH_NORMAL) && (Ws % 4 == 0) && aligned16(in) && (a.in2 == nullptr || aligned16(a.in2));
-  // output-channel tile: the widest that still fills the chip (>= 2 workgroups per CU), else the widest giving >= 1 per CU
+  // output-channel tile: the widest (best reuse of the staged input tile) that still leaves >= 2 work items per CU;
+  // failing that, the widest that leaves >= 1 per CU; else 16 channels (most parallelism)
   const long tiles = (long)a.tiles_x * a.tiles_y * N;
   int nt = 1;
-  for (int cand = 4; cand >= 1; cand >>= 1) {
-    if (cand > 1 && gemm_cols <= 16 * (cand / 2)) continue;        // would be mostly padding
-    if (tiles * cdiv(gemm_cols, 16 * cand) >= 512) { nt = cand; break; }
-  }
-  if (nt == 1) {
-    for (int cand = 4; cand >= 2; cand >>= 1) {
-      if (gemm_cols <= 16 * (cand / 2)) continue;
-      if (tiles * cdiv(gemm_cols, 16 * cand) >= 256) { nt = cand; break; }
+  bool found = false;
+  for (long want : {512L, 256L}) {
+    for (int cand = ((pro_mode == 2 || ks == 3) ? 2 : 4); cand >= 2 && !found; cand >>= 1) {   // 64-channel tiles only where they fit the register file without spilling
+      if (gemm_cols <= 16 * (cand / 2)) continue;        // would be mostly padding
+      if (tiles * cdiv(gemm_cols, 16 * cand) >= want) { nt = cand; found = true; }
     }
+    if (found) break;
   }
+  a.ncb = cdiv(gemm_cols, 16 * nt);
   hipStream_t st = (hipStream_t)stream;
   const bool use_in2 = (pro_mode == 2);
   if (ks == 3 && stride == 1) return conv_dispatch_k3s1(a, fetch, nt, vec, narrow, use_in2, st);
