@@ -21,6 +21,7 @@
 // slice of CK input channels are staged in LDS; A fragments are ds_read_b32 of 16 consecutive pixels per k (plane
 // stride == 16 mod 32 banks -> conflict-free), B fragments 16 consecutive output channels per k.
 #include <algorithm>
+#include <cstdlib>
 #include "ms_conv_kernel.h"
 #include "maxstyle_hip.h"
 
@@ -120,6 +121,7 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
     if (found) break;
   }
   a.ncb = cdiv(gemm_cols, 16 * nt);
+  { static const int dbg = getenv("MS_CONV_DBG") ? atoi(getenv("MS_CONV_DBG")) : 0; a.dbg = dbg; }
   hipStream_t st = (hipStream_t)stream;
   const bool use_in2 = (pro_mode == 2);
   if (ks == 3 && stride == 1) return conv_dispatch_k3s1(a, fetch, nt, vec, narrow, use_in2, st);

@@ -2,13 +2,17 @@
 // See ms_conv.hip for what it replaces in the reference and for the dispatch; this header is included by the
 // translation units that instantiate slices of the template (parallel compilation).
 //
-// Workgroup = 4 waves = one output tile (8x32 pixels, or 16x16 for small feature maps) x 16*NT output channels.
-// K loop over chunks of CK input channels:
-//     global --(16-B loads of an aligned window, issued back to back)--> registers   [prefetch of chunk i+1]
-//     registers --(BatchNorm apply / BatchNorm backward prologue)--> LDS               [chunk i]
-//     LDS --ds_read_b32 fragments--> MFMA 16x16x4 (A = 16 pixels x 4 channels, B = 4 channels x 16 couts)
-// The loads of chunk i+1 are in flight while chunk i is multiplied, so a workgroup hides its own HBM/L2 latency
-// even at one workgroup per CU (deep layers: few tiles, long K).
+// Persistent, wave-specialised workgroups (512 threads = 8 waves, 2 per SIMD):
+//   waves 4-7  PRODUCERS  global --16-B loads of an aligned window--> registers --BatchNorm apply / BatchNorm-backward
+//                         prologue--> LDS buffer (double buffered); they run one K-chunk ahead of the consumers
+//   waves 0-3  CONSUMERS  LDS --ds_read_b32 fragments (immediate offsets)--> MFMA 16x16x4; epilogue from registers:
+//                         +bias, per-wave BatchNorm statistics (count, mean, M2), 16-B stores
+// A work item is (image n, output tile 8x32 or 16x16 pixels, block of 16*NT output channels); a workgroup walks items
+// blockIdx.x, +gridDim.x, ... over the flattened (item, K-chunk) sequence with ONE workgroup barrier per chunk.
+// Why: measured on MI355X, a conventional "every wave stages, then every wave multiplies" loop left the matrix pipe 35 %
+// busy - the two waves of a SIMD run the same phase at the same time, so address arithmetic, prologue math and the epilogue
+// never overlap the MFMAs.  With roles split, each SIMD holds a VALU/memory wave and an MFMA wave, which do overlap
+// (separate pipes), and every global load has a full MFMA phase to land.
 #pragma once
 #include <algorithm>
 #include "ms_common.h"
@@ -27,9 +31,10 @@ struct ConvArgs {
   int N, Cin, Hs, Ws, Hin, Win, Cout, Hout, Wout, cin_pad, cout_pad;
   int pro_mode, pro_nstride, pro_cstride; float slope;
   int epi_mode, tiles_x, tiles_y, cout_real, ncb;   // ncb: number of output-channel blocks (of 16*NT)
+  int dbg;                      // timing-only ablation bits (MS_CONV_DBG): 1 skip MFMA loop, 2 skip global loads, 4 skip epilogue
 };
 
-template <int KS, int STRIDE, bool VEC, bool NARROW>
+template <int KS, int STRIDE, bool VEC, bool NARROW, int NT>
 struct Geo {
   static constexpr int TW = NARROW ? 16 : 32;
   static constexpr int TH = NARROW ? 16 : 8;
@@ -41,204 +46,236 @@ struct Geo {
   static constexpr int RS = (STRIDE == 1) ? ((WIN_W + 3) / 4 * 4) : 2 * HALF;
   static constexpr int BASE = IH * RS;
   static constexpr int PS = BASE + ((16 - BASE % 32 + 32) % 32);           // plane stride == 16 (mod 32 banks)
-  static constexpr int CK = (STRIDE == 1 && VEC) ? 16 : 8;   // scalar fallback stages 4x more slots per channel: halve the chunk
+  // input channels per K-chunk: sized so that two LDS buffers of (input tile + weight slice) leave >= 2 workgroups per CU
+  static constexpr int CK = (STRIDE == 1 && VEC && NT == 1) ? 16 : ((STRIDE == 2 && NT > 1) ? 4 : 8);
   static constexpr int VW = VEC ? 4 : 1;
   static constexpr int ROW_ITEMS = WIN_W / VW;                              // VEC: WIN_W % 4 == 0 by construction
   static constexpr int ITEMS = CK * IH * ROW_ITEMS;
   static constexpr int NI = (ITEMS + 255) / 256;
-  // LDS column of logical tap offset t = kx - PAD + PADL (added to the pixel's x inside the tile)
-  static constexpr int tap_col(int kx) {
+  static constexpr int WS = (NT == 1) ? 16 : NT * 16 + 16;                 // weight row stride (bank-conflict-free B fragments)
+  static constexpr int TAPS = KS * KS;
+  static constexpr int BUF = CK * PS + TAPS * CK * WS;                     // floats per LDS stage buffer
+  static constexpr int tap_off(int tap) {                                  // LDS offset of tap (ky,kx) relative to the pixel's slot
+    const int ky = tap / KS, kx = tap % KS;
     const int t = kx - PAD + PADL;
-    return (STRIDE == 1) ? t : ((t & 1) * HALF + (t >> 1));
+    return ky * RS + ((STRIDE == 1) ? t : ((t & 1) * HALF + (t >> 1)));
   }
 };
 
-template <int NT> struct WGeo { static constexpr int WS = (NT == 1) ? 16 : NT * 16 + 16; };
-
-// waves per SIMD the register budget is sized for (a workgroup is 4 waves = 1 per SIMD): 4 -> <=128 VGPRs, 3 -> <=168, 2 -> <=256
-template <int NT, bool IN2, int STRIDE> struct Occ { static constexpr int W = (NT == 1 && !IN2 && STRIDE == 1) ? 3 : 2; };
-
-// Persistent workgroups: work item = (image n, output tile, output-channel block); a workgroup walks items
-// blockIdx.x, blockIdx.x+gridDim.x, ... and software-pipelines over the flattened (item, K-chunk) sequence, so the
-// global loads of the NEXT tile/chunk are in flight while the current one is multiplied - the matrix pipe stays fed even
-// when all workgroups of a CU run in lock-step (measured: without this the MFMA pipe was 35 % busy, waves 55 % issue-stalled).
 template <int KS, int STRIDE, int FETCH, int NT, bool VEC, bool NARROW, bool IN2>
-__global__ __launch_bounds__(256, (Occ<NT, IN2, STRIDE>::W)) void conv_mfma_kernel(const ConvArgs a) {
-  using G = Geo<KS, STRIDE, VEC, NARROW>;
+__global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const ConvArgs a) {
+  using G = Geo<KS, STRIDE, VEC, NARROW, NT>;
   constexpr int CK = G::CK, PS = G::PS, RS = G::RS, IH = G::IH, PAD = G::PAD, PADL = G::PADL, HALF = G::HALF;
   constexpr int TW = G::TW, TH = G::TH, VW = G::VW, ROW_ITEMS = G::ROW_ITEMS, ITEMS = G::ITEMS, NI = G::NI;
-  constexpr int WS = WGeo<NT>::WS;
-  constexpr int TAPS = KS * KS;
+  constexpr int WS = G::WS, TAPS = G::TAPS, BUF = G::BUF;
   constexpr int COUT_TILE = 16 * NT;
   constexpr int WITEMS = TAPS * CK * (COUT_TILE / 4);
   constexpr int NWI = (WITEMS + 255) / 256;
   static_assert(!VEC || FETCH == FETCH_NORMAL, "vector staging needs the plain fetch");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* in_lds = smem;                 // [CK][PS]
-  float* w_lds = smem + CK * PS;        // [TAPS][CK][WS]
+  // smem: [2][BUF] stage buffers (input tile [CK][PS] then weights [TAPS][CK][WS]) | [cin_pad][4] prologue coefficients
+  float* cf_lds = smem + 2 * BUF;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = lane & 15, k = lane >> 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool producer = wave >= 4;                       // wave-uniform role
   const int ntiles = a.tiles_x * a.tiles_y;
   const int ncb = a.ncb;
   const int nitems = a.N * ntiles * ncb;
   const int nchunks = (a.cin_pad + CK - 1) / CK;
-  const size_t in_plane = (size_t)a.Hs * a.Ws;
+  const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1 (grid <= nitems)
+  const int T = my_items * nchunks;                       // (item, chunk) iterations of this workgroup
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };   // orders LDS only (no vmcnt drain)
+  auto decode = [&](int it, int& n, int& tile, int& cb) { cb = it % ncb; const int t2 = it / ncb; tile = t2 % ntiles; n = t2 / ntiles; };
 
+  // per-channel prologue coefficients are constant for the whole launch: stage them once (per-plane mode reads global memory)
+  if (a.pro_mode != 0 && a.pro_nstride == 0) {
+    for (int c = threadIdx.x; c < a.cin_pad; c += 512) {
+      float ca = 1.f, cb_ = 0.f, cc = 0.f;
+      if (c < a.Cin) { ca = a.pro_a[c * a.pro_cstride]; cb_ = a.pro_b[c * a.pro_cstride]; if (a.pro_mode == 2) cc = a.pro_c[c * a.pro_cstride]; }
+      cf_lds[c * 4] = ca; cf_lds[c * 4 + 1] = cb_; cf_lds[c * 4 + 2] = cc;
+    }
+  }
+
+  if (producer) {
+    // =========================================== PRODUCER waves ===========================================
+    const int tid = threadIdx.x - 256;
+    const size_t in_plane = (size_t)a.Hs * a.Ws;
+    int s_lds[NI];        // (channel-in-chunk << 20) | LDS float offset of the slot, or -1: no slot   (tile independent)
+    int s_rw[NI];         // (window row << 16) | window column
+    int s_goff[NI];       // global offset inside one channel plane (or -1: outside the image -> zeros)  (per tile)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int it = tid + j * 256;
+      s_lds[j] = -1; s_rw[j] = 0; s_goff[j] = -1;
+      if (it < ITEMS) {
+        const int f = it % ROW_ITEMS;
+        const int row = it / ROW_ITEMS;
+        const int r = row % IH, c = row / IH;
+        const int w = f * VW;
+        const int q = (STRIDE == 1) ? w : ((w & 1) * HALF + (w >> 1));
+        s_lds[j] = (c << 20) | (c * PS + r * RS + q);
+        s_rw[j] = (r << 16) | w;
+      }
+    }
+    auto set_tile = [&](int tile) {
+      const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+      const int iy0 = ty * TH * STRIDE - PAD;
+      const int wx0 = tx * TW * STRIDE - PADL;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int Y = iy0 + (s_rw[j] >> 16), X = wx0 + (s_rw[j] & 0xFFFF);
+        bool ok = (s_lds[j] >= 0) && (Y >= 0) && (Y < a.Hin) && (X >= 0) && (X < a.Win);
+        int ys = Y, xs = X;
+        if (FETCH == FETCH_UPS2) { ys = Y >> 1; xs = X >> 1; }
+        if (FETCH == FETCH_ZINS2) { ok = ok && !((Y | X) & 1); ys = Y >> 1; xs = X >> 1; }
+        s_goff[j] = ok ? (ys * a.Ws + xs) : -1;
+      }
+    };
+    float rin[NI][VW];
+    float rin2[IN2 ? NI : 1][VW];
+    float4 rw[NWI];
+    unsigned okmask = 0;          // bit j: slot j of the chunk held in registers lies inside the image
+    bool have_w = false;          // rw holds a weight slice that must be written to LDS
+
+    auto load_chunk = [&](int n, int co0, int c0, bool load_w) {
+      const float* in_n = a.in + (size_t)n * a.Cin * in_plane;
+      okmask = 0;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int ci = c0 + (s_lds[j] >> 20);
+        const bool ok = (s_lds[j] >= 0) && (s_goff[j] >= 0) && (ci < a.Cin);
+        okmask |= (ok ? 1u : 0u) << j;
+        const bool ld = ok && !(a.dbg & 2);
+        const size_t off = ld ? ((size_t)ci * in_plane + (size_t)s_goff[j]) : 0;
+        if constexpr (VEC) {
+          const float4 v = ld ? *reinterpret_cast<const float4*>(in_n + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          rin[j][0] = v.x; rin[j][1] = v.y; rin[j][2] = v.z; rin[j][3] = v.w;
+          if constexpr (IN2) {
+            const float* in2_n = a.in2 + (size_t)n * a.Cin * in_plane;
+            const float4 u = ld ? *reinterpret_cast<const float4*>(in2_n + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rin2[j][0] = u.x; rin2[j][1] = u.y; rin2[j][2] = u.z; rin2[j][3] = u.w;
+          }
+        } else {
+          rin[j][0] = ld ? in_n[off] : 0.f;
+          if constexpr (IN2) { const float* in2_n = a.in2 + (size_t)n * a.Cin * in_plane; rin2[j][0] = ld ? in2_n[off] : 0.f; }
+        }
+      }
+      have_w = load_w;
+      if (load_w) {
+#pragma unroll
+        for (int j = 0; j < NWI; ++j) {
+          const int idx = tid + j * 256;
+          const int j4 = idx % (COUT_TILE / 4);
+          const int row = idx / (COUT_TILE / 4);      // tap*CK + c
+          const int c = row % CK, tap = row / CK;
+          rw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (idx < WITEMS && c0 + c < a.cin_pad)
+            rw[j] = *reinterpret_cast<const float4*>(a.w + ((size_t)tap * a.cin_pad + c0 + c) * a.cout_pad + co0 + j4 * 4);
+        }
+      }
+    };
+
+    auto store_chunk = [&](float* buf, int n, int c0) {
+      float* in_lds = buf;
+      float* w_lds = buf + CK * PS;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if (s_lds[j] < 0) continue;
+        const int ci = c0 + (s_lds[j] >> 20);
+        float v[VW];
+#pragma unroll
+        for (int e = 0; e < VW; ++e) v[e] = rin[j][e];
+        if ((okmask >> j) & 1u) {
+          if (a.pro_mode == 1) {
+            float pa, pb;
+            if (a.pro_nstride == 0) { pa = cf_lds[ci * 4]; pb = cf_lds[ci * 4 + 1]; }
+            else { const int pi = (n * a.pro_nstride + ci) * a.pro_cstride; pa = a.pro_a[pi]; pb = a.pro_b[pi]; }
+#pragma unroll
+            for (int e = 0; e < VW; ++e) v[e] = leaky(pa * v[e] + pb, a.slope);
+          } else if constexpr (IN2) {
+            if (a.pro_mode == 2) {
+              const float pa = cf_lds[ci * 4], pb = cf_lds[ci * 4 + 1], pc = cf_lds[ci * 4 + 2];
+#pragma unroll
+              for (int e = 0; e < VW; ++e) v[e] = pa * v[e] + pb * rin2[j][e] + pc;
+            }
+          }
+        }
+        float* dst = in_lds + (s_lds[j] & 0xFFFFF);
+        if constexpr (VEC) {
+          if constexpr (STRIDE == 1) {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {          // de-interleave even / odd columns (w % 4 == 0 -> even half at dst, odd half at dst+HALF)
+            *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[2]);
+            *reinterpret_cast<float2*>(dst + HALF) = make_float2(v[1], v[3]);
+          }
+        } else {
+          dst[0] = v[0];
+        }
+      }
+      if (have_w) {
+#pragma unroll
+        for (int j = 0; j < NWI; ++j) {
+          const int idx = tid + j * 256;
+          if (idx < WITEMS) {
+            const int j4 = idx % (COUT_TILE / 4);
+            const int row = idx / (COUT_TILE / 4);
+            *reinterpret_cast<float4*>(w_lds + row * WS + j4 * 4) = rw[j];
+          }
+        }
+      }
+    };
+
+    // iteration p (chunk index in this workgroup's sequence): registers hold chunk p; written to buffer p&1.
+    // key_*[b]: which weight slice (cb, c0) buffer b holds -> skip the rewrite when it repeats (single-chunk layers)
+    int key_cb[2] = {-1, -1}, key_c0[2] = {-1, -1};
+    int item = blockIdx.x, chunk = 0, n, tile, cb, tile_set = -1;
+    decode(item, n, tile, cb);
+    set_tile(tile); tile_set = tile;
+    load_chunk(n, cb * COUT_TILE, 0, true);
+    lds_barrier();                                    // barrier #0: coefficient table visible (matched by the consumers)
+    for (int p = 0; p < T; ++p) {
+      // write chunk p (in registers) into buffer p&1; the consumers read buffer (p-1)&1 meanwhile
+      store_chunk(smem + (p & 1) * BUF, n, chunk * CK);
+      key_cb[p & 1] = cb; key_c0[p & 1] = chunk * CK;
+      // advance to chunk p+1 and issue its loads
+      if (p + 1 < T) {
+        if (++chunk == nchunks) { chunk = 0; item += gridDim.x; decode(item, n, tile, cb); }
+        if (tile != tile_set) { set_tile(tile); tile_set = tile; }
+        const int b = (p + 1) & 1;
+        load_chunk(n, cb * COUT_TILE, chunk * CK, !(key_cb[b] == cb && key_c0[b] == chunk * CK));
+      }
+      lds_barrier();                                  // barrier #(p+1): chunk p visible; consumers done with chunk p-1
+    }
+    return;
+  }
+
+  // =========================================== CONSUMER waves ===========================================
+  const int m = lane & 15, k = lane >> 4;
   f32x4 acc[4][NT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // ---- per-thread staging slots of the item being LOADED: slot -> (channel c, row r, window column w) ----
-  int s_lds[NI];        // (channel-in-chunk << 20) | LDS float offset of the slot, or -1: no slot   (tile independent)
-  int s_goff[NI];       // global offset inside one channel plane (or -1: out of the image -> zeros)  (per tile)
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int item = tid + j * 256;
-    s_lds[j] = -1;
-    if (item < ITEMS) {
-      const int f = item % ROW_ITEMS;
-      const int row = item / ROW_ITEMS;
-      const int r = row % IH, c = row / IH;
-      const int w = f * VW;
-      const int q = (STRIDE == 1) ? w : ((w & 1) * HALF + (w >> 1));
-      s_lds[j] = (c << 20) | (c * PS + r * RS + q);
-    }
-  }
-  auto set_tile = [&](int tile) {          // recompute the global offsets of the slots for a new output tile
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const int iy0 = ty * TH * STRIDE - PAD;
-    const int wx0 = tx * TW * STRIDE - PADL;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int item = tid + j * 256;
-      const int f = item % ROW_ITEMS;
-      const int r = (item / ROW_ITEMS) % IH;
-      const int Y = iy0 + r, X = wx0 + f * VW;
-      bool ok = (item < ITEMS) && (Y >= 0) && (Y < a.Hin) && (X >= 0) && (X < a.Win);
-      int ys = Y, xs = X;
-      if (FETCH == FETCH_UPS2) { ys = Y >> 1; xs = X >> 1; }
-      if (FETCH == FETCH_ZINS2) { ok = ok && !((Y | X) & 1); ys = Y >> 1; xs = X >> 1; }
-      s_goff[j] = ok ? (ys * a.Ws + xs) : -1;
-    }
-  };
-
-  float rin[NI][VW];
-  float rin2[IN2 ? NI : 1][VW];
-  float4 rw[NWI];
-
-  auto load_chunk = [&](int n, int co0, int c0, bool load_w) {
-    const float* in_n = a.in + (size_t)n * a.Cin * in_plane;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int ci = c0 + (s_lds[j] >> 20);
-      const bool ok = (s_lds[j] >= 0) && (s_goff[j] >= 0) && (ci < a.Cin);
-      const size_t off = ok ? ((size_t)ci * in_plane + (size_t)s_goff[j]) : 0;
-      if constexpr (VEC) {
-        const float4 v = ok ? *reinterpret_cast<const float4*>(in_n + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-        rin[j][0] = v.x; rin[j][1] = v.y; rin[j][2] = v.z; rin[j][3] = v.w;
-        if constexpr (IN2) {
-          const float* in2_n = a.in2 + (size_t)n * a.Cin * in_plane;
-          const float4 u = ok ? *reinterpret_cast<const float4*>(in2_n + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-          rin2[j][0] = u.x; rin2[j][1] = u.y; rin2[j][2] = u.z; rin2[j][3] = u.w;
-        }
-      } else {
-        rin[j][0] = ok ? in_n[off] : 0.f;
-        if constexpr (IN2) { const float* in2_n = a.in2 + (size_t)n * a.Cin * in_plane; rin2[j][0] = ok ? in2_n[off] : 0.f; }
-      }
-    }
-    if (load_w) {
-#pragma unroll
-      for (int j = 0; j < NWI; ++j) {
-        const int idx = tid + j * 256;
-        const int j4 = idx % (COUT_TILE / 4);
-        const int row = idx / (COUT_TILE / 4);      // tap*CK + c
-        const int c = row % CK, tap = row / CK;
-        rw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < WITEMS && c0 + c < a.cin_pad)
-          rw[j] = *reinterpret_cast<const float4*>(a.w + ((size_t)tap * a.cin_pad + c0 + c) * a.cout_pad + co0 + j4 * 4);
-      }
-    }
-  };
-
-  // s_ok bit j: slot j of the chunk held in registers was inside the image (its prologue must be applied)
-  auto store_chunk = [&](int n, int c0, unsigned okmask, bool store_w) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      if (s_lds[j] < 0) continue;
-      const int ci = c0 + (s_lds[j] >> 20);
-      const bool ok = ((okmask >> j) & 1u) && (ci < a.Cin);
-      float v[VW];
-#pragma unroll
-      for (int e = 0; e < VW; ++e) v[e] = rin[j][e];
-      if (ok) {
-        if (a.pro_mode == 1) {
-          const int pi = (n * a.pro_nstride + ci) * a.pro_cstride;
-          const float pa = a.pro_a[pi], pb = a.pro_b[pi];
-#pragma unroll
-          for (int e = 0; e < VW; ++e) v[e] = leaky(pa * v[e] + pb, a.slope);
-        } else if constexpr (IN2) {
-          if (a.pro_mode == 2) {
-            const int pi = ci * a.pro_cstride;
-            const float pa = a.pro_a[pi], pb = a.pro_b[pi], pc = a.pro_c[pi];
-#pragma unroll
-            for (int e = 0; e < VW; ++e) v[e] = pa * v[e] + pb * rin2[j][e] + pc;
-          }
-        }
-      }
-      float* dst = in_lds + (s_lds[j] & 0xFFFFF);
-      if constexpr (VEC) {
-        if constexpr (STRIDE == 1) {
-          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {          // de-interleave even / odd columns (w % 4 == 0 -> even half at dst, odd half at dst+HALF)
-          *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[2]);
-          *reinterpret_cast<float2*>(dst + HALF) = make_float2(v[1], v[3]);
-        }
-      } else {
-        dst[0] = v[0];
-      }
-    }
-    if (store_w) {
-#pragma unroll
-      for (int j = 0; j < NWI; ++j) {
-        const int idx = tid + j * 256;
-        if (idx < WITEMS) {
-          const int j4 = idx % (COUT_TILE / 4);
-          const int row = idx / (COUT_TILE / 4);
-          *reinterpret_cast<float4*>(w_lds + row * WS + j4 * 4) = rw[j];
-        }
-      }
-    }
-  };
-  auto okmask_now = [&]() { unsigned mk = 0; 
-#pragma unroll
-    for (int j = 0; j < NI; ++j) mk |= (s_goff[j] >= 0 ? 1u : 0u) << j;
-    return mk; };
-
   // M-tile i of this wave: NARROW: rows 4*wave+i, columns 0..15; else rows 2*wave+(i>>1), columns (i&1)*16..
-  const int a_lane = k * PS + m;
+  const int a_lane = k * PS + m + (NARROW ? wave * 4 : wave * 2) * STRIDE * RS;     // all per-MFMA offsets below are immediates
   const int b_lane = k * WS + m;
   auto mt_row = [&](int i) { return NARROW ? (wave * 4 + i) : (wave * 2 + (i >> 1)); };
   auto mt_col = [&](int i) { return NARROW ? 0 : ((i & 1) * 16); };
 
-  auto compute = [&](int ncg) {
-#pragma unroll 1
+  auto compute = [&](const float* buf, int ncg) {
+    const float* ap = buf + a_lane;
+    const float* bp = buf + CK * PS + b_lane;
+#pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
-      const int ky = tap / KS, kx = tap - ky * KS;
-      const int t = kx - PAD + PADL;
-      const int tap_off = ky * RS + ((STRIDE == 1) ? t : ((t & 1) * HALF + (t >> 1)));
-      const float* ap = in_lds + a_lane + tap_off;
-      const float* bp = w_lds + b_lane + tap * CK * WS;
 #pragma unroll
       for (int cg = 0; cg < CK / 4; ++cg) {
         if (cg < ncg) {
           float bf[NT], af[4];
 #pragma unroll
-          for (int j = 0; j < NT; ++j) bf[j] = bp[cg * 4 * WS + j * 16];
+          for (int j = 0; j < NT; ++j) bf[j] = bp[(tap * CK + cg * 4) * WS + j * 16];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) af[i] = ap[cg * 4 * PS + mt_row(i) * STRIDE * RS + mt_col(i)];
+          for (int i = 0; i < 4; ++i)
+            af[i] = ap[cg * 4 * PS + G::tap_off(tap) + (NARROW ? i : (i >> 1)) * STRIDE * RS + (NARROW ? 0 : (i & 1) * 16)];
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -248,7 +285,7 @@ __global__ __launch_bounds__(256, (Occ<NT, IN2, STRIDE>::W)) void conv_mfma_kern
     }
   };
 
-  // ---- epilogue of one finished item (registers only + global stores; no LDS, no barriers) ----
+  // ---- epilogue of one finished item (registers + global stores only) ----
   auto epilogue = [&](int n, int tile, int co0) {
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW;
@@ -264,21 +301,17 @@ __global__ __launch_bounds__(256, (Occ<NT, IN2, STRIDE>::W)) void conv_mfma_kern
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] += bv;
     }
+    const bool full = (oy0 + TH <= a.Hout) && (ox0 + TW <= a.Wout);     // no masking needed (wave-uniform)
     if (a.stats != nullptr) {
-      // per-WAVE (count, mean, M2) of this wave's pixels for each output channel: two passes over registers,
-      // cross-lane combine of the 4 lane groups that share a channel (xor 16, 32). Partials: [co][(n*ntiles+tile)*4 + wave]
-      int rows_ok = 0, cols_ok[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { cols_ok[i] = 0; }
+      // per-WAVE (count, mean, M2) of this wave's pixels per output channel: two passes over registers, cross-lane combine
+      // of the 4 lane groups that share a channel (xor 16, 32).  Partials: [co][(n*ntiles+tile)*4 + wave]
       float cnt = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int y = oy0 + mt_row(i);
-        const int x0 = ox0 + mt_col(i);
-        const int nx = min(16, a.Wout - x0);
+        const int nx = min(16, a.Wout - (ox0 + mt_col(i)));
         if (y < a.Hout && nx > 0) cnt += (float)nx;
       }
-      (void)rows_ok; (void)cols_ok;
       const int nparts = a.N * ntiles * 4;
       const int pidx = (n * ntiles + tile) * 4 + wave;
 #pragma unroll
@@ -290,7 +323,7 @@ __global__ __launch_bounds__(256, (Occ<NT, IN2, STRIDE>::W)) void conv_mfma_kern
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int x = ox0 + mt_col(i) + xq + r;
-            s += ((y < a.Hout) && (x < a.Wout)) ? acc[i][j][r] : 0.f;
+            s += (full || ((y < a.Hout) && (x < a.Wout))) ? acc[i][j][r] : 0.f;
           }
         }
         s += __shfl_xor(s, 16, 64);
@@ -304,7 +337,7 @@ __global__ __launch_bounds__(256, (Occ<NT, IN2, STRIDE>::W)) void conv_mfma_kern
           for (int r = 0; r < 4; ++r) {
             const int x = ox0 + mt_col(i) + xq + r;
             const float d = acc[i][j][r] - mean;
-            q += ((y < a.Hout) && (x < a.Wout)) ? d * d : 0.f;
+            q += (full || ((y < a.Hout) && (x < a.Wout))) ? d * d : 0.f;
           }
         }
         q += __shfl_xor(q, 16, 64);
@@ -334,8 +367,22 @@ __global__ __launch_bounds__(256, (Occ<NT, IN2, STRIDE>::W)) void conv_mfma_kern
           }
         }
       }
+    } else if (full && (a.Wout % 4 == 0)) {
+      // fast path: whole tile inside the image, 16-B stores, no per-element predicates
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = co0 + j * 16 + m;
+        if (co >= a.Cout) continue;
+        float* op = a.out + (((size_t)n * a.Cout + co) * a.Hout + oy0) * a.Wout + ox0 + xq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float* o = op + (size_t)mt_row(i) * a.Wout + mt_col(i);
+          float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          if (a.epi_mode == 1) { const float4 p = *reinterpret_cast<const float4*>(o); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+          *reinterpret_cast<float4*>(o) = v;
+        }
+      }
     } else {
-      const bool vec_ok = (a.Wout % 4 == 0);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int co = co0 + j * 16 + m;
@@ -347,15 +394,9 @@ __global__ __launch_bounds__(256, (Occ<NT, IN2, STRIDE>::W)) void conv_mfma_kern
           if (y >= a.Hout) continue;
           const int x = ox0 + mt_col(i) + xq;
           float* o = op + (size_t)y * a.Wout + x;
-          if (vec_ok && x + 3 < a.Wout) {
-            float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            if (a.epi_mode == 1) { const float4 p = *reinterpret_cast<const float4*>(o); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
-            *reinterpret_cast<float4*>(o) = v;
-          } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (x + r < a.Wout) o[r] = (a.epi_mode == 1) ? (o[r] + acc[i][j][r]) : acc[i][j][r];
-          }
+          for (int r = 0; r < 4; ++r)
+            if (x + r < a.Wout) o[r] = (a.epi_mode == 1) ? (o[r] + acc[i][j][r]) : acc[i][j][r];
         }
       }
     }
@@ -365,57 +406,40 @@ __global__ __launch_bounds__(256, (Occ<NT, IN2, STRIDE>::W)) void conv_mfma_kern
       for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  // ---- pipelined walk over (item, chunk) ----
-  int item = blockIdx.x;
-  if (item >= nitems) return;
-  auto decode = [&](int it, int& n, int& tile, int& cb) { cb = it % ncb; const int t2 = it / ncb; tile = t2 % ntiles; n = t2 / ntiles; };
-  int n_cur, tile_cur, cb_cur;
-  decode(item, n_cur, tile_cur, cb_cur);
-  set_tile(tile_cur);
-  unsigned ok_ld = okmask_now();
-  load_chunk(n_cur, cb_cur * COUT_TILE, 0, true);
-  int lds_w_cb = -1, lds_w_c0 = -1;      // which weight slice w_lds currently holds
-  int chunk = 0;
-  while (true) {
+  int item = blockIdx.x, chunk = 0, n, tile, cb;
+  decode(item, n, tile, cb);
+  lds_barrier();                                      // barrier #0
+  lds_barrier();                                      // barrier #1: chunk 0 is in buffer 0
+  for (int p = 0; p < T; ++p) {
     const int c0 = chunk * CK;
-    const bool w_fresh = !(lds_w_cb == cb_cur && lds_w_c0 == c0);
-    __syncthreads();                       // every wave finished multiplying the previous chunk
-    store_chunk(n_cur, c0, ok_ld, w_fresh);
-    lds_w_cb = cb_cur; lds_w_c0 = c0;
-    __syncthreads();
-    // what comes next: another chunk of this item, or the first chunk of this workgroup's next item
-    int n_nx = n_cur, tile_nx = tile_cur, cb_nx = cb_cur, chunk_nx = chunk + 1, item_nx = item;
-    if (chunk_nx == nchunks) { chunk_nx = 0; item_nx = item + gridDim.x; if (item_nx < nitems) decode(item_nx, n_nx, tile_nx, cb_nx); }
-    const bool have_next = item_nx < nitems;
-    if (have_next) {
-      if (tile_nx != tile_cur) set_tile(tile_nx);
-      ok_ld = okmask_now();
-      const bool w_needed = !(cb_nx == cb_cur && chunk_nx * CK == c0);
-      load_chunk(n_nx, cb_nx * COUT_TILE, chunk_nx * CK, w_needed);      // in flight while this chunk is multiplied
-    }
     const int ncg = min(CK / 4, (a.cin_pad - c0) / 4);
-    if (ncg == CK / 4) compute(CK / 4); else compute(ncg);
-    if (chunk + 1 == nchunks) epilogue(n_cur, tile_cur, cb_cur * COUT_TILE);
-    if (!have_next) break;
-    item = item_nx; n_cur = n_nx; tile_cur = tile_nx; cb_cur = cb_nx; chunk = chunk_nx;
+    if (!(a.dbg & 1)) { if (ncg == CK / 4) compute(smem + (p & 1) * BUF, CK / 4); else compute(smem + (p & 1) * BUF, ncg); }
+    if (chunk + 1 == nchunks) {
+      if (!(a.dbg & 4)) epilogue(n, tile, cb * COUT_TILE);
+      chunk = 0; item += gridDim.x;
+      if (p + 1 < T) decode(item, n, tile, cb);
+    } else {
+      ++chunk;
+    }
+    if (p + 1 < T) lds_barrier();                     // barrier #(p+2): chunk p+1 visible; this wave is done with chunk p
   }
 }
 
 template <int KS, int STRIDE, int FETCH, int NT, bool VEC, bool NARROW, bool IN2>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
-  using G = Geo<KS, STRIDE, VEC, NARROW>;
-  constexpr int lds_floats = G::CK * G::PS + KS * KS * G::CK * WGeo<NT>::WS;
-  constexpr size_t lds_bytes = sizeof(float) * lds_floats;
+  using G = Geo<KS, STRIDE, VEC, NARROW, NT>;
+  const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * (size_t)a.cin_pad);
+  if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
   static bool attr_set = false;
-  if (!attr_set && lds_bytes > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     attr_set = true;
   }
   const long nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb;
-  // resident workgroups per CU: limited by the register budget (Occ) and LDS (160 KiB per CU)
-  const int per_cu = std::max(1, std::min(Occ<NT, IN2, STRIDE>::W, (int)((160 * 1024) / (lds_bytes + 512))));
+  // resident workgroups per CU: 512 threads = 2 waves per SIMD each -> at most 2 within 256 registers per wave; LDS 160 KiB per CU
+  const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));
   const long nblocks = std::min<long>(nitems, (long)kNumCU * per_cu);
-  dim3 grid((unsigned)nblocks), block(256);
+  dim3 grid((unsigned)nblocks), block(512);
   hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2>), grid, block, lds_bytes, st, a);
   return check_launch("conv_mfma");
 }
