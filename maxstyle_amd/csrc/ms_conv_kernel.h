@@ -15,6 +15,7 @@
 // (separate pipes), and every global load has a full MFMA phase to land.
 #pragma once
 #include <algorithm>
+#include <type_traits>
 #include "ms_common.h"
 
 namespace ms {
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   }
 
   // =========================================== CONSUMER waves ===========================================
+  __builtin_amdgcn_s_setprio(2);       // the MFMA-issuing wave wins issue arbitration against the staging wave of its SIMD
   const int m = lane & 15, k = lane >> 4;
   f32x4 acc[4][NT];
 #pragma unroll
@@ -262,14 +264,17 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   auto mt_row = [&](int i) { return NARROW ? (wave * 4 + i) : (wave * 2 + (i >> 1)); };
   auto mt_col = [&](int i) { return NARROW ? 0 : ((i & 1) * 16); };
 
-  auto compute = [&](const float* buf, int ncg) {
+  // FULL = every channel group of the chunk is live: straight-line code (no guards), so the LDS reads of later steps are
+  // issued ahead of the MFMAs that consume earlier ones; the guarded form only runs for a layer's ragged last chunk.
+  auto compute = [&](const float* buf, auto full_tag, int ncg) {
+    constexpr bool FULL = decltype(full_tag)::value;
     const float* ap = buf + a_lane;
     const float* bp = buf + CK * PS + b_lane;
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
 #pragma unroll
       for (int cg = 0; cg < CK / 4; ++cg) {
-        if (cg < ncg) {
+        if (FULL || cg < ncg) {
           float bf[NT], af[4];
 #pragma unroll
           for (int j = 0; j < NT; ++j) bf[j] = bp[(tap * CK + cg * 4) * WS + j * 16];
@@ -286,21 +291,31 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   };
 
   // ---- epilogue of one finished item (registers + global stores only) ----
-  auto epilogue = [&](int n, int tile, int co0) {
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int xq = 4 * k;     // D layout (16x16): column (output channel) = lane&15, rows (pixels) = 4*(lane>>4) + reg
+  // bias of this lane's output channels, re-read only when the channel block changes (a global load inside the epilogue
+  // would expose a full L2 round trip per item on the MFMA wave's critical path)
+  float bias_v[NT];
+  int bias_co0 = -1;
+  auto load_bias = [&](int co0) {
+    if (co0 == bias_co0) return;
+    bias_co0 = co0;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int co = co0 + j * 16 + m;
       int bidx = co;
       if (a.epi_mode == 2) bidx = co % a.cout_real;
-      const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[bidx] : 0.f;
+      bias_v[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[bidx] : 0.f;
+    }
+  };
+  auto epilogue = [&](int n, int tile, int co0) {
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int xq = 4 * k;     // D layout (16x16): column (output channel) = lane&15, rows (pixels) = 4*(lane>>4) + reg
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] += bv;
-    }
+        for (int r = 0; r < 4; ++r) acc[i][j][r] += bias_v[j];
     const bool full = (oy0 + TH <= a.Hout) && (ox0 + TW <= a.Wout);     // no masking needed (wave-uniform)
     if (a.stats != nullptr) {
       // per-WAVE (count, mean, M2) of this wave's pixels per output channel: two passes over registers, cross-lane combine
@@ -408,16 +423,20 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
 
   int item = blockIdx.x, chunk = 0, n, tile, cb;
   decode(item, n, tile, cb);
+  load_bias(cb * COUT_TILE);
   lds_barrier();                                      // barrier #0
   lds_barrier();                                      // barrier #1: chunk 0 is in buffer 0
   for (int p = 0; p < T; ++p) {
     const int c0 = chunk * CK;
     const int ncg = min(CK / 4, (a.cin_pad - c0) / 4);
-    if (!(a.dbg & 1)) { if (ncg == CK / 4) compute(smem + (p & 1) * BUF, CK / 4); else compute(smem + (p & 1) * BUF, ncg); }
+    if (!(a.dbg & 1)) {
+      if (ncg == CK / 4) compute(smem + (p & 1) * BUF, std::true_type{}, CK / 4);
+      else compute(smem + (p & 1) * BUF, std::false_type{}, ncg);
+    }
     if (chunk + 1 == nchunks) {
       if (!(a.dbg & 4)) epilogue(n, tile, cb * COUT_TILE);
       chunk = 0; item += gridDim.x;
-      if (p + 1 < T) decode(item, n, tile, cb);
+      if (p + 1 < T) { decode(item, n, tile, cb); load_bias(cb * COUT_TILE); }
     } else {
       ++chunk;
     }
