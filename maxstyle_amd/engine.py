@@ -74,19 +74,39 @@ class ConvW:
 
 
 class BNW:
+    """BatchNorm2d parameters; coef_eval/bcoef_eval are the eval-mode (running statistics) forward/backward coefficients."""
+
     def __init__(self, sd, name):
         self.gamma = sd[name + ".weight"].detach().float().contiguous()
         self.beta = sd[name + ".bias"].detach().float().contiguous()
+        self.name = name
+        rm, rv = sd.get(name + ".running_mean"), sd.get(name + ".running_var")
+        self.coef_eval = self.bcoef_eval = None
+        if rm is not None and rv is not None:
+            invstd = torch.rsqrt(rv.detach().float() + BN_EPS)
+            sc = self.gamma * invstd
+            self.coef_eval = torch.stack([sc, self.beta - rm.detach().float() * sc, rm.detach().float(), invstd], dim=1).contiguous()
+            self.bcoef_eval = torch.stack([sc, torch.zeros_like(sc), torch.zeros_like(sc), torch.zeros_like(sc)], dim=1).contiguous()
 
 
 class PackedNets:
     """Device-resident, kernel-layout copies of the three sub-nets' frozen parameters (state_dict key layout of the
     reference: SURVEY.md A.6, so reference checkpoints load unchanged)."""
 
-    def __init__(self, spec: NetSpec, enc_sd, seg_sd, dec_sd):
+    def __init__(self, spec: NetSpec, enc_sd=None, seg_sd=None, dec_sd=None):
         self.spec = spec
         g = "general_encoder."
         cv = lambda sd, n, kind="conv": ConvW(sd[n + ".weight"], sd.get(n + ".bias"), kind)
+        self.enc = self.seg = self.dec = None
+        if enc_sd is not None:
+            self.enc = self._pack_encoder(enc_sd, g, cv)
+        if seg_sd is not None:
+            self.seg = self._pack_decoder(seg_sd, False, cv)
+        if dec_sd is not None:
+            self.dec = self._pack_decoder(dec_sd, True, cv)
+
+    @staticmethod
+    def _pack_encoder(enc_sd, g, cv):
         e = {}
         e["inc0"] = cv(enc_sd, g + "inc.0"); e["inc1"] = BNW(enc_sd, g + "inc.1")
         e["inc3"] = cv(enc_sd, g + "inc.3"); e["inc4"] = BNW(enc_sd, g + "inc.4")
@@ -99,23 +119,22 @@ class PackedNets:
         e["fc0"] = cv(enc_sd, g + "final_conv.0"); e["fc1"] = BNW(enc_sd, g + "final_conv.1")
         e["cd0"] = cv(enc_sd, "code_decoupler.0"); e["cd1"] = BNW(enc_sd, "code_decoupler.1")
         e["cd3"] = cv(enc_sd, "code_decoupler.3"); e["cd4"] = BNW(enc_sd, "code_decoupler.4")
-        self.enc = e
+        return e
 
-        def dec(sd, conv_t):
-            d = {}
-            for i in range(1, 5):
-                p = f"up{i}."
-                if conv_t:
-                    d[f"u{i}.up"] = cv(sd, p + "up", "convT")
-                d[f"u{i}.c0"] = cv(sd, p + "conv.0"); d[f"u{i}.bn1"] = BNW(sd, p + "conv.1")
-                d[f"u{i}.c3"] = cv(sd, p + "conv.3"); d[f"u{i}.bn4"] = BNW(sd, p + "conv.4")
-                d[f"u{i}.ci"] = cv(sd, p + "conv_input")
-            w = sd["final_conv.weight"].detach().float()
-            d["head.w"] = w.reshape(w.shape[0], w.shape[1]).contiguous()
-            d["head.b"] = sd["final_conv.bias"].detach().float().contiguous()
-            return d
-        self.seg = dec(seg_sd, False)
-        self.dec = dec(dec_sd, True)
+    @staticmethod
+    def _pack_decoder(sd, conv_t, cv):
+        d = {}
+        for i in range(1, 5):
+            p = f"up{i}."
+            if conv_t:
+                d[f"u{i}.up"] = cv(sd, p + "up", "convT")
+            d[f"u{i}.c0"] = cv(sd, p + "conv.0"); d[f"u{i}.bn1"] = BNW(sd, p + "conv.1")
+            d[f"u{i}.c3"] = cv(sd, p + "conv.3"); d[f"u{i}.bn4"] = BNW(sd, p + "conv.4")
+            d[f"u{i}.ci"] = cv(sd, p + "conv_input")
+        w = sd["final_conv.weight"].detach().float()
+        d["head.w"] = w.reshape(w.shape[0], w.shape[1]).contiguous()
+        d["head.b"] = sd["final_conv.bias"].detach().float().contiguous()
+        return d
 
 
 class StyleSlot:
@@ -148,6 +167,9 @@ class InnerLoopEngine:
         self._prefix_valid = False
         self.labels = None
         self.code = None
+        self.bn_eval = False          # True: BatchNorm uses running statistics (module.eval()); False: batch statistics
+        self.bn_observer = None       # optional callback(bn: BNW, coef4, count) - running-statistics update of a tracking forward
+        self.loss_sign = -1.0         # loss = loss_sign * cross_entropy_2D  (the inner loop maximises CE)
 
     # ------------------------------------------------------------------ buffers
     def t(self, name, *shape, dtype=F32):
@@ -175,6 +197,9 @@ class InnerLoopEngine:
             out = self.t(name, N, cout, 2 * Ho, 2 * Wo) if epi == 2 else self.t(name, N, cout, Ho, Wo)
         st = None
         parts = 0
+        if stats and self.bn_eval:
+            stats = False
+            parts = N * Ho * Wo           # only used as the element count by observers
         if stats:
             parts = lib.ms_conv_stats_parts(N, Ho, Wo)
             st = self.t(name + ".stats", cout, parts, 4)
@@ -195,8 +220,15 @@ class InnerLoopEngine:
         return out, st, parts
 
     def bn_fin(self, name, st, parts, bn: BNW):
+        if self.bn_eval:
+            if bn.coef_eval is None:
+                raise RuntimeError("eval-mode BatchNorm needs running statistics in the state_dict")
+            self.buf[name + ".coef"] = bn.coef_eval
+            return bn.coef_eval
         coef = self.t(name + ".coef", bn.gamma.numel(), 4)
         check(lib.ms_bn_finalize(st.data_ptr(), parts, bn.gamma.data_ptr(), bn.beta.data_ptr(), BN_EPS, coef.data_ptr(), bn.gamma.numel(), self._st()), "ms_bn_finalize:" + name)
+        if self.bn_observer is not None:
+            self.bn_observer(bn, coef)
         return coef
 
     def bn_act(self, name, u, coef, res=None, res_mode=0, slope=LEAKY):
@@ -212,6 +244,11 @@ class InnerLoopEngine:
         part = self.t(name + ".part", C, nparts, 2)
         check(lib.ms_act_bwd_reduce(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
                                     N, C, H * W, slope, self._st()), "ms_act_bwd_reduce:" + name)
+        if self.bn_eval:                  # eval-mode BatchNorm is a fixed per-channel affine map: du = scale * g
+            bc = self.t(name + ".bcoef", C, 4)
+            bc.zero_()
+            bc[:, 0].copy_(coef[:, 0])
+            return gin, bc
         bc = self.t(name + ".bcoef", C, 4)
         check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(N * H * W), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + name)
         return gin, bc
@@ -325,7 +362,7 @@ class InnerLoopEngine:
         ws = self.t("s.ce_ws", max(nbytes, 64), dtype=torch.uint8)
         check(lib.ms_head_ce(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), 0 if dh is None else dh.data_ptr(),
                              0 if logits is None else logits.data_ptr(), self.loss_buf.data_ptr(), 0 if loss_slot is None else loss_slot.data_ptr(),
-                             N, C, K, H * W, -1.0, ws.data_ptr(), ws.numel(), self._st()), "ms_head_ce")
+                             N, C, K, H * W, self.loss_sign, ws.data_ptr(), ws.numel(), self._st()), "ms_head_ce")
         if not need_grad:
             return None
         d = dh
@@ -444,7 +481,7 @@ class InnerLoopEngine:
             if i <= first and self._prefix_valid:
                 x = self.buf[f"d.u{i}.out"]              # style-independent prefix: computed once per call
             else:
-                x = self.res_fwd(f"d.u{i}", d, f"u{i}", x, "convT")
+                x = self.res_fwd(f"d.u{i}", d, f"u{i}", x, self._dec_kind())
             if i in self.layers:
                 x = self.style_fwd(i, x)
         N, C, H, W = x.shape
@@ -459,6 +496,18 @@ class InnerLoopEngine:
         if 5 in self.layers:
             img = self.style_fwd(5, img)
         return img
+
+    def _dec_kind(self):
+        return "convT" if "u1.up" in self.nets.dec else "nn"      # up_type 'Conv2' vs 'NN' image decoder
+
+    def seg_logits(self, z_s):
+        """MyDecoder.forward of the segmentation decoder (encoder_decoder.py:587-596): logits [N,K,H,W]."""
+        h = self.seg_fwd(z_s)
+        N, C, H, W = h.shape
+        w, bias = self.nets.seg["head.w"], self.nets.seg["head.b"]
+        out = self.t("s.logits", N, w.shape[0], H, W)
+        check(lib.ms_head_fwd(h.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), N, C, w.shape[0], H * W, 0, self._st()), "ms_head_fwd")
+        return out
 
     def decode_bwd(self, dimg):
         """Backward of apply_max_style down to the first inserted layer; fills flat_g."""
@@ -480,7 +529,7 @@ class InnerLoopEngine:
                 g = self.style_bwd(i, g, need_dx=(first < i))
                 if first == i:
                     return
-            g = self.res_bwd(f"d.u{i}", d, f"u{i}", g, "convT", need_dx=True)
+            g = self.res_bwd(f"d.u{i}", d, f"u{i}", g, self._dec_kind(), need_dx=True)
         if 0 in self.layers:
             self.style_bwd(0, g, need_dx=False)
 
@@ -516,6 +565,14 @@ class InnerLoopEngine:
     def run(self, code, labels, n_iter, use_graph=True):
         """K inner steps; returns the final stylised image (a view of an engine buffer - clone to keep)."""
         assert n_iter <= self.loss_buf.numel(), "n_iter exceeds the loss buffer"
+        # inputs live in engine-owned buffers so that a captured graph (which holds addresses) stays valid across calls
+        cb = self.t("in.code", *code.shape)
+        cb.copy_(code)
+        code = cb
+        if labels is not None:
+            lb = self.t("in.labels", *labels.shape, dtype=torch.int64)
+            lb.copy_(labels)
+            labels = lb
         self.code, self.labels = code, labels
         self._prefix_valid = False
         self.step_dev.zero_()

@@ -1,0 +1,271 @@
+"""`AdvancedTripletReconSegmentationModel` - the hot-path surface of the reference solver
+(/root/reference/src/models/advanced_triplet_recon_segmentation_model.py) on the MI355X engine.
+
+Implemented (same names, argument meaning and error behaviour):
+    __init__/get_network (:42-266, FCN_16 / FCN_64 families), encode_image / filter_code (:330-385),
+    decoder_inference (:693-716), generate_max_style_image (:458-571), predict-style evaluate helper, zero_grad/train/eval.
+The K-step inner loop runs in maxstyle_amd.engine (HIP kernels + HIP-graph replay); this file is host-side orchestration.
+Out of scope here (SURVEY.md 8, rows "next"/OUT): the outer training step, other augmentation baselines, checkpoint I/O helpers.
+"""
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from .maxstyle import MaxStyle
+from .networks import Dual_Branch_Encoder, MyDecoder, _disable_tracking_bn_stats, set_grad
+
+
+def cross_entropy_2D(input, target, weight=None, size_average=True):
+    """custom_loss.py:1043-1078 for 3-D label targets: sum of pixel NLL / (N*H*W). HIP kernel (fused log-softmax + NLL)."""
+    from . import ops
+    if weight is not None or not size_average or target.dim() != 3:
+        raise NotImplementedError("only the un-weighted, size-averaged label-map form used by the MaxStyle loop")
+    n, c, h, w = input.shape
+    eye = torch.eye(c, device=input.device, dtype=torch.float32)
+    loss, _, _ = ops.head_ce(input.contiguous().float(), eye, None, target.contiguous(), loss_sign=1.0, need_dh=False)
+    return loss[0]
+
+
+def basic_loss_fn(pred, target, loss_type='cross_entropy', class_weights=None, use_gpu=True):
+    """custom_loss.py:13-45 ('cross entropy' branch - the only one the MaxStyle loop uses; class_weights are ignored by it)."""
+    if class_weights is not None:
+        assert len(class_weights) == pred.size(1), 'each cls must have a weight, expect to have {} classses but got {} weights'.format(pred.size(1), len(class_weights))
+    if loss_type == 'cross entropy':
+        return cross_entropy_2D(pred, target)
+    raise NotImplementedError
+
+
+class AdvancedTripletReconSegmentationModel(nn.Module):
+    def __init__(self, network_type='FCN_16_standard', image_ch=1, learning_rate=1e-4, encoder_dropout=None, decoder_dropout=None,
+                 num_classes=4, n_iter=1, checkpoint_dir=None, use_gpu=True, debug=False, rec_loss_type='l2', separate_training=False,
+                 class_weights=None, optimizer_type='Adam', image_size=192, intensity_norm_type="min_max"):
+        super().__init__()
+        self.network_type = network_type
+        self.image_ch = image_ch
+        self.learning_rate = learning_rate
+        self.num_classes = num_classes
+        self.n_iter = n_iter
+        self.checkpoint_dir = checkpoint_dir
+        self.use_gpu = use_gpu
+        self.debug = debug
+        self.class_weights = class_weights
+        self.intensity_norm_type = intensity_norm_type
+        self.image_size = image_size
+        if encoder_dropout is not None or decoder_dropout is not None:
+            raise NotImplementedError("dropout is None in every MaxStyle config (SURVEY.md 2 row 6)")
+        self.latent_code = {}
+        self.model = self.get_network(checkpoint_dir=checkpoint_dir)
+        self._engines = {}
+        self._packed = None
+        self._packed_key = None
+        self.last_style_modules = None
+
+    # ------------------------------------------------------------------ construction (advanced_triplet...py:125-266)
+    def get_network(self, checkpoint_dir=None):
+        nt = self.network_type
+        if self.intensity_norm_type != 'min_max' or 'z_score' in nt or 'identity' in nt:
+            raise NotImplementedError("only the Sigmoid image decoder (intensity_norm_type='min_max') is on the MaxStyle path")
+        if nt.startswith('Unet') or 'DS_FCN' in nt or not ('FCN_16' in nt or 'FCN_64' in nt):
+            print(f'no {nt} found')
+            raise NotImplementedError
+        reduce_factor = 4 if '16' in nt else 1
+        self.reduce_factor = reduce_factor
+        image_encoder = Dual_Branch_Encoder(input_channel=self.image_ch, z_level_1_channel=512 // reduce_factor,
+                                            z_level_2_channel=512 // reduce_factor, feature_reduce=reduce_factor, norm=nn.BatchNorm2d, num_domains=1)
+        segmentation_decoder = MyDecoder(input_channel=512 // reduce_factor, up_type='NN', output_channel=self.num_classes,
+                                         feature_reduce=reduce_factor, norm=nn.BatchNorm2d)
+        model = {'image_encoder': image_encoder, 'segmentation_decoder': segmentation_decoder}
+        if 'no_im_recon' not in nt:
+            up = 'NN' if 'NN_decoder' in nt else 'Conv2'
+            model['image_decoder'] = MyDecoder(input_channel=512 // reduce_factor, up_type=up, output_channel=self.image_ch,
+                                               feature_reduce=reduce_factor, norm=nn.BatchNorm2d, last_act=nn.Sigmoid())
+        for name, module in model.items():
+            self._init_weights(module)
+            if checkpoint_dir:
+                import os
+                path = os.path.join(checkpoint_dir, f'{name}.pth')
+                if os.path.exists(path):
+                    module.load_state_dict(torch.load(path, map_location='cpu'))
+            if self.use_gpu:
+                module.cuda()
+            self.add_module(name, module)          # so .parameters()/.to()/.train() see the three sub-nets
+        return model
+
+    @staticmethod
+    def _init_weights(module):
+        """init_weight.py:52-61 semantics: kaiming conv weights, BN gamma ~ N(1,0.02), beta 0; ConvTranspose keeps the default."""
+        for m in module.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.normal_(m.weight.data, 1.0, 0.02)
+                nn.init.constant_(m.bias.data, 0.0)
+
+    def get_modules(self):
+        return self.model.values
+
+    def zero_grad(self, set_to_none=True):
+        for m in self.model.values():
+            m.zero_grad()
+
+    def train(self, mode=True):
+        for m in self.model.values():
+            m.train(mode)
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    # ------------------------------------------------------------------ thin dispatch (advanced_triplet...py:330-385, 693-716)
+    def encode_image(self, input, domain_id=0, disable_track_bn_stats=False):
+        enc = self.model['image_encoder']
+        if disable_track_bn_stats:
+            with _disable_tracking_bn_stats(enc):
+                z_i, z_s = enc(input)
+        else:
+            z_i, z_s = enc(input)
+        if 'w_o_filter' in self.network_type:
+            z_s = z_i
+        if 'share_code' in self.network_type:
+            z_i = z_s
+        self.latent_code['image'] = z_i
+        self.latent_code['segmentation'] = z_s
+        return z_i, z_s
+
+    def decoder_inference(self, latent_code, decoder_name="", decoder=None, eval=False, disable_track_bn_stats=False):
+        if decoder is None:
+            try:
+                decoder = self.model[decoder_name]
+            except Exception:
+                raise ValueError("error! no decoder named {}".format(decoder_name))
+        decoder_state = decoder.training
+        if eval:
+            decoder.eval()
+            with torch.no_grad():
+                logit = decoder(latent_code)
+        elif disable_track_bn_stats:
+            with _disable_tracking_bn_stats(decoder):
+                logit = decoder(latent_code)
+        else:
+            logit = decoder(latent_code)
+        decoder.train(mode=decoder_state)
+        return logit
+
+    def predict(self, input):
+        """eval-mode segmentation (BN running statistics): logits [N,K,H,W] (advanced_triplet...py:673-691 hot part)."""
+        states = {k: m.training for k, m in self.model.items()}
+        for m in self.model.values():
+            m.eval()
+        try:
+            _, z_s = self.encode_image(input)
+            return self.decoder_inference(decoder=self.model['segmentation_decoder'], latent_code=z_s)
+        finally:
+            for k, m in self.model.items():
+                m.train(states[k])
+
+    # ------------------------------------------------------------------ the hot path
+    def _loop_engine(self, B, H, W, dev):
+        key = tuple((id(p), p._version) for m in self.model.values() for p in list(m.parameters()) + list(m.buffers()))
+        spec = E.NetSpec(self.reduce_factor, self.image_ch, self.num_classes)
+        if self._packed_key != key:
+            sd = {k: {n: v.detach() for n, v in m.state_dict().items()} for k, m in self.model.items()}
+            self._packed = E.PackedNets(spec, sd['image_encoder'], sd['segmentation_decoder'], sd['image_decoder'])
+            self._packed_key = key
+            for eng in self._engines.values():
+                eng.set_nets(self._packed)
+        ek = (B, H, W, str(dev))
+        eng = self._engines.get(ek)
+        if eng is None:
+            eng = E.InnerLoopEngine(spec, B, H, W, dev)
+            eng.set_nets(self._packed)
+            self._engines[ek] = eng
+        return eng
+
+    def generate_max_style_image(self, image_code, decoder_layers_indexes=[3, 4, 5], channel_num=[128, 64, 32, 16, 16, 1], p=0.5,
+                                 n_iter=5, mix_style=True, lr=0.1, no_noise=False, reference_image=None, reference_segmentation=None,
+                                 noise_learnable=True, mix_learnable=True, loss_types=['seg'], loss_weights=[1], always_use_beta=False,
+                                 debug=False, fix_seed=None, use_graph=True):
+        """MaxStyle: K adversarial steps on {lmda, gamma_noise, beta_noise} of the layers inserted into the image decoder, returns the
+        stylised reconstruction (detached clone). See the reference docstring (advanced_triplet...py:467-501) for the arguments."""
+        if fix_seed is not None and isinstance(fix_seed, int):
+            torch.manual_seed(fix_seed)
+        if isinstance(image_code, list):
+            raise NotImplementedError("list-valued codes belong to the (broken in the reference) Unet_im_recon path")
+        if not len(decoder_layers_indexes) > 0:
+            recon_image = self.decoder_inference(decoder_name='image_decoder', latent_code=image_code, disable_track_bn_stats=False)
+            self.zero_grad()
+            return recon_image.detach().clone()
+        if not image_code.is_cuda:
+            raise RuntimeError("generate_max_style_image runs on the MI355X only (HIP kernels); got a CPU tensor")
+        old_state = {}
+        for name, module in self.model.items():
+            old_state[name] = module.training
+            set_grad(module, requires_grad=False)
+        try:
+            batch_size = image_code.size(0)
+            style_augmentor_dict = {}
+            for i in decoder_layers_indexes:
+                style_augmentor_dict[str(i)] = MaxStyle(batch_size, channel_num[i], p=p, mix_style=mix_style, no_noise=no_noise,
+                                                        mix_learnable=mix_learnable, noise_learnable=noise_learnable,
+                                                        always_use_beta=always_use_beta, debug=debug)
+            nn_style_augmentor_dict = nn.ModuleDict(style_augmentor_dict)
+            hook = getattr(self, "style_init_hook", None)       # test seam: inject perm / noise / lmda (SURVEY.md 7 'RNG')
+            if hook is not None:
+                hook(nn_style_augmentor_dict)
+            optimize = True
+            if n_iter > 0:
+                if len(list(nn_style_augmentor_dict.parameters())) == 0:
+                    optimize = False
+                else:
+                    assert reference_image is not None and reference_segmentation is not None, 'must provide reference images and segmentations'
+                    self.zero_grad()
+            for ltype in loss_types:
+                if ltype != 'seg' and n_iter > 0 and optimize:
+                    raise ValueError('loss type {} not supported'.format(ltype))
+            code = image_code.detach().contiguous().float()
+            B, _, h, w = code.shape
+            eng = self._loop_engine(B, h * 16, w * 16, code.device)
+            mods = {int(k): m for k, m in nn_style_augmentor_dict.items()}
+            slots = E.slots_from_modules(mods, code.device)
+            layers = [i for i in sorted(mods) if i in slots]
+            sig = self._cfg_sig(layers, slots)
+            if getattr(eng, "_cfg_sig", None) == sig and eng._graph is not None:
+                # same layout as the previous call: keep the flat buffers and the captured graph, reset the optimiser state
+                eng.flat_m.zero_(); eng.flat_v.zero_(); eng.flat_g.zero_()
+                for i in layers:
+                    eng.styles[i].have_std = False
+            else:
+                eng.configure_styles(layers, slots)
+                eng._cfg_sig = sig
+            for i in layers:
+                m = mods[i]
+                eng.set_style_state(i, m.perm, m.lmda.detach(), m.gamma_noise.detach(), m.beta_noise.detach())
+            eng.lr = lr
+            eng.loss_sign = -float(sum(w_ for w_, t in zip(loss_weights, loss_types) if t == 'seg')) if optimize and n_iter > 0 else -1.0
+            eng.bn_eval = not all(old_state.values())
+            labels = None
+            if optimize and n_iter > 0:
+                labels = reference_segmentation.to(device=code.device, dtype=torch.int64).contiguous()
+            steps = n_iter if optimize else 0
+            recon_image = eng.run(code, labels, steps, use_graph=use_graph)
+            with torch.no_grad():                                  # hand the optimised state back to the modules (debugging / tests)
+                for i in layers:
+                    m = mods[i]
+                    for nm in ("gamma_noise", "beta_noise", "lmda"):
+                        getattr(m, nm).data.copy_(eng.param(i, nm))
+                    std = eng.buf.get(f"st{i}.std")
+                    if std is not None:
+                        m.gamma_std = std[0].clone().view(1, -1, 1, 1); m.beta_std = std[1].clone().view(1, -1, 1, 1)
+            self.last_style_modules = nn_style_augmentor_dict
+            self.last_losses = eng.losses(steps).clone() if steps > 0 else None
+            out = recon_image.detach().clone()
+        finally:
+            for name, module in self.model.items():
+                set_grad(module, requires_grad=old_state[name])
+        self.zero_grad()
+        return out
+
+    @staticmethod
+    def _cfg_sig(layers, slots):
+        return tuple((i, slots[i].B, slots[i].C, slots[i].mix_style, slots[i].use_noise, slots[i].learn_noise, slots[i].learn_mix) for i in layers)

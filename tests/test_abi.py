@@ -87,3 +87,21 @@ def test_rng_draw_order_matches_reference_kat(golden_dir):
     np.testing.assert_allclose(m.gamma_noise.detach().numpy(), g["gamma_noise0"])
     np.testing.assert_allclose(m.beta_noise.detach().numpy(), g["beta_noise0"])
     np.testing.assert_allclose(m.lmda.detach().numpy(), g["lmda0"])
+
+
+def test_state_dict_layout_matches_reference():
+    """Module/parameter names of the drop-in networks == the reference's state_dict keys, so .pth files load."""
+    import maxstyle_amd as M
+    from oracle import maxstyle_oracle as orc
+    for spec in (orc.NetSpec(4, 1, 4), orc.NetSpec(1, 3, 2)):
+        shapes = orc.param_shapes(spec)
+        net = "FCN_16_standard_no_STN" if spec.reduce == 4 else "FCN_64_standard_no_STN"
+        S = M.AdvancedTripletReconSegmentationModel(network_type=net, image_ch=spec.image_ch, num_classes=spec.num_classes, use_gpu=False)
+        for name, mod in S.model.items():
+            sd = mod.state_dict()
+            assert set(sd) == set(shapes[name]), (name, set(sd) ^ set(shapes[name]))
+            for k, v in sd.items():
+                assert tuple(v.shape) == tuple(shapes[name][k]), (name, k)
+    assert sum(p.numel() for p in S.model["image_encoder"].parameters()) > 0
+    with pytest.raises(NotImplementedError):
+        M.AdvancedTripletReconSegmentationModel(network_type="Unet_16", use_gpu=False)
