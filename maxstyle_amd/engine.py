@@ -416,7 +416,8 @@ class InnerLoopEngine:
 
     def set_style_state(self, i, perm, lmda, gamma_noise, beta_noise):
         s = self.styles[i]
-        s.perm = torch.as_tensor(perm).to(device=self.dev, dtype=torch.int64).contiguous()
+        s.perm = self.t(f"st{i}.perm", s.B, dtype=torch.int64)      # engine-owned: a captured graph keeps its address
+        s.perm.copy_(torch.as_tensor(perm).to(device=self.dev, dtype=torch.int64))
         self.param(i, "lmda").copy_(torch.as_tensor(lmda).to(self.dev, F32).view(s.B, 1, 1, 1))
         self.param(i, "gamma_noise").copy_(torch.as_tensor(gamma_noise).to(self.dev, F32).view(s.B, s.C, 1, 1))
         self.param(i, "beta_noise").copy_(torch.as_tensor(beta_noise).to(self.dev, F32).view(s.B, s.C, 1, 1))
