@@ -6,6 +6,10 @@ refuses non-CUDA tensors.  Build with `python -c "import __graft_entry__ as g; g
 import ctypes
 import os
 
+import torch  # noqa: F401  MUST precede the CDLL below: PyTorch-ROCm ships its own libamdhip64; loading ours after it makes the
+               # dynamic loader reuse that one runtime (same SONAME). Loaded the other way round the process ends up with two HIP
+               # runtimes and ours reports 'no ROCm-capable device' on the first launch.
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmaxstyle_hip.so")
 

@@ -9,6 +9,10 @@
 #define MS_ERR_ALIGN (-2)        // pointer not aligned as the entry point requires
 #define MS_ERR_WORKSPACE (-3)    // caller-provided workspace too small
 
+// hipGetLastError() is per-thread state shared with every other HIP user in the process (PyTorch leaves benign errors behind,
+// e.g. from its device-availability probe): clear it right before our launch so check_launch() reports OUR launch only.
+#define MS_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 namespace ms {
 
 constexpr int kWave = 64;

@@ -131,6 +131,6 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
 
 extern "C" int ms_bn_finalize(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, int C, void* stream) {
   if (C < 1 || nparts < 1) { set_error("ms_bn_finalize: invalid shape"); return MS_ERR_INVALID; }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float4*)stats, nparts, gamma, beta, eps, (float4*)coef4);
+  MS_LAUNCH(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float4*)stats, nparts, gamma, beta, eps, (float4*)coef4);
   return check_launch("bn_finalize");
 }

@@ -459,7 +459,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
   const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));
   const long nblocks = std::min<long>(nitems, (long)kNumCU * per_cu);
   dim3 grid((unsigned)nblocks), block(512);
-  hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2>), grid, block, lds_bytes, st, a);
+  MS_LAUNCH((conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2>), grid, block, lds_bytes, st, a);
   return check_launch("conv_mfma");
 }
 

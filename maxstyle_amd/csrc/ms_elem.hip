@@ -267,9 +267,9 @@ extern "C" int ms_bn_act(const float* u, const float* coef4, const float* res, i
   dim3 grid(sp.S, N * C), block(kElemThreads);
   hipStream_t st = (hipStream_t)stream;
   const float4* cf = (const float4*)coef4;
-  if (res_mode == 0) hipLaunchKernelGGL(bn_act_kernel<0>, grid, block, 0, st, u, cf, res, out, C, H, W, sp.chunk, slope);
-  else if (res_mode == 1) hipLaunchKernelGGL(bn_act_kernel<1>, grid, block, 0, st, u, cf, res, out, C, H, W, sp.chunk, slope);
-  else hipLaunchKernelGGL(bn_act_kernel<2>, grid, block, 0, st, u, cf, res, out, C, H, W, sp.chunk, slope);
+  if (res_mode == 0) MS_LAUNCH(bn_act_kernel<0>, grid, block, 0, st, u, cf, res, out, C, H, W, sp.chunk, slope);
+  else if (res_mode == 1) MS_LAUNCH(bn_act_kernel<1>, grid, block, 0, st, u, cf, res, out, C, H, W, sp.chunk, slope);
+  else MS_LAUNCH(bn_act_kernel<2>, grid, block, 0, st, u, cf, res, out, C, H, W, sp.chunk, slope);
   return check_launch("bn_act");
 }
 
@@ -282,14 +282,14 @@ extern "C" int ms_act_bwd_reduce(const float* gin, const float* ref, const float
   const ElemSplit sp = elem_split(N * C, HW);
   dim3 grid(sp.S, N * C), block(kElemThreads);
   hipStream_t st = (hipStream_t)stream;
-  if (ref != nullptr) hipLaunchKernelGGL(act_bwd_reduce_kernel<0>, grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope);
-  else hipLaunchKernelGGL(act_bwd_reduce_kernel<1>, grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope);
+  if (ref != nullptr) MS_LAUNCH(act_bwd_reduce_kernel<0>, grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope);
+  else MS_LAUNCH(act_bwd_reduce_kernel<1>, grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope);
   return check_launch("act_bwd_reduce");
 }
 
 extern "C" int ms_bn_bwd_coefs(const float* part2, int nparts, const float* coef4, double count, float* coef_out4, int C, void* stream) {
   if (C < 1 || nparts < 1 || count <= 0) { set_error("ms_bn_bwd_coefs: invalid argument"); return MS_ERR_INVALID; }
-  hipLaunchKernelGGL(bn_bwd_coefs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float2*)part2, nparts, (const float4*)coef4, count, (float4*)coef_out4);
+  MS_LAUNCH(bn_bwd_coefs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float2*)part2, nparts, (const float4*)coef4, count, (float4*)coef_out4);
   return check_launch("bn_bwd_coefs");
 }
 
@@ -297,7 +297,7 @@ extern "C" int ms_pool2_sum(const float* in, float* out, int planes, int Ho, int
   if (planes < 1 || Ho < 1 || Wo < 1) { set_error("ms_pool2_sum: invalid shape"); return MS_ERR_INVALID; }
   const size_t total = (size_t)planes * Ho * Wo;
   const int blocks = (int)std::min<size_t>((total + kElemThreads - 1) / kElemThreads, 4096);
-  hipLaunchKernelGGL(pool2_sum_kernel, dim3(blocks), dim3(kElemThreads), 0, (hipStream_t)stream, in, out, planes, Ho, Wo, accumulate);
+  MS_LAUNCH(pool2_sum_kernel, dim3(blocks), dim3(kElemThreads), 0, (hipStream_t)stream, in, out, planes, Ho, Wo, accumulate);
   return check_launch("pool2_sum");
 }
 
@@ -311,7 +311,7 @@ extern "C" int ms_head_fwd(const float* h, const float* w, const float* b, float
   if (int e = head_check(N, C, K, HW, "ms_head_fwd")) return e;
   if (HW % 4 != 0) { set_error("ms_head_fwd: H*W must be a multiple of 4"); return MS_ERR_INVALID; }
   dim3 grid(std::min(cdiv(HW, kElemThreads * 4), 256), N);
-  hipLaunchKernelGGL(head_sigmoid_kernel, grid, dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, out, C, K, HW, apply_sigmoid);
+  MS_LAUNCH(head_sigmoid_kernel, grid, dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, out, C, K, HW, apply_sigmoid);
   return check_launch("head_fwd");
 }
 
@@ -319,7 +319,7 @@ extern "C" int ms_head_bwd(const float* dout, const float* out, const float* w, 
   if (int e = head_check(N, C, K, HW, "ms_head_bwd")) return e;
   if (HW % 4 != 0) { set_error("ms_head_bwd: H*W must be a multiple of 4"); return MS_ERR_INVALID; }
   dim3 grid(std::min(cdiv(HW, kElemThreads * 4), 256), N);
-  hipLaunchKernelGGL(head_sigmoid_bwd_kernel, grid, dim3(kElemThreads), 0, (hipStream_t)stream, dout, out, w, dh, C, K, HW, apply_sigmoid);
+  MS_LAUNCH(head_sigmoid_bwd_kernel, grid, dim3(kElemThreads), 0, (hipStream_t)stream, dout, out, w, dh, C, K, HW, apply_sigmoid);
   return check_launch("head_bwd");
 }
 
@@ -333,8 +333,8 @@ extern "C" int ms_head_ce(const float* h, const float* w, const float* b, const 
   dim3 grid(gx, N);
   const double M = (double)N * HW;
   // loss = loss_sign * CE, CE = -(1/M) sum logp[label];  d loss / d logit_k = loss_sign * (p_k - 1[k==label]) / M
-  hipLaunchKernelGGL(head_ce_kernel, grid, dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, logits, (double*)ws, C, K, HW, (float)(loss_sign / M));
+  MS_LAUNCH(head_ce_kernel, grid, dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, logits, (double*)ws, C, K, HW, (float)(loss_sign / M));
   if (int e = check_launch("head_ce")) return e;
-  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, gx * N, -(double)loss_sign / M, loss_out, loss_slot_dev);
+  MS_LAUNCH(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, gx * N, -(double)loss_sign / M, loss_out, loss_slot_dev);
   return check_launch("ce_finalize");
 }

@@ -283,7 +283,7 @@ extern "C" size_t ms_style_ws_bytes(int B, int C, int HW) {
 
 static int launch_moments(const float* x, PlanePartial* part, int P, int HW, const Split& sp, hipStream_t st) {
   dim3 grid(sp.S, P), block(kStyleThreads);
-#define MS_LAUNCH_MOM(V, N) hipLaunchKernelGGL((moments_partial_kernel<V, N>), grid, block, 0, st, x, part, HW, sp.chunk, sp.S)
+#define MS_LAUNCH_MOM(V, N) MS_LAUNCH((moments_partial_kernel<V, N>), grid, block, 0, st, x, part, HW, sp.chunk, sp.S)
   if (sp.vec) {
     switch (sp.nv) { case 8: MS_LAUNCH_MOM(4, 8); break; case 4: MS_LAUNCH_MOM(4, 4); break; case 2: MS_LAUNCH_MOM(4, 2); break; default: MS_LAUNCH_MOM(4, 1); }
   } else {
@@ -314,7 +314,7 @@ extern "C" int ms_style_moments(const float* x, float* mu, float* sig, int plane
     const int np = std::min(kMaxPlanesPerLaunch, planes - p0);
     if (int e = launch_moments(x + (size_t)p0 * HW, part + (size_t)p0 * sp.S, np, HW, sp, st)) return e;
   }
-  hipLaunchKernelGGL(moments_merge_kernel, dim3(cdiv(planes, 256)), dim3(256), 0, st, part, mu, sig, planes, sp.S, HW, eps);
+  MS_LAUNCH(moments_merge_kernel, dim3(cdiv(planes, 256)), dim3(256), 0, st, part, mu, sig, planes, sp.S, HW, eps);
   return check_launch("moments_merge");
 }
 
@@ -325,7 +325,7 @@ extern "C" int ms_style_coeffs(float* mu, float* sig, float* gamma_std, float* b
   if (compute_std && B < 2) { set_error("ms_style_coeffs: batch std needs B >= 2"); return MS_ERR_INVALID; }
   if (lmda != nullptr && perm == nullptr) { set_error("ms_style_coeffs: mixing needs perm"); return MS_ERR_INVALID; }
   if ((gamma_noise == nullptr) != (beta_noise == nullptr)) { set_error("ms_style_coeffs: gamma/beta noise must both be given"); return MS_ERR_INVALID; }
-  hipLaunchKernelGGL(style_finalize_kernel, dim3(C), dim3(256), 2 * B * sizeof(float), (hipStream_t)stream, (const PlanePartial*)nullptr, mu, sig,
+  MS_LAUNCH(style_finalize_kernel, dim3(C), dim3(256), 2 * B * sizeof(float), (hipStream_t)stream, (const PlanePartial*)nullptr, mu, sig,
                      gamma_std, beta_std, compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, 0, 0, 0.f);
   return check_launch("style_finalize");
 }
@@ -340,8 +340,8 @@ extern "C" int ms_style_apply(const float* x, float* y, const float* mu, const f
     const int np = std::min(kMaxPlanesPerLaunch, planes - p0);
     dim3 grid(sp.S, np), block(kStyleThreads);
     const size_t off = (size_t)p0 * HW;
-    if (vec) hipLaunchKernelGGL(restyle_kernel<4>, grid, block, 0, st, x + off, y + off, mu + p0, sig + p0, coefA + p0, coefS + p0, HW, sp.chunk);
-    else hipLaunchKernelGGL(restyle_kernel<1>, grid, block, 0, st, x + off, y + off, mu + p0, sig + p0, coefA + p0, coefS + p0, HW, sp.chunk);
+    if (vec) MS_LAUNCH(restyle_kernel<4>, grid, block, 0, st, x + off, y + off, mu + p0, sig + p0, coefA + p0, coefS + p0, HW, sp.chunk);
+    else MS_LAUNCH(restyle_kernel<1>, grid, block, 0, st, x + off, y + off, mu + p0, sig + p0, coefA + p0, coefS + p0, HW, sp.chunk);
   }
   return check_launch("restyle");
 }
@@ -362,7 +362,7 @@ extern "C" int ms_style_fwd(const float* x, float* y, float* mu, float* sig, flo
     const int np = std::min(kMaxPlanesPerLaunch, P - p0);
     if (int e = launch_moments(x + (size_t)p0 * HW, part + (size_t)p0 * sp.S, np, HW, sp, st)) return e;
   }
-  hipLaunchKernelGGL(style_finalize_kernel, dim3(C), dim3(256), 2 * B * sizeof(float), st, (const PlanePartial*)part, mu, sig, gamma_std, beta_std,
+  MS_LAUNCH(style_finalize_kernel, dim3(C), dim3(256), 2 * B * sizeof(float), st, (const PlanePartial*)part, mu, sig, gamma_std, beta_std,
                      compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, sp.S, HW, eps);
   if (int e = check_launch("style_finalize")) return e;
   return ms_style_apply(x, y, mu, sig, coefA, coefS, P, HW, stream);
@@ -383,12 +383,12 @@ extern "C" int ms_style_bwd(const float* dy, const float* x, float* dx, const fl
     dim3 grid(sp.S, np), block(kStyleThreads);
     const size_t off = (size_t)p0 * HW;
     float* dxo = dx ? dx + off : nullptr;
-    if (vec) hipLaunchKernelGGL(restyle_bwd_kernel<4>, grid, block, 0, st, dy + off, x + off, dxo, mu + p0, sig + p0, coefA + p0, part + (size_t)p0 * sp.S, HW, sp.chunk, sp.S);
-    else hipLaunchKernelGGL(restyle_bwd_kernel<1>, grid, block, 0, st, dy + off, x + off, dxo, mu + p0, sig + p0, coefA + p0, part + (size_t)p0 * sp.S, HW, sp.chunk, sp.S);
+    if (vec) MS_LAUNCH(restyle_bwd_kernel<4>, grid, block, 0, st, dy + off, x + off, dxo, mu + p0, sig + p0, coefA + p0, part + (size_t)p0 * sp.S, HW, sp.chunk, sp.S);
+    else MS_LAUNCH(restyle_bwd_kernel<1>, grid, block, 0, st, dy + off, x + off, dxo, mu + p0, sig + p0, coefA + p0, part + (size_t)p0 * sp.S, HW, sp.chunk, sp.S);
   }
   if (int e = check_launch("restyle_bwd")) return e;
   if (d_gamma || d_beta || d_lmda) {
-    hipLaunchKernelGGL(style_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, (const float2*)part, mu, sig, gamma_std, beta_std, lmda, perm,
+    MS_LAUNCH(style_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, (const float2*)part, mu, sig, gamma_std, beta_std, lmda, perm,
                        d_gamma, d_beta, d_lmda, B, C, sp.S);
     return check_launch("style_bwd_finalize");
   }
@@ -399,11 +399,11 @@ extern "C" int ms_adam_step(float* p, const float* g, float* m, float* v, int n,
                             const int* step_dev, void* stream) {
   if (n < 0 || (step_dev == nullptr && step < 1)) { set_error("ms_adam_step: invalid n/step"); return MS_ERR_INVALID; }
   if (n == 0) return MS_OK;
-  hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, step, step_dev);
+  MS_LAUNCH(adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, step, step_dev);
   return check_launch("adam");
 }
 
 extern "C" int ms_counter_incr(int* counter, void* stream) {
-  hipLaunchKernelGGL(incr_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter);
+  MS_LAUNCH(incr_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter);
   return check_launch("incr");
 }
