@@ -51,6 +51,18 @@ int ms_style_fwd(const float* x, float* y, float* mu, float* sig, float* gamma_s
                  const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
                  float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
 
+/* The two implementations behind ms_style_fwd (same arguments, same results to rounding):
+ *   ms_style_fwd_fused  single-read persistent kernel: x crosses HBM once (8 B/element); eligible when H*W % 4 == 0, 2 <= B <= 256 and
+ *                       one channel group (B x chunks) fits the grid - ms_style_fused_ws_bytes() returns 0 otherwise
+ *   ms_style_fwd_3k     moments / finalize / restyle as three launches (any shape; x is read twice) */
+size_t ms_style_fused_ws_bytes(int B, int C, int HW);
+int ms_style_fwd_fused(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+                       const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
+                       float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
+int ms_style_fwd_3k(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+                    const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
+                    float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
+
 /* Backward of the layer (autograd of maxstyle.py:161-185 with mu/sig detached):
  *   dx = dy*A/sig (skipped when dx == NULL);  d_gamma = gamma_std*sum(dy*xhat);  d_beta = beta_std*sum(dy);
  *   d_lmda[b] = 1[0<=lmda<=1] * sum_c (sig[perm b]-sig[b])*S2 + (mu[perm b]-mu[b])*S1.   Any of d_* may be NULL. */

@@ -30,6 +30,11 @@ SIGNATURES = {
     "ms_style_apply": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_void]),
     "ms_style_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p,
                              c_int, c_int, c_int, c_float, c_void, c_size, c_void]),
+    "ms_style_fused_ws_bytes": (c_size, [c_int, c_int, c_int]),
+    "ms_style_fwd_fused": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p,
+                                   c_int, c_int, c_int, c_float, c_void, c_size, c_void]),
+    "ms_style_fwd_3k": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p,
+                                c_int, c_int, c_int, c_float, c_void, c_size, c_void]),
     "ms_style_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p,
                              c_int, c_int, c_int, c_void, c_size, c_void]),
     "ms_adam_step": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_float, c_float, c_float, c_float, c_int, c_void, c_void]),

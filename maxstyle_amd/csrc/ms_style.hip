@@ -10,11 +10,12 @@
 //  forward  = moments_partial (1 read of x; register-resident two-pass variance per chunk)
 //           -> style_finalize (per channel: Chan-merge partials in fp64, batch std, mixing -> per-plane A,S)
 //           -> restyle        (read x, write y = A*(x-mu)/sig + S)
-//    algorithmic bytes: 8 B/element (the second read of x is served from L2/Infinity Cache when the tensor
-//    fits; the persistent single-read variant lives in ms_style_fused.hip)
+//    12 B/element of traffic for 8 algorithmic (the second read of x is served from L2/Infinity Cache when the tensor fits);
+//    ms_style_fwd dispatches to the single-read kernel of ms_style_fused.hip whenever the shape is eligible
 //  backward = restyle_bwd (read dy,x; write dx=dy*A/sig; partial S1=sum dy, S2=sum dy*xhat)
 //           -> style_bwd_finalize (d gamma, d beta, d lmda)
 #include <algorithm>
+#include <cstdlib>
 #include "ms_common.h"
 #include "maxstyle_hip.h"
 
@@ -275,10 +276,10 @@ static Split choose_split(int P, int HW, bool vec_ok) {
 using namespace ms;
 
 extern "C" size_t ms_style_ws_bytes(int B, int C, int HW) {
-  // worst case split: scalar path, nv=1 -> chunk 256
+  // worst case split: scalar path, nv=1 -> chunk 256; and room for the single-read kernel's counters + partials
   const size_t P = (size_t)B * C;
   const size_t S = (size_t)cdiv(HW, kStyleThreads);
-  return P * S * sizeof(PlanePartial) + 256;
+  return std::max(P * S * sizeof(PlanePartial) + 256, ms_style_fused_ws_bytes(B, C, HW));
 }
 
 static int launch_moments(const float* x, PlanePartial* part, int P, int HW, const Split& sp, hipStream_t st) {
@@ -349,6 +350,17 @@ extern "C" int ms_style_apply(const float* x, float* y, const float* mu, const f
 extern "C" int ms_style_fwd(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
                             const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
                             float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream) {
+  // single-read kernel when the shape is eligible (MS_STYLE_FUSED=0 forces the three-kernel path, for A/B timing)
+  static const bool fused_on = !(getenv("MS_STYLE_FUSED") != nullptr && atoi(getenv("MS_STYLE_FUSED")) == 0);
+  const size_t fb = fused_on ? ms_style_fused_ws_bytes(B, C, HW) : 0;
+  if (fb != 0 && ws != nullptr && ws_bytes >= fb && aligned16(ws) && aligned16(x) && aligned16(y))
+    return ms_style_fwd_fused(x, y, mu, sig, gamma_std, beta_std, compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, HW, eps, ws, ws_bytes, stream);
+  return ms_style_fwd_3k(x, y, mu, sig, gamma_std, beta_std, compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, HW, eps, ws, ws_bytes, stream);
+}
+
+extern "C" int ms_style_fwd_3k(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+                               const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
+                               float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream) {
   if (int e = check_style_args(B, C, HW, ws, ws_bytes)) return e;
   if (compute_std && B < 2) { set_error("ms_style_fwd: batch std needs B >= 2"); return MS_ERR_INVALID; }
   if (lmda != nullptr && perm == nullptr) { set_error("ms_style_fwd: mixing needs perm"); return MS_ERR_INVALID; }

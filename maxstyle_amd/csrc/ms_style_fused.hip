@@ -1,0 +1,224 @@
+// Single-read fused MaxStyle forward for gfx950: moments + style mixing + restyle with x read from HBM exactly once.
+//
+// Reference semantics: /root/reference/src/advanced/maxstyle.py:157-188 (same arithmetic as ms_style.hip).
+//
+// The restyle of plane (b,c) needs the statistics of plane (perm[b],c) and - on the first call - the batch standard
+// deviation over all B planes of channel c, so a naive fusion needs a grid-wide barrier.  Here the dependency is kept
+// per CHANNEL: work units (channel c, sample b, chunk s) are handed out by a device-wide ticket counter in channel-major
+// order; a workgroup keeps its chunk of x in REGISTERS (up to 64 floats per thread), publishes the chunk's
+// (mean, M2) with an agent-scope store, bumps the channel's arrival counter, waits until the B*S units of its channel
+// have arrived, merges the channel's partials (Chan, fp64), computes its plane's affine coefficients and writes y from
+// registers.  HBM traffic = 4 B/element read + 4 B/element written = the algorithmic 8 B/element.
+//
+// Progress guarantee (no co-residency or dispatch-order assumption): tickets are issued in increasing order at
+// workgroup start, so every issued ticket belongs to a RUNNING workgroup; units of fully-issued channels never wait
+// before their arrival, hence always complete and free their slots; only the last, partially issued channel can have
+// waiters, and it gets the next tickets.  The grid must be able to hold one whole channel group (B*S units): enforced
+// on the host (else the three-kernel path of ms_style.hip is used).  Every spin is bounded (error word).
+// Inter-workgroup visibility follows the 8-byte agent-scope atomic store/load form (write-through sc1 stores, arrival
+// counter after s_waitcnt vmcnt(0), relaxed agent-scope polls): MI355X_MICROARCH.md "Valid forms".
+#include <algorithm>
+#include "ms_common.h"
+#include "maxstyle_hip.h"
+
+namespace ms {
+
+constexpr unsigned kSpinLimit = 1u << 22;
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void publish_partial(u64* slot, float mean, float m2) {
+  const u64 v = ((u64)__float_as_uint(m2) << 32) | (u64)__float_as_uint(mean);
+  __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void read_partial(const u64* slot, float& mean, float& m2) {
+  const u64 v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  mean = __uint_as_float((unsigned)(v & 0xFFFFFFFFull));
+  m2 = __uint_as_float((unsigned)(v >> 32));
+}
+
+template <int NV, int kFusedThreads>
+__global__ __launch_bounds__(kFusedThreads) void style_fused_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mu,
+                                                                   float* __restrict__ sig, float* __restrict__ gamma_std, float* __restrict__ beta_std,
+                                                                   int compute_std, const float* __restrict__ lmda, const float* __restrict__ gamma_noise,
+                                                                   const float* __restrict__ beta_noise, const int64_t* __restrict__ perm,
+                                                                   float* __restrict__ coefA, float* __restrict__ coefS, u64* __restrict__ part,
+                                                                   int* __restrict__ arrive, int* __restrict__ counter, int* __restrict__ err,
+                                                                   int B, int C, int HW, int S, int chunk, float eps) {
+  __shared__ float red[16];
+  __shared__ double redd[16];
+  __shared__ int s_ticket;
+  __shared__ float smu[256], ssig[256];
+  const int tid = threadIdx.x;
+  const int G = B * S, total = C * G;
+  while (true) {
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int t = s_ticket;
+    __syncthreads();
+    if (t >= total) break;
+    const int c = t / G, r = t - c * G, b = r / S, s = r - b * S;
+    const int p = b * C + c;
+    const int beg = s * chunk, end = min(HW, beg + chunk);
+    const float* xp = x + (size_t)p * HW;
+    float4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = beg + (j * kFusedThreads + tid) * 4;
+      v[j] = (i < end) ? *reinterpret_cast<const float4*>(xp + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    const float n = (float)(end - beg);
+    const float mean_c = block_sum(sum, red) / n;
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = beg + (j * kFusedThreads + tid) * 4;
+      if (i < end) {
+        const float d0 = v[j].x - mean_c, d1 = v[j].y - mean_c, d2 = v[j].z - mean_c, d3 = v[j].w - mean_c;
+        m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+    }
+    m2 = block_sum(m2, red);
+    if (tid == 0) {
+      publish_partial(part + ((size_t)c * B + b) * S + s, mean_c, m2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the partial has left this CU before the arrival is counted
+      __hip_atomic_fetch_add(arrive + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while (__hip_atomic_load(arrive + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
+        if (++spins > kSpinLimit) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+    // every plane of channel c: Chan-merge its S chunk partials (chunk sizes follow from the geometry)
+    for (int bb = tid; bb < B; bb += kFusedThreads) {
+      double nn = 0.0, mean = 0.0, mm2 = 0.0;
+      for (int ss = 0; ss < S; ++ss) {
+        float pm, pq;
+        read_partial(part + ((size_t)c * B + bb) * S + ss, pm, pq);
+        const double cn = (double)(min(HW, (ss + 1) * chunk) - ss * chunk);
+        chan_merge(nn, mean, mm2, cn, (double)pm, (double)pq);
+      }
+      smu[bb] = (float)mean;
+      ssig[bb] = sqrtf((float)(mm2 / (double)(HW - 1)) + eps);
+    }
+    __syncthreads();
+    float gs, bs;
+    if (compute_std) {
+      double am = 0.0, as = 0.0;
+      for (int bb = tid; bb < B; bb += kFusedThreads) { am += (double)smu[bb]; as += (double)ssig[bb]; }
+      const double mean_mu = block_sum_d(am, redd) / B;
+      const double mean_sg = block_sum_d(as, redd) / B;
+      double qm = 0.0, qs = 0.0;
+      for (int bb = tid; bb < B; bb += kFusedThreads) {
+        const double d1 = (double)smu[bb] - mean_mu, d2 = (double)ssig[bb] - mean_sg;
+        qm += d1 * d1; qs += d2 * d2;
+      }
+      qm = block_sum_d(qm, redd); qs = block_sum_d(qs, redd);
+      bs = (float)sqrt(qm / (double)(B - 1));
+      gs = (float)sqrt(qs / (double)(B - 1));
+    } else {
+      gs = gamma_std[c]; bs = beta_std[c];
+    }
+    const float m = smu[b], sg = ssig[b];
+    float A = sg, Sh = m;
+    if (lmda != nullptr) {
+      const float lam = fminf(fmaxf(lmda[b], 0.f), 1.f);
+      const int pb = (int)perm[b];
+      A = sg * (1.f - lam) + ssig[pb] * lam;
+      Sh = m * (1.f - lam) + smu[pb] * lam;
+    }
+    if (gamma_noise != nullptr) {
+      A += gamma_noise[p] * gs;
+      Sh += beta_noise[p] * bs;
+    }
+    if (tid == 0 && s == 0) {
+      mu[p] = m; sig[p] = sg; coefA[p] = A; coefS[p] = Sh;
+      if (b == 0 && compute_std) { gamma_std[c] = gs; beta_std[c] = bs; }
+    }
+    const float a = A / sg;
+    float* yp = y + (size_t)p * HW;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = beg + (j * kFusedThreads + tid) * 4;
+      if (i < end) {
+        float4 o;
+        o.x = a * (v[j].x - m) + Sh; o.y = a * (v[j].y - m) + Sh; o.z = a * (v[j].z - m) + Sh; o.w = a * (v[j].w - m) + Sh;
+        *reinterpret_cast<float4*>(yp + i) = o;
+      }
+    }
+    __syncthreads();      // smu/ssig are reused by the next unit
+  }
+}
+
+struct FusedPlan { bool ok; int threads, nv, chunk, S, grid; size_t part_off, bytes; };
+
+// Header: [0] ticket counter, [1] error word, [4..4+C) arrival counters (ints); partials (8 B each) after, 16-B aligned.
+static FusedPlan fused_plan(int B, int C, int HW) {
+  FusedPlan pl{};
+  pl.ok = false;
+  if (HW % 4 != 0 || B < 2 || B > 256) return pl;
+  // Few, fat workgroups keep the ticket counter cold (one device-wide atomic per unit, ~88 dequeues/us on one word):
+  // 1024 threads x up to 64 floats hold 256 KB of a plane; fall back to 256-thread units when that leaves CUs idle.
+  int threads = 1024, nv = 16;
+  int S = cdiv(HW, threads * 4 * nv);
+  if ((long)B * C * S >= 192) {
+    while (nv > 1 && threads * 4 * (nv / 2) * S >= HW) nv >>= 1;
+  } else {
+    threads = 256; nv = 16;
+    while (nv > 1 && (long)B * C * cdiv(HW, threads * 4 * nv) < 1024) nv >>= 1;
+    while (nv < 16 && B * cdiv(HW, threads * 4 * nv) > 512) nv <<= 1;      // one channel group must fit the resident grid
+    S = cdiv(HW, threads * 4 * nv);
+  }
+  pl.threads = threads; pl.nv = nv; pl.chunk = threads * 4 * nv; pl.S = cdiv(HW, pl.chunk);
+  const int G = B * pl.S;
+  // workgroups that can certainly run together: one 1024-thread (or two 256-thread) workgroup(s) per CU at <= 96 VGPRs
+  const int capacity = (threads == 1024) ? 256 : 512;
+  if (G > capacity) return pl;
+  pl.grid = (int)std::min<long>((long)C * G, threads == 1024 ? 256L : 1024L);
+  if (pl.grid < G) return pl;
+  pl.part_off = ((size_t)(4 + C) * sizeof(int) + 15) / 16 * 16;
+  pl.bytes = pl.part_off + (size_t)C * B * pl.S * sizeof(u64);
+  pl.ok = true;
+  return pl;
+}
+
+}  // namespace ms
+
+using namespace ms;
+
+extern "C" size_t ms_style_fused_ws_bytes(int B, int C, int HW) {
+  const FusedPlan pl = fused_plan(B, C, HW);
+  return pl.ok ? pl.bytes : 0;
+}
+
+extern "C" int ms_style_fwd_fused(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+                                  const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
+                                  float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream) {
+  const FusedPlan pl = fused_plan(B, C, HW);
+  if (!pl.ok) { set_error("ms_style_fwd_fused: shape B=%d C=%d HW=%d is not eligible (use ms_style_fwd)", B, C, HW); return MS_ERR_INVALID; }
+  if (!aligned16(x) || !aligned16(y)) { set_error("ms_style_fwd_fused: x and y must be 16-byte aligned"); return MS_ERR_ALIGN; }
+  if (ws == nullptr || ws_bytes < pl.bytes || !aligned16(ws)) { set_error("ms_style_fwd_fused: workspace too small or unaligned"); return MS_ERR_WORKSPACE; }
+  if (lmda != nullptr && perm == nullptr) { set_error("ms_style_fwd_fused: mixing needs perm"); return MS_ERR_INVALID; }
+  if ((gamma_noise == nullptr) != (beta_noise == nullptr)) { set_error("ms_style_fwd_fused: gamma/beta noise must both be given"); return MS_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  // re-initialise every polled word on the stream before every launch (a memset node when captured into a graph)
+  hipError_t e = hipMemsetAsync(ws, 0, pl.part_off, st);
+  if (e != hipSuccess) { set_error("ms_style_fwd_fused: memset: %s", hipGetErrorString(e)); return (int)e; }
+  int* hdr = (int*)ws;
+  u64* part = (u64*)((char*)ws + pl.part_off);
+  dim3 grid(pl.grid), block(pl.threads);
+#define MS_FUSED(NVV, TT) MS_LAUNCH((style_fused_kernel<NVV, TT>), grid, block, 0, st, x, y, mu, sig, gamma_std, beta_std, compute_std, lmda, gamma_noise, \
+                                    beta_noise, perm, coefA, coefS, part, hdr + 4, hdr, hdr + 1, B, C, HW, pl.S, pl.chunk, eps)
+  if (pl.threads == 1024) {
+    switch (pl.nv) { case 16: MS_FUSED(16, 1024); break; case 8: MS_FUSED(8, 1024); break; case 4: MS_FUSED(4, 1024); break;
+                     case 2: MS_FUSED(2, 1024); break; default: MS_FUSED(1, 1024); break; }
+  } else {
+    switch (pl.nv) { case 16: MS_FUSED(16, 256); break; case 8: MS_FUSED(8, 256); break; case 4: MS_FUSED(4, 256); break;
+                     case 2: MS_FUSED(2, 256); break; default: MS_FUSED(1, 256); break; }
+  }
+#undef MS_FUSED
+  return check_launch("style_fused");
+}
