@@ -32,33 +32,28 @@ namespace ms {
 //   out[c] = {scale = gamma*invstd, shift = beta - mean*scale, mean, invstd}      (biased variance, eps)
 // model_util.py:468-510 mode: batch statistics, running buffers untouched.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float4* __restrict__ part, int nparts, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float4* __restrict__ tab, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, float4* __restrict__ out) {
-  __shared__ double sn[256], sm[256], sq[256];
+  // two parallel passes in fp64 (no per-partial divisions): mean = sum n_i m_i / sum n_i ; M2 = sum M2_i + n_i (m_i - mean)^2
+  __shared__ double redd[16];
   const int c = blockIdx.x;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += 256) {
-    const float4 q = part[(size_t)c * nparts + i];
-    chan_merge(n, mean, m2, (double)q.x, (double)q.y, (double)q.z);
-  }
-  sn[threadIdx.x] = n; sm[threadIdx.x] = mean; sq[threadIdx.x] = m2;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) {
-      double n1 = sn[threadIdx.x], m1 = sm[threadIdx.x], q1 = sq[threadIdx.x];
-      chan_merge(n1, m1, q1, sn[threadIdx.x + off], sm[threadIdx.x + off], sq[threadIdx.x + off]);
-      sn[threadIdx.x] = n1; sm[threadIdx.x] = m1; sq[threadIdx.x] = q1;
-    }
-    __syncthreads();
-  }
+  const int nparts = (int)tab[0].x;
+  const float4* part = tab + 1 + (size_t)c * kStatSlots;
+  double sn = 0.0, sm = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) { const float4 q = part[i]; sn += (double)q.x; sm += (double)q.x * (double)q.y; }
+  sn = block_sum_d(sn, redd);
+  sm = block_sum_d(sm, redd);
+  const double mean = sm / sn;
+  double sq = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) { const float4 q = part[i]; const double d = (double)q.y - mean; sq += (double)q.z + (double)q.x * d * d; }
+  sq = block_sum_d(sq, redd);
   if (threadIdx.x == 0) {
-    const double var = sq[0] / sn[0];
+    const double var = sq / sn;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * invstd;
-    out[c] = make_float4(sc, beta[c] - (float)sm[0] * sc, (float)sm[0], invstd);
+    out[c] = make_float4(sc, beta[c] - (float)mean * sc, (float)mean, invstd);
   }
 }
-
 
 // tile geometry is a pure function of the output width (so ms_conv_stats_parts can be answered without launching)
 static inline bool narrow_tile(int Wout) { return Wout <= 16; }
@@ -69,11 +64,11 @@ static inline int tile_w(int Wout) { return narrow_tile(Wout) ? 16 : 32; }
 
 using namespace ms;
 
-// one partial per WAVE (4 per workgroup tile): the conv epilogue needs no LDS and no barrier for the statistics
-extern "C" int ms_conv_stats_parts(int N, int Hout, int Wout) { return 4 * N * cdiv(Hout, tile_h(Wout)) * cdiv(Wout, tile_w(Wout)); }
+// capacity (slots per channel) of the partial table: one slot per consumer wave of a resident workgroup, whatever the shape
+extern "C" int ms_conv_stats_parts(int N, int Hout, int Wout) { (void)N; (void)Hout; (void)Wout; return kStatSlots; }
 
 extern "C" size_t ms_conv_stats_bytes(int N, int Cout, int Hout, int Wout) {
-  return (size_t)Cout * ms_conv_stats_parts(N, Hout, Wout) * sizeof(float4);
+  return ((size_t)Cout * ms_conv_stats_parts(N, Hout, Wout) + 1) * sizeof(float4);      // + header record
 }
 
 extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
@@ -130,7 +125,7 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
 }
 
 extern "C" int ms_bn_finalize(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, int C, void* stream) {
-  if (C < 1 || nparts < 1) { set_error("ms_bn_finalize: invalid shape"); return MS_ERR_INVALID; }
-  MS_LAUNCH(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float4*)stats, nparts, gamma, beta, eps, (float4*)coef4);
+  if (C < 1 || nparts != kStatSlots) { set_error("ms_bn_finalize: invalid shape (nparts must be ms_conv_stats_parts())"); return MS_ERR_INVALID; }
+  MS_LAUNCH(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float4*)stats, gamma, beta, eps, (float4*)coef4);
   return check_launch("bn_finalize");
 }

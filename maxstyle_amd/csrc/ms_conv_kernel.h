@@ -22,6 +22,7 @@ namespace ms {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kNumCU = 256;      // MI355X: 8 XCDs x 32 CUs
+constexpr int kStatSlots = kNumCU * 2 * 4;   // per-channel capacity of the BatchNorm partial table: one slot per consumer wave of a resident workgroup
 
 enum { FETCH_NORMAL = 0, FETCH_UPS2 = 1, FETCH_ZINS2 = 2 };
 
@@ -293,6 +294,11 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   // ---- epilogue of one finished item (registers + global stores only) ----
   // bias of this lane's output channels, re-read only when the channel block changes (a global load inside the epilogue
   // would expose a full L2 round trip per item on the MFMA wave's critical path)
+  // running per-wave BatchNorm statistics (count, mean, M2) of every pixel this wave produced, per output channel: a workgroup keeps
+  // ONE channel block for its whole life (grid is a multiple of ncb), so the partial table gets one slot per wave, not one per tile
+  float st_n = 0.f, st_mean[NT], st_m2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { st_mean[j] = 0.f; st_m2[j] = 0.f; }
   float bias_v[NT];
   int bias_co0 = -1;
   auto load_bias = [&](int co0) {
@@ -327,8 +333,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         const int nx = min(16, a.Wout - (ox0 + mt_col(i)));
         if (y < a.Hout && nx > 0) cnt += (float)nx;
       }
-      const int nparts = a.N * ntiles * 4;
-      const int pidx = (n * ntiles + tile) * 4 + wave;
+      const float nt_ = st_n + cnt;
+      const float wgt = (nt_ > 0.f) ? cnt / nt_ : 0.f;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         float s = 0.f;
@@ -357,9 +363,12 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         }
         q += __shfl_xor(q, 16, 64);
         q += __shfl_xor(q, 32, 64);
-        const int co = co0 + j * 16 + m;
-        if (k == 0 && co < a.Cout) reinterpret_cast<float4*>(a.stats)[(size_t)co * nparts + pidx] = make_float4(cnt, mean, q, 0.f);
+        // Chan merge of this tile's (cnt, mean, q) into the running statistics
+        const float d = mean - st_mean[j];
+        st_mean[j] += d * wgt;
+        st_m2[j] += q + d * d * st_n * wgt;
       }
+      st_n = nt_;
     }
     if (a.epi_mode == 2) {
       // ConvTranspose2d k=2 s=2: GEMM column j = (dy*2+dx)*cout_real + co -> out[n,co,2y+dy,2x+dx]
@@ -442,6 +451,18 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
     }
     if (p + 1 < T) lds_barrier();                     // barrier #(p+2): chunk p+1 visible; this wave is done with chunk p
   }
+  if (a.stats != nullptr) {
+    // table layout: [0] = {slots in use per channel}, then [1 + co*kStatSlots + slot]; slot = (workgroup index within its channel block)*4 + wave
+    float4* tab = reinterpret_cast<float4*>(a.stats);
+    const int cb0 = (int)blockIdx.x % ncb;
+    const int slot = ((int)blockIdx.x / ncb) * 4 + wave;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int co = cb0 * COUT_TILE + j * 16 + m;
+      if (k == 0 && co < a.Cout) tab[1 + (size_t)co * kStatSlots + slot] = make_float4(st_n, st_mean[j], st_m2[j], 0.f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) tab[0] = make_float4((float)(((int)gridDim.x / ncb) * 4), 0.f, 0.f, 0.f);
+  }
 }
 
 template <int KS, int STRIDE, int FETCH, int NT, bool VEC, bool NARROW, bool IN2>
@@ -457,7 +478,8 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
   const long nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb;
   // resident workgroups per CU: 512 threads = 2 waves per SIMD each -> at most 2 within 256 registers per wave; LDS 160 KiB per CU
   const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));
-  const long nblocks = std::min<long>(nitems, (long)kNumCU * per_cu);
+  long nblocks = std::min<long>(nitems, (long)kNumCU * per_cu);
+  if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;      // every workgroup keeps one channel block: item % ncb == blockIdx % ncb
   dim3 grid((unsigned)nblocks), block(512);
   MS_LAUNCH((conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2>), grid, block, lds_bytes, st, a);
   return check_launch("conv_mfma");

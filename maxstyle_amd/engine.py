@@ -202,7 +202,7 @@ class InnerLoopEngine:
             parts = N * Ho * Wo           # only used as the element count by observers
         if stats:
             parts = lib.ms_conv_stats_parts(N, Ho, Wo)
-            st = self.t(name + ".stats", cout, parts, 4)
+            st = self.t(name + ".stats", cout * parts + 1, 4)
         pm, pa, pb, pc, in2 = 0, 0, 0, 0, None
         slope = 1.0
         if act is not None:

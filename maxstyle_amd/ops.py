@@ -164,7 +164,7 @@ def conv2d(x, wp, bias, Cout, ks, stride=1, fetch=FETCH_NORMAL, pro_mode=0, pro_
 
 def conv_stats_buffer(N, Cout, Ho, Wo, device):
     parts = lib.ms_conv_stats_parts(N, Ho, Wo)
-    return torch.empty(Cout, parts, 4, device=device, dtype=torch.float32), parts
+    return torch.empty(Cout * parts + 1, 4, device=device, dtype=torch.float32), parts
 
 
 def bn_finalize(stats, nparts, gamma, beta, eps=1e-5, out=None):
