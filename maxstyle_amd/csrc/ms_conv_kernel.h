@@ -36,7 +36,7 @@ struct ConvArgs {
   int dbg;                      // timing-only ablation bits (MS_CONV_DBG): 1 skip MFMA loop, 2 skip global loads, 4 skip epilogue
 };
 
-template <int KS, int STRIDE, bool VEC, bool NARROW, int NT>
+template <int KS, int STRIDE, int FETCH, bool VEC, bool NARROW, int NT>
 struct Geo {
   static constexpr int TW = NARROW ? 16 : 32;
   static constexpr int TH = NARROW ? 16 : 8;
@@ -48,11 +48,15 @@ struct Geo {
   static constexpr int RS = (STRIDE == 1) ? ((WIN_W + 3) / 4 * 4) : 2 * HALF;
   static constexpr int BASE = IH * RS;
   static constexpr int PS = BASE + ((16 - BASE % 32 + 32) % 32);           // plane stride == 16 (mod 32 banks)
+  // EXP: the LDS tile is the LOGICAL (2x up-sampled / zero-inserted) input, staged from 8-byte loads of the STORED tensor:
+  // one slot = 2 stored values = 4 logical columns (UPS2: both logical rows 2sr-1, 2sr; ZINS2: logical row 2sr+1, odd columns 0)
+  static constexpr bool EXP = VEC && (FETCH != FETCH_NORMAL);
   // input channels per K-chunk: sized so that two LDS buffers of (input tile + weight slice) leave >= 2 workgroups per CU
   static constexpr int CK = (STRIDE == 1 && VEC && NT == 1) ? 16 : ((STRIDE == 2 && NT > 1) ? 4 : 8);
-  static constexpr int VW = VEC ? 4 : 1;
-  static constexpr int ROW_ITEMS = WIN_W / VW;                              // VEC: WIN_W % 4 == 0 by construction
-  static constexpr int ITEMS = CK * IH * ROW_ITEMS;
+  static constexpr int VW = EXP ? 2 : (VEC ? 4 : 1);                       // elements per staging load
+  static constexpr int SR = EXP ? ((FETCH == FETCH_UPS2) ? IH / 2 + 1 : IH / 2) : IH;   // staged rows per channel
+  static constexpr int ROW_ITEMS = EXP ? WIN_W / 4 : WIN_W / VW;           // VEC: WIN_W % 4 == 0 by construction
+  static constexpr int ITEMS = CK * SR * ROW_ITEMS;
   static constexpr int NI = (ITEMS + 255) / 256;
   static constexpr int WS = (NT == 1) ? 16 : NT * 16 + 16;                 // weight row stride (bank-conflict-free B fragments)
   static constexpr int TAPS = KS * KS;
@@ -66,14 +70,15 @@ struct Geo {
 
 template <int KS, int STRIDE, int FETCH, int NT, bool VEC, bool NARROW, bool IN2>
 __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const ConvArgs a) {
-  using G = Geo<KS, STRIDE, VEC, NARROW, NT>;
+  using G = Geo<KS, STRIDE, FETCH, VEC, NARROW, NT>;
   constexpr int CK = G::CK, PS = G::PS, RS = G::RS, IH = G::IH, PAD = G::PAD, PADL = G::PADL, HALF = G::HALF;
-  constexpr int TW = G::TW, TH = G::TH, VW = G::VW, ROW_ITEMS = G::ROW_ITEMS, ITEMS = G::ITEMS, NI = G::NI;
+  constexpr int TW = G::TW, TH = G::TH, VW = G::VW, ROW_ITEMS = G::ROW_ITEMS, ITEMS = G::ITEMS, NI = G::NI, SR = G::SR;
+  constexpr bool EXP = G::EXP;
   constexpr int WS = G::WS, TAPS = G::TAPS, BUF = G::BUF;
   constexpr int COUT_TILE = 16 * NT;
   constexpr int WITEMS = TAPS * CK * (COUT_TILE / 4);
   constexpr int NWI = (WITEMS + 255) / 256;
-  static_assert(!VEC || FETCH == FETCH_NORMAL, "vector staging needs the plain fetch");
+  static_assert(!EXP || (KS == 3 && STRIDE == 1), "expanded staging is for the 3x3 stride-1 convolution");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // smem: [2][BUF] stage buffers (input tile [CK][PS] then weights [TAPS][CK][WS]) | [cin_pad][4] prologue coefficients
   float* cf_lds = smem + 2 * BUF;
@@ -89,6 +94,9 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };   // orders LDS only (no vmcnt drain)
   auto decode = [&](int it, int& n, int& tile, int& cb) { cb = it % ncb; const int t2 = it / ncb; tile = t2 % ntiles; n = t2 / ntiles; };
 
+  if constexpr (EXP && FETCH == FETCH_ZINS2) {
+    for (int i = threadIdx.x; i < 2 * BUF; i += 512) smem[i] = 0.f;     // rows / columns the staging never writes are the inserted zeros
+  }
   // per-channel prologue coefficients are constant for the whole launch: stage them once (per-plane mode reads global memory)
   if (a.pro_mode != 0 && a.pro_nstride == 0) {
     for (int c = threadIdx.x; c < a.cin_pad; c += 512) {
@@ -112,11 +120,18 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
       if (it < ITEMS) {
         const int f = it % ROW_ITEMS;
         const int row = it / ROW_ITEMS;
-        const int r = row % IH, c = row / IH;
-        const int w = f * VW;
-        const int q = (STRIDE == 1) ? w : ((w & 1) * HALF + (w >> 1));
-        s_lds[j] = (c << 20) | (c * PS + r * RS + q);
-        s_rw[j] = (r << 16) | w;
+        const int r = row % SR, c = row / SR;
+        if constexpr (EXP) {
+          // logical row of the slot's first LDS write: UPS2 rows (2r-1, 2r), ZINS2 row 2r+1; logical column 4f
+          const int lr = (FETCH == FETCH_UPS2) ? (2 * r - 1) : (2 * r + 1);
+          s_lds[j] = (c << 20) | (c * PS + (lr + 1) * RS + 4 * f);        // +1 row bias keeps the packed offset non-negative for lr = -1
+          s_rw[j] = (r << 16) | f;
+        } else {
+          const int w = f * VW;
+          const int q = (STRIDE == 1) ? w : ((w & 1) * HALF + (w >> 1));
+          s_lds[j] = (c << 20) | (c * PS + r * RS + q);
+          s_rw[j] = (r << 16) | w;
+        }
       }
     }
     auto set_tile = [&](int tile) {
@@ -125,12 +140,21 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
       const int wx0 = tx * TW * STRIDE - PADL;
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        const int Y = iy0 + (s_rw[j] >> 16), X = wx0 + (s_rw[j] & 0xFFFF);
-        bool ok = (s_lds[j] >= 0) && (Y >= 0) && (Y < a.Hin) && (X >= 0) && (X < a.Win);
-        int ys = Y, xs = X;
-        if (FETCH == FETCH_UPS2) { ys = Y >> 1; xs = X >> 1; }
-        if (FETCH == FETCH_ZINS2) { ok = ok && !((Y | X) & 1); ys = Y >> 1; xs = X >> 1; }
-        s_goff[j] = ok ? (ys * a.Ws + xs) : -1;
+        if constexpr (EXP) {
+          // stored coordinates of the slot's two values (tile origins are even, so the shifts are exact)
+          const int sr = s_rw[j] >> 16, f = s_rw[j] & 0xFFFF;
+          const int Ys = ((ty * TH) >> 1) + sr - ((FETCH == FETCH_UPS2) ? 1 : 0);
+          const int Xs = ((tx * TW) >> 1) - 2 + 2 * f;
+          const bool ok = (s_lds[j] >= 0) && (Ys >= 0) && (Ys < a.Hs) && (Xs >= 0) && (Xs < a.Ws);
+          s_goff[j] = ok ? (Ys * a.Ws + Xs) : -1;
+        } else {
+          const int Y = iy0 + (s_rw[j] >> 16), X = wx0 + (s_rw[j] & 0xFFFF);
+          bool ok = (s_lds[j] >= 0) && (Y >= 0) && (Y < a.Hin) && (X >= 0) && (X < a.Win);
+          int ys = Y, xs = X;
+          if (FETCH == FETCH_UPS2) { ys = Y >> 1; xs = X >> 1; }
+          if (FETCH == FETCH_ZINS2) { ok = ok && !((Y | X) & 1); ys = Y >> 1; xs = X >> 1; }
+          s_goff[j] = ok ? (ys * a.Ws + xs) : -1;
+        }
       }
     };
     float rin[NI][VW];
@@ -149,7 +173,15 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         okmask |= (ok ? 1u : 0u) << j;
         const bool ld = ok && !(a.dbg & 2);
         const size_t off = ld ? ((size_t)ci * in_plane + (size_t)s_goff[j]) : 0;
-        if constexpr (VEC) {
+        if constexpr (EXP) {
+          const float2 v = ld ? *reinterpret_cast<const float2*>(in_n + off) : make_float2(0.f, 0.f);
+          rin[j][0] = v.x; rin[j][1] = v.y;
+          if constexpr (IN2) {
+            const float* in2_n = a.in2 + (size_t)n * a.Cin * in_plane;
+            const float2 u = ld ? *reinterpret_cast<const float2*>(in2_n + off) : make_float2(0.f, 0.f);
+            rin2[j][0] = u.x; rin2[j][1] = u.y;
+          }
+        } else if constexpr (VEC) {
           const float4 v = ld ? *reinterpret_cast<const float4*>(in_n + off) : make_float4(0.f, 0.f, 0.f, 0.f);
           rin[j][0] = v.x; rin[j][1] = v.y; rin[j][2] = v.z; rin[j][3] = v.w;
           if constexpr (IN2) {
@@ -203,7 +235,17 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
           }
         }
         float* dst = in_lds + (s_lds[j] & 0xFFFFF);
-        if constexpr (VEC) {
+        if constexpr (EXP) {
+          dst -= RS;                                      // undo the +1 row bias: dst = logical row lr, column 4f
+          const int sr = s_rw[j] >> 16;
+          if constexpr (FETCH == FETCH_UPS2) {
+            const float4 e = make_float4(v[0], v[0], v[1], v[1]);
+            if (sr > 0) *reinterpret_cast<float4*>(dst) = e;                     // logical row 2sr-1
+            if (2 * sr < IH) *reinterpret_cast<float4*>(dst + RS) = e;           // logical row 2sr
+          } else {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], 0.f, v[1], 0.f);   // logical row 2sr+1; odd columns are inserted zeros
+          }
+        } else if constexpr (VEC) {
           if constexpr (STRIDE == 1) {
             *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
           } else {          // de-interleave even / odd columns (w % 4 == 0 -> even half at dst, odd half at dst+HALF)
@@ -467,7 +509,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
 
 template <int KS, int STRIDE, int FETCH, int NT, bool VEC, bool NARROW, bool IN2>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
-  using G = Geo<KS, STRIDE, VEC, NARROW, NT>;
+  using G = Geo<KS, STRIDE, FETCH, VEC, NARROW, NT>;
   const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * (size_t)a.cin_pad);
   if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
   static bool attr_set = false;
