@@ -120,6 +120,11 @@ int ms_act_bwd_parts(int N, int C, int HW);
 int ms_act_bwd_reduce(const float* gin, const float* ref, const float* u, const float* coef4, float* gout, float* part2,
                       int N, int C, int HW, float slope, void* stream);
 
+/* ms_act_bwd_reduce + ms_bn_bwd_coefs in ONE launch: the last workgroup of each channel finalises coef_out4 (agent-scope hand-off,
+ * no second kernel). arrive: int[C], zero before the first use (each launch re-arms it). */
+int ms_act_bwd_bn(const float* gin, const float* ref, const float* u, const float* coef4, float* gout, float* part2, int* arrive,
+                  float* coef_out4, int N, int C, int HW, float slope, void* stream);
+
 /* native_batch_norm_backward (input gradient only, batch statistics): du = al*g + be*u + de, coef_out4[c] = {al,be,de,0}
  * (SURVEY.md A.7).  count = N*H*W.  Feed coef_out4 to ms_conv2d(pro_mode=2) of the data-gradient convolution. */
 int ms_bn_bwd_coefs(const float* part2, int nparts, const float* coef4, double count, float* coef_out4, int C, void* stream);

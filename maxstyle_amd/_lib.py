@@ -47,6 +47,7 @@ SIGNATURES = {
     "ms_bn_act": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_int, c_int, c_int, c_float, c_void]),
     "ms_act_bwd_parts": (c_int, [c_int, c_int, c_int]),
     "ms_act_bwd_reduce": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_float, c_void]),
+    "ms_act_bwd_bn": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_void, c_f32p, c_int, c_int, c_int, c_float, c_void]),
     "ms_bn_bwd_coefs": (c_int, [c_f32p, c_int, c_f32p, ctypes.c_double, c_f32p, c_int, c_void]),
     "ms_pool2_sum": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_void]),
     "ms_head_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_void]),

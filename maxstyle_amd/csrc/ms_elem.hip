@@ -61,11 +61,16 @@ __global__ __launch_bounds__(kElemThreads) void bn_act_kernel(const float* __res
 // g = gin * (ref > 0 ? 1 : slope); partial sums of g and g*u per (plane, chunk) -> part[c][n*S+s]
 //   MASK 0: ref = the materialised activation output (sign(out) == sign(pre-activation))
 //   MASK 1: ref = sc[c]*u + sh[c]  (activation whose output was never materialised: folded into the next conv's prologue)
+typedef unsigned long long u64;
+
 template <int MASK>
 __global__ __launch_bounds__(kElemThreads) void act_bwd_reduce_kernel(const float* __restrict__ gin, const float* __restrict__ ref, const float* __restrict__ u,
                                                                       const float4* __restrict__ coef, float* __restrict__ gout, float2* __restrict__ part,
-                                                                      int C, int HW, int chunk, int S, int N, float slope) {
+                                                                      int C, int HW, int chunk, int S, int N, float slope,
+                                                                      int* __restrict__ arrive, float4* __restrict__ bcoef_out, double count) {
   __shared__ float red[16];
+  __shared__ double redd[16];
+  __shared__ int s_last;
   const int p = blockIdx.y, c = p % C, n = p / C;
   const float4 cf = coef[c];
   const int beg = blockIdx.x * chunk, end = min(HW, beg + chunk);
@@ -96,7 +101,40 @@ __global__ __launch_bounds__(kElemThreads) void act_bwd_reduce_kernel(const floa
   }
   s1 = block_sum(s1, red);
   s2 = block_sum(s2, red);
-  if (threadIdx.x == 0) part[(size_t)c * (N * S) + n * S + blockIdx.x] = make_float2(s1, s2);
+  if (arrive == nullptr) {
+    if (threadIdx.x == 0) part[(size_t)c * (N * S) + n * S + blockIdx.x] = make_float2(s1, s2);
+    return;
+  }
+  // Fused finalize ("last workgroup of the channel computes the BatchNorm-backward coefficients"): partials are published with
+  // 8-byte agent-scope (write-through) stores, the arrival is counted after s_waitcnt vmcnt(0), the last arriver reads them back
+  // with agent-scope loads and re-arms the counter for the next launch (MI355X_MICROARCH.md "Valid forms": 8-B atomics both sides).
+  const int nparts = N * S;
+  u64* slots = reinterpret_cast<u64*>(part) + (size_t)c * nparts;
+  if (threadIdx.x == 0) {
+    const u64 v = ((u64)__float_as_uint(s2) << 32) | (u64)__float_as_uint(s1);
+    __hip_atomic_store(slots + n * S + blockIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int prev = __hip_atomic_fetch_add(arrive + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (prev == nparts - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double a1 = 0.0, a2 = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kElemThreads) {
+    const u64 v = __hip_atomic_load(slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a1 += (double)__uint_as_float((unsigned)(v & 0xFFFFFFFFull));
+    a2 += (double)__uint_as_float((unsigned)(v >> 32));
+  }
+  a1 = block_sum_d(a1, redd);
+  a2 = block_sum_d(a2, redd);
+  if (threadIdx.x == 0) {
+    const double mean = cf.z, invstd = cf.w, sc = cf.x;
+    const double c1 = a1 / count;
+    const double c2 = (a2 - mean * a1) * invstd / count;
+    const double be = -sc * c2 * invstd;
+    bcoef_out[c] = make_float4((float)sc, (float)be, (float)(-sc * c1 - be * mean), 0.f);
+    __hip_atomic_store(arrive + c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // BatchNorm backward coefficients: du = sc*(g - mean(g) - uhat*mean(g*uhat)) = al*g + be*u + de
@@ -282,9 +320,23 @@ extern "C" int ms_act_bwd_reduce(const float* gin, const float* ref, const float
   const ElemSplit sp = elem_split(N * C, HW);
   dim3 grid(sp.S, N * C), block(kElemThreads);
   hipStream_t st = (hipStream_t)stream;
-  if (ref != nullptr) MS_LAUNCH(act_bwd_reduce_kernel<0>, grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope);
-  else MS_LAUNCH(act_bwd_reduce_kernel<1>, grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope);
+  if (ref != nullptr) MS_LAUNCH(act_bwd_reduce_kernel<0>, grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope, (int*)nullptr, (float4*)nullptr, 0.0);
+  else MS_LAUNCH(act_bwd_reduce_kernel<1>, grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope, (int*)nullptr, (float4*)nullptr, 0.0);
   return check_launch("act_bwd_reduce");
+}
+
+extern "C" int ms_act_bwd_bn(const float* gin, const float* ref, const float* u, const float* coef4, float* gout, float* part2, int* arrive,
+                             float* coef_out4, int N, int C, int HW, float slope, void* stream) {
+  if (N < 1 || C < 1 || HW < 1 || arrive == nullptr || coef_out4 == nullptr) { set_error("ms_act_bwd_bn: invalid argument"); return MS_ERR_INVALID; }
+  if ((long)N * C > 65535) { set_error("ms_act_bwd_bn: too many planes"); return MS_ERR_INVALID; }
+  if ((reinterpret_cast<uintptr_t>(part2) & 7u) != 0) { set_error("ms_act_bwd_bn: part2 must be 8-byte aligned"); return MS_ERR_ALIGN; }
+  const ElemSplit sp = elem_split(N * C, HW);
+  dim3 grid(sp.S, N * C), block(kElemThreads);
+  hipStream_t st = (hipStream_t)stream;
+  const double count = (double)N * HW;
+  if (ref != nullptr) MS_LAUNCH(act_bwd_reduce_kernel<0>, grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope, arrive, (float4*)coef_out4, count);
+  else MS_LAUNCH(act_bwd_reduce_kernel<1>, grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope, arrive, (float4*)coef_out4, count);
+  return check_launch("act_bwd_bn");
 }
 
 extern "C" int ms_bn_bwd_coefs(const float* part2, int nparts, const float* coef4, double count, float* coef_out4, int C, void* stream) {

@@ -170,6 +170,7 @@ class InnerLoopEngine:
         self.bn_eval = False          # True: BatchNorm uses running statistics (module.eval()); False: batch statistics
         self.bn_observer = None       # optional callback(bn: BNW, coef4, count) - running-statistics update of a tracking forward
         self.loss_sign = -1.0         # loss = loss_sign * cross_entropy_2D  (the inner loop maximises CE)
+        self.fuse_bn_bwd = False      # ms_act_bwd_bn (one launch) instead of ms_act_bwd_reduce + ms_bn_bwd_coefs
 
     # ------------------------------------------------------------------ buffers
     def t(self, name, *shape, dtype=F32):
@@ -242,15 +243,26 @@ class InnerLoopEngine:
         N, C, H, W = u.shape
         nparts = lib.ms_act_bwd_parts(N, C, H * W)
         part = self.t(name + ".part", C, nparts, 2)
-        check(lib.ms_act_bwd_reduce(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
-                                    N, C, H * W, slope, self._st()), "ms_act_bwd_reduce:" + name)
-        if self.bn_eval:                  # eval-mode BatchNorm is a fixed per-channel affine map: du = scale * g
-            bc = self.t(name + ".bcoef", C, 4)
+        bc = self.t(name + ".bcoef", C, 4)
+        if self.bn_eval:                  # eval-mode BatchNorm is a fixed per-channel affine map: du = scale * g (mask only, no statistics)
+            check(lib.ms_act_bwd_reduce(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
+                                        N, C, H * W, slope, self._st()), "ms_act_bwd_reduce:" + name)
             bc.zero_()
             bc[:, 0].copy_(coef[:, 0])
             return gin, bc
-        bc = self.t(name + ".bcoef", C, 4)
-        check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(N * H * W), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + name)
+        if not self.fuse_bn_bwd:
+            # two launches measured faster at C2 (254.8 vs 236.5 steps/s): the one-launch form puts an s_waitcnt vmcnt(0) + a returning
+            # atomic on every workgroup's tail (4096 workgroups per launch), which costs more than the ~5 us second launch saves
+            check(lib.ms_act_bwd_reduce(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
+                                        N, C, H * W, slope, self._st()), "ms_act_bwd_reduce:" + name)
+            check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(N * H * W), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + name)
+            return gin, bc
+        arrive = self.buf.get("bn.arrive")
+        if arrive is None:
+            arrive = torch.zeros(1024, dtype=torch.int32, device=self.dev)     # re-armed by every launch; stream order serialises its users
+            self.buf["bn.arrive"] = arrive
+        check(lib.ms_act_bwd_bn(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
+                                arrive.data_ptr(), bc.data_ptr(), N, C, H * W, slope, self._st()), "ms_act_bwd_bn:" + name)
         return gin, bc
 
     def pool2(self, name, x, out=None, accumulate=False):

@@ -132,6 +132,15 @@ def test_bn_backward_chain(dev):
     da = ops.conv2d(g, ops.pack_conv_weight_dgrad(w.to(dev)), None, C, 3, 1, pro_mode=2, pro_a=ops.coef_ptrs(bc)[0], pro_b=ops.coef_ptrs(bc)[1],
                     pro_c=ops.coef_ptrs(bc)[2], pro_cstride=4, in2=ug)
     assert rel(da, ar.grad) < 2e-5
+    # one-launch form (last workgroup of a channel finalises the coefficients), run twice: the counters re-arm themselves
+    from maxstyle_amd._lib import lib, check
+    arrive = torch.zeros(64, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        gq = dout.to(dev).clone(); bc2 = torch.empty(C, 4, device=dev); part2 = torch.empty(C, nparts, 2, device=dev)
+        check(lib.ms_act_bwd_bn(gq.data_ptr(), og.data_ptr(), ug.data_ptr(), coef.data_ptr(), gq.data_ptr(), part2.data_ptr(), arrive.data_ptr(),
+                                bc2.data_ptr(), N, C, H * W, 0.2, torch.cuda.current_stream().cuda_stream), "ms_act_bwd_bn")
+        assert rel(bc2[:, :3], bc[:, :3]) < 1e-6 and torch.equal(gq, g)
+        assert int(arrive.abs().sum()) == 0
     # un-materialised activation: mask from coef*u+shift
     z2 = F.leaky_relu(F.batch_norm(u.detach(), None, None, gamma.double(), beta.double(), True, 0.0, 1e-5), 0.2)
     g2, _, _ = ops.act_bwd_reduce(dout.to(dev), None, ug, coef, 0.2)
