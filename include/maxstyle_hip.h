@@ -132,6 +132,10 @@ int ms_bn_bwd_coefs(const float* part2, int nparts, const float* coef4, double c
 /* out[p,y,x] (+)= in[p,2y,2x]+in[p,2y,2x+1]+in[p,2y+1,2x]+in[p,2y+1,2x+1]: gradient of nn.UpsamplingNearest2d(2) */
 int ms_pool2_sum(const float* in, float* out, int planes, int Ho, int Wo, int accumulate, void* stream);
 
+/* cm[label*K + argmax(logits)] += 1 over all pixels (accumulates; zero cm first). Evaluation: common_utils/metrics.py:12-52 (confusion
+ * matrix), :216-218 (Dice = 2|A n B| / (|A|+|B|) per class, medpy.metric.binary.dc). K <= 4. */
+int ms_confusion(const float* logits, const int64_t* labels, unsigned long long* cm, int N, int K, int HW, void* stream);
+
 /* Heads (1x1 conv with K <= 4 outputs from C <= 64 channels; w is [K][C]):
  *   ms_head_fwd  out = sigmoid?(w h + b)         MyDecoder.final_conv + nn.Sigmoid (encoder_decoder.py:582,594)
  *   ms_head_bwd  dh = w^T (dout * out*(1-out))   (apply_sigmoid=0: dh = w^T dout)

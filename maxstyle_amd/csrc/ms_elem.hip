@@ -292,9 +292,35 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(const double* __restri
   if (threadIdx.x == 0) loss_out[slot_dev ? *slot_dev : 0] = (float)(s * scale);
 }
 
+// Confusion matrix of argmax(logits) vs labels for Dice / IoU (common_utils/metrics.py:12-52,134-245 use a numpy confusion matrix /
+// medpy.metric.binary.dc = 2|A n B| / (|A|+|B|)): per-block LDS histogram, one integer atomic per non-zero bin per block.
+__global__ __launch_bounds__(kElemThreads) void confusion_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                                unsigned long long* __restrict__ cm, int K, int HW) {
+  __shared__ unsigned int hist[kMaxHeadK * kMaxHeadK];
+  if (threadIdx.x < kMaxHeadK * kMaxHeadK) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int n = blockIdx.y;
+  const float* lp = logits + (size_t)n * K * HW;
+  for (int i = blockIdx.x * kElemThreads + threadIdx.x; i < HW; i += gridDim.x * kElemThreads) {
+    int best = 0; float bv = lp[i];
+    for (int k = 1; k < K; ++k) { const float v = lp[(size_t)k * HW + i]; if (v > bv) { bv = v; best = k; } }     // first maximum, as torch.argmax
+    const int lab = (int)labels[(size_t)n * HW + i];
+    if (lab >= 0 && lab < K) atomicAdd(&hist[lab * K + best], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < K * K && hist[threadIdx.x] != 0) atomicAdd(&cm[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
 }  // namespace ms
 
 using namespace ms;
+
+extern "C" int ms_confusion(const float* logits, const int64_t* labels, unsigned long long* cm, int N, int K, int HW, void* stream) {
+  if (N < 1 || K < 1 || K > kMaxHeadK || HW < 1 || N > 65535) { set_error("ms_confusion: unsupported shape (K <= %d)", kMaxHeadK); return MS_ERR_INVALID; }
+  dim3 grid(std::min(cdiv(HW, kElemThreads), 64), N);
+  MS_LAUNCH(confusion_kernel, grid, dim3(kElemThreads), 0, (hipStream_t)stream, logits, labels, cm, K, HW);
+  return check_launch("confusion");
+}
 
 extern "C" int ms_bn_act(const float* u, const float* coef4, const float* res, int res_mode, float* out, int N, int C, int H, int W, float slope, void* stream) {
   if (N < 1 || C < 1 || H < 1 || W < 1 || res_mode < 0 || res_mode > 2) { set_error("ms_bn_act: invalid argument"); return MS_ERR_INVALID; }

@@ -161,3 +161,24 @@ def test_eval_mode_prediction_and_running_stats(dev):
         ref = orc.decoder_forward(sd["segmentation_decoder"], zs, "NN", bn_mode="running")
     assert rel(logits, ref) < 1e-4
     assert all(m.training for m in S.model.values())
+
+
+def test_gpu_dice_and_confusion(dev):
+    """HIP confusion matrix / Dice == the oracle's label-based Dice (medpy.metric.binary.dc semantics)."""
+    from maxstyle_amd.metrics import runningScore
+    from oracle import maxstyle_oracle as orc
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(5, 4, 48, 40, generator=g)
+    lab = torch.randint(0, 4, (5, 48, 40), generator=g)
+    rs = runningScore(4, dev)
+    rs.update(lab.to(dev), logits.to(dev))
+    pred = logits.argmax(1)
+    cm = torch.zeros(4, 4, dtype=torch.int64)
+    for t, p_ in zip(lab.reshape(-1), pred.reshape(-1)):
+        cm[t, p_] += 1
+    assert torch.equal(rs.confusion_matrix().cpu(), cm)
+    np.testing.assert_allclose(rs.dice(), orc.dice_per_class(pred, lab, 4), atol=1e-12)
+    scores, iou = rs.get_scores()
+    assert abs(scores["Overall Acc"] - float((pred == lab).double().mean())) < 1e-12
+    rs.update(lab.to(dev), logits.to(dev))                     # accumulates
+    assert int(rs.confusion_matrix().sum()) == 2 * lab.numel()
