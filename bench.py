@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2, help="inner steps of the CPU-oracle sample")
+    ap.add_argument("--cpu-steps", type=int, default=5, help="inner steps of the CPU-oracle sample")
     ap.add_argument("--config", default="c2", choices=["c2", "c4"], help="c2: FCN_16 1x256x256 (the quoted metric); c4: FCN_64 3x320x320 (Prostate-shaped)")
     return ap.parse_args()
 

@@ -4,19 +4,20 @@
 //
 // The restyle of plane (b,c) needs the statistics of plane (perm[b],c) and - on the first call - the batch standard
 // deviation over all B planes of channel c, so a naive fusion needs a grid-wide barrier.  Here the dependency is kept
-// per CHANNEL: work units (channel c, sample b, chunk s) are handed out by a device-wide ticket counter in channel-major
-// order; a workgroup keeps its chunk of x in REGISTERS (up to 64 floats per thread), publishes the chunk's
-// (mean, M2) with an agent-scope store, bumps the channel's arrival counter, waits until the B*S units of its channel
-// have arrived, merges the channel's partials (Chan, fp64), computes its plane's affine coefficients and writes y from
-// registers.  HBM traffic = 4 B/element read + 4 B/element written = the algorithmic 8 B/element.
+// per CHANNEL: work units (channel c, sample b, chunk s) are numbered channel-major and workgroup w processes units
+// w, w+grid, ... in increasing order; it keeps its chunk of x in REGISTERS (up to 64 floats per thread), publishes the
+// chunk's (mean, M2) as two tagged 8-byte granules {tag, value} with agent-scope (write-through) stores, then polls the
+// granules of its channel's B*S units until every tag is set - the data IS the flag, one memory round trip -, merges the
+// partials (Chan, fp64), computes its plane's affine coefficients and writes y from registers.
+// HBM traffic = 4 B/element read + 4 B/element written = the algorithmic 8 B/element.
 //
-// Progress guarantee (no co-residency or dispatch-order assumption): tickets are issued in increasing order at
-// workgroup start, so every issued ticket belongs to a RUNNING workgroup; units of fully-issued channels never wait
-// before their arrival, hence always complete and free their slots; only the last, partially issued channel can have
-// waiters, and it gets the next tickets.  The grid must be able to hold one whole channel group (B*S units): enforced
-// on the host (else the three-kernel path of ms_style.hip is used).  Every spin is bounded (error word).
-// Inter-workgroup visibility follows the 8-byte agent-scope atomic store/load form (write-through sc1 stores, arrival
-// counter after s_waitcnt vmcnt(0), relaxed agent-scope polls): MI355X_MICROARCH.md "Valid forms".
+// Progress: the grid never exceeds the workgroups that fit the chip together (1 x 1024 threads or 4 x 256 threads per CU at
+// <= 96 VGPRs), and a workgroup only ever waits for units of its own channel, which are the current or an earlier unit of
+// other workgroups of the same launch (channel-major numbering + increasing processing order): the lowest unfinished channel
+// always has every unit either done or being loaded, so it completes and releases its waiters.  Every spin is bounded (error
+// word) - a mis-sized launch flags an error instead of hanging the GPU.  Visibility: 8-byte agent-scope atomics on both sides
+// (MI355X_MICROARCH.md "Valid forms", R2: the granule carries its own tag); the granule table is zeroed by a memset node
+// before every launch (tags start at 0, a published granule carries tag 1).
 #include <algorithm>
 #include "ms_common.h"
 #include "maxstyle_hip.h"
@@ -27,14 +28,17 @@ constexpr unsigned kSpinLimit = 1u << 22;
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ void publish_partial(u64* slot, float mean, float m2) {
-  const u64 v = ((u64)__float_as_uint(m2) << 32) | (u64)__float_as_uint(mean);
-  __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// granule = {tag (1 = published) : 32 | float bits : 32}; unit u owns granules 2u (mean) and 2u+1 (M2)
+__device__ __forceinline__ void publish_granule(u64* slot, float value) {
+  __hip_atomic_store(slot, ((u64)1 << 32) | (u64)__float_as_uint(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void read_partial(const u64* slot, float& mean, float& m2) {
-  const u64 v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  mean = __uint_as_float((unsigned)(v & 0xFFFFFFFFull));
-  m2 = __uint_as_float((unsigned)(v >> 32));
+__device__ __forceinline__ bool poll_granule(const u64* slot, float& value, int* err) {
+  for (unsigned spins = 0;; ++spins) {
+    const u64 v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((v >> 32) != 0) { value = __uint_as_float((unsigned)(v & 0xFFFFFFFFull)); return true; }
+    if (spins > kSpinLimit) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); value = 0.f; return false; }
+    __builtin_amdgcn_s_sleep(1);
+  }
 }
 
 template <int NV, int kFusedThreads>
@@ -47,16 +51,12 @@ __global__ __launch_bounds__(kFusedThreads) void style_fused_kernel(const float*
                                                                    int B, int C, int HW, int S, int chunk, float eps) {
   __shared__ float red[16];
   __shared__ double redd[16];
-  __shared__ int s_ticket;
   __shared__ float smu[256], ssig[256];
+  __shared__ float pmean[1024], pm2[1024];          // polled partials of the channel: B*S <= 512 units (host-checked)
   const int tid = threadIdx.x;
   const int G = B * S, total = C * G;
-  while (true) {
-    if (tid == 0) s_ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int t = s_ticket;
-    __syncthreads();
-    if (t >= total) break;
+  (void)arrive; (void)counter;
+  for (int t = blockIdx.x; t < total; t += gridDim.x) {
     const int c = t / G, r = t - c * G, b = r / S, s = r - b * S;
     const int p = b * C + c;
     const int beg = s * chunk, end = min(HW, beg + chunk);
@@ -81,23 +81,20 @@ __global__ __launch_bounds__(kFusedThreads) void style_fused_kernel(const float*
       }
     }
     m2 = block_sum(m2, red);
-    if (tid == 0) {
-      publish_partial(part + ((size_t)c * B + b) * S + s, mean_c, m2);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the partial has left this CU before the arrival is counted
-      __hip_atomic_fetch_add(arrive + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned spins = 0;
-      while (__hip_atomic_load(arrive + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
-        if (++spins > kSpinLimit) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        __builtin_amdgcn_s_sleep(2);
-      }
+    u64* gran = part + 2 * ((size_t)c * G);          // granules of channel c: unit (bb, ss) -> index 2*(bb*S+ss) (+1)
+    if (tid == 0) { publish_granule(gran + 2 * (b * S + s), mean_c); publish_granule(gran + 2 * (b * S + s) + 1, m2); }
+    // one thread per granule polls until it is published (our own two come back from memory as well)
+    for (int q = tid; q < 2 * G; q += kFusedThreads) {
+      float val;
+      poll_granule(gran + q, val, err);
+      if (q & 1) pm2[q >> 1] = val; else pmean[q >> 1] = val;
     }
     __syncthreads();
     // every plane of channel c: Chan-merge its S chunk partials (chunk sizes follow from the geometry)
     for (int bb = tid; bb < B; bb += kFusedThreads) {
       double nn = 0.0, mean = 0.0, mm2 = 0.0;
       for (int ss = 0; ss < S; ++ss) {
-        float pm, pq;
-        read_partial(part + ((size_t)c * B + bb) * S + ss, pm, pq);
+        const float pm = pmean[bb * S + ss], pq = pm2[bb * S + ss];
         const double cn = (double)(min(HW, (ss + 1) * chunk) - ss * chunk);
         chan_merge(nn, mean, mm2, cn, (double)pm, (double)pq);
       }
@@ -177,10 +174,10 @@ static FusedPlan fused_plan(int B, int C, int HW) {
   // workgroups that can certainly run together: one 1024-thread (or two 256-thread) workgroup(s) per CU at <= 96 VGPRs
   const int capacity = (threads == 1024) ? 256 : 512;
   if (G > capacity) return pl;
-  pl.grid = (int)std::min<long>((long)C * G, threads == 1024 ? 256L : 1024L);
+  pl.grid = (int)std::min<long>((long)C * G, threads == 1024 ? 256L : 1024L);   // never more than fit the chip together
   if (pl.grid < G) return pl;
-  pl.part_off = ((size_t)(4 + C) * sizeof(int) + 15) / 16 * 16;
-  pl.bytes = pl.part_off + (size_t)C * B * pl.S * sizeof(u64);
+  pl.part_off = 16;                                                     // [0] unused, [1] error word
+  pl.bytes = pl.part_off + 2 * (size_t)C * B * pl.S * sizeof(u64);      // two tagged granules per unit
   pl.ok = true;
   return pl;
 }
@@ -205,7 +202,7 @@ extern "C" int ms_style_fwd_fused(const float* x, float* y, float* mu, float* si
   if ((gamma_noise == nullptr) != (beta_noise == nullptr)) { set_error("ms_style_fwd_fused: gamma/beta noise must both be given"); return MS_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   // re-initialise every polled word on the stream before every launch (a memset node when captured into a graph)
-  hipError_t e = hipMemsetAsync(ws, 0, pl.part_off, st);
+  hipError_t e = hipMemsetAsync(ws, 0, pl.bytes, st);                  // header + every granule tag
   if (e != hipSuccess) { set_error("ms_style_fwd_fused: memset: %s", hipGetErrorString(e)); return (int)e; }
   int* hdr = (int*)ws;
   u64* part = (u64*)((char*)ws + pl.part_off);
