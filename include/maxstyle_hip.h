@@ -34,8 +34,9 @@ size_t ms_style_ws_bytes(int B, int C, int HW);
 int ms_style_moments(const float* x, float* mu, float* sig, int planes, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
 
 /* Per-plane affine coefficients  A = sig(1-l)+sig[perm]l + gamma_noise*gamma_std,  S = mu(1-l)+mu[perm]l + beta_noise*beta_std
- * with l = clamp(lmda,0,1).  compute_std != 0: gamma_std[c]=std_b(sig[:,c]), beta_std[c]=std_b(mu[:,c]) (unbiased) are
- * computed from mu/sig and stored (the reference caches them on the first forward), else they are read.
+ * with l = clamp(lmda,0,1).  compute_std bit 0: gamma_std[c]=std_b(sig[:,c]), beta_std[c]=std_b(mu[:,c]) (unbiased) are
+ * computed from mu/sig and stored (the reference caches them on the first forward), else they are read.  compute_std bit 1:
+ * l = lmda without the clamp (MixStyle: src/advanced/mixstyle.py:91-92).
  * lmda == NULL: no style mixing (mix_style=False); gamma_noise == beta_noise == NULL: no_noise=True.  maxstyle.py:165-185 */
 int ms_style_coeffs(float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std, const float* lmda,
                     const float* gamma_noise, const float* beta_noise, const int64_t* perm, float* coefA, float* coefS,

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void style_finalize_kernel(const PlanePartial*
   }
   __syncthreads();
   float gs, bs;
-  if (compute_std) {
+  if (compute_std & 1) {
     double am = 0.0, as = 0.0;
     for (int b = threadIdx.x; b < B; b += blockDim.x) { am += (double)smu[b]; as += (double)ssig[b]; }
     const double mean_mu = block_sum_d(am, redd) / B;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void style_finalize_kernel(const PlanePartial*
     const float m = smu[b], sg = ssig[b];
     float A = sg, Sh = m;
     if (lmda != nullptr) {
-      const float lam = fminf(fmaxf(lmda[b], 0.f), 1.f);
+      const float lam = (compute_std & 2) ? lmda[b] : fminf(fmaxf(lmda[b], 0.f), 1.f);     // bit 1: MixStyle (no clamp)
       const int pb = (int)perm[b];
       A = sg * (1.f - lam) + ssig[pb] * lam;
       Sh = m * (1.f - lam) + smu[pb] * lam;
@@ -323,7 +323,7 @@ extern "C" int ms_style_coeffs(float* mu, float* sig, float* gamma_std, float* b
                                const float* gamma_noise, const float* beta_noise, const int64_t* perm, float* coefA, float* coefS,
                                int B, int C, void* stream) {
   if (B < 1 || C < 1) { set_error("ms_style_coeffs: invalid shape"); return MS_ERR_INVALID; }
-  if (compute_std && B < 2) { set_error("ms_style_coeffs: batch std needs B >= 2"); return MS_ERR_INVALID; }
+  if ((compute_std & 1) && B < 2) { set_error("ms_style_coeffs: batch std needs B >= 2"); return MS_ERR_INVALID; }
   if (lmda != nullptr && perm == nullptr) { set_error("ms_style_coeffs: mixing needs perm"); return MS_ERR_INVALID; }
   if ((gamma_noise == nullptr) != (beta_noise == nullptr)) { set_error("ms_style_coeffs: gamma/beta noise must both be given"); return MS_ERR_INVALID; }
   MS_LAUNCH(style_finalize_kernel, dim3(C), dim3(256), 2 * B * sizeof(float), (hipStream_t)stream, (const PlanePartial*)nullptr, mu, sig,
@@ -364,7 +364,7 @@ extern "C" int ms_style_fwd_3k(const float* x, float* y, float* mu, float* sig, 
                                const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
                                float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream) {
   if (int e = check_style_args(B, C, HW, ws, ws_bytes)) return e;
-  if (compute_std && B < 2) { set_error("ms_style_fwd: batch std needs B >= 2"); return MS_ERR_INVALID; }
+  if ((compute_std & 1) && B < 2) { set_error("ms_style_fwd: batch std needs B >= 2"); return MS_ERR_INVALID; }
   if (lmda != nullptr && perm == nullptr) { set_error("ms_style_fwd: mixing needs perm"); return MS_ERR_INVALID; }
   if ((gamma_noise == nullptr) != (beta_noise == nullptr)) { set_error("ms_style_fwd: gamma/beta noise must both be given"); return MS_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;

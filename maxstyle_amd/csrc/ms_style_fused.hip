@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kFusedThreads) void style_fused_kernel(const float*
     }
     __syncthreads();
     float gs, bs;
-    if (compute_std) {
+    if (compute_std & 1) {
       double am = 0.0, as = 0.0;
       for (int bb = tid; bb < B; bb += kFusedThreads) { am += (double)smu[bb]; as += (double)ssig[bb]; }
       const double mean_mu = block_sum_d(am, redd) / B;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kFusedThreads) void style_fused_kernel(const float*
     const float m = smu[b], sg = ssig[b];
     float A = sg, Sh = m;
     if (lmda != nullptr) {
-      const float lam = fminf(fmaxf(lmda[b], 0.f), 1.f);
+      const float lam = (compute_std & 2) ? lmda[b] : fminf(fmaxf(lmda[b], 0.f), 1.f);     // bit 1: MixStyle (no clamp)
       const int pb = (int)perm[b];
       A = sg * (1.f - lam) + ssig[pb] * lam;
       Sh = m * (1.f - lam) + smu[pb] * lam;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kFusedThreads) void style_fused_kernel(const float*
     }
     if (tid == 0 && s == 0) {
       mu[p] = m; sig[p] = sg; coefA[p] = A; coefS[p] = Sh;
-      if (b == 0 && compute_std) { gamma_std[c] = gs; beta_std[c] = bs; }
+      if (b == 0 && (compute_std & 1)) { gamma_std[c] = gs; beta_std[c] = bs; }
     }
     const float a = A / sg;
     float* yp = y + (size_t)p * HW;

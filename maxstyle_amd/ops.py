@@ -64,7 +64,7 @@ def style_moments(x, eps=1e-6):
 def style_fwd(x, perm, lmda, gamma_noise, beta_noise, gamma_std, beta_std, compute_std, eps=1e-6, out=None, impl=None):
     """Returns y, mu, sig, coefA, coefS. gamma_std/beta_std are [1,C,1,1] buffers (written if compute_std).
     impl: None = library dispatch, "fused" = single-read kernel, "3k" = three-launch path."""
-    _need_cuda_f32(x, lmda, gamma_noise, beta_noise, gamma_std, beta_std)
+    _need_cuda_f32(x, lmda, gamma_noise, beta_noise, gamma_std, beta_std)      # compute_std: bool, or the flag word (bit 0 std, bit 1 no clamp)
     B, C = x.shape[:2]
     HW = x[0, 0].numel()
     dev = x.device
@@ -74,7 +74,7 @@ def style_fwd(x, perm, lmda, gamma_noise, beta_noise, gamma_std, beta_std, compu
     ws = style_ws(B, C, HW, dev)
     fn = {None: lib.ms_style_fwd, "fused": lib.ms_style_fwd_fused, "3k": lib.ms_style_fwd_3k}[impl]
     check(fn(x.data_ptr(), y.data_ptr(), mu.data_ptr(), sig.data_ptr(), gamma_std.data_ptr(), beta_std.data_ptr(),
-             1 if compute_std else 0, _ptr(lmda), _ptr(gamma_noise), _ptr(beta_noise), _ptr(perm),
+             int(compute_std), _ptr(lmda), _ptr(gamma_noise), _ptr(beta_noise), _ptr(perm),
              cA.data_ptr(), cS.data_ptr(), B, C, HW, eps, ws.data_ptr(), ws.numel(), _stream()), "ms_style_fwd")
     return y, mu, sig, cA, cS
 

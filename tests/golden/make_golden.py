@@ -90,6 +90,36 @@ def layer_case(MaxStyle, B, C, H, W, seed, dtype, lmda_outside=False, mix_style=
     return res
 
 
+def mixstyle_cases():
+    """Reference MixStyle / DSU (src/advanced/mixstyle.py) with its RNG draws replayed and recorded."""
+    ref_harness.install()
+    from src.advanced.mixstyle import MixStyle as RefMix
+    out = {}
+    for tag, mix, lm in (("random", "random", None), ("cross", "crossdomain", None), ("extrap", "random", 1.7), ("dsu", "gaussian", None)):
+        B, C, H, W = 6, 5, 12, 10
+        g = torch.Generator().manual_seed(21)
+        x = torch.randn(B, C, H, W, generator=g) * 0.7 + torch.randn(B, C, 1, 1, generator=g)
+        dy = torch.randn(B, C, H, W, generator=g)
+        layer = RefMix(p=1.0, alpha=0.1, mix=mix, lmda=lm)
+        torch.manual_seed(5)
+        xr = x.clone().requires_grad_(True)
+        y = layer(xr)
+        y.backward(dy)
+        # replay the draws in the reference's order to record them
+        torch.manual_seed(5)
+        torch.rand(1)
+        rec = {}
+        if lm is None:
+            rec["lmda"] = layer.beta.sample((B, 1, 1, 1)).numpy()
+        if mix == "gaussian":
+            rec["gaussian_mu"] = torch.randn(B, C, 1, 1).numpy(); rec["gaussian_std"] = torch.randn(B, C, 1, 1).numpy()
+        else:
+            rec["perm"] = layer.perm.numpy()
+        out.update({f"{tag}.x": x.numpy(), f"{tag}.dy": dy.numpy(), f"{tag}.y": y.detach().numpy(), f"{tag}.dx": xr.grad.numpy()})
+        out.update({f"{tag}.{k}": v for k, v in rec.items()})
+    return out
+
+
 def build_reference_solver(solver_mod, spec: orc.NetSpec, dtype):
     net = "FCN_16_standard_no_STN" if spec.reduce == 4 else "FCN_64_standard_no_STN"
     import io, contextlib
@@ -222,6 +252,8 @@ def main():
         for k, v in layer_case(MaxStyle, **kw).items():
             layer[f"{tag}.{k}"] = v
     np.savez_compressed(os.path.join(out_dir, "layer_cases.npz"), **layer)
+
+    np.savez_compressed(os.path.join(out_dir, "mixstyle_cases.npz"), **mixstyle_cases())
 
     spec16 = orc.NetSpec(4, 1, 4)
     # config 1 of BASELINE.json: B=4, 1x128x128, 1 layer, 1 inner step

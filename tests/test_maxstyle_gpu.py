@@ -185,3 +185,24 @@ def test_fused_single_read_equals_three_kernel(dev, shape):
     assert torch.equal(y_a, y_b)
     ws = ops.style_ws(B, C, H * W, dev)
     assert int(ws[:8].view(torch.int32)[1]) == 0, "bounded spin timed out (error word set)"
+
+
+@pytest.mark.parametrize("tag,mix,lm", [("random", "random", None), ("cross", "crossdomain", None), ("extrap", "random", 1.7), ("dsu", "gaussian", None)])
+def test_mixstyle_dsu_vs_reference_golden(golden_dir, dev, tag, mix, lm):
+    """MixStyle / DSU baselines (src/advanced/mixstyle.py:44-108) on the K1/K2 kernels; same seed -> same CPU-generator draws as the reference."""
+    from maxstyle_amd import MixStyle
+    g = np.load(os.path.join(golden_dir, "mixstyle_cases.npz"))
+    x = torch.from_numpy(g[f"{tag}.x"]).to(dev).requires_grad_(True)
+    layer = MixStyle(p=1.0, alpha=0.1, mix=mix, lmda=lm)
+    if mix == "gaussian":
+        layer._inject_noise = (torch.from_numpy(g["dsu.gaussian_mu"]), torch.from_numpy(g["dsu.gaussian_std"]))
+    torch.manual_seed(5)
+    y = layer(x)
+    y.backward(torch.from_numpy(g[f"{tag}.dy"]).to(dev))
+    if mix != "gaussian":
+        np.testing.assert_array_equal(layer.get_perm().numpy(), g[f"{tag}.perm"])
+    assert rel(y, g[f"{tag}.y"]) < 1e-5
+    assert rel(x.grad, g[f"{tag}.dx"]) < 2e-5
+    off = MixStyle(p=-1.0)
+    xx = torch.randn(4, 3, 5, 5, device=dev)
+    assert off(xx) is xx
