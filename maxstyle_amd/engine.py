@@ -72,6 +72,15 @@ class ConvW:
             self.dwp = ops.pack_convT_weight_dgrad(w)
         self.b = None if b is None else b.detach().float().contiguous()
 
+    def update_(self, w, b):
+        """Re-pack new weight values into the SAME device buffers (captured HIP graphs keep their addresses)."""
+        if self.kind == "conv":
+            self.wp.copy_(ops.pack_conv_weight(w)); self.dwp.copy_(ops.pack_conv_weight_dgrad(w))
+        else:
+            self.wp.copy_(ops.pack_convT_weight(w)); self.dwp.copy_(ops.pack_convT_weight_dgrad(w))
+        if self.b is not None:
+            self.b.copy_(b.detach().float())
+
 
 class BNW:
     """BatchNorm2d parameters; coef_eval/bcoef_eval are the eval-mode (running statistics) forward/backward coefficients."""
@@ -87,6 +96,15 @@ class BNW:
             sc = self.gamma * invstd
             self.coef_eval = torch.stack([sc, self.beta - rm.detach().float() * sc, rm.detach().float(), invstd], dim=1).contiguous()
             self.bcoef_eval = torch.stack([sc, torch.zeros_like(sc), torch.zeros_like(sc), torch.zeros_like(sc)], dim=1).contiguous()
+
+    def update_(self, sd):
+        self.gamma.copy_(sd[self.name + ".weight"].detach().float()); self.beta.copy_(sd[self.name + ".bias"].detach().float())
+        rm, rv = sd.get(self.name + ".running_mean"), sd.get(self.name + ".running_var")
+        if self.coef_eval is not None and rm is not None:
+            invstd = torch.rsqrt(rv.detach().float() + BN_EPS)
+            sc = self.gamma * invstd
+            self.coef_eval.copy_(torch.stack([sc, self.beta - rm.detach().float() * sc, rm.detach().float(), invstd], dim=1))
+            self.bcoef_eval[:, 0].copy_(sc)
 
 
 class PackedNets:
@@ -104,6 +122,43 @@ class PackedNets:
             self.seg = self._pack_decoder(seg_sd, False, cv)
         if dec_sd is not None:
             self.dec = self._pack_decoder(dec_sd, True, cv)
+
+    def update_(self, enc_sd=None, seg_sd=None, dec_sd=None):
+        """In-place refresh after an optimiser step on the networks: same buffers, new values (graphs stay valid)."""
+        for table, sd, names in ((self.enc, enc_sd, self._enc_names), (self.seg, seg_sd, self._dec_names(False)), (self.dec, dec_sd, self._dec_names(True))):
+            if table is None or sd is None:
+                continue
+            for key, src in names.items():
+                obj = table.get(key)
+                if obj is None:
+                    continue
+                if isinstance(obj, ConvW):
+                    obj.update_(sd[src + ".weight"], sd.get(src + ".bias"))
+                elif isinstance(obj, BNW):
+                    obj.update_(sd)
+            if "head.w" in table:
+                w = sd["final_conv.weight"].detach().float()
+                table["head.w"].copy_(w.reshape(w.shape[0], w.shape[1])); table["head.b"].copy_(sd["final_conv.bias"].detach().float())
+
+    @property
+    def _enc_names(self):
+        g = "general_encoder."
+        n = {"inc0": g + "inc.0", "inc1": g + "inc.1", "inc3": g + "inc.3", "inc4": g + "inc.4", "fc0": g + "final_conv.0", "fc1": g + "final_conv.1",
+             "cd0": "code_decoupler.0", "cd1": "code_decoupler.1", "cd3": "code_decoupler.3", "cd4": "code_decoupler.4"}
+        for i in range(1, 5):
+            p = g + f"down{i}."
+            n.update({f"d{i}.down": p + "down", f"d{i}.c0": p + "conv.0", f"d{i}.bn1": p + "conv.1", f"d{i}.c3": p + "conv.3", f"d{i}.bn4": p + "conv.4",
+                      f"d{i}.ci": p + "conv_input"})
+        return n
+
+    @staticmethod
+    def _dec_names(conv_t):
+        n = {}
+        for i in range(1, 5):
+            p = f"up{i}."
+            n.update({f"u{i}.up": p + "up", f"u{i}.c0": p + "conv.0", f"u{i}.bn1": p + "conv.1", f"u{i}.c3": p + "conv.3", f"u{i}.bn4": p + "conv.4",
+                      f"u{i}.ci": p + "conv_input"})
+        return n
 
     @staticmethod
     def _pack_encoder(enc_sd, g, cv):

@@ -170,10 +170,16 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         spec = E.NetSpec(self.reduce_factor, self.image_ch, self.num_classes)
         if self._packed_key != key:
             sd = {k: {n: v.detach() for n, v in m.state_dict().items()} for k, m in self.model.items()}
-            self._packed = E.PackedNets(spec, sd['image_encoder'], sd['segmentation_decoder'], sd['image_decoder'])
+            if self._packed is None:
+                self._packed = E.PackedNets(spec, sd['image_encoder'], sd['segmentation_decoder'], sd['image_decoder'])
+                for eng in self._engines.values():
+                    eng.set_nets(self._packed)
+            else:
+                # the optimiser moved the weights: refresh the packed copies IN PLACE so captured HIP graphs stay valid
+                self._packed.update_(sd['image_encoder'], sd['segmentation_decoder'], sd['image_decoder'])
+                for eng in self._engines.values():
+                    eng._prefix_valid = False
             self._packed_key = key
-            for eng in self._engines.values():
-                eng.set_nets(self._packed)
         ek = (B, H, W, str(dev))
         eng = self._engines.get(ek)
         if eng is None:

@@ -182,3 +182,67 @@ def test_gpu_dice_and_confusion(dev):
     assert abs(scores["Overall Acc"] - float((pred == lab).double().mean())) < 1e-12
     rs.update(lab.to(dev), logits.to(dev))                     # accumulates
     assert int(rs.confusion_matrix().sum()) == 2 * lab.numel()
+
+
+def test_weight_update_keeps_graph_and_matches_fresh_pack(dev):
+    """After an (emulated) optimiser step the packed weights are refreshed in place: the captured graph is reused and the result equals
+    a freshly built solver with the new weights, bit for bit."""
+    from oracle import maxstyle_oracle as orc
+    spec = orc.NetSpec(4, 1, 4)
+    S, W = make_solver(dev, spec)
+    img, lab = orc.synthetic_batch(4, 64, 1, 4, 1234)
+    layers = [3, 4, 5]
+    styles = {i: orc.random_style_state(4, spec.channel_num[i], 7 + i) for i in layers}
+    S.style_init_hook = injector(styles, dev)
+    z_i, _ = S.encode_image(img.to(dev), disable_track_bn_stats=True)
+    kw = dict(p=1.5, n_iter=3, lr=0.1, reference_image=img.to(dev), reference_segmentation=lab.to(dev))
+    S.generate_max_style_image(z_i, layers, spec.channel_num, **kw)
+    eng = next(iter(S._engines.values()))
+    graph = eng._graph
+    assert graph is not None
+    with torch.no_grad():                                   # "optimiser step": perturb every parameter
+        for m in S.model.values():
+            for p_ in m.parameters():
+                p_.mul_(1.01).add_(0.001)
+    out = S.generate_max_style_image(z_i, layers, spec.channel_num, **kw)
+    assert eng._graph is graph, "graph must survive a weight update"
+    S2, _ = make_solver(dev, spec)
+    for name in S.model:
+        S2.model[name].load_state_dict(S.model[name].state_dict())
+    S2.style_init_hook = injector(styles, dev)
+    ref = S2.generate_max_style_image(z_i, layers, spec.channel_num, **kw)
+    assert torch.equal(out, ref)
+
+
+def test_ragged_shapes_one_step_vs_oracle(dev):
+    """Non-square image, odd batch, layers [2,4]: one loss/gradient evaluation vs the fp64 oracle."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_engine_gpu import build_engine
+    from oracle import maxstyle_oracle as orc
+    from maxstyle_amd import engine as E
+    spec = orc.NetSpec(4, 1, 4)
+    B, H, Wd, layers = 5, 48, 80, [2, 4]
+    W = orc.procedural_weights(spec, 0)
+    to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
+    eng = E.InnerLoopEngine(E.NetSpec(4, 1, 4), B, H, Wd, dev)
+    eng.set_nets(E.PackedNets(E.NetSpec(4, 1, 4), to(W["image_encoder"]), to(W["segmentation_decoder"]), to(W["image_decoder"])))
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(B, 1, H, Wd, generator=g)
+    lab = torch.randint(0, 4, (B, H, Wd), generator=g)
+    styles = {i: orc.random_style_state(B, spec.channel_num[i], 11 + i) for i in layers}
+    eng.configure_styles(layers, {i: E.StyleSlot(i, B, spec.channel_num[i]) for i in layers})
+    for i in layers:
+        st = styles[i]
+        eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
+    W64 = {k: {n: (t.double() if t.is_floating_point() else t) for n, t in sd.items()} for k, sd in W.items()}
+    with torch.no_grad():
+        z_i = orc.encoder_forward(W64["image_encoder"], img.double())[0]
+    recon, loss, grads = orc.inner_step_grads(W64, z_i, {i: s.clone(torch.float64) for i, s in styles.items()}, layers, lab)
+    eng.code = z_i.float().to(dev)
+    img_g, loss_g = eng.step_grads(lab.to(dev))
+    assert rel(img_g, recon) < 1e-4
+    assert abs(float(loss_g) - loss) < 1e-4 * abs(loss)
+    for n, gr in grads.items():
+        i, nm = n.split(".")
+        assert rel(eng.grad(int(i), nm), gr) < 0.1, n
