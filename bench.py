@@ -143,16 +143,24 @@ def kernel_rooflines(eng, z_i, lab_d, dev):
         ts = sorted(s.elapsed_time(e) for s, e in evs)
         out[name] = ts[len(ts) // 2] * 1e-3    # median seconds per launch (group of launches for the style op)
     n_elem = x.numel()
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; tools/pmc_traffic.py)
+    traffic = {}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if (B, H, W) == (16, 256, 256):
+            traffic = tj
+    except Exception:  # noqa: BLE001
+        traffic = {}
     conv_flops = 2.0 * B * H * W * cw.cout * cw.cin * 9
     conv_bytes = 2.0 * n_elem * 4
     return {
         "conv": {"bound": "mfma", "achieved": conv_flops / out["conv3x3_c16_256"] / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": conv_flops / out["conv3x3_c16_256"] / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                 "frac": conv_flops / out["conv3x3_c16_256"] / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": traffic.get("conv3x3_c16_256"),
                  "kernel": "conv_mfma_kernel<3,1,0,1> 16->16 @%dx%dx%d" % (B, H, W), "us_per_launch": out["conv3x3_c16_256"] * 1e6,
                  "hbm_GBps": conv_bytes / out["conv3x3_c16_256"] / 1e9},
         "style": {"bound": "hbm", "achieved": 8.0 * n_elem / out["maxstyle_fwd_l4"] / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                  "frac": 8.0 * n_elem / out["maxstyle_fwd_l4"] / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                  "kernel": "ms_style_fwd (moments_partial+style_finalize+restyle) 16x16x%dx%d" % (H, W), "us_per_launch": out["maxstyle_fwd_l4"] * 1e6},
+                  "frac": 8.0 * n_elem / out["maxstyle_fwd_l4"] / 1e9 / HBM_PEAK_GBPS, "traffic": traffic.get("maxstyle_fwd_l4"),
+                  "kernel": "ms_style_fwd -> style_fused_kernel<16,1024> (single read) 16x16x%dx%d" % (H, W), "us_per_launch": out["maxstyle_fwd_l4"] * 1e6},
     }
 
 

@@ -21,6 +21,7 @@ def timeit(fn, iters=50, warmup=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--only", default=None, help="comma-separated layer names (L3,L4,L5,C4_L4)")
     args = ap.parse_args()
     from maxstyle_amd import MaxStyle, ops
     dev = torch.device("cuda:0")
@@ -29,7 +30,10 @@ def main():
     a = torch.empty(64 * 1024 * 1024, device=dev); b = torch.empty_like(a)
     t = timeit(lambda: b.copy_(a), args.iters)
     out["copy_256MB_GBps"] = 2 * a.numel() * 4 / t / 1e9
-    for name, shape in {"L3": (16, 16, 128, 128), "L4": (16, 16, 256, 256), "L5": (16, 1, 256, 256), "C4_L4": (16, 64, 320, 320)}.items():
+    shapes = {"L3": (16, 16, 128, 128), "L4": (16, 16, 256, 256), "L5": (16, 1, 256, 256), "C4_L4": (16, 64, 320, 320)}
+    if args.only:
+        shapes = {k: v for k, v in shapes.items() if k in args.only.split(",")}
+    for name, shape in shapes.items():
         B, C, H, W = shape
         x = torch.randn(shape, device=dev)
         dy = torch.randn(shape, device=dev)
