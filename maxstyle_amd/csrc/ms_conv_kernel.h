@@ -89,7 +89,11 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   const int ncb = a.ncb;
   const int nitems = a.N * ntiles * ncb;
   const int nchunks = (a.cin_pad + CK - 1) / CK;
-  const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1 (grid <= nitems)
+  // XCD-aware numbering: hardware deals workgroups round-robin over the 8 XCDs (b and b+8 share one), so give XCD x the contiguous
+  // run [x*grid/8, (x+1)*grid/8) of every round - neighbouring tiles (shared halo rows/columns, shared weights) then meet in ONE L2.
+  // Speed only: any placement computes the same result.
+  const int vb = ((int)gridDim.x % 8 == 0) ? (((int)blockIdx.x % 8) * ((int)gridDim.x / 8) + (int)blockIdx.x / 8) : (int)blockIdx.x;
+  const int my_items = (nitems - vb + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1 (grid <= nitems)
   const int T = my_items * nchunks;                       // (item, chunk) iterations of this workgroup
   auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };   // orders LDS only (no vmcnt drain)
   auto decode = [&](int it, int& n, int& tile, int& cb) { cb = it % ncb; const int t2 = it / ncb; tile = t2 % ntiles; n = t2 / ntiles; };
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
     // iteration p (chunk index in this workgroup's sequence): registers hold chunk p; written to buffer p&1.
     // key_*[b]: which weight slice (cb, c0) buffer b holds -> skip the rewrite when it repeats (single-chunk layers)
     int key_cb[2] = {-1, -1}, key_c0[2] = {-1, -1};
-    int item = blockIdx.x, chunk = 0, n, tile, cb, tile_set = -1;
+    int item = vb, chunk = 0, n, tile, cb, tile_set = -1;
     decode(item, n, tile, cb);
     set_tile(tile); tile_set = tile;
     load_chunk(n, cb * COUT_TILE, 0, true);
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
       for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  int item = blockIdx.x, chunk = 0, n, tile, cb;
+  int item = vb, chunk = 0, n, tile, cb;
   decode(item, n, tile, cb);
   load_bias(cb * COUT_TILE);
   lds_barrier();                                      // barrier #0
@@ -496,14 +500,14 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   if (a.stats != nullptr) {
     // table layout: [0] = {slots in use per channel}, then [1 + co*kStatSlots + slot]; slot = (workgroup index within its channel block)*4 + wave
     float4* tab = reinterpret_cast<float4*>(a.stats);
-    const int cb0 = (int)blockIdx.x % ncb;
-    const int slot = ((int)blockIdx.x / ncb) * 4 + wave;
+    const int cb0 = vb % ncb;
+    const int slot = (vb / ncb) * 4 + wave;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int co = cb0 * COUT_TILE + j * 16 + m;
       if (k == 0 && co < a.Cout) tab[1 + (size_t)co * kStatSlots + slot] = make_float4(st_n, st_mean[j], st_m2[j], 0.f);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) tab[0] = make_float4((float)(((int)gridDim.x / ncb) * 4), 0.f, 0.f, 0.f);
+    if (vb == 0 && threadIdx.x == 0) tab[0] = make_float4((float)(((int)gridDim.x / ncb) * 4), 0.f, 0.f, 0.f);
   }
 }
 
