@@ -133,6 +133,10 @@ int ms_bn_bwd_coefs(const float* part2, int nparts, const float* coef4, double c
 /* out[p,y,x] (+)= in[p,2y,2x]+in[p,2y,2x+1]+in[p,2y+1,2x]+in[p,2y+1,2x+1]: gradient of nn.UpsamplingNearest2d(2) */
 int ms_pool2_sum(const float* in, float* out, int planes, int Ho, int Wo, int accumulate, void* stream);
 
+/* Per-plane min-max rescale y = (x - min)/(max - min + eps)*(new_max - new_min) + new_min: rescale_intensity
+ * (common_utils/basic_operations.py:257-281), applied to the stylised image right after the path (advanced_triplet...py:868-869). */
+int ms_rescale_intensity(const float* x, float* y, int planes, int HW, float new_min, float new_max, float eps, void* stream);
+
 /* cm[label*K + argmax(logits)] += 1 over all pixels (accumulates; zero cm first). Evaluation: common_utils/metrics.py:12-52 (confusion
  * matrix), :216-218 (Dice = 2|A n B| / (|A|+|B|) per class, medpy.metric.binary.dc). K <= 4. */
 int ms_confusion(const float* logits, const int64_t* labels, unsigned long long* cm, int N, int K, int HW, void* stream);

@@ -311,9 +311,32 @@ __global__ __launch_bounds__(kElemThreads) void confusion_kernel(const float* __
   if (threadIdx.x < K * K && hist[threadIdx.x] != 0) atomicAdd(&cm[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
 }
 
+// per-plane min-max rescale (common_utils/basic_operations.py:257-281): y = (x - min) / (max - min + eps) * (hi - lo) + lo
+__global__ __launch_bounds__(1024) void rescale_intensity_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, float lo, float hi, float eps) {
+  __shared__ float smin[16], smax[16];
+  const float* xp = x + (size_t)blockIdx.x * HW;
+  float* yp = y + (size_t)blockIdx.x * HW;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = threadIdx.x; i < HW; i += 1024) { const float v = xp[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off, 64)); mx = fmaxf(mx, __shfl_xor(mx, off, 64)); }
+  if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  mn = smin[0]; mx = smax[0];
+  for (int w = 1; w < 16; ++w) { mn = fminf(mn, smin[w]); mx = fmaxf(mx, smax[w]); }
+  const float den = mx - mn + eps, span = hi - lo;
+  for (int i = threadIdx.x; i < HW; i += 1024) yp[i] = (xp[i] - mn) / den * span + lo;
+}
+
 }  // namespace ms
 
 using namespace ms;
+
+extern "C" int ms_rescale_intensity(const float* x, float* y, int planes, int HW, float new_min, float new_max, float eps, void* stream) {
+  if (planes < 1 || HW < 1) { set_error("ms_rescale_intensity: invalid shape"); return MS_ERR_INVALID; }
+  MS_LAUNCH(rescale_intensity_kernel, dim3(planes), dim3(1024), 0, (hipStream_t)stream, x, y, HW, new_min, new_max, eps);
+  return check_launch("rescale_intensity");
+}
 
 extern "C" int ms_confusion(const float* logits, const int64_t* labels, unsigned long long* cm, int N, int K, int HW, void* stream) {
   if (N < 1 || K < 1 || K > kMaxHeadK || HW < 1 || N > 65535) { set_error("ms_confusion: unsupported shape (K <= %d)", kMaxHeadK); return MS_ERR_INVALID; }

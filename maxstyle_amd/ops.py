@@ -245,3 +245,17 @@ def head_ce(h, w, b, labels, loss_sign=1.0, need_dh=True, need_logits=False, dh=
     check(lib.ms_head_ce(h.data_ptr(), w.data_ptr(), _ptr(b), labels.data_ptr(), _ptr(dh if need_dh else None), _ptr(logits if need_logits else None),
                          loss_out.data_ptr(), _ptr(loss_slot_dev), N, C, K, H * W, loss_sign, ws.data_ptr(), ws.numel(), _stream()), "ms_head_ce")
     return loss_out, dh, logits
+
+
+def rescale_intensity(data, new_min=0.0, new_max=1.0, eps=1e-20):
+    """common_utils/basic_operations.py:257-281 on the GPU (per (n,c) plane min-max)."""
+    _need_cuda_f32(data)
+    if data.dim() == 3:
+        planes, hw = data.shape[0], data.shape[1] * data.shape[2]
+    elif data.dim() >= 4:
+        planes, hw = data.shape[0] * data.shape[1], data[0, 0].numel()
+    else:
+        raise ValueError
+    out = torch.empty_like(data)
+    check(lib.ms_rescale_intensity(data.data_ptr(), out.data_ptr(), planes, hw, new_min, new_max, eps, _stream()), "ms_rescale_intensity")
+    return out

@@ -272,6 +272,28 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self.zero_grad()
         return out
 
+    def generate_max_style_image_from_config(self, image_code, max_style_cfg, reference_image, reference_segmentation, p=0.5, rescale=False):
+        """The trainer's call (train_adv...py:251-278) driven by the `max_style` block of a reference JSON config
+        (config/ACDC/1500_epoch/MICCAI2022_MaxStyle.json:56-76), keys taken verbatim; `p=0.5` is the trainer's literal.
+        rescale=True additionally applies rescale_intensity(.,0,1) as hard_example_traininng does next (advanced_triplet...py:868-869)."""
+        if '16' in self.network_type:
+            channel_num = [128, 64, 32, 16, 16, self.image_ch]
+        elif '64' in self.network_type:
+            channel_num = [512, 256, 128, 64, 64, self.image_ch]
+        else:
+            raise ValueError('network_type not supported')
+        c = max_style_cfg
+        out = self.generate_max_style_image(image_code=image_code, channel_num=channel_num, p=p,
+                                            decoder_layers_indexes=c['decoder_layers_indexes'], n_iter=c['n_iter'], mix_style=c['mix_style'],
+                                            lr=c['lr'], no_noise=c['no_noise'], reference_image=reference_image,
+                                            reference_segmentation=reference_segmentation, noise_learnable=c['noise_learnable'],
+                                            mix_learnable=c['mix_learnable'], loss_types=c['loss_types'], loss_weights=c['loss_weights'],
+                                            always_use_beta=c.get('always_use_beta', False))
+        if rescale:
+            from . import ops
+            out = ops.rescale_intensity(out.contiguous(), 0.0, 1.0)
+        return out
+
     @staticmethod
     def _cfg_sig(layers, slots):
         return tuple((i, slots[i].B, slots[i].C, slots[i].mix_style, slots[i].use_noise, slots[i].learn_noise, slots[i].learn_mix) for i in layers)

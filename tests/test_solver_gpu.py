@@ -246,3 +246,24 @@ def test_ragged_shapes_one_step_vs_oracle(dev):
     for n, gr in grads.items():
         i, nm = n.split(".")
         assert rel(eng.grad(int(i), nm), gr) < 0.1, n
+
+
+def test_config_block_and_rescale(dev):
+    """The reference's JSON `max_style` block drives the call verbatim; rescale_intensity == the reference formula."""
+    from maxstyle_amd import ops
+    from oracle import maxstyle_oracle as orc
+    cfg = {"mix_style": True, "no_noise": False, "lr": 0.1, "n_iter": 2, "mix_learnable": True, "noise_learnable": True,
+           "decoder_layers_indexes": [3, 4, 5], "loss_types": ["seg"], "loss_weights": [1], "always_use_beta": False}
+    spec = orc.NetSpec(4, 1, 4)
+    S, W = make_solver(dev, spec)
+    img, lab = orc.synthetic_batch(4, 64, 1, 4, 1234)
+    z_i, _ = S.encode_image(img.to(dev), disable_track_bn_stats=True)
+    torch.manual_seed(3)
+    out = S.generate_max_style_image_from_config(z_i, cfg, img.to(dev), lab.to(dev), p=0.5, rescale=True)
+    assert out.shape == (4, 1, 64, 64)
+    mn = out.view(4, -1).min(1).values; mx = out.view(4, -1).max(1).values
+    assert float(mn.abs().max()) == 0.0 and float((mx - 1).abs().max()) < 1e-6
+    x = torch.randn(3, 2, 17, 9, device=dev) * 3 + 1
+    flat = x.view(6, -1)
+    ref = ((flat - flat.min(1, keepdim=True).values) / (flat.max(1, keepdim=True).values - flat.min(1, keepdim=True).values + 1e-20)).view_as(x)
+    assert rel(ops.rescale_intensity(x), ref) < 1e-6
