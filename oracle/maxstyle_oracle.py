@@ -315,7 +315,12 @@ def batchnorm_running(u, weight, bias, rm, rv, eps=BN_EPS):
     return u * s.view(1, -1, 1, 1) + (bias - rm * s).view(1, -1, 1, 1)
 
 
+BN_OBSERVER = None   # optional callable(sd, name, u): oracle/outer_oracle.py uses it for the running-statistics update of a tracking pass
+
+
 def _bn(sd, name, u, bn_mode):
+    if BN_OBSERVER is not None:
+        BN_OBSERVER(sd, name, u)
     if bn_mode == "batch":
         return batchnorm_batchstat(u, sd[name + ".weight"], sd[name + ".bias"])
     return batchnorm_running(u, sd[name + ".weight"], sd[name + ".bias"], sd[name + ".running_mean"], sd[name + ".running_var"])
