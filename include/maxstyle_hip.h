@@ -133,6 +133,23 @@ int ms_bn_bwd_coefs(const float* part2, int nparts, const float* coef4, double c
 /* out[p,y,x] (+)= in[p,2y,2x]+in[p,2y,2x+1]+in[p,2y+1,2x]+in[p,2y+1,2x+1]: gradient of nn.UpsamplingNearest2d(2) */
 int ms_pool2_sum(const float* in, float* out, int planes, int Ho, int Wo, int accumulate, void* stream);
 
+/* ---- weight gradients for the outer update: autograd's convolution_backward w.r.t. `weight` when loss.backward()
+ * runs after standard_training / hard_example_traininng (train_adv_supervised_segmentation_triplet.py:532-535).
+ *   dw[m][n][ty][tx] (+)= sum_{img,y,x} P[img,m,y,x] * Q[img,n, stride*y+ty-pad, stride*x+tx-pad]        pad = 1 for ks 3, else 0
+ * Conv2d (ks 3 stride 1|2, ks 1): P = gradient w.r.t. the conv output [N][M=Cout][Hp][Wp], Q = conv input [N][Nq=Cin][Hq][Wq],
+ *   dw = weight.grad [Cout][Cin][ks][ks].  ConvTranspose2d (ks 2, stride 2): P = its input, Q = gradient w.r.t. its output,
+ *   dw = weight.grad [Cin][Cout][2][2].
+ * q_fetch 1: Q is stored at half resolution and read through nearest 2x up-sampling (nn.UpsamplingNearest2d before the conv, ks 3 stride 1 only).
+ * p_mode 2: P = pa[m]*p + pb[m]*p2 + pc[m] (BatchNorm backward of the masked gradient p with the raw conv output p2 - what ms_conv2d's
+ *   pro_mode 2 applies on the data-gradient side); q_mode 1: Q = LeakyReLU_slope(qa[n]*q + qb[n]) (BatchNorm apply + activation of the
+ *   producer layer); coefficient arrays are read with stride coef_stride (4 for the float4 tables of ms_bn_finalize / ms_bn_bwd_coefs).
+ * Deterministic: per-workgroup partials in `ws` (ms_conv_wgrad_ws_bytes), summed in a fixed order; accumulate != 0 adds to dw. */
+size_t ms_conv_wgrad_ws_bytes(int N, int M, int Nq, int Hp, int Wp, int ks, int stride);
+int ms_conv_wgrad(const float* p, const float* p2, const float* q, float* dw, int N, int M, int Nq, int Hp, int Wp, int Hq, int Wq,
+                  int ks, int stride, int q_fetch, int p_mode, const float* pa, const float* pb, const float* pc,
+                  int q_mode, const float* qa, const float* qb, int coef_stride, float slope, int accumulate,
+                  void* ws, size_t ws_bytes, void* stream);
+
 /* Per-plane min-max rescale y = (x - min)/(max - min + eps)*(new_max - new_min) + new_min: rescale_intensity
  * (common_utils/basic_operations.py:257-281), applied to the stylised image right after the path (advanced_triplet...py:868-869). */
 int ms_rescale_intensity(const float* x, float* y, int planes, int HW, float new_min, float new_max, float eps, void* stream);

@@ -50,6 +50,9 @@ SIGNATURES = {
     "ms_act_bwd_bn": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_void, c_f32p, c_int, c_int, c_int, c_float, c_void]),
     "ms_bn_bwd_coefs": (c_int, [c_f32p, c_int, c_f32p, ctypes.c_double, c_f32p, c_int, c_void]),
     "ms_pool2_sum": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_void]),
+    "ms_conv_wgrad_ws_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "ms_conv_wgrad": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                              c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_int, c_float, c_int, c_void, c_size, c_void]),
     "ms_rescale_intensity": (c_int, [c_f32p, c_f32p, c_int, c_int, c_float, c_float, c_float, c_void]),
     "ms_confusion": (c_int, [c_f32p, c_i64p, c_void, c_int, c_int, c_int, c_void]),
     "ms_head_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_void]),

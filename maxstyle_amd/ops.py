@@ -259,3 +259,36 @@ def rescale_intensity(data, new_min=0.0, new_max=1.0, eps=1e-20):
     out = torch.empty_like(data)
     check(lib.ms_rescale_intensity(data.data_ptr(), out.data_ptr(), planes, hw, new_min, new_max, eps, _stream()), "ms_rescale_intensity")
     return out
+
+
+_wgrad_ws = {}
+
+
+def conv_wgrad(p, q, ks, stride=1, q_fetch=0, p_bnbwd=None, q_act=None, out=None, accumulate=False):
+    """weight.grad of a convolution (ms_conv_wgrad). p: gradient w.r.t. the conv output [N,M,Hp,Wp] (ConvTranspose2d: its input),
+    q: conv input [N,Nq,Hq,Wq] (ConvTranspose2d: gradient w.r.t. its output).  p_bnbwd=(bcoef4 [M,4], u): P = a*p + b*u + c;
+    q_act=(coef4 [Nq,4], slope): Q = LeakyReLU(a*q + b).  Returns dw [M, Nq, ks, ks]."""
+    _need_cuda_f32(p); _need_cuda_f32(q)
+    N, M, Hp, Wp = p.shape
+    Nq, Hq, Wq = q.shape[1:]
+    if out is None:
+        out = torch.empty(M, Nq, ks, ks, dtype=torch.float32, device=p.device)
+    nbytes = lib.ms_conv_wgrad_ws_bytes(N, M, Nq, Hp, Wp, ks, stride)
+    key = (p.device, torch.cuda.current_stream().cuda_stream)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=p.device)
+        _wgrad_ws[key] = ws
+    pm, p2, pa, pb, pc = 0, 0, 0, 0, 0
+    qm, qa, qb, slope = 0, 0, 0, 1.0
+    if p_bnbwd is not None:
+        pm = 2
+        pa, pb, pc = coef_ptrs(p_bnbwd[0])
+        p2 = p_bnbwd[1].data_ptr()
+    if q_act is not None:
+        qm = 1
+        qa, qb, _ = coef_ptrs(q_act[0])
+        slope = q_act[1]
+    check(lib.ms_conv_wgrad(p.data_ptr(), p2, q.data_ptr(), out.data_ptr(), N, M, Nq, Hp, Wp, Hq, Wq, ks, stride, q_fetch, pm, pa, pb, pc,
+                            qm, qa, qb, 4, slope, 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()), "ms_conv_wgrad")
+    return out
