@@ -150,6 +150,39 @@ int ms_conv_wgrad(const float* p, const float* p2, const float* q, float* dw, in
                   int q_mode, const float* qa, const float* qb, int coef_stride, float slope, int accumulate,
                   void* ws, size_t ws_bytes, void* stream);
 
+/* BatchNorm backward from the partial sums of ms_act_bwd_reduce: coefficients as ms_bn_bwd_coefs (coef_out4 may be NULL) plus
+ * BatchNorm weight.grad (dgamma) / bias.grad (dbeta) and dsum = sum of the masked gradient (bias.grad of the residual 1x1 conv that
+ * shares it); each may be NULL.  accumulate != 0 adds.  In the hard-example pass the BatchNorm affine is frozen
+ * (model_util.py:468-510): pass NULL for dgamma/dbeta there. */
+int ms_bn_bwd_full(const float* part2, int nparts, const float* coef4, double count, float* coef_out4, float* dgamma, float* dbeta, float* dsum,
+                   int accumulate, int C, void* stream);
+
+/* out[c] (+)= sum_{n,hw} x[n,c,hw]: bias.grad of a convolution from the gradient of its output. */
+int ms_channel_sum(const float* x, int N, int C, int HW, float* out, int accumulate, void* stream);
+
+/* weight.grad [K][C] / bias.grad [K] (db may be NULL) of a 1x1 head, d computed on the fly:
+ *   mode 0: d = scale*(softmax(aux) - onehot(target int64 [N,HW]))   aux = logits [N,K,HW]      (cross_entropy_2D, custom_loss.py:1043-1078)
+ *   mode 1: d = scale*(aux - target)*aux*(1-aux)                      aux = sigmoid output, target float [N,K,HW]   (0.5*MSE, :718-729)
+ *   mode 2: d = scale*aux. */
+size_t ms_head_wgrad_ws_bytes(int N, int C, int K, int HW);
+int ms_head_wgrad(const float* h, const float* aux, const void* target, int mode, float scale, float* dw, float* db,
+                  int N, int C, int K, int HW, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* loss_out[0] = loss_scale * sum (x-target)^2 (loss_out may be NULL); dx = grad_scale*(x-target) (dx may be NULL).
+ * compute_image_recon_loss 'l2' (advanced_triplet...py:718-722): loss_scale = 0.5/n, grad_scale = upstream/n. */
+size_t ms_mse_ws_bytes(void);
+int ms_mse_loss(const float* x, const float* target, size_t n, float loss_scale, float grad_scale, float* loss_out, float* dx,
+                void* ws, size_t ws_bytes, void* stream);
+
+/* torch.optim.AdamW (weight_decay > 0: p *= 1 - lr*wd first) / torch.optim.Adam (weight_decay = 0) on a flat buffer
+ * (advanced_triplet...py:1055-1086); step semantics as ms_adam_step. */
+int ms_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float weight_decay,
+                  int step, const int* step_dev, void* stream);
+
+/* Running statistics of a tracking BatchNorm forward from the coefficient table of ms_bn_finalize (mean, invstd):
+ * running = (1-momentum)*running + momentum*batch, variance unbiased (count/(count-1)). */
+int ms_bn_running_update(const float* coef4, float* running_mean, float* running_var, int C, double count, float momentum, float eps, void* stream);
+
 /* Per-plane min-max rescale y = (x - min)/(max - min + eps)*(new_max - new_min) + new_min: rescale_intensity
  * (common_utils/basic_operations.py:257-281), applied to the stylised image right after the path (advanced_triplet...py:868-869). */
 int ms_rescale_intensity(const float* x, float* y, int planes, int HW, float new_min, float new_max, float eps, void* stream);

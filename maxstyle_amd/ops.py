@@ -292,3 +292,13 @@ def conv_wgrad(p, q, ks, stride=1, q_fetch=0, p_bnbwd=None, q_act=None, out=None
     check(lib.ms_conv_wgrad(p.data_ptr(), p2, q.data_ptr(), out.data_ptr(), N, M, Nq, Hp, Wp, Hq, Wq, ks, stride, q_fetch, pm, pa, pb, pc,
                             qm, qa, qb, 4, slope, 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()), "ms_conv_wgrad")
     return out
+
+
+def mse_loss(x, target):
+    """0.5 * mean((x - target)^2) as a 0-dim device tensor (ms_mse_loss)."""
+    _need_cuda_f32(x); _need_cuda_f32(target)
+    n = x.numel()
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.ms_mse_ws_bytes(), dtype=torch.uint8, device=x.device)
+    check(lib.ms_mse_loss(x.data_ptr(), target.data_ptr(), n, 0.5 / n, 0.0, out.data_ptr(), 0, ws.data_ptr(), ws.numel(), _stream()), "ms_mse_loss")
+    return out[0]

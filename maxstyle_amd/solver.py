@@ -5,12 +5,16 @@ Implemented (same names, argument meaning and error behaviour):
     __init__/get_network (:42-266, FCN_16 / FCN_64 families), encode_image / filter_code (:330-385),
     decoder_inference (:693-716), generate_max_style_image (:458-571), predict-style evaluate helper, zero_grad/train/eval.
 The K-step inner loop runs in maxstyle_amd.engine (HIP kernels + HIP-graph replay); this file is host-side orchestration.
-Out of scope here (SURVEY.md 8, rows "next"/OUT): the outer training step, other augmentation baselines, checkpoint I/O helpers.
+Outer update (SURVEY.md 8(f) rows 1,3): standard_training (:731-786), hard_example_traininng (:843-889), fast_predict (:891-912),
+    compute_image_recon_loss 'l2' (:718-729), set_optimizers / reset_all_optimizers / optimize_all_params / optimize_params /
+    reset_optimizer (:1038-1091) - forward AND backward (weight gradients) in maxstyle_amd.train_engine, optimiser on one flat buffer.
+Out of scope here (SURVEY.md 8 OUT): the shape-refinement (STN) networks, other augmentation baselines, checkpoint I/O helpers.
 """
 import torch
 import torch.nn as nn
 
 from . import engine as E
+from . import train_engine as T
 from .maxstyle import MaxStyle
 from .networks import Dual_Branch_Encoder, MyDecoder, _disable_tracking_bn_stats, set_grad
 
@@ -54,6 +58,19 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         if encoder_dropout is not None or decoder_dropout is not None:
             raise NotImplementedError("dropout is None in every MaxStyle config (SURVEY.md 2 row 6)")
         self.latent_code = {}
+        if rec_loss_type != 'l2':
+            raise NotImplementedError("rec_loss_type 'l2' (0.5*MSE) is what every MaxStyle config uses")
+        if optimizer_type not in ('Adam', 'AdamW'):
+            raise NotImplementedError("optimizer_type 'Adam' or 'AdamW'")
+        self.rec_loss_type = rec_loss_type
+        self.optimizer_type = optimizer_type
+        self.separate_training = separate_training
+        self.optimizers = None
+        self.z_i = self.z_s = None
+        self.recon_image = None
+        self._bank = None
+        self._train_engines = {}
+        self._anchor = None
         self.model = self.get_network(checkpoint_dir=checkpoint_dir)
         self._engines = {}
         self._packed = None
@@ -105,6 +122,9 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         return self.model.values
 
     def zero_grad(self, set_to_none=True):
+        if self._bank is not None:
+            self._bank.zero_grad()              # the gradients are views of one flat buffer: keep them attached, clear the values
+            return
         for m in self.model.values():
             m.zero_grad()
 
@@ -166,7 +186,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
 
     # ------------------------------------------------------------------ the hot path
     def _loop_engine(self, B, H, W, dev):
-        key = tuple((id(p), p._version) for m in self.model.values() for p in list(m.parameters()) + list(m.buffers()))
+        key = (self._weights_epoch,) + tuple((id(p), p._version) for m in self.model.values() for p in list(m.parameters()) + list(m.buffers()))
         spec = E.NetSpec(self.reduce_factor, self.image_ch, self.num_classes)
         if self._packed_key != key:
             sd = {k: {n: v.detach() for n, v in m.state_dict().items()} for k, m in self.model.items()}
@@ -294,6 +314,172 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             out = ops.rescale_intensity(out.contiguous(), 0.0, 1.0)
         return out
 
+    # ------------------------------------------------------------------ outer update (advanced_triplet...py:718-912, 1038-1091)
+    _weights_epoch = 0
+
+    def _param_bank(self):
+        if self._bank is None:
+            dev = next(self.model['image_encoder'].parameters()).device
+            if dev.type != 'cuda':
+                raise RuntimeError("training runs on the MI355X only (HIP kernels); move the solver to the GPU first")
+            self._bank = T.ParamBank(self.model, dev)
+            self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        else:
+            self._bank.rebind(self.model)
+        return self._bank
+
+    def set_optimizers(self):
+        assert self.model
+        bank = self._param_bank()
+        self.optimizers = {name: _BankOptimizer(self, bank, name) for name in self.model}
+
+    def reset_all_optimizers(self):
+        if self.optimizers is None:
+            self.set_optimizers()
+        self._param_bank().zero_grad()
+
+    def get_optimizer(self, model_name=None):
+        assert self.optimizers, 'please set optimizers first before fetching'
+        return self.optimizers if model_name is None else self.optimizers[model_name]
+
+    def optimize_all_params(self):
+        for v in self.optimizers.values():
+            v.step()
+
+    def optimize_params(self, model_name):
+        self.optimizers[model_name].step()
+
+    def reset_optimizer(self, model_name):
+        self.optimizers[model_name].zero_grad()
+
+    def compute_image_recon_loss(self, input_image, target, rec_loss_type=None):
+        """0.5 * MSELoss(reduction='mean') of two device tensors (value only; the differentiable form is part of standard_training)."""
+        from . import ops
+        if (rec_loss_type or self.rec_loss_type) != 'l2':
+            raise NotImplementedError
+        return ops.mse_loss(input_image.contiguous().float(), target.contiguous().float())
+
+    def _train_engine(self, B, H, W, dev):
+        """A TrainEngine whose activations are not waiting for a backward (several passes can be alive before loss.backward())."""
+        spec = E.NetSpec(self.reduce_factor, self.image_ch, self.num_classes)
+        self._loop_engine(B, H, W, dev)                  # refreshes the packed weights if the optimiser moved them
+        pool = self._train_engines.setdefault((B, H, W, str(dev)), [])
+        for eng in pool:
+            if not eng.pending:
+                break
+        else:
+            eng = T.TrainEngine(spec, B, H, W, dev)
+            eng.pending = False
+            pool.append(eng)
+        eng.nets = self._packed
+        eng.bank = self._param_bank()
+        return eng
+
+    def fast_predict(self, input, domain_id=0, disable_track_bn_stats=False):
+        """advanced_triplet...py:891-912 (value only: logits are detached; the differentiable route is standard_training)."""
+        z_i, z_s = self.encode_image(input, domain_id, disable_track_bn_stats=disable_track_bn_stats)
+        y_0 = self.decoder_inference(decoder=self.model['segmentation_decoder'], latent_code=z_s, disable_track_bn_stats=disable_track_bn_stats)
+        return (z_i, z_s), y_0
+
+    def standard_training(self, clean_image_l, label_l, perturbed_image, compute_gt_recon=True, update_latent=True, if_latent_code_consistency=False,
+                          disable_track_bn_stats=False, domain_id=0, return_output=False):
+        """advanced_triplet...py:731-786 for 'no_STN' networks: seg loss = cross_entropy_2D(seg_decoder(z_s), labels), image recon loss =
+        0.5*MSE(image_decoder(z_i), clean).  The two losses carry a grad_fn: `(a*seg + b*rec).backward()` runs the HIP backward pass and
+        accumulates into the parameters' .grad.  recon_image / y_0 (return_output=True) and z_i / z_s are detached values."""
+        if 'no_STN' not in self.network_type or 'no_im_recon' in self.network_type:
+            raise NotImplementedError("shape-refinement (STN) and no_im_recon variants are outside the MaxStyle path (SURVEY.md 8)")
+        if self.class_weights is not None:
+            raise NotImplementedError("class_weights is None in every MaxStyle config")
+        self.train()
+        x = perturbed_image.detach().contiguous().float()
+        if not x.is_cuda:
+            raise RuntimeError("standard_training runs on the MI355X only (HIP kernels); got a CPU tensor")
+        B, _, H, W = x.shape
+        eng = self._train_engine(B, H, W, x.device)
+        labels = label_l.detach().to(device=x.device, dtype=torch.int64).contiguous()
+        clean = clean_image_l.detach().contiguous().float()
+        track = not disable_track_bn_stats
+        bns = tuple({n: m for n, m in self.model[k].named_modules() if isinstance(m, nn.BatchNorm2d)} for k in T.NETS)
+        seg_loss, rec_loss = _TrainPassFn.apply(self._anchor, self, eng, x, labels, clean, track, bns)
+        z_i, z_s = eng.buf["e.z_i"], eng.buf["e.z_s"]
+        if update_latent:
+            self.z_i = z_i.clone()
+            self.z_s = z_s.clone()
+        self.recon_image = eng.buf["d.image"].clone()
+        zero = torch.tensor(0., device=x.device)
+        if return_output:
+            y_0 = eng.buf["s.logits"].clone()
+            return seg_loss, rec_loss, zero, zero, self.recon_image, y_0, y_0
+        return seg_loss, rec_loss, zero, zero
+
+    def hard_example_traininng(self, perturbed_image, clean_image_l, perturbed_seg, label_l, use_gpu=True, if_latent_code_consistency=False,
+                               standard_input_image=None, standard_recon_image=None):
+        """advanced_triplet...py:843-889 ('no_STN': only the image branch exists): rescale_intensity(perturbed, 0, 1), then
+        standard_training inside _disable_tracking_bn_stats (batch statistics, no running update, BatchNorm affine frozen)."""
+        from . import ops
+        zero = torch.tensor(0., device=clean_image_l.device)
+        seg_loss, recon_loss, shape_loss = zero, zero, zero
+        if perturbed_image is not None:
+            if self.intensity_norm_type != 'min_max':
+                raise NotImplementedError
+            perturbed_image = ops.rescale_intensity(perturbed_image.detach().contiguous().float(), 0.0, 1.0)
+            seg_loss, recon_loss, _, shape_loss = self.standard_training(clean_image_l=clean_image_l, label_l=label_l, perturbed_image=perturbed_image,
+                                                                         compute_gt_recon=False, update_latent=False, disable_track_bn_stats=True, domain_id=0)
+        return seg_loss, recon_loss, shape_loss, 0 * seg_loss
+
     @staticmethod
     def _cfg_sig(layers, slots):
         return tuple((i, slots[i].B, slots[i].C, slots[i].mix_style, slots[i].use_noise, slots[i].learn_noise, slots[i].learn_mix) for i in layers)
+
+
+class _TrainPassFn(torch.autograd.Function):
+    """Differentiable handle on one TrainEngine pass: forward returns the two scalar losses, backward runs the HIP backward pass (data and
+    weight gradients) scaled by the upstream gradients and accumulates into the ParamBank - autograd itself never sees the networks."""
+
+    @staticmethod
+    def forward(ctx, anchor, solver, eng, x, labels, clean, track, bns):
+        eng.bn_affine_grad = track          # _disable_tracking_bn_stats also freezes the BatchNorm affine (model_util.py:468-510)
+        eng.forward_pass(x, labels, clean, track, bns)
+        eng.pending = True
+        ctx.solver, ctx.eng = solver, eng
+        ctx.args = (x, labels, clean)
+        out = eng.loss_buf[:2].clone()
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_seg, g_rec):
+        eng, solver = ctx.eng, ctx.solver
+        if not eng.pending:
+            raise RuntimeError("the activations of this training pass were already consumed by a backward")
+        x, labels, clean = ctx.args
+        gs = 0.0 if g_seg is None else float(g_seg)
+        gr = 0.0 if g_rec is None else float(g_rec)
+        eng.bank = solver._param_bank()
+        eng.backward_pass(x, labels, clean, gs, gr)
+        eng.pending = False
+        return torch.zeros_like(solver._anchor), None, None, None, None, None, None, None
+
+
+class _BankOptimizer:
+    """Stands in for the reference's per-sub-net torch optimiser (advanced_triplet...py:1055-1086): AdamW / Adam on that net's slice of the flat buffers."""
+
+    def __init__(self, solver, bank, net):
+        self.solver, self.bank, self.net = solver, bank, net
+        offs = [(o, n) for (k, _), (o, n, _) in bank.index.items() if k == net]
+        self.begin = min(o for o, _ in offs)
+        self.end = max(o + (n + 3) // 4 * 4 for o, n in offs)
+        self.step_count = 0
+        self.lr = solver.learning_rate
+
+    def zero_grad(self, set_to_none=False):
+        self.bank.flat_g[self.begin:self.end].zero_()
+
+    def step(self):
+        from ._lib import lib, check
+        b = self.bank
+        self.step_count += 1
+        o, n = 4 * self.begin, self.end - self.begin
+        wd = 1e-2 if self.solver.optimizer_type == 'AdamW' else 0.0
+        check(lib.ms_adamw_step(b.flat_p.data_ptr() + o, b.flat_g.data_ptr() + o, b.flat_m.data_ptr() + o, b.flat_v.data_ptr() + o, n,
+                                self.lr, 0.9, 0.999, 1e-8, wd, self.step_count, 0, torch.cuda.current_stream().cuda_stream), "ms_adamw_step")
+        self.solver._weights_epoch += 1          # packed kernel-layout copies are refreshed in place at the next use

@@ -1,0 +1,319 @@
+"""Outer training pass on one MI355X: forward with saved activations + full backward (data AND weight gradients) of
+    encoder -> segmentation decoder -> cross entropy   and   encoder code z_i -> image decoder -> sigmoid -> 0.5*MSE
+i.e. `standard_training` for 'no_STN' networks (/root/reference/src/models/advanced_triplet_recon_segmentation_model.py:731-786), which
+`hard_example_traininng` (:843-889) re-runs on the stylised image inside `_disable_tracking_bn_stats`, followed by `loss.backward()` and the
+optimiser steps of the trainer (train_adv_supervised_segmentation_triplet.py:532-535).  SURVEY.md 8(f) rows 1 and 3.
+
+Same kernels and the same fusion plan as the inner loop (engine.py); what is added:
+  * weight gradients: ms_conv_wgrad (pixel-reduction MFMA GEMM) reads the SAME tensors the data-gradient convs read - the masked gradient,
+    the raw conv output (BatchNorm backward applied on the fly) and the producer's raw output (BatchNorm apply + LeakyReLU on the fly);
+    nothing extra is materialised for them;
+  * BatchNorm weight/bias gradients and the residual 1x1 conv's bias gradient fall out of the two per-channel sums the BatchNorm backward
+    already needs (ms_bn_bwd_full);
+  * biases of convolutions that feed a batch-statistics BatchNorm get an exact 0 gradient (the loss does not depend on them; the
+    reference's value is summation round-off) - see oracle/outer_oracle.py:is_null_grad_bias;
+  * all parameters / gradients / Adam moments of the three sub-nets live in ONE flat buffer each (ParamBank): zero_grad is one memset,
+    the optimiser one launch, and the data-parallel all-reduce one collective over `flat_g` (distributed.FlatGradAllReduce).
+Host code is orchestration only; there is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from ._lib import lib, check
+from .engine import InnerLoopEngine, PackedNets, NetSpec, LEAKY, BN_EPS, F32
+
+NETS = ("image_encoder", "segmentation_decoder", "image_decoder")
+_TABLE = {"image_encoder": "enc", "segmentation_decoder": "seg", "image_decoder": "dec"}
+
+
+class ParamBank:
+    """Flat fp32 storage of every learnable tensor of the three sub-nets, in `NETS` x `named_parameters()` order (the order the reference's
+    three optimisers would visit them).  `module.parameters()` become views of `flat_p`, their `.grad` views of `flat_g`."""
+
+    def __init__(self, modules: Dict[str, torch.nn.Module], device):
+        self.device = torch.device(device)
+        self.index = {}
+        total = 0
+        plist = []
+        for net in NETS:
+            for name, p in modules[net].named_parameters():
+                n = p.numel()
+                self.index[(net, name)] = (total, n, tuple(p.shape))
+                plist.append(p)
+                total += (n + 3) // 4 * 4          # 16-byte aligned views
+        self.total = total
+        self.flat_p = torch.zeros(total, dtype=F32, device=self.device)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.step = 0
+        with torch.no_grad():
+            for (key, (off, n, shape)), p in zip(self.index.items(), plist):
+                view = self.flat_p[off:off + n].view(shape)
+                view.copy_(p.detach().to(self.device, F32))
+                p.data = view
+                p.grad = self.flat_g[off:off + n].view(shape)
+
+    def grad(self, net, name) -> Optional[torch.Tensor]:
+        e = self.index.get((net, name))
+        if e is None:
+            return None
+        off, n, shape = e
+        return self.flat_g[off:off + n].view(shape)
+
+    def param(self, net, name):
+        off, n, shape = self.index[(net, name)]
+        return self.flat_p[off:off + n].view(shape)
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def rebind(self, modules):
+        """Re-attach `.grad` views (a torch optimiser's zero_grad(set_to_none=True) drops them)."""
+        for net in NETS:
+            for name, p in modules[net].named_parameters():
+                off, n, shape = self.index[(net, name)]
+                if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                    p.grad = self.flat_g[off:off + n].view(shape)
+
+    def optimizer_step(self, lr, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, decoupled=True):
+        """torch.optim.AdamW (decoupled) / torch.optim.Adam(weight_decay=0) on every parameter: one launch."""
+        self.step += 1
+        check(lib.ms_adamw_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(), self.total,
+                                lr, betas[0], betas[1], eps, weight_decay if decoupled else 0.0, self.step, 0, torch.cuda.current_stream().cuda_stream),
+              "ms_adamw_step")
+
+
+class TrainEngine(InnerLoopEngine):
+    """One forward/backward of the segmentation + reconstruction training pass.  Activations stay in this engine's buffers until
+    `backward_pass`; use one TrainEngine per pass that is alive at the same time (standard pass, hard-example pass)."""
+
+    def __init__(self, spec: NetSpec, B: int, H: int, W: int, device):
+        super().__init__(spec, B, H, W, device)
+        self.loss_sign = 1.0
+        self.bank: Optional[ParamBank] = None
+        self.bn_affine_grad = True       # False inside _disable_tracking_bn_stats (hard-example pass): BatchNorm weight/bias are constants
+        self.bn_modules = None           # sd-name -> nn.BatchNorm2d per net, for the running-statistics update of a tracking pass
+        self.track = False
+        self.configure_styles([], {})
+
+    # ------------------------------------------------------------------ helpers
+    def _names(self, net):
+        return self.nets._enc_names if net == "image_encoder" else PackedNets._dec_names(net == "image_decoder")
+
+    def _gw(self, net, key):
+        return self.bank.grad(net, self._names(net)[key] + ".weight")
+
+    def _gb(self, net, key):
+        return self.bank.grad(net, self._names(net)[key] + ".bias")
+
+    def wgrad(self, p, q, dw, ks, stride=1, q_fetch=0, p_bnbwd=None, q_act=None):
+        N, M, Hp, Wp = p.shape
+        Nq, Hq, Wq = q.shape[1:]
+        nbytes = lib.ms_conv_wgrad_ws_bytes(N, M, Nq, Hp, Wp, ks, stride)
+        ws = self.buf.get("wg.ws")
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(int(nbytes), 8 << 20), dtype=torch.uint8, device=self.dev)
+            self.buf["wg.ws"] = ws
+        pm, p2, pa, pb, pc = 0, 0, 0, 0, 0
+        qm, qa, qb, slope = 0, 0, 0, 1.0
+        if p_bnbwd is not None:
+            pm = 2
+            pa, pb, pc = ops.coef_ptrs(p_bnbwd[0])
+            p2 = p_bnbwd[1].data_ptr()
+        if q_act is not None:
+            qm = 1
+            qa, qb, _ = ops.coef_ptrs(q_act[0])
+            slope = q_act[1]
+        check(lib.ms_conv_wgrad(p.data_ptr(), p2, q.data_ptr(), dw.data_ptr(), N, M, Nq, Hp, Wp, Hq, Wq, ks, stride, q_fetch, pm, pa, pb, pc,
+                                qm, qa, qb, 4, slope, 1, ws.data_ptr(), ws.numel(), self._st()), "ms_conv_wgrad")
+
+    def channel_sum(self, x, out):
+        N, C, H, W = x.shape
+        check(lib.ms_channel_sum(x.data_ptr(), N, C, H * W, out.data_ptr(), 1, self._st()), "ms_channel_sum")
+
+    def act_bwd_t(self, name, gin, ref, u, coef, slope, net, bn_key, dsum=None):
+        """Mask gin in place, BatchNorm-backward coefficients, BatchNorm parameter gradients (+ dsum: bias.grad of the residual 1x1 conv)."""
+        N, C, H, W = u.shape
+        nparts = lib.ms_act_bwd_parts(N, C, H * W)
+        part = self.t(name + ".part", C, nparts, 2)
+        bc = self.t(name + ".bcoef", C, 4)
+        check(lib.ms_act_bwd_reduce(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
+                                    N, C, H * W, slope, self._st()), "ms_act_bwd_reduce:" + name)
+        dg = db = None
+        if self.bn_affine_grad:
+            dg, db = self._gw(net, bn_key), self._gb(net, bn_key)
+        check(lib.ms_bn_bwd_full(part.data_ptr(), nparts, coef.data_ptr(), float(N * H * W), bc.data_ptr(), 0 if dg is None else dg.data_ptr(),
+                                 0 if db is None else db.data_ptr(), 0 if dsum is None else dsum.data_ptr(), 1, C, self._st()), "ms_bn_bwd_full:" + name)
+        return gin, bc
+
+    def conv(self, name, x, cw, **kw):
+        out, st, parts = super().conv(name, x, cw, **kw)
+        if kw.get("stats"):
+            self._last_count = out.shape[0] * out.shape[2] * out.shape[3]      # elements per channel the following BatchNorm sees
+        return out, st, parts
+
+    def bn_fin(self, name, st, parts, bn):
+        coef = super().bn_fin(name, st, parts, bn)
+        if self.track and not self.bn_eval:
+            self._tracked.append((bn.name, coef, self._last_count))
+        return coef
+
+    # ------------------------------------------------------------------ forward
+    def forward_pass(self, image, labels, clean, track: bool, net_bns=None):
+        """Returns (z_i, logits, recon); losses in loss_buf[0] (cross entropy) and loss_buf[1] (0.5*MSE)."""
+        self._prefix_valid = False
+        self.track = track
+        self._tracked = []
+        self.bn_eval = False
+        self.bn_observer = None
+        e_bns, s_bns, d_bns = net_bns if net_bns is not None else (None, None, None)
+        z_i, z_s = self.encode_fwd(image)
+        n_enc = len(self._tracked)
+        h = self.seg_fwd(z_s)
+        n_seg = len(self._tracked)
+        N, C, H, W = h.shape
+        w, bias = self.nets.seg["head.w"], self.nets.seg["head.b"]
+        K = w.shape[0]
+        logits = self.t("s.logits", N, K, H, W)
+        ws = self.t("s.ce_ws", max(lib.ms_head_ce_ws_bytes(N, H * W), 64), dtype=torch.uint8)
+        check(lib.ms_head_ce(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), 0, logits.data_ptr(), self.loss_buf.data_ptr(), 0,
+                             N, C, K, H * W, 1.0, ws.data_ptr(), ws.numel(), self._st()), "ms_head_ce")
+        self.buf["s.head_in"] = h
+        recon = self.decode(z_i)
+        mws = self.t("d.mse_ws", lib.ms_mse_ws_bytes(), dtype=torch.uint8)
+        n = recon.numel()
+        check(lib.ms_mse_loss(recon.data_ptr(), clean.data_ptr(), n, 0.5 / n, 0.0, self.loss_buf.data_ptr() + 4, 0, mws.data_ptr(), mws.numel(), self._st()), "ms_mse_loss")
+        if track and net_bns is not None:
+            self._update_running(self._tracked[:n_enc], e_bns)
+            self._update_running(self._tracked[n_enc:n_seg], s_bns)
+            self._update_running(self._tracked[n_seg:], d_bns)
+        self.track = False
+        return z_i, logits, recon
+
+    def _update_running(self, tracked, bns):
+        counters = []
+        for name, coef, u_count in tracked:
+            m = bns[name]
+            mom = 0.1 if m.momentum is None else m.momentum
+            check(lib.ms_bn_running_update(coef.data_ptr(), m.running_mean.data_ptr(), m.running_var.data_ptr(), coef.shape[0], float(u_count), mom, BN_EPS, self._st()),
+                  "ms_bn_running_update")
+            counters.append(m.num_batches_tracked)
+        if counters:
+            torch._foreach_add_(counters, 1)
+
+    # ------------------------------------------------------------------ backward
+    def res_bwd_t(self, pfx, net, key, x, dout, kind, need_dx=True):
+        """Backward of one residual block with weight gradients.  x: the block's input tensor; dout: gradient w.r.t. its output (overwritten)."""
+        b = self.buf
+        tbl = getattr(self.nets, _TABLE[net])
+        c0, c3, ci = tbl[key + ".c0"], tbl[key + ".c3"], tbl[key + ".ci"]
+        u1, u2 = b[pfx + ".u1"], b[pfx + ".u2"]
+        cf1 = b[pfx + ".bn1.coef"]
+        g2, bc2 = self.act_bwd_t(pfx + ".bw2", dout, b[pfx + ".out"], u2, b[pfx + ".bn4.coef"], LEAKY, net, key + ".bn4", dsum=self._gb(net, key + ".ci"))
+        self.wgrad(g2, u1, self._gw(net, key + ".c3"), 3, p_bnbwd=(bc2, u2), q_act=(cf1, LEAKY))
+        da1, _, _ = self.conv(pfx + ".da1", g2, c3, bnbwd=(bc2, u2), dgrad=True)
+        g1, bc1 = self.act_bwd_t(pfx + ".bw1", da1, None, u1, cf1, LEAKY, net, key + ".bn1")
+        src = x if kind == "nn" else (b[pfx + ".xu"] if kind == "convT" else b[pfx + ".xd"])
+        self.wgrad(g1, src, self._gw(net, key + ".c0"), 3, q_fetch=1 if kind == "nn" else 0, p_bnbwd=(bc1, u1))
+        dsrc, _, _ = self.conv(pfx + ".dsrc", g1, c0, bnbwd=(bc1, u1), dgrad=True)
+        if kind == "nn":
+            dx = self.pool2(pfx + ".dx", dsrc)
+            gs = self.pool2(pfx + ".gs", g2)
+            self.wgrad(gs, x, self._gw(net, key + ".ci"), 1)
+            self.conv(pfx + ".dx", gs, ci, dgrad=True, epi=1, out=dx)
+            return dx
+        self.wgrad(g2, src, self._gw(net, key + ".ci"), 1)
+        self.conv(pfx + ".dsrc", g2, ci, dgrad=True, epi=1, out=dsrc)
+        if kind == "convT":
+            self.wgrad(x, dsrc, self._gw(net, key + ".up"), 2, stride=2)
+            self.channel_sum(dsrc, self._gb(net, key + ".up"))
+            if not need_dx:
+                return None
+            dx, _, _ = self.conv(pfx + ".dx", dsrc, tbl[key + ".up"], ks=2, stride=2, dgrad=True)
+        else:
+            self.wgrad(dsrc, x, self._gw(net, key + ".down"), 3, stride=2)
+            self.channel_sum(dsrc, self._gb(net, key + ".down"))
+            if not need_dx:
+                return None
+            dx, _, _ = self.conv(pfx + ".dx", dsrc, tbl[key + ".down"], ks=3, stride=1, fetch=ops.FETCH_ZINS2, dgrad=True)
+        return dx
+
+    def backward_pass(self, image, labels, clean, g_seg: float, g_rec: float):
+        """Accumulates d(g_seg*CE + g_rec*0.5*MSE)/d(parameters) into the ParamBank's flat gradient buffer."""
+        b = self.buf
+        net_e, net_s, net_d = NETS
+        e, s, d = self.nets.enc, self.nets.seg, self.nets.dec
+        z_i, z_s = b["e.z_i"], b["e.z_s"]
+        # ---- segmentation branch: cross entropy -> head -> four 'NN' up blocks -> dz_s
+        dz_s = None
+        if g_seg != 0.0:
+            h = b["s.head_in"]
+            N, C, H, W = h.shape
+            w, bias = s["head.w"], s["head.b"]
+            K = w.shape[0]
+            dh = self.t("s.dh", N, C, H, W)
+            ws = b["s.ce_ws"]
+            scratch = self.t("s.loss_scratch", 4)
+            check(lib.ms_head_ce(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), dh.data_ptr(), 0, scratch.data_ptr(), 0,
+                                 N, C, K, H * W, float(g_seg), ws.data_ptr(), ws.numel(), self._st()), "ms_head_ce(bwd)")
+            hws = self.t("s.hw_ws", max(lib.ms_head_wgrad_ws_bytes(N, C, K, H * W), 64), dtype=torch.uint8)
+            check(lib.ms_head_wgrad(h.data_ptr(), b["s.logits"].data_ptr(), labels.data_ptr(), 0, float(g_seg) / (N * H * W),
+                                    self.bank.grad(net_s, "final_conv.weight").data_ptr(), self.bank.grad(net_s, "final_conv.bias").data_ptr(),
+                                    N, C, K, H * W, 1, hws.data_ptr(), hws.numel(), self._st()), "ms_head_wgrad(seg)")
+            g = dh
+            for i in range(4, 0, -1):
+                x = z_s if i == 1 else b[f"s.u{i - 1}.out"]
+                g = self.res_bwd_t(f"s.u{i}", net_s, f"u{i}", x, g, "nn")
+            dz_s = g
+        # ---- reconstruction branch: 0.5*MSE -> sigmoid head -> four ConvTranspose up blocks -> dz_i
+        dz_i = None
+        if g_rec != 0.0:
+            img = b["d.image"]
+            x = b["d.head_in"]
+            N, C, H, W = x.shape
+            K = d["head.w"].shape[0]
+            n = img.numel()
+            hws = self.t("d.hw_ws", max(lib.ms_head_wgrad_ws_bytes(N, C, K, H * W), 64), dtype=torch.uint8)
+            check(lib.ms_head_wgrad(x.data_ptr(), img.data_ptr(), clean.data_ptr(), 1, float(g_rec) / n,
+                                    self.bank.grad(net_d, "final_conv.weight").data_ptr(), self.bank.grad(net_d, "final_conv.bias").data_ptr(),
+                                    N, C, K, H * W, 1, hws.data_ptr(), hws.numel(), self._st()), "ms_head_wgrad(dec)")
+            dimg = self.t("d.dimg", *img.shape)
+            mws = b["d.mse_ws"]
+            check(lib.ms_mse_loss(img.data_ptr(), clean.data_ptr(), n, 0.0, float(g_rec) / n, 0, dimg.data_ptr(), mws.data_ptr(), mws.numel(), self._st()), "ms_mse_loss(bwd)")
+            dh = self.t("d.dh", N, C, H, W)
+            check(lib.ms_head_bwd(dimg.data_ptr(), img.data_ptr(), d["head.w"].data_ptr(), dh.data_ptr(), N, C, K, H * W, 1, self._st()), "ms_head_bwd")
+            g = dh
+            for i in range(4, 0, -1):
+                x = z_i if i == 1 else b[f"d.u{i - 1}.out"]
+                g = self.res_bwd_t(f"d.u{i}", net_d, f"u{i}", x, g, self._dec_kind())
+            dz_i = g
+        # ---- encoder: code_decoupler (z_s branch) joins the image-decoder gradient at z_i
+        if dz_s is not None:
+            g, bc = self.act_bwd_t("e.cd.bw2", dz_s, z_s, b["e.cd.u2"], b["e.cd.bn4.coef"], 0.0, net_e, "cd4")
+            self.wgrad(g, b["e.cd.u1"], self._gw(net_e, "cd3"), 3, p_bnbwd=(bc, b["e.cd.u2"]), q_act=(b["e.cd.bn1.coef"], LEAKY))
+            da, _, _ = self.conv("e.cd.da", g, e["cd3"], bnbwd=(bc, b["e.cd.u2"]), dgrad=True)
+            g, bc = self.act_bwd_t("e.cd.bw1", da, None, b["e.cd.u1"], b["e.cd.bn1.coef"], LEAKY, net_e, "cd1")
+            self.wgrad(g, z_i, self._gw(net_e, "cd0"), 3, p_bnbwd=(bc, b["e.cd.u1"]))
+            if dz_i is None:
+                dz_i, _, _ = self.conv("e.dz_i", g, e["cd0"], bnbwd=(bc, b["e.cd.u1"]), dgrad=True)
+            else:
+                self.conv("e.dz_i", g, e["cd0"], bnbwd=(bc, b["e.cd.u1"]), dgrad=True, epi=1, out=dz_i)
+        if dz_i is None:
+            return
+        hin = b["e.d4.out"]
+        g, bc = self.act_bwd_t("e.fc.bw", dz_i, z_i, b["e.fc.u"], b["e.fc.bn.coef"], 0.0, net_e, "fc1")
+        self.wgrad(g, hin, self._gw(net_e, "fc0"), 1, p_bnbwd=(bc, b["e.fc.u"]))
+        dh, _, _ = self.conv("e.fc.dh", g, e["fc0"], bnbwd=(bc, b["e.fc.u"]), dgrad=True)
+        for i in range(4, 0, -1):
+            x = b["e.inc.out"] if i == 1 else b[f"e.d{i - 1}.out"]
+            dh = self.res_bwd_t(f"e.d{i}", net_e, f"d{i}", x, dh, "down")
+        g, bc = self.act_bwd_t("e.inc.bw2", dh, b["e.inc.out"], b["e.inc.ub"], b["e.inc.bn4.coef"], LEAKY, net_e, "inc4")
+        self.wgrad(g, b["e.inc.ua"], self._gw(net_e, "inc3"), 3, p_bnbwd=(bc, b["e.inc.ub"]), q_act=(b["e.inc.bn1.coef"], LEAKY))
+        da, _, _ = self.conv("e.inc.da", g, e["inc3"], bnbwd=(bc, b["e.inc.ub"]), dgrad=True)
+        g, bc = self.act_bwd_t("e.inc.bw1", da, None, b["e.inc.ua"], b["e.inc.bn1.coef"], LEAKY, net_e, "inc1")
+        self.wgrad(g, image, self._gw(net_e, "inc0"), 3, p_bnbwd=(bc, b["e.inc.ua"]))      # the input image needs no gradient
