@@ -27,7 +27,9 @@ const char* ms_last_error(void);
 
 /* ---- MaxStyle layer: src/advanced/maxstyle.py:140-189 ------------------------------------------------ */
 
-/* bytes of scratch needed by ms_style_moments / ms_style_fwd / ms_style_bwd for a [B,C,H*W] tensor */
+/* bytes of workspace needed by ms_style_moments / ms_style_fwd / ms_style_bwd for a [B,C,H*W] tensor.
+ * Contract: give every layer (shape) its OWN workspace, zero-fill it once after allocation and keep it for the layer's lifetime - its
+ * tail holds the persistent launch-epoch state of the single-read forward kernel (the head is per-launch scratch). */
 size_t ms_style_ws_bytes(int B, int C, int HW);
 
 /* mu = mean_HW(x), sig = sqrt(var_HW(x, unbiased) + eps) per plane.          maxstyle.py:157-159 */
@@ -55,6 +57,8 @@ int ms_style_fwd(const float* x, float* y, float* mu, float* sig, float* gamma_s
 /* The two implementations behind ms_style_fwd (same arguments, same results to rounding):
  *   ms_style_fwd_fused  single-read persistent kernel: x crosses HBM once (8 B/element); eligible when H*W % 4 == 0, 2 <= B <= 256 and
  *                       one channel group (B x chunks) fits the grid - ms_style_fused_ws_bytes() returns 0 otherwise
+ *                       here `ws` is ONLY the kernel's persistent state (>= ms_style_fused_ws_bytes, zero-filled once, one layer, one
+ *                       stream at a time); ws[1] (int) is an error word set if a bounded spin ever times out
  *   ms_style_fwd_3k     moments / finalize / restyle as three launches (any shape; x is read twice) */
 size_t ms_style_fused_ws_bytes(int B, int C, int HW);
 int ms_style_fwd_fused(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,

@@ -275,11 +275,17 @@ static Split choose_split(int P, int HW, bool vec_ok) {
 
 using namespace ms;
 
-extern "C" size_t ms_style_ws_bytes(int B, int C, int HW) {
-  // worst case split: scalar path, nv=1 -> chunk 256; and room for the single-read kernel's counters + partials
+// workspace layout: [0, scratch) per-launch partials of the three-kernel forward and of the backward | [scratch, +fused) persistent state
+// of the single-read kernel (epoch + tagged granules: zero-filled once by the caller, never touched by the other kernels)
+static size_t style_scratch_bytes(int B, int C, int HW) {
+  // worst case split: scalar path, nv=1 -> chunk 256
   const size_t P = (size_t)B * C;
   const size_t S = (size_t)cdiv(HW, kStyleThreads);
-  return std::max(P * S * sizeof(PlanePartial) + 256, ms_style_fused_ws_bytes(B, C, HW));
+  return (P * S * sizeof(PlanePartial) + 256 + 15) / 16 * 16;
+}
+
+extern "C" size_t ms_style_ws_bytes(int B, int C, int HW) {
+  return style_scratch_bytes(B, C, HW) + (ms_style_fused_ws_bytes(B, C, HW) + 15) / 16 * 16;
 }
 
 static int launch_moments(const float* x, PlanePartial* part, int P, int HW, const Split& sp, hipStream_t st) {
@@ -355,8 +361,10 @@ extern "C" int ms_style_fwd(const float* x, float* y, float* mu, float* sig, flo
   // below ~32 MB the tensor sits in L2/Infinity Cache and the three short launches beat the ticketed persistent kernel (measured)
   const bool big = (size_t)B * C * HW * sizeof(float) >= ((size_t)32 << 20);
   const size_t fb = (fused_on && big) ? ms_style_fused_ws_bytes(B, C, HW) : 0;
-  if (fb != 0 && ws != nullptr && ws_bytes >= fb && aligned16(ws) && aligned16(x) && aligned16(y))
-    return ms_style_fwd_fused(x, y, mu, sig, gamma_std, beta_std, compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, HW, eps, ws, ws_bytes, stream);
+  const size_t off = style_scratch_bytes(B, C, HW);
+  if (fb != 0 && ws != nullptr && ws_bytes >= off + fb && aligned16(ws) && aligned16(x) && aligned16(y))
+    return ms_style_fwd_fused(x, y, mu, sig, gamma_std, beta_std, compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, HW, eps,
+                              (char*)ws + off, ws_bytes - off, stream);
   return ms_style_fwd_3k(x, y, mu, sig, gamma_std, beta_std, compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, HW, eps, ws, ws_bytes, stream);
 }
 

@@ -16,8 +16,12 @@
 // other workgroups of the same launch (channel-major numbering + increasing processing order): the lowest unfinished channel
 // always has every unit either done or being loaded, so it completes and releases its waiters.  Every spin is bounded (error
 // word) - a mis-sized launch flags an error instead of hanging the GPU.  Visibility: 8-byte agent-scope atomics on both sides
-// (MI355X_MICROARCH.md "Valid forms", R2: the granule carries its own tag); the granule table is zeroed by a memset node
-// before every launch (tags start at 0, a published granule carries tag 1).
+// (MI355X_MICROARCH.md "Valid forms", R2: the granule carries its own tag).
+// Tags are LAUNCH EPOCHS: the state block holds an epoch word; every workgroup reads it at start (T = epoch + 1), publishes and accepts
+// only granules tagged T, and the last workgroup to finish stores epoch = T.  Nothing is re-initialised between launches - an earlier
+// version cleared the table with hipMemsetAsync before every launch, and under HIP-graph replay the kernel was observed polling
+// granules the memset node had not cleared yet (stale or foreign words with a non-zero tag -> wrong statistics, NaN).  The state block
+// is zero-filled ONCE by the caller and must stay dedicated to one layer.
 #include <algorithm>
 #include "ms_common.h"
 #include "maxstyle_hip.h"
@@ -28,14 +32,14 @@ constexpr unsigned kSpinLimit = 1u << 22;
 
 typedef unsigned long long u64;
 
-// granule = {tag (1 = published) : 32 | float bits : 32}; unit u owns granules 2u (mean) and 2u+1 (M2)
-__device__ __forceinline__ void publish_granule(u64* slot, float value) {
-  __hip_atomic_store(slot, ((u64)1 << 32) | (u64)__float_as_uint(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// granule = {tag (launch epoch) : 32 | float bits : 32}; unit u owns granules 2u (mean) and 2u+1 (M2)
+__device__ __forceinline__ void publish_granule(u64* slot, float value, unsigned tag) {
+  __hip_atomic_store(slot, ((u64)tag << 32) | (u64)__float_as_uint(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool poll_granule(const u64* slot, float& value, int* err) {
+__device__ __forceinline__ bool poll_granule(const u64* slot, float& value, unsigned tag, int* err) {
   for (unsigned spins = 0;; ++spins) {
     const u64 v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((v >> 32) != 0) { value = __uint_as_float((unsigned)(v & 0xFFFFFFFFull)); return true; }
+    if ((unsigned)(v >> 32) == tag) { value = __uint_as_float((unsigned)(v & 0xFFFFFFFFull)); return true; }
     if (spins > kSpinLimit) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); value = 0.f; return false; }
     __builtin_amdgcn_s_sleep(1);
   }
@@ -53,9 +57,16 @@ __global__ __launch_bounds__(kFusedThreads) void style_fused_kernel(const float*
   __shared__ double redd[16];
   __shared__ float smu[256], ssig[256];
   __shared__ float pmean[1024], pm2[1024];          // polled partials of the channel: B*S <= 512 units (host-checked)
+  __shared__ unsigned s_tag;
   const int tid = threadIdx.x;
   const int G = B * S, total = C * G;
-  (void)arrive; (void)counter;
+  // `counter` is the epoch word, `arrive` counts finished workgroups of this launch
+  if (tid == 0) {
+    unsigned t = (unsigned)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    s_tag = (t == 0u) ? 1u : t;                     // 0 is the zero-filled (never published) state
+  }
+  __syncthreads();
+  const unsigned tag = s_tag;
   for (int t = blockIdx.x; t < total; t += gridDim.x) {
     const int c = t / G, r = t - c * G, b = r / S, s = r - b * S;
     const int p = b * C + c;
@@ -82,11 +93,11 @@ __global__ __launch_bounds__(kFusedThreads) void style_fused_kernel(const float*
     }
     m2 = block_sum(m2, red);
     u64* gran = part + 2 * ((size_t)c * G);          // granules of channel c: unit (bb, ss) -> index 2*(bb*S+ss) (+1)
-    if (tid == 0) { publish_granule(gran + 2 * (b * S + s), mean_c); publish_granule(gran + 2 * (b * S + s) + 1, m2); }
+    if (tid == 0) { publish_granule(gran + 2 * (b * S + s), mean_c, tag); publish_granule(gran + 2 * (b * S + s) + 1, m2, tag); }
     // one thread per granule polls until it is published (our own two come back from memory as well)
     for (int q = tid; q < 2 * G; q += kFusedThreads) {
       float val;
-      poll_granule(gran + q, val, err);
+      poll_granule(gran + q, val, tag, err);
       if (q & 1) pm2[q >> 1] = val; else pmean[q >> 1] = val;
     }
     __syncthreads();
@@ -148,11 +159,19 @@ __global__ __launch_bounds__(kFusedThreads) void style_fused_kernel(const float*
     }
     __syncthreads();      // smu/ssig are reused by the next unit
   }
+  // end of launch: the last workgroup to get here advances the epoch (every workgroup has read it by then) and re-arms the counter
+  if (tid == 0) {
+    const int prev = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == (int)gridDim.x - 1) {
+      __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(counter, (int)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 struct FusedPlan { bool ok; int threads, nv, chunk, S, grid; size_t part_off, bytes; };
 
-// Header: [0] ticket counter, [1] error word, [4..4+C) arrival counters (ints); partials (8 B each) after, 16-B aligned.
+// State block: ints [0] epoch, [1] error word, [2] finished-workgroup counter; granules (8 B each) from byte 16.
 static FusedPlan fused_plan(int B, int C, int HW) {
   FusedPlan pl{};
   pl.ok = false;
@@ -176,7 +195,7 @@ static FusedPlan fused_plan(int B, int C, int HW) {
   if (G > capacity) return pl;
   pl.grid = (int)std::min<long>((long)C * G, threads == 1024 ? 256L : 1024L);   // never more than fit the chip together
   if (pl.grid < G) return pl;
-  pl.part_off = 16;                                                     // [0] unused, [1] error word
+  pl.part_off = 16;                                                     // [0] epoch, [1] error word, [2] arrivals
   pl.bytes = pl.part_off + 2 * (size_t)C * B * pl.S * sizeof(u64);      // two tagged granules per unit
   pl.ok = true;
   return pl;
@@ -201,14 +220,11 @@ extern "C" int ms_style_fwd_fused(const float* x, float* y, float* mu, float* si
   if (lmda != nullptr && perm == nullptr) { set_error("ms_style_fwd_fused: mixing needs perm"); return MS_ERR_INVALID; }
   if ((gamma_noise == nullptr) != (beta_noise == nullptr)) { set_error("ms_style_fwd_fused: gamma/beta noise must both be given"); return MS_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
-  // re-initialise every polled word on the stream before every launch (a memset node when captured into a graph)
-  hipError_t e = hipMemsetAsync(ws, 0, pl.bytes, st);                  // header + every granule tag
-  if (e != hipSuccess) { set_error("ms_style_fwd_fused: memset: %s", hipGetErrorString(e)); return (int)e; }
   int* hdr = (int*)ws;
   u64* part = (u64*)((char*)ws + pl.part_off);
   dim3 grid(pl.grid), block(pl.threads);
 #define MS_FUSED(NVV, TT) MS_LAUNCH((style_fused_kernel<NVV, TT>), grid, block, 0, st, x, y, mu, sig, gamma_std, beta_std, compute_std, lmda, gamma_noise, \
-                                    beta_noise, perm, coefA, coefS, part, hdr + 4, hdr, hdr + 1, B, C, HW, pl.S, pl.chunk, eps)
+                                    beta_noise, perm, coefA, coefS, part, hdr + 2, hdr, hdr + 1, B, C, HW, pl.S, pl.chunk, eps)
   if (pl.threads == 1024) {
     switch (pl.nv) { case 16: MS_FUSED(16, 1024); break; case 8: MS_FUSED(8, 1024); break; case 4: MS_FUSED(4, 1024); break;
                      case 2: MS_FUSED(2, 1024); break; default: MS_FUSED(1, 1024); break; }

@@ -298,13 +298,16 @@ class InnerLoopEngine:
         N, C, H, W = u.shape
         nparts = lib.ms_act_bwd_parts(N, C, H * W)
         part = self.t(name + ".part", C, nparts, 2)
-        bc = self.t(name + ".bcoef", C, 4)
         if self.bn_eval:                  # eval-mode BatchNorm is a fixed per-channel affine map: du = scale * g (mask only, no statistics)
             check(lib.ms_act_bwd_reduce(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
                                         N, C, H * W, slope, self._st()), "ms_act_bwd_reduce:" + name)
-            bc.zero_()
+            bc = self.buf.get(name + ".bcoef_eval")
+            if bc is None:                # columns 1..3 stay zero for the buffer's lifetime: no per-step clear (no memset node in the captured step)
+                bc = torch.zeros(C, 4, dtype=F32, device=self.dev)
+                self.buf[name + ".bcoef_eval"] = bc
             bc[:, 0].copy_(coef[:, 0])
             return gin, bc
+        bc = self.t(name + ".bcoef", C, 4)
         if not self.fuse_bn_bwd:
             # two launches measured faster at C2 (254.8 vs 236.5 steps/s): the one-launch form puts an s_waitcnt vmcnt(0) + a returning
             # atomic on every workgroup's tail (4096 workgroups per launch), which costs more than the ~5 us second launch saves
@@ -498,7 +501,7 @@ class InnerLoopEngine:
         y = self.t(f"st{i}.y", *x.shape)
         stats = self.t(f"st{i}.stats", 4, B, C)          # mu, sig, A, S
         std = self.t(f"st{i}.std", 2, C)                 # gamma_std, beta_std (frozen after the first forward)
-        ws = self._style_ws(lib.ms_style_ws_bytes(B, C, HW))
+        ws = self._style_ws(i, lib.ms_style_ws_bytes(B, C, HW))
         po = lambda nm: self.flat_p.data_ptr() + 4 * s.off[nm][0]
         check(lib.ms_style_fwd(x.data_ptr(), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), std[0].data_ptr(), std[1].data_ptr(),
                                0 if s.have_std else 1, po("lmda") if s.mix_style else 0, po("gamma_noise") if s.use_noise else 0,
@@ -515,7 +518,7 @@ class InnerLoopEngine:
         HW = x.shape[2] * x.shape[3]
         stats, std = self.buf[f"st{i}.stats"], self.buf[f"st{i}.std"]
         dx = self.t(f"st{i}.dx", *x.shape) if need_dx else None
-        ws = self.buf["style.ws"]
+        ws = self.buf[f"st{i}.ws"]
         go = lambda nm: self.flat_g.data_ptr() + 4 * s.off[nm][0]
         po = lambda nm: self.flat_p.data_ptr() + 4 * s.off[nm][0]
         check(lib.ms_style_bwd(dy.data_ptr(), x.data_ptr(), 0 if dx is None else dx.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
@@ -524,13 +527,14 @@ class InnerLoopEngine:
                                B, C, HW, ws.data_ptr(), ws.numel(), self._st()), f"ms_style_bwd:{i}")
         return dx
 
-    def _style_ws(self, nbytes):
-        b = self.buf.get("style.ws")
+    def _style_ws(self, i, nbytes):
+        """One workspace per layer, zero-filled once: its tail is the persistent epoch state of the single-read kernel (ms_style_ws_bytes)."""
+        b = self.buf.get(f"st{i}.ws")
         if b is None or b.numel() < nbytes:
             if self._graph is not None:
-                raise RuntimeError("style workspace would grow while a captured graph is live")
-            b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=self.dev)
-            self.buf["style.ws"] = b
+                raise RuntimeError("style workspace would be re-allocated while a captured graph is live")
+            b = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.dev)
+            self.buf[f"st{i}.ws"] = b
         return b
 
     def _is_identity(self, i, shape):

@@ -45,9 +45,19 @@ def workspace(nbytes, device):
     return buf
 
 
-def style_ws(B, C, HW, device):
-    n = lib.ms_style_ws_bytes(B, C, HW)
-    return workspace(n, device)
+_style_ws_cache = {}
+
+
+def style_ws(B, C, HW, device, kind="ws"):
+    """Workspace of one MaxStyle layer shape: zero-filled once, dedicated to that shape on that stream (its tail is the persistent
+    launch-epoch state of the single-read kernel: include/maxstyle_hip.h, ms_style_ws_bytes).  kind="fused": the state block alone."""
+    key = (device, _stream(), B, C, HW, kind)
+    buf = _style_ws_cache.get(key)
+    if buf is None:
+        n = lib.ms_style_ws_bytes(B, C, HW) if kind == "ws" else lib.ms_style_fused_ws_bytes(B, C, HW)
+        buf = torch.zeros(max(int(n), 64), dtype=torch.uint8, device=device)
+        _style_ws_cache[key] = buf
+    return buf
 
 
 def style_moments(x, eps=1e-6):
@@ -71,7 +81,7 @@ def style_fwd(x, perm, lmda, gamma_noise, beta_noise, gamma_std, beta_std, compu
     y = torch.empty_like(x) if out is None else out
     stats = torch.empty(4, B, C, 1, 1, device=dev, dtype=torch.float32)
     mu, sig, cA, cS = stats[0], stats[1], stats[2], stats[3]
-    ws = style_ws(B, C, HW, dev)
+    ws = style_ws(B, C, HW, dev, "fused" if impl == "fused" else "ws")
     fn = {None: lib.ms_style_fwd, "fused": lib.ms_style_fwd_fused, "3k": lib.ms_style_fwd_3k}[impl]
     check(fn(x.data_ptr(), y.data_ptr(), mu.data_ptr(), sig.data_ptr(), gamma_std.data_ptr(), beta_std.data_ptr(),
              int(compute_std), _ptr(lmda), _ptr(gamma_noise), _ptr(beta_noise), _ptr(perm),

@@ -185,3 +185,37 @@ def test_fcn64_three_channel(dev):
     for n, gr in grads.items():
         i, nm = n.split(".")
         assert rel(eng.grad(int(i), nm), gr) < 0.1, n
+
+
+def test_single_read_kernel_under_graph_replay_with_foreign_work(dev):
+    """Regression: at config-2 size the L4 MaxStyle forward uses the single-read kernel inside the captured step.  Its granule table used
+    to be cleared by a memset node; under replay, with other kernels interleaved between calls, it was seen polling uncleared words
+    (wrong statistics -> NaN after a few training iterations).  Launch-epoch tags need no clearing: replays must equal eager, bit for bit,
+    also when unrelated work touches the GPU between the calls."""
+    from maxstyle_amd._lib import lib
+    from oracle import maxstyle_oracle as orc
+    layers = [3, 4, 5]
+    eng, W, img, lab, styles = build_engine(dev, orc.NetSpec(4, 1, 4), 16, 256, layers)
+    z_i, _ = eng.encode_fwd(img.to(dev))
+    code = z_i.clone()
+    junk = torch.randn(64, 1024, 1024, device=dev)
+    outs = []
+    for rep, graph in enumerate((False, True, True, True, True, False)):
+        for i in layers:
+            st = styles[i]
+            eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
+            eng.styles[i].have_std = False
+        eng.flat_m.zero_(); eng.flat_v.zero_(); eng.flat_g.zero_()
+        out = eng.run(code, lab.to(dev), 4, use_graph=graph).clone()
+        outs.append((out, eng.losses(4).clone()))
+        for _ in range(3):
+            junk = junk * 1.0001 + 0.5              # foreign kernels between the calls
+        torch.cuda.synchronize()
+    for out, losses in outs[1:]:
+        assert torch.equal(out, outs[0][0]) and torch.equal(losses, outs[0][1])
+    assert bool(torch.isfinite(outs[0][0]).all())
+    nfused = lib.ms_style_fused_ws_bytes(16, 16, 256 * 256)
+    assert nfused > 0
+    state = eng.buf["st4.ws"][-((nfused + 15) // 16 * 16):].view(torch.int32)
+    assert int(state[1]) == 0, "bounded spin timed out (error word set)"
+    assert int(state[0]) > 0, "the single-read kernel ran (epoch advanced)"

@@ -183,8 +183,10 @@ def test_fused_single_read_equals_three_kernel(dev, shape):
     y_a = ops.style_fwd(x, perm, lm, gn, bn, outs["fused"][5], outs["fused"][6], False, impl="fused")[0].clone()
     y_b = ops.style_fwd(x, perm, lm, gn, bn, outs["fused"][5], outs["fused"][6], False, impl="fused")[0].clone()
     assert torch.equal(y_a, y_b)
-    ws = ops.style_ws(B, C, H * W, dev)
-    assert int(ws[:8].view(torch.int32)[1]) == 0, "bounded spin timed out (error word set)"
+    st = ops.style_ws(B, C, H * W, dev, "fused")            # persistent state of the single-read kernel: [0] launch epoch, [1] error word
+    words = st[:8].view(torch.int32)
+    assert int(words[1]) == 0, "bounded spin timed out (error word set)"
+    assert int(words[0]) == 4, "every launch advances the epoch exactly once"
 
 
 @pytest.mark.parametrize("tag,mix,lm", [("random", "random", None), ("cross", "crossdomain", None), ("extrap", "random", 1.7), ("dsu", "gaussian", None)])

@@ -1,0 +1,33 @@
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+from maxstyle_amd import ops
+dev = torch.device("cuda:0")
+B, C, H, W = 16, 16, 256, 256
+torch.manual_seed(0)
+bad = 0
+filler = torch.randn(16, 16, 256, 256, device=dev)
+for it in range(1500):
+    scale = 10.0 ** float(torch.randint(-3, 4, (1,)))
+    x = torch.randn(B, C, H, W, device=dev) * scale + torch.randn(1, C, 1, 1, device=dev) * scale * 5
+    if it % 7 == 3:
+        x[:, it % C] = 0.25                     # a constant channel
+    perm = torch.randperm(B, device=dev)
+    lm = torch.rand(B, 1, 1, 1, device=dev) * 1.4 - 0.2
+    gn = torch.randn(B, C, 1, 1, device=dev); bn = torch.randn(B, C, 1, 1, device=dev)
+    gs1 = torch.zeros(1, C, 1, 1, device=dev); bs1 = torch.zeros(1, C, 1, 1, device=dev)
+    gs2 = torch.zeros(1, C, 1, 1, device=dev); bs2 = torch.zeros(1, C, 1, 1, device=dev)
+    if it % 3 == 0:
+        filler.mul_(1.0001)                     # other work in flight on the stream
+    y1, mu1, sg1, a1, s1 = ops.style_fwd(x, perm, lm, gn, bn, gs1, bs1, True, impl="fused")
+    y1 = y1.clone(); mu1 = mu1.clone(); sg1 = sg1.clone()
+    ws = ops.style_ws(B, C, H * W, dev)
+    err = int(ws.view(torch.int32)[1])
+    y2, mu2, sg2, a2, s2 = ops.style_fwd(x, perm, lm, gn, bn, gs2, bs2, True, impl="3k")
+    d = float((y1 - y2).abs().max() / (y2.abs().max() + 1e-30))
+    fin = bool(torch.isfinite(y1).all())
+    if err or not fin or d > 1e-4:
+        bad += 1
+        print(it, "err", err, "finite", fin, "rel diff", d, "scale", scale, "dmu", float((mu1 - mu2).abs().max()), "dsig", float((sg1 - sg2).abs().max()))
+        if bad > 10: break
+print("done, bad =", bad)
