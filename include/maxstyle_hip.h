@@ -147,6 +147,8 @@ int ms_pool2_sum(const float* in, float* out, int planes, int Ho, int Wo, int ac
  * p_mode 2: P = pa[m]*p + pb[m]*p2 + pc[m] (BatchNorm backward of the masked gradient p with the raw conv output p2 - what ms_conv2d's
  *   pro_mode 2 applies on the data-gradient side); q_mode 1: Q = LeakyReLU_slope(qa[n]*q + qb[n]) (BatchNorm apply + activation of the
  *   producer layer); coefficient arrays are read with stride coef_stride (4 for the float4 tables of ms_bn_finalize / ms_bn_bwd_coefs).
+ * Built combinations: 3x3 stride 1: (p_mode,q_mode) in {(0,0),(2,0),(2,1)}; 1x1: (0,0),(2,0); stride 2 (3x3, ConvTranspose 2x2): (0,0) - the ones
+ * the networks need; anything else returns an error.
  * Deterministic: per-workgroup partials in `ws` (ms_conv_wgrad_ws_bytes), summed in a fixed order; accumulate != 0 adds to dw. */
 size_t ms_conv_wgrad_ws_bytes(int N, int M, int Nq, int Hp, int Wp, int ks, int stride);
 int ms_conv_wgrad(const float* p, const float* p2, const float* q, float* dw, int N, int M, int Nq, int Hp, int Wp, int Hq, int Wq,
@@ -162,7 +164,8 @@ int ms_bn_bwd_full(const float* part2, int nparts, const float* coef4, double co
                    int accumulate, int C, void* stream);
 
 /* out[c] (+)= sum_{n,hw} x[n,c,hw]: bias.grad of a convolution from the gradient of its output. */
-int ms_channel_sum(const float* x, int N, int C, int HW, float* out, int accumulate, void* stream);
+size_t ms_channel_sum_ws_bytes(int N, int C);
+int ms_channel_sum(const float* x, int N, int C, int HW, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* weight.grad [K][C] / bias.grad [K] (db may be NULL) of a 1x1 head, d computed on the fly:
  *   mode 0: d = scale*(softmax(aux) - onehot(target int64 [N,HW]))   aux = logits [N,K,HW]      (cross_entropy_2D, custom_loss.py:1043-1078)
@@ -182,6 +185,14 @@ int ms_mse_loss(const float* x, const float* target, size_t n, float loss_scale,
  * (advanced_triplet...py:1055-1086); step semantics as ms_adam_step. */
 int ms_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float weight_decay,
                   int step, const int* step_dev, void* stream);
+
+/* After an optimiser step: re-pack every convolution weight from the flat parameter buffer into ms_conv2d's forward and data-gradient
+ * layouts with one launch.  desc_dev: device array of ndesc records of ms_repack_desc_bytes() bytes each
+ *   { int64 begin (prefix sum of element counts), int64 src_off (floats into flat), float* dst_fwd, float* dst_dgrad,
+ *     int32 kind (0 Conv2d [Cout][Cin][k][k], 1 ConvTranspose2d k2s2 [Cin][Cout][2][2]), d0, d1, k, cin_pad_fwd, cout_pad_fwd, cin_pad_dgrad, cout_pad_dgrad };
+ * total = sum of element counts.  Padding of the packed buffers is left untouched (zero from allocation). */
+size_t ms_repack_desc_bytes(void);
+int ms_repack_weights(const float* flat, const void* desc_dev, int ndesc, long long total, void* stream);
 
 /* Running statistics of a tracking BatchNorm forward from the coefficient table of ms_bn_finalize (mean, invstd):
  * running = (1-momentum)*running + momentum*batch, variance unbiased (count/(count-1)). */

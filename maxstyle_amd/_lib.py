@@ -54,12 +54,15 @@ SIGNATURES = {
     "ms_conv_wgrad": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_int, c_float, c_int, c_void, c_size, c_void]),
     "ms_bn_bwd_full": (c_int, [c_f32p, c_int, c_f32p, ctypes.c_double, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_void]),
-    "ms_channel_sum": (c_int, [c_f32p, c_int, c_int, c_int, c_f32p, c_int, c_void]),
+    "ms_channel_sum_ws_bytes": (c_size, [c_int, c_int]),
+    "ms_channel_sum": (c_int, [c_f32p, c_int, c_int, c_int, c_f32p, c_int, c_void, c_size, c_void]),
     "ms_head_wgrad_ws_bytes": (c_size, [c_int, c_int, c_int, c_int]),
     "ms_head_wgrad": (c_int, [c_f32p, c_f32p, c_void, c_int, c_float, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_void, c_size, c_void]),
     "ms_mse_ws_bytes": (c_size, []),
     "ms_mse_loss": (c_int, [c_f32p, c_f32p, c_size, c_float, c_float, c_f32p, c_f32p, c_void, c_size, c_void]),
     "ms_adamw_step": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_size, c_float, c_float, c_float, c_float, c_float, c_int, c_void, c_void]),
+    "ms_repack_desc_bytes": (c_size, []),
+    "ms_repack_weights": (c_int, [c_f32p, c_void, c_int, ctypes.c_longlong, c_void]),
     "ms_bn_running_update": (c_int, [c_f32p, c_f32p, c_f32p, c_int, ctypes.c_double, c_float, c_float, c_void]),
     "ms_rescale_intensity": (c_int, [c_f32p, c_f32p, c_int, c_int, c_float, c_float, c_float, c_void]),
     "ms_confusion": (c_int, [c_f32p, c_i64p, c_void, c_int, c_int, c_int, c_void]),

@@ -37,24 +37,32 @@ __global__ __launch_bounds__(256) void bn_bwd_full_kernel(const float2* __restri
   }
 }
 
-// out[c] (+)= sum over n, hw of x[n,c,hw]: one workgroup per channel, fp64 accumulation across the block
-__global__ __launch_bounds__(1024) void channel_sum_kernel(const float* __restrict__ x, int N, int C, int HW, float* __restrict__ out, int accumulate) {
+// out[c] (+)= sum over n, hw of x[n,c,hw].  Stage 1: one workgroup per (channel, image) plane -> part[c][n] (fp64); stage 2: fixed-order sum.
+__global__ __launch_bounds__(256) void channel_sum_part_kernel(const float* __restrict__ x, int C, int HW, double* __restrict__ part) {
   __shared__ double redd[16];
-  const int c = blockIdx.x;
-  float s = 0.f;
-  double acc = 0.0;
-  for (int n = 0; n < N; ++n) {
-    const float* p = x + ((size_t)n * C + c) * HW;
-    s = 0.f;
-    if (HW % 4 == 0) {
-      for (int i = threadIdx.x * 4; i < HW; i += 4096) { const float4 v = *reinterpret_cast<const float4*>(p + i); s += (v.x + v.y) + (v.z + v.w); }
-    } else {
-      for (int i = threadIdx.x; i < HW; i += 1024) s += p[i];
+  const int c = blockIdx.x, n = blockIdx.y;
+  const float* p = x + ((size_t)n * C + c) * HW;
+  float s0 = 0.f, s1 = 0.f;
+  if (HW % 4 == 0) {
+    int i = threadIdx.x * 4;
+    for (; i + 1024 < HW; i += 2048) {
+      const float4 v = *reinterpret_cast<const float4*>(p + i), w = *reinterpret_cast<const float4*>(p + i + 1024);
+      s0 += (v.x + v.y) + (v.z + v.w); s1 += (w.x + w.y) + (w.z + w.w);
     }
-    acc += (double)s;
+    for (; i < HW; i += 1024) { const float4 v = *reinterpret_cast<const float4*>(p + i); s0 += (v.x + v.y) + (v.z + v.w); }
+  } else {
+    for (int i = threadIdx.x; i < HW; i += 256) s0 += p[i];
   }
-  acc = block_sum_d(acc, redd);
-  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)acc : (float)acc;
+  const double acc = block_sum_d((double)s0 + (double)s1, redd);
+  if (threadIdx.x == 0) part[(size_t)c * gridDim.y + n] = acc;
+}
+
+__global__ __launch_bounds__(64) void channel_sum_final_kernel(const double* __restrict__ part, int N, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < N; i += 64) s += part[(size_t)c * N + i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 constexpr int kHeadMaxC = 64, kHeadMaxK = 4, kHeadCB = 16;
@@ -196,8 +204,48 @@ __global__ void bn_running_kernel(const float4* __restrict__ coef, float* __rest
   rv[c] = rv[c] * (1.f - mom) + mom * var;
 }
 
+// One launch re-packs every convolution weight of the three sub-nets from the flat parameter buffer into the two kernel layouts
+// (ms_conv2d forward / data-gradient).  Source-driven: thread = one weight element; the zero padding of the packed buffers is never touched.
+struct RepackDesc {          // 64 bytes, device-resident table built once by the host (addresses are stable)
+  long long begin;           // prefix sum: first global element index of this tensor
+  long long src_off;         // float offset into the flat buffer
+  float* dst_f; float* dst_d;
+  int kind;                  // 0: Conv2d [d0=Cout][d1=Cin][k][k], 1: ConvTranspose2d(k=2,s=2) [d0=Cin][d1=Cout][2][2]
+  int d0, d1, k;
+  int cinp_f, coutp_f, cinp_d, coutp_d;
+};
+
+__global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ flat, const RepackDesc* __restrict__ desc, int ndesc, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].begin <= i) lo = mid; else hi = mid - 1; }
+  const RepackDesc d = desc[lo];
+  const int e = (int)(i - d.begin);
+  const float v = flat[d.src_off + e];
+  const int kk = d.k * d.k;
+  const int tap = e % kk, ky = tap / d.k, kx = tap % d.k;
+  const int b = (e / kk) % d.d1, a = e / (kk * d.d1);
+  if (d.kind == 0) {         // a = co, b = ci
+    d.dst_f[((size_t)tap * d.cinp_f + b) * d.coutp_f + a] = v;
+    const int tapr = (d.k - 1 - ky) * d.k + (d.k - 1 - kx);
+    d.dst_d[((size_t)tapr * d.cinp_d + a) * d.coutp_d + b] = v;
+  } else {                   // a = ci, b = co, tap = dy*2+dx
+    d.dst_f[(size_t)a * d.coutp_f + tap * d.d1 + b] = v;
+    d.dst_d[((size_t)tap * d.cinp_d + b) * d.coutp_d + a] = v;
+  }
+}
+
 }  // namespace ms
 using namespace ms;
+
+extern "C" size_t ms_repack_desc_bytes(void) { return sizeof(RepackDesc); }
+
+extern "C" int ms_repack_weights(const float* flat, const void* desc_dev, int ndesc, long long total, void* stream) {
+  if (ndesc < 1 || total < 1) { set_error("ms_repack_weights: nothing to do"); return MS_ERR_INVALID; }
+  MS_LAUNCH(repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat, (const RepackDesc*)desc_dev, ndesc, total);
+  return check_launch("repack");
+}
 
 extern "C" int ms_bn_bwd_full(const float* part2, int nparts, const float* coef4, double count, float* coef_out4, float* dgamma, float* dbeta, float* dsum,
                               int accumulate, int C, void* stream) {
@@ -207,10 +255,16 @@ extern "C" int ms_bn_bwd_full(const float* part2, int nparts, const float* coef4
   return check_launch("bn_bwd_full");
 }
 
-extern "C" int ms_channel_sum(const float* x, int N, int C, int HW, float* out, int accumulate, void* stream) {
-  if (N < 1 || C < 1 || HW < 1) { set_error("ms_channel_sum: invalid shape"); return MS_ERR_INVALID; }
-  MS_LAUNCH(channel_sum_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, x, N, C, HW, out, accumulate);
-  return check_launch("channel_sum");
+extern "C" size_t ms_channel_sum_ws_bytes(int N, int C) { return (size_t)N * C * sizeof(double); }
+
+extern "C" int ms_channel_sum(const float* x, int N, int C, int HW, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  if (N < 1 || C < 1 || HW < 1 || N > 65535) { set_error("ms_channel_sum: invalid shape"); return MS_ERR_INVALID; }
+  if (ws == nullptr || ws_bytes < ms_channel_sum_ws_bytes(N, C)) { set_error("ms_channel_sum: workspace too small"); return MS_ERR_WORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  MS_LAUNCH(channel_sum_part_kernel, dim3(C, N), dim3(256), 0, st, x, C, HW, (double*)ws);
+  if (int e = check_launch("channel_sum_part")) return e;
+  MS_LAUNCH(channel_sum_final_kernel, dim3(C), dim3(64), 0, st, (const double*)ws, N, out, accumulate);
+  return check_launch("channel_sum_final");
 }
 
 static int head_wgrad_chunk(int HW) { return std::max(1024, cdiv(cdiv(HW, 64), 256) * 256); }     // <= 64 blocks per image

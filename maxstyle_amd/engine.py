@@ -90,6 +90,7 @@ class BNW:
         self.beta = sd[name + ".bias"].detach().float().contiguous()
         self.name = name
         rm, rv = sd.get(name + ".running_mean"), sd.get(name + ".running_var")
+        self._rm, self._rv = rm, rv          # the module's buffers (shared storage): refresh_eval_ re-reads them
         self.coef_eval = self.bcoef_eval = None
         if rm is not None and rv is not None:
             invstd = torch.rsqrt(rv.detach().float() + BN_EPS)
@@ -99,7 +100,10 @@ class BNW:
 
     def update_(self, sd):
         self.gamma.copy_(sd[self.name + ".weight"].detach().float()); self.beta.copy_(sd[self.name + ".bias"].detach().float())
-        rm, rv = sd.get(self.name + ".running_mean"), sd.get(self.name + ".running_var")
+        self.refresh_eval_(sd.get(self.name + ".running_mean"), sd.get(self.name + ".running_var"))
+
+    def refresh_eval_(self, rm, rv):
+        """Recompute the eval-mode coefficient tables in place from the current gamma/beta and running statistics."""
         if self.coef_eval is not None and rm is not None:
             invstd = torch.rsqrt(rv.detach().float() + BN_EPS)
             sc = self.gamma * invstd
@@ -122,6 +126,52 @@ class PackedNets:
             self.seg = self._pack_decoder(seg_sd, False, cv)
         if dec_sd is not None:
             self.dec = self._pack_decoder(dec_sd, True, cv)
+
+    eval_dirty = False          # eval-mode BatchNorm tables are stale (weights moved): recomputed on first use (InnerLoopEngine.bn_fin)
+    _desc = None
+
+    def bind_bank(self, bank):
+        """Build the device descriptor table for ms_repack_weights: every ConvW of the three tables <- its slice of bank.flat_p.
+        Requires that this PackedNets was built from state_dicts that already alias the bank (biases / BatchNorm affine / head weights are
+        then views of the flat buffer and need no copy at all)."""
+        import numpy as np
+        assert lib.ms_repack_desc_bytes() == 64
+        dt = np.dtype([("begin", "<i8"), ("src_off", "<i8"), ("dst_f", "<u8"), ("dst_d", "<u8"), ("kind", "<i4"), ("d0", "<i4"), ("d1", "<i4"), ("k", "<i4"),
+                       ("cinp_f", "<i4"), ("coutp_f", "<i4"), ("cinp_d", "<i4"), ("coutp_d", "<i4")])
+        rows, total = [], 0
+        for net, table, names in (("image_encoder", self.enc, self._enc_names), ("segmentation_decoder", self.seg, self._dec_names(False)),
+                                  ("image_decoder", self.dec, self._dec_names(True))):
+            if table is None:
+                continue
+            for key, src in names.items():
+                cw = table.get(key)
+                if not isinstance(cw, ConvW):
+                    continue
+                off, n, shape = bank.index[(net, src + ".weight")]
+                kind = 0 if cw.kind == "conv" else 1
+                rows.append((total, off, cw.wp.data_ptr(), cw.dwp.data_ptr(), kind, shape[0], shape[1], shape[2],
+                             cw.wp.shape[1], cw.wp.shape[2], cw.dwp.shape[1], cw.dwp.shape[2]))
+                total += n
+                if cw.b is not None:
+                    assert cw.b.data_ptr() == bank.param(net, src + ".bias").data_ptr(), "PackedNets must be built after the ParamBank"
+        arr = np.array(rows, dtype=dt)
+        self._desc = torch.from_numpy(arr.view(np.uint8).copy()).to(bank.flat_p.device)
+        self._desc_n, self._desc_total, self._bank = len(rows), total, bank
+
+    def repack_from_bank(self):
+        """After the flat optimiser moved the weights: one launch (graphs stay valid - same buffers)."""
+        check(lib.ms_repack_weights(self._bank.flat_p.data_ptr(), self._desc.data_ptr(), self._desc_n, self._desc_total, torch.cuda.current_stream().cuda_stream),
+              "ms_repack_weights")
+        self.eval_dirty = True
+
+    def refresh_eval(self):
+        for table in (self.enc, self.seg, self.dec):
+            if table is None:
+                continue
+            for obj in table.values():
+                if isinstance(obj, BNW):
+                    obj.refresh_eval_(obj._rm, obj._rv)
+        self.eval_dirty = False
 
     def update_(self, enc_sd=None, seg_sd=None, dec_sd=None):
         """In-place refresh after an optimiser step on the networks: same buffers, new values (graphs stay valid)."""
@@ -279,6 +329,8 @@ class InnerLoopEngine:
         if self.bn_eval:
             if bn.coef_eval is None:
                 raise RuntimeError("eval-mode BatchNorm needs running statistics in the state_dict")
+            if self.nets.eval_dirty:
+                self.nets.refresh_eval()
             self.buf[name + ".coef"] = bn.coef_eval
             return bn.coef_eval
         coef = self.t(name + ".coef", bn.gamma.numel(), 4)

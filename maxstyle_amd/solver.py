@@ -185,18 +185,35 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                 m.train(states[k])
 
     # ------------------------------------------------------------------ the hot path
+    def _weights_key(self):
+        """Changes whenever a parameter or buffer of the three sub-nets was written through torch (in-place ops bump `_version`) or by the
+        flat optimiser (`_weights_epoch`); cheap enough to evaluate on every call."""
+        if self._wk_tensors is None:
+            self._wk_tensors = [t for m in self.model.values() for t in list(m.parameters()) + list(m.buffers()) if t.is_floating_point()]
+        return (self._weights_epoch, len(self._wk_tensors), sum(t._version for t in self._wk_tensors), id(self._wk_tensors[0]))
+
+    _wk_tensors = None
+    _bn_maps = None
+
     def _loop_engine(self, B, H, W, dev):
-        key = (self._weights_epoch,) + tuple((id(p), p._version) for m in self.model.values() for p in list(m.parameters()) + list(m.buffers()))
+        key = self._weights_key()
         spec = E.NetSpec(self.reduce_factor, self.image_ch, self.num_classes)
         if self._packed_key != key:
-            sd = {k: {n: v.detach() for n, v in m.state_dict().items()} for k, m in self.model.items()}
+            only_flat = (self._packed is not None and self._bank is not None and self._packed._desc is not None and self._packed_key is not None
+                         and key[1:] == self._packed_key[1:])
+            sd = None if only_flat else {k: {n: v.detach() for n, v in m.state_dict().items()} for k, m in self.model.items()}
             if self._packed is None:
                 self._packed = E.PackedNets(spec, sd['image_encoder'], sd['segmentation_decoder'], sd['image_decoder'])
                 for eng in self._engines.values():
                     eng.set_nets(self._packed)
+                if self._bank is not None:
+                    self._packed.bind_bank(self._bank)
             else:
                 # the optimiser moved the weights: refresh the packed copies IN PLACE so captured HIP graphs stay valid
-                self._packed.update_(sd['image_encoder'], sd['segmentation_decoder'], sd['image_decoder'])
+                if only_flat:
+                    self._packed.repack_from_bank()          # one launch; biases / BatchNorm affine / heads alias the flat buffer
+                else:
+                    self._packed.update_(sd['image_encoder'], sd['segmentation_decoder'], sd['image_decoder'])
                 for eng in self._engines.values():
                     eng._prefix_valid = False
             self._packed_key = key
@@ -323,9 +340,15 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             if dev.type != 'cuda':
                 raise RuntimeError("training runs on the MI355X only (HIP kernels); move the solver to the GPU first")
             self._bank = T.ParamBank(self.model, dev)
+            self._bank_sentinel = next(self.model[T.NETS[0]].parameters())       # first tensor of the flat buffers (offset 0)
+            self._packed = None                       # rebuild the packed copies from tensors that alias the flat buffer
+            self._packed_key = None
             self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+            self._wk_tensors = None
         else:
-            self._bank.rebind(self.model)
+            p0 = self._bank_sentinel
+            if p0.grad is None or p0.grad.data_ptr() != self._bank.flat_g.data_ptr():     # a zero_grad(set_to_none=True) dropped the views
+                self._bank.rebind(self.model)
         return self._bank
 
     def set_optimizers(self):
@@ -390,7 +413,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             raise NotImplementedError("shape-refinement (STN) and no_im_recon variants are outside the MaxStyle path (SURVEY.md 8)")
         if self.class_weights is not None:
             raise NotImplementedError("class_weights is None in every MaxStyle config")
-        self.train()
+        if not (self.training and all(m.training for m in self.model.values())):
+            self.train()
         x = perturbed_image.detach().contiguous().float()
         if not x.is_cuda:
             raise RuntimeError("standard_training runs on the MI355X only (HIP kernels); got a CPU tensor")
@@ -399,7 +423,9 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         labels = label_l.detach().to(device=x.device, dtype=torch.int64).contiguous()
         clean = clean_image_l.detach().contiguous().float()
         track = not disable_track_bn_stats
-        bns = tuple({n: m for n, m in self.model[k].named_modules() if isinstance(m, nn.BatchNorm2d)} for k in T.NETS)
+        if self._bn_maps is None:
+            self._bn_maps = tuple({n: m for n, m in self.model[k].named_modules() if isinstance(m, nn.BatchNorm2d)} for k in T.NETS)
+        bns = self._bn_maps
         seg_loss, rec_loss = _TrainPassFn.apply(self._anchor, self, eng, x, labels, clean, track, bns)
         z_i, z_s = eng.buf["e.z_i"], eng.buf["e.z_s"]
         if update_latent:

@@ -134,7 +134,8 @@ class TrainEngine(InnerLoopEngine):
 
     def channel_sum(self, x, out):
         N, C, H, W = x.shape
-        check(lib.ms_channel_sum(x.data_ptr(), N, C, H * W, out.data_ptr(), 1, self._st()), "ms_channel_sum")
+        ws = self.t("cs.ws", max(lib.ms_channel_sum_ws_bytes(N, self.spec.code_ch), 64), dtype=torch.uint8)
+        check(lib.ms_channel_sum(x.data_ptr(), N, C, H * W, out.data_ptr(), 1, ws.data_ptr(), ws.numel(), self._st()), "ms_channel_sum")
 
     def act_bwd_t(self, name, gin, ref, u, coef, slope, net, bn_key, dsum=None):
         """Mask gin in place, BatchNorm-backward coefficients, BatchNorm parameter gradients (+ dsum: bias.grad of the residual 1x1 conv)."""
@@ -205,6 +206,7 @@ class TrainEngine(InnerLoopEngine):
             counters.append(m.num_batches_tracked)
         if counters:
             torch._foreach_add_(counters, 1)
+            self.nets.eval_dirty = True          # eval-mode BatchNorm tables are recomputed from the running statistics on their next use
 
     # ------------------------------------------------------------------ backward
     def res_bwd_t(self, pfx, net, key, x, dout, kind, need_dx=True):

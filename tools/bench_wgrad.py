@@ -22,8 +22,11 @@ def main():
               ("d4.c3 128->128@16 +pro", 128, 128, 16, 16, 3, 1, 0, True), ("u4.ci 16->16@256 1x1", 16, 16, 256, 256, 1, 1, 0, False),
               ("d1.ci 16->32@128 1x1", 32, 16, 128, 128, 1, 1, 0, False), ("d1.down 16->16 s2 @128", 16, 16, 128, 128, 3, 2, 0, False),
               ("d3.down 64->64 s2 @32", 64, 64, 32, 32, 3, 2, 0, False)]
+    only = sys.argv[1] if len(sys.argv) > 1 else None
     out = {}
     for name, co, ci, H, W, ks, s, ups, pro in layers:
+        if only and only not in name:
+            continue
         hq, wq = (H * s, W * s) if not ups else (H // 2, W // 2)
         dy = torch.randn(B, co, H, W, device=dev)
         x = torch.randn(B, ci, hq, wq, device=dev)
@@ -34,6 +37,10 @@ def main():
         flops = 2.0 * B * H * W * co * ci * ks * ks
         byts = 4.0 * (dy.numel() * (2 if pro else 1) + x.numel())
         out[name] = {"us": round(t * 1e6, 1), "TFLOPs": round(flops / t / 1e12, 1), "GBps": round(byts / t / 1e9)}
+    if only:
+        for k, v in out.items():
+            print(k.ljust(34), json.dumps(v))
+        return
     # ConvTranspose 2x2 s2 (image decoder up4: 16->16, 128 -> 256)
     x = torch.randn(B, 16, 128, 128, device=dev); g = torch.randn(B, 16, 256, 256, device=dev)
     t = timeit(lambda: ops.conv_wgrad(x, g, 2, 2), 30)
