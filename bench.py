@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-outer", action="store_true", help="skip the auxiliary whole-training-iteration figure")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5, help="inner steps of the CPU-oracle sample")
     ap.add_argument("--config", default="c2", choices=["c2", "c4"], help="c2: FCN_16 1x256x256 (the quoted metric); c4: FCN_64 3x320x320 (Prostate-shaped)")
@@ -244,6 +245,45 @@ def cpu_baseline(W, img, lab, styles, steps):
                       f"({t2 - t1:.1f}s timed, warm-up {t1 - t0:.1f}s), fp32, torch CPU, {torch.get_num_threads()} threads (fastest of 8/16/32/64/{ncores} on this box)"}
 
 
+def outer_iteration(dev, batch, size, iters=6):
+    """Auxiliary figure (not the headline metric): whole training iterations/s around the inner loop at the same configuration -
+    standard pass -> MaxStyle inner loop K=5 -> hard-example pass -> backward (weight gradients) -> AdamW x3
+    (train_adv_supervised_segmentation_triplet.py:163-199, 251-287, 532-535; SURVEY.md 8(f) rows 1,3)."""
+    import maxstyle_amd as M
+    from oracle import maxstyle_oracle as orc          # synthetic data generator only
+    S = M.AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard_no_STN", image_ch=1, num_classes=4, use_gpu=True, optimizer_type="AdamW")
+    clean, lab = orc.synthetic_batch(batch, size, 1, 4, 1234)
+    clean, lab = clean.to(dev), lab.to(dev)
+    cfg = {"mix_style": True, "no_noise": False, "lr": 0.1, "n_iter": 5, "mix_learnable": True, "noise_learnable": True,
+           "decoder_layers_indexes": [3, 4, 5], "loss_types": ["seg"], "loss_weights": [1], "always_use_beta": False}
+
+    def iteration():
+        S.train()
+        S.reset_all_optimizers()
+        image_l = torch.clamp(clean + 0.05 * torch.randn_like(clean), clean.min(), clean.max())
+        seg0, rec0, gt0, sh0, recon0, p0, _ = S.standard_training(clean, lab, perturbed_image=image_l, return_output=True)
+        S.reset_all_optimizers()
+        sty = S.generate_max_style_image_from_config(S.z_i, cfg, clean, lab, p=1.5).detach().clone()      # p > 1: all three layers applied (worst case)
+        seg1, rec1, sh1, sh2 = S.hard_example_traininng(perturbed_image=sty, perturbed_seg=None, clean_image_l=clean, label_l=lab)
+        loss = (seg0 + rec0 + sh0 + gt0) + (rec1 + seg1 + sh1 + sh2)
+        S.reset_all_optimizers()
+        loss.backward()
+        S.optimize_all_params()
+        return loss
+
+    first = float(iteration().detach())
+    for _ in range(2):
+        iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        loss = iteration()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {"what": "training iterations/s (standard pass + K=5 inner loop + hard-example pass + backward + AdamW), same batch", "value": 1.0 / dt,
+            "ms_per_iteration": dt * 1e3, "loss_first": first, "loss_last": float(loss.detach())}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -289,6 +329,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(W, img, lab, styles, args.cpu_steps)
             res["speedup_vs_cpu"] = value / res["cpu_baseline"]["value"]
             res["dice_parity"] = dice_parity(dev)
+        if world == 1 and not args.no_outer and args.config == "c2":
+            res["outer_iteration"] = outer_iteration(dev, args.batch, args.size)
         print(json.dumps(res), flush=True)
     if dist_on:
         import torch.distributed as dist

@@ -366,6 +366,10 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         return self.optimizers if model_name is None else self.optimizers[model_name]
 
     def optimize_all_params(self):
+        """advanced_triplet...py:1083-1085.  Under torch.distributed (one process per GPU) the flat gradient buffer is all-reduced once
+        first - the data-parallel exchange the reference would get from DDP; set `self.data_parallel = False` to opt out."""
+        if getattr(self, "data_parallel", True) and self._bank is not None:
+            self._bank.all_reduce_grads()
         for v in self.optimizers.values():
             v.step()
 

@@ -80,6 +80,18 @@ class ParamBank:
                 if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
                     p.grad = self.flat_g[off:off + n].view(shape)
 
+    def all_reduce_grads(self, group=None):
+        """Data-parallel exchange of the outer step: ONE all-reduce (sum, then x 1/world) over the flat gradient buffer, in
+        place - the gradients already live in one contiguous buffer, so there is no pack / unpack.  RCCL ("nccl") on GPUs, gloo in the CPU tests."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size(group)
+        if world == 1:
+            return
+        dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
+        self.flat_g.mul_(1.0 / world)
+
     def optimizer_step(self, lr, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, decoupled=True):
         """torch.optim.AdamW (decoupled) / torch.optim.Adam(weight_decay=0) on every parameter: one launch."""
         self.step += 1

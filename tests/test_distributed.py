@@ -35,6 +35,16 @@ def _worker(rank, world, port, q):
         for m in mods:
             for i, p in enumerate(m.parameters()):
                 ok = ok and bool(torch.allclose(p.grad, torch.full_like(p, 1.5 * (1 + (i % 3)))))
+        # the outer update's own exchange: the ParamBank holds every gradient in one flat buffer -> one in-place all-reduce, no packing
+        from maxstyle_amd.train_engine import ParamBank
+        bank = ParamBank(S.model, "cpu")
+        assert bank.total >= 1536325 and all(p.grad.data_ptr() >= bank.flat_g.data_ptr() for m in mods for p in m.parameters())
+        for m in mods:
+            for i, p in enumerate(m.parameters()):
+                p.grad.fill_(float(rank + 1) * (1 + (i % 5)))
+        bank.all_reduce_grads()
+        ok = ok and all(bool(torch.allclose(p.grad, torch.full_like(p, 1.5 * (1 + (i % 5))))) for m in mods for i, p in enumerate(m.parameters()))
+        ok = ok and bool(torch.equal(torch.cat([p.detach().reshape(-1) for m in mods for p in m.parameters()]), w0))      # parameters became views, values kept
         lo, hi = D.shard_range(32, rank, world)
         tmax = D.max_over_ranks(1.0 + rank, torch.device("cpu"))
         q.put((rank, same, ok, (lo, hi), tmax))
