@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "ms_conv_kernel.h"
+#include "ms_conv_wide.h"
 #include "maxstyle_hip.h"
 
 namespace ms {
@@ -117,8 +118,10 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
   }
   a.ncb = cdiv(gemm_cols, 16 * nt);
   { static const int dbg = getenv("MS_CONV_DBG") ? atoi(getenv("MS_CONV_DBG")) : 0; a.dbg = dbg; }
+  { static const char* tr = getenv("MS_CONV_TRACE"); a.trace = tr ? (long long*)strtoull(tr, nullptr, 0) : nullptr; }
   hipStream_t st = (hipStream_t)stream;
   const bool use_in2 = (pro_mode == 2);
+  if (conv_wide_eligible(a, ks, stride, fetch, vec)) return conv_dispatch_wide(a, nt, st);
   if (ks == 3 && stride == 1) return conv_dispatch_k3s1(a, fetch, nt, vec, narrow, use_in2, st);
   if (ks == 1) return conv_dispatch_k1s1(a, nt, vec, narrow, use_in2, st);
   return conv_dispatch_s2(a, ks, nt, vec, narrow, st);

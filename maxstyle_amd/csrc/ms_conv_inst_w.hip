@@ -1,0 +1,26 @@
+// Instantiations: wide-read 3x3 stride-1 convolution (ms_conv_wide.h).
+#include "ms_conv_wide.h"
+namespace ms {
+bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool vec) {
+  static const bool off = getenv("MS_CONV_WIDE") != nullptr && atoi(getenv("MS_CONV_WIDE")) == 0;      // A/B switch for timing
+  if (off) return false;
+  if (ks != 3 || stride != 1 || fetch != FETCH_NORMAL || !vec) return false;
+  if (a.epi_mode == 2 || (a.pro_mode != 0 && a.pro_nstride != 0)) return false;
+  if (a.pro_mode == 2) return false;       // two-tensor prologue: the staging registers of this kernel spill at 128 VGPRs; the first kernel is faster there (74.8 vs 79.7 us)
+  if (a.Wout < 64 || a.Wout % 4 != 0) return false;
+  if ((long long)a.Cin * a.Hs * a.Ws >= (1LL << 31)) return false;
+  if (!aligned16(a.out)) return false;
+  return true;
+}
+template <int NT>
+static int wide_pro(const ConvArgs& a, hipStream_t st) {
+  switch (a.pro_mode) {
+    case 0: return launch_conv_wide<NT, 0>(a, st);
+    case 1: return launch_conv_wide<NT, 1>(a, st);
+    default: return launch_conv_wide<NT, 2>(a, st);
+  }
+}
+int conv_dispatch_wide(const ConvArgs& a, int nt, hipStream_t st) {
+  return nt >= 2 ? wide_pro<2>(a, st) : wide_pro<1>(a, st);
+}
+}  // namespace ms

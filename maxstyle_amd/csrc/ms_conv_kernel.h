@@ -34,6 +34,7 @@ struct ConvArgs {
   int pro_mode, pro_nstride, pro_cstride; float slope;
   int epi_mode, tiles_x, tiles_y, cout_real, ncb;   // ncb: number of output-channel blocks (of 16*NT)
   int dbg;                      // timing-only ablation bits (MS_CONV_DBG): 1 skip MFMA loop, 2 skip global loads, 4 skip epilogue
+  long long* trace;             // MS_CONV_TRACE_BUILD only: cycle stamps of workgroup 0 (tools/dbg_convtrace.py)
 };
 
 template <int KS, int STRIDE, int FETCH, bool VEC, bool NARROW, int NT>

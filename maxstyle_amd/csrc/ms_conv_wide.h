@@ -1,0 +1,444 @@
+// "Wide-read" 3x3 stride-1 convolution kernel for gfx950: the second generation of conv_mfma_kernel (ms_conv_kernel.h) for the layers
+// whose output rows are >= 64 pixels wide (the 256^2, 128^2 and 64^2 levels of the networks = most of the FLOPs of a step).
+//
+// What changed, and why (all measured on MI355X, see profiles/ and DESIGN.md):
+//   * The first kernel reads every MFMA operand with its own ds_read_b32: 5 LDS reads per 4 MFMAs.  With eight MFMA waves per CU that is
+//     ~62 % of the LDS pipe before the staging waves write anything - the consumers were LDS-bound, not MFMA-bound.  Here the MFMA M index
+//     is BLOCKED over pixels: lane m of a 16-lane group owns pixels 4m..4m+3 of a 64-pixel row segment, one M-tile per pixel-in-quad.
+//     The three kernel columns of four M-tiles then need SIX consecutive input floats per lane, channel and kernel row: one ds_read_b128 +
+//     one ds_read_b64 feed 12*NT MFMAs (was: 12 + 3*NT ds_read_b32).  Plane stride == 0 (mod 64 dwords) keeps the b128 reads conflict-free.
+//   * The accumulator fragment of a lane is then 16 CONSECUTIVE pixels of one output channel: the epilogue stores four 16-byte vectors per
+//     channel block straight from registers and the BatchNorm statistics need no cross-lane shuffles beyond the 4 lane groups.
+//   * Staging waves: everything tile-independent (LDS offsets, image-relative element offsets, per-channel prologue coefficients) is hoisted;
+//     per tile an item costs one add, and masks / zero-fill selects only run for tiles on the image border (wave-uniform branch).  VALU
+//     work on the staging waves competes with the MFMA issue of the wave sharing their SIMD, so it is kept minimal.
+// Same contract as conv_mfma_kernel<3,1,FETCH_NORMAL,NT,true,false,IN2>: ConvArgs, packed weights, prologues, epilogues, statistics table.
+#pragma once
+#include <cstdlib>
+#include <type_traits>
+#include "ms_conv_kernel.h"
+
+namespace ms {
+
+template <int NT>
+struct WideGeo {
+  static constexpr int TH = 4, TW = 64;
+  static constexpr int CK = (NT == 1) ? 16 : 8;               // input channels per K-chunk (two stage buffers, two workgroups per CU)
+  static constexpr int IH = TH + 2;
+  static constexpr int RS = TW + 4;                           // LDS row: column 0 = left halo (x0-1), 1..64 interior, 65 = right halo
+  static constexpr int PS = 448;                              // >= IH*RS = 408, == 0 (mod 64): conflict-free ds_read_b128 of the A windows
+  static constexpr int WS = (NT == 1) ? 16 : NT * 16 + 16;    // weight row stride (bank-conflict-free B fragments)
+  static constexpr int BUF = CK * PS + 9 * CK * WS;           // floats per stage buffer
+  static constexpr int Q_ITEMS = CK * IH * (TW / 4);          // interior 16-byte items
+  static constexpr int H_ITEMS = CK * IH * 2;                 // halo scalars
+  static constexpr int NQI = (Q_ITEMS + 255) / 256, NHI = (H_ITEMS + 255) / 256;
+  static constexpr int W_ITEMS = 9 * CK * (16 * NT / 4);
+  static constexpr int NWI = (W_ITEMS + 255) / 256;
+};
+
+// PRO: 0 none, 1 BatchNorm apply + LeakyReLU, 2 BatchNorm backward (two tensors)
+template <int NT, int PRO>
+__global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const ConvArgs a) {
+  using G = WideGeo<NT>;
+  constexpr int TH = G::TH, TW = G::TW, CK = G::CK, IH = G::IH, RS = G::RS, PS = G::PS, WS = G::WS, BUF = G::BUF;
+  constexpr int NQI = G::NQI, NHI = G::NHI, NWI = G::NWI, COUT_TILE = 16 * NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool producer = wave >= 4;
+  const int ntiles = a.tiles_x * a.tiles_y, ncb = a.ncb;
+  const int nitems = a.N * ntiles * ncb;
+  const int nchunks = (a.cin_pad + CK - 1) / CK;
+  const int vb = ((int)gridDim.x % 8 == 0) ? (((int)blockIdx.x % 8) * ((int)gridDim.x / 8) + (int)blockIdx.x / 8) : (int)blockIdx.x;
+  const int my_items = (nitems - vb + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int T = my_items * nchunks;
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto decode = [&](int it, int& n, int& tile, int& cb) { cb = it % ncb; const int t2 = it / ncb; tile = t2 % ntiles; n = t2 / ntiles; };
+
+  if (producer) {
+    // =========================================== PRODUCER waves ===========================================
+    const int tid = threadIdx.x - 256;
+    const int plane = a.Hs * a.Ws;                 // host checks Cin*plane < 2^31
+    typedef unsigned mask_t;
+    int q_lds[NQI], q_rc[NQI], q_off[NQI];         // LDS offset (or -1), (row << 16) | (col_rel + 16), c*plane + (r-1)*W + col_rel  (relative to the tile origin)
+    int h_lds[NHI], h_rc[NHI], h_off[NHI];
+    static_assert(NQI <= 32 && NHI <= 32, "item masks are 32 bits");
+    mask_t q_all = 0, h_all = 0;
+#pragma unroll
+    for (int j = 0; j < NQI; ++j) {
+      const int it = tid + j * 256;
+      q_lds[j] = -1; q_rc[j] = 0; q_off[j] = 0;
+      if (it < G::Q_ITEMS) {
+        const int f = it % (TW / 4), row = it / (TW / 4);
+        const int r = row % IH, c = row / IH;
+        q_lds[j] = (c << 20) | (c * PS + r * RS + 4 * f + 1);
+        q_rc[j] = (r << 16) | (4 * f + 16);
+        q_off[j] = c * plane + (r - 1) * a.Ws + 4 * f;
+        q_all |= 1u << j;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NHI; ++j) {
+      const int it = tid + j * 256;
+      h_lds[j] = -1; h_rc[j] = 0; h_off[j] = 0;
+      if (it < G::H_ITEMS) {
+        const int h = it & 1, row = it >> 1;
+        const int r = row % IH, c = row / IH;
+        const int col_rel = h ? TW : -1;
+        h_lds[j] = (c << 20) | (c * PS + r * RS + col_rel + 1);
+        h_rc[j] = (r << 16) | (col_rel + 16);
+        h_off[j] = c * plane + (r - 1) * a.Ws + col_rel;
+        h_all |= 1u << j;
+      }
+    }
+    mask_t q_ok = 0, h_ok = 0;
+    bool edge = false;
+    int t_base = 0;
+    auto set_tile = [&](int tile) {
+      const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+      const int y0 = ty * TH, x0 = tx * TW;
+      t_base = y0 * a.Ws + x0;
+      const int ylo = 1 - y0, yhi = a.Hin - y0 + 1;               // ylo <= r < yhi
+      const int xlo = 16 - x0, xhi = a.Win - x0 + 16;             // xlo <= (col_rel + 16) < xhi
+      auto inside = [&](int rc) { const int r = rc >> 16, c = rc & 0xFFFF; return (r >= ylo) && (r < yhi) && (c >= xlo) && (c < xhi); };
+      edge = (ylo > 0) || (yhi < IH) || (x0 + TW > a.Win);
+      if (edge) {
+        q_ok = 0;
+#pragma unroll
+        for (int j = 0; j < NQI; ++j) q_ok |= (inside(q_rc[j]) ? 1u : 0u) << j;
+        q_ok &= q_all;
+      } else {
+        q_ok = q_all;
+      }
+      h_ok = 0;
+#pragma unroll
+      for (int j = 0; j < NHI; ++j) h_ok |= (inside(h_rc[j]) ? 1u : 0u) << j;
+      h_ok &= h_all;
+    };
+    float rq[NQI][4], rq2[PRO == 2 ? NQI : 1][4], rh[NHI], rh2[PRO == 2 ? NHI : 1];
+    float4 rw[NWI];
+    mask_t l_q_ok = 0, l_h_ok = 0;                  // masks of the chunk held in registers
+    bool l_edge = false, have_w = false;
+    float ca[NQI], cb_[NQI], cc[PRO == 2 ? NQI : 1], hca[NHI], hcb[NHI], hcc[PRO == 2 ? NHI : 1];   // prologue coefficients of the chunk in registers
+
+    auto load_chunk = [&](int n, int co0, int c0, bool load_w) {
+      const float* in_n = a.in + (size_t)n * a.Cin * plane + (size_t)c0 * plane + t_base;
+      const float* in2_n = (PRO == 2) ? a.in2 + (size_t)n * a.Cin * plane + (size_t)c0 * plane + t_base : nullptr;
+      const bool ragged = (c0 + CK > a.Cin);          // last chunk of a layer whose channel count is not a multiple of CK
+      l_q_ok = q_ok; l_h_ok = h_ok; l_edge = edge || ragged;
+      mask_t qm = q_ok, hm = h_ok;
+      if (ragged) {
+#pragma unroll
+        for (int j = 0; j < NQI; ++j) if (c0 + (q_lds[j] >> 20) >= a.Cin) qm &= ~(1u << j);
+#pragma unroll
+        for (int j = 0; j < NHI; ++j) if (c0 + (h_lds[j] >> 20) >= a.Cin) hm &= ~(1u << j);
+        l_q_ok = qm; l_h_ok = hm;
+      }
+      const bool live = !(a.dbg & 2);
+#pragma unroll
+      for (int j = 0; j < NQI; ++j) {
+        int off = q_off[j];
+        if (l_edge) off = (((qm >> j) & 1u) && live) ? off : 0;        // masked items read the (valid) tile origin and are zeroed at the LDS store
+        const float4 v = *reinterpret_cast<const float4*>(in_n + off);
+        rq[j][0] = v.x; rq[j][1] = v.y; rq[j][2] = v.z; rq[j][3] = v.w;
+        if constexpr (PRO == 2) {
+          const float4 u = *reinterpret_cast<const float4*>(in2_n + off);
+          rq2[j][0] = u.x; rq2[j][1] = u.y; rq2[j][2] = u.z; rq2[j][3] = u.w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NHI; ++j) {
+        const int off = (((hm >> j) & 1u) && live) ? h_off[j] : 0;
+        rh[j] = in_n[off];
+        if constexpr (PRO == 2) rh2[j] = in2_n[off];
+      }
+      if constexpr (PRO != 0) {
+        // the chunk's per-channel coefficients (L1/L2-resident table; a.pro_nstride == 0 on this path)
+#pragma unroll
+        for (int j = 0; j < NQI; ++j) {
+          const int ci = min(c0 + max(q_lds[j] >> 20, 0), a.Cin - 1) * a.pro_cstride;        // lanes without an item carry -1
+          ca[j] = a.pro_a[ci]; cb_[j] = a.pro_b[ci];
+          if constexpr (PRO == 2) cc[j] = a.pro_c[ci];
+        }
+#pragma unroll
+        for (int j = 0; j < NHI; ++j) {
+          const int ci = min(c0 + max(h_lds[j] >> 20, 0), a.Cin - 1) * a.pro_cstride;
+          hca[j] = a.pro_a[ci]; hcb[j] = a.pro_b[ci];
+          if constexpr (PRO == 2) hcc[j] = a.pro_c[ci];
+        }
+      }
+      have_w = load_w;
+      if (load_w) {
+#pragma unroll
+        for (int j = 0; j < NWI; ++j) {
+          const int idx = tid + j * 256;
+          const int j4 = idx % (COUT_TILE / 4);
+          const int row = idx / (COUT_TILE / 4);      // tap*CK + c
+          const int c = row % CK, tap = row / CK;
+          rw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (idx < G::W_ITEMS && c0 + c < a.cin_pad)
+            rw[j] = *reinterpret_cast<const float4*>(a.w + ((size_t)tap * a.cin_pad + c0 + c) * a.cout_pad + co0 + j4 * 4);
+        }
+      }
+    };
+
+    auto store_chunk = [&](float* buf, auto edge_tag) {
+      constexpr bool EDGE = decltype(edge_tag)::value;
+      float* w_lds = buf + CK * PS;
+#pragma unroll
+      for (int j = 0; j < NQI; ++j) {
+        const bool full = (j + 1) * 256 <= G::Q_ITEMS;
+        if (!full && q_lds[j] < 0) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = rq[j][e];
+          if constexpr (PRO == 1) v[e] = leaky(ca[j] * v[e] + cb_[j], a.slope);
+          if constexpr (PRO == 2) v[e] = ca[j] * v[e] + (cb_[j] * rq2[j][e] + cc[j]);
+          if constexpr (EDGE) v[e] = ((l_q_ok >> j) & 1u) ? v[e] : 0.f;          // zero padding pads the tensor AFTER the prologue
+        }
+        float* dst = buf + (q_lds[j] & 0xFFFFF);
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];            // column 1 + 4f: dword stores (paired into ds_write2_b32)
+      }
+#pragma unroll
+      for (int j = 0; j < NHI; ++j) {
+        if (h_lds[j] < 0) continue;
+        float v = rh[j];
+        if constexpr (PRO == 1) v = leaky(hca[j] * v + hcb[j], a.slope);
+        if constexpr (PRO == 2) v = hca[j] * v + (hcb[j] * rh2[j] + hcc[j]);
+        buf[h_lds[j] & 0xFFFFF] = ((l_h_ok >> j) & 1u) ? v : 0.f;
+      }
+      if (have_w) {
+#pragma unroll
+        for (int j = 0; j < NWI; ++j) {
+          const int idx = tid + j * 256;
+          if (idx < G::W_ITEMS) {
+            const int j4 = idx % (COUT_TILE / 4);
+            const int row = idx / (COUT_TILE / 4);
+            *reinterpret_cast<float4*>(w_lds + row * WS + j4 * 4) = rw[j];
+          }
+        }
+      }
+    };
+
+    int key_cb[2] = {-1, -1}, key_c0[2] = {-1, -1};
+    int item = vb, chunk = 0, n, tile, cb, tile_set = -1;
+    decode(item, n, tile, cb);
+    set_tile(tile); tile_set = tile;
+    load_chunk(n, cb * COUT_TILE, 0, true);
+    lds_barrier();                                    // barrier #0 (matched by the consumers)
+#ifdef MS_CONV_TRACE_BUILD
+    const bool tr = (a.trace != nullptr) && (blockIdx.x == 0) && (threadIdx.x == 256);
+#else
+    constexpr bool tr = false;
+#endif
+    for (int p = 0; p < T; ++p) {
+      if (tr && p < 16) a.trace[128 + p * 4 + 0] = clock64();
+      if (!(a.dbg & 8)) {
+        if (l_edge) store_chunk(smem + (p & 1) * BUF, std::true_type{}); else store_chunk(smem + (p & 1) * BUF, std::false_type{});
+      }
+      if (tr && p < 16) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); a.trace[128 + p * 4 + 1] = clock64(); }
+      key_cb[p & 1] = cb; key_c0[p & 1] = chunk * CK;
+      if (p + 1 < T) {
+        if (++chunk == nchunks) { chunk = 0; item += gridDim.x; decode(item, n, tile, cb); }
+        if (tile != tile_set) { set_tile(tile); tile_set = tile; }
+        const int b = (p + 1) & 1;
+        load_chunk(n, cb * COUT_TILE, chunk * CK, !(key_cb[b] == cb && key_c0[b] == chunk * CK));
+      }
+      if (tr && p < 16) a.trace[128 + p * 4 + 2] = clock64();
+      lds_barrier();                                  // barrier #(p+1): chunk p visible; consumers done with chunk p-1
+      if (tr && p < 16) a.trace[128 + p * 4 + 3] = clock64();
+    }
+    return;
+  }
+
+  // =========================================== CONSUMER waves ===========================================
+  __builtin_amdgcn_s_setprio(2);
+  const int m = lane & 15, k = lane >> 4;
+  f32x4 acc[4][NT];                                     // [pixel-in-quad i][channel block j]: rows = lane-local pixel quads r
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int a_lane = k * PS + wave * RS + 4 * m;       // window of row (wave + ky): columns 4m .. 4m+5
+  const int b_lane = CK * PS + k * WS + m;
+
+  // one pipeline step = (4-channel group cg, kernel row ky): 2 wide A reads + 3*NT B reads feed 12*NT MFMAs
+  auto step_load = [&](const float* buf, int st, float (&win)[6], float (&bf)[3][NT]) {
+    const int cg = st / 3, ky = st % 3;
+    const float* q = buf + a_lane + cg * 4 * PS + ky * RS;
+    const float4 v = *reinterpret_cast<const float4*>(q);
+    const float2 w = *reinterpret_cast<const float2*>(q + 4);
+    win[0] = v.x; win[1] = v.y; win[2] = v.z; win[3] = v.w; win[4] = w.x; win[5] = w.y;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[kx][j] = buf[b_lane + ((ky * 3 + kx) * CK + cg * 4) * WS + j * 16];
+  };
+  // FULL = every channel group of the chunk is live: straight-line code; the guarded form only runs for a layer's ragged last chunk
+  auto compute = [&](const float* buf, auto full_tag, int ncg) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const int nst = ncg * 3;
+    float win[2][6], bf[2][3][NT];
+    step_load(buf, 0, win[0], bf[0]);
+#pragma unroll
+    for (int st = 0; st < (CK / 4) * 3; ++st) {
+      if (FULL || st < nst) {
+        if (st + 1 < (CK / 4) * 3 && (FULL || st + 1 < nst)) step_load(buf, st + 1, win[(st + 1) & 1], bf[(st + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(win[st & 1][i + kx], bf[st & 1][kx][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  // ---- epilogue: a lane holds, per channel block, 16 consecutive pixels (16k .. 16k+15) of row `wave` of the tile for channel m ----
+  float st_n = 0.f, st_mean[NT], st_m2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { st_mean[j] = 0.f; st_m2[j] = 0.f; }
+  float bias_v[NT];
+  int bias_co0 = -1;
+  auto load_bias = [&](int co0) {
+    if (co0 == bias_co0) return;
+    bias_co0 = co0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int co = co0 + j * 16 + m;
+      bias_v[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+    }
+  };
+  auto epilogue = [&](int n, int tile, int co0) {
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int y = ty * TH + wave, xb = tx * TW + 16 * k;
+    const bool row_ok = y < a.Hout;
+    int nvalid = 0;                                      // valid pixels among this lane's 16 (Wout % 4 == 0 on this path)
+    if (row_ok) nvalid = max(0, min(16, a.Wout - xb));
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] += bias_v[j];
+    if (a.stats != nullptr) {
+      float cnt = (float)nvalid;
+      cnt += __shfl_xor(cnt, 16, 64);
+      cnt += __shfl_xor(cnt, 32, 64);
+      const float nt_ = st_n + cnt;
+      const float wgt = (nt_ > 0.f) ? cnt / nt_ : 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s += (4 * r + i < nvalid) ? acc[i][j][r] : 0.f;
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const float mean = cnt > 0.f ? s / cnt : 0.f;
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const float d = acc[i][j][r] - mean; q += (4 * r + i < nvalid) ? d * d : 0.f; }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float d = mean - st_mean[j];
+        st_mean[j] += d * wgt;
+        st_m2[j] += q + d * d * st_n * wgt;
+      }
+      st_n = nt_;
+    }
+    if (row_ok && !(a.dbg & 4)) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = co0 + j * 16 + m;
+        if (co >= a.Cout) continue;
+        float* op = a.out + (((size_t)n * a.Cout + co) * a.Hout + y) * a.Wout + xb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (4 * r < nvalid) {
+            float4 v = make_float4(acc[0][j][r], acc[1][j][r], acc[2][j][r], acc[3][j][r]);
+            if (a.epi_mode == 1) { const float4 p = *reinterpret_cast<const float4*>(op + 4 * r); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+            *reinterpret_cast<float4*>(op + 4 * r) = v;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  int item = vb, chunk = 0, n, tile, cb;
+  decode(item, n, tile, cb);
+  load_bias(cb * COUT_TILE);
+  lds_barrier();                                      // barrier #0
+  lds_barrier();                                      // barrier #1: chunk 0 is in buffer 0
+#ifdef MS_CONV_TRACE_BUILD
+  const bool tr = (a.trace != nullptr) && (blockIdx.x == 0) && (threadIdx.x == 0);
+#else
+  constexpr bool tr = false;
+#endif
+  for (int p = 0; p < T; ++p) {
+    const int c0 = chunk * CK;
+    const int ncg = min(CK / 4, (a.cin_pad - c0) / 4);
+    if (tr && p < 16) a.trace[p * 4 + 0] = clock64();
+    if (!(a.dbg & 1)) {
+      if (ncg == CK / 4) compute(smem + (p & 1) * BUF, std::true_type{}, ncg);
+      else compute(smem + (p & 1) * BUF, std::false_type{}, ncg);
+    }
+    if (tr && p < 16) a.trace[p * 4 + 1] = clock64();
+    if (chunk + 1 == nchunks) {
+      epilogue(n, tile, cb * COUT_TILE);
+      if (tr && p < 16) a.trace[p * 4 + 2] = clock64();
+      chunk = 0; item += gridDim.x;
+      if (p + 1 < T) { decode(item, n, tile, cb); load_bias(cb * COUT_TILE); }
+    } else {
+      ++chunk;
+    }
+    if (p + 1 < T) lds_barrier();                     // barrier #(p+2)
+    if (tr && p < 16) a.trace[p * 4 + 3] = clock64();
+  }
+  if (a.stats != nullptr) {
+    float4* tab = reinterpret_cast<float4*>(a.stats);
+    const int cb0 = vb % ncb;
+    const int slot = (vb / ncb) * 4 + wave;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int co = cb0 * COUT_TILE + j * 16 + m;
+      if (k == 0 && co < a.Cout) tab[1 + (size_t)co * kStatSlots + slot] = make_float4(st_n, st_mean[j], st_m2[j], 0.f);
+    }
+    if (vb == 0 && threadIdx.x == 0) tab[0] = make_float4((float)(((int)gridDim.x / ncb) * 4), 0.f, 0.f, 0.f);
+  }
+}
+
+template <int NT, int PRO>
+int launch_conv_wide(ConvArgs a, hipStream_t st) {
+  using G = WideGeo<NT>;
+  const size_t lds_bytes = sizeof(float) * 2 * (size_t)G::BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    attr_set = true;
+  }
+  a.tiles_x = cdiv(a.Wout, G::TW); a.tiles_y = cdiv(a.Hout, G::TH);
+  a.ncb = cdiv(a.Cout, 16 * NT);
+  const long nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb;
+  const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));
+  long nblocks = std::min<long>(nitems, (long)kNumCU * per_cu);
+  if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;
+  MS_LAUNCH((conv_wide_kernel<NT, PRO>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
+  return check_launch("conv_wide");
+}
+
+// wide-read path: 3x3 stride 1, plain fetch, 16-byte aligned rows, per-channel prologue coefficients; implemented in ms_conv_inst_w.hip
+bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool vec);
+int conv_dispatch_wide(const ConvArgs& a, int nt, hipStream_t st);
+
+}  // namespace ms

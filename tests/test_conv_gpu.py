@@ -184,3 +184,38 @@ def test_heads(dev):
     assert abs(float(lo) - float(loss)) < 1e-6 * abs(float(loss))
     assert rel(lg, logits) < 1e-6
     assert rel(dh, hr.grad) < 1e-5
+
+
+WIDE_CASES = [
+    # N, Cin, Cout, H, W: rows >= 64 pixels wide take the wide-read kernel (ms_conv_wide.h)
+    (2, 16, 16, 64, 64), (1, 16, 16, 9, 128), (2, 1, 16, 30, 72), (2, 20, 24, 13, 64), (1, 32, 48, 20, 192), (2, 64, 64, 64, 64), (1, 8, 33, 7, 100),
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", WIDE_CASES)
+def test_wide_kernel_all_modes(dev, N, Cin, Cout, H, W):
+    """The wide-read 3x3 kernel: plain forward + BatchNorm statistics, BN-apply prologue, BN-backward two-tensor prologue, accumulate
+    epilogue - each against fp64 math, and against the first-generation kernel (MS_CONV_WIDE=0 is the A/B switch for timing only)."""
+    from maxstyle_amd import ops
+    x = _rand((N, Cin, H, W), 11); w = _rand((Cout, Cin, 3, 3), 12, 0.1); b = _rand((Cout,), 13)
+    wp = ops.pack_conv_weight(w.to(dev))
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    stats, parts = ops.conv_stats_buffer(N, Cout, H, W, dev)
+    out = ops.conv2d(x.to(dev), wp, b.to(dev), Cout, 3, 1, stats=stats)
+    assert rel(out, ref) < 2e-6
+    coef = ops.bn_finalize(stats, parts, torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev))
+    assert rel(coef[:, 2], ref.mean((0, 2, 3))) < 1e-5
+    assert rel(coef[:, 3], 1 / torch.sqrt(ref.var((0, 2, 3), unbiased=False) + 1e-5)) < 1e-5
+    # prologue 1: LeakyReLU(a*x + b) per input channel; zero padding pads the ACTIVATED tensor (b != 0 would leak otherwise)
+    cf = _rand((Cin, 4), 14); cf[:, 1] += 0.5
+    xa = F.leaky_relu(cf[:, 0].double().view(1, -1, 1, 1) * x.double() + cf[:, 1].double().view(1, -1, 1, 1), 0.2)
+    cfd = cf.to(dev)
+    o1 = ops.conv2d(x.to(dev), wp, b.to(dev), Cout, 3, 1, pro_mode=1, pro_a=ops.coef_ptrs(cfd)[0], pro_b=ops.coef_ptrs(cfd)[1], pro_cstride=4, slope=0.2)
+    assert rel(o1, F.conv2d(xa, w.double(), b.double(), padding=1)) < 3e-6
+    # prologue 2: a*x + b*x2 + c (BatchNorm backward), no bias, accumulate into an existing tensor
+    x2 = _rand((N, Cin, H, W), 15)
+    xb = cf[:, 0].double().view(1, -1, 1, 1) * x.double() + cf[:, 1].double().view(1, -1, 1, 1) * x2.double() + cf[:, 2].double().view(1, -1, 1, 1)
+    base = _rand((N, Cout, H, W), 16)
+    o2 = ops.conv2d(x.to(dev), wp, None, Cout, 3, 1, pro_mode=2, pro_a=ops.coef_ptrs(cfd)[0], pro_b=ops.coef_ptrs(cfd)[1], pro_c=ops.coef_ptrs(cfd)[2],
+                    pro_cstride=4, in2=x2.to(dev), epi_mode=1, out=base.to(dev).clone())
+    assert rel(o2, F.conv2d(xb, w.double(), None, padding=1) + base.double()) < 3e-6

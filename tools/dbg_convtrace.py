@@ -1,0 +1,31 @@
+"""In-kernel cycle stamps of the wide conv kernel (needs a library built with -DMS_CONV_TRACE_BUILD)."""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+dev = torch.device("cuda:0")
+trace = torch.zeros(512, dtype=torch.int64, device=dev)
+os.environ["MS_CONV_TRACE"] = hex(trace.data_ptr())
+from maxstyle_amd import ops
+N, C = 16, 16
+mode = sys.argv[1] if len(sys.argv) > 1 else "plain"
+x = torch.randn(N, C, 256, 256, device=dev); w = torch.randn(C, C, 3, 3, device=dev) * 0.1; b = torch.randn(C, device=dev)
+wp = ops.pack_conv_weight(w)
+out = torch.empty_like(x)
+stats, parts = ops.conv_stats_buffer(N, C, 256, 256, dev)
+kw = dict(stats=stats)
+if mode == "bwd":
+    bc = torch.randn(C, 4, device=dev); pa, pb, pc = ops.coef_ptrs(bc)
+    kw = dict(pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=torch.randn_like(x))
+for _ in range(3):
+    ops.conv2d(x, wp, b, C, 3, 1, out=out, **kw)
+torch.cuda.synchronize()
+t = trace.cpu().tolist()
+t0 = min(t[0], t[128])
+print("consumer: p  [compute_start, compute_end, epilogue_end, after_barrier]   compute / epilogue / barrier wait")
+for p in range(12):
+    c = t[p * 4:(p + 1) * 4]
+    print(p, [v - t0 for v in c], c[1] - c[0], c[2] - c[1], c[3] - c[2])
+print("producer: p  [store_start, store_end, loads_issued, after_barrier]   store / set+load / barrier wait")
+for p in range(12):
+    c = t[128 + p * 4:128 + (p + 1) * 4]
+    print(p, [v - t0 for v in c], c[1] - c[0], c[2] - c[1], c[3] - c[2])
