@@ -49,8 +49,8 @@ def test_training_pass_gradients_vs_oracle(dev, track):
     S.reset_all_optimizers()
     out = S.standard_training(o32["clean"].to(dev), o32["lab"].to(dev), perturbed_image=o32["image_l"].to(dev), disable_track_bn_stats=not track, return_output=True)
     seg, rec, _, _, recon, y0, _ = out
-    assert abs(float(seg) - o64["seg"]) < 2e-5 * abs(o64["seg"]) + 1e-6
-    assert abs(float(rec) - o64["rec"]) < 2e-5 * abs(o64["rec"]) + 1e-7
+    assert abs(float(seg.detach()) - o64["seg"]) < 2e-5 * abs(o64["seg"]) + 1e-6
+    assert abs(float(rec.detach()) - o64["rec"]) < 2e-5 * abs(o64["rec"]) + 1e-7
     assert rel(S.z_i, o64["z_i"]) < 3e-5 and rel(recon, o64["recon"]) < 3e-5 and rel(y0, o64["logits"]) < 1e-4
     (seg + rec).backward()
     worst = ("", 0.0)
@@ -174,3 +174,91 @@ def test_full_iteration_vs_reference_golden(golden_dir, dev):
     # the next inner loop sees the updated weights (packed copies refreshed in place)
     z2, _ = S.encode_image(image_l, disable_track_bn_stats=True)
     assert float((z2 - z_i).abs().max()) > 0
+
+
+def test_two_iterations_and_adam_variant_vs_reference_golden(golden_dir, dev):
+    """(1) TWO consecutive trainer iterations (the second one starts from the weights, Adam moments and running statistics our first
+    update produced): losses of iteration 2 against the reference's, running statistics after both.  (2) optimizer_type='Adam'
+    (no decoupled decay) on a ragged-free small shape against tests/golden/outer_adam.npz."""
+    from oracle import maxstyle_oracle as orc
+    d64 = np.load(os.path.join(golden_dir, "outer_small_f64.npz"))
+    spec = orc.NetSpec(4, 1, 4)
+    S, W = make_solver(dev, spec)
+    S.optimizer_type = 'AdamW'
+    clean, lab = orc.synthetic_batch(4, 64, 1, 4, 1234)
+    clean_d, lab_d = clean.to(dev), lab.to(dev)
+    layers = [3, 4, 5]
+    for it in range(2):
+        t = f"it{it}."
+        noise = torch.from_numpy(d64[t + "noise"]).float()
+        styles = {i: orc.random_style_state(4, spec.channel_num[i], 7 + i + 10 * it) for i in layers}
+        S.style_init_hook = injector(styles, dev)
+        image_l = torch.clamp(clean_d + noise.to(dev), clean_d.min(), clean_d.max())
+        S.train(); S.reset_all_optimizers()
+        seg0, rec0, gt0, sh0, recon0, p0, _ = S.standard_training(clean_d, lab_d, perturbed_image=image_l, return_output=True)
+        S.reset_all_optimizers()
+        sty = S.generate_max_style_image(image_code=S.z_i, channel_num=spec.channel_num, p=1.5, decoder_layers_indexes=layers, n_iter=2, lr=0.1,
+                                         reference_image=clean_d, reference_segmentation=lab_d).detach().clone()
+        seg1, rec1, sh1, sh2 = S.hard_example_traininng(perturbed_image=sty, perturbed_seg=None, clean_image_l=clean_d, label_l=lab_d)
+        loss = (seg0 + rec0 + sh0 + gt0) + (rec1 + seg1 + sh1 + sh2)
+        S.reset_all_optimizers()
+        loss.backward()
+        S.optimize_all_params()
+        got = np.array([float(seg0.detach()), float(rec0.detach()), float(seg1.detach()), float(rec1.detach())])
+        # iteration 2 runs on weights that differ from the reference's by +-lr on sign-ambiguous entries (first Adam step): a few 1e-4
+        np.testing.assert_allclose(got[:2], d64[t + "losses"][:2], rtol=5e-5 if it == 0 else 2e-3)
+        np.testing.assert_allclose(got[2:], d64[t + "losses"][2:], rtol=3e-3 if it == 0 else 1e-2)
+    assert int(S.model["image_encoder"].state_dict()["general_encoder.inc.1.num_batches_tracked"]) == 2
+    for key in ("image_encoder/general_encoder.inc.1.running_mean", "segmentation_decoder/up3.conv.1.running_var"):
+        n, k = key.split("/", 1)
+        assert rel(S.model[n].state_dict()[k], d64["it1.after." + key + ".full"]) < 2e-3, key
+    # ---- Adam variant
+    da = np.load(os.path.join(golden_dir, "outer_adam.npz"))
+    S2, _ = make_solver(dev, spec)
+    S2.optimizer_type = 'Adam'
+    clean, lab = orc.synthetic_batch(3, 32, 1, 4, 1234)
+    clean_d, lab_d = clean.to(dev), lab.to(dev)
+    noise = torch.from_numpy(da["it0.noise"]).float()
+    styles = {4: orc.random_style_state(3, spec.channel_num[4], 7 + 4)}
+    S2.style_init_hook = injector(styles, dev)
+    image_l = torch.clamp(clean_d + noise.to(dev), clean_d.min(), clean_d.max())
+    S2.train(); S2.reset_all_optimizers()
+    seg0, rec0, gt0, sh0 = S2.standard_training(clean_d, lab_d, perturbed_image=image_l)
+    sty = S2.generate_max_style_image(image_code=S2.z_i, channel_num=spec.channel_num, p=1.5, decoder_layers_indexes=[4], n_iter=1, lr=0.1,
+                                      reference_image=clean_d, reference_segmentation=lab_d).detach().clone()
+    seg1, rec1, _, _ = S2.hard_example_traininng(perturbed_image=sty, perturbed_seg=None, clean_image_l=clean_d, label_l=lab_d)
+    S2.reset_all_optimizers()
+    ((seg0 + rec0) + (rec1 + seg1)).backward()
+    before = S2.model["segmentation_decoder"].final_conv.bias.detach().clone()
+    S2.optimize_all_params()
+    np.testing.assert_allclose([float(seg0.detach()), float(rec0.detach()), float(seg1.detach()), float(rec1.detach())], da["it0.losses"], rtol=2e-3)
+    moved = (S2.model["segmentation_decoder"].final_conv.bias.detach() - before).abs()
+    assert torch.allclose(moved, torch.full_like(moved, 1e-4), rtol=1e-2)                      # Adam step 1 = lr * sign(g), no decay
+    assert rel(S2.model["segmentation_decoder"].final_conv.bias, da["it0.after.segmentation_decoder/final_conv.bias.full"]) < 1e-5
+
+
+def test_training_pass_fcn64_three_channels(dev):
+    """FCN_64 (x4 widths: 64-channel heads, 512-channel code) with 3 image channels and 2 classes: one standard pass + backward against the
+    oracle's autograd at a small spatial size."""
+    from oracle import maxstyle_oracle as orc
+    from oracle import outer_oracle as outer
+    spec = orc.NetSpec(1, 3, 2)
+    S, W = make_solver(dev, spec)
+    clean, lab = orc.synthetic_batch(2, 32, 3, 2, 1234)
+    Wd = orc.procedural_weights(spec, 0, dtype=torch.float64)
+    names = [(n, k) for n in outer.NETS for k in outer.param_names(Wd[n])]
+    for n, k in names:
+        Wd[n][k].requires_grad_(True)
+    seg, rec, z_i, z_s, recon, logits = outer.training_pass(Wd, clean.double(), clean.double(), lab, track_bn=True)
+    grads = torch.autograd.grad(seg + rec, [Wd[n][k] for n, k in names])
+    S.reset_all_optimizers()
+    s_, r_, _, _ = S.standard_training(clean.to(dev), lab.to(dev), perturbed_image=clean.to(dev))
+    assert abs(float(s_.detach()) - float(seg)) < 5e-5 * abs(float(seg)) and abs(float(r_.detach()) - float(rec)) < 5e-5 * abs(float(rec))
+    (s_ + r_).backward()
+    worst = 0.0
+    for (n, k), g in zip(names, grads):
+        if outer.is_null_grad_bias(n, k):
+            continue
+        p = dict(S.model[n].named_parameters())[k]
+        worst = max(worst, rel(p.grad, g))
+    assert worst < 2e-3, worst

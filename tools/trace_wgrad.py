@@ -1,3 +1,4 @@
+"""In-kernel cycle stamps of the weight-gradient kernel (needs a library built with -DMS_WGRAD_TRACE_BUILD): who waits for whom, per tile."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
