@@ -95,6 +95,9 @@ int ms_counter_incr(int* counter, void* stream);
  *             activation of the producer; pro_nstride = 0 per channel, = Cin per (n,c) plane; pro_cstride = 4 reads the
  *             interleaved coef4 records of ms_bn_finalize / ms_bn_bwd_coefs in place)
  *             | 2 v = pro_a[i]*v + pro_b[i]*in2 + pro_c[i], i = ci*pro_cstride   (BatchNorm backward apply)
+ *             | 3 as 2, but the three coefficients are derived inside the kernel (saves the ms_bn_bwd_coefs launch): pro_a = the
+ *               partial sums [Cin][pro_nstride][2] written by ms_act_bwd_reduce, pro_b = the forward coef4 records of that BatchNorm
+ *               (pro_cstride >= 4), pro_c = NULL or an output [Cin][4] that receives the coefficients; count = N*Hs*Ws
  *   epi_mode  0 out = acc + bias | 1 out += acc + bias | 2 ConvTranspose2d(k=2,s=2) pixel-shuffle store:
  *             GEMM column (dy*2+dx)*Cout+co -> out[n,co,2y+dy,2x+dx] (needs ks=1)
  *   stats     NULL or a table of ms_conv_stats_bytes() bytes receiving per-wave running (count, mean, M2, 0) of the outputs

@@ -77,8 +77,15 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
                          int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                          int epi_mode, float* stats, void* stream) {
   if (N < 1 || Cin < 1 || Cout < 1 || Hs < 1 || Ws < 1) { set_error("ms_conv2d: invalid shape"); return MS_ERR_INVALID; }
-  if (pro_mode < 0 || pro_mode > 2 || epi_mode < 0 || epi_mode > 2 || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
-  if (pro_mode == 2 && (in2 == nullptr || pro_c == nullptr)) { set_error("ms_conv2d: pro_mode 2 needs in2 and pro_c"); return MS_ERR_INVALID; }
+  if (pro_mode < 0 || pro_mode > 3 || epi_mode < 0 || epi_mode > 2 || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
+  // pro_mode 3 = pro_mode 2 whose coefficients are derived in-kernel from the partial sums of ms_act_bwd_reduce:
+  //   pro_a = partials [Cin][pro_nstride][2], pro_b = forward coefficient records (stride pro_cstride), pro_c = optional output [Cin][4]
+  int bw_parts = 0; float* bw_out = nullptr;
+  if (pro_mode == 3) {
+    if (in2 == nullptr || pro_nstride < 1 || pro_cstride < 4) { set_error("ms_conv2d: pro_mode 3 needs in2, pro_nstride = partial count and float4 coefficient records"); return MS_ERR_INVALID; }
+    bw_parts = pro_nstride; bw_out = const_cast<float*>(pro_c);
+    pro_mode = 2; pro_nstride = 0;
+  } else if (pro_mode == 2 && (in2 == nullptr || pro_c == nullptr)) { set_error("ms_conv2d: pro_mode 2 needs in2 and pro_c"); return MS_ERR_INVALID; }
   if (pro_mode != 0 && (pro_a == nullptr || pro_b == nullptr)) { set_error("ms_conv2d: prologue coefficients missing"); return MS_ERR_INVALID; }
   if (epi_mode == 2 && (ks != 1 || stride != 1 || fetch != 0 || stats != nullptr)) { set_error("ms_conv2d: pixel-shuffle epilogue is for the k=1 GEMM form of ConvTranspose2d(k=2,s=2)"); return MS_ERR_INVALID; }
   if (!aligned16(w_packed)) { set_error("ms_conv2d: packed weights must be 16-byte aligned"); return MS_ERR_ALIGN; }
@@ -98,6 +105,7 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
   const int gemm_cols = (epi_mode == 2) ? 4 * Cout : Cout;
   a.Cout = gemm_cols;
   a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (gemm_cols + 63) / 64 * 64;
+  a.bw_parts = bw_parts; a.bw_count = (double)N * Hs * Ws; a.bw_out = bw_out;
   a.pro_mode = pro_mode; a.pro_nstride = pro_nstride; a.pro_cstride = pro_cstride < 1 ? 1 : pro_cstride; a.slope = slope; a.epi_mode = epi_mode;
   if (a.Hout < 1 || a.Wout < 1) { set_error("ms_conv2d: empty output"); return MS_ERR_INVALID; }
   if ((long)N > 65535) { set_error("ms_conv2d: batch too large for gridDim.z"); return MS_ERR_INVALID; }

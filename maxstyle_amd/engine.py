@@ -276,6 +276,7 @@ class InnerLoopEngine:
         self.bn_observer = None       # optional callback(bn: BNW, coef4, count) - running-statistics update of a tracking forward
         self.loss_sign = -1.0         # loss = loss_sign * cross_entropy_2D  (the inner loop maximises CE)
         self.fuse_bn_bwd = False      # ms_act_bwd_bn (one launch) instead of ms_act_bwd_reduce + ms_bn_bwd_coefs
+        self.inline_bn_bwd = True     # BatchNorm-backward coefficients computed inside the data-gradient conv (ms_conv2d pro_mode 3)
 
     # ------------------------------------------------------------------ buffers
     def t(self, name, *shape, dtype=F32):
@@ -309,19 +310,24 @@ class InnerLoopEngine:
         if stats:
             parts = lib.ms_conv_stats_parts(N, Ho, Wo)
             st = self.t(name + ".stats", cout * parts + 1, 4)
-        pm, pa, pb, pc, in2 = 0, 0, 0, 0, None
+        pm, pa, pb, pc, in2, pn = 0, 0, 0, 0, None, 0
         slope = 1.0
         if act is not None:
             pm = 1
             pa, pb, _ = ops.coef_ptrs(act[0])
             slope = act[1]
+        elif bnbwd is not None and isinstance(bnbwd[0], tuple):
+            # (part, nparts, coef) instead of ready coefficients: the conv derives them itself (pro_mode 3, no ms_bn_bwd_coefs launch)
+            part, nparts, coef = bnbwd[0]
+            pm, pa, pb, pc, pn = 3, part.data_ptr(), coef.data_ptr(), 0, nparts
+            in2 = bnbwd[1]
         elif bnbwd is not None:
             pm = 2
             pa, pb, pc = ops.coef_ptrs(bnbwd[0])
             in2 = bnbwd[1]
         bias = None if dgrad else cw.b
         check(lib.ms_conv2d(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
-                            N, Cin, Hs, Ws, cout, ks, stride, fetch, pm, pa, pb, pc, 0, 4, slope, epi, 0 if st is None else st.data_ptr(), self._st()),
+                            N, Cin, Hs, Ws, cout, ks, stride, fetch, pm, pa, pb, pc, pn, 4, slope, epi, 0 if st is None else st.data_ptr(), self._st()),
               "ms_conv2d:" + name)
         return out, st, parts
 
@@ -361,10 +367,13 @@ class InnerLoopEngine:
             return gin, bc
         bc = self.t(name + ".bcoef", C, 4)
         if not self.fuse_bn_bwd:
-            # two launches measured faster at C2 (254.8 vs 236.5 steps/s): the one-launch form puts an s_waitcnt vmcnt(0) + a returning
-            # atomic on every workgroup's tail (4096 workgroups per launch), which costs more than the ~5 us second launch saves
+            # The coefficients are derived by the data-gradient conv itself from the partial sums (ms_conv2d pro_mode 3): no
+            # ms_bn_bwd_coefs launch.  (The one-launch ms_act_bwd_bn form measured slower at C2, 236.5 vs 254.8 steps/s: it puts an
+            # s_waitcnt vmcnt(0) + a returning atomic on the tail of each of its 4096 workgroups.)
             check(lib.ms_act_bwd_reduce(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
                                         N, C, H * W, slope, self._st()), "ms_act_bwd_reduce:" + name)
+            if self.inline_bn_bwd:
+                return gin, (part, nparts, coef)
             check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(N * H * W), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + name)
             return gin, bc
         arrive = self.buf.get("bn.arrive")

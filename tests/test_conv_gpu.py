@@ -132,6 +132,11 @@ def test_bn_backward_chain(dev):
     da = ops.conv2d(g, ops.pack_conv_weight_dgrad(w.to(dev)), None, C, 3, 1, pro_mode=2, pro_a=ops.coef_ptrs(bc)[0], pro_b=ops.coef_ptrs(bc)[1],
                     pro_c=ops.coef_ptrs(bc)[2], pro_cstride=4, in2=ug)
     assert rel(da, ar.grad) < 2e-5
+    # pro_mode 3: the data-gradient conv derives the same coefficients itself from the partial sums (no ms_bn_bwd_coefs launch)
+    bc3 = torch.full((C, 4), float("nan"), device=dev)
+    da3 = ops.conv2d(g, ops.pack_conv_weight_dgrad(w.to(dev)), None, C, 3, 1, pro_mode=3, pro_a=part, pro_b=coef, pro_c=bc3, pro_nstride=nparts, pro_cstride=4, in2=ug)
+    assert rel(bc3[:, :3], bc[:, :3]) < 1e-6 and float(bc3[:, 3].abs().max()) == 0.0
+    assert rel(da3, da) < 1e-6
     # one-launch form (last workgroup of a channel finalises the coefficients), run twice: the counters re-arm themselves
     from maxstyle_amd._lib import lib, check
     arrive = torch.zeros(64, dtype=torch.int32, device=dev)
