@@ -157,7 +157,7 @@ def kernel_rooflines(eng, z_i, lab_d, dev):
     return {
         "conv": {"bound": "mfma", "achieved": conv_flops / out["conv3x3_c16_256"] / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": conv_flops / out["conv3x3_c16_256"] / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": traffic.get("conv3x3_c16_256"),
-                 "kernel": "conv_mfma_kernel<3,1,0,1> 16->16 @%dx%dx%d" % (B, H, W), "us_per_launch": out["conv3x3_c16_256"] * 1e6,
+                 "kernel": "conv_wide_kernel<NT=1,PRO=0> (3x3 s1, +BN statistics epilogue) 16->16 @%dx%dx%d" % (B, H, W), "us_per_launch": out["conv3x3_c16_256"] * 1e6,
                  "hbm_GBps": conv_bytes / out["conv3x3_c16_256"] / 1e9},
         "style": {"bound": "hbm", "achieved": 8.0 * n_elem / out["maxstyle_fwd_l4"] / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                   "frac": 8.0 * n_elem / out["maxstyle_fwd_l4"] / 1e9 / HBM_PEAK_GBPS, "traffic": traffic.get("maxstyle_fwd_l4"),

@@ -104,35 +104,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
     for (int i = threadIdx.x; i < 2 * BUF; i += 512) smem[i] = 0.f;     // rows / columns the staging never writes are the inserted zeros
   }
   // per-channel prologue coefficients are constant for the whole launch: stage them once (per-plane mode reads global memory)
-  if (a.bw_parts > 0) {
-    // pro_mode 3: what ms_bn_bwd_coefs would have computed in its own launch (a ~5 us kernel + launch gap, 29 times per inner step): every
-    // workgroup reduces the (sum g, sum g*u) partials of ms_act_bwd_reduce itself - <= 32 KB of L2-resident reads, 32 lanes per channel,
-    // fp64, fixed order, so all workgroups (and all runs) get the same bits.  pro_a = partials [Cin][bw_parts][2], pro_b = forward
-    // coefficient records {scale, shift, mean, invstd} (stride pro_cstride).
-    const int grp = threadIdx.x >> 5, l32 = threadIdx.x & 31;
-    for (int c = grp; c < a.cin_pad; c += 16) {
-      double s1 = 0.0, s2 = 0.0;
-      if (c < a.Cin) {
-        const float2* part = reinterpret_cast<const float2*>(a.pro_a) + (size_t)c * a.bw_parts;
-        for (int i = l32; i < a.bw_parts; i += 32) { const float2 q = part[i]; s1 += (double)q.x; s2 += (double)q.y; }
-      }
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
-      if (l32 == 0) {
-        float al = 1.f, be = 0.f, de = 0.f;
-        if (c < a.Cin) {
-          const float* cf = a.pro_b + (size_t)c * a.pro_cstride;       // {sc, sh, mean, invstd}
-          const double sc = cf[0], mean = cf[2], invstd = cf[3];
-          const double c1 = s1 / a.bw_count;
-          const double c2 = (s2 - mean * s1) * invstd / a.bw_count;
-          const double b = -sc * c2 * invstd;
-          al = (float)sc; be = (float)b; de = (float)(-sc * c1 - b * mean);
-          if (a.bw_out != nullptr && blockIdx.x == 0) { float* o = a.bw_out + 4 * c; o[0] = al; o[1] = be; o[2] = de; o[3] = 0.f; }
-        }
-        cf_lds[c * 4] = al; cf_lds[c * 4 + 1] = be; cf_lds[c * 4 + 2] = de;
-      }
-    }
-  } else if (a.pro_mode != 0 && a.pro_nstride == 0) {
+  // (pro_mode 3, bw_parts > 0: the consumer waves derive the coefficients below while the producer waves already fetch the first chunk)
+  if (a.bw_parts == 0 && a.pro_mode != 0 && a.pro_nstride == 0) {
     for (int c = threadIdx.x; c < a.cin_pad; c += 512) {
       float ca = 1.f, cb_ = 0.f, cc = 0.f;
       if (c < a.Cin) { ca = a.pro_a[c * a.pro_cstride]; cb_ = a.pro_b[c * a.pro_cstride]; if (a.pro_mode == 2) cc = a.pro_c[c * a.pro_cstride]; }
@@ -328,6 +301,35 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   }
 
   // =========================================== CONSUMER waves ===========================================
+  if (a.bw_parts > 0) {
+    // pro_mode 3: what ms_bn_bwd_coefs would have computed in its own launch (a ~5 us kernel + launch gap, 29 times per inner step): every
+    // workgroup reduces the (sum g, sum g*u) partials of ms_act_bwd_reduce itself - <= 32 KB of L2-resident reads, 32 lanes per channel,
+    // fp64, fixed order, so all workgroups (and all runs) get the same bits.  pro_a = partials [Cin][bw_parts][2], pro_b = forward
+    // coefficient records {scale, shift, mean, invstd} (stride pro_cstride).
+    const int grp = threadIdx.x >> 5, l32 = threadIdx.x & 31;          // consumer threads 0..255: 8 groups of 32 lanes
+    for (int c = grp; c < a.cin_pad; c += 8) {
+      double s1 = 0.0, s2 = 0.0;
+      if (c < a.Cin) {
+        const float2* part = reinterpret_cast<const float2*>(a.pro_a) + (size_t)c * a.bw_parts;
+        for (int i = l32; i < a.bw_parts; i += 32) { const float2 q = part[i]; s1 += (double)q.x; s2 += (double)q.y; }
+      }
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+      if (l32 == 0) {
+        float al = 1.f, be = 0.f, de = 0.f;
+        if (c < a.Cin) {
+          const float* cf = a.pro_b + (size_t)c * a.pro_cstride;       // {sc, sh, mean, invstd}
+          const double sc = cf[0], mean = cf[2], invstd = cf[3];
+          const double c1 = s1 / a.bw_count;
+          const double c2 = (s2 - mean * s1) * invstd / a.bw_count;
+          const double b = -sc * c2 * invstd;
+          al = (float)sc; be = (float)b; de = (float)(-sc * c1 - b * mean);
+          if (a.bw_out != nullptr && blockIdx.x == 0) { float* o = a.bw_out + 4 * c; o[0] = al; o[1] = be; o[2] = de; o[3] = 0.f; }
+        }
+        cf_lds[c * 4] = al; cf_lds[c * 4 + 1] = be; cf_lds[c * 4 + 2] = de;
+      }
+    }
+  }
   __builtin_amdgcn_s_setprio(2);       // the MFMA-issuing wave wins issue arbitration against the staging wave of its SIMD
   const int m = lane & 15, k = lane >> 4;
   f32x4 acc[4][NT];

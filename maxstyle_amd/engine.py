@@ -17,6 +17,7 @@ Host code is orchestration only; it raises if the HIP extension is missing (impo
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -276,7 +277,10 @@ class InnerLoopEngine:
         self.bn_observer = None       # optional callback(bn: BNW, coef4, count) - running-statistics update of a tracking forward
         self.loss_sign = -1.0         # loss = loss_sign * cross_entropy_2D  (the inner loop maximises CE)
         self.fuse_bn_bwd = False      # ms_act_bwd_bn (one launch) instead of ms_act_bwd_reduce + ms_bn_bwd_coefs
-        self.inline_bn_bwd = True     # BatchNorm-backward coefficients computed inside the data-gradient conv (ms_conv2d pro_mode 3)
+        # BatchNorm-backward coefficients computed inside the data-gradient conv (ms_conv2d pro_mode 3) instead of by ms_bn_bwd_coefs:
+        # 24 fewer launches per step, but measured SLOWER at C2 (263.1 vs 268.3 steps/s, twice each): every workgroup of the conv stalls
+        # on the dependent partial-sum loads at its start, which costs more than the 5 us kernel it replaces.  Off by default.
+        self.inline_bn_bwd = os.environ.get("MS_INLINE_BN_BWD", "0") != "0"
 
     # ------------------------------------------------------------------ buffers
     def t(self, name, *shape, dtype=F32):
@@ -367,9 +371,9 @@ class InnerLoopEngine:
             return gin, bc
         bc = self.t(name + ".bcoef", C, 4)
         if not self.fuse_bn_bwd:
-            # The coefficients are derived by the data-gradient conv itself from the partial sums (ms_conv2d pro_mode 3): no
-            # ms_bn_bwd_coefs launch.  (The one-launch ms_act_bwd_bn form measured slower at C2, 236.5 vs 254.8 steps/s: it puts an
-            # s_waitcnt vmcnt(0) + a returning atomic on the tail of each of its 4096 workgroups.)
+            # two launches (mask+reduce, then coefficients).  Both fusions were built and measured slower at C2: the one-launch
+            # ms_act_bwd_bn (236.5 vs 254.8 steps/s: an s_waitcnt vmcnt(0) + a returning atomic on the tail of each of its 4096
+            # workgroups) and ms_conv2d pro_mode 3 (`inline_bn_bwd`, see __init__).
             check(lib.ms_act_bwd_reduce(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
                                         N, C, H * W, slope, self._st()), "ms_act_bwd_reduce:" + name)
             if self.inline_bn_bwd:
