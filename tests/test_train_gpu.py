@@ -262,3 +262,34 @@ def test_training_pass_fcn64_three_channels(dev):
         p = dict(S.model[n].named_parameters())[k]
         worst = max(worst, rel(p.grad, g))
     assert worst < 2e-3, worst
+
+
+def test_training_pass_ragged_shape(dev):
+    """Non-square, non-power-of-two image (48 x 80, batch 3): deep levels have rows of 5 / 3 pixels (scalar staging paths of the conv and
+    weight-gradient kernels, ragged tiles everywhere)."""
+    from oracle import maxstyle_oracle as orc
+    from oracle import outer_oracle as outer
+    spec = orc.NetSpec(4, 1, 4)
+    S, W = make_solver(dev, spec)
+    g = torch.Generator().manual_seed(5)
+    clean = torch.rand(3, 1, 48, 80, generator=g)
+    lab = torch.randint(0, 4, (3, 48, 80), generator=g)
+    Wd = orc.procedural_weights(spec, 0, dtype=torch.float64)
+    names = [(n, k) for n in outer.NETS for k in outer.param_names(Wd[n])]
+    for n, k in names:
+        Wd[n][k].requires_grad_(True)
+    seg, rec, z_i, z_s, recon, logits = outer.training_pass(Wd, clean.double(), clean.double(), lab, track_bn=False)
+    grads = torch.autograd.grad(seg + 0.5 * rec, [Wd[n][k] for n, k in names], allow_unused=True)
+    S.reset_all_optimizers()
+    s_, r_, _, _ = S.standard_training(clean.to(dev), lab.to(dev), perturbed_image=clean.to(dev), disable_track_bn_stats=True)
+    (s_ + 0.5 * r_).backward()
+    worst = ("", 0.0)
+    for (n, k), gr in zip(names, grads):
+        p = dict(S.model[n].named_parameters())[k]
+        if gr is None or outer.is_null_grad_bias(n, k):
+            assert float(p.grad.abs().max()) == 0.0, (n, k)
+            continue
+        e = rel(p.grad, gr)
+        if e > worst[1]:
+            worst = (f"{n}/{k}", e)
+    assert worst[1] < 5e-4, worst
