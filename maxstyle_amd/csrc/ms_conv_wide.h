@@ -20,10 +20,11 @@
 
 namespace ms {
 
-template <int NT>
+template <int NT, int PRO>
 struct WideGeo {
   static constexpr int TH = 4, TW = 64;
-  static constexpr int CK = (NT == 1) ? 16 : 8;               // input channels per K-chunk (two stage buffers, two workgroups per CU)
+  // input channels per K-chunk: two stage buffers, two workgroups per CU; the two-tensor prologue stages twice the registers per channel
+  static constexpr int CK = (NT == 1 && PRO != 2) ? 16 : 8;
   static constexpr int IH = TH + 2;
   static constexpr int RS = TW + 4;                           // LDS row: column 0 = left halo (x0-1), 1..64 interior, 65 = right halo
   static constexpr int PS = 448;                              // >= IH*RS = 408, == 0 (mod 64): conflict-free ds_read_b128 of the A windows
@@ -39,7 +40,7 @@ struct WideGeo {
 // PRO: 0 none, 1 BatchNorm apply + LeakyReLU, 2 BatchNorm backward (two tensors)
 template <int NT, int PRO>
 __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const ConvArgs a) {
-  using G = WideGeo<NT>;
+  using G = WideGeo<NT, PRO>;
   constexpr int TH = G::TH, TW = G::TW, CK = G::CK, IH = G::IH, RS = G::RS, PS = G::PS, WS = G::WS, BUF = G::BUF;
   constexpr int NQI = G::NQI, NHI = G::NHI, NWI = G::NWI, COUT_TILE = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 
 template <int NT, int PRO>
 int launch_conv_wide(ConvArgs a, hipStream_t st) {
-  using G = WideGeo<NT>;
+  using G = WideGeo<NT, PRO>;
   const size_t lds_bytes = sizeof(float) * 2 * (size_t)G::BUF;
   static bool attr_set = false;
   if (!attr_set) {
