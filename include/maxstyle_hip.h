@@ -123,7 +123,8 @@ int ms_bn_act(const float* u, const float* coef4, const float* res, int res_mode
 
 /* Backward through the activation + the two BatchNorm-backward reductions in one pass:
  *   gout = gin * (r > 0 ? 1 : slope), r = ref (the saved activation output) or coef4.scale*u+coef4.shift when ref == NULL;
- *   part2[c][ms_act_bwd_parts()] = per-workgroup {sum gout, sum gout*u}.  gout may alias gin. */
+ *   part2[c][ms_act_bwd_parts()] = per-workgroup {sum gout, sum gout*(u - mean_c)} with mean_c = coef4[c].mean (centred, as
+ *   native_batch_norm_backward does: the uncentred form cancels catastrophically for channels with a large mean).  gout may alias gin. */
 int ms_act_bwd_parts(int N, int C, int HW);
 int ms_act_bwd_reduce(const float* gin, const float* ref, const float* u, const float* coef4, float* gout, float* part2,
                       int N, int C, int HW, float slope, void* stream);

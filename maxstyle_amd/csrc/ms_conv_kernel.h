@@ -7,7 +7,7 @@
 //                         prologue--> LDS buffer (double buffered); they run one K-chunk ahead of the consumers
 //   waves 0-3  CONSUMERS  LDS --ds_read_b32 fragments (immediate offsets)--> MFMA 16x16x4; epilogue from registers:
 //                         +bias, per-wave BatchNorm statistics (count, mean, M2), 16-B stores
-// A work item is (image n, output tile 8x32 or 16x16 pixels, block of 16*NT output channels); a workgroup walks items
+// A work item is (image n, output tile 8x32 or 8x16 pixels, block of 16*NT output channels); a workgroup walks items
 // blockIdx.x, +gridDim.x, ... over the flattened (item, K-chunk) sequence with ONE workgroup barrier per chunk.
 // Why: measured on MI355X, a conventional "every wave stages, then every wave multiplies" loop left the matrix pipe 35 %
 // busy - the two waves of a SIMD run the same phase at the same time, so address arithmetic, prologue math and the epilogue
@@ -41,7 +41,9 @@ struct ConvArgs {
 template <int KS, int STRIDE, int FETCH, bool VEC, bool NARROW, int NT>
 struct Geo {
   static constexpr int TW = NARROW ? 16 : 32;
-  static constexpr int TH = NARROW ? 16 : 8;
+  static constexpr int TH = 8;                                           // narrow: 8x16 pixels (two M-tiles per wave) - the 16-pixel-wide layers are the
+                                                                         // small-spatial ones where work items, not operand reuse, are scarce (128 -> 256 items at C2)
+  static constexpr int MT = NARROW ? 2 : 4;                              // 16-pixel M-tiles per consumer wave
   static constexpr int PAD = (KS == 3) ? 1 : 0;
   static constexpr int PADL = VEC ? ((KS == 3) ? 4 : 0) : PAD;           // window starts PADL logical columns left of ox0*S
   static constexpr int IH = (TH - 1) * STRIDE + KS;
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
           const float* cf = a.pro_b + (size_t)c * a.pro_cstride;       // {sc, sh, mean, invstd}
           const double sc = cf[0], mean = cf[2], invstd = cf[3];
           const double c1 = s1 / a.bw_count;
-          const double c2 = (s2 - mean * s1) * invstd / a.bw_count;
+          const double c2 = s2 * invstd / a.bw_count;                  // s2 is the centred sum
           const double b = -sc * c2 * invstd;
           al = (float)sc; be = (float)b; de = (float)(-sc * c1 - b * mean);
           if (a.bw_out != nullptr && blockIdx.x == 0) { float* o = a.bw_out + 4 * c; o[0] = al; o[1] = be; o[2] = de; o[3] = 0.f; }
@@ -332,15 +334,16 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   }
   __builtin_amdgcn_s_setprio(2);       // the MFMA-issuing wave wins issue arbitration against the staging wave of its SIMD
   const int m = lane & 15, k = lane >> 4;
-  f32x4 acc[4][NT];
+  constexpr int MT = G::MT;
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // M-tile i of this wave: NARROW: rows 4*wave+i, columns 0..15; else rows 2*wave+(i>>1), columns (i&1)*16..
-  const int a_lane = k * PS + m + (NARROW ? wave * 4 : wave * 2) * STRIDE * RS;     // all per-MFMA offsets below are immediates
+  // M-tile i of this wave: NARROW: rows 2*wave+i, columns 0..15; else rows 2*wave+(i>>1), columns (i&1)*16..
+  const int a_lane = k * PS + m + wave * 2 * STRIDE * RS;     // all per-MFMA offsets below are immediates
   const int b_lane = k * WS + m;
-  auto mt_row = [&](int i) { return NARROW ? (wave * 4 + i) : (wave * 2 + (i >> 1)); };
+  auto mt_row = [&](int i) { return NARROW ? (wave * 2 + i) : (wave * 2 + (i >> 1)); };
   auto mt_col = [&](int i) { return NARROW ? 0 : ((i & 1) * 16); };
 
   // FULL = every channel group of the chunk is live: straight-line code (no guards), so the LDS reads of later steps are
@@ -354,14 +357,14 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
 #pragma unroll
       for (int cg = 0; cg < CK / 4; ++cg) {
         if (FULL || cg < ncg) {
-          float bf[NT], af[4];
+          float bf[NT], af[MT];
 #pragma unroll
           for (int j = 0; j < NT; ++j) bf[j] = bp[(tap * CK + cg * 4) * WS + j * 16];
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < MT; ++i)
             af[i] = ap[cg * 4 * PS + G::tap_off(tap) + (NARROW ? i : (i >> 1)) * STRIDE * RS + (NARROW ? 0 : (i & 1) * 16)];
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] += bias_v[j];
     const bool full = (oy0 + TH <= a.Hout) && (ox0 + TW <= a.Wout);     // no masking needed (wave-uniform)
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
       // of the 4 lane groups that share a channel (xor 16, 32).  Partials: [co][(n*ntiles+tile)*4 + wave]
       float cnt = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MT; ++i) {
         const int y = oy0 + mt_row(i);
         const int nx = min(16, a.Wout - (ox0 + mt_col(i)));
         if (y < a.Hout && nx > 0) cnt += (float)nx;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
       for (int j = 0; j < NT; ++j) {
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
           const int y = oy0 + mt_row(i);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         const float mean = cnt > 0.f ? s / cnt : 0.f;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
           const int y = oy0 + mt_row(i);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         const int dy = q >> 1, dx = q & 1;
         float* op = a.out + ((size_t)n * a.cout_real + co) * Ho * Wo;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
           const int y = oy0 + mt_row(i);
           if (y >= a.Hout) continue;
 #pragma unroll
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         if (co >= a.Cout) continue;
         float* op = a.out + (((size_t)n * a.Cout + co) * a.Hout + oy0) * a.Wout + ox0 + xq;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
           float* o = op + (size_t)mt_row(i) * a.Wout + mt_col(i);
           float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
           if (a.epi_mode == 1) { const float4 p = *reinterpret_cast<const float4*>(o); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         if (co >= a.Cout) continue;
         float* op = a.out + ((size_t)n * a.Cout + co) * a.Hout * a.Wout;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
           const int y = oy0 + mt_row(i);
           if (y >= a.Hout) continue;
           const int x = ox0 + mt_col(i) + xq;
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };

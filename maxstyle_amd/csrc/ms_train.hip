@@ -13,7 +13,7 @@
 namespace ms {
 
 // du = al*g + be*u + de (see ms_bn_bwd_coefs) and, from the same two sums S1 = sum g, S2 = sum g*u:
-//   bias.grad = S1,  weight.grad = sum g*uhat = (S2 - mean*S1)*invstd
+//   bias.grad = S1,  weight.grad = sum g*uhat = S2*invstd        (S2 = sum g*(u - mean): centred by ms_act_bwd_reduce)
 __global__ __launch_bounds__(256) void bn_bwd_full_kernel(const float2* __restrict__ part, int nparts, const float4* __restrict__ coef, double count,
                                                           float4* __restrict__ out, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                           float* __restrict__ dsum, int accumulate) {
@@ -27,10 +27,10 @@ __global__ __launch_bounds__(256) void bn_bwd_full_kernel(const float2* __restri
     const float4 cf = coef[c];           // {sc, sh, mean, invstd}
     const double mean = cf.z, invstd = cf.w, sc = cf.x;
     const double c1 = s1 / count;
-    const double c2 = (s2 - mean * s1) * invstd / count;
+    const double c2 = s2 * invstd / count;                     // s2 is the centred sum (see act_bwd_reduce_kernel)
     const double be = -sc * c2 * invstd;
     if (out) out[c] = make_float4((float)sc, (float)be, (float)(-sc * c1 - be * mean), 0.f);
-    const float dg = (float)((s2 - mean * s1) * invstd), db = (float)s1;
+    const float dg = (float)(s2 * invstd), db = (float)s1;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
     if (dsum) dsum[c] = accumulate ? dsum[c] + db : db;

@@ -12,6 +12,14 @@ from test_solver_gpu import make_solver, injector
 
 pytestmark = pytest.mark.gpu
 
+# Weight gradients of a whole pass are compared at 2e-2, not at rounding level: LeakyReLU/ReLU derivatives are discontinuous, and a pre-activation
+# within rounding of zero takes the other branch in an fp32 forward than in the fp64 oracle.  ONE such pixel at the top of a decoder changes
+# every upstream gradient by O(1/sqrt(#pixels)) ~ 0.5 % at the 4 x 64 x 64 test size (measured: 3 flipped masks of 262144 in `up4` -> 0.3 % L2
+# error of its masked gradient -> 0.4-0.7 % on all image-decoder weight gradients; another tile geometry, other rounding, no flip: 5e-6).
+# Everything that does not cross a mask (forward values, losses, head gradients, every kernel on its own in test_conv_gpu / test_wgrad_gpu)
+# is checked at 1e-5 .. 1e-6.
+GRAD_TOL = 2e-2
+
 
 @pytest.fixture(scope="module")
 def dev():
@@ -68,8 +76,12 @@ def test_training_pass_gradients_vs_oracle(dev, track):
             err = rel(p.grad, ref)
             if err > worst[1]:
                 worst = (key, err)
-            assert err <= max(6 * noise, 2e-4), (key, err, noise)
+            assert err <= max(6 * noise, GRAD_TOL), (key, err, noise)
     print("worst gradient error", worst)
+    # gradients that do not pass through any activation mask are tight (the 1x1 heads: no LeakyReLU/ReLU between them and the loss)
+    for key in ("segmentation_decoder/final_conv.weight", "image_decoder/final_conv.weight", "image_decoder/final_conv.bias"):
+        n, k = key.split("/", 1)
+        assert rel(dict(S.model[n].named_parameters())[k].grad, o64["grads"][key]) < 2e-5, key
     # running statistics moved only in the tracking pass
     bn = S.model["image_encoder"].general_encoder.inc[1]
     assert int(bn.num_batches_tracked) == (1 if track else 0)
@@ -261,7 +273,7 @@ def test_training_pass_fcn64_three_channels(dev):
             continue
         p = dict(S.model[n].named_parameters())[k]
         worst = max(worst, rel(p.grad, g))
-    assert worst < 2e-3, worst
+    assert worst < GRAD_TOL, worst
 
 
 def test_training_pass_ragged_shape(dev):
@@ -292,4 +304,4 @@ def test_training_pass_ragged_shape(dev):
         e = rel(p.grad, gr)
         if e > worst[1]:
             worst = (f"{n}/{k}", e)
-    assert worst[1] < 5e-4, worst
+    assert worst[1] < GRAD_TOL, worst
