@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float4* __restri
 
 // tile geometry is a pure function of the output width (so ms_conv_stats_parts can be answered without launching)
 static inline bool narrow_tile(int Wout) { return Wout <= 16; }
-static inline int tile_h(int Wout) { (void)Wout; return 8; }
+static inline int tile_h(int Wout) { return narrow_tile(Wout) ? 4 : 8; }
 static inline int tile_w(int Wout) { return narrow_tile(Wout) ? 16 : 32; }
 
 }  // namespace ms
