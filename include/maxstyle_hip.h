@@ -201,6 +201,22 @@ int ms_repack_weights(const float* flat, const void* desc_dev, int ndesc, long l
 /* Running statistics of a tracking BatchNorm forward from the coefficient table of ms_bn_finalize (mean, invstd):
  * running = (1-momentum)*running + momentum*batch, variance unbiased (count/(count-1)). */
 int ms_bn_running_update(const float* coef4, float* running_mean, float* running_var, int C, double count, float momentum, float eps, void* stream);
+/* ... for all BatchNorm layers of a pass in one launch; desc_dev: nlayers records of ms_bn_running_desc_bytes() bytes
+ *   { const float* coef4, float* running_mean, float* running_var, int32 C, float count } (same momentum for all). */
+size_t ms_bn_running_desc_bytes(void);
+int ms_bn_running_update_batch(const void* desc_dev, int nlayers, float momentum, float eps, void* stream);
+
+/* The two halves of ms_conv_wgrad for a whole backward pass: ms_conv_wgrad_partials runs only the MFMA kernel (partials stay in `ws`, the
+ * number of partial slots is returned in *nslots_out), ms_wgrad_reduce_batch then sums the partials of MANY tensors with one launch.
+ * desc_dev: device array of ndesc records of ms_wgrad_batch_desc_bytes() bytes:
+ *   { int64 block_begin (prefix sum of ceil(numel/64)), const float* partial, float* dst, int32 numel, nslots, accumulate, pad };
+ * total_blocks = sum of ceil(numel/64). */
+int ms_conv_wgrad_partials(const float* p, const float* p2, const float* q, int N, int M, int Nq, int Hp, int Wp, int Hq, int Wq,
+                           int ks, int stride, int q_fetch, int p_mode, const float* pa, const float* pb, const float* pc,
+                           int q_mode, const float* qa, const float* qb, int coef_stride, float slope,
+                           void* ws, size_t ws_bytes, int* nslots_out, void* stream);
+size_t ms_wgrad_batch_desc_bytes(void);
+int ms_wgrad_reduce_batch(const void* desc_dev, int ndesc, long long total_blocks, void* stream);
 
 /* Per-plane min-max rescale y = (x - min)/(max - min + eps)*(new_max - new_min) + new_min: rescale_intensity
  * (common_utils/basic_operations.py:257-281), applied to the stylised image right after the path (advanced_triplet...py:868-869). */

@@ -64,6 +64,12 @@ SIGNATURES = {
     "ms_repack_desc_bytes": (c_size, []),
     "ms_repack_weights": (c_int, [c_f32p, c_void, c_int, ctypes.c_longlong, c_void]),
     "ms_bn_running_update": (c_int, [c_f32p, c_f32p, c_f32p, c_int, ctypes.c_double, c_float, c_float, c_void]),
+    "ms_conv_wgrad_partials": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_int, c_float, c_void, c_size, ctypes.POINTER(c_int), c_void]),
+    "ms_wgrad_batch_desc_bytes": (c_size, []),
+    "ms_wgrad_reduce_batch": (c_int, [c_void, c_int, ctypes.c_longlong, c_void]),
+    "ms_bn_running_desc_bytes": (c_size, []),
+    "ms_bn_running_update_batch": (c_int, [c_void, c_int, c_float, c_float, c_void]),
     "ms_rescale_intensity": (c_int, [c_f32p, c_f32p, c_int, c_int, c_float, c_float, c_float, c_void]),
     "ms_confusion": (c_int, [c_f32p, c_i64p, c_void, c_int, c_int, c_int, c_void]),
     "ms_head_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_void]),

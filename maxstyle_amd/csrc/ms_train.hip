@@ -236,8 +236,29 @@ __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ f
   }
 }
 
+// the same for every BatchNorm of a pass in one launch: blockIdx.x = layer
+struct BnRunDesc { const float4* coef; float* rm; float* rv; int C; float count; };
+__global__ __launch_bounds__(256) void bn_running_batch_kernel(const BnRunDesc* __restrict__ desc, float mom, float eps) {
+  const BnRunDesc d = desc[blockIdx.x];
+  for (int c = threadIdx.x; c < d.C; c += 256) {
+    const float mean = d.coef[c].z, invstd = d.coef[c].w;
+    float var = 1.f / (invstd * invstd) - eps;
+    if (d.count > 1.f) var *= d.count / (d.count - 1.f);
+    d.rm[c] = d.rm[c] * (1.f - mom) + mom * mean;
+    d.rv[c] = d.rv[c] * (1.f - mom) + mom * var;
+  }
+}
+
 }  // namespace ms
 using namespace ms;
+
+extern "C" size_t ms_bn_running_desc_bytes(void) { return sizeof(BnRunDesc); }
+
+extern "C" int ms_bn_running_update_batch(const void* desc_dev, int nlayers, float momentum, float eps, void* stream) {
+  if (nlayers < 1 || desc_dev == nullptr) { set_error("ms_bn_running_update_batch: nothing to do"); return MS_ERR_INVALID; }
+  MS_LAUNCH(bn_running_batch_kernel, dim3(nlayers), dim3(256), 0, (hipStream_t)stream, (const BnRunDesc*)desc_dev, momentum, eps);
+  return check_launch("bn_running_update_batch");
+}
 
 extern "C" size_t ms_repack_desc_bytes(void) { return sizeof(RepackDesc); }
 

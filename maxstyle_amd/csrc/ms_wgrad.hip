@@ -56,6 +56,41 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     dw[i] = accumulate ? dw[i] + t : t;
   }
 }
+
+// The same reduction for MANY weight tensors in one launch (a backward pass produces ~70 partial sets; one 5 us launch each was 10 % of the
+// pass).  One 64-element block of one tensor per workgroup; the descriptor table lives on the device (addresses are stable across iterations).
+struct WgBatchDesc { long long block_begin; const float* partial; float* dst; int numel, nslots, accumulate, pad; };   // 40 -> padded to 48 bytes
+static_assert(sizeof(WgBatchDesc) == 40 || sizeof(WgBatchDesc) == 48, "descriptor layout");
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgBatchDesc* __restrict__ desc, int ndesc) {
+  __shared__ float red[4][64];
+  int lo = 0, hi = ndesc - 1;
+  const long long blk = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].block_begin <= blk) lo = mid; else hi = mid - 1; }
+  const WgBatchDesc d = desc[lo];
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const size_t numel = (size_t)d.numel;
+  const size_t i = (size_t)(blk - d.block_begin) * 64 + e;
+  const int per = (d.nslots + 3) / 4;
+  const int s0 = q * per, s1 = min(d.nslots, s0 + per);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (i < numel) {
+    int s = s0;
+    for (; s + 8 <= s1; s += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += d.partial[(size_t)(s + j) * numel + i];
+    }
+    for (; s < s1; ++s) acc[0] += d.partial[(size_t)s * numel + i];
+  }
+  red[q][e] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (q == 0 && i < numel) {
+    const float t = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    d.dst[i] = d.accumulate ? d.dst[i] + t : t;
+  }
+}
 #endif
 
 // Prologue modes are template parameters (the staging code must not spend VALU cycles on identity math: it competes with the MFMA issue):
@@ -144,10 +179,10 @@ extern "C" size_t ms_conv_wgrad_ws_bytes(int N, int M, int Nq, int Hp, int Wp, i
   return (size_t)std::max(a.nslots, b.nslots) * M * Nq * ks * ks * sizeof(float);
 }
 
-extern "C" int ms_conv_wgrad(const float* p, const float* p2, const float* q, float* dw, int N, int M, int Nq, int Hp, int Wp, int Hq, int Wq,
-                             int ks, int stride, int q_fetch, int p_mode, const float* pa, const float* pb, const float* pc,
-                             int q_mode, const float* qa, const float* qb, int coef_stride, float slope, int accumulate,
-                             void* ws, size_t ws_bytes, void* stream) {
+static int wgrad_partials(const float* p, const float* p2, const float* q, int N, int M, int Nq, int Hp, int Wp, int Hq, int Wq,
+                          int ks, int stride, int q_fetch, int p_mode, const float* pa, const float* pb, const float* pc,
+                          int q_mode, const float* qa, const float* qb, int coef_stride, float slope,
+                          void* ws, size_t ws_bytes, int* nslots_out, void* stream) {
   if (N < 1 || M < 1 || Nq < 1 || Hp < 1 || Wp < 1 || Hq < 1 || Wq < 1) { set_error("ms_conv_wgrad: invalid shape"); return MS_ERR_INVALID; }
   if (!wgrad_geometry_ok(Hp, Wp, Hq, Wq, ks, stride, q_fetch)) {
     set_error("ms_conv_wgrad: unsupported geometry (ks=%d stride=%d fetch=%d P %dx%d Q %dx%d)", ks, stride, q_fetch, Hp, Wp, Hq, Wq);
@@ -182,7 +217,34 @@ extern "C" int ms_conv_wgrad(const float* p, const float* p2, const float* q, fl
     rc = wgrad_dispatch_s2(a, plan, ks, st);
   }
   if (rc != MS_OK) return rc;
-  MS_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((numel + 63) / 64)), dim3(256), 0, st, (const float*)ws, plan.nslots, numel, dw, accumulate);
+  *nslots_out = plan.nslots;
+  return MS_OK;
+}
+
+extern "C" int ms_conv_wgrad(const float* p, const float* p2, const float* q, float* dw, int N, int M, int Nq, int Hp, int Wp, int Hq, int Wq,
+                             int ks, int stride, int q_fetch, int p_mode, const float* pa, const float* pb, const float* pc,
+                             int q_mode, const float* qa, const float* qb, int coef_stride, float slope, int accumulate,
+                             void* ws, size_t ws_bytes, void* stream) {
+  int nslots = 0;
+  if (int rc = wgrad_partials(p, p2, q, N, M, Nq, Hp, Wp, Hq, Wq, ks, stride, q_fetch, p_mode, pa, pb, pc, q_mode, qa, qb, coef_stride, slope, ws, ws_bytes, &nslots, stream)) return rc;
+  const size_t numel = (size_t)M * Nq * ks * ks;
+  MS_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((numel + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nslots, numel, dw, accumulate);
   return check_launch("wgrad_reduce");
+}
+
+extern "C" int ms_conv_wgrad_partials(const float* p, const float* p2, const float* q, int N, int M, int Nq, int Hp, int Wp, int Hq, int Wq,
+                                      int ks, int stride, int q_fetch, int p_mode, const float* pa, const float* pb, const float* pc,
+                                      int q_mode, const float* qa, const float* qb, int coef_stride, float slope,
+                                      void* ws, size_t ws_bytes, int* nslots_out, void* stream) {
+  if (nslots_out == nullptr) { set_error("ms_conv_wgrad_partials: nslots_out is NULL"); return MS_ERR_INVALID; }
+  return wgrad_partials(p, p2, q, N, M, Nq, Hp, Wp, Hq, Wq, ks, stride, q_fetch, p_mode, pa, pb, pc, q_mode, qa, qb, coef_stride, slope, ws, ws_bytes, nslots_out, stream);
+}
+
+extern "C" size_t ms_wgrad_batch_desc_bytes(void) { return sizeof(WgBatchDesc); }
+
+extern "C" int ms_wgrad_reduce_batch(const void* desc_dev, int ndesc, long long total_blocks, void* stream) {
+  if (ndesc < 1 || total_blocks < 1 || desc_dev == nullptr) { set_error("ms_wgrad_reduce_batch: nothing to do"); return MS_ERR_INVALID; }
+  MS_LAUNCH(wgrad_reduce_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const WgBatchDesc*)desc_dev, ndesc);
+  return check_launch("wgrad_reduce_batch");
 }
 #endif

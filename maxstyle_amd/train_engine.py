@@ -18,6 +18,7 @@ Host code is orchestration only; there is no CPU path.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Dict, Optional
 
 import torch
@@ -111,6 +112,9 @@ class TrainEngine(InnerLoopEngine):
         self.bn_affine_grad = True       # False inside _disable_tracking_bn_stats (hard-example pass): BatchNorm weight/bias are constants
         self.bn_modules = None           # sd-name -> nn.BatchNorm2d per net, for the running-statistics update of a tracking pass
         self.track = False
+        self._wg_calls = []              # (partial ptr, dst ptr, numel, slots) of the weight gradients issued in the current backward pass
+        self._wg_desc = {}
+        self._run_desc = {}
         self.configure_styles([], {})
 
     # ------------------------------------------------------------------ helpers
@@ -124,13 +128,13 @@ class TrainEngine(InnerLoopEngine):
         return self.bank.grad(net, self._names(net)[key] + ".bias")
 
     def wgrad(self, p, q, dw, ks, stride=1, q_fetch=0, p_bnbwd=None, q_act=None):
+        """Weight gradient of one conv: the MFMA kernel runs now (partials into this call's own region), the reduction into `dw` is deferred
+        to ONE batched launch at the end of the backward pass (`_wgrad_flush`): ~70 reduce launches of 5 us each were 10 % of the pass."""
         N, M, Hp, Wp = p.shape
         Nq, Hq, Wq = q.shape[1:]
         nbytes = lib.ms_conv_wgrad_ws_bytes(N, M, Nq, Hp, Wp, ks, stride)
-        ws = self.buf.get("wg.ws")
-        if ws is None or ws.numel() < nbytes:
-            ws = torch.empty(max(int(nbytes), 8 << 20), dtype=torch.uint8, device=self.dev)
-            self.buf["wg.ws"] = ws
+        idx = len(self._wg_calls)
+        ws = self.t(f"wg.part{idx}", max(int(nbytes), 256), dtype=torch.uint8)
         pm, p2, pa, pb, pc = 0, 0, 0, 0, 0
         qm, qa, qb, slope = 0, 0, 0, 1.0
         if p_bnbwd is not None:
@@ -141,8 +145,32 @@ class TrainEngine(InnerLoopEngine):
             qm = 1
             qa, qb, _ = ops.coef_ptrs(q_act[0])
             slope = q_act[1]
-        check(lib.ms_conv_wgrad(p.data_ptr(), p2, q.data_ptr(), dw.data_ptr(), N, M, Nq, Hp, Wp, Hq, Wq, ks, stride, q_fetch, pm, pa, pb, pc,
-                                qm, qa, qb, 4, slope, 1, ws.data_ptr(), ws.numel(), self._st()), "ms_conv_wgrad")
+        nslots = ctypes.c_int(0)
+        check(lib.ms_conv_wgrad_partials(p.data_ptr(), p2, q.data_ptr(), N, M, Nq, Hp, Wp, Hq, Wq, ks, stride, q_fetch, pm, pa, pb, pc,
+                                         qm, qa, qb, 4, slope, ws.data_ptr(), ws.numel(), ctypes.byref(nslots), self._st()), "ms_conv_wgrad_partials")
+        self._wg_calls.append((ws.data_ptr(), dw.data_ptr(), dw.numel(), nslots.value))
+
+    def _wgrad_flush(self):
+        """One launch sums the partials of every weight tensor of this backward pass into the flat gradient buffer (accumulating)."""
+        calls = self._wg_calls
+        self._wg_calls = []
+        if not calls:
+            return
+        key = tuple(calls)
+        cached = self._wg_desc.get(key)
+        if cached is None:
+            import numpy as np
+            assert lib.ms_wgrad_batch_desc_bytes() == 40
+            dt = np.dtype([("block_begin", "<i8"), ("partial", "<u8"), ("dst", "<u8"), ("numel", "<i4"), ("nslots", "<i4"), ("accumulate", "<i4"), ("pad", "<i4")])
+            rows, blocks = [], 0
+            for part, dst, numel, nslots in calls:
+                rows.append((blocks, part, dst, numel, nslots, 1, 0))
+                blocks += (numel + 63) // 64
+            table = torch.from_numpy(np.array(rows, dtype=dt).view(np.uint8).copy()).to(self.dev)
+            cached = (table, len(rows), blocks)
+            self._wg_desc = {key: cached}            # shapes are static: one table per engine (rebuilt only if the call sequence changes)
+        table, n, blocks = cached
+        check(lib.ms_wgrad_reduce_batch(table.data_ptr(), n, blocks, self._st()), "ms_wgrad_reduce_batch")
 
     def channel_sum(self, x, out):
         N, C, H, W = x.shape
@@ -209,16 +237,31 @@ class TrainEngine(InnerLoopEngine):
         return z_i, logits, recon
 
     def _update_running(self, tracked, bns):
-        counters = []
-        for name, coef, u_count in tracked:
-            m = bns[name]
-            mom = 0.1 if m.momentum is None else m.momentum
-            check(lib.ms_bn_running_update(coef.data_ptr(), m.running_mean.data_ptr(), m.running_var.data_ptr(), coef.shape[0], float(u_count), mom, BN_EPS, self._st()),
-                  "ms_bn_running_update")
-            counters.append(m.num_batches_tracked)
-        if counters:
-            torch._foreach_add_(counters, 1)
-            self.nets.eval_dirty = True          # eval-mode BatchNorm tables are recomputed from the running statistics on their next use
+        """Running statistics of every BatchNorm of one sub-net: one launch (momentum 0.1 everywhere in these networks) + one foreach add."""
+        if not tracked:
+            return
+        key = tuple((name, coef.data_ptr()) for name, coef, _ in tracked)
+        cached = self._run_desc.get(key)
+        if cached is None:
+            import numpy as np
+            assert lib.ms_bn_running_desc_bytes() == 32
+            dt = np.dtype([("coef", "<u8"), ("rm", "<u8"), ("rv", "<u8"), ("C", "<i4"), ("count", "<f4")])
+            rows, counters, mom = [], [], None
+            for name, coef, u_count in tracked:
+                m = bns[name]
+                mm = 0.1 if m.momentum is None else float(m.momentum)
+                if mom is not None and mm != mom:
+                    raise NotImplementedError("per-layer BatchNorm momentum")
+                mom = mm
+                rows.append((coef.data_ptr(), m.running_mean.data_ptr(), m.running_var.data_ptr(), coef.shape[0], float(u_count)))
+                counters.append(m.num_batches_tracked)
+            table = torch.from_numpy(np.array(rows, dtype=dt).view(np.uint8).copy()).to(self.dev)
+            cached = (table, len(rows), mom, counters)
+            self._run_desc[key] = cached
+        table, n, mom, counters = cached
+        check(lib.ms_bn_running_update_batch(table.data_ptr(), n, mom, BN_EPS, self._st()), "ms_bn_running_update_batch")
+        torch._foreach_add_(counters, 1)
+        self.nets.eval_dirty = True          # eval-mode BatchNorm tables are recomputed from the running statistics on their next use
 
     # ------------------------------------------------------------------ backward
     def res_bwd_t(self, pfx, net, key, x, dout, kind, need_dx=True):
@@ -260,6 +303,7 @@ class TrainEngine(InnerLoopEngine):
     def backward_pass(self, image, labels, clean, g_seg: float, g_rec: float):
         """Accumulates d(g_seg*CE + g_rec*0.5*MSE)/d(parameters) into the ParamBank's flat gradient buffer."""
         b = self.buf
+        self._wg_calls = []
         net_e, net_s, net_d = NETS
         e, s, d = self.nets.enc, self.nets.seg, self.nets.dec
         z_i, z_s = b["e.z_i"], b["e.z_s"]
@@ -318,6 +362,7 @@ class TrainEngine(InnerLoopEngine):
             else:
                 self.conv("e.dz_i", g, e["cd0"], bnbwd=(bc, b["e.cd.u1"]), dgrad=True, epi=1, out=dz_i)
         if dz_i is None:
+            self._wgrad_flush()
             return
         hin = b["e.d4.out"]
         g, bc = self.act_bwd_t("e.fc.bw", dz_i, z_i, b["e.fc.u"], b["e.fc.bn.coef"], 0.0, net_e, "fc1")
@@ -331,3 +376,4 @@ class TrainEngine(InnerLoopEngine):
         da, _, _ = self.conv("e.inc.da", g, e["inc3"], bnbwd=(bc, b["e.inc.ub"]), dgrad=True)
         g, bc = self.act_bwd_t("e.inc.bw1", da, None, b["e.inc.ua"], b["e.inc.bn1.coef"], LEAKY, net_e, "inc1")
         self.wgrad(g, image, self._gw(net_e, "inc0"), 3, p_bnbwd=(bc, b["e.inc.ua"]))      # the input image needs no gradient
+        self._wgrad_flush()
