@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma_kernel(const WgArgs a) {
     // steady-state path is stripped to loads, the prologue FMAs and LDS stores: everything that does not depend on the tile is hoisted
     // into registers (LDS offsets, image-relative element offsets, per-channel coefficients), masks and zero-fill selects only run for
     // tiles that touch the image border (wave-uniform branch), and two register sets keep two tiles of loads in flight.
-    if (a.dbg & 16) __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);      // staging waves win issue arbitration (see ms_conv_wide.h)
     const int tid = threadIdx.x - 256;
     const int p_plane = a.Hp * a.Wp, q_plane = a.Hq * a.Wq;       // host checks that one image of P / Q stays below 2^31 elements
     typedef unsigned long long mask_t;
@@ -348,7 +348,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma_kernel(const WgArgs a) {
     }
   } else {
     // =========================================== CONSUMER waves ===========================================
-    if (!(a.dbg & 8)) __builtin_amdgcn_s_setprio(2);
     const int mn = lane & 15, k = lane >> 4;
     wg_f32x4 acc[AB][BB][TAPS];
 #pragma unroll
