@@ -430,7 +430,13 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         if self._bn_maps is None:
             self._bn_maps = tuple({n: m for n, m in self.model[k].named_modules() if isinstance(m, nn.BatchNorm2d)} for k in T.NETS)
         bns = self._bn_maps
-        seg_loss, rec_loss = _TrainPassFn.apply(self._anchor, self, eng, x, labels, clean, track, bns)
+        if torch.is_grad_enabled():
+            seg_loss, rec_loss = _TrainPassFn.apply(self._anchor, self, eng, x, labels, clean, track, bns)
+        else:                                   # torch.no_grad(): values only - the engine's activations are not held for a backward
+            eng.bn_affine_grad = track
+            eng.forward_pass(x, labels, clean, track, bns)
+            vals = eng.loss_buf[:2].clone()
+            seg_loss, rec_loss = vals[0], vals[1]
         z_i, z_s = eng.buf["e.z_i"], eng.buf["e.z_s"]
         if update_latent:
             self.z_i = z_i.clone()

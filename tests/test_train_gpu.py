@@ -305,3 +305,22 @@ def test_training_pass_ragged_shape(dev):
         if e > worst[1]:
             worst = (f"{n}/{k}", e)
     assert worst[1] < GRAD_TOL, worst
+
+
+def test_no_grad_forward_and_double_backward_guard(dev):
+    """Under torch.no_grad() standard_training returns plain values and does not pin an engine; a second backward through the same pass
+    is refused loudly (the activations were consumed) instead of silently accumulating garbage."""
+    from oracle import maxstyle_oracle as orc
+    S, W = make_solver(dev, orc.NetSpec(4, 1, 4))
+    clean, lab = orc.synthetic_batch(2, 32, 1, 4, 1234)
+    S.reset_all_optimizers()
+    with torch.no_grad():
+        for _ in range(3):
+            seg, rec, _, _ = S.standard_training(clean.to(dev), lab.to(dev), perturbed_image=clean.to(dev), disable_track_bn_stats=True)
+    assert not seg.requires_grad and len(S._train_engines[(2, 32, 32, str(dev))]) == 1
+    seg2, rec2, _, _ = S.standard_training(clean.to(dev), lab.to(dev), perturbed_image=clean.to(dev), disable_track_bn_stats=True)
+    assert abs(float(seg2.detach()) - float(seg)) < 1e-6 * abs(float(seg))
+    loss = seg2 + rec2
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError):
+        loss.backward()
