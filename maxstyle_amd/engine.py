@@ -281,6 +281,12 @@ class InnerLoopEngine:
         # 24 fewer launches per step, but measured SLOWER at C2 (263.1 vs 268.3 steps/s, twice each): every workgroup of the conv stalls
         # on the dependent partial-sum loads at its start, which costs more than the 5 us kernel it replaces.  Off by default.
         self.inline_bn_bwd = os.environ.get("MS_INLINE_BN_BWD", "0") != "0"
+        # independent branches of a residual block (1x1 skip conv and its gradient) on a second stream, captured into the same HIP graph.
+        # Built to fill the bubbles around the 5 us BatchNorm kernels; measured SLOWER at C2 (273.4 vs 295.3 steps/s, twice each): the conv kernels
+        # are persistent grids sized for the whole chip, and a concurrent kernel that takes CU slots turns into load imbalance. Off by default.
+        self.overlap = os.environ.get("MS_OVERLAP", "0") != "0"
+        self._side_stream = None
+        self._side_pending = False
 
     # ------------------------------------------------------------------ buffers
     def t(self, name, *shape, dtype=F32):
@@ -294,6 +300,35 @@ class InnerLoopEngine:
 
     def _st(self):
         return torch.cuda.current_stream().cuda_stream
+
+    # ------------------------------------------------------------------ side stream (independent branches of a block)
+    class _SideCtx:
+        def __init__(self, eng):
+            self.eng = eng
+
+        def __enter__(self):
+            e = self.eng
+            if e.overlap:
+                if e._side_stream is None:
+                    e._side_stream = torch.cuda.Stream(device=e.dev)
+                e._side_stream.wait_stream(torch.cuda.current_stream())       # everything issued so far on the main stream is visible
+                self.ctx = torch.cuda.stream(e._side_stream)
+                self.ctx.__enter__()
+                e._side_pending = True
+            return self
+
+        def __exit__(self, *exc):
+            if self.eng.overlap:
+                self.ctx.__exit__(*exc)
+            return False
+
+    def _side(self, after_main=True):
+        return InnerLoopEngine._SideCtx(self)
+
+    def _join_side(self):
+        if self.overlap and self._side_pending:
+            torch.cuda.current_stream().wait_stream(self._side_stream)
+            self._side_pending = False
 
     # ------------------------------------------------------------------ kernel-call helpers (no allocation after warm-up)
     def conv(self, name, x, cw: ConvW, cout=None, ks=None, stride=1, fetch=0, act=None, bnbwd=None, epi=0, out=None, stats=False, dgrad=False):
@@ -407,16 +442,18 @@ class InnerLoopEngine:
             src, _, _ = self.conv(pfx + ".xd", x, net[key + ".down"], stride=2)
         else:
             fetch = ops.FETCH_UPS2
+        # the 1x1 skip convolution only depends on the block input: with `overlap` it runs on the side stream (see __init__ for the measurement)
+        with self._side(after_main=True):
+            if kind == "nn":
+                s, _, _ = self.conv(pfx + ".s", x, ci)          # conv1x1 commutes with nearest up-sampling: low resolution
+            else:
+                s, _, _ = self.conv(pfx + ".s", src, ci)
         u1, st1, p1 = self.conv(pfx + ".u1", src, c0, fetch=fetch, stats=True)
         cf1 = self.bn_fin(pfx + ".bn1", st1, p1, net[key + ".bn1"])
         u2, st2, p2 = self.conv(pfx + ".u2", u1, c3, act=(cf1, LEAKY), stats=True)
         cf2 = self.bn_fin(pfx + ".bn4", st2, p2, net[key + ".bn4"])
-        if kind == "nn":
-            s, _, _ = self.conv(pfx + ".s", x, ci)              # conv1x1 commutes with nearest up-sampling: low resolution
-            out = self.bn_act(pfx + ".out", u2, cf2, s, 2, LEAKY)
-        else:
-            s, _, _ = self.conv(pfx + ".s", src, ci)
-            out = self.bn_act(pfx + ".out", u2, cf2, s, 1, LEAKY)
+        self._join_side()
+        out = self.bn_act(pfx + ".out", u2, cf2, s, 2 if kind == "nn" else 1, LEAKY)
         return out
 
     def res_bwd(self, pfx, net, key, dout, kind, need_dx=True):
@@ -424,15 +461,21 @@ class InnerLoopEngine:
         b = self.buf
         c0, c3, ci = net[key + ".c0"], net[key + ".c3"], net[key + ".ci"]
         g2, bc2 = self.act_bwd(pfx + ".bw2", dout, b[pfx + ".out"], b[pfx + ".u2"], b[pfx + ".bn4.coef"], LEAKY)
+        # skip branch on the side stream (it only needs g2): its data-gradient lands in the buffer the main chain then ACCUMULATES into
+        with self._side(after_main=True):
+            if kind == "nn":
+                gs = self.pool2(pfx + ".gs", g2)
+                dx, _, _ = self.conv(pfx + ".dx", gs, ci, dgrad=True)
+            else:
+                dsrc, _, _ = self.conv(pfx + ".dsrc", g2, ci, dgrad=True)
         da1, _, _ = self.conv(pfx + ".da1", g2, c3, bnbwd=(bc2, b[pfx + ".u2"]), dgrad=True)
         g1, bc1 = self.act_bwd(pfx + ".bw1", da1, None, b[pfx + ".u1"], b[pfx + ".bn1.coef"], LEAKY)
-        dsrc, _, _ = self.conv(pfx + ".dsrc", g1, c0, bnbwd=(bc1, b[pfx + ".u1"]), dgrad=True)     # at the (up-sampled / strided) resolution
+        self._join_side()
         if kind == "nn":
-            dx = self.pool2(pfx + ".dx", dsrc)
-            gs = self.pool2(pfx + ".gs", g2)
-            self.conv(pfx + ".dx", gs, ci, dgrad=True, epi=1, out=dx)
+            dhi, _, _ = self.conv(pfx + ".dhi", g1, c0, bnbwd=(bc1, b[pfx + ".u1"]), dgrad=True)   # at the up-sampled resolution
+            self.pool2(pfx + ".dx", dhi, out=dx, accumulate=True)
             return dx
-        self.conv(pfx + ".dsrc", g2, ci, dgrad=True, epi=1, out=dsrc)
+        self.conv(pfx + ".dsrc", g1, c0, bnbwd=(bc1, b[pfx + ".u1"]), dgrad=True, epi=1, out=dsrc)  # at the strided / transposed-conv resolution
         if not need_dx:
             return dsrc
         if kind == "convT":
