@@ -110,6 +110,19 @@ int ms_conv2d(const float* in, const float* in2, float* out, const float* w_pack
               int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
               int epi_mode, float* stats, void* stream);
 
+/* ms_conv2d whose output is the gradient w.r.t. an activation LeakyReLU_act_slope(coef4[c].scale*u + coef4[c].shift) that the forward pass
+ * never materialised (it was folded into the next convolution's prologue: encoder_decoder.py:44-46, 62-64): the epilogue multiplies by the
+ * activation's derivative and accumulates, per output channel, {sum g, sum g*(u - coef4[c].mean)} - the result of
+ * ms_act_bwd_reduce(ref = NULL) without its extra pass over the gradient (autograd: leaky_relu_backward + the reductions of
+ * native_batch_norm_backward).  No bias, plain store.
+ *   u [N,Cout,Hout,Wout], coef4 float4[Cout] from ms_bn_finalize, tab: ms_conv_actbwd_tab_bytes(Cout) bytes, float2 header {slots used}
+ *   + float2[Cout][slots]; hand it to ms_bn_bwd_coefs / ms_bn_bwd_full with nparts = 0. */
+size_t ms_conv_actbwd_tab_bytes(int Cout);
+int ms_conv2d_actbwd(const float* in, const float* in2, float* out, const float* w_packed,
+                     int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                     int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                     const float* u, const float* coef4, float act_slope, float* tab, void* stream);
+
 /* Chan-merge of the per-workgroup statistics in fp64 -> coef4[c] = {scale=gamma*invstd, shift=beta-mean*scale, mean, invstd}
  * (biased variance + eps: nn.BatchNorm2d training-mode normalisation with frozen affine). */
 int ms_bn_finalize(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, int C, void* stream);
@@ -135,7 +148,8 @@ int ms_act_bwd_bn(const float* gin, const float* ref, const float* u, const floa
                   float* coef_out4, int N, int C, int HW, float slope, void* stream);
 
 /* native_batch_norm_backward (input gradient only, batch statistics): du = al*g + be*u + de, coef_out4[c] = {al,be,de,0}
- * (SURVEY.md A.7).  count = N*H*W.  Feed coef_out4 to ms_conv2d(pro_mode=2) of the data-gradient convolution. */
+ * (SURVEY.md A.7).  count = N*H*W.  Feed coef_out4 to ms_conv2d(pro_mode=2) of the data-gradient convolution.
+ * nparts = 0: part2 is the table written by ms_conv2d_actbwd (its header holds the slot count). */
 int ms_bn_bwd_coefs(const float* part2, int nparts, const float* coef4, double count, float* coef_out4, int C, void* stream);
 
 /* out[p,y,x] (+)= in[p,2y,2x]+in[p,2y,2x+1]+in[p,2y+1,2x]+in[p,2y+1,2x+1]: gradient of nn.UpsamplingNearest2d(2) */
@@ -163,7 +177,7 @@ int ms_conv_wgrad(const float* p, const float* p2, const float* q, float* dw, in
 /* BatchNorm backward from the partial sums of ms_act_bwd_reduce: coefficients as ms_bn_bwd_coefs (coef_out4 may be NULL) plus
  * BatchNorm weight.grad (dgamma) / bias.grad (dbeta) and dsum = sum of the masked gradient (bias.grad of the residual 1x1 conv that
  * shares it); each may be NULL.  accumulate != 0 adds.  In the hard-example pass the BatchNorm affine is frozen
- * (model_util.py:468-510): pass NULL for dgamma/dbeta there. */
+ * (model_util.py:468-510): pass NULL for dgamma/dbeta there.  nparts = 0: part2 is the table of ms_conv2d_actbwd. */
 int ms_bn_bwd_full(const float* part2, int nparts, const float* coef4, double count, float* coef_out4, float* dgamma, float* dbeta, float* dsum,
                    int accumulate, int C, void* stream);
 

@@ -72,12 +72,20 @@ extern "C" size_t ms_conv_stats_bytes(int N, int Cout, int Hout, int Wout) {
   return ((size_t)Cout * ms_conv_stats_parts(N, Hout, Wout) + 1) * sizeof(float4);      // + header record
 }
 
-extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
-                         int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
-                         int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
-                         int epi_mode, float* stats, void* stream) {
+struct MaskEpi { const float* u; const float* coef4; float slope; float* tab; };
+
+static int conv2d_impl(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
+                       int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                       int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                       int epi_mode, float* stats, const MaskEpi* mk, void* stream) {
   if (N < 1 || Cin < 1 || Cout < 1 || Hs < 1 || Ws < 1) { set_error("ms_conv2d: invalid shape"); return MS_ERR_INVALID; }
   if (pro_mode < 0 || pro_mode > 3 || epi_mode < 0 || epi_mode > 2 || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
+  if (mk != nullptr) {
+    if (epi_mode != 0 || stats != nullptr || mk->u == nullptr || mk->coef4 == nullptr || mk->tab == nullptr || !aligned16(mk->u) || !aligned16(mk->coef4) || !aligned16(out)) {
+      set_error("ms_conv2d_actbwd: needs u, coef4 and tab (16-byte aligned) and a plain epilogue"); return MS_ERR_INVALID;
+    }
+    epi_mode = 3;
+  }
   // pro_mode 3 = pro_mode 2 whose coefficients are derived in-kernel from the partial sums of ms_act_bwd_reduce:
   //   pro_a = partials [Cin][pro_nstride][2], pro_b = forward coefficient records (stride pro_cstride), pro_c = optional output [Cin][4]
   int bw_parts = 0; float* bw_out = nullptr;
@@ -107,6 +115,7 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
   a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (gemm_cols + 63) / 64 * 64;
   a.bw_parts = bw_parts; a.bw_count = (double)N * Hs * Ws; a.bw_out = bw_out;
   a.pro_mode = pro_mode; a.pro_nstride = pro_nstride; a.pro_cstride = pro_cstride < 1 ? 1 : pro_cstride; a.slope = slope; a.epi_mode = epi_mode;
+  if (mk != nullptr) { a.mk_u = mk->u; a.mk_coef = mk->coef4; a.mk_slope = mk->slope; a.mk_tab = mk->tab; }
   if (a.Hout < 1 || a.Wout < 1) { set_error("ms_conv2d: empty output"); return MS_ERR_INVALID; }
   if ((long)N > 65535) { set_error("ms_conv2d: batch too large for gridDim.z"); return MS_ERR_INVALID; }
   const bool narrow = narrow_tile(a.Wout);
@@ -135,6 +144,25 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
   if (ks == 3 && stride == 1) return conv_dispatch_k3s1(a, fetch, nt, vec, narrow, use_in2, st);
   if (ks == 1) return conv_dispatch_k1s1(a, nt, vec, narrow, use_in2, st);
   return conv_dispatch_s2(a, ks, nt, vec, narrow, st);
+}
+
+extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
+                         int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                         int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                         int epi_mode, float* stats, void* stream) {
+  return conv2d_impl(in, in2, out, w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
+                     epi_mode, stats, nullptr, stream);
+}
+
+extern "C" size_t ms_conv_actbwd_tab_bytes(int Cout) { return ((size_t)Cout * kStatSlots + 1) * sizeof(float2); }
+
+extern "C" int ms_conv2d_actbwd(const float* in, const float* in2, float* out, const float* w_packed,
+                                int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                                int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                                const float* u, const float* coef4, float act_slope, float* tab, void* stream) {
+  const MaskEpi mk{u, coef4, act_slope, tab};
+  return conv2d_impl(in, in2, out, w_packed, nullptr, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
+                     0, nullptr, &mk, stream);
 }
 
 extern "C" int ms_bn_finalize(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, int C, void* stream) {

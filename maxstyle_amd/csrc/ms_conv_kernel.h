@@ -21,8 +21,6 @@
 namespace ms {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kNumCU = 256;      // MI355X: 8 XCDs x 32 CUs
-constexpr int kStatSlots = kNumCU * 2 * 4;   // per-channel capacity of the BatchNorm partial table: one slot per consumer wave of a resident workgroup
 
 enum { FETCH_NORMAL = 0, FETCH_UPS2 = 1, FETCH_ZINS2 = 2 };
 
@@ -36,6 +34,9 @@ struct ConvArgs {
   int dbg;                      // timing-only ablation bits (MS_CONV_DBG): 1 skip MFMA loop, 2 skip global loads, 4 skip epilogue
   int bw_parts; double bw_count; float* bw_out;   // pro_mode 3 (host side): BatchNorm-backward coefficients are derived in-kernel from bw_parts partial sums per channel
   long long* trace;             // MS_CONV_TRACE_BUILD only: cycle stamps of workgroup 0 (tools/dbg_convtrace.py)
+  // epi_mode 3 (ms_conv2d_actbwd): the output is the gradient w.r.t. an activation lrelu(sc*u + sh) that was never materialised; the epilogue
+  // applies its derivative and accumulates the BatchNorm-backward sums (sum g, sum g*(u - mean)) of u's layer: what ms_act_bwd_reduce does in its own pass
+  const float* mk_u; const float* mk_coef; float mk_slope; float* mk_tab;   // u [N,Cout,Hout,Wout]; coef float4 [Cout] {sc,sh,mean,invstd}; tab float2 [1 + Cout*kStatSlots]
 };
 
 template <int KS, int STRIDE, int FETCH, bool VEC, bool NARROW, int NT>
@@ -384,6 +385,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
 #pragma unroll
   for (int j = 0; j < NT; ++j) { st_mean[j] = 0.f; st_m2[j] = 0.f; }
   float bias_v[NT];
+  float mk_sc[NT], mk_sh[NT], mk_mu[NT];              // epi_mode 3: forward BatchNorm map + mean of this lane's channels
   int bias_co0 = -1;
   auto load_bias = [&](int co0) {
     if (co0 == bias_co0) return;
@@ -394,6 +396,10 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
       int bidx = co;
       if (a.epi_mode == 2) bidx = co % a.cout_real;
       bias_v[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[bidx] : 0.f;
+      if (a.epi_mode == 3) {
+        const float4 cf = (co < a.Cout) ? reinterpret_cast<const float4*>(a.mk_coef)[co] : make_float4(0.f, 0.f, 0.f, 0.f);
+        mk_sc[j] = cf.x; mk_sh[j] = cf.y; mk_mu[j] = cf.z;
+      }
     }
   };
   auto epilogue = [&](int n, int tile, int co0) {
@@ -454,7 +460,44 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
       }
       st_n = nt_;
     }
-    if (a.epi_mode == 2) {
+    if (a.epi_mode == 3) {
+      // g = acc * lrelu'(sc*u + sh); running sums of g and g*(u - mean) per channel in st_mean / st_m2 (act_bwd_reduce_kernel<1>)
+      const bool vec4 = full && (a.Wout % 4 == 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = co0 + j * 16 + m;
+        if (co >= a.Cout) continue;
+        const size_t pb = ((size_t)n * a.Cout + co) * a.Hout * a.Wout;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int y = oy0 + mt_row(i);
+          const int x = ox0 + mt_col(i) + xq;
+          if (y >= a.Hout) continue;
+          const size_t off = pb + (size_t)y * a.Wout + x;
+          float uu[4];
+          if (vec4) { const float4 t = *reinterpret_cast<const float4*>(a.mk_u + off); uu[0] = t.x; uu[1] = t.y; uu[2] = t.z; uu[3] = t.w; }
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) uu[r] = (x + r < a.Wout) ? a.mk_u[off + r] : 0.f;
+          }
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[i][j][r] * ((mk_sc[j] * uu[r] + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+            if (!vec4 && x + r >= a.Wout) v[r] = 0.f;
+          }
+          if (vec4) *reinterpret_cast<float4*>(a.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (x + r < a.Wout) a.out[off + r] = v[r];
+          }
+          s1 += (v[0] + v[1]) + (v[2] + v[3]);
+          s2 += (v[0] * (uu[0] - mk_mu[j]) + v[1] * (uu[1] - mk_mu[j])) + (v[2] * (uu[2] - mk_mu[j]) + v[3] * (uu[3] - mk_mu[j]));
+        }
+        st_mean[j] += s1; st_m2[j] += s2;
+      }
+    } else if (a.epi_mode == 2) {
       // ConvTranspose2d k=2 s=2: GEMM column j = (dy*2+dx)*cout_real + co -> out[n,co,2y+dy,2x+dx]
       const int Ho = 2 * a.Hout, Wo = 2 * a.Wout;
 #pragma unroll
@@ -546,6 +589,21 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
       if (k == 0 && co < a.Cout) tab[1 + (size_t)co * kStatSlots + slot] = make_float4(st_n, st_mean[j], st_m2[j], 0.f);
     }
     if (vb == 0 && threadIdx.x == 0) tab[0] = make_float4((float)(((int)gridDim.x / ncb) * 4), 0.f, 0.f, 0.f);
+  }
+  if (a.epi_mode == 3) {
+    // same slot numbering as the statistics table: [0] = {slots in use}, then float2 [1 + co*kStatSlots + slot]
+    float2* tab = reinterpret_cast<float2*>(a.mk_tab);
+    const int cb0 = vb % ncb;
+    const int slot = (vb / ncb) * 4 + wave;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float s1 = st_mean[j], s2 = st_m2[j];
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      const int co = cb0 * COUT_TILE + j * 16 + m;
+      if (k == 0 && co < a.Cout) tab[1 + (size_t)co * kStatSlots + slot] = make_float2(s1, s2);
+    }
+    if (vb == 0 && threadIdx.x == 0) tab[0] = make_float2((float)(((int)gridDim.x / ncb) * 4), 0.f);
   }
 }
 

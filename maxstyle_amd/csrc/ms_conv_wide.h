@@ -305,6 +305,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #pragma unroll
   for (int j = 0; j < NT; ++j) { st_mean[j] = 0.f; st_m2[j] = 0.f; }
   float bias_v[NT];
+  float mk_sc[NT], mk_sh[NT], mk_mu[NT];              // epi_mode 3: forward BatchNorm map + mean of this lane's channels
   int bias_co0 = -1;
   auto load_bias = [&](int co0) {
     if (co0 == bias_co0) return;
@@ -313,7 +314,25 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     for (int j = 0; j < NT; ++j) {
       const int co = co0 + j * 16 + m;
       bias_v[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+      if (a.epi_mode == 3) {
+        const float4 cf = (co < a.Cout) ? reinterpret_cast<const float4*>(a.mk_coef)[co] : make_float4(0.f, 0.f, 0.f, 0.f);
+        mk_sc[j] = cf.x; mk_sh[j] = cf.y; mk_mu[j] = cf.z;
+      }
     }
+  };
+  // epi_mode 3 with one channel block per lane: the 16 values of u this lane masks with are requested BEFORE the MFMA loop of the item's
+  // last K-chunk, so the epilogue does not wait for them (loading them inside the epilogue cost ~10 us per launch at 16->16 @16x256x256)
+  constexpr bool UPRE = (NT == 1);
+  float4 upre[4];
+  auto prefetch_u = [&](int n, int tile, int co0) {
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int y = ty * TH + wave, xb = tx * TW + 16 * k;
+    const int co = co0 + m;
+    const int nvalid = (y < a.Hout && co < a.Cout) ? max(0, min(16, a.Wout - xb)) : 0;
+    const size_t off = (((size_t)n * a.Cout + co) * a.Hout + y) * a.Wout + xb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      upre[r] = (4 * r < nvalid) ? *reinterpret_cast<const float4*>(a.mk_u + off + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto epilogue = [&](int n, int tile, int co0) {
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
@@ -356,7 +375,38 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       }
       st_n = nt_;
     }
-    if (row_ok && !(a.dbg & 4)) {
+    if (a.epi_mode == 3) {
+      // g = acc * lrelu'(sc*u + sh); running sums of g and g*(u - mean) per channel in st_mean / st_m2 (act_bwd_reduce_kernel<1>)
+      if (row_ok) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int co = co0 + j * 16 + m;
+          if (co >= a.Cout) continue;
+          const size_t off = (((size_t)n * a.Cout + co) * a.Hout + y) * a.Wout + xb;
+          float4 uu[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (UPRE) uu[r] = upre[r];                     // fetched before the item's last K-chunk (prefetch_u)
+            else if (4 * r < nvalid) uu[r] = *reinterpret_cast<const float4*>(a.mk_u + off + 4 * r);
+          }
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (4 * r < nvalid) {
+              float4 v;
+              v.x = acc[0][j][r] * ((mk_sc[j] * uu[r].x + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+              v.y = acc[1][j][r] * ((mk_sc[j] * uu[r].y + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+              v.z = acc[2][j][r] * ((mk_sc[j] * uu[r].z + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+              v.w = acc[3][j][r] * ((mk_sc[j] * uu[r].w + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+              *reinterpret_cast<float4*>(a.out + off + 4 * r) = v;
+              s1 += (v.x + v.y) + (v.z + v.w);
+              s2 += (v.x * (uu[r].x - mk_mu[j]) + v.y * (uu[r].y - mk_mu[j])) + (v.z * (uu[r].z - mk_mu[j]) + v.w * (uu[r].w - mk_mu[j]));
+            }
+          }
+          st_mean[j] += s1; st_m2[j] += s2;
+        }
+      }
+    } else if (row_ok && !(a.dbg & 4)) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int co = co0 + j * 16 + m;
@@ -392,6 +442,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     const int c0 = chunk * CK;
     const int ncg = min(CK / 4, (a.cin_pad - c0) / 4);
     if (tr && p < 16) a.trace[p * 4 + 0] = clock64();
+    if (UPRE && a.epi_mode == 3 && chunk + 1 == nchunks) prefetch_u(n, tile, cb * COUT_TILE);
     if (!(a.dbg & 1)) {
       if (ncg == CK / 4) compute(smem + (p & 1) * BUF, std::true_type{}, ncg);
       else compute(smem + (p & 1) * BUF, std::false_type{}, ncg);
@@ -418,6 +469,21 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       if (k == 0 && co < a.Cout) tab[1 + (size_t)co * kStatSlots + slot] = make_float4(st_n, st_mean[j], st_m2[j], 0.f);
     }
     if (vb == 0 && threadIdx.x == 0) tab[0] = make_float4((float)(((int)gridDim.x / ncb) * 4), 0.f, 0.f, 0.f);
+  }
+  if (a.epi_mode == 3) {
+    // same slot numbering as the statistics table: [0] = {slots in use}, then float2 [1 + co*kStatSlots + slot]
+    float2* tab = reinterpret_cast<float2*>(a.mk_tab);
+    const int cb0 = vb % ncb;
+    const int slot = (vb / ncb) * 4 + wave;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float s1 = st_mean[j], s2 = st_m2[j];
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      const int co = cb0 * COUT_TILE + j * 16 + m;
+      if (k == 0 && co < a.Cout) tab[1 + (size_t)co * kStatSlots + slot] = make_float2(s1, s2);
+    }
+    if (vb == 0 && threadIdx.x == 0) tab[0] = make_float2((float)(((int)gridDim.x / ncb) * 4), 0.f);
   }
 }
 

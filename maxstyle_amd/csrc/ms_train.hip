@@ -19,8 +19,11 @@ __global__ __launch_bounds__(256) void bn_bwd_full_kernel(const float2* __restri
                                                           float* __restrict__ dsum, int accumulate) {
   __shared__ double redd[16];
   const int c = blockIdx.x;
+  // nparts == 0: `part` is the table of ms_conv2d_actbwd - [0] = {slots in use}, rows of kStatSlots from [1]
+  const float2* row = (nparts == 0) ? part + 1 + (size_t)c * kStatSlots : part + (size_t)c * nparts;
+  if (nparts == 0) nparts = (int)part[0].x;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += 256) { const float2 q = part[(size_t)c * nparts + i]; s1 += (double)q.x; s2 += (double)q.y; }
+  for (int i = threadIdx.x; i < nparts; i += 256) { const float2 q = row[i]; s1 += (double)q.x; s2 += (double)q.y; }
   s1 = block_sum_d(s1, redd);
   s2 = block_sum_d(s2, redd);
   if (threadIdx.x == 0) {
@@ -270,7 +273,7 @@ extern "C" int ms_repack_weights(const float* flat, const void* desc_dev, int nd
 
 extern "C" int ms_bn_bwd_full(const float* part2, int nparts, const float* coef4, double count, float* coef_out4, float* dgamma, float* dbeta, float* dsum,
                               int accumulate, int C, void* stream) {
-  if (C < 1 || nparts < 1 || count <= 0) { set_error("ms_bn_bwd_full: invalid argument"); return MS_ERR_INVALID; }
+  if (C < 1 || nparts < 0 || count <= 0) { set_error("ms_bn_bwd_full: invalid argument"); return MS_ERR_INVALID; }
   MS_LAUNCH(bn_bwd_full_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float2*)part2, nparts, (const float4*)coef4, count, (float4*)coef_out4,
             dgamma, dbeta, dsum, accumulate);
   return check_launch("bn_bwd_full");

@@ -285,6 +285,9 @@ class InnerLoopEngine:
         # Built to fill the bubbles around the 5 us BatchNorm kernels; measured SLOWER at C2 (273.4 vs 295.3 steps/s, twice each): the conv kernels
         # are persistent grids sized for the whole chip, and a concurrent kernel that takes CU slots turns into load imbalance. Off by default.
         self.overlap = os.environ.get("MS_OVERLAP", "0") != "0"
+        # activation-backward mask + BatchNorm-backward sums in the epilogue of the data-gradient conv that produces the gradient
+        # (ms_conv2d_actbwd) instead of a separate ms_act_bwd_reduce pass over it; MS_FUSE_ACTBWD=0 is the A/B switch
+        self.fuse_act_bwd = os.environ.get("MS_FUSE_ACTBWD", "1") != "0"
         self._side_stream = None
         self._side_pending = False
 
@@ -423,6 +426,36 @@ class InnerLoopEngine:
                                 arrive.data_ptr(), bc.data_ptr(), N, C, H * W, slope, self._st()), "ms_act_bwd_bn:" + name)
         return gin, bc
 
+    def conv_actbwd(self, name, bw_name, g, cw: ConvW, bnbwd, u, coef, slope):
+        """Data-gradient conv (BatchNorm-backward prologue `bnbwd`) -> mask by the activation lrelu(bn(u)) below it -> (masked gradient, table).
+        The table holds the BatchNorm-backward sums of u's layer (ms_bn_bwd_coefs / ms_bn_bwd_full with nparts = 0)."""
+        N, Cin, Hs, Ws = g.shape
+        cout = cw.cin
+        out = self.t(name, N, cout, Hs, Ws)
+        tab = self.t(bw_name + ".tab", lib.ms_conv_actbwd_tab_bytes(cout) // 4)
+        pa, pb, pc = ops.coef_ptrs(bnbwd[0])
+        check(lib.ms_conv2d_actbwd(g.data_ptr(), bnbwd[1].data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), N, Cin, Hs, Ws, cout, cw.ks, 1, 0,
+                                   2, pa, pb, pc, 0, 4, 1.0, u.data_ptr(), coef.data_ptr(), slope, tab.data_ptr(), self._st()), "ms_conv2d_actbwd:" + name)
+        return out, tab
+
+    def dgrad_act_bwd(self, name, bw_name, g, cw: ConvW, bnbwd, u, coef, slope):
+        """da = dgrad(conv cw)(BN-backward(g)); g' = da * lrelu'(bn(u)); BN-backward coefficients of u's layer -> (g', bcoef4)."""
+        if not self.fuse_act_bwd or isinstance(bnbwd[0], tuple):
+            da, _, _ = self.conv(name, g, cw, bnbwd=bnbwd, dgrad=True)
+            return self.act_bwd(bw_name, da, None, u, coef, slope)
+        out, tab = self.conv_actbwd(name, bw_name, g, cw, bnbwd, u, coef, slope)
+        N, C, H, W = u.shape
+        if self.bn_eval:
+            bc = self.buf.get(bw_name + ".bcoef_eval")
+            if bc is None:
+                bc = torch.zeros(C, 4, dtype=F32, device=self.dev)
+                self.buf[bw_name + ".bcoef_eval"] = bc
+            bc[:, 0].copy_(coef[:, 0])
+            return out, bc
+        bc = self.t(bw_name + ".bcoef", C, 4)
+        check(lib.ms_bn_bwd_coefs(tab.data_ptr(), 0, coef.data_ptr(), float(N * H * W), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + bw_name)
+        return out, bc
+
     def pool2(self, name, x, out=None, accumulate=False):
         N, C, H, W = x.shape
         if out is None:
@@ -468,8 +501,7 @@ class InnerLoopEngine:
                 dx, _, _ = self.conv(pfx + ".dx", gs, ci, dgrad=True)
             else:
                 dsrc, _, _ = self.conv(pfx + ".dsrc", g2, ci, dgrad=True)
-        da1, _, _ = self.conv(pfx + ".da1", g2, c3, bnbwd=(bc2, b[pfx + ".u2"]), dgrad=True)
-        g1, bc1 = self.act_bwd(pfx + ".bw1", da1, None, b[pfx + ".u1"], b[pfx + ".bn1.coef"], LEAKY)
+        g1, bc1 = self.dgrad_act_bwd(pfx + ".da1", pfx + ".bw1", g2, c3, (bc2, b[pfx + ".u2"]), b[pfx + ".u1"], b[pfx + ".bn1.coef"], LEAKY)
         self._join_side()
         if kind == "nn":
             dhi, _, _ = self.conv(pfx + ".dhi", g1, c0, bnbwd=(bc1, b[pfx + ".u1"]), dgrad=True)   # at the up-sampled resolution
@@ -508,16 +540,14 @@ class InnerLoopEngine:
     def encode_bwd(self, dz_s):
         e, b = self.nets.enc, self.buf
         g, bc = self.act_bwd("e.cd.bw2", dz_s, b["e.z_s"], b["e.cd.u2"], b["e.cd.bn4.coef"], 0.0)
-        da, _, _ = self.conv("e.cd.da", g, e["cd3"], bnbwd=(bc, b["e.cd.u2"]), dgrad=True)
-        g, bc = self.act_bwd("e.cd.bw1", da, None, b["e.cd.u1"], b["e.cd.bn1.coef"], LEAKY)
+        g, bc = self.dgrad_act_bwd("e.cd.da", "e.cd.bw1", g, e["cd3"], (bc, b["e.cd.u2"]), b["e.cd.u1"], b["e.cd.bn1.coef"], LEAKY)
         dz_i, _, _ = self.conv("e.dz_i", g, e["cd0"], bnbwd=(bc, b["e.cd.u1"]), dgrad=True)
         g, bc = self.act_bwd("e.fc.bw", dz_i, b["e.z_i"], b["e.fc.u"], b["e.fc.bn.coef"], 0.0)
         dh, _, _ = self.conv("e.fc.dh", g, e["fc0"], bnbwd=(bc, b["e.fc.u"]), dgrad=True)
         for i in range(4, 0, -1):
             dh = self.res_bwd(f"e.d{i}", e, f"d{i}", dh, "down")
         g, bc = self.act_bwd("e.inc.bw2", dh, b["e.inc.out"], b["e.inc.ub"], b["e.inc.bn4.coef"], LEAKY)
-        da, _, _ = self.conv("e.inc.da", g, e["inc3"], bnbwd=(bc, b["e.inc.ub"]), dgrad=True)
-        g, bc = self.act_bwd("e.inc.bw1", da, None, b["e.inc.ua"], b["e.inc.bn1.coef"], LEAKY)
+        g, bc = self.dgrad_act_bwd("e.inc.da", "e.inc.bw1", g, e["inc3"], (bc, b["e.inc.ub"]), b["e.inc.ua"], b["e.inc.bn1.coef"], LEAKY)
         dimg, _, _ = self.conv("e.dimage", g, e["inc0"], bnbwd=(bc, b["e.inc.ua"]), dgrad=True)
         return dimg
 

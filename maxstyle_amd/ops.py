@@ -172,6 +172,19 @@ def conv2d(x, wp, bias, Cout, ks, stride=1, fetch=FETCH_NORMAL, pro_mode=0, pro_
     return out
 
 
+def conv2d_actbwd(x, wp, Cout, ks, u, coef4, act_slope, pro_mode=0, pro_a=None, pro_b=None, pro_c=None, pro_cstride=1, slope=1.0, in2=None, stride=1):
+    """ms_conv2d_actbwd wrapper: conv (no bias) -> * LeakyReLU'(coef4.scale*u + coef4.shift) -> (out, tab); tab feeds bn_bwd_coefs(tab, 0, ...)."""
+    _need_cuda_f32(x, wp, u, coef4, pro_a, pro_b, pro_c, in2)
+    N, Cin, Hs, Ws = x.shape
+    Ho, Wo = conv_out_hw(Hs, Ws, ks, stride, FETCH_NORMAL)
+    out = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=torch.float32)
+    tab = torch.full((lib.ms_conv_actbwd_tab_bytes(Cout) // 4,), float("nan"), device=x.device, dtype=torch.float32)
+    check(lib.ms_conv2d_actbwd(x.data_ptr(), _ptr(in2), out.data_ptr(), wp.data_ptr(), N, Cin, Hs, Ws, Cout, ks, stride, FETCH_NORMAL,
+                               pro_mode, _ptr(pro_a), _ptr(pro_b), _ptr(pro_c), 0, pro_cstride, slope, u.data_ptr(), coef4.data_ptr(), act_slope,
+                               tab.data_ptr(), _stream()), "ms_conv2d_actbwd")
+    return out, tab
+
+
 def conv_stats_buffer(N, Cout, Ho, Wo, device):
     parts = lib.ms_conv_stats_parts(N, Ho, Wo)
     return torch.empty(Cout * parts + 1, 4, device=device, dtype=torch.float32), parts

@@ -192,6 +192,21 @@ class TrainEngine(InnerLoopEngine):
                                  0 if db is None else db.data_ptr(), 0 if dsum is None else dsum.data_ptr(), 1, C, self._st()), "ms_bn_bwd_full:" + name)
         return gin, bc
 
+    def dgrad_act_bwd_t(self, name, bw_name, g, cw, bnbwd, u, coef, slope, net, bn_key):
+        """dgrad conv + act_bwd_t(ref=None) of the layer below; with `fuse_act_bwd` the mask and the sums come out of the conv's epilogue."""
+        if not self.fuse_act_bwd:
+            da, _, _ = self.conv(name, g, cw, bnbwd=bnbwd, dgrad=True)
+            return self.act_bwd_t(bw_name, da, None, u, coef, slope, net, bn_key)
+        out, tab = self.conv_actbwd(name, bw_name, g, cw, bnbwd, u, coef, slope)
+        N, C, H, W = u.shape
+        bc = self.t(bw_name + ".bcoef", C, 4)
+        dg = db = None
+        if self.bn_affine_grad:
+            dg, db = self._gw(net, bn_key), self._gb(net, bn_key)
+        check(lib.ms_bn_bwd_full(tab.data_ptr(), 0, coef.data_ptr(), float(N * H * W), bc.data_ptr(), 0 if dg is None else dg.data_ptr(),
+                                 0 if db is None else db.data_ptr(), 0, 1, C, self._st()), "ms_bn_bwd_full:" + bw_name)
+        return out, bc
+
     def conv(self, name, x, cw, **kw):
         out, st, parts = super().conv(name, x, cw, **kw)
         if kw.get("stats"):
@@ -273,8 +288,7 @@ class TrainEngine(InnerLoopEngine):
         cf1 = b[pfx + ".bn1.coef"]
         g2, bc2 = self.act_bwd_t(pfx + ".bw2", dout, b[pfx + ".out"], u2, b[pfx + ".bn4.coef"], LEAKY, net, key + ".bn4", dsum=self._gb(net, key + ".ci"))
         self.wgrad(g2, u1, self._gw(net, key + ".c3"), 3, p_bnbwd=(bc2, u2), q_act=(cf1, LEAKY))
-        da1, _, _ = self.conv(pfx + ".da1", g2, c3, bnbwd=(bc2, u2), dgrad=True)
-        g1, bc1 = self.act_bwd_t(pfx + ".bw1", da1, None, u1, cf1, LEAKY, net, key + ".bn1")
+        g1, bc1 = self.dgrad_act_bwd_t(pfx + ".da1", pfx + ".bw1", g2, c3, (bc2, u2), u1, cf1, LEAKY, net, key + ".bn1")
         src = x if kind == "nn" else (b[pfx + ".xu"] if kind == "convT" else b[pfx + ".xd"])
         self.wgrad(g1, src, self._gw(net, key + ".c0"), 3, q_fetch=1 if kind == "nn" else 0, p_bnbwd=(bc1, u1))
         dsrc, _, _ = self.conv(pfx + ".dsrc", g1, c0, bnbwd=(bc1, u1), dgrad=True)
@@ -354,8 +368,7 @@ class TrainEngine(InnerLoopEngine):
         if dz_s is not None:
             g, bc = self.act_bwd_t("e.cd.bw2", dz_s, z_s, b["e.cd.u2"], b["e.cd.bn4.coef"], 0.0, net_e, "cd4")
             self.wgrad(g, b["e.cd.u1"], self._gw(net_e, "cd3"), 3, p_bnbwd=(bc, b["e.cd.u2"]), q_act=(b["e.cd.bn1.coef"], LEAKY))
-            da, _, _ = self.conv("e.cd.da", g, e["cd3"], bnbwd=(bc, b["e.cd.u2"]), dgrad=True)
-            g, bc = self.act_bwd_t("e.cd.bw1", da, None, b["e.cd.u1"], b["e.cd.bn1.coef"], LEAKY, net_e, "cd1")
+            g, bc = self.dgrad_act_bwd_t("e.cd.da", "e.cd.bw1", g, e["cd3"], (bc, b["e.cd.u2"]), b["e.cd.u1"], b["e.cd.bn1.coef"], LEAKY, net_e, "cd1")
             self.wgrad(g, z_i, self._gw(net_e, "cd0"), 3, p_bnbwd=(bc, b["e.cd.u1"]))
             if dz_i is None:
                 dz_i, _, _ = self.conv("e.dz_i", g, e["cd0"], bnbwd=(bc, b["e.cd.u1"]), dgrad=True)
@@ -373,7 +386,6 @@ class TrainEngine(InnerLoopEngine):
             dh = self.res_bwd_t(f"e.d{i}", net_e, f"d{i}", x, dh, "down")
         g, bc = self.act_bwd_t("e.inc.bw2", dh, b["e.inc.out"], b["e.inc.ub"], b["e.inc.bn4.coef"], LEAKY, net_e, "inc4")
         self.wgrad(g, b["e.inc.ua"], self._gw(net_e, "inc3"), 3, p_bnbwd=(bc, b["e.inc.ub"]), q_act=(b["e.inc.bn1.coef"], LEAKY))
-        da, _, _ = self.conv("e.inc.da", g, e["inc3"], bnbwd=(bc, b["e.inc.ub"]), dgrad=True)
-        g, bc = self.act_bwd_t("e.inc.bw1", da, None, b["e.inc.ua"], b["e.inc.bn1.coef"], LEAKY, net_e, "inc1")
+        g, bc = self.dgrad_act_bwd_t("e.inc.da", "e.inc.bw1", g, e["inc3"], (bc, b["e.inc.ub"]), b["e.inc.ua"], b["e.inc.bn1.coef"], LEAKY, net_e, "inc1")
         self.wgrad(g, image, self._gw(net_e, "inc0"), 3, p_bnbwd=(bc, b["e.inc.ua"]))      # the input image needs no gradient
         self._wgrad_flush()

@@ -224,3 +224,44 @@ def test_wide_kernel_all_modes(dev, N, Cin, Cout, H, W):
     o2 = ops.conv2d(x.to(dev), wp, None, Cout, 3, 1, pro_mode=2, pro_a=ops.coef_ptrs(cfd)[0], pro_b=ops.coef_ptrs(cfd)[1], pro_c=ops.coef_ptrs(cfd)[2],
                     pro_cstride=4, in2=x2.to(dev), epi_mode=1, out=base.to(dev).clone())
     assert rel(o2, F.conv2d(xb, w.double(), None, padding=1) + base.double()) < 3e-6
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,ks", [
+    (2, 16, 16, 64, 64, 3), (1, 32, 48, 20, 192, 3), (2, 64, 64, 64, 64, 3), (1, 8, 33, 7, 100, 3),          # wide-read kernel, NT 1 and 2, channel tails
+    (2, 16, 16, 32, 32, 3), (2, 128, 128, 16, 16, 3), (4, 128, 128, 8, 8, 3), (1, 20, 24, 9, 70, 3),          # first-generation kernel: wide and narrow tiles
+    (2, 24, 40, 6, 10, 3), (1, 5, 7, 3, 5, 3), (2, 32, 16, 12, 20, 1),                                        # ragged rows (scalar epilogue), 1x1
+])
+def test_conv_actbwd_epilogue(dev, N, Cin, Cout, H, W, ks):
+    """ms_conv2d_actbwd == ms_conv2d followed by ms_act_bwd_reduce(ref = NULL): same masked gradient bit for bit, same BatchNorm-backward
+    coefficients up to summation order; with the BatchNorm-backward prologue the data-gradient convs use, and against fp64 math."""
+    from maxstyle_amd import ops
+    g = _rand((N, Cin, H, W), 21); g2 = _rand((N, Cin, H, W), 22); w = _rand((Cout, Cin, ks, ks), 23, 0.1)
+    u = _rand((N, Cout, H, W), 24) + 0.3
+    cf = _rand((Cin, 4), 25).to(dev)
+    coef = torch.stack([1 + 0.2 * _rand((Cout,), 26), 0.3 * _rand((Cout,), 27), 0.3 + 0.1 * _rand((Cout,), 28), 1 + 0.1 * _rand((Cout,), 29).abs()], 1).to(dev)
+    wp = ops.pack_conv_weight(w.to(dev))
+    for pro in (0, 2):
+        kw = dict(pro_mode=2, pro_a=ops.coef_ptrs(cf)[0], pro_b=ops.coef_ptrs(cf)[1], pro_c=ops.coef_ptrs(cf)[2], pro_cstride=4, in2=g2.to(dev)) if pro else {}
+        da = ops.conv2d(g.to(dev), wp, None, Cout, ks, 1, **kw)
+        gm, part, nparts = ops.act_bwd_reduce(da, None, u.to(dev), coef, 0.2)
+        bc = ops.bn_bwd_coefs(part, nparts, coef, N * H * W)
+        out, tab = ops.conv2d_actbwd(g.to(dev), wp, Cout, ks, u.to(dev), coef, 0.2, **kw)
+        assert torch.equal(out, gm)
+        bc_f = ops.bn_bwd_coefs(tab, 0, coef, N * H * W)
+        assert torch.isfinite(bc_f).all()
+        tol = 1e-5 * float(gm.abs().mean()) * max(1.0, float(coef[:, 0].abs().max()))
+        assert float((bc_f - bc).abs().max()) < 20 * tol + 1e-6 * float(bc.abs().max())
+        # fp64 reference of the whole op
+        xin = g.double() if not pro else (cf[:, 0].cpu().double().view(1, -1, 1, 1) * g.double() + cf[:, 1].cpu().double().view(1, -1, 1, 1) * g2.double()
+                                          + cf[:, 2].cpu().double().view(1, -1, 1, 1))
+        ref = F.conv2d(xin, w.double(), None, padding=ks // 2)
+        cc = coef.cpu().double()
+        pre = cc[:, 0].view(1, -1, 1, 1) * u.double() + cc[:, 1].view(1, -1, 1, 1)
+        safe = pre.abs() > 1e-4                                  # away from the activation's kink the mask cannot differ
+        refm = ref * torch.where(pre > 0, 1.0, 0.2)
+        assert rel(out.cpu().double() * safe, refm * safe) < 3e-6
+        s1 = refm.sum((0, 2, 3)); s2 = (refm * (u.double() - cc[:, 2].view(1, -1, 1, 1))).sum((0, 2, 3))
+        cnt = N * H * W
+        be = -cc[:, 0] * (s2 * cc[:, 3] / cnt) * cc[:, 3]
+        ref_bc = torch.stack([cc[:, 0], be, -cc[:, 0] * s1 / cnt - be * cc[:, 2]], 1)
+        assert rel(bc_f[:, :3], ref_bc) < 1e-4
