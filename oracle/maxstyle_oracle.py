@@ -399,13 +399,15 @@ def decoder_forward(sd, code, up_type, last_act=None, bn_mode="batch", taps=None
     return h
 
 
-def apply_max_style(sd, image_code, styles: Dict[int, StyleState], layers: Sequence[int], taps=None):
-    """MyDecoder.apply_max_style for the image decoder ('Conv2' up, Sigmoid) - encoder_decoder.py:598-631."""
+def apply_max_style(sd, image_code, styles: Dict[int, StyleState], layers: Sequence[int], taps=None, bn_mode="batch"):
+    """MyDecoder.apply_max_style for the image decoder ('Conv2' up, Sigmoid) - encoder_decoder.py:598-631.
+    bn_mode "running": the sub-networks are in .eval() when the loop is called (nn.BatchNorm2d then normalises with its running statistics
+    whatever _disable_tracking_bn_stats toggles: torch/nn/modules/batchnorm.py, `bn_training = self.training or buffers are None`)."""
     x = image_code.detach().clone()
     if 0 in layers:
         x = maxstyle_forward(x, styles[0])
     for i in range(1, 5):
-        x = res_up_block(sd, f"up{i}.", x, "Conv2", "batch", taps)
+        x = res_up_block(sd, f"up{i}.", x, "Conv2", bn_mode, taps)
         if i in layers:
             x = maxstyle_forward(x, styles[i])
             if taps is not None:
@@ -457,7 +459,7 @@ def style_param_list(styles: Dict[int, StyleState], layers: Sequence[int]):
     return names, params
 
 
-def inner_step_grads(weights, image_code, styles, layers, reference_segmentation):
+def inner_step_grads(weights, image_code, styles, layers, reference_segmentation, bn_mode="batch"):
     """One loss/gradient evaluation of the loop body (advanced_triplet...py:547-561) at the CURRENT style
     parameters: decode -> encode -> segment -> loss = -CE -> d loss / d style params.  Returns
     (recon_image, loss, {name: grad})."""
@@ -469,9 +471,9 @@ def inner_step_grads(weights, image_code, styles, layers, reference_segmentation
             p = p.detach().clone().requires_grad_(True)
             setattr(styles[int(i)], nm, p)
             params[k] = p
-    recon = apply_max_style(dec, image_code, styles, layers)
-    z_i, z_s = encoder_forward(enc, recon, "batch")
-    logits = decoder_forward(seg, z_s, "NN", None, "batch")
+    recon = apply_max_style(dec, image_code, styles, layers, bn_mode=bn_mode)
+    z_i, z_s = encoder_forward(enc, recon, bn_mode)
+    logits = decoder_forward(seg, z_s, "NN", None, bn_mode)
     loss = -cross_entropy_2d(logits, reference_segmentation)
     grads = torch.autograd.grad(loss, params, allow_unused=True)
     return recon.detach(), float(loss.detach()), {n: (None if g is None else g.detach()) for n, g in zip(names, grads)}
@@ -479,7 +481,7 @@ def inner_step_grads(weights, image_code, styles, layers, reference_segmentation
 
 def generate_max_style_image(weights, image_code, styles: Dict[int, StyleState], layers: Sequence[int],
                              reference_segmentation, n_iter=5, lr=0.1, trace: Optional[InnerLoopTrace] = None,
-                             keep_images=False):
+                             keep_images=False, bn_mode="batch"):
     """The K-step inner loop (advanced_triplet...py:458-571) with *injected* MaxStyle state.
 
     loss = -CE(seg_decoder(z_s(encoder(recon))), labels); Adam(lr) on the learnable style params in
@@ -492,7 +494,7 @@ def generate_max_style_image(weights, image_code, styles: Dict[int, StyleState],
         v = {n: torch.zeros_like(p) for n, p in zip(names, params)}
         steps = {n: 0 for n in names}
         for it in range(n_iter):
-            recon, loss, grads = inner_step_grads(weights, image_code, styles, layers, reference_segmentation)
+            recon, loss, grads = inner_step_grads(weights, image_code, styles, layers, reference_segmentation, bn_mode)
             names, params = style_param_list(styles, layers)
             with torch.no_grad():
                 for n, p in zip(names, params):
@@ -508,7 +510,7 @@ def generate_max_style_image(weights, image_code, styles: Dict[int, StyleState],
                 if keep_images:
                     trace.images.append(recon.clone())
     with torch.no_grad():
-        recon = apply_max_style(dec, image_code, styles, layers)
+        recon = apply_max_style(dec, image_code, styles, layers, bn_mode=bn_mode)
     return recon.detach().clone()
 
 

@@ -135,9 +135,13 @@ def build_reference_solver(solver_mod, spec: orc.NetSpec, dtype):
     return S, W
 
 
-def loop_case(solver_mod, spec, B, size, layers, K, dtype, style_seed=7, lr=0.1, with_taps=False):
-    """Runs the reference generate_max_style_image with injected state; returns expected outputs."""
+def loop_case(solver_mod, spec, B, size, layers, K, dtype, style_seed=7, lr=0.1, with_taps=False, eval_mode=False):
+    """Runs the reference generate_max_style_image with injected state; returns expected outputs.
+    eval_mode: the sub-networks are in .eval() (test-time use of the loop): every BatchNorm normalises with its running statistics."""
     S, W = build_reference_solver(solver_mod, spec, dtype)
+    if eval_mode:
+        for mod in S.model.values():
+            mod.eval()
     img, lab = orc.synthetic_batch(B, size, spec.image_ch, spec.num_classes, seed=1234)
     img = img.to(dtype)
     with torch.no_grad():
@@ -267,6 +271,11 @@ def main():
     np.savez_compressed(os.path.join(out_dir, "loop_c2small_f64.npz"), **keep(c2d))
     c1d = loop_case(solver_mod, spec16, B=4, size=128, layers=[3], K=1, dtype=torch.float64)
     np.savez_compressed(os.path.join(out_dir, "loop_c1_f64.npz"), **keep(c1d))
+    # the loop with the sub-networks in eval mode (BatchNorm running statistics), fp32 + fp64 twin
+    ce = loop_case(solver_mod, spec16, B=4, size=64, layers=[3, 4, 5], K=3, dtype=torch.float32, eval_mode=True)
+    np.savez_compressed(os.path.join(out_dir, "loop_eval.npz"), **ce)
+    ced = loop_case(solver_mod, spec16, B=4, size=64, layers=[3, 4, 5], K=3, dtype=torch.float64, eval_mode=True)
+    np.savez_compressed(os.path.join(out_dir, "loop_eval_f64.npz"), **keep(ced))
     # all six insertion points incl. layer 0 (on the code) at K=2
     c6 = loop_case(solver_mod, spec16, B=3, size=64, layers=[0, 1, 2, 3, 4, 5], K=2, dtype=torch.float32)
     np.savez_compressed(os.path.join(out_dir, "loop_all_layers.npz"), **{k: v for k, v in c6.items() if k != "z_i"})

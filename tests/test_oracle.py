@@ -90,16 +90,20 @@ def _setup(spec, B, size, layers, dtype=torch.float32, style_seed=7):
     return W, img, lab, z_i, styles
 
 
-def _teacher_forced(g, g64, spec, B, size, layers, K, grad_tol_later=5e-2):
+def _teacher_forced(g, g64, spec, B, size, layers, K, grad_tol_later=5e-2, bn_mode="batch"):
     """Every step from the reference's own parameters: loss/forward tight, grads noise-calibrated."""
     W, img, lab, z_i, styles = _setup(spec, B, size, layers)
+    if bn_mode != "batch":
+        with torch.no_grad():
+            z_i, _ = orc.encoder_forward(W["image_encoder"], img, bn_mode)
+        assert rel(z_i, g["z_i"]) < 1e-5
     initial = {f"{i}.{n}": getattr(styles[i], n).numpy().copy() for i in layers for n in ("gamma_noise", "beta_noise", "lmda")}
     for s in range(1, K + 1):
         cur = ref_params_at(g, s - 1, layers, initial)
         for n, val in cur.items():
             i, nm = n.split(".")
             setattr(styles[int(i)], nm, torch.from_numpy(np.array(val)).clone())
-        recon, loss, grads = orc.inner_step_grads(W, z_i, styles, layers, lab)
+        recon, loss, grads = orc.inner_step_grads(W, z_i, styles, layers, lab, bn_mode)
         assert abs(loss - g["losses"][s - 1]) < 2e-5 * abs(g["losses"][s - 1]), (s, loss, g["losses"][s - 1])
         for n in style_names(layers):
             ref = g[f"step{s}.grad.{n}"]
@@ -124,7 +128,7 @@ def _teacher_forced(g, g64, spec, B, size, layers, K, grad_tol_later=5e-2):
         i, nm = n.split(".")
         setattr(styles[int(i)], nm, torch.from_numpy(np.array(val)).clone())
     with torch.no_grad():
-        out = orc.apply_max_style(W["image_decoder"], z_i, styles, layers)
+        out = orc.apply_max_style(W["image_decoder"], z_i, styles, layers, bn_mode=bn_mode)
     assert rel(out, g["image"]) < 1e-5
     return W, lab, out
 
@@ -168,6 +172,26 @@ def test_loop_k5_three_layers(golden_dir):
         pred = orc.decoder_forward(W["segmentation_decoder"], zs, "NN").argmax(1)
     assert float((pred.numpy() == g["final_pred"]).mean()) > 0.9995
     np.testing.assert_allclose(orc.dice_per_class(pred, lab, 4), g["final_dice"], atol=1e-3)
+
+
+def test_loop_eval_mode(golden_dir):
+    """The loop called with the sub-networks in .eval() (running statistics in every BatchNorm): K=3, layers [3,4,5]."""
+    g = np.load(os.path.join(golden_dir, "loop_eval.npz"))
+    g64 = np.load(os.path.join(golden_dir, "loop_eval_f64.npz"))
+    spec = orc.NetSpec(4, 1, 4)
+    # fp32 gradients against the reference's fp32 gradients (activation-mask flips: see parity_util); exactness is pinned by the fp64 twin below
+    W, lab, out = _teacher_forced(g, None, spec, 4, 64, [3, 4, 5], 3, grad_tol_later=1e-2, bn_mode="running")
+    with torch.no_grad():
+        _, zs = orc.encoder_forward(W["image_encoder"], out, "running")
+        pred = orc.decoder_forward(W["segmentation_decoder"], zs, "NN", None, "running").argmax(1)
+    assert float((pred.numpy() == g["final_pred"]).mean()) > 0.9995
+    np.testing.assert_allclose(orc.dice_per_class(pred, lab, 4), g["final_dice"], atol=1e-3)
+    # fp64 restatement == fp64 reference to rounding
+    W, img, lab, z_i, styles = _setup(spec, 4, 64, [3, 4, 5], dtype=torch.float64)
+    with torch.no_grad():
+        z_i, _ = orc.encoder_forward(W["image_encoder"], img, "running")
+    out64 = orc.generate_max_style_image(W, z_i, styles, [3, 4, 5], lab, n_iter=3, lr=0.1, bn_mode="running")
+    assert rel(out64, g64["image"]) < 1e-9
 
 
 def test_loop_free_running(golden_dir):

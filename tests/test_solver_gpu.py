@@ -75,6 +75,31 @@ def test_generate_max_style_image_vs_reference(golden_dir, dev):
     np.testing.assert_allclose(orc.dice_per_class(logits.argmax(1).cpu(), lab, 4), g["final_dice"], atol=2e-2)
 
 
+def test_generate_max_style_image_eval_mode(golden_dir, dev):
+    """Sub-networks in .eval() when the loop is called (test-time use): BatchNorm running statistics everywhere; fixture from the reference."""
+    from oracle import maxstyle_oracle as orc
+    g = np.load(os.path.join(golden_dir, "loop_eval.npz"))
+    spec = orc.NetSpec(4, 1, 4)
+    S, W = make_solver(dev, spec)
+    for m in S.model.values():
+        m.eval()
+    img, lab = orc.synthetic_batch(4, 64, 1, 4, 1234)
+    layers = [3, 4, 5]
+    styles = {i: orc.random_style_state(4, spec.channel_num[i], 7 + i) for i in layers}
+    S.style_init_hook = injector(styles, dev)
+    z_i, _ = S.encode_image(img.to(dev), disable_track_bn_stats=True)
+    assert rel(z_i, g["z_i"]) < 3e-5
+    for rep in range(2):
+        out = S.generate_max_style_image(z_i, layers, spec.channel_num, p=1.5, n_iter=3, lr=0.1, reference_image=img.to(dev), reference_segmentation=lab.to(dev))
+        np.testing.assert_allclose(S.last_losses.cpu().numpy(), g["losses"], rtol=2e-3)
+        assert rel(out, g["image"]) < 2e-2
+    for m in S.model.values():
+        assert not m.training and all(not p.requires_grad for p in m.parameters())     # requires_grad restored to the (False) training flag
+    _, zs2 = S.encode_image(out, disable_track_bn_stats=True)
+    logits = S.decoder_inference(decoder=S.model["segmentation_decoder"], latent_code=zs2, disable_track_bn_stats=True)
+    np.testing.assert_allclose(orc.dice_per_class(logits.argmax(1).cpu(), lab, 4), g["final_dice"], atol=2e-2)
+
+
 def test_error_behaviour_and_identity(dev):
     from oracle import maxstyle_oracle as orc
     spec = orc.NetSpec(4, 1, 4)
