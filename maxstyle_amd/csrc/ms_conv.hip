@@ -127,20 +127,34 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   int nt = 1;
   bool found = false;
   for (long want : {512L, 256L}) {
-    for (int cand = ((pro_mode == 2 || ks == 3) ? 2 : 4); cand >= 2 && !found; cand >>= 1) {   // 64-channel tiles only where they fit the register file without spilling
+    // 64-channel tiles only where they fit the register file without spilling; not for the pixel-shuffle epilogue (its scattered 4-byte stores
+    // want more workgroups in flight: 16->4x16 @16x128x128 56.6 us with 64-column tiles, 46.5 us with 32; tools/tune_conv.py)
+    for (int cand = ((pro_mode == 2 || ks == 3 || epi_mode == 2) ? 2 : 4); cand >= 2 && !found; cand >>= 1) {
       if (gemm_cols <= 16 * (cand / 2)) continue;        // would be mostly padding
       if (tiles * cdiv(gemm_cols, 16 * cand) >= want) { nt = cand; found = true; }
     }
     // two resident workgroups per CU with 16-channel tiles beat one with 32-channel tiles (285.4 -> 287.3 steps/s)
-    if (!found && want == 512L && tiles * cdiv(gemm_cols, 16) >= 512L) { nt = 1; found = true; }
+    // (not for a stride-2 layer of <= 32 channels: its input tile is 4x the output tile, and one 32-channel block stages it once instead of
+    //  twice - 32->32 @16x128x128: 20.3 vs 27.1 us; with more channel blocks the extra workgroups win again: 128->128 @16x32x32 23.6 vs 26.7 us)
+    if (!found && want == 512L && !(stride == 2 && gemm_cols <= 32) && tiles * cdiv(gemm_cols, 16) >= 512L) { nt = 1; found = true; }
     if (found) break;
+  }
+  // tuning hook (tools/tune_conv.py): with MS_CONV_TUNE set, MS_CONV_FORCE_NT / MS_CONV_FORCE_WIDE are re-read on every call
+  static const bool tune = getenv("MS_CONV_TUNE") != nullptr;
+  bool allow_wide = true;
+  if (tune) {
+    const char* f = getenv("MS_CONV_FORCE_NT");
+    const int fnt = f ? atoi(f) : 0;
+    if (fnt == 1 || fnt == 2 || (fnt == 4 && ks != 3 && pro_mode != 2)) nt = fnt;
+    const char* fw = getenv("MS_CONV_FORCE_WIDE");
+    if (fw && atoi(fw) == 0) allow_wide = false;
   }
   a.ncb = cdiv(gemm_cols, 16 * nt);
   { static const int dbg = getenv("MS_CONV_DBG") ? atoi(getenv("MS_CONV_DBG")) : 0; a.dbg = dbg; }
   { static const char* tr = getenv("MS_CONV_TRACE"); a.trace = tr ? (long long*)strtoull(tr, nullptr, 0) : nullptr; }
   hipStream_t st = (hipStream_t)stream;
   const bool use_in2 = (pro_mode == 2);
-  if (conv_wide_eligible(a, ks, stride, fetch, vec)) return conv_dispatch_wide(a, nt, st);
+  if (allow_wide && conv_wide_eligible(a, ks, stride, fetch, vec)) return conv_dispatch_wide(a, nt, st);
   if (ks == 3 && stride == 1) return conv_dispatch_k3s1(a, fetch, nt, vec, narrow, use_in2, st);
   if (ks == 1) return conv_dispatch_k1s1(a, nt, vec, narrow, use_in2, st);
   return conv_dispatch_s2(a, ks, nt, vec, narrow, st);
