@@ -497,6 +497,33 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         }
         st_mean[j] += s1; st_m2[j] += s2;
       }
+    } else if (a.epi_mode == 2 && NT >= 2 && (a.cout_real == 16 || (a.cout_real == 32 && NT == 4)) && (a.Wout % 4 == 0) &&
+               ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0)) {
+      // ConvTranspose2d k=2 s=2, paired form: the columns of dx = 0 and dx = 1 of one (dy, co) sit in the same lane, 16*C16 columns apart
+      // (the tile starts at an even (dy,dx) block), so the 4 pixels of a lane become 8 CONSECUTIVE output floats: two 16-byte stores instead of
+      // eight 4-byte stores at stride 8 (16->4x16 @16x128x128: the scattered form ran at 1.4 TB/s)
+      const int Ho = 2 * a.Hout, Wo = 2 * a.Wout;
+      const int C16 = a.cout_real / 16;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const bool is_dx0 = (C16 == 1) ? ((j & 1) == 0) : ((j & 2) == 0);
+        if (!is_dx0) continue;
+        const int col = co0 + j * 16 + m;
+        const int q = col / a.cout_real, co = col - q * a.cout_real;
+        const int dy = q >> 1;
+        float* op = a.out + ((size_t)n * a.cout_real + co) * Ho * Wo;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int y = oy0 + mt_row(i);
+          const int x = ox0 + mt_col(i) + xq;
+          if (y >= a.Hout || x >= a.Wout) continue;
+          float* o = op + (size_t)(2 * y + dy) * Wo + 2 * x;
+          // (C16 is wave-uniform: both selects compile to one of the two register sets)
+          const f32x4 p0 = acc[i][j], p1 = (C16 == 1) ? acc[i][min(j + 1, NT - 1)] : acc[i][min(j + 2, NT - 1)];
+          *reinterpret_cast<float4*>(o) = make_float4(p0[0], p1[0], p0[1], p1[1]);
+          *reinterpret_cast<float4*>(o + 4) = make_float4(p0[2], p1[2], p0[3], p1[3]);
+        }
+      }
     } else if (a.epi_mode == 2) {
       // ConvTranspose2d k=2 s=2: GEMM column j = (dy*2+dx)*cout_real + co -> out[n,co,2y+dy,2x+dx]
       const int Ho = 2 * a.Hout, Wo = 2 * a.Wout;
