@@ -335,6 +335,13 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       upre[r] = (4 * r < nvalid) ? *reinterpret_cast<const float4*>(a.mk_u + off + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto epilogue = [&](int n, int tile, int co0) {
+    if (a.dbg & 16) {                                    // timing-only: no epilogue at all (upper bound of what hiding it can gain)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      return;
+    }
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const int y = ty * TH + wave, xb = tx * TW + 16 * k;
     const bool row_ok = y < a.Hout;
@@ -346,32 +353,35 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] += bias_v[j];
-    if (a.stats != nullptr) {
-      float cnt = (float)nvalid;
-      cnt += __shfl_xor(cnt, 16, 64);
-      cnt += __shfl_xor(cnt, 32, 64);
+    if (a.stats != nullptr && nvalid > 0) {
+      // PER-LANE running (count, mean, M2) of this lane's 16-pixel groups, Chan-merged group by group; the four lanes that share a channel are
+      // merged once, at the end of the kernel.  (The first version reduced every tile across those lanes: six dependent ds_bpermute round trips
+      // and two IEEE divisions per tile = ~2 k cycles of epilogue per item on an idle CU - tools/trace_conv.py with MS_CONV_DBG=15.)
+      const float cnt = (float)nvalid;
+      const float rc = (nvalid == 16) ? 0.0625f : __builtin_amdgcn_rcpf(cnt);
       const float nt_ = st_n + cnt;
-      const float wgt = (nt_ > 0.f) ? cnt / nt_ : 0.f;
+      const float wgt = cnt * __builtin_amdgcn_rcpf(nt_);       // merge weight to 1 ulp: enters as d*wgt and d*d*n*wgt, both second-order terms
+      const bool all16 = (nvalid == 16);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        float s = 0.f;
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) {
+          if (all16) { s0 += acc[0][j][r] + acc[1][j][r]; s1 += acc[2][j][r] + acc[3][j][r]; }
+          else if (4 * r < nvalid) { s0 += acc[0][j][r] + acc[1][j][r]; s1 += acc[2][j][r] + acc[3][j][r]; }
+        }
+        const float mean = (s0 + s1) * rc;
+        float q0 = 0.f, q1 = 0.f;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) s += (4 * r + i < nvalid) ? acc[i][j][r] : 0.f;
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        const float mean = cnt > 0.f ? s / cnt : 0.f;
-        float q = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { const float d = acc[i][j][r] - mean; q += (4 * r + i < nvalid) ? d * d : 0.f; }
-        q += __shfl_xor(q, 16, 64);
-        q += __shfl_xor(q, 32, 64);
+        for (int r = 0; r < 4; ++r) {
+          if (all16 || 4 * r < nvalid) {
+            const float d0 = acc[0][j][r] - mean, d1 = acc[1][j][r] - mean, d2 = acc[2][j][r] - mean, d3 = acc[3][j][r] - mean;
+            q0 += d0 * d0 + d1 * d1; q1 += d2 * d2 + d3 * d3;
+          }
+        }
         const float d = mean - st_mean[j];
         st_mean[j] += d * wgt;
-        st_m2[j] += q + d * d * st_n * wgt;
+        st_m2[j] += (q0 + q1) + d * d * st_n * wgt;
       }
       st_n = nt_;
     }
@@ -465,8 +475,20 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     const int slot = (vb / ncb) * 4 + wave;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
+      // Chan merge of the four lanes (k = 0..3) that hold the same channel: xor 16, then xor 32
+      float n_ = st_n, mu_ = st_mean[j], m2_ = st_m2[j];
+#pragma unroll
+      for (int off = 16; off <= 32; off <<= 1) {
+        const float nb = __shfl_xor(n_, off, 64), mb = __shfl_xor(mu_, off, 64), qb = __shfl_xor(m2_, off, 64);
+        const float nn = n_ + nb;
+        const float w = (nn > 0.f) ? nb / nn : 0.f;
+        const float d = mb - mu_;
+        mu_ += d * w;
+        m2_ += qb + d * d * n_ * w;
+        n_ = nn;
+      }
       const int co = cb0 * COUT_TILE + j * 16 + m;
-      if (k == 0 && co < a.Cout) tab[1 + (size_t)co * kStatSlots + slot] = make_float4(st_n, st_mean[j], st_m2[j], 0.f);
+      if (k == 0 && co < a.Cout) tab[1 + (size_t)co * kStatSlots + slot] = make_float4(n_, mu_, m2_, 0.f);
     }
     if (vb == 0 && threadIdx.x == 0) tab[0] = make_float4((float)(((int)gridDim.x / ncb) * 4), 0.f, 0.f, 0.f);
   }

@@ -105,7 +105,9 @@ def _teacher_forced(dev, g, g64, spec, B, size, layers, K, grad_tol=5e-2, bn_eva
         if s == 1:
             for i in layers:
                 assert rel(eng.buf[f"st{i}.std"][0], g[f"{i}.gamma_std"].ravel()) < 1e-5
-                assert rel(eng.buf[f"st{i}.std"][1], g[f"{i}.beta_std"].ravel()) < 1e-5
+                # std over the batch of the plane MEANS: on the sigmoid image (layer 5, B=3) the means are 0.47 +- 0.004, so a 1e-7 relative
+                # difference of a mean is a 1.2e-5 relative difference of their std
+                assert rel(eng.buf[f"st{i}.std"][1], g[f"{i}.beta_std"].ravel()) < 3e-5
             # Adam kernel: reference gradient in -> reference parameters out
             for n in style_names(layers):
                 i, nm = n.split(".")
