@@ -445,6 +445,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   lds_barrier();                                      // barrier #1: chunk 0 is in buffer 0
 #ifdef MS_CONV_TRACE_BUILD
   const bool tr = (a.trace != nullptr) && (blockIdx.x == 0) && (threadIdx.x == 0);
+  if (tr) { a.trace[500] = clock64(); a.trace[501] = (long long)__builtin_amdgcn_s_memrealtime(); }     // shader clock vs the 100 MHz constant clock
 #else
   constexpr bool tr = false;
 #endif
@@ -469,6 +470,9 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     if (p + 1 < T) lds_barrier();                     // barrier #(p+2)
     if (tr && p < 16) a.trace[p * 4 + 3] = clock64();
   }
+#ifdef MS_CONV_TRACE_BUILD
+  if (tr) { a.trace[502] = clock64(); a.trace[503] = (long long)__builtin_amdgcn_s_memrealtime(); }
+#endif
   if (a.stats != nullptr) {
     float4* tab = reinterpret_cast<float4*>(a.stats);
     const int cb0 = vb % ncb;

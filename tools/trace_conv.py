@@ -29,3 +29,6 @@ print("producer: p  [store_start, store_end, loads_issued, after_barrier]   stor
 for p in range(12):
     c = t[128 + p * 4:128 + (p + 1) * 4]
     print(p, [v - t0 for v in c], c[1] - c[0], c[2] - c[1], c[3] - c[2])
+dc, dr = t[502] - t[500], t[503] - t[501]
+if dr > 0:
+    print(f"workgroup 0 main loop: {dc} shader cycles in {dr * 10} ns (s_memrealtime, 100 MHz) -> shader clock {dc / (dr * 10):.3f} GHz")
