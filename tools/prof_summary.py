@@ -30,6 +30,20 @@ def main(d, out=None):
         lines.append("# per-step totals by kernel")
         for k, v in sorted(agg.items(), key=lambda kv: -kv[1]):
             lines.append(f"{k[:70]:70s} {v:9.1f} us")
+    # the launches bench.py prices for its `roofline` objects: back-to-back runs (>= 20) of ONE kernel on ONE shape (kernel_rooflines())
+    lines.append("")
+    lines.append("# isolated back-to-back runs (bench.py kernel_rooflines: 3 warm-up + 20 timed launches of one shape) - compare with roofline.us_per_launch")
+    i = 0
+    while i < len(rows):
+        j = i
+        while j + 1 < len(rows) and rows[j + 1]["Kernel_Name"] == rows[i]["Kernel_Name"]:
+            j += 1
+        if j - i + 1 >= 20 and "ms::" in rows[i]["Kernel_Name"]:
+            durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows[i:j + 1]][-20:]
+            name = rows[i]["Kernel_Name"].replace("void ms::", "").replace("ms::", "")
+            name = name[:name.index("(")] if "(" in name else name
+            lines.append(f"{name[:60]:60s} n={j - i + 1:3d}  avg of the last 20: {sum(durs) / len(durs):7.1f} us  (min {min(durs):.1f}, max {max(durs):.1f})")
+        i = j + 1
     txt = "\n".join(lines)
     if out:
         open(out, "w").write(txt + "\n")
