@@ -252,3 +252,30 @@ def test_single_read_kernel_under_graph_replay_with_foreign_work(dev):
     state = eng.buf["st4.ws"][-((nfused + 15) // 16 * 16):].view(torch.int32)
     assert int(state[1]) == 0, "bounded spin timed out (error word set)"
     assert int(state[0]) > 0, "the single-read kernel ran (epoch advanced)"
+
+
+def test_config2_full_size_step_vs_oracle(dev):
+    """BASELINE config 2 at its full size (16x1x256x256, layers [3,4,5]): one loss / gradient evaluation of the loop body against the CPU oracle
+    (fp32, a few seconds on the host cores), plus the decoded image; the per-sample plane statistics the MaxStyle layers froze must agree too."""
+    from oracle import maxstyle_oracle as orc
+    layers = [3, 4, 5]
+    spec = orc.NetSpec(4, 1, 4)
+    eng, W, img, lab, styles = build_engine(dev, spec, 16, 256, layers)
+    with torch.no_grad():
+        z_i = orc.encoder_forward(W["image_encoder"], img)[0]
+    z_gpu = eng.encode_fwd(img.to(dev))[0].clone()
+    assert rel(z_gpu, z_i) < 5e-5
+    eng.code = z_i.to(dev)
+    eng._prefix_valid = False
+    _, loss = eng.step_grads(lab.to(dev))
+    sty = {i: s.clone() for i, s in styles.items()}
+    recon, ref_loss, grads = orc.inner_step_grads(W, z_i, sty, layers, lab)
+    assert abs(float(loss) - ref_loss) < 3e-5 * abs(ref_loss), (float(loss), ref_loss)
+    img_gpu = eng.buf["st5.y"] if "st5.y" in eng.buf else eng.buf["d.image"]
+    assert rel(img_gpu, recon) < 2e-5
+    for n in style_names(layers):
+        i, nm = n.split(".")
+        assert rel(eng.grad(int(i), nm), grads[n]) < 2e-2, n            # activation-mask flips: see parity_util / DESIGN.md section 4
+    for i in layers:
+        assert rel(eng.buf[f"st{i}.std"][0], sty[i].gamma_std.reshape(-1)) < 2e-5
+        assert rel(eng.buf[f"st{i}.std"][1], sty[i].beta_std.reshape(-1)) < 5e-5

@@ -324,3 +324,32 @@ def test_no_grad_forward_and_double_backward_guard(dev):
     loss.backward(retain_graph=True)
     with pytest.raises(RuntimeError):
         loss.backward()
+
+
+def test_training_pass_full_size_vs_oracle(dev):
+    """BASELINE config-2 batch (16x1x256x256): standard_training forward + backward against the fp32 CPU oracle (autograd over the functional
+    forward; about half a minute of host time).  At this size a mask flip is 1 pixel in ~1e6, so the whole-pass tolerance can be tighter."""
+    from oracle import maxstyle_oracle as orc
+    from oracle import outer_oracle as outer
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    o32 = oracle_pass_grads(torch.float32, 16, 256, True)
+    S, W = make_solver(dev, orc.NetSpec(4, 1, 4))
+    S.reset_all_optimizers()
+    out = S.standard_training(o32["clean"].to(dev), o32["lab"].to(dev), perturbed_image=o32["image_l"].to(dev), disable_track_bn_stats=False, return_output=True)
+    seg, rec, _, _, recon, y0, _ = out
+    assert abs(float(seg.detach()) - o32["seg"]) < 3e-5 * abs(o32["seg"]) + 1e-6
+    assert abs(float(rec.detach()) - o32["rec"]) < 3e-5 * abs(o32["rec"]) + 1e-7
+    assert rel(S.z_i, o32["z_i"]) < 5e-5 and rel(recon, o32["recon"]) < 5e-5 and rel(y0, o32["logits"]) < 2e-4
+    (seg + rec).backward()
+    worst = ("", 0.0)
+    for net in outer.NETS:
+        for k, p in S.model[net].named_parameters():
+            key = f"{net}/{k}"
+            ref = o32["grads"][key]
+            if ref is None or outer.is_null_grad_bias(net, k):
+                continue
+            err = rel(p.grad, ref)
+            if err > worst[1]:
+                worst = (key, err)
+            assert err < 1e-2, (key, err)
+    print("worst gradient error at full size", worst)
