@@ -46,17 +46,17 @@ def parse():
 
 def build(dev, B, size, rank, net=(4, 1, 4)):
     from maxstyle_amd import engine as E
-    from oracle import maxstyle_oracle as orc     # data/weight generators only (procedural, shared with the tests)
-    spec_o = orc.NetSpec(*net)
-    W = orc.procedural_weights(spec_o, 0)
+    from maxstyle_amd import synthetic as syn      # procedural weights / images / style states (the GPU leg never imports oracle/)
+    spec_o = syn.NetSpec(*net)
+    W = syn.procedural_weights(spec_o, 0)
     to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
     spec = E.NetSpec(*net)
     nets = E.PackedNets(spec, to(W["image_encoder"]), to(W["segmentation_decoder"]), to(W["image_decoder"]))
     eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1)
     eng.set_nets(nets)
-    img, lab = orc.synthetic_batch(B, size, net[1], net[2], seed=1234 + rank)
+    img, lab = syn.synthetic_batch(B, size, net[1], net[2], seed=1234 + rank)
     layers = [3, 4, 5]
-    styles = {i: orc.random_style_state(B, spec_o.channel_num[i], 7 + i) for i in layers}
+    styles = {i: syn.random_style_state(B, spec_o.channel_num[i], 7 + i) for i in layers}
     slots = {i: E.StyleSlot(i, B, spec_o.channel_num[i]) for i in layers}
     eng.configure_styles(layers, slots)
     for i in layers:
@@ -177,7 +177,7 @@ def dice_parity(dev):
     rs.update(lab_d, eng.buf["s.logits"])
     gpu_dice = rs.dice()
     torch.set_num_threads(min(8, os.cpu_count() or 1))
-    st = {i: s.clone() for i, s in styles.items()}
+    st = {i: orc.StyleState(s.perm.clone(), s.lmda.clone(), s.gamma_noise.clone(), s.beta_noise.clone()) for i, s in styles.items()}
     ref = orc.generate_max_style_image(W, z_i.cpu(), st, layers, lab, n_iter=K, lr=0.1)
     with torch.no_grad():
         _, zs = orc.encoder_forward(W["image_encoder"], ref)
@@ -228,7 +228,7 @@ def cpu_baseline(W, img, lab, styles, steps):
     torch.set_num_threads(best_t)
     with torch.no_grad():
         z_i, _ = orc.encoder_forward(W["image_encoder"], img)
-    st = {i: s.clone() for i, s in styles.items()}
+    st = {i: orc.StyleState(s.perm.clone(), s.lmda.clone(), s.gamma_noise.clone(), s.beta_noise.clone()) for i, s in styles.items()}
     layers = sorted(st)
     t0 = time.perf_counter()
     orc.generate_max_style_image(W, z_i, st, layers, lab, n_iter=1, lr=0.1)          # warm-up (MKLDNN primitive creation)
@@ -250,9 +250,9 @@ def outer_iteration(dev, batch, size, iters=6):
     standard pass -> MaxStyle inner loop K=5 -> hard-example pass -> backward (weight gradients) -> AdamW x3
     (train_adv_supervised_segmentation_triplet.py:163-199, 251-287, 532-535; SURVEY.md 8(f) rows 1,3)."""
     import maxstyle_amd as M
-    from oracle import maxstyle_oracle as orc          # synthetic data generator only
+    from maxstyle_amd import synthetic as syn
     S = M.AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard_no_STN", image_ch=1, num_classes=4, use_gpu=True, optimizer_type="AdamW")
-    clean, lab = orc.synthetic_batch(batch, size, 1, 4, 1234)
+    clean, lab = syn.synthetic_batch(batch, size, 1, 4, 1234)
     clean, lab = clean.to(dev), lab.to(dev)
     cfg = {"mix_style": True, "no_noise": False, "lr": 0.1, "n_iter": 5, "mix_learnable": True, "noise_learnable": True,
            "decoder_layers_indexes": [3, 4, 5], "loss_types": ["seg"], "loss_weights": [1], "always_use_beta": False}

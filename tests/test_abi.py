@@ -105,3 +105,32 @@ def test_state_dict_layout_matches_reference():
     assert sum(p.numel() for p in S.model["image_encoder"].parameters()) > 0
     with pytest.raises(NotImplementedError):
         M.AdvancedTripletReconSegmentationModel(network_type="Unet_16", use_gpu=False)
+
+
+def test_synthetic_matches_oracle():
+    """bench.py / tools generate their inputs with maxstyle_amd.synthetic (the product side never imports oracle/): same values as the generators
+    the parity tests use, bit for bit."""
+    import torch
+    from maxstyle_amd import synthetic as syn
+    from oracle import maxstyle_oracle as orc
+    for net in ((4, 1, 4), (1, 3, 2)):
+        a = syn.procedural_weights(syn.NetSpec(*net), 0); b = orc.procedural_weights(orc.NetSpec(*net), 0)
+        assert list(a) == list(b)
+        for n in a:
+            assert list(a[n]) == list(b[n])
+            assert all(torch.equal(a[n][k], b[n][k]) for k in a[n])
+        assert syn.NetSpec(*net).channel_num == orc.NetSpec(*net).channel_num
+    x = syn.synthetic_batch(3, 48, 3, 2, 77); y = orc.synthetic_batch(3, 48, 3, 2, 77)
+    assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1])
+    s = syn.random_style_state(5, 8, 9); t = orc.random_style_state(5, 8, 9)
+    assert all(torch.equal(getattr(s, k), getattr(t, k)) for k in ("perm", "lmda", "gamma_noise", "beta_noise"))
+
+
+def test_product_never_imports_oracle():
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "maxstyle_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
