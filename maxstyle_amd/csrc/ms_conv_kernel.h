@@ -414,51 +414,50 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         for (int r = 0; r < 4; ++r) acc[i][j][r] += bias_v[j];
     const bool full = (oy0 + TH <= a.Hout) && (ox0 + TW <= a.Wout);     // no masking needed (wave-uniform)
     if (a.stats != nullptr) {
-      // per-WAVE (count, mean, M2) of this wave's pixels per output channel: two passes over registers, cross-lane combine
-      // of the 4 lane groups that share a channel (xor 16, 32).  Partials: [co][(n*ntiles+tile)*4 + wave]
+      // PER-LANE running (count, mean, M2) of the pixels this lane produced (4 per M-tile), Chan-merged tile by tile; the four lanes that share a
+      // channel are merged once at the end of the kernel (no ds_bpermute chain and no IEEE division per item - see ms_conv_wide.h)
       float cnt = 0.f;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int y = oy0 + mt_row(i);
-        const int nx = min(16, a.Wout - (ox0 + mt_col(i)));
-        if (y < a.Hout && nx > 0) cnt += (float)nx;
+        const int nx = min(4, a.Wout - (ox0 + mt_col(i) + xq));
+        if (full) cnt += 4.f;
+        else if (y < a.Hout && nx > 0) cnt += (float)nx;
       }
-      const float nt_ = st_n + cnt;
-      const float wgt = (nt_ > 0.f) ? cnt / nt_ : 0.f;
+      if (cnt > 0.f) {
+        const float rc = __builtin_amdgcn_rcpf(cnt);
+        const float nt_ = st_n + cnt;
+        const float wgt = cnt * __builtin_amdgcn_rcpf(nt_);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        float s = 0.f;
+        for (int j = 0; j < NT; ++j) {
+          float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int y = oy0 + mt_row(i);
+          for (int i = 0; i < MT; ++i) {
+            const int y = oy0 + mt_row(i);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int x = ox0 + mt_col(i) + xq + r;
-            s += (full || ((y < a.Hout) && (x < a.Wout))) ? acc[i][j][r] : 0.f;
+            for (int r = 0; r < 4; ++r) {
+              const int x = ox0 + mt_col(i) + xq + r;
+              s += (full || ((y < a.Hout) && (x < a.Wout))) ? acc[i][j][r] : 0.f;
+            }
           }
-        }
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        const float mean = cnt > 0.f ? s / cnt : 0.f;
-        float q = 0.f;
+          const float mean = s * rc;
+          float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int y = oy0 + mt_row(i);
+          for (int i = 0; i < MT; ++i) {
+            const int y = oy0 + mt_row(i);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int x = ox0 + mt_col(i) + xq + r;
-            const float d = acc[i][j][r] - mean;
-            q += (full || ((y < a.Hout) && (x < a.Wout))) ? d * d : 0.f;
+            for (int r = 0; r < 4; ++r) {
+              const int x = ox0 + mt_col(i) + xq + r;
+              const float d = acc[i][j][r] - mean;
+              q += (full || ((y < a.Hout) && (x < a.Wout))) ? d * d : 0.f;
+            }
           }
+          const float d = mean - st_mean[j];
+          st_mean[j] += d * wgt;
+          st_m2[j] += q + d * d * st_n * wgt;
         }
-        q += __shfl_xor(q, 16, 64);
-        q += __shfl_xor(q, 32, 64);
-        // Chan merge of this tile's (cnt, mean, q) into the running statistics
-        const float d = mean - st_mean[j];
-        st_mean[j] += d * wgt;
-        st_m2[j] += q + d * d * st_n * wgt;
+        st_n = nt_;
       }
-      st_n = nt_;
     }
     if (a.epi_mode == 3) {
       // g = acc * lrelu'(sc*u + sh); running sums of g and g*(u - mean) per channel in st_mean / st_m2 (act_bwd_reduce_kernel<1>)
@@ -612,8 +611,20 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
     const int slot = (vb / ncb) * 4 + wave;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
+      // Chan merge of the four lanes (k = 0..3) that hold the same channel: xor 16, then xor 32
+      float n_ = st_n, mu_ = st_mean[j], m2_ = st_m2[j];
+#pragma unroll
+      for (int off = 16; off <= 32; off <<= 1) {
+        const float nb = __shfl_xor(n_, off, 64), mb = __shfl_xor(mu_, off, 64), qb = __shfl_xor(m2_, off, 64);
+        const float nn = n_ + nb;
+        const float w = (nn > 0.f) ? nb / nn : 0.f;
+        const float d = mb - mu_;
+        mu_ += d * w;
+        m2_ += qb + d * d * n_ * w;
+        n_ = nn;
+      }
       const int co = cb0 * COUT_TILE + j * 16 + m;
-      if (k == 0 && co < a.Cout) tab[1 + (size_t)co * kStatSlots + slot] = make_float4(st_n, st_mean[j], st_m2[j], 0.f);
+      if (k == 0 && co < a.Cout) tab[1 + (size_t)co * kStatSlots + slot] = make_float4(n_, mu_, m2_, 0.f);
     }
     if (vb == 0 && threadIdx.x == 0) tab[0] = make_float4((float)(((int)gridDim.x / ncb) * 4), 0.f, 0.f, 0.f);
   }
