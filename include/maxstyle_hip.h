@@ -123,6 +123,19 @@ int ms_conv2d_actbwd(const float* in, const float* in2, float* out, const float*
                      int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                      const float* u, const float* coef4, float act_slope, float* tab, void* stream);
 
+/* ms_conv2d(epi_mode 0, stats) / ms_conv2d_actbwd whose LAST workgroup also reduces the table: coef4 receives what ms_bn_finalize(stats, gamma, beta,
+ * eps) would compute (nn.BatchNorm2d in batch-statistics mode, model_util.py:468-510), bcoef4 what ms_bn_bwd_coefs(tab, coef4, count) would - without
+ * the extra launch (a ~4 us kernel, 42 times per inner step).  counter: one int, zero before the first use; every launch re-arms it (one counter per
+ * layer and stream: launches that share it must be stream-ordered). */
+int ms_conv2d_fin(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
+                  int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                  int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                  float* stats, const float* gamma, const float* beta, float eps, float* coef4, int* counter, void* stream);
+int ms_conv2d_actbwd_fin(const float* in, const float* in2, float* out, const float* w_packed,
+                         int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                         int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                         const float* u, const float* coef4, float act_slope, float* tab, double count, float* bcoef4, int* counter, void* stream);
+
 /* Chan-merge of the per-workgroup statistics in fp64 -> coef4[c] = {scale=gamma*invstd, shift=beta-mean*scale, mean, invstd}
  * (biased variance + eps: nn.BatchNorm2d training-mode normalisation with frozen affine). */
 int ms_bn_finalize(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, int C, void* stream);

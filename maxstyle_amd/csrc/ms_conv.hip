@@ -73,11 +73,12 @@ extern "C" size_t ms_conv_stats_bytes(int N, int Cout, int Hout, int Wout) {
 }
 
 struct MaskEpi { const float* u; const float* coef4; float slope; float* tab; };
+struct FinEpi { int* counter; float* out; const float* gamma; const float* beta; float eps; double count; };
 
 static int conv2d_impl(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                        int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                        int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
-                       int epi_mode, float* stats, const MaskEpi* mk, void* stream) {
+                       int epi_mode, float* stats, const MaskEpi* mk, const FinEpi* fin, void* stream) {
   if (N < 1 || Cin < 1 || Cout < 1 || Hs < 1 || Ws < 1) { set_error("ms_conv2d: invalid shape"); return MS_ERR_INVALID; }
   if (pro_mode < 0 || pro_mode > 3 || epi_mode < 0 || epi_mode > 2 || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
   if (mk != nullptr) {
@@ -116,6 +117,11 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   a.bw_parts = bw_parts; a.bw_count = (double)N * Hs * Ws; a.bw_out = bw_out;
   a.pro_mode = pro_mode; a.pro_nstride = pro_nstride; a.pro_cstride = pro_cstride < 1 ? 1 : pro_cstride; a.slope = slope; a.epi_mode = epi_mode;
   if (mk != nullptr) { a.mk_u = mk->u; a.mk_coef = mk->coef4; a.mk_slope = mk->slope; a.mk_tab = mk->tab; }
+  if (fin != nullptr) {
+    if (fin->counter == nullptr || fin->out == nullptr || !aligned16(fin->out) || (mk == nullptr && (stats == nullptr || fin->gamma == nullptr || fin->beta == nullptr)) ||
+        (mk != nullptr && !(fin->count > 0))) { set_error("ms_conv2d_fin: counter, output and the BatchNorm operands are required"); return MS_ERR_INVALID; }
+    a.fin_counter = fin->counter; a.fin_out = fin->out; a.fin_gamma = fin->gamma; a.fin_beta = fin->beta; a.fin_eps = fin->eps; a.fin_count = fin->count;
+  }
   if (a.Hout < 1 || a.Wout < 1) { set_error("ms_conv2d: empty output"); return MS_ERR_INVALID; }
   if ((long)N > 65535) { set_error("ms_conv2d: batch too large for gridDim.z"); return MS_ERR_INVALID; }
   const bool narrow = narrow_tile(a.Wout);
@@ -165,7 +171,16 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
                          int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                          int epi_mode, float* stats, void* stream) {
   return conv2d_impl(in, in2, out, w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
-                     epi_mode, stats, nullptr, stream);
+                     epi_mode, stats, nullptr, nullptr, stream);
+}
+
+extern "C" int ms_conv2d_fin(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
+                             int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                             int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                             float* stats, const float* gamma, const float* beta, float eps, float* coef4, int* counter, void* stream) {
+  const FinEpi fin{counter, coef4, gamma, beta, eps, 0.0};
+  return conv2d_impl(in, in2, out, w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
+                     0, stats, nullptr, &fin, stream);
 }
 
 extern "C" size_t ms_conv_actbwd_tab_bytes(int Cout) { return ((size_t)Cout * kStatSlots + 1) * sizeof(float2); }
@@ -176,7 +191,17 @@ extern "C" int ms_conv2d_actbwd(const float* in, const float* in2, float* out, c
                                 const float* u, const float* coef4, float act_slope, float* tab, void* stream) {
   const MaskEpi mk{u, coef4, act_slope, tab};
   return conv2d_impl(in, in2, out, w_packed, nullptr, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
-                     0, nullptr, &mk, stream);
+                     0, nullptr, &mk, nullptr, stream);
+}
+
+extern "C" int ms_conv2d_actbwd_fin(const float* in, const float* in2, float* out, const float* w_packed,
+                                    int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                                    int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                                    const float* u, const float* coef4, float act_slope, float* tab, double count, float* bcoef4, int* counter, void* stream) {
+  const MaskEpi mk{u, coef4, act_slope, tab};
+  const FinEpi fin{counter, bcoef4, nullptr, nullptr, 0.f, count};
+  return conv2d_impl(in, in2, out, w_packed, nullptr, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
+                     0, nullptr, &mk, &fin, stream);
 }
 
 extern "C" int ms_bn_finalize(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, int C, void* stream) {

@@ -37,7 +37,147 @@ struct ConvArgs {
   // epi_mode 3 (ms_conv2d_actbwd): the output is the gradient w.r.t. an activation lrelu(sc*u + sh) that was never materialised; the epilogue
   // applies its derivative and accumulates the BatchNorm-backward sums (sum g, sum g*(u - mean)) of u's layer: what ms_act_bwd_reduce does in its own pass
   const float* mk_u; const float* mk_coef; float mk_slope; float* mk_tab;   // u [N,Cout,Hout,Wout]; coef float4 [Cout] {sc,sh,mean,invstd}; tab float2 [1 + Cout*kStatSlots]
+  // "last workgroup finalises" (ms_conv2d_fin / ms_conv2d_actbwd_fin): fin_counter != NULL -> the workgroup that arrives last reduces the table itself
+  // and writes fin_out: the BatchNorm coefficients {scale, shift, mean, invstd} (statistics epilogue; fin_gamma/fin_beta/fin_eps) or the
+  // BatchNorm-backward coefficients {al, be, de, 0} (mask epilogue; fin_count = N*H*W) - what ms_bn_finalize / ms_bn_bwd_coefs do in their own launch
+  int* fin_counter; float* fin_out; const float* fin_gamma; const float* fin_beta; float fin_eps; double fin_count;
 };
+
+typedef unsigned long long conv_u64;
+// 16-byte / 8-byte table slots crossing workgroups inside one launch: 8-byte agent-scope atomics on both sides (MI355X_MICROARCH.md "Valid forms")
+__device__ inline void slot_store16(float4* p, float4 v) {
+  conv_u64* q = reinterpret_cast<conv_u64*>(p);
+  __hip_atomic_store(q, ((conv_u64)__float_as_uint(v.y) << 32) | (conv_u64)__float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, ((conv_u64)__float_as_uint(v.w) << 32) | (conv_u64)__float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline float4 slot_load16(const float4* p) {
+  const conv_u64* q = reinterpret_cast<const conv_u64*>(p);
+  const conv_u64 lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float4(__uint_as_float((unsigned)(lo & 0xFFFFFFFFull)), __uint_as_float((unsigned)(lo >> 32)),
+                     __uint_as_float((unsigned)(hi & 0xFFFFFFFFull)), __uint_as_float((unsigned)(hi >> 32)));
+}
+__device__ inline void slot_store8(float2* p, float2 v) {
+  __hip_atomic_store(reinterpret_cast<conv_u64*>(p), ((conv_u64)__float_as_uint(v.y) << 32) | (conv_u64)__float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline float2 slot_load8(const float2* p) {
+  const conv_u64 v = __hip_atomic_load(reinterpret_cast<const conv_u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float2(__uint_as_float((unsigned)(v & 0xFFFFFFFFull)), __uint_as_float((unsigned)(v >> 32)));
+}
+__device__ inline double shfl_xor_d(double v, int off) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, off, 64); hi = __shfl_xor(hi, off, 64);
+  return __hiloint2double(hi, lo);
+}
+
+// End of a conv kernel, MFMA waves only (threads 0..255; the staging waves have returned - s_barrier only waits for surviving waves): the per-lane
+// partials of the epilogue become ONE table slot per workgroup and channel (table[1 + co*kStatSlots + workgroup-within-channel-block], [0] = slots in use),
+// and with a.fin_counter the last workgroup to arrive turns the table into the coefficients the next kernel needs.
+//   STATS:  v0 = count, v1[j] = mean, v2[j] = M2 (per lane)  -> float4 slots {n, mean, M2, 0}
+//   !STATS: v1[j] = sum g, v2[j] = sum g*(u - mean) (per lane) -> float2 slots
+template <int NT, bool STATS>
+__device__ inline void conv_table_tail(const ConvArgs& a, float* smem, int vb, int ncb, float v0, const float (&v1)[NT], const float (&v2)[NT]) {
+  constexpr int COUT_TILE = 16 * NT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, k = lane >> 4;
+  const int cb0 = vb % ncb, wg = vb / ncb, S = (int)gridDim.x / ncb;
+  auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  bar();                                               // every MFMA wave is done with the stage buffers: smem is free
+  float* red = smem;                                   // [4 waves][COUT_TILE][3]
+  int* flag = reinterpret_cast<int*>(smem + 4 * COUT_TILE * 3);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    float n_ = v0, a_ = v1[j], b_ = v2[j];
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {         // the four lanes (k = 0..3) that hold the same channel
+      const float nb = __shfl_xor(n_, off, 64), ab = __shfl_xor(a_, off, 64), bb = __shfl_xor(b_, off, 64);
+      if (STATS) {
+        const float nn = n_ + nb;
+        const float w = (nn > 0.f) ? nb / nn : 0.f;
+        const float d = ab - a_;
+        a_ += d * w; b_ += bb + d * d * n_ * w; n_ = nn;
+      } else { a_ += ab; b_ += bb; }
+    }
+    if (k == 0) { float* r = red + ((wave * COUT_TILE) + j * 16 + m) * 3; r[0] = n_; r[1] = a_; r[2] = b_; }
+  }
+  bar();
+  if (threadIdx.x < COUT_TILE) {
+    const int ch = threadIdx.x;
+    float n_ = red[ch * 3], a_ = red[ch * 3 + 1], b_ = red[ch * 3 + 2];
+#pragma unroll
+    for (int w_ = 1; w_ < 4; ++w_) {
+      const float* r = red + ((w_ * COUT_TILE) + ch) * 3;
+      if (STATS) {
+        const float nn = n_ + r[0];
+        const float w = (nn > 0.f) ? r[0] / nn : 0.f;
+        const float d = r[1] - a_;
+        a_ += d * w; b_ += r[2] + d * d * n_ * w; n_ = nn;
+      } else { a_ += r[1]; b_ += r[2]; }
+    }
+    const int co = cb0 * COUT_TILE + ch;
+    if (co < a.Cout) {
+      if (STATS) {
+        float4* slot = reinterpret_cast<float4*>(a.stats) + 1 + (size_t)co * kStatSlots + wg;
+        if (a.fin_counter) slot_store16(slot, make_float4(n_, a_, b_, 0.f)); else *slot = make_float4(n_, a_, b_, 0.f);
+      } else {
+        float2* slot = reinterpret_cast<float2*>(a.mk_tab) + 1 + (size_t)co * kStatSlots + wg;
+        if (a.fin_counter) slot_store8(slot, make_float2(a_, b_)); else *slot = make_float2(a_, b_);
+      }
+    }
+  }
+  if (vb == 0 && threadIdx.x == 0) {
+    if (STATS) reinterpret_cast<float4*>(a.stats)[0] = make_float4((float)S, 0.f, 0.f, 0.f);
+    else reinterpret_cast<float2*>(a.mk_tab)[0] = make_float2((float)S, 0.f);
+  }
+  if (a.fin_counter == nullptr) return;
+  if (wave == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's slots are out before it is counted
+    if (lane == 0) {
+      const int prev = __hip_atomic_fetch_add(a.fin_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = (prev == (int)gridDim.x - 1) ? 1 : 0;
+    }
+  }
+  bar();
+  if (*flag == 0) return;
+  // ---- the last workgroup: 32 channels per pass, 8 threads per channel, fp64 (ms_bn_finalize / ms_bn_bwd_coefs restated) ----
+  const int sub = threadIdx.x & 7, cl = threadIdx.x >> 3;
+  for (int c0 = 0; c0 < a.Cout; c0 += 32) {
+    const int c = c0 + cl;
+    const bool live = c < a.Cout;
+    if (STATS) {
+      const float4* row = reinterpret_cast<const float4*>(a.stats) + 1 + (size_t)(live ? c : 0) * kStatSlots;
+      double sn = 0.0, sm = 0.0;
+      if (live) for (int i = sub; i < S; i += 8) { const float4 q = slot_load16(row + i); sn += (double)q.x; sm += (double)q.x * (double)q.y; }
+#pragma unroll
+      for (int off = 1; off <= 4; off <<= 1) { sn += shfl_xor_d(sn, off); sm += shfl_xor_d(sm, off); }
+      const double mean = live ? sm / sn : 0.0;
+      double sq = 0.0;
+      if (live) for (int i = sub; i < S; i += 8) { const float4 q = slot_load16(row + i); const double d = (double)q.y - mean; sq += (double)q.z + (double)q.x * d * d; }
+#pragma unroll
+      for (int off = 1; off <= 4; off <<= 1) sq += shfl_xor_d(sq, off);
+      if (live && sub == 0) {
+        const double var = sq / sn;
+        const float invstd = (float)(1.0 / sqrt(var + (double)a.fin_eps));
+        const float sc = a.fin_gamma[c] * invstd;
+        reinterpret_cast<float4*>(a.fin_out)[c] = make_float4(sc, a.fin_beta[c] - (float)mean * sc, (float)mean, invstd);
+      }
+    } else {
+      const float2* row = reinterpret_cast<const float2*>(a.mk_tab) + 1 + (size_t)(live ? c : 0) * kStatSlots;
+      double s1 = 0.0, s2 = 0.0;
+      if (live) for (int i = sub; i < S; i += 8) { const float2 q = slot_load8(row + i); s1 += (double)q.x; s2 += (double)q.y; }
+#pragma unroll
+      for (int off = 1; off <= 4; off <<= 1) { s1 += shfl_xor_d(s1, off); s2 += shfl_xor_d(s2, off); }
+      if (live && sub == 0) {
+        const float4 cf = reinterpret_cast<const float4*>(a.mk_coef)[c];           // {sc, sh, mean, invstd}
+        const double mean = cf.z, invstd = cf.w, sc = cf.x;
+        const double c1 = s1 / a.fin_count;
+        const double c2 = s2 * invstd / a.fin_count;
+        const double be = -sc * c2 * invstd;
+        reinterpret_cast<float4*>(a.fin_out)[c] = make_float4((float)sc, (float)be, (float)(-sc * c1 - be * mean), 0.f);
+      }
+    }
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(a.fin_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+}
+
 
 template <int KS, int STRIDE, int FETCH, bool VEC, bool NARROW, int NT>
 struct Geo {
@@ -604,45 +744,9 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
     }
     if (p + 1 < T) lds_barrier();                     // barrier #(p+2): chunk p+1 visible; this wave is done with chunk p
   }
-  if (a.stats != nullptr) {
-    // table layout: [0] = {slots in use per channel}, then [1 + co*kStatSlots + slot]; slot = (workgroup index within its channel block)*4 + wave
-    float4* tab = reinterpret_cast<float4*>(a.stats);
-    const int cb0 = vb % ncb;
-    const int slot = (vb / ncb) * 4 + wave;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      // Chan merge of the four lanes (k = 0..3) that hold the same channel: xor 16, then xor 32
-      float n_ = st_n, mu_ = st_mean[j], m2_ = st_m2[j];
-#pragma unroll
-      for (int off = 16; off <= 32; off <<= 1) {
-        const float nb = __shfl_xor(n_, off, 64), mb = __shfl_xor(mu_, off, 64), qb = __shfl_xor(m2_, off, 64);
-        const float nn = n_ + nb;
-        const float w = (nn > 0.f) ? nb / nn : 0.f;
-        const float d = mb - mu_;
-        mu_ += d * w;
-        m2_ += qb + d * d * n_ * w;
-        n_ = nn;
-      }
-      const int co = cb0 * COUT_TILE + j * 16 + m;
-      if (k == 0 && co < a.Cout) tab[1 + (size_t)co * kStatSlots + slot] = make_float4(n_, mu_, m2_, 0.f);
-    }
-    if (vb == 0 && threadIdx.x == 0) tab[0] = make_float4((float)(((int)gridDim.x / ncb) * 4), 0.f, 0.f, 0.f);
-  }
-  if (a.epi_mode == 3) {
-    // same slot numbering as the statistics table: [0] = {slots in use}, then float2 [1 + co*kStatSlots + slot]
-    float2* tab = reinterpret_cast<float2*>(a.mk_tab);
-    const int cb0 = vb % ncb;
-    const int slot = (vb / ncb) * 4 + wave;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      float s1 = st_mean[j], s2 = st_m2[j];
-      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-      const int co = cb0 * COUT_TILE + j * 16 + m;
-      if (k == 0 && co < a.Cout) tab[1 + (size_t)co * kStatSlots + slot] = make_float2(s1, s2);
-    }
-    if (vb == 0 && threadIdx.x == 0) tab[0] = make_float2((float)(((int)gridDim.x / ncb) * 4), 0.f);
-  }
+  // table layout: [0] = {slots in use per channel}, then [1 + co*kStatSlots + slot]; one slot per workgroup of the channel block (conv_table_tail)
+  if (a.stats != nullptr) conv_table_tail<NT, true>(a, smem, vb, ncb, st_n, st_mean, st_m2);
+  else if (a.epi_mode == 3) conv_table_tail<NT, false>(a, smem, vb, ncb, 0.f, st_mean, st_m2);
 }
 
 template <int KS, int STRIDE, int FETCH, int NT, bool VEC, bool NARROW, bool IN2>

@@ -473,44 +473,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #ifdef MS_CONV_TRACE_BUILD
   if (tr) { a.trace[502] = clock64(); a.trace[503] = (long long)__builtin_amdgcn_s_memrealtime(); }
 #endif
-  if (a.stats != nullptr) {
-    float4* tab = reinterpret_cast<float4*>(a.stats);
-    const int cb0 = vb % ncb;
-    const int slot = (vb / ncb) * 4 + wave;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      // Chan merge of the four lanes (k = 0..3) that hold the same channel: xor 16, then xor 32
-      float n_ = st_n, mu_ = st_mean[j], m2_ = st_m2[j];
-#pragma unroll
-      for (int off = 16; off <= 32; off <<= 1) {
-        const float nb = __shfl_xor(n_, off, 64), mb = __shfl_xor(mu_, off, 64), qb = __shfl_xor(m2_, off, 64);
-        const float nn = n_ + nb;
-        const float w = (nn > 0.f) ? nb / nn : 0.f;
-        const float d = mb - mu_;
-        mu_ += d * w;
-        m2_ += qb + d * d * n_ * w;
-        n_ = nn;
-      }
-      const int co = cb0 * COUT_TILE + j * 16 + m;
-      if (k == 0 && co < a.Cout) tab[1 + (size_t)co * kStatSlots + slot] = make_float4(n_, mu_, m2_, 0.f);
-    }
-    if (vb == 0 && threadIdx.x == 0) tab[0] = make_float4((float)(((int)gridDim.x / ncb) * 4), 0.f, 0.f, 0.f);
-  }
-  if (a.epi_mode == 3) {
-    // same slot numbering as the statistics table: [0] = {slots in use}, then float2 [1 + co*kStatSlots + slot]
-    float2* tab = reinterpret_cast<float2*>(a.mk_tab);
-    const int cb0 = vb % ncb;
-    const int slot = (vb / ncb) * 4 + wave;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      float s1 = st_mean[j], s2 = st_m2[j];
-      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-      const int co = cb0 * COUT_TILE + j * 16 + m;
-      if (k == 0 && co < a.Cout) tab[1 + (size_t)co * kStatSlots + slot] = make_float2(s1, s2);
-    }
-    if (vb == 0 && threadIdx.x == 0) tab[0] = make_float2((float)(((int)gridDim.x / ncb) * 4), 0.f);
-  }
+  if (a.stats != nullptr) conv_table_tail<NT, true>(a, smem, vb, ncb, st_n, st_mean, st_m2);
+  else if (a.epi_mode == 3) conv_table_tail<NT, false>(a, smem, vb, ncb, 0.f, st_mean, st_m2);
 }
 
 template <int NT, int PRO>

@@ -288,6 +288,12 @@ class InnerLoopEngine:
         # activation-backward mask + BatchNorm-backward sums in the epilogue of the data-gradient conv that produces the gradient
         # (ms_conv2d_actbwd) instead of a separate ms_act_bwd_reduce pass over it; MS_FUSE_ACTBWD=0 is the A/B switch
         self.fuse_act_bwd = os.environ.get("MS_FUSE_ACTBWD", "1") != "0"
+        # the LAST workgroup of a conv with a statistics / mask epilogue can reduce the partial table itself (ms_conv2d_fin, ms_conv2d_actbwd_fin)
+        # instead of an ms_bn_finalize / ms_bn_bwd_coefs launch behind it.  Those launches cost ~4 us each in the replayed graph (326.6 vs 304.3
+        # steps/s with all 54 of them skipped as a timing experiment), but the fused tail costs MORE: 260.9 vs 304.2 steps/s with 42 of them fused -
+        # 512 workgroups finish together, so publish -> arrive (one counter word, ~88 arrivals/us) -> reduce by one workgroup is ~13 us of serial
+        # device-scope round trips at the end of every such conv.  Off by default (MS_FUSE_BNFIN=1 turns it on; results are identical).
+        self.fuse_bn_fin = os.environ.get("MS_FUSE_BNFIN", "0") != "0"
         self._side_stream = None
         self._side_pending = False
 
@@ -334,8 +340,16 @@ class InnerLoopEngine:
             self._side_pending = False
 
     # ------------------------------------------------------------------ kernel-call helpers (no allocation after warm-up)
-    def conv(self, name, x, cw: ConvW, cout=None, ks=None, stride=1, fetch=0, act=None, bnbwd=None, epi=0, out=None, stats=False, dgrad=False):
-        """act=(coef4, slope): BN-apply+LeakyReLU prologue; bnbwd=(bcoef4, u): BN-backward prologue. Returns (out, stats, parts)."""
+    def _counter(self, name):
+        c = self.buf.get(name + ".cnt")
+        if c is None:                     # zero once; every launch that uses it re-arms it
+            c = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            self.buf[name + ".cnt"] = c
+        return c
+
+    def conv(self, name, x, cw: ConvW, cout=None, ks=None, stride=1, fetch=0, act=None, bnbwd=None, epi=0, out=None, stats=False, dgrad=False, fin=None):
+        """act=(coef4, slope): BN-apply+LeakyReLU prologue; bnbwd=(bcoef4, u): BN-backward prologue; fin: the BatchNorm (BNW) that follows - with
+        `fuse_bn_fin` its coefficients come out of this launch. Returns (out, stats, parts); stats is ("fused", coef4) when they did."""
         N, Cin, Hs, Ws = x.shape
         wp = cw.dwp if dgrad else cw.wp
         ks = cw.ks if ks is None else ks
@@ -368,6 +382,12 @@ class InnerLoopEngine:
             pa, pb, pc = ops.coef_ptrs(bnbwd[0])
             in2 = bnbwd[1]
         bias = None if dgrad else cw.b
+        if stats and fin is not None and self.fuse_bn_fin and epi == 0 and pm != 3:
+            coef = self.t(name + ".fcoef", cout, 4)
+            check(lib.ms_conv2d_fin(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                    N, Cin, Hs, Ws, cout, ks, stride, fetch, pm, pa, pb, pc, pn, 4, slope, st.data_ptr(), fin.gamma.data_ptr(), fin.beta.data_ptr(),
+                                    BN_EPS, coef.data_ptr(), self._counter(name).data_ptr(), self._st()), "ms_conv2d_fin:" + name)
+            return out, ("fused", coef), parts
         check(lib.ms_conv2d(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
                             N, Cin, Hs, Ws, cout, ks, stride, fetch, pm, pa, pb, pc, pn, 4, slope, epi, 0 if st is None else st.data_ptr(), self._st()),
               "ms_conv2d:" + name)
@@ -381,8 +401,12 @@ class InnerLoopEngine:
                 self.nets.refresh_eval()
             self.buf[name + ".coef"] = bn.coef_eval
             return bn.coef_eval
-        coef = self.t(name + ".coef", bn.gamma.numel(), 4)
-        check(lib.ms_bn_finalize(st.data_ptr(), parts, bn.gamma.data_ptr(), bn.beta.data_ptr(), BN_EPS, coef.data_ptr(), bn.gamma.numel(), self._st()), "ms_bn_finalize:" + name)
+        if isinstance(st, tuple):         # the conv's last workgroup already wrote them (ms_conv2d_fin)
+            coef = st[1]
+            self.buf[name + ".coef"] = coef
+        else:
+            coef = self.t(name + ".coef", bn.gamma.numel(), 4)
+            check(lib.ms_bn_finalize(st.data_ptr(), parts, bn.gamma.data_ptr(), bn.beta.data_ptr(), BN_EPS, coef.data_ptr(), bn.gamma.numel(), self._st()), "ms_bn_finalize:" + name)
         if self.bn_observer is not None:
             self.bn_observer(bn, coef)
         return coef
@@ -443,8 +467,18 @@ class InnerLoopEngine:
         if not self.fuse_act_bwd or isinstance(bnbwd[0], tuple):
             da, _, _ = self.conv(name, g, cw, bnbwd=bnbwd, dgrad=True)
             return self.act_bwd(bw_name, da, None, u, coef, slope)
-        out, tab = self.conv_actbwd(name, bw_name, g, cw, bnbwd, u, coef, slope)
         N, C, H, W = u.shape
+        if self.fuse_bn_fin and not self.bn_eval:
+            Ng, Cin, Hs, Ws = g.shape
+            out = self.t(name, Ng, cw.cin, Hs, Ws)
+            tab = self.t(bw_name + ".tab", lib.ms_conv_actbwd_tab_bytes(cw.cin) // 4)
+            bc = self.t(bw_name + ".bcoef", C, 4)
+            pa, pb, pc = ops.coef_ptrs(bnbwd[0])
+            check(lib.ms_conv2d_actbwd_fin(g.data_ptr(), bnbwd[1].data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), Ng, Cin, Hs, Ws, cw.cin, cw.ks, 1, 0,
+                                           2, pa, pb, pc, 0, 4, 1.0, u.data_ptr(), coef.data_ptr(), slope, tab.data_ptr(), float(N * H * W), bc.data_ptr(),
+                                           self._counter(bw_name).data_ptr(), self._st()), "ms_conv2d_actbwd_fin:" + name)
+            return out, bc
+        out, tab = self.conv_actbwd(name, bw_name, g, cw, bnbwd, u, coef, slope)
         if self.bn_eval:
             bc = self.buf.get(bw_name + ".bcoef_eval")
             if bc is None:
@@ -481,9 +515,9 @@ class InnerLoopEngine:
                 s, _, _ = self.conv(pfx + ".s", x, ci)          # conv1x1 commutes with nearest up-sampling: low resolution
             else:
                 s, _, _ = self.conv(pfx + ".s", src, ci)
-        u1, st1, p1 = self.conv(pfx + ".u1", src, c0, fetch=fetch, stats=True)
+        u1, st1, p1 = self.conv(pfx + ".u1", src, c0, fetch=fetch, stats=True, fin=net[key + ".bn1"])
         cf1 = self.bn_fin(pfx + ".bn1", st1, p1, net[key + ".bn1"])
-        u2, st2, p2 = self.conv(pfx + ".u2", u1, c3, act=(cf1, LEAKY), stats=True)
+        u2, st2, p2 = self.conv(pfx + ".u2", u1, c3, act=(cf1, LEAKY), stats=True, fin=net[key + ".bn4"])
         cf2 = self.bn_fin(pfx + ".bn4", st2, p2, net[key + ".bn4"])
         self._join_side()
         out = self.bn_act(pfx + ".out", u2, cf2, s, 2 if kind == "nn" else 1, LEAKY)
@@ -520,19 +554,19 @@ class InnerLoopEngine:
     def encode_fwd(self, image):
         """MyEncoder.forward + code_decoupler (encoder_decoder.py:469-482, 673-680) in BN batch-stat mode."""
         e = self.nets.enc
-        ua, st, p = self.conv("e.inc.ua", image, e["inc0"], stats=True)
+        ua, st, p = self.conv("e.inc.ua", image, e["inc0"], stats=True, fin=e["inc1"])
         cfa = self.bn_fin("e.inc.bn1", st, p, e["inc1"])
-        ub, st, p = self.conv("e.inc.ub", ua, e["inc3"], act=(cfa, LEAKY), stats=True)
+        ub, st, p = self.conv("e.inc.ub", ua, e["inc3"], act=(cfa, LEAKY), stats=True, fin=e["inc4"])
         cfb = self.bn_fin("e.inc.bn4", st, p, e["inc4"])
         h = self.bn_act("e.inc.out", ub, cfb, None, 0, LEAKY)
         for i in range(1, 5):
             h = self.res_fwd(f"e.d{i}", e, f"d{i}", h, "down")
-        uf, st, p = self.conv("e.fc.u", h, e["fc0"], stats=True)
+        uf, st, p = self.conv("e.fc.u", h, e["fc0"], stats=True, fin=e["fc1"])
         cff = self.bn_fin("e.fc.bn", st, p, e["fc1"])
         z_i = self.bn_act("e.z_i", uf, cff, None, 0, 0.0)
-        u1, st, p = self.conv("e.cd.u1", z_i, e["cd0"], stats=True)
+        u1, st, p = self.conv("e.cd.u1", z_i, e["cd0"], stats=True, fin=e["cd1"])
         cf1 = self.bn_fin("e.cd.bn1", st, p, e["cd1"])
-        u2, st, p = self.conv("e.cd.u2", u1, e["cd3"], act=(cf1, LEAKY), stats=True)
+        u2, st, p = self.conv("e.cd.u2", u1, e["cd3"], act=(cf1, LEAKY), stats=True, fin=e["cd4"])
         cf2 = self.bn_fin("e.cd.bn4", st, p, e["cd4"])
         z_s = self.bn_act("e.z_s", u2, cf2, None, 0, 0.0)
         return z_i, z_s

@@ -265,3 +265,41 @@ def test_conv_actbwd_epilogue(dev, N, Cin, Cout, H, W, ks):
         be = -cc[:, 0] * (s2 * cc[:, 3] / cnt) * cc[:, 3]
         ref_bc = torch.stack([cc[:, 0], be, -cc[:, 0] * s1 / cnt - be * cc[:, 2]], 1)
         assert rel(bc_f[:, :3], ref_bc) < 1e-4
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,ks,stride", [
+    (2, 16, 16, 64, 64, 3, 1), (1, 32, 48, 20, 192, 3, 1), (2, 64, 64, 64, 64, 3, 1), (1, 8, 33, 7, 100, 3, 1),      # wide-read kernel
+    (2, 16, 16, 32, 32, 3, 1), (4, 128, 128, 8, 8, 3, 1), (1, 20, 24, 9, 70, 3, 1), (2, 24, 40, 6, 10, 3, 1),        # first-generation kernel
+    (2, 32, 16, 12, 20, 1, 1), (2, 16, 32, 32, 32, 3, 2), (16, 16, 16, 128, 128, 3, 1),                               # 1x1, stride 2, a full grid (512 workgroups)
+])
+def test_last_workgroup_finalises(dev, N, Cin, Cout, H, W, ks, stride):
+    """ms_conv2d_fin / ms_conv2d_actbwd_fin: the coefficients written by the last workgroup equal ms_bn_finalize / ms_bn_bwd_coefs on the same
+    table; the counter re-arms itself (three launches in a row), the tensors are bit-identical to the unfused launches."""
+    from maxstyle_amd import ops
+    x = _rand((N, Cin, H, W), 31); w = _rand((Cout, Cin, ks, ks), 32, 0.1); b = _rand((Cout,), 33)
+    gamma = (1 + 0.1 * _rand((Cout,), 34)).to(dev); beta = (0.1 * _rand((Cout,), 35)).to(dev)
+    wp = ops.pack_conv_weight(w.to(dev))
+    Ho, Wo = ops.conv_out_hw(H, W, ks, stride, 0)
+    stats, parts = ops.conv_stats_buffer(N, Cout, Ho, Wo, dev)
+    ref_out = ops.conv2d(x.to(dev), wp, b.to(dev), Cout, ks, stride, stats=stats)
+    ref_coef = ops.bn_finalize(stats, parts, gamma, beta)
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    for _ in range(3):
+        out, coef = ops.conv2d_fin(x.to(dev), wp, b.to(dev), Cout, ks, gamma, beta, counter, stride=stride)
+        assert torch.equal(out, ref_out)
+        assert rel(coef, ref_coef) < 1e-6, float((coef - ref_coef).abs().max())
+        assert int(counter) == 0
+    # against fp64 math
+    y = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=ks // 2)
+    mean = y.mean((0, 2, 3)); invstd = 1 / torch.sqrt(y.var((0, 2, 3), unbiased=False) + 1e-5)
+    assert rel(coef[:, 2], mean) < 1e-5 and rel(coef[:, 3], invstd) < 1e-5
+    if stride == 1:
+        g = _rand((N, Cin, H, W), 36); u = _rand((N, Cout, H, W), 37) + 0.3
+        fc = torch.stack([1 + 0.2 * _rand((Cout,), 38), 0.3 * _rand((Cout,), 39), 0.3 + 0.1 * _rand((Cout,), 40), 1 + 0.1 * _rand((Cout,), 41).abs()], 1).to(dev)
+        gm, tab = ops.conv2d_actbwd(g.to(dev), wp, Cout, ks, u.to(dev), fc, 0.2)
+        ref_bc = ops.bn_bwd_coefs(tab, 0, fc, N * H * W)
+        for _ in range(3):
+            gm2, bc = ops.conv2d_actbwd_fin(g.to(dev), wp, Cout, ks, u.to(dev), fc, 0.2, counter)
+            assert torch.equal(gm2, gm)
+            assert float((bc - ref_bc).abs().max()) <= 1e-6 * float(ref_bc.abs().max()), float((bc - ref_bc).abs().max())
+            assert int(counter) == 0
