@@ -359,7 +359,8 @@ extern "C" int ms_style_fwd(const float* x, float* y, float* mu, float* sig, flo
   // single-read kernel when the shape is eligible (MS_STYLE_FUSED=0 forces the three-kernel path, for A/B timing)
   static const bool fused_on = !(getenv("MS_STYLE_FUSED") != nullptr && atoi(getenv("MS_STYLE_FUSED")) == 0);
   // below ~32 MB the tensor sits in L2/Infinity Cache and the three short launches beat the ticketed persistent kernel (measured)
-  const bool big = (size_t)B * C * HW * sizeof(float) >= ((size_t)32 << 20);
+  static const size_t min_mb = getenv("MS_STYLE_FUSED_MIN_MB") ? (size_t)atoi(getenv("MS_STYLE_FUSED_MIN_MB")) : 32;      // A/B switch for timing
+  const bool big = (size_t)B * C * HW * sizeof(float) >= (min_mb << 20);
   const size_t fb = (fused_on && big) ? ms_style_fused_ws_bytes(B, C, HW) : 0;
   const size_t off = style_scratch_bytes(B, C, HW);
   if (fb != 0 && ws != nullptr && ws_bytes >= off + fb && aligned16(ws) && aligned16(x) && aligned16(y))
