@@ -100,7 +100,7 @@ int ms_counter_incr(int* counter, void* stream);
  *               (pro_cstride >= 4), pro_c = NULL or an output [Cin][4] that receives the coefficients; count = N*Hs*Ws
  *   epi_mode  0 out = acc + bias | 1 out += acc + bias | 2 ConvTranspose2d(k=2,s=2) pixel-shuffle store:
  *             GEMM column (dy*2+dx)*Cout+co -> out[n,co,2y+dy,2x+dx] (needs ks=1)
- *   stats     NULL or a table of ms_conv_stats_bytes() bytes receiving per-wave running (count, mean, M2, 0) of the outputs
+ *   stats     NULL or a table of ms_conv_stats_bytes() bytes receiving per-workgroup running (count, mean, M2, 0) of the outputs
  *             (float4 header {slots used} + float4[Cout][ms_conv_stats_parts()]) for ms_bn_finalize (BatchNorm batch statistics;
  *             model_util.py:468-510). */
 size_t ms_conv_stats_bytes(int N, int Cout, int Hout, int Wout);

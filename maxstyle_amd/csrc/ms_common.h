@@ -17,7 +17,7 @@ namespace ms {
 
 constexpr int kWave = 64;
 constexpr int kNumCU = 256;      // MI355X: 8 XCDs x 32 CUs
-constexpr int kStatSlots = kNumCU * 2 * 4;   // per-channel capacity of the conv kernels' partial tables: one slot per consumer wave of a resident workgroup
+constexpr int kStatSlots = kNumCU * 2 * 4;   // per-channel capacity (row stride) of the conv kernels' partial tables; one slot per workgroup of the channel block is used
 
 // last error string (thread-local; the ABI itself never throws)
 void set_error(const char* fmt, ...);
