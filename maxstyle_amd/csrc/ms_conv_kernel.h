@@ -31,9 +31,9 @@ struct ConvArgs {
   int N, Cin, Hs, Ws, Hin, Win, Cout, Hout, Wout, cin_pad, cout_pad;
   int pro_mode, pro_nstride, pro_cstride; float slope;
   int epi_mode, tiles_x, tiles_y, cout_real, ncb;   // ncb: number of output-channel blocks (of 16*NT)
-  int dbg;                      // timing-only ablation bits (MS_CONV_DBG): 1 skip MFMA loop, 2 skip global loads, 4 skip epilogue
+  int dbg;                      // timing-only ablation bits (MS_CONV_DBG): 1 skip MFMA loop, 2 skip global loads, 4 skip epilogue stores, 8 skip LDS stores, 16 skip the epilogue
   int bw_parts; double bw_count; float* bw_out;   // pro_mode 3 (host side): BatchNorm-backward coefficients are derived in-kernel from bw_parts partial sums per channel
-  long long* trace;             // MS_CONV_TRACE_BUILD only: cycle stamps of workgroup 0 (tools/dbg_convtrace.py)
+  long long* trace;             // MS_CONV_TRACE_BUILD only: cycle stamps of workgroup 0 (tools/trace_conv.py)
   // epi_mode 3 (ms_conv2d_actbwd): the output is the gradient w.r.t. an activation lrelu(sc*u + sh) that was never materialised; the epilogue
   // applies its derivative and accumulates the BatchNorm-backward sums (sum g, sum g*(u - mean)) of u's layer: what ms_act_bwd_reduce does in its own pass
   const float* mk_u; const float* mk_coef; float mk_slope; float* mk_tab;   // u [N,Cout,Hout,Wout]; coef float4 [Cout] {sc,sh,mean,invstd}; tab float2 [1 + Cout*kStatSlots]
