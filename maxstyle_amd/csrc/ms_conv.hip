@@ -33,23 +33,24 @@ namespace ms {
 //   out[c] = {scale = gamma*invstd, shift = beta - mean*scale, mean, invstd}      (biased variance, eps)
 // model_util.py:468-510 mode: batch statistics, running buffers untouched.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float4* __restrict__ tab, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps, float4* __restrict__ out) {
-  // two parallel passes in fp64 (no per-partial divisions): mean = sum n_i m_i / sum n_i ; M2 = sum M2_i + n_i (m_i - mean)^2
-  __shared__ double redd[16];
+// One WAVE per channel, one pass: the table holds one slot per workgroup of the conv (<= 512), so 64 lanes x 8 slots with shuffle reductions beat
+// a 256-thread block with two passes and three LDS reductions (this kernel sits on the ~4 us latency floor of a dependent launch, 23 times per step).
+// M2 = sum M2_i + sum n_i m_i^2 - (sum n_i m_i)^2 / N in fp64: the inputs are fp32, so the cancellation costs (mean/sigma)^2 * 1e-16.
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float4* __restrict__ tab, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, float4* __restrict__ out) {
   const int c = blockIdx.x;
   const int nparts = (int)tab[0].x;
   const float4* part = tab + 1 + (size_t)c * kStatSlots;
-  double sn = 0.0, sm = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += 256) { const float4 q = part[i]; sn += (double)q.x; sm += (double)q.x * (double)q.y; }
-  sn = block_sum_d(sn, redd);
-  sm = block_sum_d(sm, redd);
-  const double mean = sm / sn;
-  double sq = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += 256) { const float4 q = part[i]; const double d = (double)q.y - mean; sq += (double)q.z + (double)q.x * d * d; }
-  sq = block_sum_d(sq, redd);
+  double sn = 0.0, sm = 0.0, sq = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 64) {
+    const float4 q = part[i];
+    const double n = (double)q.x, mu = (double)q.y;
+    sn += n; sm += n * mu; sq += (double)q.z + n * mu * mu;
+  }
+  sn = wave_sum_d(sn); sm = wave_sum_d(sm); sq = wave_sum_d(sq);
   if (threadIdx.x == 0) {
-    const double var = sq / sn;
+    const double mean = sm / sn;
+    const double var = fmax((sq - sm * mean) / sn, 0.0);
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * invstd;
     out[c] = make_float4(sc, beta[c] - (float)mean * sc, (float)mean, invstd);
@@ -206,6 +207,6 @@ extern "C" int ms_conv2d_actbwd_fin(const float* in, const float* in2, float* ou
 
 extern "C" int ms_bn_finalize(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, int C, void* stream) {
   if (C < 1 || nparts != kStatSlots) { set_error("ms_bn_finalize: invalid shape (nparts must be ms_conv_stats_parts())"); return MS_ERR_INVALID; }
-  MS_LAUNCH(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float4*)stats, gamma, beta, eps, (float4*)coef4);
+  MS_LAUNCH(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float4*)stats, gamma, beta, eps, (float4*)coef4);
   return check_launch("bn_finalize");
 }

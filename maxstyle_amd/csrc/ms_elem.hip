@@ -140,17 +140,17 @@ __global__ __launch_bounds__(kElemThreads) void act_bwd_reduce_kernel(const floa
 }
 
 // BatchNorm backward coefficients: du = sc*(g - mean(g) - uhat*mean(g*uhat)) = al*g + be*u + de
-__global__ __launch_bounds__(256) void bn_bwd_coefs_kernel(const float2* __restrict__ part, int nparts, const float4* __restrict__ coef, double count,
-                                                           float4* __restrict__ out) {
-  __shared__ double redd[16];
+__global__ __launch_bounds__(64) void bn_bwd_coefs_kernel(const float2* __restrict__ part, int nparts, const float4* __restrict__ coef, double count,
+                                                          float4* __restrict__ out) {
+  // one wave per channel, shuffle reductions (a latency-floor kernel: see bn_finalize_kernel)
   const int c = blockIdx.x;
   // nparts == 0: `part` is the table of ms_conv2d_actbwd - [0] = {slots in use}, rows of kStatSlots from [1]
   const float2* row = (nparts == 0) ? part + 1 + (size_t)c * kStatSlots : part + (size_t)c * nparts;
   if (nparts == 0) nparts = (int)part[0].x;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += 256) { const float2 q = row[i]; s1 += (double)q.x; s2 += (double)q.y; }
-  s1 = block_sum_d(s1, redd);
-  s2 = block_sum_d(s2, redd);
+  for (int i = threadIdx.x; i < nparts; i += 64) { const float2 q = row[i]; s1 += (double)q.x; s2 += (double)q.y; }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
   if (threadIdx.x == 0) {
     const float4 cf = coef[c];           // {sc, sh, mean, invstd}
     const double mean = cf.z, invstd = cf.w, sc = cf.x;
@@ -395,7 +395,7 @@ extern "C" int ms_act_bwd_bn(const float* gin, const float* ref, const float* u,
 
 extern "C" int ms_bn_bwd_coefs(const float* part2, int nparts, const float* coef4, double count, float* coef_out4, int C, void* stream) {
   if (C < 1 || nparts < 0 || count <= 0) { set_error("ms_bn_bwd_coefs: invalid argument"); return MS_ERR_INVALID; }
-  MS_LAUNCH(bn_bwd_coefs_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float2*)part2, nparts, (const float4*)coef4, count, (float4*)coef_out4);
+  MS_LAUNCH(bn_bwd_coefs_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float2*)part2, nparts, (const float4*)coef4, count, (float4*)coef_out4);
   return check_launch("bn_bwd_coefs");
 }
 
