@@ -353,3 +353,37 @@ def test_training_pass_full_size_vs_oracle(dev):
                 worst = (key, err)
             assert err < 1e-2, (key, err)
     print("worst gradient error at full size", worst)
+
+
+def test_trainer_loop_soak(dev):
+    """The trainer's loop body (standard pass -> K=5 MaxStyle loop under the captured HIP graph -> hard-example pass -> backward -> AdamW) for 40
+    iterations at 8x1x128x128: every loss finite, the training loss goes down, every parameter and running statistic finite at the end.  (The
+    cross-workgroup hand-offs of the single-read MaxStyle kernel and of the partial tables only showed their first bug after ~10 iterations.)"""
+    import maxstyle_amd as M
+    from maxstyle_amd import synthetic as syn
+    torch.manual_seed(0)
+    S = M.AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard_no_STN", image_ch=1, num_classes=4, use_gpu=True, optimizer_type="AdamW")
+    clean, lab = syn.synthetic_batch(8, 128, 1, 4, 4321)
+    clean, lab = clean.to(dev), lab.to(dev)
+    cfg = {"mix_style": True, "no_noise": False, "lr": 0.1, "n_iter": 5, "mix_learnable": True, "noise_learnable": True,
+           "decoder_layers_indexes": [3, 4, 5], "loss_types": ["seg"], "loss_weights": [1], "always_use_beta": False}
+    losses = []
+    for it in range(40):
+        S.train()
+        S.reset_all_optimizers()
+        image_l = torch.clamp(clean + 0.05 * torch.randn_like(clean), clean.min(), clean.max())
+        seg0, rec0, gt0, sh0, _, _, _ = S.standard_training(clean, lab, perturbed_image=image_l, return_output=True)
+        S.reset_all_optimizers()
+        sty = S.generate_max_style_image_from_config(S.z_i, cfg, clean, lab, p=1.5).detach().clone()
+        assert bool(torch.isfinite(sty).all()), it
+        seg1, rec1, sh1, sh2 = S.hard_example_traininng(perturbed_image=sty, perturbed_seg=None, clean_image_l=clean, label_l=lab)
+        loss = (seg0 + rec0 + sh0 + gt0) + (rec1 + seg1 + sh1 + sh2)
+        S.reset_all_optimizers()
+        loss.backward()
+        S.optimize_all_params()
+        losses.append(float(loss.detach()))
+        assert np.isfinite(losses[-1]), (it, losses)
+    assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), losses
+    for m in S.model.values():
+        for t in list(m.parameters()) + list(m.buffers()):
+            assert bool(torch.isfinite(t).all())
