@@ -434,7 +434,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             seg_loss, rec_loss = _TrainPassFn.apply(self._anchor, self, eng, x, labels, clean, track, bns)
         else:                                   # torch.no_grad(): values only - the engine's activations are not held for a backward
             eng.bn_affine_grad = track
-            eng.forward_pass(x, labels, clean, track, bns)
+            eng.run_forward(x, labels, clean, track, bns)
             vals = eng.loss_buf[:2].clone()
             seg_loss, rec_loss = vals[0], vals[1]
         z_i, z_s = eng.buf["e.z_i"], eng.buf["e.z_s"]
@@ -475,10 +475,9 @@ class _TrainPassFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, solver, eng, x, labels, clean, track, bns):
         eng.bn_affine_grad = track          # _disable_tracking_bn_stats also freezes the BatchNorm affine (model_util.py:468-510)
-        eng.forward_pass(x, labels, clean, track, bns)
+        eng.run_forward(x, labels, clean, track, bns)
         eng.pending = True
         ctx.solver, ctx.eng = solver, eng
-        ctx.args = (x, labels, clean)
         out = eng.loss_buf[:2].clone()
         return out[0], out[1]
 
@@ -487,11 +486,10 @@ class _TrainPassFn(torch.autograd.Function):
         eng, solver = ctx.eng, ctx.solver
         if not eng.pending:
             raise RuntimeError("the activations of this training pass were already consumed by a backward")
-        x, labels, clean = ctx.args
         gs = 0.0 if g_seg is None else float(g_seg)
         gr = 0.0 if g_rec is None else float(g_rec)
         eng.bank = solver._param_bank()
-        eng.backward_pass(x, labels, clean, gs, gr)
+        eng.run_backward(gs, gr)
         eng.pending = False
         return torch.zeros_like(solver._anchor), None, None, None, None, None, None, None
 

@@ -355,12 +355,14 @@ def test_training_pass_full_size_vs_oracle(dev):
     print("worst gradient error at full size", worst)
 
 
-def test_trainer_loop_soak(dev):
-    """The trainer's loop body (standard pass -> K=5 MaxStyle loop under the captured HIP graph -> hard-example pass -> backward -> AdamW) for 40
+@pytest.mark.parametrize("graph_passes", ["0", "1"], ids=["eager_passes", "graph_passes"])
+def test_trainer_loop_soak(dev, graph_passes, monkeypatch):
+    """(graph_passes: the training passes themselves replayed as HIP graphs, MS_TRAIN_GRAPH=1.)  The trainer's loop body (standard pass -> K=5 MaxStyle loop under the captured HIP graph -> hard-example pass -> backward -> AdamW) for 40
     iterations at 8x1x128x128: every loss finite, the training loss goes down, every parameter and running statistic finite at the end.  (The
     cross-workgroup hand-offs of the single-read MaxStyle kernel and of the partial tables only showed their first bug after ~10 iterations.)"""
     import maxstyle_amd as M
     from maxstyle_amd import synthetic as syn
+    monkeypatch.setenv("MS_TRAIN_GRAPH", graph_passes)
     torch.manual_seed(0)
     S = M.AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard_no_STN", image_ch=1, num_classes=4, use_gpu=True, optimizer_type="AdamW")
     clean, lab = syn.synthetic_batch(8, 128, 1, 4, 4321)
