@@ -5,7 +5,7 @@ bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool v
   static const bool off = getenv("MS_CONV_WIDE") != nullptr && atoi(getenv("MS_CONV_WIDE")) == 0;      // A/B switch for timing
   if (off) return false;
   if (ks != 3 || stride != 1 || fetch != FETCH_NORMAL || !vec) return false;
-  if (a.epi_mode == 2 || (a.pro_mode != 0 && a.pro_nstride != 0)) return false;
+  if (a.epi_mode == 2 || (a.pro_mode != 0 && a.pro_nstride != 0) || a.bw_parts > 0) return false;      // (pro_mode 3 derives its coefficients in the first-generation kernel only)
   // (the two-tensor BatchNorm-backward prologue runs with 8-channel chunks: twice the staging registers per channel; 70.4 vs 74.2 us on the
   //  first-generation kernel at 16->16 @16x256x256)
   if (a.Wout < 64 || a.Wout % 4 != 0) return false;

@@ -111,10 +111,10 @@ def test_batch_stats_and_prologue(dev, N, C, H, W):
     assert rel(o2, F.relu(z + F.interpolate(res_h.double(), scale_factor=2, mode="nearest"))) < 1e-5
 
 
-def test_bn_backward_chain(dev):
+@pytest.mark.parametrize("N,C,H,W", [(4, 16, 32, 32), (2, 16, 16, 128)], ids=["first_generation", "wide_rows"])
+def test_bn_backward_chain(dev, N, C, H, W):
     """out = lrelu(s + BN(conv(a))): HIP mask+reduce -> coefs -> dgrad with the BN-backward prologue vs autograd (fp64)."""
     from maxstyle_amd import ops
-    N, C, H, W = 4, 16, 32, 32
     a = _rand((N, C, H, W), 1); w = _rand((C, C, 3, 3), 2, 0.15); b = _rand((C,), 3)
     gamma = 1 + 0.1 * _rand((C,), 4); beta = 0.1 * _rand((C,), 5); s = _rand((N, C, H, W), 6); dout = _rand((N, C, H, W), 7)
     ar = a.double().requires_grad_(True)
