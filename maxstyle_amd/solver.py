@@ -379,6 +379,66 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     def reset_optimizer(self, model_name):
         self.optimizers[model_name].zero_grad()
 
+    # ------------------------------------------------------------------ checkpoints (same files and keys as the reference)
+    def save_model(self, save_dir, epoch_iter, model_prefix=None, save_optimizers=False):
+        """advanced_triplet...py:936-948: <save_dir>/<epoch_iter>/checkpoints/<net>.pth (+ <net>_optim.pth), plain state_dicts."""
+        import os
+        epoch_path = os.path.join(save_dir, str(epoch_iter), 'checkpoints')
+        os.makedirs(epoch_path, exist_ok=True)
+        for model_name, model in self.model.items():
+            torch.save(model.state_dict(), os.path.join(epoch_path, '{}.pth'.format(model_name)))
+        if save_optimizers:
+            if self.optimizers is None:
+                self.set_optimizers()
+            for model_name, optimizer in self.optimizers.items():
+                torch.save(optimizer.state_dict(), os.path.join(epoch_path, '{}_optim.pth'.format(model_name)))
+
+    def get_model_states_dict(self):
+        """advanced_triplet...py:950-955."""
+        return {model_name: model.state_dict() for model_name, model in self.model.items()}
+
+    def restore_model(self, model_state_dict):
+        """advanced_triplet...py:957-959 (in-place copies: the flat parameter buffers and captured graphs stay valid)."""
+        for model_name, model_dict in model_state_dict.items():
+            self.model[model_name].load_state_dict(model_dict)
+
+    def save_snapshots(self, save_dir, epoch, model_prefix='interrupted'):
+        """advanced_triplet...py:961-980: one .pkl with network_type / epoch / model_state / optimizer_state."""
+        import os
+        epoch_path = os.path.join(save_dir, 'interrupted', 'checkpoints')
+        os.makedirs(epoch_path, exist_ok=True)
+        model_prefix = self.network_type if model_prefix is None else self.network_type + model_prefix
+        save_path = os.path.join(epoch_path, model_prefix + f'_{epoch}.pkl')
+        if self.optimizers is None:
+            self.set_optimizers()
+        state = {'network_type': self.network_type, 'epoch': epoch, 'model_state': self.get_model_states_dict(),
+                 'optimizer_state': {name: opt.state_dict() for name, opt in self.optimizers.items()}}
+        torch.save(state, save_path)
+        return save_path
+
+    def load_snapshots(self, file_path):
+        """advanced_triplet...py:982-1016: returns the epoch stored in the snapshot (0 when there is nothing to load)."""
+        import os
+        start_epoch = 0
+        if file_path is None:
+            return start_epoch
+        if file_path == '' or not os.path.exists(file_path):
+            print(f'warning: {file_path} does not exists')
+            return start_epoch
+        try:
+            checkpoint = torch.load(file_path, map_location='cpu')
+            if self.optimizers is None:
+                self.set_optimizers()
+            for k, v in self.model.items():
+                v.load_state_dict(checkpoint['model_state'][k])
+            for k, v in self.optimizers.items():
+                v.load_state_dict(checkpoint['optimizer_state'][k])
+            start_epoch = checkpoint['epoch']
+            print("Loaded checkpoint '{}' (epoch {})".format(file_path, checkpoint['epoch']))
+        except Exception as e:          # noqa: BLE001 - the reference reports and carries on
+            print('error: {} in loading {}'.format(e, file_path))
+        return start_epoch
+
     def compute_image_recon_loss(self, input_image, target, rec_loss_type=None):
         """0.5 * MSELoss(reduction='mean') of two device tensors (value only; the differentiable form is part of standard_training)."""
         from . import ops
@@ -507,6 +567,43 @@ class _BankOptimizer:
 
     def zero_grad(self, set_to_none=False):
         self.bank.flat_g[self.begin:self.end].zero_()
+
+    def _params(self):
+        """(offset, numel, shape) of this net's parameters in module.parameters() order - the index space of torch.optim state_dicts."""
+        names = [n for n, _ in self.solver.model[self.net].named_parameters()]
+        return [self.bank.index[(self.net, n)] for n in names]
+
+    def state_dict(self):
+        """Same layout as torch.optim.AdamW / Adam .state_dict() over this sub-net's parameters (what the reference stores in <net>_optim.pth)."""
+        adamw = self.solver.optimizer_type == 'AdamW'
+        state = {}
+        if self.step_count > 0:
+            for i, (o, n, shape) in enumerate(self._params()):
+                state[i] = {'step': torch.tensor(float(self.step_count)), 'exp_avg': self.bank.flat_m[o:o + n].view(shape).clone(),
+                            'exp_avg_sq': self.bank.flat_v[o:o + n].view(shape).clone()}
+        group = {'lr': self.lr, 'betas': (0.9, 0.999), 'eps': 1e-8, 'weight_decay': 1e-2 if adamw else 0.0, 'amsgrad': False, 'maximize': False,
+                 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None, 'params': list(range(len(self._params())))}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd):
+        params = self._params()
+        groups = sd['param_groups']
+        ids = [i for g in groups for i in g['params']]
+        if len(ids) != len(params):
+            raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+        self.lr = float(groups[0].get('lr', self.lr))
+        steps = set()
+        for pos, pid in enumerate(ids):
+            st = sd['state'].get(pid)
+            o, n, shape = params[pos]
+            if st is None:
+                self.bank.flat_m[o:o + n].zero_(); self.bank.flat_v[o:o + n].zero_()
+                continue
+            self.bank.flat_m[o:o + n].copy_(st['exp_avg'].reshape(-1)); self.bank.flat_v[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+            steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise NotImplementedError("per-parameter step counts")
+        self.step_count = steps.pop() if steps else 0
 
     def step(self):
         from ._lib import lib, check

@@ -389,3 +389,66 @@ def test_trainer_loop_soak(dev, graph_passes, monkeypatch):
     for m in S.model.values():
         for t in list(m.parameters()) + list(m.buffers()):
             assert bool(torch.isfinite(t).all())
+
+
+def test_checkpoints_round_trip_and_torch_optimizer_compat(dev, tmp_path):
+    """save_model / save_snapshots / load_snapshots / get_network(checkpoint_dir) use the reference's files and keys (advanced_triplet...py:936-1016):
+    an interrupted run resumed from a snapshot ends bit-identical to the uninterrupted one; <net>_optim.pth is a torch.optim.AdamW state_dict (loads
+    into a real AdamW, and a real AdamW's state loads back and gives the same next step)."""
+    import maxstyle_amd as M
+    from maxstyle_amd import synthetic as syn
+    clean, lab = syn.synthetic_batch(4, 64, 1, 4, 99)
+    clean, lab = clean.to(dev), lab.to(dev)
+
+    def make():
+        torch.manual_seed(5)
+        return M.AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard_no_STN", image_ch=1, num_classes=4, use_gpu=True, optimizer_type="AdamW")
+
+    def iterate(S, n):
+        for _ in range(n):
+            S.train(); S.reset_all_optimizers()
+            seg, rec, _, _ = S.standard_training(clean, lab, perturbed_image=clean)
+            (seg + rec).backward()
+            S.optimize_all_params()
+
+    A = make(); iterate(A, 4)
+    B = make(); iterate(B, 2)
+    snap = B.save_snapshots(str(tmp_path), epoch=7)
+    B.save_model(str(tmp_path), 7, save_optimizers=True)
+    C = make()
+    for m in C.model.values():                     # scramble: everything must come from the snapshot
+        for p in m.parameters():
+            p.data.add_(1.0)
+    assert C.load_snapshots(snap) == 7
+    iterate(C, 2)
+    for k in A.model:
+        for (n, a), (_, c) in zip(A.model[k].state_dict().items(), C.model[k].state_dict().items()):
+            assert torch.equal(a, c), (k, n)
+    # per-net .pth files: reference layout, loadable through get_network(checkpoint_dir)
+    ckpt = os.path.join(str(tmp_path), "7", "checkpoints")
+    assert sorted(os.listdir(ckpt)) == sorted([f"{k}.pth" for k in B.model] + [f"{k}_optim.pth" for k in B.model])
+    D = M.AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard_no_STN", image_ch=1, num_classes=4, use_gpu=True, checkpoint_dir=ckpt)
+    for k in B.model:
+        for (n, b), (_, d) in zip(B.model[k].state_dict().items(), D.model[k].state_dict().items()):
+            assert torch.equal(b, d), (k, n)
+    # optimiser state <-> torch.optim.AdamW
+    net = "segmentation_decoder"
+    sd = torch.load(os.path.join(ckpt, f"{net}_optim.pth"))
+    ref_params = [p.detach().clone().requires_grad_(True) for p in B.model[net].parameters()]
+    opt = torch.optim.AdamW(ref_params, lr=B.learning_rate, weight_decay=1e-2)
+    opt.load_state_dict(sd)                        # a real AdamW accepts it
+    # one more identical step on both sides from identical gradients
+    B.train(); B.reset_all_optimizers()
+    seg, rec, _, _ = B.standard_training(clean, lab, perturbed_image=clean)
+    (seg + rec).backward()
+    for rp, p in zip(ref_params, B.model[net].parameters()):
+        rp.grad = p.grad.detach().clone()
+    B.optimize_params(net)
+    opt.step()
+    for rp, p in zip(ref_params, B.model[net].parameters()):
+        assert rel(p, rp) < 2e-6
+    # and back: torch's state into the flat optimiser
+    B.optimizers[net].load_state_dict(opt.state_dict())
+    assert B.optimizers[net].step_count == 3
+    o, n, shape = B.optimizers[net]._params()[0]
+    assert rel(B._bank.flat_m[o:o + n].view(shape), opt.state_dict()["state"][0]["exp_avg"]) < 1e-7
