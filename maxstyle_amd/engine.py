@@ -296,6 +296,9 @@ class InnerLoopEngine:
         self.fuse_bn_fin = os.environ.get("MS_FUSE_BNFIN", "0") != "0"
         self._side_stream = None
         self._side_pending = False
+        # MixStyle / DSU layers inside the encoder (generate_style_augmented_latent_code, advanced_triplet...py:632-670):
+        # {index 1..6: (perm | None, lmda | None, gaussian_std | None, gaussian_mu | None, eps)}; None = plain encoder
+        self.enc_mix = None
 
     # ------------------------------------------------------------------ buffers
     def t(self, name, *shape, dtype=F32):
@@ -550,6 +553,34 @@ class InnerLoopEngine:
             dx, _, _ = self.conv(pfx + ".dx", dsrc, net[key + ".down"], ks=3, stride=1, fetch=ops.FETCH_ZINS2, dgrad=True)
         return dx
 
+    # ------------------------------------------------------------------ MixStyle layers between the encoder blocks
+    def _mix(self, idx, h):
+        m = None if self.enc_mix is None else self.enc_mix.get(idx)
+        if m is None:
+            return h
+        perm, lmda, gstd, gmu, eps = m
+        C = h.shape[1]
+        gs, bs = self.t(f"e.mix{idx}.gs", 1, C, 1, 1), self.t(f"e.mix{idx}.bs", 1, C, 1, 1)
+        # flag bit 1: lmda is not clamped (MixStyle extrapolates); bit 0: batch std recomputed on every call (DSU)
+        y, mu, sig, cA, _ = ops.style_fwd(h, perm, lmda, gstd, gmu, gs, bs, 2 | (1 if gstd is not None else 0), eps)
+        self.buf[f"e.mix{idx}.y"] = y
+        self.buf[f"e.mix{idx}.st"] = (mu, sig, cA)
+        return y
+
+    def _mixed(self, idx, name):
+        """The tensor the layer after mix point `idx` consumed (the un-mixed buffer `name` when no MixStyle layer sits there)."""
+        if self.enc_mix is not None and idx in self.enc_mix:
+            return self.buf[f"e.mix{idx}.y"]
+        return self.buf[name]
+
+    def _mix_bwd(self, idx, dy, x):
+        """mu / sig are detached in MixStyle: dx = dy * A / sig per plane."""
+        if self.enc_mix is None or idx not in self.enc_mix:
+            return dy
+        mu, sig, cA = self.buf[f"e.mix{idx}.st"]
+        dx, _, _, _ = ops.style_bwd(dy.contiguous(), x, mu, sig, cA, None, None, None, None, True, False, False)
+        return dx
+
     # ------------------------------------------------------------------ encoder + segmentation decoder + loss
     def encode_fwd(self, image):
         """MyEncoder.forward + code_decoupler (encoder_decoder.py:469-482, 673-680) in BN batch-stat mode."""
@@ -558,12 +589,12 @@ class InnerLoopEngine:
         cfa = self.bn_fin("e.inc.bn1", st, p, e["inc1"])
         ub, st, p = self.conv("e.inc.ub", ua, e["inc3"], act=(cfa, LEAKY), stats=True, fin=e["inc4"])
         cfb = self.bn_fin("e.inc.bn4", st, p, e["inc4"])
-        h = self.bn_act("e.inc.out", ub, cfb, None, 0, LEAKY)
+        h = self._mix(1, self.bn_act("e.inc.out", ub, cfb, None, 0, LEAKY))
         for i in range(1, 5):
-            h = self.res_fwd(f"e.d{i}", e, f"d{i}", h, "down")
+            h = self._mix(i + 1, self.res_fwd(f"e.d{i}", e, f"d{i}", h, "down"))
         uf, st, p = self.conv("e.fc.u", h, e["fc0"], stats=True, fin=e["fc1"])
         cff = self.bn_fin("e.fc.bn", st, p, e["fc1"])
-        z_i = self.bn_act("e.z_i", uf, cff, None, 0, 0.0)
+        z_i = self._mix(6, self.bn_act("e.z_i", uf, cff, None, 0, 0.0))
         u1, st, p = self.conv("e.cd.u1", z_i, e["cd0"], stats=True, fin=e["cd1"])
         cf1 = self.bn_fin("e.cd.bn1", st, p, e["cd1"])
         u2, st, p = self.conv("e.cd.u2", u1, e["cd3"], act=(cf1, LEAKY), stats=True, fin=e["cd4"])

@@ -469,7 +469,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         return (z_i, z_s), y_0
 
     def standard_training(self, clean_image_l, label_l, perturbed_image, compute_gt_recon=True, update_latent=True, if_latent_code_consistency=False,
-                          disable_track_bn_stats=False, domain_id=0, return_output=False):
+                          disable_track_bn_stats=False, domain_id=0, return_output=False, _enc_mix=None):
         """advanced_triplet...py:731-786 for 'no_STN' networks: seg loss = cross_entropy_2D(seg_decoder(z_s), labels), image recon loss =
         0.5*MSE(image_decoder(z_i), clean).  The two losses carry a grad_fn: `(a*seg + b*rec).backward()` runs the HIP backward pass and
         accumulates into the parameters' .grad.  recon_image / y_0 (return_output=True) and z_i / z_s are detached values."""
@@ -484,6 +484,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             raise RuntimeError("standard_training runs on the MI355X only (HIP kernels); got a CPU tensor")
         B, _, H, W = x.shape
         eng = self._train_engine(B, H, W, x.device)
+        eng.enc_mix = _enc_mix                  # MixStyle / DSU layers inside the encoder (mixstyle_training); None for the plain passes
         labels = label_l.detach().to(device=x.device, dtype=torch.int64).contiguous()
         clean = clean_image_l.detach().contiguous().float()
         track = not disable_track_bn_stats
@@ -497,7 +498,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             eng.run_forward(x, labels, clean, track, bns)
             vals = eng.loss_buf[:2].clone()
             seg_loss, rec_loss = vals[0], vals[1]
-        z_i, z_s = eng.buf["e.z_i"], eng.buf["e.z_s"]
+        z_i, z_s = eng._mixed(6, "e.z_i"), eng.buf["e.z_s"]
         if update_latent:
             self.z_i = z_i.clone()
             self.z_s = z_s.clone()
@@ -522,6 +523,68 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             seg_loss, recon_loss, _, shape_loss = self.standard_training(clean_image_l=clean_image_l, label_l=label_l, perturbed_image=perturbed_image,
                                                                          compute_gt_recon=False, update_latent=False, disable_track_bn_stats=True, domain_id=0)
         return seg_loss, recon_loss, shape_loss, 0 * seg_loss
+
+    # ------------------------------------------------------------------ MixStyle / DSU baselines inside the encoder
+    def _draw_encoder_mixstyle(self, B, layers_indexes, lmda, mix, p, device, alpha=0.1, eps=1e-8):
+        """The random draws of ONE MixStyle(p, alpha=0.1, lmda, mix) object called after inc (1), down1..down4 (2..5) and the final activation (6), in
+        the reference's order (mixstyle.py:57-108: torch.rand(1) gate, Beta / constant lmda, then randperm or the two DSU normals on the device)."""
+        r = self.reduce_factor
+        chans = {1: 64 // r, 2: 128 // r, 3: 256 // r, 4: 512 // r, 5: 512 // r, 6: 512 // r}
+        beta = torch.distributions.Beta(alpha, alpha)
+        spec = {}
+        for idx in range(1, 7):
+            if idx not in layers_indexes:
+                continue
+            if torch.rand(1) > p:
+                continue
+            lm = beta.sample((B, 1, 1, 1)) if lmda is None else torch.ones(B, 1, 1, 1) * lmda
+            lm = lm.to(device=device, dtype=torch.float32).contiguous()
+            if mix in ('random', 'crossdomain'):
+                if mix == 'random':
+                    perm = torch.randperm(B)
+                else:
+                    perm = torch.arange(B - 1, -1, -1)
+                    perm_b, perm_a = perm.chunk(2)
+                    perm = torch.cat([perm_b[torch.randperm(B // 2)], perm_a[torch.randperm(B // 2)]], 0)
+                spec[idx] = (perm.to(device=device, dtype=torch.int64).contiguous(), lm, None, None, eps)
+            elif mix == 'gaussian':
+                gmu = torch.randn(B, chans[idx], 1, 1, device=device)
+                gstd = torch.randn(B, chans[idx], 1, 1, device=device)
+                spec[idx] = (None, None, gstd.contiguous(), gmu.contiguous(), eps)
+            else:
+                raise NotImplementedError
+        return spec
+
+    def generate_style_augmented_latent_code(self, image, layers_indexes=[1, 2, 3], lmda=None, mix='random', p=0.5, _spec=None):
+        """advanced_triplet...py:632-670: the encoder (batch statistics, running buffers untouched) with MixStyle / DSU after the chosen blocks ->
+        (z_i, z_s) VALUES.  The differentiable form of the trainer's MixStyle branch is `mixstyle_training`."""
+        x = image.detach().contiguous().float()
+        if not x.is_cuda:
+            raise RuntimeError("generate_style_augmented_latent_code runs on the MI355X only (HIP kernels); got a CPU tensor")
+        B, _, H, W = x.shape
+        eng = self._loop_engine(B, H, W, x.device)
+        spec = self._draw_encoder_mixstyle(B, layers_indexes, lmda, mix, p, x.device) if _spec is None else _spec
+        old_eval, eng.bn_eval = eng.bn_eval, False
+        eng.enc_mix = spec
+        try:
+            with torch.no_grad():
+                z_i, z_s = eng.encode_fwd(x)
+                z_i, z_s = z_i.clone(), z_s.clone()
+        finally:
+            eng.enc_mix = None
+            eng.bn_eval = old_eval
+        self.latent_code['image'], self.latent_code['segmentation'] = z_i, z_s
+        return z_i, z_s
+
+    def mixstyle_training(self, clean_image_l, label_l, image, layers_indexes=[1, 2, 3], lmda=None, mix='random', p=0.5, _spec=None):
+        """The trainer's MixStyle / DSU branch as ONE differentiable pass (train_adv...py:394-415): generate_style_augmented_latent_code ->
+        segmentation decoder + image decoder inside _disable_tracking_bn_stats -> (cross_entropy_2D, 0.5*MSE to the clean image).  Both losses carry
+        a grad_fn: backward runs through the decoders, the MixStyle layers (mu / sig detached) and the encoder."""
+        x = image.detach().contiguous().float()
+        spec = self._draw_encoder_mixstyle(x.shape[0], layers_indexes, lmda, mix, p, x.device) if _spec is None else _spec
+        seg, rec, _, _ = self.standard_training(clean_image_l=clean_image_l, label_l=label_l, perturbed_image=x, compute_gt_recon=False, update_latent=False,
+                                                disable_track_bn_stats=True, _enc_mix=spec)
+        return seg, rec
 
     @staticmethod
     def _cfg_sig(layers, slots):

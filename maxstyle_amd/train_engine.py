@@ -253,7 +253,7 @@ class TrainEngine(InnerLoopEngine):
     def run_forward(self, image, labels, clean, track: bool, net_bns=None):
         """forward_pass on engine-owned copies of the inputs (a captured graph holds addresses); see `graph_passes`."""
         xi, li, ci = self._static_inputs(image, labels, clean)
-        if not self.graph_passes:
+        if not self.graph_passes or self.enc_mix is not None:        # (the MixStyle layers allocate their outputs: not capturable)
             return self.forward_pass(xi, li, ci, track, net_bns)
         key = ("fwd", bool(track), bool(self.bn_affine_grad), id(self.nets), None if net_bns is None else tuple(id(d) for d in net_bns))
         out = self._replayed(key, lambda: self.forward_pass(xi, li, ci, track, net_bns))
@@ -266,7 +266,7 @@ class TrainEngine(InnerLoopEngine):
         """backward_pass of the pass last run by run_forward (same static inputs); the two loss weights are baked into the captured launches."""
         b = self.buf
         xi, li, ci = b["in.image"], b["in.labels"], b["in.clean"]
-        if not self.graph_passes:
+        if not self.graph_passes or self.enc_mix is not None:
             return self.backward_pass(xi, li, ci, g_seg, g_rec)
         key = ("bwd", float(g_seg), float(g_rec), bool(self.bn_affine_grad), id(self.nets), id(self.bank))
         self._replayed(key, lambda: self.backward_pass(xi, li, ci, g_seg, g_rec))
@@ -372,7 +372,7 @@ class TrainEngine(InnerLoopEngine):
         self._wg_calls = []
         net_e, net_s, net_d = NETS
         e, s, d = self.nets.enc, self.nets.seg, self.nets.dec
-        z_i, z_s = b["e.z_i"], b["e.z_s"]
+        z_i, z_s = self._mixed(6, "e.z_i"), b["e.z_s"]          # z_i: what the image decoder and the code_decoupler consumed
         # ---- segmentation branch: cross entropy -> head -> four 'NN' up blocks -> dz_s
         dz_s = None
         if g_seg != 0.0:
@@ -429,13 +429,16 @@ class TrainEngine(InnerLoopEngine):
         if dz_i is None:
             self._wgrad_flush()
             return
-        hin = b["e.d4.out"]
-        g, bc = self.act_bwd_t("e.fc.bw", dz_i, z_i, b["e.fc.u"], b["e.fc.bn.coef"], 0.0, net_e, "fc1")
+        hin = self._mixed(5, "e.d4.out")
+        dz_i = self._mix_bwd(6, dz_i, b["e.z_i"])
+        g, bc = self.act_bwd_t("e.fc.bw", dz_i, b["e.z_i"], b["e.fc.u"], b["e.fc.bn.coef"], 0.0, net_e, "fc1")
         self.wgrad(g, hin, self._gw(net_e, "fc0"), 1, p_bnbwd=(bc, b["e.fc.u"]))
         dh, _, _ = self.conv("e.fc.dh", g, e["fc0"], bnbwd=(bc, b["e.fc.u"]), dgrad=True)
+        dh = self._mix_bwd(5, dh, b["e.d4.out"])
         for i in range(4, 0, -1):
-            x = b["e.inc.out"] if i == 1 else b[f"e.d{i - 1}.out"]
-            dh = self.res_bwd_t(f"e.d{i}", net_e, f"d{i}", x, dh, "down")
+            prev = "e.inc.out" if i == 1 else f"e.d{i - 1}.out"
+            dh = self.res_bwd_t(f"e.d{i}", net_e, f"d{i}", self._mixed(i, prev), dh, "down")
+            dh = self._mix_bwd(i, dh, b[prev])
         g, bc = self.act_bwd_t("e.inc.bw2", dh, b["e.inc.out"], b["e.inc.ub"], b["e.inc.bn4.coef"], LEAKY, net_e, "inc4")
         self.wgrad(g, b["e.inc.ua"], self._gw(net_e, "inc3"), 3, p_bnbwd=(bc, b["e.inc.ub"]), q_act=(b["e.inc.bn1.coef"], LEAKY))
         g, bc = self.dgrad_act_bwd_t("e.inc.da", "e.inc.bw1", g, e["inc3"], (bc, b["e.inc.ub"]), b["e.inc.ua"], b["e.inc.bn1.coef"], LEAKY, net_e, "inc1")

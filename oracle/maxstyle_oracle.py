@@ -365,8 +365,28 @@ def res_down_block(sd, p, x, bn_mode="batch", taps=None):
     return out
 
 
-def encoder_forward(sd, x, bn_mode="batch", taps=None):
-    """MyEncoder.forward (+ReLU) then code_decoupler: returns (z_i, z_s). encoder_decoder.py:469-482, 673-680."""
+def mixstyle_forward(x, perm=None, lmda=None, gaussian_mu=None, gaussian_std=None, eps=1e-8):
+    """MixStyle / DSU with the random draws injected (src/advanced/mixstyle.py:57-108): per-plane mu / sig (unbiased var + eps) are DETACHED;
+    'random' / 'crossdomain': statistics interpolated with sample perm[b] by an un-clamped lmda [B,1,1,1]; 'gaussian' (DSU): N(0,1) draws
+    [B,C,1,1] scaled by the batch std of mu / sig."""
+    mu = x.mean(dim=[2, 3], keepdim=True)
+    sig = (x.var(dim=[2, 3], keepdim=True) + eps).sqrt()
+    mu, sig = mu.detach(), sig.detach()
+    xn = (x - mu) / sig
+    if gaussian_mu is not None:
+        mu_mix = mu + gaussian_mu * torch.std(mu, dim=0, keepdim=True)
+        sig_mix = sig + gaussian_std * torch.std(sig, dim=0, keepdim=True)
+    else:
+        mu_mix = mu * (1 - lmda) + mu[perm] * lmda
+        sig_mix = sig * (1 - lmda) + sig[perm] * lmda
+    return xn * sig_mix + mu_mix
+
+
+def encoder_forward(sd, x, bn_mode="batch", taps=None, mix=None):
+    """MyEncoder.forward (+ReLU) then code_decoupler: returns (z_i, z_s). encoder_decoder.py:469-482, 673-680.
+    mix: {index 1..6: kwargs of mixstyle_forward} - generate_style_augmented_latent_code (advanced_triplet...py:632-670): MixStyle after inc (1),
+    down1..down4 (2..5) and the final activation (6); z_i is then the mixed code."""
+    mx = (lambda i, t: mixstyle_forward(t, **mix[i]) if (mix is not None and i in mix) else t)
     g = "general_encoder."
     u = F.conv2d(x, sd[g + "inc.0.weight"], sd[g + "inc.0.bias"], padding=1)
     a = F.leaky_relu(_bn(sd, g + "inc.1", u, bn_mode), LEAKY)
@@ -374,11 +394,11 @@ def encoder_forward(sd, x, bn_mode="batch", taps=None):
     x1 = F.leaky_relu(_bn(sd, g + "inc.4", u, bn_mode), LEAKY)
     if taps is not None:
         taps[g + "inc.out"] = x1
-    h = x1
+    h = mx(1, x1)
     for i in range(1, 5):
-        h = res_down_block(sd, g + f"down{i}.", h, bn_mode, taps)
+        h = mx(i + 1, res_down_block(sd, g + f"down{i}.", h, bn_mode, taps))
     u = F.conv2d(h, sd[g + "final_conv.0.weight"], sd[g + "final_conv.0.bias"])
-    z_i = F.relu(_bn(sd, g + "final_conv.1", u, bn_mode))
+    z_i = mx(6, F.relu(_bn(sd, g + "final_conv.1", u, bn_mode)))
     u = F.conv2d(z_i, sd["code_decoupler.0.weight"], None, padding=1)
     a = F.leaky_relu(_bn(sd, "code_decoupler.1", u, bn_mode), LEAKY)
     u = F.conv2d(a, sd["code_decoupler.3.weight"], None, padding=1)

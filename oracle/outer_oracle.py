@@ -68,7 +68,7 @@ def _running_update(sd, name, u, momentum=0.1):
         sd[name + ".num_batches_tracked"] += 1
 
 
-def training_pass(weights, perturbed_image, clean_image, labels, track_bn: bool):
+def training_pass(weights, perturbed_image, clean_image, labels, track_bn: bool, mix=None):
     """standard_training for a 'no_STN' network. track_bn=True: the clean pass (running statistics updated, BatchNorm affine learns);
     track_bn=False: the pass inside _disable_tracking_bn_stats (BatchNorm affine is a constant of the graph)."""
     w = weights
@@ -77,7 +77,7 @@ def training_pass(weights, perturbed_image, clean_image, labels, track_bn: bool)
     prev = orc.BN_OBSERVER
     orc.BN_OBSERVER = (lambda sd, name, u: _running_update(sd, name, u)) if track_bn else None
     try:
-        z_i, z_s = orc.encoder_forward(w["image_encoder"], perturbed_image, "batch")
+        z_i, z_s = orc.encoder_forward(w["image_encoder"], perturbed_image, "batch", mix=mix)
         logits = orc.decoder_forward(w["segmentation_decoder"], z_s, "NN", None, "batch")
         recon = orc.decoder_forward(w["image_decoder"], z_i, "Conv2", "sigmoid", "batch")
     finally:

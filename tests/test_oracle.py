@@ -228,3 +228,18 @@ def test_oracle_fp64_matches_reference_fp64(golden_dir):
             assert rel(tr.params[4][k[len("step5.param."):]], g64[k]) < 1e-8, k
         if k.startswith("step1.grad."):
             assert rel(tr.grads[0][k[len("step1.grad."):]], g64[k]) < 1e-8, k
+
+
+@pytest.mark.parametrize("tag", ["random", "cross", "extrap", "dsu"])
+def test_mixstyle_restatement_vs_reference(golden_dir, tag):
+    """oracle.mixstyle_forward (MixStyle / DSU with injected draws) against the reference's own outputs and input gradients (mixstyle_cases.npz)."""
+    g = np.load(os.path.join(golden_dir, "mixstyle_cases.npz"))
+    x = torch.from_numpy(g[f"{tag}.x"]).requires_grad_(True)
+    if tag == "dsu":
+        y = orc.mixstyle_forward(x, gaussian_mu=torch.from_numpy(g["dsu.gaussian_mu"]), gaussian_std=torch.from_numpy(g["dsu.gaussian_std"]))
+    else:
+        lm = torch.from_numpy(g[f"{tag}.lmda"]) if f"{tag}.lmda" in g.files else torch.full((x.shape[0], 1, 1, 1), 1.7)
+        y = orc.mixstyle_forward(x, perm=torch.from_numpy(g[f"{tag}.perm"]), lmda=lm)
+    y.backward(torch.from_numpy(g[f"{tag}.dy"]))
+    assert rel(y, g[f"{tag}.y"]) < 1e-6
+    assert rel(x.grad, g[f"{tag}.dx"]) < 1e-6

@@ -452,3 +452,60 @@ def test_checkpoints_round_trip_and_torch_optimizer_compat(dev, tmp_path):
     assert B.optimizers[net].step_count == 3
     o, n, shape = B.optimizers[net]._params()[0]
     assert rel(B._bank.flat_m[o:o + n].view(shape), opt.state_dict()["state"][0]["exp_avg"]) < 1e-7
+
+
+def _oracle_mix(spec):
+    """Engine-side MixStyle spec {idx: (perm, lmda, gaussian_std, gaussian_mu, eps)} -> kwargs of oracle.mixstyle_forward (CPU tensors)."""
+    out = {}
+    for i, (perm, lm, gstd, gmu, eps) in spec.items():
+        c = lambda t: None if t is None else t.detach().cpu()
+        out[i] = dict(perm=c(perm), lmda=c(lm), gaussian_mu=c(gmu), gaussian_std=c(gstd), eps=eps)
+    return out
+
+
+@pytest.mark.parametrize("mix,layers", [("random", [1, 2, 3, 4, 5, 6]), ("gaussian", [1, 2, 3, 4, 5, 6]), ("crossdomain", [2, 4])])
+def test_mixstyle_baseline_pass_vs_oracle(dev, mix, layers):
+    """MixStyle / DSU inside the encoder (generate_style_augmented_latent_code, advanced_triplet...py:632-670) - the latent codes, and
+    the trainer's MixStyle branch as one differentiable pass (losses + all weight gradients) against autograd over the oracle."""
+    from oracle import maxstyle_oracle as orc
+    from oracle import outer_oracle as outer
+    S, W = make_solver(dev, orc.NetSpec(4, 1, 4))
+    clean, lab = orc.synthetic_batch(4, 64, 1, 4, 1234)
+    torch.manual_seed(11)
+    spec = S._draw_encoder_mixstyle(4, layers, None, mix, 1.0, dev)
+    assert sorted(spec) == layers
+    # 1. values of the augmented codes
+    z_i, z_s = S.generate_style_augmented_latent_code(clean.to(dev), layers, None, mix, 1.0, _spec=spec)
+    with torch.no_grad():
+        rz_i, rz_s = orc.encoder_forward({k: v.double() for k, v in W["image_encoder"].items()}, clean.double(), "batch", mix=_oracle_mix({
+            i: tuple(None if t is None or not torch.is_tensor(t) else (t.double() if t.is_floating_point() else t) for t in v[:4]) + (v[4],) for i, v in spec.items()}))
+    assert rel(z_i, rz_i) < 5e-5 and rel(z_s, rz_s) < 1e-4
+    # 2. the differentiable pass
+    W64 = orc.procedural_weights(orc.NetSpec(4, 1, 4), 0, dtype=torch.float64)
+    names = [(n, k) for n in outer.NETS for k in outer.param_names(W64[n])]
+    for n, k in names:
+        W64[n][k].requires_grad_(True)
+    mix64 = _oracle_mix({i: tuple(None if t is None or not torch.is_tensor(t) else (t.double() if t.is_floating_point() else t) for t in v[:4]) + (v[4],)
+                         for i, v in spec.items()})
+    seg, rec, _, _, _, _ = outer.training_pass(W64, clean.double(), clean.double(), lab, track_bn=False, mix=mix64)
+    grads = torch.autograd.grad(seg + rec, [W64[n][k] for n, k in names], allow_unused=True)
+    S.reset_all_optimizers()
+    l_seg, l_rec = S.mixstyle_training(clean.to(dev), lab.to(dev), clean.to(dev), layers, None, mix, 1.0, _spec=spec)
+    assert abs(float(l_seg.detach()) - float(seg)) < 3e-5 * abs(float(seg)) and abs(float(l_rec.detach()) - float(rec)) < 3e-5 * abs(float(rec))
+    (l_seg + l_rec).backward()
+    worst = ("", 0.0)
+    for (net, k), ref in zip(names, grads):
+        p = dict(S.model[net].named_parameters())[k]
+        if ref is None or outer.is_bn_affine(W[net], k) or outer.is_null_grad_bias(net, k):
+            assert float(p.grad.abs().max()) == 0.0, (net, k)
+            continue
+        err = rel(p.grad, ref)
+        worst = max(worst, (f"{net}/{k}", err), key=lambda t: t[1])
+        assert err < GRAD_TOL, (net, k, err)
+    print("worst gradient error", worst)
+    # the same draws as a reference-style MixStyle object: gate, Beta / constant lmda, then permutation or the two normals per layer
+    torch.manual_seed(11)
+    again = S._draw_encoder_mixstyle(4, layers, None, mix, 1.0, dev)
+    for i in spec:
+        for a, b in zip(spec[i][:4], again[i][:4]):
+            assert (a is None and b is None) or torch.equal(a, b)
