@@ -128,7 +128,10 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         for m in self.model.values():
             m.zero_grad()
 
-    def train(self, mode=True):
+    def train(self, mode=True, if_testing=False):
+        """nn.Module.train(mode); `if_testing=True` is the reference's spelling of eval (advanced_triplet...py:1018-1035)."""
+        if if_testing:
+            mode = False
         for m in self.model.values():
             m.train(mode)
         self.training = mode
@@ -172,17 +175,49 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         decoder.train(mode=decoder_state)
         return logit
 
-    def predict(self, input):
-        """eval-mode segmentation (BN running statistics): logits [N,K,H,W] (advanced_triplet...py:673-691 hot part)."""
-        states = {k: m.training for k, m in self.model.items()}
-        for m in self.model.values():
-            m.eval()
-        try:
-            _, z_s = self.encode_image(input)
-            return self.decoder_inference(decoder=self.model['segmentation_decoder'], latent_code=z_s)
-        finally:
-            for k, m in self.model.items():
-                m.train(states[k])
+    def run(self, input, disable_track_bn_stats=False, normalize_input=False):
+        """advanced_triplet...py:310-328 for 'no_STN' networks: (recon_image, init_predict, refined_predict = init_predict); side effect z_i / z_s."""
+        from . import ops
+        if normalize_input:
+            if self.intensity_norm_type != 'min_max':
+                raise NotImplementedError
+            input = ops.rescale_intensity(input.detach().contiguous().float(), 0.0, 1.0)
+        (z_i, z_s), init_predict = self.fast_predict(input, disable_track_bn_stats=disable_track_bn_stats)
+        self.z_i, self.z_s = z_i, z_s
+        recon_image = self.decoder_inference(decoder_name='image_decoder', latent_code=z_i, disable_track_bn_stats=disable_track_bn_stats)
+        if 'no_STN' not in self.network_type:
+            raise NotImplementedError("shape-refinement (STN) networks are outside the MaxStyle path (SURVEY.md 8)")
+        return recon_image, init_predict, init_predict
+
+    def predict(self, input, softmax=False, n_iter=None, normalize_input=True):
+        """advanced_triplet...py:673-691: eval-mode segmentation (BatchNorm running statistics) of the min-max normalised input -> logits (or
+        probabilities) [N,K,H,W].  Like the reference it leaves the solver in eval mode."""
+        self.eval()
+        with torch.no_grad():
+            _, pred, _ = self.run(input, normalize_input=normalize_input)
+        pred = pred.detach().clone()
+        if softmax:
+            pred = torch.softmax(pred, dim=1)
+        return pred
+
+    def set_running_metric(self):
+        """advanced_triplet...py:1093-1095 (confusion matrix on the GPU: maxstyle_amd.metrics.runningScore)."""
+        from .metrics import runningScore
+        dev = next(self.model['image_encoder'].parameters()).device
+        return runningScore(self.num_classes, device=dev)
+
+    def evaluate(self, input, targets_npy, n_iter=None):
+        """advanced_triplet...py:914-934: eval-mode prediction of one batch accumulated into self.running_metric; returns the logits."""
+        if getattr(self, "running_metric", None) is None:
+            self.running_metric = self.set_running_metric()
+        self.eval()
+        pred = self.predict(input, n_iter=n_iter)
+        targets = torch.as_tensor(targets_npy)
+        self.running_metric.update(label_trues=targets, logits=pred)
+        self.cur_eval_images = input.detach().cpu().numpy()[:, 0, :, :]
+        self.cur_eval_predicts = pred.max(1)[1].cpu().numpy()
+        self.cur_eval_gts = targets.cpu().numpy()
+        return pred
 
     # ------------------------------------------------------------------ the hot path
     def _weights_key(self):

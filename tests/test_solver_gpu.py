@@ -185,7 +185,40 @@ def test_eval_mode_prediction_and_running_stats(dev):
         _, zs = orc.encoder_forward(sd["image_encoder"], img, bn_mode="running")
         ref = orc.decoder_forward(sd["segmentation_decoder"], zs, "NN", bn_mode="running")
     assert rel(logits, ref) < 1e-4
-    assert all(m.training for m in S.model.values())
+    assert all(not m.training for m in S.model.values())      # like the reference, predict() leaves the solver in eval mode (advanced_triplet...py:679)
+
+
+def test_run_predict_evaluate_api(dev):
+    """run / predict / evaluate with the reference's signatures (advanced_triplet...py:310-328, 673-691, 914-934): eval-mode logits equal the
+    oracle with running statistics, evaluate() accumulates the confusion matrix of the argmax, predict leaves the solver in eval mode."""
+    from oracle import maxstyle_oracle as orc
+    spec = orc.NetSpec(4, 1, 4)
+    S, W = make_solver(dev, spec)
+    img, lab = orc.synthetic_batch(4, 64, 1, 4, 321)
+    with torch.no_grad():
+        _, zs = orc.encoder_forward(W["image_encoder"], img, "running")
+        ref = orc.decoder_forward(W["segmentation_decoder"], zs, "NN", None, "running")
+    S.train()
+    pred = S.predict(img.to(dev) * 3.0 + 1.0)              # normalize_input=True: per-sample min-max brings it back to [0, 1]
+    assert not S.training and all(not m.training for m in S.model.values())
+    assert rel(pred, ref) < 1e-4
+    prob = S.predict(img.to(dev), softmax=True)
+    assert rel(prob, torch.softmax(ref, 1)) < 1e-4
+    S.running_metric = S.set_running_metric()
+    out = S.evaluate(img.to(dev), lab.numpy())
+    cm = S.running_metric.confusion_matrix().cpu()
+    pl = ref.argmax(1)
+    ref_cm = torch.zeros(4, 4, dtype=torch.int64)
+    for t in range(4):
+        for q in range(4):
+            ref_cm[t, q] = int(((lab == t) & (pl == q)).sum())
+    assert int((cm - ref_cm).abs().sum()) <= 4              # an argmax tie at fp32 rounding may move a pixel
+    assert S.cur_eval_predicts.shape == (4, 64, 64) and S.cur_eval_gts.shape == (4, 64, 64)
+    S.train()
+    recon, p0, p1 = S.run(img.to(dev))                     # train mode, tracking: batch statistics (this updates the running buffers)
+    assert p0 is p1 and recon.shape == img.shape and S.z_i is not None
+    S.train(if_testing=True)
+    assert not S.training
 
 
 def test_gpu_dice_and_confusion(dev):
