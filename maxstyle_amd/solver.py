@@ -76,6 +76,9 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self._packed = None
         self._packed_key = None
         self.last_style_modules = None
+        self.schedulers_dict = {}            # advanced_triplet...py:1070-1081: schedulers exist for SGD only ("No schedulers for optimizers")
+        self.running_metric = None           # created on the first evaluate() (or by set_running_metric()): it lives on the networks' device
+        self.cur_eval_images = self.cur_eval_predicts = self.cur_eval_gts = None
 
     # ------------------------------------------------------------------ construction (advanced_triplet...py:125-266)
     def get_network(self, checkpoint_dir=None):
@@ -199,6 +202,10 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         if softmax:
             pred = torch.softmax(pred, dim=1)
         return pred
+
+    def update_schedule(self):
+        for v in self.schedulers_dict.values():
+            v.step()
 
     def set_running_metric(self):
         """advanced_triplet...py:1093-1095 (confusion matrix on the GPU: maxstyle_amd.metrics.runningScore)."""
