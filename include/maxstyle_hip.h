@@ -24,6 +24,9 @@ extern "C" {
 
 int ms_version(void);
 const char* ms_last_error(void);
+/* Measurement aid: register-only fp32-MFMA chains (iters x 64 per wave) on `workgroups` x `threads`; writes, for workgroup 0, {clock64() cycles,
+ * 100 MHz ticks (s_memrealtime)} around the loop (tools/clock_probe.py). */
+int ms_clock_probe(int iters, int workgroups, int threads, long long* cycles_and_ticks, float* sink, void* stream);
 
 /* ---- MaxStyle layer: src/advanced/maxstyle.py:140-189 ------------------------------------------------ */
 

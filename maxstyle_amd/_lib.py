@@ -56,6 +56,7 @@ SIGNATURES = {
     "ms_conv2d_actbwd_fin": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_f32p, c_f32p, c_f32p, c_int, c_int, ctypes.c_float, c_f32p, c_f32p, ctypes.c_float, c_f32p,
                                      ctypes.c_double, c_f32p, c_void, c_void]),
+    "ms_clock_probe": (c_int, [c_int, c_int, c_int, c_void, c_void, c_void]),
     "ms_bn_bwd_coefs": (c_int, [c_f32p, c_int, c_f32p, ctypes.c_double, c_f32p, c_int, c_void]),
     "ms_pool2_sum": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_void]),
     "ms_conv_wgrad_ws_bytes": (c_size, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),

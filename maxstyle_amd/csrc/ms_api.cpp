@@ -16,3 +16,39 @@ void set_error(const char* fmt, ...) {
 
 extern "C" int ms_version(void) { return 100; }
 extern "C" const char* ms_last_error(void) { return ms::g_err; }
+
+// ---- measurement aid: what the fp32 matrix pipe and clock64() do under register-only MFMA load ---------------------------------------------
+// tools/clock_probe.py: 512 x 512 threads sustain 155 TFLOP/s (the 157.3 TFLOP/s spec peak is attainable on this box: 13-14.4 ns per MFMA and wave),
+// while clock64() / s_memrealtime reads 2.4 GHz for a single wave, 2.2 GHz with one MFMA wave per SIMD and 1.2 GHz with two - the counter is only good for
+// proportions inside a kernel, not as a clock.
+namespace ms {
+typedef float probe_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void clock_probe_kernel(int iters, long long* out, float* sink) {
+  probe_f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = probe_f32x4{0.f, 0.f, 0.f, 0.f};
+  const float a = 1.0f + 1e-3f * (float)(threadIdx.x & 15), b = 1.0f - 1e-3f * (float)(threadIdx.x >> 4);
+  const bool rec = (blockIdx.x == 0) && (threadIdx.x == 0);
+  long long c0 = 0, r0 = 0;
+  if (rec) { c0 = clock64(); r0 = (long long)__builtin_amdgcn_s_memrealtime(); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+  }
+  if (rec) { out[0] = clock64() - c0; out[1] = (long long)__builtin_amdgcn_s_memrealtime() - r0; }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 123.456f) sink[0] = s;                      // keeps the chains alive
+}
+}  // namespace ms
+
+extern "C" int ms_clock_probe(int iters, int workgroups, int threads, long long* cycles_and_ticks, float* sink, void* stream) {
+  if (iters < 1 || workgroups < 1 || threads < 64 || threads > 512 || threads % 64 || cycles_and_ticks == nullptr || sink == nullptr) {
+    ms::set_error("ms_clock_probe: invalid argument"); return MS_ERR_INVALID;
+  }
+  MS_LAUNCH(ms::clock_probe_kernel, dim3(workgroups), dim3(threads), 0, (hipStream_t)stream, iters, cycles_and_ticks, sink);
+  return ms::check_launch("clock_probe");
+}
