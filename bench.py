@@ -11,6 +11,13 @@ advanced_triplet_recon_segmentation_model.py:539-566: encode(recon) -> segmentat
 parameters -> Adam -> re-decode.  All inputs are resident in HBM before the timed region.  Pure data parallel: every rank runs
 the same loop on its own batch, there is no collective on the path; `value` is the whole-job step rate.
 
+`python bench.py --gpus N` WITHOUT a launcher (no RANK in the environment) makes this process a parent that touches no GPU: it
+starts N children of itself (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, RCCL rendezvous on 127.0.0.1) and waits for them;
+under `torch.distributed.run` the ranks already exist and nothing is spawned.  A process that has initialised the GPU is never
+re-exec'ed.  At N > 1 the auxiliary `outer_iteration` leg runs on every rank and exercises the ONE collective of the surrounding
+training step (flat all-reduce of the outer gradients, train_adv_supervised_segmentation_triplet.py:532-535); its time is broken out.
+`--dry-run` runs the same rank plumbing over gloo on the CPU with a stand-in step (tests/test_bench_launch.py): no number from it is a result.
+
 Prints ONE JSON line on rank 0 (contract fields + "roofline" + "cpu_baseline").
 """
 import argparse
@@ -25,6 +32,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 FLOP_PER_STEP_C2 = 154.1e9       # conv FLOPs of one inner step at C2 (fwd 83.7 + data-grad 70.4), un-cached figure
+FLOP_EXECUTED_C2 = 154.1e9 - 2 * 6.642e9   # what the engine launches: the style-independent decoder prefix (up1..up3 forward, SURVEY A.4: 3 x 2214 MMAC) is cached
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak (== fp32 vector peak)
 
@@ -41,6 +49,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5, help="inner steps of the CPU-oracle sample")
     ap.add_argument("--config", default="c2", choices=["c2", "c4"], help="c2: FCN_16 1x256x256 (the quoted metric); c4: FCN_64 3x320x320 (Prostate-shaped)")
+    ap.add_argument("--steady-seconds", type=float, default=2.0, help="length of the extra steady-state leg (graph replays, rank-local); 0 disables")
+    ap.add_argument("--dry-run", action="store_true", help="rank plumbing only: gloo on the CPU, stand-in step (CPU tests)")
     return ap.parse_args()
 
 
@@ -108,61 +118,121 @@ def timed_steps(eng, z_i, lab_d, steps, warmup, use_graph, dist_on):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return dt, graph is not None
+    return dt, graph is not None, run_one
 
 
-def kernel_rooflines(eng, z_i, lab_d, dev):
-    """Per-launch duration of the two kernels DESIGN.md prices, measured live with HIP events on the launch stream.
+def _event_time(fn, reps=20, warm=3):
+    """Median seconds per call of fn(), HIP events recorded on the stream fn launches on (torch's current stream)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(reps):
+        s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record()
+        evs.append((s, e))
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) for s, e in evs)
+    return ts[len(ts) // 2] * 1e-3
 
-    conv3x3 16->16 @256^2 (the dominant kernel: decoder up4 / encoder inc / their data-gradients) against the fp32 MFMA peak,
-    and the fused MaxStyle forward (moments+restyle) at layer 4 (16x16x256x256) against the HBM peak."""
+
+def _traffic_table(B, H, W):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE with the guide's gfx950 corrections,
+    tools/pmc_traffic.py); the newest round's file wins."""
+    if (B, H, W) != (16, 256, 256):
+        return {}
+    tab = {}
+    for name in ("r01_traffic.json", "r02_traffic.json"):
+        try:
+            tab.update(json.load(open(os.path.join(ROOT, "profiles", name))))
+        except Exception:  # noqa: BLE001
+            pass
+    return tab
+
+
+def kernel_rooflines(eng, dev, config):
+    """Per-launch duration of the kernels DESIGN.md prices, measured live with HIP events on the launch stream, on the live buffers of the
+    last step.  `dominant` = the kernel with the largest per-step total in this round's rocprofv3 summary (profiles/r02_kernel_stats.txt):
+    the data-gradient 3x3 conv with the two-tensor BatchNorm-backward prologue and the activation-backward epilogue at the top level
+    (conv_wide_kernel<NT,2>); secondary blocks: the forward conv with the statistics epilogue and the MaxStyle K1/K2 kernels at layer 4."""
     from maxstyle_amd import ops
-    from maxstyle_amd._lib import lib, check
-    out = {}
+    from maxstyle_amd.engine import LEAKY
+    b = eng.buf
     B, H, W = eng.B, eng.H, eng.W
-    x = eng.buf["d.u4.xu"]                     # [B,16,256,256] live activation of the last step
+    seg = eng.nets.seg
+    C = seg["u4.c3"].cout
+    x = b["d.u4.xu"]                           # [B,C,H,W] live activation of the last step
     cw = eng.nets.dec["u4.c0"]
     y = torch.empty_like(x)
     stats, parts = ops.conv_stats_buffer(B, cw.cout, H, W, dev)
+    g2, u2, u1 = b["s.dh"], b["s.u4.u2"], b["s.u4.u1"]
+    bc2, cf1 = b["s.u4.bw2.bcoef"], b["s.u4.bn1.coef"]
+    c3, c0 = seg["u4.c3"], seg["u4.c0"]
+    g2c = g2.clone()
 
-    def conv():
+    def conv_fwd():
         ops.conv2d(x, cw.wp, cw.b, cw.cout, 3, 1, out=y, stats=stats)
 
-    def style():
-        eng.style_fwd(4, eng.buf["d.u4.out"])
+    def conv_dgrad_actbwd():                  # = the "s.u4.da1" launch of a step
+        eng.conv_actbwd("bench.da1", "bench.bw1", g2c, c3, (bc2, u2), u1, cf1, LEAKY)
 
-    for name, fn in (("conv3x3_c16_256", conv), ("maxstyle_fwd_l4", style)):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        evs = []
-        for _ in range(20):
-            s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
-            s.record(); fn(); e.record()
-            evs.append((s, e))
-        torch.cuda.synchronize()
-        ts = sorted(s.elapsed_time(e) for s, e in evs)
-        out[name] = ts[len(ts) // 2] * 1e-3    # median seconds per launch (group of launches for the style op)
+    def conv_dgrad_plain():                   # = the "s.u4.dhi" launch of a step
+        eng.conv("bench.dhi", g2c, c0, bnbwd=(bc2, u2), dgrad=True)
+
+    def style():
+        eng.style_fwd(4, b["d.u4.out"])
+
+    dy4 = torch.empty_like(b["d.u4.out"]).copy_(b["d.dh"]) if "d.dh" in b else torch.randn_like(b["d.u4.out"])
+
+    def style_bwd():
+        eng.style_bwd(4, dy4, need_dx=True)
+
+    t = {name: _event_time(fn) for name, fn in (("conv_fwd", conv_fwd), ("dgrad_actbwd", conv_dgrad_actbwd), ("dgrad_plain", conv_dgrad_plain),
+                                                ("style", style), ("style_bwd", style_bwd))}
     n_elem = x.numel()
-    # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; tools/pmc_traffic.py)
-    traffic = {}
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if (B, H, W) == (16, 256, 256):
-            traffic = tj
-    except Exception:  # noqa: BLE001
-        traffic = {}
-    conv_flops = 2.0 * B * H * W * cw.cout * cw.cin * 9
-    conv_bytes = 2.0 * n_elem * 4
+    traffic = _traffic_table(B, H, W)
+    flops = 2.0 * B * H * W * C * C * 9
+    shape = "%d->%d @%dx%dx%d" % (C, C, B, H, W)
+
+    def conv_block(key, kernel, nbytes, tkey):
+        return {"bound": "mfma", "achieved": flops / t[key] / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops / t[key] / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": traffic.get(tkey), "kernel": kernel + " " + shape,
+                "us_per_launch": t[key] * 1e6, "algorithmic_bytes": nbytes, "hbm_GBps": nbytes / t[key] / 1e9, "flop_per_launch": flops}
+
+    def hbm_block(key, kernel, nbytes, tkey):
+        return {"bound": "hbm", "achieved": nbytes / t[key] / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / t[key] / 1e9 / HBM_PEAK_GBPS,
+                "traffic": traffic.get(tkey), "kernel": kernel, "us_per_launch": t[key] * 1e6, "algorithmic_bytes": nbytes}
+
+    nt = "NT=%d" % (1 if C <= 16 else 2)
     return {
-        "conv": {"bound": "mfma", "achieved": conv_flops / out["conv3x3_c16_256"] / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": conv_flops / out["conv3x3_c16_256"] / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": traffic.get("conv3x3_c16_256"),
-                 "kernel": "conv_wide_kernel<NT=1,PRO=0> (3x3 s1, +BN statistics epilogue) 16->16 @%dx%dx%d" % (B, H, W), "us_per_launch": out["conv3x3_c16_256"] * 1e6,
-                 "hbm_GBps": conv_bytes / out["conv3x3_c16_256"] / 1e9},
-        "style": {"bound": "hbm", "achieved": 8.0 * n_elem / out["maxstyle_fwd_l4"] / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                  "frac": 8.0 * n_elem / out["maxstyle_fwd_l4"] / 1e9 / HBM_PEAK_GBPS, "traffic": traffic.get("maxstyle_fwd_l4"),
-                  "kernel": "ms_style_fwd -> style_fused_kernel<16,1024> (single read) 16x16x%dx%d" % (H, W), "us_per_launch": out["maxstyle_fwd_l4"] * 1e6},
+        # reads g, u2 (prologue), u1 (mask), writes g1: 4 tensors
+        "dominant": conv_block("dgrad_actbwd", "conv_wide_kernel<%s,PRO=2> (3x3 data-gradient, two-tensor BatchNorm-backward prologue, activation-backward epilogue)" % nt,
+                               4.0 * n_elem * 4, "conv_dgrad_actbwd_c16_256"),
+        "dgrad_plain": conv_block("dgrad_plain", "conv_wide_kernel<%s,PRO=2> (3x3 data-gradient, two-tensor prologue, plain epilogue)" % nt, 3.0 * n_elem * 4,
+                                  "conv_dgrad_plain_c16_256"),
+        "conv_fwd": conv_block("conv_fwd", "conv_wide_kernel<%s,PRO=0> (3x3 forward, +BN statistics epilogue)" % nt, 2.0 * n_elem * 4, "conv3x3_c16_256"),
+        "style": hbm_block("style", "ms_style_fwd (K1: moments + restyle, single read) %dx%dx%dx%d" % (B, C, H, W), 8.0 * n_elem, "maxstyle_fwd_l4"),
+        "style_bwd": hbm_block("style_bwd", "ms_style_bwd (K2: restyle backward with dx) %dx%dx%dx%d" % (B, C, H, W), 12.0 * n_elem, "maxstyle_bwd_l4"),
     }
+
+
+def steady_state(run_one, eng, seconds):
+    """A seconds-long run of graph replays (the timed region of the contract is K steps = tens of ms): rules out clock / thermal drift."""
+    if seconds <= 0:
+        return None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        for _ in range(50):
+            run_one()
+        n += 50
+        eng.step_dev.zero_()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    return {"steps": n, "seconds": dt, "steps_s": n / dt}
 
 
 def dice_parity(dev):
@@ -245,14 +315,19 @@ def cpu_baseline(W, img, lab, styles, steps):
                       f"({t2 - t1:.1f}s timed, warm-up {t1 - t0:.1f}s), fp32, torch CPU, {torch.get_num_threads()} threads (fastest of 8/16/32/64/{ncores} on this box)"}
 
 
-def outer_iteration(dev, batch, size, iters=6):
+def outer_iteration(dev, batch, size, rank=0, world=1, iters=6):
     """Auxiliary figure (not the headline metric): whole training iterations/s around the inner loop at the same configuration -
-    standard pass -> MaxStyle inner loop K=5 -> hard-example pass -> backward (weight gradients) -> AdamW x3
-    (train_adv_supervised_segmentation_triplet.py:163-199, 251-287, 532-535; SURVEY.md 8(f) rows 1,3)."""
+    standard pass -> MaxStyle inner loop K=5 -> hard-example pass -> backward (weight gradients) -> [N > 1: ONE flat RCCL all-reduce of the
+    outer gradients] -> AdamW x3 (train_adv_supervised_segmentation_triplet.py:163-199, 251-287, 532-535; SURVEY.md 8(e), 8(f) rows 1,3).
+    Every rank calls this (the all-reduce is a collective); rank r trains on its own batch (seed 1234 + r) from rank 0's weights."""
     import maxstyle_amd as M
     from maxstyle_amd import synthetic as syn
+    import torch.distributed as dist
     S = M.AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard_no_STN", image_ch=1, num_classes=4, use_gpu=True, optimizer_type="AdamW")
-    clean, lab = syn.synthetic_batch(batch, size, 1, 4, 1234)
+    if world > 1:
+        from maxstyle_amd import distributed as D
+        D.broadcast_parameters(list(S.model.values()), src=0)
+    clean, lab = syn.synthetic_batch(batch, size, 1, 4, 1234 + rank)
     clean, lab = clean.to(dev), lab.to(dev)
     cfg = {"mix_style": True, "no_noise": False, "lr": 0.1, "n_iter": 5, "mix_learnable": True, "noise_learnable": True,
            "decoder_layers_indexes": [3, 4, 5], "loss_types": ["seg"], "loss_weights": [1], "always_use_beta": False}
@@ -268,75 +343,198 @@ def outer_iteration(dev, batch, size, iters=6):
         loss = (seg0 + rec0 + sh0 + gt0) + (rec1 + seg1 + sh1 + sh2)
         S.reset_all_optimizers()
         loss.backward()
-        S.optimize_all_params()
+        S.optimize_all_params()             # all-reduces the flat gradient buffer first when torch.distributed is initialised
         return loss
 
     first = float(iteration().detach())
     for _ in range(2):
         iteration()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(iters):
         loss = iteration()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     dt = (time.perf_counter() - t0) / iters
-    return {"what": "training iterations/s (standard pass + K=5 inner loop + hard-example pass + backward + AdamW), same batch", "value": 1.0 / dt,
-            "ms_per_iteration": dt * 1e3, "loss_first": first, "loss_last": float(loss.detach())}
+    out = {"what": "training iterations/s (standard pass + K=5 inner loop + hard-example pass + backward + flat all-reduce at N>1 + AdamW), per-GPU batch "
+                   + str(batch), "ms_per_iteration": dt * 1e3, "loss_first": first, "loss_last": float(loss.detach())}
+    if world > 1:
+        from maxstyle_amd import distributed as D
+        dt = D.max_over_ranks(dt, dev)
+        bank = S._param_bank()
+        flat = bank.flat_g
+        for _ in range(3):
+            bank.all_reduce_grads()
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            bank.all_reduce_grads()
+        torch.cuda.synchronize()
+        ar = D.max_over_ranks((time.perf_counter() - t0) / 20, dev)
+        # rank-equal weights after the exchanged steps: max |w_r - w_0| over ranks
+        w0 = bank.flat_p.clone()
+        dist.broadcast(w0, 0)
+        dev_max = torch.tensor([float((bank.flat_p - w0).abs().max())], device=dev)
+        dist.all_reduce(dev_max, op=dist.ReduceOp.MAX)
+        out.update({"ms_per_iteration": dt * 1e3, "allreduce_ms": ar * 1e3, "allreduce_bytes": flat.numel() * 4,
+                    "allreduce_algbw_GBps": flat.numel() * 4 / ar / 1e9, "world_seen": dist.get_world_size(),
+                    "weights_max_abs_diff_across_ranks": float(dev_max.item())})
+    out["value"] = world / dt
+    out["per_gpu"] = 1.0 / dt
+    return out
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def launch_children(args):
+    """Parent of `python bench.py --gpus N` when no launcher set RANK: starts N ranks of this file (one per GPU) and waits.
+    This process has made no GPU call (torch.cuda.device_count() does not initialise HIP on this image) and never exec's."""
+    import subprocess
+    n = args.gpus
+    if not args.dry_run:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"[bench] --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc = rc or code
+                print(f"[bench] rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()       # exact PIDs of our own children
+        time.sleep(0.05)
+    return rc
+
+
+def dry_run(args, rank, world):
+    """Rank plumbing without a GPU: gloo rendezvous, barrier-bracketed timed region, max over ranks, flat all-reduce of an FCN_16-sized buffer."""
+    import torch.distributed as dist
+    from maxstyle_amd import distributed as D
+    dev = torch.device("cpu")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    a = torch.randn(64, 64)
+    step = lambda: (a @ a).sum().item()
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ar = None
+    if world > 1:
+        dt = D.max_over_ranks(dt, dev)
+        flat = torch.full((1536325,), float(rank + 1))
+        dist.all_reduce(flat); flat.mul_(1.0 / world)
+        ar = {"world_seen": dist.get_world_size(), "mean_ok": bool(torch.allclose(flat, torch.full_like(flat, (world + 1) / 2.0)))}
+    if rank == 0:
+        print(json.dumps({"metric": "inner adversarial style-opt steps/sec (batch 16, 256x256)", "value": world * args.steps / dt, "unit": "steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "DRY RUN (CPU stand-in step, gloo): rank plumbing only, not a measurement", "global_batch": args.batch * world,
+                                     "parallelism": f"dp{world}"}, "outer_iteration": ar}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
     args = parse()
+    if "RANK" not in os.environ and args.gpus > 1:
+        return launch_children(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: reporting n_gpus={world}", file=sys.stderr)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.dry_run:
+        os.environ.setdefault("MASTER_PORT", "29513")
+        return dry_run(args, rank, world)
     dist_on = world > 1
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist_on:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)     # RCCL on ROCm; used for the barriers and the max-over-ranks only
+        dist.init_process_group("nccl", device_id=dev)     # RCCL on ROCm: barriers, max-over-ranks, the outer-gradient all-reduce
     net = (4, 1, 4)
     if args.config == "c4":
         net = (1, 3, 2)
         if args.size == 256:
             args.size = 320
     eng, W, img, lab, styles, z_i, lab_d = build(dev, args.batch, args.size, rank, net)
-    dt, graphed = timed_steps(eng, z_i, lab_d, args.steps, args.warmup, not args.no_graph, dist_on)
+    dt, graphed, run_one = timed_steps(eng, z_i, lab_d, args.steps, args.warmup, not args.no_graph, dist_on)
     if dist_on:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        from maxstyle_amd import distributed as D
+        dt = D.max_over_ranks(dt, dev)
     n_gpus = world
     value = n_gpus * args.steps / dt
+    headline = (args.config, args.batch, args.size) == ("c2", 16, 256)
     res = None
     if rank == 0:
         loss_last = float(eng.loss_buf[0])
-        roof = kernel_rooflines(eng, z_i, lab_d, dev) if args.config == "c2" else {"conv": None, "style": None}
+        steady = steady_state(run_one, eng, args.steady_seconds)
+        roof = kernel_rooflines(eng, dev, args.config)
+        step_s = dt / args.steps
         res = {
             "metric": "inner adversarial style-opt steps/sec (batch 16, 256x256)", "value": value, "unit": "steps/s", "n_gpus": n_gpus,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"C2: FCN_16 dual-branch, per-GPU batch {args.batch}x1x{args.size}x{args.size}, MaxStyle layers [3,4,5], Adam lr 0.1" if args.config == "c2"
                                     else f"C4: FCN_64 dual-branch, per-GPU batch {args.batch}x3x{args.size}x{args.size}, MaxStyle layers [3,4,5], Adam lr 0.1"),
-                       "global_batch": args.batch * n_gpus, "parallelism": f"dp{n_gpus}", "hip_graph": graphed},
-            "conv_tflops_step": FLOP_PER_STEP_C2 / (dt / args.steps) / 1e12 if (args.config, args.batch, args.size) == ("c2", 16, 256) else None,
-            "roofline": roof["conv"], "roofline_maxstyle": roof["style"], "loss_check": loss_last,
+                       "global_batch": args.batch * n_gpus, "parallelism": f"dp{n_gpus}", "hip_graph": graphed, "world_seen": world},
+            "per_gpu_steps_s": value / n_gpus,
+            "steady_state": steady,
+            "conv_flops": ({"gflop_per_step_uncached": FLOP_PER_STEP_C2 / 1e9, "gflop_per_step_executed": FLOP_EXECUTED_C2 / 1e9,
+                            "tflops_uncached_accounting": FLOP_PER_STEP_C2 / step_s / 1e12, "tflops_executed": FLOP_EXECUTED_C2 / step_s / 1e12,
+                            "note": "executed = launched by the engine (decoder prefix up1..up3 cached per call); uncached = SURVEY 8(d) figure, comparable with the reference"}
+                           if headline else None),
+            "roofline": roof["dominant"], "roofline_dgrad_plain": roof["dgrad_plain"], "roofline_conv_fwd": roof["conv_fwd"],
+            "roofline_maxstyle": roof["style"], "roofline_maxstyle_bwd": roof["style_bwd"], "loss_check": loss_last,
         }
         if world == 1 and not args.no_cpu_baseline and args.config == "c2":
             res["cpu_baseline"] = cpu_baseline(W, img, lab, styles, args.cpu_steps)
             res["speedup_vs_cpu"] = value / res["cpu_baseline"]["value"]
             res["dice_parity"] = dice_parity(dev)
-        if world == 1 and not args.no_outer and args.config == "c2":
-            res["outer_iteration"] = outer_iteration(dev, args.batch, args.size)
+    if not args.no_outer and args.config == "c2":
+        del eng
+        torch.cuda.empty_cache()
+        oi = outer_iteration(dev, args.batch, args.size, rank, world)      # every rank: contains the collective
+        if rank == 0:
+            res["outer_iteration"] = oi
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if dist_on:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -24,6 +24,9 @@ extern "C" {
 
 int ms_version(void);
 const char* ms_last_error(void);
+/* Compute units of the current device (hipDeviceProp.multiProcessorCount, read once per device): every persistent grid and every
+ * co-residency bound of the library is sized from it (a partitioned or CU-masked device reports fewer than MI355X's 256). */
+int ms_num_cus(void);
 /* Measurement aid: register-only fp32-MFMA chains (iters x 64 per wave) on `workgroups` x `threads`; writes, for workgroup 0, {clock64() cycles,
  * 100 MHz ticks (s_memrealtime)} around the loop (tools/clock_probe.py). */
 int ms_clock_probe(int iters, int workgroups, int threads, long long* cycles_and_ticks, float* sink, void* stream);
@@ -39,7 +42,8 @@ size_t ms_style_ws_bytes(int B, int C, int HW);
 int ms_style_moments(const float* x, float* mu, float* sig, int planes, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
 
 /* Per-plane affine coefficients  A = sig(1-l)+sig[perm]l + gamma_noise*gamma_std,  S = mu(1-l)+mu[perm]l + beta_noise*beta_std
- * with l = clamp(lmda,0,1).  compute_std bit 0: gamma_std[c]=std_b(sig[:,c]), beta_std[c]=std_b(mu[:,c]) (unbiased) are
+ * with l = clamp(lmda,0,1).  compute_std is a flag word.  bit 2 (ms_style_fwd only): the device is shared with kernels of other streams /
+ * processes - the single-read kernel (whose progress argument needs its whole grid resident) is not used.  bit 0: gamma_std[c]=std_b(sig[:,c]), beta_std[c]=std_b(mu[:,c]) (unbiased) are
  * computed from mu/sig and stored (the reference caches them on the first forward), else they are read.  compute_std bit 1:
  * l = lmda without the clamp (MixStyle: src/advanced/mixstyle.py:91-92).
  * lmda == NULL: no style mixing (mix_style=False); gamma_noise == beta_noise == NULL: no_noise=True.  maxstyle.py:165-185 */
@@ -64,6 +68,13 @@ int ms_style_fwd(const float* x, float* y, float* mu, float* sig, float* gamma_s
  *                       stream at a time); ws[1] (int) is an error word set if a bounded spin ever times out
  *   ms_style_fwd_3k     moments / finalize / restyle as three launches (any shape; x is read twice) */
 size_t ms_style_fused_ws_bytes(int B, int C, int HW);
+/* geometry the single-read kernel would use: threads per workgroup, float4 register slots per thread, chunks per plane, grid (diagnostics) */
+int ms_style_fused_plan(int B, int C, int HW, int* threads, int* nv, int* S, int* grid);
+/* byte offset of the single-read kernel's state block inside a workspace of ms_style_ws_bytes() bytes ((size_t)-1: the shape has none);
+ * the int at offset + 4 is its ERROR WORD.  A caller that syncs anyway can read it with its own copy; ms_style_fused_status does a
+ * stream-ordered synchronous read of the word of `state` (= workspace + offset), clears it when set and leaves the reason in ms_last_error(). */
+size_t ms_style_ws_state_offset(int B, int C, int HW);
+int ms_style_fused_status(void* state, int* out_host, void* stream);
 int ms_style_fwd_fused(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
                        const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
                        float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream);

@@ -31,6 +31,10 @@ SIGNATURES = {
     "ms_style_fwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p,
                              c_int, c_int, c_int, c_float, c_void, c_size, c_void]),
     "ms_style_fused_ws_bytes": (c_size, [c_int, c_int, c_int]),
+    "ms_num_cus": (c_int, []),
+    "ms_style_fused_plan": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "ms_style_ws_state_offset": (c_size, [c_int, c_int, c_int]),
+    "ms_style_fused_status": (c_int, [c_void, ctypes.POINTER(c_int), c_void]),
     "ms_style_fwd_fused": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p,
                                    c_int, c_int, c_int, c_float, c_void, c_size, c_void]),
     "ms_style_fwd_3k": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p,

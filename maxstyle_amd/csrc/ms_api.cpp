@@ -1,6 +1,8 @@
 // Library-level entry points: version and the thread-local error string.
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include "ms_common.h"
 #include "maxstyle_hip.h"
 
@@ -12,9 +14,27 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// Compute units of the current device, read once per device (grid sizing and the co-residency bounds of the persistent kernels come from
+// here, not from a constant: a partitioned (CPX) or CU-masked device reports fewer).  kNumCU stays the capacity of the per-workgroup tables.
+int num_cus() {
+  constexpr int kMaxDev = 64;
+  static std::once_flag once[kMaxDev];
+  static int cus[kMaxDev];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) { (void)hipGetLastError(); return kNumCU; }
+  std::call_once(once[dev], [dev]() {
+    hipDeviceProp_t p;
+    cus[dev] = kNumCU;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus[dev] = std::min(p.multiProcessorCount, kNumCU);
+    else (void)hipGetLastError();
+  });
+  return cus[dev];
+}
 }  // namespace ms
 
-extern "C" int ms_version(void) { return 100; }
+extern "C" int ms_version(void) { return 200; }
+extern "C" int ms_num_cus(void) { return ms::num_cus(); }
 extern "C" const char* ms_last_error(void) { return ms::g_err; }
 
 // ---- measurement aid: what the fp32 matrix pipe and clock64() do under register-only MFMA load ---------------------------------------------

@@ -16,7 +16,8 @@
 namespace ms {
 
 constexpr int kWave = 64;
-constexpr int kNumCU = 256;      // MI355X: 8 XCDs x 32 CUs
+constexpr int kNumCU = 256;      // MI355X: 8 XCDs x 32 CUs - CAPACITY of the per-workgroup tables; grids are sized from num_cus()
+int num_cus();                   // compute units of the current device (hipDeviceProp, read once per device; <= kNumCU)
 constexpr int kStatSlots = kNumCU * 2 * 4;   // per-channel capacity (row stride) of the conv kernels' partial tables; one slot per workgroup of the channel block is used
 
 // last error string (thread-local; the ABI itself never throws)

@@ -15,6 +15,7 @@
 // (separate pipes), and every global load has a full MFMA phase to land.
 #pragma once
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 #include "ms_common.h"
 
@@ -754,15 +755,12 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
   using G = Geo<KS, STRIDE, FETCH, VEC, NARROW, NT>;
   const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * (size_t)a.cin_pad);
   if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    attr_set = true;
-  }
+  static std::once_flag attr_once;                     // one flag per instantiation (no unsynchronised mutable state in the ABI)
+  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
   const long nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb;
   // resident workgroups per CU: 512 threads = 2 waves per SIMD each -> at most 2 within 256 registers per wave; LDS 160 KiB per CU
   const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));
-  long nblocks = std::min<long>(nitems, (long)kNumCU * per_cu);
+  long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;      // every workgroup keeps one channel block: item % ncb == blockIdx % ncb
   dim3 grid((unsigned)nblocks), block(512);
   MS_LAUNCH((conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2>), grid, block, lds_bytes, st, a);

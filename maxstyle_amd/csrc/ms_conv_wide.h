@@ -15,6 +15,7 @@
 // Same contract as conv_mfma_kernel<3,1,FETCH_NORMAL,NT,true,false,IN2>: ConvArgs, packed weights, prologues, epilogues, statistics table.
 #pragma once
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include "ms_conv_kernel.h"
 
@@ -481,16 +482,13 @@ template <int NT, int PRO>
 int launch_conv_wide(ConvArgs a, hipStream_t st) {
   using G = WideGeo<NT, PRO>;
   const size_t lds_bytes = sizeof(float) * 2 * (size_t)G::BUF;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    attr_set = true;
-  }
+  static std::once_flag attr_once;                     // one flag per instantiation; the attribute itself is immutable afterwards
+  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
   a.tiles_x = cdiv(a.Wout, G::TW); a.tiles_y = cdiv(a.Hout, G::TH);
   a.ncb = cdiv(a.Cout, 16 * NT);
   const long nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb;
   const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));
-  long nblocks = std::min<long>(nitems, (long)kNumCU * per_cu);
+  long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;
   MS_LAUNCH((conv_wide_kernel<NT, PRO>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
   return check_launch("conv_wide");

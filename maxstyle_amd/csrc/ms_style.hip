@@ -288,6 +288,12 @@ extern "C" size_t ms_style_ws_bytes(int B, int C, int HW) {
   return style_scratch_bytes(B, C, HW) + (ms_style_fused_ws_bytes(B, C, HW) + 15) / 16 * 16;
 }
 
+// byte offset of the single-read kernel's state block inside a style workspace (its int[1] is the error word), or (size_t)-1 when
+// the shape has no single-read path
+extern "C" size_t ms_style_ws_state_offset(int B, int C, int HW) {
+  return ms_style_fused_ws_bytes(B, C, HW) == 0 ? (size_t)-1 : style_scratch_bytes(B, C, HW);
+}
+
 static int launch_moments(const float* x, PlanePartial* part, int P, int HW, const Split& sp, hipStream_t st) {
   dim3 grid(sp.S, P), block(kStyleThreads);
 #define MS_LAUNCH_MOM(V, N) MS_LAUNCH((moments_partial_kernel<V, N>), grid, block, 0, st, x, part, HW, sp.chunk, sp.S)
@@ -356,12 +362,15 @@ extern "C" int ms_style_apply(const float* x, float* y, const float* mu, const f
 extern "C" int ms_style_fwd(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
                             const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
                             float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream) {
-  // single-read kernel when the shape is eligible (MS_STYLE_FUSED=0 forces the three-kernel path, for A/B timing)
+  // single-read kernel when the shape is eligible (MS_STYLE_FUSED=0 forces the three-kernel path, for A/B timing).  compute_std bit 2
+  // (MS_STYLE_SHARED_DEVICE): the caller runs other kernels beside this one (side streams, another process) - the single-read kernel's
+  // co-residency argument does not hold then, so the three-launch path is taken.
   static const bool fused_on = !(getenv("MS_STYLE_FUSED") != nullptr && atoi(getenv("MS_STYLE_FUSED")) == 0);
-  // below ~32 MB the tensor sits in L2/Infinity Cache and the three short launches beat the ticketed persistent kernel (measured)
-  static const size_t min_mb = getenv("MS_STYLE_FUSED_MIN_MB") ? (size_t)atoi(getenv("MS_STYLE_FUSED_MIN_MB")) : 32;      // A/B switch for timing
-  const bool big = (size_t)B * C * HW * sizeof(float) >= (min_mb << 20);
-  const size_t fb = (fused_on && big) ? ms_style_fused_ws_bytes(B, C, HW) : 0;
+  static const size_t min_kb = getenv("MS_STYLE_FUSED_MIN_KB") ? (size_t)atoi(getenv("MS_STYLE_FUSED_MIN_KB")) : 1024;      // A/B switch for timing
+  const bool big = (size_t)B * C * HW * sizeof(float) >= (min_kb << 10);
+  const bool shared = (compute_std & 4) != 0;
+  compute_std &= 3;
+  const size_t fb = (fused_on && big && !shared) ? ms_style_fused_ws_bytes(B, C, HW) : 0;
   const size_t off = style_scratch_bytes(B, C, HW);
   if (fb != 0 && ws != nullptr && ws_bytes >= off + fb && aligned16(ws) && aligned16(x) && aligned16(y))
     return ms_style_fwd_fused(x, y, mu, sig, gamma_std, beta_std, compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, HW, eps,

@@ -11,26 +11,40 @@
 // partials (Chan, fp64), computes its plane's affine coefficients and writes y from registers.
 // HBM traffic = 4 B/element read + 4 B/element written = the algorithmic 8 B/element.
 //
-// Progress: the grid never exceeds the workgroups that fit the chip together (1 x 1024 threads or 4 x 256 threads per CU at
-// <= 96 VGPRs), and a workgroup only ever waits for units of its own channel, which are the current or an earlier unit of
-// other workgroups of the same launch (channel-major numbering + increasing processing order): the lowest unfinished channel
-// always has every unit either done or being loaded, so it completes and releases its waiters.  Every spin is bounded (error
-// word) - a mis-sized launch flags an error instead of hanging the GPU.  Visibility: 8-byte agent-scope atomics on both sides
-// (MI355X_MICROARCH.md "Valid forms", R2: the granule carries its own tag).
+// Round-2 rewrite of the data path (the protocol is unchanged): the first version addressed its 16 float4 loads per thread with
+// 64-bit flat pointers and per-load bounds guards; at 1024 threads (128 VGPRs) hipcc spilled 16 of the 64 data registers to
+// scratch - every launch wrote and re-read 25 % of the tensor a second time (rocprofv3: WRITE_SIZE 83.9 MB against 67.1 MB
+// algorithmic, `-Rpass-analysis=kernel-resource-usage`: "VGPRs Spill: 16, ScratchSize 68").  Now a unit is ONE buffer resource
+// (base = start of the chunk, num_records = its bytes): every load / store is `buffer_load/store_dwordx4 v, voff, srsrc, soff`
+// with one per-lane offset register and a scalar offset per register slot, out-of-range lanes are dropped by the hardware range
+// check (no guards, no 64-bit address arithmetic), chunks are balanced (HW split evenly over S), and the kernel is built for
+// 1024-, 512- and 256-thread workgroups so that small tensors still fill 256 CUs and two or four workgroups per CU overlap
+// one's loads with another's stores.
+//
+// Progress: the grid never exceeds the workgroups that fit the chip together (device CU count x workgroups per CU at <= 128
+// VGPRs), and a workgroup only ever waits for units of its own channel, which are the current or an earlier unit of other
+// workgroups of the same launch (channel-major numbering + increasing processing order): the lowest unfinished channel always
+// has every unit either done or being loaded, so it completes and releases its waiters.  That argument needs the launch to get
+// the CUs it was sized for; a foreign kernel on another stream only delays it (its workgroups finish and free their slots).
+// Every spin is bounded: a time-out sets the error word, which the host reads (ms_style_fused_status) - never silent zeros.
+// Visibility: 8-byte agent-scope atomics on both sides (MI355X_MICROARCH.md "Valid forms", R2: the granule carries its own tag).
 // Tags are LAUNCH EPOCHS: the state block holds an epoch word; every workgroup reads it at start (T = epoch + 1), publishes and accepts
 // only granules tagged T, and the last workgroup to finish stores epoch = T.  Nothing is re-initialised between launches - an earlier
 // version cleared the table with hipMemsetAsync before every launch, and under HIP-graph replay the kernel was observed polling
 // granules the memset node had not cleared yet (stale or foreign words with a non-zero tag -> wrong statistics, NaN).  The state block
 // is zero-filled ONCE by the caller and must stay dedicated to one layer.
 #include <algorithm>
+#include <cstdlib>
 #include "ms_common.h"
 #include "maxstyle_hip.h"
 
 namespace ms {
 
 constexpr unsigned kSpinLimit = 1u << 22;
+constexpr int kFusedNV = 16;                      // float4 register slots per thread (64 floats)
 
 typedef unsigned long long u64;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // granule = {tag (launch epoch) : 32 | float bits : 32}; unit u owns granules 2u (mean) and 2u+1 (M2)
 __device__ __forceinline__ void publish_granule(u64* slot, float value, unsigned tag) {
@@ -45,64 +59,73 @@ __device__ __forceinline__ bool poll_granule(const u64* slot, float& value, unsi
   }
 }
 
-template <int NV, int kFusedThreads>
-__global__ __launch_bounds__(kFusedThreads) void style_fused_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mu,
-                                                                   float* __restrict__ sig, float* __restrict__ gamma_std, float* __restrict__ beta_std,
-                                                                   int compute_std, const float* __restrict__ lmda, const float* __restrict__ gamma_noise,
-                                                                   const float* __restrict__ beta_noise, const int64_t* __restrict__ perm,
-                                                                   float* __restrict__ coefA, float* __restrict__ coefS, u64* __restrict__ part,
-                                                                   int* __restrict__ arrive, int* __restrict__ counter, int* __restrict__ err,
-                                                                   int B, int C, int HW, int S, int chunk, float eps) {
+struct FusedArgs {
+  const float* x; float* y; float* mu; float* sig; float* gamma_std; float* beta_std;
+  const float* lmda; const float* gamma_noise; const float* beta_noise; const int64_t* perm;
+  float* coefA; float* coefS; u64* part; int* arrive; int* counter; int* err;
+  int compute_std, B, C, HW, S, chunk, nv;
+  float eps;
+};
+
+// THREADS: workgroup size; AUXL / AUXS: cache-policy bits of the x loads / y stores (0 default, 2 = nt)
+template <int THREADS, int AUXL, int AUXS>
+__global__ __launch_bounds__(THREADS, 4) void style_fused_kernel(const FusedArgs a) {
   __shared__ float red[16];
   __shared__ double redd[16];
   __shared__ float smu[256], ssig[256];
-  __shared__ float pmean[1024], pm2[1024];          // polled partials of the channel: B*S <= 512 units (host-checked)
+  __shared__ float pmean[1024], pm2[1024];          // polled partials of the channel: B*S <= 1024 units (host-checked)
   __shared__ unsigned s_tag;
   const int tid = threadIdx.x;
+  const int B = a.B, C = a.C, HW = a.HW, S = a.S, chunk = a.chunk, nv = a.nv;
   const int G = B * S, total = C * G;
   // `counter` is the epoch word, `arrive` counts finished workgroups of this launch
   if (tid == 0) {
-    unsigned t = (unsigned)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    unsigned t = (unsigned)__hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     s_tag = (t == 0u) ? 1u : t;                     // 0 is the zero-filled (never published) state
   }
   __syncthreads();
   const unsigned tag = s_tag;
+  const int voff = tid * 16;                        // per-lane byte offset inside a register slot's THREADS*16-byte stripe
   for (int t = blockIdx.x; t < total; t += gridDim.x) {
     const int c = t / G, r = t - c * G, b = r / S, s = r - b * S;
     const int p = b * C + c;
-    const int beg = s * chunk, end = min(HW, beg + chunk);
-    const float* xp = x + (size_t)p * HW;
-    float4 v[NV];
+    const int beg = s * chunk, cnt = min(HW - beg, chunk);                 // floats; both multiples of 4
+    const size_t base = (size_t)p * HW + beg;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + base), 0, cnt * 4, 0x00020000);
+    float4 v[kFusedNV];
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int i = beg + (j * kFusedThreads + tid) * 4;
-      v[j] = (i < end) ? *reinterpret_cast<const float4*>(xp + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-      sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    for (int j = 0; j < kFusedNV; ++j) {
+      v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < nv) {                                                          // wave-uniform; lanes past the chunk read 0 (range check)
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, j * THREADS * 16, AUXL);
+        v[j] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+      }
     }
-    const float n = (float)(end - beg);
+#pragma unroll
+    for (int j = 0; j < kFusedNV; ++j) sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    const float n = (float)cnt;
     const float mean_c = block_sum(sum, red) / n;
     float m2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int i = beg + (j * kFusedThreads + tid) * 4;
-      if (i < end) {
+    for (int j = 0; j < kFusedNV; ++j) {
+      if ((j * THREADS + tid) * 4 < cnt) {
         const float d0 = v[j].x - mean_c, d1 = v[j].y - mean_c, d2 = v[j].z - mean_c, d3 = v[j].w - mean_c;
         m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
       }
     }
     m2 = block_sum(m2, red);
-    u64* gran = part + 2 * ((size_t)c * G);          // granules of channel c: unit (bb, ss) -> index 2*(bb*S+ss) (+1)
+    u64* gran = a.part + 2 * ((size_t)c * G);        // granules of channel c: unit (bb, ss) -> index 2*(bb*S+ss) (+1)
     if (tid == 0) { publish_granule(gran + 2 * (b * S + s), mean_c, tag); publish_granule(gran + 2 * (b * S + s) + 1, m2, tag); }
     // one thread per granule polls until it is published (our own two come back from memory as well)
-    for (int q = tid; q < 2 * G; q += kFusedThreads) {
+    for (int q = tid; q < 2 * G; q += THREADS) {
       float val;
-      poll_granule(gran + q, val, tag, err);
+      poll_granule(gran + q, val, tag, a.err);
       if (q & 1) pm2[q >> 1] = val; else pmean[q >> 1] = val;
     }
     __syncthreads();
     // every plane of channel c: Chan-merge its S chunk partials (chunk sizes follow from the geometry)
-    for (int bb = tid; bb < B; bb += kFusedThreads) {
+    for (int bb = tid; bb < B; bb += THREADS) {
       double nn = 0.0, mean = 0.0, mm2 = 0.0;
       for (int ss = 0; ss < S; ++ss) {
         const float pm = pmean[bb * S + ss], pq = pm2[bb * S + ss];
@@ -110,17 +133,17 @@ __global__ __launch_bounds__(kFusedThreads) void style_fused_kernel(const float*
         chan_merge(nn, mean, mm2, cn, (double)pm, (double)pq);
       }
       smu[bb] = (float)mean;
-      ssig[bb] = sqrtf((float)(mm2 / (double)(HW - 1)) + eps);
+      ssig[bb] = sqrtf((float)(mm2 / (double)(HW - 1)) + a.eps);
     }
     __syncthreads();
     float gs, bs;
-    if (compute_std & 1) {
+    if (a.compute_std & 1) {
       double am = 0.0, as = 0.0;
-      for (int bb = tid; bb < B; bb += kFusedThreads) { am += (double)smu[bb]; as += (double)ssig[bb]; }
+      for (int bb = tid; bb < B; bb += THREADS) { am += (double)smu[bb]; as += (double)ssig[bb]; }
       const double mean_mu = block_sum_d(am, redd) / B;
       const double mean_sg = block_sum_d(as, redd) / B;
       double qm = 0.0, qs = 0.0;
-      for (int bb = tid; bb < B; bb += kFusedThreads) {
+      for (int bb = tid; bb < B; bb += THREADS) {
         const double d1 = (double)smu[bb] - mean_mu, d2 = (double)ssig[bb] - mean_sg;
         qm += d1 * d1; qs += d2 * d2;
       }
@@ -128,77 +151,97 @@ __global__ __launch_bounds__(kFusedThreads) void style_fused_kernel(const float*
       bs = (float)sqrt(qm / (double)(B - 1));
       gs = (float)sqrt(qs / (double)(B - 1));
     } else {
-      gs = gamma_std[c]; bs = beta_std[c];
+      gs = a.gamma_std[c]; bs = a.beta_std[c];
     }
     const float m = smu[b], sg = ssig[b];
     float A = sg, Sh = m;
-    if (lmda != nullptr) {
-      const float lam = (compute_std & 2) ? lmda[b] : fminf(fmaxf(lmda[b], 0.f), 1.f);     // bit 1: MixStyle (no clamp)
-      const int pb = (int)perm[b];
+    if (a.lmda != nullptr) {
+      const float lam = (a.compute_std & 2) ? a.lmda[b] : fminf(fmaxf(a.lmda[b], 0.f), 1.f);     // bit 1: MixStyle (no clamp)
+      const int pb = (int)a.perm[b];
       A = sg * (1.f - lam) + ssig[pb] * lam;
       Sh = m * (1.f - lam) + smu[pb] * lam;
     }
-    if (gamma_noise != nullptr) {
-      A += gamma_noise[p] * gs;
-      Sh += beta_noise[p] * bs;
+    if (a.gamma_noise != nullptr) {
+      A += a.gamma_noise[p] * gs;
+      Sh += a.beta_noise[p] * bs;
     }
     if (tid == 0 && s == 0) {
-      mu[p] = m; sig[p] = sg; coefA[p] = A; coefS[p] = Sh;
-      if (b == 0 && (compute_std & 1)) { gamma_std[c] = gs; beta_std[c] = bs; }
+      a.mu[p] = m; a.sig[p] = sg; a.coefA[p] = A; a.coefS[p] = Sh;
+      if (b == 0 && (a.compute_std & 1)) { a.gamma_std[c] = gs; a.beta_std[c] = bs; }
     }
-    const float a = A / sg;
-    float* yp = y + (size_t)p * HW;
+    const float sc = A / sg;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + base, 0, cnt * 4, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int i = beg + (j * kFusedThreads + tid) * 4;
-      if (i < end) {
-        float4 o;
-        o.x = a * (v[j].x - m) + Sh; o.y = a * (v[j].y - m) + Sh; o.z = a * (v[j].z - m) + Sh; o.w = a * (v[j].w - m) + Sh;
-        *reinterpret_cast<float4*>(yp + i) = o;
+    for (int j = 0; j < kFusedNV; ++j) {
+      if (j < nv) {
+        u32x4 o;
+        o.x = __float_as_uint(sc * (v[j].x - m) + Sh); o.y = __float_as_uint(sc * (v[j].y - m) + Sh);
+        o.z = __float_as_uint(sc * (v[j].z - m) + Sh); o.w = __float_as_uint(sc * (v[j].w - m) + Sh);
+        __builtin_amdgcn_raw_buffer_store_b128(o, ry, voff, j * THREADS * 16, AUXS);     // lanes past the chunk are dropped by the range check
       }
     }
     __syncthreads();      // smu/ssig are reused by the next unit
   }
   // end of launch: the last workgroup to get here advances the epoch (every workgroup has read it by then) and re-arms the counter
   if (tid == 0) {
-    const int prev = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int prev = __hip_atomic_fetch_add(a.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prev == (int)gridDim.x - 1) {
-      __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(counter, (int)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.counter, (int)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
 
 struct FusedPlan { bool ok; int threads, nv, chunk, S, grid; size_t part_off, bytes; };
 
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 // State block: ints [0] epoch, [1] error word, [2] finished-workgroup counter; granules (8 B each) from byte 16.
+// Geometry: a unit is a balanced chunk of one plane held in registers by one workgroup (<= 64 floats per thread).  Prefer the fattest
+// workgroup that still gives every CU work; all units of one channel (G = B*S) must be resident together.
 static FusedPlan fused_plan(int B, int C, int HW) {
   FusedPlan pl{};
   pl.ok = false;
   if (HW % 4 != 0 || B < 2 || B > 256) return pl;
-  // Few, fat workgroups keep the ticket counter cold (one device-wide atomic per unit, ~88 dequeues/us on one word):
-  // 1024 threads x up to 64 floats hold 256 KB of a plane; fall back to 256-thread units when that leaves CUs idle.
-  int threads = 1024, nv = 16;
-  int S = cdiv(HW, threads * 4 * nv);
-  if ((long)B * C * S >= 192) {
-    while (nv > 1 && threads * 4 * (nv / 2) * S >= HW) nv >>= 1;
-  } else {
-    threads = 256; nv = 16;
-    while (nv > 1 && (long)B * C * cdiv(HW, threads * 4 * nv) < 1024) nv >>= 1;
-    while (nv < 16 && B * cdiv(HW, threads * 4 * nv) > 512) nv <<= 1;      // one channel group must fit the resident grid
-    S = cdiv(HW, threads * 4 * nv);
+  const int cus = num_cus();
+  static const int force_threads = env_int("MS_STYLE_FUSED_THREADS", 0);        // A/B switches for tools/bench_kernels.py
+  static const int force_split = env_int("MS_STYLE_FUSED_SPLIT", 0);
+  const int cand[3] = {1024, 512, 256};
+  for (int k = 0; k < 3; ++k) {
+    const int threads = cand[k];
+    if (force_threads && threads != force_threads) continue;
+    const int per_cu = 1024 / threads;                                            // workgroups per CU at <= 128 VGPRs (4 waves per SIMD)
+    const long resident = (long)cus * per_cu;
+    const int max_chunk = threads * 4 * kFusedNV;
+    int S = cdiv(HW, max_chunk);
+    // split planes further while the tensor has fewer units than the chip has workgroup slots (small C: layer 5 has 16 planes)
+    while ((long)B * C * S < resident && (long)B * (S * 2) <= resident && HW / (S * 2) >= threads * 4 && B * S * 2 <= 1024) S *= 2;
+    if (force_split) S = std::max(S, force_split);
+    int chunk = (cdiv(HW, S) + 3) / 4 * 4;
+    S = cdiv(HW, chunk);
+    const int nv = cdiv(chunk, threads * 4);
+    const long G = (long)B * S;
+    if (nv > kFusedNV || G > resident || G > 1024) continue;
+    const bool last = (k == 2) || force_threads;
+    if (!last && (long)B * C * S < resident) continue;                            // a thinner workgroup fills more CUs
+    pl.threads = threads; pl.nv = nv; pl.chunk = chunk; pl.S = S;
+    pl.grid = (int)std::min<long>((long)C * G, resident);                         // never more than fit the chip together
+    pl.part_off = 16;                                                             // [0] epoch, [1] error word, [2] arrivals
+    pl.bytes = pl.part_off + 2 * (size_t)C * G * sizeof(u64);                     // two tagged granules per unit
+    pl.ok = true;
+    return pl;
   }
-  pl.threads = threads; pl.nv = nv; pl.chunk = threads * 4 * nv; pl.S = cdiv(HW, pl.chunk);
-  const int G = B * pl.S;
-  // workgroups that can certainly run together: one 1024-thread (or two 256-thread) workgroup(s) per CU at <= 96 VGPRs
-  const int capacity = (threads == 1024) ? 256 : 512;
-  if (G > capacity) return pl;
-  pl.grid = (int)std::min<long>((long)C * G, threads == 1024 ? 256L : 1024L);   // never more than fit the chip together
-  if (pl.grid < G) return pl;
-  pl.part_off = 16;                                                     // [0] epoch, [1] error word, [2] arrivals
-  pl.bytes = pl.part_off + 2 * (size_t)C * B * pl.S * sizeof(u64);      // two tagged granules per unit
-  pl.ok = true;
   return pl;
+}
+
+// The state block must not depend on the A/B switches above in a way that moves it between calls: its size is the maximum over the
+// candidate geometries (granules are indexed by the geometry of the launch; a launch only reads granules carrying its own epoch).
+static size_t fused_state_bytes(int B, int C, int HW) {
+  if (HW % 4 != 0 || B < 2 || B > 256) return 0;
+  return 16 + 2 * (size_t)C * 1024 * sizeof(u64);
 }
 
 }  // namespace ms
@@ -207,7 +250,17 @@ using namespace ms;
 
 extern "C" size_t ms_style_fused_ws_bytes(int B, int C, int HW) {
   const FusedPlan pl = fused_plan(B, C, HW);
-  return pl.ok ? pl.bytes : 0;
+  return pl.ok ? std::max(pl.bytes, fused_state_bytes(B, C, HW)) : 0;
+}
+
+extern "C" int ms_style_fused_plan(int B, int C, int HW, int* threads, int* nv, int* S, int* grid) {
+  const FusedPlan pl = fused_plan(B, C, HW);
+  if (!pl.ok) return MS_ERR_INVALID;
+  if (threads) *threads = pl.threads;
+  if (nv) *nv = pl.nv;
+  if (S) *S = pl.S;
+  if (grid) *grid = pl.grid;
+  return MS_OK;
 }
 
 extern "C" int ms_style_fwd_fused(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
@@ -221,17 +274,35 @@ extern "C" int ms_style_fwd_fused(const float* x, float* y, float* mu, float* si
   if ((gamma_noise == nullptr) != (beta_noise == nullptr)) { set_error("ms_style_fwd_fused: gamma/beta noise must both be given"); return MS_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   int* hdr = (int*)ws;
-  u64* part = (u64*)((char*)ws + pl.part_off);
+  FusedArgs a;
+  a.x = x; a.y = y; a.mu = mu; a.sig = sig; a.gamma_std = gamma_std; a.beta_std = beta_std;
+  a.lmda = lmda; a.gamma_noise = gamma_noise; a.beta_noise = beta_noise; a.perm = perm; a.coefA = coefA; a.coefS = coefS;
+  a.part = (u64*)((char*)ws + pl.part_off); a.arrive = hdr + 2; a.counter = hdr; a.err = hdr + 1;
+  a.compute_std = compute_std; a.B = B; a.C = C; a.HW = HW; a.S = pl.S; a.chunk = pl.chunk; a.nv = pl.nv; a.eps = eps;
+  static const int policy = env_int("MS_STYLE_FUSED_NT", 0);                      // bit 0: nt loads of x, bit 1: nt stores of y (A/B timing)
   dim3 grid(pl.grid), block(pl.threads);
-#define MS_FUSED(NVV, TT) MS_LAUNCH((style_fused_kernel<NVV, TT>), grid, block, 0, st, x, y, mu, sig, gamma_std, beta_std, compute_std, lmda, gamma_noise, \
-                                    beta_noise, perm, coefA, coefS, part, hdr + 2, hdr, hdr + 1, B, C, HW, pl.S, pl.chunk, eps)
-  if (pl.threads == 1024) {
-    switch (pl.nv) { case 16: MS_FUSED(16, 1024); break; case 8: MS_FUSED(8, 1024); break; case 4: MS_FUSED(4, 1024); break;
-                     case 2: MS_FUSED(2, 1024); break; default: MS_FUSED(1, 1024); break; }
-  } else {
-    switch (pl.nv) { case 16: MS_FUSED(16, 256); break; case 8: MS_FUSED(8, 256); break; case 4: MS_FUSED(4, 256); break;
-                     case 2: MS_FUSED(2, 256); break; default: MS_FUSED(1, 256); break; }
-  }
+#define MS_FUSED(TT, AL, AS) MS_LAUNCH((style_fused_kernel<TT, AL, AS>), grid, block, 0, st, a)
+#define MS_FUSED_T(TT) switch (policy & 3) { case 1: MS_FUSED(TT, 2, 0); break; case 2: MS_FUSED(TT, 0, 2); break; case 3: MS_FUSED(TT, 2, 2); break; default: MS_FUSED(TT, 0, 0); }
+  if (pl.threads == 1024) { MS_FUSED_T(1024) } else if (pl.threads == 512) { MS_FUSED_T(512) } else { MS_FUSED_T(256) }
+#undef MS_FUSED_T
 #undef MS_FUSED
   return check_launch("style_fused");
+}
+
+// Error word of the single-read kernel's state block (`ws` as handed to ms_style_fwd_fused): a bounded spin that timed out sets it and the
+// launch's statistics are then invalid.  Device pointer: copy it with the caller's own (asynchronous) D2H, or pass host == 1 for a synchronous read
+// (stream-ordered hipMemcpyAsync + hipStreamSynchronize) that also clears the word.
+extern "C" int ms_style_fused_status(void* ws, int* out, void* stream) {
+  if (ws == nullptr || out == nullptr) { set_error("ms_style_fused_status: null argument"); return MS_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  int* hdr = (int*)ws;
+  hipError_t e = hipMemcpyAsync(out, hdr + 1, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { set_error("ms_style_fused_status: %s", hipGetErrorString(e)); return (int)e; }
+  if (*out != 0) {
+    e = hipMemsetAsync(hdr + 1, 0, sizeof(int), st);
+    if (e != hipSuccess) { set_error("ms_style_fused_status: %s", hipGetErrorString(e)); return (int)e; }
+    set_error("single-read MaxStyle kernel: a bounded spin timed out (the launch did not get the CUs it was sized for); its output is invalid");
+  }
+  return MS_OK;
 }

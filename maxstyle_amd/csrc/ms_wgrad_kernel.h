@@ -19,6 +19,7 @@
 // workgroups that share a channel block in a fixed order (deterministic, no float atomics).
 #pragma once
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 #include "ms_common.h"
 
@@ -515,11 +516,8 @@ int launch_wgrad(WgArgs a, int max_wg, hipStream_t st) {
   using G = WgGeo<KS, S, AB, BB, TW, VEC, QUPS>;
   const size_t lds_bytes = sizeof(float) * (size_t)G::LDS_FLOATS;
   static_assert(sizeof(float) * (size_t)G::LDS_FLOATS <= 160 * 1024, "tile does not fit the LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<KS, S, AB, BB, TW, VEC, QUPS, PM, QM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    attr_set = true;
-  }
+  static std::once_flag attr_once;                     // one flag per instantiation (no unsynchronised mutable state in the ABI)
+  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<KS, S, AB, BB, TW, VEC, QUPS, PM, QM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
   a.tiles_x = cdiv(a.Wp, TW); a.tiles_y = cdiv(a.Hp, G::TH);
   a.ntiles = a.N * a.tiles_x * a.tiles_y;
   const int npm = cdiv(a.M, 16 * AB);

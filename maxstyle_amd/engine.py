@@ -270,6 +270,12 @@ class InnerLoopEngine:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.loss_buf = torch.zeros(64, dtype=F32, device=self.dev)
         self._graph = None
+        self._graph_in = None
+        self._cfg_sig = None
+        self._cfg_cache = {}
+        self._err_pending = None
+        self._ws_state_off = {}
+        self.shared_device = False    # True: other kernels run beside the loop (side streams / other processes): no single-read MaxStyle kernel
         self._prefix_valid = False
         self.labels = None
         self.code = None
@@ -304,7 +310,7 @@ class InnerLoopEngine:
     def t(self, name, *shape, dtype=F32):
         b = self.buf.get(name)
         if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
-            if b is not None and self._graph is not None:
+            if b is not None and self._any_graph():
                 raise RuntimeError(f"buffer {name} would be re-allocated while a captured graph holds its address")
             b = torch.empty(*shape, dtype=dtype, device=self.dev)
             self.buf[name] = b
@@ -312,6 +318,69 @@ class InnerLoopEngine:
 
     def _st(self):
         return torch.cuda.current_stream().cuda_stream
+
+    # ------------------------------------------------------------------ per-signature loop state (flat buffers + captured graph)
+    _CFG_FIELDS = ("layers", "styles", "nparam", "flat_p", "flat_g", "flat_m", "flat_v", "learn_segments", "_graph", "_graph_in", "_cfg_sig")
+
+    def _any_graph(self):
+        return self._graph is not None or any(ent.get("_graph") is not None for ent in self._cfg_cache.values())
+
+    def stash_config(self, sig):
+        """Remember the current style layout (flat parameter / gradient / moment buffers, the captured step) under `sig`.  A later call with the
+        same signature gets it back with `restore_config` - the trainer's random-depth insertion (p = 0.5 per layer, train_adv...py:263) cycles
+        through at most 8 layouts, each captured once."""
+        self._cfg_cache[sig] = {f: getattr(self, f, None) for f in self._CFG_FIELDS}
+
+    def restore_config(self, sig):
+        ent = self._cfg_cache.get(sig)
+        if ent is None:
+            return False
+        for f, v in ent.items():
+            setattr(self, f, v)
+        self.flat_m.zero_(); self.flat_v.zero_(); self.flat_g.zero_()
+        for sl in self.styles.values():
+            sl.have_std = False
+        self._prefix_valid = False
+        return True
+
+    # ------------------------------------------------------------------ error word of the single-read MaxStyle kernel
+    def _error_words(self):
+        """int32 views of the error words of every style workspace of this engine that has a single-read state block."""
+        words = []
+        for name, ws in self.buf.items():
+            if not (name.startswith("st") and name.endswith(".ws")):
+                continue
+            off = self._ws_state_off.get(name)
+            if off is not None:
+                words.append(ws[off + 4:off + 8].view(torch.int32))
+        return words
+
+    def check_errors(self, sync=False):
+        """A bounded spin of the single-read kernel that timed out leaves its statistics invalid and sets an error word in the layer's state block.
+        Product code must never return such a result silently: this queues an asynchronous copy of the words (pinned host buffer + event) and
+        resolves the copy queued by the PREVIOUS call (complete by then: no host stall on the hot path); sync=True waits for the new one too.
+        Raises MaxStyleHipError."""
+        from ._lib import MaxStyleHipError
+        pend = self._err_pending
+        self._err_pending = None
+        if pend is not None:
+            host, ev = pend
+            ev.synchronize()
+            if int(host.abs().sum()) != 0:
+                raise MaxStyleHipError("single-read MaxStyle kernel: a bounded spin timed out (the launch did not get the CUs it was sized for); "
+                                       "the stylised image of the previous call is invalid")
+        words = self._error_words()
+        if not words:
+            return
+        dev_words = torch.cat(words)
+        host = torch.empty(dev_words.numel(), dtype=torch.int32, pin_memory=True)
+        host.copy_(dev_words, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._err_pending = (host, ev)
+        if sync:
+            self.check_errors(sync=False)
+            self._err_pending = None
 
     # ------------------------------------------------------------------ side stream (independent branches of a block)
     class _SideCtx:
@@ -595,12 +664,16 @@ class InnerLoopEngine:
         uf, st, p = self.conv("e.fc.u", h, e["fc0"], stats=True, fin=e["fc1"])
         cff = self.bn_fin("e.fc.bn", st, p, e["fc1"])
         z_i = self._mix(6, self.bn_act("e.z_i", uf, cff, None, 0, 0.0))
+        return z_i, self.decouple_fwd(z_i)
+
+    def decouple_fwd(self, z_i):
+        """Dual_Branch_Encoder.filter_code (encoder_decoder.py:673-675): z_s = code_decoupler(z_i) = ReLU(BN(conv3x3(LeakyReLU(BN(conv3x3(z_i))))))."""
+        e = self.nets.enc
         u1, st, p = self.conv("e.cd.u1", z_i, e["cd0"], stats=True, fin=e["cd1"])
         cf1 = self.bn_fin("e.cd.bn1", st, p, e["cd1"])
         u2, st, p = self.conv("e.cd.u2", u1, e["cd3"], act=(cf1, LEAKY), stats=True, fin=e["cd4"])
         cf2 = self.bn_fin("e.cd.bn4", st, p, e["cd4"])
-        z_s = self.bn_act("e.z_s", u2, cf2, None, 0, 0.0)
-        return z_i, z_s
+        return self.bn_act("e.z_s", u2, cf2, None, 0, 0.0)
 
     def encode_bwd(self, dz_s):
         e, b = self.nets.enc, self.buf
@@ -705,9 +778,12 @@ class InnerLoopEngine:
         stats = self.t(f"st{i}.stats", 4, B, C)          # mu, sig, A, S
         std = self.t(f"st{i}.std", 2, C)                 # gamma_std, beta_std (frozen after the first forward)
         ws = self._style_ws(i, lib.ms_style_ws_bytes(B, C, HW))
+        if f"st{i}.ws" not in self._ws_state_off:
+            self._note_state_offset(i, B, C, HW)
         po = lambda nm: self.flat_p.data_ptr() + 4 * s.off[nm][0]
+        flags = (0 if s.have_std else 1) | (4 if (self.shared_device or self.overlap) else 0)
         check(lib.ms_style_fwd(x.data_ptr(), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), std[0].data_ptr(), std[1].data_ptr(),
-                               0 if s.have_std else 1, po("lmda") if s.mix_style else 0, po("gamma_noise") if s.use_noise else 0,
+                               flags, po("lmda") if s.mix_style else 0, po("gamma_noise") if s.use_noise else 0,
                                po("beta_noise") if s.use_noise else 0, s.perm.data_ptr() if s.mix_style else 0,
                                stats[2].data_ptr(), stats[3].data_ptr(), B, C, HW, s.eps, ws.data_ptr(), ws.numel(), self._st()), f"ms_style_fwd:{i}")
         s.have_std = True
@@ -734,11 +810,15 @@ class InnerLoopEngine:
         """One workspace per layer, zero-filled once: its tail is the persistent epoch state of the single-read kernel (ms_style_ws_bytes)."""
         b = self.buf.get(f"st{i}.ws")
         if b is None or b.numel() < nbytes:
-            if self._graph is not None:
+            if self._any_graph():
                 raise RuntimeError("style workspace would be re-allocated while a captured graph is live")
             b = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.dev)
             self.buf[f"st{i}.ws"] = b
         return b
+
+    def _note_state_offset(self, i, B, C, HW):
+        off = lib.ms_style_ws_state_offset(B, C, HW)
+        self._ws_state_off[f"st{i}.ws"] = None if off == (1 << 64) - 1 else int(off)
 
     def _is_identity(self, i, shape):
         s = self.styles[i]
@@ -835,6 +915,7 @@ class InnerLoopEngine:
     def set_nets(self, nets: PackedNets):
         self.nets = nets
         self._graph = None
+        self._cfg_cache = {}          # captured steps hold the addresses of the previous tables
         self._prefix_valid = False
 
     def run(self, code, labels, n_iter, use_graph=True):

@@ -82,8 +82,15 @@ class res_up_family(nn.Module):
 class _HipNet(nn.Module):
     """Shared plumbing: cached packed weights + an engine per input shape."""
 
+    _weights_epoch = 0      # bumped by writers that bypass torch (the flat optimiser's HIP kernel, raw-pointer running-statistics updates)
+
     def _sd_key(self):
-        return tuple((id(p), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        """Identity of the weights the packed copies were built from: torch-side writes bump `_version`; the flat-buffer optimiser
+        (solver._BankOptimizer.step -> ms_adamw_step) writes through raw pointers and bumps `_weights_epoch` instead."""
+        return (self._weights_epoch,) + tuple((id(p), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def note_weights_changed(self):
+        self._weights_epoch += 1
 
     def _engine(self, spec, B, H, W, dev, pack):
         key = self._sd_key()
@@ -184,7 +191,17 @@ class Dual_Branch_Encoder(_HipNet):
         return self._run(x)[0].clone()
 
     def filter_code(self, z):
-        raise NotImplementedError("use forward(): the engine computes z_i and z_s in one pass")
+        """encoder_decoder.py:673-675: z_s = code_decoupler(z) for a code z that did not come out of this module's own forward."""
+        z = self._check(z)
+        B, _, h, w = z.shape
+        eng, nets = self._engine(self.spec, B, h * 16, w * 16, z.device, lambda sd: E.PackedNets(self.spec, enc_sd=sd))
+        eng.nets = nets
+        eng.bn_eval, track = self._bn_flags()
+        eng.bn_observer = self._observer(track)
+        self._bn_count = _ElemCounts(B, h * 16, w * 16)
+        z_s = eng.decouple_fwd(z)
+        eng.bn_observer = None
+        return z_s.clone()
 
 
 class _ElemCounts(dict):

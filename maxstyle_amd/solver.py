@@ -77,7 +77,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self._packed_key = None
         self.last_style_modules = None
         self.schedulers_dict = {}            # advanced_triplet...py:1070-1081: schedulers exist for SGD only ("No schedulers for optimizers")
-        self.running_metric = None           # created on the first evaluate() (or by set_running_metric()): it lives on the networks' device
+        self.running_metric = self.set_running_metric()       # advanced_triplet...py:93 (the trainer calls .reset() before the first evaluate(), train_adv...py:77)
         self.cur_eval_images = self.cur_eval_predicts = self.cur_eval_gts = None
 
     # ------------------------------------------------------------------ construction (advanced_triplet...py:125-266)
@@ -159,6 +159,27 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self.latent_code['segmentation'] = z_s
         return z_i, z_s
 
+    def filter_code(self, z, disable_track_bn_stats=False):
+        """advanced_triplet...py:347-385 for the FCN families: latent_code_i = z, latent_code_s = image_encoder.filter_code(z)
+        ('w_o_filter': both are z; 'share_code': both are the filtered code)."""
+        if self.network_type.startswith('Unet'):
+            raise NotImplementedError("UNet backbones are outside the MaxStyle path (SURVEY.md 2)")
+        latent_code_i = z
+        if 'w_o_filter' in self.network_type:
+            latent_code_s = z
+        else:
+            enc = self.model['image_encoder']
+            if disable_track_bn_stats:
+                with _disable_tracking_bn_stats(enc):
+                    latent_code_s = enc.filter_code(z)
+            else:
+                latent_code_s = enc.filter_code(z)
+            if 'share_code' in self.network_type:
+                latent_code_i = latent_code_s
+        self.latent_code['image'] = latent_code_i
+        self.latent_code['segmentation'] = latent_code_s
+        return latent_code_i, latent_code_s
+
     def decoder_inference(self, latent_code, decoder_name="", decoder=None, eval=False, disable_track_bn_stats=False):
         if decoder is None:
             try:
@@ -210,8 +231,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     def set_running_metric(self):
         """advanced_triplet...py:1093-1095 (confusion matrix on the GPU: maxstyle_amd.metrics.runningScore)."""
         from .metrics import runningScore
-        dev = next(self.model['image_encoder'].parameters()).device
-        return runningScore(self.num_classes, device=dev)
+        return runningScore(self.num_classes)       # the matrix is created on the device of the first update
 
     def evaluate(self, input, targets_npy, n_iter=None):
         """advanced_triplet...py:914-934: eval-mode prediction of one batch accumulated into self.running_metric; returns the logits."""
@@ -220,7 +240,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         self.eval()
         pred = self.predict(input, n_iter=n_iter)
         targets = torch.as_tensor(targets_npy)
-        self.running_metric.update(label_trues=targets, logits=pred)
+        self.running_metric.update(label_trues=targets, logits=pred)     # argmax fused into the confusion kernel (reference: pred.max(1)[1] on the host)
         self.cur_eval_images = input.detach().cpu().numpy()[:, 0, :, :]
         self.cur_eval_predicts = pred.max(1)[1].cpu().numpy()
         self.cur_eval_gts = targets.cpu().numpy()
@@ -314,26 +334,29 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             mods = {int(k): m for k, m in nn_style_augmentor_dict.items()}
             slots = E.slots_from_modules(mods, code.device)
             layers = [i for i in sorted(mods) if i in slots]
-            sig = self._cfg_sig(layers, slots)
-            if getattr(eng, "_cfg_sig", None) == sig and eng._graph is not None:
-                # same layout as the previous call: keep the flat buffers and the captured graph, reset the optimiser state
-                eng.flat_m.zero_(); eng.flat_v.zero_(); eng.flat_g.zero_()
-                for i in layers:
-                    eng.styles[i].have_std = False
-            else:
+            # everything a captured step bakes in as a launch argument or a kernel choice is part of the signature: the layer layout and flags,
+            # eps, the Adam lr, the loss sign and BatchNorm batch-vs-running statistics (a replay with a different lr / loss weight / mode
+            # silently reused the old arguments).  One captured graph is kept per signature (random-depth insertion alternates between a few).
+            lr_ = float(lr)
+            loss_sign = -float(sum(w_ for w_, t in zip(loss_weights, loss_types) if t == 'seg')) if optimize and n_iter > 0 else -1.0
+            bn_eval = not all(old_state.values())
+            sig = self._cfg_sig(layers, slots) + (lr_, loss_sign, bn_eval)
+            if not eng.restore_config(sig):
                 eng.configure_styles(layers, slots)
-                eng._cfg_sig = sig
+            eng._cfg_sig = sig
             for i in layers:
                 m = mods[i]
                 eng.set_style_state(i, m.perm, m.lmda.detach(), m.gamma_noise.detach(), m.beta_noise.detach())
-            eng.lr = lr
-            eng.loss_sign = -float(sum(w_ for w_, t in zip(loss_weights, loss_types) if t == 'seg')) if optimize and n_iter > 0 else -1.0
-            eng.bn_eval = not all(old_state.values())
+            eng.lr = lr_
+            eng.loss_sign = loss_sign
+            eng.bn_eval = bn_eval
             labels = None
             if optimize and n_iter > 0:
                 labels = reference_segmentation.to(device=code.device, dtype=torch.int64).contiguous()
             steps = n_iter if optimize else 0
             recon_image = eng.run(code, labels, steps, use_graph=use_graph)
+            eng.stash_config(sig)
+            eng.check_errors()                                       # the single-read MaxStyle kernel's error word (spin time-out): never silent
             with torch.no_grad():                                  # hand the optimised state back to the modules (debugging / tests)
                 for i in layers:
                     m = mods[i]
@@ -630,7 +653,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
 
     @staticmethod
     def _cfg_sig(layers, slots):
-        return tuple((i, slots[i].B, slots[i].C, slots[i].mix_style, slots[i].use_noise, slots[i].learn_noise, slots[i].learn_mix) for i in layers)
+        return tuple((i, slots[i].B, slots[i].C, slots[i].mix_style, slots[i].use_noise, slots[i].learn_noise, slots[i].learn_mix, float(slots[i].eps)) for i in layers)
 
 
 class _TrainPassFn(torch.autograd.Function):
@@ -719,3 +742,4 @@ class _BankOptimizer:
         check(lib.ms_adamw_step(b.flat_p.data_ptr() + o, b.flat_g.data_ptr() + o, b.flat_m.data_ptr() + o, b.flat_v.data_ptr() + o, n,
                                 self.lr, 0.9, 0.999, 1e-8, wd, self.step_count, 0, torch.cuda.current_stream().cuda_stream), "ms_adamw_step")
         self.solver._weights_epoch += 1          # packed kernel-layout copies are refreshed in place at the next use
+        self.solver.model[self.net].note_weights_changed()      # ... and the module path (encode_image / predict / evaluate) re-packs too

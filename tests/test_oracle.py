@@ -243,3 +243,65 @@ def test_mixstyle_restatement_vs_reference(golden_dir, tag):
     y.backward(torch.from_numpy(g[f"{tag}.dy"]))
     assert rel(y, g[f"{tag}.y"]) < 1e-6
     assert rel(x.grad, g[f"{tag}.dx"]) < 1e-6
+
+
+# ---- round 2: random-depth insertion (p = 0.5 literal of the trainer) and the loop on trained networks ------------------------------------
+@pytest.mark.parametrize("tag", ["only3", "l45", "none"])
+def test_loop_random_depth_vs_reference(golden_dir, tag):
+    """The oracle's not-applied path (identity, no parameters, no Adam state) against the reference run with injected rand_p
+    (tests/golden/make_golden_r2.py: strict subsets {3}, {4,5}, {} of the inserted layers [3,4,5])."""
+    g = np.load(os.path.join(golden_dir, "loop_random_depth.npz"))
+    applied = set(int(i) for i in g[f"{tag}.applied"])
+    spec = orc.NetSpec(4, 1, 4)
+    W = orc.procedural_weights(spec, 0)
+    img, lab = orc.synthetic_batch(4, 64, 1, 4, 1234)
+    layers = [3, 4, 5]
+    styles = {i: orc.random_style_state(4, spec.channel_num[i], 7 + i, applied=(i in applied)) for i in layers}
+    with torch.no_grad():
+        z_i, _ = orc.encoder_forward(W["image_encoder"], img)
+    tr = orc.InnerLoopTrace()
+    out = orc.generate_max_style_image(W, z_i, styles, layers, lab, n_iter=2, lr=0.1, trace=tr)
+    ref_losses = g[f"{tag}.losses"]
+    assert len(tr.losses) == len(ref_losses)
+    if applied:
+        assert abs(tr.losses[0] - ref_losses[0]) < 1e-5 * abs(ref_losses[0])
+        np.testing.assert_allclose(tr.losses, ref_losses, rtol=5e-3)
+        assert rel(out, g[f"{tag}.image"]) < 2e-2          # free-running after one lr*sign(g) step: loose (parity_util)
+    else:
+        assert rel(out, g[f"{tag}.image"]) < 1e-5
+
+
+def _trained_weights(golden_dir, dtype):
+    z = np.load(os.path.join(golden_dir, "trained_fcn16.npz"))
+    W = {"image_encoder": {}, "segmentation_decoder": {}, "image_decoder": {}}
+    for key in z.files:
+        net, name = key.split("/", 1)
+        a = z[key]
+        t = torch.from_numpy(a.astype(np.float32) if a.dtype == np.float16 else a)
+        W[net][name] = t.to(dtype) if t.is_floating_point() else t
+    return W
+
+
+def test_loop_on_trained_networks_fp64_matches_reference(golden_dir):
+    """Networks trained by the reference's own training step (fixture trained_fcn16.npz): the fp64 oracle reproduces the reference's fp64 K=5 loop,
+    its Dice values and its predictions; the fixture's Dice is meaningful (clean >= 0.65 per class, stylised lower)."""
+    g = np.load(os.path.join(golden_dir, "loop_trained.npz"))
+    W = _trained_weights(golden_dir, torch.float64)
+    spec = orc.NetSpec(4, 1, 4)
+    img, lab = orc.synthetic_batch(4, 64, 1, 4, 777)
+    layers = [3, 4, 5]
+    styles = {i: orc.random_style_state(4, spec.channel_num[i], 7 + i, torch.float64) for i in layers}
+    with torch.no_grad():
+        z_i, z_s = orc.encoder_forward(W["image_encoder"], img.double())
+        clean_pred = orc.decoder_forward(W["segmentation_decoder"], z_s, "NN").argmax(1)
+    assert rel(z_i, g["f64.z_i"]) < 1e-10
+    np.testing.assert_allclose(orc.dice_per_class(clean_pred, lab, 4), g["f64.clean_dice"], atol=1e-12)
+    tr = orc.InnerLoopTrace()
+    out = orc.generate_max_style_image(W, z_i, styles, layers, lab, n_iter=5, lr=0.1, trace=tr)
+    np.testing.assert_allclose(tr.losses, g["f64.losses"], rtol=1e-8)
+    assert rel(out, g["f64.image"]) < 1e-7
+    with torch.no_grad():
+        _, zs2 = orc.encoder_forward(W["image_encoder"], out)
+        pred = orc.decoder_forward(W["segmentation_decoder"], zs2, "NN").argmax(1)
+    np.testing.assert_allclose(orc.dice_per_class(pred, lab, 4), g["f64.final_dice"], atol=1e-12)
+    assert min(g["f64.clean_dice"]) > 0.6 and max(g["f64.final_dice"]) < min(g["f64.clean_dice"])

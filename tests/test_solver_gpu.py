@@ -29,14 +29,28 @@ def make_solver(dev, spec_o):
 
 
 def injector(styles, dev):
+    """Overwrite the random state of freshly built MaxStyle modules.  With the trainer's p = 0.5 the construction-time draw decides whether a
+    module owns Parameters at all (maxstyle.py:62-73): a module that drew the other branch is re-drawn with p forced, then the state is set."""
     def hook(mod_dict):
         for k, m in mod_dict.items():
             st = styles[int(k)]
+            has = "gamma_noise" in m._parameters
+            if st.applied and not has:
+                p0, m.p = m.p, 2.0
+                m.init_parameters()
+                m.p = p0
+            elif not st.applied and has:
+                for n in ("gamma_noise", "beta_noise", "lmda"):
+                    m._parameters.pop(n, None)
+                p0, m.p = m.p, -1.0
+                m.init_parameters()
+                m.p = p0
             m.perm = st.perm.clone(); m.rand_p = torch.tensor([0.0 if st.applied else 1.0])
-            with torch.no_grad():
-                m.gamma_noise.data = st.gamma_noise.float().to(dev)
-                m.beta_noise.data = st.beta_noise.float().to(dev)
-                m.lmda.data = st.lmda.float().to(dev)
+            if st.applied:
+                with torch.no_grad():
+                    m.gamma_noise.data = st.gamma_noise.float().to(dev)
+                    m.beta_noise.data = st.beta_noise.float().to(dev)
+                    m.lmda.data = st.lmda.float().to(dev)
     return hook
 
 

@@ -30,7 +30,8 @@ def main():
     a = torch.empty(64 * 1024 * 1024, device=dev); b = torch.empty_like(a)
     t = timeit(lambda: b.copy_(a), args.iters)
     out["copy_256MB_GBps"] = 2 * a.numel() * 4 / t / 1e9
-    shapes = {"L3": (16, 16, 128, 128), "L4": (16, 16, 256, 256), "L5": (16, 1, 256, 256), "C4_L4": (16, 64, 320, 320)}
+    shapes = {"L3": (16, 16, 128, 128), "L4": (16, 16, 256, 256), "L5": (16, 1, 256, 256), "C4_L3": (16, 64, 160, 160), "C4_L4": (16, 64, 320, 320),
+              "C4_L5": (16, 3, 320, 320)}
     if args.only:
         shapes = {k: v for k, v in shapes.items() if k in args.only.split(",")}
     for name, shape in shapes.items():
