@@ -244,7 +244,7 @@ def dice_parity(dev):
     out = eng.run(z_i, lab_d, K, use_graph=False).clone()
     eng.seg_loss(out, lab_d, need_grad=False, need_logits=True)
     rs = runningScore(4, dev)
-    rs.update(lab_d, eng.buf["s.logits"])
+    rs.update(lab_d, logits=eng.buf["s.logits"])
     gpu_dice = rs.dice()
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     st = {i: orc.StyleState(s.perm.clone(), s.lmda.clone(), s.gamma_noise.clone(), s.beta_noise.clone()) for i, s in styles.items()}

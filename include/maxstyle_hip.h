@@ -124,6 +124,15 @@ int ms_conv2d(const float* in, const float* in2, float* out, const float* w_pack
               int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
               int epi_mode, float* stats, void* stream);
 
+/* Tail of a residual block in one launch (res_convdown / res_up_family: `last_act(conv_input(x) + conv(x))`, encoder_decoder.py:62-64, 344-346):
+ * the 1x1 skip convolution `conv_input` (packed weights, bias) whose epilogue reads the raw output `u` [N,Cout,H',W'] of the block's second 3x3
+ * convolution, applies that layer's BatchNorm record coef4 = {scale, shift, ..} per channel and the LeakyReLU:
+ *     out = lrelu((scale*u + shift) + (conv1x1(in) + bias)).
+ * Replaces ms_conv2d(ks=1) + ms_bn_act(res_mode 1 / 2) - the skip tensor is never written (2 HBM passes and one launch less per block); same
+ * arithmetic, bit for bit.  up2 = 1: `in` has HALF the resolution of u / out (up_type 'NN': nn.UpsamplingNearest2d commutes with a 1x1 conv). */
+int ms_conv1x1_bnres(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
+                     const float* u, const float* coef4, float slope, int up2, void* stream);
+
 /* ms_conv2d whose output is the gradient w.r.t. an activation LeakyReLU_act_slope(coef4[c].scale*u + coef4[c].shift) that the forward pass
  * never materialised (it was folded into the next convolution's prologue: encoder_decoder.py:44-46, 62-64): the epilogue multiplies by the
  * activation's derivative and accumulates, per output channel, {sum g, sum g*(u - coef4[c].mean)} - the result of

@@ -73,7 +73,7 @@ extern "C" size_t ms_conv_stats_bytes(int N, int Cout, int Hout, int Wout) {
   return ((size_t)Cout * ms_conv_stats_parts(N, Hout, Wout) + 1) * sizeof(float4);      // + header record
 }
 
-struct MaskEpi { const float* u; const float* coef4; float slope; float* tab; };
+struct MaskEpi { const float* u; const float* coef4; float slope; float* tab; int mode = 3; };     // mode 3: activation-backward epilogue; 4 / 5: residual-block tail
 struct FinEpi { int* counter; float* out; const float* gamma; const float* beta; float eps; double count; };
 
 static int conv2d_impl(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
@@ -82,7 +82,13 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
                        int epi_mode, float* stats, const MaskEpi* mk, const FinEpi* fin, void* stream) {
   if (N < 1 || Cin < 1 || Cout < 1 || Hs < 1 || Ws < 1) { set_error("ms_conv2d: invalid shape"); return MS_ERR_INVALID; }
   if (pro_mode < 0 || pro_mode > 3 || epi_mode < 0 || epi_mode > 2 || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
-  if (mk != nullptr) {
+  if (mk != nullptr && mk->mode != 3) {
+    if (epi_mode != 0 || stats != nullptr || ks != 1 || stride != 1 || fetch != 0 || pro_mode != 0 || mk->u == nullptr || mk->coef4 == nullptr ||
+        !aligned16(mk->u) || !aligned16(mk->coef4) || !aligned16(out)) {
+      set_error("ms_conv1x1_bnres: 1x1 stride-1 conv without prologue; u, coef4 and out 16-byte aligned"); return MS_ERR_INVALID;
+    }
+    epi_mode = mk->mode;
+  } else if (mk != nullptr) {
     if (epi_mode != 0 || stats != nullptr || mk->u == nullptr || mk->coef4 == nullptr || mk->tab == nullptr || !aligned16(mk->u) || !aligned16(mk->coef4) || !aligned16(out)) {
       set_error("ms_conv2d_actbwd: needs u, coef4 and tab (16-byte aligned) and a plain epilogue"); return MS_ERR_INVALID;
     }
@@ -158,6 +164,7 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   }
   a.ncb = cdiv(gemm_cols, 16 * nt);
   { static const int dbg = getenv("MS_CONV_DBG") ? atoi(getenv("MS_CONV_DBG")) : 0; a.dbg = dbg; }
+  { static const int stag = getenv("MS_CONV_STAGGER") ? atoi(getenv("MS_CONV_STAGGER")) : 0; a.stagger = tune && getenv("MS_CONV_STAGGER") ? atoi(getenv("MS_CONV_STAGGER")) : stag; }
   { static const char* tr = getenv("MS_CONV_TRACE"); a.trace = tr ? (long long*)strtoull(tr, nullptr, 0) : nullptr; }
   hipStream_t st = (hipStream_t)stream;
   const bool use_in2 = (pro_mode == 2);
@@ -182,6 +189,13 @@ extern "C" int ms_conv2d_fin(const float* in, const float* in2, float* out, cons
   const FinEpi fin{counter, coef4, gamma, beta, eps, 0.0};
   return conv2d_impl(in, in2, out, w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
                      0, stats, nullptr, &fin, stream);
+}
+
+extern "C" int ms_conv1x1_bnres(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
+                                const float* u, const float* coef4, float slope, int up2, void* stream) {
+  MaskEpi mk{u, coef4, slope, nullptr};
+  mk.mode = up2 ? 5 : 4;
+  return conv2d_impl(in, nullptr, out, w_packed, bias, N, Cin, Hs, Ws, Cout, 1, 1, 0, 0, nullptr, nullptr, nullptr, 0, 1, 1.0f, 0, nullptr, &mk, nullptr, stream);
 }
 
 extern "C" size_t ms_conv_actbwd_tab_bytes(int Cout) { return ((size_t)Cout * kStatSlots + 1) * sizeof(float2); }

@@ -1,4 +1,4 @@
-// Instantiations: wide-read 3x3 stride-1 convolution (ms_conv_wide.h).
+// Instantiations: wide-read 3x3 stride-1 convolution (ms_conv_wide.h), 4-row tiles; the 8-row tiles are in ms_conv_inst_w2.hip.
 #include "ms_conv_wide.h"
 namespace ms {
 bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool vec) {
@@ -16,12 +16,13 @@ bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool v
 template <int NT>
 static int wide_pro(const ConvArgs& a, hipStream_t st) {
   switch (a.pro_mode) {
-    case 0: return launch_conv_wide<NT, 0>(a, st);
-    case 1: return launch_conv_wide<NT, 1>(a, st);
-    default: return launch_conv_wide<NT, 2>(a, st);
+    case 0: return launch_conv_wide_r<NT, 0, 1>(a, st);
+    case 1: return launch_conv_wide_r<NT, 1, 1>(a, st);
+    default: return launch_conv_wide_r<NT, 2, 1>(a, st);
   }
 }
 int conv_dispatch_wide(const ConvArgs& a, int nt, hipStream_t st) {
+  if (conv_wide_rows(a, nt >= 2 ? 2 : 1) == 8) return conv_dispatch_wide8(a, nt, st);
   return nt >= 2 ? wide_pro<2>(a, st) : wide_pro<1>(a, st);
 }
 }  // namespace ms

@@ -32,9 +32,11 @@ struct ConvArgs {
   int N, Cin, Hs, Ws, Hin, Win, Cout, Hout, Wout, cin_pad, cout_pad;
   int pro_mode, pro_nstride, pro_cstride; float slope;
   int epi_mode, tiles_x, tiles_y, cout_real, ncb;   // ncb: number of output-channel blocks (of 16*NT)
+  int stagger;                  // wide kernel: the second workgroup of a CU starts `stagger` x ~1k cycles late (0 = off), see conv_wide_kernel
   int dbg;                      // timing-only ablation bits (MS_CONV_DBG): 1 skip MFMA loop, 2 skip global loads, 4 skip epilogue stores, 8 skip LDS stores, 16 skip the epilogue
   int bw_parts; double bw_count; float* bw_out;   // pro_mode 3 (host side): BatchNorm-backward coefficients are derived in-kernel from bw_parts partial sums per channel
   long long* trace;             // MS_CONV_TRACE_BUILD only: cycle stamps of workgroup 0 (tools/trace_conv.py)
+  // epi_mode 4 / 5 (ms_conv1x1_bnres): residual-block tail, out = lrelu(sc*mk_u + sh + conv); 5 = the conv ran at half resolution (see the epilogue)
   // epi_mode 3 (ms_conv2d_actbwd): the output is the gradient w.r.t. an activation lrelu(sc*u + sh) that was never materialised; the epilogue
   // applies its derivative and accumulates the BatchNorm-backward sums (sum g, sum g*(u - mean)) of u's layer: what ms_act_bwd_reduce does in its own pass
   const float* mk_u; const float* mk_coef; float mk_slope; float* mk_tab;   // u [N,Cout,Hout,Wout]; coef float4 [Cout] {sc,sh,mean,invstd}; tab float2 [1 + Cout*kStatSlots]
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
       int bidx = co;
       if (a.epi_mode == 2) bidx = co % a.cout_real;
       bias_v[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[bidx] : 0.f;
-      if (a.epi_mode == 3) {
+      if (a.epi_mode >= 3) {
         const float4 cf = (co < a.Cout) ? reinterpret_cast<const float4*>(a.mk_coef)[co] : make_float4(0.f, 0.f, 0.f, 0.f);
         mk_sc[j] = cf.x; mk_sh[j] = cf.y; mk_mu[j] = cf.z;
       }
@@ -636,6 +638,64 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
           s2 += (v[0] * (uu[0] - mk_mu[j]) + v[1] * (uu[1] - mk_mu[j])) + (v[2] * (uu[2] - mk_mu[j]) + v[3] * (uu[3] - mk_mu[j]));
         }
         st_mean[j] += s1; st_m2[j] += s2;
+      }
+    } else if (a.epi_mode == 4 || a.epi_mode == 5) {
+      // Tail of a residual block in ONE launch (encoder_decoder.py:62-64, 344-346: last_act(conv_input(x) + conv(x))): this launch is the 1x1 skip
+      // convolution; its epilogue reads the raw output u of the block's second 3x3 conv, applies that layer's BatchNorm (sc, sh) and the activation:
+      //   out = lrelu((sc*u + sh) + (acc + bias))          - the arithmetic of ms_bn_act on a materialised skip tensor, bit for bit.
+      // mode 5: the skip conv ran at HALF resolution (a 1x1 conv commutes with nearest up-sampling): every value feeds a 2x2 block of outputs.
+      const bool up2 = (a.epi_mode == 5);
+      const int Ho = up2 ? 2 * a.Hout : a.Hout, Wo = up2 ? 2 * a.Wout : a.Wout;
+      const bool vec4 = (a.Wout % 4 == 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = co0 + j * 16 + m;
+        if (co >= a.Cout) continue;
+        const float sc = mk_sc[j], sh = mk_sh[j];
+        const size_t pb = ((size_t)n * a.Cout + co) * Ho * Wo;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int y = oy0 + mt_row(i);
+          const int x = ox0 + mt_col(i) + xq;
+          if (y >= a.Hout || x >= a.Wout) continue;
+          if (!up2) {
+            const size_t off = pb + (size_t)y * Wo + x;
+            if (vec4) {
+              const float4 t = *reinterpret_cast<const float4*>(a.mk_u + off);
+              float4 o;
+              o.x = leaky((sc * t.x + sh) + acc[i][j][0], a.mk_slope); o.y = leaky((sc * t.y + sh) + acc[i][j][1], a.mk_slope);
+              o.z = leaky((sc * t.z + sh) + acc[i][j][2], a.mk_slope); o.w = leaky((sc * t.w + sh) + acc[i][j][3], a.mk_slope);
+              *reinterpret_cast<float4*>(a.out + off) = o;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (x + r < a.Wout) a.out[off + r] = leaky((sc * a.mk_u[off + r] + sh) + acc[i][j][r], a.mk_slope);
+            }
+          } else {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+              const size_t off = pb + (size_t)(2 * y + dy) * Wo + 2 * x;
+              if (vec4) {
+                const float4 t0 = *reinterpret_cast<const float4*>(a.mk_u + off), t1 = *reinterpret_cast<const float4*>(a.mk_u + off + 4);
+                float4 o0, o1;
+                o0.x = leaky((sc * t0.x + sh) + acc[i][j][0], a.mk_slope); o0.y = leaky((sc * t0.y + sh) + acc[i][j][0], a.mk_slope);
+                o0.z = leaky((sc * t0.z + sh) + acc[i][j][1], a.mk_slope); o0.w = leaky((sc * t0.w + sh) + acc[i][j][1], a.mk_slope);
+                o1.x = leaky((sc * t1.x + sh) + acc[i][j][2], a.mk_slope); o1.y = leaky((sc * t1.y + sh) + acc[i][j][2], a.mk_slope);
+                o1.z = leaky((sc * t1.z + sh) + acc[i][j][3], a.mk_slope); o1.w = leaky((sc * t1.w + sh) + acc[i][j][3], a.mk_slope);
+                *reinterpret_cast<float4*>(a.out + off) = o0;
+                *reinterpret_cast<float4*>(a.out + off + 4) = o1;
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  if (x + r < a.Wout) {
+                    a.out[off + 2 * r] = leaky((sc * a.mk_u[off + 2 * r] + sh) + acc[i][j][r], a.mk_slope);
+                    a.out[off + 2 * r + 1] = leaky((sc * a.mk_u[off + 2 * r + 1] + sh) + acc[i][j][r], a.mk_slope);
+                  }
+                }
+              }
+            }
+          }
+        }
       }
     } else if (a.epi_mode == 2 && NT >= 2 && (a.cout_real == 16 || (a.cout_real == 32 && NT == 4)) && (a.Wout % 4 == 0) &&
                ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0)) {

@@ -21,14 +21,17 @@
 
 namespace ms {
 
-template <int NT, int PRO>
+// R = output rows per MFMA wave: tile height TH = 4*R.  R = 2 (8-row tiles) stages 10 input rows for 8 output rows instead of 6 for 4 (halo overhead
+// 1.29 instead of 1.55: 17 % less work for the staging waves, which bound the two-tensor variants), re-uses each A window for two output rows
+// (4 window reads per channel group instead of 6) and each B fragment twice, and halves the barriers per FLOP; it needs enough tiles to fill the chip.
+template <int NT, int PRO, int R = 1>
 struct WideGeo {
-  static constexpr int TH = 4, TW = 64;
+  static constexpr int TH = 4 * R, TW = 64;
   // input channels per K-chunk: two stage buffers, two workgroups per CU; the two-tensor prologue stages twice the registers per channel
   static constexpr int CK = 8;   // measured: 8-channel chunks beat 16 for every variant (60.8 vs 62.1 us at 16->16 @256^2; the two-tensor prologue spills with 16)
   static constexpr int IH = TH + 2;
   static constexpr int RS = TW + 4;                           // LDS row: column 0 = left halo (x0-1), 1..64 interior, 65 = right halo
-  static constexpr int PS = 448;                              // >= IH*RS = 408, == 0 (mod 64): conflict-free ds_read_b128 of the A windows
+  static constexpr int PS = (IH * RS + 63) / 64 * 64;         // >= IH*RS (408 -> 448, 680 -> 704), == 0 (mod 64): conflict-free ds_read_b128 of the A windows
   static constexpr int WS = (NT == 1) ? 16 : NT * 16 + 16;    // weight row stride (bank-conflict-free B fragments)
   static constexpr int BUF = CK * PS + 9 * CK * WS;           // floats per stage buffer
   static constexpr int Q_ITEMS = CK * IH * (TW / 4);          // interior 16-byte items
@@ -38,10 +41,13 @@ struct WideGeo {
   static constexpr int NWI = (W_ITEMS + 255) / 256;
 };
 
+// census of workgroup arrivals per CU (stagger experiment): which of the two co-resident workgroups am I?  Timing only - never read for results.
+static __device__ int g_cu_census[1024];
+
 // PRO: 0 none, 1 BatchNorm apply + LeakyReLU, 2 BatchNorm backward (two tensors)
-template <int NT, int PRO>
+template <int NT, int PRO, int R>
 __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const ConvArgs a) {
-  using G = WideGeo<NT, PRO>;
+  using G = WideGeo<NT, PRO, R>;
   constexpr int TH = G::TH, TW = G::TW, CK = G::CK, IH = G::IH, RS = G::RS, PS = G::PS, WS = G::WS, BUF = G::BUF;
   constexpr int NQI = G::NQI, NHI = G::NHI, NWI = G::NWI, COUT_TILE = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -55,6 +61,21 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   const int T = my_items * nchunks;
   auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   auto decode = [&](int it, int& n, int& tile, int& cb) { cb = it % ncb; const int t2 = it / ncb; tile = t2 % ntiles; n = t2 / ntiles; };
+
+  if (a.stagger > 0) {
+    // Two workgroups share a CU and run the same program: left alone they stay in lockstep - both in their MFMA phase (matrix pipe contended),
+    // then both in their epilogue (matrix pipe idle).  The workgroup that arrives second on its CU starts late by a fraction of an item so that one's
+    // epilogue / staging overlaps the other's MFMA phase (MI355X_MICROARCH.md "Two waves per SIMD", item 9: stagger).
+    __shared__ int s_slot;
+    if (threadIdx.x == 0) {
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+      const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+      const unsigned key = ((xcc & 7u) << 7) | ((hw >> 8) & 0x7Fu);
+      s_slot = atomicAdd(&g_cu_census[key], 1) & 1;
+    }
+    __syncthreads();
+    if (s_slot) for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
 
   if (producer) {
     // =========================================== PRODUCER waves ===========================================
@@ -258,21 +279,28 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   // (no s_setprio here: the STAGING waves get the priority - measured 290.7 -> 295.2 steps/s against the opposite choice; a staging wave that
   //  loses issue arbitration to back-to-back MFMAs is what the MFMA waves end up waiting for at the barrier)
   const int m = lane & 15, k = lane >> 4;
-  f32x4 acc[4][NT];                                     // [pixel-in-quad i][channel block j]: rows = lane-local pixel quads r
+  f32x4 acc[R][4][NT];                                  // [row of this wave][pixel-in-quad i][channel block j]: rows = lane-local pixel quads
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int a_lane = k * PS + wave * RS + 4 * m;       // window of row (wave + ky): columns 4m .. 4m+5
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[r][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int a_lane = k * PS + (R * wave) * RS + 4 * m;  // window of staged row (R*wave + s): columns 4m .. 4m+5
   const int b_lane = CK * PS + k * WS + m;
 
-  // one pipeline step = (4-channel group cg, kernel row ky): 2 wide A reads + 3*NT B reads feed 12*NT MFMAs
-  auto step_load = [&](const float* buf, int st, float (&win)[6], float (&bf)[3][NT]) {
-    const int cg = st / 3, ky = st % 3;
-    const float* q = buf + a_lane + cg * 4 * PS + ky * RS;
+  // one pipeline step = (4-channel group cg, staged row s of this wave's R+2): ONE window (ds_read_b128 + ds_read_b64) feeds output row r with kernel
+  // row ky = s - r for every r it is valid for: 12*NT MFMAs for the first and last staged row, 24*NT in between (R = 2).  The B fragments of kernel
+  // row ky are read once per channel group (3*NT ds_read_b32) and used by every output row.  Per accumulator the order of the K loop is (cg, ky, kx):
+  // the same as with R = 1, so the two tile heights give bit-identical results.
+  constexpr int NS = R + 2;
+  auto load_win = [&](const float* buf, int cg, int st, float (&win)[6]) {
+    const float* q = buf + a_lane + cg * 4 * PS + st * RS;
     const float4 v = *reinterpret_cast<const float4*>(q);
     const float2 w = *reinterpret_cast<const float2*>(q + 4);
     win[0] = v.x; win[1] = v.y; win[2] = v.z; win[3] = v.w; win[4] = w.x; win[5] = w.y;
+  };
+  auto load_b = [&](const float* buf, int cg, int ky, float (&bf)[3][NT]) {
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -281,27 +309,43 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   // FULL = every channel group of the chunk is live: straight-line code; the guarded form only runs for a layer's ragged last chunk
   auto compute = [&](const float* buf, auto full_tag, int ncg) {
     constexpr bool FULL = decltype(full_tag)::value;
-    const int nst = ncg * 3;
-    float win[2][6], bf[2][3][NT];
-    step_load(buf, 0, win[0], bf[0]);
+    float win[2][6], bfr[3][3][NT];
+    load_win(buf, 0, 0, win[0]);
+    load_b(buf, 0, 0, bfr[0]);
 #pragma unroll
-    for (int st = 0; st < (CK / 4) * 3; ++st) {
-      if (FULL || st < nst) {
-        if (st + 1 < (CK / 4) * 3 && (FULL || st + 1 < nst)) step_load(buf, st + 1, win[(st + 1) & 1], bf[(st + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int cg = 0; cg < CK / 4; ++cg) {
+      if (FULL || cg < ncg) {
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+        for (int st = 0; st < NS; ++st) {
+          const int t = cg * NS + st;
+          if (st + 1 < NS) {
+            load_win(buf, cg, st + 1, win[(t + 1) & 1]);
+            if (st + 1 < 3) load_b(buf, cg, st + 1, bfr[st + 1]);
+          } else if (cg + 1 < CK / 4 && (FULL || cg + 1 < ncg)) {
+            load_win(buf, cg + 1, 0, win[(t + 1) & 1]);
+            load_b(buf, cg + 1, 0, bfr[0]);                // kernel row 0 of this group was last used at staged row R - 1
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int r = 0; r < R; ++r) {
+            const int ky = st - r;
+            if (ky >= 0 && ky < 3) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(win[st & 1][i + kx], bf[st & 1][kx][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+              for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                  for (int j = 0; j < NT; ++j)
+                    acc[r][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(win[t & 1][i + kx], bfr[ky][kx][j], acc[r][i][j], 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   };
 
-  // ---- epilogue: a lane holds, per channel block, 16 consecutive pixels (16k .. 16k+15) of row `wave` of the tile for channel m ----
+  // ---- epilogue: a lane holds, per output row of its wave and channel block, 16 consecutive pixels (16k .. 16k+15) of tile row R*wave + rr for channel m ----
   float st_n = 0.f, st_mean[NT], st_m2[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) { st_mean[j] = 0.f; st_m2[j] = 0.f; }
@@ -321,122 +365,148 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       }
     }
   };
-  // epi_mode 3 with one channel block per lane: the 16 values of u this lane masks with are requested BEFORE the MFMA loop of the item's
-  // last K-chunk, so the epilogue does not wait for them (loading them inside the epilogue cost ~10 us per launch at 16->16 @16x256x256)
-  constexpr bool UPRE = (NT == 1);
-  float4 upre[4];
+  // epi_mode 3 with one channel block per lane: the 16 values of u this lane masks with (per output row) are requested BEFORE the MFMA loop of the
+  // item's last K-chunk, so the epilogue does not wait for them (loading them inside the epilogue cost ~10 us per launch at 16->16 @16x256x256)
+  constexpr bool UPRE = (NT == 1 && R == 1);
+  float4 upre[UPRE ? R : 1][4];
   auto prefetch_u = [&](int n, int tile, int co0) {
+    if constexpr (!UPRE) return;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const int y = ty * TH + wave, xb = tx * TW + 16 * k;
+    const int xb = tx * TW + 16 * k;
     const int co = co0 + m;
-    const int nvalid = (y < a.Hout && co < a.Cout) ? max(0, min(16, a.Wout - xb)) : 0;
-    const size_t off = (((size_t)n * a.Cout + co) * a.Hout + y) * a.Wout + xb;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      upre[r] = (4 * r < nvalid) ? *reinterpret_cast<const float4*>(a.mk_u + off + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int rr = 0; rr < R; ++rr) {
+      const int y = ty * TH + R * wave + rr;
+      const int nvalid = (y < a.Hout && co < a.Cout) ? max(0, min(16, a.Wout - xb)) : 0;
+      const size_t off = (((size_t)n * a.Cout + co) * a.Hout + y) * a.Wout + xb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        upre[UPRE ? rr : 0][r] = (4 * r < nvalid) ? *reinterpret_cast<const float4*>(a.mk_u + off + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   };
   auto epilogue = [&](int n, int tile, int co0) {
     if (a.dbg & 16) {                                    // timing-only: no epilogue at all (upper bound of what hiding it can gain)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[rr][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       return;
     }
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const int y = ty * TH + wave, xb = tx * TW + 16 * k;
-    const bool row_ok = y < a.Hout;
-    int nvalid = 0;                                      // valid pixels among this lane's 16 (Wout % 4 == 0 on this path)
-    if (row_ok) nvalid = max(0, min(16, a.Wout - xb));
+    const int xb = tx * TW + 16 * k;
+    // epi_mode 3 without the early prefetch (8-row tiles: no registers to park 2 x 16 values across the MFMA loop): request the u values of EVERY
+    // row of this wave up front, so that their latency is paid once per item and overlaps the first row's arithmetic
+    float4 ulate[(!UPRE && NT == 1) ? R : 1][4];
+    if (!UPRE && NT == 1 && a.epi_mode == 3) {
+      const int co = co0 + m;
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+      for (int rr = 0; rr < R; ++rr) {
+        const int y = ty * TH + R * wave + rr;
+        const int nv = (y < a.Hout && co < a.Cout) ? max(0, min(16, a.Wout - xb)) : 0;
+        const size_t off = (((size_t)n * a.Cout + co) * a.Hout + y) * a.Wout + xb;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 4; ++r)
+          ulate[rr][r] = (4 * r < nv) ? *reinterpret_cast<const float4*>(a.mk_u + off + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] += bias_v[j];
-    if (a.stats != nullptr && nvalid > 0) {
-      // PER-LANE running (count, mean, M2) of this lane's 16-pixel groups, Chan-merged group by group; the four lanes that share a channel are
-      // merged once, at the end of the kernel.  (The first version reduced every tile across those lanes: six dependent ds_bpermute round trips
-      // and two IEEE divisions per tile = ~2 k cycles of epilogue per item on an idle CU - tools/trace_conv.py with MS_CONV_DBG=15.)
-      const float cnt = (float)nvalid;
-      const float rc = (nvalid == 16) ? 0.0625f : __builtin_amdgcn_rcpf(cnt);
-      const float nt_ = st_n + cnt;
-      const float wgt = cnt * __builtin_amdgcn_rcpf(nt_);       // merge weight to 1 ulp: enters as d*wgt and d*d*n*wgt, both second-order terms
-      const bool all16 = (nvalid == 16);
+    for (int rr = 0; rr < R; ++rr) {
+      const int y = ty * TH + R * wave + rr;
+      const bool row_ok = y < a.Hout;
+      int nvalid = 0;                                      // valid pixels among this lane's 16 (Wout % 4 == 0 on this path)
+      if (row_ok) nvalid = max(0, min(16, a.Wout - xb));
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        float s0 = 0.f, s1 = 0.f;
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (all16) { s0 += acc[0][j][r] + acc[1][j][r]; s1 += acc[2][j][r] + acc[3][j][r]; }
-          else if (4 * r < nvalid) { s0 += acc[0][j][r] + acc[1][j][r]; s1 += acc[2][j][r] + acc[3][j][r]; }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[rr][i][j][r] += bias_v[j];
+      if (a.stats != nullptr && nvalid > 0) {
+        // PER-LANE running (count, mean, M2) of this lane's 16-pixel groups, Chan-merged group by group; the four lanes that share a channel are
+        // merged once, at the end of the kernel.  (The first version reduced every tile across those lanes: six dependent ds_bpermute round trips
+        // and two IEEE divisions per tile = ~2 k cycles of epilogue per item on an idle CU - tools/trace_conv.py with MS_CONV_DBG=15.)
+        const float cnt = (float)nvalid;
+        const float rc = (nvalid == 16) ? 0.0625f : __builtin_amdgcn_rcpf(cnt);
+        const float nt_ = st_n + cnt;
+        const float wgt = cnt * __builtin_amdgcn_rcpf(nt_);       // merge weight to 1 ulp: enters as d*wgt and d*d*n*wgt, both second-order terms
+        const bool all16 = (nvalid == 16);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (all16 || 4 * r < nvalid) { s0 += acc[rr][0][j][r] + acc[rr][1][j][r]; s1 += acc[rr][2][j][r] + acc[rr][3][j][r]; }
+          }
+          const float mean = (s0 + s1) * rc;
+          float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (all16 || 4 * r < nvalid) {
+              const float d0 = acc[rr][0][j][r] - mean, d1 = acc[rr][1][j][r] - mean, d2 = acc[rr][2][j][r] - mean, d3 = acc[rr][3][j][r] - mean;
+              q0 += d0 * d0 + d1 * d1; q1 += d2 * d2 + d3 * d3;
+            }
+          }
+          const float d = mean - st_mean[j];
+          st_mean[j] += d * wgt;
+          st_m2[j] += (q0 + q1) + d * d * st_n * wgt;
         }
-        const float mean = (s0 + s1) * rc;
-        float q0 = 0.f, q1 = 0.f;
+        st_n = nt_;
+      }
+      if (a.epi_mode == 3) {
+        // g = acc * lrelu'(sc*u + sh); running sums of g and g*(u - mean) per channel in st_mean / st_m2 (act_bwd_reduce_kernel<1>)
+        if (row_ok) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (all16 || 4 * r < nvalid) {
-            const float d0 = acc[0][j][r] - mean, d1 = acc[1][j][r] - mean, d2 = acc[2][j][r] - mean, d3 = acc[3][j][r] - mean;
-            q0 += d0 * d0 + d1 * d1; q1 += d2 * d2 + d3 * d3;
+          for (int j = 0; j < NT; ++j) {
+            const int co = co0 + j * 16 + m;
+            if (co >= a.Cout) continue;
+            const size_t off = (((size_t)n * a.Cout + co) * a.Hout + y) * a.Wout + xb;
+            float4 uu[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (UPRE) uu[r] = upre[UPRE ? rr : 0][r];                   // fetched before the item's last K-chunk (prefetch_u)
+              else if (NT == 1) uu[r] = ulate[rr][r];          // fetched at the top of this epilogue
+              else if (4 * r < nvalid) uu[r] = *reinterpret_cast<const float4*>(a.mk_u + off + 4 * r);
+            }
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (4 * r < nvalid) {
+                float4 v;
+                v.x = acc[rr][0][j][r] * ((mk_sc[j] * uu[r].x + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+                v.y = acc[rr][1][j][r] * ((mk_sc[j] * uu[r].y + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+                v.z = acc[rr][2][j][r] * ((mk_sc[j] * uu[r].z + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+                v.w = acc[rr][3][j][r] * ((mk_sc[j] * uu[r].w + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+                *reinterpret_cast<float4*>(a.out + off + 4 * r) = v;
+                s1 += (v.x + v.y) + (v.z + v.w);
+                s2 += (v.x * (uu[r].x - mk_mu[j]) + v.y * (uu[r].y - mk_mu[j])) + (v.z * (uu[r].z - mk_mu[j]) + v.w * (uu[r].w - mk_mu[j]));
+              }
+            }
+            st_mean[j] += s1; st_m2[j] += s2;
           }
         }
-        const float d = mean - st_mean[j];
-        st_mean[j] += d * wgt;
-        st_m2[j] += (q0 + q1) + d * d * st_n * wgt;
-      }
-      st_n = nt_;
-    }
-    if (a.epi_mode == 3) {
-      // g = acc * lrelu'(sc*u + sh); running sums of g and g*(u - mean) per channel in st_mean / st_m2 (act_bwd_reduce_kernel<1>)
-      if (row_ok) {
+      } else if (row_ok && !(a.dbg & 4)) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int co = co0 + j * 16 + m;
           if (co >= a.Cout) continue;
-          const size_t off = (((size_t)n * a.Cout + co) * a.Hout + y) * a.Wout + xb;
-          float4 uu[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (UPRE) uu[r] = upre[r];                     // fetched before the item's last K-chunk (prefetch_u)
-            else if (4 * r < nvalid) uu[r] = *reinterpret_cast<const float4*>(a.mk_u + off + 4 * r);
-          }
-          float s1 = 0.f, s2 = 0.f;
+          float* op = a.out + (((size_t)n * a.Cout + co) * a.Hout + y) * a.Wout + xb;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (4 * r < nvalid) {
-              float4 v;
-              v.x = acc[0][j][r] * ((mk_sc[j] * uu[r].x + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
-              v.y = acc[1][j][r] * ((mk_sc[j] * uu[r].y + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
-              v.z = acc[2][j][r] * ((mk_sc[j] * uu[r].z + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
-              v.w = acc[3][j][r] * ((mk_sc[j] * uu[r].w + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
-              *reinterpret_cast<float4*>(a.out + off + 4 * r) = v;
-              s1 += (v.x + v.y) + (v.z + v.w);
-              s2 += (v.x * (uu[r].x - mk_mu[j]) + v.y * (uu[r].y - mk_mu[j])) + (v.z * (uu[r].z - mk_mu[j]) + v.w * (uu[r].w - mk_mu[j]));
+              float4 v = make_float4(acc[rr][0][j][r], acc[rr][1][j][r], acc[rr][2][j][r], acc[rr][3][j][r]);
+              if (a.epi_mode == 1) { const float4 p = *reinterpret_cast<const float4*>(op + 4 * r); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+              *reinterpret_cast<float4*>(op + 4 * r) = v;
             }
           }
-          st_mean[j] += s1; st_m2[j] += s2;
         }
       }
-    } else if (row_ok && !(a.dbg & 4)) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int co = co0 + j * 16 + m;
-        if (co >= a.Cout) continue;
-        float* op = a.out + (((size_t)n * a.Cout + co) * a.Hout + y) * a.Wout + xb;
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (4 * r < nvalid) {
-            float4 v = make_float4(acc[0][j][r], acc[1][j][r], acc[2][j][r], acc[3][j][r]);
-            if (a.epi_mode == 1) { const float4 p = *reinterpret_cast<const float4*>(op + 4 * r); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
-            *reinterpret_cast<float4*>(op + 4 * r) = v;
-          }
-        }
-      }
+        for (int j = 0; j < NT; ++j) acc[rr][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
   int item = vb, chunk = 0, n, tile, cb;
@@ -478,24 +548,35 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   else if (a.epi_mode == 3) conv_table_tail<NT, false>(a, smem, vb, ncb, 0.f, st_mean, st_m2);
 }
 
-template <int NT, int PRO>
-int launch_conv_wide(ConvArgs a, hipStream_t st) {
-  using G = WideGeo<NT, PRO>;
+template <int NT, int PRO, int R>
+int launch_conv_wide_r(ConvArgs a, hipStream_t st) {
+  using G = WideGeo<NT, PRO, R>;
   const size_t lds_bytes = sizeof(float) * 2 * (size_t)G::BUF;
   static std::once_flag attr_once;                     // one flag per instantiation; the attribute itself is immutable afterwards
-  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
+  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
   a.tiles_x = cdiv(a.Wout, G::TW); a.tiles_y = cdiv(a.Hout, G::TH);
   a.ncb = cdiv(a.Cout, 16 * NT);
   const long nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb;
   const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;
-  MS_LAUNCH((conv_wide_kernel<NT, PRO>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
+  MS_LAUNCH((conv_wide_kernel<NT, PRO, R>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
   return check_launch("conv_wide");
+}
+
+// tile height: 8 rows when that still leaves every resident workgroup >= 2 work items (the 256^2 / 320^2 levels), else 4 rows.
+// MS_CONV_WIDE_ROWS=4|8 forces one (A/B timing; the results are bit-identical).
+inline int conv_wide_rows(const ConvArgs& a, int nt) {
+  static const int force = getenv("MS_CONV_WIDE_ROWS") ? atoi(getenv("MS_CONV_WIDE_ROWS")) : 0;
+  if (force == 4 || force == 8) return force;
+  if (nt != 1) return 4;                 // (two channel blocks per lane x two rows per wave need 188 registers: one workgroup per CU - not built for it yet)
+  const long items8 = (long)a.N * cdiv(a.Wout, 64) * cdiv(a.Hout, 8) * cdiv(a.Cout, 16 * nt);
+  return (items8 >= 4L * num_cus()) ? 8 : 4;
 }
 
 // wide-read path: 3x3 stride 1, plain fetch, 16-byte aligned rows, per-channel prologue coefficients; implemented in ms_conv_inst_w.hip
 bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool vec);
 int conv_dispatch_wide(const ConvArgs& a, int nt, hipStream_t st);
+int conv_dispatch_wide8(const ConvArgs& a, int nt, hipStream_t st);      // ms_conv_inst_w2.hip: the 8-row tiles
 
 }  // namespace ms

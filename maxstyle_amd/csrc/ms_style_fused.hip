@@ -209,24 +209,29 @@ static FusedPlan fused_plan(int B, int C, int HW) {
   const int cus = num_cus();
   static const int force_threads = env_int("MS_STYLE_FUSED_THREADS", 0);        // A/B switches for tools/bench_kernels.py
   static const int force_split = env_int("MS_STYLE_FUSED_SPLIT", 0);
-  const int cand[3] = {1024, 512, 256};
-  for (int k = 0; k < 3; ++k) {
-    const int threads = cand[k];
+  // candidates in order of preference.  Measured on MI355X at 16x16x256x256 (kernel-trace medians): 512-thread workgroups, two per CU, 25.8 us
+  // (one's stores overlap the other's loads) against 27.0 us for one 1024-thread workgroup per CU and 30 us for four of 256; so: 512 threads
+  // when the planes already give every slot a unit, else 1024 threads (fewer, fatter units), else split planes into chunks.
+  struct Cand { int threads; bool split; };
+  const Cand cand[4] = {{512, false}, {1024, true}, {512, true}, {256, true}};
+  for (int k = 0; k < 4; ++k) {
+    const int threads = cand[k].threads;
     if (force_threads && threads != force_threads) continue;
     const int per_cu = 1024 / threads;                                            // workgroups per CU at <= 128 VGPRs (4 waves per SIMD)
     const long resident = (long)cus * per_cu;
     const int max_chunk = threads * 4 * kFusedNV;
     int S = cdiv(HW, max_chunk);
     // split planes further while the tensor has fewer units than the chip has workgroup slots (small C: layer 5 has 16 planes)
-    while ((long)B * C * S < resident && (long)B * (S * 2) <= resident && HW / (S * 2) >= threads * 4 && B * S * 2 <= 1024) S *= 2;
+    if (cand[k].split || force_threads)
+      while ((long)B * C * S < resident && (long)B * (S * 2) <= resident && HW / (S * 2) >= threads * 4 && B * S * 2 <= 1024) S *= 2;
     if (force_split) S = std::max(S, force_split);
     int chunk = (cdiv(HW, S) + 3) / 4 * 4;
     S = cdiv(HW, chunk);
     const int nv = cdiv(chunk, threads * 4);
     const long G = (long)B * S;
     if (nv > kFusedNV || G > resident || G > 1024) continue;
-    const bool last = (k == 2) || force_threads;
-    if (!last && (long)B * C * S < resident) continue;                            // a thinner workgroup fills more CUs
+    const bool last = (k == 3) || force_threads;
+    if (!last && (long)B * C * S < resident) continue;                            // the next candidate fills more CUs
     pl.threads = threads; pl.nv = nv; pl.chunk = chunk; pl.S = S;
     pl.grid = (int)std::min<long>((long)C * G, resident);                         // never more than fit the chip together
     pl.part_off = 16;                                                             // [0] epoch, [1] error word, [2] arrivals

@@ -300,6 +300,9 @@ class InnerLoopEngine:
         # 512 workgroups finish together, so publish -> arrive (one counter word, ~88 arrivals/us) -> reduce by one workgroup is ~13 us of serial
         # device-scope round trips at the end of every such conv.  Off by default (MS_FUSE_BNFIN=1 turns it on; results are identical).
         self.fuse_bn_fin = os.environ.get("MS_FUSE_BNFIN", "0") != "0"
+        # tail of a residual block as ONE launch: the 1x1 skip conv applies BatchNorm + residual add + LeakyReLU of the block in its epilogue
+        # (ms_conv1x1_bnres) instead of ms_conv2d(ks=1) -> skip tensor -> ms_bn_act; MS_FUSE_SKIP=0 is the A/B switch (bit-identical results)
+        self.fuse_skip = os.environ.get("MS_FUSE_SKIP", "1") != "0"
         self._side_stream = None
         self._side_pending = False
         # MixStyle / DSU layers inside the encoder (generate_style_augmented_latent_code, advanced_triplet...py:632-670):
@@ -581,16 +584,25 @@ class InnerLoopEngine:
             src, _, _ = self.conv(pfx + ".xd", x, net[key + ".down"], stride=2)
         else:
             fetch = ops.FETCH_UPS2
+        fused_tail = self.fuse_skip and not self.overlap
         # the 1x1 skip convolution only depends on the block input: with `overlap` it runs on the side stream (see __init__ for the measurement)
-        with self._side(after_main=True):
-            if kind == "nn":
-                s, _, _ = self.conv(pfx + ".s", x, ci)          # conv1x1 commutes with nearest up-sampling: low resolution
-            else:
-                s, _, _ = self.conv(pfx + ".s", src, ci)
+        if not fused_tail:
+            with self._side(after_main=True):
+                if kind == "nn":
+                    s, _, _ = self.conv(pfx + ".s", x, ci)          # conv1x1 commutes with nearest up-sampling: low resolution
+                else:
+                    s, _, _ = self.conv(pfx + ".s", src, ci)
         u1, st1, p1 = self.conv(pfx + ".u1", src, c0, fetch=fetch, stats=True, fin=net[key + ".bn1"])
         cf1 = self.bn_fin(pfx + ".bn1", st1, p1, net[key + ".bn1"])
         u2, st2, p2 = self.conv(pfx + ".u2", u1, c3, act=(cf1, LEAKY), stats=True, fin=net[key + ".bn4"])
         cf2 = self.bn_fin(pfx + ".bn4", st2, p2, net[key + ".bn4"])
+        if fused_tail:
+            xin = x if kind == "nn" else src
+            N, Cin, Hs, Ws = xin.shape
+            out = self.t(pfx + ".out", *u2.shape)
+            check(lib.ms_conv1x1_bnres(xin.data_ptr(), out.data_ptr(), ci.wp.data_ptr(), 0 if ci.b is None else ci.b.data_ptr(), N, Cin, Hs, Ws, ci.cout,
+                                       u2.data_ptr(), cf2.data_ptr(), LEAKY, 1 if kind == "nn" else 0, self._st()), "ms_conv1x1_bnres:" + pfx)
+            return out
         self._join_side()
         out = self.bn_act(pfx + ".out", u2, cf2, s, 2 if kind == "nn" else 1, LEAKY)
         return out
@@ -810,7 +822,7 @@ class InnerLoopEngine:
         """One workspace per layer, zero-filled once: its tail is the persistent epoch state of the single-read kernel (ms_style_ws_bytes)."""
         b = self.buf.get(f"st{i}.ws")
         if b is None or b.numel() < nbytes:
-            if self._any_graph():
+            if b is not None and self._any_graph():
                 raise RuntimeError("style workspace would be re-allocated while a captured graph is live")
             b = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.dev)
             self.buf[f"st{i}.ws"] = b

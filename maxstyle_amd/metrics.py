@@ -23,6 +23,8 @@ class runningScore:
             self.cm.zero_()
 
     def update(self, label_trues, label_preds=None, logits=None):
+        if logits is None and torch.is_tensor(label_preds) and label_preds.dim() == 4 and label_preds.is_floating_point():
+            logits, label_preds = label_preds, None          # [N,K,H,W] scores in the second position
         if logits is None:
             if label_preds is None:
                 raise TypeError("update() needs label_preds (label maps) or logits")

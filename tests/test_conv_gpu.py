@@ -303,3 +303,30 @@ def test_last_workgroup_finalises(dev, N, Cin, Cout, H, W, ks, stride):
             assert torch.equal(gm2, gm)
             assert float((bc - ref_bc).abs().max()) <= 1e-6 * float(ref_bc.abs().max()), float((bc - ref_bc).abs().max())
             assert int(counter) == 0
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,up2", [(2, 16, 16, 32, 32, 0), (2, 16, 32, 64, 64, 0), (1, 5, 7, 9, 11, 0), (2, 128, 64, 16, 16, 0), (3, 64, 32, 8, 24, 0),
+                                                (2, 16, 16, 32, 32, 1), (2, 128, 64, 8, 8, 1), (1, 20, 24, 9, 14, 1), (1, 6, 5, 7, 9, 1)])
+def test_conv1x1_bnres_block_tail(dev, N, Cin, Cout, H, W, up2):
+    """ms_conv1x1_bnres: the residual block's tail `lrelu(bn(u) + conv_input(x))` (encoder_decoder.py:62-64, 344-346) as one launch - against fp64 math
+    and, bit for bit, against the two launches it replaces (ms_conv2d ks=1 -> ms_bn_act)."""
+    from maxstyle_amd import ops
+    from maxstyle_amd._lib import lib, check
+    x = _rand((N, Cin, H, W), 1); w = _rand((Cout, Cin, 1, 1), 2, 0.2); b = _rand((Cout,), 3)
+    Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
+    u = _rand((N, Cout, Ho, Wo), 4)
+    coef = torch.stack([_rand((Cout,), 5).abs() + 0.5, _rand((Cout,), 6), torch.zeros(Cout), torch.ones(Cout)], dim=1).contiguous()
+    s = F.conv2d(x.double(), w.double(), b.double())
+    if up2:
+        s = F.interpolate(s, scale_factor=2, mode="nearest")
+    ref = F.leaky_relu(coef[:, 0].double().view(1, -1, 1, 1) * u.double() + coef[:, 1].double().view(1, -1, 1, 1) + s, 0.2)
+    xd, ud, cd, bd = x.to(dev), u.to(dev), coef.to(dev), b.to(dev)
+    wp = ops.pack_conv_weight(w.to(dev))
+    out = torch.empty(N, Cout, Ho, Wo, device=dev)
+    check(lib.ms_conv1x1_bnres(xd.data_ptr(), out.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, ud.data_ptr(), cd.data_ptr(), 0.2, up2,
+                               torch.cuda.current_stream().cuda_stream), "ms_conv1x1_bnres")
+    assert rel(out, ref) < 3e-6
+    sd = ops.conv2d(xd, wp, bd, Cout, 1, 1)
+    two = torch.empty_like(out)
+    check(lib.ms_bn_act(ud.data_ptr(), cd.data_ptr(), sd.data_ptr(), 2 if up2 else 1, two.data_ptr(), N, Cout, Ho, Wo, 0.2, torch.cuda.current_stream().cuda_stream), "ms_bn_act")
+    assert torch.equal(out, two), "the fused tail must reproduce conv1x1 + bn_act bit for bit"

@@ -281,3 +281,18 @@ def test_config2_full_size_step_vs_oracle(dev):
     for i in layers:
         assert rel(eng.buf[f"st{i}.std"][0], sty[i].gamma_std.reshape(-1)) < 2e-5
         assert rel(eng.buf[f"st{i}.std"][1], sty[i].beta_std.reshape(-1)) < 5e-5
+
+
+def test_fused_block_tail_is_bit_identical(dev):
+    """engine.fuse_skip (ms_conv1x1_bnres) against the unfused launch pair on a whole inner step: same bits everywhere."""
+    from oracle import maxstyle_oracle as orc
+    layers = [3, 4, 5]
+    outs = []
+    for fuse in (True, False):
+        eng, W, img, lab, styles = build_engine(dev, orc.NetSpec(4, 1, 4), 4, 64, layers)
+        eng.fuse_skip = fuse
+        z_i, _ = eng.encode_fwd(img.to(dev))
+        out = eng.run(z_i.clone(), lab.to(dev), 3, use_graph=False).clone()
+        outs.append((out, eng.losses(3).clone(), eng.flat_p.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)

@@ -73,18 +73,18 @@ def test_captured_graph_follows_lr_loss_weight_and_bn_mode(dev):
     layers = [3, 4, 5]
     styles = {i: orc.random_style_state(4, spec.channel_num[i], 7 + i) for i in layers}
 
-    def fresh(mode_eval, **kw):
-        S, _ = make_solver(dev, spec)
-        if mode_eval:
-            for m in S.model.values():
-                m.eval()
-        S.style_init_hook = injector(styles, dev)
-        z_i, _ = S.encode_image(img.to(dev), disable_track_bn_stats=True)
-        return S.generate_max_style_image(z_i, layers, spec.channel_num, p=1.5, n_iter=3, reference_image=img.to(dev), reference_segmentation=lab.to(dev), **kw)
-
     S, _ = make_solver(dev, spec)
     S.style_init_hook = injector(styles, dev)
-    z_i, _ = S.encode_image(img.to(dev), disable_track_bn_stats=True)
+    z_i, _ = S.encode_image(img.to(dev), disable_track_bn_stats=True)          # ONE code (train-mode encoder) for every variant below
+
+    def fresh(mode_eval, **kw):
+        S2, _ = make_solver(dev, spec)
+        if mode_eval:
+            for m in S2.model.values():
+                m.eval()
+        S2.style_init_hook = injector(styles, dev)
+        return S2.generate_max_style_image(z_i, layers, spec.channel_num, p=1.5, n_iter=3, reference_image=img.to(dev), reference_segmentation=lab.to(dev), **kw)
+
     kw = dict(p=1.5, n_iter=3, reference_image=img.to(dev), reference_segmentation=lab.to(dev))
     a = S.generate_max_style_image(z_i, layers, spec.channel_num, lr=0.1, **kw)
     b = S.generate_max_style_image(z_i, layers, spec.channel_num, lr=0.02, **kw)

@@ -251,7 +251,7 @@ def test_gpu_dice_and_confusion(dev):
     assert torch.equal(rs.confusion_matrix().cpu(), cm)
     np.testing.assert_allclose(rs.dice(), orc.dice_per_class(pred, lab, 4), atol=1e-12)
     scores, iou = rs.get_scores()
-    assert abs(scores["Overall Acc"] - float((pred == lab).double().mean())) < 1e-12
+    assert abs(scores['Overall Acc: \t'] - float((pred == lab).double().mean())) < 1e-12
     rs.update(lab.to(dev), logits.to(dev))                     # accumulates
     assert int(rs.confusion_matrix().sum()) == 2 * lab.numel()
 

@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT"
 for cfg in "0 0" "0 1" "0 2" "0 3" "512 0" "256 0" "512 3"; do
   set -- $cfg
   echo "== MS_STYLE_FUSED_THREADS=$1 MS_STYLE_FUSED_NT=$2"
-  MS_STYLE_FUSED_THREADS=$1 MS_STYLE_FUSED_NT=$2 python tools/bench_kernels.py --iters 50 2>&1 | python -c "
+  MS_STYLE_FUSED_THREADS=$1 MS_STYLE_FUSED_NT=$2 python tools/bench_kernels.py --iters 50 2>gpurun_out/sweep_err.txt | python -c "
 import sys, json
 d = json.load(sys.stdin)
 print('copy GB/s %.0f' % d.pop('copy_256MB_GBps'))
@@ -14,7 +14,7 @@ for k, v in d.items():
 "
 done
 echo "== three-launch path (MS_STYLE_FUSED=0)"
-MS_STYLE_FUSED=0 python tools/bench_kernels.py --iters 50 2>&1 | python -c "
+MS_STYLE_FUSED=0 python tools/bench_kernels.py --iters 50 2>gpurun_out/sweep_err.txt | python -c "
 import sys, json
 d = json.load(sys.stdin)
 d.pop('copy_256MB_GBps')

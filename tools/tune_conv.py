@@ -66,6 +66,25 @@ def main():
         e1.synchronize()
         return e0.elapsed_time(e1) / reps * 1e3
 
+    if len(sys.argv) > 2 and sys.argv[2] == "stagger":
+        # sweep the wide kernel's workgroup stagger (MS_CONV_STAGGER, read per call under MS_CONV_TUNE) on every distinct wide-kernel call
+        vals = [0, 2, 4, 6, 8, 12]
+        print(f"{'call':16s} {'N,Cin,Hs,Ws,Cout':>22s} pm epi st cnt " + " ".join(f"stag{v:>3d}" for v in vals))
+        tot = [0.0] * len(vals)
+        for key, (cnt, a) in sorted(seen.items(), key=lambda kv: -kv[1][0]):
+            name, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pm, epi, stats = key
+            if not (ks == 3 and stride == 1 and fetch == 0 and Ws >= 64):
+                continue
+            ts = []
+            for v in vals:
+                os.environ["MS_CONV_STAGGER"] = str(v)
+                ts.append(time_call(name, a))
+            os.environ["MS_CONV_STAGGER"] = "0"
+            for i, t in enumerate(ts):
+                tot[i] += cnt * t
+            print(f"{name[3:]:16s} {str((N, Cin, Hs, Ws, Cout)):>22s} {pm:2d} {epi:3d} {int(stats):2d} {cnt:3d} " + " ".join(f"{t:7.1f}" for t in ts))
+        print("per-step totals (us): " + " ".join(f"{t:7.0f}" for t in tot))
+        return
     rows = []
     total_auto = total_best = 0.0
     for key, (cnt, a) in seen.items():
