@@ -124,6 +124,18 @@ int ms_conv2d(const float* in, const float* in2, float* out, const float* w_pack
               int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
               int epi_mode, float* stats, void* stream);
 
+/* Sub-pixel form of the two x2 resampling convolutions (csrc/ms_conv_subpix.h): same results as ms_conv2d with fetch = 1 / 2 to fp32 rounding, without
+ * multiplying the duplicates / zeros the resampling inserts (2.25x / 4x fewer matrix instructions).  in [N,Cin,Hs,Ws] (Ws % 4 == 0), out [N,Cout,2Hs,2Ws].
+ *   mode 0: nn.UpsamplingNearest2d(2) -> nn.Conv2d(3x3,p=1) (encoder_decoder.py:298-300, 323-337); w_packed = the FORWARD packed weights, bias optional,
+ *           stats = optional BatchNorm statistics table of the outputs (ms_conv_stats_bytes);
+ *   mode 1: data-gradient of nn.Conv2d(3x3,s=2,p=1) (res_convdown.down, encoder_decoder.py:40); `in` = dY [N,Cout_fwd,Hs,Ws], w_packed = the
+ *           DATA-GRADIENT packed weights, Cout = Cin_fwd.  With ref != NULL the epilogue also does what ms_act_bwd_reduce would do on the result:
+ *           out = dX * lrelu'(ref) (ref = the materialised activation output [N,Cout,2Hs,2Ws]) and tab gets the sums of out and out*(u - mean) per channel
+ *           (u = that activation's raw BatchNorm input, coef4 = its {scale, shift, mean, invstd}; table as ms_conv2d_actbwd: ms_conv_actbwd_tab_bytes). */
+int ms_conv_subpix_eligible(int Hs, int Ws);
+int ms_conv_subpix(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int mode,
+                   float* stats, const float* ref, const float* u, const float* coef4, float act_slope, float* tab, void* stream);
+
 /* Tail of a residual block in one launch (res_convdown / res_up_family: `last_act(conv_input(x) + conv(x))`, encoder_decoder.py:62-64, 344-346):
  * the 1x1 skip convolution `conv_input` (packed weights, bias) whose epilogue reads the raw output `u` [N,Cout,H',W'] of the block's second 3x3
  * convolution, applies that layer's BatchNorm record coef4 = {scale, shift, ..} per channel and the LeakyReLU:

@@ -53,6 +53,8 @@ SIGNATURES = {
     "ms_act_bwd_reduce": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_float, c_void]),
     "ms_act_bwd_bn": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_void, c_f32p, c_int, c_int, c_int, c_float, c_void]),
     "ms_conv1x1_bnres": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_float, c_int, c_void]),
+    "ms_conv_subpix_eligible": (c_int, [c_int, c_int]),
+    "ms_conv_subpix": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_void]),
     "ms_conv_actbwd_tab_bytes": (ctypes.c_size_t, [c_int]),
     "ms_conv2d_actbwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_f32p, c_f32p, c_f32p, c_int, c_int, ctypes.c_float, c_f32p, c_f32p, ctypes.c_float, c_f32p, c_void]),

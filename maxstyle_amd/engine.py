@@ -303,6 +303,9 @@ class InnerLoopEngine:
         # tail of a residual block as ONE launch: the 1x1 skip conv applies BatchNorm + residual add + LeakyReLU of the block in its epilogue
         # (ms_conv1x1_bnres) instead of ms_conv2d(ks=1) -> skip tensor -> ms_bn_act; MS_FUSE_SKIP=0 is the A/B switch (bit-identical results)
         self.fuse_skip = os.environ.get("MS_FUSE_SKIP", "1") != "0"
+        # the two x2 resampling convolutions in their sub-pixel form (ms_conv_subpix: no products with the duplicates / zeros the resampling inserts);
+        # MS_SUBPIX=0 is the A/B switch (results agree to fp32 rounding: the up-sampling form pre-adds the taps that meet on one stored pixel)
+        self.subpix = os.environ.get("MS_SUBPIX", "1") != "0"
         self._side_stream = None
         self._side_pending = False
         # MixStyle / DSU layers inside the encoder (generate_style_augmented_latent_code, advanced_triplet...py:632-670):
@@ -572,6 +575,31 @@ class InnerLoopEngine:
         check(lib.ms_pool2_sum(x.data_ptr(), out.data_ptr(), N * C, H // 2, W // 2, 1 if accumulate else 0, self._st()), "ms_pool2_sum:" + name)
         return out
 
+    def conv_ups2(self, name, x, cw: ConvW, fin=None):
+        """nn.UpsamplingNearest2d(2) -> 3x3 conv (+ BatchNorm statistics of the outputs): sub-pixel kernel when eligible, else the fused-fetch conv."""
+        N, Cin, Hs, Ws = x.shape
+        if not (self.subpix and lib.ms_conv_subpix_eligible(Hs, Ws)) or (self.fuse_bn_fin and not self.bn_eval):
+            return self.conv(name, x, cw, fetch=ops.FETCH_UPS2, stats=True, fin=fin)
+        out = self.t(name, N, cw.cout, 2 * Hs, 2 * Ws)
+        st, parts = None, N * 4 * Hs * Ws
+        if not self.bn_eval:
+            parts = lib.ms_conv_stats_parts(N, 2 * Hs, 2 * Ws)
+            st = self.t(name + ".stats", cw.cout * parts + 1, 4)
+        check(lib.ms_conv_subpix(x.data_ptr(), out.data_ptr(), cw.wp.data_ptr(), 0 if cw.b is None else cw.b.data_ptr(), N, Cin, Hs, Ws, cw.cout, 0,
+                                 0 if st is None else st.data_ptr(), 0, 0, 0, 1.0, 0, self._st()), "ms_conv_subpix(ups2):" + name)
+        return out, st, parts
+
+    def dgrad_s2(self, name, g, cw: ConvW):
+        """Data-gradient of the 3x3 stride-2 conv `cw` (res_convdown.down): sub-pixel kernel when eligible, else the zero-insertion conv."""
+        N, Cg, Hs, Ws = g.shape
+        if not (self.subpix and lib.ms_conv_subpix_eligible(Hs, Ws)):
+            dx, _, _ = self.conv(name, g, cw, ks=3, stride=1, fetch=ops.FETCH_ZINS2, dgrad=True)
+            return dx
+        out = self.t(name, N, cw.cin, 2 * Hs, 2 * Ws)
+        check(lib.ms_conv_subpix(g.data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), 0, N, Cg, Hs, Ws, cw.cin, 1, 0, 0, 0, 0, 1.0, 0, self._st()),
+              "ms_conv_subpix(s2 dgrad):" + name)
+        return out
+
     # ------------------------------------------------------------------ residual blocks
     def res_fwd(self, pfx, net, key, x, kind):
         """encoder_decoder.py:22-74 (kind 'down') / :289-357 (kind 'convT' = up_type Conv2, 'nn' = up_type NN)."""
@@ -592,7 +620,10 @@ class InnerLoopEngine:
                     s, _, _ = self.conv(pfx + ".s", x, ci)          # conv1x1 commutes with nearest up-sampling: low resolution
                 else:
                     s, _, _ = self.conv(pfx + ".s", src, ci)
-        u1, st1, p1 = self.conv(pfx + ".u1", src, c0, fetch=fetch, stats=True, fin=net[key + ".bn1"])
+        if kind == "nn":
+            u1, st1, p1 = self.conv_ups2(pfx + ".u1", src, c0, fin=net[key + ".bn1"])
+        else:
+            u1, st1, p1 = self.conv(pfx + ".u1", src, c0, fetch=fetch, stats=True, fin=net[key + ".bn1"])
         cf1 = self.bn_fin(pfx + ".bn1", st1, p1, net[key + ".bn1"])
         u2, st2, p2 = self.conv(pfx + ".u2", u1, c3, act=(cf1, LEAKY), stats=True, fin=net[key + ".bn4"])
         cf2 = self.bn_fin(pfx + ".bn4", st2, p2, net[key + ".bn4"])
@@ -631,7 +662,7 @@ class InnerLoopEngine:
         if kind == "convT":
             dx, _, _ = self.conv(pfx + ".dx", dsrc, net[key + ".up"], ks=2, stride=2, dgrad=True)
         else:
-            dx, _, _ = self.conv(pfx + ".dx", dsrc, net[key + ".down"], ks=3, stride=1, fetch=ops.FETCH_ZINS2, dgrad=True)
+            dx = self.dgrad_s2(pfx + ".dx", dsrc, net[key + ".down"])
         return dx
 
     # ------------------------------------------------------------------ MixStyle layers between the encoder blocks

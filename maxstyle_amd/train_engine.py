@@ -220,6 +220,11 @@ class TrainEngine(InnerLoopEngine):
             self._last_count = out.shape[0] * out.shape[2] * out.shape[3]      # elements per channel the following BatchNorm sees
         return out, st, parts
 
+    def conv_ups2(self, name, x, cw, fin=None):
+        out, st, parts = super().conv_ups2(name, x, cw, fin=fin)
+        self._last_count = out.shape[0] * out.shape[2] * out.shape[3]
+        return out, st, parts
+
     def bn_fin(self, name, st, parts, bn):
         coef = super().bn_fin(name, st, parts, bn)
         if self.track and not self.bn_eval:
@@ -363,7 +368,7 @@ class TrainEngine(InnerLoopEngine):
             self.channel_sum(dsrc, self._gb(net, key + ".down"))
             if not need_dx:
                 return None
-            dx, _, _ = self.conv(pfx + ".dx", dsrc, tbl[key + ".down"], ks=3, stride=1, fetch=ops.FETCH_ZINS2, dgrad=True)
+            dx = self.dgrad_s2(pfx + ".dx", dsrc, tbl[key + ".down"])
         return dx
 
     def backward_pass(self, image, labels, clean, g_seg: float, g_rec: float):

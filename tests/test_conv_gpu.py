@@ -330,3 +330,69 @@ def test_conv1x1_bnres_block_tail(dev, N, Cin, Cout, H, W, up2):
     two = torch.empty_like(out)
     check(lib.ms_bn_act(ud.data_ptr(), cd.data_ptr(), sd.data_ptr(), 2 if up2 else 1, two.data_ptr(), N, Cout, Ho, Wo, 0.2, torch.cuda.current_stream().cuda_stream), "ms_bn_act")
     assert torch.equal(out, two), "the fused tail must reproduce conv1x1 + bn_act bit for bit"
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 16, 16, 16, 16), (2, 64, 32, 8, 8), (1, 128, 64, 5, 12), (3, 32, 16, 24, 40), (2, 20, 24, 9, 36), (16, 16, 16, 128, 128)])
+def test_subpixel_upsample_conv(dev, N, Cin, Cout, H, W):
+    """ms_conv_subpix mode 0 == nn.UpsamplingNearest2d(2) -> Conv2d(3x3, p=1) (encoder_decoder.py:298-300, 323-337) incl. the BatchNorm statistics of the outputs."""
+    from maxstyle_amd import ops
+    from maxstyle_amd._lib import lib, check
+    x = _rand((N, Cin, H, W), 1); w = _rand((Cout, Cin, 3, 3), 2, 0.1); b = _rand((Cout,), 3)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+    xd, bd = x.to(dev), b.to(dev)
+    wp = ops.pack_conv_weight(w.to(dev))
+    out = torch.empty(N, Cout, 2 * H, 2 * W, device=dev)
+    stats, parts = ops.conv_stats_buffer(N, Cout, 2 * H, 2 * W, dev)
+    assert lib.ms_conv_subpix_eligible(H, W) == 1
+    check(lib.ms_conv_subpix(xd.data_ptr(), out.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, 0, stats.data_ptr(), 0, 0, 0, 1.0, 0,
+                             torch.cuda.current_stream().cuda_stream), "ms_conv_subpix")
+    assert rel(out, ref) < 3e-6
+    gamma, beta = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+    coef = torch.empty(Cout, 4, device=dev)
+    check(lib.ms_bn_finalize(stats.data_ptr(), parts, gamma.data_ptr(), beta.data_ptr(), 1e-5, coef.data_ptr(), Cout, torch.cuda.current_stream().cuda_stream), "fin")
+    mean = ref.mean(dim=(0, 2, 3)); var = ref.var(dim=(0, 2, 3), unbiased=False)
+    assert rel(coef[:, 2], mean) < 1e-5
+    assert rel(coef[:, 3], 1.0 / torch.sqrt(var + 1e-5)) < 1e-5
+    # and against the fused-fetch kernel it replaces
+    old = ops.conv2d(xd, wp, bd, Cout, 3, 1, fetch=ops.FETCH_UPS2)
+    assert rel(out, old) < 2e-6
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 16, 16, 32, 32), (2, 32, 64, 16, 16), (1, 128, 128, 10, 24), (3, 24, 20, 18, 72), (16, 16, 16, 256, 256)])
+def test_subpixel_stride2_data_gradient(dev, N, Cin, Cout, H, W):
+    """ms_conv_subpix mode 1 == d/dx of Conv2d(3x3, s=2, p=1)(x) (res_convdown.down), plain and with the activation-backward epilogue
+    (== ms_act_bwd_reduce on the plain result: masked gradient bit for bit, BatchNorm-backward coefficients to rounding)."""
+    from maxstyle_amd import ops
+    from maxstyle_amd._lib import lib, check
+    Ho, Wo = H // 2, W // 2
+    w = _rand((Cout, Cin, 3, 3), 2, 0.1); g = _rand((N, Cout, Ho, Wo), 5)
+    ref = F.conv_transpose2d(g.double(), w.double(), stride=2, padding=1, output_padding=1)
+    assert ref.shape == (N, Cin, H, W)
+    gd = g.to(dev)
+    dwp = ops.pack_conv_weight_dgrad(w.to(dev))
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.empty(N, Cin, H, W, device=dev)
+    check(lib.ms_conv_subpix(gd.data_ptr(), out.data_ptr(), dwp.data_ptr(), 0, N, Cout, Ho, Wo, Cin, 1, 0, 0, 0, 0, 1.0, 0, st), "ms_conv_subpix")
+    assert rel(out, ref) < 3e-6
+    old = ops.conv2d(gd, dwp, None, Cin, 3, 1, fetch=ops.FETCH_ZINS2)
+    assert rel(out, old) < 2e-6
+    # activation-backward epilogue: mask by the materialised activation `act`, sums against its raw BatchNorm input `u`
+    u = _rand((N, Cin, H, W), 7).to(dev)
+    coef = torch.stack([_rand((Cin,), 8).abs() + 0.5, _rand((Cin,), 9), _rand((Cin,), 10) * 0.1, torch.rand(Cin) + 0.5], dim=1).contiguous().to(dev)
+    act = _rand((N, Cin, H, W), 11).to(dev)
+    tab = torch.zeros(lib.ms_conv_actbwd_tab_bytes(Cin) // 4, device=dev)
+    masked = torch.empty_like(out)
+    check(lib.ms_conv_subpix(gd.data_ptr(), masked.data_ptr(), dwp.data_ptr(), 0, N, Cout, Ho, Wo, Cin, 1, 0, act.data_ptr(), u.data_ptr(), coef.data_ptr(), 0.2,
+                             tab.data_ptr(), st), "ms_conv_subpix(actbwd)")
+    expect = out * torch.where(act > 0, torch.ones_like(act), torch.full_like(act, 0.2))
+    assert torch.equal(masked, expect)
+    bc = torch.empty(Cin, 4, device=dev)
+    check(lib.ms_bn_bwd_coefs(tab.data_ptr(), 0, coef.data_ptr(), float(N * H * W), bc.data_ptr(), Cin, st), "bn_bwd_coefs")
+    nparts = lib.ms_act_bwd_parts(N, Cin, H * W)
+    part = torch.empty(Cin, nparts, 2, device=dev)
+    g2 = out.clone()
+    check(lib.ms_act_bwd_reduce(g2.data_ptr(), act.data_ptr(), u.data_ptr(), coef.data_ptr(), g2.data_ptr(), part.data_ptr(), N, Cin, H * W, 0.2, st), "act_bwd_reduce")
+    bc_ref = torch.empty(Cin, 4, device=dev)
+    check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(N * H * W), bc_ref.data_ptr(), Cin, st), "bn_bwd_coefs")
+    assert torch.equal(g2, masked)
+    assert rel(bc, bc_ref) < 2e-5
