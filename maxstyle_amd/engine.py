@@ -575,10 +575,19 @@ class InnerLoopEngine:
         check(lib.ms_pool2_sum(x.data_ptr(), out.data_ptr(), N * C, H // 2, W // 2, 1 if accumulate else 0, self._st()), "ms_pool2_sum:" + name)
         return out
 
+    def _subpix_ok(self, N, Hs, Ws, cout):
+        """The sub-pixel kernel works on 8 x 32 stored-pixel tiles x 16 output channels: it pays once there is a work item for every CU (measured at C2:
+        128 ch @16^2 -> 64 ch @32^2 = 128 items took 74.8 us against 32.9 us for the fused-fetch kernel with its 4 x 16 tiles; 16 ch @128^2 = 1024 items
+        37.3 against 55.8 us)."""
+        if not (self.subpix and lib.ms_conv_subpix_eligible(Hs, Ws)):
+            return False
+        items = N * ((Hs + 7) // 8) * ((Ws + 31) // 32) * ((cout + 15) // 16)
+        return items >= lib.ms_num_cus()
+
     def conv_ups2(self, name, x, cw: ConvW, fin=None):
         """nn.UpsamplingNearest2d(2) -> 3x3 conv (+ BatchNorm statistics of the outputs): sub-pixel kernel when eligible, else the fused-fetch conv."""
         N, Cin, Hs, Ws = x.shape
-        if not (self.subpix and lib.ms_conv_subpix_eligible(Hs, Ws)) or (self.fuse_bn_fin and not self.bn_eval):
+        if not self._subpix_ok(N, Hs, Ws, cw.cout) or (self.fuse_bn_fin and not self.bn_eval):
             return self.conv(name, x, cw, fetch=ops.FETCH_UPS2, stats=True, fin=fin)
         out = self.t(name, N, cw.cout, 2 * Hs, 2 * Ws)
         st, parts = None, N * 4 * Hs * Ws
@@ -592,13 +601,26 @@ class InnerLoopEngine:
     def dgrad_s2(self, name, g, cw: ConvW):
         """Data-gradient of the 3x3 stride-2 conv `cw` (res_convdown.down): sub-pixel kernel when eligible, else the zero-insertion conv."""
         N, Cg, Hs, Ws = g.shape
-        if not (self.subpix and lib.ms_conv_subpix_eligible(Hs, Ws)):
+        if not self._subpix_ok(N, Hs, Ws, cw.cin):
             dx, _, _ = self.conv(name, g, cw, ks=3, stride=1, fetch=ops.FETCH_ZINS2, dgrad=True)
             return dx
         out = self.t(name, N, cw.cin, 2 * Hs, 2 * Ws)
         check(lib.ms_conv_subpix(g.data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), 0, N, Cg, Hs, Ws, cw.cin, 1, 0, 0, 0, 0, 1.0, 0, self._st()),
               "ms_conv_subpix(s2 dgrad):" + name)
         return out
+
+    def dgrad_s2_actbwd(self, name, g, cw: ConvW, bw_name, act_out, u, coef, slope):
+        """dgrad_s2 whose epilogue already does the activation backward of the layer BELOW (mask by the materialised activation `act_out`, sums for
+        the BatchNorm backward of its raw input `u`): replaces dgrad_s2 + act_bwd (ms_act_bwd_reduce: 4 HBM passes over the result) -> (g', bcoef4)."""
+        N, Cg, Hs, Ws = g.shape
+        C = cw.cin
+        out = self.t(name, N, C, 2 * Hs, 2 * Ws)
+        tab = self.t(bw_name + ".tab", lib.ms_conv_actbwd_tab_bytes(C) // 4)
+        check(lib.ms_conv_subpix(g.data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), 0, N, Cg, Hs, Ws, C, 1, 0, act_out.data_ptr(), u.data_ptr(), coef.data_ptr(),
+                                 slope, tab.data_ptr(), self._st()), "ms_conv_subpix(s2 dgrad + act bwd):" + name)
+        bc = self.t(bw_name + ".bcoef", C, 4)
+        check(lib.ms_bn_bwd_coefs(tab.data_ptr(), 0, coef.data_ptr(), float(N * 4 * Hs * Ws), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + bw_name)
+        return out, bc
 
     # ------------------------------------------------------------------ residual blocks
     def res_fwd(self, pfx, net, key, x, kind):
@@ -638,11 +660,17 @@ class InnerLoopEngine:
         out = self.bn_act(pfx + ".out", u2, cf2, s, 2 if kind == "nn" else 1, LEAKY)
         return out
 
-    def res_bwd(self, pfx, net, key, dout, kind, need_dx=True):
-        """dout: gradient w.r.t. the block output (overwritten). Returns the gradient w.r.t. the block input."""
+    def res_bwd(self, pfx, net, key, dout, kind, need_dx=True, pre=None, next_act=None):
+        """dout: gradient w.r.t. the block output (overwritten). Returns the gradient w.r.t. the block input.
+        pre = (g2, bcoef) when the producer of `dout` already applied this block's output-activation backward in its epilogue;
+        next_act = (bw_name, act_out, u, coef, slope) of the activation BELOW a 'down' block: its backward is then done in the epilogue of this block's
+        last data-gradient conv and the return value is the pair (masked gradient, BatchNorm-backward coefficients) for the caller to hand on as `pre`."""
         b = self.buf
         c0, c3, ci = net[key + ".c0"], net[key + ".c3"], net[key + ".ci"]
-        g2, bc2 = self.act_bwd(pfx + ".bw2", dout, b[pfx + ".out"], b[pfx + ".u2"], b[pfx + ".bn4.coef"], LEAKY)
+        if pre is not None:
+            g2, bc2 = pre
+        else:
+            g2, bc2 = self.act_bwd(pfx + ".bw2", dout, b[pfx + ".out"], b[pfx + ".u2"], b[pfx + ".bn4.coef"], LEAKY)
         # skip branch on the side stream (it only needs g2): its data-gradient lands in the buffer the main chain then ACCUMULATES into
         with self._side(after_main=True):
             if kind == "nn":
@@ -662,7 +690,11 @@ class InnerLoopEngine:
         if kind == "convT":
             dx, _, _ = self.conv(pfx + ".dx", dsrc, net[key + ".up"], ks=2, stride=2, dgrad=True)
         else:
-            dx = self.dgrad_s2(pfx + ".dx", dsrc, net[key + ".down"])
+            down = net[key + ".down"]
+            if next_act is not None and self.fuse_act_bwd and not self.bn_eval and self._subpix_ok(dsrc.shape[0], dsrc.shape[2], dsrc.shape[3], down.cin):
+                bw_name, act_out, u, coef, slope = next_act
+                return self.dgrad_s2_actbwd(pfx + ".dx", dsrc, down, bw_name, act_out, u, coef, slope)
+            dx = self.dgrad_s2(pfx + ".dx", dsrc, down)
         return dx
 
     # ------------------------------------------------------------------ MixStyle layers between the encoder blocks
@@ -725,9 +757,14 @@ class InnerLoopEngine:
         dz_i, _, _ = self.conv("e.dz_i", g, e["cd0"], bnbwd=(bc, b["e.cd.u1"]), dgrad=True)
         g, bc = self.act_bwd("e.fc.bw", dz_i, b["e.z_i"], b["e.fc.u"], b["e.fc.bn.coef"], 0.0)
         dh, _, _ = self.conv("e.fc.dh", g, e["fc0"], bnbwd=(bc, b["e.fc.u"]), dgrad=True)
+        pre = None
         for i in range(4, 0, -1):
-            dh = self.res_bwd(f"e.d{i}", e, f"d{i}", dh, "down")
-        g, bc = self.act_bwd("e.inc.bw2", dh, b["e.inc.out"], b["e.inc.ub"], b["e.inc.bn4.coef"], LEAKY)
+            lo = f"e.d{i - 1}"
+            nxt = (lo + ".bw2", b[lo + ".out"], b[lo + ".u2"], b[lo + ".bn4.coef"], LEAKY) if i > 1 else \
+                  ("e.inc.bw2", b["e.inc.out"], b["e.inc.ub"], b["e.inc.bn4.coef"], LEAKY)
+            res = self.res_bwd(f"e.d{i}", e, f"d{i}", dh, "down", pre=pre, next_act=nxt)
+            pre, dh = (res, None) if isinstance(res, tuple) else (None, res)
+        g, bc = pre if pre is not None else self.act_bwd("e.inc.bw2", dh, b["e.inc.out"], b["e.inc.ub"], b["e.inc.bn4.coef"], LEAKY)
         g, bc = self.dgrad_act_bwd("e.inc.da", "e.inc.bw1", g, e["inc3"], (bc, b["e.inc.ub"]), b["e.inc.ua"], b["e.inc.bn1.coef"], LEAKY)
         dimg, _, _ = self.conv("e.dimage", g, e["inc0"], bnbwd=(bc, b["e.inc.ua"]), dgrad=True)
         return dimg
