@@ -235,12 +235,39 @@ def steady_state(run_one, eng, seconds):
     return {"steps": n, "seconds": dt, "steps_s": n / dt}
 
 
+def _load_trained():
+    """Networks trained by the reference's own training step on the synthetic stream (tests/golden/make_golden_r2.py; fp16-rounded storage)."""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "trained_fcn16.npz"))
+    W = {"image_encoder": {}, "segmentation_decoder": {}, "image_decoder": {}}
+    for key in z.files:
+        net, name = key.split("/", 1)
+        a = z[key]
+        W[net][name] = torch.from_numpy(a.astype(np.float32) if a.dtype == np.float16 else a)
+    return W, np.load(os.path.join(ROOT, "tests", "golden", "loop_trained.npz"))
+
+
 def dice_parity(dev):
-    """Dice of the segmentation of the stylised image: HIP loop vs CPU oracle from the same seeds (K=5, 4x1x64x64, layers [3,4,5])."""
+    """Dice parity on TRAINED networks (a meaningful Dice: clean 0.65-0.80, stylised 0.39-0.55; random networks give ~0.07): K=5 free-running loop,
+    4x1x64x64, layers [3,4,5]; HIP loop vs (a) the REFERENCE's own fp32 / fp64 runs (fixture tests/golden/loop_trained.npz) and (b) the CPU oracle live."""
     from oracle import maxstyle_oracle as orc
+    from maxstyle_amd import engine as E, synthetic as syn
     from maxstyle_amd.metrics import runningScore
+    W, g = _load_trained()
     B, size, layers, K = 4, 64, [3, 4, 5], 5
-    eng, W, img, lab, styles, z_i, lab_d = build(dev, B, size, 0)
+    spec = E.NetSpec(4, 1, 4)
+    to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
+    eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1)
+    eng.set_nets(E.PackedNets(spec, to(W["image_encoder"]), to(W["segmentation_decoder"]), to(W["image_decoder"])))
+    img, lab = syn.synthetic_batch(B, size, 1, 4, seed=777)
+    chn = syn.NetSpec(4, 1, 4).channel_num
+    styles = {i: syn.random_style_state(B, chn[i], 7 + i) for i in layers}
+    eng.configure_styles(layers, {i: E.StyleSlot(i, B, chn[i]) for i in layers})
+    for i in layers:
+        st = styles[i]
+        eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
+    lab_d = lab.to(dev)
+    z_i = eng.encode_fwd(img.to(dev))[0].clone()
     out = eng.run(z_i, lab_d, K, use_graph=False).clone()
     eng.seg_loss(out, lab_d, need_grad=False, need_logits=True)
     rs = runningScore(4, dev)
@@ -253,8 +280,31 @@ def dice_parity(dev):
         _, zs = orc.encoder_forward(W["image_encoder"], ref)
         pred = orc.decoder_forward(W["segmentation_decoder"], zs, "NN").argmax(1)
     cpu_dice = orc.dice_per_class(pred, lab, 4)
-    return {"gpu": gpu_dice, "cpu_oracle": cpu_dice, "max_abs_diff": max(abs(a - b) for a, b in zip(gpu_dice, cpu_dice)),
-            "image_rel_err": float((out.cpu() - ref).abs().max() / ref.abs().max()), "case": "K=5, 4x1x64x64, layers [3,4,5], free-running"}
+    o = out.cpu().double()
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    ref64, ref32 = torch.from_numpy(g["f64.image"]), torch.from_numpy(g["f32.image"]).double()
+    return {"case": "TRAINED FCN_16 (reference's own training step, tests/golden/trained_fcn16.npz), K=5 free-running, 4x1x64x64, layers [3,4,5]",
+            "gpu": gpu_dice, "cpu_oracle": cpu_dice, "reference_fp32": [float(v) for v in g["f32.final_dice"]], "reference_clean": [float(v) for v in g["f32.clean_dice"]],
+            "max_abs_diff_vs_reference": max(abs(a - float(b)) for a, b in zip(gpu_dice, g["f32.final_dice"])),
+            "max_abs_diff_vs_oracle": max(abs(a - b) for a, b in zip(gpu_dice, cpu_dice)),
+            "image_rel_err_vs_reference_fp64": rel(o, ref64), "image_rel_err_vs_oracle_fp32": rel(o, ref.double()),
+            "reference_fp32_vs_fp64_image_rel": float(g["fp32_vs_fp64_image_rel"]), "oracle_fp32_vs_reference_fp64": rel(ref.double(), ref64),
+            "pred_agreement_with_reference": float((eng.buf["s.logits"].argmax(1).cpu().numpy() == g["f32.final_pred"]).mean())}
+
+
+def drift_c2(eng, styles, z_i, lab_d, cpu_image, K):
+    """Free-running K-step trajectory at the FULL C2 size against the fp32 CPU oracle started from the same code and state (the oracle image comes
+    from the cpu_baseline leg, which runs exactly this workload)."""
+    for i, st in styles.items():
+        eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
+        eng.styles[i].have_std = False
+    eng.flat_m.zero_(); eng.flat_v.zero_(); eng.flat_g.zero_()
+    out = eng.run(z_i, lab_d, K, use_graph=True).clone()
+    losses = eng.losses(K).cpu()
+    o = out.cpu()
+    return {"case": f"K={K} free-running at the bench size, vs the fp32 CPU oracle from the same code and state",
+            "image_rel_err": float((o - cpu_image).abs().max() / cpu_image.abs().max()),
+            "image_rms_rel": float((o - cpu_image).pow(2).mean().sqrt() / cpu_image.pow(2).mean().sqrt()), "losses_gpu": [float(v) for v in losses]}
 
 
 def physical_cores():
@@ -279,8 +329,9 @@ def physical_cores():
     return max(1, len(cores)) if cores else max(1, len(allowed))
 
 
-def cpu_baseline(W, img, lab, styles, steps):
-    """The CPU oracle (plain PyTorch restatement of the reference path, oracle/) timed on this box's host cores."""
+def cpu_baseline(W, img, lab, styles, steps, z_gpu=None):
+    """The CPU oracle (plain PyTorch restatement of the reference path, oracle/) timed on this box's host cores.  Returns (record, final image, losses)
+    - the K-step result from the code `z_gpu` doubles as the full-size drift reference."""
     from oracle import maxstyle_oracle as orc
     ncores = physical_cores()
     # eager PyTorch-CPU convolutions at batch 16 do not scale to 128 threads: calibrate the thread count on one encoder pass and keep the
@@ -296,23 +347,31 @@ def cpu_baseline(W, img, lab, styles, steps):
         if best_dt is None or dt_ < best_dt:
             best_t, best_dt = t, dt_
     torch.set_num_threads(best_t)
-    with torch.no_grad():
-        z_i, _ = orc.encoder_forward(W["image_encoder"], img)
-    st = {i: orc.StyleState(s.perm.clone(), s.lmda.clone(), s.gamma_noise.clone(), s.beta_noise.clone()) for i, s in styles.items()}
+    if z_gpu is not None:
+        z_i = z_gpu
+    else:
+        with torch.no_grad():
+            z_i, _ = orc.encoder_forward(W["image_encoder"], img)
+    mk = lambda: {i: orc.StyleState(s.perm.clone(), s.lmda.clone(), s.gamma_noise.clone(), s.beta_noise.clone()) for i, s in styles.items()}
+    st = mk()
     layers = sorted(st)
     t0 = time.perf_counter()
     orc.generate_max_style_image(W, z_i, st, layers, lab, n_iter=1, lr=0.1)          # warm-up (MKLDNN primitive creation)
     t1 = time.perf_counter()
-    orc.generate_max_style_image(W, z_i, st, layers, lab, n_iter=steps, lr=0.1)
+    st = mk()                                                                        # the timed run starts from the initial state again
+    tr = orc.InnerLoopTrace()
+    final = orc.generate_max_style_image(W, z_i, st, layers, lab, n_iter=steps, lr=0.1, trace=tr)
     t2 = time.perf_counter()
     with torch.no_grad():
         orc.apply_max_style(W["image_decoder"], z_i, st, layers)
     t3 = time.perf_counter()
     # a call of n steps = n x (loss+backward+Adam+decode) + one extra decode
     per_step = (t2 - t1 - (t3 - t2)) / steps
-    return {"value": 1.0 / per_step, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle.generate_max_style_image, same C2 workload (B=16,1x256x256,layers[3,4,5]), {steps} inner steps after a 1-step warm-up "
-                      f"({t2 - t1:.1f}s timed, warm-up {t1 - t0:.1f}s), fp32, torch CPU, {torch.get_num_threads()} threads (fastest of 8/16/32/64/{ncores} on this box)"}
+    rec = {"value": 1.0 / per_step, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"oracle.generate_max_style_image, same C2 workload (B=16,1x256x256,layers[3,4,5]), {steps} inner steps after a 1-step warm-up "
+                     f"({t2 - t1:.1f}s timed, warm-up {t1 - t0:.1f}s), fp32, torch CPU, {torch.get_num_threads()} threads (fastest of 8/16/32/64/{ncores} on this box)",
+           "losses": [float(v) for v in tr.losses]}
+    return rec, final
 
 
 def outer_iteration(dev, batch, size, rank=0, world=1, iters=6):
@@ -518,8 +577,9 @@ def main():
             "roofline_maxstyle": roof["style"], "roofline_maxstyle_bwd": roof["style_bwd"], "loss_check": loss_last,
         }
         if world == 1 and not args.no_cpu_baseline and args.config == "c2":
-            res["cpu_baseline"] = cpu_baseline(W, img, lab, styles, args.cpu_steps)
+            res["cpu_baseline"], cpu_image = cpu_baseline(W, img, lab, styles, args.cpu_steps, z_gpu=z_i.cpu())
             res["speedup_vs_cpu"] = value / res["cpu_baseline"]["value"]
+            res["drift_full_size"] = drift_c2(eng, styles, z_i, lab_d, cpu_image, args.cpu_steps)
             res["dice_parity"] = dice_parity(dev)
     if not args.no_outer and args.config == "c2":
         del eng

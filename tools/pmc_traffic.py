@@ -16,7 +16,7 @@ def per_kernel(d, counter):
             name = r["Kernel_Name"]
             name = name[:name.index("(")] if "(" in name else name
             acc[name.replace("void ", "")].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+    return {k: (sum(v) / len(v), max(v)) for k, v in acc.items()}
 
 
 def main():
@@ -24,9 +24,11 @@ def main():
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {}
     for k in sorted(set(fetch) | set(write)):
-        fr = fetch.get(k, 0.0) * 1024 * 2.0          # gfx950: FETCH_SIZE = 1/2 of the streamed bytes
-        wr = write.get(k, 0.0) * 1024
-        out[k] = {"read_bytes": fr, "write_bytes": wr, "total_bytes": fr + wr, "fetch_size_raw_KiB": fetch.get(k, 0.0), "write_size_raw_KiB": write.get(k, 0.0)}
+        fa, fm = fetch.get(k, (0.0, 0.0)); wa, wm = write.get(k, (0.0, 0.0))
+        fr = fa * 1024 * 2.0          # gfx950: FETCH_SIZE = 1/2 of the streamed bytes
+        wr = wa * 1024
+        out[k] = {"read_bytes": fr, "write_bytes": wr, "total_bytes": fr + wr, "fetch_size_raw_KiB": fa, "write_size_raw_KiB": wa,
+                  "read_bytes_max": fm * 1024 * 2.0, "write_bytes_max": wm * 1024}      # max over launches: a kernel launched with and without an optional output
     txt = json.dumps(out, indent=1)
     if len(sys.argv) > 3:
         open(sys.argv[3], "w").write(txt + "\n")

@@ -1,25 +1,32 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): kernel-trace statistics of the bench and of the training pass + HBM-traffic PMC passes of the priced kernels.
-# Usage: bash tools/profile_round.sh r01     (summaries land in gpurun_out/prof_<round>/; copy the ones to keep into profiles/)
+# Run on the GPU box (gpurun): everything the round's profiles/ entries come from.
+#   bash tools/profile_round.sh r02      -> gpurun_out/prof_r02/ ; copy the summaries to keep into profiles/
+# rocprofv3 gets the python program directly after `--` (no env / bash -c hop); PMC passes are separate from each other (SQ 8 slots, FETCH_SIZE 3 TCC
+# slots, WRITE_SIZE 2) and carry only --kernel-trace.
 set -u
-R=${1:-r01}
+R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$R
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-outer > $O/bench_under_rocprof.json 2> $O/trace.err
+# 1. the bench under kernel-trace: per-kernel totals, the launch list of one inner step, the isolated runs bench.py prices
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-outer --steady-seconds 0 > $O/bench_under_rocprof.json 2> $O/trace.err
 python tools/prof_summary.py $O/trace $O/${R}_kernel_stats.txt > /dev/null
+# 2. config 4 (FCN_64, 16x3x320x320)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c4 -- python bench.py --config c4 --steps 4 --warmup 1 --no-cpu-baseline --no-outer --steady-seconds 0 > $O/bench_c4_under_rocprof.json 2> $O/trace_c4.err
+python tools/prof_summary.py $O/trace_c4 $O/${R}_c4_kernel_stats.txt > /dev/null
+# 3. one trainer iteration (standard pass + inner loop + hard pass + backward + AdamW)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_train -- python tools/prof_train.py 6 > /dev/null 2> $O/trace_train.err
 python tools/prof_by_kernel.py $O/trace_train 0.5 > $O/${R}_train_pass_kernel_stats.txt
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python tools/bench_conv.py c16_256 3 > /dev/null 2> $O/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python tools/bench_conv.py c16_256 3 > /dev/null 2> $O/pmc_write.err
-python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/${R}_traffic_conv.json > /dev/null
+# 4. HBM-side traffic of K1 / K2 at layer 4 (16x16x256x256)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_s -- python tools/bench_kernels.py --iters 3 --only L4 > /dev/null 2> $O/pmc_fetch_s.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_s -- python tools/bench_kernels.py --iters 3 --only L4 > /dev/null 2> $O/pmc_write_s.err
 python tools/pmc_traffic.py $O/pmc_fetch_s $O/pmc_write_s $O/${R}_traffic_style.json > /dev/null
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_w -- python tools/bench_wgrad.py u4.c0 > /dev/null 2> $O/pmc_fetch_w.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_w -- python tools/bench_wgrad.py u4.c0 > /dev/null 2> $O/pmc_write_w.err
-python tools/pmc_traffic.py $O/pmc_fetch_w $O/pmc_write_w $O/${R}_traffic_wgrad.json > /dev/null
-python tools/bench_wgrad.py > $O/${R}_wgrad_bench.txt 2>&1
-python tools/bench_conv.py all 30 > $O/${R}_conv_bench.txt 2>&1
-python tools/bench_train.py > $O/${R}_train_iteration.json 2> /dev/null
+# 5. SQ / TCC counters of the wide conv kernels at their dominant shapes
+bash tools/pmc_conv.sh $R > /dev/null 2>&1
+cp gpurun_out/pmc_conv_$R/summary.txt $O/${R}_conv_wide_pmc.txt
+python tools/make_traffic.py $O/${R}_traffic_style.json gpurun_out/pmc_conv_$R $O/${R}_traffic.json
+# 6. un-profiled bench lines
+python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
+python bench.py --config c4 --steps 10 --warmup 2 > $O/${R}_bench_c4.json 2> $O/bench_c4.err
+python tools/tune_conv.py 20 > $O/${R}_conv_tuning_table.txt 2>&1
 ls -la $O
