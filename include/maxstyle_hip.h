@@ -82,6 +82,22 @@ int ms_style_fwd_3k(const float* x, float* y, float* mu, float* sig, float* gamm
                     const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
                     float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
 
+/* bf16 ACTIVATION STORAGE variants ("`_bf16` I/O variants with fp32 statistics"; BASELINE config 5): x / y / dy / dx are bf16 bit
+ * patterns (uint16_t, NCHW, 16-byte aligned, H*W % 8 == 0) - half the HBM bytes of these bandwidth-bound kernels; mu / sig / coefficients / std / partial
+ * sums / parameter gradients stay fp32 (fp64 merges) and all arithmetic is fp32.  Results equal the fp32 entry points evaluated on the bf16-rounded
+ * input, with y / dx rounded to nearest-even bf16 on store (relative error <= 2^-9 per element).  Same workspace contract (ms_style_ws_bytes_bf16). */
+size_t ms_style_ws_bytes_bf16(int B, int C, int HW);
+size_t ms_style_fused_ws_bytes_bf16(int B, int C, int HW);
+int ms_style_fwd_bf16(const uint16_t* x, uint16_t* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+                      const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
+                      float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
+int ms_style_fwd_fused_bf16(const uint16_t* x, uint16_t* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+                            const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
+                            float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
+int ms_style_bwd_bf16(const uint16_t* dy, const uint16_t* x, uint16_t* dx, const float* mu, const float* sig, const float* coefA,
+                      const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
+                      float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes, void* stream);
+
 /* Backward of the layer (autograd of maxstyle.py:161-185 with mu/sig detached):
  *   dx = dy*A/sig (skipped when dx == NULL);  d_gamma = gamma_std*sum(dy*xhat);  d_beta = beta_std*sum(dy);
  *   d_lmda[b] = 1[0<=lmda<=1] * sum_c (sig[perm b]-sig[b])*S2 + (mu[perm b]-mu[b])*S1.   Any of d_* may be NULL. */

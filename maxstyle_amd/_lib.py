@@ -39,6 +39,14 @@ SIGNATURES = {
                                    c_int, c_int, c_int, c_float, c_void, c_size, c_void]),
     "ms_style_fwd_3k": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p,
                                 c_int, c_int, c_int, c_float, c_void, c_size, c_void]),
+    "ms_style_ws_bytes_bf16": (c_size, [c_int, c_int, c_int]),
+    "ms_style_fused_ws_bytes_bf16": (c_size, [c_int, c_int, c_int]),
+    "ms_style_fwd_bf16": (c_int, [c_void, c_void, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p,
+                                  c_int, c_int, c_int, c_float, c_void, c_size, c_void]),
+    "ms_style_fwd_fused_bf16": (c_int, [c_void, c_void, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p,
+                                        c_int, c_int, c_int, c_float, c_void, c_size, c_void]),
+    "ms_style_bwd_bf16": (c_int, [c_void, c_void, c_void, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p,
+                                  c_int, c_int, c_int, c_void, c_size, c_void]),
     "ms_style_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p,
                              c_int, c_int, c_int, c_void, c_size, c_void]),
     "ms_adam_step": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_float, c_float, c_float, c_float, c_int, c_void, c_void]),

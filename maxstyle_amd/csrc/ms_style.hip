@@ -233,6 +233,99 @@ __global__ __launch_bounds__(256) void style_bwd_finalize_kernel(const float2* _
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 activation storage (`*_bf16` entry points): x / y / dy / dx are bf16 (16-byte accesses = 8 values), every statistic, coefficient and
+// partial sum stays fp32 / fp64 and the finalize kernels above are shared.  Vector path only: H*W % 8 == 0, 16-byte aligned tensors.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bf16x8_load(const uint16_t* p, float (&d)[8]) {
+  const uint4 w = *reinterpret_cast<const uint4*>(p);
+  const unsigned q[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { d[2 * i] = __uint_as_float(q[i] << 16); d[2 * i + 1] = __uint_as_float(q[i] & 0xFFFF0000u); }
+}
+__device__ __forceinline__ unsigned bf16_pack2(float a, float b) {     // round-to-nearest-even (v_cvt_pk_bf16_f32)
+  bf16x2_t p; p[0] = (__bf16)a; p[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ void bf16x8_store(uint16_t* p, const float (&d)[8]) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(bf16_pack2(d[0], d[1]), bf16_pack2(d[2], d[3]), bf16_pack2(d[4], d[5]), bf16_pack2(d[6], d[7]));
+}
+
+template <int NV>
+__global__ __launch_bounds__(kStyleThreads) void moments_partial_bf16_kernel(const uint16_t* __restrict__ x, PlanePartial* __restrict__ part, int HW, int chunk, int S) {
+  __shared__ float red[16];
+  const int p = blockIdx.y, s = blockIdx.x;
+  const int beg = s * chunk, end = min(HW, beg + chunk);
+  const uint16_t* xp = x + (size_t)p * HW;
+  float v[NV][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = beg + (j * kStyleThreads + threadIdx.x) * 8;
+    if (i < end) bf16x8_load(xp + i, v[j]);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += v[j][e];
+  }
+  const float n = (float)(end - beg);
+  const float mean = block_sum(sum, red) / n;
+  float m2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = beg + (j * kStyleThreads + threadIdx.x) * 8;
+    if (i < end) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mean; m2 += d * d; }
+    }
+  }
+  m2 = block_sum(m2, red);
+  if (threadIdx.x == 0) part[(size_t)p * S + s] = PlanePartial{n, mean, m2, 0.f};
+}
+
+__global__ __launch_bounds__(kStyleThreads) void restyle_bf16_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ mu,
+                                                                    const float* __restrict__ sig, const float* __restrict__ coefA,
+                                                                    const float* __restrict__ coefS, int HW, int chunk) {
+  const int p = blockIdx.y;
+  const float m = mu[p], a = coefA[p] / sig[p], sh = coefS[p];
+  const int beg = blockIdx.x * chunk, end = min(HW, beg + chunk);
+  for (int i = beg + threadIdx.x * 8; i < end; i += kStyleThreads * 8) {
+    float t[8];
+    bf16x8_load(x + (size_t)p * HW + i, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = a * (t[e] - m) + sh;
+    bf16x8_store(y + (size_t)p * HW + i, t);
+  }
+}
+
+__global__ __launch_bounds__(kStyleThreads) void restyle_bwd_bf16_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x, uint16_t* __restrict__ dx,
+                                                                        const float* __restrict__ mu, const float* __restrict__ sig,
+                                                                        const float* __restrict__ coefA, float2* __restrict__ part, int HW, int chunk, int S) {
+  __shared__ float red[16];
+  const int p = blockIdx.y;
+  const float m = mu[p], inv = 1.f / sig[p], a = coefA[p] * inv;
+  const int beg = blockIdx.x * chunk, end = min(HW, beg + chunk);
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = beg + threadIdx.x * 8; i < end; i += kStyleThreads * 8) {
+    float g[8], t[8];
+    bf16x8_load(dy + (size_t)p * HW + i, g);
+    bf16x8_load(x + (size_t)p * HW + i, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1 += g[e]; s2 += g[e] * ((t[e] - m) * inv); }
+    if (dx) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] *= a;
+      bf16x8_store(dx + (size_t)p * HW + i, g);
+    }
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) part[(size_t)p * S + blockIdx.x] = make_float2(s1, s2);
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
                             float lr, float b1, float b2, float eps, int step, const int* __restrict__ step_dev) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -422,6 +515,80 @@ extern "C" int ms_style_bwd(const float* dy, const float* x, float* dx, const fl
   if (d_gamma || d_beta || d_lmda) {
     MS_LAUNCH(style_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, (const float2*)part, mu, sig, gamma_std, beta_std, lmda, perm,
                        d_gamma, d_beta, d_lmda, B, C, sp.S);
+    return check_launch("style_bwd_finalize");
+  }
+  return MS_OK;
+}
+
+// ---- bf16 activation storage -----------------------------------------------------------------------------------------------
+static Split choose_split_bf16(int P, int HW) {
+  Split sp; sp.vec = true;
+  int nv = 8;                                          // 8 values per access: <= 64 fp32 registers of data per thread
+  while (nv > 1) { if ((long)P * cdiv(HW, kStyleThreads * 8 * nv) >= 1024) break; nv >>= 1; }
+  sp.nv = nv; sp.chunk = kStyleThreads * 8 * nv; sp.S = cdiv(HW, sp.chunk);
+  return sp;
+}
+
+static int check_bf16_args(const char* who, const void* a, const void* b, const void* c, int HW) {
+  if (HW % 8 != 0) { set_error("%s: bf16 storage needs H*W %% 8 == 0 (16-byte accesses)", who); return MS_ERR_INVALID; }
+  if (!aligned16(a) || !aligned16(b) || (c != nullptr && !aligned16(c))) { set_error("%s: bf16 tensors must be 16-byte aligned", who); return MS_ERR_ALIGN; }
+  return MS_OK;
+}
+
+extern "C" size_t ms_style_ws_bytes_bf16(int B, int C, int HW) {
+  return style_scratch_bytes(B, C, HW) + (ms_style_fused_ws_bytes_bf16(B, C, HW) + 15) / 16 * 16;
+}
+
+extern "C" int ms_style_fwd_bf16(const uint16_t* x, uint16_t* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+                                 const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
+                                 float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_bf16_args("ms_style_fwd_bf16", x, y, nullptr, HW)) return e;
+  if (B < 1 || C < 1 || ws == nullptr || !aligned16(ws) || ws_bytes < ms_style_ws_bytes_bf16(B, C, HW)) { set_error("ms_style_fwd_bf16: invalid shape or workspace"); return MS_ERR_WORKSPACE; }
+  const bool shared = (compute_std & 4) != 0;
+  compute_std &= 3;
+  const size_t fb = shared ? 0 : ms_style_fused_ws_bytes_bf16(B, C, HW);
+  const size_t off = style_scratch_bytes(B, C, HW);
+  if (fb != 0 && (size_t)B * C * HW * 2 >= (1u << 20))
+    return ms_style_fwd_fused_bf16(x, y, mu, sig, gamma_std, beta_std, compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, HW, eps,
+                                   (char*)ws + off, ws_bytes - off, stream);
+  if ((compute_std & 1) && B < 2) { set_error("ms_style_fwd_bf16: batch std needs B >= 2"); return MS_ERR_INVALID; }
+  if (lmda != nullptr && perm == nullptr) { set_error("ms_style_fwd_bf16: mixing needs perm"); return MS_ERR_INVALID; }
+  if ((gamma_noise == nullptr) != (beta_noise == nullptr)) { set_error("ms_style_fwd_bf16: gamma/beta noise must both be given"); return MS_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  const int P = B * C;
+  if (P > kMaxPlanesPerLaunch) { set_error("ms_style_fwd_bf16: too many planes"); return MS_ERR_INVALID; }
+  const Split sp = choose_split_bf16(P, HW);
+  PlanePartial* part = (PlanePartial*)ws;
+  dim3 grid(sp.S, P), block(kStyleThreads);
+  switch (sp.nv) {
+    case 8: MS_LAUNCH(moments_partial_bf16_kernel<8>, grid, block, 0, st, x, part, HW, sp.chunk, sp.S); break;
+    case 4: MS_LAUNCH(moments_partial_bf16_kernel<4>, grid, block, 0, st, x, part, HW, sp.chunk, sp.S); break;
+    case 2: MS_LAUNCH(moments_partial_bf16_kernel<2>, grid, block, 0, st, x, part, HW, sp.chunk, sp.S); break;
+    default: MS_LAUNCH(moments_partial_bf16_kernel<1>, grid, block, 0, st, x, part, HW, sp.chunk, sp.S);
+  }
+  if (int e = check_launch("moments_partial_bf16")) return e;
+  MS_LAUNCH(style_finalize_kernel, dim3(C), dim3(256), 2 * B * sizeof(float), st, (const PlanePartial*)part, mu, sig, gamma_std, beta_std,
+                     compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, sp.S, HW, eps);
+  if (int e = check_launch("style_finalize")) return e;
+  MS_LAUNCH(restyle_bf16_kernel, grid, block, 0, st, x, y, (const float*)mu, (const float*)sig, (const float*)coefA, (const float*)coefS, HW, sp.chunk);
+  return check_launch("restyle_bf16");
+}
+
+extern "C" int ms_style_bwd_bf16(const uint16_t* dy, const uint16_t* x, uint16_t* dx, const float* mu, const float* sig, const float* coefA,
+                                 const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
+                                 float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_bf16_args("ms_style_bwd_bf16", dy, x, dx, HW)) return e;
+  if (int e = check_style_args(B, C, HW, ws, ws_bytes)) return e;
+  if (d_lmda != nullptr && (lmda == nullptr || perm == nullptr)) { set_error("ms_style_bwd_bf16: d_lmda needs lmda and perm"); return MS_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  const int P = B * C;
+  if (P > kMaxPlanesPerLaunch) { set_error("ms_style_bwd_bf16: too many planes"); return MS_ERR_INVALID; }
+  const Split sp = choose_split_bf16(P, HW);
+  float2* part = (float2*)ws;
+  MS_LAUNCH(restyle_bwd_bf16_kernel, dim3(sp.S, P), dim3(kStyleThreads), 0, st, dy, x, dx, mu, sig, coefA, part, HW, sp.chunk, sp.S);
+  if (int e = check_launch("restyle_bwd_bf16")) return e;
+  if (d_gamma || d_beta || d_lmda) {
+    MS_LAUNCH(style_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, (const float2*)part, mu, sig, gamma_std, beta_std, lmda, perm, d_gamma, d_beta, d_lmda, B, C, sp.S);
     return check_launch("style_bwd_finalize");
   }
   return MS_OK;

@@ -35,6 +35,7 @@
 // is zero-filled ONCE by the caller and must stay dedicated to one layer.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "ms_common.h"
 #include "maxstyle_hip.h"
 
@@ -59,17 +60,53 @@ __device__ __forceinline__ bool poll_granule(const u64* slot, float& value, unsi
   }
 }
 
+// Activation storage type of x / y: fp32, or bf16 (`*_bf16` entry points: half the HBM bytes; every statistic, coefficient and the arithmetic stay fp32).
+// One 16-byte buffer load / store per register slot either way: 4 fp32 or 8 bf16 values; a thread holds 64 values in fp32 registers.
+typedef __bf16 ms_bf16x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct StyleIo;
+template <> struct StyleIo<float> {
+  static constexpr int EPL = 4;
+  template <int AUX> static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int voff, int soff, float (&d)[4]) {
+    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
+    d[0] = __uint_as_float(w.x); d[1] = __uint_as_float(w.y); d[2] = __uint_as_float(w.z); d[3] = __uint_as_float(w.w);
+  }
+  template <int AUX> static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&d)[4]) {
+    u32x4 o; o.x = __float_as_uint(d[0]); o.y = __float_as_uint(d[1]); o.z = __float_as_uint(d[2]); o.w = __float_as_uint(d[3]);
+    __builtin_amdgcn_raw_buffer_store_b128(o, r, voff, soff, AUX);
+  }
+};
+struct ms_bf16_tag {};
+template <> struct StyleIo<ms_bf16_tag> {
+  static constexpr int EPL = 8;
+  static __device__ __forceinline__ unsigned pack2(float a, float b) {       // round-to-nearest-even (v_cvt_pk_bf16_f32), NaN stays NaN
+    ms_bf16x2 p; p[0] = (__bf16)a; p[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, p);
+  }
+  template <int AUX> static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int voff, int soff, float (&d)[8]) {
+    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
+    const unsigned q[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { d[2 * i] = __uint_as_float(q[i] << 16); d[2 * i + 1] = __uint_as_float(q[i] & 0xFFFF0000u); }
+  }
+  template <int AUX> static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&d)[8]) {
+    u32x4 o; o.x = pack2(d[0], d[1]); o.y = pack2(d[2], d[3]); o.z = pack2(d[4], d[5]); o.w = pack2(d[6], d[7]);
+    __builtin_amdgcn_raw_buffer_store_b128(o, r, voff, soff, AUX);
+  }
+};
+
 struct FusedArgs {
-  const float* x; float* y; float* mu; float* sig; float* gamma_std; float* beta_std;
+  const void* x; void* y; float* mu; float* sig; float* gamma_std; float* beta_std;
   const float* lmda; const float* gamma_noise; const float* beta_noise; const int64_t* perm;
   float* coefA; float* coefS; u64* part; int* arrive; int* counter; int* err;
   int compute_std, B, C, HW, S, chunk, nv;
   float eps;
 };
 
-// THREADS: workgroup size; AUXL / AUXS: cache-policy bits of the x loads / y stores (0 default, 2 = nt)
-template <int THREADS, int AUXL, int AUXS>
+// THREADS: workgroup size; AUXL / AUXS: cache-policy bits of the x loads / y stores (0 default, 2 = nt); T: storage type of x / y (float | ms_bf16_tag)
+template <int THREADS, int AUXL, int AUXS, typename T>
 __global__ __launch_bounds__(THREADS, 4) void style_fused_kernel(const FusedArgs a) {
+  using IO = StyleIo<T>;
+  constexpr int EPL = IO::EPL, NSLOT = 4 * kFusedNV / EPL, ESZ = 16 / EPL;      // values per 16-byte access, register slots per thread, bytes per value
   __shared__ float red[16];
   __shared__ double redd[16];
   __shared__ float smu[256], ssig[256];
@@ -89,29 +126,33 @@ __global__ __launch_bounds__(THREADS, 4) void style_fused_kernel(const FusedArgs
   for (int t = blockIdx.x; t < total; t += gridDim.x) {
     const int c = t / G, r = t - c * G, b = r / S, s = r - b * S;
     const int p = b * C + c;
-    const int beg = s * chunk, cnt = min(HW - beg, chunk);                 // floats; both multiples of 4
+    const int beg = s * chunk, cnt = min(HW - beg, chunk);                 // values; both multiples of EPL
     const size_t base = (size_t)p * HW + beg;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + base), 0, cnt * 4, 0x00020000);
-    float4 v[kFusedNV];
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.x)) + base * ESZ, 0, cnt * ESZ, 0x00020000);
+    float v[NSLOT][EPL];
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < kFusedNV; ++j) {
-      v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < nv) {                                                          // wave-uniform; lanes past the chunk read 0 (range check)
-        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, j * THREADS * 16, AUXL);
-        v[j] = make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
-      }
+    for (int j = 0; j < NSLOT; ++j) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) v[j][e] = 0.f;
+      if (j < nv) IO::template load<AUXL>(rx, voff, j * THREADS * 16, v[j]);          // wave-uniform; lanes past the chunk read 0 (range check)
     }
 #pragma unroll
-    for (int j = 0; j < kFusedNV; ++j) sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    for (int j = 0; j < NSLOT; ++j) {
+#pragma unroll
+      for (int e = 0; e < EPL; e += 4) sum += (v[j][e] + v[j][e + 1]) + (v[j][e + 2] + v[j][e + 3]);
+    }
     const float n = (float)cnt;
     const float mean_c = block_sum(sum, red) / n;
     float m2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < kFusedNV; ++j) {
-      if ((j * THREADS + tid) * 4 < cnt) {
-        const float d0 = v[j].x - mean_c, d1 = v[j].y - mean_c, d2 = v[j].z - mean_c, d3 = v[j].w - mean_c;
-        m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    for (int j = 0; j < NSLOT; ++j) {
+      if ((j * THREADS + tid) * EPL < cnt) {
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) {
+          const float d0 = v[j][e] - mean_c, d1 = v[j][e + 1] - mean_c, d2 = v[j][e + 2] - mean_c, d3 = v[j][e + 3] - mean_c;
+          m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
       }
     }
     m2 = block_sum(m2, red);
@@ -170,14 +211,14 @@ __global__ __launch_bounds__(THREADS, 4) void style_fused_kernel(const FusedArgs
       if (b == 0 && (a.compute_std & 1)) { a.gamma_std[c] = gs; a.beta_std[c] = bs; }
     }
     const float sc = A / sg;
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + base, 0, cnt * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.y) + base * ESZ, 0, cnt * ESZ, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < kFusedNV; ++j) {
+    for (int j = 0; j < NSLOT; ++j) {
       if (j < nv) {
-        u32x4 o;
-        o.x = __float_as_uint(sc * (v[j].x - m) + Sh); o.y = __float_as_uint(sc * (v[j].y - m) + Sh);
-        o.z = __float_as_uint(sc * (v[j].z - m) + Sh); o.w = __float_as_uint(sc * (v[j].w - m) + Sh);
-        __builtin_amdgcn_raw_buffer_store_b128(o, ry, voff, j * THREADS * 16, AUXS);     // lanes past the chunk are dropped by the range check
+        float o[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[e] = sc * (v[j][e] - m) + Sh;
+        IO::template store<AUXS>(ry, voff, j * THREADS * 16, o);                       // lanes past the chunk are dropped by the range check
       }
     }
     __syncthreads();      // smu/ssig are reused by the next unit
@@ -202,10 +243,10 @@ static int env_int(const char* name, int dflt) {
 // State block: ints [0] epoch, [1] error word, [2] finished-workgroup counter; granules (8 B each) from byte 16.
 // Geometry: a unit is a balanced chunk of one plane held in registers by one workgroup (<= 64 floats per thread).  Prefer the fattest
 // workgroup that still gives every CU work; all units of one channel (G = B*S) must be resident together.
-static FusedPlan fused_plan(int B, int C, int HW) {
+static FusedPlan fused_plan(int B, int C, int HW, int epl = 4) {
   FusedPlan pl{};
   pl.ok = false;
-  if (HW % 4 != 0 || B < 2 || B > 256) return pl;
+  if (HW % epl != 0 || B < 2 || B > 256) return pl;
   const int cus = num_cus();
   static const int force_threads = env_int("MS_STYLE_FUSED_THREADS", 0);        // A/B switches for tools/bench_kernels.py
   static const int force_split = env_int("MS_STYLE_FUSED_SPLIT", 0);
@@ -219,17 +260,17 @@ static FusedPlan fused_plan(int B, int C, int HW) {
     if (force_threads && threads != force_threads) continue;
     const int per_cu = 1024 / threads;                                            // workgroups per CU at <= 128 VGPRs (4 waves per SIMD)
     const long resident = (long)cus * per_cu;
-    const int max_chunk = threads * 4 * kFusedNV;
+    const int max_chunk = threads * 4 * kFusedNV;                                  // 64 values per thread whatever the storage type
     int S = cdiv(HW, max_chunk);
     // split planes further while the tensor has fewer units than the chip has workgroup slots (small C: layer 5 has 16 planes)
     if (cand[k].split || force_threads)
-      while ((long)B * C * S < resident && (long)B * (S * 2) <= resident && HW / (S * 2) >= threads * 4 && B * S * 2 <= 1024) S *= 2;
+      while ((long)B * C * S < resident && (long)B * (S * 2) <= resident && HW / (S * 2) >= threads * epl && B * S * 2 <= 1024) S *= 2;
     if (force_split) S = std::max(S, force_split);
-    int chunk = (cdiv(HW, S) + 3) / 4 * 4;
+    int chunk = (cdiv(HW, S) + epl - 1) / epl * epl;
     S = cdiv(HW, chunk);
-    const int nv = cdiv(chunk, threads * 4);
+    const int nv = cdiv(chunk, threads * epl);                                    // 16-byte register slots per thread
     const long G = (long)B * S;
-    if (nv > kFusedNV || G > resident || G > 1024) continue;
+    if (nv > 4 * kFusedNV / epl || G > resident || G > 1024) continue;
     const bool last = (k == 3) || force_threads;
     if (!last && (long)B * C * S < resident) continue;                            // the next candidate fills more CUs
     pl.threads = threads; pl.nv = nv; pl.chunk = chunk; pl.S = S;
@@ -268,10 +309,11 @@ extern "C" int ms_style_fused_plan(int B, int C, int HW, int* threads, int* nv, 
   return MS_OK;
 }
 
-extern "C" int ms_style_fwd_fused(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
-                                  const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
-                                  float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream) {
-  const FusedPlan pl = fused_plan(B, C, HW);
+template <typename T>
+static int style_fwd_fused_impl(const void* x, void* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+                                const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
+                                float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream) {
+  const FusedPlan pl = fused_plan(B, C, HW, StyleIo<T>::EPL);
   if (!pl.ok) { set_error("ms_style_fwd_fused: shape B=%d C=%d HW=%d is not eligible (use ms_style_fwd)", B, C, HW); return MS_ERR_INVALID; }
   if (!aligned16(x) || !aligned16(y)) { set_error("ms_style_fwd_fused: x and y must be 16-byte aligned"); return MS_ERR_ALIGN; }
   if (ws == nullptr || ws_bytes < pl.bytes || !aligned16(ws)) { set_error("ms_style_fwd_fused: workspace too small or unaligned"); return MS_ERR_WORKSPACE; }
@@ -284,14 +326,33 @@ extern "C" int ms_style_fwd_fused(const float* x, float* y, float* mu, float* si
   a.lmda = lmda; a.gamma_noise = gamma_noise; a.beta_noise = beta_noise; a.perm = perm; a.coefA = coefA; a.coefS = coefS;
   a.part = (u64*)((char*)ws + pl.part_off); a.arrive = hdr + 2; a.counter = hdr; a.err = hdr + 1;
   a.compute_std = compute_std; a.B = B; a.C = C; a.HW = HW; a.S = pl.S; a.chunk = pl.chunk; a.nv = pl.nv; a.eps = eps;
-  static const int policy = env_int("MS_STYLE_FUSED_NT", 0);                      // bit 0: nt loads of x, bit 1: nt stores of y (A/B timing)
+  static const int policy = env_int("MS_STYLE_FUSED_NT", 0);                      // bit 0: nt loads of x, bit 1: nt stores of y (A/B timing, fp32 only)
   dim3 grid(pl.grid), block(pl.threads);
-#define MS_FUSED(TT, AL, AS) MS_LAUNCH((style_fused_kernel<TT, AL, AS>), grid, block, 0, st, a)
-#define MS_FUSED_T(TT) switch (policy & 3) { case 1: MS_FUSED(TT, 2, 0); break; case 2: MS_FUSED(TT, 0, 2); break; case 3: MS_FUSED(TT, 2, 2); break; default: MS_FUSED(TT, 0, 0); }
+#define MS_FUSED(TT, AL, AS) MS_LAUNCH((style_fused_kernel<TT, AL, AS, T>), grid, block, 0, st, a)
+#define MS_FUSED_T(TT) if (std::is_same<T, float>::value) { switch (policy & 3) { case 1: MS_FUSED(TT, 2, 0); break; case 2: MS_FUSED(TT, 0, 2); break; \
+                                                                                 case 3: MS_FUSED(TT, 2, 2); break; default: MS_FUSED(TT, 0, 0); } } else { MS_FUSED(TT, 0, 0); }
   if (pl.threads == 1024) { MS_FUSED_T(1024) } else if (pl.threads == 512) { MS_FUSED_T(512) } else { MS_FUSED_T(256) }
 #undef MS_FUSED_T
 #undef MS_FUSED
   return check_launch("style_fused");
+}
+
+extern "C" int ms_style_fwd_fused(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+                                  const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
+                                  float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream) {
+  return style_fwd_fused_impl<float>(x, y, mu, sig, gamma_std, beta_std, compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, HW, eps, ws, ws_bytes, stream);
+}
+
+// bf16 activations in, bf16 activations out (uint16_t = the bf16 bit pattern); statistics, coefficients and arithmetic fp32.  Needs H*W % 8 == 0.
+extern "C" int ms_style_fwd_fused_bf16(const uint16_t* x, uint16_t* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+                                       const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
+                                       float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream) {
+  return style_fwd_fused_impl<ms_bf16_tag>(x, y, mu, sig, gamma_std, beta_std, compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, HW, eps, ws, ws_bytes, stream);
+}
+
+extern "C" size_t ms_style_fused_ws_bytes_bf16(int B, int C, int HW) {
+  const FusedPlan pl = fused_plan(B, C, HW, 8);
+  return pl.ok ? std::max(pl.bytes, fused_state_bytes(B, C, HW)) : 0;
 }
 
 // Error word of the single-read kernel's state block (`ws` as handed to ms_style_fwd_fused): a bounded spin that timed out sets it and the

@@ -35,6 +35,17 @@ def _need_cuda_f32(*ts):
             raise ValueError("maxstyle_amd ops need contiguous NCHW tensors")
 
 
+def _need_cuda_act(t):
+    """An activation tensor: fp32, or bf16 storage (the `*_bf16` entry points: statistics and arithmetic stay fp32)."""
+    if not t.is_cuda:
+        raise RuntimeError("maxstyle_amd ops run on the MI355X only: got a CPU tensor (there is no CPU fallback)")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"maxstyle_amd activations are fp32 or bf16; got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("maxstyle_amd ops need contiguous NCHW tensors")
+    return t.dtype == torch.bfloat16
+
+
 def workspace(nbytes, device):
     """A cached scratch buffer per (device, stream); grown geometrically. Kernels on one stream are ordered, so reuse is safe."""
     key = (device, _stream())
@@ -54,7 +65,8 @@ def style_ws(B, C, HW, device, kind="ws"):
     key = (device, _stream(), B, C, HW, kind)
     buf = _style_ws_cache.get(key)
     if buf is None:
-        n = lib.ms_style_ws_bytes(B, C, HW) if kind == "ws" else lib.ms_style_fused_ws_bytes(B, C, HW)
+        n = {"ws": lib.ms_style_ws_bytes, "fused": lib.ms_style_fused_ws_bytes, "ws_bf16": lib.ms_style_ws_bytes_bf16,
+             "fused_bf16": lib.ms_style_fused_ws_bytes_bf16}[kind](B, C, HW)
         buf = torch.zeros(max(int(n), 64), dtype=torch.uint8, device=device)
         _style_ws_cache[key] = buf
     return buf
@@ -73,16 +85,26 @@ def style_moments(x, eps=1e-6):
 
 def style_fwd(x, perm, lmda, gamma_noise, beta_noise, gamma_std, beta_std, compute_std, eps=1e-6, out=None, impl=None):
     """Returns y, mu, sig, coefA, coefS. gamma_std/beta_std are [1,C,1,1] buffers (written if compute_std).
-    impl: None = library dispatch, "fused" = single-read kernel, "3k" = three-launch path."""
-    _need_cuda_f32(x, lmda, gamma_noise, beta_noise, gamma_std, beta_std)      # compute_std: bool, or the flag word (bit 0 std, bit 1 no clamp)
+    impl: None = library dispatch, "fused" = single-read kernel, "3k" = three-launch path.  x may be bf16 (activation storage): y is bf16 then,
+    everything else fp32."""
+    bf16 = _need_cuda_act(x)
+    _need_cuda_f32(lmda, gamma_noise, beta_noise, gamma_std, beta_std)      # compute_std: bool, or the flag word (bit 0 std, bit 1 no clamp)
     B, C = x.shape[:2]
     HW = x[0, 0].numel()
     dev = x.device
     y = torch.empty_like(x) if out is None else out
+    if y.dtype != x.dtype:
+        raise TypeError("style_fwd: out must have the dtype of x")
     stats = torch.empty(4, B, C, 1, 1, device=dev, dtype=torch.float32)
     mu, sig, cA, cS = stats[0], stats[1], stats[2], stats[3]
-    ws = style_ws(B, C, HW, dev, "fused" if impl == "fused" else "ws")
-    fn = {None: lib.ms_style_fwd, "fused": lib.ms_style_fwd_fused, "3k": lib.ms_style_fwd_3k}[impl]
+    if bf16:
+        if impl == "3k":
+            raise NotImplementedError("bf16 storage: library dispatch or the single-read kernel")
+        ws = style_ws(B, C, HW, dev, "fused_bf16" if impl == "fused" else "ws_bf16")
+        fn = lib.ms_style_fwd_fused_bf16 if impl == "fused" else lib.ms_style_fwd_bf16
+    else:
+        ws = style_ws(B, C, HW, dev, "fused" if impl == "fused" else "ws")
+        fn = {None: lib.ms_style_fwd, "fused": lib.ms_style_fwd_fused, "3k": lib.ms_style_fwd_3k}[impl]
     check(fn(x.data_ptr(), y.data_ptr(), mu.data_ptr(), sig.data_ptr(), gamma_std.data_ptr(), beta_std.data_ptr(),
              int(compute_std), _ptr(lmda), _ptr(gamma_noise), _ptr(beta_noise), _ptr(perm),
              cA.data_ptr(), cS.data_ptr(), B, C, HW, eps, ws.data_ptr(), ws.numel(), _stream()), "ms_style_fwd")
@@ -90,7 +112,9 @@ def style_fwd(x, perm, lmda, gamma_noise, beta_noise, gamma_std, beta_std, compu
 
 
 def style_bwd(dy, x, mu, sig, coefA, gamma_std, beta_std, lmda, perm, need_dx, need_noise, need_lmda):
-    _need_cuda_f32(dy, x)
+    bf16 = _need_cuda_act(x)
+    if _need_cuda_act(dy) != bf16:
+        raise TypeError("style_bwd: dy and x must share one storage type")
     B, C = x.shape[:2]
     HW = x[0, 0].numel()
     dev = x.device
@@ -98,10 +122,11 @@ def style_bwd(dy, x, mu, sig, coefA, gamma_std, beta_std, lmda, perm, need_dx, n
     dg = torch.empty(B, C, 1, 1, device=dev, dtype=torch.float32) if need_noise else None
     db = torch.empty(B, C, 1, 1, device=dev, dtype=torch.float32) if need_noise else None
     dl = torch.empty(B, 1, 1, 1, device=dev, dtype=torch.float32) if need_lmda else None
-    ws = style_ws(B, C, HW, dev)
-    check(lib.ms_style_bwd(dy.data_ptr(), x.data_ptr(), _ptr(dx), mu.data_ptr(), sig.data_ptr(), coefA.data_ptr(),
-                           _ptr(gamma_std), _ptr(beta_std), _ptr(lmda), _ptr(perm), _ptr(dg), _ptr(db), _ptr(dl),
-                           B, C, HW, ws.data_ptr(), ws.numel(), _stream()), "ms_style_bwd")
+    ws = style_ws(B, C, HW, dev, "ws_bf16" if bf16 else "ws")
+    fn = lib.ms_style_bwd_bf16 if bf16 else lib.ms_style_bwd
+    check(fn(dy.data_ptr(), x.data_ptr(), _ptr(dx), mu.data_ptr(), sig.data_ptr(), coefA.data_ptr(),
+             _ptr(gamma_std), _ptr(beta_std), _ptr(lmda), _ptr(perm), _ptr(dg), _ptr(db), _ptr(dl),
+             B, C, HW, ws.data_ptr(), ws.numel(), _stream()), "ms_style_bwd")
     return dx, dg, db, dl
 
 

@@ -208,3 +208,38 @@ def test_mixstyle_dsu_vs_reference_golden(golden_dir, dev, tag, mix, lm):
     off = MixStyle(p=-1.0)
     xx = torch.randn(4, 3, 5, 5, device=dev)
     assert off(xx) is xx
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 256, 256), (16, 16, 128, 128), (16, 1, 256, 256), (4, 8, 16, 24), (6, 5, 8, 8)])
+def test_bf16_activation_storage(dev, shape):
+    """`*_bf16` entry points (BASELINE config 5): x / y / dy / dx stored as bf16, statistics and arithmetic fp32.
+    Tolerance, stated: the statistics equal the fp64 oracle on the bf16-ROUNDED input to fp32 accuracy (1e-5); y and dx are rounded to
+    nearest-even bf16 on store, so every element is within 2^-8 relative of the oracle value (2^-9 rounding + fp32 arithmetic), and the parameter
+    gradients - accumulated in fp32 from the rounded inputs - within 1e-4."""
+    import maxstyle_amd as M
+    from oracle import maxstyle_oracle as orc
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(shape, generator=g) * (torch.rand(B, C, 1, 1, generator=g) + 0.2) + torch.randn(B, C, 1, 1, generator=g)).bfloat16()
+    dy = torch.randn(shape, generator=g).bfloat16()
+    st = orc.random_style_state(B, C, 9, torch.float64)
+    y64, mu64, sig64 = orc.maxstyle_forward(x.double(), st, return_stats=True)
+    dx64, dg64, db64, dl64 = orc.maxstyle_backward(dy.double(), x.double(), mu64, sig64, st)
+    layer = M.MaxStyle(B, C, p=1.5)
+    layer.perm = st.perm.clone(); layer.rand_p = torch.tensor([0.0])
+    with torch.no_grad():
+        layer.gamma_noise.data = st.gamma_noise.float().to(dev); layer.beta_noise.data = st.beta_noise.float().to(dev); layer.lmda.data = st.lmda.float().to(dev)
+    xg = x.to(dev).requires_grad_(True)
+    y = layer(xg)
+    assert y.dtype == torch.bfloat16
+    y.backward(dy.to(dev))
+    mu, sig = layer._last_stats
+    assert mu.dtype == torch.float32 and rel(mu.view(B, C), mu64.view(B, C)) < 1e-5 and rel(sig.view(B, C), sig64.view(B, C)) < 1e-5
+    tol = 2.0 ** -8
+    err_y = ((y.detach().cpu().double() - y64).abs() / (y64.abs() + 1e-3)).max()
+    assert float(err_y) < tol, float(err_y)
+    assert xg.grad.dtype == torch.bfloat16
+    err_dx = ((xg.grad.cpu().double() - dx64).abs() / (dx64.abs() + 1e-3)).max()
+    assert float(err_dx) < tol, float(err_dx)
+    assert rel(layer.gamma_noise.grad, dg64) < 1e-4 and rel(layer.beta_noise.grad, db64) < 1e-4 and rel(layer.lmda.grad, dl64) < 1e-4
+    assert rel(layer.gamma_std, st.gamma_std) < 1e-5 and rel(layer.beta_std, st.beta_std) < 1e-5
