@@ -82,6 +82,24 @@ int ms_style_fwd_3k(const float* x, float* y, float* mu, float* sig, float* gamm
                     const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
                     float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
 
+/* ms_head_ce (segmentation head + cross entropy + backward to the head input h, custom_loss.py:1043-1078) whose dh is already multiplied by lrelu'(h) - h is the
+ * output of the last residual block - and which writes the BatchNorm-backward sums of that block's last BatchNorm (raw input bn_u, record bn_coef4) to
+ * bn_part [C][ms_head_ce_actbwd_parts(N,C,HW)][2]: replaces ms_head_ce + ms_act_bwd_reduce.  C <= 16 (parts() returns 0 otherwise: use the two calls). */
+int ms_head_ce_actbwd_parts(int N, int C, int HW);
+int ms_head_ce_actbwd(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* loss_out, const int* loss_slot_dev,
+                      int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,
+                      const float* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream);
+
+/* ms_style_bwd for a layer that sits right behind a residual block (x = that block's output): dx is additionally multiplied by lrelu'(x) and the sums the
+ * BatchNorm backward of the block's last BatchNorm needs are written to bn_part [C][ms_style_bwd_actbwd_parts(B,C,HW)][2] (the partial layout of
+ * ms_act_bwd_reduce, consumed by ms_bn_bwd_coefs / ms_bn_bwd_full): bn_u = that BatchNorm's raw input [B,C,H,W], bn_coef4 = its {scale, shift, mean, invstd}.
+ * Replaces ms_style_bwd + ms_act_bwd_reduce (encoder_decoder.py:344-346 backward); needs dx and H*W % 4 == 0.  The style gradients are unaffected. */
+int ms_style_bwd_actbwd_parts(int B, int C, int HW);
+int ms_style_bwd_actbwd(const float* dy, const float* x, float* dx, const float* mu, const float* sig, const float* coefA,
+                        const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
+                        float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes,
+                        const float* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream);
+
 /* bf16 ACTIVATION STORAGE variants ("`_bf16` I/O variants with fp32 statistics"; BASELINE config 5): x / y / dy / dx are bf16 bit
  * patterns (uint16_t, NCHW, 16-byte aligned, H*W % 8 == 0) - half the HBM bytes of these bandwidth-bound kernels; mu / sig / coefficients / std / partial
  * sums / parameter gradients stay fp32 (fp64 merges) and all arithmetic is fp32.  Results equal the fp32 entry points evaluated on the bf16-rounded

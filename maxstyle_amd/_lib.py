@@ -39,6 +39,12 @@ SIGNATURES = {
                                    c_int, c_int, c_int, c_float, c_void, c_size, c_void]),
     "ms_style_fwd_3k": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p,
                                 c_int, c_int, c_int, c_float, c_void, c_size, c_void]),
+    "ms_head_ce_actbwd_parts": (c_int, [c_int, c_int, c_int]),
+    "ms_head_ce_actbwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_void, c_int, c_int, c_int, c_int, c_float, c_void, c_size,
+                                  c_f32p, c_f32p, c_f32p, c_float, c_void]),
+    "ms_style_bwd_actbwd_parts": (c_int, [c_int, c_int, c_int]),
+    "ms_style_bwd_actbwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p,
+                                    c_int, c_int, c_int, c_void, c_size, c_f32p, c_f32p, c_f32p, c_float, c_void]),
     "ms_style_ws_bytes_bf16": (c_size, [c_int, c_int, c_int]),
     "ms_style_fused_ws_bytes_bf16": (c_size, [c_int, c_int, c_int]),
     "ms_style_fwd_bf16": (c_int, [c_void, c_void, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p,

@@ -288,6 +288,111 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_kernel(const float* __re
   if (threadIdx.x == 0) part[(size_t)n * gridDim.x + blockIdx.x] = picked;
 }
 
+// head_ce_kernel + the output-activation backward of the block whose output h is (ms_head_ce_actbwd; C <= 16): dh is multiplied by lrelu'(h) - sign(h) ==
+// sign(pre-activation), and h is already in this kernel's hands - and the per-channel sums the BatchNorm backward of the block's last BatchNorm needs
+// (sum g', sum g'*(u - mean_c)) are written per block in the partial layout of ms_act_bwd_reduce: bn_part[c][n*gridDim.x + blockIdx.x].
+constexpr int kHeadFuseC = 16;
+// VEC = 4: every thread owns 4 consecutive pixels (16-byte loads / stores of every channel plane; needs H*W % 4 == 0 and 16-byte aligned tensors)
+template <int VEC>
+__global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ b,
+                                                                      const int64_t* __restrict__ labels, float* __restrict__ dh, double* __restrict__ part,
+                                                                      int C, int K, int HW, float grad_scale,
+                                                                      const float* __restrict__ bn_u, const float4* __restrict__ bn_coef, float2* __restrict__ bn_part, float slope) {
+  __shared__ float sw[kMaxHeadK * kHeadFuseC + kMaxHeadK];
+  __shared__ float smean[kHeadFuseC];
+  __shared__ double redd[16];
+  for (int i = threadIdx.x; i < K * C; i += kElemThreads) sw[i] = w[i];
+  if (threadIdx.x < K) sw[kMaxHeadK * kHeadFuseC + threadIdx.x] = b ? b[threadIdx.x] : 0.f;
+  if (threadIdx.x < C) smean[threadIdx.x] = bn_coef[threadIdx.x].z;
+  __syncthreads();
+  const int n = blockIdx.y;
+  const float* hp = h + (size_t)n * C * HW;
+  const float* up = bn_u + (size_t)n * C * HW;
+  double picked = 0.0;
+  float b1[kHeadFuseC], b2[kHeadFuseC];
+#pragma unroll
+  for (int c = 0; c < kHeadFuseC; ++c) { b1[c] = 0.f; b2[c] = 0.f; }
+  for (int i = (blockIdx.x * kElemThreads + threadIdx.x) * VEC; i < HW; i += gridDim.x * kElemThreads * VEC) {
+    float z[kMaxHeadK][VEC], hv[kHeadFuseC][VEC];
+#pragma unroll
+    for (int k = 0; k < kMaxHeadK; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) z[k][e] = sw[kMaxHeadK * kHeadFuseC + k];
+#pragma unroll
+    for (int c = 0; c < kHeadFuseC; ++c) {
+      if (c < C) {
+        if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(hp + (size_t)c * HW + i); hv[c][0] = t.x; hv[c][1 % VEC] = t.y; hv[c][2 % VEC] = t.z; hv[c][3 % VEC] = t.w; }
+        else hv[c][0] = hp[(size_t)c * HW + i];
+#pragma unroll
+        for (int k = 0; k < kMaxHeadK; ++k)
+          if (k < K) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) z[k][e] += sw[k * C + c] * hv[c][e];
+          }
+      }
+    }
+    float d[kMaxHeadK][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float mx = z[0][e];
+#pragma unroll
+      for (int k = 1; k < kMaxHeadK; ++k) if (k < K) mx = fmaxf(mx, z[k][e]);
+      float se = 0.f;
+#pragma unroll
+      for (int k = 0; k < kMaxHeadK; ++k) if (k < K) se += expf(z[k][e] - mx);
+      const float lse = mx + logf(se);
+      const int lab = (int)labels[(size_t)n * HW + i + e];
+#pragma unroll
+      for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
+        const float pk = expf(z[k][e] - lse);
+        if (k == lab) picked += (double)(z[k][e] - lse);
+        d[k][e] = grad_scale * (pk - (k == lab ? 1.f : 0.f));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kHeadFuseC; ++c) {
+      if (c < C) {
+        float a[VEC], uu[VEC];
+        if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(up + (size_t)c * HW + i); uu[0] = t.x; uu[1 % VEC] = t.y; uu[2 % VEC] = t.z; uu[3 % VEC] = t.w; }
+        else uu[0] = up[(size_t)c * HW + i];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float t = 0.f;
+#pragma unroll
+          for (int k = 0; k < kMaxHeadK; ++k) if (k < K) t += sw[k * C + c] * d[k][e];
+          t *= (hv[c][e] > 0.f) ? 1.f : slope;
+          a[e] = t;
+          b1[c] += t;
+          b2[c] += t * (uu[e] - smean[c]);
+        }
+        if (VEC == 4) *reinterpret_cast<float4*>(dh + ((size_t)n * C + c) * HW + i) = make_float4(a[0], a[1 % VEC], a[2 % VEC], a[3 % VEC]);
+        else dh[((size_t)n * C + c) * HW + i] = a[0];
+      }
+    }
+  }
+  picked = block_sum_d(picked, redd);
+  if (threadIdx.x == 0) part[(size_t)n * gridDim.x + blockIdx.x] = picked;
+  // 2*C block sums with ONE barrier: wave-level shuffles first, then the four wave results through LDS (fixed order: deterministic)
+  const int N = (int)gridDim.y, S = (int)gridDim.x;
+  __shared__ float sred[kElemThreads / 64][2 * kHeadFuseC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < kHeadFuseC; ++c) {
+    if (c < C) {
+      const float t1 = wave_sum(b1[c]), t2 = wave_sum(b2[c]);
+      if (lane == 0) { sred[wv][c] = t1; sred[wv][kHeadFuseC + c] = t2; }
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    const int c = threadIdx.x;
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < kElemThreads / 64; ++q) { t1 += sred[q][c]; t2 += sred[q][kHeadFuseC + c]; }
+    bn_part[(size_t)c * (N * S) + n * S + blockIdx.x] = make_float2(t1, t2);
+  }
+}
+
 __global__ __launch_bounds__(256) void ce_finalize_kernel(const double* __restrict__ part, int nparts, double scale, float* __restrict__ loss_out,
                                                           const int* __restrict__ slot_dev) {
   __shared__ double redd[16];
@@ -441,6 +546,31 @@ extern "C" int ms_head_ce(const float* h, const float* w, const float* b, const 
   // loss = loss_sign * CE, CE = -(1/M) sum logp[label];  d loss / d logit_k = loss_sign * (p_k - 1[k==label]) / M
   MS_LAUNCH(head_ce_kernel, grid, dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, logits, (double*)ws, C, K, HW, (float)(loss_sign / M));
   if (int e = check_launch("head_ce")) return e;
+  MS_LAUNCH(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, gx * N, -(double)loss_sign / M, loss_out, loss_slot_dev);
+  return check_launch("ce_finalize");
+}
+
+static int head_fuse_gx(int HW) { return std::max(1, std::min(cdiv(HW, kElemThreads * 4), 256)); }      // 4 pixels per thread: 16-byte accesses, the per-block reduction amortised
+extern "C" int ms_head_ce_actbwd_parts(int N, int C, int HW) { return (C >= 1 && C <= kHeadFuseC) ? N * head_fuse_gx(HW) : 0; }
+
+// ms_head_ce (loss + dh) whose dh is already masked by the activation that produced h, with the BatchNorm-backward sums of that block
+// (h = lrelu(bn(bn_u) + skip): encoder_decoder.py:344-346): replaces ms_head_ce + ms_act_bwd_reduce.  C <= 16 (ms_head_ce_actbwd_parts returns 0 otherwise).
+extern "C" int ms_head_ce_actbwd(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* loss_out, const int* loss_slot_dev,
+                                 int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,
+                                 const float* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream) {
+  if (int e = head_check(N, C, K, HW, "ms_head_ce_actbwd")) return e;
+  if (C > kHeadFuseC || dh == nullptr || bn_u == nullptr || bn_coef4 == nullptr || bn_part == nullptr || !aligned16(bn_coef4)) {
+    set_error("ms_head_ce_actbwd: C <= %d, dh, bn_u, bn_coef4 (16-byte aligned) and bn_part are required", kHeadFuseC); return MS_ERR_INVALID;
+  }
+  if (ws == nullptr || ws_bytes < ms_head_ce_ws_bytes(N, HW)) { set_error("ms_head_ce_actbwd: workspace too small"); return MS_ERR_WORKSPACE; }
+  const int gx = head_fuse_gx(HW);
+  const double M = (double)N * HW;
+  const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(bn_u)) & 15u) == 0;
+  if (vec) MS_LAUNCH(head_ce_actbwd_kernel<4>, dim3(gx, N), dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, (double*)ws, C, K, HW, (float)(loss_sign / M),
+                     bn_u, (const float4*)bn_coef4, (float2*)bn_part, act_slope);
+  else MS_LAUNCH(head_ce_actbwd_kernel<1>, dim3(gx, N), dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, (double*)ws, C, K, HW, (float)(loss_sign / M),
+                 bn_u, (const float4*)bn_coef4, (float2*)bn_part, act_slope);
+  if (int e = check_launch("head_ce_actbwd")) return e;
   MS_LAUNCH(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, gx * N, -(double)loss_sign / M, loss_out, loss_slot_dev);
   return check_launch("ce_finalize");
 }

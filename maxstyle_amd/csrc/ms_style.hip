@@ -176,11 +176,17 @@ __global__ __launch_bounds__(kStyleThreads) void restyle_kernel(const float* __r
 }
 
 // backward: partial S1 = sum dy, S2 = sum dy*xhat; dx = dy * A/sig (optional)
+// bn_u != nullptr (ms_style_bwd_actbwd): x is the OUTPUT of a residual block (the layer sits right behind it), so the gradient this kernel hands back goes
+// straight into that block's output-activation backward: dx is additionally multiplied by lrelu'(x) (sign(x) == sign(pre-activation)) and the two sums the
+// BatchNorm backward of the block's last BatchNorm needs (sum g', sum g'*(u - mean_c), u = that BatchNorm's raw input) are written per block - what
+// ms_act_bwd_reduce would do in its own 4-pass launch over dx.  The style gradients use the UNMASKED dy, as before.
 template <int VEC>
 __global__ __launch_bounds__(kStyleThreads) void restyle_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
                                                                    const float* __restrict__ mu, const float* __restrict__ sig,
                                                                    const float* __restrict__ coefA, float2* __restrict__ part,
-                                                                   int HW, int chunk, int S) {
+                                                                   int HW, int chunk, int S,
+                                                                   const float* __restrict__ bn_u, const float4* __restrict__ bn_coef, float2* __restrict__ bn_part,
+                                                                   int C, float slope) {
   __shared__ float red[16];
   const int p = blockIdx.y;
   const float m = mu[p], inv = 1.f / sig[p], a = coefA[p] * inv;
@@ -188,23 +194,40 @@ __global__ __launch_bounds__(kStyleThreads) void restyle_bwd_kernel(const float*
   const float* xp = x + (size_t)p * HW;
   const float* gp = dy + (size_t)p * HW;
   float* dxp = dx ? dx + (size_t)p * HW : nullptr;
-  float s1 = 0.f, s2 = 0.f;
+  const float* up = bn_u ? bn_u + (size_t)p * HW : nullptr;
+  const float bmean = bn_u ? bn_coef[p % C].z : 0.f;
+  float s1 = 0.f, s2 = 0.f, b1 = 0.f, b2 = 0.f;
   for (int i = beg + threadIdx.x * VEC; i < end; i += kStyleThreads * VEC) {
     if (VEC == 4) {
       const float4 g = *reinterpret_cast<const float4*>(gp + i);
       const float4 t = *reinterpret_cast<const float4*>(xp + i);
       s1 += (g.x + g.y) + (g.z + g.w);
       s2 += g.x * ((t.x - m) * inv) + g.y * ((t.y - m) * inv) + g.z * ((t.z - m) * inv) + g.w * ((t.w - m) * inv);
-      if (dxp) *reinterpret_cast<float4*>(dxp + i) = make_float4(g.x * a, g.y * a, g.z * a, g.w * a);
+      float4 o = make_float4(g.x * a, g.y * a, g.z * a, g.w * a);
+      if (up) {
+        const float4 uu = *reinterpret_cast<const float4*>(up + i);
+        o.x *= (t.x > 0.f) ? 1.f : slope; o.y *= (t.y > 0.f) ? 1.f : slope; o.z *= (t.z > 0.f) ? 1.f : slope; o.w *= (t.w > 0.f) ? 1.f : slope;
+        b1 += (o.x + o.y) + (o.z + o.w);
+        b2 += (o.x * (uu.x - bmean) + o.y * (uu.y - bmean)) + (o.z * (uu.z - bmean) + o.w * (uu.w - bmean));
+      }
+      if (dxp) *reinterpret_cast<float4*>(dxp + i) = o;
     } else {
       const float g = gp[i];
       s1 += g; s2 += g * ((xp[i] - m) * inv);
-      if (dxp) dxp[i] = g * a;
+      float o = g * a;
+      if (up) { o *= (xp[i] > 0.f) ? 1.f : slope; b1 += o; b2 += o * (up[i] - bmean); }
+      if (dxp) dxp[i] = o;
     }
   }
   s1 = block_sum(s1, red);
   s2 = block_sum(s2, red);
   if (threadIdx.x == 0) part[(size_t)p * S + blockIdx.x] = make_float2(s1, s2);
+  if (up) {
+    b1 = block_sum(b1, red);
+    b2 = block_sum(b2, red);
+    const int c = p % C, n = p / C, N = (int)gridDim.y / C;
+    if (threadIdx.x == 0) bn_part[(size_t)c * (N * S) + n * S + blockIdx.x] = make_float2(b1, b2);      // the layout of ms_act_bwd_reduce's partials
+  }
 }
 
 // one block per batch sample b; threads over channels.
@@ -493,14 +516,18 @@ extern "C" int ms_style_fwd_3k(const float* x, float* y, float* mu, float* sig, 
   return ms_style_apply(x, y, mu, sig, coefA, coefS, P, HW, stream);
 }
 
-extern "C" int ms_style_bwd(const float* dy, const float* x, float* dx, const float* mu, const float* sig, const float* coefA,
-                            const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
-                            float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes, void* stream) {
+static int style_bwd_impl(const float* dy, const float* x, float* dx, const float* mu, const float* sig, const float* coefA,
+                          const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
+                          float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes,
+                          const float* bn_u, const float* bn_coef4, float* bn_part, float slope, void* stream) {
   if (int e = check_style_args(B, C, HW, ws, ws_bytes)) return e;
   if (d_lmda != nullptr && (lmda == nullptr || perm == nullptr)) { set_error("ms_style_bwd: d_lmda needs lmda and perm"); return MS_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   const int P = B * C;
-  const bool vec = (HW % 4 == 0) && aligned16(x) && aligned16(dy) && (dx == nullptr || aligned16(dx));
+  if (bn_u != nullptr && (dx == nullptr || bn_coef4 == nullptr || bn_part == nullptr || P > kMaxPlanesPerLaunch || !aligned16(bn_coef4))) {
+    set_error("ms_style_bwd_actbwd: needs dx, bn_coef4 (16-byte aligned), bn_part and <= 65535 planes"); return MS_ERR_INVALID;
+  }
+  const bool vec = (HW % 4 == 0) && aligned16(x) && aligned16(dy) && (dx == nullptr || aligned16(dx)) && (bn_u == nullptr || aligned16(bn_u));
   const Split sp = choose_split(P, HW, vec);
   float2* part = (float2*)ws;
   for (int p0 = 0; p0 < P; p0 += kMaxPlanesPerLaunch) {
@@ -508,8 +535,10 @@ extern "C" int ms_style_bwd(const float* dy, const float* x, float* dx, const fl
     dim3 grid(sp.S, np), block(kStyleThreads);
     const size_t off = (size_t)p0 * HW;
     float* dxo = dx ? dx + off : nullptr;
-    if (vec) MS_LAUNCH(restyle_bwd_kernel<4>, grid, block, 0, st, dy + off, x + off, dxo, mu + p0, sig + p0, coefA + p0, part + (size_t)p0 * sp.S, HW, sp.chunk, sp.S);
-    else MS_LAUNCH(restyle_bwd_kernel<1>, grid, block, 0, st, dy + off, x + off, dxo, mu + p0, sig + p0, coefA + p0, part + (size_t)p0 * sp.S, HW, sp.chunk, sp.S);
+    if (vec) MS_LAUNCH(restyle_bwd_kernel<4>, grid, block, 0, st, dy + off, x + off, dxo, mu + p0, sig + p0, coefA + p0, part + (size_t)p0 * sp.S, HW, sp.chunk, sp.S,
+                       bn_u, (const float4*)bn_coef4, (float2*)bn_part, C, slope);
+    else MS_LAUNCH(restyle_bwd_kernel<1>, grid, block, 0, st, dy + off, x + off, dxo, mu + p0, sig + p0, coefA + p0, part + (size_t)p0 * sp.S, HW, sp.chunk, sp.S,
+                   bn_u, (const float4*)bn_coef4, (float2*)bn_part, C, slope);
   }
   if (int e = check_launch("restyle_bwd")) return e;
   if (d_gamma || d_beta || d_lmda) {
@@ -518,6 +547,25 @@ extern "C" int ms_style_bwd(const float* dy, const float* x, float* dx, const fl
     return check_launch("style_bwd_finalize");
   }
   return MS_OK;
+}
+
+extern "C" int ms_style_bwd(const float* dy, const float* x, float* dx, const float* mu, const float* sig, const float* coefA,
+                            const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
+                            float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes, void* stream) {
+  return style_bwd_impl(dy, x, dx, mu, sig, coefA, gamma_std, beta_std, lmda, perm, d_gamma, d_beta, d_lmda, B, C, HW, ws, ws_bytes, nullptr, nullptr, nullptr, 1.f, stream);
+}
+
+extern "C" int ms_style_bwd_actbwd_parts(int B, int C, int HW) {
+  return B * choose_split(B * C, HW, HW % 4 == 0).S;
+}
+
+extern "C" int ms_style_bwd_actbwd(const float* dy, const float* x, float* dx, const float* mu, const float* sig, const float* coefA,
+                                   const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
+                                   float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes,
+                                   const float* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream) {
+  if (bn_u == nullptr) { set_error("ms_style_bwd_actbwd: bn_u is required"); return MS_ERR_INVALID; }
+  if (HW % 4 != 0) { set_error("ms_style_bwd_actbwd: H*W must be a multiple of 4 (the partial count is fixed by ms_style_bwd_actbwd_parts)"); return MS_ERR_INVALID; }
+  return style_bwd_impl(dy, x, dx, mu, sig, coefA, gamma_std, beta_std, lmda, perm, d_gamma, d_beta, d_lmda, B, C, HW, ws, ws_bytes, bn_u, bn_coef4, bn_part, act_slope, stream);
 }
 
 // ---- bf16 activation storage -----------------------------------------------------------------------------------------------

@@ -786,14 +786,28 @@ class InnerLoopEngine:
         logits = self.t("s.logits", N, K, H, W) if need_logits else None
         nbytes = lib.ms_head_ce_ws_bytes(N, H * W)
         ws = self.t("s.ce_ws", max(nbytes, 64), dtype=torch.uint8)
-        check(lib.ms_head_ce(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), 0 if dh is None else dh.data_ptr(),
-                             0 if logits is None else logits.data_ptr(), self.loss_buf.data_ptr(), 0 if loss_slot is None else loss_slot.data_ptr(),
-                             N, C, K, H * W, self.loss_sign, ws.data_ptr(), ws.numel(), self._st()), "ms_head_ce")
+        pre = None
+        nparts = lib.ms_head_ce_actbwd_parts(N, C, H * W) if (need_grad and not need_logits and self.fuse_act_bwd and not self.bn_eval) else 0
+        if nparts > 0:
+            # the last block's output-activation backward rides on the head kernel (h is the block output: the mask is free)
+            b = self.buf
+            u2, coef = b["s.u4.u2"], b["s.u4.bn4.coef"]
+            part = self.t("s.u4.bw2.hpart", C, nparts, 2)
+            check(lib.ms_head_ce_actbwd(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), dh.data_ptr(), self.loss_buf.data_ptr(),
+                                        0 if loss_slot is None else loss_slot.data_ptr(), N, C, K, H * W, self.loss_sign, ws.data_ptr(), ws.numel(),
+                                        u2.data_ptr(), coef.data_ptr(), part.data_ptr(), LEAKY, self._st()), "ms_head_ce_actbwd")
+            bc = self.t("s.u4.bw2.bcoef", C, 4)
+            check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(N * H * W), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:s.u4")
+            pre = (dh, bc)
+        else:
+            check(lib.ms_head_ce(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), 0 if dh is None else dh.data_ptr(),
+                                 0 if logits is None else logits.data_ptr(), self.loss_buf.data_ptr(), 0 if loss_slot is None else loss_slot.data_ptr(),
+                                 N, C, K, H * W, self.loss_sign, ws.data_ptr(), ws.numel(), self._st()), "ms_head_ce")
         if not need_grad:
             return None
         d = dh
         for i in range(4, 0, -1):
-            d = self.res_bwd(f"s.u{i}", self.nets.seg, f"u{i}", d, "nn")
+            d = self.res_bwd(f"s.u{i}", self.nets.seg, f"u{i}", d, "nn", pre=pre if i == 4 else None)
         return self.encode_bwd(d)
 
     # ------------------------------------------------------------------ MaxStyle layers inside the decoder
@@ -886,6 +900,30 @@ class InnerLoopEngine:
                                B, C, HW, ws.data_ptr(), ws.numel(), self._st()), f"ms_style_bwd:{i}")
         return dx
 
+    def style_bwd_actbwd(self, i, dy, pfx):
+        """style_bwd of layer i whose input is the output of residual block `pfx`: the block's output-activation backward (mask + BatchNorm-backward sums)
+        happens in the same pass (ms_style_bwd_actbwd) -> (masked gradient, bcoef4) = the `pre` argument of res_bwd."""
+        s = self.styles[i]
+        b = self.buf
+        x = b[f"st{i}.x"]
+        B, C = x.shape[:2]
+        HW = x.shape[2] * x.shape[3]
+        stats, std = b[f"st{i}.stats"], b[f"st{i}.std"]
+        dx = self.t(f"st{i}.dx", *x.shape)
+        ws = b[f"st{i}.ws"]
+        u, coef = b[pfx + ".u2"], b[pfx + ".bn4.coef"]
+        nparts = lib.ms_style_bwd_actbwd_parts(B, C, HW)
+        part = self.t(pfx + ".bw2.spart", C, nparts, 2)
+        go = lambda nm: self.flat_g.data_ptr() + 4 * s.off[nm][0]
+        po = lambda nm: self.flat_p.data_ptr() + 4 * s.off[nm][0]
+        check(lib.ms_style_bwd_actbwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+                                      std[0].data_ptr(), std[1].data_ptr(), po("lmda") if s.mix_style else 0, s.perm.data_ptr() if s.mix_style else 0,
+                                      go("gamma_noise") if s.use_noise else 0, go("beta_noise") if s.use_noise else 0, go("lmda") if s.mix_style else 0,
+                                      B, C, HW, ws.data_ptr(), ws.numel(), u.data_ptr(), coef.data_ptr(), part.data_ptr(), LEAKY, self._st()), f"ms_style_bwd_actbwd:{i}")
+        bc = self.t(pfx + ".bw2.bcoef", C, 4)
+        check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(B * HW), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + pfx)
+        return dx, bc
+
     def _style_ws(self, i, nbytes):
         """One workspace per layer, zero-filled once: its tail is the persistent epoch state of the single-read kernel (ms_style_ws_bytes)."""
         b = self.buf.get(f"st{i}.ws")
@@ -960,11 +998,17 @@ class InnerLoopEngine:
         check(lib.ms_head_bwd(g.data_ptr(), self.buf["d.image"].data_ptr(), d["head.w"].data_ptr(), dh.data_ptr(), N, C, K, H * W, 1, self._st()), "ms_head_bwd")
         g = dh
         for i in range(4, 0, -1):
+            pre = None
             if i in self.layers and not self._is_identity(i, self.buf[f"d.u{i}.out"].shape):
-                g = self.style_bwd(i, g, need_dx=(first < i))
+                x = self.buf[f"d.u{i}.out"]
+                if first < i and self.fuse_act_bwd and not self.bn_eval and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[0] * x.shape[1] <= 65535:
+                    pre = self.style_bwd_actbwd(i, g, f"d.u{i}")      # the block's output-activation backward rides on the layer's backward pass
+                    g = None
+                else:
+                    g = self.style_bwd(i, g, need_dx=(first < i))
                 if first == i:
                     return
-            g = self.res_bwd(f"d.u{i}", d, f"u{i}", g, self._dec_kind(), need_dx=True)
+            g = self.res_bwd(f"d.u{i}", d, f"u{i}", g, self._dec_kind(), need_dx=True, pre=pre)
         if 0 in self.layers:
             self.style_bwd(0, g, need_dx=False)
 

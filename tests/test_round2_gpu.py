@@ -394,3 +394,75 @@ def test_loop_on_trained_networks_vs_reference(golden_dir, dev):
     np.testing.assert_allclose(dice, g["f32.final_dice"], atol=2e-2)
     agree = float((logits.argmax(1).cpu().numpy() == g["f32.final_pred"]).mean())
     assert agree > 0.99, agree
+
+
+# ------------------------------------------------------------------------------------------------ activation backward riding on its producer
+def _bn_coefs(lib, check, part, nparts, coef, count, C, dev):
+    bc = torch.empty(C, 4, device=dev)
+    check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(count), bc.data_ptr(), C, torch.cuda.current_stream().cuda_stream), "bn_bwd_coefs")
+    return bc
+
+
+@pytest.mark.parametrize("N,C,K,H,W", [(4, 16, 4, 64, 64), (2, 16, 2, 40, 24), (3, 7, 4, 16, 20)])
+def test_head_ce_with_block_activation_backward(dev, N, C, K, H, W):
+    """ms_head_ce_actbwd == ms_head_ce followed by ms_act_bwd_reduce on its dh (mask by the block output h, BatchNorm-backward sums): loss and masked gradient
+    bit for bit, coefficients to rounding."""
+    from maxstyle_amd._lib import lib, check
+    g = torch.Generator().manual_seed(2)
+    HW = H * W
+    h = torch.randn(N, C, H, W, generator=g).to(dev); u = torch.randn(N, C, H, W, generator=g).to(dev)
+    w = (torch.randn(K, C, generator=g) * 0.3).to(dev); b = torch.randn(K, generator=g).to(dev)
+    lab = torch.randint(0, K, (N, H, W), generator=g).to(dev)
+    coef = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5], dim=1).contiguous().to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(max(lib.ms_head_ce_ws_bytes(N, HW), 64), dtype=torch.uint8, device=dev)
+    loss_a, loss_b = torch.zeros(4, device=dev), torch.zeros(4, device=dev)
+    dh_ref = torch.empty_like(h)
+    check(lib.ms_head_ce(h.data_ptr(), w.data_ptr(), b.data_ptr(), lab.data_ptr(), dh_ref.data_ptr(), 0, loss_a.data_ptr(), 0, N, C, K, HW, -1.0, ws.data_ptr(), ws.numel(), st), "head_ce")
+    np_ref = lib.ms_act_bwd_parts(N, C, HW)
+    part_ref = torch.empty(C, np_ref, 2, device=dev)
+    check(lib.ms_act_bwd_reduce(dh_ref.data_ptr(), h.data_ptr(), u.data_ptr(), coef.data_ptr(), dh_ref.data_ptr(), part_ref.data_ptr(), N, C, HW, 0.2, st), "act_bwd_reduce")
+    bc_ref = _bn_coefs(lib, check, part_ref, np_ref, coef, N * HW, C, dev)
+    nparts = lib.ms_head_ce_actbwd_parts(N, C, HW)
+    assert nparts > 0 and lib.ms_head_ce_actbwd_parts(N, 64, HW) == 0
+    part = torch.empty(C, nparts, 2, device=dev)
+    dh = torch.empty_like(h)
+    check(lib.ms_head_ce_actbwd(h.data_ptr(), w.data_ptr(), b.data_ptr(), lab.data_ptr(), dh.data_ptr(), loss_b.data_ptr(), 0, N, C, K, HW, -1.0, ws.data_ptr(), ws.numel(),
+                                u.data_ptr(), coef.data_ptr(), part.data_ptr(), 0.2, st), "head_ce_actbwd")
+    assert torch.equal(dh, dh_ref) and torch.equal(loss_a[:1], loss_b[:1])
+    assert rel(_bn_coefs(lib, check, part, nparts, coef, N * HW, C, dev), bc_ref) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(4, 16, 64, 64), (16, 16, 256, 256), (3, 5, 12, 20)])
+def test_style_backward_with_block_activation_backward(dev, shape):
+    """ms_style_bwd_actbwd == ms_style_bwd followed by ms_act_bwd_reduce on its dx (x = the block output): dx bit for bit, style gradients unchanged,
+    BatchNorm-backward coefficients to rounding."""
+    from maxstyle_amd import ops
+    from maxstyle_amd._lib import lib, check
+    from oracle import maxstyle_oracle as orc
+    B, C, H, W = shape
+    HW = H * W
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(shape, generator=g).to(dev); dy = torch.randn(shape, generator=g).to(dev); u = torch.randn(shape, generator=g).to(dev)
+    coef = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5], dim=1).contiguous().to(dev)
+    st_ = orc.random_style_state(B, C, 3)
+    gs, bs = torch.empty(1, C, 1, 1, device=dev), torch.empty(1, C, 1, 1, device=dev)
+    perm = st_.perm.to(dev); lm = st_.lmda.to(dev).contiguous(); gn = st_.gamma_noise.to(dev).contiguous(); bn = st_.beta_noise.to(dev).contiguous()
+    y, mu, sig, cA, cS = ops.style_fwd(x, perm, lm, gn, bn, gs, bs, True)
+    dx_ref, dg_ref, db_ref, dl_ref = ops.style_bwd(dy, x, mu, sig, cA, gs, bs, lm, perm, True, True, True)
+    st = torch.cuda.current_stream().cuda_stream
+    np_ref = lib.ms_act_bwd_parts(B, C, HW)
+    part_ref = torch.empty(C, np_ref, 2, device=dev)
+    masked_ref = dx_ref.clone()
+    check(lib.ms_act_bwd_reduce(masked_ref.data_ptr(), x.data_ptr(), u.data_ptr(), coef.data_ptr(), masked_ref.data_ptr(), part_ref.data_ptr(), B, C, HW, 0.2, st), "act_bwd_reduce")
+    bc_ref = _bn_coefs(lib, check, part_ref, np_ref, coef, B * HW, C, dev)
+    ws = ops.style_ws(B, C, HW, dev)
+    nparts = lib.ms_style_bwd_actbwd_parts(B, C, HW)
+    part = torch.empty(C, nparts, 2, device=dev)
+    dx = torch.empty_like(x); dg = torch.empty(B, C, 1, 1, device=dev); db = torch.empty_like(dg); dl = torch.empty(B, 1, 1, 1, device=dev)
+    check(lib.ms_style_bwd_actbwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), mu.data_ptr(), sig.data_ptr(), cA.data_ptr(), gs.data_ptr(), bs.data_ptr(), lm.data_ptr(),
+                                  perm.data_ptr(), dg.data_ptr(), db.data_ptr(), dl.data_ptr(), B, C, HW, ws.data_ptr(), ws.numel(), u.data_ptr(), coef.data_ptr(),
+                                  part.data_ptr(), 0.2, st), "style_bwd_actbwd")
+    assert torch.equal(dx, masked_ref)
+    assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref) and torch.equal(dl, dl_ref)
+    assert rel(_bn_coefs(lib, check, part, nparts, coef, B * HW, C, dev), bc_ref) < 2e-5
