@@ -82,6 +82,11 @@ int ms_style_fwd_3k(const float* x, float* y, float* mu, float* sig, float* gamm
                     const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
                     float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
 
+/* Backward of nn.UpsamplingNearest2d (ms_pool2_sum) + the accumulate of the 1x1 skip data-gradient + the output-activation backward of the block BELOW
+ * (ms_act_bwd_reduce) in one pass: out = (pool2(in) [+ add]) * lrelu'(act); part2 as ms_act_bwd_reduce ([C][ms_act_bwd_parts(N,C,Ho*Wo)][2]). */
+int ms_pool2_actbwd(const float* in, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
+                    int N, int C, int Ho, int Wo, float slope, void* stream);
+
 /* ms_head_ce (segmentation head + cross entropy + backward to the head input h, custom_loss.py:1043-1078) whose dh is already multiplied by lrelu'(h) - h is the
  * output of the last residual block - and which writes the BatchNorm-backward sums of that block's last BatchNorm (raw input bn_u, record bn_coef4) to
  * bn_part [C][ms_head_ce_actbwd_parts(N,C,HW)][2]: replaces ms_head_ce + ms_act_bwd_reduce.  C <= 16 (parts() returns 0 otherwise: use the two calls). */
@@ -157,6 +162,13 @@ int ms_conv2d(const float* in, const float* in2, float* out, const float* w_pack
               int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
               int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
               int epi_mode, float* stats, void* stream);
+
+/* 3x3 stride-1 convolution with <= 4 OUTPUT channels on the vector ALUs (csrc/ms_conv_small.hip): the data-gradient that reaches the image (`inc.0`,
+ * encoder_decoder.py:441-445: 16 -> 1 channels at config 2, 64 -> 3 at config 4).  Same arithmetic contract as ms_conv2d(ks=3, stride=1) with pro_mode 0 or 2
+ * (BatchNorm-backward prologue pro_a*in + pro_b*in2 + pro_c); w_packed = the packed weights [9][cin_pad][cout_pad].  W % 4 == 0. */
+int ms_conv3x3_small_cout_ok(int Cout, int W);
+int ms_conv3x3_small_cout(const float* in, const float* in2, float* out, const float* w_packed, int N, int Cin, int H, int W, int Cout,
+                          int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_cstride, void* stream);
 
 /* Sub-pixel form of the two x2 resampling convolutions (csrc/ms_conv_subpix.h): same results as ms_conv2d with fetch = 1 / 2 to fp32 rounding, without
  * multiplying the duplicates / zeros the resampling inserts (2.25x / 4x fewer matrix instructions).  in [N,Cin,Hs,Ws] (Ws % 4 == 0), out [N,Cout,2Hs,2Ws].

@@ -39,6 +39,7 @@ SIGNATURES = {
                                    c_int, c_int, c_int, c_float, c_void, c_size, c_void]),
     "ms_style_fwd_3k": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p,
                                 c_int, c_int, c_int, c_float, c_void, c_size, c_void]),
+    "ms_pool2_actbwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_float, c_void]),
     "ms_head_ce_actbwd_parts": (c_int, [c_int, c_int, c_int]),
     "ms_head_ce_actbwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_void, c_int, c_int, c_int, c_int, c_float, c_void, c_size,
                                   c_f32p, c_f32p, c_f32p, c_float, c_void]),
@@ -67,6 +68,8 @@ SIGNATURES = {
     "ms_act_bwd_reduce": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_float, c_void]),
     "ms_act_bwd_bn": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_void, c_f32p, c_int, c_int, c_int, c_float, c_void]),
     "ms_conv1x1_bnres": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_float, c_int, c_void]),
+    "ms_conv3x3_small_cout_ok": (c_int, [c_int, c_int]),
+    "ms_conv3x3_small_cout": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_int, c_void]),
     "ms_conv_subpix_eligible": (c_int, [c_int, c_int]),
     "ms_conv_subpix": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_void]),
     "ms_conv_actbwd_tab_bytes": (ctypes.c_size_t, [c_int]),

@@ -177,6 +177,39 @@ __global__ __launch_bounds__(kElemThreads) void pool2_sum_kernel(const float* __
   }
 }
 
+// pool2_sum + accumulate + the output-activation backward of the block BELOW in one pass (ms_pool2_actbwd): the gradient w.r.t. the input of an up_type 'NN'
+// block is pool2(d_hi) + (1x1 skip data-gradient); that tensor is the gradient w.r.t. the OUTPUT of the block below, whose backward starts with
+// g = dout * lrelu'(act) and the two BatchNorm-backward sums (ms_act_bwd_reduce).  grid (S, N*C) as act_bwd_reduce; 4 low-resolution pixels per thread.
+__global__ __launch_bounds__(kElemThreads) void pool2_actbwd_kernel(const float* __restrict__ in, const float* __restrict__ add, float* __restrict__ gout,
+                                                                    const float* __restrict__ act, const float* __restrict__ u, const float4* __restrict__ coef,
+                                                                    float2* __restrict__ part, int C, int Ho, int Wo, int chunk, int S, int N, float slope) {
+  __shared__ float red[16];
+  const int p = blockIdx.y, c = p % C, n = p / C;
+  const float mean = coef[c].z;
+  const int HWo = Ho * Wo;
+  const int beg = blockIdx.x * chunk, end = min(HWo, beg + chunk);
+  const size_t base = (size_t)p * HWo;
+  const float* ip = in + (size_t)p * 4 * HWo;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = beg + threadIdx.x * 4; i < end; i += kElemThreads * 4) {
+    const int y = i / Wo, x = i - y * Wo;                       // Wo % 4 == 0: the quad stays in one row
+    const float* r0 = ip + (size_t)(2 * y) * (2 * Wo) + 2 * x;
+    const float4 a0 = *reinterpret_cast<const float4*>(r0), a1 = *reinterpret_cast<const float4*>(r0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(r0 + 2 * Wo), b1 = *reinterpret_cast<const float4*>(r0 + 2 * Wo + 4);
+    float4 v = make_float4((a0.x + a0.y) + (b0.x + b0.y), (a0.z + a0.w) + (b0.z + b0.w), (a1.x + a1.y) + (b1.x + b1.y), (a1.z + a1.w) + (b1.z + b1.w));
+    if (add != nullptr) { const float4 q = *reinterpret_cast<const float4*>(add + base + i); v.x = q.x + v.x; v.y = q.y + v.y; v.z = q.z + v.z; v.w = q.w + v.w; }
+    const float4 r = *reinterpret_cast<const float4*>(act + base + i);
+    const float4 uu = *reinterpret_cast<const float4*>(u + base + i);
+    v.x *= (r.x > 0.f) ? 1.f : slope; v.y *= (r.y > 0.f) ? 1.f : slope; v.z *= (r.z > 0.f) ? 1.f : slope; v.w *= (r.w > 0.f) ? 1.f : slope;
+    *reinterpret_cast<float4*>(gout + base + i) = v;
+    s1 += (v.x + v.y) + (v.z + v.w);
+    s2 += (v.x * (uu.x - mean) + v.y * (uu.y - mean)) + (v.z * (uu.z - mean) + v.w * (uu.w - mean));
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) part[(size_t)c * (N * S) + n * S + blockIdx.x] = make_float2(s1, s2);
+}
+
 // ---- heads (few output channels: VALU dot products, HBM-bound on h) -------------------------------------
 constexpr int kMaxHeadC = 64, kMaxHeadK = 4;
 
@@ -510,6 +543,20 @@ extern "C" int ms_pool2_sum(const float* in, float* out, int planes, int Ho, int
   const int blocks = (int)std::min<size_t>((total + kElemThreads - 1) / kElemThreads, 4096);
   MS_LAUNCH(pool2_sum_kernel, dim3(blocks), dim3(kElemThreads), 0, (hipStream_t)stream, in, out, planes, Ho, Wo, accumulate);
   return check_launch("pool2_sum");
+}
+
+// out = (pool2_sum(in) [+ add]) * lrelu'(act), part2 = the partial sums of ms_act_bwd_reduce ([C][ms_act_bwd_parts(N,C,Ho*Wo)][2]).  in [N,C,2Ho,2Wo]; add (may be NULL
+// or == out), out, act, u [N,C,Ho,Wo]; Wo % 4 == 0, 16-byte aligned.
+extern "C" int ms_pool2_actbwd(const float* in, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
+                               int N, int C, int Ho, int Wo, float slope, void* stream) {
+  if (N < 1 || C < 1 || Ho < 1 || Wo < 4 || Wo % 4 != 0) { set_error("ms_pool2_actbwd: invalid shape (Wo %% 4 == 0)"); return MS_ERR_INVALID; }
+  if ((long)N * C > 65535) { set_error("ms_pool2_actbwd: too many planes"); return MS_ERR_INVALID; }
+  if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(u) |
+        reinterpret_cast<uintptr_t>(coef4) | reinterpret_cast<uintptr_t>(add)) & 15u) != 0) { set_error("ms_pool2_actbwd: tensors must be 16-byte aligned"); return MS_ERR_ALIGN; }
+  const ElemSplit sp = elem_split(N * C, Ho * Wo);
+  MS_LAUNCH(pool2_actbwd_kernel, dim3(sp.S, N * C), dim3(kElemThreads), 0, (hipStream_t)stream, in, add, out, act, u, (const float4*)coef4, (float2*)part2,
+            C, Ho, Wo, sp.chunk, sp.S, N, slope);
+  return check_launch("pool2_actbwd");
 }
 
 static int head_check(int N, int C, int K, int HW, const char* who) {

@@ -306,6 +306,7 @@ class InnerLoopEngine:
         # the two x2 resampling convolutions in their sub-pixel form (ms_conv_subpix: no products with the duplicates / zeros the resampling inserts);
         # MS_SUBPIX=0 is the A/B switch (results agree to fp32 rounding: the up-sampling form pre-adds the taps that meet on one stored pixel)
         self.subpix = os.environ.get("MS_SUBPIX", "1") != "0"
+        self.small_cout = os.environ.get("MS_SMALL_COUT", "1") != "0"      # vector-ALU kernel for the 16 -> 1 (64 -> 3) data-gradient to the image
         self._side_stream = None
         self._side_pending = False
         # MixStyle / DSU layers inside the encoder (generate_style_augmented_latent_code, advanced_triplet...py:632-670):
@@ -682,6 +683,17 @@ class InnerLoopEngine:
         self._join_side()
         if kind == "nn":
             dhi, _, _ = self.conv(pfx + ".dhi", g1, c0, bnbwd=(bc1, b[pfx + ".u1"]), dgrad=True)   # at the up-sampled resolution
+            if next_act is not None and self.fuse_act_bwd and not self.bn_eval and dx.shape[3] % 4 == 0 and dx.shape[0] * dx.shape[1] <= 65535:
+                # pool + accumulate + the output-activation backward of the block below in one pass (ms_pool2_actbwd)
+                bw_name, act_out, u, coef, slope = next_act
+                N, C, Ho, Wo = dx.shape
+                nparts = lib.ms_act_bwd_parts(N, C, Ho * Wo)
+                part = self.t(bw_name + ".ppart", C, nparts, 2)
+                check(lib.ms_pool2_actbwd(dhi.data_ptr(), dx.data_ptr(), dx.data_ptr(), act_out.data_ptr(), u.data_ptr(), coef.data_ptr(), part.data_ptr(),
+                                          N, C, Ho, Wo, slope, self._st()), "ms_pool2_actbwd:" + pfx)
+                bc = self.t(bw_name + ".bcoef", C, 4)
+                check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(N * Ho * Wo), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + bw_name)
+                return dx, bc
             self.pool2(pfx + ".dx", dhi, out=dx, accumulate=True)
             return dx
         self.conv(pfx + ".dsrc", g1, c0, bnbwd=(bc1, b[pfx + ".u1"]), dgrad=True, epi=1, out=dsrc)  # at the strided / transposed-conv resolution
@@ -750,9 +762,10 @@ class InnerLoopEngine:
         cf2 = self.bn_fin("e.cd.bn4", st, p, e["cd4"])
         return self.bn_act("e.z_s", u2, cf2, None, 0, 0.0)
 
-    def encode_bwd(self, dz_s):
+    def encode_bwd(self, dz_s, pre=None):
+        """pre = (masked gradient, bcoef4) when the producer of dz_s already did the backward of the code_decoupler's last activation."""
         e, b = self.nets.enc, self.buf
-        g, bc = self.act_bwd("e.cd.bw2", dz_s, b["e.z_s"], b["e.cd.u2"], b["e.cd.bn4.coef"], 0.0)
+        g, bc = pre if pre is not None else self.act_bwd("e.cd.bw2", dz_s, b["e.z_s"], b["e.cd.u2"], b["e.cd.bn4.coef"], 0.0)
         g, bc = self.dgrad_act_bwd("e.cd.da", "e.cd.bw1", g, e["cd3"], (bc, b["e.cd.u2"]), b["e.cd.u1"], b["e.cd.bn1.coef"], LEAKY)
         dz_i, _, _ = self.conv("e.dz_i", g, e["cd0"], bnbwd=(bc, b["e.cd.u1"]), dgrad=True)
         g, bc = self.act_bwd("e.fc.bw", dz_i, b["e.z_i"], b["e.fc.u"], b["e.fc.bn.coef"], 0.0)
@@ -766,7 +779,16 @@ class InnerLoopEngine:
             pre, dh = (res, None) if isinstance(res, tuple) else (None, res)
         g, bc = pre if pre is not None else self.act_bwd("e.inc.bw2", dh, b["e.inc.out"], b["e.inc.ub"], b["e.inc.bn4.coef"], LEAKY)
         g, bc = self.dgrad_act_bwd("e.inc.da", "e.inc.bw1", g, e["inc3"], (bc, b["e.inc.ub"]), b["e.inc.ua"], b["e.inc.bn1.coef"], LEAKY)
-        dimg, _, _ = self.conv("e.dimage", g, e["inc0"], bnbwd=(bc, b["e.inc.ua"]), dgrad=True)
+        c0 = e["inc0"]
+        N, Cg, H, W = g.shape
+        if self.small_cout and lib.ms_conv3x3_small_cout_ok(c0.cin, W) and not isinstance(bc, tuple):
+            # the gradient that reaches the image has 1 (3) channels: vector-ALU kernel instead of a 16-column MFMA tile (ms_conv_small.hip)
+            dimg = self.t("e.dimage", N, c0.cin, H, W)
+            pa, pb, pc = ops.coef_ptrs(bc)
+            check(lib.ms_conv3x3_small_cout(g.data_ptr(), b["e.inc.ua"].data_ptr(), dimg.data_ptr(), c0.dwp.data_ptr(), N, Cg, H, W, c0.cin, 2, pa, pb, pc, 4, self._st()),
+                  "ms_conv3x3_small_cout:e.dimage")
+            return dimg
+        dimg, _, _ = self.conv("e.dimage", g, c0, bnbwd=(bc, b["e.inc.ua"]), dgrad=True)
         return dimg
 
     def seg_fwd(self, z_s):
@@ -806,9 +828,14 @@ class InnerLoopEngine:
         if not need_grad:
             return None
         d = dh
+        b = self.buf
         for i in range(4, 0, -1):
-            d = self.res_bwd(f"s.u{i}", self.nets.seg, f"u{i}", d, "nn", pre=pre if i == 4 else None)
-        return self.encode_bwd(d)
+            lo = f"s.u{i - 1}"
+            nxt = (lo + ".bw2", b[lo + ".out"], b[lo + ".u2"], b[lo + ".bn4.coef"], LEAKY) if i > 1 else \
+                  ("e.cd.bw2", b["e.z_s"], b["e.cd.u2"], b["e.cd.bn4.coef"], 0.0)
+            res = self.res_bwd(f"s.u{i}", self.nets.seg, f"u{i}", d, "nn", pre=pre, next_act=nxt)
+            pre, d = (res, None) if isinstance(res, tuple) else (None, res)
+        return self.encode_bwd(d, pre=pre)
 
     # ------------------------------------------------------------------ MaxStyle layers inside the decoder
     def configure_styles(self, layers: Sequence[int], slots: Dict[int, StyleSlot]):

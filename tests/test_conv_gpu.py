@@ -396,3 +396,28 @@ def test_subpixel_stride2_data_gradient(dev, N, Cin, Cout, H, W):
     check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(N * H * W), bc_ref.data_ptr(), Cin, st), "bn_bwd_coefs")
     assert torch.equal(g2, masked)
     assert rel(bc, bc_ref) < 2e-5
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,pro", [(2, 16, 1, 32, 64, 2), (16, 16, 1, 256, 256, 2), (2, 64, 3, 40, 72, 2), (1, 7, 2, 19, 20, 0), (3, 16, 4, 16, 128, 0)])
+def test_small_cout_conv(dev, N, Cin, Cout, H, W, pro):
+    """ms_conv3x3_small_cout (vector-ALU 3x3 conv for <= 4 output channels: the data-gradient to the image) vs fp64 math and vs ms_conv2d."""
+    from maxstyle_amd import ops
+    from maxstyle_amd._lib import lib, check
+    x = _rand((N, Cin, H, W), 1); u = _rand((N, Cin, H, W), 2); w = _rand((Cout, Cin, 3, 3), 3, 0.2)
+    bc = _rand((Cin, 4), 4)
+    if pro == 2:
+        p = bc[:, 0].double().view(1, -1, 1, 1) * x.double() + bc[:, 1].double().view(1, -1, 1, 1) * u.double() + bc[:, 2].double().view(1, -1, 1, 1)
+    else:
+        p = x.double()
+    ref = F.conv2d(p, w.double(), None, padding=1)
+    xd, ud, bcd = x.to(dev), u.to(dev), bc.to(dev).contiguous()
+    wp = ops.pack_conv_weight(w.to(dev))
+    out = torch.empty(N, Cout, H, W, device=dev)
+    pa, pb, pc = ops.coef_ptrs(bcd)
+    assert lib.ms_conv3x3_small_cout_ok(Cout, W) == 1
+    check(lib.ms_conv3x3_small_cout(xd.data_ptr(), ud.data_ptr() if pro == 2 else 0, out.data_ptr(), wp.data_ptr(), N, Cin, H, W, Cout, pro,
+                                    pa if pro == 2 else 0, pb if pro == 2 else 0, pc if pro == 2 else 0, 4, torch.cuda.current_stream().cuda_stream), "small_cout")
+    assert rel(out, ref) < 3e-6
+    kw = dict(pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=ud) if pro == 2 else {}
+    old = ops.conv2d(xd, wp, None, Cout, 3, 1, **kw)
+    assert rel(out, old) < 3e-6

@@ -466,3 +466,24 @@ def test_style_backward_with_block_activation_backward(dev, shape):
     assert torch.equal(dx, masked_ref)
     assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref) and torch.equal(dl, dl_ref)
     assert rel(_bn_coefs(lib, check, part, nparts, coef, B * HW, C, dev), bc_ref) < 2e-5
+
+
+@pytest.mark.parametrize("N,C,Ho,Wo,slope", [(4, 16, 32, 32, 0.2), (16, 16, 128, 128, 0.2), (2, 128, 4, 4, 0.0), (3, 5, 6, 12, 0.2)])
+def test_pool2_with_activation_backward(dev, N, C, Ho, Wo, slope):
+    """ms_pool2_actbwd == ms_pool2_sum(accumulate) followed by ms_act_bwd_reduce: masked gradient bit for bit, coefficients to rounding."""
+    from maxstyle_amd._lib import lib, check
+    g = torch.Generator().manual_seed(6)
+    hi = torch.randn(N, C, 2 * Ho, 2 * Wo, generator=g).to(dev); add = torch.randn(N, C, Ho, Wo, generator=g).to(dev)
+    act = torch.randn(N, C, Ho, Wo, generator=g).to(dev); u = torch.randn(N, C, Ho, Wo, generator=g).to(dev)
+    coef = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5], dim=1).contiguous().to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ref = add.clone()
+    check(lib.ms_pool2_sum(hi.data_ptr(), ref.data_ptr(), N * C, Ho, Wo, 1, st), "pool2_sum")
+    nparts = lib.ms_act_bwd_parts(N, C, Ho * Wo)
+    part_ref = torch.empty(C, nparts, 2, device=dev)
+    check(lib.ms_act_bwd_reduce(ref.data_ptr(), act.data_ptr(), u.data_ptr(), coef.data_ptr(), ref.data_ptr(), part_ref.data_ptr(), N, C, Ho * Wo, slope, st), "act_bwd_reduce")
+    out = add.clone()
+    part = torch.empty(C, nparts, 2, device=dev)
+    check(lib.ms_pool2_actbwd(hi.data_ptr(), out.data_ptr(), out.data_ptr(), act.data_ptr(), u.data_ptr(), coef.data_ptr(), part.data_ptr(), N, C, Ho, Wo, slope, st), "pool2_actbwd")
+    assert torch.equal(out, ref)
+    assert rel(_bn_coefs(lib, check, part, nparts, coef, N * Ho * Wo, C, dev), _bn_coefs(lib, check, part_ref, nparts, coef, N * Ho * Wo, C, dev)) < 2e-5
