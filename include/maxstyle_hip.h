@@ -177,7 +177,8 @@ int ms_conv3x3_small_cout(const float* in, const float* in2, float* out, const f
  *   mode 1: data-gradient of nn.Conv2d(3x3,s=2,p=1) (res_convdown.down, encoder_decoder.py:40); `in` = dY [N,Cout_fwd,Hs,Ws], w_packed = the
  *           DATA-GRADIENT packed weights, Cout = Cin_fwd.  With ref != NULL the epilogue also does what ms_act_bwd_reduce would do on the result:
  *           out = dX * lrelu'(ref) (ref = the materialised activation output [N,Cout,2Hs,2Ws]) and tab gets the sums of out and out*(u - mean) per channel
- *           (u = that activation's raw BatchNorm input, coef4 = its {scale, shift, mean, invstd}; table as ms_conv2d_actbwd: ms_conv_actbwd_tab_bytes). */
+ *           (u = that activation's raw BatchNorm input, coef4 = its {scale, shift, mean, invstd}; table as ms_conv2d_actbwd: ms_conv_actbwd_tab_bytes).
+ *           ref == NULL with u != NULL: the activation lrelu(scale*u + shift) was never materialised - the mask is recomputed from u. */
 int ms_conv_subpix_eligible(int Hs, int Ws);
 int ms_conv_subpix(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int mode,
                    float* stats, const float* ref, const float* u, const float* coef4, float act_slope, float* tab, void* stream);

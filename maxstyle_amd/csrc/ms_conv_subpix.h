@@ -239,14 +239,17 @@ __global__ __launch_bounds__(512, 4) void conv_subpix_kernel(const ConvArgs a, c
 
   // ---- epilogue ----
   float st_n = 0.f, st_mean[1] = {0.f}, st_m2[1] = {0.f};
-  float bias_v = 0.f, mk_mu = 0.f;
+  float bias_v = 0.f, mk_mu = 0.f, mk_sc = 0.f, mk_sh = 0.f;
   int bias_co0 = -1;
   auto load_bias = [&](int co0) {
     if (co0 == bias_co0) return;
     bias_co0 = co0;
     const int co = co0 + m;
     bias_v = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
-    if (a.epi_mode == 3) mk_mu = (co < a.Cout) ? reinterpret_cast<const float4*>(a.mk_coef)[co].z : 0.f;
+    if (a.epi_mode == 3) {
+      const float4 cf = (co < a.Cout) ? reinterpret_cast<const float4*>(a.mk_coef)[co] : make_float4(0.f, 0.f, 0.f, 0.f);
+      mk_sc = cf.x; mk_sh = cf.y; mk_mu = cf.z;
+    }
   };
   auto epilogue = [&](int n, int tile, int co0) {
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
@@ -300,7 +303,9 @@ __global__ __launch_bounds__(512, 4) void conv_subpix_kernel(const ConvArgs a, c
     if (co < a.Cout) {
       const int Wo = a.Wout;
       float* op = a.out + ((size_t)n * a.Cout + co) * a.Hout * Wo;
-      const float* rp = (a.epi_mode == 3) ? mk_ref + ((size_t)n * a.Cout + co) * a.Hout * Wo : nullptr;
+      // mask reference: the materialised activation (mk_ref), or - when the activation was never written (mk_ref == NULL: lrelu(bn(u)) without a
+      // residual add) - its pre-activation sc*u + sh recomputed from u
+      const float* rp = (a.epi_mode == 3 && mk_ref != nullptr) ? mk_ref + ((size_t)n * a.Cout + co) * a.Hout * Wo : nullptr;
       const float* up = (a.epi_mode == 3) ? a.mk_u + ((size_t)n * a.Cout + co) * a.Hout * Wo : nullptr;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -313,8 +318,13 @@ __global__ __launch_bounds__(512, 4) void conv_subpix_kernel(const ConvArgs a, c
           const f32x4 e = acc[i][py * 2], o = acc[i][py * 2 + 1];
           float4 v0 = make_float4(e[0], o[0], e[1], o[1]), v1 = make_float4(e[2], o[2], e[3], o[3]);
           if (a.epi_mode == 3) {
-            const float4 r0 = *reinterpret_cast<const float4*>(rp + off), r1 = *reinterpret_cast<const float4*>(rp + off + 4);
             const float4 u0 = *reinterpret_cast<const float4*>(up + off), u1 = *reinterpret_cast<const float4*>(up + off + 4);
+            float4 r0, r1;
+            if (rp != nullptr) { r0 = *reinterpret_cast<const float4*>(rp + off); r1 = *reinterpret_cast<const float4*>(rp + off + 4); }
+            else {
+              r0 = make_float4(mk_sc * u0.x + mk_sh, mk_sc * u0.y + mk_sh, mk_sc * u0.z + mk_sh, mk_sc * u0.w + mk_sh);
+              r1 = make_float4(mk_sc * u1.x + mk_sh, mk_sc * u1.y + mk_sh, mk_sc * u1.z + mk_sh, mk_sc * u1.w + mk_sh);
+            }
             v0.x *= (r0.x > 0.f) ? 1.f : a.mk_slope; v0.y *= (r0.y > 0.f) ? 1.f : a.mk_slope; v0.z *= (r0.z > 0.f) ? 1.f : a.mk_slope; v0.w *= (r0.w > 0.f) ? 1.f : a.mk_slope;
             v1.x *= (r1.x > 0.f) ? 1.f : a.mk_slope; v1.y *= (r1.y > 0.f) ? 1.f : a.mk_slope; v1.z *= (r1.z > 0.f) ? 1.f : a.mk_slope; v1.w *= (r1.w > 0.f) ? 1.f : a.mk_slope;
             s1 += ((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w));

@@ -12,8 +12,8 @@ extern "C" int ms_conv_subpix(const float* in, float* out, const float* w_packed
     set_error("ms_conv_subpix: invalid shape / mode (stored width must be a multiple of 4)"); return MS_ERR_INVALID;
   }
   if (!aligned16(in) || !aligned16(out) || !aligned16(w_packed)) { set_error("ms_conv_subpix: in, out and the packed weights must be 16-byte aligned"); return MS_ERR_ALIGN; }
-  const bool mask = (ref != nullptr);
-  if (mask && (u == nullptr || coef4 == nullptr || tab == nullptr || stats != nullptr || !aligned16(ref) || !aligned16(u) || !aligned16(coef4))) {
+  const bool mask = (ref != nullptr) || (u != nullptr);        // ref == NULL with u given: the mask is recomputed from sc*u + sh (activation never materialised)
+  if (mask && (u == nullptr || coef4 == nullptr || tab == nullptr || stats != nullptr || (ref != nullptr && !aligned16(ref)) || !aligned16(u) || !aligned16(coef4))) {
     set_error("ms_conv_subpix: the activation-backward epilogue needs ref, u, coef4 and tab (16-byte aligned) and no statistics"); return MS_ERR_INVALID;
   }
   if ((long long)Cin * Hs * Ws >= (1LL << 31) || (long long)Cout * 4 * Hs * Ws >= (1LL << 31)) { set_error("ms_conv_subpix: plane offsets exceed 31 bits"); return MS_ERR_INVALID; }

@@ -307,6 +307,9 @@ class InnerLoopEngine:
         # MS_SUBPIX=0 is the A/B switch (results agree to fp32 rounding: the up-sampling form pre-adds the taps that meet on one stored pixel)
         self.subpix = os.environ.get("MS_SUBPIX", "1") != "0"
         self.small_cout = os.environ.get("MS_SMALL_COUT", "1") != "0"      # vector-ALU kernel for the 16 -> 1 (64 -> 3) data-gradient to the image
+        # the activation after the encoder's first double conv (`inc`) is never written: BatchNorm + LeakyReLU become the prologue of down1's stride-2 conv
+        # and the backward mask is recomputed from the raw conv output (inner loop only: the training engine and the MixStyle baselines read that tensor)
+        self.lazy_inc = os.environ.get("MS_LAZY_INC", "1") != "0" and type(self) is InnerLoopEngine
         self._side_stream = None
         self._side_pending = False
         # MixStyle / DSU layers inside the encoder (generate_style_augmented_latent_code, advanced_triplet...py:632-670):
@@ -617,22 +620,23 @@ class InnerLoopEngine:
         C = cw.cin
         out = self.t(name, N, C, 2 * Hs, 2 * Ws)
         tab = self.t(bw_name + ".tab", lib.ms_conv_actbwd_tab_bytes(C) // 4)
-        check(lib.ms_conv_subpix(g.data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), 0, N, Cg, Hs, Ws, C, 1, 0, act_out.data_ptr(), u.data_ptr(), coef.data_ptr(),
-                                 slope, tab.data_ptr(), self._st()), "ms_conv_subpix(s2 dgrad + act bwd):" + name)
+        check(lib.ms_conv_subpix(g.data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), 0, N, Cg, Hs, Ws, C, 1, 0, 0 if act_out is None else act_out.data_ptr(), u.data_ptr(),
+                                 coef.data_ptr(), slope, tab.data_ptr(), self._st()), "ms_conv_subpix(s2 dgrad + act bwd):" + name)
         bc = self.t(bw_name + ".bcoef", C, 4)
         check(lib.ms_bn_bwd_coefs(tab.data_ptr(), 0, coef.data_ptr(), float(N * 4 * Hs * Ws), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + bw_name)
         return out, bc
 
     # ------------------------------------------------------------------ residual blocks
-    def res_fwd(self, pfx, net, key, x, kind):
-        """encoder_decoder.py:22-74 (kind 'down') / :289-357 (kind 'convT' = up_type Conv2, 'nn' = up_type NN)."""
+    def res_fwd(self, pfx, net, key, x, kind, x_act=None):
+        """encoder_decoder.py:22-74 (kind 'down') / :289-357 (kind 'convT' = up_type Conv2, 'nn' = up_type NN).
+        x_act = (coef4, slope): x is a RAW conv output whose BatchNorm + activation is applied as the prologue of the block's first conv (kind 'down')."""
         c0, c3, ci = net[key + ".c0"], net[key + ".c3"], net[key + ".ci"]
         fetch = ops.FETCH_NORMAL
         src = x
         if kind == "convT":
             src, _, _ = self.conv(pfx + ".xu", x, net[key + ".up"], cout=net[key + ".up"].cout, ks=1, epi=2)
         elif kind == "down":
-            src, _, _ = self.conv(pfx + ".xd", x, net[key + ".down"], stride=2)
+            src, _, _ = self.conv(pfx + ".xd", x, net[key + ".down"], stride=2, act=x_act)
         else:
             fetch = ops.FETCH_UPS2
         fused_tail = self.fuse_skip and not self.overlap
@@ -745,9 +749,15 @@ class InnerLoopEngine:
         cfa = self.bn_fin("e.inc.bn1", st, p, e["inc1"])
         ub, st, p = self.conv("e.inc.ub", ua, e["inc3"], act=(cfa, LEAKY), stats=True, fin=e["inc4"])
         cfb = self.bn_fin("e.inc.bn4", st, p, e["inc4"])
-        h = self._mix(1, self.bn_act("e.inc.out", ub, cfb, None, 0, LEAKY))
+        lazy = self.lazy_inc and self.enc_mix is None
+        self._inc_lazy = lazy
+        if lazy:
+            h, x_act = ub, (cfb, LEAKY)
+            self.buf.pop("e.inc.out", None)
+        else:
+            h, x_act = self._mix(1, self.bn_act("e.inc.out", ub, cfb, None, 0, LEAKY)), None
         for i in range(1, 5):
-            h = self._mix(i + 1, self.res_fwd(f"e.d{i}", e, f"d{i}", h, "down"))
+            h = self._mix(i + 1, self.res_fwd(f"e.d{i}", e, f"d{i}", h, "down", x_act=x_act if i == 1 else None))
         uf, st, p = self.conv("e.fc.u", h, e["fc0"], stats=True, fin=e["fc1"])
         cff = self.bn_fin("e.fc.bn", st, p, e["fc1"])
         z_i = self._mix(6, self.bn_act("e.z_i", uf, cff, None, 0, 0.0))
@@ -774,10 +784,10 @@ class InnerLoopEngine:
         for i in range(4, 0, -1):
             lo = f"e.d{i - 1}"
             nxt = (lo + ".bw2", b[lo + ".out"], b[lo + ".u2"], b[lo + ".bn4.coef"], LEAKY) if i > 1 else \
-                  ("e.inc.bw2", b["e.inc.out"], b["e.inc.ub"], b["e.inc.bn4.coef"], LEAKY)
+                  ("e.inc.bw2", b.get("e.inc.out"), b["e.inc.ub"], b["e.inc.bn4.coef"], LEAKY)      # None: the mask is recomputed from ub (lazy_inc)
             res = self.res_bwd(f"e.d{i}", e, f"d{i}", dh, "down", pre=pre, next_act=nxt)
             pre, dh = (res, None) if isinstance(res, tuple) else (None, res)
-        g, bc = pre if pre is not None else self.act_bwd("e.inc.bw2", dh, b["e.inc.out"], b["e.inc.ub"], b["e.inc.bn4.coef"], LEAKY)
+        g, bc = pre if pre is not None else self.act_bwd("e.inc.bw2", dh, b.get("e.inc.out"), b["e.inc.ub"], b["e.inc.bn4.coef"], LEAKY)
         g, bc = self.dgrad_act_bwd("e.inc.da", "e.inc.bw1", g, e["inc3"], (bc, b["e.inc.ub"]), b["e.inc.ua"], b["e.inc.bn1.coef"], LEAKY)
         c0 = e["inc0"]
         N, Cg, H, W = g.shape

@@ -396,6 +396,13 @@ def test_subpixel_stride2_data_gradient(dev, N, Cin, Cout, H, W):
     check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(N * H * W), bc_ref.data_ptr(), Cin, st), "bn_bwd_coefs")
     assert torch.equal(g2, masked)
     assert rel(bc, bc_ref) < 2e-5
+    # ref == NULL: the activation lrelu(sc*u + sh) was never materialised - the mask is recomputed from u (== ms_act_bwd_reduce with ref = NULL)
+    masked2 = torch.empty_like(out)
+    check(lib.ms_conv_subpix(gd.data_ptr(), masked2.data_ptr(), dwp.data_ptr(), 0, N, Cout, Ho, Wo, Cin, 1, 0, 0, u.data_ptr(), coef.data_ptr(), 0.2,
+                             tab.data_ptr(), st), "ms_conv_subpix(actbwd, mask from u)")
+    g3 = out.clone()
+    check(lib.ms_act_bwd_reduce(g3.data_ptr(), 0, u.data_ptr(), coef.data_ptr(), g3.data_ptr(), part.data_ptr(), N, Cin, H * W, 0.2, st), "act_bwd_reduce(mask from u)")
+    assert torch.equal(g3, masked2)
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W,pro", [(2, 16, 1, 32, 64, 2), (16, 16, 1, 256, 256, 2), (2, 64, 3, 40, 72, 2), (1, 7, 2, 19, 20, 0), (3, 16, 4, 16, 128, 0)])

@@ -58,7 +58,8 @@ def test_forward_taps_config1(golden_dir, dev):
         assert rel(eng.buf[f"d.u{k}.out"], taps[f"up{k}.out"]) < 2e-5, k
     assert rel(out, recon) < 1e-5
     eng.seg_loss(out, lab.to(dev), need_grad=False, need_logits=True)
-    assert rel(eng.buf["e.inc.out"], et["general_encoder.inc.out"]) < 2e-5
+    if "e.inc.out" in eng.buf:              # (lazy_inc: the activation after `inc` is folded into down1's prologue and never written)
+        assert rel(eng.buf["e.inc.out"], et["general_encoder.inc.out"]) < 2e-5
     for k in range(1, 5):
         assert rel(eng.buf[f"e.d{k}.out"], et[f"general_encoder.down{k}.out"]) < 3e-5, k
     assert rel(eng.buf["e.z_i"], zi) < 3e-5 and rel(eng.buf["e.z_s"], zs) < 5e-5
