@@ -164,6 +164,7 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   }
   a.ncb = cdiv(gemm_cols, 16 * nt);
   { static const int dbg = getenv("MS_CONV_DBG") ? atoi(getenv("MS_CONV_DBG")) : 0; a.dbg = dbg; }
+  { static const int pf = getenv("MS_CONV_PF") ? atoi(getenv("MS_CONV_PF")) : 0; a.pf = tune && getenv("MS_CONV_PF") ? atoi(getenv("MS_CONV_PF")) : pf; }
   { static const int stag = getenv("MS_CONV_STAGGER") ? atoi(getenv("MS_CONV_STAGGER")) : 0; a.stagger = tune && getenv("MS_CONV_STAGGER") ? atoi(getenv("MS_CONV_STAGGER")) : stag; }
   { static const char* tr = getenv("MS_CONV_TRACE"); a.trace = tr ? (long long*)strtoull(tr, nullptr, 0) : nullptr; }
   hipStream_t st = (hipStream_t)stream;

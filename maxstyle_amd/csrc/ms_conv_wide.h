@@ -520,10 +520,48 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #else
   constexpr bool tr = false;
 #endif
+  // EXPERIMENT, off by default (MS_CONV_PF=1): L2 prefetch by the MFMA waves.  The second tensor of the BatchNorm-backward prologue (the raw conv output of
+  // the FORWARD pass) and the mask tensor are cold by the time the backward reads them - in the step this kernel takes 82-87 us against 62 us replayed
+  // back to back with its inputs still in the Infinity Cache.  Hypothesis: the staging waves hold ONE chunk in registers, so their loads are issued only one
+  // barrier interval ahead - too late for an HBM miss.  Test: every MFMA lane touches one 128-byte line of the chunk TWO intervals ahead.  Measured:
+  // SLOWER (328.5 vs 334.5 steps/s, the launches 75-94 us): the gap is bandwidth on cold data (268 MB in 85 us = 3.2 TB/s from HBM), not exposed latency,
+  // and the touches only add requests.
+  unsigned pf_sink = 0;
+  float pf_v = 0.f, pf_m = 0.f;
+  auto l2_prefetch = [&](int p) {
+    if (!(PRO == 2 || a.epi_mode == 3) || !a.pf) return;
+    pf_sink |= __float_as_uint(pf_v) | __float_as_uint(pf_m);      // the values requested one iteration ago (long since arrived)
+    int pit = item, pch = chunk + 2;
+    while (pch >= nchunks) { pch -= nchunks; pit += (int)gridDim.x; }
+    if (pit >= nitems) return;
+    int pn, ptile, pcb;
+    decode(pit, pn, ptile, pcb);
+    const int ptx = ptile % a.tiles_x, pty = ptile / a.tiles_x;
+    const int l = threadIdx.x;                          // 0..255
+    if constexpr (PRO == 2) {
+      constexpr int NL = CK * IH * 2;                    // two lines per staged row (the halo columns share lines with the neighbours)
+      static_assert(NL <= 256, "one line per MFMA lane");
+      if (l < NL) {
+        const int c = l / (2 * IH), r = (l >> 1) % IH, hh = l & 1;
+        const int Y = min(max(pty * TH - 1 + r, 0), a.Hin - 1), X = min(ptx * TW + 32 * hh, a.Win - 4), ci = min(pch * CK + c, a.Cin - 1);
+        pf_v = a.in2[(((size_t)pn * a.Cin + ci) * a.Hs + Y) * a.Ws + X];
+      }
+    }
+    if (a.epi_mode == 3 && pch == 0) {
+      // first chunk of an item two intervals ahead: its mask tensor (16 x NT channels x TH rows x 64 columns)
+      constexpr int NM = 16 * NT * TH * 2;
+      if (NM <= 256 && l < NM) {
+        const int c = l / (2 * TH), r = (l >> 1) % TH, hh = l & 1;
+        const int Y = min(pty * TH + r, a.Hout - 1), X = min(ptx * TW + 32 * hh, a.Wout - 4), co = min(pcb * COUT_TILE + c, a.Cout - 1);
+        pf_m = a.mk_u[(((size_t)pn * a.Cout + co) * a.Hout + Y) * a.Wout + X];
+      }
+    }
+  };
   for (int p = 0; p < T; ++p) {
     const int c0 = chunk * CK;
     const int ncg = min(CK / 4, (a.cin_pad - c0) / 4);
     if (tr && p < 16) a.trace[p * 4 + 0] = clock64();
+    l2_prefetch(p);
     if (UPRE && a.epi_mode == 3 && chunk + 1 == nchunks) prefetch_u(n, tile, cb * COUT_TILE);
     if (!(a.dbg & 1)) {
       if (ncg == CK / 4) compute(smem + (p & 1) * BUF, std::true_type{}, ncg);
@@ -544,6 +582,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #ifdef MS_CONV_TRACE_BUILD
   if (tr) { a.trace[502] = clock64(); a.trace[503] = (long long)__builtin_amdgcn_s_memrealtime(); }
 #endif
+  if (pf_sink == 0x7FC12345u && a.trace != nullptr) a.trace[511] = 1;          // keeps the prefetch loads alive (never true: a NaN payload no input carries)
   if (a.stats != nullptr) conv_table_tail<NT, true>(a, smem, vb, ncb, st_n, st_mean, st_m2);
   else if (a.epi_mode == 3) conv_table_tail<NT, false>(a, smem, vb, ncb, 0.f, st_mean, st_m2);
 }
