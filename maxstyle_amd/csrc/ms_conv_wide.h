@@ -603,12 +603,11 @@ int launch_conv_wide_r(ConvArgs a, hipStream_t st) {
   return check_launch("conv_wide");
 }
 
-// tile height: 8 rows when that still leaves every resident workgroup >= 2 work items (the 256^2 / 320^2 levels), else 4 rows.
-// MS_CONV_WIDE_ROWS=4|8 forces one (A/B timing; the results are bit-identical).
+// tile height: 4 rows.  The 8-row variant (R = 2: two output rows per MFMA wave, bit-identical results) is kept behind MS_CONV_WIDE_ROWS=8: in isolation it is
+// 2-3 % faster on the activation-backward data-gradient at 16->16 @16x256x256 (72.8 vs 74.7 us), in the step it is slower (333.5 vs 336.3 steps/s, twice each).
 inline int conv_wide_rows(const ConvArgs& a, int nt) {
   static const int force = getenv("MS_CONV_WIDE_ROWS") ? atoi(getenv("MS_CONV_WIDE_ROWS")) : 0;
-  if (force == 4 || force == 8) return force;
-  if (nt != 1) return 4;                 // (two channel blocks per lane x two rows per wave need 188 registers: one workgroup per CU - not built for it yet)
+  if (force != 8 || nt != 1) return 4;     // (two channel blocks per lane x two rows per wave need 188 registers: one workgroup per CU - not built for it)
   const long items8 = (long)a.N * cdiv(a.Wout, 64) * cdiv(a.Hout, 8) * cdiv(a.Cout, 16 * nt);
   return (items8 >= 4L * num_cus()) ? 8 : 4;
 }
