@@ -428,3 +428,15 @@ def test_small_cout_conv(dev, N, Cin, Cout, H, W, pro):
     kw = dict(pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=ud) if pro == 2 else {}
     old = ops.conv2d(xd, wp, None, Cout, 3, 1, **kw)
     assert rel(out, old) < 3e-6
+
+
+def test_wide_kernel_8_row_tiles_in_a_subprocess():
+    """The 8-row-tile variant of the wide kernel (two output rows per MFMA wave) is selected by MS_CONV_WIDE_ROWS=8, which the library reads once per
+    process: run the wide-kernel and activation-backward cases in a child process with the switch set."""
+    import os, subprocess, sys
+    env = dict(os.environ, MS_CONV_WIDE_ROWS="8")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_conv_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "wide_kernel_all_modes or conv_actbwd_epilogue or batch_stats_and_prologue or bn_backward_chain"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
