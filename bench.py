@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--config", default="c2", choices=["c2", "c4"], help="c2: FCN_16 1x256x256 (the quoted metric); c4: FCN_64 3x320x320 (Prostate-shaped)")
     ap.add_argument("--steady-seconds", type=float, default=2.0, help="length of the extra steady-state leg (graph replays, rank-local); 0 disables")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only: gloo on the CPU, stand-in step (CPU tests)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend of the real run (nccl = RCCL; gloo: validation of the N>1 path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than GPUs (rank r uses GPU r %% device_count): functional validation only, not a measurement")
     return ap.parse_args()
 
 
@@ -490,7 +492,7 @@ def launch_children(args):
     This process has made no GPU call (torch.cuda.device_count() does not initialise HIP on this image) and never exec's."""
     import subprocess
     n = args.gpus
-    if not args.dry_run:
+    if not args.dry_run and not args.oversubscribe:
         have = torch.cuda.device_count()
         if have < n:
             print(f"[bench] --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
@@ -569,11 +571,16 @@ def main():
         return dry_run(args, rank, world)
     dist_on = world > 1
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if args.oversubscribe:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)     # RCCL on ROCm: barriers, max-over-ranks, the outer-gradient all-reduce
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)     # RCCL on ROCm: barriers, max-over-ranks, the outer-gradient all-reduce
+        else:
+            dist.init_process_group("gloo")
     net = (4, 1, 4)
     if args.config == "c4":
         net = (1, 3, 2)
@@ -599,7 +606,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"C2: FCN_16 dual-branch, per-GPU batch {args.batch}x1x{args.size}x{args.size}, MaxStyle layers [3,4,5], Adam lr 0.1" if args.config == "c2"
                                     else f"C4: FCN_64 dual-branch, per-GPU batch {args.batch}x3x{args.size}x{args.size}, MaxStyle layers [3,4,5], Adam lr 0.1"),
-                       "global_batch": args.batch * n_gpus, "parallelism": f"dp{n_gpus}", "hip_graph": graphed, "world_seen": world},
+                       "global_batch": args.batch * n_gpus, "parallelism": f"dp{n_gpus}", "hip_graph": graphed, "world_seen": world,
+                       **({"oversubscribed": True, "backend": args.backend} if (args.oversubscribe or args.backend != "nccl") else {})},
             "per_gpu_steps_s": value / n_gpus,
             "steady_state": steady,
             "conv_flops": ({"gflop_per_step_uncached": FLOP_PER_STEP_C2 / 1e9, "gflop_per_step_executed": FLOP_EXECUTED_C2 / 1e9,

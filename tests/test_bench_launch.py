@@ -34,3 +34,18 @@ def test_under_a_launcher_nothing_is_spawned():
     # torchrun-style environment for a 1-rank world: the process is a rank, not a parent, whatever --gpus says
     r = _run(["--gpus", "4", "--dry-run", "--steps", "2", "--warmup", "0"], {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
     assert r["n_gpus"] == 1
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_real_two_rank_run_on_one_gpu():
+    """The N > 1 path of bench.py on real kernels: two ranks share the one GPU of the test box (gloo moves the CUDA tensors; on a node the same code
+    runs one rank per GPU over RCCL).  Timed loop per rank, max over ranks, and the outer-iteration leg with the flat all-reduce on every rank."""
+    r = _run(["--gpus", "2", "--backend", "gloo", "--oversubscribe", "--steps", "3", "--warmup", "1", "--steady-seconds", "0", "--batch", "4", "--size", "64"])
+    assert r["n_gpus"] == 2 and r["config"]["parallelism"] == "dp2" and r["config"]["world_seen"] == 2 and r["config"]["global_batch"] == 8
+    assert r["value"] > 0 and abs(r["per_gpu_steps_s"] * 2 - r["value"]) < 1e-6 * r["value"]
+    oi = r["outer_iteration"]
+    assert oi["world_seen"] == 2 and oi["weights_max_abs_diff_across_ranks"] == 0.0 and oi["allreduce_bytes"] >= 1536325 * 4
+    assert oi["loss_last"] < oi["loss_first"]
