@@ -9,7 +9,7 @@ bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool v
   // (the two-tensor BatchNorm-backward prologue runs with 8-channel chunks: twice the staging registers per channel; 70.4 vs 74.2 us on the
   //  first-generation kernel at 16->16 @16x256x256)
   if (a.Wout < 64 || a.Wout % 4 != 0) return false;
-  if ((long long)a.Cin * a.Hs * a.Ws >= (1LL << 31)) return false;
+  if ((long long)a.Cin * a.Hs * a.Ws + a.Ws + 4 >= (1LL << 29)) return false;      // byte offsets inside one image fit 31 bits (buffer addressing of the staging)
   if (!aligned16(a.out)) return false;
   return true;
 }

@@ -62,6 +62,19 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   auto decode = [&](int it, int& n, int& tile, int& cb) { cb = it % ncb; const int t2 = it / ncb; tile = t2 % ntiles; n = t2 / ntiles; };
 
+  // per-channel prologue coefficients are constant for the whole launch: ONE float4 {a, b, c, 0} per input channel in LDS behind the stage buffers, zero
+  // beyond Cin.  The staging waves fetch them with one ds_read_b128 per item and chunk (was: three dependent global loads behind ~7 VALU instructions of
+  // index arithmetic each - on a SIMD whose matrix pipe is saturated every VALU instruction of a staging wave waits behind an MFMA).
+  float* cf_lds = smem + 2 * BUF;
+  if constexpr (PRO != 0) {
+    for (int c = threadIdx.x; c < nchunks * CK; c += 512) {
+      float4 cf = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < a.Cin) { cf.x = a.pro_a[c * a.pro_cstride]; cf.y = a.pro_b[c * a.pro_cstride]; if constexpr (PRO == 2) cf.z = a.pro_c[c * a.pro_cstride]; }
+      reinterpret_cast<float4*>(cf_lds)[c] = cf;
+    }
+    __syncthreads();
+  }
+
   if (a.stagger > 0) {
     // Two workgroups share a CU and run the same program: left alone they stay in lockstep - both in their MFMA phase (matrix pipe contended),
     // then both in their epilogue (matrix pipe idle).  The workgroup that arrives second on its CU starts late by a fraction of an item so that one's
@@ -83,34 +96,41 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     const int tid = threadIdx.x - 256;
     const int plane = a.Hs * a.Ws;                 // host checks Cin*plane < 2^31
     typedef unsigned mask_t;
-    int q_lds[NQI], q_rc[NQI], q_off[NQI];         // LDS offset (or -1), (row << 16) | (col_rel + 16), c*plane + (r-1)*W + col_rel  (relative to the tile origin)
-    int h_lds[NHI], h_rc[NHI], h_off[NHI];
+    // every global address of the staging is (wave-uniform base of the chunk, biased back by one row + 4 so that no offset is negative) + a 32-bit BYTE offset
+    // hoisted here: the loads take the scalar-base form (global_load ... v_off, s[base:base+1]) and cost no address arithmetic per chunk
+    const int bias = a.Ws + 4;                     // elements; a multiple of 4: the 16-byte alignment of the quad loads is kept
+    int q_lds[NQI], q_rc[NQI];                     // LDS offset (or -1), (row << 16) | (col_rel + 16)
+    int h_lds[NHI], h_rc[NHI];
+    unsigned q_off[NQI], h_off[NHI];               // byte offset of c*plane + (r-1)*W + col_rel + bias  (relative to the tile origin of channel c0)
+    int q_cf[NQI], h_cf[NHI];                      // float4 index of the item's channel-in-chunk in the coefficient table
     static_assert(NQI <= 32 && NHI <= 32, "item masks are 32 bits");
     mask_t q_all = 0, h_all = 0;
 #pragma unroll
     for (int j = 0; j < NQI; ++j) {
       const int it = tid + j * 256;
-      q_lds[j] = -1; q_rc[j] = 0; q_off[j] = 0;
+      q_lds[j] = -1; q_rc[j] = 0; q_off[j] = 4u * (unsigned)bias; q_cf[j] = 0;
       if (it < G::Q_ITEMS) {
         const int f = it % (TW / 4), row = it / (TW / 4);
         const int r = row % IH, c = row / IH;
         q_lds[j] = (c << 20) | (c * PS + r * RS + 4 * f + 1);
         q_rc[j] = (r << 16) | (4 * f + 16);
-        q_off[j] = c * plane + (r - 1) * a.Ws + 4 * f;
+        q_off[j] = 4u * (unsigned)(c * plane + (r - 1) * a.Ws + 4 * f + bias);
+        q_cf[j] = c;
         q_all |= 1u << j;
       }
     }
 #pragma unroll
     for (int j = 0; j < NHI; ++j) {
       const int it = tid + j * 256;
-      h_lds[j] = -1; h_rc[j] = 0; h_off[j] = 0;
+      h_lds[j] = -1; h_rc[j] = 0; h_off[j] = 4u * (unsigned)bias; h_cf[j] = 0;
       if (it < G::H_ITEMS) {
         const int h = it & 1, row = it >> 1;
         const int r = row % IH, c = row / IH;
         const int col_rel = h ? TW : -1;
         h_lds[j] = (c << 20) | (c * PS + r * RS + col_rel + 1);
         h_rc[j] = (r << 16) | (col_rel + 16);
-        h_off[j] = c * plane + (r - 1) * a.Ws + col_rel;
+        h_off[j] = 4u * (unsigned)(c * plane + (r - 1) * a.Ws + col_rel + bias);
+        h_cf[j] = c;
         h_all |= 1u << j;
       }
     }
@@ -144,11 +164,38 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     bool l_edge = false, have_w = false;
     float ca[NQI], cb_[NQI], cc[PRO == 2 ? NQI : 1], hca[NHI], hcb[NHI], hcc[PRO == 2 ? NHI : 1];   // prologue coefficients of the chunk in registers
 
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    auto load_data = [&](__amdgpu_buffer_rsrc_t r1, __amdgpu_buffer_rsrc_t r2, int soff, mask_t qm, mask_t hm, auto edge_tag) {
+      constexpr bool EDGE = decltype(edge_tag)::value;
+      const int origin = 4 * bias;                      // masked items read the (valid) tile origin and are zeroed at the LDS store
+#pragma unroll
+      for (int j = 0; j < NQI; ++j) {
+        int off = (int)q_off[j];
+        if constexpr (EDGE) off = ((qm >> j) & 1u) ? off : origin;
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r1, off, soff, 0);
+        rq[j][0] = __uint_as_float(v.x); rq[j][1] = __uint_as_float(v.y); rq[j][2] = __uint_as_float(v.z); rq[j][3] = __uint_as_float(v.w);
+        if constexpr (PRO == 2) {
+          const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r2, off, soff, 0);
+          rq2[j][0] = __uint_as_float(u.x); rq2[j][1] = __uint_as_float(u.y); rq2[j][2] = __uint_as_float(u.z); rq2[j][3] = __uint_as_float(u.w);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NHI; ++j) {
+        const int off = ((hm >> j) & 1u) ? (int)h_off[j] : origin;       // the halo columns of the first / last tile of a row are outside the image
+        rh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, off, soff, 0));
+        if constexpr (PRO == 2) rh2[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r2, off, soff, 0));
+      }
+    };
     auto load_chunk = [&](int n, int co0, int c0, bool load_w) {
-      const float* in_n = a.in + (size_t)n * a.Cin * plane + (size_t)c0 * plane + t_base;
-      const float* in2_n = (PRO == 2) ? a.in2 + (size_t)n * a.Cin * plane + (size_t)c0 * plane + t_base : nullptr;
+      // buffer addressing: resource base = image n, biased back (scalar arithmetic); soffset = chunk + tile origin (scalar); voffset = the hoisted item offset:
+      // `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen` - no vector address arithmetic per chunk (the host checks Cin*plane*4 < 2^31)
+      const float* img = a.in + (ptrdiff_t)n * a.Cin * plane - bias;
+      const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, 0x7FFFFFFF, 0x00020000);
+      const float* img2 = (PRO == 2) ? a.in2 + (ptrdiff_t)n * a.Cin * plane - bias : img;
+      const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img2), 0, 0x7FFFFFFF, 0x00020000);
+      const int soff = 4 * (c0 * plane + t_base);
       const bool ragged = (c0 + CK > a.Cin);          // last chunk of a layer whose channel count is not a multiple of CK
-      l_q_ok = q_ok; l_h_ok = h_ok; l_edge = edge || ragged;
+      l_q_ok = q_ok; l_h_ok = h_ok; l_edge = edge || ragged || (a.dbg & 2);
       mask_t qm = q_ok, hm = h_ok;
       if (ragged) {
 #pragma unroll
@@ -157,37 +204,22 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         for (int j = 0; j < NHI; ++j) if (c0 + (h_lds[j] >> 20) >= a.Cin) hm &= ~(1u << j);
         l_q_ok = qm; l_h_ok = hm;
       }
-      const bool live = !(a.dbg & 2);
-#pragma unroll
-      for (int j = 0; j < NQI; ++j) {
-        int off = q_off[j];
-        if (l_edge) off = (((qm >> j) & 1u) && live) ? off : 0;        // masked items read the (valid) tile origin and are zeroed at the LDS store
-        const float4 v = *reinterpret_cast<const float4*>(in_n + off);
-        rq[j][0] = v.x; rq[j][1] = v.y; rq[j][2] = v.z; rq[j][3] = v.w;
-        if constexpr (PRO == 2) {
-          const float4 u = *reinterpret_cast<const float4*>(in2_n + off);
-          rq2[j][0] = u.x; rq2[j][1] = u.y; rq2[j][2] = u.z; rq2[j][3] = u.w;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < NHI; ++j) {
-        const int off = (((hm >> j) & 1u) && live) ? h_off[j] : 0;
-        rh[j] = in_n[off];
-        if constexpr (PRO == 2) rh2[j] = in2_n[off];
-      }
+      if (a.dbg & 2) { qm = 0; hm = 0; }                // timing-only: every lane reads the tile origin
+      if (l_edge) load_data(r1, r2, soff, qm, hm, std::true_type{}); else load_data(r1, r2, soff, qm, hm, std::false_type{});
       if constexpr (PRO != 0) {
-        // the chunk's per-channel coefficients (L1/L2-resident table; a.pro_nstride == 0 on this path)
+        // the chunk's per-channel coefficients: one ds_read_b128 per item (zero beyond Cin)
+        const float4* cf_c0 = reinterpret_cast<const float4*>(cf_lds) + c0;
 #pragma unroll
         for (int j = 0; j < NQI; ++j) {
-          const int ci = min(c0 + max(q_lds[j] >> 20, 0), a.Cin - 1) * a.pro_cstride;        // lanes without an item carry -1
-          ca[j] = a.pro_a[ci]; cb_[j] = a.pro_b[ci];
-          if constexpr (PRO == 2) cc[j] = a.pro_c[ci];
+          const float4 cf = cf_c0[q_cf[j]];
+          ca[j] = cf.x; cb_[j] = cf.y;
+          if constexpr (PRO == 2) cc[j] = cf.z;
         }
 #pragma unroll
         for (int j = 0; j < NHI; ++j) {
-          const int ci = min(c0 + max(h_lds[j] >> 20, 0), a.Cin - 1) * a.pro_cstride;
-          hca[j] = a.pro_a[ci]; hcb[j] = a.pro_b[ci];
-          if constexpr (PRO == 2) hcc[j] = a.pro_c[ci];
+          const float4 cf = cf_c0[h_cf[j]];
+          hca[j] = cf.x; hcb[j] = cf.y;
+          if constexpr (PRO == 2) hcc[j] = cf.z;
         }
       }
       have_w = load_w;
@@ -590,7 +622,9 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 template <int NT, int PRO, int R>
 int launch_conv_wide_r(ConvArgs a, hipStream_t st) {
   using G = WideGeo<NT, PRO, R>;
-  const size_t lds_bytes = sizeof(float) * 2 * (size_t)G::BUF;
+  const size_t cin_tab = (PRO != 0) ? (size_t)cdiv(a.cin_pad, G::CK) * G::CK : 0;              // coefficient table: one float4 per input channel of the padded chunks
+  const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab);
+  if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
   static std::once_flag attr_once;                     // one flag per instantiation; the attribute itself is immutable afterwards
   std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
   a.tiles_x = cdiv(a.Wout, G::TW); a.tiles_y = cdiv(a.Hout, G::TH);
