@@ -45,13 +45,14 @@ struct WideGeo {
 static __device__ int g_cu_census[1024];
 
 // PRO: 0 none, 1 BatchNorm apply + LeakyReLU, 2 BatchNorm backward (two tensors)
-template <int NT, int PRO, int R>
+// AF ("all full"): cin_pad is a multiple of the K-chunk - no ragged channel group anywhere in the layer, the guarded MFMA loop is not instantiated
+template <int NT, int PRO, int R, bool AF>
 __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const ConvArgs a) {
   using G = WideGeo<NT, PRO, R>;
   constexpr int TH = G::TH, TW = G::TW, CK = G::CK, IH = G::IH, RS = G::RS, PS = G::PS, WS = G::WS, BUF = G::BUF;
   constexpr int NQI = G::NQI, NHI = G::NHI, NWI = G::NWI, COUT_TILE = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // wave-uniform by construction: keep it in a scalar register
   const bool producer = wave >= 4;
   const int ntiles = a.tiles_x * a.tiles_y, ncb = a.ncb;
   const int nitems = a.N * ntiles * ncb;
@@ -339,8 +340,11 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       for (int j = 0; j < NT; ++j) bf[kx][j] = buf[b_lane + ((ky * 3 + kx) * CK + cg * 4) * WS + j * 16];
   };
   // FULL = every channel group of the chunk is live: straight-line code; the guarded form only runs for a layer's ragged last chunk
-  auto compute = [&](const float* buf, auto full_tag, int ncg) {
+  // FIRST = first K-chunk of an item: the first MFMA of every accumulator takes a zero C operand (no clearing pass after the epilogue)
+  auto compute = [&](const float* buf, auto full_tag, int ncg, auto first_tag) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     float win[2][6], bfr[3][3][NT];
     load_win(buf, 0, 0, win[0]);
     load_b(buf, 0, 0, bfr[0]);
@@ -368,7 +372,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                   for (int j = 0; j < NT; ++j)
-                    acc[r][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(win[t & 1][i + kx], bfr[ky][kx][j], acc[r][i][j], 0, 0, 0);
+                    acc[r][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(win[t & 1][i + kx], bfr[ky][kx][j],
+                                                                        (FIRST && cg == 0 && ky == 0 && kx == 0) ? zero4 : acc[r][i][j], 0, 0, 0);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   // item's last K-chunk, so the epilogue does not wait for them (loading them inside the epilogue cost ~10 us per launch at 16->16 @16x256x256)
   constexpr bool UPRE = (NT == 1 && R == 1);
   float4 upre[UPRE ? R : 1][4];
-  auto prefetch_u = [&](int n, int tile, int co0) {
+  auto prefetch_u = [&](int n, int tile, int co0) __attribute__((always_inline)) {
     if constexpr (!UPRE) return;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const int xb = tx * TW + 16 * k;
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         upre[UPRE ? rr : 0][r] = (4 * r < nvalid) ? *reinterpret_cast<const float4*>(a.mk_u + off + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto epilogue = [&](int n, int tile, int co0) {
+  auto epilogue = [&](int n, int tile, int co0) __attribute__((always_inline)) {
     if (a.dbg & 16) {                                    // timing-only: no epilogue at all (upper bound of what hiding it can gain)
 #pragma unroll
       for (int rr = 0; rr < R; ++rr)
@@ -534,14 +539,125 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           }
         }
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[rr][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
 
-  int item = vb, chunk = 0, n, tile, cb;
+  // ---- interior items (every pixel, row and channel of the tile exists; 4-row tiles): no masks, and buffer addressing - resource base = image n,
+  // scalar offset = (channel block, row, tile column), vector offset = the lane's hoisted (channel m, pixel group k) offset: the 64-bit address arithmetic
+  // of the generic epilogue (~15 vector instructions per row) and its per-quad selects are gone.  Same arithmetic, same order: bit-identical results.
+  const int out_plane = a.Hout * a.Wout;
+  const int ep_voff = 4 * (m * out_plane + 16 * k);
+  typedef unsigned eu32x4_t __attribute__((ext_vector_type(4)));
+  auto img_rsrc = [&](const float* base, int n) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + (ptrdiff_t)n * a.Cout * out_plane, 0, 0x7FFFFFFF, 0x00020000);
+  };
+  auto bload4 = [&](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const eu32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+  };
+  // STORES take the row offset in the VECTOR offset (one v_add per row), never in the scalar-offset field.  Measured on MI355X: a 16-byte buffer store with a
+  // register soffset whose data registers are overwritten by the next vector instruction stores the NEW value in lanes 12-15 of every 16-lane row of the
+  // second data dword (16 -> 16 @2x64x64: channels 12-15, pixel 13 of every 16 wrong).  LLVM's hazard recogniser only pads ">64-bit store data overwritten by
+  // a VALU write" when soffset is NOT a register (GCNHazardRecognizer::createsVALUHazard), so with a constant soffset the compiler inserts the wait state itself.
+  auto bstore4 = [&](__amdgpu_buffer_rsrc_t r, int voff, float4 v) {
+    const eu32x4_t w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, 0, 0);
+  };
+  auto tile_interior = [&](int tile, int co0) {
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    return (R == 1) && (tx * TW + TW <= a.Wout) && (ty * TH + TH <= a.Hout) && (co0 + COUT_TILE <= a.Cout);
+  };
+  auto row_soff = [&](int tile, int co) {               // byte offset of (channel co, this wave's row, first column of the tile) inside one image
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    return 4 * ((co * a.Hout + ty * TH + wave) * a.Wout + tx * TW);
+  };
+  auto prefetch_u_fast = [&](int n, int tile, int co0) __attribute__((always_inline)) {
+    if constexpr (!UPRE) return;
+    const __amdgpu_buffer_rsrc_t ru = img_rsrc(a.mk_u, n);
+    const int so = row_soff(tile, co0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) upre[0][r] = bload4(ru, ep_voff + 16 * r, so);
+  };
+  auto epilogue_fast = [&](int n, int tile, int co0) __attribute__((always_inline)) {
+    if (a.dbg & 16) return;                              // timing-only: no epilogue at all
+    const __amdgpu_buffer_rsrc_t ro = img_rsrc(a.out, n);
+    if (a.bias != nullptr) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[0][i][j][r] += bias_v[j];
+    }
+    if (a.stats != nullptr) {
+      const float nt_ = st_n + 16.f;
+      const float wgt = 16.f * __builtin_amdgcn_rcpf(nt_);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0 += acc[0][0][j][r] + acc[0][1][j][r]; s1 += acc[0][2][j][r] + acc[0][3][j][r]; }
+        const float mean = (s0 + s1) * 0.0625f;
+        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d0 = acc[0][0][j][r] - mean, d1 = acc[0][1][j][r] - mean, d2 = acc[0][2][j][r] - mean, d3 = acc[0][3][j][r] - mean;
+          q0 += d0 * d0 + d1 * d1; q1 += d2 * d2 + d3 * d3;
+        }
+        const float d = mean - st_mean[j];
+        st_mean[j] += d * wgt;
+        st_m2[j] += (q0 + q1) + d * d * st_n * wgt;
+      }
+      st_n = nt_;
+    }
+    if (a.epi_mode == 3) {
+      const __amdgpu_buffer_rsrc_t ru = img_rsrc(a.mk_u, n);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int so = row_soff(tile, co0 + 16 * j);
+        const int st_voff = ep_voff + so;
+        float4 uu[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) uu[r] = UPRE ? upre[0][r] : bload4(ru, ep_voff + 16 * r, so);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float4 v;
+          v.x = acc[0][0][j][r] * ((mk_sc[j] * uu[r].x + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+          v.y = acc[0][1][j][r] * ((mk_sc[j] * uu[r].y + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+          v.z = acc[0][2][j][r] * ((mk_sc[j] * uu[r].z + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+          v.w = acc[0][3][j][r] * ((mk_sc[j] * uu[r].w + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+          bstore4(ro, st_voff + 16 * r, v);
+          s1 += (v.x + v.y) + (v.z + v.w);
+          s2 += (v.x * (uu[r].x - mk_mu[j]) + v.y * (uu[r].y - mk_mu[j])) + (v.z * (uu[r].z - mk_mu[j]) + v.w * (uu[r].w - mk_mu[j]));
+        }
+        st_mean[j] += s1; st_m2[j] += s2;
+      }
+    } else if (a.epi_mode == 1) {
+      // accumulate into the tensor: its own block - merged with the plain store the compiler guards the adds with selects and a vmcnt wait that, on
+      // gfx9, also waits for the STORES of the previous item (measured: +3 us per launch on the plain epilogue)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int so = row_soff(tile, co0 + 16 * j);
+        const int st_voff = ep_voff + so;
+        float4 prev[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) prev[r] = bload4(ro, ep_voff + 16 * r, so);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          bstore4(ro, st_voff + 16 * r, make_float4(acc[0][0][j][r] + prev[r].x, acc[0][1][j][r] + prev[r].y, acc[0][2][j][r] + prev[r].z, acc[0][3][j][r] + prev[r].w));
+      }
+    } else if (!(a.dbg & 4)) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int st_voff = ep_voff + row_soff(tile, co0 + 16 * j);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bstore4(ro, st_voff + 16 * r, make_float4(acc[0][0][j][r], acc[0][1][j][r], acc[0][2][j][r], acc[0][3][j][r]));
+      }
+    }
+  };
+
+  int item = vb, n, tile, cb;
   decode(item, n, tile, cb);
   load_bias(cb * COUT_TILE);
   lds_barrier();                                      // barrier #0
@@ -552,89 +668,88 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #else
   constexpr bool tr = false;
 #endif
-  // EXPERIMENT, off by default (MS_CONV_PF=1): L2 prefetch by the MFMA waves.  The second tensor of the BatchNorm-backward prologue (the raw conv output of
-  // the FORWARD pass) and the mask tensor are cold by the time the backward reads them - in the step this kernel takes 82-87 us against 62 us replayed
-  // back to back with its inputs still in the Infinity Cache.  Hypothesis: the staging waves hold ONE chunk in registers, so their loads are issued only one
-  // barrier interval ahead - too late for an HBM miss.  Test: every MFMA lane touches one 128-byte line of the chunk TWO intervals ahead.  Measured:
-  // SLOWER (328.5 vs 334.5 steps/s, the launches 75-94 us): the gap is bandwidth on cold data (268 MB in 85 us = 3.2 TB/s from HBM), not exposed latency,
-  // and the touches only add requests.
-  unsigned pf_sink = 0;
-  float pf_v = 0.f, pf_m = 0.f;
-  auto l2_prefetch = [&](int p) {
-    if (!(PRO == 2 || a.epi_mode == 3) || !a.pf) return;
-    pf_sink |= __float_as_uint(pf_v) | __float_as_uint(pf_m);      // the values requested one iteration ago (long since arrived)
-    int pit = item, pch = chunk + 2;
-    while (pch >= nchunks) { pch -= nchunks; pit += (int)gridDim.x; }
-    if (pit >= nitems) return;
-    int pn, ptile, pcb;
-    decode(pit, pn, ptile, pcb);
-    const int ptx = ptile % a.tiles_x, pty = ptile / a.tiles_x;
-    const int l = threadIdx.x;                          // 0..255
-    if constexpr (PRO == 2) {
-      constexpr int NL = CK * IH * 2;                    // two lines per staged row (the halo columns share lines with the neighbours)
-      static_assert(NL <= 256, "one line per MFMA lane");
-      if (l < NL) {
-        const int c = l / (2 * IH), r = (l >> 1) % IH, hh = l & 1;
-        const int Y = min(max(pty * TH - 1 + r, 0), a.Hin - 1), X = min(ptx * TW + 32 * hh, a.Win - 4), ci = min(pch * CK + c, a.Cin - 1);
-        pf_v = a.in2[(((size_t)pn * a.Cin + ci) * a.Hs + Y) * a.Ws + X];
+  // (the L2-prefetch experiment of round 2 - MFMA lanes touching the cold second tensor two chunks ahead, MS_CONV_PF - measured slower and was removed:
+  //  profiles/r02_experiments.txt section 6)
+  // Item loop with the first K-chunk peeled (its MFMAs start from a zero C operand).  With AF the guarded MFMA loop is not instantiated, so the
+  // accumulators keep one register assignment across the whole loop (no copies where the variants used to join).
+  {
+    int p = 0;
+    auto mfma_chunk = [&](int ch, auto first_tag) __attribute__((always_inline)) {
+      const int ncg = AF ? CK / 4 : min(CK / 4, (a.cin_pad - ch * CK) / 4);
+      if (tr && p < 16) a.trace[p * 4 + 0] = clock64();
+      if (a.dbg & 1) {
+        if (decltype(first_tag)::value) {
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) acc[r][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      } else if (AF) {
+        compute(smem + (p & 1) * BUF, std::true_type{}, ncg, first_tag);
+      } else {
+        compute(smem + (p & 1) * BUF, std::false_type{}, ncg, first_tag);
       }
-    }
-    if (a.epi_mode == 3 && pch == 0) {
-      // first chunk of an item two intervals ahead: its mask tensor (16 x NT channels x TH rows x 64 columns)
-      constexpr int NM = 16 * NT * TH * 2;
-      if (NM <= 256 && l < NM) {
-        const int c = l / (2 * TH), r = (l >> 1) % TH, hh = l & 1;
-        const int Y = min(pty * TH + r, a.Hout - 1), X = min(ptx * TW + 32 * hh, a.Wout - 4), co = min(pcb * COUT_TILE + c, a.Cout - 1);
-        pf_m = a.mk_u[(((size_t)pn * a.Cout + co) * a.Hout + Y) * a.Wout + X];
+      if (tr && p < 16) a.trace[p * 4 + 1] = clock64();
+    };
+    for (int it = 0; it < my_items; ++it) {
+      const int co0 = cb * COUT_TILE;
+      constexpr bool FAST = (NT == 1 && R == 1);      // (two channel blocks per lane: the fast epilogue's extra live values push the kernel past 128 registers = one workgroup per CU)
+      const bool interior = FAST && !(a.dbg & 32) && tile_interior(tile, co0);      // (dbg bit 32: generic epilogue everywhere - A/B switch)
+      auto pre_u = [&]() __attribute__((always_inline)) {
+        if constexpr (FAST) { if (interior && !(a.dbg & 64)) { prefetch_u_fast(n, tile, co0); return; } }
+        prefetch_u(n, tile, co0);
+      };
+      if (UPRE && a.epi_mode == 3 && nchunks == 1) pre_u();
+      mfma_chunk(0, std::true_type{});
+      for (int ch = 1; ch < nchunks; ++ch) {
+        lds_barrier();
+        if (tr && p < 16) a.trace[p * 4 + 3] = clock64();
+        ++p;
+        if (UPRE && a.epi_mode == 3 && ch + 1 == nchunks) pre_u();
+        mfma_chunk(ch, std::false_type{});
       }
-    }
-  };
-  for (int p = 0; p < T; ++p) {
-    const int c0 = chunk * CK;
-    const int ncg = min(CK / 4, (a.cin_pad - c0) / 4);
-    if (tr && p < 16) a.trace[p * 4 + 0] = clock64();
-    l2_prefetch(p);
-    if (UPRE && a.epi_mode == 3 && chunk + 1 == nchunks) prefetch_u(n, tile, cb * COUT_TILE);
-    if (!(a.dbg & 1)) {
-      if (ncg == CK / 4) compute(smem + (p & 1) * BUF, std::true_type{}, ncg);
-      else compute(smem + (p & 1) * BUF, std::false_type{}, ncg);
-    }
-    if (tr && p < 16) a.trace[p * 4 + 1] = clock64();
-    if (chunk + 1 == nchunks) {
-      epilogue(n, tile, cb * COUT_TILE);
+      bool done = false;
+      if constexpr (FAST) { if (interior) { epilogue_fast(n, tile, co0); done = true; } }
+      if (!done) epilogue(n, tile, co0);
       if (tr && p < 16) a.trace[p * 4 + 2] = clock64();
-      chunk = 0; item += gridDim.x;
-      if (p + 1 < T) { decode(item, n, tile, cb); load_bias(cb * COUT_TILE); }
-    } else {
-      ++chunk;
+      item += gridDim.x;
+      if (it + 1 < my_items) {
+        decode(item, n, tile, cb); load_bias(cb * COUT_TILE);
+        lds_barrier();
+        if (tr && p < 16) a.trace[p * 4 + 3] = clock64();
+      }
+      ++p;
     }
-    if (p + 1 < T) lds_barrier();                     // barrier #(p+2)
-    if (tr && p < 16) a.trace[p * 4 + 3] = clock64();
   }
 #ifdef MS_CONV_TRACE_BUILD
   if (tr) { a.trace[502] = clock64(); a.trace[503] = (long long)__builtin_amdgcn_s_memrealtime(); }
 #endif
-  if (pf_sink == 0x7FC12345u && a.trace != nullptr) a.trace[511] = 1;          // keeps the prefetch loads alive (never true: a NaN payload no input carries)
   if (a.stats != nullptr) conv_table_tail<NT, true>(a, smem, vb, ncb, st_n, st_mean, st_m2);
   else if (a.epi_mode == 3) conv_table_tail<NT, false>(a, smem, vb, ncb, 0.f, st_mean, st_m2);
 }
 
-template <int NT, int PRO, int R>
-int launch_conv_wide_r(ConvArgs a, hipStream_t st) {
+template <int NT, int PRO, int R, bool AF>
+int launch_conv_wide_af(ConvArgs a, hipStream_t st) {
   using G = WideGeo<NT, PRO, R>;
   const size_t cin_tab = (PRO != 0) ? (size_t)cdiv(a.cin_pad, G::CK) * G::CK : 0;              // coefficient table: one float4 per input channel of the padded chunks
   const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab);
   if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
   static std::once_flag attr_once;                     // one flag per instantiation; the attribute itself is immutable afterwards
-  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
+  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO, R, AF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
   a.tiles_x = cdiv(a.Wout, G::TW); a.tiles_y = cdiv(a.Hout, G::TH);
   a.ncb = cdiv(a.Cout, 16 * NT);
   const long nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb;
   const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;
-  MS_LAUNCH((conv_wide_kernel<NT, PRO, R>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
+  MS_LAUNCH((conv_wide_kernel<NT, PRO, R, AF>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
   return check_launch("conv_wide");
+}
+template <int NT, int PRO, int R>
+int launch_conv_wide_r(const ConvArgs& a, hipStream_t st) {
+  return (a.cin_pad % WideGeo<NT, PRO, R>::CK == 0) ? launch_conv_wide_af<NT, PRO, R, true>(a, st) : launch_conv_wide_af<NT, PRO, R, false>(a, st);
 }
 
 // tile height: 4 rows.  The 8-row variant (R = 2: two output rows per MFMA wave, bit-identical results) is kept behind MS_CONV_WIDE_ROWS=8: in isolation it is
