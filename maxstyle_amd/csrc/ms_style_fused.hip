@@ -63,6 +63,10 @@ __device__ __forceinline__ bool poll_granule(const u64* slot, float& value, unsi
 // Activation storage type of x / y: fp32, or bf16 (`*_bf16` entry points: half the HBM bytes; every statistic, coefficient and the arithmetic stay fp32).
 // One 16-byte buffer load / store per register slot either way: 4 fp32 or 8 bf16 values; a thread holds 64 values in fp32 registers.
 typedef __bf16 ms_bf16x2 __attribute__((ext_vector_type(2)));
+// A 16-byte buffer store with a REGISTER soffset must not have its data registers overwritten by the very next vector instruction: measured on MI355X in
+// the wide conv epilogue (ms_conv_wide.h, bstore4), lanes 12-15 of every 16-lane row of the second data dword then carry the NEW value, and hipcc pads this
+// hazard only for stores WITHOUT a register soffset.  The guard keeps the data registers live (and unmodified) across one idle issue slot behind the store.
+static __device__ __forceinline__ void store_guard(const u32x4& o) { asm volatile("s_nop 0" :: "v"(o)); }
 template <typename T> struct StyleIo;
 template <> struct StyleIo<float> {
   static constexpr int EPL = 4;
@@ -73,6 +77,7 @@ template <> struct StyleIo<float> {
   template <int AUX> static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&d)[4]) {
     u32x4 o; o.x = __float_as_uint(d[0]); o.y = __float_as_uint(d[1]); o.z = __float_as_uint(d[2]); o.w = __float_as_uint(d[3]);
     __builtin_amdgcn_raw_buffer_store_b128(o, r, voff, soff, AUX);
+    store_guard(o);
   }
 };
 struct ms_bf16_tag {};
@@ -91,6 +96,7 @@ template <> struct StyleIo<ms_bf16_tag> {
   template <int AUX> static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float (&d)[8]) {
     u32x4 o; o.x = pack2(d[0], d[1]); o.y = pack2(d[2], d[3]); o.z = pack2(d[4], d[5]); o.w = pack2(d[6], d[7]);
     __builtin_amdgcn_raw_buffer_store_b128(o, r, voff, soff, AUX);
+    store_guard(o);
   }
 };
 
