@@ -82,6 +82,8 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
                        int epi_mode, float* stats, const MaskEpi* mk, const FinEpi* fin, void* stream) {
   if (N < 1 || Cin < 1 || Cout < 1 || Hs < 1 || Ws < 1) { set_error("ms_conv2d: invalid shape"); return MS_ERR_INVALID; }
   if (pro_mode < 0 || pro_mode > 3 || epi_mode < 0 || epi_mode > 2 || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
+  // the activation helper computes max(v, v*slope): LeakyReLU / ReLU slopes only
+  if ((pro_mode == 1 && !(slope >= 0.f && slope <= 1.f)) || (mk != nullptr && !(mk->slope >= 0.f && mk->slope <= 1.f))) { set_error("ms_conv2d: activation slope outside [0, 1]"); return MS_ERR_INVALID; }
   if (mk != nullptr && mk->mode != 3) {
     if (epi_mode != 0 || stats != nullptr || ks != 1 || stride != 1 || fetch != 0 || pro_mode != 0 || mk->u == nullptr || mk->coef4 == nullptr ||
         !aligned16(mk->u) || !aligned16(mk->coef4) || !aligned16(out)) {

@@ -701,13 +701,12 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         if constexpr (FAST) { if (interior && !(a.dbg & 64)) { prefetch_u_fast(n, tile, co0); return; } }
         prefetch_u(n, tile, co0);
       };
-      if (UPRE && a.epi_mode == 3 && nchunks == 1) pre_u();
+      if (UPRE && a.epi_mode == 3) pre_u();            // at the START of the item: the registers are reserved anyway, and in a step the mask tensor is cold
       mfma_chunk(0, std::true_type{});
       for (int ch = 1; ch < nchunks; ++ch) {
         lds_barrier();
         if (tr && p < 16) a.trace[p * 4 + 3] = clock64();
         ++p;
-        if (UPRE && a.epi_mode == 3 && ch + 1 == nchunks) pre_u();
         mfma_chunk(ch, std::false_type{});
       }
       bool done = false;

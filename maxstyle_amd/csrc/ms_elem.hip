@@ -490,6 +490,7 @@ extern "C" int ms_confusion(const float* logits, const int64_t* labels, unsigned
 
 extern "C" int ms_bn_act(const float* u, const float* coef4, const float* res, int res_mode, float* out, int N, int C, int H, int W, float slope, void* stream) {
   if (N < 1 || C < 1 || H < 1 || W < 1 || res_mode < 0 || res_mode > 2) { set_error("ms_bn_act: invalid argument"); return MS_ERR_INVALID; }
+  if (!(slope >= 0.f && slope <= 1.f)) { set_error("ms_bn_act: activation slope outside [0, 1]"); return MS_ERR_INVALID; }
   if (res_mode != 0 && res == nullptr) { set_error("ms_bn_act: residual missing"); return MS_ERR_INVALID; }
   if (res_mode == 2 && ((H | W) & 1)) { set_error("ms_bn_act: half-resolution residual needs even H,W"); return MS_ERR_INVALID; }
   if ((long)N * C > 65535) { set_error("ms_bn_act: too many planes"); return MS_ERR_INVALID; }
