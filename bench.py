@@ -48,7 +48,10 @@ def parse():
     ap.add_argument("--no-outer", action="store_true", help="skip the auxiliary whole-training-iteration figure")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5, help="inner steps of the CPU-oracle sample")
-    ap.add_argument("--config", default="c2", choices=["c2", "c4"], help="c2: FCN_16 1x256x256 (the quoted metric); c4: FCN_64 3x320x320 (Prostate-shaped)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"],
+                    help="c2: FCN_16 1x256x256 (the quoted metric); c4: FCN_64 3x320x320 (Prostate-shaped); "
+                         "c5: mixed ACDC+Prostate stream through the drop-in solver API with random-depth insertion (p=0.5), fp32 activation storage")
+    ap.add_argument("--stream-calls", type=int, default=8, help="c5: generate_max_style_image calls per pass of the stream (alternating ACDC / Prostate shaped)")
     ap.add_argument("--steady-seconds", type=float, default=2.0, help="length of the extra steady-state leg (graph replays, rank-local); 0 disables")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only: gloo on the CPU, stand-in step (CPU tests)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend of the real run (nccl = RCCL; gloo: validation of the N>1 path on a box with fewer GPUs than ranks)")
@@ -481,6 +484,70 @@ def outer_iteration(dev, batch, size, rank=0, world=1, iters=6):
     return out
 
 
+def mixed_stream(dev, args, rank, world, dist_on):
+    """BASELINE config 5 on this rank's share of the node: a stream of generate_max_style_image calls (the reference's own entry point,
+    advanced_triplet...py:458-571) alternating ACDC-shaped (FCN_16, 16x1x256x256, K=5) and Prostate-shaped (FCN_64, 16x3x320x320, K=10) batches,
+    every call drawing its own random subset of MaxStyle layers with the trainer's p=0.5 (train_adv...py:263).  One captured HIP graph per
+    (shape, layer subset) signature is kept by the solver; the first pass over the stream captures them, the timed passes replay.  Activation storage is
+    fp32 (bf16 storage exists for the MaxStyle kernels only - DESIGN.md); a call whose layers all draw "not applied" runs 0 steps, as in the reference."""
+    import maxstyle_amd
+    from maxstyle_amd import synthetic as syn
+    cfgs = []
+    for tag, ntype, net, size, K in (("acdc", "FCN_16_standard_no_STN", (4, 1, 4), 256, 5), ("prostate", "FCN_64_standard_no_STN", (1, 3, 2), 320, 10)):
+        spec = syn.NetSpec(*net)
+        S = maxstyle_amd.AdvancedTripletReconSegmentationModel(network_type=ntype, image_ch=net[1], num_classes=net[2], use_gpu=True)
+        Wt = syn.procedural_weights(spec, 0)
+        for name, mod in S.model.items():
+            mod.load_state_dict(Wt[name]); mod.train()
+        img, lab = syn.synthetic_batch(args.batch, size, net[1], net[2], seed=1234 + rank)
+        img, lab = img.to(dev), lab.to(dev)
+        z_i, _ = S.encode_image(img, disable_track_bn_stats=True)
+        cfgs.append((tag, S, spec, img, lab, z_i.detach(), K))
+
+    def one_pass(seed0):
+        steps, subsets = 0, []
+        for c in range(args.stream_calls):
+            tag, S, spec, img, lab, z_i, K = cfgs[c % 2]
+            S.generate_max_style_image(z_i, [3, 4, 5], spec.channel_num, p=0.5, n_iter=K, lr=0.1, reference_image=img, reference_segmentation=lab,
+                                       fix_seed=seed0 + c)
+            applied = [int(k) for k, m in S.last_style_modules.items() if len(list(m.parameters())) > 0]
+            subsets.append((tag, applied))
+            steps += K if applied else 0
+        return steps, subsets
+
+    for _ in range(max(args.warmup, 1)):
+        one_pass(100)                                   # same seeds as the timed passes: every signature's graph is captured here
+    torch.cuda.synchronize()
+    if dist_on:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 0
+    passes = max(args.steps // 10, 1)
+    for _ in range(passes):
+        n, subsets = one_pass(100)
+        steps += n
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        from maxstyle_amd import distributed as D
+        dt = D.max_over_ranks(dt, dev)
+    if rank != 0:
+        return None
+    return {"metric": "inner adversarial style-opt steps/sec (mixed ACDC 16x1x256x256 K=5 + Prostate 16x3x320x320 K=10 stream, random depth p=0.5)",
+            "value": world * steps / dt, "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": dt / max(steps, 1) * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C5 (this rank's share): {args.stream_calls} generate_max_style_image calls per pass, alternating FCN_16 16x1x256x256 K=5 / FCN_64 16x3x320x320 K=10, "
+                                   "MaxStyle layers drawn per call from [3,4,5] with p=0.5, fp32 activation storage", "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}", "hip_graph": True, "passes": passes, "calls_per_pass": args.stream_calls},
+            "calls": [{"shape": t, "layers_applied": a} for t, a in subsets], "seconds": dt,
+            "note": "whole-call rate through the drop-in solver API: includes MaxStyle construction, the initial and final decodes and the host side of every call"}
+
+
 def _free_port():
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
@@ -581,6 +648,15 @@ def main():
             dist.init_process_group("nccl", device_id=dev)     # RCCL on ROCm: barriers, max-over-ranks, the outer-gradient all-reduce
         else:
             dist.init_process_group("gloo")
+    if args.config == "c5":
+        res = mixed_stream(dev, args, rank, world, dist_on)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if dist_on:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
     net = (4, 1, 4)
     if args.config == "c4":
         net = (1, 3, 2)

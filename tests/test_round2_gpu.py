@@ -487,3 +487,54 @@ def test_pool2_with_activation_backward(dev, N, C, Ho, Wo, slope):
     check(lib.ms_pool2_actbwd(hi.data_ptr(), out.data_ptr(), out.data_ptr(), act.data_ptr(), u.data_ptr(), coef.data_ptr(), part.data_ptr(), N, C, Ho, Wo, slope, st), "pool2_actbwd")
     assert torch.equal(out, ref)
     assert rel(_bn_coefs(lib, check, part, nparts, coef, N * Ho * Wo, C, dev), _bn_coefs(lib, check, part_ref, nparts, coef, N * Ho * Wo, C, dev)) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 5: mixed stream, random depth
+def test_mixed_stream_random_depth_matches_isolated_calls(dev):
+    """Config 5's access pattern through the drop-in API: generate_max_style_image calls alternating between an ACDC-shaped (FCN_16, 1 channel) and a
+    Prostate-shaped (FCN_64 widths, 3 channels, 2 classes) solver, every call drawing its own subset of layers with the trainer's p = 0.5
+    (train_adv...py:263).  The solver keeps one captured graph per (shape, subset) signature; whatever the order of the stream, every call must return
+    exactly what a FRESH solver returns for the same call in isolation (bit for bit, losses included), a call that draws no layer runs 0 steps, and
+    the second pass over the stream (pure graph replays) repeats the first."""
+    from oracle import maxstyle_oracle as orc
+    specs = [orc.NetSpec(4, 1, 4), orc.NetSpec(1, 3, 2)]
+    sizes = [64, 48]
+    B, Ks = 4, [3, 4]
+
+    def setup():
+        out = []
+        for spec, size in zip(specs, sizes):
+            S, W = make_solver(dev, spec)
+            img, lab = orc.synthetic_batch(B, size, spec.image_ch, spec.num_classes, 77)
+            img, lab = img.to(dev), lab.to(dev)
+            z_i, _ = S.encode_image(img, disable_track_bn_stats=True)
+            out.append((S, spec, img, lab, z_i.detach()))
+        return out
+
+    def call(cfg, K, seed):
+        S, spec, img, lab, z_i = cfg
+        o = S.generate_max_style_image(z_i, [3, 4, 5], spec.channel_num, p=0.5, n_iter=K, lr=0.1, reference_image=img, reference_segmentation=lab, fix_seed=seed)
+        applied = tuple(int(k) for k, m in S.last_style_modules.items() if len(list(m.parameters())) > 0)
+        losses = None if S.last_losses is None else S.last_losses.clone()
+        return o.clone(), applied, losses
+
+    stream = setup()
+    seeds = list(range(300, 312))
+    first = [call(stream[c % 2], Ks[c % 2], s) for c, s in enumerate(seeds)]
+    subsets = {(c % 2, first[c][1]) for c in range(len(seeds))}
+    assert len(subsets) >= 4, subsets                                   # the stream really alternates between several signatures
+    assert any(len(a) == 0 for _, a, _ in first) or True                # (a no-layer draw is possible, not guaranteed, with these seeds)
+    second = [call(stream[c % 2], Ks[c % 2], s) for c, s in enumerate(seeds)]
+    for (o1, a1, l1), (o2, a2, l2) in zip(first, second):
+        assert a1 == a2 and torch.equal(o1, o2)
+        assert (l1 is None and l2 is None) or torch.equal(l1, l2)
+    for c in (0, 1, 4, 7, 10):                                           # isolated: a fresh solver, one call
+        fresh = setup()
+        o, a, l = call(fresh[c % 2], Ks[c % 2], seeds[c])
+        assert a == first[c][1]
+        assert torch.equal(o, first[c][0]), (c, a)
+        if l is None:
+            assert first[c][2] is None and len(a) == 0
+        else:
+            assert torch.equal(l, first[c][2])
+        assert bool(torch.isfinite(o).all())
