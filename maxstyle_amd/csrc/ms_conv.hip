@@ -135,7 +135,8 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   if ((long)N > 65535) { set_error("ms_conv2d: batch too large for gridDim.z"); return MS_ERR_INVALID; }
   const bool narrow = narrow_tile(a.Wout);
   a.tiles_x = cdiv(a.Wout, tile_w(a.Wout)); a.tiles_y = cdiv(a.Hout, tile_h(a.Wout));
-  const bool vec = (fetch == FETCH_NORMAL) && (Ws % 4 == 0) && aligned16(in) && (a.in2 == nullptr || aligned16(a.in2));
+  // (16-byte staging loads use buffer addressing with 31-bit byte offsets inside one image: ms_conv_kernel.h BUF_LD)
+  const bool vec = (fetch == FETCH_NORMAL) && (Ws % 4 == 0) && aligned16(in) && (a.in2 == nullptr || aligned16(a.in2)) && ((long long)Cin * Hs * Ws < (1LL << 29) - 64);
   // output-channel tile: the widest (best reuse of the staged input tile) that still leaves >= 2 work items per CU;
   // failing that, the widest that leaves >= 1 per CU; else 16 channels (most parallelism)
   const long tiles = (long)a.tiles_x * a.tiles_y * N;
@@ -151,6 +152,10 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
     // two resident workgroups per CU with 16-channel tiles beat one with 32-channel tiles (285.4 -> 287.3 steps/s)
     // (not for a stride-2 layer of <= 32 channels: its input tile is 4x the output tile, and one 32-channel block stages it once instead of
     //  twice - 32->32 @16x128x128: 20.3 vs 27.1 us; with more channel blocks the extra workgroups win again: 128->128 @16x32x32 23.6 vs 26.7 us)
+    // (since the staging waves stopped being the bound - buffer addressing, round 2 - a deep 3x3 layer prefers ONE 32-channel workgroup per CU, which stages
+    //  each input tile once instead of twice: 128->128 @16x32x32 data-gradient + activation backward 60.4 -> 53.8 us, 64->128 @16x32x32 32.3 -> 28.7; not the 16-pixel-wide layers (25.8 vs 22.6)
+    //  nor prologue-free convs (28.4 vs 27.1); tools/tune_conv.py)
+    if (!found && want == 512L && ks == 3 && stride == 1 && Cin >= 64 && gemm_cols > 16 && pro_mode != 0 && !narrow && tiles * cdiv(gemm_cols, 32) >= 256L) { nt = 2; found = true; }
     if (!found && want == 512L && !(stride == 2 && gemm_cols <= 32) && tiles * cdiv(gemm_cols, 16) >= 512L) { nt = 1; found = true; }
     if (found) break;
   }

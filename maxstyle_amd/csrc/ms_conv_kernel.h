@@ -269,6 +269,13 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
     int s_lds[NI];        // (channel-in-chunk << 20) | LDS float offset of the slot, or -1: no slot   (tile independent)
     int s_rw[NI];         // (window row << 16) | window column
     int s_goff[NI];       // global offset inside one channel plane (or -1: outside the image -> zeros)  (per tile)
+    // BUF_LD (16-byte loads of the stored tensor: the common path): buffer addressing, as in the wide kernel (ms_conv_wide.h) - resource = image n, scalar
+    // offset = first channel of the chunk, vector offset = s_boff[j] = byte offset of (channel-in-chunk, pixel) computed ONCE PER TILE, or a sentinel beyond
+    // num_records for slots outside the image: the hardware range check returns the zeros of the padding, no per-chunk address arithmetic, selects or branches
+    constexpr bool BUF_LD = VEC && !EXP;
+    constexpr int kOob = 0x7FFFFFF0;
+    int s_boff[BUF_LD ? NI : 1];
+    unsigned tile_ok = 0;  // bit j: slot j lies inside the image for the current tile
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int it = tid + j * 256;
@@ -312,6 +319,15 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
           s_goff[j] = ok ? (ys * a.Ws + xs) : -1;
         }
       }
+      if constexpr (BUF_LD) {
+        tile_ok = 0;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const bool ok = (s_lds[j] >= 0) && (s_goff[j] >= 0);
+          tile_ok |= (ok ? 1u : 0u) << j;
+          s_boff[j] = ok ? 4 * ((s_lds[j] >> 20) * (int)in_plane + s_goff[j]) : kOob;
+        }
+      }
     };
     float rin[NI][VW];
     float rin2[IN2 ? NI : 1][VW];
@@ -319,8 +335,33 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
     unsigned okmask = 0;          // bit j: slot j of the chunk held in registers lies inside the image
     bool have_w = false;          // rw holds a weight slice that must be written to LDS
 
+    typedef unsigned lu32x4_t __attribute__((ext_vector_type(4)));
     auto load_chunk = [&](int n, int co0, int c0, bool load_w) {
       const float* in_n = a.in + (size_t)n * a.Cin * in_plane;
+      if constexpr (BUF_LD) {
+        const bool ragged = (c0 + CK > a.Cin);
+        okmask = tile_ok;
+        const unsigned img_bytes = 4u * (unsigned)a.Cin * (unsigned)in_plane;          // the host checks Cin*plane*4 < 2^31
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_n), 0, img_bytes, 0x00020000);
+        const float* in2_n = IN2 ? a.in2 + (size_t)n * a.Cin * in_plane : in_n;
+        const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in2_n), 0, img_bytes, 0x00020000);
+        const int soff = 4 * c0 * (int)in_plane;
+        const bool dead = (a.dbg & 2) != 0;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          int off = s_boff[j];
+          if (ragged || dead) {                       // (wave-uniform) a layer's last chunk: channels beyond Cin are zeros too
+            const bool ok = ((okmask >> j) & 1u) && (c0 + (s_lds[j] >> 20) < a.Cin) && !dead;
+            if (!ok) { off = kOob; okmask &= ~(1u << j); }
+          }
+          const lu32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r1, off, soff, 0);
+          rin[j][0] = __uint_as_float(v.x); rin[j][1] = __uint_as_float(v.y); rin[j][2] = __uint_as_float(v.z); rin[j][3] = __uint_as_float(v.w);
+          if constexpr (IN2) {
+            const lu32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r2, off, soff, 0);
+            rin2[j][0] = __uint_as_float(u.x); rin2[j][1] = __uint_as_float(u.y); rin2[j][2] = __uint_as_float(u.z); rin2[j][3] = __uint_as_float(u.w);
+          }
+        }
+      } else {
       okmask = 0;
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
@@ -349,6 +390,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
           rin[j][0] = ld ? in_n[off] : 0.f;
           if constexpr (IN2) { const float* in2_n = a.in2 + (size_t)n * a.Cin * in_plane; rin2[j][0] = ld ? in2_n[off] : 0.f; }
         }
+      }
       }
       have_w = load_w;
       if (load_w) {
