@@ -10,6 +10,7 @@ bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool v
   //  first-generation kernel at 16->16 @16x256x256)
   if (a.Wout < 64 || a.Wout % 4 != 0) return false;
   if ((long long)a.Cin * a.Hs * a.Ws + a.Ws + 4 >= (1LL << 29)) return false;      // byte offsets inside one image fit 31 bits (buffer addressing of the staging)
+  if ((long long)a.Cout * a.Hout * a.Wout >= (1LL << 29)) return false;              // ... and so do the epilogue's offsets inside one output image
   if (!aligned16(a.out)) return false;
   return true;
 }

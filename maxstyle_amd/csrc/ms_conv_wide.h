@@ -93,7 +93,10 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 
   if (producer) {
     // =========================================== PRODUCER waves ===========================================
-    __builtin_amdgcn_s_setprio(3);
+#ifndef MS_WIDE_STAGE_PRIO
+#define MS_WIDE_STAGE_PRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(MS_WIDE_STAGE_PRIO);
     const int tid = threadIdx.x - 256;
     const int plane = a.Hs * a.Ws;                 // host checks Cin*plane < 2^31
     typedef unsigned mask_t;
