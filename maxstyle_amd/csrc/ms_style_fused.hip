@@ -332,7 +332,11 @@ static int style_fwd_fused_impl(const void* x, void* y, float* mu, float* sig, f
   a.lmda = lmda; a.gamma_noise = gamma_noise; a.beta_noise = beta_noise; a.perm = perm; a.coefA = coefA; a.coefS = coefS;
   a.part = (u64*)((char*)ws + pl.part_off); a.arrive = hdr + 2; a.counter = hdr; a.err = hdr + 1;
   a.compute_std = compute_std; a.B = B; a.C = C; a.HW = HW; a.S = pl.S; a.chunk = pl.chunk; a.nv = pl.nv; a.eps = eps;
-  static const int policy = env_int("MS_STYLE_FUSED_NT", 0);                      // bit 0: nt loads of x, bit 1: nt stores of y (A/B timing, fp32 only)
+  // cache policy (fp32): bit 0 nt loads of x, bit 1 nt stores of y.  A tensor that does not fit the 256 MB Infinity Cache cannot be found there by the next kernel
+  // anyway: streaming it past the caches measured 184.8 -> 170.3 us at 16x64x320x320 (4.5 -> 4.9 TB/s, profiles/r02_experiments.txt section 4), while for the
+  // cache-sized tensors of config 2 the default policy wins in the step (the next kernel reads y from the cache).  MS_STYLE_FUSED_NT overrides (A/B timing).
+  static const int policy_env = env_int("MS_STYLE_FUSED_NT", -1);
+  const int policy = policy_env >= 0 ? policy_env : (((size_t)B * C * HW * sizeof(float) > ((size_t)256 << 20)) ? 3 : 0);
   dim3 grid(pl.grid), block(pl.threads);
 #define MS_FUSED(TT, AL, AS) MS_LAUNCH((style_fused_kernel<TT, AL, AS, T>), grid, block, 0, st, a)
 #define MS_FUSED_T(TT) if (std::is_same<T, float>::value) { switch (policy & 3) { case 1: MS_FUSED(TT, 2, 0); break; case 2: MS_FUSED(TT, 0, 2); break; \
