@@ -1,6 +1,6 @@
 """Round-2 golden vectors, produced by running the REFERENCE here (needs /root/reference; the older fixtures are left untouched).
 
-    python tests/golden/make_golden_r2.py [depth] [trained]
+    python tests/golden/make_golden_r2.py [depth] [trained] [c4]
 
 depth   -> loop_random_depth.npz : generate_max_style_image as the TRAINER calls it - p = 0.5 literal
            (train_adv_supervised_segmentation_triplet.py:263) - with injected rand_p so that strict subsets of the inserted layers
@@ -11,6 +11,7 @@ trained -> trained_fcn16.npz     : the three FCN_16 sub-nets after a short run o
            loop_trained.npz      : the reference's K=5 MaxStyle loop on those weights (fp32 + fp64 twin): losses, final image,
            segmentation of the clean and of the stylised image and their Dice against the labels.  With trained networks the Dice
            is a meaningful number (clean ~0.9, stylised lower: the hard example), unlike the ~0.07 of random networks.
+c4      -> loop_c4small.npz (+ _f64): the reference's loop on the Prostate-shaped FCN_64 / 3-channel / 2-class network (BASELINE config 4) at 4x3x64x64.
 Fixtures are data only.  The reference is imported in place, never copied.
 """
 import contextlib
@@ -180,9 +181,25 @@ def trained(solver_mod):
     print("loop_trained.npz", os.path.getsize(os.path.join(HERE, "loop_trained.npz")), flush=True)
 
 
+def config4_small(solver_mod):
+    """loop_c4small.npz (+ fp64 twin): the reference's own loop on the Prostate-shaped network of BASELINE config 4 - FCN_64 widths (512-channel code,
+    decoder 256/128/64/64), 3 image channels, 2 classes (advanced_triplet...py:42,152-171; channel_num = [512,256,128,64,64,3], train_adv...py:255-258) -
+    at 4x3x64x64, MaxStyle after blocks [3,4,5], K = 3.  Same keys as loop_c2small.npz (make_golden.loop_case)."""
+    from make_golden import loop_case
+    torch.set_num_threads(8)
+    spec = orc.NetSpec(1, 3, 2)
+    c = loop_case(solver_mod, spec, B=4, size=64, layers=[3, 4, 5], K=3, dtype=torch.float32)
+    np.savez_compressed(os.path.join(HERE, "loop_c4small.npz"), **c)
+    d = loop_case(solver_mod, spec, B=4, size=64, layers=[3, 4, 5], K=3, dtype=torch.float64)
+    np.savez_compressed(os.path.join(HERE, "loop_c4small_f64.npz"), **{k: v for k, v in d.items() if k in ("image", "losses") or k.startswith("step")})
+    print("c4small losses", c["losses"], "dice", c["final_dice"], flush=True)
+
+
 def main():
     what = sys.argv[1:] or ["depth", "trained"]
     solver_mod = ref_harness.load_solver_module()
+    if "c4" in what:
+        config4_small(solver_mod)
     if "depth" in what:
         random_depth(solver_mod)
     if "trained" in what:

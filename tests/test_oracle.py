@@ -174,6 +174,25 @@ def test_loop_k5_three_layers(golden_dir):
     np.testing.assert_allclose(orc.dice_per_class(pred, lab, 4), g["final_dice"], atol=1e-3)
 
 
+def test_loop_config4_shaped_network(golden_dir):
+    """BASELINE config 4's network - FCN_64 widths, 3 image channels, 2 classes - against the reference's OWN run of it (loop_c4small.npz, 4x3x64x64,
+    layers [3,4,5], K=3): per-step losses / gradients / parameters teacher-forced, final image, segmentation, Dice; fp64 restatement == fp64 reference."""
+    g = np.load(os.path.join(golden_dir, "loop_c4small.npz"))
+    g64 = np.load(os.path.join(golden_dir, "loop_c4small_f64.npz"))
+    spec = orc.NetSpec(1, 3, 2)
+    W, lab, out = _teacher_forced(g, g64, spec, 4, 64, [3, 4, 5], 3)
+    with torch.no_grad():
+        _, zs = orc.encoder_forward(W["image_encoder"], out)
+        pred = orc.decoder_forward(W["segmentation_decoder"], zs, "NN").argmax(1)
+    assert float((pred.numpy() == g["final_pred"]).mean()) > 0.9995
+    np.testing.assert_allclose(orc.dice_per_class(pred, lab, 2), g["final_dice"], atol=1e-3)
+    W, img, lab, z_i, styles = _setup(spec, 4, 64, [3, 4, 5], dtype=torch.float64)
+    tr = orc.InnerLoopTrace()
+    out64 = orc.generate_max_style_image(W, z_i, styles, [3, 4, 5], lab, n_iter=3, lr=0.1, trace=tr)
+    assert rel(out64, g64["image"]) < 1e-9
+    np.testing.assert_allclose(tr.losses, g64["losses"], rtol=1e-10)
+
+
 def test_loop_eval_mode(golden_dir):
     """The loop called with the sub-networks in .eval() (running statistics in every BatchNorm): K=3, layers [3,4,5]."""
     g = np.load(os.path.join(golden_dir, "loop_eval.npz"))
