@@ -148,6 +148,8 @@ int ms_counter_incr(int* counter, void* stream);
  *             activation of the producer; pro_nstride = 0 per channel, = Cin per (n,c) plane; pro_cstride = 4 reads the
  *             interleaved coef4 records of ms_bn_finalize / ms_bn_bwd_coefs in place)
  *             | 2 v = pro_a[i]*v + pro_b[i]*in2 + pro_c[i], i = ci*pro_cstride   (BatchNorm backward apply)
+ *             every activation slope of this library (slope, act_slope) must lie in [0, 1] - LeakyReLU (0.2) or ReLU (0), the only ones the
+ *             reference uses (encoder_decoder.py:646,655); anything else is MS_ERR_INVALID (the kernels compute max(v, v*slope))
  *             | 3 as 2, but the three coefficients are derived inside the kernel (saves the ms_bn_bwd_coefs launch): pro_a = the
  *               partial sums [Cin][pro_nstride][2] written by ms_act_bwd_reduce, pro_b = the forward coef4 records of that BatchNorm
  *               (pro_cstride >= 4), pro_c = NULL or an output [Cin][4] that receives the coefficients; count = N*Hs*Ws
@@ -225,7 +227,7 @@ int ms_bn_finalize(const float* stats, int nparts, const float* gamma, const flo
 /* ---- streaming kernels around the convolutions ------------------------------------------------------------- */
 
 /* out = LeakyReLU_slope(coef4[c].scale*u + coef4[c].shift + res): BatchNorm apply + residual add + activation
- * (encoder_decoder.py:62-64, 344-346; slope 0.2, or 0 for nn.ReLU).  res_mode 0 none | 1 same shape | 2 res is
+ * (encoder_decoder.py:62-64, 344-346; slope 0.2, or 0 for nn.ReLU; 0 <= slope <= 1).  res_mode 0 none | 1 same shape | 2 res is
  * [N,C,H/2,W/2] and is nearest-up-sampled on the fly (conv1x1 commutes with nn.UpsamplingNearest2d). */
 int ms_bn_act(const float* u, const float* coef4, const float* res, int res_mode, float* out, int N, int C, int H, int W, float slope, void* stream);
 
