@@ -440,3 +440,23 @@ def test_wide_kernel_8_row_tiles_in_a_subprocess():
                         "wide_kernel_all_modes or conv_actbwd_epilogue or batch_stats_and_prologue or bn_backward_chain"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_activation_slope_range_is_checked(dev):
+    """The activation helper computes max(v, v*slope) - exact for the LeakyReLU / ReLU slopes the reference uses (encoder_decoder.py:646,655) and only
+    for slopes in [0, 1]: anything else is refused at the entry points, never computed wrong."""
+    from maxstyle_amd import ops
+    from maxstyle_amd._lib import MaxStyleHipError
+    u = _rand((1, 4, 8, 8), 1).to(dev)
+    coef = torch.ones(4, 4, device=dev)
+    with pytest.raises(MaxStyleHipError):
+        ops.bn_act(u, coef, slope=1.5)
+    with pytest.raises(MaxStyleHipError):
+        ops.bn_act(u, coef, slope=-0.1)
+    w = ops.pack_conv_weight(_rand((4, 4, 3, 3), 2, 0.1).to(dev))
+    with pytest.raises(MaxStyleHipError):
+        ops.conv2d(u, w, None, 4, 3, 1, pro_mode=1, pro_a=ops.coef_ptrs(coef)[0], pro_b=ops.coef_ptrs(coef)[1], pro_cstride=4, slope=2.0)
+    out = ops.bn_act(u, coef, slope=0.0)                                   # ReLU
+    assert torch.equal(out, torch.relu(u + 1.0))
+    neg = ops.bn_act(u, coef, slope=0.2)
+    assert torch.equal(neg, torch.nn.functional.leaky_relu(u + 1.0, 0.2))   # max(v, 0.2 v) == the select form, bit for bit
