@@ -349,6 +349,38 @@ size_t ms_head_ce_ws_bytes(int N, int HW);
 int ms_head_ce(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* logits, float* loss_out,
                const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- bf16 ACTIVATION STORAGE for the conv stack (SURVEY.md 8(b) "`_bf16` I/O variants with fp32 statistics"; BASELINE config 5) -----------------
+ * Twins of the fp32 entry points above with the same argument lists and semantics; every ACTIVATION tensor (conv inputs / outputs, raw conv
+ * outputs u, gradients, residuals, head inputs / outputs) is a tensor of bf16 bit patterns (uint16_t), everything else - packed weights, biases,
+ * BatchNorm coefficient records, statistics / partial tables, losses, logits - stays fp32 (fp64 where the fp32 entry point uses it).  Arithmetic is
+ * unchanged: loads widen bf16 to fp32 exactly, the convolutions run on the fp32 matrix cores, BatchNorm statistics are taken from the fp32
+ * accumulators BEFORE the output is rounded, stores round to nearest-even bf16 (relative error <= 2^-9 per stored element).  Requirements: the
+ * vector paths of the fp32 entry points (rows of W % 4 == 0 elements - W % 2 for fetch 1 -, 16-byte aligned tensors); MS_ERR_INVALID otherwise.
+ * The sub-pixel (ms_conv_subpix) and small-Cout (ms_conv3x3_small_cout) special cases have no bf16 twin: use ms_conv2d_bf16 with fetch 1 / 2. */
+int ms_conv2d_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias,
+                   int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                   int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                   int epi_mode, float* stats, void* stream);
+int ms_conv1x1_bnres_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
+                          const uint16_t* u, const float* coef4, float slope, int up2, void* stream);
+int ms_conv2d_actbwd_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed,
+                          int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                          int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                          const uint16_t* u, const float* coef4, float act_slope, float* tab, void* stream);
+int ms_bn_act_bf16(const uint16_t* u, const float* coef4, const uint16_t* res, int res_mode, uint16_t* out, int N, int C, int H, int W, float slope, void* stream);
+int ms_act_bwd_reduce_bf16(const uint16_t* gin, const uint16_t* ref, const uint16_t* u, const float* coef4, uint16_t* gout, float* part2,
+                           int N, int C, int HW, float slope, void* stream);
+int ms_pool2_sum_bf16(const uint16_t* in, uint16_t* out, int planes, int Ho, int Wo, int accumulate, void* stream);
+int ms_pool2_actbwd_bf16(const uint16_t* in, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
+                         int N, int C, int Ho, int Wo, float slope, void* stream);
+int ms_head_fwd_bf16(const uint16_t* h, const float* w, const float* b, uint16_t* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
+int ms_head_bwd_bf16(const uint16_t* dout, const uint16_t* out, const float* w, uint16_t* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
+int ms_head_ce_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* logits, float* loss_out,
+                    const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream);
+int ms_head_ce_actbwd_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* loss_out, const int* loss_slot_dev,
+                           int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,
+                           const uint16_t* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

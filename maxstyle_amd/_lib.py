@@ -111,6 +111,10 @@ SIGNATURES = {
     "ms_head_ce": (c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_void, c_int, c_int, c_int, c_int, c_float,
                            c_void, c_size, c_void]),
 }
+# bf16 activation storage for the conv stack: same argument lists as the fp32 entry points (device pointers travel as integers either way)
+for _n in ("ms_conv2d", "ms_conv1x1_bnres", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd",
+           "ms_head_fwd", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd"):
+    SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]
 
 
 class MaxStyleHipError(RuntimeError):

@@ -83,6 +83,48 @@ __device__ __forceinline__ void chan_merge(double& n, double& mean, double& m2, 
 // every vector instruction waits behind an MFMA.
 __device__ __forceinline__ float leaky(float v, float slope) { return fmaxf(v, v * slope); }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Activation STORAGE type of the conv stack (BASELINE config 5: bf16 activations): kernels are templated on AT = float or ms_bf16 and touch
+// activation tensors only through ActIO<AT> - element offsets in, fp32 values out.  Statistics, coefficients, accumulators, LDS tiles and
+// the matrix arithmetic stay fp32 whatever AT is; a bf16 store rounds to nearest even (v_cvt_pk_bf16_f32).  For AT = float every helper is
+// the plain load / store it replaces (same instructions).  Vector forms need the element offset to be a multiple of the vector length and the
+// tensor base 16-byte aligned, as before.
+struct ms_bf16 { uint16_t v; };
+typedef __bf16 ms_bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned ms_pack_bf16x2(float a, float b) {
+  ms_bf16x2_t p; p[0] = (__bf16)a; p[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ uint16_t ms_to_bf16(float a) { return __builtin_bit_cast(uint16_t, (__bf16)a); }
+template <typename AT> struct ActIO;
+template <> struct ActIO<float> {
+  static constexpr int kBytes = 4;
+  static __device__ __forceinline__ float ld1(const void* b, size_t o) { return reinterpret_cast<const float*>(b)[o]; }
+  static __device__ __forceinline__ float2 ld2(const void* b, size_t o) { return *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(b) + o); }
+  static __device__ __forceinline__ float4 ld4(const void* b, size_t o) { return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(b) + o); }
+  static __device__ __forceinline__ void st1(void* b, size_t o, float v) { reinterpret_cast<float*>(b)[o] = v; }
+  static __device__ __forceinline__ void st2(void* b, size_t o, float2 v) { *reinterpret_cast<float2*>(reinterpret_cast<float*>(b) + o) = v; }
+  static __device__ __forceinline__ void st4(void* b, size_t o, float4 v) { *reinterpret_cast<float4*>(reinterpret_cast<float*>(b) + o) = v; }
+};
+template <> struct ActIO<ms_bf16> {
+  static constexpr int kBytes = 2;
+  static __device__ __forceinline__ float up(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+  static __device__ __forceinline__ float ld1(const void* b, size_t o) { return up(reinterpret_cast<const uint16_t*>(b)[o]); }
+  static __device__ __forceinline__ float2 ld2(const void* b, size_t o) {
+    const unsigned w = *reinterpret_cast<const unsigned*>(reinterpret_cast<const uint16_t*>(b) + o);
+    return make_float2(__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u));
+  }
+  static __device__ __forceinline__ float4 ld4(const void* b, size_t o) {
+    const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(b) + o);
+    return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xFFFF0000u));
+  }
+  static __device__ __forceinline__ void st1(void* b, size_t o, float v) { reinterpret_cast<uint16_t*>(b)[o] = ms_to_bf16(v); }
+  static __device__ __forceinline__ void st2(void* b, size_t o, float2 v) { *reinterpret_cast<unsigned*>(reinterpret_cast<uint16_t*>(b) + o) = ms_pack_bf16x2(v.x, v.y); }
+  static __device__ __forceinline__ void st4(void* b, size_t o, float4 v) {
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(b) + o) = make_uint2(ms_pack_bf16x2(v.x, v.y), ms_pack_bf16x2(v.z, v.w));
+  }
+};
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

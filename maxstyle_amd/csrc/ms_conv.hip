@@ -79,7 +79,7 @@ struct FinEpi { int* counter; float* out; const float* gamma; const float* beta;
 static int conv2d_impl(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                        int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                        int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
-                       int epi_mode, float* stats, const MaskEpi* mk, const FinEpi* fin, void* stream) {
+                       int epi_mode, float* stats, const MaskEpi* mk, const FinEpi* fin, void* stream, int act_bf16 = 0) {
   if (N < 1 || Cin < 1 || Cout < 1 || Hs < 1 || Ws < 1) { set_error("ms_conv2d: invalid shape"); return MS_ERR_INVALID; }
   if (pro_mode < 0 || pro_mode > 3 || epi_mode < 0 || epi_mode > 2 || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
   // the activation helper computes max(v, v*slope): LeakyReLU / ReLU slopes only
@@ -124,6 +124,7 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   a.Cout = gemm_cols;
   a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (gemm_cols + 63) / 64 * 64;
   a.bw_parts = bw_parts; a.bw_count = (double)N * Hs * Ws; a.bw_out = bw_out;
+  a.act_bf16 = act_bf16;
   a.pro_mode = pro_mode; a.pro_nstride = pro_nstride; a.pro_cstride = pro_cstride < 1 ? 1 : pro_cstride; a.slope = slope; a.epi_mode = epi_mode;
   if (mk != nullptr) { a.mk_u = mk->u; a.mk_coef = mk->coef4; a.mk_slope = mk->slope; a.mk_tab = mk->tab; }
   if (fin != nullptr) {
@@ -204,6 +205,32 @@ extern "C" int ms_conv1x1_bnres(const float* in, float* out, const float* w_pack
   MaskEpi mk{u, coef4, slope, nullptr};
   mk.mode = up2 ? 5 : 4;
   return conv2d_impl(in, nullptr, out, w_packed, bias, N, Cin, Hs, Ws, Cout, 1, 1, 0, 0, nullptr, nullptr, nullptr, 0, 1, 1.0f, 0, nullptr, &mk, nullptr, stream);
+}
+
+// ---- `_bf16` twins: the activation tensors (in, in2, out, u) hold bf16 bit patterns; weights, bias, coefficients, statistics and tables are fp32 as before.
+// Built for the vector staging paths: rows of W % 4 == 0 elements (W % 2 for the fused up-sampling fetch), 16-byte aligned tensors.
+static const float* as_f(const uint16_t* p) { return reinterpret_cast<const float*>(p); }
+static float* as_f(uint16_t* p) { return reinterpret_cast<float*>(p); }
+extern "C" int ms_conv2d_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias,
+                              int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                              int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                              int epi_mode, float* stats, void* stream) {
+  return conv2d_impl(as_f(in), as_f(in2), as_f(out), w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
+                     epi_mode, stats, nullptr, nullptr, stream, 1);
+}
+extern "C" int ms_conv1x1_bnres_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
+                                     const uint16_t* u, const float* coef4, float slope, int up2, void* stream) {
+  MaskEpi mk{as_f(u), coef4, slope, nullptr};
+  mk.mode = up2 ? 5 : 4;
+  return conv2d_impl(as_f(in), nullptr, as_f(out), w_packed, bias, N, Cin, Hs, Ws, Cout, 1, 1, 0, 0, nullptr, nullptr, nullptr, 0, 1, 1.0f, 0, nullptr, &mk, nullptr, stream, 1);
+}
+extern "C" int ms_conv2d_actbwd_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed,
+                                     int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                                     int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                                     const uint16_t* u, const float* coef4, float act_slope, float* tab, void* stream) {
+  const MaskEpi mk{as_f(u), coef4, act_slope, tab};
+  return conv2d_impl(as_f(in), as_f(in2), as_f(out), w_packed, nullptr, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
+                     0, nullptr, &mk, nullptr, stream, 1);
 }
 
 extern "C" size_t ms_conv_actbwd_tab_bytes(int Cout) { return ((size_t)Cout * kStatSlots + 1) * sizeof(float2); }

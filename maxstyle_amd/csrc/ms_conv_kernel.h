@@ -34,6 +34,7 @@ struct ConvArgs {
   int epi_mode, tiles_x, tiles_y, cout_real, ncb;   // ncb: number of output-channel blocks (of 16*NT)
   int pf;                       // wide kernel: the MFMA waves touch the lines of the (cold) second tensor two chunks ahead (L2 prefetch), see conv_wide_kernel
   int stagger;                  // wide kernel: the second workgroup of a CU starts `stagger` x ~1k cycles late (0 = off), see conv_wide_kernel
+  int act_bf16;                 // activation tensors (in, in2, out, mk_u) are stored as bf16 (the `_bf16` entry points); statistics / coefficients / weights fp32
   int dbg;                      // timing-only ablation bits (MS_CONV_DBG): 1 skip MFMA loop, 2 skip global loads, 4 skip epilogue stores, 8 skip LDS stores, 16 skip the epilogue
   int bw_parts; double bw_count; float* bw_out;   // pro_mode 3 (host side): BatchNorm-backward coefficients are derived in-kernel from bw_parts partial sums per channel
   long long* trace;             // MS_CONV_TRACE_BUILD only: cycle stamps of workgroup 0 (tools/trace_conv.py)
@@ -218,9 +219,12 @@ struct Geo {
   }
 };
 
-template <int KS, int STRIDE, int FETCH, int NT, bool VEC, bool NARROW, bool IN2>
+// AT = storage type of the activation tensors in / in2 / out / mk_u (float or ms_bf16, ms_common.h ActIO): everything else is fp32 either way
+template <int KS, int STRIDE, int FETCH, int NT, bool VEC, bool NARROW, bool IN2, typename AT = float>
 __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const ConvArgs a) {
   using G = Geo<KS, STRIDE, FETCH, VEC, NARROW, NT>;
+  using IO = ActIO<AT>;
+  constexpr int AB = IO::kBytes;
   constexpr int CK = G::CK, PS = G::PS, RS = G::RS, IH = G::IH, PAD = G::PAD, PADL = G::PADL, HALF = G::HALF;
   constexpr int TW = G::TW, TH = G::TH, VW = G::VW, ROW_ITEMS = G::ROW_ITEMS, ITEMS = G::ITEMS, NI = G::NI, SR = G::SR;
   constexpr bool EXP = G::EXP;
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         for (int j = 0; j < NI; ++j) {
           const bool ok = (s_lds[j] >= 0) && (s_goff[j] >= 0);
           tile_ok |= (ok ? 1u : 0u) << j;
-          s_boff[j] = ok ? 4 * ((s_lds[j] >> 20) * (int)in_plane + s_goff[j]) : kOob;
+          s_boff[j] = ok ? AB * ((s_lds[j] >> 20) * (int)in_plane + s_goff[j]) : kOob;
         }
       }
     };
@@ -336,16 +340,18 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
     bool have_w = false;          // rw holds a weight slice that must be written to LDS
 
     typedef unsigned lu32x4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned lu32x2_t __attribute__((ext_vector_type(2)));
     auto load_chunk = [&](int n, int co0, int c0, bool load_w) {
-      const float* in_n = a.in + (size_t)n * a.Cin * in_plane;
+      const size_t img_off = (size_t)n * a.Cin * in_plane;                        // element offset of image n (both input tensors)
       if constexpr (BUF_LD) {
         const bool ragged = (c0 + CK > a.Cin);
         okmask = tile_ok;
-        const unsigned img_bytes = 4u * (unsigned)a.Cin * (unsigned)in_plane;          // the host checks Cin*plane*4 < 2^31
-        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_n), 0, img_bytes, 0x00020000);
-        const float* in2_n = IN2 ? a.in2 + (size_t)n * a.Cin * in_plane : in_n;
-        const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in2_n), 0, img_bytes, 0x00020000);
-        const int soff = 4 * c0 * (int)in_plane;
+        const unsigned img_bytes = (unsigned)AB * (unsigned)a.Cin * (unsigned)in_plane;          // the host checks Cin*plane*4 < 2^31
+        char* in_n = const_cast<char*>(reinterpret_cast<const char*>(a.in)) + img_off * AB;
+        char* in2_n = IN2 ? const_cast<char*>(reinterpret_cast<const char*>(a.in2)) + img_off * AB : in_n;
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(in_n, 0, img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(in2_n, 0, img_bytes, 0x00020000);
+        const int soff = AB * c0 * (int)in_plane;
         const bool dead = (a.dbg & 2) != 0;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -354,11 +360,20 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
             const bool ok = ((okmask >> j) & 1u) && (c0 + (s_lds[j] >> 20) < a.Cin) && !dead;
             if (!ok) { off = kOob; okmask &= ~(1u << j); }
           }
-          const lu32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r1, off, soff, 0);
-          rin[j][0] = __uint_as_float(v.x); rin[j][1] = __uint_as_float(v.y); rin[j][2] = __uint_as_float(v.z); rin[j][3] = __uint_as_float(v.w);
-          if constexpr (IN2) {
-            const lu32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r2, off, soff, 0);
-            rin2[j][0] = __uint_as_float(u.x); rin2[j][1] = __uint_as_float(u.y); rin2[j][2] = __uint_as_float(u.z); rin2[j][3] = __uint_as_float(u.w);
+          if constexpr (AB == 4) {
+            const lu32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r1, off, soff, 0);
+            rin[j][0] = __uint_as_float(v.x); rin[j][1] = __uint_as_float(v.y); rin[j][2] = __uint_as_float(v.z); rin[j][3] = __uint_as_float(v.w);
+            if constexpr (IN2) {
+              const lu32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r2, off, soff, 0);
+              rin2[j][0] = __uint_as_float(u.x); rin2[j][1] = __uint_as_float(u.y); rin2[j][2] = __uint_as_float(u.z); rin2[j][3] = __uint_as_float(u.w);
+            }
+          } else {                                    // bf16 storage: 4 values = one 8-byte load, widened to fp32 (a shift / a mask each)
+            const lu32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r1, off, soff, 0);
+            rin[j][0] = __uint_as_float(v.x << 16); rin[j][1] = __uint_as_float(v.x & 0xFFFF0000u); rin[j][2] = __uint_as_float(v.y << 16); rin[j][3] = __uint_as_float(v.y & 0xFFFF0000u);
+            if constexpr (IN2) {
+              const lu32x2_t u = __builtin_amdgcn_raw_buffer_load_b64(r2, off, soff, 0);
+              rin2[j][0] = __uint_as_float(u.x << 16); rin2[j][1] = __uint_as_float(u.x & 0xFFFF0000u); rin2[j][2] = __uint_as_float(u.y << 16); rin2[j][3] = __uint_as_float(u.y & 0xFFFF0000u);
+            }
           }
         }
       } else {
@@ -371,24 +386,22 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         const bool ld = ok && !(a.dbg & 2);
         const size_t off = ld ? ((size_t)ci * in_plane + (size_t)s_goff[j]) : 0;
         if constexpr (EXP) {
-          const float2 v = ld ? *reinterpret_cast<const float2*>(in_n + off) : make_float2(0.f, 0.f);
+          const float2 v = ld ? IO::ld2(a.in, img_off + off) : make_float2(0.f, 0.f);
           rin[j][0] = v.x; rin[j][1] = v.y;
           if constexpr (IN2) {
-            const float* in2_n = a.in2 + (size_t)n * a.Cin * in_plane;
-            const float2 u = ld ? *reinterpret_cast<const float2*>(in2_n + off) : make_float2(0.f, 0.f);
+            const float2 u = ld ? IO::ld2(a.in2, img_off + off) : make_float2(0.f, 0.f);
             rin2[j][0] = u.x; rin2[j][1] = u.y;
           }
         } else if constexpr (VEC) {
-          const float4 v = ld ? *reinterpret_cast<const float4*>(in_n + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 v = ld ? IO::ld4(a.in, img_off + off) : make_float4(0.f, 0.f, 0.f, 0.f);
           rin[j][0] = v.x; rin[j][1] = v.y; rin[j][2] = v.z; rin[j][3] = v.w;
           if constexpr (IN2) {
-            const float* in2_n = a.in2 + (size_t)n * a.Cin * in_plane;
-            const float4 u = ld ? *reinterpret_cast<const float4*>(in2_n + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 u = ld ? IO::ld4(a.in2, img_off + off) : make_float4(0.f, 0.f, 0.f, 0.f);
             rin2[j][0] = u.x; rin2[j][1] = u.y; rin2[j][2] = u.z; rin2[j][3] = u.w;
           }
         } else {
-          rin[j][0] = ld ? in_n[off] : 0.f;
-          if constexpr (IN2) { const float* in2_n = a.in2 + (size_t)n * a.Cin * in_plane; rin2[j][0] = ld ? in2_n[off] : 0.f; }
+          rin[j][0] = ld ? IO::ld1(a.in, img_off + off) : 0.f;
+          if constexpr (IN2) rin2[j][0] = ld ? IO::ld1(a.in2, img_off + off) : 0.f;
         }
       }
       }
@@ -661,10 +674,10 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
           if (y >= a.Hout) continue;
           const size_t off = pb + (size_t)y * a.Wout + x;
           float uu[4];
-          if (vec4) { const float4 t = *reinterpret_cast<const float4*>(a.mk_u + off); uu[0] = t.x; uu[1] = t.y; uu[2] = t.z; uu[3] = t.w; }
+          if (vec4) { const float4 t = IO::ld4(a.mk_u, off); uu[0] = t.x; uu[1] = t.y; uu[2] = t.z; uu[3] = t.w; }
           else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) uu[r] = (x + r < a.Wout) ? a.mk_u[off + r] : 0.f;
+            for (int r = 0; r < 4; ++r) uu[r] = (x + r < a.Wout) ? IO::ld1(a.mk_u, off + r) : 0.f;
           }
           float v[4];
 #pragma unroll
@@ -672,10 +685,10 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
             v[r] = acc[i][j][r] * ((mk_sc[j] * uu[r] + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
             if (!vec4 && x + r >= a.Wout) v[r] = 0.f;
           }
-          if (vec4) *reinterpret_cast<float4*>(a.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+          if (vec4) IO::st4(a.out, off, make_float4(v[0], v[1], v[2], v[3]));
           else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (x + r < a.Wout) a.out[off + r] = v[r];
+            for (int r = 0; r < 4; ++r) if (x + r < a.Wout) IO::st1(a.out, off + r, v[r]);
           }
           s1 += (v[0] + v[1]) + (v[2] + v[3]);
           s2 += (v[0] * (uu[0] - mk_mu[j]) + v[1] * (uu[1] - mk_mu[j])) + (v[2] * (uu[2] - mk_mu[j]) + v[3] * (uu[3] - mk_mu[j]));
@@ -704,35 +717,35 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
           if (!up2) {
             const size_t off = pb + (size_t)y * Wo + x;
             if (vec4) {
-              const float4 t = *reinterpret_cast<const float4*>(a.mk_u + off);
+              const float4 t = IO::ld4(a.mk_u, off);
               float4 o;
               o.x = leaky((sc * t.x + sh) + acc[i][j][0], a.mk_slope); o.y = leaky((sc * t.y + sh) + acc[i][j][1], a.mk_slope);
               o.z = leaky((sc * t.z + sh) + acc[i][j][2], a.mk_slope); o.w = leaky((sc * t.w + sh) + acc[i][j][3], a.mk_slope);
-              *reinterpret_cast<float4*>(a.out + off) = o;
+              IO::st4(a.out, off, o);
             } else {
 #pragma unroll
               for (int r = 0; r < 4; ++r)
-                if (x + r < a.Wout) a.out[off + r] = leaky((sc * a.mk_u[off + r] + sh) + acc[i][j][r], a.mk_slope);
+                if (x + r < a.Wout) IO::st1(a.out, off + r, leaky((sc * IO::ld1(a.mk_u, off + r) + sh) + acc[i][j][r], a.mk_slope));
             }
           } else {
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy) {
               const size_t off = pb + (size_t)(2 * y + dy) * Wo + 2 * x;
               if (vec4) {
-                const float4 t0 = *reinterpret_cast<const float4*>(a.mk_u + off), t1 = *reinterpret_cast<const float4*>(a.mk_u + off + 4);
+                const float4 t0 = IO::ld4(a.mk_u, off), t1 = IO::ld4(a.mk_u, off + 4);
                 float4 o0, o1;
                 o0.x = leaky((sc * t0.x + sh) + acc[i][j][0], a.mk_slope); o0.y = leaky((sc * t0.y + sh) + acc[i][j][0], a.mk_slope);
                 o0.z = leaky((sc * t0.z + sh) + acc[i][j][1], a.mk_slope); o0.w = leaky((sc * t0.w + sh) + acc[i][j][1], a.mk_slope);
                 o1.x = leaky((sc * t1.x + sh) + acc[i][j][2], a.mk_slope); o1.y = leaky((sc * t1.y + sh) + acc[i][j][2], a.mk_slope);
                 o1.z = leaky((sc * t1.z + sh) + acc[i][j][3], a.mk_slope); o1.w = leaky((sc * t1.w + sh) + acc[i][j][3], a.mk_slope);
-                *reinterpret_cast<float4*>(a.out + off) = o0;
-                *reinterpret_cast<float4*>(a.out + off + 4) = o1;
+                IO::st4(a.out, off, o0);
+                IO::st4(a.out, off + 4, o1);
               } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   if (x + r < a.Wout) {
-                    a.out[off + 2 * r] = leaky((sc * a.mk_u[off + 2 * r] + sh) + acc[i][j][r], a.mk_slope);
-                    a.out[off + 2 * r + 1] = leaky((sc * a.mk_u[off + 2 * r + 1] + sh) + acc[i][j][r], a.mk_slope);
+                    IO::st1(a.out, off + 2 * r, leaky((sc * IO::ld1(a.mk_u, off + 2 * r) + sh) + acc[i][j][r], a.mk_slope));
+                    IO::st1(a.out, off + 2 * r + 1, leaky((sc * IO::ld1(a.mk_u, off + 2 * r + 1) + sh) + acc[i][j][r], a.mk_slope));
                   }
                 }
               }
@@ -754,17 +767,17 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         const int col = co0 + j * 16 + m;
         const int q = col / a.cout_real, co = col - q * a.cout_real;
         const int dy = q >> 1;
-        float* op = a.out + ((size_t)n * a.cout_real + co) * Ho * Wo;
+        const size_t op = ((size_t)n * a.cout_real + co) * Ho * Wo;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const int y = oy0 + mt_row(i);
           const int x = ox0 + mt_col(i) + xq;
           if (y >= a.Hout || x >= a.Wout) continue;
-          float* o = op + (size_t)(2 * y + dy) * Wo + 2 * x;
+          const size_t o = op + (size_t)(2 * y + dy) * Wo + 2 * x;
           // (C16 is wave-uniform: both selects compile to one of the two register sets)
           const f32x4 p0 = acc[i][j], p1 = (C16 == 1) ? acc[i][min(j + 1, NT - 1)] : acc[i][min(j + 2, NT - 1)];
-          *reinterpret_cast<float4*>(o) = make_float4(p0[0], p1[0], p0[1], p1[1]);
-          *reinterpret_cast<float4*>(o + 4) = make_float4(p0[2], p1[2], p0[3], p1[3]);
+          IO::st4(a.out, o, make_float4(p0[0], p1[0], p0[1], p1[1]));
+          IO::st4(a.out, o + 4, make_float4(p0[2], p1[2], p0[3], p1[3]));
         }
       }
     } else if (a.epi_mode == 2) {
@@ -776,7 +789,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         if (col >= 4 * a.cout_real) continue;
         const int q = col / a.cout_real, co = col - q * a.cout_real;
         const int dy = q >> 1, dx = q & 1;
-        float* op = a.out + ((size_t)n * a.cout_real + co) * Ho * Wo;
+        const size_t op = ((size_t)n * a.cout_real + co) * Ho * Wo;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const int y = oy0 + mt_row(i);
@@ -784,7 +797,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int x = ox0 + mt_col(i) + xq + r;
-            if (x < a.Wout) op[(size_t)(2 * y + dy) * Wo + 2 * x + dx] = acc[i][j][r];
+            if (x < a.Wout) IO::st1(a.out, op + (size_t)(2 * y + dy) * Wo + 2 * x + dx, acc[i][j][r]);
           }
         }
       }
@@ -794,13 +807,13 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
       for (int j = 0; j < NT; ++j) {
         const int co = co0 + j * 16 + m;
         if (co >= a.Cout) continue;
-        float* op = a.out + (((size_t)n * a.Cout + co) * a.Hout + oy0) * a.Wout + ox0 + xq;
+        const size_t op = (((size_t)n * a.Cout + co) * a.Hout + oy0) * a.Wout + ox0 + xq;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          float* o = op + (size_t)mt_row(i) * a.Wout + mt_col(i);
+          const size_t o = op + (size_t)mt_row(i) * a.Wout + mt_col(i);
           float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-          if (a.epi_mode == 1) { const float4 p = *reinterpret_cast<const float4*>(o); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
-          *reinterpret_cast<float4*>(o) = v;
+          if (a.epi_mode == 1) { const float4 p = IO::ld4(a.out, o); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+          IO::st4(a.out, o, v);
         }
       }
     } else {
@@ -808,16 +821,16 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
       for (int j = 0; j < NT; ++j) {
         const int co = co0 + j * 16 + m;
         if (co >= a.Cout) continue;
-        float* op = a.out + ((size_t)n * a.Cout + co) * a.Hout * a.Wout;
+        const size_t op = ((size_t)n * a.Cout + co) * a.Hout * a.Wout;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const int y = oy0 + mt_row(i);
           if (y >= a.Hout) continue;
           const int x = ox0 + mt_col(i) + xq;
-          float* o = op + (size_t)y * a.Wout + x;
+          const size_t o = op + (size_t)y * a.Wout + x;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (x + r < a.Wout) o[r] = (a.epi_mode == 1) ? (o[r] + acc[i][j][r]) : acc[i][j][r];
+            if (x + r < a.Wout) IO::st1(a.out, o + r, (a.epi_mode == 1) ? (IO::ld1(a.out, o + r) + acc[i][j][r]) : acc[i][j][r]);
         }
       }
     }
@@ -853,21 +866,30 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   else if (a.epi_mode == 3) conv_table_tail<NT, false>(a, smem, vb, ncb, 0.f, st_mean, st_m2);
 }
 
-template <int KS, int STRIDE, int FETCH, int NT, bool VEC, bool NARROW, bool IN2>
-int launch_conv(const ConvArgs& a, hipStream_t st) {
+template <int KS, int STRIDE, int FETCH, int NT, bool VEC, bool NARROW, bool IN2, typename AT>
+int launch_conv_t(const ConvArgs& a, hipStream_t st) {
   using G = Geo<KS, STRIDE, FETCH, VEC, NARROW, NT>;
   const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * (size_t)a.cin_pad);
   if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
   static std::once_flag attr_once;                     // one flag per instantiation (no unsynchronised mutable state in the ABI)
-  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
+  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
   const long nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb;
   // resident workgroups per CU: 512 threads = 2 waves per SIMD each -> at most 2 within 256 registers per wave; LDS 160 KiB per CU
   const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;      // every workgroup keeps one channel block: item % ncb == blockIdx % ncb
   dim3 grid((unsigned)nblocks), block(512);
-  MS_LAUNCH((conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2>), grid, block, lds_bytes, st, a);
+  MS_LAUNCH((conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2, AT>), grid, block, lds_bytes, st, a);
   return check_launch("conv_mfma");
+}
+template <int KS, int STRIDE, int FETCH, int NT, bool VEC, bool NARROW, bool IN2>
+int launch_conv(const ConvArgs& a, hipStream_t st) {
+  if (a.act_bf16) {
+    // bf16 storage is built for the vector staging paths only (rows of W % 4 == 0 elements, 16-byte aligned tensors: every layer of the networks)
+    if constexpr (VEC) return launch_conv_t<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2, ms_bf16>(a, st);
+    else { set_error("ms_conv2d_bf16: needs W %% 4 == 0 (W %% 2 for the fused-fetch variants) and 16-byte aligned tensors"); return MS_ERR_INVALID; }
+  }
+  return launch_conv_t<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2, float>(a, st);
 }
 
 // dispatch entry points implemented in the ms_conv_inst*.hip translation units

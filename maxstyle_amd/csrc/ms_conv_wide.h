@@ -46,9 +46,12 @@ static __device__ int g_cu_census[1024];
 
 // PRO: 0 none, 1 BatchNorm apply + LeakyReLU, 2 BatchNorm backward (two tensors)
 // AF ("all full"): cin_pad is a multiple of the K-chunk - no ragged channel group anywhere in the layer, the guarded MFMA loop is not instantiated
-template <int NT, int PRO, int R, bool AF>
+// AT = storage type of the activation tensors (float | ms_bf16, ms_common.h ActIO)
+template <int NT, int PRO, int R, bool AF, typename AT = float>
 __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const ConvArgs a) {
   using G = WideGeo<NT, PRO, R>;
+  using IO = ActIO<AT>;
+  constexpr int AB = IO::kBytes;
   constexpr int TH = G::TH, TW = G::TW, CK = G::CK, IH = G::IH, RS = G::RS, PS = G::PS, WS = G::WS, BUF = G::BUF;
   constexpr int NQI = G::NQI, NHI = G::NHI, NWI = G::NWI, COUT_TILE = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -112,13 +115,13 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #pragma unroll
     for (int j = 0; j < NQI; ++j) {
       const int it = tid + j * 256;
-      q_lds[j] = -1; q_rc[j] = 0; q_off[j] = 4u * (unsigned)bias; q_cf[j] = 0;
+      q_lds[j] = -1; q_rc[j] = 0; q_off[j] = (unsigned)AB * (unsigned)bias; q_cf[j] = 0;
       if (it < G::Q_ITEMS) {
         const int f = it % (TW / 4), row = it / (TW / 4);
         const int r = row % IH, c = row / IH;
         q_lds[j] = (c << 20) | (c * PS + r * RS + 4 * f + 1);
         q_rc[j] = (r << 16) | (4 * f + 16);
-        q_off[j] = 4u * (unsigned)(c * plane + (r - 1) * a.Ws + 4 * f + bias);
+        q_off[j] = (unsigned)AB * (unsigned)(c * plane + (r - 1) * a.Ws + 4 * f + bias);
         q_cf[j] = c;
         q_all |= 1u << j;
       }
@@ -126,14 +129,14 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #pragma unroll
     for (int j = 0; j < NHI; ++j) {
       const int it = tid + j * 256;
-      h_lds[j] = -1; h_rc[j] = 0; h_off[j] = 4u * (unsigned)bias; h_cf[j] = 0;
+      h_lds[j] = -1; h_rc[j] = 0; h_off[j] = (unsigned)AB * (unsigned)bias; h_cf[j] = 0;
       if (it < G::H_ITEMS) {
         const int h = it & 1, row = it >> 1;
         const int r = row % IH, c = row / IH;
         const int col_rel = h ? TW : -1;
         h_lds[j] = (c << 20) | (c * PS + r * RS + col_rel + 1);
         h_rc[j] = (r << 16) | (col_rel + 16);
-        h_off[j] = 4u * (unsigned)(c * plane + (r - 1) * a.Ws + col_rel + bias);
+        h_off[j] = (unsigned)AB * (unsigned)(c * plane + (r - 1) * a.Ws + col_rel + bias);
         h_cf[j] = c;
         h_all |= 1u << j;
       }
@@ -169,35 +172,51 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     float ca[NQI], cb_[NQI], cc[PRO == 2 ? NQI : 1], hca[NHI], hcb[NHI], hcc[PRO == 2 ? NHI : 1];   // prologue coefficients of the chunk in registers
 
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
     auto load_data = [&](__amdgpu_buffer_rsrc_t r1, __amdgpu_buffer_rsrc_t r2, int soff, mask_t qm, mask_t hm, auto edge_tag) {
       constexpr bool EDGE = decltype(edge_tag)::value;
-      const int origin = 4 * bias;                      // masked items read the (valid) tile origin and are zeroed at the LDS store
+      const int origin = AB * bias;                     // masked items read the (valid) tile origin and are zeroed at the LDS store
 #pragma unroll
       for (int j = 0; j < NQI; ++j) {
         int off = (int)q_off[j];
         if constexpr (EDGE) off = ((qm >> j) & 1u) ? off : origin;
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r1, off, soff, 0);
-        rq[j][0] = __uint_as_float(v.x); rq[j][1] = __uint_as_float(v.y); rq[j][2] = __uint_as_float(v.z); rq[j][3] = __uint_as_float(v.w);
-        if constexpr (PRO == 2) {
-          const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r2, off, soff, 0);
-          rq2[j][0] = __uint_as_float(u.x); rq2[j][1] = __uint_as_float(u.y); rq2[j][2] = __uint_as_float(u.z); rq2[j][3] = __uint_as_float(u.w);
+        if constexpr (AB == 4) {
+          const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r1, off, soff, 0);
+          rq[j][0] = __uint_as_float(v.x); rq[j][1] = __uint_as_float(v.y); rq[j][2] = __uint_as_float(v.z); rq[j][3] = __uint_as_float(v.w);
+          if constexpr (PRO == 2) {
+            const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r2, off, soff, 0);
+            rq2[j][0] = __uint_as_float(u.x); rq2[j][1] = __uint_as_float(u.y); rq2[j][2] = __uint_as_float(u.z); rq2[j][3] = __uint_as_float(u.w);
+          }
+        } else {                                      // bf16 storage: 4 values in 8 bytes, widened to fp32
+          const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r1, off, soff, 0);
+          rq[j][0] = __uint_as_float(v.x << 16); rq[j][1] = __uint_as_float(v.x & 0xFFFF0000u); rq[j][2] = __uint_as_float(v.y << 16); rq[j][3] = __uint_as_float(v.y & 0xFFFF0000u);
+          if constexpr (PRO == 2) {
+            const u32x2_t u = __builtin_amdgcn_raw_buffer_load_b64(r2, off, soff, 0);
+            rq2[j][0] = __uint_as_float(u.x << 16); rq2[j][1] = __uint_as_float(u.x & 0xFFFF0000u); rq2[j][2] = __uint_as_float(u.y << 16); rq2[j][3] = __uint_as_float(u.y & 0xFFFF0000u);
+          }
         }
       }
 #pragma unroll
       for (int j = 0; j < NHI; ++j) {
         const int off = ((hm >> j) & 1u) ? (int)h_off[j] : origin;       // the halo columns of the first / last tile of a row are outside the image
-        rh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, off, soff, 0));
-        if constexpr (PRO == 2) rh2[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r2, off, soff, 0));
+        if constexpr (AB == 4) {
+          rh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, off, soff, 0));
+          if constexpr (PRO == 2) rh2[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r2, off, soff, 0));
+        } else {
+          rh[j] = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r1, off, soff, 0) << 16);
+          if constexpr (PRO == 2) rh2[j] = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r2, off, soff, 0) << 16);
+        }
       }
     };
     auto load_chunk = [&](int n, int co0, int c0, bool load_w) {
       // buffer addressing: resource base = image n, biased back (scalar arithmetic); soffset = chunk + tile origin (scalar); voffset = the hoisted item offset:
       // `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen` - no vector address arithmetic per chunk (the host checks Cin*plane*4 < 2^31)
-      const float* img = a.in + (ptrdiff_t)n * a.Cin * plane - bias;
-      const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, 0x7FFFFFFF, 0x00020000);
-      const float* img2 = (PRO == 2) ? a.in2 + (ptrdiff_t)n * a.Cin * plane - bias : img;
-      const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img2), 0, 0x7FFFFFFF, 0x00020000);
-      const int soff = 4 * (c0 * plane + t_base);
+      const ptrdiff_t img_off = ((ptrdiff_t)n * a.Cin * plane - bias) * AB;                  // bytes
+      char* img = const_cast<char*>(reinterpret_cast<const char*>(a.in)) + img_off;
+      const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(img, 0, 0x7FFFFFFF, 0x00020000);
+      char* img2 = (PRO == 2) ? const_cast<char*>(reinterpret_cast<const char*>(a.in2)) + img_off : img;
+      const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(img2, 0, 0x7FFFFFFF, 0x00020000);
+      const int soff = AB * (c0 * plane + t_base);
       const bool ragged = (c0 + CK > a.Cin);          // last chunk of a layer whose channel count is not a multiple of CK
       l_q_ok = q_ok; l_h_ok = h_ok; l_edge = edge || ragged || (a.dbg & 2);
       mask_t qm = q_ok, hm = h_ok;
@@ -421,7 +440,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       const size_t off = (((size_t)n * a.Cout + co) * a.Hout + y) * a.Wout + xb;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        upre[UPRE ? rr : 0][r] = (4 * r < nvalid) ? *reinterpret_cast<const float4*>(a.mk_u + off + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+        upre[UPRE ? rr : 0][r] = (4 * r < nvalid) ? IO::ld4(a.mk_u, off + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto epilogue = [&](int n, int tile, int co0) __attribute__((always_inline)) {
@@ -448,7 +467,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         const size_t off = (((size_t)n * a.Cout + co) * a.Hout + y) * a.Wout + xb;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          ulate[rr][r] = (4 * r < nv) ? *reinterpret_cast<const float4*>(a.mk_u + off + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+          ulate[rr][r] = (4 * r < nv) ? IO::ld4(a.mk_u, off + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
 #pragma unroll
@@ -507,7 +526,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
             for (int r = 0; r < 4; ++r) {
               if (UPRE) uu[r] = upre[UPRE ? rr : 0][r];                   // fetched before the item's last K-chunk (prefetch_u)
               else if (NT == 1) uu[r] = ulate[rr][r];          // fetched at the top of this epilogue
-              else if (4 * r < nvalid) uu[r] = *reinterpret_cast<const float4*>(a.mk_u + off + 4 * r);
+              else if (4 * r < nvalid) uu[r] = IO::ld4(a.mk_u, off + 4 * r);
             }
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -518,7 +537,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
                 v.y = acc[rr][1][j][r] * ((mk_sc[j] * uu[r].y + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
                 v.z = acc[rr][2][j][r] * ((mk_sc[j] * uu[r].z + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
                 v.w = acc[rr][3][j][r] * ((mk_sc[j] * uu[r].w + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
-                *reinterpret_cast<float4*>(a.out + off + 4 * r) = v;
+                IO::st4(a.out, off + 4 * r, v);
                 s1 += (v.x + v.y) + (v.z + v.w);
                 s2 += (v.x * (uu[r].x - mk_mu[j]) + v.y * (uu[r].y - mk_mu[j])) + (v.z * (uu[r].z - mk_mu[j]) + v.w * (uu[r].w - mk_mu[j]));
               }
@@ -531,13 +550,13 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         for (int j = 0; j < NT; ++j) {
           const int co = co0 + j * 16 + m;
           if (co >= a.Cout) continue;
-          float* op = a.out + (((size_t)n * a.Cout + co) * a.Hout + y) * a.Wout + xb;
+          const size_t op = (((size_t)n * a.Cout + co) * a.Hout + y) * a.Wout + xb;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (4 * r < nvalid) {
               float4 v = make_float4(acc[rr][0][j][r], acc[rr][1][j][r], acc[rr][2][j][r], acc[rr][3][j][r]);
-              if (a.epi_mode == 1) { const float4 p = *reinterpret_cast<const float4*>(op + 4 * r); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
-              *reinterpret_cast<float4*>(op + 4 * r) = v;
+              if (a.epi_mode == 1) { const float4 p = IO::ld4(a.out, op + 4 * r); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+              IO::st4(a.out, op + 4 * r, v);
             }
           }
         }
@@ -549,22 +568,34 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   // scalar offset = (channel block, row, tile column), vector offset = the lane's hoisted (channel m, pixel group k) offset: the 64-bit address arithmetic
   // of the generic epilogue (~15 vector instructions per row) and its per-quad selects are gone.  Same arithmetic, same order: bit-identical results.
   const int out_plane = a.Hout * a.Wout;
-  const int ep_voff = 4 * (m * out_plane + 16 * k);
+  const int ep_voff = AB * (m * out_plane + 16 * k);
+  constexpr int QB = 4 * AB;                          // bytes of one quad (4 consecutive pixels)
   typedef unsigned eu32x4_t __attribute__((ext_vector_type(4)));
+  typedef unsigned eu32x2_t __attribute__((ext_vector_type(2)));
   auto img_rsrc = [&](const float* base, int n) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) + (ptrdiff_t)n * a.Cout * out_plane, 0, 0x7FFFFFFF, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + (ptrdiff_t)n * a.Cout * out_plane * AB, 0, 0x7FFFFFFF, 0x00020000);
   };
   auto bload4 = [&](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    const eu32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+    if constexpr (AB == 4) {
+      const eu32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+      return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+    } else {
+      const eu32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+      return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xFFFF0000u));
+    }
   };
   // STORES take the row offset in the VECTOR offset (one v_add per row), never in the scalar-offset field.  Measured on MI355X: a 16-byte buffer store with a
   // register soffset whose data registers are overwritten by the next vector instruction stores the NEW value in lanes 12-15 of every 16-lane row of the
   // second data dword (16 -> 16 @2x64x64: channels 12-15, pixel 13 of every 16 wrong).  LLVM's hazard recogniser only pads ">64-bit store data overwritten by
   // a VALU write" when soffset is NOT a register (GCNHazardRecognizer::createsVALUHazard), so with a constant soffset the compiler inserts the wait state itself.
   auto bstore4 = [&](__amdgpu_buffer_rsrc_t r, int voff, float4 v) {
-    const eu32x4_t w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, 0, 0);
+    if constexpr (AB == 4) {
+      const eu32x4_t w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+      __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, 0, 0);
+    } else {
+      const eu32x2_t w = {ms_pack_bf16x2(v.x, v.y), ms_pack_bf16x2(v.z, v.w)};
+      __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, 0, 0);
+    }
   };
   auto tile_interior = [&](int tile, int co0) {
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
@@ -572,14 +603,14 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   };
   auto row_soff = [&](int tile, int co) {               // byte offset of (channel co, this wave's row, first column of the tile) inside one image
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    return 4 * ((co * a.Hout + ty * TH + wave) * a.Wout + tx * TW);
+    return AB * ((co * a.Hout + ty * TH + wave) * a.Wout + tx * TW);
   };
   auto prefetch_u_fast = [&](int n, int tile, int co0) __attribute__((always_inline)) {
     if constexpr (!UPRE) return;
     const __amdgpu_buffer_rsrc_t ru = img_rsrc(a.mk_u, n);
     const int so = row_soff(tile, co0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) upre[0][r] = bload4(ru, ep_voff + 16 * r, so);
+    for (int r = 0; r < 4; ++r) upre[0][r] = bload4(ru, ep_voff + QB * r, so);
   };
   auto epilogue_fast = [&](int n, int tile, int co0) __attribute__((always_inline)) {
     if (a.dbg & 16) return;                              // timing-only: no epilogue at all
@@ -621,7 +652,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         const int st_voff = ep_voff + so;
         float4 uu[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) uu[r] = UPRE ? upre[0][r] : bload4(ru, ep_voff + 16 * r, so);
+        for (int r = 0; r < 4; ++r) uu[r] = UPRE ? upre[0][r] : bload4(ru, ep_voff + QB * r, so);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -630,7 +661,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           v.y = acc[0][1][j][r] * ((mk_sc[j] * uu[r].y + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
           v.z = acc[0][2][j][r] * ((mk_sc[j] * uu[r].z + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
           v.w = acc[0][3][j][r] * ((mk_sc[j] * uu[r].w + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
-          bstore4(ro, st_voff + 16 * r, v);
+          bstore4(ro, st_voff + QB * r, v);
           s1 += (v.x + v.y) + (v.z + v.w);
           s2 += (v.x * (uu[r].x - mk_mu[j]) + v.y * (uu[r].y - mk_mu[j])) + (v.z * (uu[r].z - mk_mu[j]) + v.w * (uu[r].w - mk_mu[j]));
         }
@@ -645,17 +676,17 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         const int st_voff = ep_voff + so;
         float4 prev[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) prev[r] = bload4(ro, ep_voff + 16 * r, so);
+        for (int r = 0; r < 4; ++r) prev[r] = bload4(ro, ep_voff + QB * r, so);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          bstore4(ro, st_voff + 16 * r, make_float4(acc[0][0][j][r] + prev[r].x, acc[0][1][j][r] + prev[r].y, acc[0][2][j][r] + prev[r].z, acc[0][3][j][r] + prev[r].w));
+          bstore4(ro, st_voff + QB * r, make_float4(acc[0][0][j][r] + prev[r].x, acc[0][1][j][r] + prev[r].y, acc[0][2][j][r] + prev[r].z, acc[0][3][j][r] + prev[r].w));
       }
     } else if (!(a.dbg & 4)) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int st_voff = ep_voff + row_soff(tile, co0 + 16 * j);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bstore4(ro, st_voff + 16 * r, make_float4(acc[0][0][j][r], acc[0][1][j][r], acc[0][2][j][r], acc[0][3][j][r]));
+        for (int r = 0; r < 4; ++r) bstore4(ro, st_voff + QB * r, make_float4(acc[0][0][j][r], acc[0][1][j][r], acc[0][2][j][r], acc[0][3][j][r]));
       }
     }
   };
@@ -732,22 +763,30 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   else if (a.epi_mode == 3) conv_table_tail<NT, false>(a, smem, vb, ncb, 0.f, st_mean, st_m2);
 }
 
-template <int NT, int PRO, int R, bool AF>
-int launch_conv_wide_af(ConvArgs a, hipStream_t st) {
+template <int NT, int PRO, int R, bool AF, typename AT>
+int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
   using G = WideGeo<NT, PRO, R>;
   const size_t cin_tab = (PRO != 0) ? (size_t)cdiv(a.cin_pad, G::CK) * G::CK : 0;              // coefficient table: one float4 per input channel of the padded chunks
   const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab);
   if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
   static std::once_flag attr_once;                     // one flag per instantiation; the attribute itself is immutable afterwards
-  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO, R, AF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
+  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO, R, AF, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
   a.tiles_x = cdiv(a.Wout, G::TW); a.tiles_y = cdiv(a.Hout, G::TH);
   a.ncb = cdiv(a.Cout, 16 * NT);
   const long nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb;
   const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;
-  MS_LAUNCH((conv_wide_kernel<NT, PRO, R, AF>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
+  MS_LAUNCH((conv_wide_kernel<NT, PRO, R, AF, AT>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
   return check_launch("conv_wide");
+}
+template <int NT, int PRO, int R, bool AF>
+int launch_conv_wide_af(const ConvArgs& a, hipStream_t st) {
+  if (a.act_bf16) {
+    if constexpr (R == 1) return launch_conv_wide_t<NT, PRO, R, AF, ms_bf16>(a, st);         // (the 8-row experiment variant is fp32 only)
+    else { set_error("ms_conv2d_bf16: 8-row tiles are built for fp32 storage only"); return MS_ERR_INVALID; }
+  }
+  return launch_conv_wide_t<NT, PRO, R, AF, float>(a, st);
 }
 template <int NT, int PRO, int R>
 int launch_conv_wide_r(const ConvArgs& a, hipStream_t st) {

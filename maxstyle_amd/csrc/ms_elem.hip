@@ -23,37 +23,37 @@ static ElemSplit elem_split(int planes, int HW) {
 }
 
 // out = LeakyReLU_slope(sc[c]*u + sh[c] + res)   res: none | same shape | half resolution (nearest up-sampled on the fly)
-template <int RES /*0 none,1 same,2 half-res*/>
-__global__ __launch_bounds__(kElemThreads) void bn_act_kernel(const float* __restrict__ u, const float4* __restrict__ coef, const float* __restrict__ res,
-                                                              float* __restrict__ out, int C, int H, int W, int chunk, float slope) {
+template <int RES /*0 none,1 same,2 half-res*/, typename AT = float>
+__global__ __launch_bounds__(kElemThreads) void bn_act_kernel(const void* __restrict__ u, const float4* __restrict__ coef, const void* __restrict__ res,
+                                                              void* __restrict__ out, int C, int H, int W, int chunk, float slope) {
+  using IO = ActIO<AT>;
   const int p = blockIdx.y, c = p % C;
   const float4 cf = coef[c];
   const int HW = H * W;
   const int beg = blockIdx.x * chunk, end = min(HW, beg + chunk);
-  const float* up = u + (size_t)p * HW;
-  float* op = out + (size_t)p * HW;
+  const size_t pb = (size_t)p * HW;
   const bool vec = (W % 4 == 0);
   if (vec) {
-    const float* rp = (RES == 1) ? res + (size_t)p * HW : (RES == 2 ? res + (size_t)p * (HW / 4) : nullptr);
+    const size_t rb = (RES == 1) ? pb : (RES == 2 ? (size_t)p * (HW / 4) : 0);
     for (int i = beg + threadIdx.x * 4; i < end; i += kElemThreads * 4) {
-      float4 t = *reinterpret_cast<const float4*>(up + i);
+      float4 t = IO::ld4(u, pb + i);
       float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (RES == 1) r = *reinterpret_cast<const float4*>(rp + i);
+      if (RES == 1) r = IO::ld4(res, rb + i);
       if (RES == 2) {
         const int y = i / W, x = i - y * W;            // x % 4 == 0
-        const float2 h = *reinterpret_cast<const float2*>(rp + (size_t)(y >> 1) * (W >> 1) + (x >> 1));
+        const float2 h = IO::ld2(res, rb + (size_t)(y >> 1) * (W >> 1) + (x >> 1));
         r = make_float4(h.x, h.x, h.y, h.y);
       }
       t.x = leaky(cf.x * t.x + cf.y + r.x, slope); t.y = leaky(cf.x * t.y + cf.y + r.y, slope);
       t.z = leaky(cf.x * t.z + cf.y + r.z, slope); t.w = leaky(cf.x * t.w + cf.y + r.w, slope);
-      *reinterpret_cast<float4*>(op + i) = t;
+      IO::st4(out, pb + i, t);
     }
   } else {
     for (int i = beg + threadIdx.x; i < end; i += kElemThreads) {
       float r = 0.f;
-      if (RES == 1) r = res[(size_t)p * HW + i];
-      if (RES == 2) { const int y = i / W, x = i - y * W; r = res[(size_t)p * ((H / 2) * (W / 2)) + (size_t)(y >> 1) * (W >> 1) + (x >> 1)]; }
-      op[i] = leaky(cf.x * up[i] + cf.y + r, slope);
+      if (RES == 1) r = IO::ld1(res, pb + i);
+      if (RES == 2) { const int y = i / W, x = i - y * W; r = IO::ld1(res, (size_t)p * ((H / 2) * (W / 2)) + (size_t)(y >> 1) * (W >> 1) + (x >> 1)); }
+      IO::st1(out, pb + i, leaky(cf.x * IO::ld1(u, pb + i) + cf.y + r, slope));
     }
   }
 }
@@ -65,9 +65,9 @@ __global__ __launch_bounds__(kElemThreads) void bn_act_kernel(const float* __res
 //   MASK 1: ref = sc[c]*u + sh[c]  (activation whose output was never materialised: folded into the next conv's prologue)
 typedef unsigned long long u64;
 
-template <int MASK>
-__global__ __launch_bounds__(kElemThreads) void act_bwd_reduce_kernel(const float* __restrict__ gin, const float* __restrict__ ref, const float* __restrict__ u,
-                                                                      const float4* __restrict__ coef, float* __restrict__ gout, float2* __restrict__ part,
+template <int MASK, typename AT = float>
+__global__ __launch_bounds__(kElemThreads) void act_bwd_reduce_kernel(const void* __restrict__ gin, const void* __restrict__ ref, const void* __restrict__ u,
+                                                                      const float4* __restrict__ coef, void* __restrict__ gout, float2* __restrict__ part,
                                                                       int C, int HW, int chunk, int S, int N, float slope,
                                                                       int* __restrict__ arrive, float4* __restrict__ bcoef_out, double count) {
   __shared__ float red[16];
@@ -77,27 +77,28 @@ __global__ __launch_bounds__(kElemThreads) void act_bwd_reduce_kernel(const floa
   const float4 cf = coef[c];
   const int beg = blockIdx.x * chunk, end = min(HW, beg + chunk);
   const size_t base = (size_t)p * HW;
+  using IO = ActIO<AT>;
   float s1 = 0.f, s2 = 0.f;
   if (HW % 4 == 0) {
     for (int i = beg + threadIdx.x * 4; i < end; i += kElemThreads * 4) {
-      const float4 g = *reinterpret_cast<const float4*>(gin + base + i);
-      const float4 uu = *reinterpret_cast<const float4*>(u + base + i);
+      const float4 g = IO::ld4(gin, base + i);
+      const float4 uu = IO::ld4(u, base + i);
       float4 r;
-      if (MASK == 0) r = *reinterpret_cast<const float4*>(ref + base + i);
+      if (MASK == 0) r = IO::ld4(ref, base + i);
       else r = make_float4(cf.x * uu.x + cf.y, cf.x * uu.y + cf.y, cf.x * uu.z + cf.y, cf.x * uu.w + cf.y);
       float4 o;
       o.x = g.x * (r.x > 0.f ? 1.f : slope); o.y = g.y * (r.y > 0.f ? 1.f : slope);
       o.z = g.z * (r.z > 0.f ? 1.f : slope); o.w = g.w * (r.w > 0.f ? 1.f : slope);
-      *reinterpret_cast<float4*>(gout + base + i) = o;
+      IO::st4(gout, base + i, o);
       s1 += (o.x + o.y) + (o.z + o.w);
       s2 += (o.x * (uu.x - cf.z) + o.y * (uu.y - cf.z)) + (o.z * (uu.z - cf.z) + o.w * (uu.w - cf.z));     // centred: sum g*(u - mean)
     }
   } else {
     for (int i = beg + threadIdx.x; i < end; i += kElemThreads) {
-      const float g = gin[base + i], uu = u[base + i];
-      const float r = (MASK == 0) ? ref[base + i] : (cf.x * uu + cf.y);
+      const float g = IO::ld1(gin, base + i), uu = IO::ld1(u, base + i);
+      const float r = (MASK == 0) ? IO::ld1(ref, base + i) : (cf.x * uu + cf.y);
       const float o = g * (r > 0.f ? 1.f : slope);
-      gout[base + i] = o;
+      IO::st1(gout, base + i, o);
       s1 += o; s2 += o * (uu - cf.z);
     }
   }
@@ -162,26 +163,29 @@ __global__ __launch_bounds__(64) void bn_bwd_coefs_kernel(const float2* __restri
 }
 
 // out[n,c,y,x] (+)= sum of the 2x2 block of in (gradient of nearest x2 up-sampling)
-__global__ __launch_bounds__(kElemThreads) void pool2_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int Ho, int Wo, int accumulate) {
+template <typename AT = float>
+__global__ __launch_bounds__(kElemThreads) void pool2_sum_kernel(const void* __restrict__ in, void* __restrict__ out, int planes, int Ho, int Wo, int accumulate) {
+  using IO = ActIO<AT>;
   const size_t total = (size_t)planes * Ho * Wo;
   for (size_t i = (size_t)blockIdx.x * kElemThreads + threadIdx.x; i < total; i += (size_t)gridDim.x * kElemThreads) {
     const int x = (int)(i % Wo);
     const size_t t = i / Wo;
     const int y = (int)(t % Ho);
     const size_t p = t / Ho;
-    const float* ip = in + (p * 2 * Ho + 2 * y) * (size_t)(2 * Wo) + 2 * x;
-    const float2 a = *reinterpret_cast<const float2*>(ip);
-    const float2 b = *reinterpret_cast<const float2*>(ip + 2 * Wo);
+    const size_t io = (p * 2 * Ho + 2 * y) * (size_t)(2 * Wo) + 2 * x;
+    const float2 a = IO::ld2(in, io);
+    const float2 b = IO::ld2(in, io + 2 * Wo);
     const float v = (a.x + a.y) + (b.x + b.y);
-    out[i] = accumulate ? out[i] + v : v;
+    IO::st1(out, i, accumulate ? IO::ld1(out, i) + v : v);
   }
 }
 
 // pool2_sum + accumulate + the output-activation backward of the block BELOW in one pass (ms_pool2_actbwd): the gradient w.r.t. the input of an up_type 'NN'
 // block is pool2(d_hi) + (1x1 skip data-gradient); that tensor is the gradient w.r.t. the OUTPUT of the block below, whose backward starts with
 // g = dout * lrelu'(act) and the two BatchNorm-backward sums (ms_act_bwd_reduce).  grid (S, N*C) as act_bwd_reduce; 4 low-resolution pixels per thread.
-__global__ __launch_bounds__(kElemThreads) void pool2_actbwd_kernel(const float* __restrict__ in, const float* __restrict__ add, float* __restrict__ gout,
-                                                                    const float* __restrict__ act, const float* __restrict__ u, const float4* __restrict__ coef,
+template <typename AT = float>
+__global__ __launch_bounds__(kElemThreads) void pool2_actbwd_kernel(const void* __restrict__ in, const void* __restrict__ add, void* __restrict__ gout,
+                                                                    const void* __restrict__ act, const void* __restrict__ u, const float4* __restrict__ coef,
                                                                     float2* __restrict__ part, int C, int Ho, int Wo, int chunk, int S, int N, float slope) {
   __shared__ float red[16];
   const int p = blockIdx.y, c = p % C, n = p / C;
@@ -189,19 +193,20 @@ __global__ __launch_bounds__(kElemThreads) void pool2_actbwd_kernel(const float*
   const int HWo = Ho * Wo;
   const int beg = blockIdx.x * chunk, end = min(HWo, beg + chunk);
   const size_t base = (size_t)p * HWo;
-  const float* ip = in + (size_t)p * 4 * HWo;
+  using IO = ActIO<AT>;
+  const size_t ipb = (size_t)p * 4 * HWo;
   float s1 = 0.f, s2 = 0.f;
   for (int i = beg + threadIdx.x * 4; i < end; i += kElemThreads * 4) {
     const int y = i / Wo, x = i - y * Wo;                       // Wo % 4 == 0: the quad stays in one row
-    const float* r0 = ip + (size_t)(2 * y) * (2 * Wo) + 2 * x;
-    const float4 a0 = *reinterpret_cast<const float4*>(r0), a1 = *reinterpret_cast<const float4*>(r0 + 4);
-    const float4 b0 = *reinterpret_cast<const float4*>(r0 + 2 * Wo), b1 = *reinterpret_cast<const float4*>(r0 + 2 * Wo + 4);
+    const size_t r0 = ipb + (size_t)(2 * y) * (2 * Wo) + 2 * x;
+    const float4 a0 = IO::ld4(in, r0), a1 = IO::ld4(in, r0 + 4);
+    const float4 b0 = IO::ld4(in, r0 + 2 * Wo), b1 = IO::ld4(in, r0 + 2 * Wo + 4);
     float4 v = make_float4((a0.x + a0.y) + (b0.x + b0.y), (a0.z + a0.w) + (b0.z + b0.w), (a1.x + a1.y) + (b1.x + b1.y), (a1.z + a1.w) + (b1.z + b1.w));
-    if (add != nullptr) { const float4 q = *reinterpret_cast<const float4*>(add + base + i); v.x = q.x + v.x; v.y = q.y + v.y; v.z = q.z + v.z; v.w = q.w + v.w; }
-    const float4 r = *reinterpret_cast<const float4*>(act + base + i);
-    const float4 uu = *reinterpret_cast<const float4*>(u + base + i);
+    if (add != nullptr) { const float4 q = IO::ld4(add, base + i); v.x = q.x + v.x; v.y = q.y + v.y; v.z = q.z + v.z; v.w = q.w + v.w; }
+    const float4 r = IO::ld4(act, base + i);
+    const float4 uu = IO::ld4(u, base + i);
     v.x *= (r.x > 0.f) ? 1.f : slope; v.y *= (r.y > 0.f) ? 1.f : slope; v.z *= (r.z > 0.f) ? 1.f : slope; v.w *= (r.w > 0.f) ? 1.f : slope;
-    *reinterpret_cast<float4*>(gout + base + i) = v;
+    IO::st4(gout, base + i, v);
     s1 += (v.x + v.y) + (v.z + v.w);
     s2 += (v.x * (uu.x - mean) + v.y * (uu.y - mean)) + (v.z * (uu.z - mean) + v.w * (uu.w - mean));
   }
@@ -214,20 +219,22 @@ __global__ __launch_bounds__(kElemThreads) void pool2_actbwd_kernel(const float*
 constexpr int kMaxHeadC = 64, kMaxHeadK = 4;
 
 // out[n,k,i] = sigmoid(b[k] + sum_c w[k][c]*h[n,c,i])
-__global__ __launch_bounds__(kElemThreads) void head_sigmoid_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ b,
-                                                                    float* __restrict__ out, int C, int K, int HW, int apply_sigmoid) {
+template <typename AT = float>
+__global__ __launch_bounds__(kElemThreads) void head_sigmoid_kernel(const void* __restrict__ h, const float* __restrict__ w, const float* __restrict__ b,
+                                                                    void* __restrict__ out, int C, int K, int HW, int apply_sigmoid) {
+  using IO = ActIO<AT>;
   __shared__ float sw[kMaxHeadK * kMaxHeadC + kMaxHeadK];
   for (int i = threadIdx.x; i < K * C; i += kElemThreads) sw[i] = w[i];
   if (threadIdx.x < K) sw[kMaxHeadK * kMaxHeadC + threadIdx.x] = b ? b[threadIdx.x] : 0.f;
   __syncthreads();
   const int n = blockIdx.y;
-  const float* hp = h + (size_t)n * C * HW;
+  const size_t hb = (size_t)n * C * HW;
   for (int i = (blockIdx.x * kElemThreads + threadIdx.x) * 4; i < HW; i += gridDim.x * kElemThreads * 4) {
     float4 acc[kMaxHeadK];
 #pragma unroll
     for (int k = 0; k < kMaxHeadK; ++k) { const float bb = sw[kMaxHeadK * kMaxHeadC + k]; acc[k] = make_float4(bb, bb, bb, bb); }
     for (int c = 0; c < C; ++c) {
-      const float4 v = *reinterpret_cast<const float4*>(hp + (size_t)c * HW + i);
+      const float4 v = IO::ld4(h, hb + (size_t)c * HW + i);
 #pragma unroll
       for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
         const float ww = sw[k * C + c];
@@ -238,14 +245,16 @@ __global__ __launch_bounds__(kElemThreads) void head_sigmoid_kernel(const float*
     for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
       float4 o = acc[k];
       if (apply_sigmoid) { o.x = 1.f / (1.f + expf(-o.x)); o.y = 1.f / (1.f + expf(-o.y)); o.z = 1.f / (1.f + expf(-o.z)); o.w = 1.f / (1.f + expf(-o.w)); }
-      *reinterpret_cast<float4*>(out + ((size_t)n * K + k) * HW + i) = o;
+      IO::st4(out, ((size_t)n * K + k) * HW + i, o);
     }
   }
 }
 
 // dh[n,c,i] = sum_k w[k][c] * dout[n,k,i] * out(1-out)
-__global__ __launch_bounds__(kElemThreads) void head_sigmoid_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ w,
-                                                                        float* __restrict__ dh, int C, int K, int HW, int apply_sigmoid) {
+template <typename AT = float>
+__global__ __launch_bounds__(kElemThreads) void head_sigmoid_bwd_kernel(const void* __restrict__ dout, const void* __restrict__ out, const float* __restrict__ w,
+                                                                        void* __restrict__ dh, int C, int K, int HW, int apply_sigmoid) {
+  using IO = ActIO<AT>;
   __shared__ float sw[kMaxHeadK * kMaxHeadC];
   for (int i = threadIdx.x; i < K * C; i += kElemThreads) sw[i] = w[i];
   __syncthreads();
@@ -254,9 +263,9 @@ __global__ __launch_bounds__(kElemThreads) void head_sigmoid_bwd_kernel(const fl
     float4 d[kMaxHeadK];
 #pragma unroll
     for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
-      const float4 g = *reinterpret_cast<const float4*>(dout + ((size_t)n * K + k) * HW + i);
+      const float4 g = IO::ld4(dout, ((size_t)n * K + k) * HW + i);
       if (apply_sigmoid) {
-        const float4 o = *reinterpret_cast<const float4*>(out + ((size_t)n * K + k) * HW + i);
+        const float4 o = IO::ld4(out, ((size_t)n * K + k) * HW + i);
         d[k] = make_float4(g.x * (o.x * (1.f - o.x)), g.y * (o.y * (1.f - o.y)), g.z * (o.z * (1.f - o.z)), g.w * (o.w * (1.f - o.w)));
       } else d[k] = g;
     }
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(kElemThreads) void head_sigmoid_bwd_kernel(const fl
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int k = 0; k < kMaxHeadK; ++k) if (k < K) { const float ww = sw[k * C + c]; a.x += ww * d[k].x; a.y += ww * d[k].y; a.z += ww * d[k].z; a.w += ww * d[k].w; }
-      *reinterpret_cast<float4*>(dh + ((size_t)n * C + c) * HW + i) = a;
+      IO::st4(dh, ((size_t)n * C + c) * HW + i, a);
     }
   }
 }
@@ -272,23 +281,25 @@ __global__ __launch_bounds__(kElemThreads) void head_sigmoid_bwd_kernel(const fl
 // Segmentation head with fused loss and backward: logits = W h + b; logp = log_softmax; CE = -(1/M) sum logp[label];
 // the loop maximises CE (loss = -CE, advanced_triplet...py:555), so d loss/d logit_k = -(softmax_k - 1[k==label]) / M.
 // Writes dh = sum_k w[k][c]*dlogit_k, optional logits, and per-block partial sums of logp[label].
-__global__ __launch_bounds__(kElemThreads) void head_ce_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ b,
-                                                               const int64_t* __restrict__ labels, float* __restrict__ dh, float* __restrict__ logits_out,
+template <typename AT = float>
+__global__ __launch_bounds__(kElemThreads) void head_ce_kernel(const void* __restrict__ h, const float* __restrict__ w, const float* __restrict__ b,
+                                                               const int64_t* __restrict__ labels, void* __restrict__ dh, float* __restrict__ logits_out,
                                                                double* __restrict__ part, int C, int K, int HW, float grad_scale) {
+  using IO = ActIO<AT>;
   __shared__ float sw[kMaxHeadK * kMaxHeadC + kMaxHeadK];
   __shared__ double redd[16];
   for (int i = threadIdx.x; i < K * C; i += kElemThreads) sw[i] = w[i];
   if (threadIdx.x < K) sw[kMaxHeadK * kMaxHeadC + threadIdx.x] = b ? b[threadIdx.x] : 0.f;
   __syncthreads();
   const int n = blockIdx.y;
-  const float* hp = h + (size_t)n * C * HW;
+  const size_t hb = (size_t)n * C * HW;
   double picked = 0.0;
   for (int i = blockIdx.x * kElemThreads + threadIdx.x; i < HW; i += gridDim.x * kElemThreads) {
     float z[kMaxHeadK];
 #pragma unroll
     for (int k = 0; k < kMaxHeadK; ++k) z[k] = sw[kMaxHeadK * kMaxHeadC + k];
     for (int c = 0; c < C; ++c) {
-      const float v = hp[(size_t)c * HW + i];
+      const float v = IO::ld1(h, hb + (size_t)c * HW + i);
 #pragma unroll
       for (int k = 0; k < kMaxHeadK; ++k) if (k < K) z[k] += sw[k * C + c] * v;
     }
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_kernel(const float* __re
         float a = 0.f;
 #pragma unroll
         for (int k = 0; k < kMaxHeadK; ++k) if (k < K) a += sw[k * C + c] * d[k];
-        dh[((size_t)n * C + c) * HW + i] = a;
+        IO::st1(dh, ((size_t)n * C + c) * HW + i, a);
       }
     }
   }
@@ -326,11 +337,12 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_kernel(const float* __re
 // (sum g', sum g'*(u - mean_c)) are written per block in the partial layout of ms_act_bwd_reduce: bn_part[c][n*gridDim.x + blockIdx.x].
 constexpr int kHeadFuseC = 16;
 // VEC = 4: every thread owns 4 consecutive pixels (16-byte loads / stores of every channel plane; needs H*W % 4 == 0 and 16-byte aligned tensors)
-template <int VEC>
-__global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ b,
-                                                                      const int64_t* __restrict__ labels, float* __restrict__ dh, double* __restrict__ part,
+template <int VEC, typename AT = float>
+__global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const void* __restrict__ h, const float* __restrict__ w, const float* __restrict__ b,
+                                                                      const int64_t* __restrict__ labels, void* __restrict__ dh, double* __restrict__ part,
                                                                       int C, int K, int HW, float grad_scale,
-                                                                      const float* __restrict__ bn_u, const float4* __restrict__ bn_coef, float2* __restrict__ bn_part, float slope) {
+                                                                      const void* __restrict__ bn_u, const float4* __restrict__ bn_coef, float2* __restrict__ bn_part, float slope) {
+  using IO = ActIO<AT>;
   __shared__ float sw[kMaxHeadK * kHeadFuseC + kMaxHeadK];
   __shared__ float smean[kHeadFuseC];
   __shared__ double redd[16];
@@ -339,8 +351,7 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const floa
   if (threadIdx.x < C) smean[threadIdx.x] = bn_coef[threadIdx.x].z;
   __syncthreads();
   const int n = blockIdx.y;
-  const float* hp = h + (size_t)n * C * HW;
-  const float* up = bn_u + (size_t)n * C * HW;
+  const size_t hb = (size_t)n * C * HW;
   double picked = 0.0;
   float b1[kHeadFuseC], b2[kHeadFuseC];
 #pragma unroll
@@ -354,8 +365,8 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const floa
 #pragma unroll
     for (int c = 0; c < kHeadFuseC; ++c) {
       if (c < C) {
-        if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(hp + (size_t)c * HW + i); hv[c][0] = t.x; hv[c][1 % VEC] = t.y; hv[c][2 % VEC] = t.z; hv[c][3 % VEC] = t.w; }
-        else hv[c][0] = hp[(size_t)c * HW + i];
+        if (VEC == 4) { const float4 t = IO::ld4(h, hb + (size_t)c * HW + i); hv[c][0] = t.x; hv[c][1 % VEC] = t.y; hv[c][2 % VEC] = t.z; hv[c][3 % VEC] = t.w; }
+        else hv[c][0] = IO::ld1(h, hb + (size_t)c * HW + i);
 #pragma unroll
         for (int k = 0; k < kMaxHeadK; ++k)
           if (k < K) {
@@ -386,8 +397,8 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const floa
     for (int c = 0; c < kHeadFuseC; ++c) {
       if (c < C) {
         float a[VEC], uu[VEC];
-        if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(up + (size_t)c * HW + i); uu[0] = t.x; uu[1 % VEC] = t.y; uu[2 % VEC] = t.z; uu[3 % VEC] = t.w; }
-        else uu[0] = up[(size_t)c * HW + i];
+        if (VEC == 4) { const float4 t = IO::ld4(bn_u, hb + (size_t)c * HW + i); uu[0] = t.x; uu[1 % VEC] = t.y; uu[2 % VEC] = t.z; uu[3 % VEC] = t.w; }
+        else uu[0] = IO::ld1(bn_u, hb + (size_t)c * HW + i);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           float t = 0.f;
@@ -398,8 +409,8 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const floa
           b1[c] += t;
           b2[c] += t * (uu[e] - smean[c]);
         }
-        if (VEC == 4) *reinterpret_cast<float4*>(dh + ((size_t)n * C + c) * HW + i) = make_float4(a[0], a[1 % VEC], a[2 % VEC], a[3 % VEC]);
-        else dh[((size_t)n * C + c) * HW + i] = a[0];
+        if (VEC == 4) IO::st4(dh, ((size_t)n * C + c) * HW + i, make_float4(a[0], a[1 % VEC], a[2 % VEC], a[3 % VEC]));
+        else IO::st1(dh, ((size_t)n * C + c) * HW + i, a[0]);
       }
     }
   }
@@ -488,7 +499,8 @@ extern "C" int ms_confusion(const float* logits, const int64_t* labels, unsigned
   return check_launch("confusion");
 }
 
-extern "C" int ms_bn_act(const float* u, const float* coef4, const float* res, int res_mode, float* out, int N, int C, int H, int W, float slope, void* stream) {
+template <typename AT>
+static int bn_act_impl(const void* u, const float* coef4, const void* res, int res_mode, void* out, int N, int C, int H, int W, float slope, void* stream) {
   if (N < 1 || C < 1 || H < 1 || W < 1 || res_mode < 0 || res_mode > 2) { set_error("ms_bn_act: invalid argument"); return MS_ERR_INVALID; }
   if (!(slope >= 0.f && slope <= 1.f)) { set_error("ms_bn_act: activation slope outside [0, 1]"); return MS_ERR_INVALID; }
   if (res_mode != 0 && res == nullptr) { set_error("ms_bn_act: residual missing"); return MS_ERR_INVALID; }
@@ -498,24 +510,40 @@ extern "C" int ms_bn_act(const float* u, const float* coef4, const float* res, i
   dim3 grid(sp.S, N * C), block(kElemThreads);
   hipStream_t st = (hipStream_t)stream;
   const float4* cf = (const float4*)coef4;
-  if (res_mode == 0) MS_LAUNCH(bn_act_kernel<0>, grid, block, 0, st, u, cf, res, out, C, H, W, sp.chunk, slope);
-  else if (res_mode == 1) MS_LAUNCH(bn_act_kernel<1>, grid, block, 0, st, u, cf, res, out, C, H, W, sp.chunk, slope);
-  else MS_LAUNCH(bn_act_kernel<2>, grid, block, 0, st, u, cf, res, out, C, H, W, sp.chunk, slope);
+  if (res_mode == 0) MS_LAUNCH((bn_act_kernel<0, AT>), grid, block, 0, st, u, cf, res, out, C, H, W, sp.chunk, slope);
+  else if (res_mode == 1) MS_LAUNCH((bn_act_kernel<1, AT>), grid, block, 0, st, u, cf, res, out, C, H, W, sp.chunk, slope);
+  else MS_LAUNCH((bn_act_kernel<2, AT>), grid, block, 0, st, u, cf, res, out, C, H, W, sp.chunk, slope);
   return check_launch("bn_act");
+}
+extern "C" int ms_bn_act(const float* u, const float* coef4, const float* res, int res_mode, float* out, int N, int C, int H, int W, float slope, void* stream) {
+  return bn_act_impl<float>(u, coef4, res, res_mode, out, N, C, H, W, slope, stream);
+}
+// `_bf16` twins of the streaming kernels: activation tensors (u, res, out, gradients, h, ...) are bf16 bit patterns, everything else as in the fp32 entry point
+extern "C" int ms_bn_act_bf16(const uint16_t* u, const float* coef4, const uint16_t* res, int res_mode, uint16_t* out, int N, int C, int H, int W, float slope, void* stream) {
+  return bn_act_impl<ms_bf16>(u, coef4, res, res_mode, out, N, C, H, W, slope, stream);
 }
 
 extern "C" int ms_act_bwd_parts(int N, int C, int HW) { return N * elem_split(N * C, HW).S; }
 
-extern "C" int ms_act_bwd_reduce(const float* gin, const float* ref, const float* u, const float* coef4, float* gout, float* part2,
-                                 int N, int C, int HW, float slope, void* stream) {
+template <typename AT>
+static int act_bwd_reduce_impl(const void* gin, const void* ref, const void* u, const float* coef4, void* gout, float* part2,
+                               int N, int C, int HW, float slope, void* stream) {
   if (N < 1 || C < 1 || HW < 1) { set_error("ms_act_bwd_reduce: invalid shape"); return MS_ERR_INVALID; }
   if ((long)N * C > 65535) { set_error("ms_act_bwd_reduce: too many planes"); return MS_ERR_INVALID; }
   const ElemSplit sp = elem_split(N * C, HW);
   dim3 grid(sp.S, N * C), block(kElemThreads);
   hipStream_t st = (hipStream_t)stream;
-  if (ref != nullptr) MS_LAUNCH(act_bwd_reduce_kernel<0>, grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope, (int*)nullptr, (float4*)nullptr, 0.0);
-  else MS_LAUNCH(act_bwd_reduce_kernel<1>, grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope, (int*)nullptr, (float4*)nullptr, 0.0);
+  if (ref != nullptr) MS_LAUNCH((act_bwd_reduce_kernel<0, AT>), grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope, (int*)nullptr, (float4*)nullptr, 0.0);
+  else MS_LAUNCH((act_bwd_reduce_kernel<1, AT>), grid, block, 0, st, gin, ref, u, (const float4*)coef4, gout, (float2*)part2, C, HW, sp.chunk, sp.S, N, slope, (int*)nullptr, (float4*)nullptr, 0.0);
   return check_launch("act_bwd_reduce");
+}
+extern "C" int ms_act_bwd_reduce(const float* gin, const float* ref, const float* u, const float* coef4, float* gout, float* part2,
+                                 int N, int C, int HW, float slope, void* stream) {
+  return act_bwd_reduce_impl<float>(gin, ref, u, coef4, gout, part2, N, C, HW, slope, stream);
+}
+extern "C" int ms_act_bwd_reduce_bf16(const uint16_t* gin, const uint16_t* ref, const uint16_t* u, const float* coef4, uint16_t* gout, float* part2,
+                                      int N, int C, int HW, float slope, void* stream) {
+  return act_bwd_reduce_impl<ms_bf16>(gin, ref, u, coef4, gout, part2, N, C, HW, slope, stream);
 }
 
 extern "C" int ms_act_bwd_bn(const float* gin, const float* ref, const float* u, const float* coef4, float* gout, float* part2, int* arrive,
@@ -538,26 +566,38 @@ extern "C" int ms_bn_bwd_coefs(const float* part2, int nparts, const float* coef
   return check_launch("bn_bwd_coefs");
 }
 
-extern "C" int ms_pool2_sum(const float* in, float* out, int planes, int Ho, int Wo, int accumulate, void* stream) {
+template <typename AT>
+static int pool2_sum_impl(const void* in, void* out, int planes, int Ho, int Wo, int accumulate, void* stream) {
   if (planes < 1 || Ho < 1 || Wo < 1) { set_error("ms_pool2_sum: invalid shape"); return MS_ERR_INVALID; }
   const size_t total = (size_t)planes * Ho * Wo;
   const int blocks = (int)std::min<size_t>((total + kElemThreads - 1) / kElemThreads, 4096);
-  MS_LAUNCH(pool2_sum_kernel, dim3(blocks), dim3(kElemThreads), 0, (hipStream_t)stream, in, out, planes, Ho, Wo, accumulate);
+  MS_LAUNCH((pool2_sum_kernel<AT>), dim3(blocks), dim3(kElemThreads), 0, (hipStream_t)stream, in, out, planes, Ho, Wo, accumulate);
   return check_launch("pool2_sum");
 }
+extern "C" int ms_pool2_sum(const float* in, float* out, int planes, int Ho, int Wo, int accumulate, void* stream) { return pool2_sum_impl<float>(in, out, planes, Ho, Wo, accumulate, stream); }
+extern "C" int ms_pool2_sum_bf16(const uint16_t* in, uint16_t* out, int planes, int Ho, int Wo, int accumulate, void* stream) { return pool2_sum_impl<ms_bf16>(in, out, planes, Ho, Wo, accumulate, stream); }
 
 // out = (pool2_sum(in) [+ add]) * lrelu'(act), part2 = the partial sums of ms_act_bwd_reduce ([C][ms_act_bwd_parts(N,C,Ho*Wo)][2]).  in [N,C,2Ho,2Wo]; add (may be NULL
 // or == out), out, act, u [N,C,Ho,Wo]; Wo % 4 == 0, 16-byte aligned.
-extern "C" int ms_pool2_actbwd(const float* in, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
-                               int N, int C, int Ho, int Wo, float slope, void* stream) {
+template <typename AT>
+static int pool2_actbwd_impl(const void* in, const void* add, void* out, const void* act, const void* u, const float* coef4, float* part2,
+                             int N, int C, int Ho, int Wo, float slope, void* stream) {
   if (N < 1 || C < 1 || Ho < 1 || Wo < 4 || Wo % 4 != 0) { set_error("ms_pool2_actbwd: invalid shape (Wo %% 4 == 0)"); return MS_ERR_INVALID; }
   if ((long)N * C > 65535) { set_error("ms_pool2_actbwd: too many planes"); return MS_ERR_INVALID; }
   if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(u) |
         reinterpret_cast<uintptr_t>(coef4) | reinterpret_cast<uintptr_t>(add)) & 15u) != 0) { set_error("ms_pool2_actbwd: tensors must be 16-byte aligned"); return MS_ERR_ALIGN; }
   const ElemSplit sp = elem_split(N * C, Ho * Wo);
-  MS_LAUNCH(pool2_actbwd_kernel, dim3(sp.S, N * C), dim3(kElemThreads), 0, (hipStream_t)stream, in, add, out, act, u, (const float4*)coef4, (float2*)part2,
+  MS_LAUNCH((pool2_actbwd_kernel<AT>), dim3(sp.S, N * C), dim3(kElemThreads), 0, (hipStream_t)stream, in, add, out, act, u, (const float4*)coef4, (float2*)part2,
             C, Ho, Wo, sp.chunk, sp.S, N, slope);
   return check_launch("pool2_actbwd");
+}
+extern "C" int ms_pool2_actbwd(const float* in, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
+                               int N, int C, int Ho, int Wo, float slope, void* stream) {
+  return pool2_actbwd_impl<float>(in, add, out, act, u, coef4, part2, N, C, Ho, Wo, slope, stream);
+}
+extern "C" int ms_pool2_actbwd_bf16(const uint16_t* in, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
+                                    int N, int C, int Ho, int Wo, float slope, void* stream) {
+  return pool2_actbwd_impl<ms_bf16>(in, add, out, act, u, coef4, part2, N, C, Ho, Wo, slope, stream);
 }
 
 static int head_check(int N, int C, int K, int HW, const char* who) {
@@ -566,36 +606,60 @@ static int head_check(int N, int C, int K, int HW, const char* who) {
   return MS_OK;
 }
 
-extern "C" int ms_head_fwd(const float* h, const float* w, const float* b, float* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream) {
+template <typename AT>
+static int head_fwd_impl(const void* h, const float* w, const float* b, void* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream) {
   if (int e = head_check(N, C, K, HW, "ms_head_fwd")) return e;
   if (HW % 4 != 0) { set_error("ms_head_fwd: H*W must be a multiple of 4"); return MS_ERR_INVALID; }
   dim3 grid(std::min(cdiv(HW, kElemThreads * 4), 256), N);
-  MS_LAUNCH(head_sigmoid_kernel, grid, dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, out, C, K, HW, apply_sigmoid);
+  MS_LAUNCH((head_sigmoid_kernel<AT>), grid, dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, out, C, K, HW, apply_sigmoid);
   return check_launch("head_fwd");
 }
+extern "C" int ms_head_fwd(const float* h, const float* w, const float* b, float* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream) {
+  return head_fwd_impl<float>(h, w, b, out, N, C, K, HW, apply_sigmoid, stream);
+}
+extern "C" int ms_head_fwd_bf16(const uint16_t* h, const float* w, const float* b, uint16_t* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream) {
+  return head_fwd_impl<ms_bf16>(h, w, b, out, N, C, K, HW, apply_sigmoid, stream);
+}
 
-extern "C" int ms_head_bwd(const float* dout, const float* out, const float* w, float* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream) {
+template <typename AT>
+static int head_bwd_impl(const void* dout, const void* out, const float* w, void* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream) {
   if (int e = head_check(N, C, K, HW, "ms_head_bwd")) return e;
   if (HW % 4 != 0) { set_error("ms_head_bwd: H*W must be a multiple of 4"); return MS_ERR_INVALID; }
   dim3 grid(std::min(cdiv(HW, kElemThreads * 4), 256), N);
-  MS_LAUNCH(head_sigmoid_bwd_kernel, grid, dim3(kElemThreads), 0, (hipStream_t)stream, dout, out, w, dh, C, K, HW, apply_sigmoid);
+  MS_LAUNCH((head_sigmoid_bwd_kernel<AT>), grid, dim3(kElemThreads), 0, (hipStream_t)stream, dout, out, w, dh, C, K, HW, apply_sigmoid);
   return check_launch("head_bwd");
+}
+extern "C" int ms_head_bwd(const float* dout, const float* out, const float* w, float* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream) {
+  return head_bwd_impl<float>(dout, out, w, dh, N, C, K, HW, apply_sigmoid, stream);
+}
+extern "C" int ms_head_bwd_bf16(const uint16_t* dout, const uint16_t* out, const float* w, uint16_t* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream) {
+  return head_bwd_impl<ms_bf16>(dout, out, w, dh, N, C, K, HW, apply_sigmoid, stream);
 }
 
 extern "C" size_t ms_head_ce_ws_bytes(int N, int HW) { return (size_t)N * std::min(cdiv(HW, kElemThreads), 256) * sizeof(double) + 64; }
 
-extern "C" int ms_head_ce(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* logits, float* loss_out,
-                          const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream) {
+template <typename AT>
+static int head_ce_impl(const void* h, const float* w, const float* b, const int64_t* labels, void* dh, float* logits, float* loss_out,
+                        const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream) {
   if (int e = head_check(N, C, K, HW, "ms_head_ce")) return e;
   if (ws == nullptr || ws_bytes < ms_head_ce_ws_bytes(N, HW)) { set_error("ms_head_ce: workspace too small"); return MS_ERR_WORKSPACE; }
   const int gx = std::min(cdiv(HW, kElemThreads), 256);
   dim3 grid(gx, N);
   const double M = (double)N * HW;
   // loss = loss_sign * CE, CE = -(1/M) sum logp[label];  d loss / d logit_k = loss_sign * (p_k - 1[k==label]) / M
-  MS_LAUNCH(head_ce_kernel, grid, dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, logits, (double*)ws, C, K, HW, (float)(loss_sign / M));
+  MS_LAUNCH((head_ce_kernel<AT>), grid, dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, logits, (double*)ws, C, K, HW, (float)(loss_sign / M));
   if (int e = check_launch("head_ce")) return e;
   MS_LAUNCH(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, gx * N, -(double)loss_sign / M, loss_out, loss_slot_dev);
   return check_launch("ce_finalize");
+}
+extern "C" int ms_head_ce(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* logits, float* loss_out,
+                          const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream) {
+  return head_ce_impl<float>(h, w, b, labels, dh, logits, loss_out, loss_slot_dev, N, C, K, HW, loss_sign, ws, ws_bytes, stream);
+}
+// (logits stay fp32: they are an output for the caller, not an activation of the loop)
+extern "C" int ms_head_ce_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* logits, float* loss_out,
+                               const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream) {
+  return head_ce_impl<ms_bf16>(h, w, b, labels, dh, logits, loss_out, loss_slot_dev, N, C, K, HW, loss_sign, ws, ws_bytes, stream);
 }
 
 static int head_fuse_gx(int HW) { return std::max(1, std::min(cdiv(HW, kElemThreads * 4), 256)); }      // 4 pixels per thread: 16-byte accesses, the per-block reduction amortised
@@ -603,9 +667,10 @@ extern "C" int ms_head_ce_actbwd_parts(int N, int C, int HW) { return (C >= 1 &&
 
 // ms_head_ce (loss + dh) whose dh is already masked by the activation that produced h, with the BatchNorm-backward sums of that block
 // (h = lrelu(bn(bn_u) + skip): encoder_decoder.py:344-346): replaces ms_head_ce + ms_act_bwd_reduce.  C <= 16 (ms_head_ce_actbwd_parts returns 0 otherwise).
-extern "C" int ms_head_ce_actbwd(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* loss_out, const int* loss_slot_dev,
-                                 int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,
-                                 const float* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream) {
+template <typename AT>
+static int head_ce_actbwd_impl(const void* h, const float* w, const float* b, const int64_t* labels, void* dh, float* loss_out, const int* loss_slot_dev,
+                               int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,
+                               const void* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream) {
   if (int e = head_check(N, C, K, HW, "ms_head_ce_actbwd")) return e;
   if (C > kHeadFuseC || dh == nullptr || bn_u == nullptr || bn_coef4 == nullptr || bn_part == nullptr || !aligned16(bn_coef4)) {
     set_error("ms_head_ce_actbwd: C <= %d, dh, bn_u, bn_coef4 (16-byte aligned) and bn_part are required", kHeadFuseC); return MS_ERR_INVALID;
@@ -614,11 +679,21 @@ extern "C" int ms_head_ce_actbwd(const float* h, const float* w, const float* b,
   const int gx = head_fuse_gx(HW);
   const double M = (double)N * HW;
   const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(bn_u)) & 15u) == 0;
-  if (vec) MS_LAUNCH(head_ce_actbwd_kernel<4>, dim3(gx, N), dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, (double*)ws, C, K, HW, (float)(loss_sign / M),
+  if (vec) MS_LAUNCH((head_ce_actbwd_kernel<4, AT>), dim3(gx, N), dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, (double*)ws, C, K, HW, (float)(loss_sign / M),
                      bn_u, (const float4*)bn_coef4, (float2*)bn_part, act_slope);
-  else MS_LAUNCH(head_ce_actbwd_kernel<1>, dim3(gx, N), dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, (double*)ws, C, K, HW, (float)(loss_sign / M),
+  else MS_LAUNCH((head_ce_actbwd_kernel<1, AT>), dim3(gx, N), dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, (double*)ws, C, K, HW, (float)(loss_sign / M),
                  bn_u, (const float4*)bn_coef4, (float2*)bn_part, act_slope);
   if (int e = check_launch("head_ce_actbwd")) return e;
   MS_LAUNCH(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, gx * N, -(double)loss_sign / M, loss_out, loss_slot_dev);
   return check_launch("ce_finalize");
+}
+extern "C" int ms_head_ce_actbwd(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* loss_out, const int* loss_slot_dev,
+                                 int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,
+                                 const float* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream) {
+  return head_ce_actbwd_impl<float>(h, w, b, labels, dh, loss_out, loss_slot_dev, N, C, K, HW, loss_sign, ws, ws_bytes, bn_u, bn_coef4, bn_part, act_slope, stream);
+}
+extern "C" int ms_head_ce_actbwd_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* loss_out, const int* loss_slot_dev,
+                                      int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,
+                                      const uint16_t* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream) {
+  return head_ce_actbwd_impl<ms_bf16>(h, w, b, labels, dh, loss_out, loss_slot_dev, N, C, K, HW, loss_sign, ws, ws_bytes, bn_u, bn_coef4, bn_part, act_slope, stream);
 }
