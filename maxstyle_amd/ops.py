@@ -46,6 +46,18 @@ def _need_cuda_act(t):
     return t.dtype == torch.bfloat16
 
 
+def _acts(*ts):
+    """Activation tensors of one call: all fp32 or all bf16 (the conv stack's `_bf16` entry points). Returns True for bf16."""
+    flags = {_need_cuda_act(t) for t in ts if t is not None and not isinstance(t, int)}
+    if len(flags) > 1:
+        raise TypeError("activation tensors of one call must share a storage type (all fp32 or all bf16)")
+    return bool(flags and flags.pop())
+
+
+def _fn(name, bf16):
+    return getattr(lib, name + "_bf16") if bf16 else getattr(lib, name)
+
+
 def workspace(nbytes, device):
     """A cached scratch buffer per (device, stream); grown geometrically. Kernels on one stream are ordered, so reuse is safe."""
     key = (device, _stream())
@@ -184,27 +196,29 @@ def conv_out_hw(Hs, Ws, ks, stride, fetch):
 def conv2d(x, wp, bias, Cout, ks, stride=1, fetch=FETCH_NORMAL, pro_mode=0, pro_a=None, pro_b=None, pro_c=None, pro_nstride=0,
            pro_cstride=1, slope=1.0, epi_mode=0, out=None, stats=None, in2=None):
     """ms_conv2d wrapper. Returns out ([N,Cout,Hout,Wout], or [N,Cout,2H,2W] for the ConvTranspose epilogue)."""
-    _need_cuda_f32(x, wp, bias, pro_a, pro_b, pro_c, out, stats, in2)
+    _need_cuda_f32(wp, bias, pro_a, pro_b, pro_c, stats)
+    bf = _acts(x, in2, out)
     N, Cin, Hs, Ws = x.shape
     Ho, Wo = conv_out_hw(Hs, Ws, ks, stride, fetch)
     if out is None:
         shape = (N, Cout, 2 * Ho, 2 * Wo) if epi_mode == 2 else (N, Cout, Ho, Wo)
         if epi_mode == 1:
             raise ValueError("accumulate epilogue needs an existing `out`")
-        out = torch.empty(shape, device=x.device, dtype=torch.float32)
-    check(lib.ms_conv2d(x.data_ptr(), _ptr(in2), out.data_ptr(), wp.data_ptr(), _ptr(bias), N, Cin, Hs, Ws, Cout, ks, stride, fetch,
+        out = torch.empty(shape, device=x.device, dtype=x.dtype)
+    check(_fn("ms_conv2d", bf)(x.data_ptr(), _ptr(in2), out.data_ptr(), wp.data_ptr(), _ptr(bias), N, Cin, Hs, Ws, Cout, ks, stride, fetch,
                         pro_mode, _ptr(pro_a), _ptr(pro_b), _ptr(pro_c), pro_nstride, pro_cstride, slope, epi_mode, _ptr(stats), _stream()), "ms_conv2d")
     return out
 
 
 def conv2d_actbwd(x, wp, Cout, ks, u, coef4, act_slope, pro_mode=0, pro_a=None, pro_b=None, pro_c=None, pro_cstride=1, slope=1.0, in2=None, stride=1):
     """ms_conv2d_actbwd wrapper: conv (no bias) -> * LeakyReLU'(coef4.scale*u + coef4.shift) -> (out, tab); tab feeds bn_bwd_coefs(tab, 0, ...)."""
-    _need_cuda_f32(x, wp, u, coef4, pro_a, pro_b, pro_c, in2)
+    _need_cuda_f32(wp, coef4, pro_a, pro_b, pro_c)
+    bf = _acts(x, u, in2)
     N, Cin, Hs, Ws = x.shape
     Ho, Wo = conv_out_hw(Hs, Ws, ks, stride, FETCH_NORMAL)
-    out = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=torch.float32)
+    out = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=x.dtype)
     tab = torch.full((lib.ms_conv_actbwd_tab_bytes(Cout) // 4,), float("nan"), device=x.device, dtype=torch.float32)
-    check(lib.ms_conv2d_actbwd(x.data_ptr(), _ptr(in2), out.data_ptr(), wp.data_ptr(), N, Cin, Hs, Ws, Cout, ks, stride, FETCH_NORMAL,
+    check(_fn("ms_conv2d_actbwd", bf)(x.data_ptr(), _ptr(in2), out.data_ptr(), wp.data_ptr(), N, Cin, Hs, Ws, Cout, ks, stride, FETCH_NORMAL,
                                pro_mode, _ptr(pro_a), _ptr(pro_b), _ptr(pro_c), 0, pro_cstride, slope, u.data_ptr(), coef4.data_ptr(), act_slope,
                                tab.data_ptr(), _stream()), "ms_conv2d_actbwd")
     return out, tab
@@ -252,20 +266,22 @@ def bn_finalize(stats, nparts, gamma, beta, eps=1e-5, out=None):
 
 
 def bn_act(u, coef4, res=None, res_mode=0, slope=0.2, out=None):
-    _need_cuda_f32(u, coef4, res, out)
+    _need_cuda_f32(coef4)
+    bf = _acts(u, res, out)
     N, C, H, W = u.shape
     out = torch.empty_like(u) if out is None else out
-    check(lib.ms_bn_act(u.data_ptr(), coef4.data_ptr(), _ptr(res), res_mode, out.data_ptr(), N, C, H, W, slope, _stream()), "ms_bn_act")
+    check(_fn("ms_bn_act", bf)(u.data_ptr(), coef4.data_ptr(), _ptr(res), res_mode, out.data_ptr(), N, C, H, W, slope, _stream()), "ms_bn_act")
     return out
 
 
 def act_bwd_reduce(gin, ref, u, coef4, slope, gout=None, part=None):
-    _need_cuda_f32(gin, ref, u, coef4, gout, part)
+    _need_cuda_f32(coef4, part)
+    bf = _acts(gin, ref, u, gout)
     N, C, H, W = u.shape
     nparts = lib.ms_act_bwd_parts(N, C, H * W)
     gout = torch.empty_like(gin) if gout is None else gout
     part = torch.empty(C, nparts, 2, device=u.device, dtype=torch.float32) if part is None else part
-    check(lib.ms_act_bwd_reduce(gin.data_ptr(), _ptr(ref), u.data_ptr(), coef4.data_ptr(), gout.data_ptr(), part.data_ptr(), N, C, H * W, slope, _stream()),
+    check(_fn("ms_act_bwd_reduce", bf)(gin.data_ptr(), _ptr(ref), u.data_ptr(), coef4.data_ptr(), gout.data_ptr(), part.data_ptr(), N, C, H * W, slope, _stream()),
           "ms_act_bwd_reduce")
     return gout, part, nparts
 
@@ -278,34 +294,37 @@ def bn_bwd_coefs(part, nparts, coef4, count, out=None):
 
 
 def pool2_sum(x, out=None, accumulate=False):
-    _need_cuda_f32(x, out)
+    bf = _acts(x, out)
     N, C, H, W = x.shape
     if out is None:
-        out = torch.empty(N, C, H // 2, W // 2, device=x.device, dtype=torch.float32)
-    check(lib.ms_pool2_sum(x.data_ptr(), out.data_ptr(), N * C, H // 2, W // 2, 1 if accumulate else 0, _stream()), "ms_pool2_sum")
+        out = torch.empty(N, C, H // 2, W // 2, device=x.device, dtype=x.dtype)
+    check(_fn("ms_pool2_sum", bf)(x.data_ptr(), out.data_ptr(), N * C, H // 2, W // 2, 1 if accumulate else 0, _stream()), "ms_pool2_sum")
     return out
 
 
 def head_fwd(h, w, b, apply_sigmoid, out=None):
-    _need_cuda_f32(h, w, b, out)
+    _need_cuda_f32(w, b)
+    bf = _acts(h, out)
     N, C, H, W = h.shape
     K = w.shape[0]
-    out = torch.empty(N, K, H, W, device=h.device, dtype=torch.float32) if out is None else out
-    check(lib.ms_head_fwd(h.data_ptr(), w.data_ptr(), _ptr(b), out.data_ptr(), N, C, K, H * W, 1 if apply_sigmoid else 0, _stream()), "ms_head_fwd")
+    out = torch.empty(N, K, H, W, device=h.device, dtype=h.dtype) if out is None else out
+    check(_fn("ms_head_fwd", bf)(h.data_ptr(), w.data_ptr(), _ptr(b), out.data_ptr(), N, C, K, H * W, 1 if apply_sigmoid else 0, _stream()), "ms_head_fwd")
     return out
 
 
 def head_bwd(dout, out, w, C, apply_sigmoid, dh=None):
-    _need_cuda_f32(dout, out, w, dh)
+    _need_cuda_f32(w)
+    bf = _acts(dout, out, dh)
     N, K, H, W = dout.shape
-    dh = torch.empty(N, C, H, W, device=dout.device, dtype=torch.float32) if dh is None else dh
-    check(lib.ms_head_bwd(dout.data_ptr(), _ptr(out), w.data_ptr(), dh.data_ptr(), N, C, K, H * W, 1 if apply_sigmoid else 0, _stream()), "ms_head_bwd")
+    dh = torch.empty(N, C, H, W, device=dout.device, dtype=dout.dtype) if dh is None else dh
+    check(_fn("ms_head_bwd", bf)(dout.data_ptr(), _ptr(out), w.data_ptr(), dh.data_ptr(), N, C, K, H * W, 1 if apply_sigmoid else 0, _stream()), "ms_head_bwd")
     return dh
 
 
 def head_ce(h, w, b, labels, loss_sign=1.0, need_dh=True, need_logits=False, dh=None, logits=None, loss_out=None, loss_slot_dev=None):
     """loss = loss_sign * cross_entropy_2D(w h + b, labels); returns (loss[1] device tensor, dh, logits)."""
-    _need_cuda_f32(h, w, b, dh, logits, loss_out)
+    _need_cuda_f32(w, b, logits, loss_out)
+    bf = _acts(h, dh)
     if labels.dtype != torch.int64 or not labels.is_cuda or not labels.is_contiguous():
         raise TypeError("labels must be a contiguous CUDA int64 tensor [N,H,W]")
     N, C, H, W = h.shape
@@ -319,7 +338,7 @@ def head_ce(h, w, b, labels, loss_sign=1.0, need_dh=True, need_logits=False, dh=
         loss_out = torch.empty(1, device=dev, dtype=torch.float32)
     nbytes = lib.ms_head_ce_ws_bytes(N, H * W)
     ws = workspace(nbytes, dev)
-    check(lib.ms_head_ce(h.data_ptr(), w.data_ptr(), _ptr(b), labels.data_ptr(), _ptr(dh if need_dh else None), _ptr(logits if need_logits else None),
+    check(_fn("ms_head_ce", bf)(h.data_ptr(), w.data_ptr(), _ptr(b), labels.data_ptr(), _ptr(dh if need_dh else None), _ptr(logits if need_logits else None),
                          loss_out.data_ptr(), _ptr(loss_slot_dev), N, C, K, H * W, loss_sign, ws.data_ptr(), ws.numel(), _stream()), "ms_head_ce")
     return loss_out, dh, logits
 
