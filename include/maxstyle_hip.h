@@ -356,7 +356,7 @@ int ms_head_ce(const float* h, const float* w, const float* b, const int64_t* la
  * unchanged: loads widen bf16 to fp32 exactly, the convolutions run on the fp32 matrix cores, BatchNorm statistics are taken from the fp32
  * accumulators BEFORE the output is rounded, stores round to nearest-even bf16 (relative error <= 2^-9 per stored element).  Requirements: the
  * vector paths of the fp32 entry points (rows of W % 4 == 0 elements - W % 2 for fetch 1 -, 16-byte aligned tensors); MS_ERR_INVALID otherwise.
- * The sub-pixel (ms_conv_subpix) and small-Cout (ms_conv3x3_small_cout) special cases have no bf16 twin: use ms_conv2d_bf16 with fetch 1 / 2. */
+ * The "last workgroup finalises" experiments (ms_conv2d_fin, ms_conv2d_actbwd_fin, ms_act_bwd_bn) have no bf16 twin. */
 int ms_conv2d_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias,
                    int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                    int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
@@ -367,6 +367,15 @@ int ms_conv2d_actbwd_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out
                           int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                           int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                           const uint16_t* u, const float* coef4, float act_slope, float* tab, void* stream);
+int ms_style_bwd_actbwd_parts_bf16(int B, int C, int HW);
+int ms_style_bwd_actbwd_bf16(const uint16_t* dy, const uint16_t* x, uint16_t* dx, const float* mu, const float* sig, const float* coefA,
+                             const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
+                             float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes,
+                             const uint16_t* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream);
+int ms_conv_subpix_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int mode,
+                        float* stats, const uint16_t* ref, const uint16_t* u, const float* coef4, float act_slope, float* tab, void* stream);
+int ms_conv3x3_small_cout_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, int N, int Cin, int H, int W, int Cout,
+                               int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_cstride, void* stream);
 int ms_bn_act_bf16(const uint16_t* u, const float* coef4, const uint16_t* res, int res_mode, uint16_t* out, int N, int C, int H, int W, float slope, void* stream);
 int ms_act_bwd_reduce_bf16(const uint16_t* gin, const uint16_t* ref, const uint16_t* u, const float* coef4, uint16_t* gout, float* part2,
                            int N, int C, int HW, float slope, void* stream);

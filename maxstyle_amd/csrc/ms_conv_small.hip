@@ -15,8 +15,8 @@ namespace ms {
 
 constexpr int kSmTH = 16, kSmTW = 64, kSmCK = 2, kSmIH = kSmTH + 2, kSmRS = kSmTW + 8, kSmPS = kSmIH * kSmRS;       // window columns x0-4 .. x0+67
 
-template <int COUT, bool PRO2>
-__global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(const float* __restrict__ in, const float* __restrict__ in2, float* __restrict__ out,
+template <int COUT, bool PRO2, typename AT = float>
+__global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(const void* __restrict__ in, const void* __restrict__ in2, void* __restrict__ out,
                                                                  const float* __restrict__ w, const float* __restrict__ pro_a, const float* __restrict__ pro_b,
                                                                  const float* __restrict__ pro_c, int pro_cstride, int Cin, int H, int W, int cin_pad, int cout_pad,
                                                                  int tiles_x) {
@@ -26,8 +26,8 @@ __global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(const float* __
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int y0 = ty * kSmTH, x0 = tx * kSmTW;
   const size_t plane = (size_t)H * W;
-  const float* in_n = in + (size_t)n * Cin * plane;
-  const float* in2_n = PRO2 ? in2 + (size_t)n * Cin * plane : nullptr;
+  using IO = ActIO<AT>;                     // storage type of in / in2 / out: float | ms_bf16
+  const size_t in_n = (size_t)n * Cin * plane;
   constexpr int ITEMS = kSmCK * kSmIH * (kSmRS / 4);        // float4 items per chunk: 4 x 18 x 18 = 1296
   constexpr int NI = (ITEMS + 255) / 256;
   float4 rg[NI], ru[PRO2 ? NI : 1];
@@ -44,9 +44,9 @@ __global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(const float* __
         const int r = row % kSmIH, c = row / kSmIH;
         const int Y = y0 - 1 + r, X = x0 - 4 + 4 * f, ci = c0 + c;
         if (ci < Cin && Y >= 0 && Y < H && X >= 0 && X < W) {          // W % 4 == 0: a quad is inside or outside as a whole
-          const size_t off = (size_t)ci * plane + (size_t)Y * W + X;
-          rg[j] = *reinterpret_cast<const float4*>(in_n + off);
-          if (PRO2) ru[j] = *reinterpret_cast<const float4*>(in2_n + off);
+          const size_t off = in_n + (size_t)ci * plane + (size_t)Y * W + X;
+          rg[j] = IO::ld4(in, off);
+          if (PRO2) ru[j] = IO::ld4(in2, off);
         }
       }
     }
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(const float* __
   if (y < H && x < W) {
 #pragma unroll
     for (int o = 0; o < COUT; ++o)
-      *reinterpret_cast<float4*>(out + ((size_t)n * COUT + o) * plane + (size_t)y * W + x) = make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
+      IO::st4(out, ((size_t)n * COUT + o) * plane + (size_t)y * W + x, make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]));
   }
 }
 
@@ -124,8 +124,9 @@ extern "C" int ms_conv3x3_small_cout_ok(int Cout, int W) { return (Cout >= 1 && 
 
 // out [N,Cout,H,W] = conv3x3(P(in), w) with Cout <= 4, stride 1, padding 1; w = packed weights [9][cin_pad][cout_pad] (for a data-gradient: the
 // data-gradient layout).  pro_mode 0: P = identity; 2: P = pro_a[c]*in + pro_b[c]*in2 + pro_c[c] (BatchNorm backward, coefficient records of stride pro_cstride).
-extern "C" int ms_conv3x3_small_cout(const float* in, const float* in2, float* out, const float* w_packed, int N, int Cin, int H, int W, int Cout,
-                                     int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_cstride, void* stream) {
+template <typename AT>
+static int small_cout_impl(const void* in, const void* in2, void* out, const float* w_packed, int N, int Cin, int H, int W, int Cout,
+                           int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_cstride, void* stream) {
   if (N < 1 || Cin < 1 || H < 1 || W < 1 || !ms_conv3x3_small_cout_ok(Cout, W) || N > 65535) { set_error("ms_conv3x3_small_cout: Cout <= 4, W %% 4 == 0"); return MS_ERR_INVALID; }
   if (pro_mode != 0 && pro_mode != 2) { set_error("ms_conv3x3_small_cout: pro_mode 0 or 2"); return MS_ERR_INVALID; }
   if (pro_mode == 2 && (in2 == nullptr || pro_a == nullptr || pro_b == nullptr || pro_c == nullptr)) { set_error("ms_conv3x3_small_cout: prologue operands missing"); return MS_ERR_INVALID; }
@@ -135,9 +136,18 @@ extern "C" int ms_conv3x3_small_cout(const float* in, const float* in2, float* o
   dim3 grid(tiles_x * tiles_y, N), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int cs = pro_cstride < 1 ? 1 : pro_cstride;
-#define MS_SM(CO, P2) MS_LAUNCH((conv3x3_small_cout_kernel<CO, P2>), grid, block, 0, st, in, in2, out, w_packed, pro_a, pro_b, pro_c, cs, Cin, H, W, cin_pad, cout_pad, tiles_x)
+#define MS_SM(CO, P2) MS_LAUNCH((conv3x3_small_cout_kernel<CO, P2, AT>), grid, block, 0, st, in, in2, out, w_packed, pro_a, pro_b, pro_c, cs, Cin, H, W, cin_pad, cout_pad, tiles_x)
   if (pro_mode == 2) { switch (Cout) { case 1: MS_SM(1, true); break; case 2: MS_SM(2, true); break; case 3: MS_SM(3, true); break; default: MS_SM(4, true); } }
   else { switch (Cout) { case 1: MS_SM(1, false); break; case 2: MS_SM(2, false); break; case 3: MS_SM(3, false); break; default: MS_SM(4, false); } }
 #undef MS_SM
   return check_launch("conv3x3_small_cout");
+}
+extern "C" int ms_conv3x3_small_cout(const float* in, const float* in2, float* out, const float* w_packed, int N, int Cin, int H, int W, int Cout,
+                                     int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_cstride, void* stream) {
+  return small_cout_impl<float>(in, in2, out, w_packed, N, Cin, H, W, Cout, pro_mode, pro_a, pro_b, pro_c, pro_cstride, stream);
+}
+// bf16 activation storage (in, in2, out are bf16 bit patterns): see the bf16 section of include/maxstyle_hip.h
+extern "C" int ms_conv3x3_small_cout_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, int N, int Cin, int H, int W, int Cout,
+                                          int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_cstride, void* stream) {
+  return small_cout_impl<ms_bf16>(in, in2, out, w_packed, N, Cin, H, W, Cout, pro_mode, pro_a, pro_b, pro_c, pro_cstride, stream);
 }

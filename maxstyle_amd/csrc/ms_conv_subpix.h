@@ -73,9 +73,10 @@ __host__ __device__ constexpr bool sub_shift_used(int sy, int sx) {
 
 // a.Hs, a.Ws: stored (low-resolution) size; a.Hout = 2*Hs, a.Wout = 2*Ws.  a.epi_mode: 0 plain, 3 activation-backward mask against the MATERIALISED
 // activation a.mk_ref (sign(out) == sign(pre-activation)) with the sums of g and g*(mk_u - mean) for the BatchNorm backward of mk_u's layer.
-template <int MODE>
+template <int MODE, typename AT = float>
 __global__ __launch_bounds__(512, 4) void conv_subpix_kernel(const ConvArgs a, const float* __restrict__ mk_ref) {
   using G = SubGeo<MODE>;
+  using IO = ActIO<AT>;                     // storage type of the activation tensors (in, out, mk_u, mk_ref): float | ms_bf16
   constexpr int TLH = G::TLH, TLW = G::TLW, CK = G::CK, IH = G::IH, RS = G::RS, PS = G::PS, NCOMBO = G::NCOMBO, WS = G::WS, BUF = G::BUF;
   constexpr int NI = G::NI, NWI = G::NWI;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -121,12 +122,12 @@ __global__ __launch_bounds__(512, 4) void conv_subpix_kernel(const ConvArgs a, c
     float4 rin[NI], rw[NWI];
     bool have_w = false;
     auto load_chunk = [&](int n, int co0, int c0, bool load_w) {
-      const float* in_n = a.in + (size_t)n * a.Cin * plane;
+      const size_t in_n = (size_t)n * a.Cin * plane;
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int ci = c0 + (s_lds[j] >> 20);
         const bool ok = (s_lds[j] >= 0) && (s_goff[j] >= 0) && (ci < a.Cin);
-        rin[j] = ok ? *reinterpret_cast<const float4*>(in_n + (size_t)ci * plane + s_goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rin[j] = ok ? IO::ld4(a.in, in_n + (size_t)ci * plane + s_goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       have_w = load_w;
       if (load_w) {
@@ -302,11 +303,10 @@ __global__ __launch_bounds__(512, 4) void conv_subpix_kernel(const ConvArgs a, c
     }
     if (co < a.Cout) {
       const int Wo = a.Wout;
-      float* op = a.out + ((size_t)n * a.Cout + co) * a.Hout * Wo;
+      const size_t pb = ((size_t)n * a.Cout + co) * a.Hout * Wo;               // element offset of this lane's output plane (out, mk_u, mk_ref share the shape)
       // mask reference: the materialised activation (mk_ref), or - when the activation was never written (mk_ref == NULL: lrelu(bn(u)) without a
       // residual add) - its pre-activation sc*u + sh recomputed from u
-      const float* rp = (a.epi_mode == 3 && mk_ref != nullptr) ? mk_ref + ((size_t)n * a.Cout + co) * a.Hout * Wo : nullptr;
-      const float* up = (a.epi_mode == 3) ? a.mk_u + ((size_t)n * a.Cout + co) * a.Hout * Wo : nullptr;
+      const bool have_ref = (a.epi_mode == 3 && mk_ref != nullptr);
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -314,13 +314,13 @@ __global__ __launch_bounds__(512, 4) void conv_subpix_kernel(const ConvArgs a, c
         if (y >= a.Hs || x >= a.Ws) continue;
 #pragma unroll
         for (int py = 0; py < 2; ++py) {
-          const size_t off = (size_t)(2 * y + py) * Wo + 2 * x;
+          const size_t off = pb + (size_t)(2 * y + py) * Wo + 2 * x;
           const f32x4 e = acc[i][py * 2], o = acc[i][py * 2 + 1];
           float4 v0 = make_float4(e[0], o[0], e[1], o[1]), v1 = make_float4(e[2], o[2], e[3], o[3]);
           if (a.epi_mode == 3) {
-            const float4 u0 = *reinterpret_cast<const float4*>(up + off), u1 = *reinterpret_cast<const float4*>(up + off + 4);
+            const float4 u0 = IO::ld4(a.mk_u, off), u1 = IO::ld4(a.mk_u, off + 4);
             float4 r0, r1;
-            if (rp != nullptr) { r0 = *reinterpret_cast<const float4*>(rp + off); r1 = *reinterpret_cast<const float4*>(rp + off + 4); }
+            if (have_ref) { r0 = IO::ld4(mk_ref, off); r1 = IO::ld4(mk_ref, off + 4); }
             else {
               r0 = make_float4(mk_sc * u0.x + mk_sh, mk_sc * u0.y + mk_sh, mk_sc * u0.z + mk_sh, mk_sc * u0.w + mk_sh);
               r1 = make_float4(mk_sc * u1.x + mk_sh, mk_sc * u1.y + mk_sh, mk_sc * u1.z + mk_sh, mk_sc * u1.w + mk_sh);
@@ -331,8 +331,8 @@ __global__ __launch_bounds__(512, 4) void conv_subpix_kernel(const ConvArgs a, c
             s2 += ((v0.x * (u0.x - mk_mu) + v0.y * (u0.y - mk_mu)) + (v0.z * (u0.z - mk_mu) + v0.w * (u0.w - mk_mu))) +
                   ((v1.x * (u1.x - mk_mu) + v1.y * (u1.y - mk_mu)) + (v1.z * (u1.z - mk_mu) + v1.w * (u1.w - mk_mu)));
           }
-          *reinterpret_cast<float4*>(op + off) = v0;
-          *reinterpret_cast<float4*>(op + off + 4) = v1;
+          IO::st4(a.out, off, v0);
+          IO::st4(a.out, off + 4, v1);
         }
       }
       if (a.epi_mode == 3) { st_mean[0] += s1; st_m2[0] += s2; }
@@ -365,20 +365,24 @@ __global__ __launch_bounds__(512, 4) void conv_subpix_kernel(const ConvArgs a, c
   else if (a.epi_mode == 3) conv_table_tail<1, false>(a, smem, vb, ncb, 0.f, st_mean, st_m2);
 }
 
-template <int MODE>
-int launch_conv_subpix(ConvArgs a, const float* mk_ref, hipStream_t st) {
+template <int MODE, typename AT>
+int launch_conv_subpix_t(ConvArgs a, const float* mk_ref, hipStream_t st) {
   using G = SubGeo<MODE>;
   const size_t lds_bytes = sizeof(float) * 2 * (size_t)G::BUF;
   static std::once_flag attr_once;
-  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_subpix_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
+  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_subpix_kernel<MODE, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
   a.tiles_x = cdiv(a.Ws, G::TLW); a.tiles_y = cdiv(a.Hs, G::TLH);
   a.ncb = cdiv(a.Cout, 16);
   const long nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb;
   const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;
-  MS_LAUNCH((conv_subpix_kernel<MODE>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a, mk_ref);
+  MS_LAUNCH((conv_subpix_kernel<MODE, AT>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a, mk_ref);
   return check_launch("conv_subpix");
+}
+template <int MODE>
+int launch_conv_subpix(const ConvArgs& a, const float* mk_ref, hipStream_t st) {
+  return a.act_bf16 ? launch_conv_subpix_t<MODE, ms_bf16>(a, mk_ref, st) : launch_conv_subpix_t<MODE, float>(a, mk_ref, st);
 }
 
 }  // namespace ms

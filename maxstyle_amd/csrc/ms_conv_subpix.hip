@@ -6,8 +6,8 @@ using namespace ms;
 
 extern "C" int ms_conv_subpix_eligible(int Hs, int Ws) { return (Hs >= 1 && Ws >= 4 && Ws % 4 == 0) ? 1 : 0; }
 
-extern "C" int ms_conv_subpix(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int mode,
-                              float* stats, const float* ref, const float* u, const float* coef4, float act_slope, float* tab, void* stream) {
+static int conv_subpix_impl(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int mode,
+                            float* stats, const float* ref, const float* u, const float* coef4, float act_slope, float* tab, void* stream, int act_bf16) {
   if (N < 1 || Cin < 1 || Cout < 1 || !ms_conv_subpix_eligible(Hs, Ws) || (mode != 0 && mode != 1)) {
     set_error("ms_conv_subpix: invalid shape / mode (stored width must be a multiple of 4)"); return MS_ERR_INVALID;
   }
@@ -23,6 +23,18 @@ extern "C" int ms_conv_subpix(const float* in, float* out, const float* w_packed
   a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (Cout + 63) / 64 * 64; a.cout_real = Cout;
   a.epi_mode = mask ? 3 : 0;
   a.mk_u = u; a.mk_coef = coef4; a.mk_slope = act_slope; a.mk_tab = tab;
+  a.act_bf16 = act_bf16;
   hipStream_t st = (hipStream_t)stream;
   return mode == 0 ? launch_conv_subpix<0>(a, ref, st) : launch_conv_subpix<1>(a, ref, st);
+}
+
+extern "C" int ms_conv_subpix(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int mode,
+                              float* stats, const float* ref, const float* u, const float* coef4, float act_slope, float* tab, void* stream) {
+  return conv_subpix_impl(in, out, w_packed, bias, N, Cin, Hs, Ws, Cout, mode, stats, ref, u, coef4, act_slope, tab, stream, 0);
+}
+// bf16 activation storage (in, out, ref, u are bf16 bit patterns): see the bf16 section of include/maxstyle_hip.h
+extern "C" int ms_conv_subpix_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int mode,
+                                   float* stats, const uint16_t* ref, const uint16_t* u, const float* coef4, float act_slope, float* tab, void* stream) {
+  return conv_subpix_impl(reinterpret_cast<const float*>(in), reinterpret_cast<float*>(out), w_packed, bias, N, Cin, Hs, Ws, Cout, mode, stats,
+                          reinterpret_cast<const float*>(ref), reinterpret_cast<const float*>(u), coef4, act_slope, tab, stream, 1);
 }

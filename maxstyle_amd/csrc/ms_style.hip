@@ -324,14 +324,18 @@ __global__ __launch_bounds__(kStyleThreads) void restyle_bf16_kernel(const uint1
   }
 }
 
+// bn_u != nullptr: the fused output-activation backward of the block below, exactly as in restyle_bwd_kernel (ms_style_bwd_actbwd_bf16)
 __global__ __launch_bounds__(kStyleThreads) void restyle_bwd_bf16_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x, uint16_t* __restrict__ dx,
                                                                         const float* __restrict__ mu, const float* __restrict__ sig,
-                                                                        const float* __restrict__ coefA, float2* __restrict__ part, int HW, int chunk, int S) {
+                                                                        const float* __restrict__ coefA, float2* __restrict__ part, int HW, int chunk, int S,
+                                                                        const uint16_t* __restrict__ bn_u, const float4* __restrict__ bn_coef, float2* __restrict__ bn_part,
+                                                                        int C, float slope) {
   __shared__ float red[16];
   const int p = blockIdx.y;
   const float m = mu[p], inv = 1.f / sig[p], a = coefA[p] * inv;
   const int beg = blockIdx.x * chunk, end = min(HW, beg + chunk);
-  float s1 = 0.f, s2 = 0.f;
+  const float bmean = bn_u ? bn_coef[p % C].z : 0.f;
+  float s1 = 0.f, s2 = 0.f, b1 = 0.f, b2 = 0.f;
   for (int i = beg + threadIdx.x * 8; i < end; i += kStyleThreads * 8) {
     float g[8], t[8];
     bf16x8_load(dy + (size_t)p * HW + i, g);
@@ -341,12 +345,24 @@ __global__ __launch_bounds__(kStyleThreads) void restyle_bwd_bf16_kernel(const u
     if (dx) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) g[e] *= a;
+      if (bn_u) {
+        float uu[8];
+        bf16x8_load(bn_u + (size_t)p * HW + i, uu);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { g[e] *= (t[e] > 0.f) ? 1.f : slope; b1 += g[e]; b2 += g[e] * (uu[e] - bmean); }
+      }
       bf16x8_store(dx + (size_t)p * HW + i, g);
     }
   }
   s1 = block_sum(s1, red);
   s2 = block_sum(s2, red);
   if (threadIdx.x == 0) part[(size_t)p * S + blockIdx.x] = make_float2(s1, s2);
+  if (bn_u) {
+    b1 = block_sum(b1, red);
+    b2 = block_sum(b2, red);
+    const int c = p % C, n = p / C, N = (int)gridDim.y / C;
+    if (threadIdx.x == 0) bn_part[(size_t)c * (N * S) + n * S + blockIdx.x] = make_float2(b1, b2);      // the layout of ms_act_bwd_reduce's partials
+  }
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
@@ -622,10 +638,14 @@ extern "C" int ms_style_fwd_bf16(const uint16_t* x, uint16_t* y, float* mu, floa
   return check_launch("restyle_bf16");
 }
 
-extern "C" int ms_style_bwd_bf16(const uint16_t* dy, const uint16_t* x, uint16_t* dx, const float* mu, const float* sig, const float* coefA,
-                                 const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
-                                 float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes, void* stream) {
+static int style_bwd_bf16_impl(const uint16_t* dy, const uint16_t* x, uint16_t* dx, const float* mu, const float* sig, const float* coefA,
+                               const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
+                               float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes,
+                               const uint16_t* bn_u, const float* bn_coef4, float* bn_part, float slope, void* stream) {
   if (int e = check_bf16_args("ms_style_bwd_bf16", dy, x, dx, HW)) return e;
+  if (bn_u != nullptr && (dx == nullptr || bn_coef4 == nullptr || bn_part == nullptr || !aligned16(bn_u) || !aligned16(bn_coef4))) {
+    set_error("ms_style_bwd_actbwd_bf16: needs dx, bn_u and bn_coef4 (16-byte aligned) and bn_part"); return MS_ERR_INVALID;
+  }
   if (int e = check_style_args(B, C, HW, ws, ws_bytes)) return e;
   if (d_lmda != nullptr && (lmda == nullptr || perm == nullptr)) { set_error("ms_style_bwd_bf16: d_lmda needs lmda and perm"); return MS_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
@@ -633,13 +653,28 @@ extern "C" int ms_style_bwd_bf16(const uint16_t* dy, const uint16_t* x, uint16_t
   if (P > kMaxPlanesPerLaunch) { set_error("ms_style_bwd_bf16: too many planes"); return MS_ERR_INVALID; }
   const Split sp = choose_split_bf16(P, HW);
   float2* part = (float2*)ws;
-  MS_LAUNCH(restyle_bwd_bf16_kernel, dim3(sp.S, P), dim3(kStyleThreads), 0, st, dy, x, dx, mu, sig, coefA, part, HW, sp.chunk, sp.S);
+  MS_LAUNCH(restyle_bwd_bf16_kernel, dim3(sp.S, P), dim3(kStyleThreads), 0, st, dy, x, dx, mu, sig, coefA, part, HW, sp.chunk, sp.S,
+            bn_u, (const float4*)bn_coef4, (float2*)bn_part, C, slope);
   if (int e = check_launch("restyle_bwd_bf16")) return e;
   if (d_gamma || d_beta || d_lmda) {
     MS_LAUNCH(style_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, (const float2*)part, mu, sig, gamma_std, beta_std, lmda, perm, d_gamma, d_beta, d_lmda, B, C, sp.S);
     return check_launch("style_bwd_finalize");
   }
   return MS_OK;
+}
+extern "C" int ms_style_bwd_bf16(const uint16_t* dy, const uint16_t* x, uint16_t* dx, const float* mu, const float* sig, const float* coefA,
+                                 const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
+                                 float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes, void* stream) {
+  return style_bwd_bf16_impl(dy, x, dx, mu, sig, coefA, gamma_std, beta_std, lmda, perm, d_gamma, d_beta, d_lmda, B, C, HW, ws, ws_bytes, nullptr, nullptr, nullptr, 0.f, stream);
+}
+// bf16 twin of ms_style_bwd_actbwd; bn_part holds [C][ms_style_bwd_actbwd_parts_bf16(B, C, HW)] float2 partials
+extern "C" int ms_style_bwd_actbwd_parts_bf16(int B, int C, int HW) { return B * choose_split_bf16(B * C, HW).S; }
+extern "C" int ms_style_bwd_actbwd_bf16(const uint16_t* dy, const uint16_t* x, uint16_t* dx, const float* mu, const float* sig, const float* coefA,
+                                        const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
+                                        float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes,
+                                        const uint16_t* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream) {
+  if (bn_u == nullptr) { set_error("ms_style_bwd_actbwd_bf16: bn_u is required"); return MS_ERR_INVALID; }
+  return style_bwd_bf16_impl(dy, x, dx, mu, sig, coefA, gamma_std, beta_std, lmda, perm, d_gamma, d_beta, d_lmda, B, C, HW, ws, ws_bytes, bn_u, bn_coef4, bn_part, act_slope, stream);
 }
 
 extern "C" int ms_adam_step(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2, float eps, int step,

@@ -258,10 +258,19 @@ class StyleSlot:
 
 
 class InnerLoopEngine:
-    def __init__(self, spec: NetSpec, B: int, H: int, W: int, device, lr=0.1):
+    def __init__(self, spec: NetSpec, B: int, H: int, W: int, device, lr=0.1, act_dtype=None):
+        """act_dtype: storage type of the activation tensors - torch.float32 (default; MS_ACT_DTYPE=bf16 in the environment selects bf16) or torch.bfloat16
+        (BASELINE config 5 "bf16 activations": every conv input / output, gradient and image is stored as bf16, statistics / coefficients / parameters / the
+        matrix arithmetic stay fp32).  The engine takes fp32 codes and hands back an image of its storage type."""
         if H % 16 or W % 16:
             raise ValueError("image height/width must be multiples of 16 (four stride-2 stages)")
         self.spec, self.B, self.H, self.W, self.dev, self.lr = spec, B, H, W, torch.device(device), lr
+        if act_dtype is None:
+            act_dtype = torch.bfloat16 if os.environ.get("MS_ACT_DTYPE", "").lower() in ("bf16", "bfloat16") else F32
+        if act_dtype not in (F32, torch.bfloat16):
+            raise TypeError("act_dtype must be torch.float32 or torch.bfloat16")
+        self.act_dtype = act_dtype
+        self.bf16 = act_dtype == torch.bfloat16
         self.buf: Dict[str, torch.Tensor] = {}
         self.nets: Optional[PackedNets] = None
         self.styles: Dict[int, StyleSlot] = {}
@@ -310,6 +319,12 @@ class InnerLoopEngine:
         # the activation after the encoder's first double conv (`inc`) is never written: BatchNorm + LeakyReLU become the prologue of down1's stride-2 conv
         # and the backward mask is recomputed from the raw conv output (inner loop only: the training engine and the MixStyle baselines read that tensor)
         self.lazy_inc = os.environ.get("MS_LAZY_INC", "1") != "0" and type(self) is InnerLoopEngine
+        self.fuse_style_actbwd = True  # ms_style_bwd_actbwd (the MaxStyle backward also does the block's output-activation backward)
+        if self.bf16:
+            # kernels without a bf16 twin: the "last workgroup finalises" experiments and the weight-gradient kernels (TrainEngine is fp32 only)
+            if type(self) is not InnerLoopEngine:
+                raise NotImplementedError("bf16 activation storage is built for the inner loop (InnerLoopEngine); the training passes store fp32")
+            self.fuse_bn_fin = self.fuse_bn_bwd = self.inline_bn_bwd = False
         self._side_stream = None
         self._side_pending = False
         # MixStyle / DSU layers inside the encoder (generate_style_augmented_latent_code, advanced_triplet...py:632-670):
@@ -325,6 +340,21 @@ class InnerLoopEngine:
             b = torch.empty(*shape, dtype=dtype, device=self.dev)
             self.buf[name] = b
         return b
+
+    def a(self, name, *shape):
+        """An ACTIVATION tensor (conv inputs / outputs, gradients, images): fp32, or bf16 storage in bf16 mode (everything else stays fp32)."""
+        return self.t(name, *shape, dtype=self.act_dtype)
+
+    _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv1x1_bnres", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd",
+                             "ms_head_fwd", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_style_fwd", "ms_style_bwd", "ms_style_ws_bytes",
+                             "ms_conv_subpix", "ms_conv3x3_small_cout", "ms_style_bwd_actbwd", "ms_style_bwd_actbwd_parts"))
+
+    def L(self, name):
+        """The library entry point for this engine's activation storage type (`_bf16` twin in bf16 mode: include/maxstyle_hip.h)."""
+        if self.bf16:
+            assert name in self._BF16_TWINS, name + " has no bf16 twin"
+            return getattr(lib, name + "_bf16")
+        return getattr(lib, name)
 
     def _st(self):
         return torch.cuda.current_stream().cuda_stream
@@ -439,7 +469,7 @@ class InnerLoopEngine:
             cout = cw.cin if dgrad else cw.cout
         Ho, Wo = ops.conv_out_hw(Hs, Ws, ks, stride, fetch)
         if out is None:
-            out = self.t(name, N, cout, 2 * Ho, 2 * Wo) if epi == 2 else self.t(name, N, cout, Ho, Wo)
+            out = self.a(name, N, cout, 2 * Ho, 2 * Wo) if epi == 2 else self.a(name, N, cout, Ho, Wo)
         st = None
         parts = 0
         if stats and self.bn_eval:
@@ -470,7 +500,7 @@ class InnerLoopEngine:
                                     N, Cin, Hs, Ws, cout, ks, stride, fetch, pm, pa, pb, pc, pn, 4, slope, st.data_ptr(), fin.gamma.data_ptr(), fin.beta.data_ptr(),
                                     BN_EPS, coef.data_ptr(), self._counter(name).data_ptr(), self._st()), "ms_conv2d_fin:" + name)
             return out, ("fused", coef), parts
-        check(lib.ms_conv2d(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
+        check(self.L("ms_conv2d")(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
                             N, Cin, Hs, Ws, cout, ks, stride, fetch, pm, pa, pb, pc, pn, 4, slope, epi, 0 if st is None else st.data_ptr(), self._st()),
               "ms_conv2d:" + name)
         return out, st, parts
@@ -495,8 +525,8 @@ class InnerLoopEngine:
 
     def bn_act(self, name, u, coef, res=None, res_mode=0, slope=LEAKY):
         N, C, H, W = u.shape
-        out = self.t(name, N, C, H, W)
-        check(lib.ms_bn_act(u.data_ptr(), coef.data_ptr(), 0 if res is None else res.data_ptr(), res_mode, out.data_ptr(), N, C, H, W, slope, self._st()), "ms_bn_act:" + name)
+        out = self.a(name, N, C, H, W)
+        check(self.L("ms_bn_act")(u.data_ptr(), coef.data_ptr(), 0 if res is None else res.data_ptr(), res_mode, out.data_ptr(), N, C, H, W, slope, self._st()), "ms_bn_act:" + name)
         return out
 
     def act_bwd(self, name, gin, ref, u, coef, slope):
@@ -505,7 +535,7 @@ class InnerLoopEngine:
         nparts = lib.ms_act_bwd_parts(N, C, H * W)
         part = self.t(name + ".part", C, nparts, 2)
         if self.bn_eval:                  # eval-mode BatchNorm is a fixed per-channel affine map: du = scale * g (mask only, no statistics)
-            check(lib.ms_act_bwd_reduce(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
+            check(self.L("ms_act_bwd_reduce")(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
                                         N, C, H * W, slope, self._st()), "ms_act_bwd_reduce:" + name)
             bc = self.buf.get(name + ".bcoef_eval")
             if bc is None:                # columns 1..3 stay zero for the buffer's lifetime: no per-step clear (no memset node in the captured step)
@@ -518,7 +548,7 @@ class InnerLoopEngine:
             # two launches (mask+reduce, then coefficients).  Both fusions were built and measured slower at C2: the one-launch
             # ms_act_bwd_bn (236.5 vs 254.8 steps/s: an s_waitcnt vmcnt(0) + a returning atomic on the tail of each of its 4096
             # workgroups) and ms_conv2d pro_mode 3 (`inline_bn_bwd`, see __init__).
-            check(lib.ms_act_bwd_reduce(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
+            check(self.L("ms_act_bwd_reduce")(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
                                         N, C, H * W, slope, self._st()), "ms_act_bwd_reduce:" + name)
             if self.inline_bn_bwd:
                 return gin, (part, nparts, coef)
@@ -537,10 +567,10 @@ class InnerLoopEngine:
         The table holds the BatchNorm-backward sums of u's layer (ms_bn_bwd_coefs / ms_bn_bwd_full with nparts = 0)."""
         N, Cin, Hs, Ws = g.shape
         cout = cw.cin
-        out = self.t(name, N, cout, Hs, Ws)
+        out = self.a(name, N, cout, Hs, Ws)
         tab = self.t(bw_name + ".tab", lib.ms_conv_actbwd_tab_bytes(cout) // 4)
         pa, pb, pc = ops.coef_ptrs(bnbwd[0])
-        check(lib.ms_conv2d_actbwd(g.data_ptr(), bnbwd[1].data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), N, Cin, Hs, Ws, cout, cw.ks, 1, 0,
+        check(self.L("ms_conv2d_actbwd")(g.data_ptr(), bnbwd[1].data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), N, Cin, Hs, Ws, cout, cw.ks, 1, 0,
                                    2, pa, pb, pc, 0, 4, 1.0, u.data_ptr(), coef.data_ptr(), slope, tab.data_ptr(), self._st()), "ms_conv2d_actbwd:" + name)
         return out, tab
 
@@ -552,7 +582,7 @@ class InnerLoopEngine:
         N, C, H, W = u.shape
         if self.fuse_bn_fin and not self.bn_eval:
             Ng, Cin, Hs, Ws = g.shape
-            out = self.t(name, Ng, cw.cin, Hs, Ws)
+            out = self.a(name, Ng, cw.cin, Hs, Ws)
             tab = self.t(bw_name + ".tab", lib.ms_conv_actbwd_tab_bytes(cw.cin) // 4)
             bc = self.t(bw_name + ".bcoef", C, 4)
             pa, pb, pc = ops.coef_ptrs(bnbwd[0])
@@ -575,8 +605,8 @@ class InnerLoopEngine:
     def pool2(self, name, x, out=None, accumulate=False):
         N, C, H, W = x.shape
         if out is None:
-            out = self.t(name, N, C, H // 2, W // 2)
-        check(lib.ms_pool2_sum(x.data_ptr(), out.data_ptr(), N * C, H // 2, W // 2, 1 if accumulate else 0, self._st()), "ms_pool2_sum:" + name)
+            out = self.a(name, N, C, H // 2, W // 2)
+        check(self.L("ms_pool2_sum")(x.data_ptr(), out.data_ptr(), N * C, H // 2, W // 2, 1 if accumulate else 0, self._st()), "ms_pool2_sum:" + name)
         return out
 
     def _subpix_ok(self, N, Hs, Ws, cout):
@@ -593,12 +623,12 @@ class InnerLoopEngine:
         N, Cin, Hs, Ws = x.shape
         if not self._subpix_ok(N, Hs, Ws, cw.cout) or (self.fuse_bn_fin and not self.bn_eval):
             return self.conv(name, x, cw, fetch=ops.FETCH_UPS2, stats=True, fin=fin)
-        out = self.t(name, N, cw.cout, 2 * Hs, 2 * Ws)
+        out = self.a(name, N, cw.cout, 2 * Hs, 2 * Ws)
         st, parts = None, N * 4 * Hs * Ws
         if not self.bn_eval:
             parts = lib.ms_conv_stats_parts(N, 2 * Hs, 2 * Ws)
             st = self.t(name + ".stats", cw.cout * parts + 1, 4)
-        check(lib.ms_conv_subpix(x.data_ptr(), out.data_ptr(), cw.wp.data_ptr(), 0 if cw.b is None else cw.b.data_ptr(), N, Cin, Hs, Ws, cw.cout, 0,
+        check(self.L("ms_conv_subpix")(x.data_ptr(), out.data_ptr(), cw.wp.data_ptr(), 0 if cw.b is None else cw.b.data_ptr(), N, Cin, Hs, Ws, cw.cout, 0,
                                  0 if st is None else st.data_ptr(), 0, 0, 0, 1.0, 0, self._st()), "ms_conv_subpix(ups2):" + name)
         return out, st, parts
 
@@ -608,8 +638,8 @@ class InnerLoopEngine:
         if not self._subpix_ok(N, Hs, Ws, cw.cin):
             dx, _, _ = self.conv(name, g, cw, ks=3, stride=1, fetch=ops.FETCH_ZINS2, dgrad=True)
             return dx
-        out = self.t(name, N, cw.cin, 2 * Hs, 2 * Ws)
-        check(lib.ms_conv_subpix(g.data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), 0, N, Cg, Hs, Ws, cw.cin, 1, 0, 0, 0, 0, 1.0, 0, self._st()),
+        out = self.a(name, N, cw.cin, 2 * Hs, 2 * Ws)
+        check(self.L("ms_conv_subpix")(g.data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), 0, N, Cg, Hs, Ws, cw.cin, 1, 0, 0, 0, 0, 1.0, 0, self._st()),
               "ms_conv_subpix(s2 dgrad):" + name)
         return out
 
@@ -618,9 +648,9 @@ class InnerLoopEngine:
         the BatchNorm backward of its raw input `u`): replaces dgrad_s2 + act_bwd (ms_act_bwd_reduce: 4 HBM passes over the result) -> (g', bcoef4)."""
         N, Cg, Hs, Ws = g.shape
         C = cw.cin
-        out = self.t(name, N, C, 2 * Hs, 2 * Ws)
+        out = self.a(name, N, C, 2 * Hs, 2 * Ws)
         tab = self.t(bw_name + ".tab", lib.ms_conv_actbwd_tab_bytes(C) // 4)
-        check(lib.ms_conv_subpix(g.data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), 0, N, Cg, Hs, Ws, C, 1, 0, 0 if act_out is None else act_out.data_ptr(), u.data_ptr(),
+        check(self.L("ms_conv_subpix")(g.data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), 0, N, Cg, Hs, Ws, C, 1, 0, 0 if act_out is None else act_out.data_ptr(), u.data_ptr(),
                                  coef.data_ptr(), slope, tab.data_ptr(), self._st()), "ms_conv_subpix(s2 dgrad + act bwd):" + name)
         bc = self.t(bw_name + ".bcoef", C, 4)
         check(lib.ms_bn_bwd_coefs(tab.data_ptr(), 0, coef.data_ptr(), float(N * 4 * Hs * Ws), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + bw_name)
@@ -657,8 +687,8 @@ class InnerLoopEngine:
         if fused_tail:
             xin = x if kind == "nn" else src
             N, Cin, Hs, Ws = xin.shape
-            out = self.t(pfx + ".out", *u2.shape)
-            check(lib.ms_conv1x1_bnres(xin.data_ptr(), out.data_ptr(), ci.wp.data_ptr(), 0 if ci.b is None else ci.b.data_ptr(), N, Cin, Hs, Ws, ci.cout,
+            out = self.a(pfx + ".out", *u2.shape)
+            check(self.L("ms_conv1x1_bnres")(xin.data_ptr(), out.data_ptr(), ci.wp.data_ptr(), 0 if ci.b is None else ci.b.data_ptr(), N, Cin, Hs, Ws, ci.cout,
                                        u2.data_ptr(), cf2.data_ptr(), LEAKY, 1 if kind == "nn" else 0, self._st()), "ms_conv1x1_bnres:" + pfx)
             return out
         self._join_side()
@@ -693,7 +723,7 @@ class InnerLoopEngine:
                 N, C, Ho, Wo = dx.shape
                 nparts = lib.ms_act_bwd_parts(N, C, Ho * Wo)
                 part = self.t(bw_name + ".ppart", C, nparts, 2)
-                check(lib.ms_pool2_actbwd(dhi.data_ptr(), dx.data_ptr(), dx.data_ptr(), act_out.data_ptr(), u.data_ptr(), coef.data_ptr(), part.data_ptr(),
+                check(self.L("ms_pool2_actbwd")(dhi.data_ptr(), dx.data_ptr(), dx.data_ptr(), act_out.data_ptr(), u.data_ptr(), coef.data_ptr(), part.data_ptr(),
                                           N, C, Ho, Wo, slope, self._st()), "ms_pool2_actbwd:" + pfx)
                 bc = self.t(bw_name + ".bcoef", C, 4)
                 check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(N * Ho * Wo), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + bw_name)
@@ -793,9 +823,9 @@ class InnerLoopEngine:
         N, Cg, H, W = g.shape
         if self.small_cout and lib.ms_conv3x3_small_cout_ok(c0.cin, W) and not isinstance(bc, tuple):
             # the gradient that reaches the image has 1 (3) channels: vector-ALU kernel instead of a 16-column MFMA tile (ms_conv_small.hip)
-            dimg = self.t("e.dimage", N, c0.cin, H, W)
+            dimg = self.a("e.dimage", N, c0.cin, H, W)
             pa, pb, pc = ops.coef_ptrs(bc)
-            check(lib.ms_conv3x3_small_cout(g.data_ptr(), b["e.inc.ua"].data_ptr(), dimg.data_ptr(), c0.dwp.data_ptr(), N, Cg, H, W, c0.cin, 2, pa, pb, pc, 4, self._st()),
+            check(self.L("ms_conv3x3_small_cout")(g.data_ptr(), b["e.inc.ua"].data_ptr(), dimg.data_ptr(), c0.dwp.data_ptr(), N, Cg, H, W, c0.cin, 2, pa, pb, pc, 4, self._st()),
                   "ms_conv3x3_small_cout:e.dimage")
             return dimg
         dimg, _, _ = self.conv("e.dimage", g, c0, bnbwd=(bc, b["e.inc.ua"]), dgrad=True)
@@ -814,7 +844,7 @@ class InnerLoopEngine:
         N, C, H, W = h.shape
         w, bias = self.nets.seg["head.w"], self.nets.seg["head.b"]
         K = w.shape[0]
-        dh = self.t("s.dh", N, C, H, W) if need_grad else None
+        dh = self.a("s.dh", N, C, H, W) if need_grad else None
         logits = self.t("s.logits", N, K, H, W) if need_logits else None
         nbytes = lib.ms_head_ce_ws_bytes(N, H * W)
         ws = self.t("s.ce_ws", max(nbytes, 64), dtype=torch.uint8)
@@ -825,14 +855,14 @@ class InnerLoopEngine:
             b = self.buf
             u2, coef = b["s.u4.u2"], b["s.u4.bn4.coef"]
             part = self.t("s.u4.bw2.hpart", C, nparts, 2)
-            check(lib.ms_head_ce_actbwd(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), dh.data_ptr(), self.loss_buf.data_ptr(),
+            check(self.L("ms_head_ce_actbwd")(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), dh.data_ptr(), self.loss_buf.data_ptr(),
                                         0 if loss_slot is None else loss_slot.data_ptr(), N, C, K, H * W, self.loss_sign, ws.data_ptr(), ws.numel(),
                                         u2.data_ptr(), coef.data_ptr(), part.data_ptr(), LEAKY, self._st()), "ms_head_ce_actbwd")
             bc = self.t("s.u4.bw2.bcoef", C, 4)
             check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(N * H * W), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:s.u4")
             pre = (dh, bc)
         else:
-            check(lib.ms_head_ce(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), 0 if dh is None else dh.data_ptr(),
+            check(self.L("ms_head_ce")(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), 0 if dh is None else dh.data_ptr(),
                                  0 if logits is None else logits.data_ptr(), self.loss_buf.data_ptr(), 0 if loss_slot is None else loss_slot.data_ptr(),
                                  N, C, K, H * W, self.loss_sign, ws.data_ptr(), ws.numel(), self._st()), "ms_head_ce")
         if not need_grad:
@@ -905,15 +935,15 @@ class InnerLoopEngine:
         HW = x.shape[2] * x.shape[3]
         if HW == 1 or B <= 1 or (not s.mix_style and not s.use_noise):
             return x                                     # identity short-cuts of maxstyle.py:146-152
-        y = self.t(f"st{i}.y", *x.shape)
+        y = self.a(f"st{i}.y", *x.shape)
         stats = self.t(f"st{i}.stats", 4, B, C)          # mu, sig, A, S
         std = self.t(f"st{i}.std", 2, C)                 # gamma_std, beta_std (frozen after the first forward)
-        ws = self._style_ws(i, lib.ms_style_ws_bytes(B, C, HW))
+        ws = self._style_ws(i, self.L("ms_style_ws_bytes")(B, C, HW))
         if f"st{i}.ws" not in self._ws_state_off:
             self._note_state_offset(i, B, C, HW)
         po = lambda nm: self.flat_p.data_ptr() + 4 * s.off[nm][0]
         flags = (0 if s.have_std else 1) | (4 if (self.shared_device or self.overlap) else 0)
-        check(lib.ms_style_fwd(x.data_ptr(), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), std[0].data_ptr(), std[1].data_ptr(),
+        check(self.L("ms_style_fwd")(x.data_ptr(), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), std[0].data_ptr(), std[1].data_ptr(),
                                flags, po("lmda") if s.mix_style else 0, po("gamma_noise") if s.use_noise else 0,
                                po("beta_noise") if s.use_noise else 0, s.perm.data_ptr() if s.mix_style else 0,
                                stats[2].data_ptr(), stats[3].data_ptr(), B, C, HW, s.eps, ws.data_ptr(), ws.numel(), self._st()), f"ms_style_fwd:{i}")
@@ -927,11 +957,11 @@ class InnerLoopEngine:
         B, C = x.shape[:2]
         HW = x.shape[2] * x.shape[3]
         stats, std = self.buf[f"st{i}.stats"], self.buf[f"st{i}.std"]
-        dx = self.t(f"st{i}.dx", *x.shape) if need_dx else None
+        dx = self.a(f"st{i}.dx", *x.shape) if need_dx else None
         ws = self.buf[f"st{i}.ws"]
         go = lambda nm: self.flat_g.data_ptr() + 4 * s.off[nm][0]
         po = lambda nm: self.flat_p.data_ptr() + 4 * s.off[nm][0]
-        check(lib.ms_style_bwd(dy.data_ptr(), x.data_ptr(), 0 if dx is None else dx.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+        check(self.L("ms_style_bwd")(dy.data_ptr(), x.data_ptr(), 0 if dx is None else dx.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
                                std[0].data_ptr(), std[1].data_ptr(), po("lmda") if s.mix_style else 0, s.perm.data_ptr() if s.mix_style else 0,
                                go("gamma_noise") if s.use_noise else 0, go("beta_noise") if s.use_noise else 0, go("lmda") if s.mix_style else 0,
                                B, C, HW, ws.data_ptr(), ws.numel(), self._st()), f"ms_style_bwd:{i}")
@@ -946,14 +976,14 @@ class InnerLoopEngine:
         B, C = x.shape[:2]
         HW = x.shape[2] * x.shape[3]
         stats, std = b[f"st{i}.stats"], b[f"st{i}.std"]
-        dx = self.t(f"st{i}.dx", *x.shape)
+        dx = self.a(f"st{i}.dx", *x.shape)
         ws = b[f"st{i}.ws"]
         u, coef = b[pfx + ".u2"], b[pfx + ".bn4.coef"]
-        nparts = lib.ms_style_bwd_actbwd_parts(B, C, HW)
+        nparts = self.L("ms_style_bwd_actbwd_parts")(B, C, HW)
         part = self.t(pfx + ".bw2.spart", C, nparts, 2)
         go = lambda nm: self.flat_g.data_ptr() + 4 * s.off[nm][0]
         po = lambda nm: self.flat_p.data_ptr() + 4 * s.off[nm][0]
-        check(lib.ms_style_bwd_actbwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+        check(self.L("ms_style_bwd_actbwd")(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
                                       std[0].data_ptr(), std[1].data_ptr(), po("lmda") if s.mix_style else 0, s.perm.data_ptr() if s.mix_style else 0,
                                       go("gamma_noise") if s.use_noise else 0, go("beta_noise") if s.use_noise else 0, go("lmda") if s.mix_style else 0,
                                       B, C, HW, ws.data_ptr(), ws.numel(), u.data_ptr(), coef.data_ptr(), part.data_ptr(), LEAKY, self._st()), f"ms_style_bwd_actbwd:{i}")
@@ -973,6 +1003,8 @@ class InnerLoopEngine:
 
     def _note_state_offset(self, i, B, C, HW):
         off = lib.ms_style_ws_state_offset(B, C, HW)
+        if self.bf16 and lib.ms_style_fused_ws_bytes_bf16(B, C, HW) == 0:      # (same layout as fp32: scratch, then the state block - ms_style_ws_bytes_bf16)
+            off = (1 << 64) - 1
         self._ws_state_off[f"st{i}.ws"] = None if off == (1 << 64) - 1 else int(off)
 
     def _is_identity(self, i, shape):
@@ -999,8 +1031,8 @@ class InnerLoopEngine:
         if first > 4 and self._prefix_valid:
             img = self.buf["d.image"]
         else:
-            img = self.t("d.image", N, K, H, W)
-            check(lib.ms_head_fwd(x.data_ptr(), d["head.w"].data_ptr(), d["head.b"].data_ptr(), img.data_ptr(), N, C, K, H * W, 1, self._st()), "ms_head_fwd")
+            img = self.a("d.image", N, K, H, W)
+            check(self.L("ms_head_fwd")(x.data_ptr(), d["head.w"].data_ptr(), d["head.b"].data_ptr(), img.data_ptr(), N, C, K, H * W, 1, self._st()), "ms_head_fwd")
             self.buf["d.head_in"] = x
         self._prefix_valid = True
         if 5 in self.layers:
@@ -1016,7 +1048,12 @@ class InnerLoopEngine:
         N, C, H, W = h.shape
         w, bias = self.nets.seg["head.w"], self.nets.seg["head.b"]
         out = self.t("s.logits", N, w.shape[0], H, W)
-        check(lib.ms_head_fwd(h.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), N, C, w.shape[0], H * W, 0, self._st()), "ms_head_fwd")
+        if self.bf16:                       # the head writes its storage type; logits are an fp32 output for the caller
+            lo = self.a("s.logits_bf16", N, w.shape[0], H, W)
+            check(self.L("ms_head_fwd")(h.data_ptr(), w.data_ptr(), bias.data_ptr(), lo.data_ptr(), N, C, w.shape[0], H * W, 0, self._st()), "ms_head_fwd")
+            out.copy_(lo)
+            return out
+        check(self.L("ms_head_fwd")(h.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), N, C, w.shape[0], H * W, 0, self._st()), "ms_head_fwd")
         return out
 
     def decode_bwd(self, dimg):
@@ -1031,14 +1068,14 @@ class InnerLoopEngine:
         x = self.buf["d.head_in"]
         N, C, H, W = x.shape
         K = d["head.w"].shape[0]
-        dh = self.t("d.dh", N, C, H, W)
-        check(lib.ms_head_bwd(g.data_ptr(), self.buf["d.image"].data_ptr(), d["head.w"].data_ptr(), dh.data_ptr(), N, C, K, H * W, 1, self._st()), "ms_head_bwd")
+        dh = self.a("d.dh", N, C, H, W)
+        check(self.L("ms_head_bwd")(g.data_ptr(), self.buf["d.image"].data_ptr(), d["head.w"].data_ptr(), dh.data_ptr(), N, C, K, H * W, 1, self._st()), "ms_head_bwd")
         g = dh
         for i in range(4, 0, -1):
             pre = None
             if i in self.layers and not self._is_identity(i, self.buf[f"d.u{i}.out"].shape):
                 x = self.buf[f"d.u{i}.out"]
-                if first < i and self.fuse_act_bwd and not self.bn_eval and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[0] * x.shape[1] <= 65535:
+                if first < i and self.fuse_act_bwd and self.fuse_style_actbwd and not self.bn_eval and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[0] * x.shape[1] <= 65535:
                     pre = self.style_bwd_actbwd(i, g, f"d.u{i}")      # the block's output-activation backward rides on the layer's backward pass
                     g = None
                 else:
@@ -1083,7 +1120,7 @@ class InnerLoopEngine:
         """K inner steps; returns the final stylised image (a view of an engine buffer - clone to keep)."""
         assert n_iter <= self.loss_buf.numel(), "n_iter exceeds the loss buffer"
         # inputs live in engine-owned buffers so that a captured graph (which holds addresses) stays valid across calls
-        cb = self.t("in.code", *code.shape)
+        cb = self.a("in.code", *code.shape)
         cb.copy_(code)
         code = cb
         if labels is not None:
