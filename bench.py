@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"],
                     help="c2: FCN_16 1x256x256 (the quoted metric); c4: FCN_64 3x320x320 (Prostate-shaped); "
                          "c5: mixed ACDC+Prostate stream through the drop-in solver API with random-depth insertion (p=0.5), fp32 activation storage")
+    ap.add_argument("--act-dtype", default="f32", choices=["f32", "bf16"],
+                    help="storage type of the activation tensors of the conv stack (bf16: BASELINE config 5's 'bf16 activations'; statistics, parameters and the "
+                         "matrix arithmetic stay fp32).  The headline metric is quoted on f32.")
     ap.add_argument("--stream-calls", type=int, default=8, help="c5: generate_max_style_image calls per pass of the stream (alternating ACDC / Prostate shaped)")
     ap.add_argument("--steady-seconds", type=float, default=2.0, help="length of the extra steady-state leg (graph replays, rank-local); 0 disables")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only: gloo on the CPU, stand-in step (CPU tests)")
@@ -59,7 +62,7 @@ def parse():
     return ap.parse_args()
 
 
-def build(dev, B, size, rank, net=(4, 1, 4)):
+def build(dev, B, size, rank, net=(4, 1, 4), act_dtype=None):
     from maxstyle_amd import engine as E
     from maxstyle_amd import synthetic as syn      # procedural weights / images / style states (the GPU leg never imports oracle/)
     spec_o = syn.NetSpec(*net)
@@ -67,7 +70,7 @@ def build(dev, B, size, rank, net=(4, 1, 4)):
     to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
     spec = E.NetSpec(*net)
     nets = E.PackedNets(spec, to(W["image_encoder"]), to(W["segmentation_decoder"]), to(W["image_decoder"]))
-    eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1)
+    eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1, act_dtype=act_dtype)
     eng.set_nets(nets)
     img, lab = syn.synthetic_batch(B, size, net[1], net[2], seed=1234 + rank)
     layers = [3, 4, 5]
@@ -77,7 +80,7 @@ def build(dev, B, size, rank, net=(4, 1, 4)):
     for i in layers:
         st = styles[i]
         eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
-    img_d, lab_d = img.to(dev), lab.to(dev)
+    img_d, lab_d = img.to(dev).to(eng.act_dtype), lab.to(dev)
     # z_i: one clean encoder pass (train-mode batch statistics), as the trainer hands it over (train_adv...py:192-193)
     z_i = eng.encode_fwd(img_d)[0].clone()
     return eng, W, img, lab, styles, z_i, lab_d
@@ -496,6 +499,8 @@ def mixed_stream(dev, args, rank, world, dist_on):
     for tag, ntype, net, size, K in (("acdc", "FCN_16_standard_no_STN", (4, 1, 4), 256, 5), ("prostate", "FCN_64_standard_no_STN", (1, 3, 2), 320, 10)):
         spec = syn.NetSpec(*net)
         S = maxstyle_amd.AdvancedTripletReconSegmentationModel(network_type=ntype, image_ch=net[1], num_classes=net[2], use_gpu=True)
+        if args.act_dtype == "bf16":
+            S.loop_act_dtype = torch.bfloat16
         Wt = syn.procedural_weights(spec, 0)
         for name, mod in S.model.items():
             mod.load_state_dict(Wt[name]); mod.train()
@@ -540,9 +545,10 @@ def mixed_stream(dev, args, rank, world, dist_on):
         return None
     return {"metric": "inner adversarial style-opt steps/sec (mixed ACDC 16x1x256x256 K=5 + Prostate 16x3x320x320 K=10 stream, random depth p=0.5)",
             "value": world * steps / dt, "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": dt / max(steps, 1) * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 arithmetic, bf16 activation storage" if args.act_dtype == "bf16" else "f32"), "data": "synthetic",
             "config": {"workload": f"C5 (this rank's share): {args.stream_calls} generate_max_style_image calls per pass, alternating FCN_16 16x1x256x256 K=5 / FCN_64 16x3x320x320 K=10, "
-                                   "MaxStyle layers drawn per call from [3,4,5] with p=0.5, fp32 activation storage", "global_batch": args.batch * world,
+                                   "MaxStyle layers drawn per call from [3,4,5] with p=0.5, " + ("bf16" if args.act_dtype == "bf16" else "fp32") + " activation storage", "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "hip_graph": True, "passes": passes, "calls_per_pass": args.stream_calls},
             "calls": [{"shape": t, "layers_applied": a} for t, a in subsets], "seconds": dt,
             "note": "whole-call rate through the drop-in solver API: includes MaxStyle construction, the initial and final decodes and the host side of every call"}
@@ -662,7 +668,8 @@ def main():
         net = (1, 3, 2)
         if args.size == 256:
             args.size = 320
-    eng, W, img, lab, styles, z_i, lab_d = build(dev, args.batch, args.size, rank, net)
+    bf16 = args.act_dtype == "bf16"
+    eng, W, img, lab, styles, z_i, lab_d = build(dev, args.batch, args.size, rank, net, torch.bfloat16 if bf16 else None)
     dt, graphed, run_one = timed_steps(eng, z_i, lab_d, args.steps, args.warmup, not args.no_graph, dist_on)
     if dist_on:
         from maxstyle_amd import distributed as D
@@ -674,12 +681,13 @@ def main():
     if rank == 0:
         loss_last = float(eng.loss_buf[0])
         steady = steady_state(run_one, eng, args.steady_seconds)
-        roof = kernel_rooflines(eng, dev, args.config)
+        none6 = {k: None for k in ("dominant", "dgrad_plain", "conv_fwd", "style", "style_bwd", "style_bf16")}
+        roof = none6 if bf16 else kernel_rooflines(eng, dev, args.config)          # (the priced kernels and their algorithmic bytes are the fp32-storage ones)
         step_s = dt / args.steps
         res = {
             "metric": "inner adversarial style-opt steps/sec (batch 16, 256x256)", "value": value, "unit": "steps/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": ("f32 arithmetic, bf16 activation storage" if bf16 else "f32"), "data": "synthetic",
             "config": {"workload": (f"C2: FCN_16 dual-branch, per-GPU batch {args.batch}x1x{args.size}x{args.size}, MaxStyle layers [3,4,5], Adam lr 0.1" if args.config == "c2"
                                     else f"C4: FCN_64 dual-branch, per-GPU batch {args.batch}x3x{args.size}x{args.size}, MaxStyle layers [3,4,5], Adam lr 0.1"),
                        "global_batch": args.batch * n_gpus, "parallelism": f"dp{n_gpus}", "hip_graph": graphed, "world_seen": world,
@@ -693,12 +701,12 @@ def main():
             "roofline": roof["dominant"], "roofline_dgrad_plain": roof["dgrad_plain"], "roofline_conv_fwd": roof["conv_fwd"],
             "roofline_maxstyle": roof["style"], "roofline_maxstyle_bwd": roof["style_bwd"], "roofline_maxstyle_bf16": roof["style_bf16"], "loss_check": loss_last,
         }
-        if world == 1 and not args.no_cpu_baseline and args.config == "c2":
+        if world == 1 and not args.no_cpu_baseline and args.config == "c2" and not bf16:
             res["cpu_baseline"], cpu_image = cpu_baseline(W, img, lab, styles, args.cpu_steps, z_gpu=z_i.cpu())
             res["speedup_vs_cpu"] = value / res["cpu_baseline"]["value"]
             res["drift_full_size"] = drift_c2(eng, styles, z_i, lab_d, cpu_image, args.cpu_steps)
             res["dice_parity"] = dice_parity(dev)
-    if not args.no_outer and args.config == "c2":
+    if not args.no_outer and args.config == "c2" and not bf16:
         del eng
         torch.cuda.empty_cache()
         oi = outer_iteration(dev, args.batch, args.size, rank, world)      # every rank: contains the collective

@@ -10,6 +10,7 @@ Outer update (SURVEY.md 8(f) rows 1,3): standard_training (:731-786), hard_examp
     reset_optimizer (:1038-1091) - forward AND backward (weight gradients) in maxstyle_amd.train_engine, optimiser on one flat buffer.
 Out of scope here (SURVEY.md 8 OUT): the shape-refinement (STN) networks, other augmentation baselines, checkpoint I/O helpers.
 """
+import os
 import torch
 import torch.nn as nn
 
@@ -257,7 +258,12 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     _wk_tensors = None
     _bn_maps = None
 
-    def _loop_engine(self, B, H, W, dev):
+    # storage type of the activation tensors of the INNER LOOP (generate_max_style_image): None / torch.float32, or torch.bfloat16 (BASELINE config 5's
+    # "bf16 activations": conv inputs / outputs, gradients and the image are stored as bf16 inside the loop, statistics / parameters / arithmetic fp32; the
+    # returned image is fp32 as in the reference).  MS_ACT_DTYPE=bf16 in the environment selects it too.  Module forwards (predict / evaluate / training) are fp32.
+    loop_act_dtype = None
+
+    def _loop_engine(self, B, H, W, dev, act_dtype=torch.float32):
         key = self._weights_key()
         spec = E.NetSpec(self.reduce_factor, self.image_ch, self.num_classes)
         if self._packed_key != key:
@@ -279,10 +285,10 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                 for eng in self._engines.values():
                     eng._prefix_valid = False
             self._packed_key = key
-        ek = (B, H, W, str(dev))
+        ek = (B, H, W, str(dev)) if act_dtype == torch.float32 else (B, H, W, str(dev), str(act_dtype))
         eng = self._engines.get(ek)
         if eng is None:
-            eng = E.InnerLoopEngine(spec, B, H, W, dev)
+            eng = E.InnerLoopEngine(spec, B, H, W, dev, act_dtype=act_dtype)
             eng.set_nets(self._packed)
             self._engines[ek] = eng
         return eng
@@ -330,7 +336,10 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                     raise ValueError('loss type {} not supported'.format(ltype))
             code = image_code.detach().contiguous().float()
             B, _, h, w = code.shape
-            eng = self._loop_engine(B, h * 16, w * 16, code.device)
+            act = self.loop_act_dtype
+            if act is None:
+                act = torch.bfloat16 if os.environ.get("MS_ACT_DTYPE", "").lower() in ("bf16", "bfloat16") else torch.float32
+            eng = self._loop_engine(B, h * 16, w * 16, code.device, act_dtype=act)
             mods = {int(k): m for k, m in nn_style_augmentor_dict.items()}
             slots = E.slots_from_modules(mods, code.device)
             layers = [i for i in sorted(mods) if i in slots]
@@ -367,7 +376,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                         m.gamma_std = std[0].clone().view(1, -1, 1, 1); m.beta_std = std[1].clone().view(1, -1, 1, 1)
             self.last_style_modules = nn_style_augmentor_dict
             self.last_losses = eng.losses(steps).clone() if steps > 0 else None
-            out = recon_image.detach().clone()
+            out = recon_image.detach().float().clone() if recon_image.dtype != torch.float32 else recon_image.detach().clone()
         finally:
             for name, module in self.model.items():
                 set_grad(module, requires_grad=old_state[name])
