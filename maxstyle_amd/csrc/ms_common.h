@@ -125,6 +125,11 @@ template <> struct ActIO<ms_bf16> {
   }
 };
 
+// ms_bf16m: bf16 storage AND bf16 matrix arithmetic (v_mfma_f32_16x16x16_bf16, fp32 accumulation) - the wide conv kernel's "bf16 MFMA" mode: the operands
+// of the contraction (prologue outputs, weights) are rounded to bf16 on their way into LDS.  Loads / stores are those of ms_bf16.
+struct ms_bf16m { uint16_t v; };
+template <> struct ActIO<ms_bf16m> : ActIO<ms_bf16> {};
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -125,6 +125,8 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (gemm_cols + 63) / 64 * 64;
   a.bw_parts = bw_parts; a.bw_count = (double)N * Hs * Ws; a.bw_out = bw_out;
   a.act_bf16 = act_bf16;
+  { static const int bfm = getenv("MS_BF16_MFMA") ? atoi(getenv("MS_BF16_MFMA")) : 0;      // EXPERIMENT: bf16 matrix arithmetic in the wide kernel of the `_bf16` entry points
+    if (act_bf16 && bfm) a.act_bf16 = 2; }
   a.pro_mode = pro_mode; a.pro_nstride = pro_nstride; a.pro_cstride = pro_cstride < 1 ? 1 : pro_cstride; a.slope = slope; a.epi_mode = epi_mode;
   if (mk != nullptr) { a.mk_u = mk->u; a.mk_coef = mk->coef4; a.mk_slope = mk->slope; a.mk_tab = mk->tab; }
   if (fin != nullptr) {

@@ -41,6 +41,27 @@ struct WideGeo {
   static constexpr int NWI = (W_ITEMS + 255) / 256;
 };
 
+// Geometry of the bf16-MFMA mode (AT = ms_bf16m): v_mfma_f32_16x16x16_bf16 per (tap, pixel-in-quad, channel block) with 8-channel K-chunks - K groups 0 and 1 of
+// the instruction carry the chunk's two channel quads, groups 2 and 3 read LDS planes that are zeroed once and never written (16-channel chunks need twice the
+// staging registers: 292 bytes of scratch per lane with the two-tensor prologue, 218 registers with two channel blocks per lane; half-empty bf16 MFMAs still
+// cost a quarter of the fp32 ones).  The LDS tile is
+// CHANNEL-QUAD interleaved: entry (g, row, col) = the 4 bf16 values of channels 4g..4g+3 at that pixel (8 bytes), so that the A operand of a lane
+// (pixel row m, K group g = lane >> 4: K = 4g..4g+3) for its 6-pixel window is 48 CONTIGUOUS bytes (three ds_read_b128 feed 12*NT MFMAs), and the B operand
+// (weights, entry (tap, g, cout) = 4 channels) one ds_read_b64.  Offsets below are in BYTES.
+template <int NT, int PRO>
+struct WideGeoBF {
+  static constexpr int TH = 4, TW = 64, CK = 8, IH = TH + 2;
+  static constexpr int RSB = TW + 4;                              // entries per staged row: 0 = left halo, 1..64 interior, 65 = right halo
+  static constexpr int GP = IH * RSB * 8;                          // bytes of one channel-quad plane (3264)
+  static constexpr int A_BYTES = 4 * GP;
+  static constexpr int B_BYTES = 9 * 4 * 16 * NT * 8;
+  static constexpr int BUF = (A_BYTES + B_BYTES) / 4;              // floats per stage buffer
+  static constexpr int RS = RSB, PS = GP / 4, WS = 16;             // (unused by the bf16-MFMA code paths; keep the shared constants defined)
+  static constexpr int Q_ITEMS = CK * IH * (TW / 4), H_ITEMS = CK * IH * 2;
+  static constexpr int NQI = (Q_ITEMS + 255) / 256, NHI = (H_ITEMS + 255) / 256;
+  static constexpr int W_ITEMS = 9 * CK * (16 * NT / 4), NWI = (W_ITEMS + 255) / 256;
+};
+
 // census of workgroup arrivals per CU (stagger experiment): which of the two co-resident workgroups am I?  Timing only - never read for results.
 static __device__ int g_cu_census[1024];
 
@@ -49,9 +70,11 @@ static __device__ int g_cu_census[1024];
 // AT = storage type of the activation tensors (float | ms_bf16, ms_common.h ActIO)
 template <int NT, int PRO, int R, bool AF, typename AT = float>
 __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const ConvArgs a) {
-  using G = WideGeo<NT, PRO, R>;
+  constexpr bool BFM = std::is_same<AT, ms_bf16m>::value;         // bf16 matrix arithmetic (needs R == 1)
+  using G = typename std::conditional<BFM, WideGeoBF<NT, PRO>, WideGeo<NT, PRO, R>>::type;
   using IO = ActIO<AT>;
   constexpr int AB = IO::kBytes;
+  static_assert(!BFM || R == 1, "bf16 MFMA mode: 4-row tiles");
   constexpr int TH = G::TH, TW = G::TW, CK = G::CK, IH = G::IH, RS = G::RS, PS = G::PS, WS = G::WS, BUF = G::BUF;
   constexpr int NQI = G::NQI, NHI = G::NHI, NWI = G::NWI, COUT_TILE = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -70,6 +93,10 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   // beyond Cin.  The staging waves fetch them with one ds_read_b128 per item and chunk (was: three dependent global loads behind ~7 VALU instructions of
   // index arithmetic each - on a SIMD whose matrix pipe is saturated every VALU instruction of a staging wave waits behind an MFMA).
   float* cf_lds = smem + 2 * BUF;
+  if constexpr (BFM) {                               // K groups 2, 3 (activation planes and weight entries) stay zero for the whole launch
+    for (int i = threadIdx.x; i < 2 * BUF; i += 512) smem[i] = 0.f;
+    if constexpr (PRO == 0) __syncthreads();
+  }
   if constexpr (PRO != 0) {
     for (int c = threadIdx.x; c < nchunks * CK; c += 512) {
       float4 cf = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -119,7 +146,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       if (it < G::Q_ITEMS) {
         const int f = it % (TW / 4), row = it / (TW / 4);
         const int r = row % IH, c = row / IH;
-        q_lds[j] = (c << 20) | (c * PS + r * RS + 4 * f + 1);
+        if constexpr (BFM) q_lds[j] = (c << 20) | ((((c >> 2) * IH + r) * G::RSB + 4 * f + 1) * 8 + (c & 3) * 2);      // BYTE address of the entry's channel slot
+        else q_lds[j] = (c << 20) | (c * PS + r * RS + 4 * f + 1);
         q_rc[j] = (r << 16) | (4 * f + 16);
         q_off[j] = (unsigned)AB * (unsigned)(c * plane + (r - 1) * a.Ws + 4 * f + bias);
         q_cf[j] = c;
@@ -134,7 +162,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         const int h = it & 1, row = it >> 1;
         const int r = row % IH, c = row / IH;
         const int col_rel = h ? TW : -1;
-        h_lds[j] = (c << 20) | (c * PS + r * RS + col_rel + 1);
+        if constexpr (BFM) h_lds[j] = (c << 20) | ((((c >> 2) * IH + r) * G::RSB + col_rel + 1) * 8 + (c & 3) * 2);
+        else h_lds[j] = (c << 20) | (c * PS + r * RS + col_rel + 1);
         h_rc[j] = (r << 16) | (col_rel + 16);
         h_off[j] = (unsigned)AB * (unsigned)(c * plane + (r - 1) * a.Ws + col_rel + bias);
         h_cf[j] = c;
@@ -165,7 +194,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       for (int j = 0; j < NHI; ++j) h_ok |= (inside(h_rc[j]) ? 1u : 0u) << j;
       h_ok &= h_all;
     };
-    float rq[NQI][4], rq2[PRO == 2 ? NQI : 1][4], rh[NHI], rh2[PRO == 2 ? NHI : 1];
+    float rq[BFM ? 1 : NQI][4], rq2[(PRO == 2 && !BFM) ? NQI : 1][4], rh[NHI], rh2[PRO == 2 ? NHI : 1];
+    unsigned rqp[BFM ? NQI : 1][2], rqp2[(BFM && PRO == 2) ? NQI : 1][2];      // bf16-MFMA mode (16-channel chunks): the quads stay PACKED in registers until the LDS store
     float4 rw[NWI];
     mask_t l_q_ok = 0, l_h_ok = 0;                  // masks of the chunk held in registers
     bool l_edge = false, have_w = false;
@@ -187,6 +217,10 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
             const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r2, off, soff, 0);
             rq2[j][0] = __uint_as_float(u.x); rq2[j][1] = __uint_as_float(u.y); rq2[j][2] = __uint_as_float(u.z); rq2[j][3] = __uint_as_float(u.w);
           }
+        } else if constexpr (BFM) {
+          const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r1, off, soff, 0);
+          rqp[j][0] = v.x; rqp[j][1] = v.y;
+          if constexpr (PRO == 2) { const u32x2_t u = __builtin_amdgcn_raw_buffer_load_b64(r2, off, soff, 0); rqp2[j][0] = u.x; rqp2[j][1] = u.y; }
         } else {                                      // bf16 storage: 4 values in 8 bytes, widened to fp32
           const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r1, off, soff, 0);
           rq[j][0] = __uint_as_float(v.x << 16); rq[j][1] = __uint_as_float(v.x & 0xFFFF0000u); rq[j][2] = __uint_as_float(v.y << 16); rq[j][3] = __uint_as_float(v.y & 0xFFFF0000u);
@@ -270,13 +304,27 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = rq[j][e];
+          float v2 = 0.f;
+          if constexpr (BFM) {
+            v[e] = __uint_as_float((e & 1) ? (rqp[j][e >> 1] & 0xFFFF0000u) : (rqp[j][e >> 1] << 16));
+            if constexpr (PRO == 2) v2 = __uint_as_float((e & 1) ? (rqp2[j][e >> 1] & 0xFFFF0000u) : (rqp2[j][e >> 1] << 16));
+          } else {
+            v[e] = rq[j][e];
+            if constexpr (PRO == 2) v2 = rq2[j][e];
+          }
           if constexpr (PRO == 1) v[e] = leaky(ca[j] * v[e] + cb_[j], a.slope);
-          if constexpr (PRO == 2) v[e] = ca[j] * v[e] + (cb_[j] * rq2[j][e] + cc[j]);
+          if constexpr (PRO == 2) v[e] = ca[j] * v[e] + (cb_[j] * v2 + cc[j]);
           if constexpr (EDGE) v[e] = ((l_q_ok >> j) & 1u) ? v[e] : 0.f;          // zero padding pads the tensor AFTER the prologue
         }
-        float* dst = buf + (q_lds[j] & 0xFFFFF);
-        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];            // column 1 + 4f: dword stores (paired into ds_write2_b32)
+        if constexpr (BFM) {
+          // round to bf16 and scatter into the channel slot of the four pixels' entries (8 bytes apart)
+          char* dst = reinterpret_cast<char*>(buf) + (q_lds[j] & 0xFFFFF);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) *reinterpret_cast<uint16_t*>(dst + 8 * e) = ms_to_bf16(v[e]);
+        } else {
+          float* dst = buf + (q_lds[j] & 0xFFFFF);
+          dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];            // column 1 + 4f: dword stores (paired into ds_write2_b32)
+        }
       }
 #pragma unroll
       for (int j = 0; j < NHI; ++j) {
@@ -284,7 +332,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         float v = rh[j];
         if constexpr (PRO == 1) v = leaky(hca[j] * v + hcb[j], a.slope);
         if constexpr (PRO == 2) v = hca[j] * v + (hcb[j] * rh2[j] + hcc[j]);
-        buf[h_lds[j] & 0xFFFFF] = ((l_h_ok >> j) & 1u) ? v : 0.f;
+        if constexpr (BFM) *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(buf) + (h_lds[j] & 0xFFFFF)) = ms_to_bf16(((l_h_ok >> j) & 1u) ? v : 0.f);
+        else buf[h_lds[j] & 0xFFFFF] = ((l_h_ok >> j) & 1u) ? v : 0.f;
       }
       if (have_w) {
 #pragma unroll
@@ -293,7 +342,16 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           if (idx < G::W_ITEMS) {
             const int j4 = idx % (COUT_TILE / 4);
             const int row = idx / (COUT_TILE / 4);
-            *reinterpret_cast<float4*>(w_lds + row * WS + j4 * 4) = rw[j];
+            if constexpr (BFM) {
+              // entry (tap, g, cout) = channels 4g..4g+3 of one output channel: this item holds 4 output channels of ONE input channel
+              const int c = row % CK, tap = row / CK;
+              char* wb = reinterpret_cast<char*>(buf) + G::A_BYTES + ((tap * 4 + (c >> 2)) * COUT_TILE + j4 * 4) * 8 + (c & 3) * 2;
+              const float wv[4] = {rw[j].x, rw[j].y, rw[j].z, rw[j].w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) *reinterpret_cast<uint16_t*>(wb + 8 * e) = ms_to_bf16(wv[e]);
+            } else {
+              *reinterpret_cast<float4*>(w_lds + row * WS + j4 * 4) = rw[j];
+            }
           }
         }
       }
@@ -361,12 +419,54 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #pragma unroll
       for (int j = 0; j < NT; ++j) bf[kx][j] = buf[b_lane + ((ky * 3 + kx) * CK + cg * 4) * WS + j * 16];
   };
+  // bf16-MFMA mode: one 16-channel chunk = for every staged row st (= kernel row ky) THREE ds_read_b128 (this lane's 6-pixel window of channel quad g = k:
+  // 6 entries of 8 bytes) + 3*NT ds_read_b64 (weights of the three kernel columns) feed 12*NT v_mfma_f32_16x16x16_bf16 - the work of 48*NT fp32 MFMAs.
+  typedef short bf4_t __attribute__((ext_vector_type(4)));
+  typedef unsigned cu32x4_t __attribute__((ext_vector_type(4)));
+  typedef unsigned cu32x2_t __attribute__((ext_vector_type(2)));
+  auto compute_bf = [&](const float* buf, auto first_tag) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BFM) {
+      const char* ab = reinterpret_cast<const char*>(buf) + ((k * IH + wave) * G::RSB + 4 * m) * 8;
+      const char* bb = reinterpret_cast<const char*>(buf) + G::A_BYTES + (k * COUT_TILE + m) * 8;
+      cu32x4_t wn[2][3];
+      cu32x2_t bw[2][3][NT];
+      auto ld = [&](int st, cu32x4_t (&w)[3], cu32x2_t (&b)[3][NT]) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) w[q] = *reinterpret_cast<const cu32x4_t*>(ab + st * G::RSB * 8 + 16 * q);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) b[kx][j] = *reinterpret_cast<const cu32x2_t*>(bb + ((st * 3 + kx) * 4 * COUT_TILE + 16 * j) * 8);
+      };
+      ld(0, wn[0], bw[0]);
+#pragma unroll
+      for (int st = 0; st < 3; ++st) {
+        if (st + 1 < 3) ld(st + 1, wn[(st + 1) & 1], bw[(st + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned* wv = reinterpret_cast<const unsigned*>(&wn[st & 1][0]);          // 12 dwords: pixel p of the window = dwords 2p, 2p+1
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const cu32x2_t ap = {wv[2 * (i + kx)], wv[2 * (i + kx) + 1]};
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf4_t, ap), __builtin_bit_cast(bf4_t, bw[st & 1][kx][j]),
+                                                                        (FIRST && st == 0 && kx == 0) ? zero4 : acc[0][i][j], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
   // FULL = every channel group of the chunk is live: straight-line code; the guarded form only runs for a layer's ragged last chunk
   // FIRST = first K-chunk of an item: the first MFMA of every accumulator takes a zero C operand (no clearing pass after the epilogue)
   auto compute = [&](const float* buf, auto full_tag, int ncg, auto first_tag) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_tag)::value;
     constexpr bool FIRST = decltype(first_tag)::value;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BFM) { compute_bf(buf, first_tag); return; }
     float win[2][6], bfr[3][3][NT];
     load_win(buf, 0, 0, win[0]);
     load_b(buf, 0, 0, bfr[0]);
@@ -765,7 +865,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 
 template <int NT, int PRO, int R, bool AF, typename AT>
 int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
-  using G = WideGeo<NT, PRO, R>;
+  using G = typename std::conditional<std::is_same<AT, ms_bf16m>::value, WideGeoBF<NT, PRO>, WideGeo<NT, PRO, R>>::type;
   const size_t cin_tab = (PRO != 0) ? (size_t)cdiv(a.cin_pad, G::CK) * G::CK : 0;              // coefficient table: one float4 per input channel of the padded chunks
   const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab);
   if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
@@ -783,8 +883,13 @@ int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
 template <int NT, int PRO, int R, bool AF>
 int launch_conv_wide_af(const ConvArgs& a, hipStream_t st) {
   if (a.act_bf16) {
-    if constexpr (R == 1) return launch_conv_wide_t<NT, PRO, R, AF, ms_bf16>(a, st);         // (the 8-row experiment variant is fp32 only)
-    else { set_error("ms_conv2d_bf16: 8-row tiles are built for fp32 storage only"); return MS_ERR_INVALID; }
+    if constexpr (R == 1) {
+      if (a.act_bf16 == 2) {                         // bf16 matrix arithmetic: 16-channel chunks, zero-filled beyond Cin - one instantiation per (NT, PRO)
+        if constexpr (AF) return launch_conv_wide_t<NT, PRO, 1, true, ms_bf16m>(a, st);
+        else return launch_conv_wide_t<NT, PRO, 1, true, ms_bf16m>(a, st);
+      }
+      return launch_conv_wide_t<NT, PRO, R, AF, ms_bf16>(a, st);         // (the 8-row experiment variant is fp32 only)
+    } else { set_error("ms_conv2d_bf16: 8-row tiles are built for fp32 storage only"); return MS_ERR_INVALID; }
   }
   return launch_conv_wide_t<NT, PRO, R, AF, float>(a, st);
 }
