@@ -8,7 +8,9 @@ bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool v
   if (a.epi_mode == 2 || (a.pro_mode != 0 && a.pro_nstride != 0) || a.bw_parts > 0) return false;      // (pro_mode 3 derives its coefficients in the first-generation kernel only)
   // (the two-tensor BatchNorm-backward prologue runs with 8-channel chunks: twice the staging registers per channel; 70.4 vs 74.2 us on the
   //  first-generation kernel at 16->16 @16x256x256)
-  if (a.Wout < 64 || a.Wout % 4 != 0) return false;
+  // fp32 arithmetic: rows of at least one 64-pixel tile.  bf16 matrix arithmetic (act_bf16 == 2): the matrix work of the padding columns of a narrower row is
+  // cheap, the first-generation kernel's fp32 MFMAs are not - rows from 16 pixels up take this kernel
+  if (a.Wout < (a.act_bf16 == 2 ? 16 : 64) || a.Wout % 4 != 0) return false;
   if ((long long)a.Cin * a.Hs * a.Ws + a.Ws + 4 >= (1LL << 29)) return false;      // byte offsets inside one image fit 31 bits (buffer addressing of the staging)
   if ((long long)a.Cout * a.Hout * a.Wout >= (1LL << 29)) return false;              // ... and so do the epilogue's offsets inside one output image
   if (!aligned16(a.out)) return false;

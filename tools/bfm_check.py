@@ -9,7 +9,7 @@ def _rand(shape, seed, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale
 rb = lambda t: t.to(BF).to(torch.float32)
-for (N, Cin, Cout, H, W) in [(2, 16, 16, 64, 64), (1, 32, 48, 20, 192), (2, 64, 64, 64, 64), (1, 8, 33, 8, 100), (2, 1, 16, 32, 64)]:
+for (N, Cin, Cout, H, W) in [(2, 16, 16, 64, 64), (1, 32, 48, 20, 192), (2, 64, 64, 64, 64), (1, 8, 33, 8, 100), (2, 1, 16, 32, 64), (2, 128, 128, 16, 16), (2, 64, 64, 40, 40), (1, 20, 24, 9, 36), (2, 256, 64, 20, 20)]:
     x = rb(_rand((N, Cin, H, W), 1)); x2 = rb(_rand((N, Cin, H, W), 2)); w = _rand((Cout, Cin, 3, 3), 3, 0.1)
     cf = _rand((Cin, 4), 5); cfd = cf.to(dev)
     wp = ops.pack_conv_weight(w.to(dev))
