@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--act-dtype", default="f32", choices=["f32", "bf16"],
                     help="storage type of the activation tensors of the conv stack (bf16: BASELINE config 5's 'bf16 activations'; statistics, parameters and the "
                          "matrix arithmetic stay fp32).  The headline metric is quoted on f32.")
+    ap.add_argument("--mfma", default="f32", choices=["f32", "bf16"],
+                    help="with --act-dtype bf16: matrix arithmetic of the 3x3 stride-1 convs (bf16: v_mfma_f32_16x16x16_bf16 on bf16-rounded operands, fp32 accumulation)")
     ap.add_argument("--stream-calls", type=int, default=8, help="c5: generate_max_style_image calls per pass of the stream (alternating ACDC / Prostate shaped)")
     ap.add_argument("--steady-seconds", type=float, default=2.0, help="length of the extra steady-state leg (graph replays, rank-local); 0 disables")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only: gloo on the CPU, stand-in step (CPU tests)")
@@ -62,7 +64,7 @@ def parse():
     return ap.parse_args()
 
 
-def build(dev, B, size, rank, net=(4, 1, 4), act_dtype=None):
+def build(dev, B, size, rank, net=(4, 1, 4), act_dtype=None, mfma_bf16=False):
     from maxstyle_amd import engine as E
     from maxstyle_amd import synthetic as syn      # procedural weights / images / style states (the GPU leg never imports oracle/)
     spec_o = syn.NetSpec(*net)
@@ -70,7 +72,7 @@ def build(dev, B, size, rank, net=(4, 1, 4), act_dtype=None):
     to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
     spec = E.NetSpec(*net)
     nets = E.PackedNets(spec, to(W["image_encoder"]), to(W["segmentation_decoder"]), to(W["image_decoder"]))
-    eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1, act_dtype=act_dtype)
+    eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1, act_dtype=act_dtype, mfma_bf16=mfma_bf16)
     eng.set_nets(nets)
     img, lab = syn.synthetic_batch(B, size, net[1], net[2], seed=1234 + rank)
     layers = [3, 4, 5]
@@ -501,6 +503,7 @@ def mixed_stream(dev, args, rank, world, dist_on):
         S = maxstyle_amd.AdvancedTripletReconSegmentationModel(network_type=ntype, image_ch=net[1], num_classes=net[2], use_gpu=True)
         if args.act_dtype == "bf16":
             S.loop_act_dtype = torch.bfloat16
+            S.loop_mfma_bf16 = args.mfma == "bf16"
         Wt = syn.procedural_weights(spec, 0)
         for name, mod in S.model.items():
             mod.load_state_dict(Wt[name]); mod.train()
@@ -546,7 +549,8 @@ def mixed_stream(dev, args, rank, world, dist_on):
     return {"metric": "inner adversarial style-opt steps/sec (mixed ACDC 16x1x256x256 K=5 + Prostate 16x3x320x320 K=10 stream, random depth p=0.5)",
             "value": world * steps / dt, "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": dt / max(steps, 1) * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 arithmetic, bf16 activation storage" if args.act_dtype == "bf16" else "f32"), "data": "synthetic",
+            "dtype": (("bf16 matrix arithmetic (fp32 accumulation), bf16 activation storage" if args.mfma == "bf16" else "f32 arithmetic, bf16 activation storage")
+                      if args.act_dtype == "bf16" else "f32"), "data": "synthetic",
             "config": {"workload": f"C5 (this rank's share): {args.stream_calls} generate_max_style_image calls per pass, alternating FCN_16 16x1x256x256 K=5 / FCN_64 16x3x320x320 K=10, "
                                    "MaxStyle layers drawn per call from [3,4,5] with p=0.5, " + ("bf16" if args.act_dtype == "bf16" else "fp32") + " activation storage", "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "hip_graph": True, "passes": passes, "calls_per_pass": args.stream_calls},
@@ -669,7 +673,7 @@ def main():
         if args.size == 256:
             args.size = 320
     bf16 = args.act_dtype == "bf16"
-    eng, W, img, lab, styles, z_i, lab_d = build(dev, args.batch, args.size, rank, net, torch.bfloat16 if bf16 else None)
+    eng, W, img, lab, styles, z_i, lab_d = build(dev, args.batch, args.size, rank, net, torch.bfloat16 if bf16 else None, bf16 and args.mfma == "bf16")
     dt, graphed, run_one = timed_steps(eng, z_i, lab_d, args.steps, args.warmup, not args.no_graph, dist_on)
     if dist_on:
         from maxstyle_amd import distributed as D
@@ -687,7 +691,7 @@ def main():
         res = {
             "metric": "inner adversarial style-opt steps/sec (batch 16, 256x256)", "value": value, "unit": "steps/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": ("f32 arithmetic, bf16 activation storage" if bf16 else "f32"), "data": "synthetic",
+            "vs_baseline": None, "dtype": (("bf16 matrix arithmetic (fp32 accumulation), bf16 activation storage" if args.mfma == "bf16" else "f32 arithmetic, bf16 activation storage") if bf16 else "f32"), "data": "synthetic",
             "config": {"workload": (f"C2: FCN_16 dual-branch, per-GPU batch {args.batch}x1x{args.size}x{args.size}, MaxStyle layers [3,4,5], Adam lr 0.1" if args.config == "c2"
                                     else f"C4: FCN_64 dual-branch, per-GPU batch {args.batch}x3x{args.size}x{args.size}, MaxStyle layers [3,4,5], Adam lr 0.1"),
                        "global_batch": args.batch * n_gpus, "parallelism": f"dp{n_gpus}", "hip_graph": graphed, "world_seen": world,

@@ -361,6 +361,18 @@ int ms_conv2d_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const
                    int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                    int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                    int epi_mode, float* stats, void* stream);
+/* `_bf16m`: bf16 storage AND bf16 matrix arithmetic.  3x3 stride-1 convolutions with rows of >= 16 pixels (W % 4 == 0) run v_mfma_f32_16x16x16_bf16 with
+ * fp32 accumulation: the contraction operands - the prologue's output and the weights - are rounded to bf16 on their way into LDS (relative error <= 2^-9
+ * per operand; the accumulation, the BatchNorm statistics and the epilogue are those of ms_conv2d_bf16).  Every other shape runs ms_conv2d_bf16 unchanged.
+ * Measured against fp64 on the rounded operands: 3.5e-3 of the output range = the bf16 rounding of the stored output. */
+int ms_conv2d_bf16m(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias,
+                    int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                    int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                    int epi_mode, float* stats, void* stream);
+int ms_conv2d_actbwd_bf16m(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed,
+                           int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                           int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                           const uint16_t* u, const float* coef4, float act_slope, float* tab, void* stream);
 int ms_conv1x1_bnres_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
                           const uint16_t* u, const float* coef4, float slope, int up2, void* stream);
 int ms_conv2d_actbwd_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed,

@@ -115,6 +115,8 @@ SIGNATURES = {
 for _n in ("ms_conv2d", "ms_conv1x1_bnres", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd",
            "ms_head_fwd", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_conv_subpix", "ms_conv3x3_small_cout", "ms_style_bwd_actbwd", "ms_style_bwd_actbwd_parts"):
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]
+for _n in ("ms_conv2d", "ms_conv2d_actbwd"):           # bf16 storage + bf16 matrix arithmetic (v_mfma_f32_16x16x16_bf16) where built
+    SIGNATURES[_n + "_bf16m"] = SIGNATURES[_n]
 
 
 class MaxStyleHipError(RuntimeError):

@@ -124,9 +124,7 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   a.Cout = gemm_cols;
   a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (gemm_cols + 63) / 64 * 64;
   a.bw_parts = bw_parts; a.bw_count = (double)N * Hs * Ws; a.bw_out = bw_out;
-  a.act_bf16 = act_bf16;
-  { static const int bfm = getenv("MS_BF16_MFMA") ? atoi(getenv("MS_BF16_MFMA")) : 0;      // EXPERIMENT: bf16 matrix arithmetic in the wide kernel of the `_bf16` entry points
-    if (act_bf16 && bfm) a.act_bf16 = 2; }
+  a.act_bf16 = act_bf16;                  // 0 fp32 storage | 1 bf16 storage, fp32 matrix arithmetic | 2 bf16 storage, bf16 matrix arithmetic where built (`_bf16m`)
   a.pro_mode = pro_mode; a.pro_nstride = pro_nstride; a.pro_cstride = pro_cstride < 1 ? 1 : pro_cstride; a.slope = slope; a.epi_mode = epi_mode;
   if (mk != nullptr) { a.mk_u = mk->u; a.mk_coef = mk->coef4; a.mk_slope = mk->slope; a.mk_tab = mk->tab; }
   if (fin != nullptr) {
@@ -233,6 +231,24 @@ extern "C" int ms_conv2d_actbwd_bf16(const uint16_t* in, const uint16_t* in2, ui
   const MaskEpi mk{as_f(u), coef4, act_slope, tab};
   return conv2d_impl(as_f(in), as_f(in2), as_f(out), w_packed, nullptr, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
                      0, nullptr, &mk, nullptr, stream, 1);
+}
+
+// ---- `_bf16m`: bf16 storage AND bf16 matrix arithmetic.  3x3 stride-1 convolutions with rows of >= 16 pixels run v_mfma_f32_16x16x16_bf16 (fp32 accumulation):
+// their contraction operands - the prologue's output and the weights - are rounded to bf16 on the way into LDS; every other shape is ms_conv2d_bf16.
+extern "C" int ms_conv2d_bf16m(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias,
+                               int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                               int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                               int epi_mode, float* stats, void* stream) {
+  return conv2d_impl(as_f(in), as_f(in2), as_f(out), w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
+                     epi_mode, stats, nullptr, nullptr, stream, 2);
+}
+extern "C" int ms_conv2d_actbwd_bf16m(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed,
+                                      int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                                      int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                                      const uint16_t* u, const float* coef4, float act_slope, float* tab, void* stream) {
+  const MaskEpi mk{as_f(u), coef4, act_slope, tab};
+  return conv2d_impl(as_f(in), as_f(in2), as_f(out), w_packed, nullptr, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
+                     0, nullptr, &mk, nullptr, stream, 2);
 }
 
 extern "C" size_t ms_conv_actbwd_tab_bytes(int Cout) { return ((size_t)Cout * kStatSlots + 1) * sizeof(float2); }

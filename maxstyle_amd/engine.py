@@ -258,7 +258,7 @@ class StyleSlot:
 
 
 class InnerLoopEngine:
-    def __init__(self, spec: NetSpec, B: int, H: int, W: int, device, lr=0.1, act_dtype=None):
+    def __init__(self, spec: NetSpec, B: int, H: int, W: int, device, lr=0.1, act_dtype=None, mfma_bf16=None):
         """act_dtype: storage type of the activation tensors - torch.float32 (default; MS_ACT_DTYPE=bf16 in the environment selects bf16) or torch.bfloat16
         (BASELINE config 5 "bf16 activations": every conv input / output, gradient and image is stored as bf16, statistics / coefficients / parameters / the
         matrix arithmetic stay fp32).  The engine takes fp32 codes and hands back an image of its storage type."""
@@ -271,6 +271,11 @@ class InnerLoopEngine:
             raise TypeError("act_dtype must be torch.float32 or torch.bfloat16")
         self.act_dtype = act_dtype
         self.bf16 = act_dtype == torch.bfloat16
+        # bf16 MATRIX arithmetic on top of bf16 storage (the `_bf16m` conv entry points: 3x3 stride-1 convs run v_mfma_f32_16x16x16_bf16, their operands -
+        # prologue outputs and weights - rounded to bf16; fp32 accumulation / statistics).  MS_MFMA_DTYPE=bf16 selects it too.  Meaningless without bf16 storage.
+        if mfma_bf16 is None:
+            mfma_bf16 = os.environ.get("MS_MFMA_DTYPE", "").lower() in ("bf16", "bfloat16")
+        self.mfma_bf16 = bool(mfma_bf16) and self.bf16
         self.buf: Dict[str, torch.Tensor] = {}
         self.nets: Optional[PackedNets] = None
         self.styles: Dict[int, StyleSlot] = {}
@@ -353,6 +358,8 @@ class InnerLoopEngine:
         """The library entry point for this engine's activation storage type (`_bf16` twin in bf16 mode: include/maxstyle_hip.h)."""
         if self.bf16:
             assert name in self._BF16_TWINS, name + " has no bf16 twin"
+            if self.mfma_bf16 and name in ("ms_conv2d", "ms_conv2d_actbwd"):
+                return getattr(lib, name + "_bf16m")
             return getattr(lib, name + "_bf16")
         return getattr(lib, name)
 

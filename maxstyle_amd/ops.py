@@ -54,7 +54,9 @@ def _acts(*ts):
     return bool(flags and flags.pop())
 
 
-def _fn(name, bf16):
+def _fn(name, bf16, mfma_bf16=False):
+    if bf16 and mfma_bf16:
+        return getattr(lib, name + "_bf16m")
     return getattr(lib, name + "_bf16") if bf16 else getattr(lib, name)
 
 
@@ -194,8 +196,8 @@ def conv_out_hw(Hs, Ws, ks, stride, fetch):
 
 
 def conv2d(x, wp, bias, Cout, ks, stride=1, fetch=FETCH_NORMAL, pro_mode=0, pro_a=None, pro_b=None, pro_c=None, pro_nstride=0,
-           pro_cstride=1, slope=1.0, epi_mode=0, out=None, stats=None, in2=None):
-    """ms_conv2d wrapper. Returns out ([N,Cout,Hout,Wout], or [N,Cout,2H,2W] for the ConvTranspose epilogue)."""
+           pro_cstride=1, slope=1.0, epi_mode=0, out=None, stats=None, in2=None, mfma_bf16=False):
+    """ms_conv2d wrapper (bf16 tensors: ms_conv2d_bf16, or ms_conv2d_bf16m with mfma_bf16=True). Returns out ([N,Cout,Hout,Wout], or [N,Cout,2H,2W] for the ConvTranspose epilogue)."""
     _need_cuda_f32(wp, bias, pro_a, pro_b, pro_c, stats)
     bf = _acts(x, in2, out)
     N, Cin, Hs, Ws = x.shape
@@ -205,12 +207,12 @@ def conv2d(x, wp, bias, Cout, ks, stride=1, fetch=FETCH_NORMAL, pro_mode=0, pro_
         if epi_mode == 1:
             raise ValueError("accumulate epilogue needs an existing `out`")
         out = torch.empty(shape, device=x.device, dtype=x.dtype)
-    check(_fn("ms_conv2d", bf)(x.data_ptr(), _ptr(in2), out.data_ptr(), wp.data_ptr(), _ptr(bias), N, Cin, Hs, Ws, Cout, ks, stride, fetch,
+    check(_fn("ms_conv2d", bf, mfma_bf16)(x.data_ptr(), _ptr(in2), out.data_ptr(), wp.data_ptr(), _ptr(bias), N, Cin, Hs, Ws, Cout, ks, stride, fetch,
                         pro_mode, _ptr(pro_a), _ptr(pro_b), _ptr(pro_c), pro_nstride, pro_cstride, slope, epi_mode, _ptr(stats), _stream()), "ms_conv2d")
     return out
 
 
-def conv2d_actbwd(x, wp, Cout, ks, u, coef4, act_slope, pro_mode=0, pro_a=None, pro_b=None, pro_c=None, pro_cstride=1, slope=1.0, in2=None, stride=1):
+def conv2d_actbwd(x, wp, Cout, ks, u, coef4, act_slope, pro_mode=0, pro_a=None, pro_b=None, pro_c=None, pro_cstride=1, slope=1.0, in2=None, stride=1, mfma_bf16=False):
     """ms_conv2d_actbwd wrapper: conv (no bias) -> * LeakyReLU'(coef4.scale*u + coef4.shift) -> (out, tab); tab feeds bn_bwd_coefs(tab, 0, ...)."""
     _need_cuda_f32(wp, coef4, pro_a, pro_b, pro_c)
     bf = _acts(x, u, in2)
@@ -218,7 +220,7 @@ def conv2d_actbwd(x, wp, Cout, ks, u, coef4, act_slope, pro_mode=0, pro_a=None, 
     Ho, Wo = conv_out_hw(Hs, Ws, ks, stride, FETCH_NORMAL)
     out = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=x.dtype)
     tab = torch.full((lib.ms_conv_actbwd_tab_bytes(Cout) // 4,), float("nan"), device=x.device, dtype=torch.float32)
-    check(_fn("ms_conv2d_actbwd", bf)(x.data_ptr(), _ptr(in2), out.data_ptr(), wp.data_ptr(), N, Cin, Hs, Ws, Cout, ks, stride, FETCH_NORMAL,
+    check(_fn("ms_conv2d_actbwd", bf, mfma_bf16)(x.data_ptr(), _ptr(in2), out.data_ptr(), wp.data_ptr(), N, Cin, Hs, Ws, Cout, ks, stride, FETCH_NORMAL,
                                pro_mode, _ptr(pro_a), _ptr(pro_b), _ptr(pro_c), 0, pro_cstride, slope, u.data_ptr(), coef4.data_ptr(), act_slope,
                                tab.data_ptr(), _stream()), "ms_conv2d_actbwd")
     return out, tab

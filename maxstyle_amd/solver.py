@@ -262,8 +262,9 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     # "bf16 activations": conv inputs / outputs, gradients and the image are stored as bf16 inside the loop, statistics / parameters / arithmetic fp32; the
     # returned image is fp32 as in the reference).  MS_ACT_DTYPE=bf16 in the environment selects it too.  Module forwards (predict / evaluate / training) are fp32.
     loop_act_dtype = None
+    loop_mfma_bf16 = None      # with bf16 storage: also bf16 matrix arithmetic in the 3x3 stride-1 convs (engine.mfma_bf16; MS_MFMA_DTYPE=bf16)
 
-    def _loop_engine(self, B, H, W, dev, act_dtype=torch.float32):
+    def _loop_engine(self, B, H, W, dev, act_dtype=torch.float32, mfma_bf16=False):
         key = self._weights_key()
         spec = E.NetSpec(self.reduce_factor, self.image_ch, self.num_classes)
         if self._packed_key != key:
@@ -285,10 +286,11 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                 for eng in self._engines.values():
                     eng._prefix_valid = False
             self._packed_key = key
-        ek = (B, H, W, str(dev)) if act_dtype == torch.float32 else (B, H, W, str(dev), str(act_dtype))
+        mfma_bf16 = bool(mfma_bf16) and act_dtype == torch.bfloat16
+        ek = (B, H, W, str(dev)) if act_dtype == torch.float32 else (B, H, W, str(dev), str(act_dtype), mfma_bf16)
         eng = self._engines.get(ek)
         if eng is None:
-            eng = E.InnerLoopEngine(spec, B, H, W, dev, act_dtype=act_dtype)
+            eng = E.InnerLoopEngine(spec, B, H, W, dev, act_dtype=act_dtype, mfma_bf16=mfma_bf16)
             eng.set_nets(self._packed)
             self._engines[ek] = eng
         return eng
@@ -339,7 +341,10 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             act = self.loop_act_dtype
             if act is None:
                 act = torch.bfloat16 if os.environ.get("MS_ACT_DTYPE", "").lower() in ("bf16", "bfloat16") else torch.float32
-            eng = self._loop_engine(B, h * 16, w * 16, code.device, act_dtype=act)
+            mf = self.loop_mfma_bf16
+            if mf is None:
+                mf = os.environ.get("MS_MFMA_DTYPE", "").lower() in ("bf16", "bfloat16")
+            eng = self._loop_engine(B, h * 16, w * 16, code.device, act_dtype=act, mfma_bf16=mf)
             mods = {int(k): m for k, m in nn_style_augmentor_dict.items()}
             slots = E.slots_from_modules(mods, code.device)
             layers = [i for i in sorted(mods) if i in slots]
