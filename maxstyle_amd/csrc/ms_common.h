@@ -130,6 +130,11 @@ template <> struct ActIO<ms_bf16> {
 struct ms_bf16m { uint16_t v; };
 template <> struct ActIO<ms_bf16m> : ActIO<ms_bf16> {};
 
+// ms_f32w: fp32 storage, fp32 matrix arithmetic on the WINOGRAD F(2x2, 3x3) form of the 3x3 stride-1 convolution (wide conv kernel, "Winograd mode"):
+// 16 products per 2x2 output pixels instead of 36.  Loads / stores are those of float.
+struct ms_f32w { float v; };
+template <> struct ActIO<ms_f32w> : ActIO<float> {};
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

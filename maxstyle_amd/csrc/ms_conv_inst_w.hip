@@ -24,7 +24,23 @@ static int wide_pro(const ConvArgs& a, hipStream_t st) {
     default: return launch_conv_wide_r<NT, 2, 1>(a, st);
   }
 }
+// Winograd F(2x2, 3x3) mode of the wide kernel (ms_conv_wide.h, AT = ms_f32w): fp32 storage, channel count a multiple of the 8-channel chunk
+static bool conv_wino_on(const ConvArgs& a, int nt) {
+  static const int mode = getenv("MS_CONV_WINO") ? atoi(getenv("MS_CONV_WINO")) : 1;      // A/B switch: 0 = direct form everywhere
+  static const int max_cb = getenv("MS_CONV_WINO_MAXCB") ? atoi(getenv("MS_CONV_WINO_MAXCB")) : 1 << 20;
+  if (mode == 0 || a.act_bf16 != 0 || a.cin_pad % 8 != 0 || a.Cin != a.cin_pad) return false;
+  (void)nt;
+  return cdiv(a.Cout, 16) <= max_cb;
+}
+static int wide_wino(const ConvArgs& a, hipStream_t st) {
+  switch (a.pro_mode) {
+    case 0: return launch_conv_wide_t<1, 0, 1, true, ms_f32w>(a, st);
+    case 1: return launch_conv_wide_t<1, 1, 1, true, ms_f32w>(a, st);
+    default: return launch_conv_wide_t<1, 2, 1, true, ms_f32w>(a, st);
+  }
+}
 int conv_dispatch_wide(const ConvArgs& a, int nt, hipStream_t st) {
+  if (conv_wino_on(a, nt)) return wide_wino(a, st);
   if (conv_wide_rows(a, nt >= 2 ? 2 : 1) == 8) return conv_dispatch_wide8(a, nt, st);
   return nt >= 2 ? wide_pro<2>(a, st) : wide_pro<1>(a, st);
 }

@@ -62,6 +62,22 @@ struct WideGeoBF {
   static constexpr int W_ITEMS = 9 * CK * (16 * NT / 4), NWI = (W_ITEMS + 255) / 256;
 };
 
+// Geometry of the Winograd mode (AT = ms_f32w): F(2x2, 3x3), one channel block per lane.  The staged input tile is the fp32 one (same rows / columns / halo);
+// its plane stride is == 32 (mod 64 dwords) so that the 8-byte patch reads of the four K lanes groups of a wave fall on disjoint banks.  The weight region of a
+// stage holds the chunk's TRANSFORMED weights U = G g G^T as [16 positions][CK channels][16 output channels]: a lane's B fragment of position p and channel
+// group cg is one ds_read_b32 at p*128 + cg*64 + lane (64 consecutive dwords per wave: conflict-free).
+template <int PRO>
+struct WideGeoW {
+  static constexpr int TH = 4, TW = 64, CK = 8, IH = TH + 2;
+  static constexpr int RS = TW + 4;
+  static constexpr int PS = 416;                                  // >= IH*RS = 408, == 32 (mod 64)
+  static constexpr int WS = 16;
+  static constexpr int BUF = CK * PS + 16 * CK * 16;              // floats per stage buffer
+  static constexpr int Q_ITEMS = CK * IH * (TW / 4), H_ITEMS = CK * IH * 2;
+  static constexpr int NQI = (Q_ITEMS + 255) / 256, NHI = (H_ITEMS + 255) / 256;
+  static constexpr int W_ITEMS = CK * 16, NWI = 1;
+};
+
 // census of workgroup arrivals per CU (stagger experiment): which of the two co-resident workgroups am I?  Timing only - never read for results.
 static __device__ int g_cu_census[1024];
 
@@ -71,7 +87,9 @@ static __device__ int g_cu_census[1024];
 template <int NT, int PRO, int R, bool AF, typename AT = float>
 __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const ConvArgs a) {
   constexpr bool BFM = std::is_same<AT, ms_bf16m>::value;         // bf16 matrix arithmetic (needs R == 1)
-  using G = typename std::conditional<BFM, WideGeoBF<NT, PRO>, WideGeo<NT, PRO, R>>::type;
+  constexpr bool WIN = std::is_same<AT, ms_f32w>::value;          // Winograd F(2x2, 3x3) (needs R == 1, NT == 1, every chunk full)
+  static_assert(!WIN || (R == 1 && NT == 1 && AF), "Winograd mode: 4-row tiles, one channel block per lane, channel count a multiple of the chunk");
+  using G = typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WIN, WideGeoW<PRO>, WideGeo<NT, PRO, R>>::type>::type;
   using IO = ActIO<AT>;
   constexpr int AB = IO::kBytes;
   static_assert(!BFM || R == 1, "bf16 MFMA mode: 4-row tiles");
@@ -197,6 +215,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     float rq[BFM ? 1 : NQI][4], rq2[(PRO == 2 && !BFM) ? NQI : 1][4], rh[NHI], rh2[PRO == 2 ? NHI : 1];
     unsigned rqp[BFM ? NQI : 1][2], rqp2[(BFM && PRO == 2) ? NQI : 1][2];      // bf16-MFMA mode (16-channel chunks): the quads stay PACKED in registers until the LDS store
     float4 rw[NWI];
+    float rww[WIN ? 9 : 1];                         // Winograd mode: the 9 taps of this thread's (input channel, output channel) pair
     mask_t l_q_ok = 0, l_h_ok = 0;                  // masks of the chunk held in registers
     bool l_edge = false, have_w = false;
     float ca[NQI], cb_[NQI], cc[PRO == 2 ? NQI : 1], hca[NHI], hcb[NHI], hcc[PRO == 2 ? NHI : 1];   // prologue coefficients of the chunk in registers
@@ -280,6 +299,12 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         }
       }
       have_w = load_w;
+      if constexpr (WIN) {
+        if (load_w && tid < G::W_ITEMS) {
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) rww[tap] = a.w[((size_t)tap * a.cin_pad + c0 + (tid >> 4)) * a.cout_pad + co0 + (tid & 15)];
+        }
+      } else
       if (load_w) {
 #pragma unroll
         for (int j = 0; j < NWI; ++j) {
@@ -335,6 +360,24 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         if constexpr (BFM) *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(buf) + (h_lds[j] & 0xFFFFF)) = ms_to_bf16(((l_h_ok >> j) & 1u) ? v : 0.f);
         else buf[h_lds[j] & 0xFFFFF] = ((l_h_ok >> j) & 1u) ? v : 0.f;
       }
+      if constexpr (WIN) {
+        if (have_w && tid < G::W_ITEMS) {
+          // U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: position p = 4*xi + nu (xi along ky, nu along kx)
+          float t[4][3];
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float g0 = rww[kx], g1 = rww[3 + kx], g2 = rww[6 + kx];
+            t[0][kx] = g0; t[1][kx] = 0.5f * ((g0 + g2) + g1); t[2][kx] = 0.5f * ((g0 + g2) - g1); t[3][kx] = g2;
+          }
+#pragma unroll
+          for (int xi = 0; xi < 4; ++xi) {
+            const float u0 = t[xi][0], u3 = t[xi][2];
+            const float u1 = 0.5f * ((t[xi][0] + t[xi][2]) + t[xi][1]), u2 = 0.5f * ((t[xi][0] + t[xi][2]) - t[xi][1]);
+            w_lds[(xi * 4 + 0) * 128 + tid] = u0; w_lds[(xi * 4 + 1) * 128 + tid] = u1;
+            w_lds[(xi * 4 + 2) * 128 + tid] = u2; w_lds[(xi * 4 + 3) * 128 + tid] = u3;
+          }
+        }
+      } else
       if (have_w) {
 #pragma unroll
         for (int j = 0; j < NWI; ++j) {
@@ -460,6 +503,62 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       }
     }
   };
+  // Winograd mode: wave = (tile row tr = wave >> 1: output rows 2tr, 2tr+1; half h = wave & 1: 32 pixels = 16 tiles of 2x2); MFMA M index = tile, N = output
+  // channel, K = input channel.  Per 4-channel group: the lane's 4x4 input patch (tile m, channel 4cg+k) = 8 ds_read_b64, V = B^T d B in registers
+  // (32 additions), 16 B fragments (one ds_read_b32 per position), 16 MFMAs - one per position, 16 independent accumulators.
+  f32x4 accw[WIN ? 16 : 1];
+  auto compute_w = [&](const float* buf, auto first_tag) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (WIN) {
+      const float* ab = buf + k * PS + (2 * (wave >> 1)) * RS + 32 * (wave & 1) + 2 * m;
+      const float* ub = buf + CK * PS + lane;
+#pragma unroll
+      for (int cg = 0; cg < CK / 4; ++cg) {
+        // Register budget (128 with two workgroups per CU): 64 accumulators + up to 16 prefetched mask values leave ~30 for operands, so the order is fixed by
+        // hand (sched_barrier): patch rows are read in the order the position rows need them (d0 d2 | d1 | d3), B fragments one position row ahead.
+        const float* pa = ab + cg * 4 * PS;
+        const float* pu = ub + cg * 64;
+        auto ldrow = [&](int r, float (&dr)[4]) {
+          const float2 lo = *reinterpret_cast<const float2*>(pa + r * RS);
+          const float2 hi = *reinterpret_cast<const float2*>(pa + r * RS + 2);
+          dr[0] = lo.x; dr[1] = lo.y; dr[2] = hi.x; dr[3] = hi.y;
+        };
+        auto ldu = [&](int xi, float (&u)[4]) {
+#pragma unroll
+          for (int nu = 0; nu < 4; ++nu) u[nu] = pu[(xi * 4 + nu) * 128];
+        };
+        auto row4 = [&](int xi, const float (&t)[4], const float (&u)[4]) {
+          const float v0 = t[0] - t[2], v1 = t[1] + t[2], v2 = t[2] - t[1], v3 = t[1] - t[3];
+          accw[xi * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, u[0], (FIRST && cg == 0) ? zero4 : accw[xi * 4 + 0], 0, 0, 0);
+          accw[xi * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, u[1], (FIRST && cg == 0) ? zero4 : accw[xi * 4 + 1], 0, 0, 0);
+          accw[xi * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, u[2], (FIRST && cg == 0) ? zero4 : accw[xi * 4 + 2], 0, 0, 0);
+          accw[xi * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v3, u[3], (FIRST && cg == 0) ? zero4 : accw[xi * 4 + 3], 0, 0, 0);
+        };
+        float d0[4], d1[4], d2[4], d3[4], ua[4], ub2[4], t[4];
+        ldrow(0, d0); ldrow(2, d2); ldu(0, ua); ldrow(1, d1); ldu(1, ub2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] = d0[c] - d2[c];
+        row4(0, t, ua);
+        ldu(2, ua); ldrow(3, d3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] = d1[c] + d2[c];
+        row4(1, t, ub2);
+        ldu(3, ub2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] = d2[c] - d1[c];
+        row4(2, t, ua);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] = d1[c] - d3[c];
+        row4(3, t, ub2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
   // FULL = every channel group of the chunk is live: straight-line code; the guarded form only runs for a layer's ragged last chunk
   // FIRST = first K-chunk of an item: the first MFMA of every accumulator takes a zero C operand (no clearing pass after the epilogue)
   auto compute = [&](const float* buf, auto full_tag, int ncg, auto first_tag) __attribute__((always_inline)) {
@@ -467,6 +566,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     constexpr bool FIRST = decltype(first_tag)::value;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (BFM) { compute_bf(buf, first_tag); return; }
+    if constexpr (WIN) { compute_w(buf, first_tag); return; }
     float win[2][6], bfr[3][3][NT];
     load_win(buf, 0, 0, win[0]);
     load_b(buf, 0, 0, bfr[0]);
@@ -664,6 +764,195 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     }
   };
 
+  // ---- Winograd mode: output transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) in registers - a lane holds all 16 positions of its 4 tiles (4k..4k+3 of the
+  // wave's 16) for channel m - then the epilogue on 2 rows x 8 consecutive pixels (x = 32h + 8k ..) per lane.  upre[0][2*row + quad] = the mask tensor's values.
+  auto wino_geo = [&](int tile, int& xb, int& y0) { const int tx = tile % a.tiles_x, ty = tile / a.tiles_x; xb = tx * TW + 32 * (wave & 1) + 8 * k; y0 = ty * TH + 2 * (wave >> 1); };
+  // interior tiles: buffer addressing as in epilogue_fast below - resource = image n, scalar offset = (channel block, row, first column of the wave's half),
+  // vector offset = the lane's hoisted (channel m, pixel group k) offset; stores carry the row offset in the vector offset (see bstore4)
+  const int w_plane = a.Hout * a.Wout;
+  const int w_voff = AB * (m * w_plane + 8 * k);
+  typedef unsigned wu32x4_t __attribute__((ext_vector_type(4)));
+  auto w_rsrc = [&](const float* base, int n) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + (ptrdiff_t)n * a.Cout * w_plane * AB, 0, 0x7FFFFFFF, 0x00020000);
+  };
+  auto w_soff = [&](int tile, int co0, int row) {
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    return AB * ((co0 * a.Hout + ty * TH + 2 * (wave >> 1) + row) * a.Wout + tx * TW + 32 * (wave & 1));
+  };
+  auto w_load4 = [&](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const wu32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+  };
+  auto w_store4 = [&](__amdgpu_buffer_rsrc_t r, int voff, float4 v) {
+    const wu32x4_t w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, 0, 0);
+  };
+  // mask-tensor values of the item (epi_mode 3): 16 per lane.  With 64 accumulators there are no registers to park them across the MFMA loop, so they are
+  // requested at the start of the item STRAIGHT INTO LDS (buffer_load_dwordx4 ... lds: lane l's 16 bytes land at base + 16 l, no vector register involved)
+  // and read back by the epilogue: 4 KB per MFMA wave behind the coefficient table.
+  float* u_lds = smem + 2 * BUF + (PRO != 0 ? 4 * (nchunks * CK) : 0) + wave * 1024;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  auto wino_interior = [&](int tile, int co0) {
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    return (tx * TW + TW <= a.Wout) && (ty * TH + TH <= a.Hout) && (co0 + 16 <= a.Cout) && !(a.dbg & 32);
+  };
+  auto prefetch_u_w = [&](int n, int tile, int co0) __attribute__((always_inline)) {
+    if constexpr (WIN) {
+      if (!wino_interior(tile, co0)) return;            // border tiles load their (masked) values inside the epilogue
+      const __amdgpu_buffer_rsrc_t ru = w_rsrc(a.mk_u, n);
+#pragma unroll
+      for (int row = 0; row < 2; ++row) {
+        const int so = w_soff(tile, co0, row);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(u_lds + (2 * row + q) * 256), 16, w_voff + 16 * q, so, 0, 0);
+      }
+    }
+  };
+  // (the transform runs ONCE, before the epilogue variants branch: 64 accumulators must not stay live across their joins)
+  auto wino_out = [&](float (&o)[2][8]) __attribute__((always_inline)) {
+    if constexpr (WIN) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s[2][4];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+          const float m0 = accw[nu][r], m1 = accw[4 + nu][r], m2 = accw[8 + nu][r], m3 = accw[12 + nu][r];
+          s[0][nu] = (m0 + m1) + m2; s[1][nu] = (m1 - m2) - m3;
+        }
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+          o[row][2 * r] = (s[row][0] + s[row][1]) + s[row][2];
+          o[row][2 * r + 1] = (s[row][1] - s[row][2]) - s[row][3];
+        }
+      }
+    }
+  };
+  auto epilogue_w = [&](int n, int tile, int co0, float (&o)[2][8], auto interior_tag) __attribute__((always_inline)) {
+    constexpr bool INT = decltype(interior_tag)::value;
+    if constexpr (WIN) {
+      if (a.dbg & 16) return;
+      int xb, y0; wino_geo(tile, xb, y0);
+      const int co = co0 + m;
+      if (a.bias != nullptr) {
+#pragma unroll
+        for (int row = 0; row < 2; ++row)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[row][e] += bias_v[0];
+      }
+      const int nvx = INT ? 8 : max(0, min(8, a.Wout - xb));       // valid pixels among this lane's 8 per row (Wout % 4 == 0 on this path)
+      bool ok[2][2];
+#pragma unroll
+      for (int row = 0; row < 2; ++row)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) ok[row][q] = INT || ((y0 + row < a.Hout) && (4 * q < nvx));
+      if (a.stats != nullptr) {
+        // per-lane running (count, mean, M2): this item's group = the valid quads of the lane's 2 x 8 pixels (see the generic epilogue)
+        int cnt_i = 0; float sm = 0.f;
+#pragma unroll
+        for (int row = 0; row < 2; ++row)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            if (ok[row][q]) { cnt_i += 4; sm += (o[row][4 * q] + o[row][4 * q + 1]) + (o[row][4 * q + 2] + o[row][4 * q + 3]); }
+        if (INT || cnt_i > 0) {
+          const float cnt = INT ? 16.f : (float)cnt_i;
+          const float rc = (INT || cnt_i == 16) ? 0.0625f : __builtin_amdgcn_rcpf(cnt);
+          const float mean = sm * rc;
+          float qq = 0.f;
+#pragma unroll
+          for (int row = 0; row < 2; ++row)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+              if (ok[row][q]) {
+                const float d0 = o[row][4 * q] - mean, d1 = o[row][4 * q + 1] - mean, d2 = o[row][4 * q + 2] - mean, d3 = o[row][4 * q + 3] - mean;
+                qq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+              }
+          const float nt_ = st_n + cnt;
+          const float wgt = cnt * __builtin_amdgcn_rcpf(nt_);
+          const float dd = mean - st_mean[0];
+          st_mean[0] += dd * wgt;
+          st_m2[0] += qq + dd * dd * st_n * wgt;
+          st_n = nt_;
+        }
+      }
+      if (!INT && co >= a.Cout) return;
+      const __amdgpu_buffer_rsrc_t ro = w_rsrc(a.out, n);
+      if (a.epi_mode == 3) {
+        float4 um[2][2];
+        if constexpr (INT) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the item's LDS-destined loads have landed
+#pragma unroll
+          for (int i = 0; i < 4; ++i) um[i >> 1][i & 1] = *reinterpret_cast<const float4*>(u_lds + i * 256 + lane * 4);
+        } else {
+#pragma unroll
+          for (int row = 0; row < 2; ++row) {
+            const size_t off = (((size_t)n * a.Cout + co) * a.Hout + (y0 + row)) * a.Wout + xb;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) um[row][q] = ok[row][q] ? IO::ld4(a.mk_u, off + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+          const size_t off = (((size_t)n * a.Cout + co) * a.Hout + (y0 + row)) * a.Wout + xb;
+          const int st_voff = w_voff + w_soff(tile, co0, row);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if (ok[row][q]) {
+              const float4 uu = um[row][q];
+              float4 v;
+              v.x = o[row][4 * q] * ((mk_sc[0] * uu.x + mk_sh[0] > 0.f) ? 1.f : a.mk_slope);
+              v.y = o[row][4 * q + 1] * ((mk_sc[0] * uu.y + mk_sh[0] > 0.f) ? 1.f : a.mk_slope);
+              v.z = o[row][4 * q + 2] * ((mk_sc[0] * uu.z + mk_sh[0] > 0.f) ? 1.f : a.mk_slope);
+              v.w = o[row][4 * q + 3] * ((mk_sc[0] * uu.w + mk_sh[0] > 0.f) ? 1.f : a.mk_slope);
+              if constexpr (INT) w_store4(ro, st_voff + 16 * q, v); else IO::st4(a.out, off + 4 * q, v);
+              s1 += (v.x + v.y) + (v.z + v.w);
+              s2 += (v.x * (uu.x - mk_mu[0]) + v.y * (uu.y - mk_mu[0])) + (v.z * (uu.z - mk_mu[0]) + v.w * (uu.w - mk_mu[0]));
+            }
+          }
+        }
+        st_mean[0] += s1; st_m2[0] += s2;
+      } else if (a.epi_mode == 1) {
+        float4 pv[2][2];
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+          const size_t off = (((size_t)n * a.Cout + co) * a.Hout + (y0 + row)) * a.Wout + xb;
+          const int so = w_soff(tile, co0, row);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if constexpr (INT) pv[row][q] = w_load4(ro, w_voff + 16 * q, so);
+            else pv[row][q] = ok[row][q] ? IO::ld4(a.out, off + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+          const size_t off = (((size_t)n * a.Cout + co) * a.Hout + (y0 + row)) * a.Wout + xb;
+          const int st_voff = w_voff + w_soff(tile, co0, row);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if (ok[row][q]) {
+              const float4 v = make_float4(o[row][4 * q] + pv[row][q].x, o[row][4 * q + 1] + pv[row][q].y, o[row][4 * q + 2] + pv[row][q].z, o[row][4 * q + 3] + pv[row][q].w);
+              if constexpr (INT) w_store4(ro, st_voff + 16 * q, v); else IO::st4(a.out, off + 4 * q, v);
+            }
+          }
+        }
+      } else if (!(a.dbg & 4)) {
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+          const size_t off = (((size_t)n * a.Cout + co) * a.Hout + (y0 + row)) * a.Wout + xb;
+          const int st_voff = w_voff + w_soff(tile, co0, row);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if (ok[row][q]) {
+              const float4 v = make_float4(o[row][4 * q], o[row][4 * q + 1], o[row][4 * q + 2], o[row][4 * q + 3]);
+              if constexpr (INT) w_store4(ro, st_voff + 16 * q, v); else IO::st4(a.out, off + 4 * q, v);
+            }
+          }
+        }
+      }
+    }
+  };
+
   // ---- interior items (every pixel, row and channel of the tile exists; 4-row tiles): no masks, and buffer addressing - resource base = image n,
   // scalar offset = (channel block, row, tile column), vector offset = the lane's hoisted (channel m, pixel group k) offset: the 64-bit address arithmetic
   // of the generic epilogue (~15 vector instructions per row) and its per-quad selects are gone.  Same arithmetic, same order: bit-identical results.
@@ -812,6 +1101,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       const int ncg = AF ? CK / 4 : min(CK / 4, (a.cin_pad - ch * CK) / 4);
       if (tr && p < 16) a.trace[p * 4 + 0] = clock64();
       if (a.dbg & 1) {
+        if constexpr (WIN) { if (decltype(first_tag)::value) { for (int q = 0; q < 16; ++q) accw[q] = f32x4{0.f, 0.f, 0.f, 0.f}; } }
         if (decltype(first_tag)::value) {
 #pragma unroll
           for (int r = 0; r < R; ++r)
@@ -829,10 +1119,11 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     };
     for (int it = 0; it < my_items; ++it) {
       const int co0 = cb * COUT_TILE;
-      constexpr bool FAST = (NT == 1 && R == 1);      // (two channel blocks per lane: the fast epilogue's extra live values push the kernel past 128 registers = one workgroup per CU)
+      constexpr bool FAST = (NT == 1 && R == 1 && !WIN);      // (two channel blocks per lane: the fast epilogue's extra live values push the kernel past 128 registers = one workgroup per CU)
       const bool interior = FAST && !(a.dbg & 32) && tile_interior(tile, co0);      // (dbg bit 32: generic epilogue everywhere - A/B switch)
       auto pre_u = [&]() __attribute__((always_inline)) {
         if constexpr (FAST) { if (interior && !(a.dbg & 64)) { prefetch_u_fast(n, tile, co0); return; } }
+        if constexpr (WIN) { prefetch_u_w(n, tile, co0); return; }
         prefetch_u(n, tile, co0);
       };
       if (UPRE && a.epi_mode == 3) pre_u();            // at the START of the item: the registers are reserved anyway, and in a step the mask tensor is cold
@@ -845,6 +1136,13 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       }
       bool done = false;
       if constexpr (FAST) { if (interior) { epilogue_fast(n, tile, co0); done = true; } }
+      if constexpr (WIN) {
+        float o[2][8];
+        wino_out(o);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wino_interior(tile, co0)) epilogue_w(n, tile, co0, o, std::true_type{}); else epilogue_w(n, tile, co0, o, std::false_type{});
+        done = true;
+      }
       if (!done) epilogue(n, tile, co0);
       if (tr && p < 16) a.trace[p * 4 + 2] = clock64();
       item += gridDim.x;
@@ -865,16 +1163,18 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 
 template <int NT, int PRO, int R, bool AF, typename AT>
 int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
-  using G = typename std::conditional<std::is_same<AT, ms_bf16m>::value, WideGeoBF<NT, PRO>, WideGeo<NT, PRO, R>>::type;
+  using G = typename std::conditional<std::is_same<AT, ms_bf16m>::value, WideGeoBF<NT, PRO>,
+                                      typename std::conditional<std::is_same<AT, ms_f32w>::value, WideGeoW<PRO>, WideGeo<NT, PRO, R>>::type>::type;
   const size_t cin_tab = (PRO != 0) ? (size_t)cdiv(a.cin_pad, G::CK) * G::CK : 0;              // coefficient table: one float4 per input channel of the padded chunks
-  const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab);
+  const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab) + (std::is_same<AT, ms_f32w>::value ? 16 * 1024 : 0);      // Winograd mode: + the mask tensor's landing zone
   if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
   static std::once_flag attr_once;                     // one flag per instantiation; the attribute itself is immutable afterwards
   std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO, R, AF, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
   a.tiles_x = cdiv(a.Wout, G::TW); a.tiles_y = cdiv(a.Hout, G::TH);
   a.ncb = cdiv(a.Cout, 16 * NT);
   const long nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb;
-  const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));
+  static const int cu_cap = getenv("MS_WIDE_PER_CU") ? atoi(getenv("MS_WIDE_PER_CU")) : 2;      // A/B switch: workgroups per CU of the persistent grid
+  const int per_cu = std::max(1, std::min(NT == 1 ? cu_cap : 2, (int)((160 * 1024) / (lds_bytes + 256))));
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;
   MS_LAUNCH((conv_wide_kernel<NT, PRO, R, AF, AT>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
