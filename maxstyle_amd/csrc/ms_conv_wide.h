@@ -519,42 +519,42 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         // hand (sched_barrier): patch rows are read in the order the position rows need them (d0 d2 | d1 | d3), B fragments one position row ahead.
         const float* pa = ab + cg * 4 * PS;
         const float* pu = ub + cg * 64;
-        auto ldrow = [&](int r, float (&dr)[4]) {
-          const float2 lo = *reinterpret_cast<const float2*>(pa + r * RS);
-          const float2 hi = *reinterpret_cast<const float2*>(pa + r * RS + 2);
-          dr[0] = lo.x; dr[1] = lo.y; dr[2] = hi.x; dr[3] = hi.y;
+        // the patch rows stay in the register PAIRS the 8-byte reads deliver: (d0,d1) and (d2,d3) of a row.  Row transform = 2 packed additions per
+        // position row; column transform (a,b | c,e) -> (a-c, b+c, c-b, b-e) = one packed subtraction (v0, v3) + two scalar ones: 5 vector instructions
+        // per 4 MFMAs, each computed one position row AHEAD of the MFMAs that read it (no wait states between a v_add and the MFMA behind it).
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        auto ldrow = [&](int r, f2& lo, f2& hi) {
+          lo = *reinterpret_cast<const f2*>(pa + r * RS);
+          hi = *reinterpret_cast<const f2*>(pa + r * RS + 2);
         };
         auto ldu = [&](int xi, float (&u)[4]) {
 #pragma unroll
           for (int nu = 0; nu < 4; ++nu) u[nu] = pu[(xi * 4 + nu) * 128];
         };
-        auto row4 = [&](int xi, const float (&t)[4], const float (&u)[4]) {
-          const float v0 = t[0] - t[2], v1 = t[1] + t[2], v2 = t[2] - t[1], v3 = t[1] - t[3];
-          accw[xi * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, u[0], (FIRST && cg == 0) ? zero4 : accw[xi * 4 + 0], 0, 0, 0);
-          accw[xi * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, u[1], (FIRST && cg == 0) ? zero4 : accw[xi * 4 + 1], 0, 0, 0);
-          accw[xi * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, u[2], (FIRST && cg == 0) ? zero4 : accw[xi * 4 + 2], 0, 0, 0);
-          accw[xi * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v3, u[3], (FIRST && cg == 0) ? zero4 : accw[xi * 4 + 3], 0, 0, 0);
+        auto vrow = [&](f2 ta, f2 tb, float (&v)[4]) {
+          const f2 w = ta - tb;
+          v[0] = w.x; v[3] = w.y; v[1] = ta.y + tb.x; v[2] = tb.x - ta.y;
         };
-        float d0[4], d1[4], d2[4], d3[4], ua[4], ub2[4], t[4];
-        ldrow(0, d0); ldrow(2, d2); ldu(0, ua); ldrow(1, d1); ldu(1, ub2);
-        __builtin_amdgcn_sched_barrier(0);
+        auto mm = [&](int xi, const float (&v)[4], const float (&u)[4]) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) t[c] = d0[c] - d2[c];
-        row4(0, t, ua);
-        ldu(2, ua); ldrow(3, d3);
+          for (int nu = 0; nu < 4; ++nu)
+            accw[xi * 4 + nu] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[nu], u[nu], (FIRST && cg == 0) ? zero4 : accw[xi * 4 + nu], 0, 0, 0);
+        };
+        f2 d0a, d0b, d1a, d1b, d2a, d2b, d3a, d3b;
+        float ua[4], ub2[4], va[4], vb[4];
+        ldrow(0, d0a, d0b); ldrow(2, d2a, d2b); ldu(0, ua); ldrow(1, d1a, d1b); ldu(1, ub2);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) t[c] = d1[c] + d2[c];
-        row4(1, t, ub2);
+        vrow(d0a - d2a, d0b - d2b, va);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(0, va, ua); vrow(d1a + d2a, d1b + d2b, vb); ldrow(3, d3a, d3b);
+        __builtin_amdgcn_sched_barrier(0);
+        ldu(2, ua);
+        mm(1, vb, ub2); vrow(d2a - d1a, d2b - d1b, va);
+        __builtin_amdgcn_sched_barrier(0);
         ldu(3, ub2);
+        mm(2, va, ua); vrow(d1a - d3a, d1b - d3b, vb);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) t[c] = d2[c] - d1[c];
-        row4(2, t, ua);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) t[c] = d1[c] - d3[c];
-        row4(3, t, ub2);
+        mm(3, vb, ub2);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
