@@ -24,6 +24,8 @@ extern "C" {
 
 int ms_version(void);
 const char* ms_last_error(void);
+/* bit of the `fetch` argument of the convolution entry points: the caller accepts the Winograd form for this call (see ms_conv2d) */
+#define MS_FETCH_WINOGRAD 0x100
 /* Compute units of the current device (hipDeviceProp.multiProcessorCount, read once per device): every persistent grid and every
  * co-residency bound of the library is sized from it (a partitioned or CU-masked device reports fewer than MI355X's 256). */
 int ms_num_cus(void);
@@ -144,6 +146,14 @@ int ms_counter_incr(int* counter, void* stream);
  *             w_packed[ky*ks+kx][ci][co] = weight[co][ci][ky][kx]           (gemm_cols = Cout, or 4*Cout for epi_mode 2)
  *   ks/stride (3,1) (3,2) (1,1) (2,2); padding = 1 for ks 3 else 0
  *   fetch     0 normal | 1 nearest x2 up-sampling fused into the load | 2 zero-insertion x2 (stride-2 data-gradient)
+ *             | MS_FETCH_WINOGRAD (bit 8, with fetch 0): the caller ACCEPTS the Winograd F(2x2,3x3) form of a 3x3 stride-1 convolution where it is built
+ *             (fp32 storage, Cin % 8 == 0, rows of >= 64 pixels with W % 4 == 0): 16 instead of 36 multiplications per 2x2 outputs, the same fp32
+ *             matrix instruction.  On random data it is as close to fp64 as the direct form (2-4e-7 of the output range); on the networks'
+ *             activations (non-zero channel means: the transforms add and subtract values of the size of the mean) its rounding error is about twice
+ *             the direct form's, which doubles the activation-mask flips behind a backward pass - measured on the full-size training pass, weight
+ *             gradients against the fp64 oracle: direct form 4.7e-4 mean / 3.3e-3 worst, Winograd 1.0e-3 / 1.0e-2, the fp32 CPU reference itself
+ *             5.2e-4 / 4.2e-3.  The inner style-optimisation loop sets the bit (its parity tests hold unchanged); the training passes do not.
+ *             Without the bit the result is the direct form's, bit for bit.
  *   pro_mode  0 none | 1 v = LeakyReLU_slope(pro_a[i]*v + pro_b[i]), i = (n*pro_nstride + ci)*pro_cstride  (BatchNorm apply +
  *             activation of the producer; pro_nstride = 0 per channel, = Cin per (n,c) plane; pro_cstride = 4 reads the
  *             interleaved coef4 records of ms_bn_finalize / ms_bn_bwd_coefs in place)

@@ -26,9 +26,11 @@ static int wide_pro(const ConvArgs& a, hipStream_t st) {
 }
 // Winograd F(2x2, 3x3) mode of the wide kernel (ms_conv_wide.h, AT = ms_f32w): fp32 storage, channel count a multiple of the 8-channel chunk
 static bool conv_wino_on(const ConvArgs& a, int nt) {
-  static const int mode = getenv("MS_CONV_WINO") ? atoi(getenv("MS_CONV_WINO")) : 1;      // A/B switch: 0 = direct form everywhere
+  // MS_CONV_WINO: 0 = direct form everywhere | 1 (default) = where the caller allows it (MS_FETCH_WINOGRAD) | 2 = every eligible call (tools / tests)
+  static const int mode = getenv("MS_CONV_WINO") ? atoi(getenv("MS_CONV_WINO")) : 1;
   static const int max_cb = getenv("MS_CONV_WINO_MAXCB") ? atoi(getenv("MS_CONV_WINO_MAXCB")) : 1 << 20;
-  if (mode == 0 || a.act_bf16 != 0 || a.cin_pad % 8 != 0 || a.Cin != a.cin_pad) return false;
+  if (mode == 0 || (mode == 1 && !a.wino_ok)) return false;
+  if (a.act_bf16 != 0 || a.cin_pad % 8 != 0 || a.Cin != a.cin_pad) return false;
   (void)nt;
   return cdiv(a.Cout, 16) <= max_cb;
 }

@@ -324,6 +324,10 @@ class InnerLoopEngine:
         # the activation after the encoder's first double conv (`inc`) is never written: BatchNorm + LeakyReLU become the prologue of down1's stride-2 conv
         # and the backward mask is recomputed from the raw conv output (inner loop only: the training engine and the MixStyle baselines read that tensor)
         self.lazy_inc = os.environ.get("MS_LAZY_INC", "1") != "0" and type(self) is InnerLoopEngine
+        # Winograd F(2x2,3x3) form of the wide 3x3 stride-1 convolutions (MS_FETCH_WINOGRAD): inner loop only - its rounding error on the networks'
+        # activations is about twice the direct form's (include/maxstyle_hip.h, ms_conv2d), harmless for the augmentation loop (parity tests unchanged),
+        # not wanted in the weight gradients of the training passes.  MS_LOOP_WINOGRAD=0 is the A/B switch.
+        self.winograd = type(self) is InnerLoopEngine and os.environ.get("MS_LOOP_WINOGRAD", "1") != "0"
         self.fuse_style_actbwd = True  # ms_style_bwd_actbwd (the MaxStyle backward also does the block's output-activation backward)
         if self.bf16:
             # kernels without a bf16 twin: the "last workgroup finalises" experiments and the weight-gradient kernels (TrainEngine is fp32 only)
@@ -507,8 +511,9 @@ class InnerLoopEngine:
                                     N, Cin, Hs, Ws, cout, ks, stride, fetch, pm, pa, pb, pc, pn, 4, slope, st.data_ptr(), fin.gamma.data_ptr(), fin.beta.data_ptr(),
                                     BN_EPS, coef.data_ptr(), self._counter(name).data_ptr(), self._st()), "ms_conv2d_fin:" + name)
             return out, ("fused", coef), parts
+        wf = ops.FETCH_WINOGRAD if (self.winograd and fetch == 0 and ks == 3 and stride == 1) else 0
         check(self.L("ms_conv2d")(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
-                            N, Cin, Hs, Ws, cout, ks, stride, fetch, pm, pa, pb, pc, pn, 4, slope, epi, 0 if st is None else st.data_ptr(), self._st()),
+                            N, Cin, Hs, Ws, cout, ks, stride, fetch | wf, pm, pa, pb, pc, pn, 4, slope, epi, 0 if st is None else st.data_ptr(), self._st()),
               "ms_conv2d:" + name)
         return out, st, parts
 
@@ -577,7 +582,8 @@ class InnerLoopEngine:
         out = self.a(name, N, cout, Hs, Ws)
         tab = self.t(bw_name + ".tab", lib.ms_conv_actbwd_tab_bytes(cout) // 4)
         pa, pb, pc = ops.coef_ptrs(bnbwd[0])
-        check(self.L("ms_conv2d_actbwd")(g.data_ptr(), bnbwd[1].data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), N, Cin, Hs, Ws, cout, cw.ks, 1, 0,
+        check(self.L("ms_conv2d_actbwd")(g.data_ptr(), bnbwd[1].data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), N, Cin, Hs, Ws, cout, cw.ks, 1,
+                                   ops.FETCH_WINOGRAD if (self.winograd and cw.ks == 3) else 0,
                                    2, pa, pb, pc, 0, 4, 1.0, u.data_ptr(), coef.data_ptr(), slope, tab.data_ptr(), self._st()), "ms_conv2d_actbwd:" + name)
         return out, tab
 

