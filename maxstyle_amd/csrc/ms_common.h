@@ -134,6 +134,9 @@ template <> struct ActIO<ms_bf16m> : ActIO<ms_bf16> {};
 // 16 products per 2x2 output pixels instead of 36.  Loads / stores are those of float.
 struct ms_f32w { float v; };
 template <> struct ActIO<ms_f32w> : ActIO<float> {};
+// ms_f32w32: the same on 8-row x 32-pixel tiles (rows of 32..63 pixels)
+struct ms_f32w32 { float v; };
+template <> struct ActIO<ms_f32w32> : ActIO<float> {};
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -1,6 +1,20 @@
 // Instantiations: wide-read 3x3 stride-1 convolution (ms_conv_wide.h), 4-row tiles; the 8-row tiles are in ms_conv_inst_w2.hip.
 #include "ms_conv_wide.h"
 namespace ms {
+// Winograd F(2x2, 3x3) mode of the wide kernel (ms_conv_wide.h, AT = ms_f32w / ms_f32w32): fp32 storage, channel count a multiple of the 8-channel chunk
+static bool conv_wino_on(const ConvArgs& a) {
+  // MS_CONV_WINO: 0 = direct form everywhere | 1 (default) = where the caller allows it (MS_FETCH_WINOGRAD) | 2 = every eligible call (tools / tests)
+  static const int mode = getenv("MS_CONV_WINO") ? atoi(getenv("MS_CONV_WINO")) : 1;
+  static const int max_cb = getenv("MS_CONV_WINO_MAXCB") ? atoi(getenv("MS_CONV_WINO_MAXCB")) : 1 << 20;
+  if (mode == 0 || (mode == 1 && !a.wino_ok)) return false;
+  if (a.act_bf16 != 0 || a.cin_pad % 8 != 0 || a.Cin != a.cin_pad) return false;
+  return cdiv(a.Cout, 16) <= max_cb;
+}
+// rows of 32..63 pixels: only the Winograd form has a tile for them (8 rows x 32 pixels); MS_CONV_WINO32=0 leaves them to the first-generation kernel
+static bool conv_wino32_on(const ConvArgs& a) {
+  static const bool on = !(getenv("MS_CONV_WINO32") && atoi(getenv("MS_CONV_WINO32")) == 0);
+  return on && a.Wout >= 32 && a.Wout < 64 && conv_wino_on(a);
+}
 bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool vec) {
   static const bool off = getenv("MS_CONV_WIDE") != nullptr && atoi(getenv("MS_CONV_WIDE")) == 0;      // A/B switch for timing
   if (off) return false;
@@ -10,7 +24,7 @@ bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool v
   //  first-generation kernel at 16->16 @16x256x256)
   // fp32 arithmetic: rows of at least one 64-pixel tile.  bf16 matrix arithmetic (act_bf16 == 2): the matrix work of the padding columns of a narrower row is
   // cheap, the first-generation kernel's fp32 MFMAs are not - rows from 16 pixels up take this kernel
-  if (a.Wout < (a.act_bf16 == 2 ? 16 : 64) || a.Wout % 4 != 0) return false;
+  if (a.Wout < (a.act_bf16 == 2 ? 16 : (conv_wino32_on(a) ? 32 : 64)) || a.Wout % 4 != 0) return false;
   if ((long long)a.Cin * a.Hs * a.Ws + a.Ws + 4 >= (1LL << 29)) return false;      // byte offsets inside one image fit 31 bits (buffer addressing of the staging)
   if ((long long)a.Cout * a.Hout * a.Wout >= (1LL << 29)) return false;              // ... and so do the epilogue's offsets inside one output image
   if (!aligned16(a.out)) return false;
@@ -24,25 +38,17 @@ static int wide_pro(const ConvArgs& a, hipStream_t st) {
     default: return launch_conv_wide_r<NT, 2, 1>(a, st);
   }
 }
-// Winograd F(2x2, 3x3) mode of the wide kernel (ms_conv_wide.h, AT = ms_f32w): fp32 storage, channel count a multiple of the 8-channel chunk
-static bool conv_wino_on(const ConvArgs& a, int nt) {
-  // MS_CONV_WINO: 0 = direct form everywhere | 1 (default) = where the caller allows it (MS_FETCH_WINOGRAD) | 2 = every eligible call (tools / tests)
-  static const int mode = getenv("MS_CONV_WINO") ? atoi(getenv("MS_CONV_WINO")) : 1;
-  static const int max_cb = getenv("MS_CONV_WINO_MAXCB") ? atoi(getenv("MS_CONV_WINO_MAXCB")) : 1 << 20;
-  if (mode == 0 || (mode == 1 && !a.wino_ok)) return false;
-  if (a.act_bf16 != 0 || a.cin_pad % 8 != 0 || a.Cin != a.cin_pad) return false;
-  (void)nt;
-  return cdiv(a.Cout, 16) <= max_cb;
-}
+template <typename WT>
 static int wide_wino(const ConvArgs& a, hipStream_t st) {
   switch (a.pro_mode) {
-    case 0: return launch_conv_wide_t<1, 0, 1, true, ms_f32w>(a, st);
-    case 1: return launch_conv_wide_t<1, 1, 1, true, ms_f32w>(a, st);
-    default: return launch_conv_wide_t<1, 2, 1, true, ms_f32w>(a, st);
+    case 0: return launch_conv_wide_t<1, 0, 1, true, WT>(a, st);
+    case 1: return launch_conv_wide_t<1, 1, 1, true, WT>(a, st);
+    default: return launch_conv_wide_t<1, 2, 1, true, WT>(a, st);
   }
 }
 int conv_dispatch_wide(const ConvArgs& a, int nt, hipStream_t st) {
-  if (conv_wino_on(a, nt)) return wide_wino(a, st);
+  if (a.Wout < 64 && a.act_bf16 != 2) return wide_wino<ms_f32w32>(a, st);      // (conv_wide_eligible admitted it for this form only)
+  if (conv_wino_on(a)) return wide_wino<ms_f32w>(a, st);
   if (conv_wide_rows(a, nt >= 2 ? 2 : 1) == 8) return conv_dispatch_wide8(a, nt, st);
   return nt >= 2 ? wide_pro<2>(a, st) : wide_pro<1>(a, st);
 }

@@ -66,11 +66,13 @@ struct WideGeoBF {
 // its plane stride is == 32 (mod 64 dwords) so that the 8-byte patch reads of the four K lanes groups of a wave fall on disjoint banks.  The weight region of a
 // stage holds the chunk's TRANSFORMED weights U = G g G^T as [16 positions][CK channels][16 output channels]: a lane's B fragment of position p and channel
 // group cg is one ds_read_b32 at p*128 + cg*64 + lane (64 consecutive dwords per wave: conflict-free).
-template <int PRO>
+// TW_ = 64: 4-row tiles (waves = 2 tile rows x 2 halves of 32 pixels); TW_ = 32: 8-row tiles (waves = 4 tile rows) for rows of 32..63 pixels.
+template <int PRO, int TW_ = 64>
 struct WideGeoW {
-  static constexpr int TH = 4, TW = 64, CK = 8, IH = TH + 2;
+  static constexpr int TW = TW_, TH = 256 / TW_, CK = 8, IH = TH + 2;
   static constexpr int RS = TW + 4;
-  static constexpr int PS = 416;                                  // >= IH*RS = 408, == 32 (mod 64)
+  static constexpr int PS = 416;                                  // >= IH*RS (6*68 = 408, 10*36 = 360), == 32 (mod 64)
+  static_assert(IH * RS <= PS, "plane stride");
   static constexpr int WS = 16;
   static constexpr int BUF = CK * PS + 16 * CK * 16;              // floats per stage buffer
   static constexpr int Q_ITEMS = CK * IH * (TW / 4), H_ITEMS = CK * IH * 2;
@@ -87,9 +89,11 @@ static __device__ int g_cu_census[1024];
 template <int NT, int PRO, int R, bool AF, typename AT = float>
 __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const ConvArgs a) {
   constexpr bool BFM = std::is_same<AT, ms_bf16m>::value;         // bf16 matrix arithmetic (needs R == 1)
-  constexpr bool WIN = std::is_same<AT, ms_f32w>::value;          // Winograd F(2x2, 3x3) (needs R == 1, NT == 1, every chunk full)
+  constexpr bool WIN = std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value;      // Winograd F(2x2, 3x3) (needs R == 1, NT == 1, every chunk full)
+  constexpr int WTW = std::is_same<AT, ms_f32w32>::value ? 32 : 64;
+  constexpr int WHALVES = WTW / 32;                               // 32-pixel halves of a tile row = waves per tile row
   static_assert(!WIN || (R == 1 && NT == 1 && AF), "Winograd mode: 4-row tiles, one channel block per lane, channel count a multiple of the chunk");
-  using G = typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WIN, WideGeoW<PRO>, WideGeo<NT, PRO, R>>::type>::type;
+  using G = typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WIN, WideGeoW<PRO, WTW>, WideGeo<NT, PRO, R>>::type>::type;
   using IO = ActIO<AT>;
   constexpr int AB = IO::kBytes;
   static_assert(!BFM || R == 1, "bf16 MFMA mode: 4-row tiles");
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     constexpr bool FIRST = decltype(first_tag)::value;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (WIN) {
-      const float* ab = buf + k * PS + (2 * (wave >> 1)) * RS + 32 * (wave & 1) + 2 * m;
+      const float* ab = buf + k * PS + (2 * (wave / WHALVES)) * RS + 32 * (wave % WHALVES) + 2 * m;
       const float* ub = buf + CK * PS + lane;
 #pragma unroll
       for (int cg = 0; cg < CK / 4; ++cg) {
@@ -766,7 +770,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 
   // ---- Winograd mode: output transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) in registers - a lane holds all 16 positions of its 4 tiles (4k..4k+3 of the
   // wave's 16) for channel m - then the epilogue on 2 rows x 8 consecutive pixels (x = 32h + 8k ..) per lane.  upre[0][2*row + quad] = the mask tensor's values.
-  auto wino_geo = [&](int tile, int& xb, int& y0) { const int tx = tile % a.tiles_x, ty = tile / a.tiles_x; xb = tx * TW + 32 * (wave & 1) + 8 * k; y0 = ty * TH + 2 * (wave >> 1); };
+  auto wino_geo = [&](int tile, int& xb, int& y0) { const int tx = tile % a.tiles_x, ty = tile / a.tiles_x; xb = tx * TW + 32 * (wave % WHALVES) + 8 * k; y0 = ty * TH + 2 * (wave / WHALVES); };
   // interior tiles: buffer addressing as in epilogue_fast below - resource = image n, scalar offset = (channel block, row, first column of the wave's half),
   // vector offset = the lane's hoisted (channel m, pixel group k) offset; stores carry the row offset in the vector offset (see bstore4)
   const int w_plane = a.Hout * a.Wout;
@@ -777,7 +781,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   };
   auto w_soff = [&](int tile, int co0, int row) {
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    return AB * ((co0 * a.Hout + ty * TH + 2 * (wave >> 1) + row) * a.Wout + tx * TW + 32 * (wave & 1));
+    return AB * ((co0 * a.Hout + ty * TH + 2 * (wave / WHALVES) + row) * a.Wout + tx * TW + 32 * (wave % WHALVES));
   };
   auto w_load4 = [&](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     const wu32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
@@ -1164,9 +1168,10 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 template <int NT, int PRO, int R, bool AF, typename AT>
 int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
   using G = typename std::conditional<std::is_same<AT, ms_bf16m>::value, WideGeoBF<NT, PRO>,
-                                      typename std::conditional<std::is_same<AT, ms_f32w>::value, WideGeoW<PRO>, WideGeo<NT, PRO, R>>::type>::type;
+                                      typename std::conditional<std::is_same<AT, ms_f32w>::value, WideGeoW<PRO, 64>,
+                                      typename std::conditional<std::is_same<AT, ms_f32w32>::value, WideGeoW<PRO, 32>, WideGeo<NT, PRO, R>>::type>::type>::type;
   const size_t cin_tab = (PRO != 0) ? (size_t)cdiv(a.cin_pad, G::CK) * G::CK : 0;              // coefficient table: one float4 per input channel of the padded chunks
-  const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab) + (std::is_same<AT, ms_f32w>::value ? 16 * 1024 : 0);      // Winograd mode: + the mask tensor's landing zone
+  const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab) + ((std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value) ? 16 * 1024 : 0);      // Winograd mode: + the mask tensor's landing zone
   if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
   static std::once_flag attr_once;                     // one flag per instantiation; the attribute itself is immutable afterwards
   std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO, R, AF, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });

@@ -65,7 +65,7 @@ def main():
     ep, cin, hs, pm, epi, stats = WHICH[which]
     for name, a in calls:
         d = describe(name, a)
-        if name == ep and d["Cin"] == cin and d["Hs"] == hs and d["pm"] == pm and d["epi"] == epi and d["stats"] == stats and d["ks"] == 3 and d["stride"] == 1 and d["fetch"] == 0 \
+        if name == ep and d["Cin"] == cin and d["Hs"] == hs and d["pm"] == pm and d["epi"] == epi and d["stats"] == stats and d["ks"] == 3 and d["stride"] == 1 and (d["fetch"] & 0xFF) == 0 \
                 and d["Cout"] == cin:
             for _ in range(reps):
                 rc = orig[name](*a)

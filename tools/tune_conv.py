@@ -73,7 +73,7 @@ def main():
         tot = [0.0] * len(vals)
         for key, (cnt, a) in sorted(seen.items(), key=lambda kv: -kv[1][0]):
             name, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pm, epi, stats = key
-            if not (ks == 3 and stride == 1 and fetch == 0 and Ws >= 64):
+            if not (ks == 3 and stride == 1 and (fetch & 0xFF) == 0 and Ws >= 64):
                 continue
             ts = []
             for v in vals:
@@ -101,17 +101,17 @@ def main():
         os.environ["MS_CONV_FORCE_NT"] = "0"; os.environ["MS_CONV_FORCE_WIDE"] = "1"
         auto = res[(0, 1)]
         best = min(res, key=res.get)
-        Ho = Hs * (2 if fetch else 1) // stride if ks != 2 else Hs // 2
-        Wo = Ws * (2 if fetch else 1) // stride if ks != 2 else Ws // 2
+        Ho = Hs * (2 if (fetch & 0xFF) else 1) // stride if ks != 2 else Hs // 2
+        Wo = Ws * (2 if (fetch & 0xFF) else 1) // stride if ks != 2 else Ws // 2
         cols = 4 * Cout if epi == 2 else Cout
         flop = 2.0 * N * Ho * Wo * cols * Cin * ks * ks
         rows.append((cnt * auto, key, cnt, auto, best, res[best], flop / auto / 1e6))
         total_auto += cnt * auto; total_best += cnt * res[best]
     rows.sort(reverse=True)
-    print(f"{'call':16s} {'N,Cin,Hs,Ws,Cout':>22s} ks s f pm epi st  cnt  auto_us  TF/s   best(nt,wide) best_us  gain_us/step")
+    print(f"{'call':16s} {'N,Cin,Hs,Ws,Cout':>22s} ks s f  pm epi st  cnt  auto_us  TF/s   best(nt,wide) best_us  gain_us/step")
     for tot, key, cnt, auto, best, tb, tf in rows:
         name, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pm, epi, stats = key
-        print(f"{name[3:]:16s} {str((N, Cin, Hs, Ws, Cout)):>22s} {ks:2d} {stride} {fetch} {pm:2d} {epi:3d} {int(stats):2d} {cnt:4d} {auto:8.1f} {tf:6.1f}   {str(best):>10s} {tb:8.1f} {cnt * (auto - tb):8.1f}")
+        print(f"{name[3:]:16s} {str((N, Cin, Hs, Ws, Cout)):>22s} {ks:2d} {stride} {str(fetch & 0xFF) + ('w' if fetch & 0x100 else ' ')} {pm:2d} {epi:3d} {int(stats):2d} {cnt:4d} {auto:8.1f} {tf:6.1f}   {str(best):>10s} {tb:8.1f} {cnt * (auto - tb):8.1f}")
     print(f"conv time per step: heuristic {total_auto:.0f} us, best-of-table {total_best:.0f} us")
 
 

@@ -9,7 +9,7 @@ def _rand(shape, seed, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 def err(o, r):
     return float((o.cpu().double() - r).abs().max() / r.abs().max())
-for (N, Cin, Cout, H, W) in [(2, 16, 16, 64, 64), (1, 32, 48, 20, 192), (2, 64, 64, 64, 64), (1, 8, 33, 10, 100), (2, 16, 16, 6, 72), (16, 16, 16, 256, 256)]:
+for (N, Cin, Cout, H, W) in [(2, 16, 16, 64, 64), (1, 32, 48, 20, 192), (2, 64, 64, 64, 64), (1, 8, 33, 10, 100), (2, 16, 16, 6, 72), (2, 64, 64, 32, 32), (2, 128, 64, 20, 40), (1, 16, 16, 9, 36), (16, 128, 128, 32, 32), (16, 16, 16, 256, 256)]:
     x = _rand((N, Cin, H, W), 1); x2 = _rand((N, Cin, H, W), 2); w = _rand((Cout, Cin, 3, 3), 3, 0.1); b = _rand((Cout,), 4)
     cf = _rand((Cin, 4), 5); cfd = cf.to(dev)
     wp = ops.pack_conv_weight(w.to(dev))
