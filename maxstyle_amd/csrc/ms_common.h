@@ -134,6 +134,11 @@ template <> struct ActIO<ms_bf16m> : ActIO<ms_bf16> {};
 // 16 products per 2x2 output pixels instead of 36.  Loads / stores are those of float.
 struct ms_f32w { float v; };
 template <> struct ActIO<ms_f32w> : ActIO<float> {};
+// ms_bf16w / ms_bf16w32: bf16 STORAGE (loads / stores of ms_bf16), fp32 Winograd arithmetic
+struct ms_bf16w { uint16_t v; };
+template <> struct ActIO<ms_bf16w> : ActIO<ms_bf16> {};
+struct ms_bf16w32 { uint16_t v; };
+template <> struct ActIO<ms_bf16w32> : ActIO<ms_bf16> {};
 // ms_f32w32: the same on 8-row x 32-pixel tiles (rows of 32..63 pixels)
 struct ms_f32w32 { float v; };
 template <> struct ActIO<ms_f32w32> : ActIO<float> {};

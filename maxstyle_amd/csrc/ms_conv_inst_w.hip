@@ -7,7 +7,7 @@ static bool conv_wino_on(const ConvArgs& a) {
   static const int mode = getenv("MS_CONV_WINO") ? atoi(getenv("MS_CONV_WINO")) : 1;
   static const int max_cb = getenv("MS_CONV_WINO_MAXCB") ? atoi(getenv("MS_CONV_WINO_MAXCB")) : 1 << 20;
   if (mode == 0 || (mode == 1 && !a.wino_ok)) return false;
-  if (a.act_bf16 != 0 || a.cin_pad % 8 != 0 || a.Cin != a.cin_pad) return false;
+  if (a.act_bf16 == 2 || a.cin_pad % 8 != 0 || a.Cin != a.cin_pad) return false;      // (bf16 matrix arithmetic has its own kernel mode)
   return cdiv(a.Cout, 16) <= max_cb;
 }
 // rows of 32..63 pixels: only the Winograd form has a tile for them (8 rows x 32 pixels); MS_CONV_WINO32=0 leaves them to the first-generation kernel
@@ -47,8 +47,8 @@ static int wide_wino(const ConvArgs& a, hipStream_t st) {
   }
 }
 int conv_dispatch_wide(const ConvArgs& a, int nt, hipStream_t st) {
-  if (a.Wout < 64 && a.act_bf16 != 2) return wide_wino<ms_f32w32>(a, st);      // (conv_wide_eligible admitted it for this form only)
-  if (conv_wino_on(a)) return wide_wino<ms_f32w>(a, st);
+  if (a.Wout < 64 && a.act_bf16 != 2) return a.act_bf16 ? wide_wino<ms_bf16w32>(a, st) : wide_wino<ms_f32w32>(a, st);      // (conv_wide_eligible admitted it for this form only)
+  if (conv_wino_on(a)) return a.act_bf16 ? wide_wino<ms_bf16w>(a, st) : wide_wino<ms_f32w>(a, st);
   if (conv_wide_rows(a, nt >= 2 ? 2 : 1) == 8) return conv_dispatch_wide8(a, nt, st);
   return nt >= 2 ? wide_pro<2>(a, st) : wide_pro<1>(a, st);
 }

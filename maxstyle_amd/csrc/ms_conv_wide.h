@@ -89,8 +89,9 @@ static __device__ int g_cu_census[1024];
 template <int NT, int PRO, int R, bool AF, typename AT = float>
 __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const ConvArgs a) {
   constexpr bool BFM = std::is_same<AT, ms_bf16m>::value;         // bf16 matrix arithmetic (needs R == 1)
-  constexpr bool WIN = std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value;      // Winograd F(2x2, 3x3) (needs R == 1, NT == 1, every chunk full)
-  constexpr int WTW = std::is_same<AT, ms_f32w32>::value ? 32 : 64;
+  constexpr bool WIN = std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value ||       // Winograd F(2x2, 3x3) (needs R == 1, NT == 1, every chunk full)
+                       std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value;      // ... on bf16 storage
+  constexpr int WTW = (std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w32>::value) ? 32 : 64;
   constexpr int WHALVES = WTW / 32;                               // 32-pixel halves of a tile row = waves per tile row
   static_assert(!WIN || (R == 1 && NT == 1 && AF), "Winograd mode: 4-row tiles, one channel block per lane, channel count a multiple of the chunk");
   using G = typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WIN, WideGeoW<PRO, WTW>, WideGeo<NT, PRO, R>>::type>::type;
@@ -783,13 +784,25 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     return AB * ((co0 * a.Hout + ty * TH + 2 * (wave / WHALVES) + row) * a.Wout + tx * TW + 32 * (wave % WHALVES));
   };
+  typedef unsigned wu32x2_t __attribute__((ext_vector_type(2)));
+  constexpr int WQB = 4 * AB;                           // bytes of one quad
   auto w_load4 = [&](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    const wu32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+    if constexpr (AB == 4) {
+      const wu32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+      return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w));
+    } else {
+      const wu32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+      return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xFFFF0000u));
+    }
   };
   auto w_store4 = [&](__amdgpu_buffer_rsrc_t r, int voff, float4 v) {
-    const wu32x4_t w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, 0, 0);
+    if constexpr (AB == 4) {
+      const wu32x4_t w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+      __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, 0, 0);
+    } else {
+      const wu32x2_t w = {ms_pack_bf16x2(v.x, v.y), ms_pack_bf16x2(v.z, v.w)};
+      __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, 0, 0);
+    }
   };
   // mask-tensor values of the item (epi_mode 3): 16 per lane.  With 64 accumulators there are no registers to park them across the MFMA loop, so they are
   // requested at the start of the item STRAIGHT INTO LDS (buffer_load_dwordx4 ... lds: lane l's 16 bytes land at base + 16 l, no vector register involved)
@@ -807,9 +820,13 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #pragma unroll
       for (int row = 0; row < 2; ++row) {
         const int so = w_soff(tile, co0, row);
+        if constexpr (AB == 4) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(u_lds + (2 * row + q) * 256), 16, w_voff + 16 * q, so, 0, 0);
+          for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(u_lds + (2 * row + q) * 256), 16, w_voff + 16 * q, so, 0, 0);
+        } else {                                       // bf16 storage: the lane's 8 pixels of a row are ONE 16-byte transfer
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(u_lds + row * 256), 16, w_voff, so, 0, 0);
+        }
       }
     }
   };
@@ -885,8 +902,17 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         float4 um[2][2];
         if constexpr (INT) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the item's LDS-destined loads have landed
+          if constexpr (AB == 4) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) um[i >> 1][i & 1] = *reinterpret_cast<const float4*>(u_lds + i * 256 + lane * 4);
+            for (int i = 0; i < 4; ++i) um[i >> 1][i & 1] = *reinterpret_cast<const float4*>(u_lds + i * 256 + lane * 4);
+          } else {
+#pragma unroll
+            for (int row = 0; row < 2; ++row) {
+              const wu32x4_t w = *reinterpret_cast<const wu32x4_t*>(u_lds + row * 256 + lane * 4);
+              um[row][0] = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xFFFF0000u));
+              um[row][1] = make_float4(__uint_as_float(w.z << 16), __uint_as_float(w.z & 0xFFFF0000u), __uint_as_float(w.w << 16), __uint_as_float(w.w & 0xFFFF0000u));
+            }
+          }
         } else {
 #pragma unroll
           for (int row = 0; row < 2; ++row) {
@@ -909,7 +935,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
               v.y = o[row][4 * q + 1] * ((mk_sc[0] * uu.y + mk_sh[0] > 0.f) ? 1.f : a.mk_slope);
               v.z = o[row][4 * q + 2] * ((mk_sc[0] * uu.z + mk_sh[0] > 0.f) ? 1.f : a.mk_slope);
               v.w = o[row][4 * q + 3] * ((mk_sc[0] * uu.w + mk_sh[0] > 0.f) ? 1.f : a.mk_slope);
-              if constexpr (INT) w_store4(ro, st_voff + 16 * q, v); else IO::st4(a.out, off + 4 * q, v);
+              if constexpr (INT) w_store4(ro, st_voff + WQB * q, v); else IO::st4(a.out, off + 4 * q, v);
               s1 += (v.x + v.y) + (v.z + v.w);
               s2 += (v.x * (uu.x - mk_mu[0]) + v.y * (uu.y - mk_mu[0])) + (v.z * (uu.z - mk_mu[0]) + v.w * (uu.w - mk_mu[0]));
             }
@@ -924,7 +950,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           const int so = w_soff(tile, co0, row);
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
-            if constexpr (INT) pv[row][q] = w_load4(ro, w_voff + 16 * q, so);
+            if constexpr (INT) pv[row][q] = w_load4(ro, w_voff + WQB * q, so);
             else pv[row][q] = ok[row][q] ? IO::ld4(a.out, off + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
         }
@@ -936,7 +962,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           for (int q = 0; q < 2; ++q) {
             if (ok[row][q]) {
               const float4 v = make_float4(o[row][4 * q] + pv[row][q].x, o[row][4 * q + 1] + pv[row][q].y, o[row][4 * q + 2] + pv[row][q].z, o[row][4 * q + 3] + pv[row][q].w);
-              if constexpr (INT) w_store4(ro, st_voff + 16 * q, v); else IO::st4(a.out, off + 4 * q, v);
+              if constexpr (INT) w_store4(ro, st_voff + WQB * q, v); else IO::st4(a.out, off + 4 * q, v);
             }
           }
         }
@@ -949,7 +975,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           for (int q = 0; q < 2; ++q) {
             if (ok[row][q]) {
               const float4 v = make_float4(o[row][4 * q], o[row][4 * q + 1], o[row][4 * q + 2], o[row][4 * q + 3]);
-              if constexpr (INT) w_store4(ro, st_voff + 16 * q, v); else IO::st4(a.out, off + 4 * q, v);
+              if constexpr (INT) w_store4(ro, st_voff + WQB * q, v); else IO::st4(a.out, off + 4 * q, v);
             }
           }
         }
@@ -1168,10 +1194,11 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 template <int NT, int PRO, int R, bool AF, typename AT>
 int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
   using G = typename std::conditional<std::is_same<AT, ms_bf16m>::value, WideGeoBF<NT, PRO>,
-                                      typename std::conditional<std::is_same<AT, ms_f32w>::value, WideGeoW<PRO, 64>,
-                                      typename std::conditional<std::is_same<AT, ms_f32w32>::value, WideGeoW<PRO, 32>, WideGeo<NT, PRO, R>>::type>::type>::type;
+                                      typename std::conditional<std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_bf16w>::value, WideGeoW<PRO, 64>,
+                                      typename std::conditional<std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w32>::value, WideGeoW<PRO, 32>,
+                                                                WideGeo<NT, PRO, R>>::type>::type>::type;
   const size_t cin_tab = (PRO != 0) ? (size_t)cdiv(a.cin_pad, G::CK) * G::CK : 0;              // coefficient table: one float4 per input channel of the padded chunks
-  const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab) + ((std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value) ? 16 * 1024 : 0);      // Winograd mode: + the mask tensor's landing zone
+  const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab) + ((std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value) ? 16 * 1024 : 0);      // Winograd mode: + the mask tensor's landing zone
   if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
   static std::once_flag attr_once;                     // one flag per instantiation; the attribute itself is immutable afterwards
   std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO, R, AF, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });

@@ -30,6 +30,7 @@ def err(o, r):
 
 
 SHAPES = [(2, 16, 16, 64, 64), (1, 32, 48, 20, 192), (2, 64, 64, 64, 64),      # interior tiles only / several channel blocks / a channel tail in Cout
+          (2, 64, 64, 32, 32), (2, 128, 64, 20, 40), (1, 16, 16, 9, 36),                # 8-row x 32-pixel tiles (rows of 32..63 pixels)
           (1, 8, 33, 10, 100), (2, 16, 16, 6, 72), (1, 24, 16, 7, 68),         # ragged width, heights that are not multiples of the 4-row tile (odd: half a 2x2 tile)
           (2, 16, 16, 128, 128)]
 
@@ -83,15 +84,12 @@ def test_winograd_form_all_prologues_and_epilogues(dev, N, Cin, Cout, H, W):
 
 
 def test_winograd_bit_is_ignored_where_the_form_is_not_built(dev):
-    """Rows narrower than 64 pixels, Cin % 8 != 0, stride 2, 1x1, bf16 storage: the call runs the direct form - bit-identical with and without the bit."""
+    """Rows narrower than 32 pixels, Cin % 8 != 0, 1x1: the call runs the direct form - bit-identical with and without the bit."""
     from maxstyle_amd import ops
-    for (N, Cin, Cout, H, W, ks, stride) in [(2, 16, 16, 32, 32, 3, 1), (2, 12, 16, 16, 64, 3, 1), (2, 16, 16, 64, 64, 1, 1)]:
+    for (N, Cin, Cout, H, W, ks, stride) in [(2, 16, 16, 16, 28, 3, 1), (2, 12, 16, 16, 64, 3, 1), (2, 16, 16, 64, 64, 1, 1)]:
         x = _rand((N, Cin, H, W), 1).to(dev); w = _rand((Cout, Cin, ks, ks), 3, 0.1)
         wp = ops.pack_conv_weight(w.to(dev))
         assert torch.equal(ops.conv2d(x, wp, None, Cout, ks, stride, fetch=ops.FETCH_WINOGRAD), ops.conv2d(x, wp, None, Cout, ks, stride))
-    x = _rand((2, 16, 64, 64), 1).to(dev).to(torch.bfloat16); w = _rand((16, 16, 3, 3), 3, 0.1)
-    wp = ops.pack_conv_weight(w.to(dev))
-    assert torch.equal(ops.conv2d(x, wp, None, 16, 3, 1, fetch=ops.FETCH_WINOGRAD), ops.conv2d(x, wp, None, 16, 3, 1))
 
 
 def test_only_the_inner_loop_asks_for_the_winograd_form(dev):
@@ -100,3 +98,54 @@ def test_only_the_inner_loop_asks_for_the_winograd_form(dev):
     assert loop.winograd
     from maxstyle_amd.train_engine import TrainEngine
     assert not TrainEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev).winograd
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 16, 16, 64, 64), (1, 32, 48, 20, 192), (2, 64, 64, 32, 32), (1, 8, 33, 10, 100), (1, 16, 16, 9, 36)])
+def test_winograd_form_on_bf16_storage(dev, N, Cin, Cout, H, W):
+    """bf16 activation storage under the Winograd form (tags ms_bf16w / ms_bf16w32): fp32 arithmetic on the widened values, so against fp64 on the
+    ROUNDED inputs the only error beyond fp32 rounding is the bf16 rounding of the stored output (the `_bf16` tests' bar)."""
+    from maxstyle_amd import ops
+    BF = torch.bfloat16
+    WG = ops.FETCH_WINOGRAD
+
+    def rb(t):
+        return t.to(BF).to(torch.float32)
+
+    def close(got, ref64):
+        g = got.float().cpu().double()
+        bad = (g - ref64).abs() > ref64.abs() * 2.0 ** -8 + ref64.abs().max() * 2.0 ** -13
+        assert not bool(bad.any()), (int(bad.sum()), float((g - ref64).abs().max()), float(ref64.abs().max()))
+    x = rb(_rand((N, Cin, H, W), 1)); x2 = rb(_rand((N, Cin, H, W), 2)); w = _rand((Cout, Cin, 3, 3), 3, 0.1); b = _rand((Cout,), 4)
+    cf = _rand((Cin, 4), 5); cfd = cf.to(dev)
+    wp = ops.pack_conv_weight(w.to(dev))
+    a, bb, cc = (cf[:, i].double().view(1, -1, 1, 1) for i in range(3))
+    xd, x2d = x.to(dev).to(BF), x2.to(dev).to(BF)
+    stats, parts = ops.conv_stats_buffer(N, Cout, H, W, dev)
+    out = ops.conv2d(xd, wp, b.to(dev), Cout, 3, 1, fetch=WG, stats=stats)
+    assert out.dtype == BF
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    close(out, ref)
+    coef = ops.bn_finalize(stats, parts, torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)).cpu().double()
+    mean = ref.mean((0, 2, 3)); invstd = 1 / torch.sqrt(ref.var((0, 2, 3), unbiased=False) + 1e-5)
+    assert float((coef[:, 2] - mean).abs().max()) < 1e-5 * max(1.0, float(mean.abs().max()))      # statistics of the fp32 values before rounding
+    assert float((coef[:, 3] / invstd - 1).abs().max()) < 1e-5
+    o1 = ops.conv2d(xd, wp, None, Cout, 3, 1, fetch=WG, pro_mode=1, pro_a=ops.coef_ptrs(cfd)[0], pro_b=ops.coef_ptrs(cfd)[1], pro_cstride=4, slope=0.2)
+    close(o1, F.conv2d(F.leaky_relu(a * x.double() + bb, 0.2), w.double(), None, padding=1))
+    base = rb(_rand((N, Cout, H, W), 6))
+    o2 = ops.conv2d(xd, wp, None, Cout, 3, 1, fetch=WG, pro_mode=2, pro_a=ops.coef_ptrs(cfd)[0], pro_b=ops.coef_ptrs(cfd)[1], pro_c=ops.coef_ptrs(cfd)[2],
+                    pro_cstride=4, in2=x2d, epi_mode=1, out=base.to(dev).to(BF).clone())
+    close(o2, F.conv2d(a * x.double() + bb * x2.double() + cc, w.double(), None, padding=1) + base.double())
+    u = rb(_rand((N, Cout, H, W), 24) + 0.3)
+    coef4 = torch.stack([1 + 0.2 * _rand((Cout,), 26), 0.3 * _rand((Cout,), 27), 0.3 + 0.1 * _rand((Cout,), 28), 1 + 0.1 * _rand((Cout,), 29).abs()], 1)
+    og, tab = ops.conv2d_actbwd(xd, wp, Cout, 3, u.to(dev).to(BF), coef4.to(dev), 0.2, fetch=WG)
+    c4 = coef4.double()
+    pre = c4[:, 0].view(1, -1, 1, 1) * u.double() + c4[:, 1].view(1, -1, 1, 1)
+    refm = F.conv2d(x.double(), w.double(), None, padding=1) * torch.where(pre > 0, 1.0, 0.2)
+    safe = (pre.abs() > 1e-4).double()
+    close((og.float() * safe.float().to(dev)).to(BF), refm * safe)
+    bc = ops.bn_bwd_coefs(tab, 0, coef4.to(dev), N * H * W).cpu().double()
+    s1 = refm.sum((0, 2, 3)); s2 = (refm * (u.double() - c4[:, 2].view(1, -1, 1, 1))).sum((0, 2, 3))
+    cnt = N * H * W
+    be = -c4[:, 0] * (s2 * c4[:, 3] / cnt) * c4[:, 3]
+    ref_bc = torch.stack([c4[:, 0], be, -c4[:, 0] * s1 / cnt - be * c4[:, 2]], 1)
+    assert float((bc[:, :3] - ref_bc).abs().max()) < 2e-4 * float(ref_bc.abs().max())
