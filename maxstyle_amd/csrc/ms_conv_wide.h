@@ -306,8 +306,15 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       have_w = load_w;
       if constexpr (WIN) {
         if (load_w && tid < G::W_ITEMS) {
+          {
+            // buffer addressing: resource = the packed weights, scalar offset = (tap, first channel of the chunk, channel block), vector offset = the
+            // thread's hoisted (channel-in-chunk, output channel) - nine loads, no vector address arithmetic (layers with many chunks re-stage per chunk)
+            const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0x7FFFFFFF, 0x00020000);
+            const int w_vo = 4 * ((tid >> 4) * a.cout_pad + (tid & 15));
+            const int tap_stride = 4 * a.cin_pad * a.cout_pad, w_so = 4 * (c0 * a.cout_pad + co0);
 #pragma unroll
-          for (int tap = 0; tap < 9; ++tap) rww[tap] = a.w[((size_t)tap * a.cin_pad + c0 + (tid >> 4)) * a.cout_pad + co0 + (tid & 15)];
+            for (int tap = 0; tap < 9; ++tap) rww[tap] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rwt, w_vo, w_so + tap * tap_stride, 0));
+          }
         }
       } else
       if (load_w) {
