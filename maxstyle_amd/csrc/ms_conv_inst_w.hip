@@ -38,17 +38,9 @@ static int wide_pro(const ConvArgs& a, hipStream_t st) {
     default: return launch_conv_wide_r<NT, 2, 1>(a, st);
   }
 }
-template <typename WT>
-static int wide_wino(const ConvArgs& a, hipStream_t st) {
-  switch (a.pro_mode) {
-    case 0: return launch_conv_wide_t<1, 0, 1, true, WT>(a, st);
-    case 1: return launch_conv_wide_t<1, 1, 1, true, WT>(a, st);
-    default: return launch_conv_wide_t<1, 2, 1, true, WT>(a, st);
-  }
-}
+int conv_dispatch_wino(const ConvArgs& a, hipStream_t st);      // ms_conv_inst_wino.hip
 int conv_dispatch_wide(const ConvArgs& a, int nt, hipStream_t st) {
-  if (a.Wout < 64 && a.act_bf16 != 2) return a.act_bf16 ? wide_wino<ms_bf16w32>(a, st) : wide_wino<ms_f32w32>(a, st);      // (conv_wide_eligible admitted it for this form only)
-  if (conv_wino_on(a)) return a.act_bf16 ? wide_wino<ms_bf16w>(a, st) : wide_wino<ms_f32w>(a, st);
+  if ((a.Wout < 64 && a.act_bf16 != 2) || conv_wino_on(a)) return conv_dispatch_wino(a, st);      // (rows below 64 pixels: conv_wide_eligible admitted them for this form only)
   if (conv_wide_rows(a, nt >= 2 ? 2 : 1) == 8) return conv_dispatch_wide8(a, nt, st);
   return nt >= 2 ? wide_pro<2>(a, st) : wide_pro<1>(a, st);
 }
