@@ -893,7 +893,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
             for (int q = 0; q < 2; ++q)
               if (ok[row][q]) {
                 const float d0 = o[row][4 * q] - mean, d1 = o[row][4 * q + 1] - mean, d2 = o[row][4 * q + 2] - mean, d3 = o[row][4 * q + 3] - mean;
-                qq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                qq += __builtin_fmaf(d1, d1, d0 * d0) + __builtin_fmaf(d3, d3, d2 * d2);      // (fused: 2 instructions less per quad, and closer to the exact sum)
               }
           const float nt_ = st_n + cnt;
           const float wgt = cnt * __builtin_amdgcn_rcpf(nt_);
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
               v.w = o[row][4 * q + 3] * ((mk_sc[0] * uu.w + mk_sh[0] > 0.f) ? 1.f : a.mk_slope);
               if constexpr (INT) w_store4(ro, st_voff + WQB * q, v); else IO::st4(a.out, off + 4 * q, v);
               s1 += (v.x + v.y) + (v.z + v.w);
-              s2 += (v.x * (uu.x - mk_mu[0]) + v.y * (uu.y - mk_mu[0])) + (v.z * (uu.z - mk_mu[0]) + v.w * (uu.w - mk_mu[0]));
+              s2 += __builtin_fmaf(v.y, uu.y - mk_mu[0], v.x * (uu.x - mk_mu[0])) + __builtin_fmaf(v.w, uu.w - mk_mu[0], v.z * (uu.z - mk_mu[0]));
             }
           }
         }
