@@ -1,6 +1,5 @@
 // Instantiations: Winograd F(2x2, 3x3) mode of the wide-read convolution kernel (ms_conv_wide.h, storage tags ms_f32w / ms_f32w32 / ms_bf16w / ms_bf16w32).
-// Its own translation unit because it is compiled with -fno-slp-vectorize (Makefile): left on, the SLP vectorizer packs the transforms' additions into
-// v_pk_add_f32 through v_mov shuffles - 149 instead of 133 vector instructions for the output transform, 20 moves in the statistics epilogue.
+// (Its own translation unit for build parallelism; the whole library is compiled with -fno-slp-vectorize, see the Makefile.)
 #include "ms_conv_wide.h"
 namespace ms {
 template <typename WT>
