@@ -13,7 +13,8 @@ static bool conv_wino_on(const ConvArgs& a) {
 // rows of 32..63 pixels: only the Winograd form has a tile for them (8 rows x 32 pixels); MS_CONV_WINO32=0 leaves them to the first-generation kernel
 static bool conv_wino32_on(const ConvArgs& a) {
   static const bool on = !(getenv("MS_CONV_WINO32") && atoi(getenv("MS_CONV_WINO32")) == 0);
-  return on && a.Wout >= 32 && a.Wout < 64 && conv_wino_on(a);
+  static const int minw = getenv("MS_CONV_WINO32_MINW") ? atoi(getenv("MS_CONV_WINO32_MINW")) : 32;      // A/B: narrower rows leave part of the 32-pixel tile empty
+  return on && a.Wout >= minw && a.Wout < 64 && conv_wino_on(a);
 }
 bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool vec) {
   static const bool off = getenv("MS_CONV_WIDE") != nullptr && atoi(getenv("MS_CONV_WIDE")) == 0;      // A/B switch for timing
@@ -24,7 +25,7 @@ bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool v
   //  first-generation kernel at 16->16 @16x256x256)
   // fp32 arithmetic: rows of at least one 64-pixel tile.  bf16 matrix arithmetic (act_bf16 == 2): the matrix work of the padding columns of a narrower row is
   // cheap, the first-generation kernel's fp32 MFMAs are not - rows from 16 pixels up take this kernel
-  if (a.Wout < (a.act_bf16 == 2 ? 16 : (conv_wino32_on(a) ? 32 : 64)) || a.Wout % 4 != 0) return false;
+  if (a.Wout < (a.act_bf16 == 2 ? 16 : (conv_wino32_on(a) ? 16 : 64)) || a.Wout % 4 != 0) return false;
   if ((long long)a.Cin * a.Hs * a.Ws + a.Ws + 4 >= (1LL << 29)) return false;      // byte offsets inside one image fit 31 bits (buffer addressing of the staging)
   if ((long long)a.Cout * a.Hout * a.Wout >= (1LL << 29)) return false;              // ... and so do the epilogue's offsets inside one output image
   if (!aligned16(a.out)) return false;
