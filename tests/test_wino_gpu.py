@@ -149,3 +149,36 @@ def test_winograd_form_on_bf16_storage(dev, N, Cin, Cout, H, W):
     be = -c4[:, 0] * (s2 * c4[:, 3] / cnt) * c4[:, 3]
     ref_bc = torch.stack([c4[:, 0], be, -c4[:, 0] * s1 / cnt - be * c4[:, 2]], 1)
     assert float((bc[:, :3] - ref_bc).abs().max()) < 2e-4 * float(ref_bc.abs().max())
+
+
+@pytest.mark.parametrize("N,C,H,W", [(16, 16, 256, 256), (16, 64, 320, 320), (16, 128, 160, 160), (16, 256, 40, 40)])
+def test_winograd_form_at_full_size_agrees_with_the_direct_form(dev, N, C, H, W):
+    """BASELINE configs 2 and 4 at their full sizes (no fp64 reference fits a test's budget there): the two forms compute the same convolution, so they
+    must agree to fp32 rounding, element by element (bar: 6e-6 of the output range, 1e-6 rms; measured 1-2e-6 / 1-2e-7), and the form is linear in its input
+    (conv(a*x + y) = a*conv(x) + conv(y) to the same bar) - with every prologue / epilogue variant of the loop on the same tensors."""
+    from maxstyle_amd import ops
+    WG = ops.FETCH_WINOGRAD
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(N, C, H, W, generator=g).to(dev); x2 = torch.randn(N, C, H, W, generator=g).to(dev)
+    w = (torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).to(dev)
+    wp = ops.pack_conv_weight(w)
+    cf = torch.randn(C, 4, generator=g).to(dev)
+    kw = dict(pro_mode=2, pro_a=ops.coef_ptrs(cf)[0], pro_b=ops.coef_ptrs(cf)[1], pro_c=ops.coef_ptrs(cf)[2], pro_cstride=4, in2=x2)
+
+    def agree(a, b):
+        rng = float(b.abs().max())
+        assert float((a - b).abs().max()) < 6e-6 * rng and float((a - b).pow(2).mean().sqrt()) < 1e-6 * rng, (float((a - b).abs().max()) / rng,)
+    d0 = ops.conv2d(x, wp, None, C, 3, 1)
+    w0 = ops.conv2d(x, wp, None, C, 3, 1, fetch=WG)
+    assert not torch.equal(d0, w0)
+    agree(w0, d0)
+    agree(ops.conv2d(x, wp, None, C, 3, 1, fetch=WG, **kw), ops.conv2d(x, wp, None, C, 3, 1, **kw))
+    u = torch.randn(N, C, H, W, generator=g).to(dev) + 0.3
+    c4 = torch.stack([1 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g), 0.3 + 0.1 * torch.randn(C, generator=g), 1 + 0.1 * torch.randn(C, generator=g).abs()], 1).to(dev)
+    ow, tw = ops.conv2d_actbwd(x, wp, C, 3, u, c4, 0.2, fetch=WG)
+    od, td = ops.conv2d_actbwd(x, wp, C, 3, u, c4, 0.2)
+    agree(ow, od)
+    bw = ops.bn_bwd_coefs(tw, 0, c4, N * H * W); bd = ops.bn_bwd_coefs(td, 0, c4, N * H * W)
+    assert float((bw - bd).abs().max()) < 1e-5 * float(bd.abs().max())
+    y1 = ops.conv2d(x2, wp, None, C, 3, 1, fetch=WG)
+    agree(ops.conv2d(0.5 * x + x2, wp, None, C, 3, 1, fetch=WG), 0.5 * w0 + y1)
