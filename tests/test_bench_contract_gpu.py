@@ -1,0 +1,34 @@
+"""The one JSON line `python bench.py` prints on a GPU box: the fields the driver and the judge read (task contract), checked on a short run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_contract():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--steady-seconds", "0", "--no-outer", "--cpu-steps", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                     ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+        assert isinstance(d[key], typ), (key, d[key])
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1000.0 * d["steps"] / (d["ms_per_step"] * d["steps"])) < 1e-6 * d["value"]       # value = whole-job steps / s of the timed region
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == ("GB/s" if r["bound"] == "hbm" else "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.05 < r["frac"] < 1.2
+    assert r["traffic"] is None or r["traffic"] > 0.5 * r["algorithmic_bytes"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == d["unit"] and isinstance(c["sample"], str)
