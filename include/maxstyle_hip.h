@@ -147,7 +147,7 @@ int ms_counter_incr(int* counter, void* stream);
  *   ks/stride (3,1) (3,2) (1,1) (2,2); padding = 1 for ks 3 else 0
  *   fetch     0 normal | 1 nearest x2 up-sampling fused into the load | 2 zero-insertion x2 (stride-2 data-gradient)
  *             | MS_FETCH_WINOGRAD (bit 8, with fetch 0): the caller ACCEPTS the Winograd F(2x2,3x3) form of a 3x3 stride-1 convolution where it is built
- *             (fp32 storage, Cin % 8 == 0, rows of >= 64 pixels with W % 4 == 0): 16 instead of 36 multiplications per 2x2 outputs, the same fp32
+ *             (fp32 or bf16 storage, Cin % 8 == 0, rows of >= 20 pixels with W % 4 == 0): 16 instead of 36 multiplications per 2x2 outputs, the same fp32
  *             matrix instruction.  On random data it is as close to fp64 as the direct form (2-4e-7 of the output range); on the networks'
  *             activations (non-zero channel means: the transforms add and subtract values of the size of the mean) its rounding error is about twice
  *             the direct form's, which doubles the activation-mask flips behind a backward pass - measured on the full-size training pass, weight

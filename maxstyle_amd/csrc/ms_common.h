@@ -139,7 +139,7 @@ struct ms_bf16w { uint16_t v; };
 template <> struct ActIO<ms_bf16w> : ActIO<ms_bf16> {};
 struct ms_bf16w32 { uint16_t v; };
 template <> struct ActIO<ms_bf16w32> : ActIO<ms_bf16> {};
-// ms_f32w32: the same on 8-row x 32-pixel tiles (rows of 32..63 pixels)
+// ms_f32w32: the same on 8-row x 32-pixel tiles (rows of 20..63 pixels)
 struct ms_f32w32 { float v; };
 template <> struct ActIO<ms_f32w32> : ActIO<float> {};
 

@@ -10,10 +10,12 @@ static bool conv_wino_on(const ConvArgs& a) {
   if (a.act_bf16 == 2 || a.cin_pad % 8 != 0 || a.Cin != a.cin_pad) return false;      // (bf16 matrix arithmetic has its own kernel mode)
   return cdiv(a.Cout, 16) <= max_cb;
 }
-// rows of 32..63 pixels: only the Winograd form has a tile for them (8 rows x 32 pixels); MS_CONV_WINO32=0 leaves them to the first-generation kernel
+// rows of 20..63 pixels: only the Winograd form has a tile for them (8 rows x 32 pixels); MS_CONV_WINO32=0 leaves them to the first-generation kernel
 static bool conv_wino32_on(const ConvArgs& a) {
   static const bool on = !(getenv("MS_CONV_WINO32") && atoi(getenv("MS_CONV_WINO32")) == 0);
-  static const int minw = getenv("MS_CONV_WINO32_MINW") ? atoi(getenv("MS_CONV_WINO32_MINW")) : 32;      // A/B: narrower rows leave part of the 32-pixel tile empty
+  // narrower rows leave part of the 32-pixel tile empty: at 20 pixels (62 % full) the form still executes 0.71x the direct form's multiplications and wins
+  // (C4's 512-channel 20x20 layers: 27.1 -> 29.3 steps/s), at 16 pixels (0.89x) it loses to the first-generation kernel (C2: 21.9 -> 23.7 us per launch)
+  static const int minw = getenv("MS_CONV_WINO32_MINW") ? atoi(getenv("MS_CONV_WINO32_MINW")) : 20;
   return on && a.Wout >= minw && a.Wout < 64 && conv_wino_on(a);
 }
 bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool vec) {

@@ -66,7 +66,7 @@ struct WideGeoBF {
 // its plane stride is == 32 (mod 64 dwords) so that the 8-byte patch reads of the four K lanes groups of a wave fall on disjoint banks.  The weight region of a
 // stage holds the chunk's TRANSFORMED weights U = G g G^T as [16 positions][CK channels][16 output channels]: a lane's B fragment of position p and channel
 // group cg is one ds_read_b32 at p*128 + cg*64 + lane (64 consecutive dwords per wave: conflict-free).
-// TW_ = 64: 4-row tiles (waves = 2 tile rows x 2 halves of 32 pixels); TW_ = 32: 8-row tiles (waves = 4 tile rows) for rows of 32..63 pixels.
+// TW_ = 64: 4-row tiles (waves = 2 tile rows x 2 halves of 32 pixels); TW_ = 32: 8-row tiles (waves = 4 tile rows) for rows of 20..63 pixels.
 template <int PRO, int TW_ = 64>
 struct WideGeoW {
   static constexpr int TW = TW_, TH = 256 / TW_, CK = 8, IH = TH + 2;
