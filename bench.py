@@ -249,6 +249,10 @@ def kernel_rooflines(eng, dev, config):
         blk.update({"traffic": traffic.get(tkey), "kernel": kernel + " " + shape, "us_per_launch": t[key] * 1e6, "algorithmic_bytes": nbytes,
                     "hbm_GBps": nbytes / t[key] / 1e9, "hbm_frac": hf, "flop_per_launch": flops, "tflops": flops / t[key] / 1e12, "mfma_frac": mf,
                     "form": "winograd F(2x2,3x3)" if (wino and C % 8 == 0 and W >= 64 and W % 4 == 0) else "direct"})
+        if blk["form"] != "direct":
+            # what the matrix pipe itself executes in this form: 16 multiplications per 2x2 outputs instead of 36
+            blk["executed_tflops"] = blk["tflops"] * 16.0 / 36.0
+            blk["executed_mfma_frac"] = mf * 16.0 / 36.0
         return blk
 
     def hbm_block(key, kernel, nbytes, tkey):
