@@ -508,7 +508,7 @@ def mixed_stream(dev, args, rank, world, dist_on):
     advanced_triplet...py:458-571) alternating ACDC-shaped (FCN_16, 16x1x256x256, K=5) and Prostate-shaped (FCN_64, 16x3x320x320, K=10) batches,
     every call drawing its own random subset of MaxStyle layers with the trainer's p=0.5 (train_adv...py:263).  One captured HIP graph per
     (shape, layer subset) signature is kept by the solver; the first pass over the stream captures them, the timed passes replay.  Activation storage is
-    fp32 (bf16 storage exists for the MaxStyle kernels only - DESIGN.md); a call whose layers all draw "not applied" runs 0 steps, as in the reference."""
+    fp32 unless --act-dtype bf16 [--mfma bf16] ("bf16 conv stack"); a call whose layers all draw "not applied" runs 0 steps, as in the reference."""
     import maxstyle_amd
     from maxstyle_amd import synthetic as syn
     cfgs = []
@@ -570,6 +570,41 @@ def mixed_stream(dev, args, rank, world, dist_on):
                        "parallelism": f"dp{world}", "hip_graph": True, "passes": passes, "calls_per_pass": args.stream_calls},
             "calls": [{"shape": t, "layers_applied": a} for t, a in subsets], "seconds": dt,
             "note": "whole-call rate through the drop-in solver API: includes MaxStyle construction, the initial and final decodes and the host side of every call"}
+
+
+def whole_call(dev, args, rank):
+    """the rate of the reference's own entry point, `generate_max_style_image` through the drop-in solver API at the C2 workload - whole-call
+    steps/s K / t_call (MaxStyle construction, the clean decode, K steps, the final decode, the host side) and K / (t_call - t_decode_only), where
+    t_decode_only is the same call with n_iter = 0 (everything but the K steps)."""
+    import maxstyle_amd
+    from maxstyle_amd import synthetic as syn
+    net, K = (4, 1, 4), 5
+    spec = syn.NetSpec(*net)
+    S = maxstyle_amd.AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard_no_STN", image_ch=net[1], num_classes=net[2], use_gpu=True)
+    Wt = syn.procedural_weights(spec, 0)
+    for name, mod in S.model.items():
+        mod.load_state_dict(Wt[name]); mod.train()
+    img, lab = syn.synthetic_batch(args.batch, args.size, net[1], net[2], seed=1234 + rank)
+    img, lab = img.to(dev), lab.to(dev)
+    z_i, _ = S.encode_image(img, disable_track_bn_stats=True)
+    z_i = z_i.detach()
+
+    def call(n_iter):
+        return S.generate_max_style_image(z_i, [3, 4, 5], spec.channel_num, p=1.5, n_iter=n_iter, lr=0.1, reference_image=img, reference_segmentation=lab, fix_seed=7)
+
+    def timed(n_iter, reps):
+        for _ in range(3):
+            call(n_iter)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call(n_iter)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    t_call, t_dec = timed(K, 20), timed(0, 20)
+    return {"what": "generate_max_style_image through the drop-in API, C2 workload, K=5, every layer applied (p forced), captured graph replayed per call",
+            "ms_per_call": t_call * 1e3, "ms_decode_only_call": t_dec * 1e3, "whole_call_steps_s": K / t_call,
+            "steps_s_excluding_decode": K / max(t_call - t_dec, 1e-9)}
 
 
 def _free_port():
@@ -724,6 +759,8 @@ def main():
             res["speedup_vs_cpu"] = value / res["cpu_baseline"]["value"]
             res["drift_full_size"] = drift_c2(eng, styles, z_i, lab_d, cpu_image, args.cpu_steps)
             res["dice_parity"] = dice_parity(dev)
+        if world == 1 and args.config == "c2" and not bf16 and not args.no_outer:
+            res["whole_call"] = whole_call(dev, args, rank)
     if not args.no_outer and args.config == "c2" and not bf16:
         del eng
         torch.cuda.empty_cache()
