@@ -182,3 +182,35 @@ def test_winograd_form_at_full_size_agrees_with_the_direct_form(dev, N, C, H, W)
     assert float((bw - bd).abs().max()) < 1e-5 * float(bd.abs().max())
     y1 = ops.conv2d(x2, wp, None, C, 3, 1, fetch=WG)
     agree(ops.conv2d(0.5 * x + x2, wp, None, C, 3, 1, fetch=WG), 0.5 * w0 + y1)
+
+
+def test_inner_loop_with_and_without_the_winograd_form(dev):
+    """K = 3 free-running steps at 64x64 on the same networks and style state: the loop that asks for the Winograd form and the one that does not are two
+    roundings of the same computation - different bits (the form really runs inside the loop), losses equal to 2e-5, images to 2e-4 of their range."""
+    from oracle import maxstyle_oracle as orc
+    from maxstyle_amd import engine as E
+    from test_engine_gpu import build_engine
+    spec = orc.NetSpec(4, 1, 4)
+    B, size, layers = 4, 64, [3, 4, 5]
+    ew, W, img, lab, styles = build_engine(dev, spec, B, size, layers)
+    ed = E.InnerLoopEngine(E.NetSpec(spec.reduce, spec.image_ch, spec.num_classes), B, size, size, dev, lr=0.1)
+    ed.winograd = False
+    ed.set_nets(ew.nets)
+    ed.configure_styles(layers, {i: E.StyleSlot(i, B, spec.channel_num[i]) for i in layers})
+    assert ew.winograd and not ed.winograd
+    z = ew.encode_fwd(img.to(dev))[0].clone()
+    labd = lab.to(dev)
+    outs = []
+    for eng in (ew, ed):
+        for i in layers:
+            eng.styles[i].have_std = False
+            st = orc.random_style_state(B, spec.channel_num[i], 7 + i)
+            eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
+        eng.flat_m.zero_(); eng.flat_v.zero_(); eng.flat_g.zero_()
+        out = eng.run(z, labd, 3, use_graph=False).float().clone()
+        outs.append((out, eng.losses(3).clone()))
+        eng.check_errors(sync=True)
+    (ow, lw), (od, ld) = outs
+    assert not torch.equal(ow, od)
+    assert float(((lw - ld) / ld).abs().max()) < 2e-5, (lw, ld)
+    assert float((ow - od).abs().max()) < 2e-4 * float(od.abs().max())
