@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only: gloo on the CPU, stand-in step (CPU tests)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend of the real run (nccl = RCCL; gloo: validation of the N>1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than GPUs (rank r uses GPU r %% device_count): functional validation only, not a measurement")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the distributed path at ANY world size, also 1: the launcher parent starts the rank(s), the rank creates the RCCL process group with "
+                         "device_id, barriers bracket the timed region, max-over-ranks and the flat outer-gradient all-reduce go through RCCL")
+    ap.add_argument("--no-rccl-selftest", action="store_true", help="skip the world-size-1 RCCL self-test leg of a plain single-process run")
     return ap.parse_args()
 
 
@@ -431,7 +435,7 @@ def cpu_baseline(W, img, lab, styles, steps, z_gpu=None):
     return rec, final
 
 
-def outer_iteration(dev, batch, size, rank=0, world=1, iters=6):
+def outer_iteration(dev, batch, size, rank=0, world=1, iters=6, dist_on=None):
     """Auxiliary figure (not the headline metric): whole training iterations/s around the inner loop at the same configuration -
     standard pass -> MaxStyle inner loop K=5 -> hard-example pass -> backward (weight gradients) -> [N > 1: ONE flat RCCL all-reduce of the
     outer gradients] -> AdamW x3 (train_adv_supervised_segmentation_triplet.py:163-199, 251-287, 532-535; SURVEY.md 8(e), 8(f) rows 1,3).
@@ -440,7 +444,8 @@ def outer_iteration(dev, batch, size, rank=0, world=1, iters=6):
     from maxstyle_amd import synthetic as syn
     import torch.distributed as dist
     S = M.AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard_no_STN", image_ch=1, num_classes=4, use_gpu=True, optimizer_type="AdamW")
-    if world > 1:
+    dist_on = (world > 1) if dist_on is None else dist_on           # --force-dist: the collective path also at world size 1
+    if dist_on:
         from maxstyle_amd import distributed as D
         D.broadcast_parameters(list(S.model.values()), src=0)
     clean, lab = syn.synthetic_batch(batch, size, 1, 4, 1234 + rank)
@@ -466,28 +471,28 @@ def outer_iteration(dev, batch, size, rank=0, world=1, iters=6):
     for _ in range(2):
         iteration()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(iters):
         loss = iteration()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     dt = (time.perf_counter() - t0) / iters
     out = {"what": "training iterations/s (standard pass + K=5 inner loop + hard-example pass + backward + flat all-reduce at N>1 + AdamW), per-GPU batch "
                    + str(batch), "ms_per_iteration": dt * 1e3, "loss_first": first, "loss_last": float(loss.detach())}
-    if world > 1:
+    if dist_on:
         from maxstyle_amd import distributed as D
         dt = D.max_over_ranks(dt, dev)
         bank = S._param_bank()
         flat = bank.flat_g
         for _ in range(3):
-            bank.all_reduce_grads()
+            bank.all_reduce_grads(force=True)
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
         for _ in range(20):
-            bank.all_reduce_grads()
+            bank.all_reduce_grads(force=True)
         torch.cuda.synchronize()
         ar = D.max_over_ranks((time.perf_counter() - t0) / 20, dev)
         # rank-equal weights after the exchanged steps: max |w_r - w_0| over ranks
@@ -501,6 +506,54 @@ def outer_iteration(dev, batch, size, rank=0, world=1, iters=6):
     out["value"] = world / dt
     out["per_gpu"] = 1.0 / dt
     return out
+
+
+def rccl_leg(dev, rank, run_one=None):
+    """The collective path of the surrounding training step on the LIVE process group, at any world size (1 included): barrier, max-over-ranks, and the
+    ONE exchange of an outer iteration - the in-place flat all-reduce (sum, then x 1/world) of the outer gradients (train_adv...py:532-535) -
+    timed at the two sizes the path has: FCN_16's 1.54 M parameters (6.1 MB) and an FCN_64-sized buffer (24.5 M, 98 MB).  With `run_one` (the captured
+    inner step) it also replays the step graph between collectives: graph replay and the process group coexist on the device."""
+    import torch.distributed as dist
+    from maxstyle_amd import distributed as D
+    world = dist.get_world_size()
+    out = {"backend": dist.get_backend(), "world_seen": world, "device_id_bound": True}
+    dist.barrier()
+    out["max_over_ranks_ok"] = D.max_over_ranks(float(rank + 1), dev) == float(world)
+    for tag, n in (("fcn16_6MB", 1536325), ("fcn64_98MB", 24500000)):
+        flat = torch.full((n,), float(rank + 1), device=dev)
+        dist.all_reduce(flat); flat.mul_(1.0 / world)
+        ok = bool(torch.all(flat == (world + 1) / 2.0))
+        for _ in range(3):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(flat)
+            if run_one is not None and tag == "fcn16_6MB":
+                run_one()                                   # the inner step's graph between two collectives
+        torch.cuda.synchronize()
+        dt = D.max_over_ranks((time.perf_counter() - t0) / 20, dev)
+        out[tag] = {"bytes": n * 4, "mean_ok": ok, "ms": dt * 1e3, "algbw_GBps": n * 4 / dt / 1e9,
+                    **({"with_step_graph_replay_between": True} if (run_one is not None and tag == "fcn16_6MB") else {})}
+        del flat
+    dist.barrier()
+    return out
+
+
+def rccl_selftest(dev, run_one=None):
+    """A plain `python bench.py` (one process, no launcher) still executes the RCCL path: a world-size-1 `nccl` process group bound to the device
+    (`device_id`), created AFTER the timed region so it cannot touch the headline, torn down afterwards.  Never fatal: a failure is reported in the line."""
+    import torch.distributed as dist
+    try:
+        if dist.is_initialized():
+            return {"skipped": "a process group is already live"}
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+        try:
+            return rccl_leg(dev, 0, run_one)
+        finally:
+            dist.destroy_process_group()
+    except Exception as ex:  # noqa: BLE001
+        return {"error": repr(ex)[:400]}
 
 
 def mixed_stream(dev, args, rank, world, dist_on):
@@ -615,13 +668,15 @@ def _free_port():
 
 def launch_children(args):
     """Parent of `python bench.py --gpus N` when no launcher set RANK: starts N ranks of this file (one per GPU) and waits.
-    This process has made no GPU call (torch.cuda.device_count() does not initialise HIP on this image) and never exec's."""
+    This process makes no GPU call of any kind - the GPUs are counted from the KFD topology in sysfs, not through torch.cuda / HIP
+    (maxstyle_amd.distributed.visible_gpu_count) - and never exec's."""
     import subprocess
+    from maxstyle_amd.distributed import visible_gpu_count
     n = args.gpus
     if not args.dry_run and not args.oversubscribe:
-        have = torch.cuda.device_count()
-        if have < n:
-            print(f"[bench] --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+        have = visible_gpu_count()
+        if 0 <= have < n:
+            print(f"[bench] --gpus {n} but only {have} GPU(s) are visible (KFD topology, *_VISIBLE_DEVICES applied)", file=sys.stderr)
             return 2
     port = _free_port()
     procs = []
@@ -650,22 +705,23 @@ def dry_run(args, rank, world):
     import torch.distributed as dist
     from maxstyle_amd import distributed as D
     dev = torch.device("cpu")
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     a = torch.randn(64, 64)
     step = lambda: (a @ a).sum().item()
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if multi:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
     ar = None
-    if world > 1:
+    if multi:
         dt = D.max_over_ranks(dt, dev)
         flat = torch.full((1536325,), float(rank + 1))
         dist.all_reduce(flat); flat.mul_(1.0 / world)
@@ -676,7 +732,7 @@ def dry_run(args, rank, world):
                           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
                           "config": {"workload": "DRY RUN (CPU stand-in step, gloo): rank plumbing only, not a measurement", "global_batch": args.batch * world,
                                      "parallelism": f"dp{world}"}, "outer_iteration": ar}), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     return 0
@@ -684,7 +740,7 @@ def dry_run(args, rank, world):
 
 def main():
     args = parse()
-    if "RANK" not in os.environ and args.gpus > 1:
+    if "RANK" not in os.environ and (args.gpus > 1 or args.force_dist):
         return launch_children(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -695,14 +751,21 @@ def main():
     if args.dry_run:
         os.environ.setdefault("MASTER_PORT", "29513")
         return dry_run(args, rank, world)
-    dist_on = world > 1
+    dist_on = world > 1 or args.force_dist
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    ndev = torch.cuda.device_count()
+    shared = args.oversubscribe or int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > ndev
+    if shared:
+        # several ranks on one GPU: the co-residency-dependent single-read MaxStyle kernel must not be selected; the engines read this switch
+        os.environ["MS_SHARED_DEVICE"] = "1"
     if args.oversubscribe:
-        local = local % torch.cuda.device_count()
+        local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist_on:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29514")
+        os.environ.setdefault("RANK", str(rank)); os.environ.setdefault("WORLD_SIZE", str(world))
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)     # RCCL on ROCm: barriers, max-over-ranks, the outer-gradient all-reduce
         else:
@@ -761,10 +824,16 @@ def main():
             res["dice_parity"] = dice_parity(dev)
         if world == 1 and args.config == "c2" and not bf16 and not args.no_outer:
             res["whole_call"] = whole_call(dev, args, rank)
+    if dist_on:
+        rl = rccl_leg(dev, rank, run_one) if args.backend == "nccl" else None      # every rank: collectives
+        if rank == 0:
+            res["rccl"] = rl
+    elif rank == 0 and not args.no_rccl_selftest:
+        res["rccl"] = rccl_selftest(dev, run_one)
     if not args.no_outer and args.config == "c2" and not bf16:
-        del eng
+        del eng, run_one
         torch.cuda.empty_cache()
-        oi = outer_iteration(dev, args.batch, args.size, rank, world)      # every rank: contains the collective
+        oi = outer_iteration(dev, args.batch, args.size, rank, world, dist_on=dist_on)      # every rank: contains the collective
         if rank == 0:
             res["outer_iteration"] = oi
     if rank == 0:

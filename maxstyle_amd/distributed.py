@@ -7,10 +7,60 @@ FCN_16, ~98 MB for FCN_64) between `loss.backward()` and the optimiser steps (tr
 (sum, then x 1/world) instead of one collective per tensor - on MI355X xGMI is point-to-point (7 links x ~153 GB/s per GPU), the
 6 MB buffer is latency-bound, so fewer, larger messages are what matters.  backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
 """
-from typing import Dict, Iterable, List
+import os
+from typing import Dict, Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
+
+KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"
+
+
+def _visible_list(value: str) -> int:
+    """Number of devices a *_VISIBLE_DEVICES value selects: comma-separated indexes / UUIDs, cut at the first empty or negative entry
+    (the runtime's rule: everything after an invalid entry is ignored)."""
+    n = 0
+    for tok in value.split(","):
+        tok = tok.strip()
+        if not tok or tok.startswith("-"):
+            break
+        n += 1
+    return n
+
+
+def visible_gpu_count(kfd_nodes: str = KFD_NODES, env: Optional[Dict[str, str]] = None, dri: str = "/dev/dri") -> int:
+    """GPUs this process tree may use, WITHOUT touching HIP / torch.cuda: KFD topology nodes that have SIMDs (CPU nodes have simd_count 0)
+    and whose render node this process can open (a container sees every GPU of the host in sysfs but only its own /dev/dri/renderD*),
+    narrowed by ROCR_VISIBLE_DEVICES and then HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  For the parent of `bench.py --gpus N`, which must
+    stay free of any GPU call before it starts its ranks (a GPU-initialised process is never forked or exec'ed).  Returns -1 when the
+    topology is not readable (not a ROCm box): the caller then skips its check rather than guess."""
+    env = os.environ if env is None else env
+    try:
+        nodes = sorted(os.listdir(kfd_nodes), key=lambda s: (len(s), s))
+    except OSError:
+        return -1
+    n = 0
+    for node in nodes:
+        try:
+            props = {}
+            with open(os.path.join(kfd_nodes, node, "properties")) as f:
+                for line in f:
+                    k, _, v = line.partition(" ")
+                    props[k] = v.strip()
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            minor = int(props.get("drm_render_minor", "-1"))
+            if minor >= 0 and os.path.isdir(dri) and not os.access(os.path.join(dri, f"renderD{minor}"), os.R_OK | os.W_OK):
+                continue
+            n += 1
+        except (OSError, ValueError):
+            continue
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+        if var in env:
+            n = min(n, _visible_list(env[var]))
+    if "HIP_VISIBLE_DEVICES" not in env and "CUDA_VISIBLE_DEVICES" in env:      # HIP honours the CUDA spelling when its own is unset
+        n = min(n, _visible_list(env["CUDA_VISIBLE_DEVICES"]))
+    return n
 
 
 def _params(modules: Iterable[torch.nn.Module]) -> List[torch.nn.Parameter]:

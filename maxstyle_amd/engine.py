@@ -289,7 +289,9 @@ class InnerLoopEngine:
         self._cfg_cache = {}
         self._err_pending = None
         self._ws_state_off = {}
-        self.shared_device = False    # True: other kernels run beside the loop (side streams / other processes): no single-read MaxStyle kernel
+        # True: other kernels run beside the loop (side streams / other processes on this GPU): the co-residency-dependent single-read MaxStyle kernel
+        # is not selected (three-launch path).  MS_SHARED_DEVICE=1 sets it for every engine of the process (several ranks per GPU, bench.py --oversubscribe).
+        self.shared_device = os.environ.get("MS_SHARED_DEVICE", "0") != "0"
         self._prefix_valid = False
         self.labels = None
         self.code = None
@@ -371,6 +373,7 @@ class InnerLoopEngine:
         return torch.cuda.current_stream().cuda_stream
 
     # ------------------------------------------------------------------ per-signature loop state (flat buffers + captured graph)
+    CFG_CACHE_MAX = 16
     _CFG_FIELDS = ("layers", "styles", "nparam", "flat_p", "flat_g", "flat_m", "flat_v", "learn_segments", "_graph", "_graph_in", "_cfg_sig")
 
     def _any_graph(self):
@@ -380,12 +383,20 @@ class InnerLoopEngine:
         """Remember the current style layout (flat parameter / gradient / moment buffers, the captured step) under `sig`.  A later call with the
         same signature gets it back with `restore_config` - the trainer's random-depth insertion (p = 0.5 per layer, train_adv...py:263) cycles
         through at most 8 layouts, each captured once."""
+        self._cfg_cache.pop(sig, None)                       # re-insert: dict order = recency
         self._cfg_cache[sig] = {f: getattr(self, f, None) for f in self._CFG_FIELDS}
+        while len(self._cfg_cache) > self.CFG_CACHE_MAX:       # a caller that schedules lr / the loss weight makes a new signature per call:
+            old = next(iter(self._cfg_cache))                # drop the least recently used entry, its captured graph first, then its buffers
+            ent = self._cfg_cache.pop(old)
+            g = ent.pop("_graph", None)
+            del g
+            ent.clear()
 
     def restore_config(self, sig):
-        ent = self._cfg_cache.get(sig)
+        ent = self._cfg_cache.pop(sig, None)
         if ent is None:
             return False
+        self._cfg_cache[sig] = ent                            # most recently used
         for f, v in ent.items():
             setattr(self, f, v)
         self.flat_m.zero_(); self.flat_v.zero_(); self.flat_g.zero_()
@@ -406,21 +417,29 @@ class InnerLoopEngine:
                 words.append(ws[off + 4:off + 8].view(torch.int32))
         return words
 
-    def check_errors(self, sync=False):
+    def check_errors(self, sync=True):
         """A bounded spin of the single-read kernel that timed out leaves its statistics invalid and sets an error word in the layer's state block.
-        Product code must never return such a result silently: this queues an asynchronous copy of the words (pinned host buffer + event) and
-        resolves the copy queued by the PREVIOUS call (complete by then: no host stall on the hot path); sync=True waits for the new one too.
-        Raises MaxStyleHipError."""
+        Product code must never return such a result: sync=True (the default, what the solver uses) copies the words and WAITS for the copy, so the
+        error is raised by the very call that produced the invalid image.  sync=False is the deferred protocol for callers that must not stall the
+        host: it queues the copy (pinned buffer + event) and resolves the copy queued by the previous call; such a caller flushes with
+        `flush_errors()` before it uses results for anything lasting (the solver does at optimize_all_params / evaluate / save).  Once reported,
+        the device words are cleared - the kernel's epoch / arrival state stays consistent through a time-out (every workgroup still finishes) - so
+        one time-out does not condemn every later call.  Raises MaxStyleHipError."""
         from ._lib import MaxStyleHipError
         pend = self._err_pending
         self._err_pending = None
+        words = self._error_words()
+
+        def report(host, which):
+            if int(host.abs().sum()) != 0:
+                for w in words:
+                    w.zero_()
+                raise MaxStyleHipError("single-read MaxStyle kernel: a bounded spin timed out (the launch did not get the CUs it was sized for - another "
+                                       f"process or stream on this GPU? set MS_SHARED_DEVICE=1 / engine.shared_device); the stylised image of {which} is invalid")
         if pend is not None:
             host, ev = pend
             ev.synchronize()
-            if int(host.abs().sum()) != 0:
-                raise MaxStyleHipError("single-read MaxStyle kernel: a bounded spin timed out (the launch did not get the CUs it was sized for); "
-                                       "the stylised image of the previous call is invalid")
-        words = self._error_words()
+            report(host, "the previous call")
         if not words:
             return
         dev_words = torch.cat(words)
@@ -428,10 +447,23 @@ class InnerLoopEngine:
         host.copy_(dev_words, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._err_pending = (host, ev)
         if sync:
-            self.check_errors(sync=False)
-            self._err_pending = None
+            ev.synchronize()
+            report(host, "this call")
+        else:
+            self._err_pending = (host, ev)
+
+    def flush_errors(self):
+        """Resolve a deferred check (check_errors(sync=False)) now."""
+        if self._err_pending is not None:
+            pend, self._err_pending = self._err_pending, None
+            host, ev = pend
+            ev.synchronize()
+            if int(host.abs().sum()) != 0:
+                from ._lib import MaxStyleHipError
+                for w in self._error_words():
+                    w.zero_()
+                raise MaxStyleHipError("single-read MaxStyle kernel: a bounded spin timed out; the stylised image of the last loop call is invalid")
 
     # ------------------------------------------------------------------ side stream (independent branches of a block)
     class _SideCtx:
@@ -796,7 +828,8 @@ class InnerLoopEngine:
         self._inc_lazy = lazy
         if lazy:
             h, x_act = ub, (cfb, LEAKY)
-            self.buf.pop("e.inc.out", None)
+            if not self._any_graph():          # (a captured graph may hold the tensor's address: leave the stale buffer alone, like t())
+                self.buf.pop("e.inc.out", None)
         else:
             h, x_act = self._mix(1, self.bn_act("e.inc.out", ub, cfb, None, 0, LEAKY)), None
         for i in range(1, 5):

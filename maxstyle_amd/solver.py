@@ -238,6 +238,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         """advanced_triplet...py:914-934: eval-mode prediction of one batch accumulated into self.running_metric; returns the logits."""
         if getattr(self, "running_metric", None) is None:
             self.running_metric = self.set_running_metric()
+        self.flush_loop_errors()
         self.eval()
         pred = self.predict(input, n_iter=n_iter)
         targets = torch.as_tensor(targets_npy)
@@ -262,6 +263,12 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     # "bf16 activations": conv inputs / outputs, gradients and the image are stored as bf16 inside the loop, statistics / parameters / arithmetic fp32; the
     # returned image is fp32 as in the reference).  MS_ACT_DTYPE=bf16 in the environment selects it too.  Module forwards (predict / evaluate / training) are fp32.
     loop_act_dtype = None
+    # True: this process shares its GPU with other processes / streams (several ranks per GPU): the inner loop must not select the single-read MaxStyle
+    # kernel, whose grid assumes it gets every CU (engine.shared_device).  None: the MS_SHARED_DEVICE environment switch decides (default off).
+    loop_shared_device = None
+    # "sync": a spin time-out of the single-read kernel raises MaxStyleHipError from the call that produced the invalid image (one event wait per call);
+    # "deferred": the check is resolved by the next call / optimize_all_params / evaluate / save_model (no host stall on the hot path).  MS_ERROR_CHECK sets the default.
+    loop_error_check = None
     loop_mfma_bf16 = None      # with bf16 storage: also bf16 matrix arithmetic in the 3x3 stride-1 convs (engine.mfma_bf16; MS_MFMA_DTYPE=bf16)
 
     def _loop_engine(self, B, H, W, dev, act_dtype=torch.float32, mfma_bf16=False):
@@ -345,6 +352,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             if mf is None:
                 mf = os.environ.get("MS_MFMA_DTYPE", "").lower() in ("bf16", "bfloat16")
             eng = self._loop_engine(B, h * 16, w * 16, code.device, act_dtype=act, mfma_bf16=mf)
+            if self.loop_shared_device is not None:
+                eng.shared_device = bool(self.loop_shared_device)
             mods = {int(k): m for k, m in nn_style_augmentor_dict.items()}
             slots = E.slots_from_modules(mods, code.device)
             layers = [i for i in sorted(mods) if i in slots]
@@ -354,7 +363,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             lr_ = float(lr)
             loss_sign = -float(sum(w_ for w_, t in zip(loss_weights, loss_types) if t == 'seg')) if optimize and n_iter > 0 else -1.0
             bn_eval = not all(old_state.values())
-            sig = self._cfg_sig(layers, slots) + (lr_, loss_sign, bn_eval)
+            sig = self._cfg_sig(layers, slots) + (lr_, loss_sign, bn_eval, bool(eng.shared_device))
             if not eng.restore_config(sig):
                 eng.configure_styles(layers, slots)
             eng._cfg_sig = sig
@@ -370,7 +379,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             steps = n_iter if optimize else 0
             recon_image = eng.run(code, labels, steps, use_graph=use_graph)
             eng.stash_config(sig)
-            eng.check_errors()                                       # the single-read MaxStyle kernel's error word (spin time-out): never silent
+            mode = self.loop_error_check or os.environ.get("MS_ERROR_CHECK", "sync")
+            eng.check_errors(sync=(mode != "deferred"))                 # the single-read MaxStyle kernel's error word (spin time-out): never silent
             with torch.no_grad():                                  # hand the optimised state back to the modules (debugging / tests)
                 for i in layers:
                     m = mods[i]
@@ -447,10 +457,16 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     def optimize_all_params(self):
         """advanced_triplet...py:1083-1085.  Under torch.distributed (one process per GPU) the flat gradient buffer is all-reduced once
         first - the data-parallel exchange the reference would get from DDP; set `self.data_parallel = False` to opt out."""
+        self.flush_loop_errors()            # (deferred error protocol: never step the weights on a hard example that came from an invalid image)
         if getattr(self, "data_parallel", True) and self._bank is not None:
             self._bank.all_reduce_grads()
         for v in self.optimizers.values():
             v.step()
+
+    def flush_loop_errors(self):
+        """Resolve the deferred error check of every inner-loop engine (loop_error_check = "deferred"); a no-op in the default "sync" mode."""
+        for eng in self._engines.values():
+            eng.flush_errors()
 
     def optimize_params(self, model_name):
         self.optimizers[model_name].step()
@@ -462,6 +478,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     def save_model(self, save_dir, epoch_iter, model_prefix=None, save_optimizers=False):
         """advanced_triplet...py:936-948: <save_dir>/<epoch_iter>/checkpoints/<net>.pth (+ <net>_optim.pth), plain state_dicts."""
         import os
+        self.flush_loop_errors()
         epoch_path = os.path.join(save_dir, str(epoch_iter), 'checkpoints')
         os.makedirs(epoch_path, exist_ok=True)
         for model_name, model in self.model.items():

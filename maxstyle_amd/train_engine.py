@@ -83,14 +83,14 @@ class ParamBank:
                 if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
                     p.grad = self.flat_g[off:off + n].view(shape)
 
-    def all_reduce_grads(self, group=None):
+    def all_reduce_grads(self, group=None, force=False):
         """Data-parallel exchange of the outer step: ONE all-reduce (sum, then x 1/world) over the flat gradient buffer, in
         place - the gradients already live in one contiguous buffer, so there is no pack / unpack.  RCCL ("nccl") on GPUs, gloo in the CPU tests."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size(group)
-        if world == 1:
+        if world == 1 and not force:        # force: issue the collective anyway (bench.py --force-dist / the RCCL self-test: the call path at world size 1)
             return
         dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
         self.flat_g.mul_(1.0 / world)
