@@ -209,11 +209,13 @@ class StyleState:
     eps: float = 1e-6
     gamma_std: Optional[torch.Tensor] = None   # [1,C,1,1], frozen after the first forward
     beta_std: Optional[torch.Tensor] = None
+    learn_noise: bool = True               # noise_learnable (maxstyle.py:83-98): False -> gamma_noise / beta_noise are plain tensors, never updated
+    learn_mix: bool = True                 # mix_learnable (maxstyle.py:113-116): False -> lmda is a Parameter without gradient, skipped by Adam
 
     def clone(self, dtype=None):
         c = lambda t: None if t is None else t.detach().clone().to(dtype if (dtype and t.is_floating_point()) else t.dtype)
         return StyleState(c(self.perm), c(self.lmda), c(self.gamma_noise), c(self.beta_noise), self.applied,
-                          self.mix_style, self.no_noise, self.eps, c(self.gamma_std), c(self.beta_std))
+                          self.mix_style, self.no_noise, self.eps, c(self.gamma_std), c(self.beta_std), self.learn_noise, self.learn_mix)
 
 
 def random_style_state(batch: int, channels: int, seed: int, dtype=torch.float32, applied=True) -> StyleState:
@@ -472,14 +474,16 @@ def style_param_list(styles: Dict[int, StyleState], layers: Sequence[int]):
         if not st.applied:
             continue
         for nm in ("gamma_noise", "beta_noise", "lmda"):
-            if nm == "lmda" and not st.mix_style:
+            if nm == "lmda" and not (st.mix_style and st.learn_mix):
+                continue
+            if nm != "lmda" and not st.learn_noise:
                 continue
             names.append(f"{i}.{nm}")
             params.append(getattr(st, nm))
     return names, params
 
 
-def inner_step_grads(weights, image_code, styles, layers, reference_segmentation, bn_mode="batch"):
+def inner_step_grads(weights, image_code, styles, layers, reference_segmentation, bn_mode="batch", loss_weight=1.0):
     """One loss/gradient evaluation of the loop body (advanced_triplet...py:547-561) at the CURRENT style
     parameters: decode -> encode -> segment -> loss = -CE -> d loss / d style params.  Returns
     (recon_image, loss, {name: grad})."""
@@ -494,14 +498,15 @@ def inner_step_grads(weights, image_code, styles, layers, reference_segmentation
     recon = apply_max_style(dec, image_code, styles, layers, bn_mode=bn_mode)
     z_i, z_s = encoder_forward(enc, recon, bn_mode)
     logits = decoder_forward(seg, z_s, "NN", None, bn_mode)
-    loss = -cross_entropy_2d(logits, reference_segmentation)
+    # loss = sum_k w_k * (-CE) over the 'seg' terms (advanced_triplet...py:552-558): loss_weight is their sum
+    loss = -cross_entropy_2d(logits, reference_segmentation) * loss_weight if loss_weight != 1.0 else -cross_entropy_2d(logits, reference_segmentation)
     grads = torch.autograd.grad(loss, params, allow_unused=True)
     return recon.detach(), float(loss.detach()), {n: (None if g is None else g.detach()) for n, g in zip(names, grads)}
 
 
 def generate_max_style_image(weights, image_code, styles: Dict[int, StyleState], layers: Sequence[int],
                              reference_segmentation, n_iter=5, lr=0.1, trace: Optional[InnerLoopTrace] = None,
-                             keep_images=False, bn_mode="batch"):
+                             keep_images=False, bn_mode="batch", loss_weight=1.0):
     """The K-step inner loop (advanced_triplet...py:458-571) with *injected* MaxStyle state.
 
     loss = -CE(seg_decoder(z_s(encoder(recon))), labels); Adam(lr) on the learnable style params in
@@ -514,7 +519,7 @@ def generate_max_style_image(weights, image_code, styles: Dict[int, StyleState],
         v = {n: torch.zeros_like(p) for n, p in zip(names, params)}
         steps = {n: 0 for n in names}
         for it in range(n_iter):
-            recon, loss, grads = inner_step_grads(weights, image_code, styles, layers, reference_segmentation, bn_mode)
+            recon, loss, grads = inner_step_grads(weights, image_code, styles, layers, reference_segmentation, bn_mode, loss_weight)
             names, params = style_param_list(styles, layers)
             with torch.no_grad():
                 for n, p in zip(names, params):

@@ -1,0 +1,91 @@
+"""Round-3 parity on the GPU, through the drop-in solver API: the benchmarked size against the reference's own run (Winograd form on and off), and one
+reference-generated case per non-default argument of generate_max_style_image.  Every bar is `max(c x the reference's own fp32-vs-fp64 error, floor)`:
+the measured ratios are in profiles/r03_parity_report.txt (tools/parity_report.py)."""
+import numpy as np
+import pytest
+import torch
+
+import r3_cases as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("winograd", ["1", "0"])
+def test_headline_config_vs_reference_run(dev, monkeypatch, winograd):
+    """BASELINE config 2 as benchmarked (16x1x256x256, layers [3,4,5], K=5 free-running, trained FCN_16 fine-tuned at 256^2 by the reference's own
+    training step) against the reference's fp64 run of the same call (advanced_triplet...py:539-571; tests/golden/loop_full_c2.npz):
+    image error <= 2x the reference's OWN fp32 error (max and rms; measured 1.1-1.3x / 0.9-1.0x), labels >= 99.99 % equal, Dice within 1e-3,
+    with the Winograd form of the wide convolutions (the benchmarked default) and with the direct form."""
+    monkeypatch.setenv("MS_LOOP_WINOGRAD", winograd)
+    r = R.full_size_case(dev)
+    assert r["winograd"] == (winograd == "1")
+    assert r["z_i_rel"] < 5e-6
+    assert r["image_max"] <= 2.0 * r["noise_image_max"], (r["image_max"], r["noise_image_max"])
+    assert r["image_rms"] <= 2.0 * r["noise_image_rms"], (r["image_rms"], r["noise_image_rms"])
+    for e, n in zip(r["losses_rel"], r["noise_losses_rel"]):
+        assert e <= max(2.0 * n, 2e-6), (r["losses_rel"], r["noise_losses_rel"])
+    worst_noise = max(r["noise_params_rel"].values())
+    for k, e in r["params_rel"].items():
+        assert e <= 3.0 * worst_noise, (k, e, worst_noise)
+    assert r["labels_equal_f64"] >= 0.9999 and r["clean_labels_equal"] >= 0.9999
+    assert r["dice_abs_diff"] <= 1e-3
+    assert max(abs(a - b) for a, b in zip(r["dice_clean"], r["dice_clean_ref"])) <= 1e-3
+    assert min(r["dice_clean"]) > 0.9 and max(r["dice"]) < 0.4          # a meaningful Dice, and a hard example
+
+
+@pytest.mark.parametrize("case", list(R.ARG_CALLS))
+def test_drop_in_arguments_vs_reference_run(dev, case):
+    """One case per non-default argument of the drop-in signature (advanced_triplet...py:458-466; maxstyle.py:75-117), each a run of the REFERENCE
+    (tests/golden/loop_args.npz, fp32 + fp64): which tensors are Parameters / learnable, the state drawn under fix_seed, losses, the stylised image, the
+    parameters after the loop, labels and Dice of its segmentation."""
+    r = R.arg_case(dev, case)
+    assert r["z_i_rel"] < 5e-6
+    assert r["param_names"] == r["param_names_ref"]
+    assert r["state_equal"] and r["fixed_params_unchanged"]
+    if case == "beta_drawn":
+        assert r["rand_p_equal"] and r["drawn_lmda_equal"]              # randperm / rand(1) / Beta(0.1,0.1) under fix_seed: the CPU generator's draws
+    assert r["n_losses"][0] == r["n_losses"][1]
+    if r["losses_rel"]:
+        for e, n in zip(r["losses_rel"], r["noise_losses_rel"]):
+            assert e <= max(3.0 * n, 5e-6), (r["losses_rel"], r["noise_losses_rel"])
+    assert r["image_rel"] <= max(3.0 * r["noise_image_rel"], 1e-4), (r["image_rel"], r["noise_image_rel"])     # 1e-4: north_star's stated tolerance
+    worst_noise = max(list(r["noise_params_rel"].values()) + [0.0])
+    for k, e in r["params_rel"].items():
+        assert e <= max(3.0 * worst_noise, 5e-4), (k, e, worst_noise)
+    assert r["labels_equal"] >= 0.9998 and r["dice_abs_diff"] <= 5e-3   # 16384 pixels: one flipped label is 6e-5 / up to 3e-3 of a class's Dice
+
+
+def test_deferred_error_protocol_and_flush(dev):
+    """the error word of the single-read kernel is resolved by the call that produced the image (default), or - deferred - by the next
+    call / flush_loop_errors(); once reported it is cleared, so later calls are not condemned."""
+    from maxstyle_amd._lib import MaxStyleHipError
+    S = R.trained_solver(dev, "trained_fcn16.npz")
+    from maxstyle_amd import synthetic as syn
+    img, lab = syn.synthetic_batch(4, 64, 1, 4, seed=777)
+    img, lab = img.to(dev), lab.to(dev)
+    z_i, _ = S.encode_image(img, disable_track_bn_stats=True)
+    call = lambda: S.generate_max_style_image(z_i.detach(), [3, 4, 5], [128, 64, 32, 16, 16, 1], p=1.5, n_iter=1, reference_image=img, reference_segmentation=lab)
+    call()
+    eng = next(iter(S._engines.values()))
+    words = eng._error_words()
+    if not words:
+        pytest.skip("no single-read state block at this shape")
+    words[0].fill_(1)                                    # what a timed-out spin leaves behind
+    S.loop_error_check = "deferred"
+    eng._err_pending = None
+    eng.check_errors(sync=False)                         # queued, not raised
+    with pytest.raises(MaxStyleHipError):
+        S.flush_loop_errors()
+    assert int(words[0].item()) == 0                     # cleared once reported
+    S.loop_error_check = "sync"
+    call()                                               # the next call is clean
+    words[0].fill_(1)
+    with pytest.raises(MaxStyleHipError, match="this call"):
+        eng.check_errors()
+    call()

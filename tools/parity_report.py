@@ -1,0 +1,49 @@
+"""Measured parity numbers of round 3 against the reference's own fp32-vs-fp64 noise (run on the GPU box):
+    python tools/parity_report.py > gpurun_out/r03_parity_report.txt
+Prints, for every round-3 case of tests/r3_cases.py and the teacher-forced fixtures of tests/test_engine_gpu.py, the GPU's error against the
+reference's fp64 run beside the reference's own fp32 error - the numbers the constants in tests/test_round3_gpu.py / test_engine_gpu.py come from."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    import r3_cases as R
+    import test_engine_gpu as TE
+    dev = torch.device("cuda:0")
+    golden = os.path.join(ROOT, "tests", "golden")
+    print("== full size (BASELINE config 2, trained FCN_16, K=5 free-running) vs the reference's fp64 run")
+    for wino in ("1", "0"):
+        os.environ["MS_LOOP_WINOGRAD"] = wino
+        r = R.full_size_case(dev)
+        print(json.dumps(r))
+        print(f"   winograd={r['winograd']}: image max {r['image_max']:.3e} (reference noise {r['noise_image_max']:.3e}, ratio {r['image_max'] / r['noise_image_max']:.2f}), "
+              f"rms {r['image_rms']:.3e} ({r['noise_image_rms']:.3e}, {r['image_rms'] / r['noise_image_rms']:.2f}), labels equal {r['labels_equal_f64']:.6f} "
+              f"(reference {r['noise_labels_equal']:.6f}), Dice diff {r['dice_abs_diff']:.2e}")
+    os.environ.pop("MS_LOOP_WINOGRAD")
+    print("== arguments of the drop-in signature (trained FCN_16, 4x1x64x64) vs the reference's fp64 run")
+    for case in R.ARG_CALLS:
+        r = R.arg_case(dev, case)
+        print(case, json.dumps(r))
+    print("== teacher-forced gradients: err(GPU, fp64 twin) / reference fp32 noise of the step")
+    orc = __import__("oracle.maxstyle_oracle", fromlist=["x"])
+    TE.TF_C, TE.TF_FLOOR = 1e9, 1e9          # measure, do not assert
+    for tag, fx, net, B, layers, K in (("c2small", "loop_c2small", (4, 1, 4), 4, [3, 4, 5], 5), ("c4small", "loop_c4small", (1, 3, 2), 4, [3, 4, 5], 3),
+                                       ("all_layers", "loop_all_layers", (4, 1, 4), 3, [0, 1, 2, 3, 4, 5], 2)):
+        g = np.load(os.path.join(golden, fx + ".npz")); tf = np.load(os.path.join(golden, fx + "_tf64.npz"))
+        TE._teacher_forced(dev, g, None, orc.NetSpec(*net), B, 64, layers, K, tf=tf, tag=tag)
+    for (tag, s, n), (err, noise) in sorted(TE.TF_TABLE.items()):
+        print(f"   {tag:10s} step {s} {n:14s} err {err:.2e}  step noise {noise:.2e}  ratio {err / noise:.2f}")
+    worst = max(err / max(noise, 1e-30) for err, noise in TE.TF_TABLE.values())
+    print("   worst ratio", worst, " worst abs", max(err for err, _ in TE.TF_TABLE.values()))
+
+
+if __name__ == "__main__":
+    main()
