@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-outer", action="store_true", help="skip the auxiliary whole-training-iteration figure")
+    ap.add_argument("--no-parity", action="store_true", help="skip the full-size parity legs against the reference fixture (drift_full_size / dice_parity)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary blocks of the default line (winograd_off, c4, c5_bf16)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5, help="inner steps of the CPU-oracle sample")
     ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"],
@@ -176,9 +178,10 @@ def _traffic_table(B, H, W):
     if (B, H, W) != (16, 256, 256):
         return {}
     tab = {}
-    for name in ("r01_traffic.json", "r02_traffic.json"):
+    for name in ("r01_traffic.json", "r02_traffic.json", "r03_traffic.json"):
         try:
             tab.update(json.load(open(os.path.join(ROOT, "profiles", name))))
+            tab["_source"] = f"profiles/{name}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (tools/profile_round.sh), NOT collected in this run"
         except Exception:  # noqa: BLE001
             pass
     return tab
@@ -250,7 +253,7 @@ def kernel_rooflines(eng, dev, config):
         blk = {"bound": "mfma", "achieved": flops / t[key] / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mf}
         if hf > mf:
             blk = {"bound": "hbm", "achieved": nbytes / t[key] / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hf}
-        blk.update({"traffic": traffic.get(tkey), "kernel": kernel + " " + shape, "us_per_launch": t[key] * 1e6, "algorithmic_bytes": nbytes,
+        blk.update({"traffic": traffic.get(tkey), "traffic_source": traffic.get("_source") if traffic.get(tkey) else None, "kernel": kernel + " " + shape, "us_per_launch": t[key] * 1e6, "algorithmic_bytes": nbytes,
                     "hbm_GBps": nbytes / t[key] / 1e9, "hbm_frac": hf, "flop_per_launch": flops, "tflops": flops / t[key] / 1e12, "mfma_frac": mf,
                     "form": "winograd F(2x2,3x3)" if (wino and C % 8 == 0 and W >= 64 and W % 4 == 0) else "direct"})
         if blk["form"] != "direct":
@@ -261,7 +264,8 @@ def kernel_rooflines(eng, dev, config):
 
     def hbm_block(key, kernel, nbytes, tkey):
         return {"bound": "hbm", "achieved": nbytes / t[key] / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / t[key] / 1e9 / HBM_PEAK_GBPS,
-                "traffic": traffic.get(tkey), "kernel": kernel, "us_per_launch": t[key] * 1e6, "algorithmic_bytes": nbytes}
+                "traffic": traffic.get(tkey), "traffic_source": traffic.get("_source") if traffic.get(tkey) else None, "kernel": kernel,
+                "us_per_launch": t[key] * 1e6, "algorithmic_bytes": nbytes}
 
     nt = "NT=%d" % (1 if C <= 16 else 2)
     return {
@@ -353,19 +357,33 @@ def dice_parity(dev):
             "pred_agreement_with_reference": float((eng.buf["s.logits"].argmax(1).cpu().numpy() == g["f32.final_pred"]).mean())}
 
 
-def drift_c2(eng, styles, z_i, lab_d, cpu_image, K):
-    """Free-running K-step trajectory at the FULL C2 size against the fp32 CPU oracle started from the same code and state (the oracle image comes
-    from the cpu_baseline leg, which runs exactly this workload)."""
-    for i, st in styles.items():
-        eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
-        eng.styles[i].have_std = False
-    eng.flat_m.zero_(); eng.flat_v.zero_(); eng.flat_g.zero_()
-    out = eng.run(z_i, lab_d, K, use_graph=True).clone()
-    losses = eng.losses(K).cpu()
-    o = out.cpu()
-    return {"case": f"K={K} free-running at the bench size, vs the fp32 CPU oracle from the same code and state",
-            "image_rel_err": float((o - cpu_image).abs().max() / cpu_image.abs().max()),
-            "image_rms_rel": float((o - cpu_image).pow(2).mean().sqrt() / cpu_image.pow(2).mean().sqrt()), "losses_gpu": [float(v) for v in losses]}
+def parity_full_size(dev):
+    """Parity at the BENCHMARKED configuration against the reference itself: generate_max_style_image through the drop-in solver at
+    16x1x256x256, layers [3,4,5], K=5 free-running, on the FCN_16 trained by the reference's own training step (fine-tuned at 256^2: clean Dice 0.92-0.95),
+    against the REFERENCE's fp64 run of the same call (tests/golden/loop_full_c2.npz, made by tests/golden/make_golden_r3.py); `reference_noise_*` is the
+    reference's own fp32 run against its fp64 run.  Both forms of the wide convolutions: Winograd F(2x2,3x3) (the timed default) and direct."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import r3_cases as R
+    out = {"case": "C2 as benchmarked: trained FCN_16 (tests/golden/trained_fcn16_256.npz), 16x1x256x256, layers [3,4,5], K=5 free-running, drop-in API; "
+                   "errors are against the reference's fp64 run, relative to max|image|"}
+    old = os.environ.get("MS_LOOP_WINOGRAD")
+    try:
+        for form, flag in (("winograd", "1"), ("direct", "0")):
+            os.environ["MS_LOOP_WINOGRAD"] = flag
+            r = R.full_size_case(dev)
+            out[form] = {"image_max_err": r["image_max"], "image_rms_err": r["image_rms"],
+                         "ratio_to_reference_noise_max": r["image_max"] / r["noise_image_max"], "ratio_to_reference_noise_rms": r["image_rms"] / r["noise_image_rms"],
+                         "losses": r["losses"], "losses_rel_err": r["losses_rel"], "dice": r["dice"], "dice_clean": r["dice_clean"],
+                         "dice_max_abs_diff_vs_reference": r["dice_abs_diff"], "labels_equal_to_reference": r["labels_equal_f64"]}
+        out.update({"reference_noise_image_max": r["noise_image_max"], "reference_noise_image_rms": r["noise_image_rms"],
+                    "reference_noise_losses_rel": r["noise_losses_rel"], "reference_noise_labels_equal": r["noise_labels_equal"],
+                    "reference_dice_fp64": r["dice_ref_f64"], "reference_dice_fp32": r["dice_ref_f32"], "reference_dice_clean": r["dice_clean_ref"]})
+    finally:
+        if old is None:
+            os.environ.pop("MS_LOOP_WINOGRAD", None)
+        else:
+            os.environ["MS_LOOP_WINOGRAD"] = old
+    return out
 
 
 def physical_cores():
@@ -660,6 +678,41 @@ def whole_call(dev, args, rank):
             "steps_s_excluding_decode": K / max(t_call - t_dec, 1e-9)}
 
 
+def secondary_blocks(dev, args, rank):
+    """Driver-visible figures for what the headline line does not cover, a few hundred ms of GPU time each:
+    `winograd_off` - the C2 workload with the direct form of the wide convolutions; `c4` - BASELINE config 4 (FCN_64, 16x3x320x320) with its dominant
+    kernel priced on direct-form AND executed multiplications; `c5_bf16` - config 5's mixed stream (random depth, both shapes) with bf16 activation storage."""
+    import copy
+    out = {}
+    old = os.environ.get("MS_LOOP_WINOGRAD")
+    os.environ["MS_LOOP_WINOGRAD"] = "0"
+    try:
+        eng, _, _, _, _, z_i, lab_d = build(dev, args.batch, args.size, rank)
+        dt, graphed, _ = timed_steps(eng, z_i, lab_d, 20, 3, True, False)
+        out["winograd_off"] = {"what": "the headline workload (C2) with the DIRECT form of the wide 3x3 convolutions (MS_LOOP_WINOGRAD=0)", "steps_s": 20 / dt,
+                               "ms_per_step": dt / 20 * 1e3, "hip_graph": graphed}
+        del eng
+    finally:
+        if old is None:
+            os.environ.pop("MS_LOOP_WINOGRAD", None)
+        else:
+            os.environ["MS_LOOP_WINOGRAD"] = old
+    torch.cuda.empty_cache()
+    eng, _, _, _, _, z_i, lab_d = build(dev, args.batch, 320, rank, (1, 3, 2))
+    dt, graphed, _ = timed_steps(eng, z_i, lab_d, 10, 2, True, False)
+    roof = kernel_rooflines(eng, dev, "c4")
+    out["c4"] = {"workload": f"C4: FCN_64 dual-branch, batch {args.batch}x3x320x320, MaxStyle layers [3,4,5], Adam lr 0.1, fp32", "steps_s": 10 / dt, "ms_per_step": dt / 10 * 1e3,
+                 "hip_graph": graphed, "roofline": roof["dominant"], "roofline_conv_fwd": roof["conv_fwd"], "roofline_maxstyle": roof["style"], "roofline_maxstyle_bwd": roof["style_bwd"]}
+    del eng
+    torch.cuda.empty_cache()
+    a5 = copy.copy(args)
+    a5.act_dtype, a5.mfma, a5.steps, a5.warmup, a5.stream_calls = "bf16", "f32", 10, 1, 8
+    r5 = mixed_stream(dev, a5, rank, 1, False)
+    out["c5_bf16"] = {"workload": r5["config"]["workload"], "steps_s": r5["value"], "seconds": r5["seconds"], "calls": r5["calls"], "dtype": r5["dtype"], "note": r5["note"]}
+    torch.cuda.empty_cache()
+    return out
+
+
 def _free_port():
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
@@ -801,7 +854,9 @@ def main():
         roof = none6 if bf16 else kernel_rooflines(eng, dev, args.config)          # (the priced kernels and their algorithmic bytes are the fp32-storage ones)
         step_s = dt / args.steps
         res = {
-            "metric": "inner adversarial style-opt steps/sec (batch 16, 256x256)", "value": value, "unit": "steps/s", "n_gpus": n_gpus,
+            "metric": ("inner adversarial style-opt steps/sec (batch 16, 256x256)" if headline else
+                       f"inner adversarial style-opt steps/sec ({args.config.upper()}: batch {args.batch}, {net[1]}x{args.size}x{args.size}" + (", bf16 activation storage" if bf16 else "") + ")"),
+            "value": value, "unit": "steps/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": (("bf16 matrix arithmetic (fp32 accumulation), bf16 activation storage" if args.mfma == "bf16" else "f32 arithmetic, bf16 activation storage") if bf16 else "f32"), "data": "synthetic",
             "config": {"workload": (f"C2: FCN_16 dual-branch, per-GPU batch {args.batch}x1x{args.size}x{args.size}, MaxStyle layers [3,4,5], Adam lr 0.1" if args.config == "c2"
@@ -818,12 +873,20 @@ def main():
             "roofline_maxstyle": roof["style"], "roofline_maxstyle_bwd": roof["style_bwd"], "roofline_maxstyle_bf16": roof["style_bf16"], "loss_check": loss_last,
         }
         if world == 1 and not args.no_cpu_baseline and args.config == "c2" and not bf16:
-            res["cpu_baseline"], cpu_image = cpu_baseline(W, img, lab, styles, args.cpu_steps, z_gpu=z_i.cpu())
+            res["cpu_baseline"], _ = cpu_baseline(W, img, lab, styles, args.cpu_steps, z_gpu=z_i.cpu())
             res["speedup_vs_cpu"] = value / res["cpu_baseline"]["value"]
-            res["drift_full_size"] = drift_c2(eng, styles, z_i, lab_d, cpu_image, args.cpu_steps)
-            res["dice_parity"] = dice_parity(dev)
+        if world == 1 and headline and not bf16 and not args.no_parity:
+            pf = parity_full_size(dev)
+            res["drift_full_size"] = {"case": pf["case"], "reference_noise_image_max": pf["reference_noise_image_max"], "reference_noise_image_rms": pf["reference_noise_image_rms"],
+                                      **{form: {k: pf[form][k] for k in ("image_max_err", "image_rms_err", "ratio_to_reference_noise_max", "ratio_to_reference_noise_rms", "losses_rel_err")}
+                                         for form in ("winograd", "direct")}}
+            res["dice_parity"] = {"case": pf["case"], "reference_fp64": pf["reference_dice_fp64"], "reference_fp32": pf["reference_dice_fp32"], "reference_clean": pf["reference_dice_clean"],
+                                  **{form: {k: pf[form][k] for k in ("dice", "dice_clean", "dice_max_abs_diff_vs_reference", "labels_equal_to_reference")} for form in ("winograd", "direct")}}
+            res["dice_parity_small"] = dice_parity(dev)
         if world == 1 and args.config == "c2" and not bf16 and not args.no_outer:
             res["whole_call"] = whole_call(dev, args, rank)
+    if rank == 0 and world == 1 and headline and not bf16 and not args.no_secondary:
+        res["secondary"] = secondary_blocks(dev, args, rank)
     if dist_on:
         rl = rccl_leg(dev, rank, run_one) if args.backend == "nccl" else None      # every rank: collectives
         if rank == 0:
