@@ -89,7 +89,7 @@ def test_force_dist_world_size_one_runs_rccl():
     rc = r["rccl"]
     assert rc["backend"] == "nccl" and rc["world_seen"] == 1 and rc["max_over_ranks_ok"]
     assert rc["fcn16_6MB"]["mean_ok"] and rc["fcn64_98MB"]["mean_ok"] and rc["fcn64_98MB"]["bytes"] == 98000000
-    assert rc["fcn16_6MB"]["ms"] > 0 and rc["fcn16_6MB"]["with_step_graph_replay_between"]
+    assert rc["fcn16_6MB"]["ms"] > 0 and rc["fcn16_6MB"]["ok_with_step_graph_replay_between"]
     oi = r["outer_iteration"]
     assert oi["world_seen"] == 1 and oi["weights_max_abs_diff_across_ranks"] == 0.0 and oi["allreduce_bytes"] >= 1536325 * 4
 
