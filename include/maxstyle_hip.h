@@ -137,6 +137,26 @@ int ms_adam_step(float* p, const float* g, float* m, float* v, int n, float lr, 
                  const int* step_dev, void* stream);
 int ms_counter_incr(int* counter, void* stream);
 
+/* The tail of one inner step of generate_max_style_image (advanced_triplet...py:559-562: loss.backward() has produced the layers' partial sums,
+ * optimizer.step()) as ONE launch: for every inserted MaxStyle layer the reduction ms_style_bwd does behind its streaming pass (call ms_style_bwd /
+ * ms_style_bwd_actbwd with d_gamma = d_beta = d_lmda = NULL: the per-plane partial sums stay in the layer's workspace, ms_style_bwd_slots() per plane),
+ * torch.optim.Adam on those parameters (ms_adam_step's arithmetic), the cross-entropy sum of ms_head_ce_actbwd called with loss_out = NULL (ce_part = that
+ * call's workspace, ce_nparts = ms_head_ce_actbwd_parts(); loss_out[*step_dev] = ce_scale * sum), and *step_dev += 1.  Bit-identical to the separate calls.
+ * Parameters / gradients / moments are ONE flat buffer each (p, g, m, v); a layer names its rows by element offsets (-1: the layer has no such tensor),
+ * learn_* = 0 leaves a tensor's parameters untouched (its gradient is still written).  `arrive`: one int, zero-initialised once, dedicated to this call site. */
+#define MS_MAX_TAIL_LAYERS 8
+typedef struct ms_tail_layer {
+  const void* part;                 /* float2 [B*C][S] */
+  const float* mu; const float* sig; const float* gamma_std; const float* beta_std;
+  const int64_t* perm;              /* NULL: no style mixing (off_lmda = -1) */
+  int off_gamma, off_beta, off_lmda;
+  int learn_noise, learn_mix;
+  int B, C, S;
+} ms_tail_layer;
+int ms_style_bwd_slots(int B, int C, int HW, int bf16);
+int ms_step_tail(const ms_tail_layer* layers, int n_layers, const double* ce_part, int ce_nparts, double ce_scale, float* loss_out,
+                 float* p, float* g, float* m, float* v, float lr, float b1, float b2, float eps, int* step_dev, int* arrive, void* stream);
+
 /* ---- convolution stack: src/models/ebm/encoder_decoder.py:22-74, 289-357, 423-482, 561-596, 634-680 -------- */
 
 /* Implicit-GEMM convolution on the exact-fp32 matrix cores.  Replaces nn.Conv2d(k=3,p=1,s=1|2), nn.Conv2d(k=1),

@@ -20,6 +20,13 @@ c_int = ctypes.c_int
 c_float = ctypes.c_float
 c_size = ctypes.c_size_t
 
+class TailLayer(ctypes.Structure):
+    """`ms_tail_layer` of include/maxstyle_hip.h (ms_step_tail)."""
+    _fields_ = [("part", ctypes.c_void_p), ("mu", ctypes.c_void_p), ("sig", ctypes.c_void_p), ("gamma_std", ctypes.c_void_p), ("beta_std", ctypes.c_void_p),
+                ("perm", ctypes.c_void_p), ("off_gamma", c_int), ("off_beta", c_int), ("off_lmda", c_int), ("learn_noise", c_int), ("learn_mix", c_int),
+                ("B", c_int), ("C", c_int), ("S", c_int)]
+
+
 # name -> (restype, argtypes): mirrors include/maxstyle_hip.h one to one (tests/test_abi.py checks both ways)
 SIGNATURES = {
     "ms_version": (c_int, []),
@@ -58,6 +65,9 @@ SIGNATURES = {
                              c_int, c_int, c_int, c_void, c_size, c_void]),
     "ms_adam_step": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_float, c_float, c_float, c_float, c_int, c_void, c_void]),
     "ms_counter_incr": (c_int, [c_void, c_void]),
+    "ms_style_bwd_slots": (c_int, [c_int, c_int, c_int, c_int]),
+    "ms_step_tail": (c_int, [ctypes.POINTER(TailLayer), c_int, c_void, c_int, ctypes.c_double, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                             c_float, c_float, c_float, c_float, c_void, c_void, c_void]),
     "ms_conv_stats_bytes": (c_size, [c_int, c_int, c_int, c_int]),
     "ms_conv_stats_parts": (c_int, [c_int, c_int, c_int]),
     "ms_conv2d": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -24,6 +24,9 @@ namespace ms {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { FETCH_NORMAL = 0, FETCH_UPS2 = 1, FETCH_ZINS2 = 2 };
+#ifndef MS_CONV_PF2
+#define MS_CONV_PF2 1            // 0: build the staging waves with one register set everywhere (A/B)
+#endif
 
 struct ConvArgs {
   const float* in; const float* in2; float* out; const float* w; const float* bias;
@@ -213,6 +216,7 @@ struct Geo {
   static constexpr int WS = (NT == 1) ? 16 : NT * 16 + 16;                 // weight row stride (bank-conflict-free B fragments)
   static constexpr int TAPS = KS * KS;
   static constexpr int BUF = CK * PS + TAPS * CK * WS;                     // floats per LDS stage buffer
+
   static constexpr int tap_off(int tap) {                                  // LDS offset of tap (ky,kx) relative to the pixel's slot
     const int ky = tap / KS, kx = tap % KS;
     const int t = kx - PAD + PADL;
@@ -233,6 +237,11 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   constexpr int COUT_TILE = 16 * NT;
   constexpr int WITEMS = TAPS * CK * (COUT_TILE / 4);
   constexpr int NWI = (WITEMS + 255) / 256;
+  // two register sets in the staging waves (prefetch distance 2, see StageRegs) where a set is small enough to double inside the kernel's register budget
+  // (chosen per variant from `tools/kernel_resources.sh`: on only where the kernel stays within 128 VGPRs without spills - the narrow 4x16-pixel tiles,
+  //  the 1x1 convolutions and the expanded-fetch 3x3: the small-spatial layers that are latency-bound, not the top-level ones that are bandwidth-bound)
+  constexpr bool PF2 = MS_CONV_PF2 && ((IN2 ? 2 : 1) * NI * VW + 4 * NWI <= 56) &&
+                       (NARROW ? !(NT == 4 && IN2) : ((KS == 1 && NT < 4) || (EXP && NT == 1)));
   static_assert(!EXP || (KS == 3 && STRIDE == 1), "expanded staging is for the 3x3 stride-1 convolution");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // smem: [2][BUF] stage buffers (input tile [CK][PS] then weights [TAPS][CK][WS]) | [cin_pad][4] prologue coefficients
@@ -334,19 +343,26 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         }
       }
     };
-    float rin[NI][VW];
-    float rin2[IN2 ? NI : 1][VW];
-    float4 rw[NWI];
-    unsigned okmask = 0;          // bit j: slot j of the chunk held in registers lies inside the image
-    bool have_w = false;          // rw holds a weight slice that must be written to LDS
+    // One chunk in flight between its global loads and its LDS stores.  With G::PF2 the staging waves keep TWO such sets and run two chunks ahead of the
+    // MFMA waves (the loop below is unrolled by two, one set per half): a chunk's loads then have two chunk periods to land instead of one.  The small-spatial
+    // deep layers (128 channels at 16x16: 8 chunks of ~0.5 us of matrix work each, one item per workgroup) were bound by exactly that latency.
+    struct StageRegs {
+      float rin[NI][VW];
+      float rin2[IN2 ? NI : 1][VW];
+      float4 rw[NWI];
+      unsigned okmask;              // bit j: slot j of the chunk held in registers lies inside the image
+      bool have_w;                  // rw holds a weight slice that must be written to LDS
+      int n, c0;                    // image and first input channel of the chunk
+    };
 
     typedef unsigned lu32x4_t __attribute__((ext_vector_type(4)));
     typedef unsigned lu32x2_t __attribute__((ext_vector_type(2)));
-    auto load_chunk = [&](int n, int co0, int c0, bool load_w) {
+    auto load_chunk = [&](StageRegs& R, int n, int co0, int c0, bool load_w) {
+      R.n = n; R.c0 = c0;
       const size_t img_off = (size_t)n * a.Cin * in_plane;                        // element offset of image n (both input tensors)
       if constexpr (BUF_LD) {
         const bool ragged = (c0 + CK > a.Cin);
-        okmask = tile_ok;
+        R.okmask = tile_ok;
         const unsigned img_bytes = (unsigned)AB * (unsigned)a.Cin * (unsigned)in_plane;          // the host checks Cin*plane*4 < 2^31
         char* in_n = const_cast<char*>(reinterpret_cast<const char*>(a.in)) + img_off * AB;
         char* in2_n = IN2 ? const_cast<char*>(reinterpret_cast<const char*>(a.in2)) + img_off * AB : in_n;
@@ -358,55 +374,55 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         for (int j = 0; j < NI; ++j) {
           int off = s_boff[j];
           if (ragged || dead) {                       // (wave-uniform) a layer's last chunk: channels beyond Cin are zeros too
-            const bool ok = ((okmask >> j) & 1u) && (c0 + (s_lds[j] >> 20) < a.Cin) && !dead;
-            if (!ok) { off = kOob; okmask &= ~(1u << j); }
+            const bool ok = ((R.okmask >> j) & 1u) && (c0 + (s_lds[j] >> 20) < a.Cin) && !dead;
+            if (!ok) { off = kOob; R.okmask &= ~(1u << j); }
           }
           if constexpr (AB == 4) {
             const lu32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r1, off, soff, 0);
-            rin[j][0] = __uint_as_float(v.x); rin[j][1] = __uint_as_float(v.y); rin[j][2] = __uint_as_float(v.z); rin[j][3] = __uint_as_float(v.w);
+            R.rin[j][0] = __uint_as_float(v.x); R.rin[j][1] = __uint_as_float(v.y); R.rin[j][2] = __uint_as_float(v.z); R.rin[j][3] = __uint_as_float(v.w);
             if constexpr (IN2) {
               const lu32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r2, off, soff, 0);
-              rin2[j][0] = __uint_as_float(u.x); rin2[j][1] = __uint_as_float(u.y); rin2[j][2] = __uint_as_float(u.z); rin2[j][3] = __uint_as_float(u.w);
+              R.rin2[j][0] = __uint_as_float(u.x); R.rin2[j][1] = __uint_as_float(u.y); R.rin2[j][2] = __uint_as_float(u.z); R.rin2[j][3] = __uint_as_float(u.w);
             }
           } else {                                    // bf16 storage: 4 values = one 8-byte load, widened to fp32 (a shift / a mask each)
             const lu32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r1, off, soff, 0);
-            rin[j][0] = __uint_as_float(v.x << 16); rin[j][1] = __uint_as_float(v.x & 0xFFFF0000u); rin[j][2] = __uint_as_float(v.y << 16); rin[j][3] = __uint_as_float(v.y & 0xFFFF0000u);
+            R.rin[j][0] = __uint_as_float(v.x << 16); R.rin[j][1] = __uint_as_float(v.x & 0xFFFF0000u); R.rin[j][2] = __uint_as_float(v.y << 16); R.rin[j][3] = __uint_as_float(v.y & 0xFFFF0000u);
             if constexpr (IN2) {
               const lu32x2_t u = __builtin_amdgcn_raw_buffer_load_b64(r2, off, soff, 0);
-              rin2[j][0] = __uint_as_float(u.x << 16); rin2[j][1] = __uint_as_float(u.x & 0xFFFF0000u); rin2[j][2] = __uint_as_float(u.y << 16); rin2[j][3] = __uint_as_float(u.y & 0xFFFF0000u);
+              R.rin2[j][0] = __uint_as_float(u.x << 16); R.rin2[j][1] = __uint_as_float(u.x & 0xFFFF0000u); R.rin2[j][2] = __uint_as_float(u.y << 16); R.rin2[j][3] = __uint_as_float(u.y & 0xFFFF0000u);
             }
           }
         }
       } else {
-      okmask = 0;
+      R.okmask = 0;
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int ci = c0 + (s_lds[j] >> 20);
         const bool ok = (s_lds[j] >= 0) && (s_goff[j] >= 0) && (ci < a.Cin);
-        okmask |= (ok ? 1u : 0u) << j;
+        R.okmask |= (ok ? 1u : 0u) << j;
         const bool ld = ok && !(a.dbg & 2);
         const size_t off = ld ? ((size_t)ci * in_plane + (size_t)s_goff[j]) : 0;
         if constexpr (EXP) {
           const float2 v = ld ? IO::ld2(a.in, img_off + off) : make_float2(0.f, 0.f);
-          rin[j][0] = v.x; rin[j][1] = v.y;
+          R.rin[j][0] = v.x; R.rin[j][1] = v.y;
           if constexpr (IN2) {
             const float2 u = ld ? IO::ld2(a.in2, img_off + off) : make_float2(0.f, 0.f);
-            rin2[j][0] = u.x; rin2[j][1] = u.y;
+            R.rin2[j][0] = u.x; R.rin2[j][1] = u.y;
           }
         } else if constexpr (VEC) {
           const float4 v = ld ? IO::ld4(a.in, img_off + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-          rin[j][0] = v.x; rin[j][1] = v.y; rin[j][2] = v.z; rin[j][3] = v.w;
+          R.rin[j][0] = v.x; R.rin[j][1] = v.y; R.rin[j][2] = v.z; R.rin[j][3] = v.w;
           if constexpr (IN2) {
             const float4 u = ld ? IO::ld4(a.in2, img_off + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rin2[j][0] = u.x; rin2[j][1] = u.y; rin2[j][2] = u.z; rin2[j][3] = u.w;
+            R.rin2[j][0] = u.x; R.rin2[j][1] = u.y; R.rin2[j][2] = u.z; R.rin2[j][3] = u.w;
           }
         } else {
-          rin[j][0] = ld ? IO::ld1(a.in, img_off + off) : 0.f;
-          if constexpr (IN2) rin2[j][0] = ld ? IO::ld1(a.in2, img_off + off) : 0.f;
+          R.rin[j][0] = ld ? IO::ld1(a.in, img_off + off) : 0.f;
+          if constexpr (IN2) R.rin2[j][0] = ld ? IO::ld1(a.in2, img_off + off) : 0.f;
         }
       }
       }
-      have_w = load_w;
+      R.have_w = load_w;
       if (load_w) {
 #pragma unroll
         for (int j = 0; j < NWI; ++j) {
@@ -414,14 +430,15 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
           const int j4 = idx % (COUT_TILE / 4);
           const int row = idx / (COUT_TILE / 4);      // tap*CK + c
           const int c = row % CK, tap = row / CK;
-          rw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          R.rw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (idx < WITEMS && c0 + c < a.cin_pad)
-            rw[j] = *reinterpret_cast<const float4*>(a.w + ((size_t)tap * a.cin_pad + c0 + c) * a.cout_pad + co0 + j4 * 4);
+            R.rw[j] = *reinterpret_cast<const float4*>(a.w + ((size_t)tap * a.cin_pad + c0 + c) * a.cout_pad + co0 + j4 * 4);
         }
       }
     };
 
-    auto store_chunk = [&](float* buf, int n, int c0) {
+    auto store_chunk = [&](StageRegs& R, float* buf) {
+      const int n = R.n, c0 = R.c0;
       float* in_lds = buf;
       float* w_lds = buf + CK * PS;
 #pragma unroll
@@ -430,8 +447,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
         const int ci = c0 + (s_lds[j] >> 20);
         float v[VW];
 #pragma unroll
-        for (int e = 0; e < VW; ++e) v[e] = rin[j][e];
-        if ((okmask >> j) & 1u) {
+        for (int e = 0; e < VW; ++e) v[e] = R.rin[j][e];
+        if ((R.okmask >> j) & 1u) {
           if (a.pro_mode == 1) {
             float pa, pb;
             if (a.pro_nstride == 0) { pa = cf_lds[ci * 4]; pb = cf_lds[ci * 4 + 1]; }
@@ -442,7 +459,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
             if (a.pro_mode == 2) {
               const float pa = cf_lds[ci * 4], pb = cf_lds[ci * 4 + 1], pc = cf_lds[ci * 4 + 2];
 #pragma unroll
-              for (int e = 0; e < VW; ++e) v[e] = pa * v[e] + pb * rin2[j][e] + pc;
+              for (int e = 0; e < VW; ++e) v[e] = pa * v[e] + pb * R.rin2[j][e] + pc;
             }
           }
         }
@@ -468,39 +485,68 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
           dst[0] = v[0];
         }
       }
-      if (have_w) {
+      if (R.have_w) {
 #pragma unroll
         for (int j = 0; j < NWI; ++j) {
           const int idx = tid + j * 256;
           if (idx < WITEMS) {
             const int j4 = idx % (COUT_TILE / 4);
             const int row = idx / (COUT_TILE / 4);
-            *reinterpret_cast<float4*>(w_lds + row * WS + j4 * 4) = rw[j];
+            *reinterpret_cast<float4*>(w_lds + row * WS + j4 * 4) = R.rw[j];
           }
         }
       }
     };
 
-    // iteration p (chunk index in this workgroup's sequence): registers hold chunk p; written to buffer p&1.
+    // iteration p (chunk index in this workgroup's sequence): a register set holds chunk p; it is written to buffer p&1.
     // key_*[b]: which weight slice (cb, c0) buffer b holds -> skip the rewrite when it repeats (single-chunk layers)
     int key_cb[2] = {-1, -1}, key_c0[2] = {-1, -1};
-    int item = vb, chunk = 0, n, tile, cb, tile_set = -1;
+    int item = vb, chunk = 0, n, tile, cb, tile_set = -1;     // the LOAD cursor
     decode(item, n, tile, cb);
     set_tile(tile); tile_set = tile;
-    load_chunk(n, cb * COUT_TILE, 0, true);
-    lds_barrier();                                    // barrier #0: coefficient table visible (matched by the consumers)
-    for (int p = 0; p < T; ++p) {
-      // write chunk p (in registers) into buffer p&1; the consumers read buffer (p-1)&1 meanwhile
-      store_chunk(smem + (p & 1) * BUF, n, chunk * CK);
-      key_cb[p & 1] = cb; key_c0[p & 1] = chunk * CK;
-      // advance to chunk p+1 and issue its loads
-      if (p + 1 < T) {
-        if (++chunk == nchunks) { chunk = 0; item += gridDim.x; decode(item, n, tile, cb); }
-        if (tile != tile_set) { set_tile(tile); tile_set = tile; }
-        const int b = (p + 1) & 1;
-        load_chunk(n, cb * COUT_TILE, chunk * CK, !(key_cb[b] == cb && key_c0[b] == chunk * CK));
+    auto advance = [&]() {
+      if (++chunk == nchunks) { chunk = 0; item += gridDim.x; decode(item, n, tile, cb); }
+      if (tile != tile_set) { set_tile(tile); tile_set = tile; }
+    };
+    if constexpr (PF2) {
+      StageRegs R0, R1;
+      R0.okmask = R1.okmask = 0; R0.have_w = R1.have_w = false;
+      // chunk q goes to buffer q&1, whose weight key is decided when chunk q-2 is stored: a load compares against the key its buffer WILL hold then
+      auto issue = [&](StageRegs& R, int b) {
+        const bool same = (key_cb[b] == cb && key_c0[b] == chunk * CK);
+        load_chunk(R, n, cb * COUT_TILE, chunk * CK, !same);
+        key_cb[b] = cb; key_c0[b] = chunk * CK;
+      };
+      issue(R0, 0);
+      if (T > 1) { advance(); issue(R1, 1); }
+      lds_barrier();                                  // barrier #0: coefficient table visible (matched by the consumers)
+      for (int p = 0; p < T; p += 2) {
+        store_chunk(R0, smem);
+        if (p + 2 < T) { advance(); issue(R0, 0); }
+        lds_barrier();                                // barrier #(p+1): chunk p visible; consumers done with chunk p-1
+        if (p + 1 < T) {
+          store_chunk(R1, smem + BUF);
+          if (p + 3 < T) { advance(); issue(R1, 1); }
+          lds_barrier();                              // barrier #(p+2)
+        }
       }
-      lds_barrier();                                  // barrier #(p+1): chunk p visible; consumers done with chunk p-1
+    } else {
+      StageRegs R;
+      R.okmask = 0; R.have_w = false;
+      load_chunk(R, n, cb * COUT_TILE, 0, true);
+      lds_barrier();                                    // barrier #0: coefficient table visible (matched by the consumers)
+      for (int p = 0; p < T; ++p) {
+        // write chunk p (in registers) into buffer p&1; the consumers read buffer (p-1)&1 meanwhile
+        store_chunk(R, smem + (p & 1) * BUF);
+        key_cb[p & 1] = cb; key_c0[p & 1] = chunk * CK;
+        // advance to chunk p+1 and issue its loads
+        if (p + 1 < T) {
+          advance();
+          const int b = (p + 1) & 1;
+          load_chunk(R, n, cb * COUT_TILE, chunk * CK, !(key_cb[b] == cb && key_c0[b] == chunk * CK));
+        }
+        lds_barrier();                                  // barrier #(p+1): chunk p visible; consumers done with chunk p-1
+      }
     }
     return;
   }

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_kernel(const void* __res
 // (sum g', sum g'*(u - mean_c)) are written per block in the partial layout of ms_act_bwd_reduce: bn_part[c][n*gridDim.x + blockIdx.x].
 constexpr int kHeadFuseC = 16;
 // VEC = 4: every thread owns 4 consecutive pixels (16-byte loads / stores of every channel plane; needs H*W % 4 == 0 and 16-byte aligned tensors)
-template <int VEC, typename AT = float>
+template <int VEC, typename AT = float, bool PF = false>
 __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const void* __restrict__ h, const float* __restrict__ w, const float* __restrict__ b,
                                                                       const int64_t* __restrict__ labels, void* __restrict__ dh, double* __restrict__ part,
                                                                       int C, int K, int HW, float grad_scale,
@@ -357,7 +357,29 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const void
 #pragma unroll
   for (int c = 0; c < kHeadFuseC; ++c) { b1[c] = 0.f; b2[c] = 0.f; }
   for (int i = (blockIdx.x * kElemThreads + threadIdx.x) * VEC; i < HW; i += gridDim.x * kElemThreads * VEC) {
-    float z[kMaxHeadK][VEC], hv[kHeadFuseC][VEC];
+    float z[kMaxHeadK][VEC], hv[kHeadFuseC][VEC], uv[PF ? kHeadFuseC : 1][VEC];
+    int labv[VEC];
+    // every load of the item is issued before the first use (PF): h (C planes), the labels, and the raw BatchNorm input u that only the SECOND half of the
+    // item needs.  Without it the grid - one item per thread, all waves in step - alternates between a load phase and an arithmetic phase twice per launch
+    // (h ... softmax ... u ... stores): 201 MB in 68 us.  Costs 4*C more registers per thread.
+#pragma unroll
+    for (int c = 0; c < kHeadFuseC; ++c) {
+      if (c < C) {
+        if (VEC == 4) { const float4 t = IO::ld4(h, hb + (size_t)c * HW + i); hv[c][0] = t.x; hv[c][1 % VEC] = t.y; hv[c][2 % VEC] = t.z; hv[c][3 % VEC] = t.w; }
+        else hv[c][0] = IO::ld1(h, hb + (size_t)c * HW + i);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) labv[e] = (int)labels[(size_t)n * HW + i + e];
+    if (PF) {
+#pragma unroll
+      for (int c = 0; c < kHeadFuseC; ++c) {
+        if (c < C) {
+          if (VEC == 4) { const float4 t = IO::ld4(bn_u, hb + (size_t)c * HW + i); uv[c][0] = t.x; uv[c][1 % VEC] = t.y; uv[c][2 % VEC] = t.z; uv[c][3 % VEC] = t.w; }
+          else uv[c][0] = IO::ld1(bn_u, hb + (size_t)c * HW + i);
+        }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < kMaxHeadK; ++k)
 #pragma unroll
@@ -365,8 +387,6 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const void
 #pragma unroll
     for (int c = 0; c < kHeadFuseC; ++c) {
       if (c < C) {
-        if (VEC == 4) { const float4 t = IO::ld4(h, hb + (size_t)c * HW + i); hv[c][0] = t.x; hv[c][1 % VEC] = t.y; hv[c][2 % VEC] = t.z; hv[c][3 % VEC] = t.w; }
-        else hv[c][0] = IO::ld1(h, hb + (size_t)c * HW + i);
 #pragma unroll
         for (int k = 0; k < kMaxHeadK; ++k)
           if (k < K) {
@@ -385,7 +405,7 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const void
 #pragma unroll
       for (int k = 0; k < kMaxHeadK; ++k) if (k < K) se += expf(z[k][e] - mx);
       const float lse = mx + logf(se);
-      const int lab = (int)labels[(size_t)n * HW + i + e];
+      const int lab = labv[e];
 #pragma unroll
       for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
         const float pk = expf(z[k][e] - lse);
@@ -397,7 +417,10 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const void
     for (int c = 0; c < kHeadFuseC; ++c) {
       if (c < C) {
         float a[VEC], uu[VEC];
-        if (VEC == 4) { const float4 t = IO::ld4(bn_u, hb + (size_t)c * HW + i); uu[0] = t.x; uu[1 % VEC] = t.y; uu[2 % VEC] = t.z; uu[3 % VEC] = t.w; }
+        if (PF) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) uu[e] = uv[c][e];
+        } else if (VEC == 4) { const float4 t = IO::ld4(bn_u, hb + (size_t)c * HW + i); uu[0] = t.x; uu[1 % VEC] = t.y; uu[2 % VEC] = t.z; uu[3 % VEC] = t.w; }
         else uu[0] = IO::ld1(bn_u, hb + (size_t)c * HW + i);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -679,11 +702,17 @@ static int head_ce_actbwd_impl(const void* h, const float* w, const float* b, co
   const int gx = head_fuse_gx(HW);
   const double M = (double)N * HW;
   const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(bn_u)) & 15u) == 0;
-  if (vec) MS_LAUNCH((head_ce_actbwd_kernel<4, AT>), dim3(gx, N), dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, (double*)ws, C, K, HW, (float)(loss_sign / M),
+  // MS_HEAD_PF=1: every load of an item issued up front (239 instead of 175 VGPRs, 2 waves per SIMD either way).  Measured null on MI355X (69.0 vs 69.3 us at
+  // 16x16x256x256, profiles/r03_experiments.txt): the kernel is not alternating between load and arithmetic phases - off by default.
+  static const bool pf = []() { const char* e = getenv("MS_HEAD_PF"); return e != nullptr && atoi(e) != 0; }();
+  if (vec && pf) MS_LAUNCH((head_ce_actbwd_kernel<4, AT, true>), dim3(gx, N), dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, (double*)ws, C, K, HW, (float)(loss_sign / M),
+                           bn_u, (const float4*)bn_coef4, (float2*)bn_part, act_slope);
+  else if (vec) MS_LAUNCH((head_ce_actbwd_kernel<4, AT>), dim3(gx, N), dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, (double*)ws, C, K, HW, (float)(loss_sign / M),
                      bn_u, (const float4*)bn_coef4, (float2*)bn_part, act_slope);
   else MS_LAUNCH((head_ce_actbwd_kernel<1, AT>), dim3(gx, N), dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, (double*)ws, C, K, HW, (float)(loss_sign / M),
                  bn_u, (const float4*)bn_coef4, (float2*)bn_part, act_slope);
   if (int e = check_launch("head_ce_actbwd")) return e;
+  if (loss_out == nullptr) return MS_OK;               // the caller sums the gx*N partials in `ws` itself (ms_step_tail)
   MS_LAUNCH(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, gx * N, -(double)loss_sign / M, loss_out, loss_slot_dev);
   return check_launch("ce_finalize");
 }

@@ -384,6 +384,82 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 __global__ void incr_kernel(int* c) { if (threadIdx.x == 0 && blockIdx.x == 0) *c += 1; }
 
+// ---- the tail of an inner step as ONE launch (ms_step_tail) ---------------------------------------------------------------------------------------
+// After the backward pass a step used to end with six tiny dependent launches - style_bwd_finalize per inserted layer, ce_finalize, adam, incr - each ~4.8 us
+// of launch boundary around a few KB of work.  The gradient of sample b of a layer is produced entirely by the block (layer, b) of the finalize kernel, and Adam
+// on those parameters needs nothing else: so block (b, layer) finalises its row AND takes its Adam step; block (0, 0) also sums the cross-entropy partials of
+// the head kernel; the last block to arrive advances the step counter (every block has read it by then - an arrival counter, no spinning).  Same arithmetic,
+// same order as the kernels it replaces: the gradients, parameters and the loss are bit-identical.
+constexpr int kMaxTailLayers = MS_MAX_TAIL_LAYERS;
+struct TailArgs {
+  ms_tail_layer layer[kMaxTailLayers];
+  const double* ce_part; int ce_nparts; double ce_scale; float* loss_out;
+  float* p; float* g; float* m; float* v;
+  float lr, b1, b2, eps;
+  int* step_dev; int* arrive; int total_blocks, n_layers;
+};
+__global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs a) {
+  __shared__ double redd[16];
+  // (every global load below misses the caches - the data was just written by kernels on other XCDs - so a block is a chain of ~2 us round trips: the
+  //  independent ones are issued together up front, and the cross-entropy sum has its own block row instead of queueing behind a layer's work)
+  const int slot = *a.step_dev;                    // every block reads the counter before it arrives below
+  const int t = slot + 1;
+  if ((int)blockIdx.y == a.n_layers) {             // the extra block row: ce_finalize_kernel, restated (same order of additions)
+    if (blockIdx.x == 0 && a.ce_part != nullptr) {
+      double s = 0.0;
+      for (int i = threadIdx.x; i < a.ce_nparts; i += 256) s += a.ce_part[i];
+      s = block_sum_d(s, redd);
+      if (threadIdx.x == 0) a.loss_out[slot] = (float)(s * a.ce_scale);
+    }
+  } else {
+    const ms_tail_layer& L = a.layer[blockIdx.y];
+    const int b = blockIdx.x;
+    if (b < L.B) {
+      const float2* part = reinterpret_cast<const float2*>(L.part);
+      const int C = L.C, S = L.S;
+      const int pb = L.perm ? (int)L.perm[b] : b;
+      const float lm = (L.off_lmda >= 0) ? a.p[L.off_lmda + b] : 0.f;
+      const double bc1 = 1.0 - pow((double)a.b1, (double)t), bc2 = 1.0 - pow((double)a.b2, (double)t);
+      const float step_size = (float)((double)a.lr / bc1), rs2 = (float)sqrt(bc2);
+      auto adam = [&](int i, float gi) {             // adam_kernel's arithmetic, bias corrections hoisted
+        const float mi = a.m[i] * a.b1 + gi * (1.f - a.b1);
+        const float vi = a.v[i] * a.b2 + gi * gi * (1.f - a.b2);
+        a.m[i] = mi; a.v[i] = vi;
+        const float denom = sqrtf(vi) / rs2 + a.eps;
+        a.p[i] = a.p[i] - step_size * (mi / denom);
+      };
+      double acc = 0.0;
+      for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int p = b * C + c;
+        const int q = pb * C + c;
+        const double dsig = (double)L.sig[q] - (double)L.sig[p], dmu = (double)L.mu[q] - (double)L.mu[p];
+        double s1 = 0.0, s2 = 0.0;
+        for (int s = 0; s < S; ++s) { const float2 v2 = part[(size_t)p * S + s]; s1 += (double)v2.x; s2 += (double)v2.y; }
+        if (L.off_gamma >= 0) {
+          const float dg = (float)((double)L.gamma_std[c] * s2), db = (float)((double)L.beta_std[c] * s1);
+          a.g[L.off_gamma + p] = dg; a.g[L.off_beta + p] = db;
+          if (L.learn_noise) { adam(L.off_gamma + p, dg); adam(L.off_beta + p, db); }
+        }
+        acc += dsig * s2 + dmu * s1;
+      }
+      acc = block_sum_d(acc, redd);
+      if (threadIdx.x == 0 && L.off_lmda >= 0) {
+        const float dl = (lm >= 0.f && lm <= 1.f) ? (float)acc : 0.f;       // clamp(): zero gradient outside [0,1]
+        a.g[L.off_lmda + b] = dl;
+        if (L.learn_mix) adam(L.off_lmda + b, dl);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int prev = __hip_atomic_fetch_add(a.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == a.total_blocks - 1) {
+      __hip_atomic_store(a.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+      *a.step_dev = t;
+    }
+  }
+}
+
 struct Split { int chunk, S, nv; bool vec; };
 
 static Split choose_split(int P, int HW, bool vec_ok) {
@@ -683,6 +759,35 @@ extern "C" int ms_adam_step(float* p, const float* g, float* m, float* v, int n,
   if (n == 0) return MS_OK;
   MS_LAUNCH(adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, step, step_dev);
   return check_launch("adam");
+}
+
+extern "C" int ms_style_bwd_slots(int B, int C, int HW, int bf16) {
+  return bf16 ? choose_split_bf16(B * C, HW).S : choose_split(B * C, HW, HW % 4 == 0).S;
+}
+
+extern "C" int ms_step_tail(const ms_tail_layer* layers, int n_layers, const double* ce_part, int ce_nparts, double ce_scale, float* loss_out,
+                            float* p, float* g, float* m, float* v, float lr, float b1, float b2, float eps, int* step_dev, int* arrive, void* stream) {
+  if ((layers == nullptr && n_layers > 0) || n_layers < 0 || n_layers > kMaxTailLayers || p == nullptr || g == nullptr || m == nullptr || v == nullptr || step_dev == nullptr ||
+      arrive == nullptr || (ce_part != nullptr && (loss_out == nullptr || ce_nparts < 1))) {
+    set_error("ms_step_tail: 0..%d layers, flat p/g/m/v, step_dev, arrive (zero-initialised, dedicated) are required", kMaxTailLayers); return MS_ERR_INVALID;
+  }
+  TailArgs a;
+  int maxB = 1;
+  for (int i = 0; i < n_layers; ++i) {
+    const ms_tail_layer& L = layers[i];
+    if (L.part == nullptr || L.mu == nullptr || L.sig == nullptr || L.B < 1 || L.C < 1 || L.S < 1 || (L.off_gamma >= 0 && (L.gamma_std == nullptr || L.beta_std == nullptr || L.off_beta < 0)) ||
+        (L.off_lmda >= 0 && L.perm == nullptr)) {
+      set_error("ms_step_tail: layer %d is incomplete", i); return MS_ERR_INVALID;
+    }
+    a.layer[i] = L;
+    maxB = std::max(maxB, L.B);
+  }
+  a.ce_part = ce_part; a.ce_nparts = ce_nparts; a.ce_scale = ce_scale; a.loss_out = loss_out;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps;
+  const int gy = n_layers + 1;                       // + the cross-entropy block row
+  a.step_dev = step_dev; a.arrive = arrive; a.total_blocks = maxB * gy; a.n_layers = n_layers;
+  MS_LAUNCH(step_tail_kernel, dim3(maxB, gy), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("step_tail");
 }
 
 extern "C" int ms_counter_incr(int* counter, void* stream) {

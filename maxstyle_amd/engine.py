@@ -331,6 +331,10 @@ class InnerLoopEngine:
         # not wanted in the weight gradients of the training passes.  MS_LOOP_WINOGRAD=0 is the A/B switch.
         self.winograd = type(self) is InnerLoopEngine and os.environ.get("MS_LOOP_WINOGRAD", "1") != "0"
         self.fuse_style_actbwd = True  # ms_style_bwd_actbwd (the MaxStyle backward also does the block's output-activation backward)
+        # the tail of a step as ONE launch (ms_step_tail: the layers' gradient reductions + Adam + the cross-entropy sum + the step counter; was six
+        # ~4.8 us launches); MS_FUSE_TAIL=0 is the A/B switch (bit-identical results)
+        self.fuse_tail = os.environ.get("MS_FUSE_TAIL", "1") != "0"
+        self._tail = None              # while a step defers its tail: {"layers": [...], "ce": (ws, nparts, scale) | None}
         if self.bf16:
             # kernels without a bf16 twin: the "last workgroup finalises" experiments and the weight-gradient kernels (TrainEngine is fp32 only)
             if type(self) is not InnerLoopEngine:
@@ -901,7 +905,10 @@ class InnerLoopEngine:
             b = self.buf
             u2, coef = b["s.u4.u2"], b["s.u4.bn4.coef"]
             part = self.t("s.u4.bw2.hpart", C, nparts, 2)
-            check(self.L("ms_head_ce_actbwd")(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), dh.data_ptr(), self.loss_buf.data_ptr(),
+            defer_ce = self._tail is not None and loss_slot is self.step_dev
+            if defer_ce:                # the head kernel's cross-entropy partials are summed by ms_step_tail: loss = -loss_sign/M * sum
+                self._tail["ce"] = (ws.data_ptr(), nparts, -float(self.loss_sign) / float(N * H * W))
+            check(self.L("ms_head_ce_actbwd")(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), dh.data_ptr(), 0 if defer_ce else self.loss_buf.data_ptr(),
                                         0 if loss_slot is None else loss_slot.data_ptr(), N, C, K, H * W, self.loss_sign, ws.data_ptr(), ws.numel(),
                                         u2.data_ptr(), coef.data_ptr(), part.data_ptr(), LEAKY, self._st()), "ms_head_ce_actbwd")
             bc = self.t("s.u4.bw2.bcoef", C, 4)
@@ -1005,7 +1012,7 @@ class InnerLoopEngine:
         stats, std = self.buf[f"st{i}.stats"], self.buf[f"st{i}.std"]
         dx = self.a(f"st{i}.dx", *x.shape) if need_dx else None
         ws = self.buf[f"st{i}.ws"]
-        go = lambda nm: self.flat_g.data_ptr() + 4 * s.off[nm][0]
+        go = (lambda nm: 0) if self._defer_layer(i, B, C, HW) else (lambda nm: self.flat_g.data_ptr() + 4 * s.off[nm][0])
         po = lambda nm: self.flat_p.data_ptr() + 4 * s.off[nm][0]
         check(self.L("ms_style_bwd")(dy.data_ptr(), x.data_ptr(), 0 if dx is None else dx.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
                                std[0].data_ptr(), std[1].data_ptr(), po("lmda") if s.mix_style else 0, s.perm.data_ptr() if s.mix_style else 0,
@@ -1027,7 +1034,7 @@ class InnerLoopEngine:
         u, coef = b[pfx + ".u2"], b[pfx + ".bn4.coef"]
         nparts = self.L("ms_style_bwd_actbwd_parts")(B, C, HW)
         part = self.t(pfx + ".bw2.spart", C, nparts, 2)
-        go = lambda nm: self.flat_g.data_ptr() + 4 * s.off[nm][0]
+        go = (lambda nm: 0) if self._defer_layer(i, B, C, HW) else (lambda nm: self.flat_g.data_ptr() + 4 * s.off[nm][0])
         po = lambda nm: self.flat_p.data_ptr() + 4 * s.off[nm][0]
         check(self.L("ms_style_bwd_actbwd")(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
                                       std[0].data_ptr(), std[1].data_ptr(), po("lmda") if s.mix_style else 0, s.perm.data_ptr() if s.mix_style else 0,
@@ -1036,6 +1043,43 @@ class InnerLoopEngine:
         bc = self.t(pfx + ".bw2.bcoef", C, 4)
         check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(B * HW), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + pfx)
         return dx, bc
+
+    def _defer_layer(self, i, B, C, HW):
+        """Inside a step with a fused tail: the layer's backward leaves its per-plane partial sums in the workspace (d_* = NULL) and ms_step_tail
+        reduces them, takes the Adam step and advances the counter.  Records the layer's descriptor; returns whether the gradients are deferred."""
+        if self._tail is None:
+            return False
+        from ._lib import TailLayer
+        s = self.styles[i]
+        stats, std = self.buf[f"st{i}.stats"], self.buf[f"st{i}.std"]
+        L = TailLayer()
+        L.part = self.buf[f"st{i}.ws"].data_ptr()
+        L.mu, L.sig = stats[0].data_ptr(), stats[1].data_ptr()
+        L.gamma_std, L.beta_std = std[0].data_ptr(), std[1].data_ptr()
+        L.perm = s.perm.data_ptr() if s.mix_style else 0
+        L.off_gamma = s.off["gamma_noise"][0] if s.use_noise else -1
+        L.off_beta = s.off["beta_noise"][0] if s.use_noise else -1
+        L.off_lmda = s.off["lmda"][0] if s.mix_style else -1
+        L.learn_noise = int(bool(s.learn_noise and s.use_noise))
+        L.learn_mix = int(bool(s.learn_mix and s.mix_style))
+        L.B, L.C, L.S = B, C, lib.ms_style_bwd_slots(B, C, HW, int(self.bf16))
+        self._tail["layers"].append(L)
+        return True
+
+    def step_tail(self):
+        """ms_step_tail over what the backward pass of this step deferred (see _defer_layer / seg_loss)."""
+        from ._lib import TailLayer
+        tl = self._tail
+        self._tail = None
+        n = len(tl["layers"])
+        arr = (TailLayer * max(n, 1))(*tl["layers"])
+        ce = tl["ce"]
+        arrive = self.buf.get("tail.arrive")
+        if arrive is None:
+            arrive = self.buf["tail.arrive"] = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        check(lib.ms_step_tail(arr, n, ce[0] if ce else 0, ce[1] if ce else 0, ce[2] if ce else 0.0, self.loss_buf.data_ptr(),
+                               self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
+                               self.lr, 0.9, 0.999, 1e-8, self.step_dev.data_ptr(), arrive.data_ptr(), self._st()), "ms_step_tail")
 
     def _style_ws(self, i, nbytes):
         """One workspace per layer, zero-filled once: its tail is the persistent epoch state of the single-read kernel (ms_style_ws_bytes)."""
@@ -1142,9 +1186,17 @@ class InnerLoopEngine:
 
     def step(self, image):
         """One inner iteration i >= 1 of advanced_triplet...py:539-566. Returns the re-decoded image."""
-        dimg = self.seg_loss(image, self.labels, need_grad=True, loss_slot=self.step_dev)
-        self.decode_bwd(dimg)
-        self.adam()
+        fused = self.fuse_tail and bool(self.layers) and len(self.layers) <= 8
+        self._tail = {"layers": [], "ce": None} if fused else None
+        try:
+            dimg = self.seg_loss(image, self.labels, need_grad=True, loss_slot=self.step_dev)
+            self.decode_bwd(dimg)
+            if fused:
+                self.step_tail()
+            else:
+                self.adam()
+        finally:
+            self._tail = None
         return self.decode(self.code)
 
     def step_grads(self, labels):

@@ -89,3 +89,37 @@ def test_deferred_error_protocol_and_flush(dev):
     with pytest.raises(MaxStyleHipError, match="this call"):
         eng.check_errors()
     call()
+
+
+@pytest.mark.parametrize("variant", ["default", "nomix", "noisefixed", "mixfixed"])
+def test_fused_step_tail_is_bit_identical(dev, monkeypatch, variant):
+    """ms_step_tail (the layers' gradient reductions + Adam + the cross-entropy sum + the step counter in ONE launch) against the six launches it
+    replaces: parameters, gradients, Adam moments, losses and the image after K = 3 steps are the same bits - also when some tensors are not learnable."""
+    from maxstyle_amd import engine as E, synthetic as syn
+    spec_o = syn.NetSpec(4, 1, 4)
+    B, size, layers = 4, 64, [3, 4, 5]
+    W = R.load_trained("trained_fcn16.npz")
+    to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MS_FUSE_TAIL", fuse)
+        spec = E.NetSpec(4, 1, 4)
+        eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1)
+        assert eng.fuse_tail == (fuse == "1")
+        eng.set_nets(E.PackedNets(spec, to(W["image_encoder"]), to(W["segmentation_decoder"]), to(W["image_decoder"])))
+        img, lab = syn.synthetic_batch(B, size, 1, 4, seed=777)
+        slots = {i: E.StyleSlot(i, B, spec_o.channel_num[i]) for i in layers}
+        for s in slots.values():
+            s.mix_style = variant != "nomix"
+            s.learn_noise = variant != "noisefixed"
+            s.learn_mix = variant != "mixfixed"
+        eng.configure_styles(layers, slots)
+        for i in layers:
+            st = syn.random_style_state(B, spec_o.channel_num[i], 7 + i)
+            eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
+        z_i = eng.encode_fwd(img.to(dev))[0].clone()
+        out = eng.run(z_i, lab.to(dev), 3, use_graph=(variant == "default")).clone()
+        outs.append((out, eng.losses(3).clone(), eng.flat_p.clone(), eng.flat_g.clone(), eng.flat_m.clone(), eng.flat_v.clone(), eng.step_dev.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert int(outs[0][6]) == 3 and bool((outs[0][1] != 0).all())

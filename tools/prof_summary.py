@@ -14,7 +14,7 @@ def main(d, out=None):
         lines.append(f"{r['Name'][:80]:80s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:9.2f} {float(r['AverageNs'])/1e3:8.1f} {float(r['Percentage']):6.1f}")
     rows = list(csv.DictReader(open(kt)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    inc = [i for i, r in enumerate(rows) if "incr_kernel" in r["Kernel_Name"]]
+    inc = [i for i, r in enumerate(rows) if "incr_kernel" in r["Kernel_Name"] or "step_tail_kernel" in r["Kernel_Name"]]      # the last launch of a step
     if len(inc) >= 3:
         a, b = inc[-3] + 1, inc[-2] + 1
         lines.append("")
