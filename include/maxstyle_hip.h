@@ -224,6 +224,17 @@ int ms_conv_subpix(const float* in, float* out, const float* w_packed, const flo
 int ms_conv1x1_bnres(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
                      const float* u, const float* coef4, float slope, int up2, void* stream);
 
+/* Cross-workgroup finalize (`_xfin`): ms_bn_finalize + its consumer in ONE launch.  The consumer launch derives the BatchNorm coefficients itself from the
+ * statistics table `stats` of the conv that produced u (one wave per channel runs ms_bn_finalize's arithmetic - same bits -, writes the record to coef4 for
+ * later kernels and publishes (scale, shift) as two tagged 8-byte granules in `gran`; the waves that need a channel poll its granules - bounded spin, *err = 1
+ * on time-out).  Tag = the launch epoch the producing conv left in the table header, so nothing is cleared between launches: `gran` (ms_xfin_gran_bytes(C))
+ * and `err` are zero-filled ONCE by the caller and dedicated to this BatchNorm layer.  Needs every workgroup of the launch co-resident (an exclusive device).
+ * Replaces, per residual block, the ms_bn_finalize launch behind its second conv (~4.8 us of launch boundary in a replayed graph). */
+size_t ms_xfin_gran_bytes(int C);
+int ms_conv1x1_bnres_xfin(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
+                          const float* u, const float* stats, const float* gamma, const float* beta, float eps, float* coef4, void* gran, int* err,
+                          float slope, int up2, void* stream);
+
 /* ms_conv2d whose output is the gradient w.r.t. an activation LeakyReLU_act_slope(coef4[c].scale*u + coef4[c].shift) that the forward pass
  * never materialised (it was folded into the next convolution's prologue: encoder_decoder.py:44-46, 62-64): the epilogue multiplies by the
  * activation's derivative and accumulates, per output channel, {sum g, sum g*(u - coef4[c].mean)} - the result of
@@ -424,6 +435,9 @@ int ms_act_bwd_reduce_bf16(const uint16_t* gin, const uint16_t* ref, const uint1
 int ms_pool2_sum_bf16(const uint16_t* in, uint16_t* out, int planes, int Ho, int Wo, int accumulate, void* stream);
 int ms_pool2_actbwd_bf16(const uint16_t* in, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
                          int N, int C, int Ho, int Wo, float slope, void* stream);
+int ms_conv1x1_bnres_xfin_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
+                               const uint16_t* u, const float* stats, const float* gamma, const float* beta, float eps, float* coef4, void* gran, int* err,
+                               float slope, int up2, void* stream);
 int ms_head_fwd_bf16(const uint16_t* h, const float* w, const float* b, uint16_t* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
 int ms_head_bwd_bf16(const uint16_t* dout, const uint16_t* out, const float* w, uint16_t* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
 int ms_head_ce_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* logits, float* loss_out,

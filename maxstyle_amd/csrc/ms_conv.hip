@@ -75,11 +75,14 @@ extern "C" size_t ms_conv_stats_bytes(int N, int Cout, int Hout, int Wout) {
 
 struct MaskEpi { const float* u; const float* coef4; float slope; float* tab; int mode = 3; };     // mode 3: activation-backward epilogue; 4 / 5: residual-block tail
 struct FinEpi { int* counter; float* out; const float* gamma; const float* beta; float eps; double count; };
+// cross-workgroup finalize (ConvArgs::xf_*): the statistics table of the BatchNorm whose coefficients this launch consumes, its affine parameters, the record
+// buffer the launch fills for later kernels, the granule table (2 x 8 bytes per channel, zero-filled once by the caller) and the error word
+struct XFin { const float* tab; const float* gamma; const float* beta; float eps; float* coef4; void* gran; int* err; int C; };
 
 static int conv2d_impl(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                        int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                        int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
-                       int epi_mode, float* stats, const MaskEpi* mk, const FinEpi* fin, void* stream, int act_bf16 = 0) {
+                       int epi_mode, float* stats, const MaskEpi* mk, const FinEpi* fin, void* stream, int act_bf16 = 0, const XFin* xf = nullptr) {
   if (N < 1 || Cin < 1 || Cout < 1 || Hs < 1 || Ws < 1) { set_error("ms_conv2d: invalid shape"); return MS_ERR_INVALID; }
   // bit 8 of `fetch` (MS_FETCH_WINOGRAD): the caller accepts the Winograd F(2x2,3x3) form for this call where it is built (see include/maxstyle_hip.h)
   const bool wino_ok = (fetch >= 0) && (fetch & MS_FETCH_WINOGRAD) != 0;
@@ -135,6 +138,14 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
     if (fin->counter == nullptr || fin->out == nullptr || !aligned16(fin->out) || (mk == nullptr && (stats == nullptr || fin->gamma == nullptr || fin->beta == nullptr)) ||
         (mk != nullptr && !(fin->count > 0))) { set_error("ms_conv2d_fin: counter, output and the BatchNorm operands are required"); return MS_ERR_INVALID; }
     a.fin_counter = fin->counter; a.fin_out = fin->out; a.fin_gamma = fin->gamma; a.fin_beta = fin->beta; a.fin_eps = fin->eps; a.fin_count = fin->count;
+  }
+  if (xf != nullptr) {
+    if (xf->tab == nullptr || xf->gamma == nullptr || xf->beta == nullptr || xf->coef4 == nullptr || xf->gran == nullptr || xf->err == nullptr || xf->C < 1 ||
+        !aligned16(xf->tab) || !aligned16(xf->coef4) || (reinterpret_cast<uintptr_t>(xf->gran) & 7u) != 0) {
+      set_error("ms_conv*_xfin: statistics table, gamma, beta, coef4 (16-byte aligned), granule table (8-byte aligned) and the error word are required"); return MS_ERR_INVALID;
+    }
+    a.xf_tab = xf->tab; a.xf_gamma = xf->gamma; a.xf_beta = xf->beta; a.xf_eps = xf->eps; a.xf_coef = xf->coef4;
+    a.xf_gran = reinterpret_cast<conv_u64_t*>(xf->gran); a.xf_err = xf->err; a.xf_C = xf->C;
   }
   if (a.Hout < 1 || a.Wout < 1) { set_error("ms_conv2d: empty output"); return MS_ERR_INVALID; }
   if ((long)N > 65535) { set_error("ms_conv2d: batch too large for gridDim.z"); return MS_ERR_INVALID; }
@@ -209,6 +220,28 @@ extern "C" int ms_conv1x1_bnres(const float* in, float* out, const float* w_pack
   MaskEpi mk{u, coef4, slope, nullptr};
   mk.mode = up2 ? 5 : 4;
   return conv2d_impl(in, nullptr, out, w_packed, bias, N, Cin, Hs, Ws, Cout, 1, 1, 0, 0, nullptr, nullptr, nullptr, 0, 1, 1.0f, 0, nullptr, &mk, nullptr, stream);
+}
+
+extern "C" size_t ms_xfin_gran_bytes(int C) { return (size_t)C * 2 * kXfinRep * sizeof(conv_u64_t); }
+
+// ms_bn_finalize + ms_conv1x1_bnres in ONE launch: the BatchNorm coefficients of u's layer are derived inside this launch from the statistics table `stats`
+// the conv that produced u wrote (one wave per channel, published to the waves that need them; see ConvArgs::xf_*), and stored to coef4 for later kernels.
+extern "C" int ms_conv1x1_bnres_xfin(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
+                                     const float* u, const float* stats, const float* gamma, const float* beta, float eps, float* coef4, void* gran, int* err,
+                                     float slope, int up2, void* stream) {
+  MaskEpi mk{u, coef4, slope, nullptr};
+  mk.mode = up2 ? 5 : 4;
+  const XFin xf{stats, gamma, beta, eps, coef4, gran, err, Cout};
+  return conv2d_impl(in, nullptr, out, w_packed, bias, N, Cin, Hs, Ws, Cout, 1, 1, 0, 0, nullptr, nullptr, nullptr, 0, 1, 1.0f, 0, nullptr, &mk, nullptr, stream, 0, &xf);
+}
+extern "C" int ms_conv1x1_bnres_xfin_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
+                                          const uint16_t* u, const float* stats, const float* gamma, const float* beta, float eps, float* coef4, void* gran, int* err,
+                                          float slope, int up2, void* stream) {
+  MaskEpi mk{reinterpret_cast<const float*>(u), coef4, slope, nullptr};
+  mk.mode = up2 ? 5 : 4;
+  const XFin xf{stats, gamma, beta, eps, coef4, gran, err, Cout};
+  return conv2d_impl(reinterpret_cast<const float*>(in), nullptr, reinterpret_cast<float*>(out), w_packed, bias, N, Cin, Hs, Ws, Cout, 1, 1, 0, 0, nullptr, nullptr, nullptr, 0, 1, 1.0f,
+                     0, nullptr, &mk, nullptr, stream, 1, &xf);
 }
 
 // ---- `_bf16` twins: the activation tensors (in, in2, out, u) hold bf16 bit patterns; weights, bias, coefficients, statistics and tables are fp32 as before.

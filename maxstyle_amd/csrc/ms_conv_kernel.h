@@ -28,6 +28,7 @@ enum { FETCH_NORMAL = 0, FETCH_UPS2 = 1, FETCH_ZINS2 = 2 };
 #define MS_CONV_PF2 1            // 0: build the staging waves with one register set everywhere (A/B)
 #endif
 
+typedef unsigned long long conv_u64_t;
 struct ConvArgs {
   const float* in; const float* in2; float* out; const float* w; const float* bias;
   const float* pro_a; const float* pro_b; const float* pro_c;
@@ -50,6 +51,12 @@ struct ConvArgs {
   // and writes fin_out: the BatchNorm coefficients {scale, shift, mean, invstd} (statistics epilogue; fin_gamma/fin_beta/fin_eps) or the
   // BatchNorm-backward coefficients {al, be, de, 0} (mask epilogue; fin_count = N*H*W) - what ms_bn_finalize / ms_bn_bwd_coefs do in their own launch
   int* fin_counter; float* fin_out; const float* fin_gamma; const float* fin_beta; float fin_eps; double fin_count;
+  // "cross-workgroup finalize" (the `_xfin` entry points): this launch CONSUMES BatchNorm coefficients (prologue pro_mode 1, or the residual-tail epilogue
+  // epi_mode 4 / 5) that no ms_bn_finalize launch has produced yet.  xf_tab = the statistics table the producing conv wrote (its header carries a launch
+  // epoch, bumped by conv_table_tail); one MFMA wave per channel - wave w of workgroup vb takes channel 4*vb + w - runs ms_bn_finalize's arithmetic on it,
+  // stores the record to xf_coef (for later kernels) and publishes {tag = epoch | scale}, {tag | shift} as two 8-byte granules in xf_gran with agent-scope
+  // stores; every consumer of a channel polls its granules (bounded spin; *xf_err on time-out).  See xfin_* below.
+  const float* xf_tab; const float* xf_gamma; const float* xf_beta; float xf_eps; float* xf_coef; conv_u64_t* xf_gran; int* xf_err; int xf_C;
 };
 
 typedef unsigned long long conv_u64;
@@ -76,6 +83,65 @@ __device__ inline double shfl_xor_d(double v, int off) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __shfl_xor(lo, off, 64); hi = __shfl_xor(hi, off, 64);
   return __hiloint2double(hi, lo);
+}
+
+// ---- cross-workgroup finalize (see ConvArgs::xf_*) ------------------------------------------------------------------------------------------------
+constexpr unsigned kXfinSpin = 1u << 18;
+constexpr int kXfinRep = 64;
+__device__ inline double xf_wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += shfl_xor_d(v, off);
+  return v;
+}
+__device__ inline unsigned xfin_tag(const ConvArgs& a) { return __float_as_uint(reinterpret_cast<const float4*>(a.xf_tab)[0].y); }
+// One full wave, channel c: bn_finalize_kernel's arithmetic (ms_conv.hip), same order -> the same bits; record to xf_coef, (scale, shift) published.
+__device__ inline void xfin_reduce_publish(const ConvArgs& a, int c, unsigned tag) {
+  const int lane = threadIdx.x & 63;
+  const float4* tab = reinterpret_cast<const float4*>(a.xf_tab);
+  const int nparts = (int)tab[0].x;
+  const float4* part = tab + 1 + (size_t)c * kStatSlots;
+  double sn = 0.0, sm = 0.0, sq = 0.0;
+  for (int i = lane; i < nparts; i += 64) {
+    const float4 q = part[i];
+    const double n = (double)q.x, mu = (double)q.y;
+    sn += n; sm += n * mu; sq += (double)q.z + n * mu * mu;
+  }
+  sn = xf_wave_sum_d(sn); sm = xf_wave_sum_d(sm); sq = xf_wave_sum_d(sq);
+  float psc = 0.f, psh = 0.f;
+  if (lane == 0) {
+    const double mean = sm / sn;
+    const double var = fmax((sq - sm * mean) / sn, 0.0);
+    const float invstd = (float)(1.0 / sqrt(var + (double)a.xf_eps));
+    const float sc = a.xf_gamma[c] * invstd;
+    const float sh = a.xf_beta[c] - (float)mean * sc;
+    reinterpret_cast<float4*>(a.xf_coef)[c] = make_float4(sc, sh, (float)mean, invstd);
+    psc = sc; psh = sh;
+  }
+  // kXfinRep replicas of each granule, one per lane (ONE coalesced 512-byte store per granule): a reader takes the replica of its workgroup, so an address is
+  // polled by grid/64 workgroups instead of all of them.  (First version: one copy - at 16 channels every lane of 512 workgroups polled the same two cache
+  // lines and the launch at 256x256 got 11 us SLOWER: single-address throughput of the memory side, not latency; profiles/r03_experiments.txt.)
+  psc = __shfl(psc, 0, 64); psh = __shfl(psh, 0, 64);
+  __hip_atomic_store(a.xf_gran + (size_t)(2 * c) * kXfinRep + lane, ((conv_u64_t)tag << 32) | (conv_u64_t)__float_as_uint(psc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(a.xf_gran + (size_t)(2 * c + 1) * kXfinRep + lane, ((conv_u64_t)tag << 32) | (conv_u64_t)__float_as_uint(psh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The MFMA waves of the launch share the channels out: wave w of workgroup vb reduces channels 4*vb + w, + 4*grid, ...
+__device__ inline void xfin_produce(const ConvArgs& a, int vb, unsigned tag) {
+  const int wave = threadIdx.x >> 6;
+  for (int c = 4 * vb + wave; c < a.xf_C; c += 4 * (int)gridDim.x) xfin_reduce_publish(a, c, tag);
+}
+// both granules of a channel per round trip (each half validates itself by its tag, so a torn pair is simply retried); rep = the workgroup's replica
+__device__ inline void xfin_peek(const ConvArgs& a, int c, int rep, conv_u64_t (&g)[2]) {
+  g[0] = __hip_atomic_load(a.xf_gran + (size_t)(2 * c) * kXfinRep + rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  g[1] = __hip_atomic_load(a.xf_gran + (size_t)(2 * c + 1) * kXfinRep + rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline float2 xfin_poll(const ConvArgs& a, int c, int rep, unsigned tag, conv_u64_t (&g)[2]) {      // g: an earlier peek (issued long before this call)
+  for (unsigned spins = 0;; ++spins) {
+    if ((unsigned)(g[0] >> 32) == tag && (unsigned)(g[1] >> 32) == tag)
+      return make_float2(__uint_as_float((unsigned)(g[0] & 0xFFFFFFFFull)), __uint_as_float((unsigned)(g[1] & 0xFFFFFFFFull)));
+    if (spins > kXfinSpin) { __hip_atomic_store(a.xf_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return make_float2(0.f, 0.f); }
+    __builtin_amdgcn_s_sleep(8);
+    xfin_peek(a, c, rep, g);
+  }
 }
 
 // End of a conv kernel, MFMA waves only (threads 0..255; the staging waves have returned - s_barrier only waits for surviving waves): the per-lane
@@ -133,8 +199,14 @@ __device__ inline void conv_table_tail(const ConvArgs& a, float* smem, int vb, i
     }
   }
   if (vb == 0 && threadIdx.x == 0) {
-    if (STATS) reinterpret_cast<float4*>(a.stats)[0] = make_float4((float)S, 0.f, 0.f, 0.f);
-    else reinterpret_cast<float2*>(a.mk_tab)[0] = make_float2((float)S, 0.f);
+    // header: {slots in use, launch epoch of this table (an integer in float bits: the tag of the `_xfin` consumers' granules), 0, 0}
+    if (STATS) {
+      const unsigned ep = __float_as_uint(reinterpret_cast<const float4*>(a.stats)[0].y) + 1u;
+      reinterpret_cast<float4*>(a.stats)[0] = make_float4((float)S, __uint_as_float(ep == 0u ? 1u : ep), 0.f, 0.f);
+    } else {
+      const unsigned ep = __float_as_uint(reinterpret_cast<const float2*>(a.mk_tab)[0].y) + 1u;
+      reinterpret_cast<float2*>(a.mk_tab)[0] = make_float2((float)S, __uint_as_float(ep == 0u ? 1u : ep));
+    }
   }
   if (a.fin_counter == nullptr) return;
   if (wave == 0) {
@@ -581,6 +653,13 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
       }
     }
   }
+  unsigned xf_tag = 0u;
+  conv_u64_t xf_pre[NT][2];                            // the lane's granules, peeked at the start of the last chunk of the first item: landed by the epilogue
+  bool xf_pending = false;                             // epi_mode 4 / 5 with xf_tab: (scale, shift) of this lane's channels are polled before the first epilogue
+  if (a.xf_tab != nullptr) {
+    xf_tag = xfin_tag(a);
+    xf_pending = (a.epi_mode == 4 || a.epi_mode == 5);
+  }
   // (no s_setprio here: the STAGING waves get the priority - measured 290.7 -> 295.2 steps/s against the opposite choice; a staging wave that
   //  loses issue arbitration to back-to-back MFMAs is what the MFMA waves end up waiting for at the barrier)       // the MFMA-issuing wave wins issue arbitration against the staging wave of its SIMD
   const int m = lane & 15, k = lane >> 4;
@@ -642,13 +721,22 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
       int bidx = co;
       if (a.epi_mode == 2) bidx = co % a.cout_real;
       bias_v[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[bidx] : 0.f;
-      if (a.epi_mode >= 3) {
+      if (a.epi_mode >= 3 && !xf_pending) {
         const float4 cf = (co < a.Cout) ? reinterpret_cast<const float4*>(a.mk_coef)[co] : make_float4(0.f, 0.f, 0.f, 0.f);
         mk_sc[j] = cf.x; mk_sh[j] = cf.y; mk_mu[j] = cf.z;
       }
     }
   };
   auto epilogue = [&](int n, int tile, int co0) {
+    if (xf_pending) {          // first epilogue of this workgroup (it keeps one channel block for its life): the coefficients some wave of the launch published
+      xf_pending = false;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = co0 + j * 16 + m;
+        const float2 cf = (co < a.Cout) ? xfin_poll(a, co, vb & (kXfinRep - 1), xf_tag, xf_pre[j]) : make_float2(0.f, 0.f);
+        mk_sc[j] = cf.x; mk_sh[j] = cf.y; mk_mu[j] = 0.f;
+      }
+    }
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int xq = 4 * k;     // D layout (16x16): column (output channel) = lane&15, rows (pixels) = 4*(lane>>4) + reg
@@ -891,10 +979,18 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   decode(item, n, tile, cb);
   load_bias(cb * COUT_TILE);
   lds_barrier();                                      // barrier #0
+  // the reducing waves of a cross-workgroup finalize work HERE, while the staging waves of their workgroup wait for the first chunk's global loads anyway:
+  // in front of barrier #0 the ~4.5 us of cold table loads + publish delayed the whole workgroup's pipeline, and with a static work split the launch ends
+  // with its slowest workgroup (measured: +3.9 us per launch, profiles/r03_experiments.txt)
+  if (a.xf_tab != nullptr) xfin_produce(a, vb, xf_tag);
   lds_barrier();                                      // barrier #1: chunk 0 is in buffer 0
   for (int p = 0; p < T; ++p) {
     const int c0 = chunk * CK;
     const int ncg = min(CK / 4, (a.cin_pad - c0) / 4);
+    if (xf_pending && chunk + 1 == nchunks) {          // (wave-uniform) one round trip ahead of the first epilogue
+#pragma unroll
+      for (int j = 0; j < NT; ++j) xfin_peek(a, min(cb * COUT_TILE + j * 16 + m, a.xf_C - 1), vb & (kXfinRep - 1), xf_pre[j]);
+    }
     if (!(a.dbg & 1)) {
       if (ncg == CK / 4) compute(smem + (p & 1) * BUF, std::true_type{}, CK / 4);
       else compute(smem + (p & 1) * BUF, std::false_type{}, ncg);

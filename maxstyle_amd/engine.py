@@ -334,6 +334,10 @@ class InnerLoopEngine:
         # the tail of a step as ONE launch (ms_step_tail: the layers' gradient reductions + Adam + the cross-entropy sum + the step counter; was six
         # ~4.8 us launches); MS_FUSE_TAIL=0 is the A/B switch (bit-identical results)
         self.fuse_tail = os.environ.get("MS_FUSE_TAIL", "1") != "0"
+        # cross-workgroup finalize (`_xfin` entry points): the BatchNorm coefficients a launch consumes are derived INSIDE that launch (one wave per channel,
+        # published through tagged granules) instead of by an ms_bn_finalize launch in front of it.  Needs every workgroup of a launch co-resident: not with
+        # shared_device.  MS_XFIN=0 is the A/B switch (bit-identical results).
+        self.xfin = os.environ.get("MS_XFIN", "1") != "0" and type(self) is InnerLoopEngine
         self._tail = None              # while a step defers its tail: {"layers": [...], "ce": (ws, nparts, scale) | None}
         if self.bf16:
             # kernels without a bf16 twin: the "last workgroup finalises" experiments and the weight-gradient kernels (TrainEngine is fp32 only)
@@ -360,7 +364,7 @@ class InnerLoopEngine:
         """An ACTIVATION tensor (conv inputs / outputs, gradients, images): fp32, or bf16 storage in bf16 mode (everything else stays fp32)."""
         return self.t(name, *shape, dtype=self.act_dtype)
 
-    _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv1x1_bnres", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd",
+    _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd",
                              "ms_head_fwd", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_style_fwd", "ms_style_bwd", "ms_style_ws_bytes",
                              "ms_conv_subpix", "ms_conv3x3_small_cout", "ms_style_bwd_actbwd", "ms_style_bwd_actbwd_parts"))
 
@@ -419,6 +423,8 @@ class InnerLoopEngine:
             off = self._ws_state_off.get(name)
             if off is not None:
                 words.append(ws[off + 4:off + 8].view(torch.int32))
+        if "xfin.err" in self.buf:                       # time-out word of the cross-workgroup finalize (`_xfin` conv launches)
+            words.append(self.buf["xfin.err"])
         return words
 
     def check_errors(self, sync=True):
@@ -570,6 +576,24 @@ class InnerLoopEngine:
         if self.bn_observer is not None:
             self.bn_observer(bn, coef)
         return coef
+
+    def _xfin_ok(self, st):
+        """The consumer launch may derive its BatchNorm coefficients itself (`_xfin`): batch statistics, a statistics TABLE in hand (not the pair the
+        'last workgroup finalises' experiment returns), an exclusive device."""
+        return self.xfin and not self.bn_eval and not self.shared_device and not isinstance(st, tuple) and self.bn_observer is None
+
+    def _xfin_bufs(self, name, C):
+        """(coefficient records [C,4], granule table, error word) of one BatchNorm layer; granules and error word zero-filled once."""
+        coef = self.t(name + ".coef", C, 4)
+        gran = self.buf.get(name + ".gran")
+        if gran is None or gran.numel() < lib.ms_xfin_gran_bytes(C):
+            if gran is not None and self._any_graph():
+                raise RuntimeError("granule table would be re-allocated while a captured graph is live")
+            gran = self.buf[name + ".gran"] = torch.zeros(int(lib.ms_xfin_gran_bytes(C)), dtype=torch.uint8, device=self.dev)
+        err = self.buf.get("xfin.err")
+        if err is None:
+            err = self.buf["xfin.err"] = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        return coef, gran, err
 
     def bn_act(self, name, u, coef, res=None, res_mode=0, slope=LEAKY):
         N, C, H, W = u.shape
@@ -732,11 +756,19 @@ class InnerLoopEngine:
             u1, st1, p1 = self.conv(pfx + ".u1", src, c0, fetch=fetch, stats=True, fin=net[key + ".bn1"])
         cf1 = self.bn_fin(pfx + ".bn1", st1, p1, net[key + ".bn1"])
         u2, st2, p2 = self.conv(pfx + ".u2", u1, c3, act=(cf1, LEAKY), stats=True, fin=net[key + ".bn4"])
-        cf2 = self.bn_fin(pfx + ".bn4", st2, p2, net[key + ".bn4"])
+        xf2 = fused_tail and self._xfin_ok(st2)
+        cf2 = None if xf2 else self.bn_fin(pfx + ".bn4", st2, p2, net[key + ".bn4"])
         if fused_tail:
             xin = x if kind == "nn" else src
             N, Cin, Hs, Ws = xin.shape
             out = self.a(pfx + ".out", *u2.shape)
+            if xf2:
+                bn = net[key + ".bn4"]
+                cf2, gran, err = self._xfin_bufs(pfx + ".bn4", bn.gamma.numel())
+                check(self.L("ms_conv1x1_bnres_xfin")(xin.data_ptr(), out.data_ptr(), ci.wp.data_ptr(), 0 if ci.b is None else ci.b.data_ptr(), N, Cin, Hs, Ws, ci.cout,
+                                                u2.data_ptr(), st2.data_ptr(), bn.gamma.data_ptr(), bn.beta.data_ptr(), BN_EPS, cf2.data_ptr(), gran.data_ptr(), err.data_ptr(),
+                                                LEAKY, 1 if kind == "nn" else 0, self._st()), "ms_conv1x1_bnres_xfin:" + pfx)
+                return out
             check(self.L("ms_conv1x1_bnres")(xin.data_ptr(), out.data_ptr(), ci.wp.data_ptr(), 0 if ci.b is None else ci.b.data_ptr(), N, Cin, Hs, Ws, ci.cout,
                                        u2.data_ptr(), cf2.data_ptr(), LEAKY, 1 if kind == "nn" else 0, self._st()), "ms_conv1x1_bnres:" + pfx)
             return out

@@ -197,3 +197,52 @@ def test_config5_combined_stream_bf16_vs_fp32(dev):
             assert max(abs(x - y) for x, y in zip(d32, d16)) < 3e-2, (c, d32, d16)
         else:                                               # Prostate on random networks: bounded, not compared step by step
             assert float(o16.min()) > float(o32.min()) - 0.5 * rng and float(o16.max()) < float(o32.max()) + 0.5 * rng
+
+
+@pytest.mark.parametrize("case", ["c2small", "c4small", "bf16", "c2full"])
+def test_cross_workgroup_finalize_is_bit_identical(dev, monkeypatch, case):
+    """`_xfin` (ms_conv1x1_bnres_xfin: the residual-block tail derives the BatchNorm coefficients of the block's second conv itself - one wave per channel,
+    published through tagged, replicated granules - instead of an ms_bn_finalize launch in front of it) against the separate launches: same bits in the
+    image, the losses and the parameters after K steps, eager and through the captured graph; the error word stays clear; and the coefficient records the
+    launch leaves for later kernels are the ones ms_bn_finalize writes."""
+    from maxstyle_amd import engine as E, synthetic as syn
+    net, B, size, act = {"c2small": ((4, 1, 4), 4, 64, None), "c4small": ((1, 3, 2), 4, 64, None), "bf16": ((4, 1, 4), 4, 64, torch.bfloat16),
+                         "c2full": ((4, 1, 4), 16, 256, None)}[case]
+    spec_o = syn.NetSpec(*net)
+    W = syn.procedural_weights(spec_o, 0)
+    to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
+    layers = [3, 4, 5]
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MS_XFIN", flag)
+        spec = E.NetSpec(*net)
+        eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1, act_dtype=act)
+        assert eng.xfin == (flag == "1")
+        eng.set_nets(E.PackedNets(spec, to(W["image_encoder"]), to(W["segmentation_decoder"]), to(W["image_decoder"])))
+        img, lab = syn.synthetic_batch(B, size, net[1], net[2], seed=1234)
+        eng.configure_styles(layers, {i: E.StyleSlot(i, B, spec_o.channel_num[i]) for i in layers})
+        for i in layers:
+            st = syn.random_style_state(B, spec_o.channel_num[i], 7 + i)
+            eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
+        z_i = eng.encode_fwd(img.to(dev).to(eng.act_dtype))[0].clone()
+        res = []
+        for graph in (False, True):
+            for i in layers:
+                st = syn.random_style_state(B, spec_o.channel_num[i], 7 + i)
+                eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
+                eng.styles[i].have_std = False
+            eng.flat_m.zero_(); eng.flat_v.zero_(); eng.flat_g.zero_()
+            out = eng.run(z_i, lab.to(dev), 3, use_graph=graph).clone()
+            res.append((out, eng.losses(3).clone(), eng.flat_p.clone()))
+        eng.check_errors()
+        if flag == "1":
+            assert "xfin.err" in eng.buf and int(eng.buf["xfin.err"].item()) == 0
+            assert any(k.endswith(".gran") for k in eng.buf)
+        assert all(torch.equal(a, b) for a, b in zip(res[0], res[1])), "graph replay == eager"
+        coefs = {k: v.clone() for k, v in eng.buf.items() if k.endswith(".bn4.coef")}
+        outs.append((res[0], coefs))
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
+    assert outs[0][1].keys() == outs[1][1].keys() and len(outs[0][1]) >= 9
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
