@@ -124,10 +124,13 @@ __device__ inline void xfin_reduce_publish(const ConvArgs& a, int c, unsigned ta
   __hip_atomic_store(a.xf_gran + (size_t)(2 * c) * kXfinRep + lane, ((conv_u64_t)tag << 32) | (conv_u64_t)__float_as_uint(psc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(a.xf_gran + (size_t)(2 * c + 1) * kXfinRep + lane, ((conv_u64_t)tag << 32) | (conv_u64_t)__float_as_uint(psh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// The MFMA waves of the launch share the channels out: wave w of workgroup vb reduces channels 4*vb + w, + 4*grid, ...
-__device__ inline void xfin_produce(const ConvArgs& a, int vb, unsigned tag) {
+// The MFMA waves of the launch share the channels out: wave w of workgroup b (HARDWARE block index, not the XCD-permuted vb) reduces channels 4*b + w, ...
+// Workgroups are dispatched in block-index order, so the publishers are the first ones on the chip: a resident workgroup never waits for one that is
+// not - also when the grid does not fit the chip at once (found by the bounded spin: the 64-channel-tile 1x1 kernel needs 205 VGPRs, one workgroup per
+// CU, and with publishers numbered by vb half of them sat behind their own pollers).
+__device__ inline void xfin_produce(const ConvArgs& a, unsigned tag) {
   const int wave = threadIdx.x >> 6;
-  for (int c = 4 * vb + wave; c < a.xf_C; c += 4 * (int)gridDim.x) xfin_reduce_publish(a, c, tag);
+  for (int c = 4 * (int)blockIdx.x + wave; c < a.xf_C; c += 4 * (int)gridDim.x) xfin_reduce_publish(a, c, tag);
 }
 // both granules of a channel per round trip (each half validates itself by its tag, so a torn pair is simply retried); rep = the workgroup's replica
 __device__ inline void xfin_peek(const ConvArgs& a, int c, int rep, conv_u64_t (&g)[2]) {
@@ -982,7 +985,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   // the reducing waves of a cross-workgroup finalize work HERE, while the staging waves of their workgroup wait for the first chunk's global loads anyway:
   // in front of barrier #0 the ~4.5 us of cold table loads + publish delayed the whole workgroup's pipeline, and with a static work split the launch ends
   // with its slowest workgroup (measured: +3.9 us per launch, profiles/r03_experiments.txt)
-  if (a.xf_tab != nullptr) xfin_produce(a, vb, xf_tag);
+  if (a.xf_tab != nullptr) xfin_produce(a, xf_tag);
   lds_barrier();                                      // barrier #1: chunk 0 is in buffer 0
   for (int p = 0; p < T; ++p) {
     const int c0 = chunk * CK;
@@ -1015,10 +1018,17 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
   const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * (size_t)a.cin_pad);
   if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
   static std::once_flag attr_once;                     // one flag per instantiation (no unsynchronised mutable state in the ABI)
-  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
+  static int reg_limit = 2;                            // written once, inside the call_once
+  std::call_once(attr_once, []() {
+    const void* fn = (const void*)conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2, AT>;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    hipFuncAttributes fa{};
+    if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.numRegs > 128) reg_limit = 1;
+  });
   const long nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb;
-  // resident workgroups per CU: 512 threads = 2 waves per SIMD each -> at most 2 within 256 registers per wave; LDS 160 KiB per CU
-  const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));
+  // resident workgroups per CU: 512 threads = 2 waves per SIMD each -> at most 2 within 128 registers per wave, ONE above that (the 64-channel-tile variants:
+  // a grid of two per CU ran as two rounds of a persistent kernel); LDS 160 KiB per CU.  The register count is a property of the instantiation: asked once.
+  const int per_cu = std::max(1, std::min(reg_limit, (int)((160 * 1024) / (lds_bytes + 256))));
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;      // every workgroup keeps one channel block: item % ncb == blockIdx % ncb
   dim3 grid((unsigned)nblocks), block(512);
