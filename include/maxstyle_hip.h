@@ -101,6 +101,14 @@ int ms_head_ce_actbwd(const float* h, const float* w, const float* b, const int6
  * BatchNorm backward of the block's last BatchNorm needs are written to bn_part [C][ms_style_bwd_actbwd_parts(B,C,HW)][2] (the partial layout of
  * ms_act_bwd_reduce, consumed by ms_bn_bwd_coefs / ms_bn_bwd_full): bn_u = that BatchNorm's raw input [B,C,H,W], bn_coef4 = its {scale, shift, mean, invstd}.
  * Replaces ms_style_bwd + ms_act_bwd_reduce (encoder_decoder.py:344-346 backward); needs dx and H*W % 4 == 0.  The style gradients are unaffected. */
+/* ms_head_bwd + ms_style_bwd[_actbwd] in ONE pass, for a MaxStyle layer that sits directly in front of a 1x1 head (apply_max_style: layer 4 -> final_conv ->
+ * Sigmoid, encoder_decoder.py:619-627): the layer's incoming gradient dy[c] = sum_k head_w[k][c] * head_g[k] * out_k(1-out_k) is formed while streaming instead of
+ * being written by ms_head_bwd and read back (a [B,C,H,W] tensor each way).  head_g, head_out [B,K,HW] (head_out NULL: no sigmoid), head_w [K][C], K <= 4.
+ * Everything else as ms_style_bwd_actbwd; bn_u / bn_coef4 / bn_part may be NULL (plain ms_style_bwd), dx may be NULL.  Same arithmetic, same order: bit-identical. */
+int ms_style_bwd_head(const float* head_g, const float* head_out, const float* head_w, int K, const float* x, float* dx, const float* mu, const float* sig,
+                      const float* coefA, const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
+                      float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes,
+                      const float* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream);
 int ms_style_bwd_actbwd_parts(int B, int C, int HW);
 int ms_style_bwd_actbwd(const float* dy, const float* x, float* dx, const float* mu, const float* sig, const float* coefA,
                         const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,

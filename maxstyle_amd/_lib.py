@@ -53,6 +53,8 @@ SIGNATURES = {
     "ms_style_bwd_actbwd_parts": (c_int, [c_int, c_int, c_int]),
     "ms_style_bwd_actbwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p,
                                     c_int, c_int, c_int, c_void, c_size, c_f32p, c_f32p, c_f32p, c_float, c_void]),
+    "ms_style_bwd_head": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p,
+                                  c_int, c_int, c_int, c_void, c_size, c_f32p, c_f32p, c_f32p, c_float, c_void]),
     "ms_style_ws_bytes_bf16": (c_size, [c_int, c_int, c_int]),
     "ms_style_fused_ws_bytes_bf16": (c_size, [c_int, c_int, c_int]),
     "ms_style_fwd_bf16": (c_int, [c_void, c_void, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p,

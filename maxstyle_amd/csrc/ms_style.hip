@@ -180,26 +180,49 @@ __global__ __launch_bounds__(kStyleThreads) void restyle_kernel(const float* __r
 // straight into that block's output-activation backward: dx is additionally multiplied by lrelu'(x) (sign(x) == sign(pre-activation)) and the two sums the
 // BatchNorm backward of the block's last BatchNorm needs (sum g', sum g'*(u - mean_c), u = that BatchNorm's raw input) are written per block - what
 // ms_act_bwd_reduce would do in its own 4-pass launch over dx.  The style gradients use the UNMASKED dy, as before.
+// the head in front of a MaxStyle layer's backward (ms_style_bwd_head): g [N,K,HW] gradient w.r.t. the head's output, out = its sigmoid output (NULL: no sigmoid),
+// w [K][C] the 1x1 head weights
+struct HeadSrc { const float* g; const float* out; const float* w; int K; };
 template <int VEC>
 __global__ __launch_bounds__(kStyleThreads) void restyle_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
                                                                    const float* __restrict__ mu, const float* __restrict__ sig,
                                                                    const float* __restrict__ coefA, float2* __restrict__ part,
                                                                    int HW, int chunk, int S,
                                                                    const float* __restrict__ bn_u, const float4* __restrict__ bn_coef, float2* __restrict__ bn_part,
-                                                                   int C, float slope) {
+                                                                   int C, float slope, const HeadSrc hd) {
   __shared__ float red[16];
   const int p = blockIdx.y;
   const float m = mu[p], inv = 1.f / sig[p], a = coefA[p] * inv;
   const int beg = blockIdx.x * chunk, end = min(HW, beg + chunk);
   const float* xp = x + (size_t)p * HW;
-  const float* gp = dy + (size_t)p * HW;
+  const float* gp = hd.g ? nullptr : dy + (size_t)p * HW;
+  // hd.g != NULL: dy is not read - it is the gradient that ms_head_bwd would have written for this plane, formed on the fly from the K planes of the head's
+  // output gradient: dy[c] = sum_k w[k][c] * (g_k * out_k * (1 - out_k)), the same operations in the same order (bit-identical to the stored tensor)
+  const int hn = p / C, hc = p % C;
+  float hw[4] = {0.f, 0.f, 0.f, 0.f};
+  if (hd.g) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < hd.K) hw[k] = hd.w[k * C + hc];
+  }
+  auto head_dy4 = [&](int i) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < hd.K) {
+      const size_t off = ((size_t)hn * hd.K + k) * HW + i;
+      const float4 g = *reinterpret_cast<const float4*>(hd.g + off);
+      float4 d = g;
+      if (hd.out) { const float4 o = *reinterpret_cast<const float4*>(hd.out + off); d = make_float4(g.x * (o.x * (1.f - o.x)), g.y * (o.y * (1.f - o.y)), g.z * (o.z * (1.f - o.z)), g.w * (o.w * (1.f - o.w))); }
+      acc.x += hw[k] * d.x; acc.y += hw[k] * d.y; acc.z += hw[k] * d.z; acc.w += hw[k] * d.w;
+    }
+    return acc;
+  };
   float* dxp = dx ? dx + (size_t)p * HW : nullptr;
   const float* up = bn_u ? bn_u + (size_t)p * HW : nullptr;
   const float bmean = bn_u ? bn_coef[p % C].z : 0.f;
   float s1 = 0.f, s2 = 0.f, b1 = 0.f, b2 = 0.f;
   for (int i = beg + threadIdx.x * VEC; i < end; i += kStyleThreads * VEC) {
     if (VEC == 4) {
-      const float4 g = *reinterpret_cast<const float4*>(gp + i);
+      const float4 g = hd.g ? head_dy4(i) : *reinterpret_cast<const float4*>(gp + i);
       const float4 t = *reinterpret_cast<const float4*>(xp + i);
       s1 += (g.x + g.y) + (g.z + g.w);
       s2 += g.x * ((t.x - m) * inv) + g.y * ((t.y - m) * inv) + g.z * ((t.z - m) * inv) + g.w * ((t.w - m) * inv);
@@ -611,15 +634,20 @@ extern "C" int ms_style_fwd_3k(const float* x, float* y, float* mu, float* sig, 
 static int style_bwd_impl(const float* dy, const float* x, float* dx, const float* mu, const float* sig, const float* coefA,
                           const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
                           float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes,
-                          const float* bn_u, const float* bn_coef4, float* bn_part, float slope, void* stream) {
+                          const float* bn_u, const float* bn_coef4, float* bn_part, float slope, void* stream, const HeadSrc* head = nullptr) {
   if (int e = check_style_args(B, C, HW, ws, ws_bytes)) return e;
   if (d_lmda != nullptr && (lmda == nullptr || perm == nullptr)) { set_error("ms_style_bwd: d_lmda needs lmda and perm"); return MS_ERR_INVALID; }
+  const HeadSrc hd = head ? *head : HeadSrc{nullptr, nullptr, nullptr, 0};
+  if (head != nullptr && (hd.g == nullptr || hd.w == nullptr || hd.K < 1 || hd.K > 4 || HW % 4 != 0 || !aligned16(hd.g) || (hd.out != nullptr && !aligned16(hd.out)) || !aligned16(x))) {
+    set_error("ms_style_bwd_head: head gradient [N,K,HW] (K <= 4), weights [K][C], H*W %% 4 == 0 and 16-byte aligned tensors are required"); return MS_ERR_INVALID;
+  }
   hipStream_t st = (hipStream_t)stream;
   const int P = B * C;
   if (bn_u != nullptr && (dx == nullptr || bn_coef4 == nullptr || bn_part == nullptr || P > kMaxPlanesPerLaunch || !aligned16(bn_coef4))) {
     set_error("ms_style_bwd_actbwd: needs dx, bn_coef4 (16-byte aligned), bn_part and <= 65535 planes"); return MS_ERR_INVALID;
   }
-  const bool vec = (HW % 4 == 0) && aligned16(x) && aligned16(dy) && (dx == nullptr || aligned16(dx)) && (bn_u == nullptr || aligned16(bn_u));
+  const bool vec = (HW % 4 == 0) && aligned16(x) && (head != nullptr || aligned16(dy)) && (dx == nullptr || aligned16(dx)) && (bn_u == nullptr || aligned16(bn_u));
+  if (head != nullptr && !vec) { set_error("ms_style_bwd_head: the vector path is required (16-byte aligned x, dx, bn_u)"); return MS_ERR_ALIGN; }
   const Split sp = choose_split(P, HW, vec);
   float2* part = (float2*)ws;
   for (int p0 = 0; p0 < P; p0 += kMaxPlanesPerLaunch) {
@@ -627,10 +655,11 @@ static int style_bwd_impl(const float* dy, const float* x, float* dx, const floa
     dim3 grid(sp.S, np), block(kStyleThreads);
     const size_t off = (size_t)p0 * HW;
     float* dxo = dx ? dx + off : nullptr;
-    if (vec) MS_LAUNCH(restyle_bwd_kernel<4>, grid, block, 0, st, dy + off, x + off, dxo, mu + p0, sig + p0, coefA + p0, part + (size_t)p0 * sp.S, HW, sp.chunk, sp.S,
-                       bn_u, (const float4*)bn_coef4, (float2*)bn_part, C, slope);
+    if (head != nullptr && p0 != 0) { set_error("ms_style_bwd_head: more than 65535 planes"); return MS_ERR_INVALID; }
+    if (vec) MS_LAUNCH(restyle_bwd_kernel<4>, grid, block, 0, st, dy ? dy + off : nullptr, x + off, dxo, mu + p0, sig + p0, coefA + p0, part + (size_t)p0 * sp.S, HW, sp.chunk, sp.S,
+                       bn_u, (const float4*)bn_coef4, (float2*)bn_part, C, slope, hd);
     else MS_LAUNCH(restyle_bwd_kernel<1>, grid, block, 0, st, dy + off, x + off, dxo, mu + p0, sig + p0, coefA + p0, part + (size_t)p0 * sp.S, HW, sp.chunk, sp.S,
-                   bn_u, (const float4*)bn_coef4, (float2*)bn_part, C, slope);
+                   bn_u, (const float4*)bn_coef4, (float2*)bn_part, C, slope, hd);
   }
   if (int e = check_launch("restyle_bwd")) return e;
   if (d_gamma || d_beta || d_lmda) {
@@ -658,6 +687,17 @@ extern "C" int ms_style_bwd_actbwd(const float* dy, const float* x, float* dx, c
   if (bn_u == nullptr) { set_error("ms_style_bwd_actbwd: bn_u is required"); return MS_ERR_INVALID; }
   if (HW % 4 != 0) { set_error("ms_style_bwd_actbwd: H*W must be a multiple of 4 (the partial count is fixed by ms_style_bwd_actbwd_parts)"); return MS_ERR_INVALID; }
   return style_bwd_impl(dy, x, dx, mu, sig, coefA, gamma_std, beta_std, lmda, perm, d_gamma, d_beta, d_lmda, B, C, HW, ws, ws_bytes, bn_u, bn_coef4, bn_part, act_slope, stream);
+}
+
+// ms_style_bwd / ms_style_bwd_actbwd of a layer that sits directly in front of a 1x1 head (+ sigmoid): the layer's incoming gradient dy = ms_head_bwd(g, out, w)
+// is never written - this launch forms it from g [B,K,HW], out [B,K,HW] (the head's sigmoid output; NULL: no sigmoid) and w [K][C] while it streams.
+// bn_u / bn_coef4 / bn_part may be NULL (no activation backward); dx may be NULL.
+extern "C" int ms_style_bwd_head(const float* head_g, const float* head_out, const float* head_w, int K, const float* x, float* dx, const float* mu, const float* sig,
+                                 const float* coefA, const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
+                                 float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes,
+                                 const float* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream) {
+  const HeadSrc hd{head_g, head_out, head_w, K};
+  return style_bwd_impl(nullptr, x, dx, mu, sig, coefA, gamma_std, beta_std, lmda, perm, d_gamma, d_beta, d_lmda, B, C, HW, ws, ws_bytes, bn_u, bn_coef4, bn_part, act_slope, stream, &hd);
 }
 
 // ---- bf16 activation storage -----------------------------------------------------------------------------------------------

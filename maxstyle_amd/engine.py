@@ -334,6 +334,7 @@ class InnerLoopEngine:
         # the tail of a step as ONE launch (ms_step_tail: the layers' gradient reductions + Adam + the cross-entropy sum + the step counter; was six
         # ~4.8 us launches); MS_FUSE_TAIL=0 is the A/B switch (bit-identical results)
         self.fuse_tail = os.environ.get("MS_FUSE_TAIL", "1") != "0"
+        self.fuse_head_bwd = os.environ.get("MS_FUSE_HEAD_BWD", "1") != "0"     # ms_style_bwd_head: layer 4's backward forms the head's input gradient itself
         # cross-workgroup finalize (`_xfin` entry points): the BatchNorm coefficients a launch consumes are derived INSIDE that launch (one wave per channel,
         # published through tagged granules) instead of by an ms_bn_finalize launch in front of it.  Needs every workgroup of a launch co-resident: not with
         # shared_device.  MS_XFIN=0 is the A/B switch (bit-identical results).
@@ -1036,7 +1037,8 @@ class InnerLoopEngine:
         self.buf[f"st{i}.x"] = x
         return y
 
-    def style_bwd(self, i, dy, need_dx):
+    def style_bwd(self, i, dy, need_dx, head=None):
+        """head = (g, out, w, K): the layer sits directly in front of the 1x1 head; dy is formed inside the pass (ms_style_bwd_head), never materialised."""
         s = self.styles[i]
         x = self.buf.get(f"st{i}.x")
         B, C = x.shape[:2]
@@ -1046,13 +1048,20 @@ class InnerLoopEngine:
         ws = self.buf[f"st{i}.ws"]
         go = (lambda nm: 0) if self._defer_layer(i, B, C, HW) else (lambda nm: self.flat_g.data_ptr() + 4 * s.off[nm][0])
         po = lambda nm: self.flat_p.data_ptr() + 4 * s.off[nm][0]
+        if head is not None:
+            hg, ho, hw, K = head
+            check(lib.ms_style_bwd_head(hg.data_ptr(), ho.data_ptr(), hw.data_ptr(), K, x.data_ptr(), 0 if dx is None else dx.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                                        stats[2].data_ptr(), std[0].data_ptr(), std[1].data_ptr(), po("lmda") if s.mix_style else 0, s.perm.data_ptr() if s.mix_style else 0,
+                                        go("gamma_noise") if s.use_noise else 0, go("beta_noise") if s.use_noise else 0, go("lmda") if s.mix_style else 0,
+                                        B, C, HW, ws.data_ptr(), ws.numel(), 0, 0, 0, 1.0, self._st()), f"ms_style_bwd_head:{i}")
+            return dx
         check(self.L("ms_style_bwd")(dy.data_ptr(), x.data_ptr(), 0 if dx is None else dx.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
                                std[0].data_ptr(), std[1].data_ptr(), po("lmda") if s.mix_style else 0, s.perm.data_ptr() if s.mix_style else 0,
                                go("gamma_noise") if s.use_noise else 0, go("beta_noise") if s.use_noise else 0, go("lmda") if s.mix_style else 0,
                                B, C, HW, ws.data_ptr(), ws.numel(), self._st()), f"ms_style_bwd:{i}")
         return dx
 
-    def style_bwd_actbwd(self, i, dy, pfx):
+    def style_bwd_actbwd(self, i, dy, pfx, head=None):
         """style_bwd of layer i whose input is the output of residual block `pfx`: the block's output-activation backward (mask + BatchNorm-backward sums)
         happens in the same pass (ms_style_bwd_actbwd) -> (masked gradient, bcoef4) = the `pre` argument of res_bwd."""
         s = self.styles[i]
@@ -1068,10 +1077,17 @@ class InnerLoopEngine:
         part = self.t(pfx + ".bw2.spart", C, nparts, 2)
         go = (lambda nm: 0) if self._defer_layer(i, B, C, HW) else (lambda nm: self.flat_g.data_ptr() + 4 * s.off[nm][0])
         po = lambda nm: self.flat_p.data_ptr() + 4 * s.off[nm][0]
-        check(self.L("ms_style_bwd_actbwd")(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
-                                      std[0].data_ptr(), std[1].data_ptr(), po("lmda") if s.mix_style else 0, s.perm.data_ptr() if s.mix_style else 0,
-                                      go("gamma_noise") if s.use_noise else 0, go("beta_noise") if s.use_noise else 0, go("lmda") if s.mix_style else 0,
-                                      B, C, HW, ws.data_ptr(), ws.numel(), u.data_ptr(), coef.data_ptr(), part.data_ptr(), LEAKY, self._st()), f"ms_style_bwd_actbwd:{i}")
+        if head is not None:
+            hg, ho, hw, K = head
+            check(lib.ms_style_bwd_head(hg.data_ptr(), ho.data_ptr(), hw.data_ptr(), K, x.data_ptr(), dx.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+                                        std[0].data_ptr(), std[1].data_ptr(), po("lmda") if s.mix_style else 0, s.perm.data_ptr() if s.mix_style else 0,
+                                        go("gamma_noise") if s.use_noise else 0, go("beta_noise") if s.use_noise else 0, go("lmda") if s.mix_style else 0,
+                                        B, C, HW, ws.data_ptr(), ws.numel(), u.data_ptr(), coef.data_ptr(), part.data_ptr(), LEAKY, self._st()), f"ms_style_bwd_head:{i}")
+        else:
+            check(self.L("ms_style_bwd_actbwd")(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+                                          std[0].data_ptr(), std[1].data_ptr(), po("lmda") if s.mix_style else 0, s.perm.data_ptr() if s.mix_style else 0,
+                                          go("gamma_noise") if s.use_noise else 0, go("beta_noise") if s.use_noise else 0, go("lmda") if s.mix_style else 0,
+                                          B, C, HW, ws.data_ptr(), ws.numel(), u.data_ptr(), coef.data_ptr(), part.data_ptr(), LEAKY, self._st()), f"ms_style_bwd_actbwd:{i}")
         bc = self.t(pfx + ".bw2.bcoef", C, 4)
         check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(B * HW), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + pfx)
         return dx, bc
@@ -1190,18 +1206,26 @@ class InnerLoopEngine:
         x = self.buf["d.head_in"]
         N, C, H, W = x.shape
         K = d["head.w"].shape[0]
-        dh = self.a("d.dh", N, C, H, W)
-        check(self.L("ms_head_bwd")(g.data_ptr(), self.buf["d.image"].data_ptr(), d["head.w"].data_ptr(), dh.data_ptr(), N, C, K, H * W, 1, self._st()), "ms_head_bwd")
-        g = dh
+        # layer 4 sits directly in front of the head: its backward forms the head's input gradient itself (ms_style_bwd_head) - ms_head_bwd's launch and
+        # the write + read of a [N,C,H,W] tensor disappear (MS_FUSE_HEAD_BWD=0 is the A/B switch, bit-identical)
+        head = None
+        if self.fuse_head_bwd and not self.bf16 and 4 in self.layers and not self._is_identity(4, x.shape) and (H * W) % 4 == 0 and N * C <= 65535 and K <= 4:
+            head = (g, self.buf["d.image"], d["head.w"], K)
+            g = None
+        else:
+            dh = self.a("d.dh", N, C, H, W)
+            check(self.L("ms_head_bwd")(g.data_ptr(), self.buf["d.image"].data_ptr(), d["head.w"].data_ptr(), dh.data_ptr(), N, C, K, H * W, 1, self._st()), "ms_head_bwd")
+            g = dh
         for i in range(4, 0, -1):
             pre = None
             if i in self.layers and not self._is_identity(i, self.buf[f"d.u{i}.out"].shape):
                 x = self.buf[f"d.u{i}.out"]
+                hd = head if i == 4 else None
                 if first < i and self.fuse_act_bwd and self.fuse_style_actbwd and not self.bn_eval and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[0] * x.shape[1] <= 65535:
-                    pre = self.style_bwd_actbwd(i, g, f"d.u{i}")      # the block's output-activation backward rides on the layer's backward pass
+                    pre = self.style_bwd_actbwd(i, g, f"d.u{i}", head=hd)      # the block's output-activation backward rides on the layer's backward pass
                     g = None
                 else:
-                    g = self.style_bwd(i, g, need_dx=(first < i))
+                    g = self.style_bwd(i, g, need_dx=(first < i), head=hd)
                 if first == i:
                     return
             g = self.res_bwd(f"d.u{i}", d, f"u{i}", g, self._dec_kind(), need_dx=True, pre=pre)

@@ -246,3 +246,32 @@ def test_cross_workgroup_finalize_is_bit_identical(dev, monkeypatch, case):
     assert outs[0][1].keys() == outs[1][1].keys() and len(outs[0][1]) >= 9
     for k in outs[0][1]:
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
+@pytest.mark.parametrize("net,layers", [((4, 1, 4), [3, 4, 5]), ((4, 1, 4), [4, 5]), ((4, 1, 4), [4]), ((1, 3, 2), [3, 4, 5])])
+def test_head_backward_fused_into_layer4_is_bit_identical(dev, monkeypatch, net, layers):
+    """ms_style_bwd_head (layer 4's backward forms the gradient ms_head_bwd would have written for it - K = 1 and K = 3 image channels, with and without
+    dx / the block's activation backward) against the two launches: same bits after K = 3 steps."""
+    from maxstyle_amd import engine as E, synthetic as syn
+    spec_o = syn.NetSpec(*net)
+    W = syn.procedural_weights(spec_o, 0)
+    to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
+    B, size = 4, 64
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MS_FUSE_HEAD_BWD", flag)
+        spec = E.NetSpec(*net)
+        eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1)
+        assert eng.fuse_head_bwd == (flag == "1")
+        eng.set_nets(E.PackedNets(spec, to(W["image_encoder"]), to(W["segmentation_decoder"]), to(W["image_decoder"])))
+        img, lab = syn.synthetic_batch(B, size, net[1], net[2], seed=1234)
+        eng.configure_styles(layers, {i: E.StyleSlot(i, B, spec_o.channel_num[i]) for i in layers})
+        for i in layers:
+            st = syn.random_style_state(B, spec_o.channel_num[i], 7 + i)
+            eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
+        z_i = eng.encode_fwd(img.to(dev))[0].clone()
+        out = eng.run(z_i, lab.to(dev), 3, use_graph=True).clone()
+        outs.append((out, eng.losses(3).clone(), eng.flat_p.clone(), eng.flat_g.clone()))
+        assert ("d.dh" in eng.buf) == (flag == "0")
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
