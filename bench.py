@@ -562,6 +562,8 @@ def rccl_leg(dev, rank, run_one=None):
             torch.cuda.synchronize()
             out[tag]["ok_with_step_graph_replay_between"] = bool(torch.all(flat == (world + 1) / 2.0)) if world == 1 else bool(torch.isfinite(flat).all())
         del flat
+    if world == 1:
+        out["note"] = "world size 1: the collectives degenerate (nothing crosses a link); ms = latency of the RCCL call path, algbw is not a bandwidth"
     dist.barrier()
     return out
 
