@@ -239,6 +239,13 @@ int ms_conv1x1_bnres(const float* in, float* out, const float* w_packed, const f
  * and `err` are zero-filled ONCE by the caller and dedicated to this BatchNorm layer.  Needs every workgroup of the launch co-resident (an exclusive device).
  * Replaces, per residual block, the ms_bn_finalize launch behind its second conv (~4.8 us of launch boundary in a replayed graph). */
 size_t ms_xfin_gran_bytes(int C);
+/* The same for a consumer that needs the coefficients in its PROLOGUE: ms_conv2d with pro_mode 1 (kind 0: ms_bn_finalize folded in; tab = statistics table of the
+ * producing conv, p0 = gamma, p1 = beta, eps) or pro_mode 2 (kind 1: ms_bn_bwd_coefs folded in; tab = the float2 table of ms_conv2d_actbwd / ms_conv_subpix, p0 =
+ * the forward records {sc, sh, mean, invstd} [Cin][4], count = N*H*W).  The MFMA waves reduce and publish, then fill the launch's LDS coefficient table from
+ * the granules while the staging waves' first global loads are in flight.  coef4 [Cin][4] receives the records ms_bn_finalize / ms_bn_bwd_coefs would write. */
+int ms_conv2d_xfin(const float* in, const float* in2, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride,
+                   int fetch, int pro_mode, float slope, int epi_mode, float* stats, int kind, const float* tab, const float* p0, const float* p1, float eps, double count,
+                   float* coef4, void* gran, int* err, void* stream);
 int ms_conv1x1_bnres_xfin(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
                           const float* u, const float* stats, const float* gamma, const float* beta, float eps, float* coef4, void* gran, int* err,
                           float slope, int up2, void* stream);
@@ -443,6 +450,9 @@ int ms_act_bwd_reduce_bf16(const uint16_t* gin, const uint16_t* ref, const uint1
 int ms_pool2_sum_bf16(const uint16_t* in, uint16_t* out, int planes, int Ho, int Wo, int accumulate, void* stream);
 int ms_pool2_actbwd_bf16(const uint16_t* in, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
                          int N, int C, int Ho, int Wo, float slope, void* stream);
+int ms_conv2d_xfin_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride,
+                        int fetch, int pro_mode, float slope, int epi_mode, float* stats, int kind, const float* tab, const float* p0, const float* p1, float eps, double count,
+                        float* coef4, void* gran, int* err, void* stream);
 int ms_conv1x1_bnres_xfin_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
                                const uint16_t* u, const float* stats, const float* gamma, const float* beta, float eps, float* coef4, void* gran, int* err,
                                float slope, int up2, void* stream);

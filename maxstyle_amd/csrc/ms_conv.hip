@@ -77,7 +77,7 @@ struct MaskEpi { const float* u; const float* coef4; float slope; float* tab; in
 struct FinEpi { int* counter; float* out; const float* gamma; const float* beta; float eps; double count; };
 // cross-workgroup finalize (ConvArgs::xf_*): the statistics table of the BatchNorm whose coefficients this launch consumes, its affine parameters, the record
 // buffer the launch fills for later kernels, the granule table (2 x 8 bytes per channel, zero-filled once by the caller) and the error word
-struct XFin { const float* tab; const float* gamma; const float* beta; float eps; float* coef4; void* gran; int* err; int C; };
+struct XFin { const float* tab; const float* gamma; const float* beta; float eps; float* coef4; void* gran; int* err; int C; int kind = 0; double count = 0.0; };
 
 static int conv2d_impl(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                        int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
@@ -101,6 +101,14 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
       set_error("ms_conv2d_actbwd: needs u, coef4 and tab (16-byte aligned) and a plain epilogue"); return MS_ERR_INVALID;
     }
     epi_mode = 3;
+  }
+  const bool xf_pro = (xf != nullptr) && (mk == nullptr || mk->mode == 3);        // the `_xfin` launch feeds its PROLOGUE (not a residual tail's epilogue)
+  if (xf_pro) {
+    if (!((xf->kind == 0 && pro_mode == 1) || (xf->kind == 1 && pro_mode == 2 && xf->count > 0)) || pro_nstride != 0 || act_bf16 == 2) {
+      set_error("ms_conv2d_xfin: kind 0 with pro_mode 1 or kind 1 with pro_mode 2 (count > 0), per-channel coefficients, not the bf16-MFMA mode"); return MS_ERR_INVALID;
+    }
+    pro_a = pro_b = pro_c = xf->coef4;                                             // (not read by the launch: the table is filled from the granules)
+    pro_cstride = 4;
   }
   // pro_mode 3 = pro_mode 2 whose coefficients are derived in-kernel from the partial sums of ms_act_bwd_reduce:
   //   pro_a = partials [Cin][pro_nstride][2], pro_b = forward coefficient records (stride pro_cstride), pro_c = optional output [Cin][4]
@@ -140,12 +148,12 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
     a.fin_counter = fin->counter; a.fin_out = fin->out; a.fin_gamma = fin->gamma; a.fin_beta = fin->beta; a.fin_eps = fin->eps; a.fin_count = fin->count;
   }
   if (xf != nullptr) {
-    if (xf->tab == nullptr || xf->gamma == nullptr || xf->beta == nullptr || xf->coef4 == nullptr || xf->gran == nullptr || xf->err == nullptr || xf->C < 1 ||
+    if (xf->tab == nullptr || xf->gamma == nullptr || (xf->kind == 0 && xf->beta == nullptr) || xf->coef4 == nullptr || xf->gran == nullptr || xf->err == nullptr || xf->C < 1 ||
         !aligned16(xf->tab) || !aligned16(xf->coef4) || (reinterpret_cast<uintptr_t>(xf->gran) & 7u) != 0) {
       set_error("ms_conv*_xfin: statistics table, gamma, beta, coef4 (16-byte aligned), granule table (8-byte aligned) and the error word are required"); return MS_ERR_INVALID;
     }
     a.xf_tab = xf->tab; a.xf_gamma = xf->gamma; a.xf_beta = xf->beta; a.xf_eps = xf->eps; a.xf_coef = xf->coef4;
-    a.xf_gran = reinterpret_cast<conv_u64_t*>(xf->gran); a.xf_err = xf->err; a.xf_C = xf->C;
+    a.xf_gran = reinterpret_cast<conv_u64_t*>(xf->gran); a.xf_err = xf->err; a.xf_C = xf->C; a.xf_kind = xf->kind; a.xf_count = xf->count;
   }
   if (a.Hout < 1 || a.Wout < 1) { set_error("ms_conv2d: empty output"); return MS_ERR_INVALID; }
   if ((long)N > 65535) { set_error("ms_conv2d: batch too large for gridDim.z"); return MS_ERR_INVALID; }
@@ -222,7 +230,7 @@ extern "C" int ms_conv1x1_bnres(const float* in, float* out, const float* w_pack
   return conv2d_impl(in, nullptr, out, w_packed, bias, N, Cin, Hs, Ws, Cout, 1, 1, 0, 0, nullptr, nullptr, nullptr, 0, 1, 1.0f, 0, nullptr, &mk, nullptr, stream);
 }
 
-extern "C" size_t ms_xfin_gran_bytes(int C) { return (size_t)C * 2 * kXfinRep * sizeof(conv_u64_t); }
+extern "C" size_t ms_xfin_gran_bytes(int C) { return (size_t)C * kXfinNG * kXfinRep * sizeof(conv_u64_t); }
 
 // ms_bn_finalize + ms_conv1x1_bnres in ONE launch: the BatchNorm coefficients of u's layer are derived inside this launch from the statistics table `stats`
 // the conv that produced u wrote (one wave per channel, published to the waves that need them; see ConvArgs::xf_*), and stored to coef4 for later kernels.
@@ -242,6 +250,29 @@ extern "C" int ms_conv1x1_bnres_xfin_bf16(const uint16_t* in, uint16_t* out, con
   const XFin xf{stats, gamma, beta, eps, coef4, gran, err, Cout};
   return conv2d_impl(reinterpret_cast<const float*>(in), nullptr, reinterpret_cast<float*>(out), w_packed, bias, N, Cin, Hs, Ws, Cout, 1, 1, 0, 0, nullptr, nullptr, nullptr, 0, 1, 1.0f,
                      0, nullptr, &mk, nullptr, stream, 1, &xf);
+}
+
+// ms_bn_finalize (kind 0, pro_mode 1) or ms_bn_bwd_coefs on a conv-epilogue table (kind 1, pro_mode 2) + the ms_conv2d that consumes the coefficients in its
+// PROLOGUE, in one launch.  kind 0: tab = statistics table of the producing conv, p0 = gamma, p1 = beta, eps; kind 1: tab = the table of ms_conv2d_actbwd /
+// ms_conv_subpix (float2 records with header), p0 = the forward records {sc, sh, mean, invstd} [Cin][4], count = N*H*W.  coef4 [Cin][4] receives the records.
+static int conv2d_xfin_impl(const float* in, const float* in2, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride,
+                            int fetch, int pro_mode, float slope, int epi_mode, float* stats, int kind, const float* tab, const float* p0, const float* p1, float eps, double count,
+                            float* coef4, void* gran, int* err, void* stream, int act_bf16) {
+  XFin xf{tab, p0, p1, eps, coef4, gran, err, Cin};
+  xf.kind = kind; xf.count = count;
+  return conv2d_impl(in, in2, out, w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, nullptr, nullptr, nullptr, 0, 4, slope, epi_mode, stats, nullptr, nullptr, stream,
+                     act_bf16, &xf);
+}
+extern "C" int ms_conv2d_xfin(const float* in, const float* in2, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride,
+                              int fetch, int pro_mode, float slope, int epi_mode, float* stats, int kind, const float* tab, const float* p0, const float* p1, float eps, double count,
+                              float* coef4, void* gran, int* err, void* stream) {
+  return conv2d_xfin_impl(in, in2, out, w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, slope, epi_mode, stats, kind, tab, p0, p1, eps, count, coef4, gran, err, stream, 0);
+}
+extern "C" int ms_conv2d_xfin_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride,
+                                   int fetch, int pro_mode, float slope, int epi_mode, float* stats, int kind, const float* tab, const float* p0, const float* p1, float eps, double count,
+                                   float* coef4, void* gran, int* err, void* stream) {
+  return conv2d_xfin_impl(reinterpret_cast<const float*>(in), reinterpret_cast<const float*>(in2), reinterpret_cast<float*>(out), w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch,
+                          pro_mode, slope, epi_mode, stats, kind, tab, p0, p1, eps, count, coef4, gran, err, stream, 1);
 }
 
 // ---- `_bf16` twins: the activation tensors (in, in2, out, u) hold bf16 bit patterns; weights, bias, coefficients, statistics and tables are fp32 as before.

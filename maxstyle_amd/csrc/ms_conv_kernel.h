@@ -57,6 +57,7 @@ struct ConvArgs {
   // stores the record to xf_coef (for later kernels) and publishes {tag = epoch | scale}, {tag | shift} as two 8-byte granules in xf_gran with agent-scope
   // stores; every consumer of a channel polls its granules (bounded spin; *xf_err on time-out).  See xfin_* below.
   const float* xf_tab; const float* xf_gamma; const float* xf_beta; float xf_eps; float* xf_coef; conv_u64_t* xf_gran; int* xf_err; int xf_C;
+  int xf_kind; double xf_count;     // kind 0: BatchNorm statistics -> {scale, shift, mean, invstd}; kind 1: BatchNorm-backward sums (+ xf_gamma = forward records, xf_count = N*H*W) -> {al, be, de, 0}
 };
 
 typedef unsigned long long conv_u64;
@@ -87,55 +88,83 @@ __device__ inline double shfl_xor_d(double v, int off) {
 
 // ---- cross-workgroup finalize (see ConvArgs::xf_*) ------------------------------------------------------------------------------------------------
 constexpr unsigned kXfinSpin = 1u << 18;
-constexpr int kXfinRep = 64;
+constexpr int kXfinRep = 64;        // replicas of every granule (one per lane of the publishing wave: one coalesced store); a reader takes replica (workgroup & 63)
+constexpr int kXfinNG = 4;          // granules per channel: kind 0 {scale, shift, -, -}, kind 1 {al, be, de, -}
 __device__ inline double xf_wave_sum_d(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += shfl_xor_d(v, off);
   return v;
 }
-__device__ inline unsigned xfin_tag(const ConvArgs& a) { return __float_as_uint(reinterpret_cast<const float4*>(a.xf_tab)[0].y); }
-// One full wave, channel c: bn_finalize_kernel's arithmetic (ms_conv.hip), same order -> the same bits; record to xf_coef, (scale, shift) published.
-__device__ inline void xfin_reduce_publish(const ConvArgs& a, int c, unsigned tag) {
+__device__ inline conv_u64_t* xfin_slot(const ConvArgs& a, int c, int g, int rep) { return a.xf_gran + ((size_t)c * kXfinNG + g) * kXfinRep + rep; }
+// header of the producing conv's table: {slots in use, launch epoch}; float4 records (statistics, kind 0) or float2 records (BatchNorm-backward sums, kind 1)
+__device__ inline void xfin_header(const ConvArgs& a, unsigned& tag, int& nparts) {
+  const float2 h = *reinterpret_cast<const float2*>(a.xf_tab);
+  nparts = (int)h.x; tag = __float_as_uint(h.y);
+}
+__device__ inline void xfin_publish(const ConvArgs& a, int c, unsigned tag, float v0, float v1, float v2, int nv) {
+  // (first version: ONE copy per granule - at 16 channels every lane of 512 workgroups polled the same two cache lines; the replicas cost one coalesced
+  //  512-byte store per granule; profiles/r03_experiments.txt)
   const int lane = threadIdx.x & 63;
-  const float4* tab = reinterpret_cast<const float4*>(a.xf_tab);
-  const int nparts = (int)tab[0].x;
-  const float4* part = tab + 1 + (size_t)c * kStatSlots;
-  double sn = 0.0, sm = 0.0, sq = 0.0;
-  for (int i = lane; i < nparts; i += 64) {
-    const float4 q = part[i];
-    const double n = (double)q.x, mu = (double)q.y;
-    sn += n; sm += n * mu; sq += (double)q.z + n * mu * mu;
+  v0 = __shfl(v0, 0, 64); v1 = __shfl(v1, 0, 64); v2 = __shfl(v2, 0, 64);
+  __hip_atomic_store(xfin_slot(a, c, 0, lane), ((conv_u64_t)tag << 32) | (conv_u64_t)__float_as_uint(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(xfin_slot(a, c, 1, lane), ((conv_u64_t)tag << 32) | (conv_u64_t)__float_as_uint(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (nv > 2) __hip_atomic_store(xfin_slot(a, c, 2, lane), ((conv_u64_t)tag << 32) | (conv_u64_t)__float_as_uint(v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One full wave, channel c.  kind 0: bn_finalize_kernel's arithmetic (ms_conv.hip); kind 1: bn_bwd_coefs_kernel's (ms_elem.hip) - same order, the same bits.
+// The record goes to xf_coef (for later kernels), the values a consumer of THIS launch needs are published.
+__device__ inline void xfin_reduce_publish(const ConvArgs& a, int c, unsigned tag, int nparts) {
+  const int lane = threadIdx.x & 63;
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+  if (a.xf_kind == 0) {
+    const float4* part = reinterpret_cast<const float4*>(a.xf_tab) + 1 + (size_t)c * kStatSlots;
+    double sn = 0.0, sm = 0.0, sq = 0.0;
+    for (int i = lane; i < nparts; i += 64) {
+      const float4 q = part[i];
+      const double n = (double)q.x, mu = (double)q.y;
+      sn += n; sm += n * mu; sq += (double)q.z + n * mu * mu;
+    }
+    sn = xf_wave_sum_d(sn); sm = xf_wave_sum_d(sm); sq = xf_wave_sum_d(sq);
+    if (lane == 0) {
+      const double mean = sm / sn;
+      const double var = fmax((sq - sm * mean) / sn, 0.0);
+      const float invstd = (float)(1.0 / sqrt(var + (double)a.xf_eps));
+      const float sc = a.xf_gamma[c] * invstd;
+      const float sh = a.xf_beta[c] - (float)mean * sc;
+      reinterpret_cast<float4*>(a.xf_coef)[c] = make_float4(sc, sh, (float)mean, invstd);
+      p0 = sc; p1 = sh;
+    }
+    xfin_publish(a, c, tag, p0, p1, 0.f, 2);
+  } else {
+    const float2* row = reinterpret_cast<const float2*>(a.xf_tab) + 1 + (size_t)c * kStatSlots;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = lane; i < nparts; i += 64) { const float2 q = row[i]; s1 += (double)q.x; s2 += (double)q.y; }
+    s1 = xf_wave_sum_d(s1); s2 = xf_wave_sum_d(s2);
+    if (lane == 0) {
+      const float4 cf = reinterpret_cast<const float4*>(a.xf_gamma)[c];           // kind 1: xf_gamma = the forward records {sc, sh, mean, invstd}
+      const double mean = cf.z, invstd = cf.w, sc = cf.x;
+      const double c1 = s1 / a.xf_count;
+      const double c2 = s2 * invstd / a.xf_count;
+      const double be = -sc * c2 * invstd;
+      p0 = (float)sc; p1 = (float)be; p2 = (float)(-sc * c1 - be * mean);
+      reinterpret_cast<float4*>(a.xf_coef)[c] = make_float4(p0, p1, p2, 0.f);
+    }
+    xfin_publish(a, c, tag, p0, p1, p2, 3);
   }
-  sn = xf_wave_sum_d(sn); sm = xf_wave_sum_d(sm); sq = xf_wave_sum_d(sq);
-  float psc = 0.f, psh = 0.f;
-  if (lane == 0) {
-    const double mean = sm / sn;
-    const double var = fmax((sq - sm * mean) / sn, 0.0);
-    const float invstd = (float)(1.0 / sqrt(var + (double)a.xf_eps));
-    const float sc = a.xf_gamma[c] * invstd;
-    const float sh = a.xf_beta[c] - (float)mean * sc;
-    reinterpret_cast<float4*>(a.xf_coef)[c] = make_float4(sc, sh, (float)mean, invstd);
-    psc = sc; psh = sh;
-  }
-  // kXfinRep replicas of each granule, one per lane (ONE coalesced 512-byte store per granule): a reader takes the replica of its workgroup, so an address is
-  // polled by grid/64 workgroups instead of all of them.  (First version: one copy - at 16 channels every lane of 512 workgroups polled the same two cache
-  // lines and the launch at 256x256 got 11 us SLOWER: single-address throughput of the memory side, not latency; profiles/r03_experiments.txt.)
-  psc = __shfl(psc, 0, 64); psh = __shfl(psh, 0, 64);
-  __hip_atomic_store(a.xf_gran + (size_t)(2 * c) * kXfinRep + lane, ((conv_u64_t)tag << 32) | (conv_u64_t)__float_as_uint(psc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(a.xf_gran + (size_t)(2 * c + 1) * kXfinRep + lane, ((conv_u64_t)tag << 32) | (conv_u64_t)__float_as_uint(psh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // The MFMA waves of the launch share the channels out: wave w of workgroup b (HARDWARE block index, not the XCD-permuted vb) reduces channels 4*b + w, ...
 // Workgroups are dispatched in block-index order, so the publishers are the first ones on the chip: a resident workgroup never waits for one that is
 // not - also when the grid does not fit the chip at once (found by the bounded spin: the 64-channel-tile 1x1 kernel needs 205 VGPRs, one workgroup per
-// CU, and with publishers numbered by vb half of them sat behind their own pollers).
-__device__ inline void xfin_produce(const ConvArgs& a, unsigned tag) {
+// CU, and with publishers numbered by vb half of them sat behind their own pollers).  Returns whether this wave published anything.
+__device__ inline bool xfin_produce(const ConvArgs& a, unsigned tag, int nparts) {
   const int wave = threadIdx.x >> 6;
-  for (int c = 4 * (int)blockIdx.x + wave; c < a.xf_C; c += 4 * (int)gridDim.x) xfin_reduce_publish(a, c, tag);
+  bool any = false;
+  for (int c = 4 * (int)blockIdx.x + wave; c < a.xf_C; c += 4 * (int)gridDim.x) { xfin_reduce_publish(a, c, tag, nparts); any = true; }
+  return any;
 }
-// both granules of a channel per round trip (each half validates itself by its tag, so a torn pair is simply retried); rep = the workgroup's replica
+// both granules of a channel per round trip (each validates itself by its tag, so a torn pair is simply retried); rep = the workgroup's replica
 __device__ inline void xfin_peek(const ConvArgs& a, int c, int rep, conv_u64_t (&g)[2]) {
-  g[0] = __hip_atomic_load(a.xf_gran + (size_t)(2 * c) * kXfinRep + rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  g[1] = __hip_atomic_load(a.xf_gran + (size_t)(2 * c + 1) * kXfinRep + rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  g[0] = __hip_atomic_load(xfin_slot(a, c, 0, rep), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  g[1] = __hip_atomic_load(xfin_slot(a, c, 1, rep), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ inline float2 xfin_poll(const ConvArgs& a, int c, int rep, unsigned tag, conv_u64_t (&g)[2]) {      // g: an earlier peek (issued long before this call)
   for (unsigned spins = 0;; ++spins) {
@@ -144,6 +173,30 @@ __device__ inline float2 xfin_poll(const ConvArgs& a, int c, int rep, unsigned t
     if (spins > kXfinSpin) { __hip_atomic_store(a.xf_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return make_float2(0.f, 0.f); }
     __builtin_amdgcn_s_sleep(8);
     xfin_peek(a, c, rep, g);
+  }
+}
+// PROLOGUE consumers (pro_mode 1 / 2 with xf_tab): `nthreads` threads (the MFMA waves, tid = 0..nthreads-1) fill the launch's LDS coefficient table - one float4
+// {a, b, c, 0} per input channel, `ntab` entries, (d0, d1, 0) beyond Cin - from the published granules: NV = 2 (BatchNorm apply) or 3 (BatchNorm backward).
+template <int NV>
+__device__ inline void xfin_fill(const ConvArgs& a, float* cf_lds, int ntab, unsigned tag, int rep, int tid, int nthreads, float d0, float d1) {
+  for (int c = tid; c < ntab; c += nthreads) {
+    float v[3] = {d0, d1, 0.f};
+    if (c < a.Cin) {
+      conv_u64_t g[3];
+      for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { g[i] = __hip_atomic_load(xfin_slot(a, c, i, rep), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) ok = ok && ((unsigned)(g[i] >> 32) == tag);
+        if (ok) break;
+        if (spins > kXfinSpin) { __hip_atomic_store(a.xf_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); g[0] = g[1] = g[2] = 0; break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = __uint_as_float((unsigned)(g[i] & 0xFFFFFFFFull));
+    }
+    reinterpret_cast<float4*>(cf_lds)[c] = make_float4(v[0], v[1], v[2], 0.f);
   }
 }
 
@@ -342,7 +395,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   }
   // per-channel prologue coefficients are constant for the whole launch: stage them once (per-plane mode reads global memory)
   // (pro_mode 3, bw_parts > 0: the consumer waves derive the coefficients below while the producer waves already fetch the first chunk)
-  if (a.bw_parts == 0 && a.pro_mode != 0 && a.pro_nstride == 0) {
+  if (a.bw_parts == 0 && a.pro_mode != 0 && a.pro_nstride == 0 && a.xf_tab == nullptr) {
     for (int c = threadIdx.x; c < a.cin_pad; c += 512) {
       float ca = 1.f, cb_ = 0.f, cc = 0.f;
       if (c < a.Cin) { ca = a.pro_a[c * a.pro_cstride]; cb_ = a.pro_b[c * a.pro_cstride]; if (a.pro_mode == 2) cc = a.pro_c[c * a.pro_cstride]; }
@@ -659,9 +712,18 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   unsigned xf_tag = 0u;
   conv_u64_t xf_pre[NT][2];                            // the lane's granules, peeked at the start of the last chunk of the first item: landed by the epilogue
   bool xf_pending = false;                             // epi_mode 4 / 5 with xf_tab: (scale, shift) of this lane's channels are polled before the first epilogue
+  int xf_nparts = 0;
+  const bool xf_epi = (a.xf_tab != nullptr) && (a.epi_mode == 4 || a.epi_mode == 5);      // the coefficients feed this launch's EPILOGUE (residual tail)
   if (a.xf_tab != nullptr) {
-    xf_tag = xfin_tag(a);
-    xf_pending = (a.epi_mode == 4 || a.epi_mode == 5);
+    xfin_header(a, xf_tag, xf_nparts);
+    xf_pending = xf_epi;
+    if (!xf_epi) {
+      // the coefficients feed this launch's PROLOGUE: they must be in LDS before the staging waves store their first chunk (barrier #0).  The staging waves
+      // have issued that chunk's global loads already; the MFMA waves reduce their channels, then fill the table from the published granules.
+      if (!xfin_produce(a, xf_tag, xf_nparts)) __builtin_amdgcn_s_sleep(30);               // (~1 us: a first poll before any publisher can be done is a wasted round trip)
+      if (a.pro_mode == 2) xfin_fill<3>(a, cf_lds, a.cin_pad, xf_tag, vb & (kXfinRep - 1), threadIdx.x, 256, 1.f, 0.f);
+      else xfin_fill<2>(a, cf_lds, a.cin_pad, xf_tag, vb & (kXfinRep - 1), threadIdx.x, 256, 1.f, 0.f);
+    }
   }
   // (no s_setprio here: the STAGING waves get the priority - measured 290.7 -> 295.2 steps/s against the opposite choice; a staging wave that
   //  loses issue arbitration to back-to-back MFMAs is what the MFMA waves end up waiting for at the barrier)       // the MFMA-issuing wave wins issue arbitration against the staging wave of its SIMD
@@ -985,7 +1047,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   // the reducing waves of a cross-workgroup finalize work HERE, while the staging waves of their workgroup wait for the first chunk's global loads anyway:
   // in front of barrier #0 the ~4.5 us of cold table loads + publish delayed the whole workgroup's pipeline, and with a static work split the launch ends
   // with its slowest workgroup (measured: +3.9 us per launch, profiles/r03_experiments.txt)
-  if (a.xf_tab != nullptr) xfin_produce(a, xf_tag);
+  if (xf_epi) xfin_produce(a, xf_tag, xf_nparts);
   lds_barrier();                                      // barrier #1: chunk 0 is in buffer 0
   for (int p = 0; p < T; ++p) {
     const int c0 = chunk * CK;

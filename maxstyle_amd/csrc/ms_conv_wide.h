@@ -120,13 +120,18 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     for (int i = threadIdx.x; i < 2 * BUF; i += 512) smem[i] = 0.f;
     if constexpr (PRO == 0) __syncthreads();
   }
+  // cross-workgroup finalize (`_xfin`, ms_conv_kernel.h): the table is filled by the MFMA waves from granules published inside this launch - in front of
+  // barrier #0, while the staging waves already have their first chunk's global loads in flight (they read their coefficients behind that barrier)
+  const bool xf_pro = (PRO != 0) && (a.xf_tab != nullptr);
   if constexpr (PRO != 0) {
-    for (int c = threadIdx.x; c < nchunks * CK; c += 512) {
-      float4 cf = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < a.Cin) { cf.x = a.pro_a[c * a.pro_cstride]; cf.y = a.pro_b[c * a.pro_cstride]; if constexpr (PRO == 2) cf.z = a.pro_c[c * a.pro_cstride]; }
-      reinterpret_cast<float4*>(cf_lds)[c] = cf;
+    if (!xf_pro) {
+      for (int c = threadIdx.x; c < nchunks * CK; c += 512) {
+        float4 cf = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < a.Cin) { cf.x = a.pro_a[c * a.pro_cstride]; cf.y = a.pro_b[c * a.pro_cstride]; if constexpr (PRO == 2) cf.z = a.pro_c[c * a.pro_cstride]; }
+        reinterpret_cast<float4*>(cf_lds)[c] = cf;
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 
   if (a.stagger > 0) {
@@ -266,7 +271,25 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         }
       }
     };
-    auto load_chunk = [&](int n, int co0, int c0, bool load_w) {
+    auto load_coefs = [&](int c0) {
+      if constexpr (PRO != 0) {
+        // the chunk's per-channel coefficients: one ds_read_b128 per item (zero beyond Cin)
+        const float4* cf_c0 = reinterpret_cast<const float4*>(cf_lds) + c0;
+#pragma unroll
+        for (int j = 0; j < NQI; ++j) {
+          const float4 cf = cf_c0[q_cf[j]];
+          ca[j] = cf.x; cb_[j] = cf.y;
+          if constexpr (PRO == 2) cc[j] = cf.z;
+        }
+#pragma unroll
+        for (int j = 0; j < NHI; ++j) {
+          const float4 cf = cf_c0[h_cf[j]];
+          hca[j] = cf.x; hcb[j] = cf.y;
+          if constexpr (PRO == 2) hcc[j] = cf.z;
+        }
+      }
+    };
+    auto load_chunk = [&](int n, int co0, int c0, bool load_w, bool coefs = true) {
       // buffer addressing: resource base = image n, biased back (scalar arithmetic); soffset = chunk + tile origin (scalar); voffset = the hoisted item offset:
       // `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen` - no vector address arithmetic per chunk (the host checks Cin*plane*4 < 2^31)
       const ptrdiff_t img_off = ((ptrdiff_t)n * a.Cin * plane - bias) * AB;                  // bytes
@@ -287,22 +310,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       }
       if (a.dbg & 2) { qm = 0; hm = 0; }                // timing-only: every lane reads the tile origin
       if (l_edge) load_data(r1, r2, soff, qm, hm, std::true_type{}); else load_data(r1, r2, soff, qm, hm, std::false_type{});
-      if constexpr (PRO != 0) {
-        // the chunk's per-channel coefficients: one ds_read_b128 per item (zero beyond Cin)
-        const float4* cf_c0 = reinterpret_cast<const float4*>(cf_lds) + c0;
-#pragma unroll
-        for (int j = 0; j < NQI; ++j) {
-          const float4 cf = cf_c0[q_cf[j]];
-          ca[j] = cf.x; cb_[j] = cf.y;
-          if constexpr (PRO == 2) cc[j] = cf.z;
-        }
-#pragma unroll
-        for (int j = 0; j < NHI; ++j) {
-          const float4 cf = cf_c0[h_cf[j]];
-          hca[j] = cf.x; hcb[j] = cf.y;
-          if constexpr (PRO == 2) hcc[j] = cf.z;
-        }
-      }
+      if (coefs) load_coefs(c0);
       have_w = load_w;
       if constexpr (WIN) {
         if (load_w && tid < G::W_ITEMS) {
@@ -416,8 +424,9 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     int item = vb, chunk = 0, n, tile, cb, tile_set = -1;
     decode(item, n, tile, cb);
     set_tile(tile); tile_set = tile;
-    load_chunk(n, cb * COUT_TILE, 0, true);
-    lds_barrier();                                    // barrier #0 (matched by the consumers)
+    load_chunk(n, cb * COUT_TILE, 0, true, !xf_pro);
+    lds_barrier();                                    // barrier #0 (matched by the consumers); `_xfin`: the coefficient table is complete behind it
+    if (xf_pro) load_coefs(0);
 #ifdef MS_CONV_TRACE_BUILD
     const bool tr = (a.trace != nullptr) && (blockIdx.x == 0) && (threadIdx.x == 256);
 #else
@@ -1120,6 +1129,14 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   int item = vb, n, tile, cb;
   decode(item, n, tile, cb);
   load_bias(cb * COUT_TILE);
+  if constexpr (PRO != 0) {
+    if (xf_pro) {
+      unsigned xf_tag; int xf_nparts;
+      xfin_header(a, xf_tag, xf_nparts);
+      if (!xfin_produce(a, xf_tag, xf_nparts)) __builtin_amdgcn_s_sleep(30);
+      xfin_fill<(PRO == 2 ? 3 : 2)>(a, cf_lds, nchunks * CK, xf_tag, vb & (kXfinRep - 1), threadIdx.x, 256, 0.f, 0.f);
+    }
+  }
   lds_barrier();                                      // barrier #0
   lds_barrier();                                      // barrier #1: chunk 0 is in buffer 0
 #ifdef MS_CONV_TRACE_BUILD

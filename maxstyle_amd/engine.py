@@ -243,6 +243,15 @@ class PackedNets:
         return d
 
 
+class XfCoef:
+    """BatchNorm coefficients that no launch has produced yet: the conv that consumes them in its prologue derives them itself (`ms_conv2d_xfin`).
+    kind 0: ms_bn_finalize folded in (tab = statistics table, p0 / p1 = gamma / beta); kind 1: ms_bn_bwd_coefs folded in (tab = the float2 table of a conv
+    epilogue, p0 = forward records, count = N*H*W).  `coef` is the record buffer the consumer fills for later kernels."""
+
+    def __init__(self, kind, tab, p0, p1, count, coef, gran, err, C):
+        self.kind, self.tab, self.p0, self.p1, self.count, self.coef, self.gran, self.err, self.C = kind, tab, p0, p1, count, coef, gran, err, C
+
+
 class StyleSlot:
     """Device state of one applied MaxStyle layer inside the engine (views into the flat parameter buffers)."""
 
@@ -339,6 +348,8 @@ class InnerLoopEngine:
         # published through tagged granules) instead of by an ms_bn_finalize launch in front of it.  Needs every workgroup of a launch co-resident: not with
         # shared_device.  MS_XFIN=0 is the A/B switch (bit-identical results).
         self.xfin = os.environ.get("MS_XFIN", "1") != "0" and type(self) is InnerLoopEngine
+        # ... also for the consumers that need the coefficients in their PROLOGUE (ms_conv2d_xfin: conv2 of a block; MS_XFIN_PRO=0 is the A/B switch)
+        self.xfin_pro = self.xfin and os.environ.get("MS_XFIN_PRO", "1") != "0"
         self._tail = None              # while a step defers its tail: {"layers": [...], "ce": (ws, nparts, scale) | None}
         if self.bf16:
             # kernels without a bf16 twin: the "last workgroup finalises" experiments and the weight-gradient kernels (TrainEngine is fp32 only)
@@ -365,7 +376,7 @@ class InnerLoopEngine:
         """An ACTIVATION tensor (conv inputs / outputs, gradients, images): fp32, or bf16 storage in bf16 mode (everything else stays fp32)."""
         return self.t(name, *shape, dtype=self.act_dtype)
 
-    _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd",
+    _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv2d_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd",
                              "ms_head_fwd", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_style_fwd", "ms_style_bwd", "ms_style_ws_bytes",
                              "ms_conv_subpix", "ms_conv3x3_small_cout", "ms_style_bwd_actbwd", "ms_style_bwd_actbwd_parts"))
 
@@ -534,7 +545,12 @@ class InnerLoopEngine:
             st = self.t(name + ".stats", cout * parts + 1, 4)
         pm, pa, pb, pc, in2, pn = 0, 0, 0, 0, None, 0
         slope = 1.0
-        if act is not None:
+        xf = None
+        if act is not None and isinstance(act[0], XfCoef):
+            pm, xf, slope = 1, act[0], act[1]
+        elif bnbwd is not None and isinstance(bnbwd[0], XfCoef):
+            pm, xf, in2 = 2, bnbwd[0], bnbwd[1]
+        elif act is not None:
             pm = 1
             pa, pb, _ = ops.coef_ptrs(act[0])
             slope = act[1]
@@ -555,6 +571,13 @@ class InnerLoopEngine:
                                     BN_EPS, coef.data_ptr(), self._counter(name).data_ptr(), self._st()), "ms_conv2d_fin:" + name)
             return out, ("fused", coef), parts
         wf = ops.FETCH_WINOGRAD if (self.winograd and fetch == 0 and ks == 3 and stride == 1) else 0
+        if xf is not None:
+            assert xf.C == Cin, "the pending coefficients belong to this conv's input channels"
+            check(self.L("ms_conv2d_xfin")(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                     N, Cin, Hs, Ws, cout, ks, stride, fetch | wf, pm, slope, epi, 0 if st is None else st.data_ptr(),
+                                     xf.kind, xf.tab.data_ptr(), xf.p0.data_ptr(), 0 if xf.p1 is None else xf.p1.data_ptr(), BN_EPS, xf.count,
+                                     xf.coef.data_ptr(), xf.gran.data_ptr(), xf.err.data_ptr(), self._st()), "ms_conv2d_xfin:" + name)
+            return out, st, parts
         check(self.L("ms_conv2d")(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
                             N, Cin, Hs, Ws, cout, ks, stride, fetch | wf, pm, pa, pb, pc, pn, 4, slope, epi, 0 if st is None else st.data_ptr(), self._st()),
               "ms_conv2d:" + name)
@@ -582,6 +605,23 @@ class InnerLoopEngine:
         """The consumer launch may derive its BatchNorm coefficients itself (`_xfin`): batch statistics, a statistics TABLE in hand (not the pair the
         'last workgroup finalises' experiment returns), an exclusive device."""
         return self.xfin and not self.bn_eval and not self.shared_device and not isinstance(st, tuple) and self.bn_observer is None
+
+    def bn_fin_or_pending(self, name, st, parts, bn: BNW, consumer_ok=True):
+        """bn_fin, or - when the consumer is a conv that can derive the coefficients in its own launch (`_xfin`, prologue kind) - the pending record."""
+        if consumer_ok and self.xfin_pro and self._xfin_ok(st):
+            coef, gran, err = self._xfin_bufs(name, bn.gamma.numel())
+            return XfCoef(0, st, bn.gamma, bn.beta, 0.0, coef, gran, err, bn.gamma.numel())
+        return self.bn_fin(name, st, parts, bn)
+
+    def coef_tensor(self, cf):
+        """The coefficient records as a tensor: a pending XfCoef whose consumer cannot derive them itself is finalised by its own launch after all."""
+        if not isinstance(cf, XfCoef):
+            return cf
+        if cf.kind == 0:
+            check(lib.ms_bn_finalize(cf.tab.data_ptr(), lib.ms_conv_stats_parts(1, 1, 1), cf.p0.data_ptr(), cf.p1.data_ptr(), BN_EPS, cf.coef.data_ptr(), cf.C, self._st()), "ms_bn_finalize")
+        else:
+            check(lib.ms_bn_bwd_coefs(cf.tab.data_ptr(), 0, cf.p0.data_ptr(), cf.count, cf.coef.data_ptr(), cf.C, self._st()), "ms_bn_bwd_coefs")
+        return cf.coef
 
     def _xfin_bufs(self, name, C):
         """(coefficient records [C,4], granule table, error word) of one BatchNorm layer; granules and error word zero-filled once."""
@@ -672,6 +712,11 @@ class InnerLoopEngine:
                 self.buf[bw_name + ".bcoef_eval"] = bc
             bc[:, 0].copy_(coef[:, 0])
             return out, bc
+        if self.xfin_pro and self._xfin_ok(tab):
+            # the BatchNorm-backward coefficients are derived by the conv that consumes them in its prologue (ms_conv2d_xfin kind 1): no ms_bn_bwd_coefs launch
+            bc, gran, err = self._xfin_bufs(bw_name + ".b", C)
+            self.buf[bw_name + ".bcoef"] = bc
+            return out, XfCoef(1, tab, coef, None, float(N * H * W), bc, gran, err, C)
         bc = self.t(bw_name + ".bcoef", C, 4)
         check(lib.ms_bn_bwd_coefs(tab.data_ptr(), 0, coef.data_ptr(), float(N * H * W), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + bw_name)
         return out, bc
@@ -755,7 +800,7 @@ class InnerLoopEngine:
             u1, st1, p1 = self.conv_ups2(pfx + ".u1", src, c0, fin=net[key + ".bn1"])
         else:
             u1, st1, p1 = self.conv(pfx + ".u1", src, c0, fetch=fetch, stats=True, fin=net[key + ".bn1"])
-        cf1 = self.bn_fin(pfx + ".bn1", st1, p1, net[key + ".bn1"])
+        cf1 = self.bn_fin_or_pending(pfx + ".bn1", st1, p1, net[key + ".bn1"])
         u2, st2, p2 = self.conv(pfx + ".u2", u1, c3, act=(cf1, LEAKY), stats=True, fin=net[key + ".bn4"])
         xf2 = fused_tail and self._xfin_ok(st2)
         cf2 = None if xf2 else self.bn_fin(pfx + ".bn4", st2, p2, net[key + ".bn4"])
@@ -858,10 +903,10 @@ class InnerLoopEngine:
         """MyEncoder.forward + code_decoupler (encoder_decoder.py:469-482, 673-680) in BN batch-stat mode."""
         e = self.nets.enc
         ua, st, p = self.conv("e.inc.ua", image, e["inc0"], stats=True, fin=e["inc1"])
-        cfa = self.bn_fin("e.inc.bn1", st, p, e["inc1"])
+        cfa = self.bn_fin_or_pending("e.inc.bn1", st, p, e["inc1"])
         ub, st, p = self.conv("e.inc.ub", ua, e["inc3"], act=(cfa, LEAKY), stats=True, fin=e["inc4"])
-        cfb = self.bn_fin("e.inc.bn4", st, p, e["inc4"])
         lazy = self.lazy_inc and self.enc_mix is None
+        cfb = self.bn_fin_or_pending("e.inc.bn4", st, p, e["inc4"], consumer_ok=lazy)      # lazy: consumed by down1's stride-2 conv (prologue)
         self._inc_lazy = lazy
         if lazy:
             h, x_act = ub, (cfb, LEAKY)
@@ -880,7 +925,7 @@ class InnerLoopEngine:
         """Dual_Branch_Encoder.filter_code (encoder_decoder.py:673-675): z_s = code_decoupler(z_i) = ReLU(BN(conv3x3(LeakyReLU(BN(conv3x3(z_i))))))."""
         e = self.nets.enc
         u1, st, p = self.conv("e.cd.u1", z_i, e["cd0"], stats=True, fin=e["cd1"])
-        cf1 = self.bn_fin("e.cd.bn1", st, p, e["cd1"])
+        cf1 = self.bn_fin_or_pending("e.cd.bn1", st, p, e["cd1"])
         u2, st, p = self.conv("e.cd.u2", u1, e["cd3"], act=(cf1, LEAKY), stats=True, fin=e["cd4"])
         cf2 = self.bn_fin("e.cd.bn4", st, p, e["cd4"])
         return self.bn_act("e.z_s", u2, cf2, None, 0, 0.0)
@@ -907,7 +952,7 @@ class InnerLoopEngine:
         if self.small_cout and lib.ms_conv3x3_small_cout_ok(c0.cin, W) and not isinstance(bc, tuple):
             # the gradient that reaches the image has 1 (3) channels: vector-ALU kernel instead of a 16-column MFMA tile (ms_conv_small.hip)
             dimg = self.a("e.dimage", N, c0.cin, H, W)
-            pa, pb, pc = ops.coef_ptrs(bc)
+            pa, pb, pc = ops.coef_ptrs(self.coef_tensor(bc))      # (not a conv_mfma / conv_wide launch: the coefficients get their own launch here)
             check(self.L("ms_conv3x3_small_cout")(g.data_ptr(), b["e.inc.ua"].data_ptr(), dimg.data_ptr(), c0.dwp.data_ptr(), N, Cg, H, W, c0.cin, 2, pa, pb, pc, 4, self._st()),
                   "ms_conv3x3_small_cout:e.dimage")
             return dimg
