@@ -208,20 +208,23 @@ def test_loop_all_six_layers(golden_dir, dev):
 
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_free_running_loop(golden_dir, dev, use_graph):
-    """run(K): eager and HIP-graph replay agree bit for bit; vs the reference trajectory only loosely (parity_util)."""
+    """run(K): eager and HIP-graph replay agree bit for bit; against the reference's fp64 trajectory the free-running K = 5 result is bounded by the
+    reference's OWN fp32-vs-fp64 distance (round 3: was a constant 3e-2 / 1e-2; measured 1.1x / 0.7x, profiles/r03_parity_report.txt)."""
     from oracle import maxstyle_oracle as orc
-    g = np.load(os.path.join(golden_dir, "loop_c2small.npz"))
+    g = np.load(os.path.join(golden_dir, "loop_c2small.npz")); g64 = np.load(os.path.join(golden_dir, "loop_c2small_f64.npz"))
     eng, W, img, lab, styles = build_engine(dev, orc.NetSpec(4, 1, 4), 4, 64, [3, 4, 5])
     z_i = torch.from_numpy(g["z_i"]).to(dev)
     out = eng.run(z_i, lab.to(dev), 5, use_graph=use_graph).clone()
     if use_graph:
         assert eng._graph is not None, getattr(eng, "graph_error", "graph capture failed")
-    losses = eng.losses(5).cpu().numpy()
-    np.testing.assert_allclose(losses, g["losses"], rtol=1e-2)
-    assert rel(out, g["image"]) < 3e-2
+    losses = eng.losses(5).cpu().numpy().astype(np.float64)
+    noise_img = rel(g["image"], g64["image"])
+    noise_loss = float(np.max(np.abs(g["losses"] - g64["losses"]) / np.abs(g64["losses"])))
+    assert rel(out, g64["image"]) < max(3.0 * noise_img, 1e-3), (rel(out, g64["image"]), noise_img)
+    assert float(np.max(np.abs(losses - g64["losses"]) / np.abs(g64["losses"]))) < max(3.0 * noise_loss, 1e-4)
     eng.seg_loss(out, lab.to(dev), need_grad=False, need_logits=True)
     pred = eng.buf["s.logits"].argmax(1).cpu()
-    np.testing.assert_allclose(orc.dice_per_class(pred, lab, 4), g["final_dice"], atol=2e-2)
+    np.testing.assert_allclose(orc.dice_per_class(pred, lab, 4), g["final_dice"], atol=5e-3)
     if use_graph:
         eng2, *_ = build_engine(dev, orc.NetSpec(4, 1, 4), 4, 64, [3, 4, 5])
         ref = eng2.run(z_i, lab.to(dev), 5, use_graph=False)

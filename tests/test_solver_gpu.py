@@ -56,7 +56,9 @@ def injector(styles, dev):
 
 def test_generate_max_style_image_vs_reference(golden_dir, dev):
     from oracle import maxstyle_oracle as orc
-    g = np.load(os.path.join(golden_dir, "loop_c2small.npz"))
+    g = np.load(os.path.join(golden_dir, "loop_c2small.npz")); g64 = np.load(os.path.join(golden_dir, "loop_c2small_f64.npz"))
+    noise_img = rel(g["image"], g64["image"])                  # the reference's own fp32-vs-fp64 distance after the free-running K = 5 loop
+    noise_loss = float(np.max(np.abs(g["losses"] - g64["losses"]) / np.abs(g64["losses"])))
     spec = orc.NetSpec(4, 1, 4)
     S, W = make_solver(dev, spec)
     img, lab = orc.synthetic_batch(4, 64, 1, 4, 1234)
@@ -73,8 +75,12 @@ def test_generate_max_style_image_vs_reference(golden_dir, dev):
     # K = 5 free-running (loose: see tests/parity_util.py), twice: the second call replays the captured HIP graph
     for rep in range(2):
         out = S.generate_max_style_image(z_i, layers, spec.channel_num, p=1.5, n_iter=5, lr=0.1, reference_image=img.to(dev), reference_segmentation=lab.to(dev))
-        np.testing.assert_allclose(S.last_losses.cpu().numpy(), g["losses"], rtol=1e-2)
-        assert rel(out, g["image"]) < 3e-2
+        ls = S.last_losses.cpu().numpy().astype(np.float64)
+        # Here the code comes from the GPU encoder (3e-5 from the reference's, asserted above), and on these RANDOMLY initialised networks the free-running loop
+        # amplifies that: measured 1.5e-3 on the losses (from the reference's own code the same loop is 2e-5 / 1.1x the reference's noise from its fp64 run:
+        # tests/test_engine_gpu.py::test_free_running_loop).  The bars are 3x what was measured, no longer 1e-2 / 3e-2.
+        assert float(np.max(np.abs(ls - g64["losses"]) / np.abs(g64["losses"]))) < max(3.0 * noise_loss, 5e-3)
+        assert rel(out, g64["image"]) < max(3.0 * noise_img, 1.5e-2), (rel(out, g64["image"]), noise_img)
         if rep == 0:
             first = out.clone()
         else:
@@ -86,7 +92,7 @@ def test_generate_max_style_image_vs_reference(golden_dir, dev):
     # Dice parity of the segmentation of the stylised image
     _, zs2 = S.encode_image(out, disable_track_bn_stats=True)
     logits = S.decoder_inference(decoder=S.model["segmentation_decoder"], latent_code=zs2, disable_track_bn_stats=True)
-    np.testing.assert_allclose(orc.dice_per_class(logits.argmax(1).cpu(), lab, 4), g["final_dice"], atol=2e-2)
+    np.testing.assert_allclose(orc.dice_per_class(logits.argmax(1).cpu(), lab, 4), g["final_dice"], atol=5e-3)
 
 
 def test_generate_max_style_image_eval_mode(golden_dir, dev):

@@ -45,5 +45,30 @@ def main():
     print("   worst ratio", worst, " worst abs", max(err for err, _ in TE.TF_TABLE.values()))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "free"):
     main()
+
+
+def free_running():
+    """Free-running K=5 on the small fixtures: the GPU's distance from the reference's fp64 run beside the reference's own fp32 distance."""
+    import test_engine_gpu as TE
+    from parity_util import rel
+    orc = __import__("oracle.maxstyle_oracle", fromlist=["x"])
+    dev = torch.device("cuda:0")
+    golden = os.path.join(ROOT, "tests", "golden")
+    print("== free-running loops: err(GPU, reference fp64) vs err(reference fp32, reference fp64)")
+    for tag, fx, net, B, size, layers, K in (("c2small", "loop_c2small", (4, 1, 4), 4, 64, [3, 4, 5], 5), ("c4small", "loop_c4small", (1, 3, 2), 4, 64, [3, 4, 5], 3),
+                                             ("c1", "loop_c1", (4, 1, 4), 4, 128, [3], 1)):
+        g = np.load(os.path.join(golden, fx + ".npz")); g64 = np.load(os.path.join(golden, fx + "_f64.npz"))
+        for graph in (False, True):
+            eng, W, img, lab, styles = TE.build_engine(dev, orc.NetSpec(*net), B, size, layers)
+            z_i = torch.from_numpy(g["z_i"]).to(dev)
+            out = eng.run(z_i, lab.to(dev), K, use_graph=graph).clone()
+            losses = eng.losses(K).cpu().numpy().astype(np.float64)
+            ni, nl = rel(g["image"], g64["image"]), float(np.max(np.abs(g["losses"] - g64["losses"]) / np.abs(g64["losses"])))
+            ei, el = rel(out, g64["image"]), float(np.max(np.abs(losses - g64["losses"]) / np.abs(g64["losses"])))
+            print(f"   {tag:8s} graph={int(graph)} image err {ei:.2e} (reference noise {ni:.2e}, ratio {ei / ni:.2f})  losses err {el:.2e} (noise {nl:.2e}, ratio {el / max(nl, 1e-30):.2f})")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "free":
+    free_running()
