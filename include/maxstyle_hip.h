@@ -26,6 +26,7 @@ int ms_version(void);
 const char* ms_last_error(void);
 /* bit of the `fetch` argument of the convolution entry points: the caller accepts the Winograd form for this call (see ms_conv2d) */
 #define MS_FETCH_WINOGRAD 0x100
+#define MS_FETCH_X3 0x200
 /* Compute units of the current device (hipDeviceProp.multiProcessorCount, read once per device): every persistent grid and every
  * co-residency bound of the library is sized from it (a partitioned or CU-masked device reports fewer than MI355X's 256). */
 int ms_num_cus(void);
@@ -174,6 +175,9 @@ int ms_step_tail(const ms_tail_layer* layers, int n_layers, const double* ce_par
  *             w_packed[ky*ks+kx][ci][co] = weight[co][ci][ky][kx]           (gemm_cols = Cout, or 4*Cout for epi_mode 2)
  *   ks/stride (3,1) (3,2) (1,1) (2,2); padding = 1 for ks 3 else 0
  *   fetch     0 normal | 1 nearest x2 up-sampling fused into the load | 2 zero-insertion x2 (stride-2 data-gradient)
+ *             | MS_FETCH_X3 (bit 9, with fetch 0): the caller ACCEPTS the three-way bf16 split form of a 3x3 stride-1 convolution where it is built (rows >= 64 pixels,
+ *               channel count a multiple of 8): fp32 storage, operands split into three bf16 numbers, six leading products on v_mfma_f32_16x16x16_bf16 with fp32
+ *               accumulation - fp32-faithful (error against fp64 below an fp32 FMA chain's), not bit-identical to the fp32 forms; wins over MS_FETCH_WINOGRAD where both are set
  *             | MS_FETCH_WINOGRAD (bit 8, with fetch 0): the caller ACCEPTS the Winograd F(2x2,3x3) form of a 3x3 stride-1 convolution where it is built
  *             (fp32 or bf16 storage, Cin % 8 == 0, rows of >= 20 pixels with W % 4 == 0): 16 instead of 36 multiplications per 2x2 outputs, the same fp32
  *             matrix instruction.  On random data it is as close to fp64 as the direct form (2-4e-7 of the output range); on the networks'

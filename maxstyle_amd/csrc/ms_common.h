@@ -143,6 +143,13 @@ template <> struct ActIO<ms_bf16w32> : ActIO<ms_bf16> {};
 struct ms_f32w32 { float v; };
 template <> struct ActIO<ms_f32w32> : ActIO<float> {};
 
+// ms_f32x3: fp32 storage, fp32-FAITHFUL matrix arithmetic on the bf16 matrix cores: every operand of the contraction is split into three bf16 numbers
+// (hi + mid + lo = the fp32 value to 2^-24) and the six leading products hi*hi, mid*hi, hi*mid, lo*hi, hi*lo, mid*mid are accumulated in fp32 by
+// v_mfma_f32_16x16x16_bf16 - two products per instruction (the K = 16 of the instruction holds two splits of an 8-channel chunk).  Error against fp64
+// below that of an fp32 FMA chain (profiles/r03_experiments.txt, section 7).  Loads / stores are those of float.
+struct ms_f32x3 { float v; };
+template <> struct ActIO<ms_f32x3> : ActIO<float> {};
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -86,7 +86,8 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   if (N < 1 || Cin < 1 || Cout < 1 || Hs < 1 || Ws < 1) { set_error("ms_conv2d: invalid shape"); return MS_ERR_INVALID; }
   // bit 8 of `fetch` (MS_FETCH_WINOGRAD): the caller accepts the Winograd F(2x2,3x3) form for this call where it is built (see include/maxstyle_hip.h)
   const bool wino_ok = (fetch >= 0) && (fetch & MS_FETCH_WINOGRAD) != 0;
-  if (fetch >= 0) fetch &= ~MS_FETCH_WINOGRAD;
+  const bool x3_ok = (fetch >= 0) && (fetch & MS_FETCH_X3) != 0;               // bit 9: ... the three-way bf16 split form
+  if (fetch >= 0) fetch &= ~(MS_FETCH_WINOGRAD | MS_FETCH_X3);
   if (pro_mode < 0 || pro_mode > 3 || epi_mode < 0 || epi_mode > 2 || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
   // the activation helper computes max(v, v*slope): LeakyReLU / ReLU slopes only
   if ((pro_mode == 1 && !(slope >= 0.f && slope <= 1.f)) || (mk != nullptr && !(mk->slope >= 0.f && mk->slope <= 1.f))) { set_error("ms_conv2d: activation slope outside [0, 1]"); return MS_ERR_INVALID; }
@@ -139,6 +140,7 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (gemm_cols + 63) / 64 * 64;
   a.bw_parts = bw_parts; a.bw_count = (double)N * Hs * Ws; a.bw_out = bw_out;
   a.wino_ok = wino_ok ? 1 : 0;
+  a.x3_ok = x3_ok ? 1 : 0;
   a.act_bf16 = act_bf16;                  // 0 fp32 storage | 1 bf16 storage, fp32 matrix arithmetic | 2 bf16 storage, bf16 matrix arithmetic where built (`_bf16m`)
   a.pro_mode = pro_mode; a.pro_nstride = pro_nstride; a.pro_cstride = pro_cstride < 1 ? 1 : pro_cstride; a.slope = slope; a.epi_mode = epi_mode;
   if (mk != nullptr) { a.mk_u = mk->u; a.mk_coef = mk->coef4; a.mk_slope = mk->slope; a.mk_tab = mk->tab; }

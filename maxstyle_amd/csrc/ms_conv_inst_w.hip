@@ -42,7 +42,16 @@ static int wide_pro(const ConvArgs& a, hipStream_t st) {
   }
 }
 int conv_dispatch_wino(const ConvArgs& a, hipStream_t st);      // ms_conv_inst_wino.hip
+int conv_dispatch_x3(const ConvArgs& a, hipStream_t st);        // ms_conv_inst_x3.hip
+// three-way bf16 split mode (ms_conv_wide.h, AT = ms_f32x3): fp32 storage, rows of at least one 64-pixel tile, channel count a multiple of the 8-channel chunk
+static bool conv_x3_on(const ConvArgs& a) {
+  // MS_CONV_X3: 0 = never | 1 (default) = where the caller allows it (MS_FETCH_X3) | 2 = every eligible call (tools / tests)
+  static const int mode = getenv("MS_CONV_X3") ? atoi(getenv("MS_CONV_X3")) : 1;
+  if (mode == 0 || (mode == 1 && !a.x3_ok)) return false;
+  return a.act_bf16 == 0 && a.cin_pad % 8 == 0 && a.Cin == a.cin_pad && a.Wout >= 64;
+}
 int conv_dispatch_wide(const ConvArgs& a, int nt, hipStream_t st) {
+  if (conv_x3_on(a)) return conv_dispatch_x3(a, st);
   if ((a.Wout < 64 && a.act_bf16 != 2) || conv_wino_on(a)) return conv_dispatch_wino(a, st);      // (rows below 64 pixels: conv_wide_eligible admitted them for this form only)
   if (conv_wide_rows(a, nt >= 2 ? 2 : 1) == 8) return conv_dispatch_wide8(a, nt, st);
   return nt >= 2 ? wide_pro<2>(a, st) : wide_pro<1>(a, st);

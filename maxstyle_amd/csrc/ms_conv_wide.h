@@ -62,6 +62,30 @@ struct WideGeoBF {
   static constexpr int W_ITEMS = 9 * CK * (16 * NT / 4), NWI = (W_ITEMS + 255) / 256;
 };
 
+// Geometry of the three-way bf16 split mode (AT = ms_f32x3): the LDS layout of the bf16-MFMA mode (channel-quad interleaved 8-byte entries), SIX activation planes
+// per 8-channel chunk - plane p = 2*split + quad: hi(q0), hi(q1), mid(q0), mid(q1), lo(q0), lo(q1) - and THREE weight sets of 4 K-groups each, arranged so
+// that one instruction multiplies two splits at once (K group g of the instruction, A fragment x B fragment):
+//   MFMA 1: A1 = [hi0, hi1, mid0, mid1] x B1 = [hi0, hi1, hi0, hi1]    = hi*hi + mid*hi
+//   MFMA 2: A2 = [hi0, hi1, lo0,  lo1 ] x B2 = [mid0, mid1, hi0, hi1]  = hi*mid + lo*hi
+//   MFMA 3: A1                          x B3 = [lo0, lo1, mid0, mid1]  = hi*lo + mid*mid
+// A lane of K group k reads plane k for A1 and plane (k < 2 ? k : k + 2) for A2.  6 planes x 3264 B + 3 x 4608 B of weights = 33.4 KB per stage: two
+// workgroups per CU.  3 instructions of 8 cycles per (tap, 16 pixels, 8 channels, 16 output channels) against 2 x 32 cycles of v_mfma_f32_16x16x4_f32.
+template <int NT, int PRO>
+struct WideGeoX3 {
+  static_assert(NT == 1, "three-way split mode: one channel block per lane");
+  static constexpr int TH = 4, TW = 64, CK = 8, IH = TH + 2;
+  static constexpr int RSB = TW + 4;
+  static constexpr int GP = IH * RSB * 8;                          // bytes of one plane (3264)
+  static constexpr int A_BYTES = 6 * GP;
+  static constexpr int B_SET = 9 * 4 * 16 * NT * 8;                // one weight set: (tap, K group, output channel) entries of 8 bytes
+  static constexpr int B_BYTES = 3 * B_SET;
+  static constexpr int BUF = (A_BYTES + B_BYTES) / 4;
+  static constexpr int RS = RSB, PS = GP / 4, WS = 16;
+  static constexpr int Q_ITEMS = CK * IH * (TW / 4), H_ITEMS = CK * IH * 2;
+  static constexpr int NQI = (Q_ITEMS + 255) / 256, NHI = (H_ITEMS + 255) / 256;
+  static constexpr int W_ITEMS = 9 * CK * (16 * NT / 4), NWI = (W_ITEMS + 255) / 256;
+};
+
 // Geometry of the Winograd mode (AT = ms_f32w): F(2x2, 3x3), one channel block per lane.  The staged input tile is the fp32 one (same rows / columns / halo);
 // its plane stride is == 32 (mod 64 dwords) so that the 8-byte patch reads of the four K lanes groups of a wave fall on disjoint banks.  The weight region of a
 // stage holds the chunk's TRANSFORMED weights U = G g G^T as [16 positions][CK channels][16 output channels]: a lane's B fragment of position p and channel
@@ -89,12 +113,15 @@ static __device__ int g_cu_census[1024];
 template <int NT, int PRO, int R, bool AF, typename AT = float>
 __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const ConvArgs a) {
   constexpr bool BFM = std::is_same<AT, ms_bf16m>::value;         // bf16 matrix arithmetic (needs R == 1)
+  constexpr bool X3 = std::is_same<AT, ms_f32x3>::value;          // fp32 storage, three-way bf16 split on the bf16 matrix cores (needs R == 1, NT == 1, every chunk full)
+  constexpr bool BFL = BFM || X3;                                 // the bf16 LDS layout (8-byte channel-quad entries)
+  static_assert(!X3 || (R == 1 && NT == 1 && AF), "three-way split mode: 4-row tiles, one channel block per lane, channel count a multiple of the chunk");
   constexpr bool WIN = std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value ||       // Winograd F(2x2, 3x3) (needs R == 1, NT == 1, every chunk full)
                        std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value;      // ... on bf16 storage
   constexpr int WTW = (std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w32>::value) ? 32 : 64;
   constexpr int WHALVES = WTW / 32;                               // 32-pixel halves of a tile row = waves per tile row
   static_assert(!WIN || (R == 1 && NT == 1 && AF), "Winograd mode: 4-row tiles, one channel block per lane, channel count a multiple of the chunk");
-  using G = typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WIN, WideGeoW<PRO, WTW>, WideGeo<NT, PRO, R>>::type>::type;
+  using G = typename std::conditional<X3, WideGeoX3<(X3 ? NT : 1), PRO>, typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WIN, WideGeoW<PRO, WTW>, WideGeo<NT, PRO, R>>::type>::type>::type;
   using IO = ActIO<AT>;
   constexpr int AB = IO::kBytes;
   static_assert(!BFM || R == 1, "bf16 MFMA mode: 4-row tiles");
@@ -174,7 +201,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       if (it < G::Q_ITEMS) {
         const int f = it % (TW / 4), row = it / (TW / 4);
         const int r = row % IH, c = row / IH;
-        if constexpr (BFM) q_lds[j] = (c << 20) | ((((c >> 2) * IH + r) * G::RSB + 4 * f + 1) * 8 + (c & 3) * 2);      // BYTE address of the entry's channel slot
+        if constexpr (BFL) q_lds[j] = (c << 20) | ((((c >> 2) * IH + r) * G::RSB + 4 * f + 1) * 8 + (c & 3) * 2);      // BYTE address of the entry's channel slot (X3: in the `hi` planes)
         else q_lds[j] = (c << 20) | (c * PS + r * RS + 4 * f + 1);
         q_rc[j] = (r << 16) | (4 * f + 16);
         q_off[j] = (unsigned)AB * (unsigned)(c * plane + (r - 1) * a.Ws + 4 * f + bias);
@@ -190,7 +217,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         const int h = it & 1, row = it >> 1;
         const int r = row % IH, c = row / IH;
         const int col_rel = h ? TW : -1;
-        if constexpr (BFM) h_lds[j] = (c << 20) | ((((c >> 2) * IH + r) * G::RSB + col_rel + 1) * 8 + (c & 3) * 2);
+        if constexpr (BFL) h_lds[j] = (c << 20) | ((((c >> 2) * IH + r) * G::RSB + col_rel + 1) * 8 + (c & 3) * 2);
         else h_lds[j] = (c << 20) | (c * PS + r * RS + col_rel + 1);
         h_rc[j] = (r << 16) | (col_rel + 16);
         h_off[j] = (unsigned)AB * (unsigned)(c * plane + (r - 1) * a.Ws + col_rel + bias);
@@ -361,7 +388,20 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           if constexpr (PRO == 2) v[e] = ca[j] * v[e] + (cb_[j] * v2 + cc[j]);
           if constexpr (EDGE) v[e] = ((l_q_ok >> j) & 1u) ? v[e] : 0.f;          // zero padding pads the tensor AFTER the prologue
         }
-        if constexpr (BFM) {
+        if constexpr (X3) {
+          // three bf16 splits of every value (hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid)) into the hi / mid / lo planes of its channel quad
+          char* dst = reinterpret_cast<char*>(buf) + (q_lds[j] & 0xFFFFF);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint16_t hi = ms_to_bf16(v[e]);
+            const float r1 = v[e] - __uint_as_float((unsigned)hi << 16);
+            const uint16_t mid = ms_to_bf16(r1);
+            const uint16_t lo = ms_to_bf16(r1 - __uint_as_float((unsigned)mid << 16));
+            *reinterpret_cast<uint16_t*>(dst + 8 * e) = hi;
+            *reinterpret_cast<uint16_t*>(dst + 2 * G::GP + 8 * e) = mid;
+            *reinterpret_cast<uint16_t*>(dst + 4 * G::GP + 8 * e) = lo;
+          }
+        } else if constexpr (BFM) {
           // round to bf16 and scatter into the channel slot of the four pixels' entries (8 bytes apart)
           char* dst = reinterpret_cast<char*>(buf) + (q_lds[j] & 0xFFFFF);
 #pragma unroll
@@ -377,7 +417,16 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         float v = rh[j];
         if constexpr (PRO == 1) v = leaky(hca[j] * v + hcb[j], a.slope);
         if constexpr (PRO == 2) v = hca[j] * v + (hcb[j] * rh2[j] + hcc[j]);
-        if constexpr (BFM) *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(buf) + (h_lds[j] & 0xFFFFF)) = ms_to_bf16(((l_h_ok >> j) & 1u) ? v : 0.f);
+        if constexpr (X3) {
+          const float vv = ((l_h_ok >> j) & 1u) ? v : 0.f;
+          char* dst = reinterpret_cast<char*>(buf) + (h_lds[j] & 0xFFFFF);
+          const uint16_t hi = ms_to_bf16(vv);
+          const float r1 = vv - __uint_as_float((unsigned)hi << 16);
+          const uint16_t mid = ms_to_bf16(r1);
+          *reinterpret_cast<uint16_t*>(dst) = hi;
+          *reinterpret_cast<uint16_t*>(dst + 2 * G::GP) = mid;
+          *reinterpret_cast<uint16_t*>(dst + 4 * G::GP) = ms_to_bf16(r1 - __uint_as_float((unsigned)mid << 16));
+        } else if constexpr (BFM) *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(buf) + (h_lds[j] & 0xFFFFF)) = ms_to_bf16(((l_h_ok >> j) & 1u) ? v : 0.f);
         else buf[h_lds[j] & 0xFFFFF] = ((l_h_ok >> j) & 1u) ? v : 0.f;
       }
       if constexpr (WIN) {
@@ -405,7 +454,24 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           if (idx < G::W_ITEMS) {
             const int j4 = idx % (COUT_TILE / 4);
             const int row = idx / (COUT_TILE / 4);
-            if constexpr (BFM) {
+            if constexpr (X3) {
+              // the three weight sets (WideGeoX3): channel c = quad q, slot c & 3; hi -> B1 groups q and q+2, B2 group q+2; mid -> B2 group q, B3 group q+2; lo -> B3 group q
+              const int c = row % CK, tap = row / CK, q = c >> 2;
+              char* w0 = reinterpret_cast<char*>(buf) + G::A_BYTES + (c & 3) * 2;
+              auto ent = [&](int set, int g, int co) { return w0 + set * G::B_SET + ((tap * 4 + g) * COUT_TILE + co) * 8; };
+              const float wv[4] = {rw[j].x, rw[j].y, rw[j].z, rw[j].w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int co = j4 * 4 + e;
+                const uint16_t hi = ms_to_bf16(wv[e]);
+                const float r1 = wv[e] - __uint_as_float((unsigned)hi << 16);
+                const uint16_t mid = ms_to_bf16(r1);
+                const uint16_t lo = ms_to_bf16(r1 - __uint_as_float((unsigned)mid << 16));
+                *reinterpret_cast<uint16_t*>(ent(0, q, co)) = hi; *reinterpret_cast<uint16_t*>(ent(0, q + 2, co)) = hi; *reinterpret_cast<uint16_t*>(ent(1, q + 2, co)) = hi;
+                *reinterpret_cast<uint16_t*>(ent(1, q, co)) = mid; *reinterpret_cast<uint16_t*>(ent(2, q + 2, co)) = mid;
+                *reinterpret_cast<uint16_t*>(ent(2, q, co)) = lo;
+              }
+            } else if constexpr (BFM) {
               // entry (tap, g, cout) = channels 4g..4g+3 of one output channel: this item holds 4 output channels of ONE input channel
               const int c = row % CK, tap = row / CK;
               char* wb = reinterpret_cast<char*>(buf) + G::A_BYTES + ((tap * 4 + (c >> 2)) * COUT_TILE + j4 * 4) * 8 + (c & 3) * 2;
@@ -524,6 +590,44 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       }
     }
   };
+  // three-way split mode (WideGeoX3): per staged row st and kernel column kx, three instructions per pixel-in-quad i: A1 x B1, A2 x B2, A1 x B3
+  auto compute_x3 = [&](const float* buf, auto first_tag) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (X3) {
+      const int p1 = k, p2 = (k < 2) ? k : k + 2;                 // planes of this lane's K group: A1 = [hi0, hi1, mid0, mid1], A2 = [hi0, hi1, lo0, lo1]
+      const char* a1 = reinterpret_cast<const char*>(buf) + ((p1 * IH + wave) * G::RSB + 4 * m) * 8;
+      const char* a2 = reinterpret_cast<const char*>(buf) + ((p2 * IH + wave) * G::RSB + 4 * m) * 8;
+      const char* bb = reinterpret_cast<const char*>(buf) + G::A_BYTES + (k * COUT_TILE + m) * 8;
+#pragma unroll
+      for (int st = 0; st < 3; ++st) {
+        cu32x4_t w1[3], w2[3];
+        cu32x2_t b[3][3];                                         // [set][kx]
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          w1[q] = *reinterpret_cast<const cu32x4_t*>(a1 + st * G::RSB * 8 + 16 * q);
+          w2[q] = *reinterpret_cast<const cu32x4_t*>(a2 + st * G::RSB * 8 + 16 * q);
+        }
+#pragma unroll
+        for (int set = 0; set < 3; ++set)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) b[set][kx] = *reinterpret_cast<const cu32x2_t*>(bb + set * G::B_SET + ((st * 3 + kx) * 4 * COUT_TILE) * 8);
+        const unsigned* v1 = reinterpret_cast<const unsigned*>(&w1[0]);
+        const unsigned* v2 = reinterpret_cast<const unsigned*>(&w2[0]);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const cu32x2_t x1 = {v1[2 * (i + kx)], v1[2 * (i + kx) + 1]};
+            const cu32x2_t x2 = {v2[2 * (i + kx)], v2[2 * (i + kx) + 1]};
+            f32x4 c = (FIRST && st == 0 && kx == 0) ? zero4 : acc[0][i][0];
+            c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf4_t, x1), __builtin_bit_cast(bf4_t, b[2][kx]), c, 0, 0, 0);      // hi*lo + mid*mid (smallest first)
+            c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf4_t, x2), __builtin_bit_cast(bf4_t, b[1][kx]), c, 0, 0, 0);      // hi*mid + lo*hi
+            acc[0][i][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf4_t, x1), __builtin_bit_cast(bf4_t, b[0][kx]), c, 0, 0, 0);   // hi*hi + mid*hi
+          }
+      }
+    }
+  };
   // Winograd mode: wave = (tile row tr = wave >> 1: output rows 2tr, 2tr+1; half h = wave & 1: 32 pixels = 16 tiles of 2x2); MFMA M index = tile, N = output
   // channel, K = input channel.  Per 4-channel group: the lane's 4x4 input patch (tile m, channel 4cg+k) = 8 ds_read_b64, V = B^T d B in registers
   // (32 additions), 16 B fragments (one ds_read_b32 per position), 16 MFMAs - one per position, 16 independent accumulators.
@@ -587,6 +691,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     constexpr bool FIRST = decltype(first_tag)::value;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (BFM) { compute_bf(buf, first_tag); return; }
+    if constexpr (X3) { compute_x3(buf, first_tag); return; }
     if constexpr (WIN) { compute_w(buf, first_tag); return; }
     float win[2][6], bfr[3][3][NT];
     load_win(buf, 0, 0, win[0]);
@@ -1217,10 +1322,10 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 
 template <int NT, int PRO, int R, bool AF, typename AT>
 int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
-  using G = typename std::conditional<std::is_same<AT, ms_bf16m>::value, WideGeoBF<NT, PRO>,
+  using G = typename std::conditional<std::is_same<AT, ms_f32x3>::value, WideGeoX3<(std::is_same<AT, ms_f32x3>::value ? NT : 1), PRO>, typename std::conditional<std::is_same<AT, ms_bf16m>::value, WideGeoBF<NT, PRO>,
                                       typename std::conditional<std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_bf16w>::value, WideGeoW<PRO, 64>,
                                       typename std::conditional<std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w32>::value, WideGeoW<PRO, 32>,
-                                                                WideGeo<NT, PRO, R>>::type>::type>::type;
+                                                                WideGeo<NT, PRO, R>>::type>::type>::type>::type;
   const size_t cin_tab = (PRO != 0) ? (size_t)cdiv(a.cin_pad, G::CK) * G::CK : 0;              // coefficient table: one float4 per input channel of the padded chunks
   const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab) + ((std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value) ? 16 * 1024 : 0);      // Winograd mode: + the mask tensor's landing zone
   if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }

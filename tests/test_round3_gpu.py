@@ -276,3 +276,33 @@ def test_head_backward_fused_into_layer4_is_bit_identical(dev, monkeypatch, net,
         assert ("d.dh" in eng.buf) == (flag == "0")
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+def test_three_way_split_mode_vs_fp64(dev):
+    """MS_FETCH_X3 (ms_f32x3 mode of the wide conv kernel: operands split into three bf16 numbers, six leading products on v_mfma_f32_16x16x16_bf16, fp32
+    accumulation) is fp32-FAITHFUL: against fp64 it holds the bars of the fp32 forms (tests/test_wino_gpu.py) on every prologue / epilogue combination.
+    An experiment of round 3 (2x slower than the Winograd form: profiles/r03_experiments.txt section 8) - opt-in only, used by nothing."""
+    import torch.nn.functional as F
+    from maxstyle_amd import ops
+    rnd = lambda shape, seed, scale=1.0: torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+    err = lambda o, r: float((o.cpu().double() - r).abs().max() / r.abs().max())
+    for (N, Cin, Cout, H, W) in [(2, 16, 16, 64, 64), (1, 32, 48, 20, 192), (2, 64, 64, 64, 64), (1, 8, 33, 10, 100), (2, 16, 16, 6, 72)]:
+        x = rnd((N, Cin, H, W), 1) * 0.7 + 0.5; x2 = rnd((N, Cin, H, W), 2); w = rnd((Cout, Cin, 3, 3), 3, 0.1); b = rnd((Cout,), 4)
+        cf = rnd((Cin, 4), 5); cfd = cf.to(dev)
+        a, bb, cc = (cf[:, i].double().view(1, -1, 1, 1) for i in range(3))
+        wp = ops.pack_conv_weight(w.to(dev))
+        xd, x2d = x.to(dev), x2.to(dev)
+        stats, parts = ops.conv_stats_buffer(N, Cout, H, W, dev)
+        out = ops.conv2d(xd, wp, b.to(dev), Cout, 3, 1, fetch=ops.FETCH_X3, stats=stats)
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        assert err(out, ref) < 2e-6, (N, Cin, Cout, H, W)
+        direct = ops.conv2d(xd, wp, b.to(dev), Cout, 3, 1)
+        assert not torch.equal(out, direct), "the call must have taken the three-way split mode (not bit-identical to the fp32 chain)"
+        coef = ops.bn_finalize(stats, parts, torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)).cpu().double()
+        assert float((coef[:, 2] - ref.mean((0, 2, 3))).abs().max()) < 1e-6
+        pa, pb, pc = ops.coef_ptrs(cfd)
+        o1 = ops.conv2d(xd, wp, None, Cout, 3, 1, fetch=ops.FETCH_X3, pro_mode=1, pro_a=pa, pro_b=pb, pro_cstride=4, slope=0.2)
+        assert err(o1, F.conv2d(F.leaky_relu(a * x.double() + bb, 0.2), w.double(), None, padding=1)) < 3e-6
+        base = rnd((N, Cout, H, W), 6)
+        o2 = ops.conv2d(xd, wp, None, Cout, 3, 1, fetch=ops.FETCH_X3, pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=x2d, epi_mode=1, out=base.to(dev).clone())
+        assert err(o2, F.conv2d(a * x.double() + bb * x2.double() + cc, w.double(), None, padding=1) + base.double()) < 3e-6
