@@ -9,10 +9,10 @@ cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$R
 rm -rf $O; mkdir -p $O
 # 1. the bench under kernel-trace: per-kernel totals, the launch list of one inner step, the isolated runs bench.py prices
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-outer --steady-seconds 0 > $O/bench_under_rocprof.json 2> $O/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-outer --no-parity --no-secondary --no-rccl-selftest --steady-seconds 0 > $O/bench_under_rocprof.json 2> $O/trace.err
 python tools/prof_summary.py $O/trace $O/${R}_kernel_stats.txt > /dev/null
 # 2. config 4 (FCN_64, 16x3x320x320)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c4 -- python bench.py --config c4 --steps 4 --warmup 1 --no-cpu-baseline --no-outer --steady-seconds 0 > $O/bench_c4_under_rocprof.json 2> $O/trace_c4.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c4 -- python bench.py --config c4 --steps 4 --warmup 1 --no-cpu-baseline --no-outer --no-parity --no-secondary --no-rccl-selftest --steady-seconds 0 > $O/bench_c4_under_rocprof.json 2> $O/trace_c4.err
 python tools/prof_summary.py $O/trace_c4 $O/${R}_c4_kernel_stats.txt > /dev/null
 # 3. one trainer iteration (standard pass + inner loop + hard pass + backward + AdamW)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_train -- python tools/prof_train.py 6 > /dev/null 2> $O/trace_train.err
