@@ -349,7 +349,7 @@ class InnerLoopEngine:
         # shared_device.  MS_XFIN=0 is the A/B switch (bit-identical results).
         self.xfin = os.environ.get("MS_XFIN", "1") != "0" and type(self) is InnerLoopEngine
         # ... also for the consumers that need the coefficients in their PROLOGUE (ms_conv2d_xfin: conv2 of a block; MS_XFIN_PRO=0 is the A/B switch)
-        self.xfin_pro = self.xfin and os.environ.get("MS_XFIN_PRO", "1") != "0"
+        self.xfin_pro = self.xfin and os.environ.get("MS_XFIN_PRO", "1") != "0" and not self.mfma_bf16      # (the bf16-MFMA conv mode has no `_xfin` twin)
         self._tail = None              # while a step defers its tail: {"layers": [...], "ce": (ws, nparts, scale) | None}
         if self.bf16:
             # kernels without a bf16 twin: the "last workgroup finalises" experiments and the weight-gradient kernels (TrainEngine is fp32 only)
