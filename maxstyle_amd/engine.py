@@ -623,9 +623,9 @@ class InnerLoopEngine:
             check(lib.ms_bn_bwd_coefs(cf.tab.data_ptr(), 0, cf.p0.data_ptr(), cf.count, cf.coef.data_ptr(), cf.C, self._st()), "ms_bn_bwd_coefs")
         return cf.coef
 
-    def _xfin_bufs(self, name, C):
+    def _xfin_bufs(self, name, C, coef_name=None):
         """(coefficient records [C,4], granule table, error word) of one BatchNorm layer; granules and error word zero-filled once."""
-        coef = self.t(name + ".coef", C, 4)
+        coef = self.t(coef_name or (name + ".coef"), C, 4)
         gran = self.buf.get(name + ".gran")
         if gran is None or gran.numel() < lib.ms_xfin_gran_bytes(C):
             if gran is not None and self._any_graph():
@@ -714,8 +714,7 @@ class InnerLoopEngine:
             return out, bc
         if self.xfin_pro and self._xfin_ok(tab):
             # the BatchNorm-backward coefficients are derived by the conv that consumes them in its prologue (ms_conv2d_xfin kind 1): no ms_bn_bwd_coefs launch
-            bc, gran, err = self._xfin_bufs(bw_name + ".b", C)
-            self.buf[bw_name + ".bcoef"] = bc
+            bc, gran, err = self._xfin_bufs(bw_name + ".b", C, coef_name=bw_name + ".bcoef")
             return out, XfCoef(1, tab, coef, None, float(N * H * W), bc, gran, err, C)
         bc = self.t(bw_name + ".bcoef", C, 4)
         check(lib.ms_bn_bwd_coefs(tab.data_ptr(), 0, coef.data_ptr(), float(N * H * W), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + bw_name)
