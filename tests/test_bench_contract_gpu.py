@@ -32,3 +32,13 @@ def test_bench_line_contract():
     assert r["traffic"] is None or r["traffic"] > 0.5 * r["algorithmic_bytes"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == d["unit"] and isinstance(c["sample"], str)
+    # round 3: the driver-visible line also carries parity at the benchmarked size against the reference's own run (both conv forms), the secondary
+    # configurations and the RCCL self-test
+    for form in ("winograd", "direct"):
+        assert d["drift_full_size"][form]["ratio_to_reference_noise_max"] <= 2.0 and d["drift_full_size"][form]["ratio_to_reference_noise_rms"] <= 2.0
+        assert d["dice_parity"][form]["dice_max_abs_diff_vs_reference"] <= 1e-3 and d["dice_parity"][form]["labels_equal_to_reference"] >= 0.9999
+    sec = d["secondary"]
+    assert sec["winograd_off"]["steps_s"] > 0 and sec["c4"]["steps_s"] > 0 and sec["c5_bf16"]["steps_s"] > 0
+    assert "executed_mfma_frac" in sec["c4"]["roofline"] and sec["c4"]["roofline"]["form"].startswith("winograd")
+    assert "error" not in d["rccl"] and d["rccl"]["backend"] == "nccl" and d["rccl"]["fcn16_6MB"]["mean_ok"]
+    assert d["roofline"].get("traffic_source") is None or d["roofline"]["traffic_source"].startswith("profiles/")
