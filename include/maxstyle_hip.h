@@ -93,6 +93,12 @@ int ms_pool2_actbwd(const float* in, const float* add, float* out, const float* 
 /* ms_head_ce (segmentation head + cross entropy + backward to the head input h, custom_loss.py:1043-1078) whose dh is already multiplied by lrelu'(h) - h is the
  * output of the last residual block - and which writes the BatchNorm-backward sums of that block's last BatchNorm (raw input bn_u, record bn_coef4) to
  * bn_part [C][ms_head_ce_actbwd_parts(N,C,HW)][2]: replaces ms_head_ce + ms_act_bwd_reduce.  C <= 16 (parts() returns 0 otherwise: use the two calls). */
+/* ms_conv1x1_bnres (half-resolution skip) + ms_head_ce_actbwd in ONE pass over u: the output h = lrelu(bn(u) + skip[y/2][x/2]) of the segmentation decoder's last
+ * residual block (encoder_decoder.py:344-346; final_conv + cross_entropy_2D, custom_loss.py:1043-1078) is formed inside the head kernel and never written.
+ * u [N,C,H,W] the block's second conv output, coef4 its BatchNorm record {sc, sh, mean, invstd}, skip [N,C,H/2,W/2] the 1x1 skip conv (+ bias) at half
+ * resolution (plain ms_conv2d).  dh, bn_part, loss_out (may be NULL: ms_step_tail), ws as ms_head_ce_actbwd.  Same arithmetic, same order: bit-identical. */
+int ms_head_ce_tail(const float* u, const float* skip, const float* coef4, const float* w, const float* b, const int64_t* labels, float* dh, float* loss_out,
+                    const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, void* stream);
 int ms_head_ce_actbwd_parts(int N, int C, int HW);
 int ms_head_ce_actbwd(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* loss_out, const int* loss_slot_dev,
                       int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,
@@ -464,6 +470,8 @@ int ms_head_fwd_bf16(const uint16_t* h, const float* w, const float* b, uint16_t
 int ms_head_bwd_bf16(const uint16_t* dout, const uint16_t* out, const float* w, uint16_t* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
 int ms_head_ce_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* logits, float* loss_out,
                     const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream);
+int ms_head_ce_tail_bf16(const uint16_t* u, const uint16_t* skip, const float* coef4, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* loss_out,
+                         const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, void* stream);
 int ms_head_ce_actbwd_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* loss_out, const int* loss_slot_dev,
                            int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,
                            const uint16_t* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream);

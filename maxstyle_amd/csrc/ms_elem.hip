@@ -460,6 +460,114 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const void
   }
 }
 
+// ms_head_ce_tail: head_ce_actbwd_kernel<4> whose input h is not read but FORMED here - the output of the residual block in front of the head,
+// h = lrelu((sc*u + sh) + skip[y/2][x/2]) from the block's second conv output u, that BatchNorm's record and the 1x1 skip conv at half resolution
+// (ms_conv1x1_bnres's arithmetic, same order: the same bits).  The block output is never written; u is read ONCE for both halves of the item (h is consumed
+// channel by channel into the logits, only its sign - 64 bits per thread - survives to the backward half, so the 64 registers of u fit beside the rest).
+template <int K, typename AT = float>
+__global__ __launch_bounds__(kElemThreads) void head_ce_tail_kernel(const void* __restrict__ u, const void* __restrict__ skip, const float4* __restrict__ bn_coef,
+                                                                    const float* __restrict__ w, const float* __restrict__ b, const int64_t* __restrict__ labels,
+                                                                    void* __restrict__ dh, double* __restrict__ part, int HW, int W, float grad_scale,
+                                                                    float2* __restrict__ bn_part, float slope) {
+  using IO = ActIO<AT>;
+  constexpr int C = kHeadFuseC;             // compile-time channel count: no per-channel branches, the K*C weights arrive as wide scalar loads
+  // head weights, bias and the BatchNorm record are read through UNIFORM addresses (scalar loads): no LDS copy and no vector registers holding K*C weights
+  // across the item; every tensor access is a uniform per-(sample, channel) base + a 32-bit per-thread byte offset (global_load saddr form: no 64-bit
+  // per-channel address pairs in vector registers)
+  __shared__ double redd[16];
+  const int n = blockIdx.y;
+  const int HWl = HW >> 2, Wl = W >> 1;
+  const char* ub = reinterpret_cast<const char*>(u) + (size_t)n * C * HW * IO::kBytes;
+  const char* kb = reinterpret_cast<const char*>(skip) + (size_t)n * C * HWl * IO::kBytes;
+  char* db = reinterpret_cast<char*>(dh) + (size_t)n * C * HW * IO::kBytes;
+  const size_t pu = (size_t)HW * IO::kBytes, pk = (size_t)HWl * IO::kBytes;       // plane strides in bytes
+  double picked = 0.0;
+  float b1[C], b2[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { b1[c] = 0.f; b2[c] = 0.f; }
+  for (int i = (blockIdx.x * kElemThreads + threadIdx.x) * 4; i < HW; i += gridDim.x * kElemThreads * 4) {
+    const int y = i / W, x = i - y * W;                        // W % 4 == 0: the quad stays in one row; skip pixels (x/2, x/2 + 1) of row y/2
+    const unsigned ou = (unsigned)i * IO::kBytes, ok = (unsigned)((y >> 1) * Wl + (x >> 1)) * IO::kBytes;
+    float4 tu[C]; float2 ts[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { tu[c] = IO::ld4(ub + c * pu + ou, 0); ts[c] = IO::ld2(kb + c * pk + ok, 0); }
+    int labv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) labv[e] = (int)labels[(size_t)n * HW + i + e];
+    float z[K][4];
+    unsigned pos[2] = {0u, 0u};                                 // bit 4*(c & 7) + e of word c >> 3: h[c][e] > 0
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[k][e] = b != nullptr ? b[k] : 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float4 cf = bn_coef[c];
+      const float hv[4] = {leaky((cf.x * tu[c].x + cf.y) + ts[c].x, slope), leaky((cf.x * tu[c].y + cf.y) + ts[c].x, slope),
+                           leaky((cf.x * tu[c].z + cf.y) + ts[c].y, slope), leaky((cf.x * tu[c].w + cf.y) + ts[c].y, slope)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pos[c >> 3] |= (hv[e] > 0.f ? 1u : 0u) << (4 * (c & 7) + e);
+#pragma unroll
+        for (int k = 0; k < K; ++k) z[k][e] += w[k * C + c] * hv[e];
+      }
+    }
+    float d[K][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float mx = z[0][e];
+#pragma unroll
+      for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k][e]);
+      float se = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) se += expf(z[k][e] - mx);
+      const float lse = mx + logf(se);
+      const int lab = labv[e];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float pk_ = expf(z[k][e] - lse);
+        if (k == lab) picked += (double)(z[k][e] - lse);
+        d[k][e] = grad_scale * (pk_ - (k == lab ? 1.f : 0.f));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float mean = bn_coef[c].z;
+      const float uq[4] = {tu[c].x, tu[c].y, tu[c].z, tu[c].w};
+      float a[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) t += w[k * C + c] * d[k][e];
+        t *= ((pos[c >> 3] >> (4 * (c & 7) + e)) & 1u) ? 1.f : slope;
+        a[e] = t;
+        b1[c] += t;
+        b2[c] += t * (uq[e] - mean);
+      }
+      IO::st4(db + c * pu + ou, 0, make_float4(a[0], a[1], a[2], a[3]));
+    }
+  }
+  picked = block_sum_d(picked, redd);
+  if (threadIdx.x == 0) part[(size_t)n * gridDim.x + blockIdx.x] = picked;
+  const int N = (int)gridDim.y, S = (int)gridDim.x;
+  __shared__ float sred[kElemThreads / 64][2 * C];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float t1 = wave_sum(b1[c]), t2 = wave_sum(b2[c]);
+    if (lane == 0) { sred[wv][c] = t1; sred[wv][C + c] = t2; }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    const int c = threadIdx.x;
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < kElemThreads / 64; ++q) { t1 += sred[q][c]; t2 += sred[q][C + c]; }
+    bn_part[(size_t)c * (N * S) + n * S + blockIdx.x] = make_float2(t1, t2);
+  }
+}
+
 __global__ __launch_bounds__(256) void ce_finalize_kernel(const double* __restrict__ part, int nparts, double scale, float* __restrict__ loss_out,
                                                           const int* __restrict__ slot_dev) {
   __shared__ double redd[16];
@@ -720,6 +828,39 @@ extern "C" int ms_head_ce_actbwd(const float* h, const float* w, const float* b,
                                  int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,
                                  const float* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream) {
   return head_ce_actbwd_impl<float>(h, w, b, labels, dh, loss_out, loss_slot_dev, N, C, K, HW, loss_sign, ws, ws_bytes, bn_u, bn_coef4, bn_part, act_slope, stream);
+}
+// ms_conv1x1_bnres (mode 5) + ms_head_ce_actbwd in one pass over the block's second conv output: the output of the LAST residual block of the segmentation
+// decoder (encoder_decoder.py:344-346, up_type 'NN') is formed inside the head kernel as lrelu(bn(u) + skip[y/2][x/2]) - u [N,C,H,W] that block's second conv
+// output, coef4 its BatchNorm record, skip [N,C,H/2,W/2] the 1x1 skip conv (+ bias) at half resolution - and is never written.  Everything else as
+// ms_head_ce_actbwd (dh already masked by lrelu', bn_part the BatchNorm-backward sums, loss_out may be NULL for ms_step_tail).  C == 16 (FCN_16's last block), K <= 4.
+template <typename AT>
+static int head_ce_tail_impl(const void* u, const void* skip, const float* coef4, const float* w, const float* b, const int64_t* labels, void* dh, float* loss_out,
+                             const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, void* stream) {
+  const int HW = H * W;
+  if (int e = head_check(N, C, K, HW, "ms_head_ce_tail")) return e;
+  if (C != kHeadFuseC || K > kMaxHeadK || u == nullptr || skip == nullptr || coef4 == nullptr || dh == nullptr || bn_part == nullptr || W < 4 || W % 4 != 0 || H % 2 != 0 || !aligned16(u) || !aligned16(dh) ||
+      !aligned16(coef4) || (reinterpret_cast<uintptr_t>(skip) & 7u) != 0 || !(act_slope >= 0.f && act_slope <= 1.f)) {
+    set_error("ms_head_ce_tail: C == %d, W %% 4 == 0, even H, 16-byte aligned u / dh / coef4, 8-byte aligned skip, slope in [0, 1]", kHeadFuseC); return MS_ERR_INVALID;
+  }
+  if (ws == nullptr || ws_bytes < ms_head_ce_ws_bytes(N, HW)) { set_error("ms_head_ce_tail: workspace too small"); return MS_ERR_WORKSPACE; }
+  const int gx = head_fuse_gx(HW);
+  const double M = (double)N * HW;
+#define MS_HT(KK) MS_LAUNCH((head_ce_tail_kernel<KK, AT>), dim3(gx, N), dim3(kElemThreads), 0, (hipStream_t)stream, u, skip, (const float4*)coef4, w, b, labels, dh, (double*)ws, HW, W, \
+                           (float)(loss_sign / M), (float2*)bn_part, act_slope)
+  switch (K) { case 1: MS_HT(1); break; case 2: MS_HT(2); break; case 3: MS_HT(3); break; default: MS_HT(4); }
+#undef MS_HT
+  if (int e = check_launch("head_ce_tail")) return e;
+  if (loss_out == nullptr) return MS_OK;
+  MS_LAUNCH(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, gx * N, -(double)loss_sign / M, loss_out, loss_slot_dev);
+  return check_launch("ce_finalize");
+}
+extern "C" int ms_head_ce_tail(const float* u, const float* skip, const float* coef4, const float* w, const float* b, const int64_t* labels, float* dh, float* loss_out,
+                               const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, void* stream) {
+  return head_ce_tail_impl<float>(u, skip, coef4, w, b, labels, dh, loss_out, loss_slot_dev, N, C, K, H, W, loss_sign, ws, ws_bytes, bn_part, act_slope, stream);
+}
+extern "C" int ms_head_ce_tail_bf16(const uint16_t* u, const uint16_t* skip, const float* coef4, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* loss_out,
+                                    const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, void* stream) {
+  return head_ce_tail_impl<ms_bf16>(u, skip, coef4, w, b, labels, dh, loss_out, loss_slot_dev, N, C, K, H, W, loss_sign, ws, ws_bytes, bn_part, act_slope, stream);
 }
 extern "C" int ms_head_ce_actbwd_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* loss_out, const int* loss_slot_dev,
                                       int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,

@@ -344,6 +344,7 @@ class InnerLoopEngine:
         # ~4.8 us launches); MS_FUSE_TAIL=0 is the A/B switch (bit-identical results)
         self.fuse_tail = os.environ.get("MS_FUSE_TAIL", "1") != "0"
         self.fuse_head_bwd = os.environ.get("MS_FUSE_HEAD_BWD", "1") != "0"     # ms_style_bwd_head: layer 4's backward forms the head's input gradient itself
+        self.lazy_seg_tail = os.environ.get("MS_LAZY_SEG_TAIL", "1") != "0" and type(self) is InnerLoopEngine      # ms_head_ce_tail (see seg_loss)
         # cross-workgroup finalize (`_xfin` entry points): the BatchNorm coefficients a launch consumes are derived INSIDE that launch (one wave per channel,
         # published through tagged granules) instead of by an ms_bn_finalize launch in front of it.  Needs every workgroup of a launch co-resident: not with
         # shared_device.  MS_XFIN=0 is the A/B switch (bit-identical results).
@@ -377,7 +378,7 @@ class InnerLoopEngine:
         return self.t(name, *shape, dtype=self.act_dtype)
 
     _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv2d_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd",
-                             "ms_head_fwd", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_style_fwd", "ms_style_bwd", "ms_style_ws_bytes",
+                             "ms_head_fwd", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_head_ce_tail", "ms_style_fwd", "ms_style_bwd", "ms_style_ws_bytes",
                              "ms_conv_subpix", "ms_conv3x3_small_cout", "ms_style_bwd_actbwd", "ms_style_bwd_actbwd_parts"))
 
     def L(self, name):
@@ -775,7 +776,7 @@ class InnerLoopEngine:
         return out, bc
 
     # ------------------------------------------------------------------ residual blocks
-    def res_fwd(self, pfx, net, key, x, kind, x_act=None):
+    def res_fwd(self, pfx, net, key, x, kind, x_act=None, lazy_tail=False):
         """encoder_decoder.py:22-74 (kind 'down') / :289-357 (kind 'convT' = up_type Conv2, 'nn' = up_type NN).
         x_act = (coef4, slope): x is a RAW conv output whose BatchNorm + activation is applied as the prologue of the block's first conv (kind 'down')."""
         c0, c3, ci = net[key + ".c0"], net[key + ".c3"], net[key + ".ci"]
@@ -801,6 +802,13 @@ class InnerLoopEngine:
             u1, st1, p1 = self.conv(pfx + ".u1", src, c0, fetch=fetch, stats=True, fin=net[key + ".bn1"])
         cf1 = self.bn_fin_or_pending(pfx + ".bn1", st1, p1, net[key + ".bn1"])
         u2, st2, p2 = self.conv(pfx + ".u2", u1, c3, act=(cf1, LEAKY), stats=True, fin=net[key + ".bn4"])
+        if lazy_tail:
+            # the block output is never written: its consumer (the segmentation head, ms_head_ce_tail) forms lrelu(bn(u2) + skip) itself from u2, the BatchNorm
+            # record and the 1x1 skip conv at low resolution - a plain 1x1 conv here instead of the residual-tail launch
+            assert kind == "nn"
+            cf2 = self.bn_fin(pfx + ".bn4", st2, p2, net[key + ".bn4"])
+            sk, _, _ = self.conv(pfx + ".s", x, ci)
+            return ("lazy", u2, cf2, sk)
         xf2 = fused_tail and self._xfin_ok(st2)
         cf2 = None if xf2 else self.bn_fin(pfx + ".bn4", st2, p2, net[key + ".bn4"])
         if fused_tail:
@@ -958,19 +966,52 @@ class InnerLoopEngine:
         dimg, _, _ = self.conv("e.dimage", g, c0, bnbwd=(bc, b["e.inc.ua"]), dgrad=True)
         return dimg
 
-    def seg_fwd(self, z_s):
+    def seg_fwd(self, z_s, lazy_tail=False):
+        """lazy_tail: the last block returns ("lazy", u2, coef4, skip) instead of its output (see res_fwd)."""
         h = z_s
         for i in range(1, 5):
-            h = self.res_fwd(f"s.u{i}", self.nets.seg, f"u{i}", h, "nn")
+            h = self.res_fwd(f"s.u{i}", self.nets.seg, f"u{i}", h, "nn", lazy_tail=(lazy_tail and i == 4))
         return h
 
     def seg_loss(self, image, labels, need_grad=True, need_logits=False, loss_slot=None):
         """encode -> segment -> loss = -cross_entropy_2D (advanced_triplet...py:547-558) [+ backward to the image]."""
         z_i, z_s = self.encode_fwd(image)
-        h = self.seg_fwd(z_s)
-        N, C, H, W = h.shape
         w, bias = self.nets.seg["head.w"], self.nets.seg["head.b"]
         K = w.shape[0]
+        Cq = w.shape[1]
+        # the last residual block of the segmentation decoder hands the head (u2, BatchNorm record, low-resolution skip) instead of its output, which is then
+        # never written (ms_head_ce_tail; MS_LAZY_SEG_TAIL=0 is the A/B switch, bit-identical): the residual-tail launch becomes a 1x1 conv at half resolution
+        lazy = (self.lazy_seg_tail and need_grad and not need_logits and self.fuse_act_bwd and not self.bn_eval and self.fuse_skip and not self.overlap
+                and Cq == 16 and K <= 4            # (the kernel's channel count is compile-time: FCN_16's last block)
+                and lib.ms_head_ce_actbwd_parts(image.shape[0], Cq, image.shape[2] * image.shape[3]) > 0 and image.shape[3] % 4 == 0 and image.shape[2] % 2 == 0)
+        h = self.seg_fwd(z_s, lazy_tail=lazy)
+        if lazy:
+            _, u2l, cf2l, skl = h
+            N, C, H, W = u2l.shape
+            dh = self.a("s.dh", N, C, H, W)
+            nbytes = lib.ms_head_ce_ws_bytes(N, H * W)
+            ws = self.t("s.ce_ws", max(nbytes, 64), dtype=torch.uint8)
+            nparts = lib.ms_head_ce_actbwd_parts(N, C, H * W)
+            part = self.t("s.u4.bw2.hpart", C, nparts, 2)
+            defer_ce = self._tail is not None and loss_slot is self.step_dev
+            if defer_ce:
+                self._tail["ce"] = (ws.data_ptr(), nparts, -float(self.loss_sign) / float(N * H * W))
+            check(self.L("ms_head_ce_tail")(u2l.data_ptr(), skl.data_ptr(), cf2l.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), dh.data_ptr(),
+                                      0 if defer_ce else self.loss_buf.data_ptr(), 0 if loss_slot is None else loss_slot.data_ptr(), N, C, K, H, W, self.loss_sign,
+                                      ws.data_ptr(), ws.numel(), part.data_ptr(), LEAKY, self._st()), "ms_head_ce_tail")
+            bc = self.t("s.u4.bw2.bcoef", C, 4)
+            check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, cf2l.data_ptr(), float(N * H * W), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:s.u4")
+            pre = (dh, bc)
+            d = dh
+            b = self.buf
+            for i in range(4, 0, -1):
+                lo = f"s.u{i - 1}"
+                nxt = (lo + ".bw2", b[lo + ".out"], b[lo + ".u2"], b[lo + ".bn4.coef"], LEAKY) if i > 1 else \
+                      ("e.cd.bw2", b["e.z_s"], b["e.cd.u2"], b["e.cd.bn4.coef"], 0.0)
+                res = self.res_bwd(f"s.u{i}", self.nets.seg, f"u{i}", d, "nn", pre=pre, next_act=nxt)
+                pre, d = (res, None) if isinstance(res, tuple) else (None, res)
+            return self.encode_bwd(d, pre=pre)
+        N, C, H, W = h.shape
         dh = self.a("s.dh", N, C, H, W) if need_grad else None
         logits = self.t("s.logits", N, K, H, W) if need_logits else None
         nbytes = lib.ms_head_ce_ws_bytes(N, H * W)

@@ -306,3 +306,45 @@ def test_three_way_split_mode_vs_fp64(dev):
         base = rnd((N, Cout, H, W), 6)
         o2 = ops.conv2d(xd, wp, None, Cout, 3, 1, fetch=ops.FETCH_X3, pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=x2d, epi_mode=1, out=base.to(dev).clone())
         assert err(o2, F.conv2d(a * x.double() + bb * x2.double() + cc, w.double(), None, padding=1) + base.double()) < 3e-6
+
+
+@pytest.mark.parametrize("net,act", [((4, 1, 4), None), ((1, 3, 2), None), ((4, 1, 4), torch.bfloat16)])
+def test_lazy_segmentation_tail_is_bit_identical(dev, monkeypatch, net, act):
+    """ms_head_ce_tail (the segmentation head forms the output of the decoder's last residual block itself from u2, its BatchNorm record and the half-resolution
+    skip conv: that tensor is never written, the residual-tail launch becomes a plain 1x1 conv) against the materialised path: same bits after K = 3 steps
+    (C = 16 and, FCN_64, C = 64 -> the lazy path must switch itself off there), fp32 and bf16 storage."""
+    from maxstyle_amd import engine as E, synthetic as syn
+    spec_o = syn.NetSpec(*net)
+    W = syn.procedural_weights(spec_o, 0)
+    to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
+    B, size, layers = 4, 64, [3, 4, 5]
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MS_LAZY_SEG_TAIL", flag)
+        spec = E.NetSpec(*net)
+        eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1, act_dtype=act)
+        assert eng.lazy_seg_tail == (flag == "1")
+        eng.set_nets(E.PackedNets(spec, to(W["image_encoder"]), to(W["segmentation_decoder"]), to(W["image_decoder"])))
+        img, lab = syn.synthetic_batch(B, size, net[1], net[2], seed=1234)
+        eng.configure_styles(layers, {i: E.StyleSlot(i, B, spec_o.channel_num[i]) for i in layers})
+        for i in layers:
+            st = syn.random_style_state(B, spec_o.channel_num[i], 7 + i)
+            eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
+        z_i = eng.encode_fwd(img.to(dev).to(eng.act_dtype))[0].clone()
+        K = 3 if act is None else 1               # (bf16: ONE step, so that both paths take their gradients at the same parameters)
+        out = eng.run(z_i, lab.to(dev), K, use_graph=True).clone()
+        outs.append((out, eng.losses(K).clone(), eng.flat_p.clone(), eng.flat_g.clone()))
+        if net[0] == 4:
+            assert ("s.u4.out" in eng.buf) == (flag == "0"), "the block output must not exist on the lazy path"
+    if act is None:
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b)
+    else:
+        # bf16 storage: the materialised path rounds the block output to bf16 and keeps the skip conv in fp32 registers, the lazy path rounds the skip conv
+        # and keeps the block output in fp32 registers - two roundings of the same size in different places, so the bar is the storage format's
+        d = [float((a.double() - b.double()).abs().max()) for a, b in zip(outs[0], outs[1])]
+        gmax = float(outs[1][3].abs().max())
+        print("lazy tail bf16 max diffs (image, losses, params, grads):", d, "max |grad|", gmax)
+        # (parameters: Adam's first step moves every entry by lr * sign(gradient): a near-zero gradient whose sign differs moves a parameter by 2 * 0.1 -
+        # the bound is that, not a rounding bound)
+        assert d[0] < 5e-2 and d[1] < 2e-3 * float(outs[1][1].abs().max()) and d[2] <= 0.2 + 1e-6 and d[3] < 0.1 * gmax
