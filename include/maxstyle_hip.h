@@ -273,6 +273,19 @@ int ms_conv2d_actbwd(const float* in, const float* in2, float* out, const float*
                      int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                      const float* u, const float* coef4, float act_slope, float* tab, void* stream);
 
+/* ms_conv2d (a 1x1 conv: ks == 1) that also CARRIES a ms_bn_bwd_coefs job for the launch behind it: one MFMA wave per channel c < ride_C reduces that channel's
+ * BatchNorm-backward partial sums (ride_part2 [ride_C][ride_nparts][2], or - ride_nparts == 0 - the table of ms_conv2d_actbwd / ms_conv_subpix) with
+ * ms_bn_bwd_coefs' arithmetic in its order (same bits) and writes ride_out4[c] = {al, be, de, 0}, while the workgroup's staging waves fetch their first chunk.
+ * The conv neither reads nor waits for ride_out4: it is for the NEXT launch on the stream (the residual block's data-gradient conv, whose prologue needs it
+ * - model_util.py:468-510 backward; the 1x1 skip data-gradient runs between producer and consumer anyway, so the ~5 us coefficient launch disappears).
+ * MFMA wave w of workgroup b takes channel 4b + w: ride_C <= ms_conv_ride_capacity(N, Hout, Wout) always fits (MS_ERR_INVALID when a launch is too small). */
+int ms_conv_ride_capacity(int N, int Hout, int Wout);
+int ms_conv2d_ride(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
+                   int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                   int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                   int epi_mode, float* stats, const float* ride_part2, int ride_nparts, const float* ride_coef4, double ride_count, float* ride_out4, int ride_C,
+                   void* stream);
+
 /* ms_conv2d(epi_mode 0, stats) / ms_conv2d_actbwd whose LAST workgroup also reduces the table: coef4 receives what ms_bn_finalize(stats, gamma, beta,
  * eps) would compute (nn.BatchNorm2d in batch-statistics mode, model_util.py:468-510), bcoef4 what ms_bn_bwd_coefs(tab, coef4, count) would - without
  * the extra launch (a ~4 us kernel, 42 times per inner step).  counter: one int, zero before the first use; every launch re-arms it (one counter per
@@ -460,6 +473,11 @@ int ms_act_bwd_reduce_bf16(const uint16_t* gin, const uint16_t* ref, const uint1
 int ms_pool2_sum_bf16(const uint16_t* in, uint16_t* out, int planes, int Ho, int Wo, int accumulate, void* stream);
 int ms_pool2_actbwd_bf16(const uint16_t* in, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
                          int N, int C, int Ho, int Wo, float slope, void* stream);
+int ms_conv2d_ride_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias,
+                        int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                        int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
+                        int epi_mode, float* stats, const float* ride_part2, int ride_nparts, const float* ride_coef4, double ride_count, float* ride_out4, int ride_C,
+                        void* stream);
 int ms_conv2d_xfin_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride,
                         int fetch, int pro_mode, float slope, int epi_mode, float* stats, int kind, const float* tab, const float* p0, const float* p1, float eps, double count,
                         float* coef4, void* gran, int* err, void* stream);

@@ -58,6 +58,10 @@ struct ConvArgs {
   // stores the record to xf_coef (for later kernels) and publishes {tag = epoch | scale}, {tag | shift} as two 8-byte granules in xf_gran with agent-scope
   // stores; every consumer of a channel polls its granules (bounded spin; *xf_err on time-out).  See xfin_* below.
   const float* xf_tab; const float* xf_gamma; const float* xf_beta; float xf_eps; float* xf_coef; conv_u64_t* xf_gran; int* xf_err; int xf_C;
+  // "rider" (ms_conv2d_ride): a ms_bn_bwd_coefs job this launch carries for the NEXT launch - MFMA wave w of workgroup b reduces channel c = 4b + w < ride_C:
+  // BatchNorm-backward partial sums (ride_part [ride_C][ride_nparts] float2, or a conv-epilogue table when ride_nparts == 0) with ms_bn_bwd_coefs' arithmetic in
+  // its order (same bits) and writes ride_out[c] = {al, be, de, 0} while the staging waves fetch the first chunk.  This launch itself does not read ride_out.
+  const float2* ride_part; int ride_nparts; const float4* ride_coef; double ride_count; float4* ride_out; int ride_C;
   int xf_kind; double xf_count;     // kind 0: BatchNorm statistics -> {scale, shift, mean, invstd}; kind 1: BatchNorm-backward sums (+ xf_gamma = forward records, xf_count = N*H*W) -> {al, be, de, 0}
 };
 
@@ -95,6 +99,24 @@ __device__ inline double xf_wave_sum_d(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += shfl_xor_d(v, off);
   return v;
+}
+// the rider job (ConvArgs::ride_*): exactly bn_bwd_coefs_kernel (ms_elem.hip) run by one wave
+__device__ inline void conv_ride(const ConvArgs& a, int c, int lane) {
+  int nparts = a.ride_nparts;
+  const float2* row = (nparts == 0) ? a.ride_part + 1 + (size_t)c * kStatSlots : a.ride_part + (size_t)c * nparts;
+  if (nparts == 0) nparts = (int)a.ride_part[0].x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = lane; i < nparts; i += 64) { const float2 q = row[i]; s1 += (double)q.x; s2 += (double)q.y; }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if (lane == 0) {
+    const float4 cf = a.ride_coef[c];           // {sc, sh, mean, invstd}
+    const double mean = cf.z, invstd = cf.w, sc = cf.x;
+    const double c1 = s1 / a.ride_count;
+    const double c2 = s2 * invstd / a.ride_count;
+    const double be = -sc * c2 * invstd;
+    a.ride_out[c] = make_float4((float)sc, (float)be, (float)(-sc * c1 - be * mean), 0.f);
+  }
 }
 __device__ inline conv_u64_t* xfin_slot(const ConvArgs& a, int c, int g, int rep) { return a.xf_gran + ((size_t)c * kXfinNG + g) * kXfinRep + rep; }
 // header of the producing conv's table: {slots in use, launch epoch}; float4 records (statistics, kind 0) or float2 records (BatchNorm-backward sums, kind 1)
@@ -681,6 +703,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   }
 
   // =========================================== CONSUMER waves ===========================================
+  if (a.ride_out != nullptr && (int)blockIdx.x * 4 + wave < a.ride_C) conv_ride(a, (int)blockIdx.x * 4 + wave, lane);      // (hardware index: the first workgroups dispatched)
   if (a.bw_parts > 0) {
     // pro_mode 3: what ms_bn_bwd_coefs would have computed in its own launch (a ~5 us kernel + launch gap, 29 times per inner step): every
     // workgroup reduces the (sum g, sum g*u) partials of ms_act_bwd_reduce itself - <= 32 KB of L2-resident reads, 32 lanes per channel,
@@ -1094,6 +1117,7 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
   const int per_cu = std::max(1, std::min(reg_limit, (int)((160 * 1024) / (lds_bytes + 256))));
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;      // every workgroup keeps one channel block: item % ncb == blockIdx % ncb
+  if (a.ride_out != nullptr && a.ride_C > 4 * nblocks) { set_error("ms_conv2d_ride: %d rider channels, %ld workgroups", a.ride_C, nblocks); return MS_ERR_INVALID; }
   dim3 grid((unsigned)nblocks), block(512);
   MS_LAUNCH((conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2, AT>), grid, block, lds_bytes, st, a);
   return check_launch("conv_mfma");

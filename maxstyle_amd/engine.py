@@ -252,6 +252,15 @@ class XfCoef:
         self.kind, self.tab, self.p0, self.p1, self.count, self.coef, self.gran, self.err, self.C = kind, tab, p0, p1, count, coef, gran, err, C
 
 
+class RideCoef:
+    """BatchNorm-backward coefficients no launch has produced yet, on their way to a residual block's backward: the block's 1x1 skip data-gradient - which runs
+    between the producer of the partial sums and the conv that needs the coefficients anyway - carries the ms_bn_bwd_coefs job (`ms_conv2d_ride`).
+    part [C][nparts][2] (nparts = 0: a conv-epilogue table), coef = forward records, count = N*H*W, bc = the tensor the job fills."""
+
+    def __init__(self, part, nparts, coef, count, bc, C):
+        self.part, self.nparts, self.coef, self.count, self.bc, self.C = part, nparts, coef, count, bc, C
+
+
 class StyleSlot:
     """Device state of one applied MaxStyle layer inside the engine (views into the flat parameter buffers)."""
 
@@ -344,6 +353,9 @@ class InnerLoopEngine:
         # ~4.8 us launches); MS_FUSE_TAIL=0 is the A/B switch (bit-identical results)
         self.fuse_tail = os.environ.get("MS_FUSE_TAIL", "1") != "0"
         self.fuse_head_bwd = os.environ.get("MS_FUSE_HEAD_BWD", "1") != "0"     # ms_style_bwd_head: layer 4's backward forms the head's input gradient itself
+        # ms_bn_bwd_coefs jobs whose consumer is a residual block's backward ride on that block's 1x1 skip data-gradient launch (ms_conv2d_ride) instead of
+        # being ~5 us launches of their own; MS_RIDE=0 is the A/B switch (bit-identical results)
+        self.ride = os.environ.get("MS_RIDE", "1") != "0"
         self.lazy_seg_tail = os.environ.get("MS_LAZY_SEG_TAIL", "1") != "0" and type(self) is InnerLoopEngine      # ms_head_ce_tail (see seg_loss)
         # cross-workgroup finalize (`_xfin` entry points): the BatchNorm coefficients a launch consumes are derived INSIDE that launch (one wave per channel,
         # published through tagged granules) instead of by an ms_bn_finalize launch in front of it.  Needs every workgroup of a launch co-resident: not with
@@ -377,7 +389,7 @@ class InnerLoopEngine:
         """An ACTIVATION tensor (conv inputs / outputs, gradients, images): fp32, or bf16 storage in bf16 mode (everything else stays fp32)."""
         return self.t(name, *shape, dtype=self.act_dtype)
 
-    _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv2d_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd",
+    _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv2d_ride", "ms_conv2d_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd",
                              "ms_head_fwd", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_head_ce_tail", "ms_style_fwd", "ms_style_bwd", "ms_style_ws_bytes",
                              "ms_conv_subpix", "ms_conv3x3_small_cout", "ms_style_bwd_actbwd", "ms_style_bwd_actbwd_parts"))
 
@@ -525,7 +537,7 @@ class InnerLoopEngine:
             self.buf[name + ".cnt"] = c
         return c
 
-    def conv(self, name, x, cw: ConvW, cout=None, ks=None, stride=1, fetch=0, act=None, bnbwd=None, epi=0, out=None, stats=False, dgrad=False, fin=None):
+    def conv(self, name, x, cw: ConvW, cout=None, ks=None, stride=1, fetch=0, act=None, bnbwd=None, epi=0, out=None, stats=False, dgrad=False, fin=None, ride=None):
         """act=(coef4, slope): BN-apply+LeakyReLU prologue; bnbwd=(bcoef4, u): BN-backward prologue; fin: the BatchNorm (BNW) that follows - with
         `fuse_bn_fin` its coefficients come out of this launch. Returns (out, stats, parts); stats is ("fused", coef4) when they did."""
         N, Cin, Hs, Ws = x.shape
@@ -565,6 +577,7 @@ class InnerLoopEngine:
             pa, pb, pc = ops.coef_ptrs(bnbwd[0])
             in2 = bnbwd[1]
         bias = None if dgrad else cw.b
+        assert ride is None or (xf is None and ks == 1 and not (stats and fin is not None and self.fuse_bn_fin)), "a rider travels on a plain 1x1 ms_conv2d"
         if stats and fin is not None and self.fuse_bn_fin and epi == 0 and pm != 3:
             coef = self.t(name + ".fcoef", cout, 4)
             check(lib.ms_conv2d_fin(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
@@ -579,10 +592,31 @@ class InnerLoopEngine:
                                      xf.kind, xf.tab.data_ptr(), xf.p0.data_ptr(), 0 if xf.p1 is None else xf.p1.data_ptr(), BN_EPS, xf.count,
                                      xf.coef.data_ptr(), xf.gran.data_ptr(), xf.err.data_ptr(), self._st()), "ms_conv2d_xfin:" + name)
             return out, st, parts
+        if ride is not None:
+            # (a 1x1 conv: the launch also derives the BatchNorm-backward coefficients the NEXT launch needs - RideCoef)
+            check(self.L("ms_conv2d_ride")(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                     N, Cin, Hs, Ws, cout, ks, stride, fetch | wf, pm, pa, pb, pc, pn, 4, slope, epi, 0 if st is None else st.data_ptr(),
+                                     ride.part.data_ptr(), ride.nparts, ride.coef.data_ptr(), ride.count, ride.bc.data_ptr(), ride.C, self._st()), "ms_conv2d_ride:" + name)
+            return out, st, parts
         check(self.L("ms_conv2d")(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
                             N, Cin, Hs, Ws, cout, ks, stride, fetch | wf, pm, pa, pb, pc, pn, 4, slope, epi, 0 if st is None else st.data_ptr(), self._st()),
               "ms_conv2d:" + name)
         return out, st, parts
+
+    def bwd_coefs(self, bc_name, part, nparts, coef, count, C, ride=False):
+        """ms_bn_bwd_coefs -> the coefficient tensor; ride=True (the consumer is res_bwd): the pending job (RideCoef) for that block's skip conv to carry."""
+        bc = self.t(bc_name, C, 4)
+        if ride and self.ride and not self.overlap and not self.bn_eval:
+            return RideCoef(part, nparts, coef, float(count), bc, C)
+        check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(count), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + bc_name)
+        return bc
+
+    def ride_now(self, bc):
+        """A pending RideCoef nobody can carry: its own launch after all."""
+        if isinstance(bc, RideCoef):
+            check(lib.ms_bn_bwd_coefs(bc.part.data_ptr(), bc.nparts, bc.coef.data_ptr(), bc.count, bc.bc.data_ptr(), bc.C, self._st()), "ms_bn_bwd_coefs(ride_now)")
+            return bc.bc
+        return bc
 
     def bn_fin(self, name, st, parts, bn: BNW):
         if self.bn_eval:
@@ -643,8 +677,8 @@ class InnerLoopEngine:
         check(self.L("ms_bn_act")(u.data_ptr(), coef.data_ptr(), 0 if res is None else res.data_ptr(), res_mode, out.data_ptr(), N, C, H, W, slope, self._st()), "ms_bn_act:" + name)
         return out
 
-    def act_bwd(self, name, gin, ref, u, coef, slope):
-        """In-place mask of gin + BN-backward reductions -> (g, bcoef4)."""
+    def act_bwd(self, name, gin, ref, u, coef, slope, ride=False):
+        """In-place mask of gin + BN-backward reductions -> (g, bcoef4)  (ride: see bwd_coefs)."""
         N, C, H, W = u.shape
         nparts = lib.ms_act_bwd_parts(N, C, H * W)
         part = self.t(name + ".part", C, nparts, 2)
@@ -657,7 +691,6 @@ class InnerLoopEngine:
                 self.buf[name + ".bcoef_eval"] = bc
             bc[:, 0].copy_(coef[:, 0])
             return gin, bc
-        bc = self.t(name + ".bcoef", C, 4)
         if not self.fuse_bn_bwd:
             # two launches (mask+reduce, then coefficients).  Both fusions were built and measured slower at C2: the one-launch
             # ms_act_bwd_bn (236.5 vs 254.8 steps/s: an s_waitcnt vmcnt(0) + a returning atomic on the tail of each of its 4096
@@ -666,8 +699,8 @@ class InnerLoopEngine:
                                         N, C, H * W, slope, self._st()), "ms_act_bwd_reduce:" + name)
             if self.inline_bn_bwd:
                 return gin, (part, nparts, coef)
-            check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(N * H * W), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + name)
-            return gin, bc
+            return gin, self.bwd_coefs(name + ".bcoef", part, nparts, coef, N * H * W, C, ride=ride)
+        bc = self.t(name + ".bcoef", C, 4)
         arrive = self.buf.get("bn.arrive")
         if arrive is None:
             arrive = torch.zeros(1024, dtype=torch.int32, device=self.dev)     # re-armed by every launch; stream order serialises its users
@@ -762,7 +795,7 @@ class InnerLoopEngine:
               "ms_conv_subpix(s2 dgrad):" + name)
         return out
 
-    def dgrad_s2_actbwd(self, name, g, cw: ConvW, bw_name, act_out, u, coef, slope):
+    def dgrad_s2_actbwd(self, name, g, cw: ConvW, bw_name, act_out, u, coef, slope, ride=False):
         """dgrad_s2 whose epilogue already does the activation backward of the layer BELOW (mask by the materialised activation `act_out`, sums for
         the BatchNorm backward of its raw input `u`): replaces dgrad_s2 + act_bwd (ms_act_bwd_reduce: 4 HBM passes over the result) -> (g', bcoef4)."""
         N, Cg, Hs, Ws = g.shape
@@ -771,9 +804,7 @@ class InnerLoopEngine:
         tab = self.t(bw_name + ".tab", lib.ms_conv_actbwd_tab_bytes(C) // 4)
         check(self.L("ms_conv_subpix")(g.data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), 0, N, Cg, Hs, Ws, C, 1, 0, 0 if act_out is None else act_out.data_ptr(), u.data_ptr(),
                                  coef.data_ptr(), slope, tab.data_ptr(), self._st()), "ms_conv_subpix(s2 dgrad + act bwd):" + name)
-        bc = self.t(bw_name + ".bcoef", C, 4)
-        check(lib.ms_bn_bwd_coefs(tab.data_ptr(), 0, coef.data_ptr(), float(N * 4 * Hs * Ws), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + bw_name)
-        return out, bc
+        return out, self.bwd_coefs(bw_name + ".bcoef", tab, 0, coef, N * 4 * Hs * Ws, C, ride=ride)
 
     # ------------------------------------------------------------------ residual blocks
     def res_fwd(self, pfx, net, key, x, kind, x_act=None, lazy_tail=False):
@@ -829,24 +860,35 @@ class InnerLoopEngine:
         out = self.bn_act(pfx + ".out", u2, cf2, s, 2 if kind == "nn" else 1, LEAKY)
         return out
 
-    def res_bwd(self, pfx, net, key, dout, kind, need_dx=True, pre=None, next_act=None):
+    def res_bwd(self, pfx, net, key, dout, kind, need_dx=True, pre=None, next_act=None, ride_next=False):
         """dout: gradient w.r.t. the block output (overwritten). Returns the gradient w.r.t. the block input.
         pre = (g2, bcoef) when the producer of `dout` already applied this block's output-activation backward in its epilogue;
         next_act = (bw_name, act_out, u, coef, slope) of the activation BELOW a 'down' block: its backward is then done in the epilogue of this block's
-        last data-gradient conv and the return value is the pair (masked gradient, BatchNorm-backward coefficients) for the caller to hand on as `pre`."""
+        last data-gradient conv and the return value is the pair (masked gradient, BatchNorm-backward coefficients) for the caller to hand on as `pre`.
+        ride_next: the caller hands that pair to another res_bwd (whose skip conv can carry the coefficient job: RideCoef)."""
         b = self.buf
         c0, c3, ci = net[key + ".c0"], net[key + ".c3"], net[key + ".ci"]
         if pre is not None:
             g2, bc2 = pre
         else:
-            g2, bc2 = self.act_bwd(pfx + ".bw2", dout, b[pfx + ".out"], b[pfx + ".u2"], b[pfx + ".bn4.coef"], LEAKY)
+            g2, bc2 = self.act_bwd(pfx + ".bw2", dout, b[pfx + ".out"], b[pfx + ".u2"], b[pfx + ".bn4.coef"], LEAKY, ride=True)
+        ride = None
+        if isinstance(bc2, RideCoef):
+            # the coefficients of this block's own BatchNorm backward are still partial sums: the skip conv below (1x1, needs only g2) carries the job
+            N_, _, H_, W_ = g2.shape
+            if kind == "nn":
+                H_, W_ = H_ // 2, W_ // 2
+            if bc2.C <= lib.ms_conv_ride_capacity(N_, H_, W_):
+                ride, bc2 = bc2, bc2.bc
+            else:
+                bc2 = self.ride_now(bc2)
         # skip branch on the side stream (it only needs g2): its data-gradient lands in the buffer the main chain then ACCUMULATES into
         with self._side(after_main=True):
             if kind == "nn":
                 gs = self.pool2(pfx + ".gs", g2)
-                dx, _, _ = self.conv(pfx + ".dx", gs, ci, dgrad=True)
+                dx, _, _ = self.conv(pfx + ".dx", gs, ci, dgrad=True, ride=ride)
             else:
-                dsrc, _, _ = self.conv(pfx + ".dsrc", g2, ci, dgrad=True)
+                dsrc, _, _ = self.conv(pfx + ".dsrc", g2, ci, dgrad=True, ride=ride)
         g1, bc1 = self.dgrad_act_bwd(pfx + ".da1", pfx + ".bw1", g2, c3, (bc2, b[pfx + ".u2"]), b[pfx + ".u1"], b[pfx + ".bn1.coef"], LEAKY)
         self._join_side()
         if kind == "nn":
@@ -859,9 +901,7 @@ class InnerLoopEngine:
                 part = self.t(bw_name + ".ppart", C, nparts, 2)
                 check(self.L("ms_pool2_actbwd")(dhi.data_ptr(), dx.data_ptr(), dx.data_ptr(), act_out.data_ptr(), u.data_ptr(), coef.data_ptr(), part.data_ptr(),
                                           N, C, Ho, Wo, slope, self._st()), "ms_pool2_actbwd:" + pfx)
-                bc = self.t(bw_name + ".bcoef", C, 4)
-                check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(N * Ho * Wo), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + bw_name)
-                return dx, bc
+                return dx, self.bwd_coefs(bw_name + ".bcoef", part, nparts, coef, N * Ho * Wo, C, ride=ride_next)
             self.pool2(pfx + ".dx", dhi, out=dx, accumulate=True)
             return dx
         self.conv(pfx + ".dsrc", g1, c0, bnbwd=(bc1, b[pfx + ".u1"]), dgrad=True, epi=1, out=dsrc)  # at the strided / transposed-conv resolution
@@ -873,7 +913,7 @@ class InnerLoopEngine:
             down = net[key + ".down"]
             if next_act is not None and self.fuse_act_bwd and not self.bn_eval and self._subpix_ok(dsrc.shape[0], dsrc.shape[2], dsrc.shape[3], down.cin):
                 bw_name, act_out, u, coef, slope = next_act
-                return self.dgrad_s2_actbwd(pfx + ".dx", dsrc, down, bw_name, act_out, u, coef, slope)
+                return self.dgrad_s2_actbwd(pfx + ".dx", dsrc, down, bw_name, act_out, u, coef, slope, ride=ride_next)
             dx = self.dgrad_s2(pfx + ".dx", dsrc, down)
         return dx
 
@@ -950,7 +990,7 @@ class InnerLoopEngine:
             lo = f"e.d{i - 1}"
             nxt = (lo + ".bw2", b[lo + ".out"], b[lo + ".u2"], b[lo + ".bn4.coef"], LEAKY) if i > 1 else \
                   ("e.inc.bw2", b.get("e.inc.out"), b["e.inc.ub"], b["e.inc.bn4.coef"], LEAKY)      # None: the mask is recomputed from ub (lazy_inc)
-            res = self.res_bwd(f"e.d{i}", e, f"d{i}", dh, "down", pre=pre, next_act=nxt)
+            res = self.res_bwd(f"e.d{i}", e, f"d{i}", dh, "down", pre=pre, next_act=nxt, ride_next=(i > 1))
             pre, dh = (res, None) if isinstance(res, tuple) else (None, res)
         g, bc = pre if pre is not None else self.act_bwd("e.inc.bw2", dh, b.get("e.inc.out"), b["e.inc.ub"], b["e.inc.bn4.coef"], LEAKY)
         g, bc = self.dgrad_act_bwd("e.inc.da", "e.inc.bw1", g, e["inc3"], (bc, b["e.inc.ub"]), b["e.inc.ua"], b["e.inc.bn1.coef"], LEAKY)
@@ -999,16 +1039,14 @@ class InnerLoopEngine:
             check(self.L("ms_head_ce_tail")(u2l.data_ptr(), skl.data_ptr(), cf2l.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), dh.data_ptr(),
                                       0 if defer_ce else self.loss_buf.data_ptr(), 0 if loss_slot is None else loss_slot.data_ptr(), N, C, K, H, W, self.loss_sign,
                                       ws.data_ptr(), ws.numel(), part.data_ptr(), LEAKY, self._st()), "ms_head_ce_tail")
-            bc = self.t("s.u4.bw2.bcoef", C, 4)
-            check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, cf2l.data_ptr(), float(N * H * W), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:s.u4")
-            pre = (dh, bc)
+            pre = (dh, self.bwd_coefs("s.u4.bw2.bcoef", part, nparts, cf2l, N * H * W, C, ride=True))
             d = dh
             b = self.buf
             for i in range(4, 0, -1):
                 lo = f"s.u{i - 1}"
                 nxt = (lo + ".bw2", b[lo + ".out"], b[lo + ".u2"], b[lo + ".bn4.coef"], LEAKY) if i > 1 else \
                       ("e.cd.bw2", b["e.z_s"], b["e.cd.u2"], b["e.cd.bn4.coef"], 0.0)
-                res = self.res_bwd(f"s.u{i}", self.nets.seg, f"u{i}", d, "nn", pre=pre, next_act=nxt)
+                res = self.res_bwd(f"s.u{i}", self.nets.seg, f"u{i}", d, "nn", pre=pre, next_act=nxt, ride_next=(i > 1))
                 pre, d = (res, None) if isinstance(res, tuple) else (None, res)
             return self.encode_bwd(d, pre=pre)
         N, C, H, W = h.shape
@@ -1029,9 +1067,7 @@ class InnerLoopEngine:
             check(self.L("ms_head_ce_actbwd")(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), dh.data_ptr(), 0 if defer_ce else self.loss_buf.data_ptr(),
                                         0 if loss_slot is None else loss_slot.data_ptr(), N, C, K, H * W, self.loss_sign, ws.data_ptr(), ws.numel(),
                                         u2.data_ptr(), coef.data_ptr(), part.data_ptr(), LEAKY, self._st()), "ms_head_ce_actbwd")
-            bc = self.t("s.u4.bw2.bcoef", C, 4)
-            check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(N * H * W), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:s.u4")
-            pre = (dh, bc)
+            pre = (dh, self.bwd_coefs("s.u4.bw2.bcoef", part, nparts, coef, N * H * W, C, ride=True))
         else:
             check(self.L("ms_head_ce")(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), 0 if dh is None else dh.data_ptr(),
                                  0 if logits is None else logits.data_ptr(), self.loss_buf.data_ptr(), 0 if loss_slot is None else loss_slot.data_ptr(),
@@ -1044,7 +1080,7 @@ class InnerLoopEngine:
             lo = f"s.u{i - 1}"
             nxt = (lo + ".bw2", b[lo + ".out"], b[lo + ".u2"], b[lo + ".bn4.coef"], LEAKY) if i > 1 else \
                   ("e.cd.bw2", b["e.z_s"], b["e.cd.u2"], b["e.cd.bn4.coef"], 0.0)
-            res = self.res_bwd(f"s.u{i}", self.nets.seg, f"u{i}", d, "nn", pre=pre, next_act=nxt)
+            res = self.res_bwd(f"s.u{i}", self.nets.seg, f"u{i}", d, "nn", pre=pre, next_act=nxt, ride_next=(i > 1))
             pre, d = (res, None) if isinstance(res, tuple) else (None, res)
         return self.encode_bwd(d, pre=pre)
 
@@ -1173,9 +1209,7 @@ class InnerLoopEngine:
                                           std[0].data_ptr(), std[1].data_ptr(), po("lmda") if s.mix_style else 0, s.perm.data_ptr() if s.mix_style else 0,
                                           go("gamma_noise") if s.use_noise else 0, go("beta_noise") if s.use_noise else 0, go("lmda") if s.mix_style else 0,
                                           B, C, HW, ws.data_ptr(), ws.numel(), u.data_ptr(), coef.data_ptr(), part.data_ptr(), LEAKY, self._st()), f"ms_style_bwd_actbwd:{i}")
-        bc = self.t(pfx + ".bw2.bcoef", C, 4)
-        check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(B * HW), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + pfx)
-        return dx, bc
+        return dx, self.bwd_coefs(pfx + ".bw2.bcoef", part, nparts, coef, B * HW, C, ride=True)      # (the consumer is res_bwd of block `pfx`)
 
     def _defer_layer(self, i, B, C, HW):
         """Inside a step with a fused tail: the layer's backward leaves its per-plane partial sums in the workspace (d_* = NULL) and ms_step_tail

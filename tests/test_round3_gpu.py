@@ -199,26 +199,21 @@ def test_config5_combined_stream_bf16_vs_fp32(dev):
             assert float(o16.min()) > float(o32.min()) - 0.5 * rng and float(o16.max()) < float(o32.max()) + 0.5 * rng
 
 
-@pytest.mark.parametrize("case", ["c2small", "c4small", "bf16", "c2full"])
-def test_cross_workgroup_finalize_is_bit_identical(dev, monkeypatch, case):
-    """`_xfin` (ms_conv1x1_bnres_xfin / ms_conv2d_xfin: the launch that consumes BatchNorm coefficients - in its epilogue: the residual-block tail; in its prologue:
-    conv2 of a block, the data-gradient convs - derives them itself, one wave per channel, published through tagged, replicated granules, instead of an
-    ms_bn_finalize / ms_bn_bwd_coefs launch in front of it) against the separate launches: same bits in the
-    image, the losses and the parameters after K steps, eager and through the captured graph; the error word stays clear; and the coefficient records the
-    launch leaves for later kernels are the ones ms_bn_finalize writes."""
+def _switch_ab(dev, monkeypatch, case, env, attr, layers=(3, 4, 5), decoder_kind=None):
+    """K = 3 steps (eager, then through the captured graph) with the engine switch `env` on and off -> [(image, losses, parameters), coefficient records] per setting."""
     from maxstyle_amd import engine as E, synthetic as syn
     net, B, size, act = {"c2small": ((4, 1, 4), 4, 64, None), "c4small": ((1, 3, 2), 4, 64, None), "bf16": ((4, 1, 4), 4, 64, torch.bfloat16),
                          "c2full": ((4, 1, 4), 16, 256, None)}[case]
     spec_o = syn.NetSpec(*net)
     W = syn.procedural_weights(spec_o, 0)
     to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
-    layers = [3, 4, 5]
+    layers = list(layers)
     outs = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("MS_XFIN", flag)
+        monkeypatch.setenv(env, flag)
         spec = E.NetSpec(*net)
         eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1, act_dtype=act)
-        assert eng.xfin == (flag == "1")
+        assert getattr(eng, attr) == (flag == "1")
         eng.set_nets(E.PackedNets(spec, to(W["image_encoder"]), to(W["segmentation_decoder"]), to(W["image_decoder"])))
         img, lab = syn.synthetic_batch(B, size, net[1], net[2], seed=1234)
         eng.configure_styles(layers, {i: E.StyleSlot(i, B, spec_o.channel_num[i]) for i in layers})
@@ -236,17 +231,64 @@ def test_cross_workgroup_finalize_is_bit_identical(dev, monkeypatch, case):
             out = eng.run(z_i, lab.to(dev), 3, use_graph=graph).clone()
             res.append((out, eng.losses(3).clone(), eng.flat_p.clone()))
         eng.check_errors()
-        if flag == "1":
-            assert "xfin.err" in eng.buf and int(eng.buf["xfin.err"].item()) == 0
-            assert any(k.endswith(".gran") for k in eng.buf)
         assert all(torch.equal(a, b) for a, b in zip(res[0], res[1])), "graph replay == eager"
         coefs = {k: v.clone() for k, v in eng.buf.items() if k.endswith(".coef") or k.endswith(".bcoef")}      # forward records and BatchNorm-backward records
-        outs.append((res[0], coefs))
+        outs.append((res[0], coefs, eng))
+    return outs
+
+
+def _same_bits(outs, min_records=40):
     for a, b in zip(outs[0][0], outs[1][0]):
         assert torch.equal(a, b)
-    assert outs[0][1].keys() == outs[1][1].keys() and len(outs[0][1]) >= 40
+    assert outs[0][1].keys() == outs[1][1].keys() and len(outs[0][1]) >= min_records
     for k in outs[0][1]:
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
+@pytest.mark.parametrize("case", ["c2small", "c4small", "bf16", "c2full"])
+def test_cross_workgroup_finalize_is_bit_identical(dev, monkeypatch, case):
+    """`_xfin` (ms_conv1x1_bnres_xfin / ms_conv2d_xfin: the launch that consumes BatchNorm coefficients - in its epilogue: the residual-block tail; in its prologue:
+    conv2 of a block, the data-gradient convs - derives them itself, one wave per channel, published through tagged, replicated granules, instead of an
+    ms_bn_finalize / ms_bn_bwd_coefs launch in front of it) against the separate launches: same bits in the
+    image, the losses and the parameters after K steps, eager and through the captured graph; the error word stays clear; and the coefficient records the
+    launch leaves for later kernels are the ones ms_bn_finalize writes."""
+    outs = _switch_ab(dev, monkeypatch, case, "MS_XFIN", "xfin")
+    eng = outs[0][2]
+    assert "xfin.err" in eng.buf and int(eng.buf["xfin.err"].item()) == 0
+    assert any(k.endswith(".gran") for k in eng.buf)
+    _same_bits(outs)
+
+
+@pytest.mark.parametrize("case", ["c2small", "c4small", "bf16", "c2full"])
+def test_rider_coefficient_jobs_are_bit_identical(dev, monkeypatch, case):
+    """ms_conv2d_ride (the 1x1 skip data-gradient of a residual block carries the ms_bn_bwd_coefs job whose result the block's NEXT launch needs, instead of a
+    ~5 us launch of its own) against the separate launches: same bits everywhere, including every coefficient record; and the launches really went away."""
+    import maxstyle_amd._lib as L
+    calls = {"ride": 0, "coefs": 0}
+    real_ride, real_coefs = L.lib.ms_conv2d_ride, L.lib.ms_bn_bwd_coefs
+    outs = _switch_ab(dev, monkeypatch, case, "MS_RIDE", "ride")
+    _same_bits(outs)
+    # launch counts of one eager step with the switch on / off (the engine of each setting is still alive)
+    counts = []
+    for _, _, eng in outs:
+        n = {"ride": 0, "coefs": 0}
+        def count(name, fn):
+            def f(*a):
+                n[name] += 1
+                return fn(*a)
+            return f
+        monkeypatch.setattr(L.lib, "ms_conv2d_ride", count("ride", real_ride), raising=False)
+        monkeypatch.setattr(L.lib, "ms_bn_bwd_coefs", count("coefs", real_coefs), raising=False)
+        if case == "bf16":
+            real_rb = L.lib.ms_conv2d_ride_bf16
+            monkeypatch.setattr(L.lib, "ms_conv2d_ride_bf16", count("ride", real_rb), raising=False)
+        eng.step(eng.buf["d.image"])
+        torch.cuda.synchronize()
+        counts.append(n)
+        monkeypatch.undo()
+    # (the 4x4 / 8x8 levels of the 64x64 cases have fewer workgroups than channels: ms_conv_ride_capacity says no and the job keeps its own launch)
+    assert counts[0]["ride"] >= {"c2full": 9, "c4small": 3}.get(case, 5) and counts[1]["ride"] == 0, counts
+    assert counts[1]["coefs"] - counts[0]["coefs"] == counts[0]["ride"], counts
 
 
 @pytest.mark.parametrize("net,layers", [((4, 1, 4), [3, 4, 5]), ((4, 1, 4), [4, 5]), ((4, 1, 4), [4]), ((1, 3, 2), [3, 4, 5])])
