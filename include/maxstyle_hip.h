@@ -89,20 +89,30 @@ int ms_style_fwd_3k(const float* x, float* y, float* mu, float* sig, float* gamm
  * (ms_act_bwd_reduce) in one pass: out = (pool2(in) [+ add]) * lrelu'(act); part2 as ms_act_bwd_reduce ([C][ms_act_bwd_parts(N,C,Ho*Wo)][2]). */
 int ms_pool2_actbwd(const float* in, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
                     int N, int C, int Ho, int Wo, float slope, void* stream);
+/* ... that also writes pooled [N,C,Ho/2,Wo/2] = ms_pool2_sum(out) - the input of the NEXT block's 1x1 skip data-gradient (no pooling launch there): a thread owns a
+ * 2x2 quad of output pixels instead of four pixels of a row, sums the STORED values in ms_pool2_sum's order (same bits); part2 agrees with ms_pool2_actbwd's to
+ * rounding (the per-thread grouping of the sums follows the mapping).  Ho even, Wo % 4 == 0. */
+int ms_pool2_actbwd_pool(const float* in, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
+                         int N, int C, int Ho, int Wo, float slope, float* pooled, void* stream);
 
 /* ms_head_ce (segmentation head + cross entropy + backward to the head input h, custom_loss.py:1043-1078) whose dh is already multiplied by lrelu'(h) - h is the
  * output of the last residual block - and which writes the BatchNorm-backward sums of that block's last BatchNorm (raw input bn_u, record bn_coef4) to
  * bn_part [C][ms_head_ce_actbwd_parts(N,C,HW)][2]: replaces ms_head_ce + ms_act_bwd_reduce.  C <= 16 (parts() returns 0 otherwise: use the two calls). */
-/* ms_conv1x1_bnres (half-resolution skip) + ms_head_ce_actbwd in ONE pass over u: the output h = lrelu(bn(u) + skip[y/2][x/2]) of the segmentation decoder's last
- * residual block (encoder_decoder.py:344-346; final_conv + cross_entropy_2D, custom_loss.py:1043-1078) is formed inside the head kernel and never written.
- * u [N,C,H,W] the block's second conv output, coef4 its BatchNorm record {sc, sh, mean, invstd}, skip [N,C,H/2,W/2] the 1x1 skip conv (+ bias) at half
- * resolution (plain ms_conv2d).  dh, bn_part, loss_out (may be NULL: ms_step_tail), ws as ms_head_ce_actbwd.  Same arithmetic, same order: bit-identical. */
-int ms_head_ce_tail(const float* u, const float* skip, const float* coef4, const float* w, const float* b, const int64_t* labels, float* dh, float* loss_out,
-                    const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, void* stream);
 int ms_head_ce_actbwd_parts(int N, int C, int HW);
 int ms_head_ce_actbwd(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* loss_out, const int* loss_slot_dev,
                       int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,
                       const float* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream);
+/* ms_conv1x1_bnres (half-resolution skip) + ms_head_ce_actbwd in ONE pass over u: the output h = lrelu(bn(u) + skip[y/2][x/2]) of the segmentation decoder's last
+ * residual block (encoder_decoder.py:344-346; final_conv + cross_entropy_2D, custom_loss.py:1043-1078) is formed inside the head kernel and never written.
+ * u [N,C,H,W] the block's second conv output, coef4 its BatchNorm record {sc, sh, mean, invstd}, skip [N,C,H/2,W/2] the 1x1 skip conv (+ bias) at half
+ * resolution (plain ms_conv2d).  dh, bn_part, loss_out (may be NULL: ms_step_tail), ws as ms_head_ce_actbwd.  Same arithmetic, same order: bit-identical.
+ * pooled != NULL: a thread owns a 2x2 pixel quad instead of four pixels of a row and also writes pooled [N,C,H/2,W/2] = ms_pool2_sum(dh) (the sum of the STORED
+ * values, in ms_pool2_sum's order: same bits) - the input of the block's 1x1 skip data-gradient; the per-thread grouping of the BatchNorm-backward sums changes
+ * with the mapping, so bn_part agrees with the pooled == NULL form to rounding, not to the bit. */
+int ms_head_ce_tail(const float* u, const float* skip, const float* coef4, const float* w, const float* b, const int64_t* labels, float* dh, float* loss_out,
+                    const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, float* pooled,
+                    void* stream);
+
 
 /* ms_style_bwd for a layer that sits right behind a residual block (x = that block's output): dx is additionally multiplied by lrelu'(x) and the sums the
  * BatchNorm backward of the block's last BatchNorm needs are written to bn_part [C][ms_style_bwd_actbwd_parts(B,C,HW)][2] (the partial layout of
@@ -273,9 +283,11 @@ int ms_conv2d_actbwd(const float* in, const float* in2, float* out, const float*
                      int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                      const float* u, const float* coef4, float act_slope, float* tab, void* stream);
 
-/* ms_conv2d (a 1x1 conv: ks == 1) that also CARRIES a ms_bn_bwd_coefs job for the launch behind it: one MFMA wave per channel c < ride_C reduces that channel's
- * BatchNorm-backward partial sums (ride_part2 [ride_C][ride_nparts][2], or - ride_nparts == 0 - the table of ms_conv2d_actbwd / ms_conv_subpix) with
- * ms_bn_bwd_coefs' arithmetic in its order (same bits) and writes ride_out4[c] = {al, be, de, 0}, while the workgroup's staging waves fetch their first chunk.
+/* ms_conv2d (a 1x1 conv: ks == 1) that also CARRIES a coefficient job for the launch behind it.  ride_kind 0 = ms_bn_bwd_coefs: one MFMA wave per channel
+ * c < ride_C reduces that channel's BatchNorm-backward partial sums (ride_tab [ride_C][ride_nparts][2], or - ride_nparts == 0 - the table of ms_conv2d_actbwd /
+ * ms_conv_subpix; ride_p0 = the forward records [C][4], ride_count = N*H*W) with ms_bn_bwd_coefs' arithmetic in its order (same bits) and writes
+ * ride_out4[c] = {al, be, de, 0}, while the workgroup's staging waves fetch their first chunk.  ride_kind 1 = ms_bn_finalize: ride_tab = the statistics table of
+ * the conv in front (ms_conv2d `stats`), ride_p0 / ride_p1 = gamma / beta, ride_eps -> ride_out4[c] = {scale, shift, mean, invstd}.
  * The conv neither reads nor waits for ride_out4: it is for the NEXT launch on the stream (the residual block's data-gradient conv, whose prologue needs it
  * - model_util.py:468-510 backward; the 1x1 skip data-gradient runs between producer and consumer anyway, so the ~5 us coefficient launch disappears).
  * MFMA wave w of workgroup b takes channel 4b + w: ride_C <= ms_conv_ride_capacity(N, Hout, Wout) always fits (MS_ERR_INVALID when a launch is too small). */
@@ -283,8 +295,8 @@ int ms_conv_ride_capacity(int N, int Hout, int Wout);
 int ms_conv2d_ride(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                    int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                    int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
-                   int epi_mode, float* stats, const float* ride_part2, int ride_nparts, const float* ride_coef4, double ride_count, float* ride_out4, int ride_C,
-                   void* stream);
+                   int epi_mode, float* stats, int ride_kind, const float* ride_tab, int ride_nparts, const float* ride_p0, const float* ride_p1, float ride_eps, double ride_count,
+                   float* ride_out4, int ride_C, void* stream);
 
 /* ms_conv2d(epi_mode 0, stats) / ms_conv2d_actbwd whose LAST workgroup also reduces the table: coef4 receives what ms_bn_finalize(stats, gamma, beta,
  * eps) would compute (nn.BatchNorm2d in batch-statistics mode, model_util.py:468-510), bcoef4 what ms_bn_bwd_coefs(tab, coef4, count) would - without
@@ -476,20 +488,23 @@ int ms_pool2_actbwd_bf16(const uint16_t* in, const uint16_t* add, uint16_t* out,
 int ms_conv2d_ride_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias,
                         int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                         int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
-                        int epi_mode, float* stats, const float* ride_part2, int ride_nparts, const float* ride_coef4, double ride_count, float* ride_out4, int ride_C,
-                        void* stream);
+                        int epi_mode, float* stats, int ride_kind, const float* ride_tab, int ride_nparts, const float* ride_p0, const float* ride_p1, float ride_eps, double ride_count,
+                        float* ride_out4, int ride_C, void* stream);
 int ms_conv2d_xfin_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride,
                         int fetch, int pro_mode, float slope, int epi_mode, float* stats, int kind, const float* tab, const float* p0, const float* p1, float eps, double count,
                         float* coef4, void* gran, int* err, void* stream);
 int ms_conv1x1_bnres_xfin_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
                                const uint16_t* u, const float* stats, const float* gamma, const float* beta, float eps, float* coef4, void* gran, int* err,
                                float slope, int up2, void* stream);
+int ms_pool2_actbwd_pool_bf16(const uint16_t* in, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
+                              int N, int C, int Ho, int Wo, float slope, uint16_t* pooled, void* stream);
 int ms_head_fwd_bf16(const uint16_t* h, const float* w, const float* b, uint16_t* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
 int ms_head_bwd_bf16(const uint16_t* dout, const uint16_t* out, const float* w, uint16_t* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
 int ms_head_ce_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* logits, float* loss_out,
                     const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream);
 int ms_head_ce_tail_bf16(const uint16_t* u, const uint16_t* skip, const float* coef4, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* loss_out,
-                         const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, void* stream);
+                         const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, uint16_t* pooled,
+                         void* stream);
 int ms_head_ce_actbwd_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* loss_out, const int* loss_slot_dev,
                            int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,
                            const uint16_t* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream);

@@ -77,7 +77,7 @@ struct MaskEpi { const float* u; const float* coef4; float slope; float* tab; in
 struct FinEpi { int* counter; float* out; const float* gamma; const float* beta; float eps; double count; };
 // cross-workgroup finalize (ConvArgs::xf_*): the statistics table of the BatchNorm whose coefficients this launch consumes, its affine parameters, the record
 // buffer the launch fills for later kernels, the granule table (2 x 8 bytes per channel, zero-filled once by the caller) and the error word
-struct Ride { const float* part2; int nparts; const float* coef4; double count; float* out4; int C; };      // ConvArgs::ride_*
+struct Ride { int kind; const float* part2; int nparts; const float* coef4; const float* p1; float eps; double count; float* out4; int C; };      // ConvArgs::ride_*
 struct XFin { const float* tab; const float* gamma; const float* beta; float eps; float* coef4; void* gran; int* err; int C; int kind = 0; double count = 0.0; };
 
 static int conv2d_impl(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
@@ -159,10 +159,12 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
     a.xf_gran = reinterpret_cast<conv_u64_t*>(xf->gran); a.xf_err = xf->err; a.xf_C = xf->C; a.xf_kind = xf->kind; a.xf_count = xf->count;
   }
   if (ride != nullptr) {
-    if (ks != 1 || ride->part2 == nullptr || ride->coef4 == nullptr || ride->out4 == nullptr || ride->C < 1 || ride->nparts < 0 || !(ride->count > 0) ||
-        !aligned16(ride->coef4) || !aligned16(ride->out4) || (reinterpret_cast<uintptr_t>(ride->part2) & 7u) != 0) {
-      set_error("ms_conv2d_ride: a 1x1 conv; partial sums (8-byte aligned), coef4 and out4 (16-byte aligned), count > 0"); return MS_ERR_INVALID;
+    const bool k0 = ride->kind == 0 && ride->nparts >= 0 && ride->count > 0 && aligned16(ride->coef4) && (reinterpret_cast<uintptr_t>(ride->part2) & 7u) == 0;
+    const bool k1 = ride->kind == 1 && ride->p1 != nullptr && aligned16(ride->part2);
+    if (ks != 1 || ride->part2 == nullptr || ride->coef4 == nullptr || ride->out4 == nullptr || ride->C < 1 || !aligned16(ride->out4) || !(k0 || k1)) {
+      set_error("ms_conv2d_ride: a 1x1 conv; kind 0: partial sums (8-byte aligned), forward records and out4 (16-byte aligned), count > 0; kind 1: statistics table, gamma, beta"); return MS_ERR_INVALID;
     }
+    a.ride_kind = ride->kind; a.ride_beta = ride->p1; a.ride_eps = ride->eps;
     a.ride_part = reinterpret_cast<const float2*>(ride->part2); a.ride_nparts = ride->nparts; a.ride_coef = reinterpret_cast<const float4*>(ride->coef4);
     a.ride_count = ride->count; a.ride_out = reinterpret_cast<float4*>(ride->out4); a.ride_C = ride->C;
   }
@@ -225,8 +227,8 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
                      epi_mode, stats, nullptr, nullptr, stream);
 }
 
-// ms_conv2d (a 1x1 conv) that also carries a ms_bn_bwd_coefs job for the launch BEHIND it: workgroup c < ride_C derives out4[c] from the partial sums while its
-// staging waves fetch (ConvArgs::ride_*).  The conv itself neither reads nor waits for out4; ride_C must not exceed the launch's workgroup count (checked).
+// ms_conv2d (a 1x1 conv) that also carries a ms_bn_bwd_coefs (ride_kind 0) or ms_bn_finalize (ride_kind 1) job for the launch BEHIND it: one MFMA wave per channel
+// derives out4[c] while the staging waves fetch (ConvArgs::ride_*).  The conv itself neither reads nor waits for out4; ride_C must not exceed the launch's workgroup count (checked).
 // channels a rider may have on a conv launch with this output shape (a lower bound of 4 x its workgroup count: one channel block, one workgroup per CU)
 extern "C" int ms_conv_ride_capacity(int N, int Hout, int Wout) {
   if (N < 1 || Hout < 1 || Wout < 1) return 0;
@@ -236,18 +238,20 @@ extern "C" int ms_conv_ride_capacity(int N, int Hout, int Wout) {
 extern "C" int ms_conv2d_ride(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                               int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                               int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
-                              int epi_mode, float* stats, const float* ride_part2, int ride_nparts, const float* ride_coef4, double ride_count, float* ride_out4, int ride_C,
+                              int epi_mode, float* stats, int ride_kind, const float* ride_tab, int ride_nparts, const float* ride_p0, const float* ride_p1, float ride_eps, double ride_count,
+                              float* ride_out4, int ride_C,
                               void* stream) {
-  const Ride rd{ride_part2, ride_nparts, ride_coef4, ride_count, ride_out4, ride_C};
+  const Ride rd{ride_kind, ride_tab, ride_nparts, ride_p0, ride_p1, ride_eps, ride_count, ride_out4, ride_C};
   return conv2d_impl(in, in2, out, w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
                      epi_mode, stats, nullptr, nullptr, stream, 0, nullptr, &rd);
 }
 extern "C" int ms_conv2d_ride_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias,
                                    int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                                    int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
-                                   int epi_mode, float* stats, const float* ride_part2, int ride_nparts, const float* ride_coef4, double ride_count, float* ride_out4, int ride_C,
+                                   int epi_mode, float* stats, int ride_kind, const float* ride_tab, int ride_nparts, const float* ride_p0, const float* ride_p1, float ride_eps, double ride_count,
+                              float* ride_out4, int ride_C,
                                    void* stream) {
-  const Ride rd{ride_part2, ride_nparts, ride_coef4, ride_count, ride_out4, ride_C};
+  const Ride rd{ride_kind, ride_tab, ride_nparts, ride_p0, ride_p1, ride_eps, ride_count, ride_out4, ride_C};
   return conv2d_impl(reinterpret_cast<const float*>(in), reinterpret_cast<const float*>(in2), reinterpret_cast<float*>(out), w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch,
                      pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope, epi_mode, stats, nullptr, nullptr, stream, 1, nullptr, &rd);
 }

@@ -61,7 +61,9 @@ struct ConvArgs {
   // "rider" (ms_conv2d_ride): a ms_bn_bwd_coefs job this launch carries for the NEXT launch - MFMA wave w of workgroup b reduces channel c = 4b + w < ride_C:
   // BatchNorm-backward partial sums (ride_part [ride_C][ride_nparts] float2, or a conv-epilogue table when ride_nparts == 0) with ms_bn_bwd_coefs' arithmetic in
   // its order (same bits) and writes ride_out[c] = {al, be, de, 0} while the staging waves fetch the first chunk.  This launch itself does not read ride_out.
+  // ride_kind 1: a ms_bn_finalize job instead (ride_part = the statistics table of the producing conv, ride_coef = gamma, ride_beta, ride_eps).
   const float2* ride_part; int ride_nparts; const float4* ride_coef; double ride_count; float4* ride_out; int ride_C;
+  int ride_kind; const float* ride_beta; float ride_eps;
   int xf_kind; double xf_count;     // kind 0: BatchNorm statistics -> {scale, shift, mean, invstd}; kind 1: BatchNorm-backward sums (+ xf_gamma = forward records, xf_count = N*H*W) -> {al, be, de, 0}
 };
 
@@ -102,6 +104,26 @@ __device__ inline double xf_wave_sum_d(double v) {
 }
 // the rider job (ConvArgs::ride_*): exactly bn_bwd_coefs_kernel (ms_elem.hip) run by one wave
 __device__ inline void conv_ride(const ConvArgs& a, int c, int lane) {
+  if (a.ride_kind == 1) {                     // exactly bn_finalize_kernel (ms_conv.hip)
+    const float4* tab = reinterpret_cast<const float4*>(a.ride_part);
+    const int np = (int)tab[0].x;
+    const float4* part = tab + 1 + (size_t)c * kStatSlots;
+    double sn = 0.0, sm = 0.0, sq = 0.0;
+    for (int i = lane; i < np; i += 64) {
+      const float4 q = part[i];
+      const double n = (double)q.x, mu = (double)q.y;
+      sn += n; sm += n * mu; sq += (double)q.z + n * mu * mu;
+    }
+    sn = wave_sum_d(sn); sm = wave_sum_d(sm); sq = wave_sum_d(sq);
+    if (lane == 0) {
+      const double mean = sm / sn;
+      const double var = fmax((sq - sm * mean) / sn, 0.0);
+      const float invstd = (float)(1.0 / sqrt(var + (double)a.ride_eps));
+      const float sc = reinterpret_cast<const float*>(a.ride_coef)[c] * invstd;
+      a.ride_out[c] = make_float4(sc, a.ride_beta[c] - (float)mean * sc, (float)mean, invstd);
+    }
+    return;
+  }
   int nparts = a.ride_nparts;
   const float2* row = (nparts == 0) ? a.ride_part + 1 + (size_t)c * kStatSlots : a.ride_part + (size_t)c * nparts;
   if (nparts == 0) nparts = (int)a.ride_part[0].x;

@@ -183,10 +183,13 @@ __global__ __launch_bounds__(kElemThreads) void pool2_sum_kernel(const void* __r
 // pool2_sum + accumulate + the output-activation backward of the block BELOW in one pass (ms_pool2_actbwd): the gradient w.r.t. the input of an up_type 'NN'
 // block is pool2(d_hi) + (1x1 skip data-gradient); that tensor is the gradient w.r.t. the OUTPUT of the block below, whose backward starts with
 // g = dout * lrelu'(act) and the two BatchNorm-backward sums (ms_act_bwd_reduce).  grid (S, N*C) as act_bwd_reduce; 4 low-resolution pixels per thread.
-template <typename AT = float>
+// POOL: a thread owns a 2x2 quad of OUTPUT pixels (a 4x4 patch of `in`) instead of 4 output pixels of a row, and also writes the quad's sum to `pooled`
+// [N,C,Ho/2,Wo/2] = what ms_pool2_sum(gout) would write, in its order: the input of the NEXT block's 1x1 skip data-gradient, no pooling launch there.
+template <typename AT = float, bool POOL = false>
 __global__ __launch_bounds__(kElemThreads) void pool2_actbwd_kernel(const void* __restrict__ in, const void* __restrict__ add, void* __restrict__ gout,
                                                                     const void* __restrict__ act, const void* __restrict__ u, const float4* __restrict__ coef,
-                                                                    float2* __restrict__ part, int C, int Ho, int Wo, int chunk, int S, int N, float slope) {
+                                                                    float2* __restrict__ part, int C, int Ho, int Wo, int chunk, int S, int N, float slope,
+                                                                    void* __restrict__ pooled) {
   __shared__ float red[16];
   const int p = blockIdx.y, c = p % C, n = p / C;
   const float mean = coef[c].z;
@@ -197,6 +200,28 @@ __global__ __launch_bounds__(kElemThreads) void pool2_actbwd_kernel(const void* 
   const size_t ipb = (size_t)p * 4 * HWo;
   float s1 = 0.f, s2 = 0.f;
   for (int i = beg + threadIdx.x * 4; i < end; i += kElemThreads * 4) {
+    if constexpr (POOL) {
+      const int Wq = Wo >> 1, q = i >> 2;
+      const int yq = q / Wq, xq = q - yq * Wq;                  // output pixels (2yq + r, 2xq + {0, 1}), r = 0, 1
+      float2 v[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const size_t r0 = ipb + (size_t)(4 * yq + 2 * r) * (2 * Wo) + 4 * xq;
+        const float4 a0 = IO::ld4(in, r0), b0 = IO::ld4(in, r0 + 2 * Wo);
+        float2 t = make_float2((a0.x + a0.y) + (b0.x + b0.y), (a0.z + a0.w) + (b0.z + b0.w));
+        const size_t o = base + (size_t)(2 * yq + r) * Wo + 2 * xq;
+        if (add != nullptr) { const float2 qq = IO::ld2(add, o); t.x = qq.x + t.x; t.y = qq.y + t.y; }
+        const float2 rr = IO::ld2(act, o);
+        const float2 uu = IO::ld2(u, o);
+        t.x *= (rr.x > 0.f) ? 1.f : slope; t.y *= (rr.y > 0.f) ? 1.f : slope;
+        IO::st2(gout, o, t);
+        s1 += t.x + t.y;
+        s2 += t.x * (uu.x - mean) + t.y * (uu.y - mean);
+        v[r] = t;
+      }
+      auto rt = [](float x) { if constexpr (IO::kBytes == 2) return IO::up(ms_to_bf16(x)); else return x; };      // bf16 storage: the sum of the STORED values
+      IO::st1(pooled, (size_t)p * (HWo >> 2) + q, (rt(v[0].x) + rt(v[0].y)) + (rt(v[1].x) + rt(v[1].y)));
+    } else {
     const int y = i / Wo, x = i - y * Wo;                       // Wo % 4 == 0: the quad stays in one row
     const size_t r0 = ipb + (size_t)(2 * y) * (2 * Wo) + 2 * x;
     const float4 a0 = IO::ld4(in, r0), a1 = IO::ld4(in, r0 + 4);
@@ -209,6 +234,7 @@ __global__ __launch_bounds__(kElemThreads) void pool2_actbwd_kernel(const void* 
     IO::st4(gout, base + i, v);
     s1 += (v.x + v.y) + (v.z + v.w);
     s2 += (v.x * (uu.x - mean) + v.y * (uu.y - mean)) + (v.z * (uu.z - mean) + v.w * (uu.w - mean));
+    }
   }
   s1 = block_sum(s1, red);
   s2 = block_sum(s2, red);
@@ -464,11 +490,13 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const void
 // h = lrelu((sc*u + sh) + skip[y/2][x/2]) from the block's second conv output u, that BatchNorm's record and the 1x1 skip conv at half resolution
 // (ms_conv1x1_bnres's arithmetic, same order: the same bits).  The block output is never written; u is read ONCE for both halves of the item (h is consumed
 // channel by channel into the logits, only its sign - 64 bits per thread - survives to the backward half, so the 64 registers of u fit beside the rest).
-template <int K, typename AT = float>
+// POOL: a thread owns a 2x2 pixel quad (two 8-byte accesses per channel, ONE skip pixel) instead of 4 pixels of a row, and also writes the quad's sum of dh to
+// `pooled` [N,C,H/2,W/2] = what ms_pool2_sum(dh) would write, (a.x + a.y) + (b.x + b.y): the next block's 1x1 skip data-gradient reads that, no pooling launch.
+template <int K, bool POOL, typename AT = float>
 __global__ __launch_bounds__(kElemThreads) void head_ce_tail_kernel(const void* __restrict__ u, const void* __restrict__ skip, const float4* __restrict__ bn_coef,
                                                                     const float* __restrict__ w, const float* __restrict__ b, const int64_t* __restrict__ labels,
                                                                     void* __restrict__ dh, double* __restrict__ part, int HW, int W, float grad_scale,
-                                                                    float2* __restrict__ bn_part, float slope) {
+                                                                    float2* __restrict__ bn_part, float slope, void* __restrict__ pooled) {
   using IO = ActIO<AT>;
   constexpr int C = kHeadFuseC;             // compile-time channel count: no per-channel branches, the K*C weights arrive as wide scalar loads
   // head weights, bias and the BatchNorm record are read through UNIFORM addresses (scalar loads): no LDS copy and no vector registers holding K*C weights
@@ -486,14 +514,28 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_tail_kernel(const void* 
 #pragma unroll
   for (int c = 0; c < C; ++c) { b1[c] = 0.f; b2[c] = 0.f; }
   for (int i = (blockIdx.x * kElemThreads + threadIdx.x) * 4; i < HW; i += gridDim.x * kElemThreads * 4) {
-    const int y = i / W, x = i - y * W;                        // W % 4 == 0: the quad stays in one row; skip pixels (x/2, x/2 + 1) of row y/2
-    const unsigned ou = (unsigned)i * IO::kBytes, ok = (unsigned)((y >> 1) * Wl + (x >> 1)) * IO::kBytes;
+    // !POOL: i = first of 4 pixels of one row (W % 4 == 0; skip pixels x/2, x/2 + 1 of row y/2).  POOL: i / 4 = the low-resolution pixel (yl, xl) whose 2x2 quad this is;
+    // element e of tu / labv / a below = pixel (2yl + (e >> 1), 2xl + (e & 1))
+    int y, x; unsigned ou, ou2 = 0u, ok;
+    if constexpr (POOL) { const int q = i >> 2; y = q / Wl; x = q - y * Wl; ou = (unsigned)(2 * y * W + 2 * x) * IO::kBytes; ou2 = ou + (unsigned)W * IO::kBytes; ok = (unsigned)q * IO::kBytes; }
+    else { y = i / W; x = i - y * W; ou = (unsigned)i * IO::kBytes; ok = (unsigned)((y >> 1) * Wl + (x >> 1)) * IO::kBytes; }
     float4 tu[C]; float2 ts[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) { tu[c] = IO::ld4(ub + c * pu + ou, 0); ts[c] = IO::ld2(kb + c * pk + ok, 0); }
     int labv[4];
+    if constexpr (POOL) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) labv[e] = (int)labels[(size_t)n * HW + i + e];
+      for (int c = 0; c < C; ++c) {
+        const float2 r0 = IO::ld2(ub + c * pu + ou, 0), r1 = IO::ld2(ub + c * pu + ou2, 0);
+        const float sv = IO::ld1(kb + c * pk + ok, 0);
+        tu[c] = make_float4(r0.x, r0.y, r1.x, r1.y); ts[c] = make_float2(sv, sv);
+      }
+      const int64_t* lp = labels + (size_t)n * HW + (size_t)(2 * y) * W + 2 * x;
+      labv[0] = (int)lp[0]; labv[1] = (int)lp[1]; labv[2] = (int)lp[W]; labv[3] = (int)lp[W + 1];
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) { tu[c] = IO::ld4(ub + c * pu + ou, 0); ts[c] = IO::ld2(kb + c * pk + ok, 0); }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) labv[e] = (int)labels[(size_t)n * HW + i + e];
+    }
     float z[K][4];
     unsigned pos[2] = {0u, 0u};                                 // bit 4*(c & 7) + e of word c >> 3: h[c][e] > 0
 #pragma unroll
@@ -545,7 +587,15 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_tail_kernel(const void* 
         b1[c] += t;
         b2[c] += t * (uq[e] - mean);
       }
-      IO::st4(db + c * pu + ou, 0, make_float4(a[0], a[1], a[2], a[3]));
+      if constexpr (POOL) {
+        IO::st2(db + c * pu + ou, 0, make_float2(a[0], a[1]));
+        IO::st2(db + c * pu + ou2, 0, make_float2(a[2], a[3]));
+        // (bf16 storage: the sum of the STORED values, like ms_pool2_sum reading dh back)
+        auto rt = [](float v) { if constexpr (IO::kBytes == 2) return IO::up(ms_to_bf16(v)); else return v; };
+        IO::st1(reinterpret_cast<char*>(pooled) + ((size_t)n * C + c) * pk + ok, 0, (rt(a[0]) + rt(a[1])) + (rt(a[2]) + rt(a[3])));
+      } else {
+        IO::st4(db + c * pu + ou, 0, make_float4(a[0], a[1], a[2], a[3]));
+      }
     }
   }
   picked = block_sum_d(picked, redd);
@@ -712,19 +762,36 @@ extern "C" int ms_pool2_sum_bf16(const uint16_t* in, uint16_t* out, int planes, 
 // or == out), out, act, u [N,C,Ho,Wo]; Wo % 4 == 0, 16-byte aligned.
 template <typename AT>
 static int pool2_actbwd_impl(const void* in, const void* add, void* out, const void* act, const void* u, const float* coef4, float* part2,
-                             int N, int C, int Ho, int Wo, float slope, void* stream) {
+                             int N, int C, int Ho, int Wo, float slope, void* stream, void* pooled = nullptr) {
   if (N < 1 || C < 1 || Ho < 1 || Wo < 4 || Wo % 4 != 0) { set_error("ms_pool2_actbwd: invalid shape (Wo %% 4 == 0)"); return MS_ERR_INVALID; }
   if ((long)N * C > 65535) { set_error("ms_pool2_actbwd: too many planes"); return MS_ERR_INVALID; }
   if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(u) |
         reinterpret_cast<uintptr_t>(coef4) | reinterpret_cast<uintptr_t>(add)) & 15u) != 0) { set_error("ms_pool2_actbwd: tensors must be 16-byte aligned"); return MS_ERR_ALIGN; }
   const ElemSplit sp = elem_split(N * C, Ho * Wo);
-  MS_LAUNCH((pool2_actbwd_kernel<AT>), dim3(sp.S, N * C), dim3(kElemThreads), 0, (hipStream_t)stream, in, add, out, act, u, (const float4*)coef4, (float2*)part2,
-            C, Ho, Wo, sp.chunk, sp.S, N, slope);
+  if (pooled != nullptr) {
+    if (Ho % 2 != 0 || (reinterpret_cast<uintptr_t>(pooled) & 3u) != 0) { set_error("ms_pool2_actbwd_pool: even Ho, 4-byte aligned pooled"); return MS_ERR_INVALID; }
+    MS_LAUNCH((pool2_actbwd_kernel<AT, true>), dim3(sp.S, N * C), dim3(kElemThreads), 0, (hipStream_t)stream, in, add, out, act, u, (const float4*)coef4, (float2*)part2,
+              C, Ho, Wo, sp.chunk, sp.S, N, slope, pooled);
+    return check_launch("pool2_actbwd_pool");
+  }
+  MS_LAUNCH((pool2_actbwd_kernel<AT, false>), dim3(sp.S, N * C), dim3(kElemThreads), 0, (hipStream_t)stream, in, add, out, act, u, (const float4*)coef4, (float2*)part2,
+            C, Ho, Wo, sp.chunk, sp.S, N, slope, (void*)nullptr);
   return check_launch("pool2_actbwd");
 }
 extern "C" int ms_pool2_actbwd(const float* in, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
                                int N, int C, int Ho, int Wo, float slope, void* stream) {
   return pool2_actbwd_impl<float>(in, add, out, act, u, coef4, part2, N, C, Ho, Wo, slope, stream);
+}
+// ms_pool2_actbwd that also writes pooled [N,C,Ho/2,Wo/2] = ms_pool2_sum(out) (same bits): see the kernel.  Ho even, Wo % 4 == 0.
+extern "C" int ms_pool2_actbwd_pool(const float* in, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
+                                    int N, int C, int Ho, int Wo, float slope, float* pooled, void* stream) {
+  if (pooled == nullptr) { set_error("ms_pool2_actbwd_pool: pooled is required"); return MS_ERR_INVALID; }
+  return pool2_actbwd_impl<float>(in, add, out, act, u, coef4, part2, N, C, Ho, Wo, slope, stream, pooled);
+}
+extern "C" int ms_pool2_actbwd_pool_bf16(const uint16_t* in, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
+                                         int N, int C, int Ho, int Wo, float slope, uint16_t* pooled, void* stream) {
+  if (pooled == nullptr) { set_error("ms_pool2_actbwd_pool: pooled is required"); return MS_ERR_INVALID; }
+  return pool2_actbwd_impl<ms_bf16>(in, add, out, act, u, coef4, part2, N, C, Ho, Wo, slope, stream, pooled);
 }
 extern "C" int ms_pool2_actbwd_bf16(const uint16_t* in, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
                                     int N, int C, int Ho, int Wo, float slope, void* stream) {
@@ -835,19 +902,21 @@ extern "C" int ms_head_ce_actbwd(const float* h, const float* w, const float* b,
 // ms_head_ce_actbwd (dh already masked by lrelu', bn_part the BatchNorm-backward sums, loss_out may be NULL for ms_step_tail).  C == 16 (FCN_16's last block), K <= 4.
 template <typename AT>
 static int head_ce_tail_impl(const void* u, const void* skip, const float* coef4, const float* w, const float* b, const int64_t* labels, void* dh, float* loss_out,
-                             const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, void* stream) {
+                             const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, void* pooled,
+                             void* stream) {
   const int HW = H * W;
   if (int e = head_check(N, C, K, HW, "ms_head_ce_tail")) return e;
   if (C != kHeadFuseC || K > kMaxHeadK || u == nullptr || skip == nullptr || coef4 == nullptr || dh == nullptr || bn_part == nullptr || W < 4 || W % 4 != 0 || H % 2 != 0 || !aligned16(u) || !aligned16(dh) ||
-      !aligned16(coef4) || (reinterpret_cast<uintptr_t>(skip) & 7u) != 0 || !(act_slope >= 0.f && act_slope <= 1.f)) {
+      !aligned16(coef4) || (reinterpret_cast<uintptr_t>(skip) & 7u) != 0 || (reinterpret_cast<uintptr_t>(pooled) & 3u) != 0 || !(act_slope >= 0.f && act_slope <= 1.f)) {
     set_error("ms_head_ce_tail: C == %d, W %% 4 == 0, even H, 16-byte aligned u / dh / coef4, 8-byte aligned skip, slope in [0, 1]", kHeadFuseC); return MS_ERR_INVALID;
   }
   if (ws == nullptr || ws_bytes < ms_head_ce_ws_bytes(N, HW)) { set_error("ms_head_ce_tail: workspace too small"); return MS_ERR_WORKSPACE; }
   const int gx = head_fuse_gx(HW);
   const double M = (double)N * HW;
-#define MS_HT(KK) MS_LAUNCH((head_ce_tail_kernel<KK, AT>), dim3(gx, N), dim3(kElemThreads), 0, (hipStream_t)stream, u, skip, (const float4*)coef4, w, b, labels, dh, (double*)ws, HW, W, \
-                           (float)(loss_sign / M), (float2*)bn_part, act_slope)
-  switch (K) { case 1: MS_HT(1); break; case 2: MS_HT(2); break; case 3: MS_HT(3); break; default: MS_HT(4); }
+#define MS_HT(KK, PP) MS_LAUNCH((head_ce_tail_kernel<KK, PP, AT>), dim3(gx, N), dim3(kElemThreads), 0, (hipStream_t)stream, u, skip, (const float4*)coef4, w, b, labels, dh, (double*)ws, HW, W, \
+                               (float)(loss_sign / M), (float2*)bn_part, act_slope, pooled)
+  if (pooled != nullptr) { switch (K) { case 1: MS_HT(1, true); break; case 2: MS_HT(2, true); break; case 3: MS_HT(3, true); break; default: MS_HT(4, true); } }
+  else { switch (K) { case 1: MS_HT(1, false); break; case 2: MS_HT(2, false); break; case 3: MS_HT(3, false); break; default: MS_HT(4, false); } }
 #undef MS_HT
   if (int e = check_launch("head_ce_tail")) return e;
   if (loss_out == nullptr) return MS_OK;
@@ -855,12 +924,14 @@ static int head_ce_tail_impl(const void* u, const void* skip, const float* coef4
   return check_launch("ce_finalize");
 }
 extern "C" int ms_head_ce_tail(const float* u, const float* skip, const float* coef4, const float* w, const float* b, const int64_t* labels, float* dh, float* loss_out,
-                               const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, void* stream) {
-  return head_ce_tail_impl<float>(u, skip, coef4, w, b, labels, dh, loss_out, loss_slot_dev, N, C, K, H, W, loss_sign, ws, ws_bytes, bn_part, act_slope, stream);
+                               const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, float* pooled,
+                               void* stream) {
+  return head_ce_tail_impl<float>(u, skip, coef4, w, b, labels, dh, loss_out, loss_slot_dev, N, C, K, H, W, loss_sign, ws, ws_bytes, bn_part, act_slope, pooled, stream);
 }
 extern "C" int ms_head_ce_tail_bf16(const uint16_t* u, const uint16_t* skip, const float* coef4, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* loss_out,
-                                    const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, void* stream) {
-  return head_ce_tail_impl<ms_bf16>(u, skip, coef4, w, b, labels, dh, loss_out, loss_slot_dev, N, C, K, H, W, loss_sign, ws, ws_bytes, bn_part, act_slope, stream);
+                                    const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, uint16_t* pooled,
+                                    void* stream) {
+  return head_ce_tail_impl<ms_bf16>(u, skip, coef4, w, b, labels, dh, loss_out, loss_slot_dev, N, C, K, H, W, loss_sign, ws, ws_bytes, bn_part, act_slope, pooled, stream);
 }
 extern "C" int ms_head_ce_actbwd_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* loss_out, const int* loss_slot_dev,
                                       int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,

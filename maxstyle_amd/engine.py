@@ -257,8 +257,9 @@ class RideCoef:
     between the producer of the partial sums and the conv that needs the coefficients anyway - carries the ms_bn_bwd_coefs job (`ms_conv2d_ride`).
     part [C][nparts][2] (nparts = 0: a conv-epilogue table), coef = forward records, count = N*H*W, bc = the tensor the job fills."""
 
-    def __init__(self, part, nparts, coef, count, bc, C):
-        self.part, self.nparts, self.coef, self.count, self.bc, self.C = part, nparts, coef, count, bc, C
+    def __init__(self, part, nparts, coef, count, bc, C, kind=0, beta=None):
+        # kind 1: a ms_bn_finalize job (part = the statistics table, coef = gamma, beta; bc = the forward record buffer)
+        self.part, self.nparts, self.coef, self.count, self.bc, self.C, self.kind, self.beta = part, nparts, coef, count, bc, C, kind, beta
 
 
 class StyleSlot:
@@ -356,6 +357,10 @@ class InnerLoopEngine:
         # ms_bn_bwd_coefs jobs whose consumer is a residual block's backward ride on that block's 1x1 skip data-gradient launch (ms_conv2d_ride) instead of
         # being ~5 us launches of their own; MS_RIDE=0 is the A/B switch (bit-identical results)
         self.ride = os.environ.get("MS_RIDE", "1") != "0"
+        # the producers of a masked gradient that an up-sampling block's backward pools 2x2 for its skip branch (ms_head_ce_tail, ms_pool2_actbwd) write the
+        # pooled tensor themselves: no ms_pool2_sum launch in res_bwd (MS_POOL_FUSE=0 is the A/B switch; results agree to rounding - the producers' per-thread
+        # grouping of the BatchNorm-backward sums changes with their pixel mapping)
+        self.pool_fuse = os.environ.get("MS_POOL_FUSE", "1") != "0" and type(self) is InnerLoopEngine
         self.lazy_seg_tail = os.environ.get("MS_LAZY_SEG_TAIL", "1") != "0" and type(self) is InnerLoopEngine      # ms_head_ce_tail (see seg_loss)
         # cross-workgroup finalize (`_xfin` entry points): the BatchNorm coefficients a launch consumes are derived INSIDE that launch (one wave per channel,
         # published through tagged granules) instead of by an ms_bn_finalize launch in front of it.  Needs every workgroup of a launch co-resident: not with
@@ -389,7 +394,7 @@ class InnerLoopEngine:
         """An ACTIVATION tensor (conv inputs / outputs, gradients, images): fp32, or bf16 storage in bf16 mode (everything else stays fp32)."""
         return self.t(name, *shape, dtype=self.act_dtype)
 
-    _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv2d_ride", "ms_conv2d_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd",
+    _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv2d_ride", "ms_conv2d_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd", "ms_pool2_actbwd_pool",
                              "ms_head_fwd", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_head_ce_tail", "ms_style_fwd", "ms_style_bwd", "ms_style_ws_bytes",
                              "ms_conv_subpix", "ms_conv3x3_small_cout", "ms_style_bwd_actbwd", "ms_style_bwd_actbwd_parts"))
 
@@ -596,7 +601,8 @@ class InnerLoopEngine:
             # (a 1x1 conv: the launch also derives the BatchNorm-backward coefficients the NEXT launch needs - RideCoef)
             check(self.L("ms_conv2d_ride")(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
                                      N, Cin, Hs, Ws, cout, ks, stride, fetch | wf, pm, pa, pb, pc, pn, 4, slope, epi, 0 if st is None else st.data_ptr(),
-                                     ride.part.data_ptr(), ride.nparts, ride.coef.data_ptr(), ride.count, ride.bc.data_ptr(), ride.C, self._st()), "ms_conv2d_ride:" + name)
+                                     ride.kind, ride.part.data_ptr(), ride.nparts, ride.coef.data_ptr(), 0 if ride.beta is None else ride.beta.data_ptr(), BN_EPS, ride.count,
+                                     ride.bc.data_ptr(), ride.C, self._st()), "ms_conv2d_ride:" + name)
             return out, st, parts
         check(self.L("ms_conv2d")(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
                             N, Cin, Hs, Ws, cout, ks, stride, fetch | wf, pm, pa, pb, pc, pn, 4, slope, epi, 0 if st is None else st.data_ptr(), self._st()),
@@ -837,8 +843,15 @@ class InnerLoopEngine:
             # the block output is never written: its consumer (the segmentation head, ms_head_ce_tail) forms lrelu(bn(u2) + skip) itself from u2, the BatchNorm
             # record and the 1x1 skip conv at low resolution - a plain 1x1 conv here instead of the residual-tail launch
             assert kind == "nn"
-            cf2 = self.bn_fin(pfx + ".bn4", st2, p2, net[key + ".bn4"])
-            sk, _, _ = self.conv(pfx + ".s", x, ci)
+            bn = net[key + ".bn4"]
+            N_, _, H_, W_ = x.shape
+            if self.ride and not self.bn_eval and not isinstance(st2, tuple) and self.bn_observer is None and bn.gamma.numel() <= lib.ms_conv_ride_capacity(N_, H_, W_):
+                # ... and that conv carries the block's ms_bn_finalize job (ms_conv2d_ride kind 1): the head behind it reads the record
+                cf2 = self.t(pfx + ".bn4.coef", bn.gamma.numel(), 4)
+                sk, _, _ = self.conv(pfx + ".s", x, ci, ride=RideCoef(st2, 0, bn.gamma, 0.0, cf2, bn.gamma.numel(), kind=1, beta=bn.beta))
+            else:
+                cf2 = self.bn_fin(pfx + ".bn4", st2, p2, bn)
+                sk, _, _ = self.conv(pfx + ".s", x, ci)
             return ("lazy", u2, cf2, sk)
         xf2 = fused_tail and self._xfin_ok(st2)
         cf2 = None if xf2 else self.bn_fin(pfx + ".bn4", st2, p2, net[key + ".bn4"])
@@ -860,16 +873,19 @@ class InnerLoopEngine:
         out = self.bn_act(pfx + ".out", u2, cf2, s, 2 if kind == "nn" else 1, LEAKY)
         return out
 
-    def res_bwd(self, pfx, net, key, dout, kind, need_dx=True, pre=None, next_act=None, ride_next=False):
+    def res_bwd(self, pfx, net, key, dout, kind, need_dx=True, pre=None, next_act=None, ride_next=False, pool_next=None):
         """dout: gradient w.r.t. the block output (overwritten). Returns the gradient w.r.t. the block input.
         pre = (g2, bcoef) when the producer of `dout` already applied this block's output-activation backward in its epilogue;
         next_act = (bw_name, act_out, u, coef, slope) of the activation BELOW a 'down' block: its backward is then done in the epilogue of this block's
         last data-gradient conv and the return value is the pair (masked gradient, BatchNorm-backward coefficients) for the caller to hand on as `pre`.
-        ride_next: the caller hands that pair to another res_bwd (whose skip conv can carry the coefficient job: RideCoef)."""
+        ride_next: the caller hands that pair to another res_bwd (whose skip conv can carry the coefficient job: RideCoef); pool_next: ... to another
+        up-sampling block's res_bwd, whose skip branch wants pool2_sum of the masked gradient in the buffer of that name: the pair becomes a triple."""
         b = self.buf
         c0, c3, ci = net[key + ".c0"], net[key + ".c3"], net[key + ".ci"]
+        gs_ready = None
         if pre is not None:
-            g2, bc2 = pre
+            g2, bc2 = pre[0], pre[1]
+            gs_ready = pre[2] if len(pre) > 2 else None       # pool2_sum(g2), already written by the producer of g2 (pool_fuse)
         else:
             g2, bc2 = self.act_bwd(pfx + ".bw2", dout, b[pfx + ".out"], b[pfx + ".u2"], b[pfx + ".bn4.coef"], LEAKY, ride=True)
         ride = None
@@ -885,7 +901,7 @@ class InnerLoopEngine:
         # skip branch on the side stream (it only needs g2): its data-gradient lands in the buffer the main chain then ACCUMULATES into
         with self._side(after_main=True):
             if kind == "nn":
-                gs = self.pool2(pfx + ".gs", g2)
+                gs = gs_ready if gs_ready is not None else self.pool2(pfx + ".gs", g2)
                 dx, _, _ = self.conv(pfx + ".dx", gs, ci, dgrad=True, ride=ride)
             else:
                 dsrc, _, _ = self.conv(pfx + ".dsrc", g2, ci, dgrad=True, ride=ride)
@@ -899,6 +915,12 @@ class InnerLoopEngine:
                 N, C, Ho, Wo = dx.shape
                 nparts = lib.ms_act_bwd_parts(N, C, Ho * Wo)
                 part = self.t(bw_name + ".ppart", C, nparts, 2)
+                if pool_next is not None and self.pool_fuse and Ho % 2 == 0 and Wo % 8 == 0:
+                    # ... and the 2x2 sums of the result, which the NEXT block's skip branch (also an up-sampling block) starts from
+                    gs_next = self.a(pool_next, N, C, Ho // 2, Wo // 2)
+                    check(self.L("ms_pool2_actbwd_pool")(dhi.data_ptr(), dx.data_ptr(), dx.data_ptr(), act_out.data_ptr(), u.data_ptr(), coef.data_ptr(), part.data_ptr(),
+                                                   N, C, Ho, Wo, slope, gs_next.data_ptr(), self._st()), "ms_pool2_actbwd_pool:" + pfx)
+                    return dx, self.bwd_coefs(bw_name + ".bcoef", part, nparts, coef, N * Ho * Wo, C, ride=ride_next), gs_next
                 check(self.L("ms_pool2_actbwd")(dhi.data_ptr(), dx.data_ptr(), dx.data_ptr(), act_out.data_ptr(), u.data_ptr(), coef.data_ptr(), part.data_ptr(),
                                           N, C, Ho, Wo, slope, self._st()), "ms_pool2_actbwd:" + pfx)
                 return dx, self.bwd_coefs(bw_name + ".bcoef", part, nparts, coef, N * Ho * Wo, C, ride=ride_next)
@@ -1036,17 +1058,20 @@ class InnerLoopEngine:
             defer_ce = self._tail is not None and loss_slot is self.step_dev
             if defer_ce:
                 self._tail["ce"] = (ws.data_ptr(), nparts, -float(self.loss_sign) / float(N * H * W))
+            gs4 = self.a("s.u4.gs", N, C, H // 2, W // 2) if self.pool_fuse else None      # pool2_sum(dh) for res_bwd's skip branch, written by the head kernel
             check(self.L("ms_head_ce_tail")(u2l.data_ptr(), skl.data_ptr(), cf2l.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), dh.data_ptr(),
                                       0 if defer_ce else self.loss_buf.data_ptr(), 0 if loss_slot is None else loss_slot.data_ptr(), N, C, K, H, W, self.loss_sign,
-                                      ws.data_ptr(), ws.numel(), part.data_ptr(), LEAKY, self._st()), "ms_head_ce_tail")
+                                      ws.data_ptr(), ws.numel(), part.data_ptr(), LEAKY, 0 if gs4 is None else gs4.data_ptr(), self._st()), "ms_head_ce_tail")
             pre = (dh, self.bwd_coefs("s.u4.bw2.bcoef", part, nparts, cf2l, N * H * W, C, ride=True))
+            if gs4 is not None:
+                pre = pre + (gs4,)
             d = dh
             b = self.buf
             for i in range(4, 0, -1):
                 lo = f"s.u{i - 1}"
                 nxt = (lo + ".bw2", b[lo + ".out"], b[lo + ".u2"], b[lo + ".bn4.coef"], LEAKY) if i > 1 else \
                       ("e.cd.bw2", b["e.z_s"], b["e.cd.u2"], b["e.cd.bn4.coef"], 0.0)
-                res = self.res_bwd(f"s.u{i}", self.nets.seg, f"u{i}", d, "nn", pre=pre, next_act=nxt, ride_next=(i > 1))
+                res = self.res_bwd(f"s.u{i}", self.nets.seg, f"u{i}", d, "nn", pre=pre, next_act=nxt, ride_next=(i > 1), pool_next=(f"s.u{i - 1}.gs" if i > 1 else None))
                 pre, d = (res, None) if isinstance(res, tuple) else (None, res)
             return self.encode_bwd(d, pre=pre)
         N, C, H, W = h.shape
@@ -1080,7 +1105,7 @@ class InnerLoopEngine:
             lo = f"s.u{i - 1}"
             nxt = (lo + ".bw2", b[lo + ".out"], b[lo + ".u2"], b[lo + ".bn4.coef"], LEAKY) if i > 1 else \
                   ("e.cd.bw2", b["e.z_s"], b["e.cd.u2"], b["e.cd.bn4.coef"], 0.0)
-            res = self.res_bwd(f"s.u{i}", self.nets.seg, f"u{i}", d, "nn", pre=pre, next_act=nxt, ride_next=(i > 1))
+            res = self.res_bwd(f"s.u{i}", self.nets.seg, f"u{i}", d, "nn", pre=pre, next_act=nxt, ride_next=(i > 1), pool_next=(f"s.u{i - 1}.gs" if i > 1 else None))
             pre, d = (res, None) if isinstance(res, tuple) else (None, res)
         return self.encode_bwd(d, pre=pre)
 

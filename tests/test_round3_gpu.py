@@ -264,8 +264,7 @@ def test_rider_coefficient_jobs_are_bit_identical(dev, monkeypatch, case):
     """ms_conv2d_ride (the 1x1 skip data-gradient of a residual block carries the ms_bn_bwd_coefs job whose result the block's NEXT launch needs, instead of a
     ~5 us launch of its own) against the separate launches: same bits everywhere, including every coefficient record; and the launches really went away."""
     import maxstyle_amd._lib as L
-    calls = {"ride": 0, "coefs": 0}
-    real_ride, real_coefs = L.lib.ms_conv2d_ride, L.lib.ms_bn_bwd_coefs
+    real_ride, real_coefs, real_fin = L.lib.ms_conv2d_ride, L.lib.ms_bn_bwd_coefs, L.lib.ms_bn_finalize
     outs = _switch_ab(dev, monkeypatch, case, "MS_RIDE", "ride")
     _same_bits(outs)
     # launch counts of one eager step with the switch on / off (the engine of each setting is still alive)
@@ -279,6 +278,7 @@ def test_rider_coefficient_jobs_are_bit_identical(dev, monkeypatch, case):
             return f
         monkeypatch.setattr(L.lib, "ms_conv2d_ride", count("ride", real_ride), raising=False)
         monkeypatch.setattr(L.lib, "ms_bn_bwd_coefs", count("coefs", real_coefs), raising=False)
+        monkeypatch.setattr(L.lib, "ms_bn_finalize", count("coefs", real_fin), raising=False)      # (the lazy segmentation tail's ms_bn_finalize rides too: kind 1)
         if case == "bf16":
             real_rb = L.lib.ms_conv2d_ride_bf16
             monkeypatch.setattr(L.lib, "ms_conv2d_ride_bf16", count("ride", real_rb), raising=False)
@@ -361,6 +361,9 @@ def test_lazy_segmentation_tail_is_bit_identical(dev, monkeypatch, net, act):
     to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
     B, size, layers = 4, 64, [3, 4, 5]
     outs = []
+    # (the row mapping of ms_head_ce_tail is the bit-identical one; with MS_POOL_FUSE it owns 2x2 quads and groups the BatchNorm-backward sums differently:
+    #  test_pooled_gradient_from_the_producers)
+    monkeypatch.setenv("MS_POOL_FUSE", "0")
     for flag in ("1", "0"):
         monkeypatch.setenv("MS_LAZY_SEG_TAIL", flag)
         spec = E.NetSpec(*net)
@@ -390,3 +393,39 @@ def test_lazy_segmentation_tail_is_bit_identical(dev, monkeypatch, net, act):
         # (parameters: Adam's first step moves every entry by lr * sign(gradient): a near-zero gradient whose sign differs moves a parameter by 2 * 0.1 -
         # the bound is that, not a rounding bound)
         assert d[0] < 5e-2 and d[1] < 2e-3 * float(outs[1][1].abs().max()) and d[2] <= 0.2 + 1e-6 and d[3] < 0.1 * gmax
+
+
+@pytest.mark.parametrize("case", ["c2small", "bf16", "c2full"])
+def test_pooled_gradient_from_the_producers(dev, monkeypatch, case):
+    """MS_POOL_FUSE: ms_head_ce_tail / ms_pool2_actbwd_pool write pool2_sum of their masked gradient themselves (2x2 pixel quads per thread) - the four
+    ms_pool2_sum launches of the segmentation decoder's backward go away.  The pooled tensors are EXACTLY pool2_sum of the stored gradient; everything else
+    agrees with the separate launches to rounding (the producers' per-thread grouping of the BatchNorm-backward sums follows their pixel mapping)."""
+    from maxstyle_amd import engine as E, synthetic as syn
+    net, B, size, act = {"c2small": ((4, 1, 4), 4, 64, None), "bf16": ((4, 1, 4), 4, 64, torch.bfloat16), "c2full": ((4, 1, 4), 16, 256, None)}[case]
+    spec_o = syn.NetSpec(*net)
+    W = syn.procedural_weights(spec_o, 0)
+    to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
+    layers = [3, 4, 5]
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MS_POOL_FUSE", flag)
+        spec = E.NetSpec(*net)
+        eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1, act_dtype=act)
+        assert eng.pool_fuse == (flag == "1")
+        eng.set_nets(E.PackedNets(spec, to(W["image_encoder"]), to(W["segmentation_decoder"]), to(W["image_decoder"])))
+        img, lab = syn.synthetic_batch(B, size, net[1], net[2], seed=1234)
+        eng.configure_styles(layers, {i: E.StyleSlot(i, B, spec_o.channel_num[i]) for i in layers})
+        for i in layers:
+            st = syn.random_style_state(B, spec_o.channel_num[i], 7 + i)
+            eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
+        z_i = eng.encode_fwd(img.to(dev).to(eng.act_dtype))[0].clone()
+        out = eng.run(z_i, lab.to(dev), 1, use_graph=False).clone()
+        outs.append((out.float(), eng.losses(1).clone(), eng.flat_g.clone()))
+        pool = lambda a: ((a[..., 0::2, 0::2].float() + a[..., 0::2, 1::2].float()) + (a[..., 1::2, 0::2].float() + a[..., 1::2, 1::2].float())).to(a.dtype)
+        for name, src in (("s.u4.gs", "s.dh"), ("s.u3.gs", "s.u4.dx"), ("s.u2.gs", "s.u3.dx"), ("s.u1.gs", "s.u2.dx")):
+            assert torch.equal(eng.buf[name], pool(eng.buf[src])), name             # (both settings: the same tensor, whoever wrote it)
+    gmax = float(outs[1][2].abs().max())
+    d = [float((a.double() - b.double()).abs().max()) for a, b in zip(outs[0], outs[1])]
+    print("pool fuse on/off max diffs (image, loss, grads):", d, "max |grad|", gmax)
+    tol = (2e-2, 2e-3, 5e-2) if act is not None else (5e-6, 1e-6, 2e-5)      # (measured: 7e-7, 0, 1.2e-6 of max |grad|)
+    assert d[0] < tol[0] and d[1] < tol[1] * float(outs[1][1].abs().max()) and d[2] < tol[2] * gmax
