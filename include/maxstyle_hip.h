@@ -27,6 +27,12 @@ const char* ms_last_error(void);
 /* bit of the `fetch` argument of the convolution entry points: the caller accepts the Winograd form for this call (see ms_conv2d) */
 #define MS_FETCH_WINOGRAD 0x100
 #define MS_FETCH_X3 0x200
+/* ms_conv2d epi_mode 6: the 2x2-POOLED store.  out is [N, Cout, H/2, W/2] and receives the sum of every 2x2 block of the convolution's result, in ms_pool2_sum's
+ * order over the values as they would have been stored: the same bits as ms_conv2d + ms_pool2_sum, a quarter of the bytes written and none read back.  The
+ * data-gradient of `conv3x3(nearest-up-sampled x)` (encoder_decoder.py:298-300, 323-337 backward) ends in exactly that sum.  Built for the Winograd form of the
+ * wide kernel only (ks 3, stride 1, MS_FETCH_WINOGRAD; no bias / statistics): ask ms_conv2d_pool2_ok first. */
+#define MS_EPI_POOL2 6
+int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16);
 /* Compute units of the current device (hipDeviceProp.multiProcessorCount, read once per device): every persistent grid and every
  * co-residency bound of the library is sized from it (a partitioned or CU-masked device reports fewer than MI355X's 256). */
 int ms_num_cus(void);
@@ -94,6 +100,10 @@ int ms_pool2_actbwd(const float* in, const float* add, float* out, const float* 
  * rounding (the per-thread grouping of the sums follows the mapping).  Ho even, Wo % 4 == 0. */
 int ms_pool2_actbwd_pool(const float* in, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
                          int N, int C, int Ho, int Wo, float slope, float* pooled, void* stream);
+/* ... whose first operand in_lo [N,C,Ho,Wo] is ALREADY pooled (the data-gradient conv in front stored the 2x2 sums itself: ms_conv2d epi_mode MS_EPI_POOL2);
+ * pooled may be NULL (then: ms_pool2_actbwd's pixel mapping, else ms_pool2_actbwd_pool's). */
+int ms_add_actbwd(const float* in_lo, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
+                  int N, int C, int Ho, int Wo, float slope, float* pooled, void* stream);
 
 /* ms_head_ce (segmentation head + cross entropy + backward to the head input h, custom_loss.py:1043-1078) whose dh is already multiplied by lrelu'(h) - h is the
  * output of the last residual block - and which writes the BatchNorm-backward sums of that block's last BatchNorm (raw input bn_u, record bn_coef4) to
@@ -498,6 +508,8 @@ int ms_conv1x1_bnres_xfin_bf16(const uint16_t* in, uint16_t* out, const float* w
                                float slope, int up2, void* stream);
 int ms_pool2_actbwd_pool_bf16(const uint16_t* in, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
                               int N, int C, int Ho, int Wo, float slope, uint16_t* pooled, void* stream);
+int ms_add_actbwd_bf16(const uint16_t* in_lo, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
+                       int N, int C, int Ho, int Wo, float slope, uint16_t* pooled, void* stream);
 int ms_head_fwd_bf16(const uint16_t* h, const float* w, const float* b, uint16_t* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
 int ms_head_bwd_bf16(const uint16_t* dout, const uint16_t* out, const float* w, uint16_t* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
 int ms_head_ce_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* logits, float* loss_out,

@@ -89,7 +89,8 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   const bool wino_ok = (fetch >= 0) && (fetch & MS_FETCH_WINOGRAD) != 0;
   const bool x3_ok = (fetch >= 0) && (fetch & MS_FETCH_X3) != 0;               // bit 9: ... the three-way bf16 split form
   if (fetch >= 0) fetch &= ~(MS_FETCH_WINOGRAD | MS_FETCH_X3);
-  if (pro_mode < 0 || pro_mode > 3 || epi_mode < 0 || epi_mode > 2 || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
+  if (pro_mode < 0 || pro_mode > 3 || epi_mode < 0 || (epi_mode > 2 && epi_mode != MS_EPI_POOL2) || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
+  if (epi_mode == MS_EPI_POOL2 && (mk != nullptr || fin != nullptr || stats != nullptr || bias != nullptr)) { set_error("ms_conv2d: the pooled epilogue is a plain store (no bias, statistics or mask)"); return MS_ERR_INVALID; }
   // the activation helper computes max(v, v*slope): LeakyReLU / ReLU slopes only
   if ((pro_mode == 1 && !(slope >= 0.f && slope <= 1.f)) || (mk != nullptr && !(mk->slope >= 0.f && mk->slope <= 1.f))) { set_error("ms_conv2d: activation slope outside [0, 1]"); return MS_ERR_INVALID; }
   if (mk != nullptr && mk->mode != 3) {
@@ -213,6 +214,12 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   { static const char* tr = getenv("MS_CONV_TRACE"); a.trace = tr ? (long long*)strtoull(tr, nullptr, 0) : nullptr; }
   hipStream_t st = (hipStream_t)stream;
   const bool use_in2 = (pro_mode == 2);
+  if (epi_mode == MS_EPI_POOL2) {
+    if (!(allow_wide && conv_wide_eligible(a, ks, stride, fetch, vec) && conv_wide_is_wino(a) && a.Hout % 2 == 0)) {
+      set_error("ms_conv2d: the pooled epilogue needs the Winograd form of the wide kernel (ms_conv2d_pool2_ok)"); return MS_ERR_INVALID;
+    }
+    return conv_dispatch_wide(a, nt, st);
+  }
   if (allow_wide && conv_wide_eligible(a, ks, stride, fetch, vec)) return conv_dispatch_wide(a, nt, st);
   if (ks == 3 && stride == 1) return conv_dispatch_k3s1(a, fetch, nt, vec, narrow, use_in2, st);
   if (ks == 1) return conv_dispatch_k1s1(a, nt, vec, narrow, use_in2, st);
@@ -229,6 +236,15 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
 
 // ms_conv2d (a 1x1 conv) that also carries a ms_bn_bwd_coefs (ride_kind 0) or ms_bn_finalize (ride_kind 1) job for the launch BEHIND it: one MFMA wave per channel
 // derives out4[c] while the staging waves fetch (ConvArgs::ride_*).  The conv itself neither reads nor waits for out4; ride_C must not exceed the launch's workgroup count (checked).
+// whether ms_conv2d(ks 3, stride 1, fetch MS_FETCH_WINOGRAD, epi_mode MS_EPI_POOL2) is built for this shape (16-byte aligned tensors assumed; bf16: activation storage)
+extern "C" int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16) {
+  if (N < 1 || Cin < 1 || H < 2 || W < 4 || Cout < 1 || H % 2 != 0 || W % 4 != 0 || pro_mode < 0 || pro_mode > 2) return 0;
+  ConvArgs a{};
+  a.N = N; a.Cin = Cin; a.Hs = a.Hin = a.Hout = H; a.Ws = a.Win = a.Wout = W; a.Cout = a.cout_real = Cout;
+  a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (Cout + 63) / 64 * 64;
+  a.pro_mode = pro_mode; a.epi_mode = MS_EPI_POOL2; a.wino_ok = 1; a.act_bf16 = bf16 ? 1 : 0;
+  return (conv_wide_eligible(a, 3, 1, FETCH_NORMAL, true) && conv_wide_is_wino(a)) ? 1 : 0;
+}
 // channels a rider may have on a conv launch with this output shape (a lower bound of 4 x its workgroup count: one channel block, one workgroup per CU)
 extern "C" int ms_conv_ride_capacity(int N, int Hout, int Wout) {
   if (N < 1 || Hout < 1 || Wout < 1) return 0;

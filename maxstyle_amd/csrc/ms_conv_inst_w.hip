@@ -50,6 +50,7 @@ static bool conv_x3_on(const ConvArgs& a) {
   if (mode == 0 || (mode == 1 && !a.x3_ok)) return false;
   return a.act_bf16 == 0 && a.cin_pad % 8 == 0 && a.Cin == a.cin_pad && a.Wout >= 64;
 }
+bool conv_wide_is_wino(const ConvArgs& a) { return !conv_x3_on(a) && ((a.Wout < 64 && a.act_bf16 != 2) || conv_wino_on(a)); }
 int conv_dispatch_wide(const ConvArgs& a, int nt, hipStream_t st) {
   if (conv_x3_on(a)) return conv_dispatch_x3(a, st);
   if ((a.Wout < 64 && a.act_bf16 != 2) || conv_wino_on(a)) return conv_dispatch_wino(a, st);      // (rows below 64 pixels: conv_wide_eligible admitted them for this form only)

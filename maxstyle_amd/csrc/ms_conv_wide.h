@@ -1087,6 +1087,20 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
             }
           }
         }
+      } else if (a.epi_mode == 6) {
+        // 2x2-POOLED store (MS_EPI_POOL2): out is [N, Cout, Hout/2, Wout/2] and receives the sum of every 2x2 block of the result - the lane's 2 rows x 8 pixels
+        // are four such blocks (the Winograd output tiles themselves), summed in ms_pool2_sum's order (a.x + a.y) + (b.x + b.y) over the values as they would
+        // have been STORED (bf16 storage: rounded first): the same bits as ms_conv2d + ms_pool2_sum, a quarter of the bytes written and none read back.
+        auto rt = [](float v) { if constexpr (AB == 2) return IO::up(ms_to_bf16(v)); else return v; };
+        const size_t offp = (((size_t)n * a.Cout + co) * (size_t)(a.Hout >> 1) + (size_t)(y0 >> 1)) * (size_t)(a.Wout >> 1) + (size_t)(xb >> 1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          if (ok[0][q] && ok[1][q]) {
+            const float p0 = (rt(o[0][4 * q]) + rt(o[0][4 * q + 1])) + (rt(o[1][4 * q]) + rt(o[1][4 * q + 1]));
+            const float p1 = (rt(o[0][4 * q + 2]) + rt(o[0][4 * q + 3])) + (rt(o[1][4 * q + 2]) + rt(o[1][4 * q + 3]));
+            IO::st2(a.out, offp + 2 * q, make_float2(p0, p1));
+          }
+        }
       } else if (!(a.dbg & 4)) {
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
@@ -1371,6 +1385,7 @@ inline int conv_wide_rows(const ConvArgs& a, int nt) {
 // wide-read path: 3x3 stride 1, plain fetch, 16-byte aligned rows, per-channel prologue coefficients; implemented in ms_conv_inst_w.hip
 bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool vec);
 int conv_dispatch_wide(const ConvArgs& a, int nt, hipStream_t st);
+bool conv_wide_is_wino(const ConvArgs& a);      // conv_dispatch_wide would run the Winograd form (the only one with the pooled epilogue, epi_mode 6)
 int conv_dispatch_wide8(const ConvArgs& a, int nt, hipStream_t st);      // ms_conv_inst_w2.hip: the 8-row tiles
 
 }  // namespace ms

@@ -189,7 +189,8 @@ template <typename AT = float, bool POOL = false>
 __global__ __launch_bounds__(kElemThreads) void pool2_actbwd_kernel(const void* __restrict__ in, const void* __restrict__ add, void* __restrict__ gout,
                                                                     const void* __restrict__ act, const void* __restrict__ u, const float4* __restrict__ coef,
                                                                     float2* __restrict__ part, int C, int Ho, int Wo, int chunk, int S, int N, float slope,
-                                                                    void* __restrict__ pooled) {
+                                                                    void* __restrict__ pooled, int in_lo) {
+  // in_lo: `in` is ALREADY pooled ([N,C,Ho,Wo]: the conv in front stored 2x2 sums itself, MS_EPI_POOL2) - same arithmetic from there on
   __shared__ float red[16];
   const int p = blockIdx.y, c = p % C, n = p / C;
   const float mean = coef[c].z;
@@ -206,10 +207,15 @@ __global__ __launch_bounds__(kElemThreads) void pool2_actbwd_kernel(const void* 
       float2 v[2];
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const size_t r0 = ipb + (size_t)(4 * yq + 2 * r) * (2 * Wo) + 4 * xq;
-        const float4 a0 = IO::ld4(in, r0), b0 = IO::ld4(in, r0 + 2 * Wo);
-        float2 t = make_float2((a0.x + a0.y) + (b0.x + b0.y), (a0.z + a0.w) + (b0.z + b0.w));
         const size_t o = base + (size_t)(2 * yq + r) * Wo + 2 * xq;
+        float2 t;
+        if (in_lo) {
+          t = IO::ld2(in, o);
+        } else {
+          const size_t r0 = ipb + (size_t)(4 * yq + 2 * r) * (2 * Wo) + 4 * xq;
+          const float4 a0 = IO::ld4(in, r0), b0 = IO::ld4(in, r0 + 2 * Wo);
+          t = make_float2((a0.x + a0.y) + (b0.x + b0.y), (a0.z + a0.w) + (b0.z + b0.w));
+        }
         if (add != nullptr) { const float2 qq = IO::ld2(add, o); t.x = qq.x + t.x; t.y = qq.y + t.y; }
         const float2 rr = IO::ld2(act, o);
         const float2 uu = IO::ld2(u, o);
@@ -223,10 +229,15 @@ __global__ __launch_bounds__(kElemThreads) void pool2_actbwd_kernel(const void* 
       IO::st1(pooled, (size_t)p * (HWo >> 2) + q, (rt(v[0].x) + rt(v[0].y)) + (rt(v[1].x) + rt(v[1].y)));
     } else {
     const int y = i / Wo, x = i - y * Wo;                       // Wo % 4 == 0: the quad stays in one row
-    const size_t r0 = ipb + (size_t)(2 * y) * (2 * Wo) + 2 * x;
-    const float4 a0 = IO::ld4(in, r0), a1 = IO::ld4(in, r0 + 4);
-    const float4 b0 = IO::ld4(in, r0 + 2 * Wo), b1 = IO::ld4(in, r0 + 2 * Wo + 4);
-    float4 v = make_float4((a0.x + a0.y) + (b0.x + b0.y), (a0.z + a0.w) + (b0.z + b0.w), (a1.x + a1.y) + (b1.x + b1.y), (a1.z + a1.w) + (b1.z + b1.w));
+    float4 v;
+    if (in_lo) {
+      v = IO::ld4(in, base + i);
+    } else {
+      const size_t r0 = ipb + (size_t)(2 * y) * (2 * Wo) + 2 * x;
+      const float4 a0 = IO::ld4(in, r0), a1 = IO::ld4(in, r0 + 4);
+      const float4 b0 = IO::ld4(in, r0 + 2 * Wo), b1 = IO::ld4(in, r0 + 2 * Wo + 4);
+      v = make_float4((a0.x + a0.y) + (b0.x + b0.y), (a0.z + a0.w) + (b0.z + b0.w), (a1.x + a1.y) + (b1.x + b1.y), (a1.z + a1.w) + (b1.z + b1.w));
+    }
     if (add != nullptr) { const float4 q = IO::ld4(add, base + i); v.x = q.x + v.x; v.y = q.y + v.y; v.z = q.z + v.z; v.w = q.w + v.w; }
     const float4 r = IO::ld4(act, base + i);
     const float4 uu = IO::ld4(u, base + i);
@@ -762,7 +773,7 @@ extern "C" int ms_pool2_sum_bf16(const uint16_t* in, uint16_t* out, int planes, 
 // or == out), out, act, u [N,C,Ho,Wo]; Wo % 4 == 0, 16-byte aligned.
 template <typename AT>
 static int pool2_actbwd_impl(const void* in, const void* add, void* out, const void* act, const void* u, const float* coef4, float* part2,
-                             int N, int C, int Ho, int Wo, float slope, void* stream, void* pooled = nullptr) {
+                             int N, int C, int Ho, int Wo, float slope, void* stream, void* pooled = nullptr, int in_lo = 0) {
   if (N < 1 || C < 1 || Ho < 1 || Wo < 4 || Wo % 4 != 0) { set_error("ms_pool2_actbwd: invalid shape (Wo %% 4 == 0)"); return MS_ERR_INVALID; }
   if ((long)N * C > 65535) { set_error("ms_pool2_actbwd: too many planes"); return MS_ERR_INVALID; }
   if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(u) |
@@ -771,11 +782,11 @@ static int pool2_actbwd_impl(const void* in, const void* add, void* out, const v
   if (pooled != nullptr) {
     if (Ho % 2 != 0 || (reinterpret_cast<uintptr_t>(pooled) & 3u) != 0) { set_error("ms_pool2_actbwd_pool: even Ho, 4-byte aligned pooled"); return MS_ERR_INVALID; }
     MS_LAUNCH((pool2_actbwd_kernel<AT, true>), dim3(sp.S, N * C), dim3(kElemThreads), 0, (hipStream_t)stream, in, add, out, act, u, (const float4*)coef4, (float2*)part2,
-              C, Ho, Wo, sp.chunk, sp.S, N, slope, pooled);
+              C, Ho, Wo, sp.chunk, sp.S, N, slope, pooled, in_lo);
     return check_launch("pool2_actbwd_pool");
   }
   MS_LAUNCH((pool2_actbwd_kernel<AT, false>), dim3(sp.S, N * C), dim3(kElemThreads), 0, (hipStream_t)stream, in, add, out, act, u, (const float4*)coef4, (float2*)part2,
-            C, Ho, Wo, sp.chunk, sp.S, N, slope, (void*)nullptr);
+            C, Ho, Wo, sp.chunk, sp.S, N, slope, (void*)nullptr, in_lo);
   return check_launch("pool2_actbwd");
 }
 extern "C" int ms_pool2_actbwd(const float* in, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
@@ -792,6 +803,15 @@ extern "C" int ms_pool2_actbwd_pool_bf16(const uint16_t* in, const uint16_t* add
                                          int N, int C, int Ho, int Wo, float slope, uint16_t* pooled, void* stream) {
   if (pooled == nullptr) { set_error("ms_pool2_actbwd_pool: pooled is required"); return MS_ERR_INVALID; }
   return pool2_actbwd_impl<ms_bf16>(in, add, out, act, u, coef4, part2, N, C, Ho, Wo, slope, stream, pooled);
+}
+// ms_pool2_actbwd[_pool] whose `in_lo` [N,C,Ho,Wo] is already the pooled tensor (the conv in front stored the 2x2 sums itself: MS_EPI_POOL2); pooled may be NULL.
+extern "C" int ms_add_actbwd(const float* in_lo, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
+                             int N, int C, int Ho, int Wo, float slope, float* pooled, void* stream) {
+  return pool2_actbwd_impl<float>(in_lo, add, out, act, u, coef4, part2, N, C, Ho, Wo, slope, stream, pooled, 1);
+}
+extern "C" int ms_add_actbwd_bf16(const uint16_t* in_lo, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
+                                  int N, int C, int Ho, int Wo, float slope, uint16_t* pooled, void* stream) {
+  return pool2_actbwd_impl<ms_bf16>(in_lo, add, out, act, u, coef4, part2, N, C, Ho, Wo, slope, stream, pooled, 1);
 }
 extern "C" int ms_pool2_actbwd_bf16(const uint16_t* in, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
                                     int N, int C, int Ho, int Wo, float slope, void* stream) {

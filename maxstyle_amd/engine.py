@@ -26,6 +26,7 @@ import torch
 from . import ops
 from ._lib import lib, check
 
+EPI_POOL2 = 6          # include/maxstyle_hip.h MS_EPI_POOL2
 LEAKY = 0.2
 BN_EPS = 1e-5
 F32 = torch.float32
@@ -361,6 +362,9 @@ class InnerLoopEngine:
         # pooled tensor themselves: no ms_pool2_sum launch in res_bwd (MS_POOL_FUSE=0 is the A/B switch; results agree to rounding - the producers' per-thread
         # grouping of the BatchNorm-backward sums changes with their pixel mapping)
         self.pool_fuse = os.environ.get("MS_POOL_FUSE", "1") != "0" and type(self) is InnerLoopEngine
+        # the data-gradient of an up-sampling block's first conv stores the 2x2 sums of its result itself (ms_conv2d epi_mode MS_EPI_POOL2, Winograd form):
+        # the full-resolution gradient is never written or read back (MS_POOL_EPI=0 is the A/B switch; bit-identical in fp32 storage)
+        self.pool_epi = os.environ.get("MS_POOL_EPI", "1") != "0" and type(self) is InnerLoopEngine
         self.lazy_seg_tail = os.environ.get("MS_LAZY_SEG_TAIL", "1") != "0" and type(self) is InnerLoopEngine      # ms_head_ce_tail (see seg_loss)
         # cross-workgroup finalize (`_xfin` entry points): the BatchNorm coefficients a launch consumes are derived INSIDE that launch (one wave per channel,
         # published through tagged granules) instead of by an ms_bn_finalize launch in front of it.  Needs every workgroup of a launch co-resident: not with
@@ -394,7 +398,7 @@ class InnerLoopEngine:
         """An ACTIVATION tensor (conv inputs / outputs, gradients, images): fp32, or bf16 storage in bf16 mode (everything else stays fp32)."""
         return self.t(name, *shape, dtype=self.act_dtype)
 
-    _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv2d_ride", "ms_conv2d_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd", "ms_pool2_actbwd_pool",
+    _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv2d_ride", "ms_conv2d_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd", "ms_pool2_actbwd_pool", "ms_add_actbwd",
                              "ms_head_fwd", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_head_ce_tail", "ms_style_fwd", "ms_style_bwd", "ms_style_ws_bytes",
                              "ms_conv_subpix", "ms_conv3x3_small_cout", "ms_style_bwd_actbwd", "ms_style_bwd_actbwd_parts"))
 
@@ -552,7 +556,7 @@ class InnerLoopEngine:
             cout = cw.cin if dgrad else cw.cout
         Ho, Wo = ops.conv_out_hw(Hs, Ws, ks, stride, fetch)
         if out is None:
-            out = self.a(name, N, cout, 2 * Ho, 2 * Wo) if epi == 2 else self.a(name, N, cout, Ho, Wo)
+            out = self.a(name, N, cout, 2 * Ho, 2 * Wo) if epi == 2 else (self.a(name, N, cout, Ho // 2, Wo // 2) if epi == EPI_POOL2 else self.a(name, N, cout, Ho, Wo))
         st = None
         parts = 0
         if stats and self.bn_eval:
@@ -908,8 +912,13 @@ class InnerLoopEngine:
         g1, bc1 = self.dgrad_act_bwd(pfx + ".da1", pfx + ".bw1", g2, c3, (bc2, b[pfx + ".u2"]), b[pfx + ".u1"], b[pfx + ".bn1.coef"], LEAKY)
         self._join_side()
         if kind == "nn":
-            dhi, _, _ = self.conv(pfx + ".dhi", g1, c0, bnbwd=(bc1, b[pfx + ".u1"]), dgrad=True)   # at the up-sampled resolution
-            if next_act is not None and self.fuse_act_bwd and not self.bn_eval and dx.shape[3] % 4 == 0 and dx.shape[0] * dx.shape[1] <= 65535:
+            fused_next = next_act is not None and self.fuse_act_bwd and not self.bn_eval and dx.shape[3] % 4 == 0 and dx.shape[0] * dx.shape[1] <= 65535
+            Ng, Cg, Hg, Wg = g1.shape
+            pooled_epi = (fused_next and self.pool_epi and self.winograd and
+                          lib.ms_conv2d_pool2_ok(Ng, Cg, Hg, Wg, c0.cin, 2, int(self.bf16)) == 1)
+            # at the up-sampled resolution - or, pooled_epi, already summed 2x2 by the conv's epilogue (the full-resolution gradient is never written)
+            dhi, _, _ = self.conv(pfx + (".dlo" if pooled_epi else ".dhi"), g1, c0, bnbwd=(bc1, b[pfx + ".u1"]), dgrad=True, epi=(EPI_POOL2 if pooled_epi else 0))
+            if fused_next:
                 # pool + accumulate + the output-activation backward of the block below in one pass (ms_pool2_actbwd)
                 bw_name, act_out, u, coef, slope = next_act
                 N, C, Ho, Wo = dx.shape
@@ -918,11 +927,16 @@ class InnerLoopEngine:
                 if pool_next is not None and self.pool_fuse and Ho % 2 == 0 and Wo % 8 == 0:
                     # ... and the 2x2 sums of the result, which the NEXT block's skip branch (also an up-sampling block) starts from
                     gs_next = self.a(pool_next, N, C, Ho // 2, Wo // 2)
-                    check(self.L("ms_pool2_actbwd_pool")(dhi.data_ptr(), dx.data_ptr(), dx.data_ptr(), act_out.data_ptr(), u.data_ptr(), coef.data_ptr(), part.data_ptr(),
-                                                   N, C, Ho, Wo, slope, gs_next.data_ptr(), self._st()), "ms_pool2_actbwd_pool:" + pfx)
+                    check(self.L("ms_add_actbwd" if pooled_epi else "ms_pool2_actbwd_pool")(dhi.data_ptr(), dx.data_ptr(), dx.data_ptr(), act_out.data_ptr(), u.data_ptr(),
+                                                                                      coef.data_ptr(), part.data_ptr(), N, C, Ho, Wo, slope, gs_next.data_ptr(), self._st()),
+                          "ms_pool2_actbwd_pool:" + pfx)
                     return dx, self.bwd_coefs(bw_name + ".bcoef", part, nparts, coef, N * Ho * Wo, C, ride=ride_next), gs_next
-                check(self.L("ms_pool2_actbwd")(dhi.data_ptr(), dx.data_ptr(), dx.data_ptr(), act_out.data_ptr(), u.data_ptr(), coef.data_ptr(), part.data_ptr(),
-                                          N, C, Ho, Wo, slope, self._st()), "ms_pool2_actbwd:" + pfx)
+                if pooled_epi:
+                    check(self.L("ms_add_actbwd")(dhi.data_ptr(), dx.data_ptr(), dx.data_ptr(), act_out.data_ptr(), u.data_ptr(), coef.data_ptr(), part.data_ptr(),
+                                            N, C, Ho, Wo, slope, 0, self._st()), "ms_add_actbwd:" + pfx)
+                else:
+                    check(self.L("ms_pool2_actbwd")(dhi.data_ptr(), dx.data_ptr(), dx.data_ptr(), act_out.data_ptr(), u.data_ptr(), coef.data_ptr(), part.data_ptr(),
+                                              N, C, Ho, Wo, slope, self._st()), "ms_pool2_actbwd:" + pfx)
                 return dx, self.bwd_coefs(bw_name + ".bcoef", part, nparts, coef, N * Ho * Wo, C, ride=ride_next)
             self.pool2(pfx + ".dx", dhi, out=dx, accumulate=True)
             return dx

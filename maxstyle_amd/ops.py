@@ -155,6 +155,7 @@ def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8, step_dev=None):
 # ---------------------------------------------------------------------------------------------------------
 FETCH_NORMAL, FETCH_UPS2, FETCH_ZINS2 = 0, 1, 2
 FETCH_X3 = 0x200            # MS_FETCH_X3: the caller accepts the three-way bf16 split form (fp32-faithful, bf16 matrix cores)
+EPI_POOL2 = 6                # ms_conv2d epi_mode: 2x2-pooled store (MS_EPI_POOL2)
 FETCH_WINOGRAD = 0x100      # MS_FETCH_WINOGRAD: OR into fetch = the caller accepts the Winograd form of a 3x3 stride-1 convolution (include/maxstyle_hip.h)
 
 
@@ -205,7 +206,7 @@ def conv2d(x, wp, bias, Cout, ks, stride=1, fetch=FETCH_NORMAL, pro_mode=0, pro_
     N, Cin, Hs, Ws = x.shape
     Ho, Wo = conv_out_hw(Hs, Ws, ks, stride, fetch & 0xFF)
     if out is None:
-        shape = (N, Cout, 2 * Ho, 2 * Wo) if epi_mode == 2 else (N, Cout, Ho, Wo)
+        shape = (N, Cout, 2 * Ho, 2 * Wo) if epi_mode == 2 else ((N, Cout, Ho // 2, Wo // 2) if epi_mode == EPI_POOL2 else (N, Cout, Ho, Wo))
         if epi_mode == 1:
             raise ValueError("accumulate epilogue needs an existing `out`")
         out = torch.empty(shape, device=x.device, dtype=x.dtype)

@@ -429,3 +429,47 @@ def test_pooled_gradient_from_the_producers(dev, monkeypatch, case):
     print("pool fuse on/off max diffs (image, loss, grads):", d, "max |grad|", gmax)
     tol = (2e-2, 2e-3, 5e-2) if act is not None else (5e-6, 1e-6, 2e-5)      # (measured: 7e-7, 0, 1.2e-6 of max |grad|)
     assert d[0] < tol[0] and d[1] < tol[1] * float(outs[1][1].abs().max()) and d[2] < tol[2] * gmax
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64, 0), (2, 16, 16, 64, 64, 2), (3, 64, 32, 32, 32, 2), (2, 32, 16, 72, 96, 2), (1, 16, 16, 256, 256, 0)])
+@pytest.mark.parametrize("act", [None, torch.bfloat16])
+def test_pooled_epilogue_is_conv_plus_pool2_sum(dev, shape, act):
+    """ms_conv2d epi_mode MS_EPI_POOL2 (the Winograd epilogue stores the 2x2 sums of its result: the data-gradient of conv3x3(up-sampled x)) == ms_conv2d +
+    ms_pool2_sum, bit for bit (fp32 and bf16 storage; 64- and 32-pixel tiles, ragged tiles, with and without the two-tensor BatchNorm-backward prologue)."""
+    from maxstyle_amd import ops
+    import maxstyle_amd._lib as L
+    N, Cin, Cout, H, W, pm = shape
+    assert L.lib.ms_conv2d_pool2_ok(N, Cin, H, W, Cout, pm, int(act is not None)) == 1
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    x, x2, w = rnd(N, Cin, H, W), rnd(N, Cin, H, W), rnd(Cout, Cin, 3, 3) * 0.1
+    wp = ops.pack_conv_weight(w).to(dev)
+    dt = act or torch.float32
+    xd, x2d = x.to(dev).to(dt), x2.to(dev).to(dt)
+    kw = {}
+    if pm == 2:
+        cf = torch.stack([rnd(Cin) * 0.3 + 1.0, rnd(Cin) * 0.2, rnd(Cin) * 0.1, torch.zeros(Cin)], 1).contiguous().to(dev)
+        pa, pb, pc = ops.coef_ptrs(cf)
+        kw = dict(pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=x2d)
+    full = ops.conv2d(xd, wp, None, Cout, 3, 1, fetch=ops.FETCH_WINOGRAD, **kw)
+    ref = torch.empty(N, Cout, H // 2, W // 2, device=dev, dtype=dt)
+    fn = L.lib.ms_pool2_sum_bf16 if act is not None else L.lib.ms_pool2_sum
+    L.check(fn(full.data_ptr(), ref.data_ptr(), N * Cout, H // 2, W // 2, 0, 0), "ms_pool2_sum")
+    got = ops.conv2d(xd, wp, None, Cout, 3, 1, fetch=ops.FETCH_WINOGRAD, epi_mode=ops.EPI_POOL2, **kw)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    assert L.lib.ms_conv2d_pool2_ok(2, 16, 16, 16, 16, 0, 0) == 0          # 16-pixel rows: the first-generation kernel's, no pooled epilogue
+
+
+@pytest.mark.parametrize("case", ["c2small", "c2full", "bf16"])
+def test_pooled_data_gradient_in_the_loop(dev, monkeypatch, case):
+    """MS_POOL_EPI (the up-sampling blocks' first data-gradient conv stores 2x2 sums; ms_add_actbwd behind it) against the full-resolution gradient + pooling
+    pass: same bits in fp32 storage (bf16: the pooled sum is rounded once more on its way through memory)."""
+    outs = _switch_ab(dev, monkeypatch, case, "MS_POOL_EPI", "pool_epi")
+    assert any(k.endswith(".dlo") for k in outs[0][2].buf) and not any(k.endswith(".dlo") for k in outs[1][2].buf)
+    if case != "bf16":
+        _same_bits(outs)
+    else:
+        d = [float((a.double() - b.double()).abs().max()) for a, b in zip(outs[0][0], outs[1][0])]
+        print("pooled epilogue bf16 max diffs (image, losses, params):", d)
+        assert d[0] < 5e-2 and d[1] < 5e-3 * float(outs[1][0][1].abs().max())
