@@ -11,7 +11,8 @@ import torch  # noqa: F401  MUST precede the CDLL below: PyTorch-ROCm ships its 
                # runtimes and ours reports 'no ROCm-capable device' on the first launch.
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmaxstyle_hip.so")
+# MS_LIB: an alternative build of the same library (A/B timing of compile-time choices: `make BUILD=.. OUT=.. EXTRA=-D..` in csrc/); default = the in-tree build
+LIB_PATH = os.environ.get("MS_LIB") or os.path.join(_HERE, "lib", "libmaxstyle_hip.so")
 
 c_f32p = ctypes.c_void_p   # raw device pointers travel as integers
 c_i64p = ctypes.c_void_p

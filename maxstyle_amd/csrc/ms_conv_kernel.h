@@ -29,6 +29,9 @@ enum { FETCH_NORMAL = 0, FETCH_UPS2 = 1, FETCH_ZINS2 = 2 };
 #endif
 
 typedef unsigned long long conv_u64_t;
+#ifndef MS_CONV_S2_CK
+#define MS_CONV_S2_CK 8        // input channels per chunk of the stride-2 kernels with a 16-channel tile (see Geo::CK)
+#endif
 struct ConvArgs {
   const float* in; const float* in2; float* out; const float* w; const float* bias;
   const float* pro_a; const float* pro_b; const float* pro_c;
@@ -380,7 +383,7 @@ struct Geo {
   // one slot = 2 stored values = 4 logical columns (UPS2: both logical rows 2sr-1, 2sr; ZINS2: logical row 2sr+1, odd columns 0)
   static constexpr bool EXP = VEC && (FETCH != FETCH_NORMAL);
   // input channels per K-chunk: sized so that two LDS buffers of (input tile + weight slice) leave >= 2 workgroups per CU
-  static constexpr int CK = (STRIDE == 1 && VEC && NT == 1) ? 16 : ((STRIDE == 2 && NT > 1) ? 4 : 8);
+  static constexpr int CK = (STRIDE == 1 && VEC && NT == 1) ? 16 : ((STRIDE == 2 && NT > 1) ? 4 : ((STRIDE == 2) ? MS_CONV_S2_CK : 8));
   static constexpr int VW = EXP ? 2 : (VEC ? 4 : 1);                       // elements per staging load
   static constexpr int SR = EXP ? ((FETCH == FETCH_UPS2) ? IH / 2 + 1 : IH / 2) : IH;   // staged rows per channel
   static constexpr int ROW_ITEMS = EXP ? WIN_W / 4 : WIN_W / VW;           // VEC: WIN_W % 4 == 0 by construction

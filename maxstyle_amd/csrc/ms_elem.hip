@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_kernel(const void* __res
     for (int c = 0; c < C; ++c) {
       const float v = IO::ld1(h, hb + (size_t)c * HW + i);
 #pragma unroll
-      for (int k = 0; k < kMaxHeadK; ++k) if (k < K) z[k] += sw[k * C + c] * v;
+      for (int k = 0; k < kMaxHeadK; ++k) if (k < K) z[k] = __builtin_fmaf(sw[k * C + c], v, z[k]);
     }
     float mx = z[0];
 #pragma unroll
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_kernel(const void* __res
       for (int c = 0; c < C; ++c) {
         float a = 0.f;
 #pragma unroll
-        for (int k = 0; k < kMaxHeadK; ++k) if (k < K) a += sw[k * C + c] * d[k];
+        for (int k = 0; k < kMaxHeadK; ++k) if (k < K) a = __builtin_fmaf(sw[k * C + c], d[k], a);
         IO::st1(dh, ((size_t)n * C + c) * HW + i, a);
       }
     }
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const void
         for (int k = 0; k < kMaxHeadK; ++k)
           if (k < K) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) z[k][e] += sw[k * C + c] * hv[c][e];
+            for (int e = 0; e < VEC; ++e) z[k][e] = __builtin_fmaf(sw[k * C + c], hv[c][e], z[k][e]);
           }
       }
     }
@@ -463,11 +463,11 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const void
         for (int e = 0; e < VEC; ++e) {
           float t = 0.f;
 #pragma unroll
-          for (int k = 0; k < kMaxHeadK; ++k) if (k < K) t += sw[k * C + c] * d[k][e];
+          for (int k = 0; k < kMaxHeadK; ++k) if (k < K) t = __builtin_fmaf(sw[k * C + c], d[k][e], t);
           t *= (hv[c][e] > 0.f) ? 1.f : slope;
           a[e] = t;
           b1[c] += t;
-          b2[c] += t * (uu[e] - smean[c]);
+          b2[c] = __builtin_fmaf(t, uu[e] - smean[c], b2[c]);
         }
         if (VEC == 4) IO::st4(dh, ((size_t)n * C + c) * HW + i, make_float4(a[0], a[1 % VEC], a[2 % VEC], a[3 % VEC]));
         else IO::st1(dh, ((size_t)n * C + c) * HW + i, a[0]);
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_tail_kernel(const void* 
       for (int e = 0; e < 4; ++e) {
         pos[c >> 3] |= (hv[e] > 0.f ? 1u : 0u) << (4 * (c & 7) + e);
 #pragma unroll
-        for (int k = 0; k < K; ++k) z[k][e] += w[k * C + c] * hv[e];
+        for (int k = 0; k < K; ++k) z[k][e] = __builtin_fmaf(w[k * C + c], hv[e], z[k][e]);
       }
     }
     float d[K][4];
@@ -592,11 +592,11 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_tail_kernel(const void* 
       for (int e = 0; e < 4; ++e) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < K; ++k) t += w[k * C + c] * d[k][e];
+        for (int k = 0; k < K; ++k) t = __builtin_fmaf(w[k * C + c], d[k][e], t);
         t *= ((pos[c >> 3] >> (4 * (c & 7) + e)) & 1u) ? 1.f : slope;
         a[e] = t;
         b1[c] += t;
-        b2[c] += t * (uq[e] - mean);
+        b2[c] = __builtin_fmaf(t, uq[e] - mean, b2[c]);
       }
       if constexpr (POOL) {
         IO::st2(db + c * pu + ou, 0, make_float2(a[0], a[1]));
