@@ -32,7 +32,7 @@ const char* ms_last_error(void);
  * data-gradient of `conv3x3(nearest-up-sampled x)` (encoder_decoder.py:298-300, 323-337 backward) ends in exactly that sum.  Built for the Winograd form of the
  * wide kernel only (ks 3, stride 1, MS_FETCH_WINOGRAD; no bias / statistics): ask ms_conv2d_pool2_ok first. */
 #define MS_EPI_POOL2 6
-int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16);
+int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16);      /* bf16: 0 = the fp32 entry point, 1 = `_bf16`, 2 = `_bf16m` */
 /* Compute units of the current device (hipDeviceProp.multiProcessorCount, read once per device): every persistent grid and every
  * co-residency bound of the library is sized from it (a partitioned or CU-masked device reports fewer than MI355X's 256). */
 int ms_num_cus(void);
@@ -445,6 +445,12 @@ int ms_confusion(const float* logits, const int64_t* labels, unsigned long long*
  *                pixel NLL / (N*H*W)); writes loss_out[*loss_slot_dev or 0], dh = d loss / d h (NULL to skip) and the
  *                logits (NULL to skip).  The inner loop uses loss_sign = -1 (advanced_triplet...py:555). */
 int ms_head_fwd(const float* h, const float* w, const float* b, float* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
+/* ms_style_fwd's restyle + ms_head_fwd in one pass, for a MaxStyle layer that sits directly in front of the 1x1 head (apply_max_style: layer 4 -> final_conv ->
+ * Sigmoid, encoder_decoder.py:598-631): x [N,C,HW] is the layer's INPUT, (mu, sig, coefA, coefS) [N*C] what ms_style_fwd - called with y = NULL: statistics and
+ * coefficients only - left; y = coefA/sig * (x - mu) + coefS (maxstyle.py:157-188) is formed per element with the layer's own expression and rounding and never
+ * written: same bits in `out` as ms_style_fwd + ms_head_fwd. */
+int ms_head_fwd_styled(const float* x, const float* mu, const float* sig, const float* coefA, const float* coefS, const float* w, const float* b, float* out,
+                       int N, int C, int K, int HW, int apply_sigmoid, void* stream);
 int ms_head_bwd(const float* dout, const float* out, const float* w, float* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
 size_t ms_head_ce_ws_bytes(int N, int HW);
 int ms_head_ce(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* logits, float* loss_out,
@@ -511,6 +517,8 @@ int ms_pool2_actbwd_pool_bf16(const uint16_t* in, const uint16_t* add, uint16_t*
 int ms_add_actbwd_bf16(const uint16_t* in_lo, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
                        int N, int C, int Ho, int Wo, float slope, uint16_t* pooled, void* stream);
 int ms_head_fwd_bf16(const uint16_t* h, const float* w, const float* b, uint16_t* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
+int ms_head_fwd_styled_bf16(const uint16_t* x, const float* mu, const float* sig, const float* coefA, const float* coefS, const float* w, const float* b, uint16_t* out,
+                            int N, int C, int K, int HW, int apply_sigmoid, void* stream);
 int ms_head_bwd_bf16(const uint16_t* dout, const uint16_t* out, const float* w, uint16_t* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
 int ms_head_ce_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* logits, float* loss_out,
                     const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream);

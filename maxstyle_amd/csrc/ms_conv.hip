@@ -236,13 +236,13 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
 
 // ms_conv2d (a 1x1 conv) that also carries a ms_bn_bwd_coefs (ride_kind 0) or ms_bn_finalize (ride_kind 1) job for the launch BEHIND it: one MFMA wave per channel
 // derives out4[c] while the staging waves fetch (ConvArgs::ride_*).  The conv itself neither reads nor waits for out4; ride_C must not exceed the launch's workgroup count (checked).
-// whether ms_conv2d(ks 3, stride 1, fetch MS_FETCH_WINOGRAD, epi_mode MS_EPI_POOL2) is built for this shape (16-byte aligned tensors assumed; bf16: activation storage)
+// whether ms_conv2d(ks 3, stride 1, fetch MS_FETCH_WINOGRAD, epi_mode MS_EPI_POOL2) is built for this shape (16-byte aligned tensors assumed; bf16: 0 = fp32 entry point, 1 = `_bf16`, 2 = `_bf16m`)
 extern "C" int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16) {
   if (N < 1 || Cin < 1 || H < 2 || W < 4 || Cout < 1 || H % 2 != 0 || W % 4 != 0 || pro_mode < 0 || pro_mode > 2) return 0;
   ConvArgs a{};
   a.N = N; a.Cin = Cin; a.Hs = a.Hin = a.Hout = H; a.Ws = a.Win = a.Wout = W; a.Cout = a.cout_real = Cout;
   a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (Cout + 63) / 64 * 64;
-  a.pro_mode = pro_mode; a.epi_mode = MS_EPI_POOL2; a.wino_ok = 1; a.act_bf16 = bf16 ? 1 : 0;
+  a.pro_mode = pro_mode; a.epi_mode = MS_EPI_POOL2; a.wino_ok = 1; a.act_bf16 = (bf16 < 0 || bf16 > 2) ? 2 : bf16;
   return (conv_wide_eligible(a, 3, 1, FETCH_NORMAL, true) && conv_wide_is_wino(a)) ? 1 : 0;
 }
 // channels a rider may have on a conv launch with this output shape (a lower bound of 4 x its workgroup count: one channel block, one workgroup per CU)

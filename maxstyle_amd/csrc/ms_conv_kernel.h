@@ -29,6 +29,21 @@ enum { FETCH_NORMAL = 0, FETCH_UPS2 = 1, FETCH_ZINS2 = 2 };
 #endif
 
 typedef unsigned long long conv_u64_t;
+// Thread numbering of the 512-thread conv workgroups (MFMA waves = logical waves 0-3, staging waves = 4-7).  The hardware places wave h of a workgroup on SIMD
+// (h + const) mod 4, so with MS_ROLE_SPLIT = 0 every SIMD hosts one MFMA wave and one staging wave of a workgroup; MS_ROLE_SPLIT = 1 makes hardware waves {0,1,4,5}
+// the MFMA waves and {2,3,6,7} the staging waves: two SIMDs issue MFMAs, two stage (an fp32 MFMA blocks its SIMD's vector issue: profiles/r03_experiments.txt 15).
+#ifndef MS_ROLE_SPLIT
+#define MS_ROLE_SPLIT 0
+#endif
+#if MS_ROLE_SPLIT
+__device__ __forceinline__ int conv_tid() {
+  const int t = (int)threadIdx.x, h = t >> 6;
+  return ((((h & 2) << 1) | (h & 1) | ((h >> 2) << 1)) << 6) | (t & 63);
+}
+#define MS_TID conv_tid()
+#else
+#define MS_TID ((int)threadIdx.x)
+#endif
 #ifndef MS_CONV_S2_CK
 #define MS_CONV_S2_CK 8        // input channels per chunk of the stride-2 kernels with a 16-channel tile (see Geo::CK)
 #endif
@@ -152,7 +167,7 @@ __device__ inline void xfin_header(const ConvArgs& a, unsigned& tag, int& nparts
 __device__ inline void xfin_publish(const ConvArgs& a, int c, unsigned tag, float v0, float v1, float v2, int nv) {
   // (first version: ONE copy per granule - at 16 channels every lane of 512 workgroups polled the same two cache lines; the replicas cost one coalesced
   //  512-byte store per granule; profiles/r03_experiments.txt)
-  const int lane = threadIdx.x & 63;
+  const int lane = MS_TID & 63;
   v0 = __shfl(v0, 0, 64); v1 = __shfl(v1, 0, 64); v2 = __shfl(v2, 0, 64);
   __hip_atomic_store(xfin_slot(a, c, 0, lane), ((conv_u64_t)tag << 32) | (conv_u64_t)__float_as_uint(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(xfin_slot(a, c, 1, lane), ((conv_u64_t)tag << 32) | (conv_u64_t)__float_as_uint(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -161,7 +176,7 @@ __device__ inline void xfin_publish(const ConvArgs& a, int c, unsigned tag, floa
 // One full wave, channel c.  kind 0: bn_finalize_kernel's arithmetic (ms_conv.hip); kind 1: bn_bwd_coefs_kernel's (ms_elem.hip) - same order, the same bits.
 // The record goes to xf_coef (for later kernels), the values a consumer of THIS launch needs are published.
 __device__ inline void xfin_reduce_publish(const ConvArgs& a, int c, unsigned tag, int nparts) {
-  const int lane = threadIdx.x & 63;
+  const int lane = MS_TID & 63;
   float p0 = 0.f, p1 = 0.f, p2 = 0.f;
   if (a.xf_kind == 0) {
     const float4* part = reinterpret_cast<const float4*>(a.xf_tab) + 1 + (size_t)c * kStatSlots;
@@ -204,7 +219,7 @@ __device__ inline void xfin_reduce_publish(const ConvArgs& a, int c, unsigned ta
 // not - also when the grid does not fit the chip at once (found by the bounded spin: the 64-channel-tile 1x1 kernel needs 205 VGPRs, one workgroup per
 // CU, and with publishers numbered by vb half of them sat behind their own pollers).  Returns whether this wave published anything.
 __device__ inline bool xfin_produce(const ConvArgs& a, unsigned tag, int nparts) {
-  const int wave = threadIdx.x >> 6;
+  const int wave = MS_TID >> 6;
   bool any = false;
   for (int c = 4 * (int)blockIdx.x + wave; c < a.xf_C; c += 4 * (int)gridDim.x) { xfin_reduce_publish(a, c, tag, nparts); any = true; }
   return any;
@@ -256,7 +271,7 @@ __device__ inline void xfin_fill(const ConvArgs& a, float* cf_lds, int ntab, uns
 template <int NT, bool STATS>
 __device__ inline void conv_table_tail(const ConvArgs& a, float* smem, int vb, int ncb, float v0, const float (&v1)[NT], const float (&v2)[NT]) {
   constexpr int COUT_TILE = 16 * NT;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, k = lane >> 4;
+  const int lane = MS_TID & 63, wave = MS_TID >> 6, m = lane & 15, k = lane >> 4;
   const int cb0 = vb % ncb, wg = vb / ncb, S = (int)gridDim.x / ncb;
   auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   bar();                                               // every MFMA wave is done with the stage buffers: smem is free
@@ -278,8 +293,8 @@ __device__ inline void conv_table_tail(const ConvArgs& a, float* smem, int vb, i
     if (k == 0) { float* r = red + ((wave * COUT_TILE) + j * 16 + m) * 3; r[0] = n_; r[1] = a_; r[2] = b_; }
   }
   bar();
-  if (threadIdx.x < COUT_TILE) {
-    const int ch = threadIdx.x;
+  if (MS_TID < COUT_TILE) {
+    const int ch = MS_TID;
     float n_ = red[ch * 3], a_ = red[ch * 3 + 1], b_ = red[ch * 3 + 2];
 #pragma unroll
     for (int w_ = 1; w_ < 4; ++w_) {
@@ -302,7 +317,7 @@ __device__ inline void conv_table_tail(const ConvArgs& a, float* smem, int vb, i
       }
     }
   }
-  if (vb == 0 && threadIdx.x == 0) {
+  if (vb == 0 && MS_TID == 0) {
     // header: {slots in use, launch epoch of this table (an integer in float bits: the tag of the `_xfin` consumers' granules), 0, 0}
     if (STATS) {
       const unsigned ep = __float_as_uint(reinterpret_cast<const float4*>(a.stats)[0].y) + 1u;
@@ -323,7 +338,7 @@ __device__ inline void conv_table_tail(const ConvArgs& a, float* smem, int vb, i
   bar();
   if (*flag == 0) return;
   // ---- the last workgroup: 32 channels per pass, 8 threads per channel, fp64 (ms_bn_finalize / ms_bn_bwd_coefs restated) ----
-  const int sub = threadIdx.x & 7, cl = threadIdx.x >> 3;
+  const int sub = MS_TID & 7, cl = MS_TID >> 3;
   for (int c0 = 0; c0 < a.Cout; c0 += 32) {
     const int c = c0 + cl;
     const bool live = c < a.Cout;
@@ -360,7 +375,7 @@ __device__ inline void conv_table_tail(const ConvArgs& a, float* smem, int vb, i
       }
     }
   }
-  if (threadIdx.x == 0) __hip_atomic_store(a.fin_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+  if (MS_TID == 0) __hip_atomic_store(a.fin_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
 }
 
 
@@ -423,7 +438,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   // smem: [2][BUF] stage buffers (input tile [CK][PS] then weights [TAPS][CK][WS]) | [cin_pad][4] prologue coefficients
   float* cf_lds = smem + 2 * BUF;
 
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = MS_TID >> 6, lane = MS_TID & 63;
   const bool producer = wave >= 4;                       // wave-uniform role
   const int ntiles = a.tiles_x * a.tiles_y;
   const int ncb = a.ncb;
@@ -439,12 +454,12 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   auto decode = [&](int it, int& n, int& tile, int& cb) { cb = it % ncb; const int t2 = it / ncb; tile = t2 % ntiles; n = t2 / ntiles; };
 
   if constexpr (EXP && FETCH == FETCH_ZINS2) {
-    for (int i = threadIdx.x; i < 2 * BUF; i += 512) smem[i] = 0.f;     // rows / columns the staging never writes are the inserted zeros
+    for (int i = MS_TID; i < 2 * BUF; i += 512) smem[i] = 0.f;     // rows / columns the staging never writes are the inserted zeros
   }
   // per-channel prologue coefficients are constant for the whole launch: stage them once (per-plane mode reads global memory)
   // (pro_mode 3, bw_parts > 0: the consumer waves derive the coefficients below while the producer waves already fetch the first chunk)
   if (a.bw_parts == 0 && a.pro_mode != 0 && a.pro_nstride == 0 && a.xf_tab == nullptr) {
-    for (int c = threadIdx.x; c < a.cin_pad; c += 512) {
+    for (int c = MS_TID; c < a.cin_pad; c += 512) {
       float ca = 1.f, cb_ = 0.f, cc = 0.f;
       if (c < a.Cin) { ca = a.pro_a[c * a.pro_cstride]; cb_ = a.pro_b[c * a.pro_cstride]; if (a.pro_mode == 2) cc = a.pro_c[c * a.pro_cstride]; }
       cf_lds[c * 4] = ca; cf_lds[c * 4 + 1] = cb_; cf_lds[c * 4 + 2] = cc;
@@ -454,7 +469,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   if (producer) {
     // =========================================== PRODUCER waves ===========================================
     __builtin_amdgcn_s_setprio(3);
-    const int tid = threadIdx.x - 256;
+    const int tid = MS_TID - 256;
     const size_t in_plane = (size_t)a.Hs * a.Ws;
     int s_lds[NI];        // (channel-in-chunk << 20) | LDS float offset of the slot, or -1: no slot   (tile independent)
     int s_rw[NI];         // (window row << 16) | window column
@@ -734,7 +749,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
     // workgroup reduces the (sum g, sum g*u) partials of ms_act_bwd_reduce itself - <= 32 KB of L2-resident reads, 32 lanes per channel,
     // fp64, fixed order, so all workgroups (and all runs) get the same bits.  pro_a = partials [Cin][bw_parts][2], pro_b = forward
     // coefficient records {scale, shift, mean, invstd} (stride pro_cstride).
-    const int grp = threadIdx.x >> 5, l32 = threadIdx.x & 31;          // consumer threads 0..255: 8 groups of 32 lanes
+    const int grp = MS_TID >> 5, l32 = MS_TID & 31;          // consumer threads 0..255: 8 groups of 32 lanes
     for (int c = grp; c < a.cin_pad; c += 8) {
       double s1 = 0.0, s2 = 0.0;
       if (c < a.Cin) {
@@ -770,8 +785,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
       // the coefficients feed this launch's PROLOGUE: they must be in LDS before the staging waves store their first chunk (barrier #0).  The staging waves
       // have issued that chunk's global loads already; the MFMA waves reduce their channels, then fill the table from the published granules.
       if (!xfin_produce(a, xf_tag, xf_nparts)) __builtin_amdgcn_s_sleep(30);               // (~1 us: a first poll before any publisher can be done is a wasted round trip)
-      if (a.pro_mode == 2) xfin_fill<3>(a, cf_lds, a.cin_pad, xf_tag, vb & (kXfinRep - 1), threadIdx.x, 256, 1.f, 0.f);
-      else xfin_fill<2>(a, cf_lds, a.cin_pad, xf_tag, vb & (kXfinRep - 1), threadIdx.x, 256, 1.f, 0.f);
+      if (a.pro_mode == 2) xfin_fill<3>(a, cf_lds, a.cin_pad, xf_tag, vb & (kXfinRep - 1), MS_TID, 256, 1.f, 0.f);
+      else xfin_fill<2>(a, cf_lds, a.cin_pad, xf_tag, vb & (kXfinRep - 1), MS_TID, 256, 1.f, 0.f);
     }
   }
   // (no s_setprio here: the STAGING waves get the priority - measured 290.7 -> 295.2 steps/s against the opposite choice; a staging wave that

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(512, 4) void conv_subpix_kernel(const ConvArgs a, c
   constexpr int TLH = G::TLH, TLW = G::TLW, CK = G::CK, IH = G::IH, RS = G::RS, PS = G::PS, NCOMBO = G::NCOMBO, WS = G::WS, BUF = G::BUF;
   constexpr int NI = G::NI, NWI = G::NWI;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = MS_TID >> 6, lane = MS_TID & 63;
   const bool producer = wave >= 4;
   const int ntiles = a.tiles_x * a.tiles_y, ncb = a.ncb;
   const int nitems = a.N * ntiles * ncb;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(512, 4) void conv_subpix_kernel(const ConvArgs a, c
   if (producer) {
     // =========================================== STAGING waves ===========================================
     __builtin_amdgcn_s_setprio(3);
-    const int tid = threadIdx.x - 256;
+    const int tid = MS_TID - 256;
     const int plane = a.Hs * a.Ws;
     int s_lds[NI], s_rc[NI];                // LDS float offset | (channel << 20), (row << 16) | column-quad; -1: no item
 #pragma unroll

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   constexpr int TH = G::TH, TW = G::TW, CK = G::CK, IH = G::IH, RS = G::RS, PS = G::PS, WS = G::WS, BUF = G::BUF;
   constexpr int NQI = G::NQI, NHI = G::NHI, NWI = G::NWI, COUT_TILE = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // wave-uniform by construction: keep it in a scalar register
+  const int wave = __builtin_amdgcn_readfirstlane((int)(MS_TID >> 6)), lane = MS_TID & 63;      // wave-uniform by construction: keep it in a scalar register
   const bool producer = wave >= 4;
   const int ntiles = a.tiles_x * a.tiles_y, ncb = a.ncb;
   const int nitems = a.N * ntiles * ncb;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   // index arithmetic each - on a SIMD whose matrix pipe is saturated every VALU instruction of a staging wave waits behind an MFMA).
   float* cf_lds = smem + 2 * BUF;
   if constexpr (BFM) {                               // K groups 2, 3 (activation planes and weight entries) stay zero for the whole launch
-    for (int i = threadIdx.x; i < 2 * BUF; i += 512) smem[i] = 0.f;
+    for (int i = MS_TID; i < 2 * BUF; i += 512) smem[i] = 0.f;
     if constexpr (PRO == 0) __syncthreads();
   }
   // cross-workgroup finalize (`_xfin`, ms_conv_kernel.h): the table is filled by the MFMA waves from granules published inside this launch - in front of
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   const bool xf_pro = (PRO != 0) && (a.xf_tab != nullptr);
   if constexpr (PRO != 0) {
     if (!xf_pro) {
-      for (int c = threadIdx.x; c < nchunks * CK; c += 512) {
+      for (int c = MS_TID; c < nchunks * CK; c += 512) {
         float4 cf = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < a.Cin) { cf.x = a.pro_a[c * a.pro_cstride]; cf.y = a.pro_b[c * a.pro_cstride]; if constexpr (PRO == 2) cf.z = a.pro_c[c * a.pro_cstride]; }
         reinterpret_cast<float4*>(cf_lds)[c] = cf;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     // then both in their epilogue (matrix pipe idle).  The workgroup that arrives second on its CU starts late by a fraction of an item so that one's
     // epilogue / staging overlaps the other's MFMA phase (MI355X_MICROARCH.md "Two waves per SIMD", item 9: stagger).
     __shared__ int s_slot;
-    if (threadIdx.x == 0) {
+    if (MS_TID == 0) {
       const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
       const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
       const unsigned key = ((xcc & 7u) << 7) | ((hw >> 8) & 0x7Fu);
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #define MS_WIDE_STAGE_PRIO 3
 #endif
     __builtin_amdgcn_s_setprio(MS_WIDE_STAGE_PRIO);
-    const int tid = threadIdx.x - 256;
+    const int tid = MS_TID - 256;
     const int plane = a.Hs * a.Ws;                 // host checks Cin*plane < 2^31
     typedef unsigned mask_t;
     // every global address of the staging is (wave-uniform base of the chunk, biased back by one row + 4 so that no offset is negative) + a 32-bit BYTE offset
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     lds_barrier();                                    // barrier #0 (matched by the consumers); `_xfin`: the coefficient table is complete behind it
     if (xf_pro) load_coefs(0);
 #ifdef MS_CONV_TRACE_BUILD
-    const bool tr = (a.trace != nullptr) && (blockIdx.x == 0) && (threadIdx.x == 256);
+    const bool tr = (a.trace != nullptr) && (blockIdx.x == 0) && (MS_TID == 256);
 #else
     constexpr bool tr = false;
 #endif
@@ -1253,13 +1253,13 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       unsigned xf_tag; int xf_nparts;
       xfin_header(a, xf_tag, xf_nparts);
       if (!xfin_produce(a, xf_tag, xf_nparts)) __builtin_amdgcn_s_sleep(30);
-      xfin_fill<(PRO == 2 ? 3 : 2)>(a, cf_lds, nchunks * CK, xf_tag, vb & (kXfinRep - 1), threadIdx.x, 256, 0.f, 0.f);
+      xfin_fill<(PRO == 2 ? 3 : 2)>(a, cf_lds, nchunks * CK, xf_tag, vb & (kXfinRep - 1), MS_TID, 256, 0.f, 0.f);
     }
   }
   lds_barrier();                                      // barrier #0
   lds_barrier();                                      // barrier #1: chunk 0 is in buffer 0
 #ifdef MS_CONV_TRACE_BUILD
-  const bool tr = (a.trace != nullptr) && (blockIdx.x == 0) && (threadIdx.x == 0);
+  const bool tr = (a.trace != nullptr) && (blockIdx.x == 0) && (MS_TID == 0);
   if (tr) { a.trace[500] = clock64(); a.trace[501] = (long long)__builtin_amdgcn_s_memrealtime(); }     // shader clock vs the 100 MHz constant clock
 #else
   constexpr bool tr = false;

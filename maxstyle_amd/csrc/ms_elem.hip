@@ -256,22 +256,37 @@ __global__ __launch_bounds__(kElemThreads) void pool2_actbwd_kernel(const void* 
 constexpr int kMaxHeadC = 64, kMaxHeadK = 4;
 
 // out[n,k,i] = sigmoid(b[k] + sum_c w[k][c]*h[n,c,i])
+// st_mu != NULL (ms_head_fwd_styled): h is the INPUT of a MaxStyle layer that sits directly in front of the head; its output y = A/sig * (h - mu) + S (per plane,
+// the expression and rounding of the layer's own kernels) is formed here and never written.
 template <typename AT = float>
 __global__ __launch_bounds__(kElemThreads) void head_sigmoid_kernel(const void* __restrict__ h, const float* __restrict__ w, const float* __restrict__ b,
-                                                                    void* __restrict__ out, int C, int K, int HW, int apply_sigmoid) {
+                                                                    void* __restrict__ out, int C, int K, int HW, int apply_sigmoid,
+                                                                    const float* __restrict__ st_mu, const float* __restrict__ st_sig, const float* __restrict__ st_A,
+                                                                    const float* __restrict__ st_S) {
   using IO = ActIO<AT>;
   __shared__ float sw[kMaxHeadK * kMaxHeadC + kMaxHeadK];
   for (int i = threadIdx.x; i < K * C; i += kElemThreads) sw[i] = w[i];
   if (threadIdx.x < K) sw[kMaxHeadK * kMaxHeadC + threadIdx.x] = b ? b[threadIdx.x] : 0.f;
-  __syncthreads();
   const int n = blockIdx.y;
+  __shared__ float sty[3 * kMaxHeadC];                 // {mu, A / sig, S} of the sample's planes
+  const bool styled = st_mu != nullptr;
+  if (styled && (int)threadIdx.x < C) {
+    const int p = n * C + threadIdx.x;
+    sty[threadIdx.x] = st_mu[p]; sty[kMaxHeadC + threadIdx.x] = st_A[p] / st_sig[p]; sty[2 * kMaxHeadC + threadIdx.x] = st_S[p];
+  }
+  __syncthreads();
   const size_t hb = (size_t)n * C * HW;
   for (int i = (blockIdx.x * kElemThreads + threadIdx.x) * 4; i < HW; i += gridDim.x * kElemThreads * 4) {
     float4 acc[kMaxHeadK];
 #pragma unroll
     for (int k = 0; k < kMaxHeadK; ++k) { const float bb = sw[kMaxHeadK * kMaxHeadC + k]; acc[k] = make_float4(bb, bb, bb, bb); }
     for (int c = 0; c < C; ++c) {
-      const float4 v = IO::ld4(h, hb + (size_t)c * HW + i);
+      float4 v = IO::ld4(h, hb + (size_t)c * HW + i);
+      if (styled) {
+        const float m = sty[c], a = sty[kMaxHeadC + c], sh = sty[2 * kMaxHeadC + c];
+        auto rt = [](float t) { if constexpr (IO::kBytes == 2) return IO::up(ms_to_bf16(t)); else return t; };      // bf16 storage: y as it would have been stored
+        v.x = rt(a * (v.x - m) + sh); v.y = rt(a * (v.y - m) + sh); v.z = rt(a * (v.z - m) + sh); v.w = rt(a * (v.w - m) + sh);
+      }
 #pragma unroll
       for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
         const float ww = sw[k * C + c];
@@ -825,12 +840,25 @@ static int head_check(int N, int C, int K, int HW, const char* who) {
 }
 
 template <typename AT>
-static int head_fwd_impl(const void* h, const float* w, const float* b, void* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream) {
+static int head_fwd_impl(const void* h, const float* w, const float* b, void* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream,
+                         const float* st_mu = nullptr, const float* st_sig = nullptr, const float* st_A = nullptr, const float* st_S = nullptr) {
   if (int e = head_check(N, C, K, HW, "ms_head_fwd")) return e;
   if (HW % 4 != 0) { set_error("ms_head_fwd: H*W must be a multiple of 4"); return MS_ERR_INVALID; }
   dim3 grid(std::min(cdiv(HW, kElemThreads * 4), 256), N);
-  MS_LAUNCH((head_sigmoid_kernel<AT>), grid, dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, out, C, K, HW, apply_sigmoid);
+  MS_LAUNCH((head_sigmoid_kernel<AT>), grid, dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, out, C, K, HW, apply_sigmoid, st_mu, st_sig, st_A, st_S);
   return check_launch("head_fwd");
+}
+// ms_style_fwd's restyle + ms_head_fwd in one pass: x [N,C,HW] is the INPUT of a MaxStyle layer directly in front of the 1x1 head, (mu, sig, coefA, coefS) [N*C] what
+// ms_style_fwd (called with y = NULL) left for it; y = coefA/sig * (x - mu) + coefS is formed per element (same expression, same rounding) and never written.
+extern "C" int ms_head_fwd_styled(const float* x, const float* mu, const float* sig, const float* coefA, const float* coefS, const float* w, const float* b, float* out,
+                                  int N, int C, int K, int HW, int apply_sigmoid, void* stream) {
+  if (mu == nullptr || sig == nullptr || coefA == nullptr || coefS == nullptr) { set_error("ms_head_fwd_styled: the layer's statistics are required"); return MS_ERR_INVALID; }
+  return head_fwd_impl<float>(x, w, b, out, N, C, K, HW, apply_sigmoid, stream, mu, sig, coefA, coefS);
+}
+extern "C" int ms_head_fwd_styled_bf16(const uint16_t* x, const float* mu, const float* sig, const float* coefA, const float* coefS, const float* w, const float* b, uint16_t* out,
+                                       int N, int C, int K, int HW, int apply_sigmoid, void* stream) {
+  if (mu == nullptr || sig == nullptr || coefA == nullptr || coefS == nullptr) { set_error("ms_head_fwd_styled: the layer's statistics are required"); return MS_ERR_INVALID; }
+  return head_fwd_impl<ms_bf16>(x, w, b, out, N, C, K, HW, apply_sigmoid, stream, mu, sig, coefA, coefS);
 }
 extern "C" int ms_head_fwd(const float* h, const float* w, const float* b, float* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream) {
   return head_fwd_impl<float>(h, w, b, out, N, C, K, HW, apply_sigmoid, stream);

@@ -628,6 +628,7 @@ extern "C" int ms_style_fwd_3k(const float* x, float* y, float* mu, float* sig, 
   MS_LAUNCH(style_finalize_kernel, dim3(C), dim3(256), 2 * B * sizeof(float), st, (const PlanePartial*)part, mu, sig, gamma_std, beta_std,
                      compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, sp.S, HW, eps);
   if (int e = check_launch("style_finalize")) return e;
+  if (y == nullptr) return MS_OK;                      // statistics and coefficients only (see ms_style_fwd)
   return ms_style_apply(x, y, mu, sig, coefA, coefS, P, HW, stream);
 }
 
@@ -750,6 +751,7 @@ extern "C" int ms_style_fwd_bf16(const uint16_t* x, uint16_t* y, float* mu, floa
   MS_LAUNCH(style_finalize_kernel, dim3(C), dim3(256), 2 * B * sizeof(float), st, (const PlanePartial*)part, mu, sig, gamma_std, beta_std,
                      compute_std, lmda, gamma_noise, beta_noise, perm, coefA, coefS, B, C, sp.S, HW, eps);
   if (int e = check_launch("style_finalize")) return e;
+  if (y == nullptr) return MS_OK;
   MS_LAUNCH(restyle_bf16_kernel, grid, block, 0, st, x, y, (const float*)mu, (const float*)sig, (const float*)coefA, (const float*)coefS, HW, sp.chunk);
   return check_launch("restyle_bf16");
 }

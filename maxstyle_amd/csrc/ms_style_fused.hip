@@ -216,15 +216,17 @@ __global__ __launch_bounds__(THREADS, 4) void style_fused_kernel(const FusedArgs
       a.mu[p] = m; a.sig[p] = sg; a.coefA[p] = A; a.coefS[p] = Sh;
       if (b == 0 && (a.compute_std & 1)) { a.gamma_std[c] = gs; a.beta_std[c] = bs; }
     }
-    const float sc = A / sg;
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.y) + base * ESZ, 0, cnt * ESZ, 0x00020000);
+    if (a.y != nullptr) {       // y == NULL: statistics and coefficients only (the consumer applies y = A/sig * (x - mu) + S itself: ms_head_fwd_styled)
+      const float sc = A / sg;
+      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.y) + base * ESZ, 0, cnt * ESZ, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < NSLOT; ++j) {
-      if (j < nv) {
-        float o[EPL];
+      for (int j = 0; j < NSLOT; ++j) {
+        if (j < nv) {
+          float o[EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) o[e] = sc * (v[j][e] - m) + Sh;
-        IO::template store<AUXS>(ry, voff, j * THREADS * 16, o);                       // lanes past the chunk are dropped by the range check
+          for (int e = 0; e < EPL; ++e) o[e] = sc * (v[j][e] - m) + Sh;
+          IO::template store<AUXS>(ry, voff, j * THREADS * 16, o);                       // lanes past the chunk are dropped by the range check
+        }
       }
     }
     __syncthreads();      // smu/ssig are reused by the next unit

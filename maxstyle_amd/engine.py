@@ -365,6 +365,9 @@ class InnerLoopEngine:
         # the data-gradient of an up-sampling block's first conv stores the 2x2 sums of its result itself (ms_conv2d epi_mode MS_EPI_POOL2, Winograd form):
         # the full-resolution gradient is never written or read back (MS_POOL_EPI=0 is the A/B switch; bit-identical in fp32 storage)
         self.pool_epi = os.environ.get("MS_POOL_EPI", "1") != "0" and type(self) is InnerLoopEngine
+        # the output of the MaxStyle layer in front of the image head is never written: the layer's kernel leaves statistics and coefficients, the head applies
+        # them per element (ms_head_fwd_styled; MS_LAZY_STYLE_HEAD=0 is the A/B switch, bit-identical)
+        self.lazy_style_head = os.environ.get("MS_LAZY_STYLE_HEAD", "1") != "0" and type(self) is InnerLoopEngine
         self.lazy_seg_tail = os.environ.get("MS_LAZY_SEG_TAIL", "1") != "0" and type(self) is InnerLoopEngine      # ms_head_ce_tail (see seg_loss)
         # cross-workgroup finalize (`_xfin` entry points): the BatchNorm coefficients a launch consumes are derived INSIDE that launch (one wave per channel,
         # published through tagged granules) instead of by an ms_bn_finalize launch in front of it.  Needs every workgroup of a launch co-resident: not with
@@ -399,7 +402,7 @@ class InnerLoopEngine:
         return self.t(name, *shape, dtype=self.act_dtype)
 
     _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv2d_ride", "ms_conv2d_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd", "ms_pool2_actbwd_pool", "ms_add_actbwd",
-                             "ms_head_fwd", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_head_ce_tail", "ms_style_fwd", "ms_style_bwd", "ms_style_ws_bytes",
+                             "ms_head_fwd", "ms_head_fwd_styled", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_head_ce_tail", "ms_style_fwd", "ms_style_bwd", "ms_style_ws_bytes",
                              "ms_conv_subpix", "ms_conv3x3_small_cout", "ms_style_bwd_actbwd", "ms_style_bwd_actbwd_parts"))
 
     def L(self, name):
@@ -915,7 +918,7 @@ class InnerLoopEngine:
             fused_next = next_act is not None and self.fuse_act_bwd and not self.bn_eval and dx.shape[3] % 4 == 0 and dx.shape[0] * dx.shape[1] <= 65535
             Ng, Cg, Hg, Wg = g1.shape
             pooled_epi = (fused_next and self.pool_epi and self.winograd and
-                          lib.ms_conv2d_pool2_ok(Ng, Cg, Hg, Wg, c0.cin, 2, int(self.bf16)) == 1)
+                          lib.ms_conv2d_pool2_ok(Ng, Cg, Hg, Wg, c0.cin, 2, 2 if self.mfma_bf16 else int(self.bf16)) == 1)
             # at the up-sampled resolution - or, pooled_epi, already summed 2x2 by the conv's epilogue (the full-resolution gradient is never written)
             dhi, _, _ = self.conv(pfx + (".dlo" if pooled_epi else ".dhi"), g1, c0, bnbwd=(bc1, b[pfx + ".u1"]), dgrad=True, epi=(EPI_POOL2 if pooled_epi else 0))
             if fused_next:
@@ -1175,13 +1178,14 @@ class InnerLoopEngine:
         self.param(i, "gamma_noise").copy_(torch.as_tensor(gamma_noise).to(self.dev, F32).view(s.B, s.C, 1, 1))
         self.param(i, "beta_noise").copy_(torch.as_tensor(beta_noise).to(self.dev, F32).view(s.B, s.C, 1, 1))
 
-    def style_fwd(self, i, x):
+    def style_fwd(self, i, x, store=True):
+        """store=False: statistics and coefficients only (y = NULL) - the caller's next kernel applies the layer itself; returns None then."""
         s = self.styles[i]
         B, C = x.shape[:2]
         HW = x.shape[2] * x.shape[3]
         if HW == 1 or B <= 1 or (not s.mix_style and not s.use_noise):
             return x                                     # identity short-cuts of maxstyle.py:146-152
-        y = self.a(f"st{i}.y", *x.shape)
+        y = self.a(f"st{i}.y", *x.shape) if store else None
         stats = self.t(f"st{i}.stats", 4, B, C)          # mu, sig, A, S
         std = self.t(f"st{i}.std", 2, C)                 # gamma_std, beta_std (frozen after the first forward)
         ws = self._style_ws(i, self.L("ms_style_ws_bytes")(B, C, HW))
@@ -1189,7 +1193,7 @@ class InnerLoopEngine:
             self._note_state_offset(i, B, C, HW)
         po = lambda nm: self.flat_p.data_ptr() + 4 * s.off[nm][0]
         flags = (0 if s.have_std else 1) | (4 if (self.shared_device or self.overlap) else 0)
-        check(self.L("ms_style_fwd")(x.data_ptr(), y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), std[0].data_ptr(), std[1].data_ptr(),
+        check(self.L("ms_style_fwd")(x.data_ptr(), 0 if y is None else y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), std[0].data_ptr(), std[1].data_ptr(),
                                flags, po("lmda") if s.mix_style else 0, po("gamma_noise") if s.use_noise else 0,
                                po("beta_noise") if s.use_noise else 0, s.perm.data_ptr() if s.mix_style else 0,
                                stats[2].data_ptr(), stats[3].data_ptr(), B, C, HW, s.eps, ws.data_ptr(), ws.numel(), self._st()), f"ms_style_fwd:{i}")
@@ -1313,6 +1317,7 @@ class InnerLoopEngine:
         d = self.nets.dec
         first = min(self.layers) if self.layers else 6
         x = code
+        styled = False
         if 0 in self.layers:
             x = self.style_fwd(0, x)
         for i in range(1, 5):
@@ -1321,14 +1326,23 @@ class InnerLoopEngine:
             else:
                 x = self.res_fwd(f"d.u{i}", d, f"u{i}", x, self._dec_kind())
             if i in self.layers:
-                x = self.style_fwd(i, x)
+                if i == 4 and self.lazy_style_head and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[1] <= 64:
+                    # layer 4 -> head: the layer's output is never written (statistics only; the head applies them: ms_head_fwd_styled)
+                    styled = self.style_fwd(i, x, store=False) is None
+                else:
+                    x = self.style_fwd(i, x)
         N, C, H, W = x.shape
         K = d["head.w"].shape[0]
         if first > 4 and self._prefix_valid:
             img = self.buf["d.image"]
         else:
             img = self.a("d.image", N, K, H, W)
-            check(self.L("ms_head_fwd")(x.data_ptr(), d["head.w"].data_ptr(), d["head.b"].data_ptr(), img.data_ptr(), N, C, K, H * W, 1, self._st()), "ms_head_fwd")
+            if styled:
+                st = self.buf["st4.stats"]
+                check(self.L("ms_head_fwd_styled")(x.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(), d["head.w"].data_ptr(), d["head.b"].data_ptr(),
+                                             img.data_ptr(), N, C, K, H * W, 1, self._st()), "ms_head_fwd_styled")
+            else:
+                check(self.L("ms_head_fwd")(x.data_ptr(), d["head.w"].data_ptr(), d["head.b"].data_ptr(), img.data_ptr(), N, C, K, H * W, 1, self._st()), "ms_head_fwd")
             self.buf["d.head_in"] = x
         self._prefix_valid = True
         if 5 in self.layers:

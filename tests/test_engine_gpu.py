@@ -322,6 +322,9 @@ def test_fused_block_tail_is_bit_identical(dev):
     for fuse in (True, False):
         eng, W, img, lab, styles = build_engine(dev, orc.NetSpec(4, 1, 4), 4, 64, layers)
         eng.fuse_skip = fuse
+        # (the head kernel of the fused tail's lazy form owns 2x2 pixel quads when it also pools - engine.pool_fuse - and then groups the BatchNorm-backward
+        #  sums differently from the row-mapped kernels of the unfused path: agreement to rounding, tests/test_round3_gpu.py::test_pooled_gradient_from_the_producers)
+        eng.pool_fuse = False
         z_i, _ = eng.encode_fwd(img.to(dev))
         out = eng.run(z_i.clone(), lab.to(dev), 3, use_graph=False).clone()
         outs.append((out, eng.losses(3).clone(), eng.flat_p.clone()))

@@ -473,3 +473,12 @@ def test_pooled_data_gradient_in_the_loop(dev, monkeypatch, case):
         d = [float((a.double() - b.double()).abs().max()) for a, b in zip(outs[0][0], outs[1][0])]
         print("pooled epilogue bf16 max diffs (image, losses, params):", d)
         assert d[0] < 5e-2 and d[1] < 5e-3 * float(outs[1][0][1].abs().max())
+
+
+@pytest.mark.parametrize("case", ["c2small", "c4small", "bf16", "c2full"])
+def test_style_layer_in_front_of_the_head_is_never_written(dev, monkeypatch, case):
+    """MS_LAZY_STYLE_HEAD: layer 4's kernel leaves statistics and coefficients only (ms_style_fwd with y = NULL), the image head applies y = A/sig (x - mu) + S per
+    element itself (ms_head_fwd_styled) - against the materialised layer output: same bits (fp32 and bf16 storage, 1 and 3 image channels)."""
+    outs = _switch_ab(dev, monkeypatch, case, "MS_LAZY_STYLE_HEAD", "lazy_style_head")
+    assert "st4.y" not in outs[0][2].buf and "st4.y" in outs[1][2].buf
+    _same_bits(outs)
