@@ -917,7 +917,7 @@ class InnerLoopEngine:
         if kind == "nn":
             fused_next = next_act is not None and self.fuse_act_bwd and not self.bn_eval and dx.shape[3] % 4 == 0 and dx.shape[0] * dx.shape[1] <= 65535
             Ng, Cg, Hg, Wg = g1.shape
-            pooled_epi = (fused_next and self.pool_epi and self.winograd and
+            pooled_epi = (fused_next and self.pool_epi and self.winograd and not isinstance(bc1, tuple) and      # (a (partials, n, records) tuple = pro_mode 3: first-generation kernel)
                           lib.ms_conv2d_pool2_ok(Ng, Cg, Hg, Wg, c0.cin, 2, 2 if self.mfma_bf16 else int(self.bf16)) == 1)
             # at the up-sampled resolution - or, pooled_epi, already summed 2x2 by the conv's epilogue (the full-resolution gradient is never written)
             dhi, _, _ = self.conv(pfx + (".dlo" if pooled_epi else ".dhi"), g1, c0, bnbwd=(bc1, b[pfx + ".u1"]), dgrad=True, epi=(EPI_POOL2 if pooled_epi else 0))
