@@ -45,10 +45,10 @@ __device__ __forceinline__ int conv_tid() {
 #define MS_TID ((int)threadIdx.x)
 #endif
 #ifndef MS_CONV_S2_PF2
-#define MS_CONV_S2_PF2 0      // two register sets in the staging waves of the stride-2 kernels with a 16-channel tile (needs MS_CONV_S2_CK=4 to fit; experiment 17)
+#define MS_CONV_S2_PF2 1      // two register sets in the staging waves of the vector-staged stride-2 kernels with a 16-channel tile (fits with MS_CONV_S2_CK = 4: 98 VGPRs; profiles/r03_experiments.txt 17)
 #endif
 #ifndef MS_CONV_S2_CK
-#define MS_CONV_S2_CK 8        // input channels per chunk of the stride-2 kernels with a 16-channel tile (see Geo::CK)
+#define MS_CONV_S2_CK 4        // input channels per chunk of the stride-2 kernels with a 16-channel tile (see Geo::CK; 8 until round 3)
 #endif
 struct ConvArgs {
   const float* in; const float* in2; float* out; const float* w; const float* bias;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   // (chosen per variant from `tools/kernel_resources.sh`: on only where the kernel stays within 128 VGPRs without spills - the narrow 4x16-pixel tiles,
   //  the 1x1 convolutions and the expanded-fetch 3x3: the small-spatial layers that are latency-bound, not the top-level ones that are bandwidth-bound)
   constexpr bool PF2 = MS_CONV_PF2 && ((IN2 ? 2 : 1) * NI * VW + 4 * NWI <= 56) &&
-                       (NARROW ? !(NT == 4 && IN2) : ((KS == 1 && NT < 4) || (EXP && NT == 1) || (MS_CONV_S2_PF2 && STRIDE == 2 && NT == 1)));
+                       (NARROW ? !(NT == 4 && IN2) : ((KS == 1 && NT < 4) || (EXP && NT == 1) || (MS_CONV_S2_PF2 && STRIDE == 2 && NT == 1 && VEC)));
   static_assert(!EXP || (KS == 3 && STRIDE == 1), "expanded staging is for the 3x3 stride-1 convolution");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // smem: [2][BUF] stage buffers (input tile [CK][PS] then weights [TAPS][CK][WS]) | [cin_pad][4] prologue coefficients
