@@ -233,6 +233,14 @@ int ms_conv2d(const float* in, const float* in2, float* out, const float* w_pack
               int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
               int epi_mode, float* stats, void* stream);
 
+/* 3x3 stride-1 convolution with <= 4 INPUT channels and 16 output channels on the vector ALUs - the encoder's first conv on the image (`inc.0`, encoder_decoder.py:
+ * 441-445 forward; on the matrix cores its single input channel is padded to an 8-channel chunk: 3 of 18 MFMAs per 16 pixels carry data).  out [N,16,H,W] =
+ * conv3x3(in [N,Cin,H,W], w) + bias; w_packed = ms_conv2d's forward layout; stats (may be NULL) = ms_conv2d's statistics table of the outputs (one slot per
+ * workgroup, header {slots, launch epoch}): ms_bn_finalize and the `_xfin` consumers read it like any other.  W % 4 == 0, 16-byte aligned tensors.
+ * ms_conv3x3_small_cin_ok answers 1 where the entry point is also the FASTER choice (Cin == 1: 30 vs 34 us at 16x1x256x256), not merely accepted. */
+int ms_conv3x3_small_cin_ok(int Cin, int Cout, int W);
+int ms_conv3x3_small_cin(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int H, int W, int Cout, float* stats, void* stream);
+
 /* 3x3 stride-1 convolution with <= 4 OUTPUT channels on the vector ALUs (csrc/ms_conv_small.hip): the data-gradient that reaches the image (`inc.0`,
  * encoder_decoder.py:441-445: 16 -> 1 channels at config 2, 64 -> 3 at config 4).  Same arithmetic contract as ms_conv2d(ks=3, stride=1) with pro_mode 0 or 2
  * (BatchNorm-backward prologue pro_a*in + pro_b*in2 + pro_c); w_packed = the packed weights [9][cin_pad][cout_pad].  W % 4 == 0. */
@@ -493,6 +501,7 @@ int ms_style_bwd_actbwd_bf16(const uint16_t* dy, const uint16_t* x, uint16_t* dx
                              const uint16_t* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream);
 int ms_conv_subpix_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int mode,
                         float* stats, const uint16_t* ref, const uint16_t* u, const float* coef4, float act_slope, float* tab, void* stream);
+int ms_conv3x3_small_cin_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int H, int W, int Cout, float* stats, void* stream);
 int ms_conv3x3_small_cout_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, int N, int Cin, int H, int W, int Cout,
                                int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_cstride, void* stream);
 int ms_bn_act_bf16(const uint16_t* u, const float* coef4, const uint16_t* res, int res_mode, uint16_t* out, int N, int C, int H, int W, float slope, void* stream);

@@ -116,6 +116,128 @@ __global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(const void* __r
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolutions with a handful of INPUT channels (<= 4) and 16 output channels on the vector ALUs: the encoder's first conv on the image
+// (`inc.0`: 1 -> 16 channels at C2; encoder_decoder.py:441-445 forward).  On the matrix cores the layer pads its single input channel to an 8-channel chunk
+// (18 MFMAs per 16 pixels of which 3 carry data) and goes through the whole staging pipeline for a 4 MB input: 34 us for what is a 67 MB write.  Here a
+// thread computes 4 pixels x 16 channels from a 3 x 6 window per input channel read straight from global memory (the input is L2-resident; neighbouring
+// threads share their windows in the vector L1), weights through uniform (scalar) loads, 16 coalesced 16-byte stores - and keeps the per-channel running
+// (count, mean, M2) of its outputs in registers (Chan), merged once per workgroup into the conv kernels' statistics table (one slot per workgroup, header
+// {slots, launch epoch}: what ms_bn_finalize and the `_xfin` consumers read).  Persistent grid (<= 2 workgroups per CU), tiles of 16 x 64 pixels.
+constexpr int kSciCout = 16;
+
+__device__ __forceinline__ void sci_chan_merge(float& n, float& a, float& b, float nb, float ab, float bb) {      // (n, mean a, M2 b) += (nb, ab, bb)
+  const float nn = n + nb;
+  const float w = (nn > 0.f) ? nb / nn : 0.f;
+  const float d = ab - a;
+  a += d * w; b += bb + d * d * n * w; n = nn;
+}
+
+template <int CIN, typename AT = float>
+__global__ __launch_bounds__(256) void conv3x3_small_cin_kernel(const void* __restrict__ in, void* __restrict__ out, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float4* __restrict__ stats, int N, int H, int W, int cin_pad,
+                                                                int cout_pad, int tiles_x, int tiles_per_img) {
+  using IO = ActIO<AT>;
+  __shared__ float red[4][kSciCout][3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int py = tid >> 4, px4 = (tid & 15) * 4;
+  const size_t plane = (size_t)H * W;
+  const int ntiles = N * tiles_per_img;
+  float st_n = 0.f, st_mean[kSciCout], st_m2[kSciCout];
+#pragma unroll
+  for (int o = 0; o < kSciCout; ++o) { st_mean[o] = 0.f; st_m2[o] = 0.f; }
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int n = t / tiles_per_img, tile = t - n * tiles_per_img;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int y = ty * kSmTH + py, x = tx * kSmTW + px4;
+    const bool live = (y < H) && (x < W);                   // W % 4 == 0: the quad is inside or outside as a whole
+    float acc[kSciCout][4];
+#pragma unroll
+    for (int o = 0; o < kSciCout; ++o) {
+      const float bv = bias != nullptr ? bias[o] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[o][e] = bv;
+    }
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+      const size_t pb = ((size_t)n * CIN + ci) * plane;
+      float win[3][6];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int Y = y - 1 + ky;
+        const bool rok = live && Y >= 0 && Y < H;
+        const size_t ro = pb + (size_t)(rok ? Y : 0) * W;
+        const float4 mid = rok ? IO::ld4(in, ro + x) : make_float4(0.f, 0.f, 0.f, 0.f);
+        win[ky][0] = (rok && x > 0) ? IO::ld1(in, ro + x - 1) : 0.f;
+        win[ky][1] = mid.x; win[ky][2] = mid.y; win[ky][3] = mid.z; win[ky][4] = mid.w;
+        win[ky][5] = (rok && x + 4 < W) ? IO::ld1(in, ro + x + 4) : 0.f;
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          // uniform address: 16 consecutive weights, scalar loads, hoisted out of the tile loop by the compiler (144 SGPRs, part of them parked in vector-register lanes).
+          // Measured alternatives (profiles/r03_experiments.txt 18): weights in LDS 118 us (hoisted into 144 VECTOR registers: spills), re-read per tile through the
+          // scalar cache 38 us, packed v_pk_fma_f32 31.5 us - this form 30.4 us.
+          const float* wr = w + ((size_t)(ky * 3 + kx) * cin_pad + ci) * cout_pad;
+#pragma unroll
+          for (int o = 0; o < kSciCout; ++o) {
+            const float wv = wr[o];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[o][e] = __builtin_fmaf(wv, win[ky][e + kx], acc[o][e]);      // (explicit: the library is built with -ffp-contract=off)
+          }
+        }
+    }
+    if (live) {
+#pragma unroll
+      for (int o = 0; o < kSciCout; ++o)
+        IO::st4(out, ((size_t)n * kSciCout + o) * plane + (size_t)y * W + x, make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]));
+      if (stats != nullptr) {
+        // the quad's (4, mean, M2) per channel, Chan-merged into the thread's running statistics (of the values as STORED: bf16 storage rounds first)
+        const float nt_ = st_n + 4.f;
+        const float wgt = 4.f / nt_;
+#pragma unroll
+        for (int o = 0; o < kSciCout; ++o) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { if constexpr (IO::kBytes == 2) v[e] = IO::up(ms_to_bf16(acc[o][e])); else v[e] = acc[o][e]; }
+          const float gm = ((v[0] + v[1]) + (v[2] + v[3])) * 0.25f;
+          const float d0 = v[0] - gm, d1 = v[1] - gm, d2 = v[2] - gm, d3 = v[3] - gm;
+          const float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+          const float dd = gm - st_mean[o];
+          st_mean[o] += dd * wgt;
+          st_m2[o] += q + dd * dd * st_n * wgt;
+        }
+        st_n = nt_;
+      }
+    }
+  }
+  if (stats == nullptr) return;
+  // one slot per workgroup and channel: lanes of a wave (xor shuffles), then the four waves through LDS, in a fixed order
+#pragma unroll
+  for (int o = 0; o < kSciCout; ++o) {
+    float n_ = st_n, a_ = st_mean[o], b_ = st_m2[o];
+#pragma unroll
+    for (int off = 1; off <= 32; off <<= 1) {
+      const float nb = __shfl_xor(n_, off, 64), ab = __shfl_xor(a_, off, 64), bb = __shfl_xor(b_, off, 64);
+      sci_chan_merge(n_, a_, b_, nb, ab, bb);
+    }
+    if (lane == 0) { red[wave][o][0] = n_; red[wave][o][1] = a_; red[wave][o][2] = b_; }
+  }
+  __syncthreads();
+  if (tid < kSciCout) {
+    float n_ = red[0][tid][0], a_ = red[0][tid][1], b_ = red[0][tid][2];
+#pragma unroll
+    for (int w_ = 1; w_ < 4; ++w_) sci_chan_merge(n_, a_, b_, red[w_][tid][0], red[w_][tid][1], red[w_][tid][2]);
+    stats[1 + (size_t)tid * kStatSlots + blockIdx.x] = make_float4(n_, a_, b_, 0.f);
+  }
+  if (blockIdx.x == 0 && tid == 0) {      // header: {slots in use, launch epoch of this table}: the `_xfin` consumers' tag (conv_table_tail's convention)
+    const unsigned ep = __float_as_uint(stats[0].y) + 1u;
+    stats[0] = make_float4((float)gridDim.x, __uint_as_float(ep == 0u ? 1u : ep), 0.f, 0.f);
+  }
+}
+
 }  // namespace ms
 
 using namespace ms;
@@ -150,4 +272,31 @@ extern "C" int ms_conv3x3_small_cout(const float* in, const float* in2, float* o
 extern "C" int ms_conv3x3_small_cout_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, int N, int Cin, int H, int W, int Cout,
                                           int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_cstride, void* stream) {
   return small_cout_impl<ms_bf16>(in, in2, out, w_packed, N, Cin, H, W, Cout, pro_mode, pro_a, pro_b, pro_c, pro_cstride, stream);
+}
+
+// 1: the entry point takes the shape AND is the faster choice (measured at Cin = 1 only: 30 vs 34 us at 16x1x256x256; with 2..4 input channels the kernel is
+// correct but its 300..600 weights no longer fit the scalar registers); 0: use ms_conv2d
+extern "C" int ms_conv3x3_small_cin_ok(int Cin, int Cout, int W) { return (Cin == 1 && Cout == kSciCout && W % 4 == 0) ? 1 : 0; }
+
+// out [N,16,H,W] = conv3x3(in [N,Cin,H,W], w) + bias, Cin <= 4, stride 1, padding 1; w = packed forward weights [9][cin_pad][cout_pad] (ms_conv2d's layout).
+// stats (may be NULL): the statistics table of ms_conv2d ([1 + 16 * ms_conv_stats_parts()] float4, header {slots, epoch}) for ms_bn_finalize / the `_xfin` consumers.
+template <typename AT>
+static int small_cin_impl(const void* in, void* out, const float* w_packed, const float* bias, int N, int Cin, int H, int W, int Cout, float* stats, void* stream) {
+  if (N < 1 || H < 1 || W < 1 || Cin < 1 || Cin > 4 || Cout != kSciCout || W % 4 != 0) { set_error("ms_conv3x3_small_cin: Cin <= 4, Cout == 16, W %% 4 == 0"); return MS_ERR_INVALID; }
+  if (!aligned16(in) || !aligned16(out) || (stats != nullptr && !aligned16(stats))) { set_error("ms_conv3x3_small_cin: tensors must be 16-byte aligned"); return MS_ERR_ALIGN; }
+  const int tiles_x = cdiv(W, kSmTW), tiles_y = cdiv(H, kSmTH);
+  const long ntiles = (long)N * tiles_x * tiles_y;
+  const int cin_pad = (Cin + 3) / 4 * 4, cout_pad = (Cout + 63) / 64 * 64;
+  const int grid = (int)std::min<long>(ntiles, std::min<long>((Cin == 1 ? 3L : 2L) * num_cus(), kStatSlots));      // resident workgroups per CU: 143 VGPRs at Cin = 1
+  hipStream_t st = (hipStream_t)stream;
+#define MS_SCI(CI) MS_LAUNCH((conv3x3_small_cin_kernel<CI, AT>), dim3(grid), dim3(256), 0, st, in, out, w_packed, bias, (float4*)stats, N, H, W, cin_pad, cout_pad, tiles_x, tiles_x * tiles_y)
+  switch (Cin) { case 1: MS_SCI(1); break; case 2: MS_SCI(2); break; case 3: MS_SCI(3); break; default: MS_SCI(4); }
+#undef MS_SCI
+  return check_launch("conv3x3_small_cin");
+}
+extern "C" int ms_conv3x3_small_cin(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int H, int W, int Cout, float* stats, void* stream) {
+  return small_cin_impl<float>(in, out, w_packed, bias, N, Cin, H, W, Cout, stats, stream);
+}
+extern "C" int ms_conv3x3_small_cin_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int H, int W, int Cout, float* stats, void* stream) {
+  return small_cin_impl<ms_bf16>(in, out, w_packed, bias, N, Cin, H, W, Cout, stats, stream);
 }

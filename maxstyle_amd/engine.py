@@ -361,6 +361,9 @@ class InnerLoopEngine:
         # the producers of a masked gradient that an up-sampling block's backward pools 2x2 for its skip branch (ms_head_ce_tail, ms_pool2_actbwd) write the
         # pooled tensor themselves: no ms_pool2_sum launch in res_bwd (MS_POOL_FUSE=0 is the A/B switch; results agree to rounding - the producers' per-thread
         # grouping of the BatchNorm-backward sums changes with their pixel mapping)
+        # the encoder's first conv (1 / 3 -> 16 channels) on the vector ALUs (ms_conv3x3_small_cin) instead of an MFMA tile with 7 of 8 K lanes empty; MS_SMALL_CIN=0
+        # is the A/B switch (results agree to rounding: an fp32 FMA chain instead of the matrix core's accumulation order)
+        self.small_cin = os.environ.get("MS_SMALL_CIN", "1") != "0" and type(self) is InnerLoopEngine
         self.pool_fuse = os.environ.get("MS_POOL_FUSE", "1") != "0" and type(self) is InnerLoopEngine
         # the data-gradient of an up-sampling block's first conv stores the 2x2 sums of its result itself (ms_conv2d epi_mode MS_EPI_POOL2, Winograd form):
         # the full-resolution gradient is never written or read back (MS_POOL_EPI=0 is the A/B switch; bit-identical in fp32 storage)
@@ -403,7 +406,7 @@ class InnerLoopEngine:
 
     _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv2d_ride", "ms_conv2d_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd", "ms_pool2_actbwd_pool", "ms_add_actbwd",
                              "ms_head_fwd", "ms_head_fwd_styled", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_head_ce_tail", "ms_style_fwd", "ms_style_bwd", "ms_style_ws_bytes",
-                             "ms_conv_subpix", "ms_conv3x3_small_cout", "ms_style_bwd_actbwd", "ms_style_bwd_actbwd_parts"))
+                             "ms_conv_subpix", "ms_conv3x3_small_cout", "ms_conv3x3_small_cin", "ms_style_bwd_actbwd", "ms_style_bwd_actbwd_parts"))
 
     def L(self, name):
         """The library entry point for this engine's activation storage type (`_bf16` twin in bf16 mode: include/maxstyle_hip.h)."""
@@ -988,7 +991,16 @@ class InnerLoopEngine:
     def encode_fwd(self, image):
         """MyEncoder.forward + code_decoupler (encoder_decoder.py:469-482, 673-680) in BN batch-stat mode."""
         e = self.nets.enc
-        ua, st, p = self.conv("e.inc.ua", image, e["inc0"], stats=True, fin=e["inc1"])
+        c0 = e["inc0"]
+        if self.small_cin and not self.bn_eval and not self.fuse_bn_fin and lib.ms_conv3x3_small_cin_ok(c0.cin, c0.cout, image.shape[3]) == 1:
+            N_, _, H_, W_ = image.shape
+            ua = self.a("e.inc.ua", N_, c0.cout, H_, W_)
+            p = lib.ms_conv_stats_parts(N_, H_, W_)
+            st = self.t("e.inc.ua.stats", c0.cout * p + 1, 4)
+            check(self.L("ms_conv3x3_small_cin")(image.data_ptr(), ua.data_ptr(), c0.wp.data_ptr(), 0 if c0.b is None else c0.b.data_ptr(), N_, c0.cin, H_, W_, c0.cout,
+                                           st.data_ptr(), self._st()), "ms_conv3x3_small_cin:e.inc.ua")
+        else:
+            ua, st, p = self.conv("e.inc.ua", image, e["inc0"], stats=True, fin=e["inc1"])
         cfa = self.bn_fin_or_pending("e.inc.bn1", st, p, e["inc1"])
         ub, st, p = self.conv("e.inc.ub", ua, e["inc3"], act=(cfa, LEAKY), stats=True, fin=e["inc4"])
         lazy = self.lazy_inc and self.enc_mix is None

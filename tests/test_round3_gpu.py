@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import r3_cases as R
+from parity_util import rel
 
 pytestmark = pytest.mark.gpu
 
@@ -482,3 +483,50 @@ def test_style_layer_in_front_of_the_head_is_never_written(dev, monkeypatch, cas
     outs = _switch_ab(dev, monkeypatch, case, "MS_LAZY_STYLE_HEAD", "lazy_style_head")
     assert "st4.y" not in outs[0][2].buf and "st4.y" in outs[1][2].buf
     _same_bits(outs)
+
+
+@pytest.mark.parametrize("shape", [(16, 1, 256, 256), (3, 3, 40, 64), (2, 4, 17, 36), (4, 1, 64, 64)])
+@pytest.mark.parametrize("act", [None, torch.bfloat16])
+def test_small_cin_conv_vs_matrix_core_conv_and_fp64(dev, shape, act):
+    """ms_conv3x3_small_cin (the encoder's first conv on the vector ALUs) against fp64 and against ms_conv2d: outputs to fp32 rounding, and the statistics table
+    gives ms_bn_finalize the same BatchNorm record (header {slots, epoch} included: a second launch bumps the epoch)."""
+    import torch.nn.functional as F
+    from maxstyle_amd import ops
+    import maxstyle_amd._lib as L
+    N, Cin, H, W = shape
+    Cout = 16
+    assert L.lib.ms_conv3x3_small_cin_ok(1, Cout, W) == 1 and L.lib.ms_conv3x3_small_cin_ok(3, 16, W) == 0 and L.lib.ms_conv3x3_small_cin_ok(1, 32, W) == 0      # (_ok: the RECOMMENDED shapes)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.3
+    b = torch.randn(Cout, generator=g) * 0.1
+    dt = act or torch.float32
+    xd = x.to(dev).to(dt)
+    wp = ops.pack_conv_weight(w).to(dev)
+    bd = b.to(dev)
+    ref = F.conv2d(xd.double().cpu(), w.double(), b.double(), padding=1)
+    out = torch.empty(N, Cout, H, W, device=dev, dtype=dt)
+    parts = L.lib.ms_conv_stats_parts(N, H, W)
+    st = torch.zeros(Cout * parts + 1, 4, device=dev)
+    fn = L.lib.ms_conv3x3_small_cin_bf16 if act is not None else L.lib.ms_conv3x3_small_cin
+    for rep in range(2):
+        L.check(fn(xd.data_ptr(), out.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, st.data_ptr(), 0), "ms_conv3x3_small_cin")
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    err = float((out.double().cpu() - ref).abs().max()) / scale
+    assert err < (1e-6 if act is None else 6e-3), err
+    hdr = st[0].cpu()
+    assert int(hdr[0]) >= 1 and hdr[1:2].view(torch.int32).item() == 2           # two launches: epoch 2
+    st2 = torch.zeros_like(st)
+    o2 = ops.conv2d(xd, wp, bd, Cout, 3, 1, stats=st2)
+    assert float((o2.double() - out.double()).abs().max()) / scale < (2e-6 if act is None else 1e-2)
+    gamma, beta = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev)
+    cf1, cf2 = torch.empty(Cout, 4, device=dev), torch.empty(Cout, 4, device=dev)
+    L.check(L.lib.ms_bn_finalize(st.data_ptr(), parts, gamma.data_ptr(), beta.data_ptr(), 1e-5, cf1.data_ptr(), Cout, 0), "bn_finalize")
+    L.check(L.lib.ms_bn_finalize(st2.data_ptr(), parts, gamma.data_ptr(), beta.data_ptr(), 1e-5, cf2.data_ptr(), Cout, 0), "bn_finalize")
+    torch.cuda.synchronize()
+    o64 = out.double()
+    mean64 = o64.mean(dim=(0, 2, 3)); var64 = o64.var(dim=(0, 2, 3), unbiased=False)
+    assert float((cf1[:, 2].double() - mean64).abs().max()) < 2e-6 * scale                    # the record is that of the values as stored
+    assert float((cf1[:, 3].double() - (var64 + 1e-5).rsqrt()).abs().max() / cf1[:, 3].abs().max()) < 2e-5
+    assert rel(cf1, cf2) < (2e-5 if act is None else 2e-2)
