@@ -45,10 +45,10 @@ __device__ __forceinline__ int conv_tid() {
 #define MS_TID ((int)threadIdx.x)
 #endif
 #ifndef MS_CONV_S2_PF2
-#define MS_CONV_S2_PF2 1      // two register sets in the staging waves of the vector-staged stride-2 kernels with a 16-channel tile (fits with MS_CONV_S2_CK = 4: 98 VGPRs; profiles/r03_experiments.txt 17)
+#define MS_CONV_S2_PF2 0      // two register sets in the staging waves of the vector-staged stride-2 kernels with a 16-channel tile (fits with MS_CONV_S2_CK = 4: 98 VGPRs; +0.25 %, not adopted: profiles/r03_experiments.txt 17)
 #endif
 #ifndef MS_CONV_S2_CK
-#define MS_CONV_S2_CK 4        // input channels per chunk of the stride-2 kernels with a 16-channel tile (see Geo::CK; 8 until round 3)
+#define MS_CONV_S2_CK 8        // input channels per chunk of the stride-2 kernels with a 16-channel tile (see Geo::CK)
 #endif
 struct ConvArgs {
   const float* in; const float* in2; float* out; const float* w; const float* bias;
