@@ -1,3 +1,4 @@
+# (round 3 diagnostic; see profiles/r03_experiments.txt 17-18 and DESIGN.md section 4)
 import sys, torch
 a, b = torch.load(sys.argv[1]), torch.load(sys.argv[2])
 for k in sorted(a):

@@ -1,3 +1,4 @@
+# (round 3 diagnostic; see profiles/r03_experiments.txt 17-18 and DESIGN.md section 4)
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
