@@ -6,7 +6,7 @@ import torch
 from maxstyle_amd import ops
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(11)
-for (N, Cin, Cout, H, W) in [(16, 128, 128, 16, 16), (16, 128, 64, 16, 16), (4, 512, 512, 4, 4), (16, 64, 128, 16, 16), (3, 100, 40, 8, 12), (16, 128, 128, 8, 8)]:
+for (N, Cin, Cout, H, W) in [(16, 32, 64, 128, 128), (16, 64, 128, 64, 64), (16, 128, 256, 32, 32), (16, 128, 128, 16, 16), (16, 128, 64, 16, 16), (4, 512, 512, 4, 4), (16, 64, 128, 16, 16), (3, 100, 40, 8, 12), (16, 128, 128, 8, 8)]:
     x = torch.randn(N, Cin, H, W, generator=g).to(dev); w = (torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1)
     b = torch.randn(Cout, generator=g).to(dev)
     cf = torch.stack([torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3, torch.randn(Cin, generator=g) * 0.1, torch.zeros(Cin)], 1).contiguous().to(dev)
