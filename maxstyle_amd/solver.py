@@ -17,7 +17,7 @@ import torch.nn as nn
 from . import engine as E
 from . import train_engine as T
 from .maxstyle import MaxStyle
-from .networks import Dual_Branch_Encoder, MyDecoder, _disable_tracking_bn_stats, set_grad
+from .networks import Dual_Branch_Encoder, MyDecoder, _disable_tracking_bn_stats, set_grad, module_params
 
 
 def cross_entropy_2D(input, target, weight=None, size_average=True):
@@ -130,7 +130,11 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             self._bank.zero_grad()              # the gradients are views of one flat buffer: keep them attached, clear the values
             return
         for m in self.model.values():
-            m.zero_grad()
+            if set_to_none:
+                for p in module_params(m):          # nn.Module.zero_grad(set_to_none=True) on the cached parameter list (see networks.module_params)
+                    p.grad = None
+            else:
+                m.zero_grad(set_to_none=False)
 
     def train(self, mode=True, if_testing=False):
         """nn.Module.train(mode); `if_testing=True` is the reference's spelling of eval (advanced_triplet...py:1018-1035)."""
