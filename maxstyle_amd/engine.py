@@ -244,6 +244,15 @@ class PackedNets:
         return d
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _raw_stream(device_index):
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
+
+
 class XfCoef:
     """BatchNorm coefficients that no launch has produced yet: the conv that consumes them in its prologue derives them itself (`ms_conv2d_xfin`).
     kind 0: ms_bn_finalize folded in (tab = statistics table, p0 / p1 = gamma / beta); kind 1: ms_bn_bwd_coefs folded in (tab = the float2 table of a conv
@@ -420,7 +429,9 @@ class InnerLoopEngine:
         return getattr(lib, name)
 
     def _st(self):
-        return torch.cuda.current_stream().cuda_stream
+        # the raw handle of torch's CURRENT stream on this device (it changes under torch.cuda.graph capture and inside _side()): asked per launch, through the
+        # accessor that does not build a torch.cuda.Stream object (1 us instead of ~10 us per launch of host time - a trainer pass is ~300 eager launches)
+        return _raw_stream(self.dev.index if self.dev.index is not None else torch.cuda.current_device())
 
     # ------------------------------------------------------------------ per-signature loop state (flat buffers + captured graph)
     CFG_CACHE_MAX = 16
