@@ -7,7 +7,13 @@ from ._lib import lib, check
 _ws_cache = {}
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """Raw handle of torch's current stream on the current device (without building a torch.cuda.Stream object per launch)."""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
