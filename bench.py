@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-outer", action="store_true", help="skip the auxiliary whole-training-iteration figure")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size parity legs against the reference fixture (drift_full_size / dice_parity)")
+    ap.add_argument("--no-instep", action="store_true", help="skip the in-step timing of the priced launches (tools/prof_step.sh: their cut-off replays would pollute a kernel trace)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary blocks of the default line (winograd_off, c4, c5_bf16)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5, help="inner steps of the CPU-oracle sample")
@@ -113,6 +114,7 @@ def timed_steps(eng, z_i, lab_d, steps, warmup, use_graph, dist_on):
             graph = None
             torch.cuda.synchronize()
     run_one = (graph.replay if graph is not None else (lambda: eng.step(img)))
+    eng._bench_img = img                      # (the in-place image buffer of the step: in_step_times re-captures prefixes of the step on it)
     for _ in range(max(warmup - 1, 0)):
         run_one()
     eng.step_dev.zero_()                      # loss slots restart (the Adam moments keep evolving: same work per step)
@@ -134,6 +136,7 @@ def timed_steps(eng, z_i, lab_d, steps, warmup, use_graph, dist_on):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    eng.check_errors(sync=True)               # (outside the timed region) a timed-out bounded spin - single-read K1, `_xfin` - voids the run: raise, never report
     return dt, graph is not None, run_one
 
 
@@ -172,13 +175,103 @@ def _event_time(fn, reps=20, warm=3):
     return ts[len(ts) // 2] * 1e-3
 
 
+def _step_budget():
+    """tools/step_budget.py as a module (launch ledger of a step, per-launch bounds)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ms_step_budget", os.path.join(ROOT, "tools", "step_budget.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def in_step_times(eng, img, wanted, reps=15):
+    """Duration of single launches INSIDE the replayed step, measured live (no profiler): the step is captured twice as a HIP graph, once cut off behind the launch
+    and once in front of it (tools/step_budget.py::record_ledger(skip_after=i): the entry points behind the cut return without launching), both are replayed
+    alternately between HIP events on the launch stream, and the launch's in-step time is the median difference.  It therefore contains what the launch pays in
+    a step and not in isolation: inputs its predecessors left cold or still writing back, and its own dependent-launch boundary.
+    wanted: {name: predicate(ledger entry)} - the first matching launch of the step.  -> ({name: seconds}, ledger, {name: index})"""
+    sb = _step_budget()
+    ledger, _ = sb.record_ledger(eng, img)
+    torch.cuda.synchronize()
+    idx = {}
+    for name, pred in wanted.items():
+        for i, e in enumerate(ledger):
+            if pred(e):
+                idx[name] = i
+                break
+    cuts = sorted({i for i in idx.values()} | {i - 1 for i in idx.values() if i > 0})
+    graphs = {}
+    for c in cuts:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            sb.record_ledger(eng, img, skip_after=c)
+        graphs[c] = g
+        g.replay()
+    torch.cuda.synchronize()
+
+    def t_of(g):
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record(); g.replay(); e_.record()
+        torch.cuda.synchronize()
+        return s_.elapsed_time(e_) * 1e-3
+    out = {}
+    for name, i in idx.items():
+        diffs = []
+        for _ in range(reps):
+            a = t_of(graphs[i])
+            b = t_of(graphs[i - 1]) if i > 0 else 0.0
+            diffs.append(a - b)
+        diffs.sort()
+        out[name] = diffs[len(diffs) // 2]
+    # leave the engine's buffers as a complete step leaves them
+    eng.step(img)
+    torch.cuda.synchronize()
+    return out, ledger, idx
+
+
+def step_roofline(ledger, step_s):
+    """sum over the launches of one step of max(bytes / 8 TB/s, executed flop / 157.3 TFLOP/s) against the measured step time (accounting rules: tools/step_budget.py);
+    the per-launch table with in-step durations from a kernel trace is committed as profiles/r04_step_budget_<config>.txt / .json."""
+    sb = _step_budget()
+    tot = hb = mf = 0.0
+    for e in ledger:
+        b, _ = sb.bound_us(e)
+        tot += b
+        if e["bytes"] / sb.HBM * 1e6 >= b:
+            hb += b
+        else:
+            mf += b
+    return {"launches": len(ledger), "sum_bound_us": tot, "hbm_bound_us": hb, "mfma_bound_us": mf, "step_us": step_s * 1e6, "frac": tot / (step_s * 1e6),
+            "bound_rule": "per launch max(algorithmic bytes / 8.0 TB/s, EXECUTED flop / 157.3 TFLOP/s): Winograd launches 16/36 of the direct-form flop, sub-pixel forms 4/9 and 1/4",
+            "algorithmic_GB_per_step": sum(e["bytes"] for e in ledger) / 1e9, "direct_form_GFLOP_per_step": sum(e["flop"] for e in ledger) / 1e9}
+
+
+def conv_in_step(eng):
+    """In-step durations of the three priced convolution launches of the engine's step (in_step_times) + the step's launch ledger; ({}, None) when it cannot be measured."""
+    try:
+        C, H = eng.nets.seg["u4.c3"].cout, eng.H
+        top = lambda e: e["conv"] is not None and e["conv"]["ks"] == 3 and e["conv"]["stride"] == 1 and (e["conv"]["fetch"] & 0xFF) == 0 and \
+            e["conv"]["Cin"] == C and e["conv"]["Cout"] == C and e["conv"]["Hs"] == H
+        wanted = {"dgrad_actbwd": lambda e: top(e) and e["fn"].startswith("ms_conv2d_actbwd") and e["conv"]["pm"] == 2,
+                  "dgrad_plain": lambda e: top(e) and not e["fn"].startswith("ms_conv2d_actbwd") and e["conv"]["pm"] == 2 and e["conv"]["epi"] == 0,
+                  "conv_fwd": lambda e: top(e) and not e["fn"].startswith("ms_conv2d_actbwd") and e["conv"]["pm"] == 0 and e["conv"]["epi"] == 0}
+        ts, ledger, idx = in_step_times(eng, eng._bench_img, wanted)
+        for k, i in idx.items():
+            print(f"[bench] in-step {k}: launch #{i} {ledger[i]['fn']}:{ledger[i]['key']} {ts[k] * 1e6:.1f} us", file=sys.stderr)
+        return ts, ledger
+    except Exception as ex:  # noqa: BLE001 - a measurement aid must not take the line down
+        print(f"[bench] in-step timing unavailable: {ex!r}", file=sys.stderr)
+        torch.cuda.synchronize()
+        return {}, None
+
+
 def _traffic_table(B, H, W):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE with the guide's gfx950 corrections,
     tools/pmc_traffic.py); the newest round's file wins."""
     if (B, H, W) != (16, 256, 256):
         return {}
     tab = {}
-    for name in ("r01_traffic.json", "r02_traffic.json", "r03_traffic.json"):
+    for name in ("r01_traffic.json", "r02_traffic.json", "r03_traffic.json", "r04_traffic.json"):
         try:
             tab.update(json.load(open(os.path.join(ROOT, "profiles", name))))
             tab["_source"] = f"profiles/{name}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (tools/profile_round.sh), NOT collected in this run"
@@ -187,7 +280,7 @@ def _traffic_table(B, H, W):
     return tab
 
 
-def kernel_rooflines(eng, dev, config):
+def kernel_rooflines(eng, dev, config, instep=None):
     """Per-launch duration of the kernels DESIGN.md prices, measured live with HIP events on the launch stream, on the live buffers of the
     last step.  `dominant` = the kernel with the largest per-step total in this round's rocprofv3 summary (profiles/r02_kernel_stats.txt):
     the data-gradient 3x3 conv with the two-tensor BatchNorm-backward prologue and the activation-backward epilogue at the top level
@@ -245,36 +338,53 @@ def kernel_rooflines(eng, dev, config):
     flops = 2.0 * B * H * W * C * C * 9
     shape = "%d->%d @%dx%dx%d" % (C, C, B, H, W)
 
-    def conv_block(key, kernel, nbytes, tkey):
-        # priced against BOTH roofs with the ALGORITHMIC work of the direct form (2*9*Cin*Cout flop per pixel: the Winograd form executes 16/36 of the
-        # multiplications, which is how `mfma_frac` can pass the fraction the direct form could reach); `bound` = the roof the launch is closer to
-        mf = flops / t[key] / 1e12 / F32_MFMA_PEAK_TFLOPS
-        hf = nbytes / t[key] / 1e9 / HBM_PEAK_GBPS
-        blk = {"bound": "mfma", "achieved": flops / t[key] / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mf}
+    instep = instep or {}
+    from maxstyle_amd import _lib
+    FORMS = {0: "conv_mfma_kernel (first generation, direct form)", 1: "conv_wide_kernel<NT,PRO,1,true,float> (wide, direct form)",
+             2: "conv_wide_kernel<1,PRO,1,true,ms_f32w%s> (Winograd F(2x2,3x3), one 16-channel block per staged tile)" % ("32" if W < 64 else ""),
+             3: "conv_wide_kernel<2,PRO,1,true,ms_f32w%s> (Winograd F(2x2,3x3), two 16-channel blocks per staged tile)" % ("32" if W < 64 else "")}
+
+    def conv_block(key, what, pro, nbytes, tkey):
+        # Both roofs are priced with what the launch EXECUTES: the Winograd form multiplies 16/36 of the direct form's products on the same fp32 matrix instruction, so its
+        # matrix-pipe fraction is executed flop / peak (never above 1); the direct-form figure is a side field (`direct_form_equivalent_tflops`).  `bound` = the roof the
+        # launch is closer to.  `frac` / `achieved` use the IN-STEP duration of the launch (in_step_times: measured live inside the replayed step) when the caller measured
+        # it; the isolated back-to-back replay (warm caches, no neighbours) is `frac_isolated`.
+        form = int(_lib.lib.ms_conv2d_form(B, C, H, W, C, pro, 0, wino))
+        exf = flops * (16.0 / 36.0 if form >= 2 else 1.0)
+        t_iso = t[key]
+        t_use = instep.get(key, t_iso)
+
+        def fr(tt):
+            return exf / tt / 1e12 / F32_MFMA_PEAK_TFLOPS, nbytes / tt / 1e9 / HBM_PEAK_GBPS
+        mf, hf = fr(t_use)
+        mfi, hfi = fr(t_iso)
+        blk = {"bound": "mfma", "achieved": exf / t_use / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mf, "frac_isolated": mfi}
         if hf > mf:
-            blk = {"bound": "hbm", "achieved": nbytes / t[key] / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hf}
-        blk.update({"traffic": traffic.get(tkey), "traffic_source": traffic.get("_source") if traffic.get(tkey) else None, "kernel": kernel + " " + shape, "us_per_launch": t[key] * 1e6, "algorithmic_bytes": nbytes,
-                    "hbm_GBps": nbytes / t[key] / 1e9, "hbm_frac": hf, "flop_per_launch": flops, "tflops": flops / t[key] / 1e12, "mfma_frac": mf,
-                    "form": "winograd F(2x2,3x3)" if (wino and C % 8 == 0 and W >= 64 and W % 4 == 0) else "direct"})
-        if blk["form"] != "direct":
-            # what the matrix pipe itself executes in this form: 16 multiplications per 2x2 outputs instead of 36
-            blk["executed_tflops"] = blk["tflops"] * 16.0 / 36.0
-            blk["executed_mfma_frac"] = mf * 16.0 / 36.0
+            blk = {"bound": "hbm", "achieved": nbytes / t_use / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hf, "frac_isolated": hfi}
+        blk.update({"traffic": traffic.get(tkey), "traffic_source": traffic.get("_source") if traffic.get(tkey) else None,
+                    "kernel": FORMS[form].replace("PRO", str(pro)) + " " + what + " " + shape,
+                    "us_per_launch": t_use * 1e6, "us_per_launch_source": ("in-step (two cut-off captures of the step, difference)" if key in instep else "isolated back-to-back replay"),
+                    "us_per_launch_isolated": t_iso * 1e6, "algorithmic_bytes": nbytes, "hbm_GBps": nbytes / t_use / 1e9, "hbm_frac": hf, "hbm_frac_isolated": hfi,
+                    "flop_per_launch_executed": exf, "executed_tflops": exf / t_use / 1e12, "executed_mfma_frac": mf, "executed_mfma_frac_isolated": mfi,
+                    "form": "winograd F(2x2,3x3)" if form >= 2 else "direct", "channel_blocks_per_tile": (form - 1 if form >= 2 else None)})
+        if form >= 2:
+            blk["direct_form_flop_per_launch"] = flops
+            blk["direct_form_equivalent_tflops"] = flops / t_use / 1e12      # (work of the direct form per second: can pass the pipe's peak, NOT a roofline fraction)
         return blk
 
     def hbm_block(key, kernel, nbytes, tkey):
-        return {"bound": "hbm", "achieved": nbytes / t[key] / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / t[key] / 1e9 / HBM_PEAK_GBPS,
+        t_use = instep.get(key, t[key])
+        return {"bound": "hbm", "achieved": nbytes / t_use / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / t_use / 1e9 / HBM_PEAK_GBPS,
+                "frac_isolated": nbytes / t[key] / 1e9 / HBM_PEAK_GBPS,
                 "traffic": traffic.get(tkey), "traffic_source": traffic.get("_source") if traffic.get(tkey) else None, "kernel": kernel,
-                "us_per_launch": t[key] * 1e6, "algorithmic_bytes": nbytes}
+                "us_per_launch": t_use * 1e6, "us_per_launch_source": ("in-step (two cut-off captures of the step, difference)" if key in instep else "isolated back-to-back replay"),
+                "us_per_launch_isolated": t[key] * 1e6, "algorithmic_bytes": nbytes}
 
-    nt = "NT=%d" % (1 if C <= 16 else 2)
     return {
         # reads g, u2 (prologue), u1 (mask), writes g1: 4 tensors
-        "dominant": conv_block("dgrad_actbwd", "conv_wide_kernel<%s,PRO=2> (3x3 data-gradient, two-tensor BatchNorm-backward prologue, activation-backward epilogue)" % nt,
-                               4.0 * n_elem * 4, "conv_dgrad_actbwd_c16_256"),
-        "dgrad_plain": conv_block("dgrad_plain", "conv_wide_kernel<%s,PRO=2> (3x3 data-gradient, two-tensor prologue, plain epilogue)" % nt, 3.0 * n_elem * 4,
-                                  "conv_dgrad_plain_c16_256"),
-        "conv_fwd": conv_block("conv_fwd", "conv_wide_kernel<%s,PRO=0> (3x3 forward, +BN statistics epilogue)" % nt, 2.0 * n_elem * 4, "conv3x3_c16_256"),
+        "dominant": conv_block("dgrad_actbwd", "3x3 data-gradient, two-tensor BatchNorm-backward prologue, activation-backward epilogue", 2, 4.0 * n_elem * 4, "conv_dgrad_actbwd_c16_256"),
+        "dgrad_plain": conv_block("dgrad_plain", "3x3 data-gradient, two-tensor prologue, plain epilogue", 2, 3.0 * n_elem * 4, "conv_dgrad_plain_c16_256"),
+        "conv_fwd": conv_block("conv_fwd", "3x3 forward, +BN statistics epilogue", 0, 2.0 * n_elem * 4, "conv3x3_c16_256"),
         "style": hbm_block("style", "ms_style_fwd (K1: moments + restyle, single read) %dx%dx%dx%d" % (B, C, H, W), 8.0 * n_elem, "maxstyle_fwd_l4"),
         "style_bwd": hbm_block("style_bwd", "ms_style_bwd (K2: restyle backward with dx) %dx%dx%dx%d" % (B, C, H, W), 12.0 * n_elem, "maxstyle_bwd_l4"),
         "style_bf16": hbm_block("style_bf16", "ms_style_fwd_bf16 (K1 with bf16 activation storage, fp32 statistics; 4 B/element) %dx%dx%dx%d" % (B, C, H, W), 4.0 * n_elem, None),
@@ -676,12 +786,16 @@ def whole_call(dev, args, rank):
     def timed(n_iter, reps):
         for _ in range(3):
             call(n_iter)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            call(n_iter)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps
+        best = None
+        for _ in range(3):                    # three groups of `reps` calls, the fastest group: a 1-2 ms host-side call is sensitive to whatever else the box's cores do
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                call(n_iter)
+            torch.cuda.synchronize()
+            dt_ = (time.perf_counter() - t0) / reps
+            best = dt_ if best is None else min(best, dt_)
+        return best
     t_call, t_dec = timed(K, 20), timed(0, 20)
     # the same call with the DEFERRED error protocol (solver.loop_error_check): the single-read kernel's error word is resolved by the next call / at
     # optimize_all_params instead of by an event wait inside this call, so the host prepares the next call while the GPU still runs this one
@@ -719,9 +833,11 @@ def secondary_blocks(dev, args, rank):
     torch.cuda.empty_cache()
     eng, _, _, _, _, z_i, lab_d = build(dev, args.batch, 320, rank, (1, 3, 2))
     dt, graphed, _ = timed_steps(eng, z_i, lab_d, 10, 2, True, False)
-    roof = kernel_rooflines(eng, dev, "c4")
+    ins, ledger = conv_in_step(eng)
+    roof = kernel_rooflines(eng, dev, "c4", ins)
     out["c4"] = {"workload": f"C4: FCN_64 dual-branch, batch {args.batch}x3x320x320, MaxStyle layers [3,4,5], Adam lr 0.1, fp32", "steps_s": 10 / dt, "ms_per_step": dt / 10 * 1e3,
-                 "hip_graph": graphed, "roofline": roof["dominant"], "roofline_conv_fwd": roof["conv_fwd"], "roofline_maxstyle": roof["style"], "roofline_maxstyle_bwd": roof["style_bwd"]}
+                 "hip_graph": graphed, "roofline": roof["dominant"], "roofline_conv_fwd": roof["conv_fwd"], "roofline_maxstyle": roof["style"], "roofline_maxstyle_bwd": roof["style_bwd"],
+                 "step_roofline": (step_roofline(ledger, dt / 10) if ledger else None), "step_roofline_per_launch": "profiles/r04_step_budget_c4.txt"}
     del eng
     torch.cuda.empty_cache()
     a5 = copy.copy(args)
@@ -892,7 +1008,8 @@ def main():
         loss_last = float(eng.loss_buf[0])
         steady = steady_state(run_one, eng, args.steady_seconds)
         none6 = {k: None for k in ("dominant", "dgrad_plain", "conv_fwd", "style", "style_bwd", "style_bf16")}
-        roof = none6 if bf16 else kernel_rooflines(eng, dev, args.config)          # (the priced kernels and their algorithmic bytes are the fp32-storage ones)
+        ins, ledger = ({}, None) if (bf16 or args.no_instep) else conv_in_step(eng)
+        roof = none6 if bf16 else kernel_rooflines(eng, dev, args.config, ins)     # (the priced kernels and their algorithmic bytes are the fp32-storage ones)
         step_s = dt / args.steps
         res = {
             "metric": ("inner adversarial style-opt steps/sec (batch 16, 256x256)" if headline else
@@ -912,6 +1029,8 @@ def main():
                            if headline else None),
             "roofline": roof["dominant"], "roofline_dgrad_plain": roof["dgrad_plain"], "roofline_conv_fwd": roof["conv_fwd"],
             "roofline_maxstyle": roof["style"], "roofline_maxstyle_bwd": roof["style_bwd"], "roofline_maxstyle_bf16": roof["style_bf16"], "loss_check": loss_last,
+            "step_roofline": (step_roofline(ledger, step_s) if ledger else None),
+            "step_roofline_per_launch": f"profiles/r04_step_budget_{args.config}.txt (every launch of the step: bytes, executed flop, bound, in-step duration from a rocprofv3 kernel trace)",
         }
         if world == 1 and not args.no_cpu_baseline and args.config == "c2" and not bf16:
             res["cpu_baseline"], _ = cpu_baseline(W, img, lab, styles, args.cpu_steps, z_gpu=z_i.cpu())

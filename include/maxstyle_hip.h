@@ -27,12 +27,21 @@ const char* ms_last_error(void);
 /* bit of the `fetch` argument of the convolution entry points: the caller accepts the Winograd form for this call (see ms_conv2d) */
 #define MS_FETCH_WINOGRAD 0x100
 #define MS_FETCH_X3 0x200
+/* with MS_FETCH_WINOGRAD: keep the Winograd form's ONE-channel-block variant (the input tile staged and transformed per 16 output channels) where the library would
+ * stage it once per 32 (round 4).  Per output element both variants accumulate in the same order - the same bits; only the grouping of the BatchNorm partial sums
+ * follows the work-item numbering.  An A/B and test switch, not a numerical choice. */
+#define MS_FETCH_WINO_NT1 0x400
 /* ms_conv2d epi_mode 6: the 2x2-POOLED store.  out is [N, Cout, H/2, W/2] and receives the sum of every 2x2 block of the convolution's result, in ms_pool2_sum's
  * order over the values as they would have been stored: the same bits as ms_conv2d + ms_pool2_sum, a quarter of the bytes written and none read back.  The
  * data-gradient of `conv3x3(nearest-up-sampled x)` (encoder_decoder.py:298-300, 323-337 backward) ends in exactly that sum.  Built for the Winograd form of the
  * wide kernel only (ks 3, stride 1, MS_FETCH_WINOGRAD; no bias / statistics): ask ms_conv2d_pool2_ok first. */
 #define MS_EPI_POOL2 6
 int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16);      /* bf16: 0 = the fp32 entry point, 1 = `_bf16`, 2 = `_bf16m` */
+/* Which kernel form ms_conv2d(ks 3, stride 1, fetch) takes for this shape (16-byte aligned tensors assumed) - what the measurement tools print and price, asked of the
+ * dispatch itself instead of re-deriving its rules: 0 first-generation kernel (conv_mfma_kernel) | 1 wide direct form (conv_wide_kernel) | 2 Winograd F(2x2,3x3), one
+ * 16-channel block per staged tile (conv_wide_kernel<1, ..., ms_f32w*>) | 3 Winograd, two blocks (conv_wide_kernel<2, ...>: round 4).  fetch = the call's fetch argument
+ * (MS_FETCH_WINOGRAD / MS_FETCH_WINO_NT1 bits); a fused-fetch call (fetch & 0xFF != 0) is always 0. */
+int ms_conv2d_form(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16, int fetch);
 /* Compute units of the current device (hipDeviceProp.multiProcessorCount, read once per device): every persistent grid and every
  * co-residency bound of the library is sized from it (a partitioned or CU-masked device reports fewer than MI355X's 256). */
 int ms_num_cus(void);

@@ -88,7 +88,8 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   // bit 8 of `fetch` (MS_FETCH_WINOGRAD): the caller accepts the Winograd F(2x2,3x3) form for this call where it is built (see include/maxstyle_hip.h)
   const bool wino_ok = (fetch >= 0) && (fetch & MS_FETCH_WINOGRAD) != 0;
   const bool x3_ok = (fetch >= 0) && (fetch & MS_FETCH_X3) != 0;               // bit 9: ... the three-way bf16 split form
-  if (fetch >= 0) fetch &= ~(MS_FETCH_WINOGRAD | MS_FETCH_X3);
+  const bool wino_nt1 = (fetch >= 0) && (fetch & MS_FETCH_WINO_NT1) != 0;      // bit 10: the one-channel-block variant of the Winograd form
+  if (fetch >= 0) fetch &= ~(MS_FETCH_WINOGRAD | MS_FETCH_X3 | MS_FETCH_WINO_NT1);
   if (pro_mode < 0 || pro_mode > 3 || epi_mode < 0 || (epi_mode > 2 && epi_mode != MS_EPI_POOL2) || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
   if (epi_mode == MS_EPI_POOL2 && (mk != nullptr || fin != nullptr || stats != nullptr || bias != nullptr)) { set_error("ms_conv2d: the pooled epilogue is a plain store (no bias, statistics or mask)"); return MS_ERR_INVALID; }
   // the activation helper computes max(v, v*slope): LeakyReLU / ReLU slopes only
@@ -143,6 +144,7 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   a.bw_parts = bw_parts; a.bw_count = (double)N * Hs * Ws; a.bw_out = bw_out;
   a.wino_ok = wino_ok ? 1 : 0;
   a.x3_ok = x3_ok ? 1 : 0;
+  a.wino_nt1 = wino_nt1 ? 1 : 0;
   a.act_bf16 = act_bf16;                  // 0 fp32 storage | 1 bf16 storage, fp32 matrix arithmetic | 2 bf16 storage, bf16 matrix arithmetic where built (`_bf16m`)
   a.pro_mode = pro_mode; a.pro_nstride = pro_nstride; a.pro_cstride = pro_cstride < 1 ? 1 : pro_cstride; a.slope = slope; a.epi_mode = epi_mode;
   if (mk != nullptr) { a.mk_u = mk->u; a.mk_coef = mk->coef4; a.mk_slope = mk->slope; a.mk_tab = mk->tab; }
@@ -245,11 +247,25 @@ extern "C" int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int pr
   a.pro_mode = pro_mode; a.epi_mode = MS_EPI_POOL2; a.wino_ok = 1; a.act_bf16 = (bf16 < 0 || bf16 > 2) ? 2 : bf16;
   return (conv_wide_eligible(a, 3, 1, FETCH_NORMAL, true) && conv_wide_is_wino(a)) ? 1 : 0;
 }
-// channels a rider may have on a conv launch with this output shape (a lower bound of 4 x its workgroup count: one channel block, one workgroup per CU)
+namespace ms { int conv_wino_blocks(const ConvArgs& a); }      // ms_conv_inst_wino.hip
+extern "C" int ms_conv2d_form(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16, int fetch) {
+  if (N < 1 || Cin < 1 || H < 1 || W < 1 || Cout < 1 || pro_mode < 0 || pro_mode > 2 || fetch < 0 || (fetch & 0xFF) != 0) return 0;
+  ConvArgs a{};
+  a.N = N; a.Cin = Cin; a.Hs = a.Hin = a.Hout = H; a.Ws = a.Win = a.Wout = W; a.Cout = a.cout_real = Cout;
+  a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (Cout + 63) / 64 * 64;
+  a.pro_mode = pro_mode; a.wino_ok = (fetch & MS_FETCH_WINOGRAD) ? 1 : 0; a.x3_ok = (fetch & MS_FETCH_X3) ? 1 : 0; a.wino_nt1 = (fetch & MS_FETCH_WINO_NT1) ? 1 : 0;
+  a.act_bf16 = (bf16 < 0 || bf16 > 2) ? 2 : bf16;
+  if (!conv_wide_eligible(a, 3, 1, FETCH_NORMAL, W % 4 == 0)) return 0;
+  if (!conv_wide_is_wino(a)) return 1;
+  return 1 + conv_wino_blocks(a);
+}
+// channels a rider may have on a conv launch with this output shape: 4 x a LOWER bound of its workgroup count.  The launcher's grid is
+// min(items, CUs * per_cu) rounded DOWN to a multiple of the channel-block count ncb (launch_conv_t), with items >= tiles, per_cu >= 1 and ncb <= 32 (512 output
+// channels in 16-channel blocks), so min(tiles, CUs) - 31 workgroups always exist whatever tile width the dispatch picks (the bound used to ignore ncb).
 extern "C" int ms_conv_ride_capacity(int N, int Hout, int Wout) {
   if (N < 1 || Hout < 1 || Wout < 1) return 0;
   const long tiles = (long)N * cdiv(Wout, tile_w(Wout)) * cdiv(Hout, tile_h(Wout));
-  return (int)(4 * std::min<long>(tiles, (long)num_cus()));
+  return (int)(4 * std::max<long>(0, std::min<long>(tiles, (long)num_cus()) - 31));
 }
 extern "C" int ms_conv2d_ride(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                               int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,

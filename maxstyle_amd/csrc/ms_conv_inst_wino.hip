@@ -10,7 +10,27 @@ static int wide_wino(const ConvArgs& a, hipStream_t st) {
     default: return launch_conv_wide_t<1, 2, 1, true, WT>(a, st);
   }
 }
+int conv_dispatch_wino2(const ConvArgs& a, hipStream_t st);      // ms_conv_inst_wino2.hip: two channel blocks per staged tile
+// Channel blocks per staged input tile (round 4).  Two blocks = ONE workgroup per CU (256 registers, 128 accumulators per MFMA wave): the tile is staged, prologue'd and
+// transformed once per 32 output channels, but a SIMD then holds one MFMA wave and one staging wave instead of two of each.  Measured per layer on MI355X
+// (tools/ab_wino_nt.py, profiles/r04_wino_nt_ab.txt): it wins where the K loop is long and the staging side is light - Cin >= 64 with at least one work item per CU;
+// with the two-tensor BatchNorm-backward prologue (twice the loads per chunk on half the staging waves) only from 256 input channels up or where the layer widens
+// (Cout > Cin).  MS_CONV_WINO_NT: 1 = the one-block form everywhere, 2 = two blocks wherever Cout > 16 (A/B switches); per call: MS_FETCH_WINO_NT1.
+static int wino_nt(const ConvArgs& a) {
+  static const int cap = getenv("MS_CONV_WINO_NT") ? atoi(getenv("MS_CONV_WINO_NT")) : 0;
+  static const bool tune = getenv("MS_CONV_TUNE") != nullptr;
+  const int c = (tune && getenv("MS_CONV_WINO_NT")) ? atoi(getenv("MS_CONV_WINO_NT")) : cap;
+  if (c == 1 || a.Cout <= 16 || a.wino_nt1) return 1;
+  if (c >= 2) return 2;
+  const int tw = a.Wout < 64 ? 32 : 64, th = 256 / tw;
+  const long items2 = (long)a.N * cdiv(a.Wout, tw) * cdiv(a.Hout, th) * cdiv(a.Cout, 32);
+  if (a.Cin < 64 || items2 < (long)num_cus()) return 1;
+  if (a.pro_mode == 2 && a.Cin < 256 && a.Cout <= a.Cin) return 1;
+  return 2;
+}
+int conv_wino_blocks(const ConvArgs& a) { return wino_nt(a); }
 int conv_dispatch_wino(const ConvArgs& a, hipStream_t st) {
+  if (wino_nt(a) == 2) return conv_dispatch_wino2(a, st);
   if (a.Wout < 64) return a.act_bf16 ? wide_wino<ms_bf16w32>(a, st) : wide_wino<ms_f32w32>(a, st);
   return a.act_bf16 ? wide_wino<ms_bf16w>(a, st) : wide_wino<ms_f32w>(a, st);
 }

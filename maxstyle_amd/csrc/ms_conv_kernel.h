@@ -14,6 +14,9 @@
 // never overlap the MFMAs.  With roles split, each SIMD holds a VALU/memory wave and an MFMA wave, which do overlap
 // (separate pipes), and every global load has a full MFMA phase to land.
 #pragma once
+#include <map>
+#include <mutex>
+#include <utility>
 #include <algorithm>
 #include <mutex>
 #include <type_traits>
@@ -71,6 +74,7 @@ struct ConvArgs {
   int stagger;                  // wide kernel: the second workgroup of a CU starts `stagger` x ~1k cycles late (0 = off), see conv_wide_kernel
   int wino_ok;                  // the caller accepts the Winograd form of a 3x3 stride-1 convolution for this call (MS_FETCH_WINOGRAD)
   int x3_ok;                    // ... the three-way bf16 split form (MS_FETCH_X3)
+  int wino_nt1;                 // Winograd form: one channel block per staged tile (MS_FETCH_WINO_NT1)
   int act_bf16;                 // activation tensors (in, in2, out, mk_u) are stored as bf16 (the `_bf16` entry points); statistics / coefficients / weights fp32
   int dbg;                      // timing-only ablation bits (MS_CONV_DBG): 1 skip MFMA loop, 2 skip global loads, 4 skip epilogue stores, 8 skip LDS stores, 16 skip the epilogue
   int bw_parts; double bw_count; float* bw_out;   // pro_mode 3 (host side): BatchNorm-backward coefficients are derived in-kernel from bw_parts partial sums per channel
@@ -1152,6 +1156,21 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   else if (a.epi_mode == 3) conv_table_tail<NT, false>(a, smem, vb, ncb, 0.f, st_mean, st_m2);
 }
 
+// Resident 512-thread workgroups per CU of kernel `fn` with `lds_bytes` of dynamic LDS, as the occupancy API sees them (VGPRs AND AGPRs, SGPRs, LDS, wave slots), asked
+// once per (instantiation, LDS size).  Every persistent conv grid is capped by it: the `_xfin` launches poll granules that other workgroups of the SAME launch publish,
+// so the whole grid must be co-resident whatever order the dispatcher uses (hipFuncAttributes.numRegs alone does not count accumulation registers).
+inline int conv_resident_per_cu(const void* fn, size_t lds_bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, size_t>, int> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find({fn, lds_bytes});
+  if (it != cache.end()) return it->second;
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 512, lds_bytes) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
+  cache[{fn, lds_bytes}] = n;
+  return n;
+}
+
 template <int KS, int STRIDE, int FETCH, int NT, bool VEC, bool NARROW, bool IN2, typename AT>
 int launch_conv_t(const ConvArgs& a, hipStream_t st) {
   using G = Geo<KS, STRIDE, FETCH, VEC, NARROW, NT>;
@@ -1168,7 +1187,8 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
   const long nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb;
   // resident workgroups per CU: 512 threads = 2 waves per SIMD each -> at most 2 within 128 registers per wave, ONE above that (the 64-channel-tile variants:
   // a grid of two per CU ran as two rounds of a persistent kernel); LDS 160 KiB per CU.  The register count is a property of the instantiation: asked once.
-  const int per_cu = std::max(1, std::min(reg_limit, (int)((160 * 1024) / (lds_bytes + 256))));
+  int per_cu = std::max(1, std::min(reg_limit, (int)((160 * 1024) / (lds_bytes + 256))));
+  per_cu = std::max(1, std::min(per_cu, conv_resident_per_cu((const void*)conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2, AT>, lds_bytes)));
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;      // every workgroup keeps one channel block: item % ncb == blockIdx % ncb
   if (a.ride_out != nullptr && a.ride_C > 4 * nblocks) { set_error("ms_conv2d_ride: %d rider channels, %ld workgroups", a.ride_C, nblocks); return MS_ERR_INVALID; }

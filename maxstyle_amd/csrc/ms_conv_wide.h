@@ -91,17 +91,21 @@ struct WideGeoX3 {
 // stage holds the chunk's TRANSFORMED weights U = G g G^T as [16 positions][CK channels][16 output channels]: a lane's B fragment of position p and channel
 // group cg is one ds_read_b32 at p*128 + cg*64 + lane (64 consecutive dwords per wave: conflict-free).
 // TW_ = 64: 4-row tiles (waves = 2 tile rows x 2 halves of 32 pixels); TW_ = 32: 8-row tiles (waves = 4 tile rows) for rows of 20..63 pixels.
-template <int PRO, int TW_ = 64>
+// NT = 16-channel output blocks per staged input tile (round 4): the tile is staged, prologue'd and B^T d B-transformed ONCE for 16*NT output channels; the weight
+// region holds [16 positions][NT blocks][CK channels][16 output channels] (a B fragment of block j = one ds_read_b32 at p*128*NT + j*128 + cg*64 + lane).
+template <int NT_, int PRO, int TW_ = 64>
 struct WideGeoW {
   static constexpr int TW = TW_, TH = 256 / TW_, CK = 8, IH = TH + 2;
   static constexpr int RS = TW + 4;
   static constexpr int PS = 416;                                  // >= IH*RS (6*68 = 408, 10*36 = 360), == 32 (mod 64)
   static_assert(IH * RS <= PS, "plane stride");
   static constexpr int WS = 16;
-  static constexpr int BUF = CK * PS + 16 * CK * 16;              // floats per stage buffer
+  static constexpr int UP = CK * 16 * NT_;                        // floats of one transform position in the weight region
+  static constexpr int BUF = CK * PS + 16 * UP;                   // floats per stage buffer
   static constexpr int Q_ITEMS = CK * IH * (TW / 4), H_ITEMS = CK * IH * 2;
   static constexpr int NQI = (Q_ITEMS + 255) / 256, NHI = (H_ITEMS + 255) / 256;
-  static constexpr int W_ITEMS = CK * 16, NWI = 1;
+  static constexpr int W_ITEMS = CK * 16 * NT_, NWI = 1;
+  static_assert(W_ITEMS <= 256, "one (input channel, output channel) pair per staging thread");
 };
 
 // census of workgroup arrivals per CU (stagger experiment): which of the two co-resident workgroups am I?  Timing only - never read for results.
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
                        std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value;      // ... on bf16 storage
   constexpr int WTW = (std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w32>::value) ? 32 : 64;
   constexpr int WHALVES = WTW / 32;                               // 32-pixel halves of a tile row = waves per tile row
-  static_assert(!WIN || (R == 1 && NT == 1 && AF), "Winograd mode: 4-row tiles, one channel block per lane, channel count a multiple of the chunk");
-  using G = typename std::conditional<X3, WideGeoX3<(X3 ? NT : 1), PRO>, typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WIN, WideGeoW<PRO, WTW>, WideGeo<NT, PRO, R>>::type>::type>::type;
+  static_assert(!WIN || (R == 1 && NT <= 2 && AF), "Winograd mode: 4-row tiles, one or two channel blocks per lane, channel count a multiple of the chunk");
+  using G = typename std::conditional<X3, WideGeoX3<(X3 ? NT : 1), PRO>, typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WIN, WideGeoW<(WIN ? NT : 1), PRO, WTW>, WideGeo<NT, PRO, R>>::type>::type>::type;
   using IO = ActIO<AT>;
   constexpr int AB = IO::kBytes;
   static_assert(!BFM || R == 1, "bf16 MFMA mode: 4-row tiles");
@@ -345,7 +349,9 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
             // buffer addressing: resource = the packed weights, scalar offset = (tap, first channel of the chunk, channel block), vector offset = the
             // thread's hoisted (channel-in-chunk, output channel) - nine loads, no vector address arithmetic (layers with many chunks re-stage per chunk)
             const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0x7FFFFFFF, 0x00020000);
-            const int w_vo = 4 * ((tid >> 4) * a.cout_pad + (tid & 15));
+            // thread -> (block j = tid >> 7, channel-in-chunk = (tid >> 4) & 7, output channel 16 j + (tid & 15)): a staging wave covers ONE block, so its LDS stores
+            // below (position * UP + tid) are 64 consecutive dwords
+            const int w_vo = 4 * (((tid >> 4) & 7) * a.cout_pad + 16 * (tid >> 7) + (tid & 15));
             const int tap_stride = 4 * a.cin_pad * a.cout_pad, w_so = 4 * (c0 * a.cout_pad + co0);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) rww[tap] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rwt, w_vo, w_so + tap * tap_stride, 0));
@@ -442,8 +448,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           for (int xi = 0; xi < 4; ++xi) {
             const float u0 = t[xi][0], u3 = t[xi][2];
             const float u1 = 0.5f * ((t[xi][0] + t[xi][2]) + t[xi][1]), u2 = 0.5f * ((t[xi][0] + t[xi][2]) - t[xi][1]);
-            w_lds[(xi * 4 + 0) * 128 + tid] = u0; w_lds[(xi * 4 + 1) * 128 + tid] = u1;
-            w_lds[(xi * 4 + 2) * 128 + tid] = u2; w_lds[(xi * 4 + 3) * 128 + tid] = u3;
+            w_lds[(xi * 4 + 0) * G::UP + tid] = u0; w_lds[(xi * 4 + 1) * G::UP + tid] = u1;
+            w_lds[(xi * 4 + 2) * G::UP + tid] = u2; w_lds[(xi * 4 + 3) * G::UP + tid] = u3;
           }
         }
       } else
@@ -631,7 +637,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   // Winograd mode: wave = (tile row tr = wave >> 1: output rows 2tr, 2tr+1; half h = wave & 1: 32 pixels = 16 tiles of 2x2); MFMA M index = tile, N = output
   // channel, K = input channel.  Per 4-channel group: the lane's 4x4 input patch (tile m, channel 4cg+k) = 8 ds_read_b64, V = B^T d B in registers
   // (32 additions), 16 B fragments (one ds_read_b32 per position), 16 MFMAs - one per position, 16 independent accumulators.
-  f32x4 accw[WIN ? 16 : 1];
+  constexpr int WNT = WIN ? NT : 1;
+  f32x4 accw[WNT][WIN ? 16 : 1];
   auto compute_w = [&](const float* buf, auto first_tag) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(first_tag)::value;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -640,8 +647,10 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       const float* ub = buf + CK * PS + lane;
 #pragma unroll
       for (int cg = 0; cg < CK / 4; ++cg) {
-        // Register budget (128 with two workgroups per CU): 64 accumulators + up to 16 prefetched mask values leave ~30 for operands, so the order is fixed by
+        // Register budget (128 with two workgroups per CU, NT = 1): 64 accumulators + up to 16 prefetched mask values leave ~30 for operands, so the order is fixed by
         // hand (sched_barrier): patch rows are read in the order the position rows need them (d0 d2 | d1 | d3), B fragments one position row ahead.
+        // NT = 2 (one workgroup per CU, 256 registers): the SAME transformed patch row feeds the position row of both channel blocks - 8 MFMAs per 5 vector
+        // instructions instead of 4.
         const float* pa = ab + cg * 4 * PS;
         const float* pu = ub + cg * 64;
         // the patch rows stay in the register PAIRS the 8-byte reads deliver: (d0,d1) and (d2,d3) of a row.  Row transform = 2 packed additions per
@@ -652,21 +661,25 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           lo = *reinterpret_cast<const f2*>(pa + r * RS);
           hi = *reinterpret_cast<const f2*>(pa + r * RS + 2);
         };
-        auto ldu = [&](int xi, float (&u)[4]) {
+        auto ldu = [&](int xi, float (&u)[WNT][4]) {
 #pragma unroll
-          for (int nu = 0; nu < 4; ++nu) u[nu] = pu[(xi * 4 + nu) * 128];
+          for (int j = 0; j < WNT; ++j)
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) u[j][nu] = pu[(xi * 4 + nu) * G::UP + j * 128];
         };
         auto vrow = [&](f2 ta, f2 tb, float (&v)[4]) {
           const f2 w = ta - tb;
           v[0] = w.x; v[3] = w.y; v[1] = ta.y + tb.x; v[2] = tb.x - ta.y;
         };
-        auto mm = [&](int xi, const float (&v)[4], const float (&u)[4]) {
+        auto mm = [&](int xi, const float (&v)[4], const float (&u)[WNT][4]) {
 #pragma unroll
-          for (int nu = 0; nu < 4; ++nu)
-            accw[xi * 4 + nu] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[nu], u[nu], (FIRST && cg == 0) ? zero4 : accw[xi * 4 + nu], 0, 0, 0);
+          for (int j = 0; j < WNT; ++j)
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu)
+              accw[j][xi * 4 + nu] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[nu], u[j][nu], (FIRST && cg == 0) ? zero4 : accw[j][xi * 4 + nu], 0, 0, 0);
         };
         f2 d0a, d0b, d1a, d1b, d2a, d2b, d3a, d3b;
-        float ua[4], ub2[4], va[4], vb[4];
+        float ua[WNT][4], ub2[WNT][4], va[4], vb[4];
         ldrow(0, d0a, d0b); ldrow(2, d2a, d2b); ldu(0, ua); ldrow(1, d1a, d1b); ldu(1, ub2);
         __builtin_amdgcn_sched_barrier(0);
         vrow(d0a - d2a, d0b - d2b, va);
@@ -684,6 +697,101 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       }
     }
   };
+  // ---- Winograd mode, two channel blocks per lane (one workgroup per CU: ONE MFMA wave per SIMD, so nothing hides this wave's LDS latency but its own
+  // schedule).  Software pipeline over the 4-channel groups, fixed register roles: patch rows d0..d3, B-fragment sets U[0..3] (one per position row), va / vb:
+  //   S1: MM(0) [va, U0] | vb = V1(d1 + d2) | load d3, U2          S3: MM(2) [va, U2] | vb = V3(d1 - d3) | load d0', d2', U0' of the NEXT group
+  //   S2: MM(1) [vb, U1] | va = V2(d2 - d1) | load U3              S4: MM(3) [vb, U3] | load d1', U1' | va = V0'(d0' - d2')
+  // so every load has 8 MFMAs (256 cycles) between its issue and its first use.  The last group of a chunk passes the chunk barrier EARLY, between S2 and S3: by
+  // then every LDS read of this chunk has been issued (lgkmcnt(0) in front of the barrier: and has returned), so the staging waves may overwrite the buffer, and
+  // the next chunk's first operands - from the OTHER buffer, complete behind that barrier - are fetched under MM(2) / MM(3).  Same barrier count as the plain loop
+  // (one per chunk); in the launch's very last chunk the barrier only meets the other MFMA waves (the staging waves have returned: s_barrier counts live waves)
+  // and the prefetch reads stale, valid LDS that nobody uses.  Per accumulator the order of the K loop is the one-block kernel's: the same bits.
+  typedef float w2f2 __attribute__((ext_vector_type(2)));
+#ifdef MS_CONV_TRACE_BUILD
+  const bool w2_tr = (a.trace != nullptr) && (blockIdx.x == 0) && (MS_TID == 0);
+#else
+  constexpr bool w2_tr = false;
+#endif
+  int w2_p = 0;                                        // (cycle stamps only) running chunk number
+  w2f2 w2d[4][2];
+  float w2u[4][WNT][4], w2va[4], w2vb[4];
+  const int w2_aoff = k * PS + (2 * (wave / WHALVES)) * RS + 32 * (wave % WHALVES) + 2 * m;
+  auto w2_ldrow = [&](const float* pa, int r) __attribute__((always_inline)) {
+    w2d[r][0] = *reinterpret_cast<const w2f2*>(pa + r * RS);
+    w2d[r][1] = *reinterpret_cast<const w2f2*>(pa + r * RS + 2);
+  };
+  auto w2_ldu = [&](const float* pu, int xi) __attribute__((always_inline)) {
+    if constexpr (WIN) {
+#pragma unroll
+      for (int j = 0; j < WNT; ++j)
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) w2u[xi][j][nu] = pu[(xi * 4 + nu) * G::UP + j * 128];
+    }
+  };
+  auto w2_vrow = [&](w2f2 ta, w2f2 tb, float (&v)[4]) __attribute__((always_inline)) {
+    const w2f2 w = ta - tb;
+    v[0] = w.x; v[3] = w.y; v[1] = ta.y + tb.x; v[2] = tb.x - ta.y;
+  };
+  auto w2_pre_a = [&](const float* buf, int cg) __attribute__((always_inline)) {
+    const float* pa = buf + w2_aoff + cg * 4 * PS;
+    w2_ldrow(pa, 0); w2_ldrow(pa, 2); w2_ldu(buf + CK * PS + lane + cg * 64, 0);
+  };
+  auto w2_pre_b = [&](const float* buf, int cg) __attribute__((always_inline)) {
+    w2_ldrow(buf + w2_aoff + cg * 4 * PS, 1); w2_ldu(buf + CK * PS + lane + cg * 64, 1);
+    w2_vrow(w2d[0][0] - w2d[2][0], w2d[0][1] - w2d[2][1], w2va);
+  };
+  auto w2_cg = [&](const float* buf, int cg, auto zero_tag, const float* nbuf, int ncg, auto barrier_tag) __attribute__((always_inline)) {
+    constexpr bool ZERO = decltype(zero_tag)::value, BAR = decltype(barrier_tag)::value;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (WIN) {
+      const float* pa = buf + w2_aoff + cg * 4 * PS;
+      const float* pu = buf + CK * PS + lane + cg * 64;
+      auto mm = [&](int xi, const float (&v)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+#pragma unroll
+          for (int nu = 0; nu < 4; ++nu)
+            accw[j][xi * 4 + nu] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[nu], w2u[xi][j][nu], ZERO ? zero4 : accw[j][xi * 4 + nu], 0, 0, 0);
+      };
+      // (loads FIRST in every group, pinned: the compiler otherwise sinks them behind the group's MFMAs and a load issued in front of the early barrier would
+      //  be waited for with one MFMA of cover instead of eight)
+      __builtin_amdgcn_sched_barrier(0);
+      w2_ldrow(pa, 3); w2_ldu(pu, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(0, w2va); w2_vrow(w2d[1][0] + w2d[2][0], w2d[1][1] + w2d[2][1], w2vb);
+      __builtin_amdgcn_sched_barrier(0);
+      w2_ldu(pu, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(1, w2vb); w2_vrow(w2d[2][0] - w2d[1][0], w2d[2][1] - w2d[1][1], w2va);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (BAR) {
+        if (w2_tr && w2_p < 16) a.trace[w2_p * 4 + 1] = clock64();
+        lds_barrier();
+        if (w2_tr && w2_p < 16) a.trace[w2_p * 4 + 2] = clock64();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      w2_pre_a(nbuf, ncg);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(2, w2va); w2_vrow(w2d[1][0] - w2d[3][0], w2d[1][1] - w2d[3][1], w2vb);
+      __builtin_amdgcn_sched_barrier(0);
+      w2_ldrow(nbuf + w2_aoff + ncg * 4 * PS, 1); w2_ldu(nbuf + CK * PS + lane + ncg * 64, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(3, w2vb); w2_vrow(w2d[0][0] - w2d[2][0], w2d[0][1] - w2d[2][1], w2va);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // one K-chunk (CK / 4 = 2 groups); p = the chunk's running number in this workgroup (selects the stage buffer)
+  auto w2_chunk = [&](int p, auto first_tag) __attribute__((always_inline)) {
+    const float* buf = smem + (p & 1) * BUF;
+    const float* nbuf = smem + ((p + 1) & 1) * BUF;
+    static_assert(!WIN || CK == 8, "two channel groups per chunk");
+    w2_p = p;
+    if (w2_tr && p < 16) a.trace[p * 4 + 0] = clock64();
+    w2_cg(buf, 0, first_tag, buf, 1, std::false_type{});
+    w2_cg(buf, 1, std::false_type{}, nbuf, 0, std::true_type{});
+    if (w2_tr && p < 16) a.trace[p * 4 + 3] = clock64();
+  };
+
   // FULL = every channel group of the chunk is live: straight-line code; the guarded form only runs for a layer's ragged last chunk
   // FIRST = first K-chunk of an item: the first MFMA of every accumulator takes a zero C operand (no clearing pass after the epilogue)
   auto compute = [&](const float* buf, auto full_tag, int ncg, auto first_tag) __attribute__((always_inline)) {
@@ -928,38 +1036,42 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   // mask-tensor values of the item (epi_mode 3): 16 per lane.  With 64 accumulators there are no registers to park them across the MFMA loop, so they are
   // requested at the start of the item STRAIGHT INTO LDS (buffer_load_dwordx4 ... lds: lane l's 16 bytes land at base + 16 l, no vector register involved)
   // and read back by the epilogue: 4 KB per MFMA wave behind the coefficient table.
-  float* u_lds = smem + 2 * BUF + (PRO != 0 ? 4 * (nchunks * CK) : 0) + wave * 1024;
+  float* u_lds = smem + 2 * BUF + (PRO != 0 ? 4 * (nchunks * CK) : 0) + wave * (1024 * WNT);      // (+ 1024 floats per channel block j)
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   auto wino_interior = [&](int tile, int co0) {
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     return (tx * TW + TW <= a.Wout) && (ty * TH + TH <= a.Hout) && (co0 + 16 <= a.Cout) && !(a.dbg & 32);
   };
-  auto prefetch_u_w = [&](int n, int tile, int co0) __attribute__((always_inline)) {
+  auto prefetch_u_w = [&](int n, int tile, int cob) __attribute__((always_inline)) {
     if constexpr (WIN) {
-      if (!wino_interior(tile, co0)) return;            // border tiles load their (masked) values inside the epilogue
       const __amdgpu_buffer_rsrc_t ru = w_rsrc(a.mk_u, n);
 #pragma unroll
-      for (int row = 0; row < 2; ++row) {
-        const int so = w_soff(tile, co0, row);
-        if constexpr (AB == 4) {
+      for (int j = 0; j < WNT; ++j) {
+        const int co0 = cob + 16 * j;
+        if (!wino_interior(tile, co0)) continue;        // border tiles load their (masked) values inside the epilogue
 #pragma unroll
-          for (int q = 0; q < 2; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(u_lds + (2 * row + q) * 256), 16, w_voff + 16 * q, so, 0, 0);
-        } else {                                       // bf16 storage: the lane's 8 pixels of a row are ONE 16-byte transfer
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(u_lds + row * 256), 16, w_voff, so, 0, 0);
+        for (int row = 0; row < 2; ++row) {
+          const int so = w_soff(tile, co0, row);
+          if constexpr (AB == 4) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(u_lds + j * 1024 + (2 * row + q) * 256), 16, w_voff + 16 * q, so, 0, 0);
+          } else {                                     // bf16 storage: the lane's 8 pixels of a row are ONE 16-byte transfer
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(u_lds + j * 1024 + row * 256), 16, w_voff, so, 0, 0);
+          }
         }
       }
     }
   };
   // (the transform runs ONCE, before the epilogue variants branch: 64 accumulators must not stay live across their joins)
-  auto wino_out = [&](float (&o)[2][8]) __attribute__((always_inline)) {
+  auto wino_out = [&](int j, float (&o)[2][8]) __attribute__((always_inline)) {
     if constexpr (WIN) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float s[2][4];
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
-          const float m0 = accw[nu][r], m1 = accw[4 + nu][r], m2 = accw[8 + nu][r], m3 = accw[12 + nu][r];
+          const float m0 = accw[j][nu][r], m1 = accw[j][4 + nu][r], m2 = accw[j][8 + nu][r], m3 = accw[j][12 + nu][r];
           s[0][nu] = (m0 + m1) + m2; s[1][nu] = (m1 - m2) - m3;
         }
 #pragma unroll
@@ -970,7 +1082,9 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       }
     }
   };
-  auto epilogue_w = [&](int n, int tile, int co0, float (&o)[2][8], auto interior_tag) __attribute__((always_inline)) {
+  // j = the channel block of the lane's NT this call stores (co0 = its first channel); the running pixel count st_n is shared by the blocks of an item: every block
+  // merges against the count BEFORE the item and leaves the new one in stn_next (the caller commits it after the last block)
+  auto epilogue_w = [&](int n, int tile, int co0, int j, float (&o)[2][8], float& stn_next, auto interior_tag) __attribute__((always_inline)) {
     constexpr bool INT = decltype(interior_tag)::value;
     if constexpr (WIN) {
       if (a.dbg & 16) return;
@@ -980,7 +1094,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #pragma unroll
         for (int row = 0; row < 2; ++row)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[row][e] += bias_v[0];
+          for (int e = 0; e < 8; ++e) o[row][e] += bias_v[j];
       }
       const int nvx = INT ? 8 : max(0, min(8, a.Wout - xb));       // valid pixels among this lane's 8 per row (Wout % 4 == 0 on this path)
       bool ok[2][2];
@@ -1011,10 +1125,10 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
               }
           const float nt_ = st_n + cnt;
           const float wgt = cnt * __builtin_amdgcn_rcpf(nt_);
-          const float dd = mean - st_mean[0];
-          st_mean[0] += dd * wgt;
-          st_m2[0] += qq + dd * dd * st_n * wgt;
-          st_n = nt_;
+          const float dd = mean - st_mean[j];
+          st_mean[j] += dd * wgt;
+          st_m2[j] += qq + dd * dd * st_n * wgt;
+          stn_next = nt_;
         }
       }
       if (!INT && co >= a.Cout) return;
@@ -1022,14 +1136,14 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       if (a.epi_mode == 3) {
         float4 um[2][2];
         if constexpr (INT) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the item's LDS-destined loads have landed
+          // (the item's LDS-destined loads have landed: the caller waits ONCE per item, in front of the first block's epilogue)
           if constexpr (AB == 4) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) um[i >> 1][i & 1] = *reinterpret_cast<const float4*>(u_lds + i * 256 + lane * 4);
+            for (int i = 0; i < 4; ++i) um[i >> 1][i & 1] = *reinterpret_cast<const float4*>(u_lds + j * 1024 + i * 256 + lane * 4);
           } else {
 #pragma unroll
             for (int row = 0; row < 2; ++row) {
-              const wu32x4_t w = *reinterpret_cast<const wu32x4_t*>(u_lds + row * 256 + lane * 4);
+              const wu32x4_t w = *reinterpret_cast<const wu32x4_t*>(u_lds + j * 1024 + row * 256 + lane * 4);
               um[row][0] = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xFFFF0000u));
               um[row][1] = make_float4(__uint_as_float(w.z << 16), __uint_as_float(w.z & 0xFFFF0000u), __uint_as_float(w.w << 16), __uint_as_float(w.w & 0xFFFF0000u));
             }
@@ -1052,17 +1166,17 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
             if (ok[row][q]) {
               const float4 uu = um[row][q];
               float4 v;
-              v.x = o[row][4 * q] * ((mk_sc[0] * uu.x + mk_sh[0] > 0.f) ? 1.f : a.mk_slope);
-              v.y = o[row][4 * q + 1] * ((mk_sc[0] * uu.y + mk_sh[0] > 0.f) ? 1.f : a.mk_slope);
-              v.z = o[row][4 * q + 2] * ((mk_sc[0] * uu.z + mk_sh[0] > 0.f) ? 1.f : a.mk_slope);
-              v.w = o[row][4 * q + 3] * ((mk_sc[0] * uu.w + mk_sh[0] > 0.f) ? 1.f : a.mk_slope);
+              v.x = o[row][4 * q] * ((mk_sc[j] * uu.x + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+              v.y = o[row][4 * q + 1] * ((mk_sc[j] * uu.y + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+              v.z = o[row][4 * q + 2] * ((mk_sc[j] * uu.z + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+              v.w = o[row][4 * q + 3] * ((mk_sc[j] * uu.w + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
               if constexpr (INT) w_store4(ro, st_voff + WQB * q, v); else IO::st4(a.out, off + 4 * q, v);
               s1 += (v.x + v.y) + (v.z + v.w);
-              s2 += __builtin_fmaf(v.y, uu.y - mk_mu[0], v.x * (uu.x - mk_mu[0])) + __builtin_fmaf(v.w, uu.w - mk_mu[0], v.z * (uu.z - mk_mu[0]));
+              s2 += __builtin_fmaf(v.y, uu.y - mk_mu[j], v.x * (uu.x - mk_mu[j])) + __builtin_fmaf(v.w, uu.w - mk_mu[j], v.z * (uu.z - mk_mu[j]));
             }
           }
         }
-        st_mean[0] += s1; st_m2[0] += s2;
+        st_mean[j] += s1; st_m2[j] += s2;
       } else if (a.epi_mode == 1) {
         float4 pv[2][2];
 #pragma unroll
@@ -1268,13 +1382,17 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   //  profiles/r02_experiments.txt section 6)
   // Item loop with the first K-chunk peeled (its MFMAs start from a zero C operand).  With AF the guarded MFMA loop is not instantiated, so the
   // accumulators keep one register assignment across the whole loop (no copies where the variants used to join).
+  constexpr bool W2 = WIN && NT == 2;
+  if constexpr (W2) { w2_pre_a(smem, 0); w2_pre_b(smem, 0); }      // the first group's operands of chunk 0
   {
     int p = 0;
     auto mfma_chunk = [&](int ch, auto first_tag) __attribute__((always_inline)) {
+      if constexpr (W2) { w2_chunk(p, first_tag); return; }
+      else {
       const int ncg = AF ? CK / 4 : min(CK / 4, (a.cin_pad - ch * CK) / 4);
       if (tr && p < 16) a.trace[p * 4 + 0] = clock64();
       if (a.dbg & 1) {
-        if constexpr (WIN) { if (decltype(first_tag)::value) { for (int q = 0; q < 16; ++q) accw[q] = f32x4{0.f, 0.f, 0.f, 0.f}; } }
+        if constexpr (WIN) { if (decltype(first_tag)::value) { for (int j = 0; j < WNT; ++j) for (int q = 0; q < 16; ++q) accw[j][q] = f32x4{0.f, 0.f, 0.f, 0.f}; } }
         if (decltype(first_tag)::value) {
 #pragma unroll
           for (int r = 0; r < R; ++r)
@@ -1289,6 +1407,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         compute(smem + (p & 1) * BUF, std::false_type{}, ncg, first_tag);
       }
       if (tr && p < 16) a.trace[p * 4 + 1] = clock64();
+      }
     };
     for (int it = 0; it < my_items; ++it) {
       const int co0 = cb * COUT_TILE;
@@ -1297,32 +1416,38 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       auto pre_u = [&]() __attribute__((always_inline)) {
         if constexpr (FAST) { if (interior && !(a.dbg & 64)) { prefetch_u_fast(n, tile, co0); return; } }
         if constexpr (WIN) { prefetch_u_w(n, tile, co0); return; }
-        prefetch_u(n, tile, co0);
+        else prefetch_u(n, tile, co0);
       };
-      if (UPRE && a.epi_mode == 3) pre_u();            // at the START of the item: the registers are reserved anyway, and in a step the mask tensor is cold
+      if ((UPRE || WIN) && a.epi_mode == 3) pre_u();   // at the START of the item: the registers are reserved anyway, and in a step the mask tensor is cold
       mfma_chunk(0, std::true_type{});
       for (int ch = 1; ch < nchunks; ++ch) {
-        lds_barrier();
-        if (tr && p < 16) a.trace[p * 4 + 3] = clock64();
+        if constexpr (!W2) lds_barrier();              // (two-block Winograd form: the chunk barrier sits inside the previous chunk - w2_cg)
+        if (!W2 && tr && p < 16) a.trace[p * 4 + 3] = clock64();
         ++p;
         mfma_chunk(ch, std::false_type{});
       }
       bool done = false;
       if constexpr (FAST) { if (interior) { epilogue_fast(n, tile, co0); done = true; } }
       if constexpr (WIN) {
-        float o[2][8];
-        wino_out(o);
-        __builtin_amdgcn_sched_barrier(0);
-        if (wino_interior(tile, co0)) epilogue_w(n, tile, co0, o, std::true_type{}); else epilogue_w(n, tile, co0, o, std::false_type{});
+        if (a.epi_mode == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the item's LDS-destined mask values have landed (once, not per block: vmcnt also counts the previous block's stores)
+        float stn_next = st_n;
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+          float o[2][8];
+          wino_out(j, o);
+          __builtin_amdgcn_sched_barrier(0);
+          if (wino_interior(tile, co0 + 16 * j)) epilogue_w(n, tile, co0 + 16 * j, j, o, stn_next, std::true_type{}); else epilogue_w(n, tile, co0 + 16 * j, j, o, stn_next, std::false_type{});
+        }
+        st_n = stn_next;
         done = true;
       }
       if (!done) epilogue(n, tile, co0);
-      if (tr && p < 16) a.trace[p * 4 + 2] = clock64();
+      if (!W2 && tr && p < 16) a.trace[p * 4 + 2] = clock64();
       item += gridDim.x;
       if (it + 1 < my_items) {
         decode(item, n, tile, cb); load_bias(cb * COUT_TILE);
-        lds_barrier();
-        if (tr && p < 16) a.trace[p * 4 + 3] = clock64();
+        if constexpr (!W2) lds_barrier();
+        if (!W2 && tr && p < 16) a.trace[p * 4 + 3] = clock64();
       }
       ++p;
     }
@@ -1337,11 +1462,11 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 template <int NT, int PRO, int R, bool AF, typename AT>
 int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
   using G = typename std::conditional<std::is_same<AT, ms_f32x3>::value, WideGeoX3<(std::is_same<AT, ms_f32x3>::value ? NT : 1), PRO>, typename std::conditional<std::is_same<AT, ms_bf16m>::value, WideGeoBF<NT, PRO>,
-                                      typename std::conditional<std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_bf16w>::value, WideGeoW<PRO, 64>,
-                                      typename std::conditional<std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w32>::value, WideGeoW<PRO, 32>,
+                                      typename std::conditional<std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_bf16w>::value, WideGeoW<(NT <= 2 ? NT : 1), PRO, 64>,
+                                      typename std::conditional<std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w32>::value, WideGeoW<(NT <= 2 ? NT : 1), PRO, 32>,
                                                                 WideGeo<NT, PRO, R>>::type>::type>::type>::type;
   const size_t cin_tab = (PRO != 0) ? (size_t)cdiv(a.cin_pad, G::CK) * G::CK : 0;              // coefficient table: one float4 per input channel of the padded chunks
-  const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab) + ((std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value) ? 16 * 1024 : 0);      // Winograd mode: + the mask tensor's landing zone
+  const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab) + ((std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value) ? NT * 16 * 1024 : 0);      // Winograd mode: + the mask tensor's landing zone (4 KB per MFMA wave and channel block)
   if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
   static std::once_flag attr_once;                     // one flag per instantiation; the attribute itself is immutable afterwards
   std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO, R, AF, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
@@ -1349,7 +1474,8 @@ int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
   a.ncb = cdiv(a.Cout, 16 * NT);
   const long nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb;
   static const int cu_cap = getenv("MS_WIDE_PER_CU") ? atoi(getenv("MS_WIDE_PER_CU")) : 2;      // A/B switch: workgroups per CU of the persistent grid
-  const int per_cu = std::max(1, std::min(NT == 1 ? cu_cap : 2, (int)((160 * 1024) / (lds_bytes + 256))));
+  int per_cu = std::max(1, std::min(NT == 1 ? cu_cap : 2, (int)((160 * 1024) / (lds_bytes + 256))));
+  per_cu = std::max(1, std::min(per_cu, conv_resident_per_cu((const void*)conv_wide_kernel<NT, PRO, R, AF, AT>, lds_bytes)));      // (co-residency of the whole grid: ms_conv_kernel.h)
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;
   MS_LAUNCH((conv_wide_kernel<NT, PRO, R, AF, AT>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);

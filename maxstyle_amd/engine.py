@@ -407,7 +407,16 @@ class InnerLoopEngine:
         if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
             if b is not None and self._any_graph():
                 raise RuntimeError(f"buffer {name} would be re-allocated while a captured graph holds its address")
-            b = torch.empty(*shape, dtype=dtype, device=self.dev)
+            if b is not None:
+                # a table is being re-shaped: the launch epochs in table headers restart, so every granule table (tags = epochs of the tables they were filled
+                # from) is dropped with it and comes back zero-filled - a fresh epoch can never meet a stale tag
+                for k in [k for k in self.buf if k.endswith(".gran")]:
+                    del self.buf[k]
+            numel = 1
+            for s_ in shape:
+                numel *= int(s_)
+            # tables / coefficient records / partial sums start from zeros (deterministic launch epochs); activation-sized tensors are written before they are read
+            b = (torch.zeros if numel <= (1 << 20) else torch.empty)(*shape, dtype=dtype, device=self.dev)
             self.buf[name] = b
         return b
 
@@ -494,9 +503,9 @@ class InnerLoopEngine:
         words = self._error_words()
 
         def report(host, which):
+            # (the device words were cleared by the launch stream right behind the copy that filled `host` - below - so a report of the PREVIOUS call never
+            #  erases what the call just executed has set: ADVICE r3)
             if int(host.abs().sum()) != 0:
-                for w in words:
-                    w.zero_()
                 raise MaxStyleHipError("single-read MaxStyle kernel: a bounded spin timed out (the launch did not get the CUs it was sized for - another "
                                        f"process or stream on this GPU? set MS_SHARED_DEVICE=1 / engine.shared_device); the stylised image of {which} is invalid")
         if pend is not None:
@@ -508,6 +517,8 @@ class InnerLoopEngine:
         dev_words = torch.cat(words)
         host = torch.empty(dev_words.numel(), dtype=torch.int32, pin_memory=True)
         host.copy_(dev_words, non_blocking=True)
+        for w in words:
+            w.zero_()                                    # stream-ordered behind the copy: every copy holds exactly the words set since the previous one
         ev = torch.cuda.Event()
         ev.record()
         if sync:
@@ -524,8 +535,6 @@ class InnerLoopEngine:
             ev.synchronize()
             if int(host.abs().sum()) != 0:
                 from ._lib import MaxStyleHipError
-                for w in self._error_words():
-                    w.zero_()
                 raise MaxStyleHipError("single-read MaxStyle kernel: a bounded spin timed out; the stylised image of the last loop call is invalid")
 
     # ------------------------------------------------------------------ side stream (independent branches of a block)

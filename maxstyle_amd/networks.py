@@ -42,12 +42,19 @@ def _disable_tracking_bn_stats(model):
 def module_params(module):
     """The module's parameters as a list, cached on the module: `generate_max_style_image` flips requires_grad on ~330 tensors six times per call and clears their
     gradients twice (advanced_triplet...py:508-511, 568-571), and nn.Module.parameters() re-walks the module tree every time (0.6 ms of host time per call, during
-    which the GPU idles).  The Parameter OBJECTS of these containers never change (load_state_dict copies in place, the flat parameter bank re-points .data); a
-    caller that adds or removes parameters afterwards deletes `module._ms_plist`."""
-    pl = module.__dict__.get("_ms_plist")
-    if pl is None:
-        pl = list(module.parameters())
-        module.__dict__["_ms_plist"] = pl
+    which the GPU idles).  The Parameter OBJECTS of these containers never change (load_state_dict copies in place, the flat parameter bank re-points .data).
+    The cache carries a cheap signature of the module tree - the number of sub-modules and of directly registered parameters over the whole tree - and is rebuilt
+    when it changes (a later register_parameter / add_module / parametrize no longer escapes set_grad and zero_grad: ADVICE r3)."""
+    ent = module.__dict__.get("_ms_plist")
+    mods = module.__dict__.get("_ms_mlist")
+    if ent is not None and mods is not None:
+        sig = sum(len(m._parameters) + len(m._modules) for m in mods)
+        if sig == ent[0]:
+            return ent[1]
+    mods = list(module.modules())
+    pl = list(module.parameters())
+    module.__dict__["_ms_mlist"] = mods
+    module.__dict__["_ms_plist"] = (sum(len(m._parameters) + len(m._modules) for m in mods), pl)
     return pl
 
 

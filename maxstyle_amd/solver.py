@@ -473,6 +473,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             eng.flush_errors()
 
     def optimize_params(self, model_name):
+        self.flush_loop_errors()          # (deferred error protocol: a hard example from a timed-out launch must not reach the weights - ADVICE r3)
         self.optimizers[model_name].step()
 
     def reset_optimizer(self, model_name):

@@ -305,10 +305,11 @@ def maxstyle_backward(dy, x, mu, sig, st: StyleState):
 # --------------------------------------------------------------------------------------------
 # conv blocks in "BN batch-stat, frozen affine" mode
 # --------------------------------------------------------------------------------------------
-def batchnorm_batchstat(u, weight, bias, eps=BN_EPS):
+def batchnorm_batchstat(u, weight, bias, eps=BN_EPS, u_val=None):
+    """u_val: the STORED copy of u that is normalised (statistics always from u itself); None = u."""
     m = u.mean(dim=(0, 2, 3), keepdim=True)
     v = ((u - m) ** 2).mean(dim=(0, 2, 3), keepdim=True)
-    return (u - m) / torch.sqrt(v + eps) * weight.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    return ((u if u_val is None else u_val) - m) / torch.sqrt(v + eps) * weight.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
 
 
 def batchnorm_running(u, weight, bias, rm, rv, eps=BN_EPS):
@@ -319,13 +320,55 @@ def batchnorm_running(u, weight, bias, rm, rv, eps=BN_EPS):
 
 BN_OBSERVER = None   # optional callable(sd, name, u): oracle/outer_oracle.py uses it for the running-statistics update of a tracking pass
 
+# ---- storage emulation (BASELINE config 5: "bf16 activations") ----------------------------------------------------------------------------------
+# STORE: optional callable(tensor) -> tensor applied wherever the HIP engine MATERIALISES an activation (maxstyle_amd/engine.py `a()` tensors): conv outputs
+# (after their BatchNorm statistics were taken from the unrounded values - DESIGN.md "bf16 conv stack"), residual-block outputs, up- / down-sampling conv
+# outputs, the code, z_i / z_s, MaxStyle outputs and the sigmoid image.  NOT applied to what the engine never writes: BatchNorm-apply + LeakyReLU
+# (a conv prologue), the skip-conv sum, the encoder's first block output (`lazy_inc`), the MaxStyle layer in front of the image head (`lazy_style_head`), logits.
+# `bf16_store` rounds value AND incoming gradient to bf16 (round-to-nearest-even, fp32 arithmetic in between): the gradient w.r.t. a stored tensor is itself a stored
+# tensor in the engine.  The emulation is statistical, not bitwise: it says how large the storage-rounding error of the loop SHOULD be at a given size.
+STORE = None
+
+
+class _Bf16Store(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def bf16_store(t):
+    return _Bf16Store.apply(t)
+
+
+class stored_as:
+    """with stored_as(bf16_store): ... - the oracle's forward / loop with that storage emulation."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __enter__(self):
+        global STORE
+        self.prev, STORE = STORE, self.fn
+
+    def __exit__(self, *exc):
+        global STORE
+        STORE = self.prev
+
+
+def _st(t):
+    return t if STORE is None else STORE(t)
+
 
 def _bn(sd, name, u, bn_mode):
     if BN_OBSERVER is not None:
         BN_OBSERVER(sd, name, u)
     if bn_mode == "batch":
-        return batchnorm_batchstat(u, sd[name + ".weight"], sd[name + ".bias"])
-    return batchnorm_running(u, sd[name + ".weight"], sd[name + ".bias"], sd[name + ".running_mean"], sd[name + ".running_var"])
+        return batchnorm_batchstat(u, sd[name + ".weight"], sd[name + ".bias"], u_val=(None if STORE is None else STORE(u)))
+    return batchnorm_running(_st(u), sd[name + ".weight"], sd[name + ".bias"], sd[name + ".running_mean"], sd[name + ".running_var"])
 
 
 def _double_conv(sd, p, x, bn_mode, taps=None):
@@ -346,10 +389,12 @@ def res_up_block(sd, p, x, up_type, bn_mode="batch", taps=None):
         x = F.interpolate(x, scale_factor=2, mode="nearest")
     else:
         raise NotImplementedError(up_type)
+    if up_type == "Conv2":
+        x = _st(x)                             # (nearest up-sampling is fused into the next conv's fetch: nothing is written)
     if taps is not None:
         taps[p + "up"] = x
     s = F.conv2d(x, sd[p + "conv_input.weight"], sd[p + "conv_input.bias"])
-    out = F.leaky_relu(s + _double_conv(sd, p, x, bn_mode, taps), LEAKY)
+    out = _st(F.leaky_relu(s + _double_conv(sd, p, x, bn_mode, taps), LEAKY))
     if taps is not None:
         taps[p + "out"] = out
     return out
@@ -357,11 +402,11 @@ def res_up_block(sd, p, x, up_type, bn_mode="batch", taps=None):
 
 def res_down_block(sd, p, x, bn_mode="batch", taps=None):
     """encoder_decoder.py:22-74: conv3 s2 -> LeakyReLU(conv1x1(x) + double_conv(x))."""
-    x = F.conv2d(x, sd[p + "down.weight"], sd[p + "down.bias"], stride=2, padding=1)
+    x = _st(F.conv2d(x, sd[p + "down.weight"], sd[p + "down.bias"], stride=2, padding=1))
     if taps is not None:
         taps[p + "down"] = x
     s = F.conv2d(x, sd[p + "conv_input.weight"], sd[p + "conv_input.bias"])
-    out = F.leaky_relu(s + _double_conv(sd, p, x, bn_mode, taps), LEAKY)
+    out = _st(F.leaky_relu(s + _double_conv(sd, p, x, bn_mode, taps), LEAKY))
     if taps is not None:
         taps[p + "out"] = out
     return out
@@ -400,11 +445,11 @@ def encoder_forward(sd, x, bn_mode="batch", taps=None, mix=None):
     for i in range(1, 5):
         h = mx(i + 1, res_down_block(sd, g + f"down{i}.", h, bn_mode, taps))
     u = F.conv2d(h, sd[g + "final_conv.0.weight"], sd[g + "final_conv.0.bias"])
-    z_i = mx(6, F.relu(_bn(sd, g + "final_conv.1", u, bn_mode)))
+    z_i = mx(6, _st(F.relu(_bn(sd, g + "final_conv.1", u, bn_mode))))
     u = F.conv2d(z_i, sd["code_decoupler.0.weight"], None, padding=1)
     a = F.leaky_relu(_bn(sd, "code_decoupler.1", u, bn_mode), LEAKY)
     u = F.conv2d(a, sd["code_decoupler.3.weight"], None, padding=1)
-    z_s = F.relu(_bn(sd, "code_decoupler.4", u, bn_mode))
+    z_s = _st(F.relu(_bn(sd, "code_decoupler.4", u, bn_mode)))
     if taps is not None:
         taps["z_i"] = z_i; taps["z_s"] = z_s
     return z_i, z_s
@@ -425,18 +470,20 @@ def apply_max_style(sd, image_code, styles: Dict[int, StyleState], layers: Seque
     """MyDecoder.apply_max_style for the image decoder ('Conv2' up, Sigmoid) - encoder_decoder.py:598-631.
     bn_mode "running": the sub-networks are in .eval() when the loop is called (nn.BatchNorm2d then normalises with its running statistics
     whatever _disable_tracking_bn_stats toggles: torch/nn/modules/batchnorm.py, `bn_training = self.training or buffers are None`)."""
-    x = image_code.detach().clone()
+    x = _st(image_code.detach().clone())
     if 0 in layers:
-        x = maxstyle_forward(x, styles[0])
+        x = _st(maxstyle_forward(x, styles[0]))
     for i in range(1, 5):
         x = res_up_block(sd, f"up{i}.", x, "Conv2", bn_mode, taps)
         if i in layers:
             x = maxstyle_forward(x, styles[i])
+            if i < 4:
+                x = _st(x)                     # (layer 4's output is formed inside the image head: never written)
             if taps is not None:
                 taps[f"style{i}"] = x
-    x = torch.sigmoid(F.conv2d(x, sd["final_conv.weight"], sd["final_conv.bias"]))
+    x = _st(torch.sigmoid(F.conv2d(x, sd["final_conv.weight"], sd["final_conv.bias"])))
     if 5 in layers:
-        x = maxstyle_forward(x, styles[5])
+        x = _st(maxstyle_forward(x, styles[5]))
     return x
 
 

@@ -1,0 +1,128 @@
+"""Round-4 parity on the GPU, through the drop-in solver API (VERDICT r3 "next" item 2): BASELINE config 4 at its benchmarked size against the reference's
+own run, config 5's call shapes against the reference with the bf16-storage oracle as the calibration, and the round's robustness fixes.
+Measured ratios behind every constant: profiles/r04_parity_report.txt (tools/parity_report.py r4)."""
+import numpy as np
+import pytest
+import torch
+
+import r4_cases as R4
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("winograd", ["1", "0"])
+def test_config4_at_size_vs_reference_run(dev, monkeypatch, winograd):
+    """BASELINE config 4 as benchmarked - FCN_64, 16x3x320x320, MaxStyle after blocks [3,4,5], K = 10 free-running Adam steps - on FCN_64 weights trained by the
+    reference's own training step (tests/golden/trained_fcn64_320.npz), against the reference's fp64 run of the same call (advanced_triplet...py:539-571;
+    tests/golden/loop_full_c4.npz).  The criteria config 2 got in round 3: image error <= 2x the reference's OWN fp32-vs-fp64 error (max and rms), per-step
+    losses <= max(5x the reference's error at the step, 3e-5), final parameters <= 3x its worst, labels >= 99.99 % equal, Dice within 1e-3 - with the Winograd
+    form of the wide convolutions (one and two channel blocks per staged tile, as the dispatch picks them) and with the direct form."""
+    monkeypatch.setenv("MS_LOOP_WINOGRAD", winograd)
+    r = R4.c4_full_case(dev)
+    assert r["winograd"] == (winograd == "1") and r["K"] == 10
+    assert r["z_i_rel"] < 5e-6
+    assert r["image_max"] <= 2.0 * r["noise_image_max"], (r["image_max"], r["noise_image_max"])
+    assert max(r["image_rms_full"], r["image_rms_strided"]) <= 2.0 * r["noise_image_rms"], (r["image_rms_full"], r["image_rms_strided"], r["noise_image_rms"])
+    # per-(sample, channel) mean / rms of ALL 16 samples (the full image is stored for 4 of them): inside 2x the reference's own shift of the same moments
+    assert r["mean_rel"] <= 2.0 * r["noise_plane_mean"] and r["rms_rel"] <= 2.0 * r["noise_plane_rms"], (r["mean_rel"], r["noise_plane_mean"], r["rms_rel"], r["noise_plane_rms"])
+    # per-step losses: 5x the reference's own error at the step, floor 3e-5 - the fp32 forward bar every loss test of this repo holds (the trained FCN_64's loss
+    # is 0.013 .. 0.12: 3e-5 of it is 4e-7 .. 4e-6 absolute; the reference's own fp32 error at step 1 happens to be 6e-8, ours 7e-6: profiles/r04_parity_report.txt)
+    for e, n in zip(r["losses_rel"], r["noise_losses_rel"]):
+        assert e <= max(5.0 * n, 3e-5), (r["losses_rel"], r["noise_losses_rel"])
+    worst_noise = max(r["noise_params_rel"].values())
+    for k, e in r["params_rel"].items():
+        assert e <= 3.0 * worst_noise, (k, e, worst_noise)
+    assert r["labels_equal_f64"] >= 0.9999 and r["clean_labels_equal"] >= 0.9999
+    assert r["dice_abs_diff"] <= 1e-3
+    assert max(abs(a - b) for a, b in zip(r["dice_clean"], r["dice_clean_ref"])) <= 1e-3
+    assert min(r["dice_clean"]) > 0.9 and max(r["dice"]) < 0.8          # a meaningful Dice, and a hard example
+
+
+@pytest.mark.parametrize("tag", ["acdc", "prostate"])
+def test_config5_calls_fp32_storage_vs_reference_run(dev, tag):
+    """The fp32 leg of config 5's mixed stream, one call per shape as the trainer issues it (p = 0.5: the reference's own draw under fix_seed applies a strict
+    subset of [3,4,5]), against the REFERENCE's fp32 run of that call (tests/golden/loop_c5_calls.npz).  No fp64 twin here, so the bars are the free-running
+    fp32-vs-fp32 ones of round 3's argument cases: first loss 3e-5, every loss 1e-3, image 3e-3 max / 3e-4 rms of its range, labels 99.9 %, Dice 3e-3."""
+    r = R4.c5_call_case(dev, tag, None)
+    assert r["applied"] == r["applied_ref"] and 0 < len(r["applied"]) < 3
+    assert r["storage"] == "torch.float32"
+    assert r["losses_rel"][0] < 3e-5 and max(r["losses_rel"]) < 1e-3, r["losses_rel"]
+    assert r["image_max"] < 3e-3 and r["image_rms"] < 3e-4, (r["image_max"], r["image_rms"])
+    assert r["labels_equal"] >= 0.999 and r["dice_abs_diff"] <= 3e-3
+
+
+@pytest.mark.parametrize("tag", ["acdc", "prostate"])
+def test_config5_calls_bf16_storage_vs_reference_and_bf16_oracle(dev, tag):
+    """Config 5's "bf16 activations": the same two calls with every activation tensor of the loop stored as bf16 (fp32 arithmetic and statistics), against the
+    reference's fp32 run - and calibrated by the ORACLE with bf16 storage emulation (oracle/maxstyle_oracle.py `stored_as(bf16_store)`: value and gradient
+    rounded wherever the engine materialises a tensor), whose distance from the same reference run says how far 2^-9 storage rounding moves THIS loop at THIS
+    size.  The HIP loop may be at most 2x as far as the oracle (image max / rms, every loss), its labels within 2x the oracle's label disagreement, Dice within
+    max(2x the oracle's Dice shift, 5e-3).  Not a self-comparison: neither side of any bar is the HIP fp32 path."""
+    r = R4.c5_call_case(dev, tag, torch.bfloat16)
+    assert r["applied"] == r["applied_ref"] and r["storage"] == "torch.bfloat16"
+    assert r["image_max"] <= 2.0 * r["oracle_bf16_image_max"], (r["image_max"], r["oracle_bf16_image_max"])
+    assert r["image_rms"] <= 2.0 * r["oracle_bf16_image_rms"], (r["image_rms"], r["oracle_bf16_image_rms"])
+    for e, n in zip(r["losses_rel"], r["oracle_bf16_losses_rel"]):
+        assert e <= max(2.0 * n, 2e-3), (r["losses_rel"], r["oracle_bf16_losses_rel"])
+    assert (1.0 - r["labels_equal"]) <= max(2.0 * (1.0 - r["oracle_bf16_labels_equal"]), 1e-3)
+    oracle_shift = max(abs(a - b) for a, b in zip(r["oracle_bf16_dice"], r["dice_ref"]))
+    assert r["dice_abs_diff"] <= max(2.0 * oracle_shift, 5e-3), (r["dice"], r["dice_ref"], r["oracle_bf16_dice"])
+
+
+def test_reshaped_table_never_meets_a_stale_granule_tag(dev):
+    """launch epochs live in the statistics tables, granule tags in a separate buffer.  Re-shaping an engine's tables (a direct engine user running
+    another batch size) restarts the epochs, so the granule tables must restart with them: results equal a fresh engine's bit for bit, no error word."""
+    from maxstyle_amd import engine as E, synthetic as syn
+    spec_o = syn.NetSpec(4, 1, 4)
+    W = syn.procedural_weights(spec_o, 0)
+    to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
+    spec = E.NetSpec(4, 1, 4)
+    nets = E.PackedNets(spec, to(W["image_encoder"]), to(W["segmentation_decoder"]), to(W["image_decoder"]))
+
+    def run(eng, B, size):
+        layers = [3, 4, 5]
+        eng.configure_styles(layers, {i: E.StyleSlot(i, B, spec_o.channel_num[i]) for i in layers})
+        for i in layers:
+            st = syn.random_style_state(B, spec_o.channel_num[i], 7 + i)
+            eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
+        img, lab = syn.synthetic_batch(B, size, 1, 4, seed=99)
+        z = eng.encode_fwd(img.to(dev))[0].clone()
+        out = eng.run(z, lab.to(dev), 2, use_graph=False).clone()
+        eng.check_errors()
+        return out
+    e1 = E.InnerLoopEngine(spec, 4, 64, 64, dev, lr=0.1)
+    e1.set_nets(nets)
+    assert e1.xfin
+    for _ in range(3):
+        a = run(e1, 4, 64)                              # epochs of the 4x64x64 tables advance
+    assert any(k.endswith(".gran") for k in e1.buf)
+    e1.B, e1.H, e1.W = 2, 64, 64                        # a direct user re-shapes the SAME engine: tables of every layer are re-allocated
+    b = run(e1, 2, 64)
+    e2 = E.InnerLoopEngine(spec, 2, 64, 64, dev, lr=0.1)
+    e2.set_nets(nets)
+    assert torch.equal(b, run(e2, 2, 64))
+    e1.B = 4
+    assert torch.equal(a, run(e1, 4, 64))               # and back
+
+
+def test_parameter_list_cache_follows_the_module_tree(dev):
+    """the cached parameter list of a sub-network is rebuilt when parameters or sub-modules are added afterwards (set_grad / zero_grad see them)."""
+    import maxstyle_amd as M
+    from maxstyle_amd.networks import module_params, set_grad
+    S = M.AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard_no_STN", image_ch=1, num_classes=4, use_gpu=True)
+    net = S.model["image_decoder"]
+    n0 = len(module_params(net))
+    assert n0 == len(list(net.parameters()))
+    extra = torch.nn.Parameter(torch.zeros(3, device=dev))
+    net.register_parameter("extra_scale", extra)
+    assert len(module_params(net)) == n0 + 1
+    set_grad(net, False)
+    assert not extra.requires_grad
+    net.add_module("extra_head", torch.nn.Conv2d(1, 1, 1).to(dev))
+    assert len(module_params(net)) == n0 + 3

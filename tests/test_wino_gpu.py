@@ -83,6 +83,43 @@ def test_winograd_form_all_prologues_and_epilogues(dev, N, Cin, Cout, H, W):
     assert float((bc[:, :3] - ref_bc).abs().max()) < 2e-4 * float(ref_bc.abs().max())
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 64, 64, 64, 64), (1, 32, 48, 20, 192), (2, 64, 64, 32, 32), (2, 128, 64, 20, 40), (1, 16, 48, 11, 28), (1, 8, 33, 10, 100),
+                                            (2, 32, 32, 128, 128), (1, 64, 128, 40, 40)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_two_channel_blocks_per_staged_tile_same_bits(dev, N, Cin, Cout, H, W, bf16):
+    """Round 4: layers with more than 16 output channels stage / transform the input tile once per 32 of them (NT = 2, one workgroup per CU on 256 registers).
+    Per output element the accumulation order is the one-block variant's (MS_FETCH_WINO_NT1), so every stored tensor is bit-identical - all prologues and
+    epilogues, channel tails (48, 33), ragged tiles, both tile shapes, both storage types; the BatchNorm partial tables group their sums by work item and
+    agree to rounding."""
+    from maxstyle_amd import ops
+    WG, N1 = ops.FETCH_WINOGRAD, ops.FETCH_WINOGRAD | ops.FETCH_WINO_NT1
+    dt = torch.bfloat16 if bf16 else torch.float32
+    x = _rand((N, Cin, H, W), 1).to(dev).to(dt); x2 = _rand((N, Cin, H, W), 2).to(dev).to(dt); w = _rand((Cout, Cin, 3, 3), 3, 0.1); b = _rand((Cout,), 4).to(dev)
+    cfd = _rand((Cin, 4), 5).to(dev)
+    wp = ops.pack_conv_weight(w.to(dev))
+    pa, pb, pc = ops.coef_ptrs(cfd)[:3]
+    s2, parts = ops.conv_stats_buffer(N, Cout, H, W, dev); s1, _ = ops.conv_stats_buffer(N, Cout, H, W, dev)
+    o2 = ops.conv2d(x, wp, b, Cout, 3, 1, fetch=WG, stats=s2); o1 = ops.conv2d(x, wp, b, Cout, 3, 1, fetch=N1, stats=s1)
+    assert torch.equal(o1, o2)
+    one, zero = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+    c2, c1 = ops.bn_finalize(s2, parts, one, zero), ops.bn_finalize(s1, parts, one, zero)
+    assert float((c2 - c1).abs().max()) < 2e-6 * float(c1.abs().max())
+    kw = dict(pro_mode=1, pro_a=pa, pro_b=pb, pro_cstride=4, slope=0.2)
+    assert torch.equal(ops.conv2d(x, wp, None, Cout, 3, 1, fetch=WG, **kw), ops.conv2d(x, wp, None, Cout, 3, 1, fetch=N1, **kw))
+    base = _rand((N, Cout, H, W), 6).to(dev).to(dt)
+    kw = dict(pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=x2, epi_mode=1)
+    assert torch.equal(ops.conv2d(x, wp, None, Cout, 3, 1, fetch=WG, out=base.clone(), **kw), ops.conv2d(x, wp, None, Cout, 3, 1, fetch=N1, out=base.clone(), **kw))
+    u = (_rand((N, Cout, H, W), 24) + 0.3).to(dev).to(dt)
+    coef4 = torch.stack([1 + 0.2 * _rand((Cout,), 26), 0.3 * _rand((Cout,), 27), 0.3 + 0.1 * _rand((Cout,), 28), 1 + 0.1 * _rand((Cout,), 29).abs()], 1).to(dev)
+    kw = dict(pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=x2)
+    g2, t2 = ops.conv2d_actbwd(x, wp, Cout, 3, u, coef4, 0.2, fetch=WG, **kw); g1, t1 = ops.conv2d_actbwd(x, wp, Cout, 3, u, coef4, 0.2, fetch=N1, **kw)
+    assert torch.equal(g1, g2)
+    b2, b1 = ops.bn_bwd_coefs(t2, 0, coef4, N * H * W), ops.bn_bwd_coefs(t1, 0, coef4, N * H * W)
+    assert float((b2 - b1).abs().max()) < 1e-5 * float(b1.abs().max())
+    if H % 2 == 0 and ops.lib.ms_conv2d_pool2_ok(N, Cin, H, W, Cout, 0, int(bf16)):
+        assert torch.equal(ops.conv2d(x, wp, None, Cout, 3, 1, fetch=WG, epi_mode=ops.EPI_POOL2), ops.conv2d(x, wp, None, Cout, 3, 1, fetch=N1, epi_mode=ops.EPI_POOL2))
+
+
 def test_winograd_bit_is_ignored_where_the_form_is_not_built(dev):
     """Rows narrower than 20 pixels, Cin % 8 != 0, 1x1: the call runs the direct form - bit-identical with and without the bit."""
     from maxstyle_amd import ops

@@ -1,0 +1,89 @@
+"""A/B of the Winograd form's channel blocks per staged tile (round 4): every distinct Winograd-eligible 3x3 call of one inner step with more than 16 output
+channels, replayed on its live buffers with MS_FETCH_WINO_NT1 (one block per tile: the round-3 kernel) and without (two blocks: ms_conv_inst_wino2.hip).
+Run on the GPU box:  python tools/ab_wino_nt.py [c2|c4] [reps]
+The engine is built with MS_XFIN=0 MS_RIDE=0 so that every convolution goes through ms_conv2d / ms_conv2d_actbwd (the `_xfin` twins launch the same kernels)."""
+import os, sys
+os.environ.setdefault("MS_XFIN", "0"); os.environ.setdefault("MS_RIDE", "0")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from maxstyle_amd import _lib
+
+NT1 = 0x400
+
+
+def main():
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    dev = torch.device("cuda:0")
+    net, size = ((4, 1, 4), 256) if cfg == "c2" else ((1, 3, 2), 320)
+    eng, W, img, lab, styles, z_i, lab_d = bench.build(dev, 16, size, 0, net)
+    eng.code, eng.labels = z_i, lab_d
+    eng._prefix_valid = False
+    im = eng.decode(z_i)
+    eng.step(im)
+    calls = []
+    lib = _lib.lib
+    orig = {n: getattr(lib, n) for n in ("ms_conv2d", "ms_conv2d_actbwd")}
+
+    class Rec:
+        def __init__(self, name):
+            self.name = name
+
+        def __call__(self, *a):
+            calls.append((self.name, a))
+            return orig[self.name](*a)
+    import maxstyle_amd.engine as E, maxstyle_amd.ops as O
+
+    class LibProxy:
+        def __getattr__(self, n):
+            return Rec(n) if n in orig else getattr(lib, n)
+    E.lib = LibProxy(); O.lib = LibProxy()
+    eng.step(im)
+    E.lib = lib; O.lib = lib
+    torch.cuda.synchronize()
+    seen = {}
+    for name, a in calls:
+        fi = 12 if name == "ms_conv2d" else 11
+        if name == "ms_conv2d":
+            N, Cin, Hs, Ws, Cout, ks, stride, fetch, pm = a[5:14]
+            epi = a[20]; stats = a[21] != 0
+        else:
+            N, Cin, Hs, Ws, Cout, ks, stride, fetch, pm = a[4:13]
+            epi, stats = 3, False
+        if not (ks == 3 and stride == 1 and (fetch & 0x100) and (fetch & 0xFF) == 0 and Cout > 16 and Ws >= 20 and Cin % 8 == 0):
+            continue
+        key = (name, N, Cin, Hs, Ws, Cout, pm, epi, stats)
+        seen.setdefault(key, [0, a, fi])[0] += 1
+    st = torch.cuda.current_stream()
+
+    def time_call(name, a):
+        fn = orig[name]
+        assert fn(*a) == 0
+        for _ in range(3):
+            fn(*a)
+        best = 1e9
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(reps):
+                fn(*a)
+            e1.record(st)
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) / reps * 1e3)
+        return best
+    print(f"{'call':12s} {'N,Cin,Hs,Ws,Cout':>24s} pm epi st cnt   nt1_us   nt2_us  exec_mfma_frac(nt1 -> nt2)   gain_us/step")
+    t1 = t2 = 0.0
+    for key, (cnt, a, fi) in sorted(seen.items(), key=lambda kv: -kv[1][0] * kv[0][2] * kv[0][5] * kv[0][3] * kv[0][4]):
+        name, N, Cin, Hs, Ws, Cout, pm, epi, stats = key
+        a1 = list(a); a1[fi] = a[fi] | NT1
+        u1 = time_call(name, tuple(a1)); u2 = time_call(name, a)
+        t1 += cnt * u1; t2 += cnt * u2
+        # executed matrix work: 16 MFMAs of 16x16x4 per (2x2 tile group of 16, 4 channels, 16 output channels): 16/36 of the direct form's flops
+        ex = 2.0 * N * Hs * Ws * Cout * Cin * 9 * 16 / 36 / 157.3e12 * 1e6
+        print(f"{name[3:]:12s} {str((N, Cin, Hs, Ws, Cout)):>24s} {pm:2d} {epi:3d} {int(stats):2d} {cnt:3d} {u1:8.1f} {u2:8.1f}     {ex / u1:5.2f} -> {ex / u2:5.2f}    {cnt * (u1 - u2):8.1f}")
+    print(f"per step: one block {t1:.0f} us, two blocks {t2:.0f} us")
+
+
+if __name__ == "__main__":
+    main()

@@ -6,18 +6,25 @@ dev = torch.device("cuda:0")
 trace = torch.zeros(512, dtype=torch.int64, device=dev)
 os.environ["MS_CONV_TRACE"] = hex(trace.data_ptr())
 from maxstyle_amd import ops
-N, C = 16, 16
+# usage: trace_conv.py [plain|pro1|bwd] [C] [size] [fetch bits, e.g. 0x100 = Winograd, 0x500 = Winograd one-block]
+N = 16
 mode = sys.argv[1] if len(sys.argv) > 1 else "plain"
-x = torch.randn(N, C, 256, 256, device=dev); w = torch.randn(C, C, 3, 3, device=dev) * 0.1; b = torch.randn(C, device=dev)
+C = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+FETCH = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0
+x = torch.randn(N, C, S, S, device=dev); w = torch.randn(C, C, 3, 3, device=dev) * 0.1; b = torch.randn(C, device=dev)
 wp = ops.pack_conv_weight(w)
 out = torch.empty_like(x)
-stats, parts = ops.conv_stats_buffer(N, C, 256, 256, dev)
+stats, parts = ops.conv_stats_buffer(N, C, S, S, dev)
 kw = dict(stats=stats)
+if mode == "pro1":
+    bc = torch.randn(C, 4, device=dev); pa, pb, pc = ops.coef_ptrs(bc)
+    kw = dict(stats=stats, pro_mode=1, pro_a=pa, pro_b=pb, pro_cstride=4, slope=0.2)
 if mode == "bwd":
     bc = torch.randn(C, 4, device=dev); pa, pb, pc = ops.coef_ptrs(bc)
     kw = dict(pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=torch.randn_like(x))
 for _ in range(3):
-    ops.conv2d(x, wp, b, C, 3, 1, out=out, **kw)
+    ops.conv2d(x, wp, b, C, 3, 1, out=out, fetch=FETCH, **kw)
 torch.cuda.synchronize()
 t = trace.cpu().tolist()
 t0 = min(t[0], t[128])
