@@ -301,6 +301,8 @@ def kernel_rooflines(eng, dev, config, instep=None):
     g2c = g2.clone()
 
     wino = ops.FETCH_WINOGRAD if getattr(eng, "winograd", False) else 0      # the form the engine's own launches take
+    if wino and cw.wu:
+        wino |= ops.FETCH_WINO_U                                              # ... with the transformed weights staged from the packed tensor's appendix
 
     def conv_fwd():
         ops.conv2d(x, cw.wp, cw.b, cw.cout, 3, 1, fetch=wino, out=y, stats=stats)

@@ -22,8 +22,20 @@
 extern "C" {
 #endif
 
-int ms_version(void);
-const char* ms_last_error(void);
+/* Two surfaces.  Both macros expand to nothing: they are labels a binding author can grep for.
+ *   MS_STABLE    one entry point per operator of the reference path (convolution, BatchNorm finalize / apply / backward, pooling, heads, the MaxStyle layer and its
+ *                backward, Adam / AdamW, weight gradients, running statistics, Dice confusion matrix) plus their size queries and `_bf16` twins: plain tensors in,
+ *                plain tensors out, no precondition beyond shapes and alignment.  This is what INTEGRATION.md binds and what is kept source-compatible.
+ *   MS_INTERNAL  engine-private fusions and their helpers (`_xfin`, `_ride`, `_fin`, residual tails, activation-backward epilogues, sub-pixel / small-channel forms, the
+ *                fused step tail, planning and measurement queries).  They carry PRECONDITIONS the engine guarantees and a foreign caller would have to reproduce:
+ *                launch epochs left in statistics tables by the producing conv, zero-initialised granule tables and error words, a GPU the launch does not share
+ *                (`_xfin`, single-read MaxStyle kernel: every workgroup of the grid must be resident at once - grids are sized from the occupancy API for that, and
+ *                NO dispatch order is assumed), a rider's channel count within ms_conv_ride_capacity.  Their results are bit-identical to the MS_STABLE sequence
+ *                they replace (tests/test_round3_gpu.py); they may change between rounds. */
+#define MS_STABLE
+#define MS_INTERNAL
+MS_STABLE int ms_version(void);
+MS_STABLE const char* ms_last_error(void);
 /* bit of the `fetch` argument of the convolution entry points: the caller accepts the Winograd form for this call (see ms_conv2d) */
 #define MS_FETCH_WINOGRAD 0x100
 #define MS_FETCH_X3 0x200
@@ -31,33 +43,44 @@ const char* ms_last_error(void);
  * stage it once per 32 (round 4).  Per output element both variants accumulate in the same order - the same bits; only the grouping of the BatchNorm partial sums
  * follows the work-item numbering.  An A/B and test switch, not a numerical choice. */
 #define MS_FETCH_WINO_NT1 0x400
+/* with MS_FETCH_WINOGRAD: w_packed carries the Winograd APPENDIX - the transformed weights U = G g G^T of every (input channel, output channel) pair behind the
+ * packed taps, at float offset 9 * cin_pad * cout_pad, ms_wino_pack_floats(Cin, Cout) floats, filled by ms_wino_pack (below) - and the kernel may stage U from
+ * there with LDS-DMA instead of transforming the nine taps of every chunk again in its staging waves (weights are constant over the K steps of a loop call and over
+ * every call until the next optimiser step).  ms_wino_pack computes each value with the in-kernel expression, so results are bit-identical with and without the bit.
+ * Ignored where the Winograd form is not taken. */
+#define MS_FETCH_WINO_U 0x800
 /* ms_conv2d epi_mode 6: the 2x2-POOLED store.  out is [N, Cout, H/2, W/2] and receives the sum of every 2x2 block of the convolution's result, in ms_pool2_sum's
  * order over the values as they would have been stored: the same bits as ms_conv2d + ms_pool2_sum, a quarter of the bytes written and none read back.  The
  * data-gradient of `conv3x3(nearest-up-sampled x)` (encoder_decoder.py:298-300, 323-337 backward) ends in exactly that sum.  Built for the Winograd form of the
  * wide kernel only (ks 3, stride 1, MS_FETCH_WINOGRAD; no bias / statistics): ask ms_conv2d_pool2_ok first. */
 #define MS_EPI_POOL2 6
-int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16);      /* bf16: 0 = the fp32 entry point, 1 = `_bf16`, 2 = `_bf16m` */
+MS_INTERNAL int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16);      /* bf16: 0 = the fp32 entry point, 1 = `_bf16`, 2 = `_bf16m` */
 /* Which kernel form ms_conv2d(ks 3, stride 1, fetch) takes for this shape (16-byte aligned tensors assumed) - what the measurement tools print and price, asked of the
  * dispatch itself instead of re-deriving its rules: 0 first-generation kernel (conv_mfma_kernel) | 1 wide direct form (conv_wide_kernel) | 2 Winograd F(2x2,3x3), one
  * 16-channel block per staged tile (conv_wide_kernel<1, ..., ms_f32w*>) | 3 Winograd, two blocks (conv_wide_kernel<2, ...>: round 4).  fetch = the call's fetch argument
  * (MS_FETCH_WINOGRAD / MS_FETCH_WINO_NT1 bits); a fused-fetch call (fetch & 0xFF != 0) is always 0. */
-int ms_conv2d_form(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16, int fetch);
+MS_INTERNAL int ms_conv2d_form(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16, int fetch);
+/* The Winograd appendix of a packed 3x3 weight tensor (MS_FETCH_WINO_U): layout [ceil(Cout/16)][Cin/8][16 positions][8 input channels][16 output channels] fp32
+ * (one 8 KB block per (16-channel output block, 8-channel chunk): what one LDS-DMA burst of a staging wave copies).  Needs Cin % 8 == 0 (ms_wino_pack_floats
+ * returns 0 otherwise).  ms_wino_pack reads the taps at w_packed and writes the appendix behind them - call it after every (re-)pack of the weights. */
+MS_INTERNAL size_t ms_wino_pack_floats(int Cin, int Cout);
+MS_INTERNAL int ms_wino_pack(float* w_packed, int Cin, int Cout, void* stream);
 /* Compute units of the current device (hipDeviceProp.multiProcessorCount, read once per device): every persistent grid and every
  * co-residency bound of the library is sized from it (a partitioned or CU-masked device reports fewer than MI355X's 256). */
-int ms_num_cus(void);
+MS_STABLE int ms_num_cus(void);
 /* Measurement aid: register-only fp32-MFMA chains (iters x 64 per wave) on `workgroups` x `threads`; writes, for workgroup 0, {clock64() cycles,
  * 100 MHz ticks (s_memrealtime)} around the loop (tools/clock_probe.py). */
-int ms_clock_probe(int iters, int workgroups, int threads, long long* cycles_and_ticks, float* sink, void* stream);
+MS_INTERNAL int ms_clock_probe(int iters, int workgroups, int threads, long long* cycles_and_ticks, float* sink, void* stream);
 
 /* ---- MaxStyle layer: src/advanced/maxstyle.py:140-189 ------------------------------------------------ */
 
 /* bytes of workspace needed by ms_style_moments / ms_style_fwd / ms_style_bwd for a [B,C,H*W] tensor.
  * Contract: give every layer (shape) its OWN workspace, zero-fill it once after allocation and keep it for the layer's lifetime - its
  * tail holds the persistent launch-epoch state of the single-read forward kernel (the head is per-launch scratch). */
-size_t ms_style_ws_bytes(int B, int C, int HW);
+MS_STABLE size_t ms_style_ws_bytes(int B, int C, int HW);
 
 /* mu = mean_HW(x), sig = sqrt(var_HW(x, unbiased) + eps) per plane.          maxstyle.py:157-159 */
-int ms_style_moments(const float* x, float* mu, float* sig, int planes, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
+MS_INTERNAL int ms_style_moments(const float* x, float* mu, float* sig, int planes, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
 
 /* Per-plane affine coefficients  A = sig(1-l)+sig[perm]l + gamma_noise*gamma_std,  S = mu(1-l)+mu[perm]l + beta_noise*beta_std
  * with l = clamp(lmda,0,1).  compute_std is a flag word.  bit 2 (ms_style_fwd only): the device is shared with kernels of other streams /
@@ -65,17 +88,17 @@ int ms_style_moments(const float* x, float* mu, float* sig, int planes, int HW, 
  * computed from mu/sig and stored (the reference caches them on the first forward), else they are read.  compute_std bit 1:
  * l = lmda without the clamp (MixStyle: src/advanced/mixstyle.py:91-92).
  * lmda == NULL: no style mixing (mix_style=False); gamma_noise == beta_noise == NULL: no_noise=True.  maxstyle.py:165-185 */
-int ms_style_coeffs(float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std, const float* lmda,
+MS_INTERNAL int ms_style_coeffs(float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std, const float* lmda,
                     const float* gamma_noise, const float* beta_noise, const int64_t* perm, float* coefA, float* coefS,
                     int B, int C, void* stream);
 
 /* y = A * ((x - mu) / sig) + S                                                 maxstyle.py:161,184-185 */
-int ms_style_apply(const float* x, float* y, const float* mu, const float* sig, const float* coefA, const float* coefS,
+MS_INTERNAL int ms_style_apply(const float* x, float* y, const float* mu, const float* sig, const float* coefA, const float* coefS,
                    int planes, int HW, void* stream);
 
 /* The fused forward: moments + coeffs + apply (K1 of SURVEY.md 2.2).  Outputs y, and mu/sig/coefA/coefS [B*C]
  * (kept for the backward pass), gamma_std/beta_std [C] (written when compute_std != 0). */
-int ms_style_fwd(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+MS_STABLE int ms_style_fwd(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
                  const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
                  float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
 
@@ -85,40 +108,40 @@ int ms_style_fwd(const float* x, float* y, float* mu, float* sig, float* gamma_s
  *                       here `ws` is ONLY the kernel's persistent state (>= ms_style_fused_ws_bytes, zero-filled once, one layer, one
  *                       stream at a time); ws[1] (int) is an error word set if a bounded spin ever times out
  *   ms_style_fwd_3k     moments / finalize / restyle as three launches (any shape; x is read twice) */
-size_t ms_style_fused_ws_bytes(int B, int C, int HW);
+MS_INTERNAL size_t ms_style_fused_ws_bytes(int B, int C, int HW);
 /* geometry the single-read kernel would use: threads per workgroup, float4 register slots per thread, chunks per plane, grid (diagnostics) */
-int ms_style_fused_plan(int B, int C, int HW, int* threads, int* nv, int* S, int* grid);
+MS_INTERNAL int ms_style_fused_plan(int B, int C, int HW, int* threads, int* nv, int* S, int* grid);
 /* byte offset of the single-read kernel's state block inside a workspace of ms_style_ws_bytes() bytes ((size_t)-1: the shape has none);
  * the int at offset + 4 is its ERROR WORD.  A caller that syncs anyway can read it with its own copy; ms_style_fused_status does a
  * stream-ordered synchronous read of the word of `state` (= workspace + offset), clears it when set and leaves the reason in ms_last_error(). */
-size_t ms_style_ws_state_offset(int B, int C, int HW);
-int ms_style_fused_status(void* state, int* out_host, void* stream);
-int ms_style_fwd_fused(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+MS_INTERNAL size_t ms_style_ws_state_offset(int B, int C, int HW);
+MS_INTERNAL int ms_style_fused_status(void* state, int* out_host, void* stream);
+MS_INTERNAL int ms_style_fwd_fused(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
                        const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
                        float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
-int ms_style_fwd_3k(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+MS_INTERNAL int ms_style_fwd_3k(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
                     const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
                     float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
 
 /* Backward of nn.UpsamplingNearest2d (ms_pool2_sum) + the accumulate of the 1x1 skip data-gradient + the output-activation backward of the block BELOW
  * (ms_act_bwd_reduce) in one pass: out = (pool2(in) [+ add]) * lrelu'(act); part2 as ms_act_bwd_reduce ([C][ms_act_bwd_parts(N,C,Ho*Wo)][2]). */
-int ms_pool2_actbwd(const float* in, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
+MS_INTERNAL int ms_pool2_actbwd(const float* in, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
                     int N, int C, int Ho, int Wo, float slope, void* stream);
 /* ... that also writes pooled [N,C,Ho/2,Wo/2] = ms_pool2_sum(out) - the input of the NEXT block's 1x1 skip data-gradient (no pooling launch there): a thread owns a
  * 2x2 quad of output pixels instead of four pixels of a row, sums the STORED values in ms_pool2_sum's order (same bits); part2 agrees with ms_pool2_actbwd's to
  * rounding (the per-thread grouping of the sums follows the mapping).  Ho even, Wo % 4 == 0. */
-int ms_pool2_actbwd_pool(const float* in, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
+MS_INTERNAL int ms_pool2_actbwd_pool(const float* in, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
                          int N, int C, int Ho, int Wo, float slope, float* pooled, void* stream);
 /* ... whose first operand in_lo [N,C,Ho,Wo] is ALREADY pooled (the data-gradient conv in front stored the 2x2 sums itself: ms_conv2d epi_mode MS_EPI_POOL2);
  * pooled may be NULL (then: ms_pool2_actbwd's pixel mapping, else ms_pool2_actbwd_pool's). */
-int ms_add_actbwd(const float* in_lo, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
+MS_INTERNAL int ms_add_actbwd(const float* in_lo, const float* add, float* out, const float* act, const float* u, const float* coef4, float* part2,
                   int N, int C, int Ho, int Wo, float slope, float* pooled, void* stream);
 
 /* ms_head_ce (segmentation head + cross entropy + backward to the head input h, custom_loss.py:1043-1078) whose dh is already multiplied by lrelu'(h) - h is the
  * output of the last residual block - and which writes the BatchNorm-backward sums of that block's last BatchNorm (raw input bn_u, record bn_coef4) to
  * bn_part [C][ms_head_ce_actbwd_parts(N,C,HW)][2]: replaces ms_head_ce + ms_act_bwd_reduce.  C <= 16 (parts() returns 0 otherwise: use the two calls). */
-int ms_head_ce_actbwd_parts(int N, int C, int HW);
-int ms_head_ce_actbwd(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* loss_out, const int* loss_slot_dev,
+MS_INTERNAL int ms_head_ce_actbwd_parts(int N, int C, int HW);
+MS_INTERNAL int ms_head_ce_actbwd(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* loss_out, const int* loss_slot_dev,
                       int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,
                       const float* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream);
 /* ms_conv1x1_bnres (half-resolution skip) + ms_head_ce_actbwd in ONE pass over u: the output h = lrelu(bn(u) + skip[y/2][x/2]) of the segmentation decoder's last
@@ -128,7 +151,7 @@ int ms_head_ce_actbwd(const float* h, const float* w, const float* b, const int6
  * pooled != NULL: a thread owns a 2x2 pixel quad instead of four pixels of a row and also writes pooled [N,C,H/2,W/2] = ms_pool2_sum(dh) (the sum of the STORED
  * values, in ms_pool2_sum's order: same bits) - the input of the block's 1x1 skip data-gradient; the per-thread grouping of the BatchNorm-backward sums changes
  * with the mapping, so bn_part agrees with the pooled == NULL form to rounding, not to the bit. */
-int ms_head_ce_tail(const float* u, const float* skip, const float* coef4, const float* w, const float* b, const int64_t* labels, float* dh, float* loss_out,
+MS_INTERNAL int ms_head_ce_tail(const float* u, const float* skip, const float* coef4, const float* w, const float* b, const int64_t* labels, float* dh, float* loss_out,
                     const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, float* pooled,
                     void* stream);
 
@@ -141,12 +164,12 @@ int ms_head_ce_tail(const float* u, const float* skip, const float* coef4, const
  * Sigmoid, encoder_decoder.py:619-627): the layer's incoming gradient dy[c] = sum_k head_w[k][c] * head_g[k] * out_k(1-out_k) is formed while streaming instead of
  * being written by ms_head_bwd and read back (a [B,C,H,W] tensor each way).  head_g, head_out [B,K,HW] (head_out NULL: no sigmoid), head_w [K][C], K <= 4.
  * Everything else as ms_style_bwd_actbwd; bn_u / bn_coef4 / bn_part may be NULL (plain ms_style_bwd), dx may be NULL.  Same arithmetic, same order: bit-identical. */
-int ms_style_bwd_head(const float* head_g, const float* head_out, const float* head_w, int K, const float* x, float* dx, const float* mu, const float* sig,
+MS_INTERNAL int ms_style_bwd_head(const float* head_g, const float* head_out, const float* head_w, int K, const float* x, float* dx, const float* mu, const float* sig,
                       const float* coefA, const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
                       float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes,
                       const float* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream);
-int ms_style_bwd_actbwd_parts(int B, int C, int HW);
-int ms_style_bwd_actbwd(const float* dy, const float* x, float* dx, const float* mu, const float* sig, const float* coefA,
+MS_INTERNAL int ms_style_bwd_actbwd_parts(int B, int C, int HW);
+MS_INTERNAL int ms_style_bwd_actbwd(const float* dy, const float* x, float* dx, const float* mu, const float* sig, const float* coefA,
                         const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
                         float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes,
                         const float* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream);
@@ -155,31 +178,31 @@ int ms_style_bwd_actbwd(const float* dy, const float* x, float* dx, const float*
  * patterns (uint16_t, NCHW, 16-byte aligned, H*W % 8 == 0) - half the HBM bytes of these bandwidth-bound kernels; mu / sig / coefficients / std / partial
  * sums / parameter gradients stay fp32 (fp64 merges) and all arithmetic is fp32.  Results equal the fp32 entry points evaluated on the bf16-rounded
  * input, with y / dx rounded to nearest-even bf16 on store (relative error <= 2^-9 per element).  Same workspace contract (ms_style_ws_bytes_bf16). */
-size_t ms_style_ws_bytes_bf16(int B, int C, int HW);
-size_t ms_style_fused_ws_bytes_bf16(int B, int C, int HW);
-int ms_style_fwd_bf16(const uint16_t* x, uint16_t* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+MS_STABLE size_t ms_style_ws_bytes_bf16(int B, int C, int HW);
+MS_INTERNAL size_t ms_style_fused_ws_bytes_bf16(int B, int C, int HW);
+MS_STABLE int ms_style_fwd_bf16(const uint16_t* x, uint16_t* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
                       const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
                       float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
-int ms_style_fwd_fused_bf16(const uint16_t* x, uint16_t* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
+MS_INTERNAL int ms_style_fwd_fused_bf16(const uint16_t* x, uint16_t* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
                             const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
                             float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream);
-int ms_style_bwd_bf16(const uint16_t* dy, const uint16_t* x, uint16_t* dx, const float* mu, const float* sig, const float* coefA,
+MS_STABLE int ms_style_bwd_bf16(const uint16_t* dy, const uint16_t* x, uint16_t* dx, const float* mu, const float* sig, const float* coefA,
                       const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
                       float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes, void* stream);
 
 /* Backward of the layer (autograd of maxstyle.py:161-185 with mu/sig detached):
  *   dx = dy*A/sig (skipped when dx == NULL);  d_gamma = gamma_std*sum(dy*xhat);  d_beta = beta_std*sum(dy);
  *   d_lmda[b] = 1[0<=lmda<=1] * sum_c (sig[perm b]-sig[b])*S2 + (mu[perm b]-mu[b])*S1.   Any of d_* may be NULL. */
-int ms_style_bwd(const float* dy, const float* x, float* dx, const float* mu, const float* sig, const float* coefA,
+MS_STABLE int ms_style_bwd(const float* dy, const float* x, float* dx, const float* mu, const float* sig, const float* coefA,
                  const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
                  float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes, void* stream);
 
 /* torch.optim.Adam(lr, betas=(b1,b2), eps, weight_decay=0, amsgrad=False) single update on a flat buffer
  * (advanced_triplet_recon_segmentation_model.py:537,562).  step is 1-based; if step_dev != NULL the kernel uses
  * *step_dev + 1 instead (graph replay) - advance it with ms_counter_incr. */
-int ms_adam_step(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2, float eps, int step,
+MS_STABLE int ms_adam_step(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2, float eps, int step,
                  const int* step_dev, void* stream);
-int ms_counter_incr(int* counter, void* stream);
+MS_INTERNAL int ms_counter_incr(int* counter, void* stream);
 
 /* The tail of one inner step of generate_max_style_image (advanced_triplet...py:559-562: loss.backward() has produced the layers' partial sums,
  * optimizer.step()) as ONE launch: for every inserted MaxStyle layer the reduction ms_style_bwd does behind its streaming pass (call ms_style_bwd /
@@ -197,8 +220,8 @@ typedef struct ms_tail_layer {
   int learn_noise, learn_mix;
   int B, C, S;
 } ms_tail_layer;
-int ms_style_bwd_slots(int B, int C, int HW, int bf16);
-int ms_step_tail(const ms_tail_layer* layers, int n_layers, const double* ce_part, int ce_nparts, double ce_scale, float* loss_out,
+MS_INTERNAL int ms_style_bwd_slots(int B, int C, int HW, int bf16);
+MS_INTERNAL int ms_step_tail(const ms_tail_layer* layers, int n_layers, const double* ce_part, int ce_nparts, double ce_scale, float* loss_out,
                  float* p, float* g, float* m, float* v, float lr, float b1, float b2, float eps, int* step_dev, int* arrive, void* stream);
 
 /* ---- convolution stack: src/models/ebm/encoder_decoder.py:22-74, 289-357, 423-482, 561-596, 634-680 -------- */
@@ -235,9 +258,9 @@ int ms_step_tail(const ms_tail_layer* layers, int n_layers, const double* ce_par
  *   stats     NULL or a table of ms_conv_stats_bytes() bytes receiving per-workgroup running (count, mean, M2, 0) of the outputs
  *             (float4 header {slots used} + float4[Cout][ms_conv_stats_parts()]) for ms_bn_finalize (BatchNorm batch statistics;
  *             model_util.py:468-510). */
-size_t ms_conv_stats_bytes(int N, int Cout, int Hout, int Wout);
-int ms_conv_stats_parts(int N, int Hout, int Wout);
-int ms_conv2d(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
+MS_STABLE size_t ms_conv_stats_bytes(int N, int Cout, int Hout, int Wout);
+MS_STABLE int ms_conv_stats_parts(int N, int Hout, int Wout);
+MS_STABLE int ms_conv2d(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
               int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
               int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
               int epi_mode, float* stats, void* stream);
@@ -247,14 +270,14 @@ int ms_conv2d(const float* in, const float* in2, float* out, const float* w_pack
  * conv3x3(in [N,Cin,H,W], w) + bias; w_packed = ms_conv2d's forward layout; stats (may be NULL) = ms_conv2d's statistics table of the outputs (one slot per
  * workgroup, header {slots, launch epoch}): ms_bn_finalize and the `_xfin` consumers read it like any other.  W % 4 == 0, 16-byte aligned tensors.
  * ms_conv3x3_small_cin_ok answers 1 where the entry point is also the FASTER choice (Cin == 1: 30 vs 34 us at 16x1x256x256), not merely accepted. */
-int ms_conv3x3_small_cin_ok(int Cin, int Cout, int W);
-int ms_conv3x3_small_cin(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int H, int W, int Cout, float* stats, void* stream);
+MS_INTERNAL int ms_conv3x3_small_cin_ok(int Cin, int Cout, int W);
+MS_INTERNAL int ms_conv3x3_small_cin(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int H, int W, int Cout, float* stats, void* stream);
 
 /* 3x3 stride-1 convolution with <= 4 OUTPUT channels on the vector ALUs (csrc/ms_conv_small.hip): the data-gradient that reaches the image (`inc.0`,
  * encoder_decoder.py:441-445: 16 -> 1 channels at config 2, 64 -> 3 at config 4).  Same arithmetic contract as ms_conv2d(ks=3, stride=1) with pro_mode 0 or 2
  * (BatchNorm-backward prologue pro_a*in + pro_b*in2 + pro_c); w_packed = the packed weights [9][cin_pad][cout_pad].  W % 4 == 0. */
-int ms_conv3x3_small_cout_ok(int Cout, int W);
-int ms_conv3x3_small_cout(const float* in, const float* in2, float* out, const float* w_packed, int N, int Cin, int H, int W, int Cout,
+MS_INTERNAL int ms_conv3x3_small_cout_ok(int Cout, int W);
+MS_INTERNAL int ms_conv3x3_small_cout(const float* in, const float* in2, float* out, const float* w_packed, int N, int Cin, int H, int W, int Cout,
                           int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_cstride, void* stream);
 
 /* Sub-pixel form of the two x2 resampling convolutions (csrc/ms_conv_subpix.h): same results as ms_conv2d with fetch = 1 / 2 to fp32 rounding, without
@@ -266,8 +289,8 @@ int ms_conv3x3_small_cout(const float* in, const float* in2, float* out, const f
  *           out = dX * lrelu'(ref) (ref = the materialised activation output [N,Cout,2Hs,2Ws]) and tab gets the sums of out and out*(u - mean) per channel
  *           (u = that activation's raw BatchNorm input, coef4 = its {scale, shift, mean, invstd}; table as ms_conv2d_actbwd: ms_conv_actbwd_tab_bytes).
  *           ref == NULL with u != NULL: the activation lrelu(scale*u + shift) was never materialised - the mask is recomputed from u. */
-int ms_conv_subpix_eligible(int Hs, int Ws);
-int ms_conv_subpix(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int mode,
+MS_INTERNAL int ms_conv_subpix_eligible(int Hs, int Ws);
+MS_INTERNAL int ms_conv_subpix(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int mode,
                    float* stats, const float* ref, const float* u, const float* coef4, float act_slope, float* tab, void* stream);
 
 /* Tail of a residual block in one launch (res_convdown / res_up_family: `last_act(conv_input(x) + conv(x))`, encoder_decoder.py:62-64, 344-346):
@@ -276,7 +299,7 @@ int ms_conv_subpix(const float* in, float* out, const float* w_packed, const flo
  *     out = lrelu((scale*u + shift) + (conv1x1(in) + bias)).
  * Replaces ms_conv2d(ks=1) + ms_bn_act(res_mode 1 / 2) - the skip tensor is never written (2 HBM passes and one launch less per block); same
  * arithmetic, bit for bit.  up2 = 1: `in` has HALF the resolution of u / out (up_type 'NN': nn.UpsamplingNearest2d commutes with a 1x1 conv). */
-int ms_conv1x1_bnres(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
+MS_INTERNAL int ms_conv1x1_bnres(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
                      const float* u, const float* coef4, float slope, int up2, void* stream);
 
 /* Cross-workgroup finalize (`_xfin`): ms_bn_finalize + its consumer in ONE launch.  The consumer launch derives the BatchNorm coefficients itself from the
@@ -285,15 +308,15 @@ int ms_conv1x1_bnres(const float* in, float* out, const float* w_packed, const f
  * on time-out).  Tag = the launch epoch the producing conv left in the table header, so nothing is cleared between launches: `gran` (ms_xfin_gran_bytes(C))
  * and `err` are zero-filled ONCE by the caller and dedicated to this BatchNorm layer.  Needs every workgroup of the launch co-resident (an exclusive device).
  * Replaces, per residual block, the ms_bn_finalize launch behind its second conv (~4.8 us of launch boundary in a replayed graph). */
-size_t ms_xfin_gran_bytes(int C);
+MS_INTERNAL size_t ms_xfin_gran_bytes(int C);
 /* The same for a consumer that needs the coefficients in its PROLOGUE: ms_conv2d with pro_mode 1 (kind 0: ms_bn_finalize folded in; tab = statistics table of the
  * producing conv, p0 = gamma, p1 = beta, eps) or pro_mode 2 (kind 1: ms_bn_bwd_coefs folded in; tab = the float2 table of ms_conv2d_actbwd / ms_conv_subpix, p0 =
  * the forward records {sc, sh, mean, invstd} [Cin][4], count = N*H*W).  The MFMA waves reduce and publish, then fill the launch's LDS coefficient table from
  * the granules while the staging waves' first global loads are in flight.  coef4 [Cin][4] receives the records ms_bn_finalize / ms_bn_bwd_coefs would write. */
-int ms_conv2d_xfin(const float* in, const float* in2, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride,
+MS_INTERNAL int ms_conv2d_xfin(const float* in, const float* in2, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride,
                    int fetch, int pro_mode, float slope, int epi_mode, float* stats, int kind, const float* tab, const float* p0, const float* p1, float eps, double count,
                    float* coef4, void* gran, int* err, void* stream);
-int ms_conv1x1_bnres_xfin(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
+MS_INTERNAL int ms_conv1x1_bnres_xfin(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
                           const float* u, const float* stats, const float* gamma, const float* beta, float eps, float* coef4, void* gran, int* err,
                           float slope, int up2, void* stream);
 
@@ -304,8 +327,8 @@ int ms_conv1x1_bnres_xfin(const float* in, float* out, const float* w_packed, co
  * native_batch_norm_backward).  No bias, plain store.
  *   u [N,Cout,Hout,Wout], coef4 float4[Cout] from ms_bn_finalize, tab: ms_conv_actbwd_tab_bytes(Cout) bytes, float2 header {slots used}
  *   + float2[Cout][slots]; hand it to ms_bn_bwd_coefs / ms_bn_bwd_full with nparts = 0. */
-size_t ms_conv_actbwd_tab_bytes(int Cout);
-int ms_conv2d_actbwd(const float* in, const float* in2, float* out, const float* w_packed,
+MS_STABLE size_t ms_conv_actbwd_tab_bytes(int Cout);
+MS_INTERNAL int ms_conv2d_actbwd(const float* in, const float* in2, float* out, const float* w_packed,
                      int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                      int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                      const float* u, const float* coef4, float act_slope, float* tab, void* stream);
@@ -318,8 +341,8 @@ int ms_conv2d_actbwd(const float* in, const float* in2, float* out, const float*
  * The conv neither reads nor waits for ride_out4: it is for the NEXT launch on the stream (the residual block's data-gradient conv, whose prologue needs it
  * - model_util.py:468-510 backward; the 1x1 skip data-gradient runs between producer and consumer anyway, so the ~5 us coefficient launch disappears).
  * MFMA wave w of workgroup b takes channel 4b + w: ride_C <= ms_conv_ride_capacity(N, Hout, Wout) always fits (MS_ERR_INVALID when a launch is too small). */
-int ms_conv_ride_capacity(int N, int Hout, int Wout);
-int ms_conv2d_ride(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
+MS_INTERNAL int ms_conv_ride_capacity(int N, int Hout, int Wout);
+MS_INTERNAL int ms_conv2d_ride(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                    int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                    int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                    int epi_mode, float* stats, int ride_kind, const float* ride_tab, int ride_nparts, const float* ride_p0, const float* ride_p1, float ride_eps, double ride_count,
@@ -329,46 +352,46 @@ int ms_conv2d_ride(const float* in, const float* in2, float* out, const float* w
  * eps) would compute (nn.BatchNorm2d in batch-statistics mode, model_util.py:468-510), bcoef4 what ms_bn_bwd_coefs(tab, coef4, count) would - without
  * the extra launch (a ~4 us kernel, 42 times per inner step).  counter: one int, zero before the first use; every launch re-arms it (one counter per
  * layer and stream: launches that share it must be stream-ordered). */
-int ms_conv2d_fin(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
+MS_INTERNAL int ms_conv2d_fin(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                   int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                   int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                   float* stats, const float* gamma, const float* beta, float eps, float* coef4, int* counter, void* stream);
-int ms_conv2d_actbwd_fin(const float* in, const float* in2, float* out, const float* w_packed,
+MS_INTERNAL int ms_conv2d_actbwd_fin(const float* in, const float* in2, float* out, const float* w_packed,
                          int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                          int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                          const float* u, const float* coef4, float act_slope, float* tab, double count, float* bcoef4, int* counter, void* stream);
 
 /* Chan-merge of the per-workgroup statistics in fp64 -> coef4[c] = {scale=gamma*invstd, shift=beta-mean*scale, mean, invstd}
  * (biased variance + eps: nn.BatchNorm2d training-mode normalisation with frozen affine). */
-int ms_bn_finalize(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, int C, void* stream);
+MS_STABLE int ms_bn_finalize(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, int C, void* stream);
 
 /* ---- streaming kernels around the convolutions ------------------------------------------------------------- */
 
 /* out = LeakyReLU_slope(coef4[c].scale*u + coef4[c].shift + res): BatchNorm apply + residual add + activation
  * (encoder_decoder.py:62-64, 344-346; slope 0.2, or 0 for nn.ReLU; 0 <= slope <= 1).  res_mode 0 none | 1 same shape | 2 res is
  * [N,C,H/2,W/2] and is nearest-up-sampled on the fly (conv1x1 commutes with nn.UpsamplingNearest2d). */
-int ms_bn_act(const float* u, const float* coef4, const float* res, int res_mode, float* out, int N, int C, int H, int W, float slope, void* stream);
+MS_STABLE int ms_bn_act(const float* u, const float* coef4, const float* res, int res_mode, float* out, int N, int C, int H, int W, float slope, void* stream);
 
 /* Backward through the activation + the two BatchNorm-backward reductions in one pass:
  *   gout = gin * (r > 0 ? 1 : slope), r = ref (the saved activation output) or coef4.scale*u+coef4.shift when ref == NULL;
  *   part2[c][ms_act_bwd_parts()] = per-workgroup {sum gout, sum gout*(u - mean_c)} with mean_c = coef4[c].mean (centred, as
  *   native_batch_norm_backward does: the uncentred form cancels catastrophically for channels with a large mean).  gout may alias gin. */
-int ms_act_bwd_parts(int N, int C, int HW);
-int ms_act_bwd_reduce(const float* gin, const float* ref, const float* u, const float* coef4, float* gout, float* part2,
+MS_STABLE int ms_act_bwd_parts(int N, int C, int HW);
+MS_STABLE int ms_act_bwd_reduce(const float* gin, const float* ref, const float* u, const float* coef4, float* gout, float* part2,
                       int N, int C, int HW, float slope, void* stream);
 
 /* ms_act_bwd_reduce + ms_bn_bwd_coefs in ONE launch: the last workgroup of each channel finalises coef_out4 (agent-scope hand-off,
  * no second kernel). arrive: int[C], zero before the first use (each launch re-arms it). */
-int ms_act_bwd_bn(const float* gin, const float* ref, const float* u, const float* coef4, float* gout, float* part2, int* arrive,
+MS_INTERNAL int ms_act_bwd_bn(const float* gin, const float* ref, const float* u, const float* coef4, float* gout, float* part2, int* arrive,
                   float* coef_out4, int N, int C, int HW, float slope, void* stream);
 
 /* native_batch_norm_backward (input gradient only, batch statistics): du = al*g + be*u + de, coef_out4[c] = {al,be,de,0}
  * (SURVEY.md A.7).  count = N*H*W.  Feed coef_out4 to ms_conv2d(pro_mode=2) of the data-gradient convolution.
  * nparts = 0: part2 is the table written by ms_conv2d_actbwd (its header holds the slot count). */
-int ms_bn_bwd_coefs(const float* part2, int nparts, const float* coef4, double count, float* coef_out4, int C, void* stream);
+MS_STABLE int ms_bn_bwd_coefs(const float* part2, int nparts, const float* coef4, double count, float* coef_out4, int C, void* stream);
 
 /* out[p,y,x] (+)= in[p,2y,2x]+in[p,2y,2x+1]+in[p,2y+1,2x]+in[p,2y+1,2x+1]: gradient of nn.UpsamplingNearest2d(2) */
-int ms_pool2_sum(const float* in, float* out, int planes, int Ho, int Wo, int accumulate, void* stream);
+MS_STABLE int ms_pool2_sum(const float* in, float* out, int planes, int Ho, int Wo, int accumulate, void* stream);
 
 /* ---- weight gradients for the outer update: autograd's convolution_backward w.r.t. `weight` when loss.backward()
  * runs after standard_training / hard_example_traininng (train_adv_supervised_segmentation_triplet.py:532-535).
@@ -383,8 +406,8 @@ int ms_pool2_sum(const float* in, float* out, int planes, int Ho, int Wo, int ac
  * Built combinations: 3x3 stride 1: (p_mode,q_mode) in {(0,0),(2,0),(2,1)}; 1x1: (0,0),(2,0); stride 2 (3x3, ConvTranspose 2x2): (0,0) - the ones
  * the networks need; anything else returns an error.
  * Deterministic: per-workgroup partials in `ws` (ms_conv_wgrad_ws_bytes), summed in a fixed order; accumulate != 0 adds to dw. */
-size_t ms_conv_wgrad_ws_bytes(int N, int M, int Nq, int Hp, int Wp, int ks, int stride);
-int ms_conv_wgrad(const float* p, const float* p2, const float* q, float* dw, int N, int M, int Nq, int Hp, int Wp, int Hq, int Wq,
+MS_STABLE size_t ms_conv_wgrad_ws_bytes(int N, int M, int Nq, int Hp, int Wp, int ks, int stride);
+MS_STABLE int ms_conv_wgrad(const float* p, const float* p2, const float* q, float* dw, int N, int M, int Nq, int Hp, int Wp, int Hq, int Wq,
                   int ks, int stride, int q_fetch, int p_mode, const float* pa, const float* pb, const float* pc,
                   int q_mode, const float* qa, const float* qb, int coef_stride, float slope, int accumulate,
                   void* ws, size_t ws_bytes, void* stream);
@@ -393,30 +416,30 @@ int ms_conv_wgrad(const float* p, const float* p2, const float* q, float* dw, in
  * BatchNorm weight.grad (dgamma) / bias.grad (dbeta) and dsum = sum of the masked gradient (bias.grad of the residual 1x1 conv that
  * shares it); each may be NULL.  accumulate != 0 adds.  In the hard-example pass the BatchNorm affine is frozen
  * (model_util.py:468-510): pass NULL for dgamma/dbeta there.  nparts = 0: part2 is the table of ms_conv2d_actbwd. */
-int ms_bn_bwd_full(const float* part2, int nparts, const float* coef4, double count, float* coef_out4, float* dgamma, float* dbeta, float* dsum,
+MS_STABLE int ms_bn_bwd_full(const float* part2, int nparts, const float* coef4, double count, float* coef_out4, float* dgamma, float* dbeta, float* dsum,
                    int accumulate, int C, void* stream);
 
 /* out[c] (+)= sum_{n,hw} x[n,c,hw]: bias.grad of a convolution from the gradient of its output. */
-size_t ms_channel_sum_ws_bytes(int N, int C);
-int ms_channel_sum(const float* x, int N, int C, int HW, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream);
+MS_STABLE size_t ms_channel_sum_ws_bytes(int N, int C);
+MS_STABLE int ms_channel_sum(const float* x, int N, int C, int HW, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* weight.grad [K][C] / bias.grad [K] (db may be NULL) of a 1x1 head, d computed on the fly:
  *   mode 0: d = scale*(softmax(aux) - onehot(target int64 [N,HW]))   aux = logits [N,K,HW]      (cross_entropy_2D, custom_loss.py:1043-1078)
  *   mode 1: d = scale*(aux - target)*aux*(1-aux)                      aux = sigmoid output, target float [N,K,HW]   (0.5*MSE, :718-729)
  *   mode 2: d = scale*aux. */
-size_t ms_head_wgrad_ws_bytes(int N, int C, int K, int HW);
-int ms_head_wgrad(const float* h, const float* aux, const void* target, int mode, float scale, float* dw, float* db,
+MS_STABLE size_t ms_head_wgrad_ws_bytes(int N, int C, int K, int HW);
+MS_STABLE int ms_head_wgrad(const float* h, const float* aux, const void* target, int mode, float scale, float* dw, float* db,
                   int N, int C, int K, int HW, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* loss_out[0] = loss_scale * sum (x-target)^2 (loss_out may be NULL); dx = grad_scale*(x-target) (dx may be NULL).
  * compute_image_recon_loss 'l2' (advanced_triplet...py:718-722): loss_scale = 0.5/n, grad_scale = upstream/n. */
-size_t ms_mse_ws_bytes(void);
-int ms_mse_loss(const float* x, const float* target, size_t n, float loss_scale, float grad_scale, float* loss_out, float* dx,
+MS_STABLE size_t ms_mse_ws_bytes(void);
+MS_STABLE int ms_mse_loss(const float* x, const float* target, size_t n, float loss_scale, float grad_scale, float* loss_out, float* dx,
                 void* ws, size_t ws_bytes, void* stream);
 
 /* torch.optim.AdamW (weight_decay > 0: p *= 1 - lr*wd first) / torch.optim.Adam (weight_decay = 0) on a flat buffer
  * (advanced_triplet...py:1055-1086); step semantics as ms_adam_step. */
-int ms_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float weight_decay,
+MS_STABLE int ms_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float weight_decay,
                   int step, const int* step_dev, void* stream);
 
 /* After an optimiser step: re-pack every convolution weight from the flat parameter buffer into ms_conv2d's forward and data-gradient
@@ -424,36 +447,36 @@ int ms_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float 
  *   { int64 begin (prefix sum of element counts), int64 src_off (floats into flat), float* dst_fwd, float* dst_dgrad,
  *     int32 kind (0 Conv2d [Cout][Cin][k][k], 1 ConvTranspose2d k2s2 [Cin][Cout][2][2]), d0, d1, k, cin_pad_fwd, cout_pad_fwd, cin_pad_dgrad, cout_pad_dgrad };
  * total = sum of element counts.  Padding of the packed buffers is left untouched (zero from allocation). */
-size_t ms_repack_desc_bytes(void);
-int ms_repack_weights(const float* flat, const void* desc_dev, int ndesc, long long total, void* stream);
+MS_INTERNAL size_t ms_repack_desc_bytes(void);
+MS_STABLE int ms_repack_weights(const float* flat, const void* desc_dev, int ndesc, long long total, void* stream);
 
 /* Running statistics of a tracking BatchNorm forward from the coefficient table of ms_bn_finalize (mean, invstd):
  * running = (1-momentum)*running + momentum*batch, variance unbiased (count/(count-1)). */
-int ms_bn_running_update(const float* coef4, float* running_mean, float* running_var, int C, double count, float momentum, float eps, void* stream);
+MS_STABLE int ms_bn_running_update(const float* coef4, float* running_mean, float* running_var, int C, double count, float momentum, float eps, void* stream);
 /* ... for all BatchNorm layers of a pass in one launch; desc_dev: nlayers records of ms_bn_running_desc_bytes() bytes
  *   { const float* coef4, float* running_mean, float* running_var, int32 C, float count } (same momentum for all). */
-size_t ms_bn_running_desc_bytes(void);
-int ms_bn_running_update_batch(const void* desc_dev, int nlayers, float momentum, float eps, void* stream);
+MS_INTERNAL size_t ms_bn_running_desc_bytes(void);
+MS_INTERNAL int ms_bn_running_update_batch(const void* desc_dev, int nlayers, float momentum, float eps, void* stream);
 
 /* The two halves of ms_conv_wgrad for a whole backward pass: ms_conv_wgrad_partials runs only the MFMA kernel (partials stay in `ws`, the
  * number of partial slots is returned in *nslots_out), ms_wgrad_reduce_batch then sums the partials of MANY tensors with one launch.
  * desc_dev: device array of ndesc records of ms_wgrad_batch_desc_bytes() bytes:
  *   { int64 block_begin (prefix sum of ceil(numel/64)), const float* partial, float* dst, int32 numel, nslots, accumulate, pad };
  * total_blocks = sum of ceil(numel/64). */
-int ms_conv_wgrad_partials(const float* p, const float* p2, const float* q, int N, int M, int Nq, int Hp, int Wp, int Hq, int Wq,
+MS_INTERNAL int ms_conv_wgrad_partials(const float* p, const float* p2, const float* q, int N, int M, int Nq, int Hp, int Wp, int Hq, int Wq,
                            int ks, int stride, int q_fetch, int p_mode, const float* pa, const float* pb, const float* pc,
                            int q_mode, const float* qa, const float* qb, int coef_stride, float slope,
                            void* ws, size_t ws_bytes, int* nslots_out, void* stream);
-size_t ms_wgrad_batch_desc_bytes(void);
-int ms_wgrad_reduce_batch(const void* desc_dev, int ndesc, long long total_blocks, void* stream);
+MS_INTERNAL size_t ms_wgrad_batch_desc_bytes(void);
+MS_INTERNAL int ms_wgrad_reduce_batch(const void* desc_dev, int ndesc, long long total_blocks, void* stream);
 
 /* Per-plane min-max rescale y = (x - min)/(max - min + eps)*(new_max - new_min) + new_min: rescale_intensity
  * (common_utils/basic_operations.py:257-281), applied to the stylised image right after the path (advanced_triplet...py:868-869). */
-int ms_rescale_intensity(const float* x, float* y, int planes, int HW, float new_min, float new_max, float eps, void* stream);
+MS_STABLE int ms_rescale_intensity(const float* x, float* y, int planes, int HW, float new_min, float new_max, float eps, void* stream);
 
 /* cm[label*K + argmax(logits)] += 1 over all pixels (accumulates; zero cm first). Evaluation: common_utils/metrics.py:12-52 (confusion
  * matrix), :216-218 (Dice = 2|A n B| / (|A|+|B|) per class, medpy.metric.binary.dc). K <= 4. */
-int ms_confusion(const float* logits, const int64_t* labels, unsigned long long* cm, int N, int K, int HW, void* stream);
+MS_STABLE int ms_confusion(const float* logits, const int64_t* labels, unsigned long long* cm, int N, int K, int HW, void* stream);
 
 /* Heads (1x1 conv with K <= 4 outputs from C <= 64 channels; w is [K][C]):
  *   ms_head_fwd  out = sigmoid?(w h + b)         MyDecoder.final_conv + nn.Sigmoid (encoder_decoder.py:582,594)
@@ -461,16 +484,16 @@ int ms_confusion(const float* logits, const int64_t* labels, unsigned long long*
  *   ms_head_ce   logits = w h + b; loss = loss_sign * cross_entropy_2D(logits, labels) (custom_loss.py:1043-1078: sum of
  *                pixel NLL / (N*H*W)); writes loss_out[*loss_slot_dev or 0], dh = d loss / d h (NULL to skip) and the
  *                logits (NULL to skip).  The inner loop uses loss_sign = -1 (advanced_triplet...py:555). */
-int ms_head_fwd(const float* h, const float* w, const float* b, float* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
+MS_STABLE int ms_head_fwd(const float* h, const float* w, const float* b, float* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
 /* ms_style_fwd's restyle + ms_head_fwd in one pass, for a MaxStyle layer that sits directly in front of the 1x1 head (apply_max_style: layer 4 -> final_conv ->
  * Sigmoid, encoder_decoder.py:598-631): x [N,C,HW] is the layer's INPUT, (mu, sig, coefA, coefS) [N*C] what ms_style_fwd - called with y = NULL: statistics and
  * coefficients only - left; y = coefA/sig * (x - mu) + coefS (maxstyle.py:157-188) is formed per element with the layer's own expression and rounding and never
  * written: same bits in `out` as ms_style_fwd + ms_head_fwd. */
-int ms_head_fwd_styled(const float* x, const float* mu, const float* sig, const float* coefA, const float* coefS, const float* w, const float* b, float* out,
+MS_INTERNAL int ms_head_fwd_styled(const float* x, const float* mu, const float* sig, const float* coefA, const float* coefS, const float* w, const float* b, float* out,
                        int N, int C, int K, int HW, int apply_sigmoid, void* stream);
-int ms_head_bwd(const float* dout, const float* out, const float* w, float* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
-size_t ms_head_ce_ws_bytes(int N, int HW);
-int ms_head_ce(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* logits, float* loss_out,
+MS_STABLE int ms_head_bwd(const float* dout, const float* out, const float* w, float* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
+MS_STABLE size_t ms_head_ce_ws_bytes(int N, int HW);
+MS_STABLE int ms_head_ce(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* logits, float* loss_out,
                const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- bf16 ACTIVATION STORAGE for the conv stack (SURVEY.md 8(b) "`_bf16` I/O variants with fp32 statistics"; BASELINE config 5) -----------------
@@ -481,7 +504,7 @@ int ms_head_ce(const float* h, const float* w, const float* b, const int64_t* la
  * accumulators BEFORE the output is rounded, stores round to nearest-even bf16 (relative error <= 2^-9 per stored element).  Requirements: the
  * vector paths of the fp32 entry points (rows of W % 4 == 0 elements - W % 2 for fetch 1 -, 16-byte aligned tensors); MS_ERR_INVALID otherwise.
  * The "last workgroup finalises" experiments (ms_conv2d_fin, ms_conv2d_actbwd_fin, ms_act_bwd_bn) have no bf16 twin. */
-int ms_conv2d_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias,
+MS_STABLE int ms_conv2d_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias,
                    int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                    int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                    int epi_mode, float* stats, void* stream);
@@ -489,61 +512,61 @@ int ms_conv2d_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const
  * fp32 accumulation: the contraction operands - the prologue's output and the weights - are rounded to bf16 on their way into LDS (relative error <= 2^-9
  * per operand; the accumulation, the BatchNorm statistics and the epilogue are those of ms_conv2d_bf16).  Every other shape runs ms_conv2d_bf16 unchanged.
  * Measured against fp64 on the rounded operands: 3.5e-3 of the output range = the bf16 rounding of the stored output. */
-int ms_conv2d_bf16m(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias,
+MS_STABLE int ms_conv2d_bf16m(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias,
                     int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                     int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                     int epi_mode, float* stats, void* stream);
-int ms_conv2d_actbwd_bf16m(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed,
+MS_INTERNAL int ms_conv2d_actbwd_bf16m(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed,
                            int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                            int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                            const uint16_t* u, const float* coef4, float act_slope, float* tab, void* stream);
-int ms_conv1x1_bnres_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
+MS_INTERNAL int ms_conv1x1_bnres_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
                           const uint16_t* u, const float* coef4, float slope, int up2, void* stream);
-int ms_conv2d_actbwd_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed,
+MS_INTERNAL int ms_conv2d_actbwd_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed,
                           int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                           int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                           const uint16_t* u, const float* coef4, float act_slope, float* tab, void* stream);
-int ms_style_bwd_actbwd_parts_bf16(int B, int C, int HW);
-int ms_style_bwd_actbwd_bf16(const uint16_t* dy, const uint16_t* x, uint16_t* dx, const float* mu, const float* sig, const float* coefA,
+MS_INTERNAL int ms_style_bwd_actbwd_parts_bf16(int B, int C, int HW);
+MS_INTERNAL int ms_style_bwd_actbwd_bf16(const uint16_t* dy, const uint16_t* x, uint16_t* dx, const float* mu, const float* sig, const float* coefA,
                              const float* gamma_std, const float* beta_std, const float* lmda, const int64_t* perm,
                              float* d_gamma, float* d_beta, float* d_lmda, int B, int C, int HW, void* ws, size_t ws_bytes,
                              const uint16_t* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream);
-int ms_conv_subpix_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int mode,
+MS_INTERNAL int ms_conv_subpix_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int mode,
                         float* stats, const uint16_t* ref, const uint16_t* u, const float* coef4, float act_slope, float* tab, void* stream);
-int ms_conv3x3_small_cin_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int H, int W, int Cout, float* stats, void* stream);
-int ms_conv3x3_small_cout_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, int N, int Cin, int H, int W, int Cout,
+MS_INTERNAL int ms_conv3x3_small_cin_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int H, int W, int Cout, float* stats, void* stream);
+MS_INTERNAL int ms_conv3x3_small_cout_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, int N, int Cin, int H, int W, int Cout,
                                int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_cstride, void* stream);
-int ms_bn_act_bf16(const uint16_t* u, const float* coef4, const uint16_t* res, int res_mode, uint16_t* out, int N, int C, int H, int W, float slope, void* stream);
-int ms_act_bwd_reduce_bf16(const uint16_t* gin, const uint16_t* ref, const uint16_t* u, const float* coef4, uint16_t* gout, float* part2,
+MS_STABLE int ms_bn_act_bf16(const uint16_t* u, const float* coef4, const uint16_t* res, int res_mode, uint16_t* out, int N, int C, int H, int W, float slope, void* stream);
+MS_STABLE int ms_act_bwd_reduce_bf16(const uint16_t* gin, const uint16_t* ref, const uint16_t* u, const float* coef4, uint16_t* gout, float* part2,
                            int N, int C, int HW, float slope, void* stream);
-int ms_pool2_sum_bf16(const uint16_t* in, uint16_t* out, int planes, int Ho, int Wo, int accumulate, void* stream);
-int ms_pool2_actbwd_bf16(const uint16_t* in, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
+MS_STABLE int ms_pool2_sum_bf16(const uint16_t* in, uint16_t* out, int planes, int Ho, int Wo, int accumulate, void* stream);
+MS_INTERNAL int ms_pool2_actbwd_bf16(const uint16_t* in, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
                          int N, int C, int Ho, int Wo, float slope, void* stream);
-int ms_conv2d_ride_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias,
+MS_INTERNAL int ms_conv2d_ride_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias,
                         int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                         int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                         int epi_mode, float* stats, int ride_kind, const float* ride_tab, int ride_nparts, const float* ride_p0, const float* ride_p1, float ride_eps, double ride_count,
                         float* ride_out4, int ride_C, void* stream);
-int ms_conv2d_xfin_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride,
+MS_INTERNAL int ms_conv2d_xfin_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride,
                         int fetch, int pro_mode, float slope, int epi_mode, float* stats, int kind, const float* tab, const float* p0, const float* p1, float eps, double count,
                         float* coef4, void* gran, int* err, void* stream);
-int ms_conv1x1_bnres_xfin_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
+MS_INTERNAL int ms_conv1x1_bnres_xfin_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
                                const uint16_t* u, const float* stats, const float* gamma, const float* beta, float eps, float* coef4, void* gran, int* err,
                                float slope, int up2, void* stream);
-int ms_pool2_actbwd_pool_bf16(const uint16_t* in, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
+MS_INTERNAL int ms_pool2_actbwd_pool_bf16(const uint16_t* in, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
                               int N, int C, int Ho, int Wo, float slope, uint16_t* pooled, void* stream);
-int ms_add_actbwd_bf16(const uint16_t* in_lo, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
+MS_INTERNAL int ms_add_actbwd_bf16(const uint16_t* in_lo, const uint16_t* add, uint16_t* out, const uint16_t* act, const uint16_t* u, const float* coef4, float* part2,
                        int N, int C, int Ho, int Wo, float slope, uint16_t* pooled, void* stream);
-int ms_head_fwd_bf16(const uint16_t* h, const float* w, const float* b, uint16_t* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
-int ms_head_fwd_styled_bf16(const uint16_t* x, const float* mu, const float* sig, const float* coefA, const float* coefS, const float* w, const float* b, uint16_t* out,
+MS_STABLE int ms_head_fwd_bf16(const uint16_t* h, const float* w, const float* b, uint16_t* out, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
+MS_INTERNAL int ms_head_fwd_styled_bf16(const uint16_t* x, const float* mu, const float* sig, const float* coefA, const float* coefS, const float* w, const float* b, uint16_t* out,
                             int N, int C, int K, int HW, int apply_sigmoid, void* stream);
-int ms_head_bwd_bf16(const uint16_t* dout, const uint16_t* out, const float* w, uint16_t* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
-int ms_head_ce_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* logits, float* loss_out,
+MS_STABLE int ms_head_bwd_bf16(const uint16_t* dout, const uint16_t* out, const float* w, uint16_t* dh, int N, int C, int K, int HW, int apply_sigmoid, void* stream);
+MS_STABLE int ms_head_ce_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* logits, float* loss_out,
                     const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream);
-int ms_head_ce_tail_bf16(const uint16_t* u, const uint16_t* skip, const float* coef4, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* loss_out,
+MS_INTERNAL int ms_head_ce_tail_bf16(const uint16_t* u, const uint16_t* skip, const float* coef4, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* loss_out,
                          const int* loss_slot_dev, int N, int C, int K, int H, int W, float loss_sign, void* ws, size_t ws_bytes, float* bn_part, float act_slope, uint16_t* pooled,
                          void* stream);
-int ms_head_ce_actbwd_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* loss_out, const int* loss_slot_dev,
+MS_INTERNAL int ms_head_ce_actbwd_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* loss_out, const int* loss_slot_dev,
                            int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes,
                            const uint16_t* bn_u, const float* bn_coef4, float* bn_part, float act_slope, void* stream);
 

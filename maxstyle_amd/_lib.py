@@ -51,6 +51,8 @@ SIGNATURES = {
     "ms_add_actbwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_float, c_f32p, c_void]),
     "ms_conv2d_pool2_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "ms_conv2d_form": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "ms_wino_pack_floats": (c_size, [c_int, c_int]),
+    "ms_wino_pack": (c_int, [c_f32p, c_int, c_int, c_void]),
     "ms_pool2_actbwd_pool": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_float, c_f32p, c_void]),
     "ms_head_ce_actbwd_parts": (c_int, [c_int, c_int, c_int]),
     "ms_head_ce_actbwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_void, c_int, c_int, c_int, c_int, c_float, c_void, c_size,

@@ -89,7 +89,8 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   const bool wino_ok = (fetch >= 0) && (fetch & MS_FETCH_WINOGRAD) != 0;
   const bool x3_ok = (fetch >= 0) && (fetch & MS_FETCH_X3) != 0;               // bit 9: ... the three-way bf16 split form
   const bool wino_nt1 = (fetch >= 0) && (fetch & MS_FETCH_WINO_NT1) != 0;      // bit 10: the one-channel-block variant of the Winograd form
-  if (fetch >= 0) fetch &= ~(MS_FETCH_WINOGRAD | MS_FETCH_X3 | MS_FETCH_WINO_NT1);
+  const bool wino_u = (fetch >= 0) && (fetch & MS_FETCH_WINO_U) != 0;          // bit 11: w_packed carries the Winograd appendix
+  if (fetch >= 0) fetch &= ~(MS_FETCH_WINOGRAD | MS_FETCH_X3 | MS_FETCH_WINO_NT1 | MS_FETCH_WINO_U);
   if (pro_mode < 0 || pro_mode > 3 || epi_mode < 0 || (epi_mode > 2 && epi_mode != MS_EPI_POOL2) || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
   if (epi_mode == MS_EPI_POOL2 && (mk != nullptr || fin != nullptr || stats != nullptr || bias != nullptr)) { set_error("ms_conv2d: the pooled epilogue is a plain store (no bias, statistics or mask)"); return MS_ERR_INVALID; }
   // the activation helper computes max(v, v*slope): LeakyReLU / ReLU slopes only
@@ -145,6 +146,7 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   a.wino_ok = wino_ok ? 1 : 0;
   a.x3_ok = x3_ok ? 1 : 0;
   a.wino_nt1 = wino_nt1 ? 1 : 0;
+  a.wu = (wino_u && wino_ok && ks == 3 && stride == 1 && Cin % 8 == 0) ? w_packed + (size_t)9 * a.cin_pad * a.cout_pad : nullptr;
   a.act_bf16 = act_bf16;                  // 0 fp32 storage | 1 bf16 storage, fp32 matrix arithmetic | 2 bf16 storage, bf16 matrix arithmetic where built (`_bf16m`)
   a.pro_mode = pro_mode; a.pro_nstride = pro_nstride; a.pro_cstride = pro_cstride < 1 ? 1 : pro_cstride; a.slope = slope; a.epi_mode = epi_mode;
   if (mk != nullptr) { a.mk_u = mk->u; a.mk_coef = mk->coef4; a.mk_slope = mk->slope; a.mk_tab = mk->tab; }
@@ -248,6 +250,47 @@ extern "C" int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int pr
   return (conv_wide_eligible(a, 3, 1, FETCH_NORMAL, true) && conv_wide_is_wino(a)) ? 1 : 0;
 }
 namespace ms { int conv_wino_blocks(const ConvArgs& a); }      // ms_conv_inst_wino.hip
+namespace ms {
+// one thread per (input channel, output channel) pair: U = G g G^T with EXACTLY the expression of the staging waves (conv_wide_kernel store_chunk), so the kernel that
+// copies U from here computes the same bits as the one that transforms the taps itself
+__global__ __launch_bounds__(256) void wino_pack_kernel(float* __restrict__ wp, int Cin, int Cout, int cin_pad, int cout_pad) {
+  const int nchunks = Cin / 8, ncb = (Cout + 15) / 16;
+  const long total = (long)ncb * nchunks * 128;
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= total) return;
+  const int m = (int)(id & 15), ci = (int)((id >> 4) & 7);
+  const long blk = id >> 7;                        // cb16 * nchunks + chunk
+  const int chunk = (int)(blk % nchunks), cb = (int)(blk / nchunks);
+  const int c = chunk * 8 + ci, co = cb * 16 + m;
+  float g[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) g[tap] = (co < cout_pad) ? wp[((size_t)tap * cin_pad + c) * cout_pad + co] : 0.f;
+  float t[4][3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const float g0 = g[kx], g1 = g[3 + kx], g2 = g[6 + kx];
+    t[0][kx] = g0; t[1][kx] = 0.5f * ((g0 + g2) + g1); t[2][kx] = 0.5f * ((g0 + g2) - g1); t[3][kx] = g2;
+  }
+  float* u = wp + (size_t)9 * cin_pad * cout_pad + (size_t)blk * 2048 + ci * 16 + m;
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi) {
+    const float u0 = t[xi][0], u3 = t[xi][2];
+    const float u1 = 0.5f * ((t[xi][0] + t[xi][2]) + t[xi][1]), u2 = 0.5f * ((t[xi][0] + t[xi][2]) - t[xi][1]);
+    u[(xi * 4 + 0) * 128] = u0; u[(xi * 4 + 1) * 128] = u1; u[(xi * 4 + 2) * 128] = u2; u[(xi * 4 + 3) * 128] = u3;
+  }
+}
+}  // namespace ms
+extern "C" size_t ms_wino_pack_floats(int Cin, int Cout) {
+  if (Cin < 8 || Cout < 1 || Cin % 8 != 0) return 0;
+  return (size_t)((Cout + 15) / 16) * (size_t)(Cin / 8) * 2048;
+}
+extern "C" int ms_wino_pack(float* w_packed, int Cin, int Cout, void* stream) {
+  if (w_packed == nullptr || ms_wino_pack_floats(Cin, Cout) == 0) { set_error("ms_wino_pack: packed 3x3 weights with Cin %% 8 == 0"); return MS_ERR_INVALID; }
+  const int cin_pad = (Cin + 3) / 4 * 4, cout_pad = (Cout + 63) / 64 * 64;
+  const long total = (long)((Cout + 15) / 16) * (Cin / 8) * 128;
+  MS_LAUNCH(wino_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_packed, Cin, Cout, cin_pad, cout_pad);
+  return check_launch("wino_pack");
+}
 extern "C" int ms_conv2d_form(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16, int fetch) {
   if (N < 1 || Cin < 1 || H < 1 || W < 1 || Cout < 1 || pro_mode < 0 || pro_mode > 2 || fetch < 0 || (fetch & 0xFF) != 0) return 0;
   ConvArgs a{};
@@ -255,6 +298,8 @@ extern "C" int ms_conv2d_form(int N, int Cin, int H, int W, int Cout, int pro_mo
   a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (Cout + 63) / 64 * 64;
   a.pro_mode = pro_mode; a.wino_ok = (fetch & MS_FETCH_WINOGRAD) ? 1 : 0; a.x3_ok = (fetch & MS_FETCH_X3) ? 1 : 0; a.wino_nt1 = (fetch & MS_FETCH_WINO_NT1) ? 1 : 0;
   a.act_bf16 = (bf16 < 0 || bf16 > 2) ? 2 : bf16;
+  static const float appendix_marker = 0.f;             // (only compared with null by the dispatch rules)
+  a.wu = ((fetch & MS_FETCH_WINO_U) && a.wino_ok && Cin % 8 == 0) ? &appendix_marker : nullptr;
   if (!conv_wide_eligible(a, 3, 1, FETCH_NORMAL, W % 4 == 0)) return 0;
   if (!conv_wide_is_wino(a)) return 1;
   return 1 + conv_wino_blocks(a);

@@ -13,9 +13,9 @@ static int wide_wino(const ConvArgs& a, hipStream_t st) {
 int conv_dispatch_wino2(const ConvArgs& a, hipStream_t st);      // ms_conv_inst_wino2.hip: two channel blocks per staged tile
 // Channel blocks per staged input tile (round 4).  Two blocks = ONE workgroup per CU (256 registers, 128 accumulators per MFMA wave): the tile is staged, prologue'd and
 // transformed once per 32 output channels, but a SIMD then holds one MFMA wave and one staging wave instead of two of each.  Measured per layer on MI355X
-// (tools/ab_wino_nt.py, profiles/r04_wino_nt_ab.txt): it wins where the K loop is long and the staging side is light - Cin >= 64 with at least one work item per CU;
-// with the two-tensor BatchNorm-backward prologue (twice the loads per chunk on half the staging waves) only from 256 input channels up or where the layer widens
-// (Cout > Cin).  MS_CONV_WINO_NT: 1 = the one-block form everywhere, 2 = two blocks wherever Cout > 16 (A/B switches); per call: MS_FETCH_WINO_NT1.
+// (tools/ab_wino_nt.py, profiles/r04_wino_nt_ab.txt): it wins where the K loop is long and the staging side is light - at least one work item per CU and, with the
+// transformed weights staged from the packed tensor's appendix (MS_FETCH_WINO_U: what the engine does), Cin >= 32 under every prologue; when the staging waves transform
+// the taps themselves, Cin >= 64, and with the two-tensor BatchNorm-backward prologue only from 256 input channels up or where the layer widens (Cout > Cin).  MS_CONV_WINO_NT: 1 = the one-block form everywhere, 2 = two blocks wherever Cout > 16 (A/B switches); per call: MS_FETCH_WINO_NT1.
 static int wino_nt(const ConvArgs& a) {
   static const int cap = getenv("MS_CONV_WINO_NT") ? atoi(getenv("MS_CONV_WINO_NT")) : 0;
   static const bool tune = getenv("MS_CONV_TUNE") != nullptr;
@@ -24,7 +24,9 @@ static int wino_nt(const ConvArgs& a) {
   if (c >= 2) return 2;
   const int tw = a.Wout < 64 ? 32 : 64, th = 256 / tw;
   const long items2 = (long)a.N * cdiv(a.Wout, tw) * cdiv(a.Hout, th) * cdiv(a.Cout, 32);
-  if (a.Cin < 64 || items2 < (long)num_cus()) return 1;
+  if (items2 < (long)num_cus()) return 1;
+  if (a.wu != nullptr) return a.Cin >= 32 ? 2 : 1;      // weights staged from the appendix (no transform in the staging waves): two blocks win from 32 input channels up, every prologue
+  if (a.Cin < 64) return 1;
   if (a.pro_mode == 2 && a.Cin < 256 && a.Cout <= a.Cin) return 1;
   return 2;
 }

@@ -75,6 +75,7 @@ struct ConvArgs {
   int wino_ok;                  // the caller accepts the Winograd form of a 3x3 stride-1 convolution for this call (MS_FETCH_WINOGRAD)
   int x3_ok;                    // ... the three-way bf16 split form (MS_FETCH_X3)
   int wino_nt1;                 // Winograd form: one channel block per staged tile (MS_FETCH_WINO_NT1)
+  const float* wu;              // Winograd appendix of the packed weights (MS_FETCH_WINO_U): transformed weights [cb16][chunk][16][8][16], or null
   int act_bf16;                 // activation tensors (in, in2, out, mk_u) are stored as bf16 (the `_bf16` entry points); statistics / coefficients / weights fp32
   int dbg;                      // timing-only ablation bits (MS_CONV_DBG): 1 skip MFMA loop, 2 skip global loads, 4 skip epilogue stores, 8 skip LDS stores, 16 skip the epilogue
   int bw_parts; double bw_count; float* bw_out;   // pro_mode 3 (host side): BatchNorm-backward coefficients are derived in-kernel from bw_parts partial sums per channel

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       if (coefs) load_coefs(c0);
       have_w = load_w;
       if constexpr (WIN) {
-        if (load_w && tid < G::W_ITEMS) {
+        if (load_w && tid < G::W_ITEMS && a.wu == nullptr) {
           {
             // buffer addressing: resource = the packed weights, scalar offset = (tap, first channel of the chunk, channel block), vector offset = the
             // thread's hoisted (channel-in-chunk, output channel) - nine loads, no vector address arithmetic (layers with many chunks re-stage per chunk)
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         else buf[h_lds[j] & 0xFFFFF] = ((l_h_ok >> j) & 1u) ? v : 0.f;
       }
       if constexpr (WIN) {
-        if (have_w && tid < G::W_ITEMS) {
+        if (have_w && tid < G::W_ITEMS && a.wu == nullptr) {
           // U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: position p = 4*xi + nu (xi along ky, nu along kx)
           float t[4][3];
 #pragma unroll
@@ -504,8 +504,38 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #else
     constexpr bool tr = false;
 #endif
+    // Winograd appendix (a.wu, MS_FETCH_WINO_U): the chunk's transformed weights come straight from HBM / L2 into the stage's weight region by LDS-DMA
+    // (buffer_load_dwordx4 ... lds: 1 KB per wave-instruction, no vector register, no vector arithmetic) - 2 * NT instructions per staging wave instead of nine tap loads,
+    // ~37 vector instructions and 16 LDS stores per thread.  Issued FIRST in the iteration that stores the chunk (the consumers left this buffer at the previous
+    // barrier), covered by a counted vmcnt in front of this iteration's barrier: the next chunk's data loads, issued later, stay in flight.
+    typedef __attribute__((address_space(3))) void* plds_t;
+    int wu_voff = 0;
+    if constexpr (WIN) {
+      const int pl = tid & 63;
+      // lane -> (block j, channel-in-chunk, 4 output channels) inside one position's UP floats of the stage (see WideGeoW)
+      if constexpr (NT == 2) wu_voff = 4 * ((pl >> 5) * nchunks * 2048 + ((pl & 31) >> 2) * 16 + (pl & 3) * 4);
+      else wu_voff = 4 * ((pl >> 5) * 128 + ((pl & 31) >> 2) * 16 + (pl & 3) * 4);
+    }
+    auto dma_u = [&](float* buf, int cbi, int chunk_i) __attribute__((always_inline)) {
+      if constexpr (WIN) {
+        const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wu), 0, 0x7FFFFFFF, 0x00020000);
+        const int sw = __builtin_amdgcn_readfirstlane(tid >> 6);
+        float* dst = buf + CK * PS;
+#pragma unroll
+        for (int q = 0; q < 2 * NT; ++q) {
+          const int piece = q * 4 + sw;                 // 256 floats of the weight region each
+          const int so = (NT == 2) ? 4 * ((cbi * 2 * nchunks + chunk_i) * 2048 + piece * 128) : 4 * ((cbi * nchunks + chunk_i) * 2048 + piece * 256);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (plds_t)(dst + piece * 256), 16, wu_voff, so, 0, 0);
+        }
+      }
+    };
+    constexpr int kDataLoads = (PRO == 2 ? 2 : 1) * (NQI + NHI);      // vector-memory loads load_chunk issues for one chunk's activations
     for (int p = 0; p < T; ++p) {
       if (tr && p < 16) a.trace[128 + p * 4 + 0] = clock64();
+      bool dma_now = false;
+      if constexpr (WIN) {
+        if (a.wu != nullptr && have_w) { dma_u(smem + (p & 1) * BUF, cb, chunk); dma_now = true; }
+      }
       if (!(a.dbg & 8)) {
         if (l_edge) store_chunk(smem + (p & 1) * BUF, std::true_type{}); else store_chunk(smem + (p & 1) * BUF, std::false_type{});
       }
@@ -518,6 +548,12 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         load_chunk(n, cb * COUT_TILE, chunk * CK, !(key_cb[b] == cb && key_c0[b] == chunk * CK));
       }
       if (tr && p < 16) a.trace[128 + p * 4 + 2] = clock64();
+      if constexpr (WIN) {
+        if (dma_now) {                                  // the LDS-DMA of this chunk's weights has landed (loads complete in order; the younger data loads may still fly)
+          if (p + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDataLoads) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
       lds_barrier();                                  // barrier #(p+1): chunk p visible; consumers done with chunk p-1
       if (tr && p < 16) a.trace[128 + p * 4 + 3] = clock64();
     }

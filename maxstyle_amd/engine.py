@@ -30,6 +30,7 @@ EPI_POOL2 = 6          # include/maxstyle_hip.h MS_EPI_POOL2
 LEAKY = 0.2
 BN_EPS = 1e-5
 F32 = torch.float32
+WINO_APPENDIX = os.environ.get("MS_WINO_APPENDIX", "1") != "0"      # A/B switch: pack the Winograd-transformed weights behind the taps of every 3x3 conv
 
 
 @dataclass
@@ -64,10 +65,14 @@ class ConvW:
 
     def __init__(self, w, b, kind="conv"):
         self.kind = kind
+        self.wu = self.dwu = False                 # the packed tensors carry a Winograd appendix (3x3 convs whose contraction width is a multiple of 8)
         if kind == "conv":
             self.cout, self.cin, self.ks = w.shape[0], w.shape[1], w.shape[2]
             self.wp = ops.pack_conv_weight(w)
             self.dwp = ops.pack_conv_weight_dgrad(w)
+            if self.ks == 3 and w.is_cuda and WINO_APPENDIX:
+                self.wp, self.wu = ops.with_wino_appendix(self.wp, self.cin, self.cout)
+                self.dwp, self.dwu = ops.with_wino_appendix(self.dwp, self.cout, self.cin)
         else:  # ConvTranspose2d k2 s2: weight [Cin, Cout, 2, 2]
             self.cin, self.cout, self.ks = w.shape[0], w.shape[1], 2
             self.wp = ops.pack_convT_weight(w)
@@ -78,10 +83,19 @@ class ConvW:
         """Re-pack new weight values into the SAME device buffers (captured HIP graphs keep their addresses)."""
         if self.kind == "conv":
             self.wp.copy_(ops.pack_conv_weight(w)); self.dwp.copy_(ops.pack_conv_weight_dgrad(w))
+            self.refresh_appendix()
         else:
             self.wp.copy_(ops.pack_convT_weight(w)); self.dwp.copy_(ops.pack_convT_weight_dgrad(w))
         if self.b is not None:
             self.b.copy_(b.detach().float())
+
+
+    def refresh_appendix(self):
+        """After the taps changed in place (update_, ms_repack_weights): the Winograd appendices follow."""
+        if self.wu:
+            ops.wino_repack(self.wp, self.cin, self.cout)
+        if self.dwu:
+            ops.wino_repack(self.dwp, self.cout, self.cin)
 
 
 class BNW:
@@ -164,6 +178,11 @@ class PackedNets:
         """After the flat optimiser moved the weights: one launch (graphs stay valid - same buffers)."""
         check(lib.ms_repack_weights(self._bank.flat_p.data_ptr(), self._desc.data_ptr(), self._desc_n, self._desc_total, torch.cuda.current_stream().cuda_stream),
               "ms_repack_weights")
+        for table in (self.enc, self.seg, self.dec):
+            if table is not None:
+                for obj in table.values():
+                    if isinstance(obj, ConvW):
+                        obj.refresh_appendix()
         self.eval_dirty = True
 
     def refresh_eval(self):
@@ -622,6 +641,8 @@ class InnerLoopEngine:
                                     BN_EPS, coef.data_ptr(), self._counter(name).data_ptr(), self._st()), "ms_conv2d_fin:" + name)
             return out, ("fused", coef), parts
         wf = ops.FETCH_WINOGRAD if (self.winograd and fetch == 0 and ks == 3 and stride == 1) else 0
+        if wf and (cw.dwu if dgrad else cw.wu):
+            wf |= ops.FETCH_WINO_U                     # the transformed weights are staged from the packed tensor's appendix
         if xf is not None:
             assert xf.C == Cin, "the pending coefficients belong to this conv's input channels"
             check(self.L("ms_conv2d_xfin")(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
@@ -756,7 +777,7 @@ class InnerLoopEngine:
         tab = self.t(bw_name + ".tab", lib.ms_conv_actbwd_tab_bytes(cout) // 4)
         pa, pb, pc = ops.coef_ptrs(bnbwd[0])
         check(self.L("ms_conv2d_actbwd")(g.data_ptr(), bnbwd[1].data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), N, Cin, Hs, Ws, cout, cw.ks, 1,
-                                   ops.FETCH_WINOGRAD if (self.winograd and cw.ks == 3) else 0,
+                                   (ops.FETCH_WINOGRAD | (ops.FETCH_WINO_U if cw.dwu else 0)) if (self.winograd and cw.ks == 3) else 0,
                                    2, pa, pb, pc, 0, 4, 1.0, u.data_ptr(), coef.data_ptr(), slope, tab.data_ptr(), self._st()), "ms_conv2d_actbwd:" + name)
         return out, tab
 

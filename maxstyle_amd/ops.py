@@ -162,6 +162,7 @@ def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8, step_dev=None):
 FETCH_NORMAL, FETCH_UPS2, FETCH_ZINS2 = 0, 1, 2
 FETCH_X3 = 0x200            # MS_FETCH_X3: the caller accepts the three-way bf16 split form (fp32-faithful, bf16 matrix cores)
 EPI_POOL2 = 6                # ms_conv2d epi_mode: 2x2-pooled store (MS_EPI_POOL2)
+FETCH_WINO_U = 0x800        # MS_FETCH_WINO_U: the packed weights carry the Winograd appendix (with_wino_appendix below)
 FETCH_WINO_NT1 = 0x400      # MS_FETCH_WINO_NT1: with FETCH_WINOGRAD, the one-channel-block variant (A/B and test switch; same bits per output element)
 FETCH_WINOGRAD = 0x100      # MS_FETCH_WINOGRAD: OR into fetch = the caller accepts the Winograd form of a 3x3 stride-1 convolution (include/maxstyle_hip.h)
 
@@ -197,6 +198,24 @@ def pack_convT_weight(w):
 def pack_convT_weight_dgrad(w):
     """Data-gradient of ConvTranspose2d(k=2,s=2) = Conv2d(k=2,s=2,p=0) from Cout to Cin channels with kernel w[ci][co][dy][dx]."""
     return _pack(w.detach())          # as a conv weight: [Cout'=Cin, Cin'=Cout, 2, 2]
+
+
+def with_wino_appendix(wp, Cin, Cout):
+    """The packed 3x3 weights `wp` [9, cin_pad, cout_pad] re-homed into ONE buffer that also holds their Winograd appendix (include/maxstyle_hip.h, MS_FETCH_WINO_U):
+    returns (view of the taps - same shape, the buffer's first bytes -, has_appendix).  Call wino_repack(view, Cin, Cout) after every change of the taps."""
+    n_u = int(lib.ms_wino_pack_floats(Cin, Cout))
+    if wp.dim() != 3 or wp.shape[0] != 9 or n_u == 0:
+        return wp, False
+    buf = torch.zeros(wp.numel() + n_u, dtype=torch.float32, device=wp.device)
+    view = buf[:wp.numel()].view(wp.shape)
+    view.copy_(wp)
+    view._ms_wino_buf = buf                      # keeps the allocation alive with the view
+    wino_repack(view, Cin, Cout)
+    return view, True
+
+
+def wino_repack(wp_view, Cin, Cout):
+    check(lib.ms_wino_pack(wp_view.data_ptr(), Cin, Cout, _stream()), "ms_wino_pack")
 
 
 def conv_out_hw(Hs, Ws, ks, stride, fetch):

@@ -27,6 +27,21 @@ def test_library_exports_every_declared_symbol():
     assert L.lib.ms_version() >= 100
 
 
+def test_every_entry_point_is_tagged_stable_or_internal():
+    """the header marks which entry points are the stable operator surface and which are engine-private fusions with preconditions."""
+    text = open(os.path.join(ROOT, "include", "maxstyle_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decl = re.findall(r"^(MS_STABLE|MS_INTERNAL)?\s*(?:int|size_t|const char\*)\s+(ms_[a-z0-9_]+)\s*\(", text, flags=re.M)
+    assert len(decl) == len(_header_symbols())
+    untagged = [n for t, n in decl if not t]
+    assert not untagged, untagged
+    stable = {n for t, n in decl if t == "MS_STABLE"}
+    internal = {n for t, n in decl if t == "MS_INTERNAL"}
+    assert {"ms_conv2d", "ms_bn_finalize", "ms_style_fwd", "ms_style_bwd", "ms_adam_step", "ms_conv_wgrad", "ms_confusion"} <= stable
+    assert {"ms_conv2d_xfin", "ms_conv2d_ride", "ms_step_tail", "ms_head_ce_tail", "ms_conv1x1_bnres_xfin"} <= internal
+    assert all(n.replace("_bf16m", "").replace("_bf16", "") in stable for n in stable if n.endswith(("_bf16", "_bf16m")))      # a twin shares its base's tag
+
+
 def test_missing_extension_fails_loudly(tmp_path, monkeypatch):
     import importlib, maxstyle_amd._lib as L
     monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))

@@ -120,6 +120,34 @@ def test_two_channel_blocks_per_staged_tile_same_bits(dev, N, Cin, Cout, H, W, b
         assert torch.equal(ops.conv2d(x, wp, None, Cout, 3, 1, fetch=WG, epi_mode=ops.EPI_POOL2), ops.conv2d(x, wp, None, Cout, 3, 1, fetch=N1, epi_mode=ops.EPI_POOL2))
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 16, 16, 64, 64), (2, 64, 64, 64, 64), (1, 32, 48, 20, 192), (2, 64, 64, 32, 32), (1, 128, 64, 20, 40), (1, 8, 33, 10, 100), (1, 256, 256, 40, 40)])
+def test_winograd_appendix_same_bits(dev, N, Cin, Cout, H, W):
+    """MS_FETCH_WINO_U: the transformed weights staged by LDS-DMA from the packed tensor's appendix (ms_wino_pack: the in-kernel expression, evaluated once per weight
+    version) against the kernel that transforms the nine taps of every chunk itself - the same bits, for one and two channel blocks per staged tile, every prologue,
+    channel tails in Cout, several chunks per item (weights re-staged per chunk) and layers whose two chunks stay resident (16 -> 16)."""
+    from maxstyle_amd import ops
+    WG = ops.FETCH_WINOGRAD
+    x = _rand((N, Cin, H, W), 1).to(dev); x2 = _rand((N, Cin, H, W), 2).to(dev); w = _rand((Cout, Cin, 3, 3), 3, 0.1); b = _rand((Cout,), 4).to(dev)
+    cfd = _rand((Cin, 4), 5).to(dev)
+    pa, pb, pc = ops.coef_ptrs(cfd)[:3]
+    wp0 = ops.pack_conv_weight(w.to(dev))
+    wp, has = ops.with_wino_appendix(wp0.clone(), Cin, Cout)
+    assert has and torch.equal(wp, wp0)
+    for nt in (0, ops.FETCH_WINO_NT1):
+        U = WG | nt | ops.FETCH_WINO_U
+        assert torch.equal(ops.conv2d(x, wp, b, Cout, 3, 1, fetch=U), ops.conv2d(x, wp0, b, Cout, 3, 1, fetch=WG | nt))
+        kw = dict(pro_mode=1, pro_a=pa, pro_b=pb, pro_cstride=4, slope=0.2)
+        assert torch.equal(ops.conv2d(x, wp, None, Cout, 3, 1, fetch=U, **kw), ops.conv2d(x, wp0, None, Cout, 3, 1, fetch=WG | nt, **kw))
+        kw = dict(pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=x2)
+        assert torch.equal(ops.conv2d(x, wp, None, Cout, 3, 1, fetch=U, **kw), ops.conv2d(x, wp0, None, Cout, 3, 1, fetch=WG | nt, **kw))
+    # a change of the taps is followed by the appendix only through wino_repack
+    wp.mul_(2.0)
+    stale = ops.conv2d(x, wp, None, Cout, 3, 1, fetch=WG | ops.FETCH_WINO_U)
+    ops.wino_repack(wp, Cin, Cout)
+    fresh = ops.conv2d(x, wp, None, Cout, 3, 1, fetch=WG | ops.FETCH_WINO_U)
+    assert torch.equal(fresh, ops.conv2d(x, wp, None, Cout, 3, 1, fetch=WG)) and not torch.equal(stale, fresh)
+
+
 def test_winograd_bit_is_ignored_where_the_form_is_not_built(dev):
     """Rows narrower than 20 pixels, Cin % 8 != 0, 1x1: the call runs the direct form - bit-identical with and without the bit."""
     from maxstyle_amd import ops

@@ -3,7 +3,8 @@ channels, replayed on its live buffers with MS_FETCH_WINO_NT1 (one block per til
 Run on the GPU box:  python tools/ab_wino_nt.py [c2|c4] [reps]
 The engine is built with MS_XFIN=0 MS_RIDE=0 so that every convolution goes through ms_conv2d / ms_conv2d_actbwd (the `_xfin` twins launch the same kernels)."""
 import os, sys
-os.environ.setdefault("MS_XFIN", "0"); os.environ.setdefault("MS_RIDE", "0")
+os.environ.setdefault("MS_XFIN", "0"); os.environ.setdefault("MS_RIDE", "0"); os.environ["MS_CONV_WINO_NT"] = "2"      # NT1 bit decides per call; "auto" column: the heuristic (env dropped + MS_CONV_TUNE)
+os.environ["MS_CONV_TUNE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
@@ -72,17 +73,26 @@ def main():
             e1.synchronize()
             best = min(best, e0.elapsed_time(e1) / reps * 1e3)
         return best
-    print(f"{'call':12s} {'N,Cin,Hs,Ws,Cout':>24s} pm epi st cnt   nt1_us   nt2_us  exec_mfma_frac(nt1 -> nt2)   gain_us/step")
-    t1 = t2 = 0.0
+    # columns: one / two channel blocks per staged tile, weights transformed in the kernel (the MS_FETCH_WINO_U bit cleared) or staged from the appendix (+U)
+    WU = 0x800
+    print(f"{'call':12s} {'N,Cin,Hs,Ws,Cout':>24s} pm epi st cnt   nt1_us  nt1+U_us   nt2_us  nt2+U_us  exec_mfma_frac(nt1 -> best)   auto")
+    tot = [0.0, 0.0, 0.0, 0.0, 0.0]
     for key, (cnt, a, fi) in sorted(seen.items(), key=lambda kv: -kv[1][0] * kv[0][2] * kv[0][5] * kv[0][3] * kv[0][4]):
         name, N, Cin, Hs, Ws, Cout, pm, epi, stats = key
-        a1 = list(a); a1[fi] = a[fi] | NT1
-        u1 = time_call(name, tuple(a1)); u2 = time_call(name, a)
-        t1 += cnt * u1; t2 += cnt * u2
+        has_u = bool(a[fi] & WU)
+        ts = []
+        os.environ["MS_CONV_WINO_NT"] = "2"         # (re-read per call under MS_CONV_TUNE) two blocks wherever the call's own NT1 bit does not say one
+        for nt1, wu in ((1, 0), (1, 1), (0, 0), (0, 1)):
+            a1 = list(a); a1[fi] = (a[fi] & ~WU & ~NT1) | (NT1 if nt1 else 0) | (WU if (wu and has_u) else 0)
+            ts.append(time_call(name, tuple(a1)))
+        os.environ.pop("MS_CONV_WINO_NT", None)
+        auto = time_call(name, a)
+        for i, t in enumerate(ts + [auto]):
+            tot[i] += cnt * t
         # executed matrix work: 16 MFMAs of 16x16x4 per (2x2 tile group of 16, 4 channels, 16 output channels): 16/36 of the direct form's flops
         ex = 2.0 * N * Hs * Ws * Cout * Cin * 9 * 16 / 36 / 157.3e12 * 1e6
-        print(f"{name[3:]:12s} {str((N, Cin, Hs, Ws, Cout)):>24s} {pm:2d} {epi:3d} {int(stats):2d} {cnt:3d} {u1:8.1f} {u2:8.1f}     {ex / u1:5.2f} -> {ex / u2:5.2f}    {cnt * (u1 - u2):8.1f}")
-    print(f"per step: one block {t1:.0f} us, two blocks {t2:.0f} us")
+        print(f"{name[3:]:12s} {str((N, Cin, Hs, Ws, Cout)):>24s} {pm:2d} {epi:3d} {int(stats):2d} {cnt:3d} {ts[0]:8.1f} {ts[1]:8.1f} {ts[2]:8.1f} {ts[3]:8.1f}     {ex / ts[0]:5.2f} -> {ex / min(ts):5.2f}    {auto:8.1f}")
+    print(f"per step: nt1 {tot[0]:.0f} us, nt1+U {tot[1]:.0f} us, nt2 {tot[2]:.0f} us, nt2+U {tot[3]:.0f} us; the dispatch's own choice {tot[4]:.0f} us")
 
 
 if __name__ == "__main__":

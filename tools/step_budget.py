@@ -122,7 +122,7 @@ def conv_form(cv, bf16=0):
     from maxstyle_amd import _lib
     if cv is None or cv["ks"] != 3 or cv["stride"] != 1 or (cv["fetch"] & 0xFF) != 0 or cv.get("vector_alu"):
         return 0
-    return int(_lib.lib.ms_conv2d_form(cv["N"], cv["Cin"], cv["Hs"], cv["Ws"], cv["Cout"], cv["pm"] if cv["pm"] < 3 else 2, bf16, cv["fetch"]))
+    return int(_lib.lib.ms_conv2d_form(cv["N"], cv["Cin"], cv["Hs"], cv["Ws"], cv["Cout"], cv["pm"] if cv["pm"] < 3 else 2, bf16, cv["fetch"] & 0xF00))
 
 
 def bound_us(entry, kernel=None):
