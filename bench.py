@@ -344,7 +344,9 @@ def kernel_rooflines(eng, dev, config, instep=None):
     from maxstyle_amd import _lib
     FORMS = {0: "conv_mfma_kernel (first generation, direct form)", 1: "conv_wide_kernel<NT,PRO,1,true,float> (wide, direct form)",
              2: "conv_wide_kernel<1,PRO,1,true,ms_f32w%s> (Winograd F(2x2,3x3), one 16-channel block per staged tile)" % ("32" if W < 64 else ""),
-             3: "conv_wide_kernel<2,PRO,1,true,ms_f32w%s> (Winograd F(2x2,3x3), two 16-channel blocks per staged tile)" % ("32" if W < 64 else "")}
+             3: "conv_wide_kernel<2,PRO,1,true,ms_f32w%s> (Winograd F(2x2,3x3), two 16-channel blocks per staged tile)" % ("32" if W < 64 else ""),
+             4: "conv_wide_kernel<1,PRO,1,true,ms_f32wb> (Winograd F(2x2,3x3) on 8x8-pixel blocks, one 16-channel block)",
+             5: "conv_wide_kernel<2,PRO,1,true,ms_f32wb> (Winograd F(2x2,3x3) on 8x8-pixel blocks, two 16-channel blocks)"}
 
     def conv_block(key, what, pro, nbytes, tkey):
         # Both roofs are priced with what the launch EXECUTES: the Winograd form multiplies 16/36 of the direct form's products on the same fp32 matrix instruction, so its
@@ -368,7 +370,7 @@ def kernel_rooflines(eng, dev, config, instep=None):
                     "us_per_launch": t_use * 1e6, "us_per_launch_source": ("in-step (two cut-off captures of the step, difference)" if key in instep else "isolated back-to-back replay"),
                     "us_per_launch_isolated": t_iso * 1e6, "algorithmic_bytes": nbytes, "hbm_GBps": nbytes / t_use / 1e9, "hbm_frac": hf, "hbm_frac_isolated": hfi,
                     "flop_per_launch_executed": exf, "executed_tflops": exf / t_use / 1e12, "executed_mfma_frac": mf, "executed_mfma_frac_isolated": mfi,
-                    "form": "winograd F(2x2,3x3)" if form >= 2 else "direct", "channel_blocks_per_tile": (form - 1 if form >= 2 else None)})
+                    "form": "winograd F(2x2,3x3)" if form >= 2 else "direct", "channel_blocks_per_tile": ((form - 2) % 2 + 1 if form >= 2 else None)})
         if form >= 2:
             blk["direct_form_flop_per_launch"] = flops
             blk["direct_form_equivalent_tflops"] = flops / t_use / 1e12      # (work of the direct form per second: can pass the pipe's peak, NOT a roofline fraction)

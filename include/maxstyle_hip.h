@@ -49,6 +49,9 @@ MS_STABLE const char* ms_last_error(void);
  * every call until the next optimiser step).  ms_wino_pack computes each value with the in-kernel expression, so results are bit-identical with and without the bit.
  * Ignored where the Winograd form is not taken. */
 #define MS_FETCH_WINO_U 0x800
+/* with MS_FETCH_WINOGRAD: take the BLOCK form of the Winograd kernel (four independent 8x8-pixel blocks per work item, see ms_conv2d_form) wherever it is legal,
+ * not only where the dispatch finds it faster.  Same bits per output element as the tiled form.  A test and A/B switch. */
+#define MS_FETCH_WINO_BLOCKS 0x1000
 /* ms_conv2d epi_mode 6: the 2x2-POOLED store.  out is [N, Cout, H/2, W/2] and receives the sum of every 2x2 block of the convolution's result, in ms_pool2_sum's
  * order over the values as they would have been stored: the same bits as ms_conv2d + ms_pool2_sum, a quarter of the bytes written and none read back.  The
  * data-gradient of `conv3x3(nearest-up-sampled x)` (encoder_decoder.py:298-300, 323-337 backward) ends in exactly that sum.  Built for the Winograd form of the
@@ -57,7 +60,8 @@ MS_STABLE const char* ms_last_error(void);
 MS_INTERNAL int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16);      /* bf16: 0 = the fp32 entry point, 1 = `_bf16`, 2 = `_bf16m` */
 /* Which kernel form ms_conv2d(ks 3, stride 1, fetch) takes for this shape (16-byte aligned tensors assumed) - what the measurement tools print and price, asked of the
  * dispatch itself instead of re-deriving its rules: 0 first-generation kernel (conv_mfma_kernel) | 1 wide direct form (conv_wide_kernel) | 2 Winograd F(2x2,3x3), one
- * 16-channel block per staged tile (conv_wide_kernel<1, ..., ms_f32w*>) | 3 Winograd, two blocks (conv_wide_kernel<2, ...>: round 4).  fetch = the call's fetch argument
+ * 16-channel block per staged tile (conv_wide_kernel<1, ..., ms_f32w*>) | 3 Winograd, two blocks (conv_wide_kernel<2, ...>: round 4) | 4 / 5 the same on independent
+ * 8x8-pixel blocks instead of 4x64 / 8x32 tiles (ms_f32wb: rows that are not multiples of 32 / 64 pixels).  fetch = the call's fetch argument
  * (MS_FETCH_WINOGRAD / MS_FETCH_WINO_NT1 bits); a fused-fetch call (fetch & 0xFF != 0) is always 0. */
 MS_INTERNAL int ms_conv2d_form(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16, int fetch);
 /* The Winograd appendix of a packed 3x3 weight tensor (MS_FETCH_WINO_U): layout [ceil(Cout/16)][Cin/8][16 positions][8 input channels][16 output channels] fp32
@@ -340,7 +344,8 @@ MS_INTERNAL int ms_conv2d_actbwd(const float* in, const float* in2, float* out, 
  * the conv in front (ms_conv2d `stats`), ride_p0 / ride_p1 = gamma / beta, ride_eps -> ride_out4[c] = {scale, shift, mean, invstd}.
  * The conv neither reads nor waits for ride_out4: it is for the NEXT launch on the stream (the residual block's data-gradient conv, whose prologue needs it
  * - model_util.py:468-510 backward; the 1x1 skip data-gradient runs between producer and consumer anyway, so the ~5 us coefficient launch disappears).
- * MFMA wave w of workgroup b takes channel 4b + w: ride_C <= ms_conv_ride_capacity(N, Hout, Wout) always fits (MS_ERR_INVALID when a launch is too small). */
+ * MFMA wave w of workgroup b takes channels 4b + w, 4b + w + 4*grid, ...: any grid carries the whole job; within ride_C <= ms_conv_ride_capacity(N, Hout, Wout) a wave has
+ * at most one channel (the speed the rider is meant to have). */
 MS_INTERNAL int ms_conv_ride_capacity(int N, int Hout, int Wout);
 MS_INTERNAL int ms_conv2d_ride(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                    int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,

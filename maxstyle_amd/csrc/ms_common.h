@@ -142,6 +142,13 @@ template <> struct ActIO<ms_bf16w32> : ActIO<ms_bf16> {};
 // ms_f32w32: the same on 8-row x 32-pixel tiles (rows of 20..63 pixels)
 struct ms_f32w32 { float v; };
 template <> struct ActIO<ms_f32w32> : ActIO<float> {};
+// ms_f32wb / ms_bf16wb: the Winograd form on BLOCKS - a workgroup's four MFMA waves take four independent 8x8-pixel blocks (4x4 tiles of 2x2 outputs each) from a
+// flattened (image, block row, block column) enumeration, each staged with its own halo: any W, H that are multiples of 8 run without tile-quantisation waste
+// (rows of 80 / 40 / 20 pixels fill the 64- and 32-pixel tiles to 62 %)
+struct ms_f32wb { float v; };
+template <> struct ActIO<ms_f32wb> : ActIO<float> {};
+struct ms_bf16wb { uint16_t v; };
+template <> struct ActIO<ms_bf16wb> : ActIO<ms_bf16> {};
 
 // ms_f32x3: fp32 storage, fp32-FAITHFUL matrix arithmetic on the bf16 matrix cores: every operand of the contraction is split into three bf16 numbers
 // (hi + mid + lo = the fp32 value to 2^-24) and the six leading products hi*hi, mid*hi, hi*mid, lo*hi, hi*lo, mid*mid are accumulated in fp32 by
@@ -153,4 +160,29 @@ template <> struct ActIO<ms_f32x3> : ActIO<float> {};
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+
+// ---- LDS-DMA by hand ------------------------------------------------------------------------------------------------------------------------------------
+// buffer_load_dwordx4 ... lds (1 KB per wave-instruction: lane l's 16 bytes land at M0 + 16 l, no vector register).  Issued as INLINE ASSEMBLY, not through
+// __builtin_amdgcn_raw_ptr_buffer_load_lds: the compiler's wait-count pass treats every later LDS access of the wave as a possible reader of the builtin's
+// destination and puts `s_waitcnt vmcnt(0)` in front of the first ds_read / ds_write behind it (found in round 4: the mask prefetch of the Winograd kernel was waited for
+// at once - its ~1 us of HBM latency exposed once per work item - and in the staging waves the wait also covered the NEXT chunk's global loads: no prefetch at all).
+// The assembly is opaque to that pass; the code that reads the landing zone waits with its own counted `s_waitcnt vmcnt(N)` (loads return in order).
+// rsrc: {base lo, base hi (stride 0), num_records, flags}; lds_byte_addr: wave-uniform LDS byte address; voff: per-lane byte offset; soff: wave-uniform byte offset.
+typedef int ms_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ms_i32x4 ms_dma_rsrc(const void* base) {
+  const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+  ms_i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(p & 0xFFFFFFFFull));
+  r.y = __builtin_amdgcn_readfirstlane((int)((p >> 32) & 0xFFFFull));
+  r.z = 0x7FFFFFFF;
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void ms_lds_dma16(ms_i32x4 rsrc, unsigned lds_byte_addr, int voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ unsigned ms_lds_addr(const void* p) {      // byte address inside the workgroup's LDS allocation of a pointer into a __shared__ array
+  typedef __attribute__((address_space(3))) void* lds_p;
+  return (unsigned)(unsigned long long)(lds_p)(const_cast<void*>(p));      // generic -> LDS address space (the low 32 bits of a flat LDS address are its offset)
+}
 }  // namespace ms

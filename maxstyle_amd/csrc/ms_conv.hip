@@ -90,7 +90,8 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   const bool x3_ok = (fetch >= 0) && (fetch & MS_FETCH_X3) != 0;               // bit 9: ... the three-way bf16 split form
   const bool wino_nt1 = (fetch >= 0) && (fetch & MS_FETCH_WINO_NT1) != 0;      // bit 10: the one-channel-block variant of the Winograd form
   const bool wino_u = (fetch >= 0) && (fetch & MS_FETCH_WINO_U) != 0;          // bit 11: w_packed carries the Winograd appendix
-  if (fetch >= 0) fetch &= ~(MS_FETCH_WINOGRAD | MS_FETCH_X3 | MS_FETCH_WINO_NT1 | MS_FETCH_WINO_U);
+  const bool wino_blocks = (fetch >= 0) && (fetch & MS_FETCH_WINO_BLOCKS) != 0;     // bit 12: the block form wherever legal
+  if (fetch >= 0) fetch &= ~(MS_FETCH_WINOGRAD | MS_FETCH_X3 | MS_FETCH_WINO_NT1 | MS_FETCH_WINO_U | MS_FETCH_WINO_BLOCKS);
   if (pro_mode < 0 || pro_mode > 3 || epi_mode < 0 || (epi_mode > 2 && epi_mode != MS_EPI_POOL2) || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
   if (epi_mode == MS_EPI_POOL2 && (mk != nullptr || fin != nullptr || stats != nullptr || bias != nullptr)) { set_error("ms_conv2d: the pooled epilogue is a plain store (no bias, statistics or mask)"); return MS_ERR_INVALID; }
   // the activation helper computes max(v, v*slope): LeakyReLU / ReLU slopes only
@@ -146,6 +147,7 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   a.wino_ok = wino_ok ? 1 : 0;
   a.x3_ok = x3_ok ? 1 : 0;
   a.wino_nt1 = wino_nt1 ? 1 : 0;
+  a.wino_blocks = wino_blocks ? 1 : 0;
   a.wu = (wino_u && wino_ok && ks == 3 && stride == 1 && Cin % 8 == 0) ? w_packed + (size_t)9 * a.cin_pad * a.cout_pad : nullptr;
   a.act_bf16 = act_bf16;                  // 0 fp32 storage | 1 bf16 storage, fp32 matrix arithmetic | 2 bf16 storage, bf16 matrix arithmetic where built (`_bf16m`)
   a.pro_mode = pro_mode; a.pro_nstride = pro_nstride; a.pro_cstride = pro_cstride < 1 ? 1 : pro_cstride; a.slope = slope; a.epi_mode = epi_mode;
@@ -239,7 +241,7 @@ extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const fl
 }
 
 // ms_conv2d (a 1x1 conv) that also carries a ms_bn_bwd_coefs (ride_kind 0) or ms_bn_finalize (ride_kind 1) job for the launch BEHIND it: one MFMA wave per channel
-// derives out4[c] while the staging waves fetch (ConvArgs::ride_*).  The conv itself neither reads nor waits for out4; ride_C must not exceed the launch's workgroup count (checked).
+// derives out4[c] while the staging waves fetch (ConvArgs::ride_*).  The conv itself neither reads nor waits for out4; the channels are dealt round-robin over the launch's MFMA waves (any grid).
 // whether ms_conv2d(ks 3, stride 1, fetch MS_FETCH_WINOGRAD, epi_mode MS_EPI_POOL2) is built for this shape (16-byte aligned tensors assumed; bf16: 0 = fp32 entry point, 1 = `_bf16`, 2 = `_bf16m`)
 extern "C" int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16) {
   if (N < 1 || Cin < 1 || H < 2 || W < 4 || Cout < 1 || H % 2 != 0 || W % 4 != 0 || pro_mode < 0 || pro_mode > 2) return 0;
@@ -249,7 +251,7 @@ extern "C" int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int pr
   a.pro_mode = pro_mode; a.epi_mode = MS_EPI_POOL2; a.wino_ok = 1; a.act_bf16 = (bf16 < 0 || bf16 > 2) ? 2 : bf16;
   return (conv_wide_eligible(a, 3, 1, FETCH_NORMAL, true) && conv_wide_is_wino(a)) ? 1 : 0;
 }
-namespace ms { int conv_wino_blocks(const ConvArgs& a); }      // ms_conv_inst_wino.hip
+namespace ms { int conv_wino_blocks(const ConvArgs& a); bool conv_wino_blockform(const ConvArgs& a); }      // ms_conv_inst_wino.hip
 namespace ms {
 // one thread per (input channel, output channel) pair: U = G g G^T with EXACTLY the expression of the staging waves (conv_wide_kernel store_chunk), so the kernel that
 // copies U from here computes the same bits as the one that transforms the taps itself
@@ -297,20 +299,21 @@ extern "C" int ms_conv2d_form(int N, int Cin, int H, int W, int Cout, int pro_mo
   a.N = N; a.Cin = Cin; a.Hs = a.Hin = a.Hout = H; a.Ws = a.Win = a.Wout = W; a.Cout = a.cout_real = Cout;
   a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (Cout + 63) / 64 * 64;
   a.pro_mode = pro_mode; a.wino_ok = (fetch & MS_FETCH_WINOGRAD) ? 1 : 0; a.x3_ok = (fetch & MS_FETCH_X3) ? 1 : 0; a.wino_nt1 = (fetch & MS_FETCH_WINO_NT1) ? 1 : 0;
+  a.wino_blocks = (fetch & MS_FETCH_WINO_BLOCKS) ? 1 : 0;
   a.act_bf16 = (bf16 < 0 || bf16 > 2) ? 2 : bf16;
   static const float appendix_marker = 0.f;             // (only compared with null by the dispatch rules)
   a.wu = ((fetch & MS_FETCH_WINO_U) && a.wino_ok && Cin % 8 == 0) ? &appendix_marker : nullptr;
   if (!conv_wide_eligible(a, 3, 1, FETCH_NORMAL, W % 4 == 0)) return 0;
   if (!conv_wide_is_wino(a)) return 1;
-  return 1 + conv_wino_blocks(a);
+  return 1 + conv_wino_blocks(a) + (conv_wino_blockform(a) ? 2 : 0);
 }
-// channels a rider may have on a conv launch with this output shape: 4 x a LOWER bound of its workgroup count.  The launcher's grid is
-// min(items, CUs * per_cu) rounded DOWN to a multiple of the channel-block count ncb (launch_conv_t), with items >= tiles, per_cu >= 1 and ncb <= 32 (512 output
-// channels in 16-channel blocks), so min(tiles, CUs) - 31 workgroups always exist whatever tile width the dispatch picks (the bound used to ignore ncb).
+// Channels a rider should have at most on a conv launch with this output shape so that every MFMA wave takes ONE channel: 4 x (an estimate of) the workgroup count.
+// A speed hint for the caller's choice between a rider and a launch of its own - the kernel deals the channels round-robin over whatever grid it gets, so a launch
+// whose grid turns out smaller (channel-block rounding, one workgroup per CU) still carries the whole job (this used to be a hard bound that ignored both).
 extern "C" int ms_conv_ride_capacity(int N, int Hout, int Wout) {
   if (N < 1 || Hout < 1 || Wout < 1) return 0;
   const long tiles = (long)N * cdiv(Wout, tile_w(Wout)) * cdiv(Hout, tile_h(Wout));
-  return (int)(4 * std::max<long>(0, std::min<long>(tiles, (long)num_cus()) - 31));
+  return (int)(4 * std::min<long>(tiles, (long)num_cus()));
 }
 extern "C" int ms_conv2d_ride(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                               int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,

@@ -75,6 +75,7 @@ struct ConvArgs {
   int wino_ok;                  // the caller accepts the Winograd form of a 3x3 stride-1 convolution for this call (MS_FETCH_WINOGRAD)
   int x3_ok;                    // ... the three-way bf16 split form (MS_FETCH_X3)
   int wino_nt1;                 // Winograd form: one channel block per staged tile (MS_FETCH_WINO_NT1)
+  int wino_blocks;              // Winograd form: force the block form (MS_FETCH_WINO_BLOCKS)
   const float* wu;              // Winograd appendix of the packed weights (MS_FETCH_WINO_U): transformed weights [cb16][chunk][16][8][16], or null
   int act_bf16;                 // activation tensors (in, in2, out, mk_u) are stored as bf16 (the `_bf16` entry points); statistics / coefficients / weights fp32
   int dbg;                      // timing-only ablation bits (MS_CONV_DBG): 1 skip MFMA loop, 2 skip global loads, 4 skip epilogue stores, 8 skip LDS stores, 16 skip the epilogue
@@ -762,7 +763,10 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   }
 
   // =========================================== CONSUMER waves ===========================================
-  if (a.ride_out != nullptr && (int)blockIdx.x * 4 + wave < a.ride_C) conv_ride(a, (int)blockIdx.x * 4 + wave, lane);      // (hardware index: the first workgroups dispatched)
+  // (hardware index: the first workgroups dispatched.  The channels are dealt round-robin over the launch's MFMA waves, so ANY grid carries the whole job - with
+  //  fewer than ride_C / 4 workgroups a wave takes more than one channel: ms_conv_ride_capacity is a speed hint, no longer a correctness bound)
+  if (a.ride_out != nullptr)
+    for (int c = (int)blockIdx.x * 4 + wave; c < a.ride_C; c += 4 * (int)gridDim.x) conv_ride(a, c, lane);
   if (a.bw_parts > 0) {
     // pro_mode 3: what ms_bn_bwd_coefs would have computed in its own launch (a ~5 us kernel + launch gap, 29 times per inner step): every
     // workgroup reduces the (sum g, sum g*u) partials of ms_act_bwd_reduce itself - <= 32 KB of L2-resident reads, 32 lanes per channel,
@@ -1192,7 +1196,6 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st) {
   per_cu = std::max(1, std::min(per_cu, conv_resident_per_cu((const void*)conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2, AT>, lds_bytes)));
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;      // every workgroup keeps one channel block: item % ncb == blockIdx % ncb
-  if (a.ride_out != nullptr && a.ride_C > 4 * nblocks) { set_error("ms_conv2d_ride: %d rider channels, %ld workgroups", a.ride_C, nblocks); return MS_ERR_INVALID; }
   dim3 grid((unsigned)nblocks), block(512);
   MS_LAUNCH((conv_mfma_kernel<KS, STRIDE, FETCH, NT, VEC, NARROW, IN2, AT>), grid, block, lds_bytes, st, a);
   return check_launch("conv_mfma");

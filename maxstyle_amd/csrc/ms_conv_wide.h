@@ -108,6 +108,23 @@ struct WideGeoW {
   static_assert(W_ITEMS <= 256, "one (input channel, output channel) pair per staging thread");
 };
 
+// Block form of the Winograd mode (AT = ms_f32wb / ms_bf16wb): staging wave s stages patch s = block s of the work item (10 rows x 10 columns per channel, own halo),
+// MFMA wave w multiplies block w: lane m = tile (m >> 2, m & 3) of the block's 4 x 4 tiles, so after the MFMAs a lane holds tile ROW k (2 output rows x 8 pixels) of
+// channel m - the epilogue's 2 x 8 pixels per lane, unchanged.  Patch rows are 12 dwords, patches 120, the channel plane 480 == 32 (mod 64): the 8-byte patch reads of a
+// 32-lane group (two K lane groups x 16 tiles) fall on 64 distinct banks.
+template <int NT_, int PRO>
+struct WideGeoWB {
+  static constexpr int TW = 8, TH = 8, CK = 8, IH = TH + 2;
+  static constexpr int RS = 12, PP = IH * RS, PS = 480;
+  static_assert(4 * PP <= PS, "plane stride");
+  static constexpr int WS = 16;
+  static constexpr int UP = CK * 16 * NT_;
+  static constexpr int BUF = CK * PS + 16 * UP;
+  static constexpr int Q_ITEMS = CK * IH * (TW / 4), H_ITEMS = CK * IH * 2;      // per PATCH: one staging wave (64 lanes) stages one patch
+  static constexpr int NQI = (Q_ITEMS + 63) / 64, NHI = (H_ITEMS + 63) / 64;
+  static constexpr int W_ITEMS = CK * 16 * NT_, NWI = 1;
+};
+
 // census of workgroup arrivals per CU (stagger experiment): which of the two co-resident workgroups am I?  Timing only - never read for results.
 static __device__ int g_cu_census[1024];
 
@@ -120,12 +137,13 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   constexpr bool X3 = std::is_same<AT, ms_f32x3>::value;          // fp32 storage, three-way bf16 split on the bf16 matrix cores (needs R == 1, NT == 1, every chunk full)
   constexpr bool BFL = BFM || X3;                                 // the bf16 LDS layout (8-byte channel-quad entries)
   static_assert(!X3 || (R == 1 && NT == 1 && AF), "three-way split mode: 4-row tiles, one channel block per lane, channel count a multiple of the chunk");
-  constexpr bool WIN = std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value ||       // Winograd F(2x2, 3x3) (needs R == 1, NT == 1, every chunk full)
+  constexpr bool WB = std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value;        // Winograd form on independent 8x8-pixel blocks (WideGeoWB)
+  constexpr bool WIN = std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value || WB ||       // Winograd F(2x2, 3x3) (needs R == 1, NT <= 2, every chunk full)
                        std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value;      // ... on bf16 storage
   constexpr int WTW = (std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w32>::value) ? 32 : 64;
   constexpr int WHALVES = WTW / 32;                               // 32-pixel halves of a tile row = waves per tile row
   static_assert(!WIN || (R == 1 && NT <= 2 && AF), "Winograd mode: 4-row tiles, one or two channel blocks per lane, channel count a multiple of the chunk");
-  using G = typename std::conditional<X3, WideGeoX3<(X3 ? NT : 1), PRO>, typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WIN, WideGeoW<(WIN ? NT : 1), PRO, WTW>, WideGeo<NT, PRO, R>>::type>::type>::type;
+  using G = typename std::conditional<X3, WideGeoX3<(X3 ? NT : 1), PRO>, typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WB, WideGeoWB<(WB ? NT : 1), PRO>, typename std::conditional<WIN, WideGeoW<(WIN ? NT : 1), PRO, WTW>, WideGeo<NT, PRO, R>>::type>::type>::type>::type;
   using IO = ActIO<AT>;
   constexpr int AB = IO::kBytes;
   static_assert(!BFM || R == 1, "bf16 MFMA mode: 4-row tiles");
@@ -135,8 +153,17 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   const int wave = __builtin_amdgcn_readfirstlane((int)(MS_TID >> 6)), lane = MS_TID & 63;      // wave-uniform by construction: keep it in a scalar register
   const bool producer = wave >= 4;
   const int ntiles = a.tiles_x * a.tiles_y, ncb = a.ncb;
-  const int nitems = a.N * ntiles * ncb;
+  const int nitems = (WB ? 1 : a.N) * ntiles * ncb;          // (block form: a "tile" is a group of four blocks of the flattened (image, block row, block column) list)
   const int nchunks = (a.cin_pad + CK - 1) / CK;
+  // block form: block b of the flattened list -> (image, first row, first column); b beyond the list -> an empty block (rows beyond the image: nothing loaded or stored)
+  const int wb_bx = (a.Wout + 7) >> 3, wb_by = (a.Hout + 7) >> 3, wb_total = a.N * wb_bx * wb_by;
+  auto wb_decode = [&](int b, int& bn, int& y0, int& x0) {
+    if (b >= wb_total) { bn = 0; y0 = a.Hout; x0 = 0; return false; }
+    const int per = wb_bx * wb_by;
+    bn = b / per; const int r = b - bn * per; const int byi = r / wb_bx;
+    y0 = byi * 8; x0 = (r - byi * wb_bx) * 8;
+    return true;
+  };
   const int vb = ((int)gridDim.x % 8 == 0) ? (((int)blockIdx.x % 8) * ((int)gridDim.x / 8) + (int)blockIdx.x / 8) : (int)blockIdx.x;
   const int my_items = (nitems - vb + (int)gridDim.x - 1) / (int)gridDim.x;
   const int T = my_items * nchunks;
@@ -187,6 +214,11 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #endif
     __builtin_amdgcn_s_setprio(MS_WIDE_STAGE_PRIO);
     const int tid = MS_TID - 256;
+    const int sw_ = __builtin_amdgcn_readfirstlane(tid >> 6);      // staging wave 0..3 (block form: = the patch it stages)
+    const int itid = WB ? (tid & 63) : tid;        // item numbering: per workgroup (256 staging threads), or per patch (64 lanes) in the block form
+    constexpr int ISTR = WB ? 64 : 256;
+    const int patch_off = WB ? sw_ * (IH * RS) : 0;
+    int pb_n = 0;                                  // block form: the image of this wave's patch
     const int plane = a.Hs * a.Ws;                 // host checks Cin*plane < 2^31
     typedef unsigned mask_t;
     // every global address of the staging is (wave-uniform base of the chunk, biased back by one row + 4 so that no offset is negative) + a 32-bit BYTE offset
@@ -200,13 +232,13 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     mask_t q_all = 0, h_all = 0;
 #pragma unroll
     for (int j = 0; j < NQI; ++j) {
-      const int it = tid + j * 256;
+      const int it = itid + j * ISTR;
       q_lds[j] = -1; q_rc[j] = 0; q_off[j] = (unsigned)AB * (unsigned)bias; q_cf[j] = 0;
       if (it < G::Q_ITEMS) {
         const int f = it % (TW / 4), row = it / (TW / 4);
         const int r = row % IH, c = row / IH;
         if constexpr (BFL) q_lds[j] = (c << 20) | ((((c >> 2) * IH + r) * G::RSB + 4 * f + 1) * 8 + (c & 3) * 2);      // BYTE address of the entry's channel slot (X3: in the `hi` planes)
-        else q_lds[j] = (c << 20) | (c * PS + r * RS + 4 * f + 1);
+        else q_lds[j] = (c << 20) | (c * PS + patch_off + r * RS + 4 * f + 1);
         q_rc[j] = (r << 16) | (4 * f + 16);
         q_off[j] = (unsigned)AB * (unsigned)(c * plane + (r - 1) * a.Ws + 4 * f + bias);
         q_cf[j] = c;
@@ -215,14 +247,14 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     }
 #pragma unroll
     for (int j = 0; j < NHI; ++j) {
-      const int it = tid + j * 256;
+      const int it = itid + j * ISTR;
       h_lds[j] = -1; h_rc[j] = 0; h_off[j] = (unsigned)AB * (unsigned)bias; h_cf[j] = 0;
       if (it < G::H_ITEMS) {
         const int h = it & 1, row = it >> 1;
         const int r = row % IH, c = row / IH;
         const int col_rel = h ? TW : -1;
         if constexpr (BFL) h_lds[j] = (c << 20) | ((((c >> 2) * IH + r) * G::RSB + col_rel + 1) * 8 + (c & 3) * 2);
-        else h_lds[j] = (c << 20) | (c * PS + r * RS + col_rel + 1);
+        else h_lds[j] = (c << 20) | (c * PS + patch_off + r * RS + col_rel + 1);
         h_rc[j] = (r << 16) | (col_rel + 16);
         h_off[j] = (unsigned)AB * (unsigned)(c * plane + (r - 1) * a.Ws + col_rel + bias);
         h_cf[j] = c;
@@ -233,13 +265,15 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     bool edge = false;
     int t_base = 0;
     auto set_tile = [&](int tile) {
-      const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-      const int y0 = ty * TH, x0 = tx * TW;
-      t_base = y0 * a.Ws + x0;
+      int y0, x0;
+      bool live = true;
+      if constexpr (WB) { live = wb_decode(tile * 4 + sw_, pb_n, y0, x0); }
+      else { const int tx = tile % a.tiles_x, ty = tile / a.tiles_x; y0 = ty * TH; x0 = tx * TW; }
+      t_base = live ? y0 * a.Ws + x0 : 0;              // (an empty block: every item masked, loads at the first pixel of image 0)
       const int ylo = 1 - y0, yhi = a.Hin - y0 + 1;               // ylo <= r < yhi
       const int xlo = 16 - x0, xhi = a.Win - x0 + 16;             // xlo <= (col_rel + 16) < xhi
       auto inside = [&](int rc) { const int r = rc >> 16, c = rc & 0xFFFF; return (r >= ylo) && (r < yhi) && (c >= xlo) && (c < xhi); };
-      edge = (ylo > 0) || (yhi < IH) || (x0 + TW > a.Win);
+      edge = (ylo > 0) || (yhi < IH) || (x0 + TW > a.Win) || !live;
       if (edge) {
         q_ok = 0;
 #pragma unroll
@@ -252,6 +286,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #pragma unroll
       for (int j = 0; j < NHI; ++j) h_ok |= (inside(h_rc[j]) ? 1u : 0u) << j;
       h_ok &= h_all;
+      if (!live) { q_ok = 0; h_ok = 0; }
     };
     float rq[BFM ? 1 : NQI][4], rq2[(PRO == 2 && !BFM) ? NQI : 1][4], rh[NHI], rh2[PRO == 2 ? NHI : 1];
     unsigned rqp[BFM ? NQI : 1][2], rqp2[(BFM && PRO == 2) ? NQI : 1][2];      // bf16-MFMA mode (16-channel chunks): the quads stay PACKED in registers until the LDS store
@@ -323,6 +358,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     auto load_chunk = [&](int n, int co0, int c0, bool load_w, bool coefs = true) {
       // buffer addressing: resource base = image n, biased back (scalar arithmetic); soffset = chunk + tile origin (scalar); voffset = the hoisted item offset:
       // `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen` - no vector address arithmetic per chunk (the host checks Cin*plane*4 < 2^31)
+      if constexpr (WB) n = pb_n;                                                             // (block form: this wave's patch has its own image)
       const ptrdiff_t img_off = ((ptrdiff_t)n * a.Cin * plane - bias) * AB;                  // bytes
       char* img = const_cast<char*>(reinterpret_cast<const char*>(a.in)) + img_off;
       const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(img, 0, 0x7FFFFFFF, 0x00020000);
@@ -377,7 +413,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       float* w_lds = buf + CK * PS;
 #pragma unroll
       for (int j = 0; j < NQI; ++j) {
-        const bool full = (j + 1) * 256 <= G::Q_ITEMS;
+        const bool full = (j + 1) * ISTR <= G::Q_ITEMS;
         if (!full && q_lds[j] < 0) continue;
         float v[4];
 #pragma unroll
@@ -508,7 +544,6 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     // (buffer_load_dwordx4 ... lds: 1 KB per wave-instruction, no vector register, no vector arithmetic) - 2 * NT instructions per staging wave instead of nine tap loads,
     // ~37 vector instructions and 16 LDS stores per thread.  Issued FIRST in the iteration that stores the chunk (the consumers left this buffer at the previous
     // barrier), covered by a counted vmcnt in front of this iteration's barrier: the next chunk's data loads, issued later, stay in flight.
-    typedef __attribute__((address_space(3))) void* plds_t;
     int wu_voff = 0;
     if constexpr (WIN) {
       const int pl = tid & 63;
@@ -518,29 +553,30 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     }
     auto dma_u = [&](float* buf, int cbi, int chunk_i) __attribute__((always_inline)) {
       if constexpr (WIN) {
-        const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wu), 0, 0x7FFFFFFF, 0x00020000);
+        const ms_i32x4 ru = ms_dma_rsrc(a.wu);
         const int sw = __builtin_amdgcn_readfirstlane(tid >> 6);
-        float* dst = buf + CK * PS;
+        const unsigned dst = ms_lds_addr(buf + CK * PS);
 #pragma unroll
         for (int q = 0; q < 2 * NT; ++q) {
           const int piece = q * 4 + sw;                 // 256 floats of the weight region each
           const int so = (NT == 2) ? 4 * ((cbi * 2 * nchunks + chunk_i) * 2048 + piece * 128) : 4 * ((cbi * nchunks + chunk_i) * 2048 + piece * 256);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (plds_t)(dst + piece * 256), 16, wu_voff, so, 0, 0);
+          ms_lds_dma16(ru, dst + 1024u * (unsigned)piece, wu_voff, __builtin_amdgcn_readfirstlane(so));
         }
       }
     };
     constexpr int kDataLoads = (PRO == 2 ? 2 : 1) * (NQI + NHI);      // vector-memory loads load_chunk issues for one chunk's activations
     for (int p = 0; p < T; ++p) {
       if (tr && p < 16) a.trace[128 + p * 4 + 0] = clock64();
-      bool dma_now = false;
-      if constexpr (WIN) {
-        if (a.wu != nullptr && have_w) { dma_u(smem + (p & 1) * BUF, cb, chunk); dma_now = true; }
-      }
+      const bool dma_now = WIN && (a.wu != nullptr) && have_w;      // (have_w / cb / chunk describe chunk p here: they move on below)
+      const int dma_cb = cb, dma_chunk = chunk;
       if (!(a.dbg & 8)) {
         if (l_edge) store_chunk(smem + (p & 1) * BUF, std::true_type{}); else store_chunk(smem + (p & 1) * BUF, std::false_type{});
       }
       if (tr && p < 16) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); a.trace[128 + p * 4 + 1] = clock64(); }
       key_cb[p & 1] = cb; key_c0[p & 1] = chunk * CK;
+      // the weights of chunk p by LDS-DMA: behind this iteration's LDS stores (the consumers left the buffer at the previous barrier), in front of the next chunk's
+      // data loads - so the compiler's own counted waits for THOSE never include a DMA piece, and the counted wait below leaves them in flight
+      if constexpr (WIN) { if (dma_now) dma_u(smem + (p & 1) * BUF, dma_cb, dma_chunk); }
       if (p + 1 < T) {
         if (++chunk == nchunks) { chunk = 0; item += gridDim.x; decode(item, n, tile, cb); }
         if (tile != tile_set) { set_tile(tile); tile_set = tile; }
@@ -679,7 +715,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     constexpr bool FIRST = decltype(first_tag)::value;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (WIN) {
-      const float* ab = buf + k * PS + (2 * (wave / WHALVES)) * RS + 32 * (wave % WHALVES) + 2 * m;
+      const float* ab = WB ? buf + k * PS + wave * (IH * RS) + (2 * (m >> 2)) * RS + 2 * (m & 3)
+                           : buf + k * PS + (2 * (wave / WHALVES)) * RS + 32 * (wave % WHALVES) + 2 * m;
       const float* ub = buf + CK * PS + lane;
 #pragma unroll
       for (int cg = 0; cg < CK / 4; ++cg) {
@@ -751,7 +788,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   int w2_p = 0;                                        // (cycle stamps only) running chunk number
   w2f2 w2d[4][2];
   float w2u[4][WNT][4], w2va[4], w2vb[4];
-  const int w2_aoff = k * PS + (2 * (wave / WHALVES)) * RS + 32 * (wave % WHALVES) + 2 * m;
+  const int w2_aoff = WB ? k * PS + wave * (IH * RS) + (2 * (m >> 2)) * RS + 2 * (m & 3) : k * PS + (2 * (wave / WHALVES)) * RS + 32 * (wave % WHALVES) + 2 * m;
   auto w2_ldrow = [&](const float* pa, int r) __attribute__((always_inline)) {
     w2d[r][0] = *reinterpret_cast<const w2f2*>(pa + r * RS);
     w2d[r][1] = *reinterpret_cast<const w2f2*>(pa + r * RS + 2);
@@ -1036,16 +1073,24 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 
   // ---- Winograd mode: output transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) in registers - a lane holds all 16 positions of its 4 tiles (4k..4k+3 of the
   // wave's 16) for channel m - then the epilogue on 2 rows x 8 consecutive pixels (x = 32h + 8k ..) per lane.  upre[0][2*row + quad] = the mask tensor's values.
-  auto wino_geo = [&](int tile, int& xb, int& y0) { const int tx = tile % a.tiles_x, ty = tile / a.tiles_x; xb = tx * TW + 32 * (wave % WHALVES) + 8 * k; y0 = ty * TH + 2 * (wave / WHALVES); };
+  // block form: the MFMA wave's block of the current item (image, first row, first column; an empty block sits below the image: every row invalid) - set per item
+  int wb_n = 0, wb_y0 = 0, wb_x0 = 0;
+  bool wb_live = true;
+  auto wb_set = [&](int tile) { if constexpr (WB) wb_live = wb_decode(tile * 4 + wave, wb_n, wb_y0, wb_x0); };
+  auto wino_geo = [&](int tile, int& xb, int& y0) {
+    if constexpr (WB) { xb = wb_x0; y0 = wb_y0 + 2 * k; }
+    else { const int tx = tile % a.tiles_x, ty = tile / a.tiles_x; xb = tx * TW + 32 * (wave % WHALVES) + 8 * k; y0 = ty * TH + 2 * (wave / WHALVES); }
+  };
   // interior tiles: buffer addressing as in epilogue_fast below - resource = image n, scalar offset = (channel block, row, first column of the wave's half),
   // vector offset = the lane's hoisted (channel m, pixel group k) offset; stores carry the row offset in the vector offset (see bstore4)
   const int w_plane = a.Hout * a.Wout;
-  const int w_voff = AB * (m * w_plane + 8 * k);
+  const int w_voff = WB ? AB * (m * w_plane + 2 * k * a.Wout) : AB * (m * w_plane + 8 * k);
   typedef unsigned wu32x4_t __attribute__((ext_vector_type(4)));
   auto w_rsrc = [&](const float* base, int n) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + (ptrdiff_t)n * a.Cout * w_plane * AB, 0, 0x7FFFFFFF, 0x00020000);
   };
   auto w_soff = [&](int tile, int co0, int row) {
+    if constexpr (WB) return AB * ((co0 * a.Hout + wb_y0 + row) * a.Wout + wb_x0);
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     return AB * ((co0 * a.Hout + ty * TH + 2 * (wave / WHALVES) + row) * a.Wout + tx * TW + 32 * (wave % WHALVES));
   };
@@ -1073,27 +1118,29 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   // requested at the start of the item STRAIGHT INTO LDS (buffer_load_dwordx4 ... lds: lane l's 16 bytes land at base + 16 l, no vector register involved)
   // and read back by the epilogue: 4 KB per MFMA wave behind the coefficient table.
   float* u_lds = smem + 2 * BUF + (PRO != 0 ? 4 * (nchunks * CK) : 0) + wave * (1024 * WNT);      // (+ 1024 floats per channel block j)
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
   auto wino_interior = [&](int tile, int co0) {
+    if constexpr (WB) return wb_live && (wb_x0 + 8 <= a.Wout) && (wb_y0 + 8 <= a.Hout) && (co0 + 16 <= a.Cout) && !(a.dbg & 32);
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     return (tx * TW + TW <= a.Wout) && (ty * TH + TH <= a.Hout) && (co0 + 16 <= a.Cout) && !(a.dbg & 32);
   };
   auto prefetch_u_w = [&](int n, int tile, int cob) __attribute__((always_inline)) {
     if constexpr (WIN) {
-      const __amdgpu_buffer_rsrc_t ru = w_rsrc(a.mk_u, n);
+      // (LDS-DMA as inline assembly - ms_lds_dma16, ms_common.h: behind the compiler's builtin every later LDS access waited for vmcnt(0), i.e. for these loads)
+      const ms_i32x4 ru = ms_dma_rsrc(reinterpret_cast<const char*>(a.mk_u) + (ptrdiff_t)n * a.Cout * w_plane * AB);
+      const unsigned ul = ms_lds_addr(u_lds);
 #pragma unroll
       for (int j = 0; j < WNT; ++j) {
         const int co0 = cob + 16 * j;
         if (!wino_interior(tile, co0)) continue;        // border tiles load their (masked) values inside the epilogue
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
-          const int so = w_soff(tile, co0, row);
+          const int so = __builtin_amdgcn_readfirstlane(w_soff(tile, co0, row));
           if constexpr (AB == 4) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(u_lds + j * 1024 + (2 * row + q) * 256), 16, w_voff + 16 * q, so, 0, 0);
+              ms_lds_dma16(ru, ul + 4u * (unsigned)(j * 1024 + (2 * row + q) * 256), w_voff + 16 * q, so);
           } else {                                     // bf16 storage: the lane's 8 pixels of a row are ONE 16-byte transfer
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(u_lds + j * 1024 + row * 256), 16, w_voff, so, 0, 0);
+            ms_lds_dma16(ru, ul + 4u * (unsigned)(j * 1024 + row * 256), w_voff, so);
           }
         }
       }
@@ -1397,6 +1444,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 
   int item = vb, n, tile, cb;
   decode(item, n, tile, cb);
+  if constexpr (WB) { wb_set(tile); n = wb_n; }         // (block form: this wave's own block and image)
   load_bias(cb * COUT_TILE);
   if constexpr (PRO != 0) {
     if (xf_pro) {
@@ -1454,8 +1502,12 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         if constexpr (WIN) { prefetch_u_w(n, tile, co0); return; }
         else prefetch_u(n, tile, co0);
       };
-      if ((UPRE || WIN) && a.epi_mode == 3) pre_u();   // at the START of the item: the registers are reserved anyway, and in a step the mask tensor is cold
+      // direct form: at the START of the item (the registers are reserved anyway, and in a step the mask tensor is cold).  Winograd form (LDS-DMA): BEHIND the first
+      // chunk - the accumulator set-up of an item waits for vmcnt(0) (the previous item's stores still hold their data registers), and a prefetch issued in front of
+      // that wait is simply waited for: its HBM latency was exposed once per item until round 4 (found in the ISA; the remaining chunks now cover it)
+      if (UPRE && !WIN && a.epi_mode == 3) pre_u();
       mfma_chunk(0, std::true_type{});
+      if (WIN && a.epi_mode == 3) pre_u();
       for (int ch = 1; ch < nchunks; ++ch) {
         if constexpr (!W2) lds_barrier();              // (two-block Winograd form: the chunk barrier sits inside the previous chunk - w2_cg)
         if (!W2 && tr && p < 16) a.trace[p * 4 + 3] = clock64();
@@ -1482,6 +1534,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       item += gridDim.x;
       if (it + 1 < my_items) {
         decode(item, n, tile, cb); load_bias(cb * COUT_TILE);
+        if constexpr (WB) { wb_set(tile); n = wb_n; }
         if constexpr (!W2) lds_barrier();
         if (!W2 && tr && p < 16) a.trace[p * 4 + 3] = clock64();
       }
@@ -1500,15 +1553,19 @@ int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
   using G = typename std::conditional<std::is_same<AT, ms_f32x3>::value, WideGeoX3<(std::is_same<AT, ms_f32x3>::value ? NT : 1), PRO>, typename std::conditional<std::is_same<AT, ms_bf16m>::value, WideGeoBF<NT, PRO>,
                                       typename std::conditional<std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_bf16w>::value, WideGeoW<(NT <= 2 ? NT : 1), PRO, 64>,
                                       typename std::conditional<std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w32>::value, WideGeoW<(NT <= 2 ? NT : 1), PRO, 32>,
-                                                                WideGeo<NT, PRO, R>>::type>::type>::type>::type;
+                                      typename std::conditional<std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value, WideGeoWB<(NT <= 2 ? NT : 1), PRO>,
+                                                                WideGeo<NT, PRO, R>>::type>::type>::type>::type>::type;
   const size_t cin_tab = (PRO != 0) ? (size_t)cdiv(a.cin_pad, G::CK) * G::CK : 0;              // coefficient table: one float4 per input channel of the padded chunks
-  const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab) + ((std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value) ? NT * 16 * 1024 : 0);      // Winograd mode: + the mask tensor's landing zone (4 KB per MFMA wave and channel block)
+  const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab) + ((std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value ||
+                                                                                      std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value) ? NT * 16 * 1024 : 0);      // Winograd mode: + the mask tensor's landing zone (4 KB per MFMA wave and channel block)
   if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
   static std::once_flag attr_once;                     // one flag per instantiation; the attribute itself is immutable afterwards
   std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO, R, AF, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
+  constexpr bool kWB = std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value;
   a.tiles_x = cdiv(a.Wout, G::TW); a.tiles_y = cdiv(a.Hout, G::TH);
+  if (kWB) { a.tiles_x = cdiv(a.N * a.tiles_x * a.tiles_y, 4); a.tiles_y = 1; }      // block form: groups of four blocks of the flattened (image, block row, block column) list
   a.ncb = cdiv(a.Cout, 16 * NT);
-  const long nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb;
+  const long nitems = (long)(kWB ? 1 : a.N) * a.tiles_x * a.tiles_y * a.ncb;
   static const int cu_cap = getenv("MS_WIDE_PER_CU") ? atoi(getenv("MS_WIDE_PER_CU")) : 2;      // A/B switch: workgroups per CU of the persistent grid
   int per_cu = std::max(1, std::min(NT == 1 ? cu_cap : 2, (int)((160 * 1024) / (lds_bytes + 256))));
   per_cu = std::max(1, std::min(per_cu, conv_resident_per_cu((const void*)conv_wide_kernel<NT, PRO, R, AF, AT>, lds_bytes)));      // (co-residency of the whole grid: ms_conv_kernel.h)

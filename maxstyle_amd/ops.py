@@ -162,6 +162,7 @@ def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8, step_dev=None):
 FETCH_NORMAL, FETCH_UPS2, FETCH_ZINS2 = 0, 1, 2
 FETCH_X3 = 0x200            # MS_FETCH_X3: the caller accepts the three-way bf16 split form (fp32-faithful, bf16 matrix cores)
 EPI_POOL2 = 6                # ms_conv2d epi_mode: 2x2-pooled store (MS_EPI_POOL2)
+FETCH_WINO_BLOCKS = 0x1000  # MS_FETCH_WINO_BLOCKS: the block form of the Winograd kernel wherever legal (test / A-B switch)
 FETCH_WINO_U = 0x800        # MS_FETCH_WINO_U: the packed weights carry the Winograd appendix (with_wino_appendix below)
 FETCH_WINO_NT1 = 0x400      # MS_FETCH_WINO_NT1: with FETCH_WINOGRAD, the one-channel-block variant (A/B and test switch; same bits per output element)
 FETCH_WINOGRAD = 0x100      # MS_FETCH_WINOGRAD: OR into fetch = the caller accepts the Winograd form of a 3x3 stride-1 convolution (include/maxstyle_hip.h)

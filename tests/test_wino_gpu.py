@@ -120,6 +120,51 @@ def test_two_channel_blocks_per_staged_tile_same_bits(dev, N, Cin, Cout, H, W, b
         assert torch.equal(ops.conv2d(x, wp, None, Cout, 3, 1, fetch=WG, epi_mode=ops.EPI_POOL2), ops.conv2d(x, wp, None, Cout, 3, 1, fetch=N1, epi_mode=ops.EPI_POOL2))
 
 
+BLOCK_SHAPES = [(2, 64, 64, 40, 40), (16, 64, 32, 20, 20), (3, 32, 48, 80, 80), (2, 16, 16, 64, 64), (1, 32, 48, 20, 192), (2, 128, 64, 20, 40), (1, 16, 48, 11, 28),
+                (1, 8, 33, 10, 100), (2, 16, 16, 6, 72), (1, 24, 16, 7, 68), (5, 16, 16, 24, 24), (1, 64, 64, 24, 36)]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", BLOCK_SHAPES)
+@pytest.mark.parametrize("bf16", [False, True])
+def test_block_form_same_bits_as_the_tiled_form(dev, N, Cin, Cout, H, W, bf16):
+    """Round 4: the BLOCK form of the Winograd kernel (MS_FETCH_WINO_BLOCKS: four independent 8x8-pixel blocks per work item, each staged with its own halo, taken by
+    the dispatch where 64x4 / 32x8 tiles would be mostly padding - rows of 80, 40, 20 pixels) against the tiled one-block kernel (MS_FETCH_WINO_NT1): per output element
+    the same accumulation order, so every stored tensor is bit-identical - all prologues and epilogues, image sizes that are not multiples of the block (partial blocks,
+    odd heights), block lists that do not fill the last group of four, several images per group, channel tails, both storage types; BatchNorm tables agree to rounding."""
+    from maxstyle_amd import ops
+    BL, N1 = ops.FETCH_WINOGRAD | ops.FETCH_WINO_BLOCKS, ops.FETCH_WINOGRAD | ops.FETCH_WINO_NT1
+    assert ops.lib.ms_conv2d_form(N, Cin, H, W, Cout, 0, int(bf16), BL) in (4, 5) and ops.lib.ms_conv2d_form(N, Cin, H, W, Cout, 0, int(bf16), N1) == 2
+    dt = torch.bfloat16 if bf16 else torch.float32
+    x = _rand((N, Cin, H, W), 1).to(dev).to(dt); x2 = _rand((N, Cin, H, W), 2).to(dev).to(dt); w = _rand((Cout, Cin, 3, 3), 3, 0.1); b = _rand((Cout,), 4).to(dev)
+    cfd = _rand((Cin, 4), 5).to(dev)
+    wp = ops.pack_conv_weight(w.to(dev))
+    pa, pb, pc = ops.coef_ptrs(cfd)[:3]
+    s2, parts = ops.conv_stats_buffer(N, Cout, H, W, dev); s1, _ = ops.conv_stats_buffer(N, Cout, H, W, dev)
+    o2 = ops.conv2d(x, wp, b, Cout, 3, 1, fetch=BL, stats=s2); o1 = ops.conv2d(x, wp, b, Cout, 3, 1, fetch=N1, stats=s1)
+    assert torch.equal(o1, o2)
+    one, zero = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+    c2, c1 = ops.bn_finalize(s2, parts, one, zero), ops.bn_finalize(s1, parts, one, zero)
+    assert float((c2 - c1).abs().max()) < 2e-6 * float(c1.abs().max())
+    kw = dict(pro_mode=1, pro_a=pa, pro_b=pb, pro_cstride=4, slope=0.2)
+    assert torch.equal(ops.conv2d(x, wp, None, Cout, 3, 1, fetch=BL, **kw), ops.conv2d(x, wp, None, Cout, 3, 1, fetch=N1, **kw))
+    base = _rand((N, Cout, H, W), 6).to(dev).to(dt)
+    kw = dict(pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=x2, epi_mode=1)
+    assert torch.equal(ops.conv2d(x, wp, None, Cout, 3, 1, fetch=BL, out=base.clone(), **kw), ops.conv2d(x, wp, None, Cout, 3, 1, fetch=N1, out=base.clone(), **kw))
+    u = (_rand((N, Cout, H, W), 24) + 0.3).to(dev).to(dt)
+    coef4 = torch.stack([1 + 0.2 * _rand((Cout,), 26), 0.3 * _rand((Cout,), 27), 0.3 + 0.1 * _rand((Cout,), 28), 1 + 0.1 * _rand((Cout,), 29).abs()], 1).to(dev)
+    kw = dict(pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=x2)
+    g2, t2 = ops.conv2d_actbwd(x, wp, Cout, 3, u, coef4, 0.2, fetch=BL, **kw); g1, t1 = ops.conv2d_actbwd(x, wp, Cout, 3, u, coef4, 0.2, fetch=N1, **kw)
+    assert torch.equal(g1, g2)
+    b2, b1 = ops.bn_bwd_coefs(t2, 0, coef4, N * H * W), ops.bn_bwd_coefs(t1, 0, coef4, N * H * W)
+    assert float((b2 - b1).abs().max()) < 1e-5 * float(b1.abs().max())
+    if H % 2 == 0 and ops.lib.ms_conv2d_pool2_ok(N, Cin, H, W, Cout, 0, int(bf16)):
+        assert torch.equal(ops.conv2d(x, wp, None, Cout, 3, 1, fetch=BL, epi_mode=ops.EPI_POOL2), ops.conv2d(x, wp, None, Cout, 3, 1, fetch=N1, epi_mode=ops.EPI_POOL2))
+    # with the Winograd appendix (LDS-DMA of the transformed weights) the block form stays bit-identical too
+    wpu, has = ops.with_wino_appendix(wp.clone(), Cin, Cout)
+    if has:
+        assert torch.equal(ops.conv2d(x, wpu, b, Cout, 3, 1, fetch=BL | ops.FETCH_WINO_U), o1)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 16, 16, 64, 64), (2, 64, 64, 64, 64), (1, 32, 48, 20, 192), (2, 64, 64, 32, 32), (1, 128, 64, 20, 40), (1, 8, 33, 10, 100), (1, 256, 256, 40, 40)])
 def test_winograd_appendix_same_bits(dev, N, Cin, Cout, H, W):
     """MS_FETCH_WINO_U: the transformed weights staged by LDS-DMA from the packed tensor's appendix (ms_wino_pack: the in-kernel expression, evaluated once per weight

@@ -75,24 +75,29 @@ def main():
         return best
     # columns: one / two channel blocks per staged tile, weights transformed in the kernel (the MS_FETCH_WINO_U bit cleared) or staged from the appendix (+U)
     WU = 0x800
-    print(f"{'call':12s} {'N,Cin,Hs,Ws,Cout':>24s} pm epi st cnt   nt1_us  nt1+U_us   nt2_us  nt2+U_us  exec_mfma_frac(nt1 -> best)   auto")
-    tot = [0.0, 0.0, 0.0, 0.0, 0.0]
+    BLK = 0x1000
+    print(f"{'call':12s} {'N,Cin,Hs,Ws,Cout':>24s} pm epi st cnt   nt1_us  nt1+U_us   nt2_us  nt2+U_us  blk2+U_us  exec_mfma_frac(nt1 -> best)   auto")
+    tot = [0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
     for key, (cnt, a, fi) in sorted(seen.items(), key=lambda kv: -kv[1][0] * kv[0][2] * kv[0][5] * kv[0][3] * kv[0][4]):
         name, N, Cin, Hs, Ws, Cout, pm, epi, stats = key
         has_u = bool(a[fi] & WU)
         ts = []
         os.environ["MS_CONV_WINO_NT"] = "2"         # (re-read per call under MS_CONV_TUNE) two blocks wherever the call's own NT1 bit does not say one
+        os.environ["MS_CONV_WINO_BLOCK"] = "0"      # tiled columns: never the block form
         for nt1, wu in ((1, 0), (1, 1), (0, 0), (0, 1)):
             a1 = list(a); a1[fi] = (a[fi] & ~WU & ~NT1) | (NT1 if nt1 else 0) | (WU if (wu and has_u) else 0)
             ts.append(time_call(name, tuple(a1)))
-        os.environ.pop("MS_CONV_WINO_NT", None)
+        a1 = list(a); a1[fi] = (a[fi] & ~NT1) | BLK
+        ts.append(time_call(name, tuple(a1)))        # the block form, two channel blocks, weights from the appendix when the engine packed one
+        os.environ.pop("MS_CONV_WINO_BLOCK", None)
+        os.environ["MS_CONV_WINO_NT"] = "0"         # 0 = the heuristic
         auto = time_call(name, a)
         for i, t in enumerate(ts + [auto]):
             tot[i] += cnt * t
         # executed matrix work: 16 MFMAs of 16x16x4 per (2x2 tile group of 16, 4 channels, 16 output channels): 16/36 of the direct form's flops
         ex = 2.0 * N * Hs * Ws * Cout * Cin * 9 * 16 / 36 / 157.3e12 * 1e6
-        print(f"{name[3:]:12s} {str((N, Cin, Hs, Ws, Cout)):>24s} {pm:2d} {epi:3d} {int(stats):2d} {cnt:3d} {ts[0]:8.1f} {ts[1]:8.1f} {ts[2]:8.1f} {ts[3]:8.1f}     {ex / ts[0]:5.2f} -> {ex / min(ts):5.2f}    {auto:8.1f}")
-    print(f"per step: nt1 {tot[0]:.0f} us, nt1+U {tot[1]:.0f} us, nt2 {tot[2]:.0f} us, nt2+U {tot[3]:.0f} us; the dispatch's own choice {tot[4]:.0f} us")
+        print(f"{name[3:]:12s} {str((N, Cin, Hs, Ws, Cout)):>24s} {pm:2d} {epi:3d} {int(stats):2d} {cnt:3d} {ts[0]:8.1f} {ts[1]:8.1f} {ts[2]:8.1f} {ts[3]:8.1f} {ts[4]:8.1f}     {ex / ts[0]:5.2f} -> {ex / min(ts):5.2f}    {auto:8.1f}")
+    print(f"per step: nt1 {tot[0]:.0f} us, nt1+U {tot[1]:.0f} us, nt2 {tot[2]:.0f} us, nt2+U {tot[3]:.0f} us, blocks {tot[4]:.0f} us; the dispatch's own choice {tot[5]:.0f} us")
 
 
 if __name__ == "__main__":

@@ -6,7 +6,7 @@ dev = torch.device("cuda:0")
 trace = torch.zeros(512, dtype=torch.int64, device=dev)
 os.environ["MS_CONV_TRACE"] = hex(trace.data_ptr())
 from maxstyle_amd import ops
-# usage: trace_conv.py [plain|pro1|bwd] [C] [size] [fetch bits, e.g. 0x100 = Winograd, 0x500 = Winograd one-block]
+# usage: trace_conv.py [plain|pro1|bwd] [C] [size] [fetch bits: 0x100 = Winograd, 0x500 = Winograd one-block, +0x800 = weights from the appendix (0x900 / 0xD00)]
 N = 16
 mode = sys.argv[1] if len(sys.argv) > 1 else "plain"
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 16
@@ -14,6 +14,8 @@ S = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 FETCH = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0
 x = torch.randn(N, C, S, S, device=dev); w = torch.randn(C, C, 3, 3, device=dev) * 0.1; b = torch.randn(C, device=dev)
 wp = ops.pack_conv_weight(w)
+if FETCH & 0x800:                                  # MS_FETCH_WINO_U: the transformed weights staged from the packed tensor's appendix
+    wp, _ = ops.with_wino_appendix(wp, C, C)
 out = torch.empty_like(x)
 stats, parts = ops.conv_stats_buffer(N, C, S, S, dev)
 kw = dict(stats=stats)
