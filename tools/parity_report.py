@@ -45,6 +45,36 @@ def main():
     print("   worst ratio", worst, " worst abs", max(err for err, _ in TE.TF_TABLE.values()))
 
 
+def round4():
+    """python tools/parity_report.py r4 > gpurun_out/r04_parity_report.txt - config 4 at size against the reference's own run (both conv forms) and config 5's two
+    call shapes (fp32 and bf16 storage) against the reference's fp32 run with the bf16-storage oracle's distance beside them: the numbers behind tests/test_round4_gpu.py."""
+    import r4_cases as R4
+    dev = torch.device("cuda:0")
+    print("== BASELINE config 4 at size (trained FCN_64, 16x3x320x320, K=10 free-running) vs the reference's fp64 run; noise_* = the reference's own fp32 run against it")
+    for wino in ("1", "0"):
+        os.environ["MS_LOOP_WINOGRAD"] = wino
+        r = R4.c4_full_case(dev)
+        print(json.dumps(r))
+        print(f"   winograd={r['winograd']}: image max {r['image_max']:.3e} (reference noise {r['noise_image_max']:.3e}, ratio {r['image_max'] / r['noise_image_max']:.2f}), "
+              f"rms {max(r['image_rms_full'], r['image_rms_strided']):.3e} ({r['noise_image_rms']:.3e}, {max(r['image_rms_full'], r['image_rms_strided']) / r['noise_image_rms']:.2f}), "
+              f"plane mean {r['mean_rel']:.2e} ({r['noise_plane_mean']:.2e}), plane rms {r['rms_rel']:.2e} ({r['noise_plane_rms']:.2e}), labels equal {r['labels_equal_f64']:.6f} "
+              f"(reference {r['noise_labels_equal']:.6f}), Dice diff {r['dice_abs_diff']:.2e}, Dice {r['dice']} clean {r['dice_clean']}")
+        print("   losses rel err per step:", ["%.1e" % e for e in r["losses_rel"]], " reference noise:", ["%.1e" % e for e in r["noise_losses_rel"]])
+        print("   params rel err:", {k: "%.1e" % v for k, v in r["params_rel"].items()}, " worst reference noise: %.1e" % max(r["noise_params_rel"].values()))
+    os.environ.pop("MS_LOOP_WINOGRAD")
+    print("== BASELINE config 5, one call per shape (p = 0.5: the reference's own draw), vs the reference's fp32 run; oracle_bf16_* = the CPU oracle with bf16 storage emulation")
+    for tag in ("acdc", "prostate"):
+        for dt in (None, torch.bfloat16):
+            r = R4.c5_call_case(dev, tag, dt)
+            print(tag, r["storage"], json.dumps({k: v for k, v in r.items() if k not in ("losses", "losses_ref")}))
+            print(f"   applied {r['applied']}: image max {r['image_max']:.2e} rms {r['image_rms']:.2e} (bf16 oracle {r['oracle_bf16_image_max']:.2e} / {r['oracle_bf16_image_rms']:.2e}), "
+                  f"labels {r['labels_equal']:.5f} (oracle {r['oracle_bf16_labels_equal']:.5f}), Dice diff {r['dice_abs_diff']:.1e}, worst loss err {max(r['losses_rel']):.1e} "
+                  f"(oracle {max(r['oracle_bf16_losses_rel']):.1e})")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "r4":
+    round4()
+    sys.exit(0)
 if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "free"):
     main()
 

@@ -26,3 +26,4 @@ for k in sorted(agg):
     v = agg[k]
     print(f"{k:28s} {sum(v) / len(v):14.4e}   (n={len(v)})")
 PY
+rm -rf $O/sq1 $O/sq2 $O/fetch $O/write

@@ -8,12 +8,17 @@ R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$R
 rm -rf $O; mkdir -p $O
-# 1. the bench under kernel-trace: per-kernel totals, the launch list of one inner step, the isolated runs bench.py prices
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-outer --no-parity --no-secondary --no-rccl-selftest --steady-seconds 0 > $O/bench_under_rocprof.json 2> $O/trace.err
+# 1. the bench under kernel-trace: per-kernel totals, the launch list of one inner step, the isolated runs bench.py prices; + the per-launch step budget
+#    (tools/step_budget.py: launch ledger of one eager step merged with the in-step durations of this trace)
+python tools/step_budget.py record c2 $O/ledger_c2.json > $O/ledger.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-outer --no-parity --no-secondary --no-instep --no-rccl-selftest --steady-seconds 0 > $O/bench_under_rocprof.json 2> $O/trace.err
 python tools/prof_summary.py $O/trace $O/${R}_kernel_stats.txt > /dev/null
+python tools/step_budget.py merge $O/ledger_c2.json $O/trace $O/${R}_step_budget_c2 >> $O/ledger.log 2>&1
 # 2. config 4 (FCN_64, 16x3x320x320)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c4 -- python bench.py --config c4 --steps 4 --warmup 1 --no-cpu-baseline --no-outer --no-parity --no-secondary --no-rccl-selftest --steady-seconds 0 > $O/bench_c4_under_rocprof.json 2> $O/trace_c4.err
+python tools/step_budget.py record c4 $O/ledger_c4.json >> $O/ledger.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c4 -- python bench.py --config c4 --steps 6 --warmup 1 --no-cpu-baseline --no-outer --no-parity --no-secondary --no-instep --no-rccl-selftest --steady-seconds 0 > $O/bench_c4_under_rocprof.json 2> $O/trace_c4.err
 python tools/prof_summary.py $O/trace_c4 $O/${R}_c4_kernel_stats.txt > /dev/null
+python tools/step_budget.py merge $O/ledger_c4.json $O/trace_c4 $O/${R}_step_budget_c4 >> $O/ledger.log 2>&1
 # 3. one trainer iteration (standard pass + inner loop + hard pass + backward + AdamW)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_train -- python tools/prof_train.py 6 > /dev/null 2> $O/trace_train.err
 python tools/prof_by_kernel.py $O/trace_train 0.5 > $O/${R}_train_pass_kernel_stats.txt
@@ -25,6 +30,14 @@ python tools/pmc_traffic.py $O/pmc_fetch_s $O/pmc_write_s $O/${R}_traffic_style.
 bash tools/pmc_conv.sh $R > /dev/null 2>&1
 cp gpurun_out/pmc_conv_$R/summary.txt $O/${R}_conv_wide_pmc.txt
 python tools/make_traffic.py $O/${R}_traffic_style.json gpurun_out/pmc_conv_$R $O/${R}_traffic.json
+# 5b. config 4's dominant shapes: SQ counters + FETCH_SIZE / WRITE_SIZE (tools/pmc_one.sh on tools/trace_conv.py: 64 -> 64 @16x320x320 with the BatchNorm-apply and the
+#     two-tensor prologue, two channel blocks per staged tile, weights from the appendix; 256 -> 256 @16x80x80 in the block form; the round-3 kernel (0x500) beside them)
+{ for args in "pro1 64 320 0x900" "bwd 64 320 0x900" "pro1 64 320 0x500" "pro1 256 80 0x900" "pro1 256 80 0x500"; do
+    echo "== tools/trace_conv.py $args"; bash tools/pmc_one.sh $O/pmc_c4_$(echo $args | tr ' ' '_') $args 2>&1 | grep -v amdgpu; echo; done; } > $O/${R}_conv_wide_pmc_c4.txt
+# 5c. the round's parity numbers and the per-layer A/B of the Winograd variants
+python tools/parity_report.py r4 > $O/${R}_parity_report.txt 2>&1
+python tools/ab_wino_nt.py c2 > $O/${R}_wino_ab_c2.txt 2>&1
+python tools/ab_wino_nt.py c4 10 > $O/${R}_wino_ab_c4.txt 2>&1
 # 6. un-profiled bench lines
 python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
 python bench.py --config c4 --steps 10 --warmup 2 > $O/${R}_bench_c4.json 2> $O/bench_c4.err
