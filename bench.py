@@ -275,6 +275,11 @@ def _traffic_table(B, H, W):
         try:
             tab.update(json.load(open(os.path.join(ROOT, "profiles", name))))
             tab["_source"] = f"profiles/{name}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (tools/profile_round.sh), NOT collected in this run"
+            # fresh = the kernel sources the passes priced are byte-identical to the tree's (sha256 recorded by tools/make_traffic.py); files of earlier rounds carry none
+            import hashlib
+            srcs = tab.get("_sources")
+            tab["_fresh"] = bool(srcs) and all(os.path.exists(os.path.join(ROOT, f)) and hashlib.sha256(open(os.path.join(ROOT, f), "rb").read()).hexdigest() == h
+                                               for f, h in srcs.items())
         except Exception:  # noqa: BLE001
             pass
     return tab
@@ -365,7 +370,7 @@ def kernel_rooflines(eng, dev, config, instep=None):
         blk = {"bound": "mfma", "achieved": exf / t_use / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mf, "frac_isolated": mfi}
         if hf > mf:
             blk = {"bound": "hbm", "achieved": nbytes / t_use / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hf, "frac_isolated": hfi}
-        blk.update({"traffic": traffic.get(tkey), "traffic_source": traffic.get("_source") if traffic.get(tkey) else None,
+        blk.update({"traffic": traffic.get(tkey), "traffic_source": traffic.get("_source") if traffic.get(tkey) else None, "traffic_fresh": (traffic.get("_fresh") if traffic.get(tkey) else None),
                     "kernel": FORMS[form].replace("PRO", str(pro)) + " " + what + " " + shape,
                     "us_per_launch": t_use * 1e6, "us_per_launch_source": ("in-step (two cut-off captures of the step, difference)" if key in instep else "isolated back-to-back replay"),
                     "us_per_launch_isolated": t_iso * 1e6, "algorithmic_bytes": nbytes, "hbm_GBps": nbytes / t_use / 1e9, "hbm_frac": hf, "hbm_frac_isolated": hfi,
@@ -380,7 +385,7 @@ def kernel_rooflines(eng, dev, config, instep=None):
         t_use = instep.get(key, t[key])
         return {"bound": "hbm", "achieved": nbytes / t_use / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / t_use / 1e9 / HBM_PEAK_GBPS,
                 "frac_isolated": nbytes / t[key] / 1e9 / HBM_PEAK_GBPS,
-                "traffic": traffic.get(tkey), "traffic_source": traffic.get("_source") if traffic.get(tkey) else None, "kernel": kernel,
+                "traffic": traffic.get(tkey), "traffic_source": traffic.get("_source") if traffic.get(tkey) else None, "traffic_fresh": (traffic.get("_fresh") if traffic.get(tkey) else None), "kernel": kernel,
                 "us_per_launch": t_use * 1e6, "us_per_launch_source": ("in-step (two cut-off captures of the step, difference)" if key in instep else "isolated back-to-back replay"),
                 "us_per_launch_isolated": t[key] * 1e6, "algorithmic_bytes": nbytes}
 

@@ -5,6 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_conv_summary import last_dispatches
 
 
+TRAFFIC_SOURCES = ("maxstyle_amd/csrc/ms_conv_wide.h", "maxstyle_amd/csrc/ms_conv_kernel.h", "maxstyle_amd/csrc/ms_common.h", "maxstyle_amd/csrc/ms_style_fused.hip",
+                   "maxstyle_amd/csrc/ms_style.hip", "maxstyle_amd/csrc/ms_conv_inst_wino.hip")
+
+
 def main(style_json, conv_root, out):
     res, detail = {}, {}
     st = json.load(open(style_json))
@@ -22,6 +26,10 @@ def main(style_json, conv_root, out):
             wb = wr.get("WRITE_SIZE", 0.0) * 1024
             res[key] = rd + wb; detail[key] = {"read_bytes": rd, "write_bytes": wb, "kernel": f.get("_kernel")}
     res["_detail"] = detail
+    # the kernel sources these figures price: bench.py reports `traffic_fresh` = they are unchanged since (tests/test_bench_contract_gpu.py fails on stale figures)
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res["_sources"] = {f: hashlib.sha256(open(os.path.join(root, f), "rb").read()).hexdigest() for f in TRAFFIC_SOURCES}
     res["_how"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/replay_conv.py (one launch of the C2 step replayed on its live "
                    "buffers) and tools/bench_kernels.py --only L4; KiB -> bytes, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts the 128-B requests of "
                    "16-B/lane streaming reads as 64 B), WRITE_SIZE as reported")
