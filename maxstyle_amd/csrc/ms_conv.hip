@@ -203,6 +203,10 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
     if (!found && want == 512L && !(stride == 2 && gemm_cols <= 32) && tiles * cdiv(gemm_cols, 16) >= 512L) { nt = 1; found = true; }
     if (found) break;
   }
+  // 1x1 convolutions on small images with many channels (config 4's 20x20 / 40x40 levels, 256-512 channels: fewer tiles than CUs): 16-channel tiles, i.e. the most
+  // work items - the 64-channel tile needs 205 registers (one workgroup per CU) and leaves most of the chip idle there (tools/tune_conv.py 10 c4: 120 -> 92 us at
+  // 512 -> 512 @16x20x20, 201 -> 150 us at 512 -> 256 @16x40x40).  Not the 16-pixel-wide levels (their own tile shape and chunking, tuned in round 3).
+  if (ks == 1 && !narrow && epi_mode != 2 && tiles < (long)num_cus() && gemm_cols >= 256 && tiles * cdiv(gemm_cols, 16) >= 512L) nt = 1;
   // tuning hook (tools/tune_conv.py): with MS_CONV_TUNE set, MS_CONV_FORCE_NT / MS_CONV_FORCE_WIDE are re-read on every call
   static const bool tune = getenv("MS_CONV_TUNE") != nullptr;
   bool allow_wide = true;

@@ -5,6 +5,7 @@ under the library's tuning hook (MS_CONV_TUNE: output-channel tile NT forced to 
 heuristic chose against the best alternative.  Usage: python tools/tune_conv.py [reps]"""
 import os, sys, json
 os.environ["MS_CONV_TUNE"] = "1"
+os.environ.setdefault("MS_XFIN", "0"); os.environ.setdefault("MS_RIDE", "0")      # every conv through ms_conv2d / ms_conv2d_actbwd (the `_xfin` / rider twins launch the same kernels)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
@@ -14,7 +15,8 @@ from maxstyle_amd import _lib
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     dev = torch.device("cuda:0")
-    eng, W, img, lab, styles, z_i, lab_d = bench.build(dev, 16, 256, 0, (4, 1, 4))
+    c4 = "c4" in sys.argv[2:]                      # python tools/tune_conv.py 10 c4: BASELINE config 4's shapes (FCN_64, 16x3x320x320)
+    eng, W, img, lab, styles, z_i, lab_d = bench.build(dev, 16, 320, 0, (1, 3, 2)) if c4 else bench.build(dev, 16, 256, 0, (4, 1, 4))
     eng.code, eng.labels = z_i, lab_d
     eng._prefix_valid = False
     im = eng.decode(z_i)
