@@ -258,6 +258,9 @@ def arg_cases(solver_mod):
             call = dict(decoder_layers_indexes=list(layers), channel_num=spec.channel_num, p=1.5, n_iter=3, lr=0.1,
                         reference_image=x, reference_segmentation=lab)
             call.update(kw)
+            # nuisance draws that no test reads (rand_p under p = 1.5, the N(0,1) tensors the `no_noise` forward never uses) come from the global generator: pin its
+            # position so that every key of the fixture regenerates bit for bit (cases with `fix_seed` re-seed inside the call anyway)
+            torch.manual_seed(4000 + sorted(ARG_CASES).index(case))
             with Spy(solver_mod) as spy, contextlib.redirect_stdout(io.StringIO()):
                 out = R.generate_max_style_image(z_i, **call)
             pre = f"{case}.{tag}."
