@@ -296,6 +296,19 @@ MS_INTERNAL int ms_conv3x3_small_cout(const float* in, const float* in2, float* 
 MS_INTERNAL int ms_conv_subpix_eligible(int Hs, int Ws);
 MS_INTERNAL int ms_conv_subpix(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int mode,
                    float* stats, const float* ref, const float* u, const float* coef4, float act_slope, float* tab, void* stream);
+/* Second generation (csrc/ms_conv_subpix2.h; fp32 storage): the same products in the same order per output element (`out` has ms_conv_subpix's bits; the statistics /
+ * activation-backward tables agree to summation order), staged entirely by LDS-DMA.  Mode 0 reads its 16 sub-pixel weight matrices from w_sums, an appendix of
+ * ms_subpix_pack_floats(Cin, Cout) floats that ms_subpix_pack() fills from the packed forward weights ONCE PER WEIGHT VERSION (repack after every change of the taps;
+ * the sums are formed in the first generation's order: same bits).  w_sums == NULL in mode 0, bf16 storage or tensors beyond 2 GiB: the first generation runs.
+ * flags: MS_SUBPIX_FIRST_GEN forces the first generation; MS_SUBPIX_TILES / MS_SUBPIX_BLOCKS force the work-item geometry (8 x 32-pixel tiles | sixteen 4 x 4-pixel
+ * blocks from a flattened block list: every stored size that is a multiple of 4 fills its MFMA rows); neither: chosen by fill.  ms_conv_subpix = flags 0, w_sums NULL. */
+#define MS_SUBPIX_FIRST_GEN 1
+#define MS_SUBPIX_TILES 2
+#define MS_SUBPIX_BLOCKS 4
+MS_INTERNAL size_t ms_subpix_pack_floats(int Cin, int Cout);
+MS_INTERNAL int ms_subpix_pack(const float* w_packed, float* w_sums, int Cin, int Cout, void* stream);
+MS_INTERNAL int ms_conv_subpix2(const float* in, float* out, const float* w_packed, const float* w_sums, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int mode,
+                    float* stats, const float* ref, const float* u, const float* coef4, float act_slope, float* tab, int flags, void* stream);
 
 /* Tail of a residual block in one launch (res_convdown / res_up_family: `last_act(conv_input(x) + conv(x))`, encoder_decoder.py:62-64, 344-346):
  * the 1x1 skip convolution `conv_input` (packed weights, bias) whose epilogue reads the raw output `u` [N,Cout,H',W'] of the block's second 3x3

@@ -103,6 +103,9 @@ SIGNATURES = {
     "ms_conv3x3_small_cout": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_int, c_void]),
     "ms_conv_subpix_eligible": (c_int, [c_int, c_int]),
     "ms_conv_subpix": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_void]),
+    "ms_conv_subpix2": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void]),
+    "ms_subpix_pack_floats": (c_size, [c_int, c_int]),
+    "ms_subpix_pack": (c_int, [c_f32p, c_f32p, c_int, c_int, c_void]),
     "ms_conv_actbwd_tab_bytes": (ctypes.c_size_t, [c_int]),
     "ms_conv2d_actbwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_f32p, c_f32p, c_f32p, c_int, c_int, ctypes.c_float, c_f32p, c_f32p, ctypes.c_float, c_f32p, c_void]),

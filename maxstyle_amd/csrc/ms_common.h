@@ -178,8 +178,17 @@ __device__ __forceinline__ ms_i32x4 ms_dma_rsrc(const void* base) {
   r.w = 0x00020000;
   return r;
 }
+__device__ __forceinline__ ms_i32x4 ms_dma_rsrc_n(const void* base, unsigned bytes) {      // ... with the exact size: every offset >= bytes reads as 0
+  ms_i32x4 r = ms_dma_rsrc(base);
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  return r;
+}
 __device__ __forceinline__ void ms_lds_dma16(ms_i32x4 rsrc, unsigned lds_byte_addr, int voff, int soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+// the 4-byte form: lane i's dword lands at lds_byte_addr + 4 i (256 contiguous bytes per wave instruction)
+__device__ __forceinline__ void ms_lds_dma4(ms_i32x4 rsrc, unsigned lds_byte_addr, int voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ unsigned ms_lds_addr(const void* p) {      // byte address inside the workgroup's LDS allocation of a pointer into a __shared__ array
   typedef __attribute__((address_space(3))) void* lds_p;

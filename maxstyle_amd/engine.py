@@ -66,6 +66,7 @@ class ConvW:
     def __init__(self, w, b, kind="conv"):
         self.kind = kind
         self.wu = self.dwu = False                 # the packed tensors carry a Winograd appendix (3x3 convs whose contraction width is a multiple of 8)
+        self.ws = None                             # sub-pixel weight sums of the forward taps (ms_subpix_pack), made on first use by conv_ups2
         if kind == "conv":
             self.cout, self.cin, self.ks = w.shape[0], w.shape[1], w.shape[2]
             self.wp = ops.pack_conv_weight(w)
@@ -96,6 +97,16 @@ class ConvW:
             ops.wino_repack(self.wp, self.cin, self.cout)
         if self.dwu:
             ops.wino_repack(self.dwp, self.cout, self.cin)
+        if self.ws is not None:
+            check(lib.ms_subpix_pack(self.wp.data_ptr(), self.ws.data_ptr(), self.cin, self.cout, torch.cuda.current_stream().cuda_stream), "ms_subpix_pack")
+
+    def subpix_sums(self):
+        """The 16 sub-pixel weight matrices of nn.UpsamplingNearest2d(2) -> this 3x3 conv (include/maxstyle_hip.h, ms_conv_subpix2): packed on first use, kept in step
+        with the taps by refresh_appendix (same buffer: captured graphs keep its address)."""
+        if self.ws is None:
+            self.ws = torch.empty(int(lib.ms_subpix_pack_floats(self.cin, self.cout)), dtype=F32, device=self.wp.device)
+            check(lib.ms_subpix_pack(self.wp.data_ptr(), self.ws.data_ptr(), self.cin, self.cout, torch.cuda.current_stream().cuda_stream), "ms_subpix_pack")
+        return self.ws
 
 
 class BNW:
@@ -370,6 +381,9 @@ class InnerLoopEngine:
         # the two x2 resampling convolutions in their sub-pixel form (ms_conv_subpix: no products with the duplicates / zeros the resampling inserts);
         # MS_SUBPIX=0 is the A/B switch (results agree to fp32 rounding: the up-sampling form pre-adds the taps that meet on one stored pixel)
         self.subpix = os.environ.get("MS_SUBPIX", "1") != "0"
+        # second generation of that kernel (LDS-DMA staging, sums appendix, 4 x 4-pixel block items on small images): MS_SUBPIX_GEN=1 is the A/B switch (the library reads
+        # it too: the mode-1 calls go through ms_conv_subpix, which picks the generation itself)
+        self.subpix_gen2 = os.environ.get("MS_SUBPIX_GEN", "2") != "1"
         self.small_cout = os.environ.get("MS_SMALL_COUT", "1") != "0"      # vector-ALU kernel for the 16 -> 1 (64 -> 3) data-gradient to the image
         # the activation after the encoder's first double conv (`inc`) is never written: BatchNorm + LeakyReLU become the prologue of down1's stride-2 conv
         # and the backward mask is recomputed from the raw conv output (inner loop only: the training engine and the MixStyle baselines read that tensor)
@@ -839,8 +853,13 @@ class InnerLoopEngine:
         if not self.bn_eval:
             parts = lib.ms_conv_stats_parts(N, 2 * Hs, 2 * Ws)
             st = self.t(name + ".stats", cw.cout * parts + 1, 4)
-        check(self.L("ms_conv_subpix")(x.data_ptr(), out.data_ptr(), cw.wp.data_ptr(), 0 if cw.b is None else cw.b.data_ptr(), N, Cin, Hs, Ws, cw.cout, 0,
-                                 0 if st is None else st.data_ptr(), 0, 0, 0, 1.0, 0, self._st()), "ms_conv_subpix(ups2):" + name)
+        if self.bf16 or not self.subpix_gen2:
+            check(self.L("ms_conv_subpix")(x.data_ptr(), out.data_ptr(), cw.wp.data_ptr(), 0 if cw.b is None else cw.b.data_ptr(), N, Cin, Hs, Ws, cw.cout, 0,
+                                     0 if st is None else st.data_ptr(), 0, 0, 0, 1.0, 0, self._st()), "ms_conv_subpix(ups2):" + name)
+        else:
+            # second generation (csrc/ms_conv_subpix2.h): all staging by LDS-DMA, the tap sums from an appendix packed once per weight version; same bits in `out`
+            check(lib.ms_conv_subpix2(x.data_ptr(), out.data_ptr(), cw.wp.data_ptr(), cw.subpix_sums().data_ptr(), 0 if cw.b is None else cw.b.data_ptr(), N, Cin, Hs, Ws, cw.cout, 0,
+                                      0 if st is None else st.data_ptr(), 0, 0, 0, 1.0, 0, 0, self._st()), "ms_conv_subpix2(ups2):" + name)
         return out, st, parts
 
     def dgrad_s2(self, name, g, cw: ConvW):

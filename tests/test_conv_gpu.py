@@ -405,6 +405,66 @@ def test_subpixel_stride2_data_gradient(dev, N, Cin, Cout, H, W):
     assert torch.equal(g3, masked2)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,Hs,Ws", [(2, 16, 16, 16, 16), (16, 128, 64, 20, 20), (3, 20, 24, 9, 36), (1, 128, 64, 5, 12), (5, 40, 48, 40, 40), (2, 64, 32, 8, 8),
+                                              (4, 12, 16, 18, 44), (16, 16, 16, 64, 64)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_subpixel_generations_same_bits(dev, N, Cin, Cout, Hs, Ws, mode):
+    """Second generation of the sub-pixel kernel (csrc/ms_conv_subpix2.h: LDS-DMA staging, sums appendix, tile and 4 x 4-block work items) against the first: the output
+    tensor bit for bit in both geometries (same products in the same order per element), the BatchNorm statistics / activation-backward sums to summation order; and
+    against fp64 math.  Shapes: channel tails (Cin % 8 != 0), partial blocks and tiles (Hs % 4 != 0), block groups that cross images, a batch with more items than CUs."""
+    from maxstyle_amd import ops
+    from maxstyle_amd._lib import lib, check
+    st = torch.cuda.current_stream().cuda_stream
+    x = _rand((N, Cin, Hs, Ws), 1).to(dev)
+    FIRST, TILES, BLOCKS = 1, 2, 4
+    if mode == 0:
+        w = _rand((Cout, Cin, 3, 3), 2, 0.1); b = _rand((Cout,), 3)
+        ref = F.conv2d(F.interpolate(x.cpu().double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+        wp = ops.pack_conv_weight(w.to(dev)); bd = b.to(dev)
+        sums = torch.empty(int(lib.ms_subpix_pack_floats(Cin, Cout)), device=dev)
+        check(lib.ms_subpix_pack(wp.data_ptr(), sums.data_ptr(), Cin, Cout, st), "ms_subpix_pack")
+        outs, coefs = {}, {}
+        for flags in (FIRST, TILES, BLOCKS, 0):
+            out = torch.full((N, Cout, 2 * Hs, 2 * Ws), float("nan"), device=dev)
+            stats, parts = ops.conv_stats_buffer(N, Cout, 2 * Hs, 2 * Ws, dev)
+            check(lib.ms_conv_subpix2(x.data_ptr(), out.data_ptr(), wp.data_ptr(), sums.data_ptr(), bd.data_ptr(), N, Cin, Hs, Ws, Cout, 0, stats.data_ptr(), 0, 0, 0, 1.0, 0,
+                                      flags, st), "ms_conv_subpix2")
+            coef = torch.empty(Cout, 4, device=dev)
+            check(lib.ms_bn_finalize(stats.data_ptr(), parts, torch.ones(Cout, device=dev).data_ptr(), torch.zeros(Cout, device=dev).data_ptr(), 1e-5, coef.data_ptr(), Cout, st), "fin")
+            outs[flags], coefs[flags] = out, coef
+        assert rel(outs[FIRST], ref) < 3e-6
+        for flags in (TILES, BLOCKS, 0):
+            assert torch.equal(outs[flags], outs[FIRST]), f"flags {flags}: the output must have the first generation's bits"
+            assert rel(coefs[flags][:, 2:], coefs[FIRST][:, 2:]) < 1e-5
+        # w_sums == NULL: the first generation runs (no appendix to read)
+        out = torch.empty_like(outs[FIRST])
+        check(lib.ms_conv_subpix2(x.data_ptr(), out.data_ptr(), wp.data_ptr(), 0, bd.data_ptr(), N, Cin, Hs, Ws, Cout, 0, 0, 0, 0, 0, 1.0, 0, BLOCKS, st), "ms_conv_subpix2(no sums)")
+        assert torch.equal(out, outs[FIRST])
+        return
+    # mode 1: data-gradient of Conv2d(3x3, s=2, p=1) from Cout_fwd = Cin (of this call) gradient channels to Cin_fwd = Cout channels
+    w = _rand((Cin, Cout, 3, 3), 2, 0.1)
+    ref = F.conv_transpose2d(x.cpu().double(), w.double(), stride=2, padding=1, output_padding=1)
+    dwp = ops.pack_conv_weight_dgrad(w.to(dev))
+    u = _rand((N, Cout, 2 * Hs, 2 * Ws), 7).to(dev)
+    coef = torch.stack([_rand((Cout,), 8).abs() + 0.5, _rand((Cout,), 9), _rand((Cout,), 10) * 0.1, torch.rand(Cout) + 0.5], dim=1).contiguous().to(dev)
+    act = _rand((N, Cout, 2 * Hs, 2 * Ws), 11).to(dev)
+    res = {}
+    for flags in (FIRST, TILES, BLOCKS, 0):
+        plain = torch.full((N, Cout, 2 * Hs, 2 * Ws), float("nan"), device=dev)
+        check(lib.ms_conv_subpix2(x.data_ptr(), plain.data_ptr(), dwp.data_ptr(), 0, 0, N, Cin, Hs, Ws, Cout, 1, 0, 0, 0, 0, 1.0, 0, flags, st), "ms_conv_subpix2")
+        masked = torch.full_like(plain, float("nan"))
+        tab = torch.zeros(lib.ms_conv_actbwd_tab_bytes(Cout) // 4, device=dev)
+        check(lib.ms_conv_subpix2(x.data_ptr(), masked.data_ptr(), dwp.data_ptr(), 0, 0, N, Cin, Hs, Ws, Cout, 1, 0, act.data_ptr(), u.data_ptr(), coef.data_ptr(), 0.2,
+                                  tab.data_ptr(), flags, st), "ms_conv_subpix2(actbwd)")
+        bc = torch.empty(Cout, 4, device=dev)
+        check(lib.ms_bn_bwd_coefs(tab.data_ptr(), 0, coef.data_ptr(), float(N * 4 * Hs * Ws), bc.data_ptr(), Cout, st), "bn_bwd_coefs")
+        res[flags] = (plain, masked, bc)
+    assert rel(res[FIRST][0], ref) < 3e-6
+    for flags in (TILES, BLOCKS, 0):
+        assert torch.equal(res[flags][0], res[FIRST][0]) and torch.equal(res[flags][1], res[FIRST][1]), f"flags {flags}"
+        assert rel(res[flags][2], res[FIRST][2]) < 2e-5
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W,pro", [(2, 16, 1, 32, 64, 2), (16, 16, 1, 256, 256, 2), (2, 64, 3, 40, 72, 2), (1, 7, 2, 19, 20, 0), (3, 16, 4, 16, 128, 0)])
 def test_small_cout_conv(dev, N, Cin, Cout, H, W, pro):
     """ms_conv3x3_small_cout (vector-ALU 3x3 conv for <= 4 output channels: the data-gradient to the image) vs fp64 math and vs ms_conv2d."""
