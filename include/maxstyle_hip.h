@@ -359,6 +359,11 @@ MS_INTERNAL int ms_conv2d_actbwd(const float* in, const float* in2, float* out, 
  * - model_util.py:468-510 backward; the 1x1 skip data-gradient runs between producer and consumer anyway, so the ~5 us coefficient launch disappears).
  * MFMA wave w of workgroup b takes channels 4b + w, 4b + w + 4*grid, ...: any grid carries the whole job; within ride_C <= ms_conv_ride_capacity(N, Hout, Wout) a wave has
  * at most one channel (the speed the rider is meant to have). */
+/* Streaming form of the 1x1 convolutions (csrc/ms_conv_k1s.h: every wave streams 64-pixel units with 16 loads in flight, no LDS / barrier on the activation path; the
+ * channels are accumulated in the tiled kernel's order: same bits).  Chosen by ms_conv2d / ms_conv2d_ride / ms_conv1x1_bnres(_xfin) themselves for fp32 storage, no
+ * prologue, Cin a power of two in 16..128, H W % 4 == 0, no statistics, and at least one 64-pixel unit per CU.  ms_conv_k1s_enable(0 | 1) switches the choice off / on
+ * for the process (A/B runs, the same-bits tests) and returns the previous setting; any other argument only reads it.  MS_CONV_K1S=0 in the environment: off. */
+MS_INTERNAL int ms_conv_k1s_enable(int on);
 MS_INTERNAL int ms_conv_ride_capacity(int N, int Hout, int Wout);
 MS_INTERNAL int ms_conv2d_ride(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                    int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include "ms_conv_kernel.h"
 #include "ms_conv_wide.h"
+#include "ms_conv_k1s.h"
 #include "maxstyle_hip.h"
 
 namespace ms {
@@ -232,9 +233,13 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   }
   if (allow_wide && conv_wide_eligible(a, ks, stride, fetch, vec)) return conv_dispatch_wide(a, nt, st);
   if (ks == 3 && stride == 1) return conv_dispatch_k3s1(a, fetch, nt, vec, narrow, use_in2, st);
+  if (ks == 1 && allow_wide && conv_k1s_eligible(a, ks, stride, fetch)) return conv_dispatch_k1s(a, st);      // streaming form (ms_conv_k1s.h)
   if (ks == 1) return conv_dispatch_k1s1(a, nt, vec, narrow, use_in2, st);
   return conv_dispatch_s2(a, ks, nt, vec, narrow, st);
 }
+
+namespace ms { int& conv_k1s_switch() { static int on = []() { const char* e = getenv("MS_CONV_K1S"); return (e && atoi(e) == 0) ? 0 : 1; }(); return on; } }
+extern "C" int ms_conv_k1s_enable(int on) { const int was = conv_k1s_switch(); if (on == 0 || on == 1) conv_k1s_switch() = on; return was; }
 
 extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                          int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,

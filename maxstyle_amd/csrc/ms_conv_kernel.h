@@ -57,6 +57,9 @@ __device__ __forceinline__ int conv_tid() {
 #ifndef MS_CONV_K1W2_CK
 #define MS_CONV_K1W2_CK 8      // ... with a 32-channel output tile (the ConvTranspose2d GEMMs)
 #endif
+#ifndef MS_CONV_K1W4_CK
+#define MS_CONV_K1W4_CK 8      // ... with a 64-channel output tile (the 1x1 convs of config 4)
+#endif
 #ifndef MS_CONV_S2_PF2
 #define MS_CONV_S2_PF2 0      // two register sets in the staging waves of the vector-staged stride-2 kernels with a 16-channel tile (fits with MS_CONV_S2_CK = 4: 98 VGPRs; +0.25 %, not adopted: profiles/r03_experiments.txt 17)
 #endif
@@ -417,8 +420,8 @@ struct Geo {
   // one slot = 2 stored values = 4 logical columns (UPS2: both logical rows 2sr-1, 2sr; ZINS2: logical row 2sr+1, odd columns 0)
   static constexpr bool EXP = VEC && (FETCH != FETCH_NORMAL);
   // input channels per K-chunk: sized so that two LDS buffers of (input tile + weight slice) leave >= 2 workgroups per CU
-  static constexpr int CK = (KS == 1 && NARROW && VEC && NT == 1) ? MS_CONV_K1N_CK : ((KS == 1 && !NARROW && VEC && NT == 1) ? MS_CONV_K1W_CK : ((KS == 1 && !NARROW && VEC && NT == 2) ? MS_CONV_K1W2_CK :
-                            ((STRIDE == 1 && VEC && NT == 1) ? 16 : ((STRIDE == 2 && NT > 1) ? 4 : ((STRIDE == 2) ? MS_CONV_S2_CK : 8)))));
+  static constexpr int CK = (KS == 1 && NARROW && VEC && NT == 1) ? MS_CONV_K1N_CK : ((KS == 1 && !NARROW && VEC && NT == 1) ? MS_CONV_K1W_CK : ((KS == 1 && !NARROW && VEC && NT == 2) ? MS_CONV_K1W2_CK : ((KS == 1 && !NARROW && VEC && NT == 4) ? MS_CONV_K1W4_CK :
+                            ((STRIDE == 1 && VEC && NT == 1) ? 16 : ((STRIDE == 2 && NT > 1) ? 4 : ((STRIDE == 2) ? MS_CONV_S2_CK : 8))))));
   static constexpr int VW = EXP ? 2 : (VEC ? 4 : 1);                       // elements per staging load
   static constexpr int SR = EXP ? ((FETCH == FETCH_UPS2) ? IH / 2 + 1 : IH / 2) : IH;   // staged rows per channel
   static constexpr int ROW_ITEMS = EXP ? WIN_W / 4 : WIN_W / VW;           // VEC: WIN_W % 4 == 0 by construction

@@ -1,0 +1,111 @@
+"""Streaming form of the 1x1 convolutions (csrc/ms_conv_k1s.h) against the tiled first-generation kernel it replaces on large images: same bits for the plain conv,
+the residual tail at the same and at twice the resolution (encoder_decoder.py:62-64, 344-346), with a rider job and with the cross-workgroup finalize; and against
+fp64 math."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from parity_util import rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+SHAPES = [(16, 16, 16, 64, 64), (4, 64, 64, 96, 80), (2, 128, 256, 96, 96), (3, 32, 16, 100, 84), (16, 64, 128, 40, 40), (5, 16, 32, 66, 62), (2, 128, 64, 90, 92)]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture
+def k1s():
+    from maxstyle_amd._lib import lib
+    was = lib.ms_conv_k1s_enable(1)
+    yield lib
+    lib.ms_conv_k1s_enable(was)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", SHAPES)
+def test_streaming_1x1_same_bits_as_tiled(dev, k1s, N, Cin, Cout, H, W):
+    from maxstyle_amd import ops
+    from maxstyle_amd._lib import check
+    lib = k1s
+    st = torch.cuda.current_stream().cuda_stream
+    x = _rand((N, Cin, H, W), 1).to(dev)
+    w = _rand((Cout, Cin, 1, 1), 2, 0.2); b = _rand((Cout,), 3)
+    wp = ops.pack_conv_weight(w.to(dev)); bd = b.to(dev)
+    ref = F.conv2d(x.cpu().double(), w.double(), b.double())
+
+    def plain():
+        out = torch.full((N, Cout, H, W), float("nan"), device=dev)
+        check(lib.ms_conv2d(x.data_ptr(), 0, out.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0, 0, 0, st), "ms_conv2d")
+        return out
+    u = _rand((N, Cout, H, W), 5).to(dev)
+    u2 = _rand((N, Cout, 2 * H, 2 * W), 6).to(dev)
+    coef = torch.stack([_rand((Cout,), 8).abs() + 0.5, _rand((Cout,), 9), _rand((Cout,), 10) * 0.1, torch.rand(Cout) + 0.5], dim=1).contiguous().to(dev)
+
+    def tail(up2):
+        uu = u2 if up2 else u
+        out = torch.full_like(uu, float("nan"))
+        check(lib.ms_conv1x1_bnres(x.data_ptr(), out.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, uu.data_ptr(), coef.data_ptr(), 0.2, up2, st), "ms_conv1x1_bnres")
+        return out
+    lib.ms_conv_k1s_enable(1)
+    a0, a1, a2 = plain(), tail(0), tail(1)
+    lib.ms_conv_k1s_enable(0)
+    b0, b1, b2 = plain(), tail(0), tail(1)
+    lib.ms_conv_k1s_enable(1)
+    assert rel(a0, ref) < 3e-6
+    assert torch.equal(a0, b0) and torch.equal(a1, b1) and torch.equal(a2, b2)
+    # the residual tail against its definition
+    sk = ref + 0.0
+    t1 = F.leaky_relu(coef[:, 0].cpu().double().view(1, -1, 1, 1) * u.cpu().double() + coef[:, 1].cpu().double().view(1, -1, 1, 1) + sk, 0.2)
+    assert rel(a1, t1) < 3e-6
+    t2 = F.leaky_relu(coef[:, 0].cpu().double().view(1, -1, 1, 1) * u2.cpu().double() + coef[:, 1].cpu().double().view(1, -1, 1, 1) + F.interpolate(sk, scale_factor=2, mode="nearest"), 0.2)
+    assert rel(a2, t2) < 3e-6
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(16, 16, 16, 128, 128), (4, 64, 128, 80, 80)])
+def test_streaming_1x1_rider_and_cross_workgroup_finalize(dev, k1s, N, Cin, Cout, H, W):
+    """The side jobs travel on the streaming kernel as they do on the tiled one: the rider's records (ms_bn_bwd_coefs / ms_bn_finalize arithmetic) and the residual tail
+    whose BatchNorm coefficients are derived inside the launch from the statistics table of the conv in front (`_xfin`): same bits as the separate launches."""
+    from maxstyle_amd import ops
+    from maxstyle_amd._lib import check
+    lib = k1s
+    st = torch.cuda.current_stream().cuda_stream
+    x = _rand((N, Cin, H, W), 1).to(dev)
+    w = _rand((Cout, Cin, 1, 1), 2, 0.2); b = _rand((Cout,), 3)
+    wp = ops.pack_conv_weight(w.to(dev)); bd = b.to(dev)
+    # a statistics table: from a 3x3 conv with Cout channels at the tail's resolution
+    w3 = _rand((Cout, Cin, 3, 3), 4, 0.1)
+    wp3 = ops.pack_conv_weight(w3.to(dev))
+    u = torch.empty(N, Cout, H, W, device=dev)
+    stats, parts = ops.conv_stats_buffer(N, Cout, H, W, dev)
+    check(lib.ms_conv2d(x.data_ptr(), 0, u.data_ptr(), wp3.data_ptr(), 0, N, Cin, H, W, Cout, 3, 1, 0, 0, 0, 0, 0, 0, 1, 1.0, 0, stats.data_ptr(), st), "ms_conv2d(3x3)")
+    gamma, beta = (_rand((Cout,), 11).abs() + 0.5).to(dev), _rand((Cout,), 12).to(dev)
+    coef = torch.empty(Cout, 4, device=dev)
+    check(lib.ms_bn_finalize(stats.data_ptr(), parts, gamma.data_ptr(), beta.data_ptr(), 1e-5, coef.data_ptr(), Cout, st), "ms_bn_finalize")
+    want = torch.empty_like(u)
+    check(lib.ms_conv1x1_bnres(x.data_ptr(), want.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, u.data_ptr(), coef.data_ptr(), 0.2, 0, st), "ms_conv1x1_bnres")
+    got = torch.full_like(u, float("nan"))
+    coef2 = torch.zeros(Cout, 4, device=dev)
+    gran = torch.zeros(int(lib.ms_xfin_gran_bytes(Cout)), dtype=torch.uint8, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib.ms_conv1x1_bnres_xfin(x.data_ptr(), got.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, u.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5,
+                                    coef2.data_ptr(), gran.data_ptr(), err.data_ptr(), 0.2, 0, st), "ms_conv1x1_bnres_xfin")
+    assert int(err.item()) == 0
+    assert torch.equal(coef2, coef) and torch.equal(got, want)
+    # rider kind 1 (ms_bn_finalize job) on a plain 1x1 conv
+    out4 = torch.zeros(Cout, 4, device=dev)
+    o1 = torch.empty(N, Cout, H, W, device=dev)
+    check(lib.ms_conv2d_ride(x.data_ptr(), 0, o1.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0, 0, 0,
+                             1, stats.data_ptr(), 0, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.0, out4.data_ptr(), Cout, st), "ms_conv2d_ride")
+    o0 = torch.empty_like(o1)
+    check(lib.ms_conv2d(x.data_ptr(), 0, o0.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0, 0, 0, st), "ms_conv2d")
+    assert torch.equal(o1, o0) and torch.equal(out4, coef)
