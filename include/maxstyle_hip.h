@@ -459,6 +459,13 @@ MS_STABLE int ms_head_wgrad(const float* h, const float* aux, const void* target
 MS_STABLE size_t ms_mse_ws_bytes(void);
 MS_STABLE int ms_mse_loss(const float* x, const float* target, size_t n, float loss_scale, float grad_scale, float* loss_out, float* dx,
                 void* ws, size_t ws_bytes, void* stream);
+/* `_ds`: the three launches that seed a backward pass (ms_head_ce's dh, ms_head_wgrad's d, ms_mse_loss's dx) with the UPSTREAM gradient as a device scalar
+ * (*..._dev multiplies the host-side scale inside the kernel; NULL = 1): `loss.backward()` hands the training pass its incoming gradient as a GPU tensor, and reading it
+ * on the host would make the host wait for everything queued before it - the inner loop included (advanced_triplet...py:731-786, train_adv...py:532-535). */
+MS_STABLE int ms_head_wgrad_ds(const float* h, const float* aux, const void* target, int mode, float scale, const float* scale_dev, float* dw, float* db,
+                     int N, int C, int K, int HW, int accumulate, void* ws, size_t ws_bytes, void* stream);
+MS_STABLE int ms_mse_loss_ds(const float* x, const float* target, size_t n, float loss_scale, float grad_scale, const float* grad_scale_dev, float* loss_out, float* dx,
+                   void* ws, size_t ws_bytes, void* stream);
 
 /* torch.optim.AdamW (weight_decay > 0: p *= 1 - lr*wd first) / torch.optim.Adam (weight_decay = 0) on a flat buffer
  * (advanced_triplet...py:1055-1086); step semantics as ms_adam_step. */
@@ -518,6 +525,8 @@ MS_STABLE int ms_head_bwd(const float* dout, const float* out, const float* w, f
 MS_STABLE size_t ms_head_ce_ws_bytes(int N, int HW);
 MS_STABLE int ms_head_ce(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* logits, float* loss_out,
                const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream);
+MS_STABLE int ms_head_ce_ds(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* logits, float* loss_out,
+                  const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, const float* grad_scale_dev, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- bf16 ACTIVATION STORAGE for the conv stack (SURVEY.md 8(b) "`_bf16` I/O variants with fp32 statistics"; BASELINE config 5) -----------------
  * Twins of the fp32 entry points above with the same argument lists and semantics; every ACTIVATION tensor (conv inputs / outputs, raw conv

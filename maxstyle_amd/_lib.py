@@ -126,6 +126,10 @@ SIGNATURES = {
     "ms_channel_sum": (c_int, [c_f32p, c_int, c_int, c_int, c_f32p, c_int, c_void, c_size, c_void]),
     "ms_head_wgrad_ws_bytes": (c_size, [c_int, c_int, c_int, c_int]),
     "ms_head_wgrad": (c_int, [c_f32p, c_f32p, c_void, c_int, c_float, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_void, c_size, c_void]),
+    "ms_head_wgrad_ds": (c_int, [c_f32p, c_f32p, c_void, c_int, c_float, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_void, c_size, c_void]),
+    "ms_mse_loss_ds": (c_int, [c_f32p, c_f32p, c_size, c_float, c_float, c_f32p, c_f32p, c_f32p, c_void, c_size, c_void]),
+    "ms_head_ce_ds": (c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_void, c_int, c_int, c_int, c_int, c_float, c_f32p,
+                              c_void, c_size, c_void]),
     "ms_mse_ws_bytes": (c_size, []),
     "ms_mse_loss": (c_int, [c_f32p, c_f32p, c_size, c_float, c_float, c_f32p, c_f32p, c_void, c_size, c_void]),
     "ms_adamw_step": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_size, c_float, c_float, c_float, c_float, c_float, c_int, c_void, c_void]),

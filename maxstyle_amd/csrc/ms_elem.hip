@@ -336,10 +336,11 @@ __global__ __launch_bounds__(kElemThreads) void head_sigmoid_bwd_kernel(const vo
 template <typename AT = float>
 __global__ __launch_bounds__(kElemThreads) void head_ce_kernel(const void* __restrict__ h, const float* __restrict__ w, const float* __restrict__ b,
                                                                const int64_t* __restrict__ labels, void* __restrict__ dh, float* __restrict__ logits_out,
-                                                               double* __restrict__ part, int C, int K, int HW, float grad_scale) {
+                                                               double* __restrict__ part, int C, int K, int HW, float grad_scale, const float* __restrict__ dscale) {
   using IO = ActIO<AT>;
   __shared__ float sw[kMaxHeadK * kMaxHeadC + kMaxHeadK];
   __shared__ double redd[16];
+  if (dscale != nullptr) grad_scale *= *dscale;          // (ms_head_ce_ds: the upstream gradient as a device scalar - no host read of it)
   for (int i = threadIdx.x; i < K * C; i += kElemThreads) sw[i] = w[i];
   if (threadIdx.x < K) sw[kMaxHeadK * kMaxHeadC + threadIdx.x] = b ? b[threadIdx.x] : 0.f;
   __syncthreads();
@@ -886,14 +887,14 @@ extern "C" size_t ms_head_ce_ws_bytes(int N, int HW) { return (size_t)N * std::m
 
 template <typename AT>
 static int head_ce_impl(const void* h, const float* w, const float* b, const int64_t* labels, void* dh, float* logits, float* loss_out,
-                        const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream) {
+                        const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream, const float* dscale = nullptr) {
   if (int e = head_check(N, C, K, HW, "ms_head_ce")) return e;
   if (ws == nullptr || ws_bytes < ms_head_ce_ws_bytes(N, HW)) { set_error("ms_head_ce: workspace too small"); return MS_ERR_WORKSPACE; }
   const int gx = std::min(cdiv(HW, kElemThreads), 256);
   dim3 grid(gx, N);
   const double M = (double)N * HW;
   // loss = loss_sign * CE, CE = -(1/M) sum logp[label];  d loss / d logit_k = loss_sign * (p_k - 1[k==label]) / M
-  MS_LAUNCH((head_ce_kernel<AT>), grid, dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, logits, (double*)ws, C, K, HW, (float)(loss_sign / M));
+  MS_LAUNCH((head_ce_kernel<AT>), grid, dim3(kElemThreads), 0, (hipStream_t)stream, h, w, b, labels, dh, logits, (double*)ws, C, K, HW, (float)(loss_sign / M), dscale);
   if (int e = check_launch("head_ce")) return e;
   MS_LAUNCH(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, gx * N, -(double)loss_sign / M, loss_out, loss_slot_dev);
   return check_launch("ce_finalize");
@@ -901,6 +902,10 @@ static int head_ce_impl(const void* h, const float* w, const float* b, const int
 extern "C" int ms_head_ce(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* logits, float* loss_out,
                           const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, void* ws, size_t ws_bytes, void* stream) {
   return head_ce_impl<float>(h, w, b, labels, dh, logits, loss_out, loss_slot_dev, N, C, K, HW, loss_sign, ws, ws_bytes, stream);
+}
+extern "C" int ms_head_ce_ds(const float* h, const float* w, const float* b, const int64_t* labels, float* dh, float* logits, float* loss_out,
+                             const int* loss_slot_dev, int N, int C, int K, int HW, float loss_sign, const float* grad_scale_dev, void* ws, size_t ws_bytes, void* stream) {
+  return head_ce_impl<float>(h, w, b, labels, dh, logits, loss_out, loss_slot_dev, N, C, K, HW, loss_sign, ws, ws_bytes, stream, grad_scale_dev);
 }
 // (logits stay fp32: they are an output for the caller, not an activation of the loop)
 extern "C" int ms_head_ce_bf16(const uint16_t* h, const float* w, const float* b, const int64_t* labels, uint16_t* dh, float* logits, float* loss_out,

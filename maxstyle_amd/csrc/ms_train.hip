@@ -76,8 +76,9 @@ constexpr int kHeadMaxC = 64, kHeadMaxK = 4, kHeadCB = 16;
 //   MODE 2: d = scale*aux
 template <int MODE>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ h, const float* __restrict__ aux, const void* __restrict__ tgt, float scale,
-                                                         float* __restrict__ partial, int C, int K, int HW, int chunk) {
+                                                         float* __restrict__ partial, int C, int K, int HW, int chunk, const float* __restrict__ dscale) {
   __shared__ float red[4][kHeadMaxK * (kHeadCB + 1)];
+  if (dscale != nullptr) scale *= *dscale;               // (ms_head_wgrad_ds: the upstream gradient as a device scalar)
   const int n = blockIdx.y;
   const int beg = blockIdx.x * chunk, end = min(HW, beg + chunk);
   const float* hp = h + (size_t)n * C * HW;
@@ -158,8 +159,10 @@ __global__ __launch_bounds__(64) void head_wgrad_reduce_kernel(const float* __re
 }
 
 // partial sums of (x-t)^2 in fp64; dx = grad_scale*(x-t)
-__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ x, const float* __restrict__ t, size_t n, float grad_scale, float* __restrict__ dx, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ x, const float* __restrict__ t, size_t n, float grad_scale, float* __restrict__ dx, double* __restrict__ part,
+                                                  const float* __restrict__ dscale) {
   __shared__ double redd[16];
+  if (dscale != nullptr) grad_scale *= *dscale;          // (ms_mse_loss_ds)
   double s = 0.0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float d = x[i] - t[i];
@@ -296,37 +299,54 @@ extern "C" size_t ms_head_wgrad_ws_bytes(int N, int C, int K, int HW) {
   return (size_t)N * cdiv(HW, head_wgrad_chunk(HW)) * K * (C + 1) * sizeof(float);
 }
 
-extern "C" int ms_head_wgrad(const float* h, const float* aux, const void* target, int mode, float scale, float* dw, float* db,
-                             int N, int C, int K, int HW, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+static int head_wgrad_impl(const float* h, const float* aux, const void* target, int mode, float scale, float* dw, float* db,
+                           int N, int C, int K, int HW, int accumulate, void* ws, size_t ws_bytes, void* stream, const float* dscale) {
   if (N < 1 || C < 1 || C > kHeadMaxC || K < 1 || K > kHeadMaxK || HW < 1 || N > 65535) { set_error("ms_head_wgrad: unsupported head shape C=%d K=%d", C, K); return MS_ERR_INVALID; }
   if (mode < 0 || mode > 2 || (mode != 2 && target == nullptr)) { set_error("ms_head_wgrad: invalid mode / missing target"); return MS_ERR_INVALID; }
   if (ws == nullptr || ws_bytes < ms_head_wgrad_ws_bytes(N, C, K, HW)) { set_error("ms_head_wgrad: workspace too small"); return MS_ERR_WORKSPACE; }
   const int chunk = head_wgrad_chunk(HW);
   dim3 grid(cdiv(HW, chunk), N);
   hipStream_t st = (hipStream_t)stream;
-  if (mode == 0) MS_LAUNCH(head_wgrad_kernel<0>, grid, dim3(256), 0, st, h, aux, target, scale, (float*)ws, C, K, HW, chunk);
-  else if (mode == 1) MS_LAUNCH(head_wgrad_kernel<1>, grid, dim3(256), 0, st, h, aux, target, scale, (float*)ws, C, K, HW, chunk);
-  else MS_LAUNCH(head_wgrad_kernel<2>, grid, dim3(256), 0, st, h, aux, target, scale, (float*)ws, C, K, HW, chunk);
+  if (mode == 0) MS_LAUNCH(head_wgrad_kernel<0>, grid, dim3(256), 0, st, h, aux, target, scale, (float*)ws, C, K, HW, chunk, dscale);
+  else if (mode == 1) MS_LAUNCH(head_wgrad_kernel<1>, grid, dim3(256), 0, st, h, aux, target, scale, (float*)ws, C, K, HW, chunk, dscale);
+  else MS_LAUNCH(head_wgrad_kernel<2>, grid, dim3(256), 0, st, h, aux, target, scale, (float*)ws, C, K, HW, chunk, dscale);
   if (int e = check_launch("head_wgrad")) return e;
   MS_LAUNCH(head_wgrad_reduce_kernel, dim3(K * (C + 1)), dim3(64), 0, st, (const float*)ws, (int)(grid.x * N), C, K, dw, db, accumulate);
   return check_launch("head_wgrad_reduce");
 }
 
+extern "C" int ms_head_wgrad(const float* h, const float* aux, const void* target, int mode, float scale, float* dw, float* db,
+                             int N, int C, int K, int HW, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  return head_wgrad_impl(h, aux, target, mode, scale, dw, db, N, C, K, HW, accumulate, ws, ws_bytes, stream, nullptr);
+}
+extern "C" int ms_head_wgrad_ds(const float* h, const float* aux, const void* target, int mode, float scale, const float* scale_dev, float* dw, float* db,
+                                int N, int C, int K, int HW, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  return head_wgrad_impl(h, aux, target, mode, scale, dw, db, N, C, K, HW, accumulate, ws, ws_bytes, stream, scale_dev);
+}
+
 extern "C" size_t ms_mse_ws_bytes(void) { return 1024 * sizeof(double); }
 
-extern "C" int ms_mse_loss(const float* x, const float* target, size_t n, float loss_scale, float grad_scale, float* loss_out, float* dx,
-                           void* ws, size_t ws_bytes, void* stream) {
+static int mse_loss_impl(const float* x, const float* target, size_t n, float loss_scale, float grad_scale, float* loss_out, float* dx,
+                         void* ws, size_t ws_bytes, void* stream, const float* dscale) {
   if (n < 1) { set_error("ms_mse_loss: empty input"); return MS_ERR_INVALID; }
   if (ws == nullptr || ws_bytes < ms_mse_ws_bytes()) { set_error("ms_mse_loss: workspace too small"); return MS_ERR_WORKSPACE; }
   const int nb = (int)std::min<size_t>(1024, (n + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
-  MS_LAUNCH(mse_kernel, dim3(nb), dim3(256), 0, st, x, target, n, grad_scale, dx, (double*)ws);
+  MS_LAUNCH(mse_kernel, dim3(nb), dim3(256), 0, st, x, target, n, grad_scale, dx, (double*)ws, dscale);
   if (int e = check_launch("mse")) return e;
   if (loss_out) {
     MS_LAUNCH(sum_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, (double)loss_scale, loss_out);
     return check_launch("mse_finalize");
   }
   return MS_OK;
+}
+extern "C" int ms_mse_loss(const float* x, const float* target, size_t n, float loss_scale, float grad_scale, float* loss_out, float* dx,
+                           void* ws, size_t ws_bytes, void* stream) {
+  return mse_loss_impl(x, target, n, loss_scale, grad_scale, loss_out, dx, ws, ws_bytes, stream, nullptr);
+}
+extern "C" int ms_mse_loss_ds(const float* x, const float* target, size_t n, float loss_scale, float grad_scale, const float* grad_scale_dev, float* loss_out, float* dx,
+                              void* ws, size_t ws_bytes, void* stream) {
+  return mse_loss_impl(x, target, n, loss_scale, grad_scale, loss_out, dx, ws, ws_bytes, stream, grad_scale_dev);
 }
 
 extern "C" int ms_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float weight_decay,

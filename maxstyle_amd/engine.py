@@ -419,7 +419,10 @@ class InnerLoopEngine:
         # cross-workgroup finalize (`_xfin` entry points): the BatchNorm coefficients a launch consumes are derived INSIDE that launch (one wave per channel,
         # published through tagged granules) instead of by an ms_bn_finalize launch in front of it.  Needs every workgroup of a launch co-resident: not with
         # shared_device.  MS_XFIN=0 is the A/B switch (bit-identical results).
-        self.xfin = os.environ.get("MS_XFIN", "1") != "0" and type(self) is InnerLoopEngine
+        # (the training engine can take it for its forward passes - MS_TRAIN_XFIN=1; every record a launch derives is reported to `_coef_made` - but its passes are
+        #  bound by kernel time, not by launches: -0.1 ms of a 23 ms trainer iteration, less than the error-word check in front of the weight step costs:
+        #  profiles/r04_experiments.txt 9; off by default)
+        self.xfin = os.environ.get("MS_XFIN", "1") != "0" and (type(self) is InnerLoopEngine or os.environ.get("MS_TRAIN_XFIN", "0") != "0")
         # ... also for the consumers that need the coefficients in their PROLOGUE (ms_conv2d_xfin: conv2 of a block; MS_XFIN_PRO=0 is the A/B switch)
         self.xfin_pro = self.xfin and os.environ.get("MS_XFIN_PRO", "1") != "0" and not self.mfma_bf16      # (the bf16-MFMA conv mode has no `_xfin` twin)
         self._tail = None              # while a step defers its tail: {"layers": [...], "ce": (ws, nparts, scale) | None}
@@ -718,8 +721,14 @@ class InnerLoopEngine:
         """bn_fin, or - when the consumer is a conv that can derive the coefficients in its own launch (`_xfin`, prologue kind) - the pending record."""
         if consumer_ok and self.xfin_pro and self._xfin_ok(st):
             coef, gran, err = self._xfin_bufs(name, bn.gamma.numel())
+            self._coef_made(bn, coef)
             return XfCoef(0, st, bn.gamma, bn.beta, 0.0, coef, gran, err, bn.gamma.numel())
         return self.bn_fin(name, st, parts, bn)
+
+    def _coef_made(self, bn: BNW, coef):
+        """A launch other than ms_bn_finalize will have written this BatchNorm's forward record into `coef` (an `_xfin` consumer, a rider): the training engine's
+        running-statistics update reads it behind the pass (TrainEngine._coef_made)."""
+        return None
 
     def coef_tensor(self, cf):
         """The coefficient records as a tensor: a pending XfCoef whose consumer cannot derive them itself is finalised by its own launch after all."""
@@ -920,6 +929,7 @@ class InnerLoopEngine:
             if self.ride and not self.bn_eval and not isinstance(st2, tuple) and self.bn_observer is None and bn.gamma.numel() <= lib.ms_conv_ride_capacity(N_, H_, W_):
                 # ... and that conv carries the block's ms_bn_finalize job (ms_conv2d_ride kind 1): the head behind it reads the record
                 cf2 = self.t(pfx + ".bn4.coef", bn.gamma.numel(), 4)
+                self._coef_made(bn, cf2)
                 sk, _, _ = self.conv(pfx + ".s", x, ci, ride=RideCoef(st2, 0, bn.gamma, 0.0, cf2, bn.gamma.numel(), kind=1, beta=bn.beta))
             else:
                 cf2 = self.bn_fin(pfx + ".bn4", st2, p2, bn)
@@ -934,6 +944,7 @@ class InnerLoopEngine:
             if xf2:
                 bn = net[key + ".bn4"]
                 cf2, gran, err = self._xfin_bufs(pfx + ".bn4", bn.gamma.numel())
+                self._coef_made(bn, cf2)
                 check(self.L("ms_conv1x1_bnres_xfin")(xin.data_ptr(), out.data_ptr(), ci.wp.data_ptr(), 0 if ci.b is None else ci.b.data_ptr(), N, Cin, Hs, Ws, ci.cout,
                                                 u2.data_ptr(), st2.data_ptr(), bn.gamma.data_ptr(), bn.beta.data_ptr(), BN_EPS, cf2.data_ptr(), gran.data_ptr(), err.data_ptr(),
                                                 LEAKY, 1 if kind == "nn" else 0, self._st()), "ms_conv1x1_bnres_xfin:" + pfx)

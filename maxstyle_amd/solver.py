@@ -471,6 +471,12 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         """Resolve the deferred error check of every inner-loop engine (loop_error_check = "deferred"); a no-op in the default "sync" mode."""
         for eng in self._engines.values():
             eng.flush_errors()
+        # the training engines' `_xfin` launches (cross-workgroup BatchNorm finalize in the forward passes) have an error word too: a weight step must not follow a
+        # pass whose coefficients were zero-filled by a spin time-out - resolved here, in front of the step (the host waits for the passes it has queued)
+        for pool in self._train_engines.values():
+            for eng in pool:
+                if "xfin.err" in eng.buf:
+                    eng.check_errors(sync=True)
 
     def optimize_params(self, model_name):
         self.flush_loop_errors()          # (deferred error protocol: a hard example from a timed-out launch must not reach the weights - ADVICE r3)
@@ -604,7 +610,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             self.z_i = z_i.clone()
             self.z_s = z_s.clone()
         self.recon_image = eng.buf["d.image"].clone()
-        zero = torch.tensor(0., device=x.device)
+        zero = torch.zeros((), device=x.device)                 # (torch.tensor(0., device=...) is a host-to-device copy: it waits for the stream)
         if return_output:
             y_0 = eng.buf["s.logits"].clone()
             return seg_loss, rec_loss, zero, zero, self.recon_image, y_0, y_0
@@ -615,7 +621,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         """advanced_triplet...py:843-889 ('no_STN': only the image branch exists): rescale_intensity(perturbed, 0, 1), then
         standard_training inside _disable_tracking_bn_stats (batch statistics, no running update, BatchNorm affine frozen)."""
         from . import ops
-        zero = torch.tensor(0., device=clean_image_l.device)
+        zero = torch.zeros((), device=clean_image_l.device)
         seg_loss, recon_loss, shape_loss = zero, zero, zero
         if perturbed_image is not None:
             if self.intensity_norm_type != 'min_max':
@@ -710,10 +716,14 @@ class _TrainPassFn(torch.autograd.Function):
         eng, solver = ctx.eng, ctx.solver
         if not eng.pending:
             raise RuntimeError("the activations of this training pass were already consumed by a backward")
-        gs = 0.0 if g_seg is None else float(g_seg)
-        gr = 0.0 if g_rec is None else float(g_rec)
+        # the upstream gradients stay on the device (TrainEngine.run_backward, the `_ds` seed launches): float(g) here would make the host wait for everything queued in
+        # front of this backward - in a trainer iteration the whole inner loop - before it could issue the ~250 launches of the pass
+        def dev_scalar(g):
+            if g is None:
+                return None
+            return g.detach().to(dtype=torch.float32) if g.is_cuda else float(g)
         eng.bank = solver._param_bank()
-        eng.run_backward(gs, gr)
+        eng.run_backward(dev_scalar(g_seg), dev_scalar(g_rec))
         eng.pending = False
         return torch.zeros_like(solver._anchor), None, None, None, None, None, None, None
 

@@ -205,6 +205,8 @@ class TrainEngine(InnerLoopEngine):
             da, _, _ = self.conv(name, g, cw, bnbwd=bnbwd, dgrad=True)
             return self.act_bwd_t(bw_name, da, None, u, coef, slope, net, bn_key)
         out, tab = self.conv_actbwd(name, bw_name, g, cw, bnbwd, u, coef, slope)
+        if not torch.is_tensor(tab):       # (a pending `_xfin` record: this engine reduces the table itself - ms_bn_bwd_full also yields the BatchNorm parameter gradients)
+            tab = tab.tab
         N, C, H, W = u.shape
         bc = self.t(bw_name + ".bcoef", C, 4)
         dg = db = None
@@ -227,9 +229,13 @@ class TrainEngine(InnerLoopEngine):
 
     def bn_fin(self, name, st, parts, bn):
         coef = super().bn_fin(name, st, parts, bn)
+        self._coef_made(bn, coef)
+        return coef
+
+    def _coef_made(self, bn, coef):
+        # (every BatchNorm of a tracking pass exactly once, in layer order: the statistics conv in front set _last_count)
         if self.track and not self.bn_eval:
             self._tracked.append((bn.name, coef, self._last_count))
-        return coef
 
     # ------------------------------------------------------------------ graph-replayed passes
     def _static_inputs(self, image, labels, clean):
@@ -267,10 +273,24 @@ class TrainEngine(InnerLoopEngine):
         self.track = False
         return out
 
-    def run_backward(self, g_seg: float, g_rec: float):
-        """backward_pass of the pass last run by run_forward (same static inputs); the two loss weights are baked into the captured launches."""
+    def run_backward(self, g_seg, g_rec):
+        """backward_pass of the pass last run by run_forward (same static inputs).  g_seg / g_rec: the upstream gradients of the two losses - host floats (baked into
+        the launches) or 0-dim fp32 CUDA tensors (read by the seed kernels on the device: no host wait for the queue in front of the backward); None / 0.0: branch skipped."""
         b = self.buf
         xi, li, ci = b["in.image"], b["in.labels"], b["in.clean"]
+        if torch.is_tensor(g_seg) or torch.is_tensor(g_rec):
+            # engine-owned copies: the launches (and a captured graph) keep these addresses
+            def own(name, g):
+                if g is None:
+                    return None
+                t = self.t(name, 1)
+                t.copy_(g.detach().reshape(1) if torch.is_tensor(g) else torch.full((1,), float(g), device=self.dev))
+                return t
+            g_seg, g_rec = own("in.g_seg", g_seg), own("in.g_rec", g_rec)
+            if not self.graph_passes or self.enc_mix is not None:
+                return self.backward_pass(xi, li, ci, g_seg, g_rec)
+            key = ("bwd", g_seg is not None, g_rec is not None, "dev", bool(self.bn_affine_grad), id(self.nets), id(self.bank))
+            return self._replayed(key, lambda: self.backward_pass(xi, li, ci, g_seg, g_rec))
         if not self.graph_passes or self.enc_mix is not None:
             return self.backward_pass(xi, li, ci, g_seg, g_rec)
         key = ("bwd", float(g_seg), float(g_rec), bool(self.bn_affine_grad), id(self.nets), id(self.bank))
@@ -371,9 +391,17 @@ class TrainEngine(InnerLoopEngine):
             dx = self.dgrad_s2(pfx + ".dx", dsrc, tbl[key + ".down"])
         return dx
 
-    def backward_pass(self, image, labels, clean, g_seg: float, g_rec: float):
-        """Accumulates d(g_seg*CE + g_rec*0.5*MSE)/d(parameters) into the ParamBank's flat gradient buffer."""
+    def backward_pass(self, image, labels, clean, g_seg, g_rec):
+        """Accumulates d(g_seg*CE + g_rec*0.5*MSE)/d(parameters) into the ParamBank's flat gradient buffer (g_*: host floats or 1-element CUDA tensors, see run_backward)."""
         b = self.buf
+        ds_seg = g_seg.data_ptr() if torch.is_tensor(g_seg) else 0        # device-side upstream gradients (the `_ds` seed launches)
+        ds_rec = g_rec.data_ptr() if torch.is_tensor(g_rec) else 0
+        if torch.is_tensor(g_seg):
+            g_seg = 1.0
+        if torch.is_tensor(g_rec):
+            g_rec = 1.0
+        g_seg = 0.0 if g_seg is None else g_seg
+        g_rec = 0.0 if g_rec is None else g_rec
         self._wg_calls = []
         net_e, net_s, net_d = NETS
         e, s, d = self.nets.enc, self.nets.seg, self.nets.dec
@@ -388,12 +416,12 @@ class TrainEngine(InnerLoopEngine):
             dh = self.t("s.dh", N, C, H, W)
             ws = b["s.ce_ws"]
             scratch = self.t("s.loss_scratch", 4)
-            check(lib.ms_head_ce(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), dh.data_ptr(), 0, scratch.data_ptr(), 0,
-                                 N, C, K, H * W, float(g_seg), ws.data_ptr(), ws.numel(), self._st()), "ms_head_ce(bwd)")
+            check(lib.ms_head_ce_ds(h.data_ptr(), w.data_ptr(), bias.data_ptr(), labels.data_ptr(), dh.data_ptr(), 0, scratch.data_ptr(), 0,
+                                    N, C, K, H * W, float(g_seg), ds_seg, ws.data_ptr(), ws.numel(), self._st()), "ms_head_ce(bwd)")
             hws = self.t("s.hw_ws", max(lib.ms_head_wgrad_ws_bytes(N, C, K, H * W), 64), dtype=torch.uint8)
-            check(lib.ms_head_wgrad(h.data_ptr(), b["s.logits"].data_ptr(), labels.data_ptr(), 0, float(g_seg) / (N * H * W),
-                                    self.bank.grad(net_s, "final_conv.weight").data_ptr(), self.bank.grad(net_s, "final_conv.bias").data_ptr(),
-                                    N, C, K, H * W, 1, hws.data_ptr(), hws.numel(), self._st()), "ms_head_wgrad(seg)")
+            check(lib.ms_head_wgrad_ds(h.data_ptr(), b["s.logits"].data_ptr(), labels.data_ptr(), 0, float(g_seg) / (N * H * W), ds_seg,
+                                       self.bank.grad(net_s, "final_conv.weight").data_ptr(), self.bank.grad(net_s, "final_conv.bias").data_ptr(),
+                                       N, C, K, H * W, 1, hws.data_ptr(), hws.numel(), self._st()), "ms_head_wgrad(seg)")
             g = dh
             for i in range(4, 0, -1):
                 x = z_s if i == 1 else b[f"s.u{i - 1}.out"]
@@ -408,12 +436,12 @@ class TrainEngine(InnerLoopEngine):
             K = d["head.w"].shape[0]
             n = img.numel()
             hws = self.t("d.hw_ws", max(lib.ms_head_wgrad_ws_bytes(N, C, K, H * W), 64), dtype=torch.uint8)
-            check(lib.ms_head_wgrad(x.data_ptr(), img.data_ptr(), clean.data_ptr(), 1, float(g_rec) / n,
-                                    self.bank.grad(net_d, "final_conv.weight").data_ptr(), self.bank.grad(net_d, "final_conv.bias").data_ptr(),
-                                    N, C, K, H * W, 1, hws.data_ptr(), hws.numel(), self._st()), "ms_head_wgrad(dec)")
+            check(lib.ms_head_wgrad_ds(x.data_ptr(), img.data_ptr(), clean.data_ptr(), 1, float(g_rec) / n, ds_rec,
+                                       self.bank.grad(net_d, "final_conv.weight").data_ptr(), self.bank.grad(net_d, "final_conv.bias").data_ptr(),
+                                       N, C, K, H * W, 1, hws.data_ptr(), hws.numel(), self._st()), "ms_head_wgrad(dec)")
             dimg = self.t("d.dimg", *img.shape)
             mws = b["d.mse_ws"]
-            check(lib.ms_mse_loss(img.data_ptr(), clean.data_ptr(), n, 0.0, float(g_rec) / n, 0, dimg.data_ptr(), mws.data_ptr(), mws.numel(), self._st()), "ms_mse_loss(bwd)")
+            check(lib.ms_mse_loss_ds(img.data_ptr(), clean.data_ptr(), n, 0.0, float(g_rec) / n, ds_rec, 0, dimg.data_ptr(), mws.data_ptr(), mws.numel(), self._st()), "ms_mse_loss(bwd)")
             dh = self.t("d.dh", N, C, H, W)
             check(lib.ms_head_bwd(dimg.data_ptr(), img.data_ptr(), d["head.w"].data_ptr(), dh.data_ptr(), N, C, K, H * W, 1, self._st()), "ms_head_bwd")
             g = dh

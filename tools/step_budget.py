@@ -45,8 +45,8 @@ def conv_cost(fn, a):
     if base in ("ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin"):
         N, Cin, Hs, Ws, Cout = a[4:9]
         return dict(N=N, Cin=Cin, Hs=Hs, Ws=Ws, Cout=Cout, ks=1, stride=1, fetch=0, pm=0, epi=4, flop=2.0 * N * Hs * Ws * Cout * Cin)
-    if base == "ms_conv_subpix":
-        N, Cin, Hs, Ws, Cout, mode = a[4:10]
+    if base in ("ms_conv_subpix", "ms_conv_subpix2"):
+        N, Cin, Hs, Ws, Cout, mode = a[4:10] if base == "ms_conv_subpix" else a[5:11]      # (ms_conv_subpix2: w_sums sits behind w_packed)
         # direct-form flop of the conv it replaces: 3x3 on the up-sampled / zero-inserted [2Hs, 2Ws] grid
         return dict(N=N, Cin=Cin, Hs=Hs, Ws=Ws, Cout=Cout, ks=3, stride=1, fetch=1 + mode, pm=0, epi=0, flop=2.0 * N * 4 * Hs * Ws * Cout * Cin * 9)
     if base == "ms_conv3x3_small_cout":
@@ -162,9 +162,9 @@ def executed_fraction(kernel, cv):
         return 0.0
     if cv.get("vector_alu"):
         return 0.0                                  # (vector-ALU kernels: priced by their bytes)
-    if "conv_subpix_kernel<0" in kernel:
+    if "conv_subpix_kernel<0" in kernel or "conv_subpix2_kernel<0" in kernel:
         return 4.0 / 9.0
-    if "conv_subpix_kernel<1" in kernel:
+    if "conv_subpix_kernel<1" in kernel or "conv_subpix2_kernel<1" in kernel:
         return 0.25
     if "conv_wide_kernel" in kernel and any(t in kernel for t in ("ms_f32w", "ms_bf16w")):
         return 16.0 / 36.0
