@@ -15,6 +15,7 @@ static int k1s_epi(const ConvArgs& a, hipStream_t st) {
   return k1s_ncg<NT, 0>(a, st);
 }
 int conv_dispatch_k1s(const ConvArgs& a, hipStream_t st) {
+  if (a.epi_mode == 2) return k1s_ncg<4, 2>(a, st);
   if (a.Cout <= 16) return k1s_epi<1>(a, st);
   if (a.Cout <= 32) return k1s_epi<2>(a, st);
   return k1s_epi<4>(a, st);

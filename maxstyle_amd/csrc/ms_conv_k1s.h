@@ -21,7 +21,9 @@ namespace ms {
 constexpr int kK1sD = 16;                    // loads in flight per wave
 constexpr int kK1sOob = (int)0x80000000;
 
-template <int NT, int EPI, int NCGS>         // EPI: 0 plain | 4 residual tail | 5 residual tail at twice the resolution; NCGS = min(Cin / 4, D)
+// EPI: 0 plain | 2 ConvTranspose2d(k=2, s=2) as a GEMM with 4 Cout columns (NT = 4: column block q = (dy, dx) of 16 output channels; out[n, co, 2y+dy, 2x+dx]) |
+//      4 residual tail | 5 residual tail at twice the resolution; NCGS = min(Cin / 4, D)
+template <int NT, int EPI, int NCGS>
 __global__ __launch_bounds__(256, 2) void conv_k1s_kernel(const ConvArgs a) {
   constexpr int D = kK1sD, COUT_TILE = 16 * NT, WS = (NT == 1) ? 16 : 16 * NT + 16;
   typedef unsigned lu32x4_t __attribute__((ext_vector_type(4)));
@@ -66,7 +68,9 @@ __global__ __launch_bounds__(256, 2) void conv_k1s_kernel(const ConvArgs a) {
     constexpr int Q = COUT_TILE / 4;
     for (int idx = MS_TID; idx < a.cin_pad * Q; idx += 256) {
       const int c = idx / Q, j4 = idx - c * Q;
-      *reinterpret_cast<float4*>(smem + c * WS + 4 * j4) = *reinterpret_cast<const float4*>(a.w + (size_t)c * a.cout_pad + cb * COUT_TILE + 4 * j4);
+      // EPI 2: the slice's column block q holds GEMM columns q * Cout + 16 cb .. + 15 (the four (dy, dx) positions of this item's 16 output channels)
+      const size_t src = (EPI == 2) ? ((size_t)c * a.cout_pad + (size_t)(j4 >> 2) * a.cout_real + cb * 16 + 4 * (j4 & 3)) : ((size_t)c * a.cout_pad + cb * COUT_TILE + 4 * j4);
+      *reinterpret_cast<float4*>(smem + c * WS + 4 * j4) = *reinterpret_cast<const float4*>(a.w + src);
     }
   }
   __syncthreads();
@@ -77,8 +81,8 @@ __global__ __launch_bounds__(256, 2) void conv_k1s_kernel(const ConvArgs a) {
   bool co_ok[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int co = cb * COUT_TILE + j * 16 + m;
-    co_ok[j] = co < a.Cout;
+    const int co = (EPI == 2) ? (cb * 16 + m) : (cb * COUT_TILE + j * 16 + m);
+    co_ok[j] = co < ((EPI == 2) ? a.cout_real : a.Cout);
     bias_v[j] = (a.bias != nullptr && co_ok[j]) ? a.bias[co] : 0.f;
     mk_sc[j] = mk_sh[j] = 0.f;
     if (EPI != 0 && !xf_epi) {
@@ -128,7 +132,25 @@ __global__ __launch_bounds__(256, 2) void conv_k1s_kernel(const ConvArgs a) {
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][j][r] += bias_v[j];
-    if (EPI == 5) {
+    if (EPI == 2) {
+      // pixel (y, x), channel co, position (dy, dx) -> out[n, co, 2y + dy, 2x + dx]: the lane's four pixels x .. x+3 and both dx are 8 consecutive floats of row 2y + dy
+      int y = pl / a.Ws, x = pl - y * a.Ws;
+      const int Wo = 2 * a.Ws;
+      const size_t pb = ((size_t)n * a.cout_real + cb * 16 + m) * (size_t)(4 * HW);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (co_ok[0] && pl + 4 * r < HW) {
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy) {
+            const size_t off = pb + (size_t)(2 * y + dy) * Wo + 2 * x;
+            *reinterpret_cast<float4*>(a.out + off) = make_float4(acc[0][2 * dy][r], acc[0][2 * dy + 1][r], acc[1][2 * dy][r], acc[1][2 * dy + 1][r]);
+            *reinterpret_cast<float4*>(a.out + off + 4) = make_float4(acc[2][2 * dy][r], acc[2][2 * dy + 1][r], acc[3][2 * dy][r], acc[3][2 * dy + 1][r]);
+          }
+        }
+        x += 4;
+        if (x >= a.Ws) { x -= a.Ws; ++y; }
+      }
+    } else if (EPI == 5) {
       // every value feeds a 2 x 2 block of outputs: (y, x) of the lane's pixel quads (a quad never crosses a row: Ws % 4 == 0)
       int y = pl / a.Ws, x = pl - y * a.Ws;
       const int Wo = 2 * a.Ws;
@@ -211,8 +233,9 @@ __global__ __launch_bounds__(256, 2) void conv_k1s_kernel(const ConvArgs a) {
 int& conv_k1s_switch();      // ms_conv.hip: 1 (default; MS_CONV_K1S=0 in the environment: 0) - ms_conv_k1s_enable() flips it for A/B runs and the same-bits tests
 inline bool conv_k1s_eligible(const ConvArgs& a, int ks, int stride, int fetch) {
   if (conv_k1s_switch() == 0 || ks != 1 || stride != 1 || fetch != FETCH_NORMAL || a.act_bf16 != 0 || a.pro_mode != 0 || a.in2 != nullptr || a.stats != nullptr || a.fin_counter != nullptr ||
-      a.bw_parts > 0 || !(a.epi_mode == 0 || a.epi_mode == 4 || a.epi_mode == 5)) return false;
-  if (a.xf_tab != nullptr && a.epi_mode == 0) return false;                     // (a prologue-kind `_xfin`: there is no prologue here)
+      a.bw_parts > 0 || !(a.epi_mode == 0 || a.epi_mode == 2 || a.epi_mode == 4 || a.epi_mode == 5)) return false;
+  if (a.epi_mode == 2 && (a.cout_real % 16 != 0 || a.Ws % 4 != 0 || a.xf_tab != nullptr)) return false;
+  if (a.xf_tab != nullptr && (a.epi_mode == 0 || a.epi_mode == 2)) return false;                     // (a prologue-kind `_xfin`: there is no prologue here)
   const int C = a.Cin;
   // measured (tools/ab_k1.py, profiles/r04_experiments.txt 8): the stream pays from 64 input channels up (64-channel output tiles: the tiled kernel's 205 registers allow
   // one workgroup per CU); config 2's 16 .. 32-channel layers and the half-resolution tails keep the tiled kernel
@@ -224,14 +247,14 @@ inline bool conv_k1s_eligible(const ConvArgs& a, int ks, int stride, int fetch) 
   if (!aligned16(a.in) || !aligned16(a.out) || !aligned16(a.w) || (a.epi_mode != 0 && !aligned16(a.mk_u))) return false;
   // a streaming kernel: it pays where there is a stream - at least one 4-wave workgroup of 64-pixel units per CU (config 2's 64 / 128-channel layers on 32 x 32 images
   // have a quarter of that and lose: 13.4 -> 18.3 us; the small, channel-heavy levels keep the tiled kernel)
-  return (long)a.N * ((HW + 63) / 64) * cdiv(a.Cout, 64) >= 4L * num_cus();
+  return (long)a.N * ((HW + 63) / 64) * cdiv(a.Cout, 64) >= 4L * num_cus();      // (EPI 2: a.Cout = the 4 Cout GEMM columns = 64 per item)
 }
 
 template <int NT, int EPI, int NCGS>
 int launch_conv_k1s_t(ConvArgs a, hipStream_t st) {
   constexpr int WS = (NT == 1) ? 16 : 16 * NT + 16;
   const size_t lds_bytes = sizeof(float) * (size_t)a.cin_pad * WS;
-  a.ncb = cdiv(a.Cout, 16 * NT);
+  a.ncb = (EPI == 2) ? a.cout_real / 16 : cdiv(a.Cout, 16 * NT);
   static std::mutex mu;
   static std::map<size_t, int> occ;
   int per_cu;

@@ -109,3 +109,29 @@ def test_streaming_1x1_rider_and_cross_workgroup_finalize(dev, k1s, N, Cin, Cout
     o0 = torch.empty_like(o1)
     check(lib.ms_conv2d(x.data_ptr(), 0, o0.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0, 0, 0, st), "ms_conv2d")
     assert torch.equal(o1, o0) and torch.equal(out4, coef)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(16, 64, 64, 80, 80), (4, 128, 32, 96, 100), (16, 64, 16, 64, 64)])
+def test_streaming_1x1_conv_transpose_gemm_same_bits(dev, k1s, N, Cin, Cout, H, W):
+    """nn.ConvTranspose2d(k=2, s=2) as a GEMM with 4 Cout columns and the pixel-shuffle epilogue (res_up_family 'Conv2' up-sampling, encoder_decoder.py:301-303):
+    streaming kernel == tiled kernel bit for bit, == fp64 math."""
+    from maxstyle_amd import ops
+    from maxstyle_amd._lib import check
+    lib = k1s
+    st = torch.cuda.current_stream().cuda_stream
+    x = _rand((N, Cin, H, W), 1).to(dev)
+    w = _rand((Cin, Cout, 2, 2), 2, 0.2); b = _rand((Cout,), 3)
+    wp = ops.pack_convT_weight(w.to(dev)); bd = b.to(dev)
+    ref = F.conv_transpose2d(x.cpu().double(), w.double(), b.double(), stride=2)
+
+    def run():
+        out = torch.full((N, Cout, 2 * H, 2 * W), float("nan"), device=dev)
+        check(lib.ms_conv2d(x.data_ptr(), 0, out.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0, 2, 0, st), "ms_conv2d(epi 2)")
+        return out
+    lib.ms_conv_k1s_enable(1)
+    a = run()
+    lib.ms_conv_k1s_enable(0)
+    t = run()
+    lib.ms_conv_k1s_enable(1)
+    assert rel(a, ref) < 3e-6
+    assert torch.equal(a, t)

@@ -12,7 +12,7 @@ from maxstyle_amd._lib import lib, check
 # (kind, Cin, Cout, H, W): kind "tail" = ms_conv1x1_bnres, "up2" = ... with the input at half resolution (H, W = input size), "plain" = ms_conv2d
 SHAPES = {
     "c4": [("tail", 64, 64, 320, 320), ("up2", 64, 64, 160, 160), ("tail", 64, 128, 160, 160), ("tail", 128, 256, 80, 80), ("up2", 128, 64, 80, 80),
-           ("plain", 64, 64, 320, 320), ("plain", 128, 64, 160, 160), ("plain", 64, 64, 160, 160), ("plain", 64, 128, 80, 80), ("plain", 128, 256, 40, 40)],
+           ("convT", 64, 64, 160, 160), ("plain", 64, 64, 320, 320), ("plain", 128, 64, 160, 160), ("plain", 64, 64, 160, 160), ("plain", 64, 128, 80, 80), ("plain", 128, 256, 40, 40)],
     "c2": [("tail", 16, 16, 256, 256), ("tail", 16, 32, 128, 128), ("tail", 32, 64, 64, 64), ("tail", 64, 128, 32, 32), ("up2", 32, 16, 64, 64), ("up2", 64, 32, 32, 32),
            ("plain", 16, 16, 256, 256), ("plain", 16, 16, 128, 128), ("plain", 32, 16, 128, 128), ("plain", 64, 32, 64, 64), ("plain", 16, 32, 64, 64)],
 }
@@ -30,10 +30,15 @@ def main():
         x = torch.randn(N, Cin, H, W, generator=g).to(dev)
         wp = ops.pack_conv_weight((torch.randn(Cout, Cin, 1, 1, generator=g) * 0.2).to(dev))
         b = torch.randn(Cout, generator=g).to(dev)
-        Ho, Wo = (2 * H, 2 * W) if kind == "up2" else (H, W)
+        Ho, Wo = (2 * H, 2 * W) if kind in ("up2", "convT") else (H, W)
+        if kind == "convT":
+            wp = ops.pack_convT_weight((torch.randn(Cin, Cout, 2, 2, generator=g) * 0.2).to(dev))
         out = torch.empty(N, Cout, Ho, Wo, device=dev)
         nbytes = x.numel() * 4 + out.numel() * 4
-        if kind == "plain":
+        if kind == "convT":
+            def run():
+                check(lib.ms_conv2d(x.data_ptr(), 0, out.data_ptr(), wp.data_ptr(), b.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0, 2, 0, st), "ms_conv2d(epi 2)")
+        elif kind == "plain":
             def run():
                 check(lib.ms_conv2d(x.data_ptr(), 0, out.data_ptr(), wp.data_ptr(), b.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0, 0, 0, st), "ms_conv2d")
         else:
