@@ -364,6 +364,7 @@ MS_INTERNAL int ms_conv2d_actbwd(const float* in, const float* in2, float* out, 
  * prologue, Cin a power of two in 16..128, H W % 4 == 0, no statistics, and at least one 64-pixel unit per CU.  ms_conv_k1s_enable(0 | 1) switches the choice off / on
  * for the process (A/B runs, the same-bits tests) and returns the previous setting; any other argument only reads it.  MS_CONV_K1S=0 in the environment: off. */
 MS_INTERNAL int ms_conv_k1s_enable(int on);
+MS_INTERNAL int ms_conv_k1s_would_run(int N, int Cin, int H, int W, int Cout, int epi_mode);      /* the choice for this shape (epi_mode 0 plain, 2 ConvTranspose GEMM, 4 residual tail) */
 MS_INTERNAL int ms_conv_ride_capacity(int N, int Hout, int Wout);
 MS_INTERNAL int ms_conv2d_ride(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                    int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,

@@ -239,6 +239,14 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
 }
 
 namespace ms { int& conv_k1s_switch() { static int on = []() { const char* e = getenv("MS_CONV_K1S"); return (e && atoi(e) == 0) ? 0 : 1; }(); return on; } }
+// whether ms_conv2d (epi_mode 0 / 2) / ms_conv1x1_bnres (epi_mode 4; 5 = half-resolution input) would take the streaming kernel for this 1x1 shape (16-byte aligned fp32 tensors assumed)
+extern "C" int ms_conv_k1s_would_run(int N, int Cin, int H, int W, int Cout, int epi_mode) {
+  if (N < 1 || Cin < 1 || H < 1 || W < 1 || Cout < 1) return 0;
+  ConvArgs a{};
+  a.N = N; a.Cin = Cin; a.Hs = a.Hin = a.Hout = H; a.Ws = a.Win = a.Wout = W; a.cout_real = Cout; a.Cout = (epi_mode == 2) ? 4 * Cout : Cout;
+  a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (a.Cout + 63) / 64 * 64; a.epi_mode = epi_mode;
+  return conv_k1s_eligible(a, 1, 1, FETCH_NORMAL) ? 1 : 0;
+}
 extern "C" int ms_conv_k1s_enable(int on) { const int was = conv_k1s_switch(); if (on == 0 || on == 1) conv_k1s_switch() = on; return was; }
 
 extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,

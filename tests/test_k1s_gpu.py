@@ -15,7 +15,9 @@ def _rand(shape, seed, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
-SHAPES = [(16, 16, 16, 64, 64), (4, 64, 64, 96, 80), (2, 128, 256, 96, 96), (3, 32, 16, 100, 84), (16, 64, 128, 40, 40), (5, 16, 32, 66, 62), (2, 128, 64, 90, 92)]
+# streamed shapes (asserted below): unit counts with a ragged last unit (H W % 64 != 0), several units per wave, 1 - 4 channel blocks, both channel counts; and two
+# shapes that stay on the tiled kernel (the switch must be a no-op there)
+SHAPES = [(16, 64, 64, 64, 64), (16, 64, 64, 160, 160), (8, 128, 256, 64, 48), (16, 64, 128, 48, 48), (16, 64, 64, 66, 62), (16, 128, 64, 90, 92), (3, 32, 16, 100, 84), (16, 16, 16, 64, 64)]
 
 
 @pytest.fixture(scope="module")
@@ -56,6 +58,8 @@ def test_streaming_1x1_same_bits_as_tiled(dev, k1s, N, Cin, Cout, H, W):
         out = torch.full_like(uu, float("nan"))
         check(lib.ms_conv1x1_bnres(x.data_ptr(), out.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, uu.data_ptr(), coef.data_ptr(), 0.2, up2, st), "ms_conv1x1_bnres")
         return out
+    if Cin >= 64:
+        assert lib.ms_conv_k1s_would_run(N, Cin, H, W, Cout, 0) == 1 and lib.ms_conv_k1s_would_run(N, Cin, H, W, Cout, 4) == 1, "this shape is meant to be streamed"
     lib.ms_conv_k1s_enable(1)
     a0, a1, a2 = plain(), tail(0), tail(1)
     lib.ms_conv_k1s_enable(0)
@@ -71,7 +75,7 @@ def test_streaming_1x1_same_bits_as_tiled(dev, k1s, N, Cin, Cout, H, W):
     assert rel(a2, t2) < 3e-6
 
 
-@pytest.mark.parametrize("N,Cin,Cout,H,W", [(16, 16, 16, 128, 128), (4, 64, 128, 80, 80)])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(16, 64, 64, 128, 128), (8, 64, 128, 80, 80), (16, 16, 16, 128, 128)])
 def test_streaming_1x1_rider_and_cross_workgroup_finalize(dev, k1s, N, Cin, Cout, H, W):
     """The side jobs travel on the streaming kernel as they do on the tiled one: the rider's records (ms_bn_bwd_coefs / ms_bn_finalize arithmetic) and the residual tail
     whose BatchNorm coefficients are derived inside the launch from the statistics table of the conv in front (`_xfin`): same bits as the separate launches."""
@@ -121,6 +125,7 @@ def test_streaming_1x1_conv_transpose_gemm_same_bits(dev, k1s, N, Cin, Cout, H, 
     st = torch.cuda.current_stream().cuda_stream
     x = _rand((N, Cin, H, W), 1).to(dev)
     w = _rand((Cin, Cout, 2, 2), 2, 0.2); b = _rand((Cout,), 3)
+    assert lib.ms_conv_k1s_would_run(N, Cin, H, W, Cout, 2) == 1
     wp = ops.pack_convT_weight(w.to(dev)); bd = b.to(dev)
     ref = F.conv_transpose2d(x.cpu().double(), w.double(), b.double(), stride=2)
 
