@@ -38,6 +38,12 @@ python tools/make_traffic.py $O/${R}_traffic_style.json gpurun_out/pmc_conv_$R $
 python tools/parity_report.py r4 > $O/${R}_parity_report.txt 2>&1
 python tools/ab_wino_nt.py c2 > $O/${R}_wino_ab_c2.txt 2>&1
 python tools/ab_wino_nt.py c4 10 > $O/${R}_wino_ab_c4.txt 2>&1
+# 5d. round 4: the sub-pixel and 1x1 kernels against their first generations, the trainer's phases
+python tools/ab_subpix.py c4 10 > $O/${R}_subpix_ab_c4.txt 2>&1
+python tools/ab_subpix.py c2 10 > $O/${R}_subpix_ab_c2.txt 2>&1
+python tools/ab_k1.py c4 10 > $O/${R}_k1_ab_c4.txt 2>&1
+python tools/ab_k1.py c2 10 > $O/${R}_k1_ab_c2.txt 2>&1
+python tools/train_timeline.py 10 > $O/${R}_train_timeline.txt 2>&1
 # 6. un-profiled bench lines
 python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
 python bench.py --config c4 --steps 10 --warmup 2 > $O/${R}_bench_c4.json 2> $O/bench_c4.err
