@@ -363,6 +363,11 @@ MS_INTERNAL int ms_conv2d_actbwd(const float* in, const float* in2, float* out, 
  * channels are accumulated in the tiled kernel's order: same bits).  Chosen by ms_conv2d / ms_conv2d_ride / ms_conv1x1_bnres(_xfin) themselves for fp32 storage, no
  * prologue, Cin a power of two in 16..128, H W % 4 == 0, no statistics, and at least one 64-pixel unit per CU.  ms_conv_k1s_enable(0 | 1) switches the choice off / on
  * for the process (A/B runs, the same-bits tests) and returns the previous setting; any other argument only reads it.  MS_CONV_K1S=0 in the environment: off. */
+/* Second generation of the 3x3 stride-2 forward conv (csrc/ms_conv_s2.h: LDS-DMA staging, 64-bit A-fragment reads of the interleaved patch, 1 / 2 / 4 channel blocks per
+ * staged patch, 4 x 4-block work items on small outputs), taken by ms_conv2d(ks 3, stride 2) itself for fp32 storage without prologue / statistics.  Same products per output
+ * element; the 4-channel groups are accumulated in ascending order (the first generation's order where it uses 4-channel chunks).  ms_conv_s2g2_enable(0 | 1): off / on for
+ * the process, returns the previous setting.  MS_CONV_S2G2=0 in the environment: off. */
+MS_INTERNAL int ms_conv_s2g2_enable(int on);
 MS_INTERNAL int ms_conv_k1s_enable(int on);
 MS_INTERNAL int ms_conv_k1s_would_run(int N, int Cin, int H, int W, int Cout, int epi_mode);      /* the choice for this shape (epi_mode 0 plain, 2 ConvTranspose GEMM, 4 residual tail) */
 MS_INTERNAL int ms_conv_ride_capacity(int N, int Hout, int Wout);

@@ -465,6 +465,38 @@ def test_subpixel_generations_same_bits(dev, N, Cin, Cout, Hs, Ws, mode):
         assert rel(res[flags][2], res[FIRST][2]) < 2e-5
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(16, 512, 512, 40, 40), (16, 64, 64, 64, 64), (4, 128, 96, 80, 80), (3, 32, 48, 36, 72), (2, 20, 16, 18, 40), (16, 16, 16, 64, 128),
+                                            (5, 64, 160, 24, 24), (16, 128, 128, 32, 32)])
+def test_stride2_conv_second_generation(dev, N, Cin, Cout, H, W):
+    """3x3 stride-2 forward conv (res_convdown.down, encoder_decoder.py:40), second generation (csrc/ms_conv_s2.h) against fp64 math and against the first generation
+    (same products; the order of the 4-channel groups can differ where the first generation uses 8-channel chunks: rounding level).  Shapes: both work-item geometries
+    (tiles / 4 x 4 blocks: small outputs), 1 / 2 / 4 channel blocks, partial tiles and blocks (Hout % 4 != 0), channel counts that are not multiples of 16."""
+    from maxstyle_amd import ops
+    from maxstyle_amd._lib import lib, check
+    st = torch.cuda.current_stream().cuda_stream
+    x = _rand((N, Cin, H, W), 1).to(dev)
+    w = _rand((Cout, Cin, 3, 3), 2, 0.1); b = _rand((Cout,), 3)
+    ref = F.conv2d(x.cpu().double(), w.double(), b.double(), stride=2, padding=1)
+    wp = ops.pack_conv_weight(w.to(dev)); bd = b.to(dev)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+
+    def run():
+        out = torch.full((N, Cout, Ho, Wo), float("nan"), device=dev)
+        check(lib.ms_conv2d(x.data_ptr(), 0, out.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, 3, 2, 0, 0, 0, 0, 0, 0, 1, 1.0, 0, 0, st), "ms_conv2d(s2)")
+        return out
+    was = lib.ms_conv_s2g2_enable(1)
+    try:
+        new = run()
+        lib.ms_conv_s2g2_enable(0)
+        old = run()
+    finally:
+        lib.ms_conv_s2g2_enable(was)
+    assert rel(old, ref) < 3e-6
+    assert rel(new, ref) < 3e-6
+    assert rel(new, old) < 2e-6
+    assert torch.equal(new, run())              # and deterministic
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W,pro", [(2, 16, 1, 32, 64, 2), (16, 16, 1, 256, 256, 2), (2, 64, 3, 40, 72, 2), (1, 7, 2, 19, 20, 0), (3, 16, 4, 16, 128, 0)])
 def test_small_cout_conv(dev, N, Cin, Cout, H, W, pro):
     """ms_conv3x3_small_cout (vector-ALU 3x3 conv for <= 4 output channels: the data-gradient to the image) vs fp64 math and vs ms_conv2d."""

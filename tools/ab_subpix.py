@@ -53,7 +53,7 @@ def main():
             flop = 2.0 * N * Ho * Ho * Cout * Cin * 9
 
             def run(flags=0):
-                check(lib.ms_conv2d(x.data_ptr(), 0, out.data_ptr(), wp.data_ptr(), 0, N, Cin, Hs, Ws, Cout, 3, 2, 0, 0, 0, 0, 0, 0, 4, 1.0, 0, stats.data_ptr(), st), "ms_conv2d")
+                check(lib.ms_conv2d(x.data_ptr(), 0, out.data_ptr(), wp.data_ptr(), 0, N, Cin, Hs, Ws, Cout, 3, 2, 0, 0, 0, 0, 0, 0, 4, 1.0, 0, 0, st), "ms_conv2d")      # (as the engine calls it: bias-free here, no statistics)
         else:
             mode = 0 if kind == "up" else 1
             Ho = 2 * Hs
@@ -84,10 +84,12 @@ def main():
                 else:
                     def run(flags=0):
                         check(lib.ms_conv_subpix2(x.data_ptr(), out.data_ptr(), wp.data_ptr(), 0, 0, N, Cin, Hs, Ws, Cout, 1, 0, 0, 0, 0, 1.0, 0, flags, st), "ms_conv_subpix2")
-        variants = [("", 0)] if kind == "s2" else [("gen1", 1), ("tiles", 2), ("blocks", 4), ("auto", 0)]
+        variants = [("gen1", -1), ("gen2", -2), ("gen1", -1), ("gen2", -2)] if kind == "s2" else [("gen1", 1), ("tiles", 2), ("blocks", 4), ("auto", 0)]
         line = f"{idx:2d} {kind:4s} {N}x{Cin}x{Hs}x{Ws} -> {Cout:4d} "
         sums0 = None
         for vname, flags in variants:
+            if flags < 0:                      # the stride-2 forward: a process-wide switch, not a per-call flag
+                lib.ms_conv_s2g2_enable(1 if flags == -2 else 0)
             out.zero_()
             for _ in range(3):
                 run(flags)
@@ -105,6 +107,7 @@ def main():
             if sums0 is None:
                 sums0 = cs
             line += f" | {vname} {us:7.1f} us {flop / PEAK / (us * 1e-6):.3f}{same}"
+        lib.ms_conv_s2g2_enable(1)
         print(line + f"   out {sums0:012x}", flush=True)
 
 
