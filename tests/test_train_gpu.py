@@ -327,12 +327,19 @@ def test_no_grad_forward_and_double_backward_guard(dev):
 
 
 def test_training_pass_full_size_vs_oracle(dev):
-    """BASELINE config-2 batch (16x1x256x256): standard_training forward + backward against the fp32 CPU oracle (autograd over the functional
-    forward; about half a minute of host time).  At this size a mask flip is 1 pixel in ~1e6, so the whole-pass tolerance can be tighter."""
+    """BASELINE config-2 batch (16x1x256x256): standard_training forward + backward against the CPU oracle (autograd over the functional forward) in fp32 AND fp64
+    (about half a minute of host time).  Forward quantities: tight.  Parameter gradients: every fp32 forward is ~5e-6 away from the fp64 one at the top level (the fp32
+    oracle too), ~13 LeakyReLU masks per 16.7 M-element tensor flip, and a flipped mask changes that element's gradient by 80 % - WHICH masks flip depends on the order in
+    which the forward accumulates its products.  Measured over six input seeds x the two accumulation orders of the stride-2 convs (8- and 4-channel chunks, both in the
+    first-generation kernel; tools/dbg_train_seeds.py, profiles/r04_experiments.txt 12): worst parameter in the max norm 3.3e-3 .. 3.1e-2 (outliers on the 16 x 16-pixel
+    layers: down4, code_decoupler), in the L2 norm 1.7e-3 .. 7.7e-3; the fp32 ORACLE against the fp64 one: 1.9e-3 .. 5.2e-3 / 0.9e-3 .. 2.5e-3.  So the bar on the L2
+    norm is 2e-2 (2.6x the worst draw seen, 8x the reference side's own worst) and 8e-2 on the max norm; the backward kernels themselves are held to fp64 at a size where
+    no mask flips (test_training_pass_gradients_vs_oracle) and one by one (test_conv_gpu, test_wgrad_gpu)."""
     from oracle import maxstyle_oracle as orc
     from oracle import outer_oracle as outer
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     o32 = oracle_pass_grads(torch.float32, 16, 256, True)
+    o64 = oracle_pass_grads(torch.float64, 16, 256, True)
     S, W = make_solver(dev, orc.NetSpec(4, 1, 4))
     S.reset_all_optimizers()
     out = S.standard_training(o32["clean"].to(dev), o32["lab"].to(dev), perturbed_image=o32["image_l"].to(dev), disable_track_bn_stats=False, return_output=True)
@@ -340,19 +347,25 @@ def test_training_pass_full_size_vs_oracle(dev):
     assert abs(float(seg.detach()) - o32["seg"]) < 3e-5 * abs(o32["seg"]) + 1e-6
     assert abs(float(rec.detach()) - o32["rec"]) < 3e-5 * abs(o32["rec"]) + 1e-7
     assert rel(S.z_i, o32["z_i"]) < 5e-5 and rel(recon, o32["recon"]) < 5e-5 and rel(y0, o32["logits"]) < 2e-4
+    # ... and no further from the fp64 forward than 3x the fp32 oracle is
+    for got, key in ((S.z_i, "z_i"), (recon, "recon"), (y0, "logits")):
+        assert rel(got.cpu().double(), o64[key]) < 3.0 * rel(o32[key].double(), o64[key]) + 1e-6, key
     (seg + rec).backward()
-    worst = ("", 0.0)
+    worst_max, worst_l2 = ("", 0.0), ("", 0.0)
     for net in outer.NETS:
         for k, p in S.model[net].named_parameters():
             key = f"{net}/{k}"
-            ref = o32["grads"][key]
+            ref = o64["grads"][key]
             if ref is None or outer.is_null_grad_bias(net, k):
                 continue
-            err = rel(p.grad, ref)
-            if err > worst[1]:
-                worst = (key, err)
-            assert err < 1e-2, (key, err)
-    print("worst gradient error at full size", worst)
+            g = p.grad.detach().cpu().double()
+            e_max, e_l2 = rel(g, ref), float((g - ref).norm() / ref.norm())
+            if e_max > worst_max[1]:
+                worst_max = (key, e_max)
+            if e_l2 > worst_l2[1]:
+                worst_l2 = (key, e_l2)
+            assert e_l2 < 2e-2 and e_max < 8e-2, (key, e_l2, e_max)
+    print("worst gradient error at full size vs fp64: max norm", worst_max, " L2", worst_l2)
 
 
 @pytest.mark.parametrize("graph_passes", ["0", "1"], ids=["eager_passes", "graph_passes"])
