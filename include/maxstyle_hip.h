@@ -368,6 +368,10 @@ MS_INTERNAL int ms_conv2d_actbwd(const float* in, const float* in2, float* out, 
  * element; the 4-channel groups are accumulated in ascending order (the first generation's order where it uses 4-channel chunks).  ms_conv_s2g2_enable(0 | 1): off / on for
  * the process, returns the previous setting.  MS_CONV_S2G2=0 in the environment: off. */
 MS_INTERNAL int ms_conv_s2g2_enable(int on);
+/* LDS-tiled GEMM form of the 1x1 convolutions with >= 256 input channels (csrc/ms_conv_k1g.h: 64-pixel units of a flattened (image, unit) list, LDS-DMA staging, 1 / 2 / 4
+ * sixteen-channel blocks per staged tile; plain and residual-tail epilogues, rider, cross-workgroup finalize; same bits as the tiled kernel), chosen by the 1x1 entry points
+ * themselves.  ms_conv_k1g_enable(0 | 1): off / on for the process, returns the previous setting.  MS_CONV_K1G=0 in the environment: off. */
+MS_INTERNAL int ms_conv_k1g_enable(int on);
 MS_INTERNAL int ms_conv_k1s_enable(int on);
 MS_INTERNAL int ms_conv_k1s_would_run(int N, int Cin, int H, int W, int Cout, int epi_mode);      /* the choice for this shape (epi_mode 0 plain, 2 ConvTranspose GEMM, 4 residual tail) */
 MS_INTERNAL int ms_conv_ride_capacity(int N, int Hout, int Wout);

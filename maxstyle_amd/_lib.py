@@ -84,6 +84,7 @@ SIGNATURES = {
     "ms_conv2d": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                           c_int, c_f32p, c_f32p, c_f32p, c_int, c_int, c_float, c_int, c_f32p, c_void]),
     "ms_conv_s2g2_enable": (c_int, [c_int]),
+    "ms_conv_k1g_enable": (c_int, [c_int]),
     "ms_conv_k1s_enable": (c_int, [c_int]),
     "ms_conv_k1s_would_run": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "ms_conv_ride_capacity": (c_int, [c_int, c_int, c_int]),

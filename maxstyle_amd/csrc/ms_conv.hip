@@ -26,6 +26,7 @@
 #include "ms_conv_wide.h"
 #include "ms_conv_k1s.h"
 #include "ms_conv_s2.h"
+#include "ms_conv_k1g.h"
 #include "maxstyle_hip.h"
 
 namespace ms {
@@ -235,6 +236,7 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   if (allow_wide && conv_wide_eligible(a, ks, stride, fetch, vec)) return conv_dispatch_wide(a, nt, st);
   if (ks == 3 && stride == 1) return conv_dispatch_k3s1(a, fetch, nt, vec, narrow, use_in2, st);
   if (ks == 1 && allow_wide && conv_k1s_eligible(a, ks, stride, fetch)) return conv_dispatch_k1s(a, st);      // streaming form (ms_conv_k1s.h)
+  if (ks == 1 && allow_wide && conv_k1g_eligible(a, ks, stride, fetch)) return conv_dispatch_k1g(a, st);      // LDS-tiled GEMM form of the channel-heavy levels (ms_conv_k1g.h)
   if (ks == 1) return conv_dispatch_k1s1(a, nt, vec, narrow, use_in2, st);
   if (allow_wide && conv_s2g2_eligible(a, ks, stride, fetch)) return conv_dispatch_s2g2(a, st);      // second generation (ms_conv_s2.h)
   return conv_dispatch_s2(a, ks, nt, vec, narrow, st);
@@ -250,6 +252,8 @@ extern "C" int ms_conv_k1s_would_run(int N, int Cin, int H, int W, int Cout, int
   return conv_k1s_eligible(a, 1, 1, FETCH_NORMAL) ? 1 : 0;
 }
 namespace ms { int& conv_s2g2_switch() { static int on = []() { const char* e = getenv("MS_CONV_S2G2"); return (e && atoi(e) == 0) ? 0 : 1; }(); return on; } }
+namespace ms { int& conv_k1g_switch() { static int on = []() { const char* e = getenv("MS_CONV_K1G"); return (e && atoi(e) == 0) ? 0 : 1; }(); return on; } }
+extern "C" int ms_conv_k1g_enable(int on) { const int was = conv_k1g_switch(); if (on == 0 || on == 1) conv_k1g_switch() = on; return was; }
 extern "C" int ms_conv_s2g2_enable(int on) { const int was = conv_s2g2_switch(); if (on == 0 || on == 1) conv_s2g2_switch() = on; return was; }
 extern "C" int ms_conv_k1s_enable(int on) { const int was = conv_k1s_switch(); if (on == 0 || on == 1) conv_k1s_switch() = on; return was; }
 

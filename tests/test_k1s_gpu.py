@@ -140,3 +140,57 @@ def test_streaming_1x1_conv_transpose_gemm_same_bits(dev, k1s, N, Cin, Cout, H, 
     lib.ms_conv_k1s_enable(1)
     assert rel(a, ref) < 3e-6
     assert torch.equal(a, t)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(16, 512, 512, 20, 20), (16, 256, 512, 40, 40), (3, 256, 80, 18, 22), (16, 512, 256, 20, 20), (2, 320, 48, 64, 64), (16, 256, 16, 8, 8)])
+def test_lds_tiled_1x1_gemm_same_bits_as_tiled(dev, N, Cin, Cout, H, W):
+    """LDS-tiled GEMM form of the channel-heavy 1x1 convolutions (csrc/ms_conv_k1g.h) against the tiled kernel: same bits for the plain conv and the residual tail, the
+    rider's records and the in-launch BatchNorm finalize of the tail unchanged; against fp64 math.  Shapes: ragged units (H W % 64 != 0), channel counts that are not
+    multiples of 16 / 64, 1 / 2 / 4 channel blocks per tile, fewer work items than CUs."""
+    from maxstyle_amd import ops
+    from maxstyle_amd._lib import lib, check
+    st = torch.cuda.current_stream().cuda_stream
+    x = _rand((N, Cin, H, W), 1).to(dev)
+    w = _rand((Cout, Cin, 1, 1), 2, 0.1); b = _rand((Cout,), 3)
+    wp = ops.pack_conv_weight(w.to(dev)); bd = b.to(dev)
+    ref = F.conv2d(x.cpu().double(), w.double(), b.double())
+    u = _rand((N, Cout, H, W), 5).to(dev)
+    coef = torch.stack([_rand((Cout,), 8).abs() + 0.5, _rand((Cout,), 9), _rand((Cout,), 10) * 0.1, torch.rand(Cout) + 0.5], dim=1).contiguous().to(dev)
+    # statistics table for the `_xfin` tail: from a 3x3 conv at the same resolution
+    w3 = _rand((Cout, 16, 3, 3), 4, 0.1)
+    x3 = _rand((N, 16, H, W), 6).to(dev)
+    u3 = torch.empty(N, Cout, H, W, device=dev)
+    stats, parts = ops.conv_stats_buffer(N, Cout, H, W, dev)
+    check(lib.ms_conv2d(x3.data_ptr(), 0, u3.data_ptr(), ops.pack_conv_weight(w3.to(dev)).data_ptr(), 0, N, 16, H, W, Cout, 3, 1, 0, 0, 0, 0, 0, 0, 1, 1.0, 0, stats.data_ptr(), st), "conv3x3")
+    gamma, beta = (_rand((Cout,), 11).abs() + 0.5).to(dev), _rand((Cout,), 12).to(dev)
+
+    def run_all():
+        plain = torch.full((N, Cout, H, W), float("nan"), device=dev)
+        check(lib.ms_conv2d(x.data_ptr(), 0, plain.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0, 0, 0, st), "ms_conv2d")
+        tail = torch.full_like(plain, float("nan"))
+        check(lib.ms_conv1x1_bnres(x.data_ptr(), tail.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, u.data_ptr(), coef.data_ptr(), 0.2, 0, st), "ms_conv1x1_bnres")
+        xt = torch.full_like(plain, float("nan"))
+        coef2 = torch.zeros(Cout, 4, device=dev)
+        gran = torch.zeros(int(lib.ms_xfin_gran_bytes(Cout)), dtype=torch.uint8, device=dev)
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(lib.ms_conv1x1_bnres_xfin(x.data_ptr(), xt.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, u3.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5,
+                                        coef2.data_ptr(), gran.data_ptr(), err.data_ptr(), 0.2, 0, st), "ms_conv1x1_bnres_xfin")
+        assert int(err.item()) == 0
+        out4 = torch.zeros(Cout, 4, device=dev)
+        rid = torch.full_like(plain, float("nan"))
+        check(lib.ms_conv2d_ride(x.data_ptr(), 0, rid.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0, 0, 0,
+                                 1, stats.data_ptr(), 0, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.0, out4.data_ptr(), Cout, st), "ms_conv2d_ride")
+        u2 = _rand((N, Cout, 2 * H, 2 * W), 13).to(dev)
+        up = torch.full_like(u2, float("nan"))
+        check(lib.ms_conv1x1_bnres(x.data_ptr(), up.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, u2.data_ptr(), coef.data_ptr(), 0.2, 1, st), "ms_conv1x1_bnres(up2)")
+        return plain, tail, xt, coef2, rid, out4, up
+    was = lib.ms_conv_k1g_enable(1)
+    try:
+        new = run_all()
+        lib.ms_conv_k1g_enable(0)
+        old = run_all()
+    finally:
+        lib.ms_conv_k1g_enable(was)
+    assert rel(new[0], ref) < 3e-6
+    for a_, b_, what in zip(new, old, ("plain", "tail", "xfin tail", "xfin records", "rider conv", "rider records", "half-resolution tail")):
+        assert torch.equal(a_, b_), what

@@ -12,7 +12,9 @@ from maxstyle_amd._lib import lib, check
 # (kind, Cin, Cout, H, W): kind "tail" = ms_conv1x1_bnres, "up2" = ... with the input at half resolution (H, W = input size), "plain" = ms_conv2d
 SHAPES = {
     "c4": [("tail", 64, 64, 320, 320), ("up2", 64, 64, 160, 160), ("tail", 64, 128, 160, 160), ("tail", 128, 256, 80, 80), ("up2", 128, 64, 80, 80),
-           ("convT", 64, 64, 160, 160), ("plain", 64, 64, 320, 320), ("plain", 128, 64, 160, 160), ("plain", 64, 64, 160, 160), ("plain", 64, 128, 80, 80), ("plain", 128, 256, 40, 40)],
+           ("convT", 64, 64, 160, 160), ("plain", 64, 64, 320, 320), ("plain", 128, 64, 160, 160), ("plain", 64, 64, 160, 160), ("plain", 64, 128, 80, 80), ("plain", 128, 256, 40, 40),
+           # the channel-heavy levels (LDS-tiled GEMM form, csrc/ms_conv_k1g.h)
+           ("tail", 256, 512, 40, 40), ("tail", 512, 512, 20, 20), ("plain", 512, 512, 20, 20), ("plain", 512, 256, 40, 40), ("plain", 256, 128, 80, 80), ("plain", 256, 512, 20, 20)],
     "c2": [("tail", 16, 16, 256, 256), ("tail", 16, 32, 128, 128), ("tail", 32, 64, 64, 64), ("tail", 64, 128, 32, 32), ("up2", 32, 16, 64, 64), ("up2", 64, 32, 32, 32),
            ("plain", 16, 16, 256, 256), ("plain", 16, 16, 128, 128), ("plain", 32, 16, 128, 128), ("plain", 64, 32, 64, 64), ("plain", 16, 32, 64, 64)],
 }
@@ -50,7 +52,7 @@ def main():
                 check(lib.ms_conv1x1_bnres(x.data_ptr(), out.data_ptr(), wp.data_ptr(), b.data_ptr(), N, Cin, H, W, Cout, u.data_ptr(), coef.data_ptr(), 0.2, 1 if kind == "up2" else 0, st), "bnres")
         line, outs = f"{kind:5s} {Cin:4d}->{Cout:4d} @{H}x{W}  {nbytes / 1e6:8.1f} MB ", []
         for on in (0, 1, 0, 1):
-            lib.ms_conv_k1s_enable(on)
+            lib.ms_conv_k1s_enable(on); lib.ms_conv_k1g_enable(on)
             for _ in range(5):
                 run()
             torch.cuda.synchronize()
@@ -63,7 +65,7 @@ def main():
             us = ts[len(ts) // 2]
             outs.append(out.clone())
             line += f" | {'stream' if on else 'tiled '} {us:7.1f} us {nbytes / 8e12 / (us * 1e-6):.2f}"
-        lib.ms_conv_k1s_enable(1)
+        lib.ms_conv_k1s_enable(1); lib.ms_conv_k1g_enable(1)
         print(line + ("   same bits" if torch.equal(outs[0], outs[1]) else "   DIFFERENT BITS"), flush=True)
 
 
