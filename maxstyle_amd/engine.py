@@ -336,6 +336,7 @@ class InnerLoopEngine:
             mfma_bf16 = os.environ.get("MS_MFMA_DTYPE", "").lower() in ("bf16", "bfloat16")
         self.mfma_bf16 = bool(mfma_bf16) and self.bf16
         self.buf: Dict[str, torch.Tensor] = {}
+        self._stage = {}                    # pinned host staging buffers of _upload: key -> [buffer, event of the last copy queued from it]
         self.nets: Optional[PackedNets] = None
         self.styles: Dict[int, StyleSlot] = {}
         self.layers: List[int] = []
@@ -1255,13 +1256,33 @@ class InnerLoopEngine:
         s = self.styles[i]
         return self.flat_g[o:o + n].view(s.B, s.C if name != "lmda" else 1, 1, 1)
 
+    def _upload(self, key, src, dst):
+        """dst (engine-owned device tensor) <- src.  A host tensor travels through an engine-owned PINNED buffer with a non-blocking copy: `src.to(device)` from pageable
+        memory makes the host wait until the stream has drained (13 such copies per generate_max_style_image call: the host could not queue anything behind a call that
+        was still running, and the GPU idled ~1 ms per call between its launches - profiles/r04_experiments.txt 15).  An event per buffer guards its reuse."""
+        src = torch.as_tensor(src)
+        if src.is_cuda:
+            dst.copy_(src.to(dst.dtype).reshape(dst.shape))
+            return
+        st = self._stage.get(key)
+        if st is None or st[0].numel() != dst.numel() or st[0].dtype != dst.dtype:
+            st = [torch.empty(dst.numel(), dtype=dst.dtype, pin_memory=True), None]
+            self._stage[key] = st
+        if st[1] is not None:
+            st[1].synchronize()                      # (the copy queued from this buffer by the previous call has run)
+        st[0].copy_(src.detach().reshape(-1))        # host-side conversion + memcpy
+        dst.view(-1).copy_(st[0], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st[1] = ev
+
     def set_style_state(self, i, perm, lmda, gamma_noise, beta_noise):
         s = self.styles[i]
         s.perm = self.t(f"st{i}.perm", s.B, dtype=torch.int64)      # engine-owned: a captured graph keeps its address
-        s.perm.copy_(torch.as_tensor(perm).to(device=self.dev, dtype=torch.int64))
-        self.param(i, "lmda").copy_(torch.as_tensor(lmda).to(self.dev, F32).view(s.B, 1, 1, 1))
-        self.param(i, "gamma_noise").copy_(torch.as_tensor(gamma_noise).to(self.dev, F32).view(s.B, s.C, 1, 1))
-        self.param(i, "beta_noise").copy_(torch.as_tensor(beta_noise).to(self.dev, F32).view(s.B, s.C, 1, 1))
+        self._upload(f"st{i}.perm", perm, s.perm)
+        self._upload(f"st{i}.lmda", lmda, self.param(i, "lmda"))
+        self._upload(f"st{i}.gamma_noise", gamma_noise, self.param(i, "gamma_noise"))
+        self._upload(f"st{i}.beta_noise", beta_noise, self.param(i, "beta_noise"))
 
     def style_fwd(self, i, x, store=True):
         """store=False: statistics and coefficients only (y = NULL) - the caller's next kernel applies the layer itself; returns None then."""

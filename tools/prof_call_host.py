@@ -1,5 +1,5 @@
-"""A few generate_max_style_image calls at config 2 through the drop-in API (for rocprofv3 --kernel-trace: tools/prof_call_gaps.py reads the trace)."""
-import os, sys
+"""cProfile of the host side of generate_max_style_image (config 2, deferred error check)."""
+import os, sys, cProfile, pstats
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import maxstyle_amd as M
@@ -14,7 +14,13 @@ cfg = {"mix_style": True, "no_noise": False, "lr": 0.1, "n_iter": 5, "mix_learna
 S.eval()
 with torch.no_grad():
     z_i, _ = S.encode_image(clean, disable_track_bn_stats=True)
-for it in range(8):
+for it in range(5):
     out = S.generate_max_style_image_from_config(z_i, cfg, clean, lab, p=1.5)
-    torch.cuda.synchronize()
-print("done")
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for it in range(20):
+    out = S.generate_max_style_image_from_config(z_i, cfg, clean, lab, p=1.5)
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(28)
