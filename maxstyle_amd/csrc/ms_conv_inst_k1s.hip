@@ -5,7 +5,7 @@ template <int NT, int EPI>
 static int k1s_ncg(const ConvArgs& a, hipStream_t st) {
   const int ncg = a.cin_pad / 4;
   if (ncg == 4) return launch_conv_k1s_t<NT, EPI, 4>(a, st);
-  if (ncg == 8) return launch_conv_k1s_t<NT, EPI, 8>(a, st);
+  if (ncg == 8 || kK1sD == 8) return launch_conv_k1s_t<NT, EPI, 8>(a, st);
   return launch_conv_k1s_t<NT, EPI, 16>(a, st);
 }
 template <int NT>

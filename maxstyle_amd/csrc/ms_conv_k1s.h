@@ -18,7 +18,10 @@
 
 namespace ms {
 
-constexpr int kK1sD = 16;                    // loads in flight per wave
+#ifndef MS_K1S_D
+#define MS_K1S_D 16
+#endif
+constexpr int kK1sD = MS_K1S_D;              // loads in flight per wave (8: measured no better, profiles/r04_experiments.txt 16)
 constexpr int kK1sOob = (int)0x80000000;
 
 // EPI: 0 plain | 2 ConvTranspose2d(k=2, s=2) as a GEMM with 4 Cout columns (NT = 4: column block q = (dy, dx) of 16 output channels; out[n, co, 2y+dy, 2x+dx]) |
