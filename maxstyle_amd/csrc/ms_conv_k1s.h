@@ -8,7 +8,9 @@
 //     group g is the A fragment of four M-tiles at once (M-tile t = pixels {4i + t});
 //   * a ring of D = 16 such loads per wave is kept in flight across units (15 KB per wave, ~120 KB per CU), the MFMAs of group g run while group g + 15 is fetched;
 //   * the weight slice [Cin][16 NT] sits in LDS for the life of the workgroup (B fragments: one ds_read_b32 per MFMA column block);
-//   * the accumulator layout gives every lane 16 consecutive pixels of one output channel: the epilogue (plain + bias, or the residual tail
+//   * M row 4k + r of tile t is pixel 4k + 16r + t of the unit (lane m loads its 16 bytes at pixel 4 (m >> 2) + 16 (m & 3)): in the accumulator layout the four k-lanes of
+//     an output channel then hold ADJACENT pixel quads, so every 16-byte store / u load instruction covers 64 contiguous bytes per channel (with the natural mapping,
+//     pixel 4m + t, the quads of a store sat 64 bytes apart: 0.52 -> 0.61 of HBM on the dominant shape, profiles/r04_experiments.txt 17); the epilogue (plain + bias, or the residual tail
 //     out = lrelu((sc u + sh) + (acc + bias)) at the same or at twice the resolution) reads / writes 16-byte pieces, 64 contiguous bytes per lane.
 // The channels are accumulated in the first generation's order (g ascending, one v_mfma_f32_16x16x4_f32 per group): same bits.
 // Carries the same side jobs as the first generation: the rider (ConvArgs::ride_*) and the cross-workgroup finalize of a residual tail (xf_*, epilogue kind).
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256, 2) void conv_k1s_kernel(const ConvArgs a) {
   // ---- load cursor: the unit / channel group the next issued load belongs to ----
   int l_u = first, l_cg = 0, l_soff = 0, l_voff = kK1sOob;
   auto l_set = [&]() {
-    const int n = l_u / upi, p0 = (l_u - n * upi) << 6, px = p0 + 4 * m;
+    const int n = l_u / upi, p0 = (l_u - n * upi) << 6, px = p0 + 4 * (m >> 2) + 16 * (m & 3);      // (M row m = 4k + r of tile t <-> pixel 4k + 16r + t: see the epilogue)
     l_voff = (l_u < U && px < HW) ? ((k * HW + px) << 2) : kK1sOob;
     l_soff = (n * a.Cin * HW) << 2;
   };
@@ -112,23 +114,23 @@ __global__ __launch_bounds__(256, 2) void conv_k1s_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // D layout of a 16x16 MFMA tile: this lane holds output channel m of pixels (rows) 4k + r of M-tile t, i.e. pixels p0 + 16k + 4r + t: 16 consecutive pixels
+  // D layout of a 16x16 MFMA tile: this lane holds output channel m of rows 4k + r of M-tile t, i.e. pixels p0 + 4k + 16r + t: quad r of the lane at pixel 4k + 16r
   // EPI 4 with Cin >= 64: the residual tail's u values of the unit being accumulated, requested at the head of the unit's LAST ring round (16 MFMA groups ahead of
   // their use) - every load of the epilogue in one batch and in front of its stores (which the compiler must assume to alias the later loads)
   float4 uu[(EPI == 4) ? NT : 1][4];
   auto fetch_u = [&](int u) {
-    const int n = u / upi, p0 = (u - n * upi) << 6, pl = p0 + 16 * k;
+    const int n = u / upi, p0 = (u - n * upi) << 6, pl = p0 + 4 * k;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const size_t pb = ((size_t)n * a.Cout + cb * COUT_TILE + j * 16 + m) * (size_t)HW;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        uu[(EPI == 4) ? j : 0][r] = (co_ok[j] && pl + 4 * r < HW) ? *reinterpret_cast<const float4*>(a.mk_u + pb + pl + 4 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+        uu[(EPI == 4) ? j : 0][r] = (co_ok[j] && pl + 16 * r < HW) ? *reinterpret_cast<const float4*>(a.mk_u + pb + pl + 16 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto epilogue = [&](int u) {
     const int n = u / upi, p0 = (u - n * upi) << 6;
-    const int pl = p0 + 16 * k;                                   // this lane's first pixel
+    const int pl = p0 + 4 * k;                                    // this lane's first pixel quad; quad r sits 16 r pixels on: the four k-lanes of a channel write 64 contiguous bytes per store
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv_k1s_kernel(const ConvArgs a) {
       const size_t pb = ((size_t)n * a.cout_real + cb * 16 + m) * (size_t)(4 * HW);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (co_ok[0] && pl + 4 * r < HW) {
+        if (co_ok[0] && pl + 16 * r < HW) {
 #pragma unroll
           for (int dy = 0; dy < 2; ++dy) {
             const size_t off = pb + (size_t)(2 * y + dy) * Wo + 2 * x;
@@ -150,8 +152,8 @@ __global__ __launch_bounds__(256, 2) void conv_k1s_kernel(const ConvArgs a) {
             *reinterpret_cast<float4*>(a.out + off + 4) = make_float4(acc[2][2 * dy][r], acc[2][2 * dy + 1][r], acc[3][2 * dy][r], acc[3][2 * dy + 1][r]);
           }
         }
-        x += 4;
-        if (x >= a.Ws) { x -= a.Ws; ++y; }
+        x += 16;
+        while (x >= a.Ws) { x -= a.Ws; ++y; }
       }
     } else if (EPI == 5) {
       // every value feeds a 2 x 2 block of outputs: (y, x) of the lane's pixel quads (a quad never crosses a row: Ws % 4 == 0)
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv_k1s_kernel(const ConvArgs a) {
       const int Wo = 2 * a.Ws;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (pl + 4 * r < HW) {
+        if (pl + 16 * r < HW) {
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             if (!co_ok[j]) continue;
@@ -179,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void conv_k1s_kernel(const ConvArgs a) {
             }
           }
         }
-        x += 4;
-        if (x >= a.Ws) { x -= a.Ws; ++y; }
+        x += 16;
+        while (x >= a.Ws) { x -= a.Ws; ++y; }
       }
     } else {
 #pragma unroll
@@ -190,14 +192,14 @@ __global__ __launch_bounds__(256, 2) void conv_k1s_kernel(const ConvArgs a) {
         const float sc = mk_sc[j], sh = mk_sh[j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (pl + 4 * r >= HW) continue;
+          if (pl + 16 * r >= HW) continue;
           float4 o = make_float4(acc[0][j][r], acc[1][j][r], acc[2][j][r], acc[3][j][r]);
           if (EPI == 4) {
             const float4 t = uu[(EPI == 4) ? j : 0][r];
             o.x = leaky((sc * t.x + sh) + o.x, a.mk_slope); o.y = leaky((sc * t.y + sh) + o.y, a.mk_slope);
             o.z = leaky((sc * t.z + sh) + o.z, a.mk_slope); o.w = leaky((sc * t.w + sh) + o.w, a.mk_slope);
           }
-          *reinterpret_cast<float4*>(a.out + pb + pl + 4 * r) = o;
+          *reinterpret_cast<float4*>(a.out + pb + pl + 16 * r) = o;
         }
       }
     }
