@@ -14,7 +14,8 @@
 //     out = lrelu((sc u + sh) + (acc + bias)) at the same or at twice the resolution) reads / writes 16-byte pieces, 64 contiguous bytes per lane.
 // The channels are accumulated in the first generation's order (g ascending, one v_mfma_f32_16x16x4_f32 per group): same bits.
 // Carries the same side jobs as the first generation: the rider (ConvArgs::ride_*) and the cross-workgroup finalize of a residual tail (xf_*, epilogue kind).
-// Eligibility (conv_k1s_eligible): fp32 storage, no prologue, Cin a power of two in 16 .. 128, H W % 4 == 0, plain or residual-tail epilogue, no statistics.
+// Eligibility (conv_k1s_eligible): fp32 storage, no prologue, Cin a power of two in 16 .. 128, H W % 4 == 0, plain / ConvTranspose / same-resolution residual-tail
+// epilogue, no statistics, at least four 64-pixel units per CU.
 #pragma once
 #include "ms_conv_kernel.h"
 
@@ -242,9 +243,10 @@ inline bool conv_k1s_eligible(const ConvArgs& a, int ks, int stride, int fetch) 
   if (a.epi_mode == 2 && (a.cout_real % 16 != 0 || a.Ws % 4 != 0 || a.xf_tab != nullptr)) return false;
   if (a.xf_tab != nullptr && (a.epi_mode == 0 || a.epi_mode == 2)) return false;                     // (a prologue-kind `_xfin`: there is no prologue here)
   const int C = a.Cin;
-  // measured (tools/ab_k1.py, profiles/r04_experiments.txt 8): the stream pays from 64 input channels up (64-channel output tiles: the tiled kernel's 205 registers allow
-  // one workgroup per CU); config 2's 16 .. 32-channel layers and the half-resolution tails keep the tiled kernel
-  if (C < 64 || C > 128 || (C & (C - 1)) != 0 || a.epi_mode == 5) return false;
+  // measured (tools/ab_k1.py, profiles/r04_experiments.txt 8, 17, 19): with the 64-byte store mapping the stream also beats the tiled kernel on config 2's 16 / 32-channel
+  // top levels (16 -> 16 @16x256x256 tail 39.8 -> 34.7 us = 0.73 of HBM); the half-resolution tails keep the tiled kernel
+  static const int cmin = []() { const char* e = getenv("MS_K1S_CMIN"); return e ? atoi(e) : 16; }();      // (A/B: 64 keeps config 2's 16 / 32-channel layers on the tiled kernel)
+  if (C < cmin || C > 128 || (C & (C - 1)) != 0 || a.epi_mode == 5) return false;
   const long HW = (long)a.Hs * a.Ws;
   if (HW % 4 != 0 || (a.epi_mode == 5 && a.Ws % 4 != 0)) return false;
   if (a.epi_mode == 5 && C == 16 && a.Cout > 32) return false;                // (the one instantiation whose ring does not stay in registers; no layer has this shape)
