@@ -117,9 +117,10 @@ ARG_CALLS = {
 
 def arg_case(dev, case, S=None):
     from maxstyle_amd import synthetic as syn
-    g = np.load(os.path.join(GOLDEN, "loop_args.npz"))
-    kw = dict(ARG_CALLS[case])
-    B, layers = 4, [3, 4, 5]
+    # "all6": every decoder layer, on the trained network (its own fixture, tests/golden/make_golden_r3.py all6)
+    g = np.load(os.path.join(GOLDEN, "loop_args_all6.npz" if case == "all6" else "loop_args.npz"))
+    kw = dict(ARG_CALLS.get(case, {}))
+    B, layers = 4, ([0, 1, 2, 3, 4, 5] if case == "all6" else [3, 4, 5])
     spec = syn.NetSpec(4, 1, 4)
     if S is None:
         S = trained_solver(dev, "trained_fcn16.npz")

@@ -200,7 +200,10 @@ def test_loop_eval_mode_teacher_forced(golden_dir, dev):
         assert sum(e < 3e-4 for e in per) >= 3, (n, per)
 
 
-def test_loop_all_six_layers(golden_dir, dev):
+def test_loop_all_six_layers_random_weights_badly_conditioned(golden_dir, dev):
+    """All six decoder layers on RANDOM weights, teacher-forced K = 2.  Badly conditioned by construction: the reference's own fp32 gradients are 6.4e-2 .. 7.0e-2
+    from their fp64 twins at these points (profiles/r03_parity_report.txt), so the bar here (a multiple of THAT noise, per step) is wide - 0.28 at step 1 - while the
+    measured errors are 4e-4 .. 9e-3.  The well-conditioned all-six-layers case is test_round3_gpu.py::test_all_six_layers_on_trained_network_vs_reference_run."""
     from oracle import maxstyle_oracle as orc
     g = np.load(os.path.join(golden_dir, "loop_all_layers.npz")); tf = np.load(os.path.join(golden_dir, "loop_all_layers_tf64.npz"))
     _teacher_forced(dev, g, None, orc.NetSpec(4, 1, 4), 3, 64, [0, 1, 2, 3, 4, 5], 2, tf=tf, tag="all_layers")

@@ -70,6 +70,13 @@ def round4():
             print(f"   applied {r['applied']}: image max {r['image_max']:.2e} rms {r['image_rms']:.2e} (bf16 oracle {r['oracle_bf16_image_max']:.2e} / {r['oracle_bf16_image_rms']:.2e}), "
                   f"labels {r['labels_equal']:.5f} (oracle {r['oracle_bf16_labels_equal']:.5f}), Dice diff {r['dice_abs_diff']:.1e}, worst loss err {max(r['losses_rel']):.1e} "
                   f"(oracle {max(r['oracle_bf16_losses_rel']):.1e})")
+    import r3_cases as R
+    print("== arguments of the drop-in signature + all six layers (trained FCN_16, 4x1x64x64, K = 3) vs the reference's fp64 run; noise = the reference's fp32 run against it")
+    for case in list(R.ARG_CALLS) + ["all6"]:
+        r = R.arg_case(dev, case)
+        pm = max(list(r["params_rel"].values()) + [0.0]); pn = max(list(r["noise_params_rel"].values()) + [0.0])
+        print(f"   {case:14s} image {r['image_rel']:.2e} (noise {r['noise_image_rel']:.2e})  params {pm:.2e} ({pn:.2e})  losses {max(r['losses_rel'] or [0]):.1e} "
+              f"({max(r['noise_losses_rel'] or [0]):.1e})  labels {r['labels_equal']:.6f}  Dice diff {r['dice_abs_diff']:.1e}")
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "r4":
