@@ -14,63 +14,110 @@
 namespace ms {
 
 constexpr int kSmTH = 16, kSmTW = 64, kSmCK = 2, kSmIH = kSmTH + 2, kSmRS = kSmTW + 8, kSmPS = kSmIH * kSmRS;       // window columns x0-4 .. x0+67
+typedef unsigned sm_u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kSmWS = 12;                                   // LDS floats per (channel, output channel) of a chunk's weights: 9 taps, padded to three 16-byte reads
 
+// Second form (round 4): the loop body of the first one was ~560 instructions per 2-channel chunk for 72 multiply-adds per thread - 18 dependent scalar weight loads
+// each with its own wait, a branch nest per staged quad, zero-filled staging registers, multiply and add as two instructions.  Now: the staging quads are buffer loads
+// whose out-of-image offsets read as zero (no branches, no zero fill; fp32 storage), their addresses and LDS slots are computed once per thread, the chunk's weights
+// travel with the data (one element per thread of the first waves, parked in LDS beside the window, read back as broadcast 16-byte reads), the prologue coefficients are
+// uniform loads issued a chunk ahead, and the multiply-adds are FMAs (~190 instructions per chunk).  Same sums in the same order (channel by channel, tap by tap).
 template <int COUT, bool PRO2, typename AT = float>
 __global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(const void* __restrict__ in, const void* __restrict__ in2, void* __restrict__ out,
                                                                  const float* __restrict__ w, const float* __restrict__ pro_a, const float* __restrict__ pro_b,
                                                                  const float* __restrict__ pro_c, int pro_cstride, int Cin, int H, int W, int cin_pad, int cout_pad,
-                                                                 int tiles_x) {
+                                                                 int tiles_x, int tiles_per_img) {
   __shared__ __attribute__((aligned(16))) float smem[2][kSmCK * kSmPS];
+  __shared__ __attribute__((aligned(16))) float wsm[2][kSmCK * COUT * kSmWS];
   const int tid = threadIdx.x;
-  const int n = blockIdx.y, tile = blockIdx.x;
+  // work item = (image, tile), numbered so that the workgroups of one XCD (every 8th workgroup id) take CONSECUTIVE tiles: neighbouring tiles share their halo rows and the
+  // 128-byte lines their 288-byte row segments straddle, and the L2 is per XCD - with round-robin numbering those lines came over the fabric twice (counters: 257 MB
+  // fetched for 138 MB at config 2, L2 hit rate 9 %)
+  const int total = (int)gridDim.x;
+  const int work = (total % 8 == 0) ? (int)(blockIdx.x % 8) * (total / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int n = work / tiles_per_img, tile = work % tiles_per_img;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int y0 = ty * kSmTH, x0 = tx * kSmTW;
   const size_t plane = (size_t)H * W;
   using IO = ActIO<AT>;                     // storage type of in / in2 / out: float | ms_bf16
+  constexpr bool F32 = (IO::kBytes == 4);
   const size_t in_n = (size_t)n * Cin * plane;
-  constexpr int ITEMS = kSmCK * kSmIH * (kSmRS / 4);        // float4 items per chunk: 4 x 18 x 18 = 1296
+  constexpr int ITEMS = kSmCK * kSmIH * (kSmRS / 4);        // float4 items per chunk: 2 x 18 x 18 = 648
   constexpr int NI = (ITEMS + 255) / 256;
-  float4 rg[NI], ru[PRO2 ? NI : 1];
+  struct Stage { float4 rg[NI], ru[PRO2 ? NI : 1]; float rw, ca[kSmCK], cb[kSmCK], cd[kSmCK]; };      // one chunk on its way: data quads, its weight element, its coefficients
+  Stage sa;                                                   // (two chunks in flight - a second Stage, 128 registers - measured no faster: 45.2 against 44.0 us at config 2, 250 against 246 at config 4)
   const int nchunks = (Cin + kSmCK - 1) / kSmCK;
 
-  auto load_chunk = [&](int c0) {
+  // per staging item of this thread (the same for every chunk): channel within the chunk, LDS slot (floats; -1: none), inside the image?, offset inside a channel plane
+  int ic[NI], ilds[NI], ioff[NI]; bool iok[NI];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int it = tid + j * 256;
-      rg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (PRO2) ru[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < ITEMS) {
-        const int f = it % (kSmRS / 4), row = it / (kSmRS / 4);
-        const int r = row % kSmIH, c = row / kSmIH;
-        const int Y = y0 - 1 + r, X = x0 - 4 + 4 * f, ci = c0 + c;
-        if (ci < Cin && Y >= 0 && Y < H && X >= 0 && X < W) {          // W % 4 == 0: a quad is inside or outside as a whole
-          const size_t off = in_n + (size_t)ci * plane + (size_t)Y * W + X;
-          rg[j] = IO::ld4(in, off);
-          if (PRO2) ru[j] = IO::ld4(in2, off);
+  for (int j = 0; j < NI; ++j) {
+    const int it = tid + j * 256;
+    const int f = it % (kSmRS / 4), row = it / (kSmRS / 4);
+    const int r = row % kSmIH, c = row / kSmIH;
+    const int Y = y0 - 1 + r, X = x0 - 4 + 4 * f;
+    ic[j] = c;
+    ilds[j] = (it < ITEMS) ? c * (kSmPS / 4) + r * (kSmRS / 4) + f : -1;       // in 16-byte slots: the compiler then knows the alignment (ds_write_b128)
+    iok[j] = (it < ITEMS) && Y >= 0 && Y < H && X >= 0 && X < W;          // W % 4 == 0: a quad is inside or outside as a whole
+    ioff[j] = Y * W + X;
+  }
+  // the weight element this thread carries per chunk: (channel wc of the chunk, output channel wo, tap wt)
+  const bool wthr = tid < kSmCK * COUT * 9;
+  const int wc = tid / (COUT * 9), wo = (tid / 9) % COUT, wt = tid % 9;
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(in) + in_n * IO::kBytes), 0, (int)((unsigned)Cin * (unsigned)plane * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(PRO2 ? in2 : in) + in_n * IO::kBytes), 0, (int)((unsigned)Cin * (unsigned)plane * 4u), 0x00020000);
+  unsigned voff[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) voff[j] = iok[j] ? ((unsigned)ic[j] * (unsigned)plane + (unsigned)ioff[j]) * 4u : 0x80000000u;      // outside the image: an offset the resource refuses -> zeros
+
+  auto load_chunk = [&](Stage& g, int c0) {
+    if constexpr (F32) {
+      const int soff = (int)((unsigned)c0 * (unsigned)plane * 4u);       // channels >= Cin lie behind the resource's last byte: zeros as well
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const sm_u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r1, (int)voff[j], soff, 0);
+        g.rg[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        if (PRO2) {
+          const sm_u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r2, (int)voff[j], soff, 0);
+          g.ru[j] = make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3]));
         }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        g.rg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PRO2) g.ru[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iok[j] && c0 + ic[j] < Cin) {
+          const size_t off = in_n + (size_t)(c0 + ic[j]) * plane + (size_t)ioff[j];
+          g.rg[j] = IO::ld4(in, off);
+          if (PRO2) g.ru[j] = IO::ld4(in2, off);
+        }
+      }
+    }
+    g.rw = (wthr && c0 + wc < Cin) ? w[((size_t)wt * cin_pad + (c0 + wc)) * cout_pad + wo] : 0.f;
+    if (PRO2) {
+#pragma unroll
+      for (int c = 0; c < kSmCK; ++c) {
+        const bool in_c = (c0 + c < Cin);                                 // uniform
+        g.ca[c] = in_c ? pro_a[(c0 + c) * pro_cstride] : 0.f; g.cb[c] = in_c ? pro_b[(c0 + c) * pro_cstride] : 0.f; g.cd[c] = in_c ? pro_c[(c0 + c) * pro_cstride] : 0.f;
       }
     }
   };
-  auto store_chunk = [&](float* buf, int c0) {
+  auto store_chunk = [&](const Stage& g, int b) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int it = tid + j * 256;
-      if (it < ITEMS) {
-        const int f = it % (kSmRS / 4), row = it / (kSmRS / 4);
-        const int r = row % kSmIH, c = row / kSmIH;
-        const int Y = y0 - 1 + r, X = x0 - 4 + 4 * f, ci = c0 + c;
-        float4 v = rg[j];
-        if (PRO2) {
-          const bool ok = (ci < Cin && Y >= 0 && Y < H && X >= 0 && X < W);
-          if (ok) {
-            const float al = pro_a[ci * pro_cstride], be = pro_b[ci * pro_cstride], de = pro_c[ci * pro_cstride];
-            v.x = al * v.x + (be * ru[j].x + de); v.y = al * v.y + (be * ru[j].y + de);
-            v.z = al * v.z + (be * ru[j].z + de); v.w = al * v.w + (be * ru[j].w + de);
-          }
-        }
-        *reinterpret_cast<float4*>(buf + c * kSmPS + r * kSmRS + 4 * f) = v;
+      float4 v = g.rg[j];
+      if (PRO2) {
+        float al = g.ca[0], be = g.cb[0], de = g.cd[0];
+#pragma unroll
+        for (int c = 1; c < kSmCK; ++c) { al = (ic[j] == c) ? g.ca[c] : al; be = (ic[j] == c) ? g.cb[c] : be; de = (ic[j] == c) ? g.cd[c] : de; }
+        de = iok[j] ? de : 0.f;                                           // zeros outside the image AFTER the prologue = the conv's zero padding (the loaded values are 0 there)
+        v.x = al * v.x + (be * g.ru[j].x + de); v.y = al * v.y + (be * g.ru[j].y + de);
+        v.z = al * v.z + (be * g.ru[j].z + de); v.w = al * v.w + (be * g.ru[j].w + de);
       }
+      if (ilds[j] >= 0) reinterpret_cast<float4*>(smem[b])[ilds[j]] = v;
     }
+    if (wthr) wsm[b][(wc * COUT + wo) * kSmWS + wt] = g.rw;
   };
 
   const int py = tid >> 4, px4 = (tid & 15) * 4;          // this thread's pixels: row y0+py, columns x0+px4 .. +3
@@ -80,33 +127,46 @@ __global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(const void* __r
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[o][e] = 0.f;
 
-  load_chunk(0);
-  for (int ch = 0; ch < nchunks; ++ch) {
-    float* buf = smem[ch & 1];
-    store_chunk(buf, ch * kSmCK);
-    if (ch + 1 < nchunks) load_chunk((ch + 1) * kSmCK);
-    __syncthreads();
+  auto compute = [&](int b, int ch) {
 #pragma unroll
     for (int c = 0; c < kSmCK; ++c) {
       const int ci = ch * kSmCK + c;
       if (ci < Cin) {
+        float wv[COUT][kSmWS];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o)
+#pragma unroll
+          for (int q = 0; q < kSmWS / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(&wsm[b][(c * COUT + o) * kSmWS + 4 * q]);        // the same address in every lane: a broadcast read
+            wv[o][4 * q] = t.x; wv[o][4 * q + 1] = t.y; wv[o][4 * q + 2] = t.z; wv[o][4 * q + 3] = t.w;
+          }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-          const float* q = buf + c * kSmPS + (py + ky) * kSmRS + px4 + 3;       // window columns x-1 .. x+4 at LDS columns px4+3 .. px4+8
-          const float4 mid = *reinterpret_cast<const float4*>(q + 1);
-          const float win[6] = {q[0], mid.x, mid.y, mid.z, mid.w, q[5]};
+          // window columns x-1 .. x+4 = LDS columns px4+3 .. px4+8, read as the three ALIGNED quads px4 .. px4+11: 16-byte reads at a 16-byte lane stride are
+          // conflict-free, the dword pairs the compiler made of {q[3], quad, q[8]} were 8-way conflicts (counters: 70 % of the LDS cycles of the first form)
+          const float4* q4 = reinterpret_cast<const float4*>(smem[b]) + (c * (kSmPS / 4) + (py + ky) * (kSmRS / 4) + (tid & 15));
+          float4 lft = q4[0], mid = q4[1], rgt = q4[2];
+          asm volatile("" : "+v"(lft.x), "+v"(lft.y), "+v"(lft.z), "+v"(lft.w));      // (every component "used": the compiler must not narrow the quads back to dword pairs)
+          asm volatile("" : "+v"(rgt.x), "+v"(rgt.y), "+v"(rgt.z), "+v"(rgt.w));
+          const float win[6] = {lft.w, mid.x, mid.y, mid.z, mid.w, rgt.x};
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int o = 0; o < COUT; ++o) {
-              const float wv = w[((size_t)(ky * 3 + kx) * cin_pad + ci) * cout_pad + o];      // uniform address: scalar load
+            for (int o = 0; o < COUT; ++o)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc[o][e] += wv * win[e + kx];
-            }
+              for (int e = 0; e < 4; ++e) acc[o][e] = __builtin_fmaf(wv[o][ky * 3 + kx], win[e + kx], acc[o][e]);
         }
       }
     }
-    // (the next iteration writes the OTHER buffer; the barrier of that iteration orders it against these reads)
+  };
+  load_chunk(sa, 0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int b = ch & 1;
+    store_chunk(sa, b);
+    if (ch + 1 < nchunks) load_chunk(sa, (ch + 1) * kSmCK);
+    __syncthreads();
+    compute(b, ch);
+    // (the next iteration writes the OTHER buffers; the barrier of that iteration orders it against these reads)
   }
   const int y = y0 + py, x = x0 + px4;
   if (y < H && x < W) {
@@ -249,16 +309,18 @@ extern "C" int ms_conv3x3_small_cout_ok(int Cout, int W) { return (Cout >= 1 && 
 template <typename AT>
 static int small_cout_impl(const void* in, const void* in2, void* out, const float* w_packed, int N, int Cin, int H, int W, int Cout,
                            int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_cstride, void* stream) {
-  if (N < 1 || Cin < 1 || H < 1 || W < 1 || !ms_conv3x3_small_cout_ok(Cout, W) || N > 65535) { set_error("ms_conv3x3_small_cout: Cout <= 4, W %% 4 == 0"); return MS_ERR_INVALID; }
+  if (N < 1 || Cin < 1 || H < 1 || W < 1 || !ms_conv3x3_small_cout_ok(Cout, W)) { set_error("ms_conv3x3_small_cout: Cout <= 4, W %% 4 == 0"); return MS_ERR_INVALID; }
   if (pro_mode != 0 && pro_mode != 2) { set_error("ms_conv3x3_small_cout: pro_mode 0 or 2"); return MS_ERR_INVALID; }
   if (pro_mode == 2 && (in2 == nullptr || pro_a == nullptr || pro_b == nullptr || pro_c == nullptr)) { set_error("ms_conv3x3_small_cout: prologue operands missing"); return MS_ERR_INVALID; }
   if (!aligned16(in) || !aligned16(out) || (in2 != nullptr && !aligned16(in2))) { set_error("ms_conv3x3_small_cout: tensors must be 16-byte aligned"); return MS_ERR_ALIGN; }
+  if ((size_t)Cin * H * W * 4u >= ((size_t)1 << 31)) { set_error("ms_conv3x3_small_cout: one image of the input must stay below 2 GiB (buffer-resource addressing)"); return MS_ERR_INVALID; }
   const int tiles_x = cdiv(W, kSmTW), tiles_y = cdiv(H, kSmTH);
   const int cin_pad = (Cin + 3) / 4 * 4, cout_pad = (Cout + 63) / 64 * 64;
-  dim3 grid(tiles_x * tiles_y, N), block(256);
+  if ((long)tiles_x * tiles_y * N > 0x7fffffffL) { set_error("ms_conv3x3_small_cout: too many tiles"); return MS_ERR_INVALID; }
+  dim3 grid(tiles_x * tiles_y * N), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int cs = pro_cstride < 1 ? 1 : pro_cstride;
-#define MS_SM(CO, P2) MS_LAUNCH((conv3x3_small_cout_kernel<CO, P2, AT>), grid, block, 0, st, in, in2, out, w_packed, pro_a, pro_b, pro_c, cs, Cin, H, W, cin_pad, cout_pad, tiles_x)
+#define MS_SM(CO, P2) MS_LAUNCH((conv3x3_small_cout_kernel<CO, P2, AT>), grid, block, 0, st, in, in2, out, w_packed, pro_a, pro_b, pro_c, cs, Cin, H, W, cin_pad, cout_pad, tiles_x, tiles_x * tiles_y)
   if (pro_mode == 2) { switch (Cout) { case 1: MS_SM(1, true); break; case 2: MS_SM(2, true); break; case 3: MS_SM(3, true); break; default: MS_SM(4, true); } }
   else { switch (Cout) { case 1: MS_SM(1, false); break; case 2: MS_SM(2, false); break; case 3: MS_SM(3, false); break; default: MS_SM(4, false); } }
 #undef MS_SM
