@@ -17,5 +17,5 @@ for k in sorted(agg):
     v = agg[k]
     print(f"{k:32s} {sum(v) / len(v):14.4e}   (n={len(v)})")
 PY
-tail -3 $O/c1.err $O/c2.err | grep -i "error\|invalid\|not found" | head -5
+
 rm -rf $O/c1 $O/c2

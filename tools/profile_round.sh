@@ -44,6 +44,11 @@ python tools/ab_subpix.py c2 10 > $O/${R}_subpix_ab_c2.txt 2>&1
 python tools/ab_k1.py c4 10 > $O/${R}_k1_ab_c4.txt 2>&1
 python tools/ab_k1.py c2 10 > $O/${R}_k1_ab_c2.txt 2>&1
 python tools/train_timeline.py 10 > $O/${R}_train_timeline.txt 2>&1
+# 5e. round 4: fabric traffic per kernel of an eager step against the step budget's algorithmic bytes (the screen that found the small-cout kernel's doubled fetch),
+#     and that kernel's own counters
+bash tools/traffic_by_kernel.sh c2 $O/${R}_step_budget_c2.json > $O/${R}_traffic_by_kernel_c2.txt 2>&1
+bash tools/traffic_by_kernel.sh c4 $O/${R}_step_budget_c4.json > $O/${R}_traffic_by_kernel_c4.txt 2>&1
+{ python tools/one_small.py c2; python tools/one_small.py c4; bash tools/pmc_cmd.sh $O/pmc_small small_cout tools/one_small.py c2; bash tools/pmc_cache.sh $O/pmc_small2 small_cout tools/one_small.py c2; } 2>&1 | grep -v amdgpu > $O/${R}_small_cout_pmc.txt
 # 6. un-profiled bench lines
 python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
 python bench.py --config c4 --steps 10 --warmup 2 > $O/${R}_bench_c4.json 2> $O/bench_c4.err
