@@ -23,4 +23,4 @@ for i in range(reps):
 torch.cuda.synchronize()
 t = sorted(ev[2 * i].elapsed_time(ev[2 * i + 1]) * 1e3 for i in range(1, reps))
 mb = (2 * N * Cin * H * W + N * Cout * H * W) * 4 / 1e6
-print(f"{cfg}: {mb:.1f} MB, median {t[len(t) // 2]:.1f} us (events, inputs evicted by a 384 MB fill between launches) = {mb / t[len(t) // 2] / 1e6:.2f} TB/s")
+print(f"{cfg}: {mb:.1f} MB, median {t[len(t) // 2]:.1f} us (events, inputs evicted by a 384 MB fill between launches) = {mb / t[len(t) // 2]:.2f} TB/s")
