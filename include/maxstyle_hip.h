@@ -279,7 +279,9 @@ MS_INTERNAL int ms_conv3x3_small_cin(const float* in, float* out, const float* w
 
 /* 3x3 stride-1 convolution with <= 4 OUTPUT channels on the vector ALUs (csrc/ms_conv_small.hip): the data-gradient that reaches the image (`inc.0`,
  * encoder_decoder.py:441-445: 16 -> 1 channels at config 2, 64 -> 3 at config 4).  Same arithmetic contract as ms_conv2d(ks=3, stride=1) with pro_mode 0 or 2
- * (BatchNorm-backward prologue pro_a*in + pro_b*in2 + pro_c); w_packed = the packed weights [9][cin_pad][cout_pad].  W % 4 == 0. */
+ * (BatchNorm-backward prologue pro_a*in + pro_b*in2 + pro_c); w_packed = the packed weights [9][cin_pad][cout_pad].  W % 4 == 0; one image of the input
+ * (Cin * H * W * 4 bytes) below 2 GiB (buffer-resource addressing: MS_ERR_INVALID otherwise).  The products of an output are summed channel by channel, tap by tap,
+ * as fused multiply-adds (to rounding against ms_conv2d, which sums them in the matrix cores' order). */
 MS_INTERNAL int ms_conv3x3_small_cout_ok(int Cout, int W);
 MS_INTERNAL int ms_conv3x3_small_cout(const float* in, const float* in2, float* out, const float* w_packed, int N, int Cin, int H, int W, int Cout,
                           int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_cstride, void* stream);

@@ -393,6 +393,8 @@ class InnerLoopEngine:
         # activations is about twice the direct form's (include/maxstyle_hip.h, ms_conv2d), harmless for the augmentation loop (parity tests unchanged),
         # not wanted in the weight gradients of the training passes.  MS_LOOP_WINOGRAD=0 is the A/B switch.
         self.winograd = type(self) is InnerLoopEngine and os.environ.get("MS_LOOP_WINOGRAD", "1") != "0"
+        if type(self) is not InnerLoopEngine and os.environ.get("MS_TRAIN_WINOGRAD", "0") != "0":
+            self.winograd = True                   # experiment switch: the training passes' forward / data-gradient convs in the Winograd form too (the weight-gradient kernels are their own)
         self.fuse_style_actbwd = True  # ms_style_bwd_actbwd (the MaxStyle backward also does the block's output-activation backward)
         # the tail of a step as ONE launch (ms_step_tail: the layers' gradient reductions + Adam + the cross-entropy sum + the step counter; was six
         # ~4.8 us launches); MS_FUSE_TAIL=0 is the A/B switch (bit-identical results)

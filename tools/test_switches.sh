@@ -45,3 +45,12 @@ run MS_SMALL_CIN=1 $KNIFE "--deselect=tests/test_round3_gpu.py::test_drop_in_arg
 run MS_LOOP_WINOGRAD=0 $KNIFE -k "not (pooled_data_gradient or winograd or bench_line_contract)"
 # shared device: neither the single-read kernel nor the cross-workgroup finalize is selected
 run MS_SHARED_DEVICE=1 $KNIFE -k "not (single_read_kernel or cross_workgroup_finalize)"
+# ---- round 4: the second-generation kernels' process-wide switches (each falls back to the first generation: same bits at config 4, rounding-level differences of the
+#      stride-2 conv's chunking at config 2) ----
+# (tests that assert "the streaming / second-generation kernel ran" cannot pass with it switched off)
+run MS_CONV_K1S=0 $KNIFE -k "not (streamed or streaming_1x1 or k1s)"
+run MS_K1S_CMIN=64 $KNIFE -k "not (streamed or streaming_1x1 or k1s)"
+run MS_CONV_K1G=0 $KNIFE -k "not lds_tiled_1x1_gemm"
+run MS_CONV_S2G2=0 $KNIFE -k "not stride2_conv_second_generation"
+run MS_SUBPIX_GEN=1 $KNIFE
+run MS_TRAIN_XFIN=1 $KNIFE
