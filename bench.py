@@ -1066,6 +1066,16 @@ def main():
         del eng, run_one
         torch.cuda.empty_cache()
         oi = outer_iteration(dev, args.batch, args.size, rank, world, dist_on=dist_on)      # every rank: contains the collective
+        if not dist_on and rank == 0 and os.environ.get("MS_TRAIN_WINOGRAD") is None:
+            # side field: the same iteration with the training passes' forward / data-gradient convs in the Winograd form (opt-in MS_TRAIN_WINOGRAD=1, engine.py);
+            # the headline of this block stays on the default (direct form: weight gradients at the reference's fidelity)
+            os.environ["MS_TRAIN_WINOGRAD"] = "1"
+            try:
+                torch.cuda.empty_cache()
+                ow = outer_iteration(dev, args.batch, args.size, rank, world, dist_on=dist_on)
+                oi["winograd_training_passes_opt_in"] = {"switch": "MS_TRAIN_WINOGRAD=1", "ms_per_iteration": ow["ms_per_iteration"], "value": ow["value"]}
+            finally:
+                del os.environ["MS_TRAIN_WINOGRAD"]
         if rank == 0:
             res["outer_iteration"] = oi
     if rank == 0:

@@ -1,8 +1,9 @@
 """Winograd F(2x2,3x3) form of the wide 3x3 stride-1 convolution (fetch | FETCH_WINOGRAD; ms_conv_wide.h, storage tag ms_f32w).
 
 Tolerance statement: against fp64 on random data the form is as close as the direct one (measured 1-4e-7 of the output range on every shape below; bar 2e-6).
-On the networks' activations its rounding error is about twice the direct form's (include/maxstyle_hip.h, ms_conv2d) - which is why only the inner
-loop asks for it; the loop-level parity tests (test_engine_gpu.py, test_round2_gpu.py, test_solver_gpu.py) run WITH it and hold their bars unchanged."""
+On the networks' activations its rounding error is about twice the direct form's (include/maxstyle_hip.h, ms_conv2d); the loop-level parity tests
+(test_engine_gpu.py, test_round2_gpu.py, test_solver_gpu.py) run WITH it and hold their bars unchanged; the training passes take it only on request
+(MS_TRAIN_WINOGRAD=1: test_train_gpu.py holds its bars under the switch too, tools/test_switches.sh)."""
 import os
 import sys
 
@@ -202,12 +203,18 @@ def test_winograd_bit_is_ignored_where_the_form_is_not_built(dev):
         assert torch.equal(ops.conv2d(x, wp, None, Cout, ks, stride, fetch=ops.FETCH_WINOGRAD), ops.conv2d(x, wp, None, Cout, ks, stride))
 
 
-def test_only_the_inner_loop_asks_for_the_winograd_form(dev):
+def test_which_engines_ask_for_the_winograd_form(dev, monkeypatch):
+    """The inner loop asks for the form (MS_LOOP_WINOGRAD=0 switches it off); the training passes keep the direct form - weight gradients at the reference's fidelity -
+    unless MS_TRAIN_WINOGRAD=1 opts them in (forward / data-gradient convs only; measured in engine.py)."""
     from maxstyle_amd import engine as E
-    loop = E.InnerLoopEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev)
-    assert loop.winograd
     from maxstyle_amd.train_engine import TrainEngine
+    monkeypatch.delenv("MS_TRAIN_WINOGRAD", raising=False); monkeypatch.delenv("MS_LOOP_WINOGRAD", raising=False)
+    assert E.InnerLoopEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev).winograd
     assert not TrainEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev).winograd
+    monkeypatch.setenv("MS_TRAIN_WINOGRAD", "1")
+    assert TrainEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev).winograd
+    monkeypatch.setenv("MS_LOOP_WINOGRAD", "0")
+    assert not E.InnerLoopEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev).winograd
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 16, 16, 64, 64), (1, 32, 48, 20, 192), (2, 64, 64, 32, 32), (1, 8, 33, 10, 100), (1, 16, 16, 9, 36)])

@@ -54,3 +54,4 @@ run MS_CONV_K1G=0 $KNIFE -k "not lds_tiled_1x1_gemm"
 run MS_CONV_S2G2=0 $KNIFE -k "not stride2_conv_second_generation"
 run MS_SUBPIX_GEN=1 $KNIFE
 run MS_TRAIN_XFIN=1 $KNIFE
+run MS_TRAIN_WINOGRAD=1 $KNIFE -k "not which_engines_ask"
