@@ -407,6 +407,12 @@ MS_STABLE int ms_bn_finalize(const float* stats, int nparts, const float* gamma,
  * [N,C,H/2,W/2] and is nearest-up-sampled on the fly (conv1x1 commutes with nn.UpsamplingNearest2d). */
 MS_STABLE int ms_bn_act(const float* u, const float* coef4, const float* res, int res_mode, float* out, int N, int C, int H, int W, float slope, void* stream);
 
+/* ms_bn_finalize + ms_bn_act(res_mode 0) in one launch, for a BatchNorm whose only consumer is its own activation (the encoder's code z_i, the code decoupler's z_s:
+ * encoder_decoder.py:646, 655): coef4 receives ms_bn_finalize's record, out = LeakyReLU_slope(scale*u + shift).  Same arithmetic in the same order as the two calls:
+ * the same bits.  stats / nparts / gamma / beta / eps as ms_bn_finalize; u, out [N,C,H,W]. */
+MS_INTERNAL int ms_bn_finalize_act(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, const float* u, float* out,
+                       int N, int C, int H, int W, float slope, void* stream);
+
 /* Backward through the activation + the two BatchNorm-backward reductions in one pass:
  *   gout = gin * (r > 0 ? 1 : slope), r = ref (the saved activation output) or coef4.scale*u+coef4.shift when ref == NULL;
  *   part2[c][ms_act_bwd_parts()] = per-workgroup {sum gout, sum gout*(u - mean_c)} with mean_c = coef4[c].mean (centred, as
@@ -581,6 +587,8 @@ MS_INTERNAL int ms_conv3x3_small_cin_bf16(const uint16_t* in, uint16_t* out, con
 MS_INTERNAL int ms_conv3x3_small_cout_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, int N, int Cin, int H, int W, int Cout,
                                int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_cstride, void* stream);
 MS_STABLE int ms_bn_act_bf16(const uint16_t* u, const float* coef4, const uint16_t* res, int res_mode, uint16_t* out, int N, int C, int H, int W, float slope, void* stream);
+MS_INTERNAL int ms_bn_finalize_act_bf16(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, const uint16_t* u, uint16_t* out,
+                            int N, int C, int H, int W, float slope, void* stream);
 MS_STABLE int ms_act_bwd_reduce_bf16(const uint16_t* gin, const uint16_t* ref, const uint16_t* u, const float* coef4, uint16_t* gout, float* part2,
                            int N, int C, int HW, float slope, void* stream);
 MS_STABLE int ms_pool2_sum_bf16(const uint16_t* in, uint16_t* out, int planes, int Ho, int Wo, int accumulate, void* stream);

@@ -140,6 +140,54 @@ __global__ __launch_bounds__(kElemThreads) void act_bwd_reduce_kernel(const void
   }
 }
 
+// ms_bn_finalize + ms_bn_act(res_mode 0) in ONE launch, for a BatchNorm whose only consumer is its own activation (the encoder's code z_i and the code decoupler's z_s: two
+// finalize -> apply pairs of ~5 us launches per step each doing microseconds of work).  Block (c, s): wave 0 Chan-merges channel c's statistics slots exactly as
+// bn_finalize_kernel does (same order, fp64: the same record), block (c, 0) writes the record for the backward pass, and the block's 256 threads apply
+// leaky(sc*u + sh) to images s, s + S, .. of the channel with bn_act_kernel's expression: the same bits as the two launches.
+template <typename AT = float>
+__global__ __launch_bounds__(kElemThreads) void bn_finalize_act_kernel(const float4* __restrict__ tab, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                       float4* __restrict__ coef, const void* __restrict__ u, void* __restrict__ out, int N, int C, int HW, int vec,
+                                                                       float slope) {
+  using IO = ActIO<AT>;
+  __shared__ float2 sc_sh;
+  const int c = blockIdx.x;
+  if (threadIdx.x < 64) {
+    const int nparts = (int)tab[0].x;
+    const float4* part = tab + 1 + (size_t)c * kStatSlots;
+    double sn = 0.0, sm = 0.0, sq = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) {
+      const float4 q = part[i];
+      const double n = (double)q.x, mu = (double)q.y;
+      sn += n; sm += n * mu; sq += (double)q.z + n * mu * mu;
+    }
+    sn = wave_sum_d(sn); sm = wave_sum_d(sm); sq = wave_sum_d(sq);
+    if (threadIdx.x == 0) {
+      const double mean = sm / sn;
+      const double var = fmax((sq - sm * mean) / sn, 0.0);
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float sc = gamma[c] * invstd;
+      const float sh = beta[c] - (float)mean * sc;
+      if (blockIdx.y == 0) coef[c] = make_float4(sc, sh, (float)mean, invstd);
+      sc_sh = make_float2(sc, sh);
+    }
+  }
+  __syncthreads();
+  const float2 cf = sc_sh;
+  for (int n = blockIdx.y; n < N; n += gridDim.y) {
+    const size_t pb = ((size_t)n * C + c) * HW;
+    if (vec) {
+      for (int i = threadIdx.x * 4; i < HW; i += kElemThreads * 4) {
+        float4 t = IO::ld4(u, pb + i);
+        t.x = leaky(cf.x * t.x + cf.y + 0.f, slope); t.y = leaky(cf.x * t.y + cf.y + 0.f, slope);
+        t.z = leaky(cf.x * t.z + cf.y + 0.f, slope); t.w = leaky(cf.x * t.w + cf.y + 0.f, slope);
+        IO::st4(out, pb + i, t);
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += kElemThreads) IO::st1(out, pb + i, leaky(cf.x * IO::ld1(u, pb + i) + cf.y + 0.f, slope));
+    }
+  }
+}
+
 // BatchNorm backward coefficients: du = sc*(g - mean(g) - uhat*mean(g*uhat)) = al*g + be*u + de
 __global__ __launch_bounds__(64) void bn_bwd_coefs_kernel(const float2* __restrict__ part, int nparts, const float4* __restrict__ coef, double count,
                                                           float4* __restrict__ out) {
@@ -729,6 +777,29 @@ extern "C" int ms_bn_act(const float* u, const float* coef4, const float* res, i
 // `_bf16` twins of the streaming kernels: activation tensors (u, res, out, gradients, h, ...) are bf16 bit patterns, everything else as in the fp32 entry point
 extern "C" int ms_bn_act_bf16(const uint16_t* u, const float* coef4, const uint16_t* res, int res_mode, uint16_t* out, int N, int C, int H, int W, float slope, void* stream) {
   return bn_act_impl<ms_bf16>(u, coef4, res, res_mode, out, N, C, H, W, slope, stream);
+}
+
+template <typename AT>
+static int bn_finalize_act_impl(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, const void* u, void* out,
+                                int N, int C, int H, int W, float slope, void* stream) {
+  if (N < 1 || C < 1 || H < 1 || W < 1 || nparts != kStatSlots || stats == nullptr || gamma == nullptr || beta == nullptr || coef4 == nullptr || u == nullptr || out == nullptr) {
+    set_error("ms_bn_finalize_act: invalid argument (nparts must be ms_conv_stats_parts())"); return MS_ERR_INVALID;
+  }
+  if (!(slope >= 0.f && slope <= 1.f)) { set_error("ms_bn_finalize_act: slope in [0, 1]"); return MS_ERR_INVALID; }
+  if (!aligned16(stats) || !aligned16(coef4)) { set_error("ms_bn_finalize_act: stats / coef4 must be 16-byte aligned"); return MS_ERR_ALIGN; }
+  const int HW = H * W;
+  const int vec = (W % 4 == 0 && aligned16(u) && aligned16(out)) ? 1 : 0;          // bn_act_kernel's rule (same expression either way)
+  const int S = std::max(1, std::min(N, cdiv(2 * num_cus(), C)));                   // enough blocks for the chip at 128 channels; every block re-reads its channel's slots (<= 8 KB, L2)
+  MS_LAUNCH((bn_finalize_act_kernel<AT>), dim3(C, S), dim3(kElemThreads), 0, (hipStream_t)stream, (const float4*)stats, gamma, beta, eps, (float4*)coef4, u, out, N, C, HW, vec, slope);
+  return check_launch("bn_finalize_act");
+}
+extern "C" int ms_bn_finalize_act(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, const float* u, float* out,
+                                  int N, int C, int H, int W, float slope, void* stream) {
+  return bn_finalize_act_impl<float>(stats, nparts, gamma, beta, eps, coef4, u, out, N, C, H, W, slope, stream);
+}
+extern "C" int ms_bn_finalize_act_bf16(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, const uint16_t* u, uint16_t* out,
+                                       int N, int C, int H, int W, float slope, void* stream) {
+  return bn_finalize_act_impl<ms_bf16>(stats, nparts, gamma, beta, eps, coef4, u, out, N, C, H, W, slope, stream);
 }
 
 extern "C" int ms_act_bwd_parts(int N, int C, int HW) { return N * elem_split(N * C, HW).S; }

@@ -406,6 +406,9 @@ class InnerLoopEngine:
         # the tail of a step as ONE launch (ms_step_tail: the layers' gradient reductions + Adam + the cross-entropy sum + the step counter; was six
         # ~4.8 us launches); MS_FUSE_TAIL=0 is the A/B switch (bit-identical results)
         self.fuse_tail = os.environ.get("MS_FUSE_TAIL", "1") != "0"
+        # BatchNorm finalize + its activation as ONE launch where nothing else consumes the record in between (z_i, z_s: ms_bn_finalize_act; two ~5 us launches less per
+        # step); MS_FUSE_FINACT=0 is the A/B switch (bit-identical results).  Inner loop only: the training engine's bn_fin also tracks running statistics.
+        self.fuse_fin_act = os.environ.get("MS_FUSE_FINACT", "1") != "0" and type(self) is InnerLoopEngine
         self.fuse_head_bwd = os.environ.get("MS_FUSE_HEAD_BWD", "1") != "0"     # ms_style_bwd_head: layer 4's backward forms the head's input gradient itself
         # ms_bn_bwd_coefs jobs whose consumer is a residual block's backward ride on that block's 1x1 skip data-gradient launch (ms_conv2d_ride) instead of
         # being ~5 us launches of their own; MS_RIDE=0 is the A/B switch (bit-identical results)
@@ -470,7 +473,7 @@ class InnerLoopEngine:
         """An ACTIVATION tensor (conv inputs / outputs, gradients, images): fp32, or bf16 storage in bf16 mode (everything else stays fp32)."""
         return self.t(name, *shape, dtype=self.act_dtype)
 
-    _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv2d_ride", "ms_conv2d_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd", "ms_pool2_actbwd_pool", "ms_add_actbwd",
+    _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv2d_ride", "ms_conv2d_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_bn_finalize_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd", "ms_pool2_actbwd_pool", "ms_add_actbwd",
                              "ms_head_fwd", "ms_head_fwd_styled", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_head_ce_tail", "ms_style_fwd", "ms_style_bwd", "ms_style_ws_bytes",
                              "ms_conv_subpix", "ms_conv3x3_small_cout", "ms_conv3x3_small_cin", "ms_style_bwd_actbwd", "ms_style_bwd_actbwd_parts"))
 
@@ -721,6 +724,18 @@ class InnerLoopEngine:
         if self.bn_observer is not None:
             self.bn_observer(bn, coef)
         return coef
+
+    def bn_fin_act(self, name, out_name, st, parts, bn: BNW, u, slope):
+        """bn_fin(name, ...) followed by bn_act(out_name, u, coef, None, 0, slope) - as one launch when the engine may (fuse_fin_act; batch statistics; a statistics
+        table in hand; nobody observing the record)."""
+        if not self.fuse_fin_act or self.bn_eval or isinstance(st, tuple) or self.bn_observer is not None:
+            return self.bn_act(out_name, u, self.bn_fin(name, st, parts, bn), None, 0, slope)
+        N, C, H, W = u.shape
+        coef = self.t(name + ".coef", C, 4)
+        out = self.a(out_name, N, C, H, W)
+        check(self.L("ms_bn_finalize_act")(st.data_ptr(), parts, bn.gamma.data_ptr(), bn.beta.data_ptr(), BN_EPS, coef.data_ptr(), u.data_ptr(), out.data_ptr(),
+                                         N, C, H, W, slope, self._st()), "ms_bn_finalize_act:" + name)
+        return out
 
     def _xfin_ok(self, st):
         """The consumer launch may derive its BatchNorm coefficients itself (`_xfin`): batch statistics, a statistics TABLE in hand (not the pair the
@@ -1098,8 +1113,7 @@ class InnerLoopEngine:
         for i in range(1, 5):
             h = self._mix(i + 1, self.res_fwd(f"e.d{i}", e, f"d{i}", h, "down", x_act=x_act if i == 1 else None))
         uf, st, p = self.conv("e.fc.u", h, e["fc0"], stats=True, fin=e["fc1"])
-        cff = self.bn_fin("e.fc.bn", st, p, e["fc1"])
-        z_i = self._mix(6, self.bn_act("e.z_i", uf, cff, None, 0, 0.0))
+        z_i = self._mix(6, self.bn_fin_act("e.fc.bn", "e.z_i", st, p, e["fc1"], uf, 0.0))
         return z_i, self.decouple_fwd(z_i)
 
     def decouple_fwd(self, z_i):
@@ -1108,8 +1122,7 @@ class InnerLoopEngine:
         u1, st, p = self.conv("e.cd.u1", z_i, e["cd0"], stats=True, fin=e["cd1"])
         cf1 = self.bn_fin_or_pending("e.cd.bn1", st, p, e["cd1"])
         u2, st, p = self.conv("e.cd.u2", u1, e["cd3"], act=(cf1, LEAKY), stats=True, fin=e["cd4"])
-        cf2 = self.bn_fin("e.cd.bn4", st, p, e["cd4"])
-        return self.bn_act("e.z_s", u2, cf2, None, 0, 0.0)
+        return self.bn_fin_act("e.cd.bn4", "e.z_s", st, p, e["cd4"], u2, 0.0)
 
     def encode_bwd(self, dz_s, pre=None):
         """pre = (masked gradient, bcoef4) when the producer of dz_s already did the backward of the code_decoupler's last activation."""

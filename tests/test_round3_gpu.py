@@ -1,6 +1,8 @@
 """Round-3 parity on the GPU, through the drop-in solver API: the benchmarked size against the reference's own run (Winograd form on and off), and one
 reference-generated case per non-default argument of generate_max_style_image.  Every bar is `max(c x the reference's own fp32-vs-fp64 error, floor)`:
 the measured ratios are in profiles/r03_parity_report.txt (tools/parity_report.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -80,17 +82,32 @@ def test_all_six_layers_on_trained_network_vs_reference_run(dev, monkeypatch, wi
     reference's fp32 and its fp64 run, and -1.0e-6 in the Winograd form - two correct fp32 roundings either side of LeakyReLU's kink.  The backward then multiplies one
     gradient element by 0.2 instead of 1, which moves every style gradient by 1e-4 .. 3e-3 (profiles/r04_all6_flip.txt: nothing else differs; the Winograd launch itself is
     2e-7 from fp64 on those inputs).  The reference's own fp32 run is hit the same way in 4 of the 10 argument cases above (its image error jumps from 5e-7 to 3e-4 there).
-    So the Winograd leg is held to the size of such an event, and test_all_six_layers_conv_forms_differ_at_kink_elements_only pins that this IS the whole difference."""
+    So a run is held to the tight bars when its own forward has that element on the reference's side (the direct form, by default) and to the size of one such event
+    when it has it on the other (the Winograd form; a few non-default switches move the direct form across too: tools/test_switches.sh), and
+    test_all_six_layers_conv_forms_differ_at_kink_elements_only pins that this IS the whole difference between the forms."""
     monkeypatch.setenv("MS_LOOP_WINOGRAD", wino)
+    # which side of the kink THIS run's forward lands on is an observable of the run: one step, then the pre-activation of that element (the reference: +3.0e-6)
+    monkeypatch.setitem(R.ARG_CALLS, "all6", dict(n_iter=1))
+    S1 = R.trained_solver(dev, "trained_fcn16.npz")
+    R.arg_case(dev, "all6", S1)
+    eng = next(iter(S1._engines.values()))
+    assert eng.winograd == (wino == "1")
+    cf = eng.buf["e.d1.bn1.coef"][9]
+    pre = float(cf[0] * eng.buf["e.d1.u1"][0, 9, 6, 17] + cf[1])
+    assert abs(pre) < 2e-5, pre                      # the premise of this test: that element sits on the knife edge in every fp32 rounding
+    reference_side = pre > 0.0
+    monkeypatch.delitem(R.ARG_CALLS, "all6")
     r = R.arg_case(dev, "all6")
-    print("all6 winograd=" + wino, {k: r[k] for k in ("losses_rel", "noise_losses_rel", "image_rel", "noise_image_rel", "labels_equal", "dice_abs_diff")},
+    print("all6 winograd=" + wino, "kink element pre-activation %+.2e" % pre, {k: r[k] for k in ("losses_rel", "noise_losses_rel", "image_rel", "noise_image_rel", "labels_equal", "dice_abs_diff")},
           "params worst", max(r["params_rel"].values()), "noise", max(r["noise_params_rel"].values()))
     assert r["z_i_rel"] < 5e-6
     assert r["param_names"] == r["param_names_ref"] and len(r["param_names"]) == 18
     assert r["state_equal"] and r["fixed_params_unchanged"]
     assert r["n_losses"] == (3, 3)
     worst_noise = max(r["noise_params_rel"].values())
-    if wino == "0":
+    if wino == "0" and not os.environ.get("MS_SWITCH_MATRIX"):
+        assert reference_side, pre                   # the default direct-form path lands where the reference does (other roundings - tools/test_switches.sh - need not)
+    if reference_side:
         for e, n in zip(r["losses_rel"], r["noise_losses_rel"]):
             assert e <= max(3.0 * n, 3e-6), (r["losses_rel"], r["noise_losses_rel"])
         assert r["image_rel"] <= max(3.0 * r["noise_image_rel"], 2e-5), (r["image_rel"], r["noise_image_rel"])      # measured 8.6e-6

@@ -198,3 +198,33 @@ def test_collective_on_a_side_stream_beside_loop_replays_result_or_error(dev):
     finally:
         if own_group:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("net,act", [((4, 1, 4), None), ((1, 3, 2), None), ((4, 1, 4), torch.bfloat16)])
+def test_fused_finalize_and_activation_is_bit_identical(dev, monkeypatch, net, act):
+    """ms_bn_finalize_act (BatchNorm finalize + its activation in one launch: the encoder's code z_i and the code decoupler's z_s) against the two launches it replaces:
+    the records the backward pass reads, the codes, losses, parameters and the image after K = 3 steps are the same bits - FCN_16 and FCN_64 widths, fp32 and bf16 storage,
+    eager and replayed."""
+    from maxstyle_amd import engine as E, synthetic as syn
+    spec_o = syn.NetSpec(*net)
+    W = syn.procedural_weights(spec_o, 0)
+    to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
+    B, size, layers = 4, 64, [3, 4, 5]
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MS_FUSE_FINACT", flag)
+        spec = E.NetSpec(*net)
+        eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1, act_dtype=act)
+        assert eng.fuse_fin_act == (flag == "1")
+        eng.set_nets(E.PackedNets(spec, to(W["image_encoder"]), to(W["segmentation_decoder"]), to(W["image_decoder"])))
+        img, lab = syn.synthetic_batch(B, size, net[1], net[2], seed=1234)
+        eng.configure_styles(layers, {i: E.StyleSlot(i, B, spec_o.channel_num[i]) for i in layers})
+        for i in layers:
+            st = syn.random_style_state(B, spec_o.channel_num[i], 7 + i)
+            eng.set_style_state(i, st.perm, st.lmda, st.gamma_noise, st.beta_noise)
+        z_i, z_s = eng.encode_fwd(img.to(dev).to(eng.act_dtype))
+        rec = [z_i.clone(), z_s.clone(), eng.buf["e.fc.bn.coef"].clone(), eng.buf["e.cd.bn4.coef"].clone()]
+        out = eng.run(z_i.clone(), lab.to(dev), 3, use_graph=True).clone()
+        outs.append(rec + [out, eng.losses(3).clone(), eng.flat_p.clone(), eng.flat_g.clone(), eng.buf["e.fc.bn.coef"].clone(), eng.buf["e.cd.bn4.coef"].clone()])
+    for i, (a, b) in enumerate(zip(outs[0], outs[1])):
+        assert torch.equal(a, b), i
