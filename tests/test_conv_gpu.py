@@ -191,6 +191,25 @@ def test_heads(dev):
     assert rel(dh, hr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("N,C,K,H,W", [(2, 64, 2, 40, 40), (1, 16, 4, 7, 9), (2, 16, 3, 256, 64), (1, 64, 2, 320, 320)])
+def test_head_ce_shapes(dev, N, C, K, H, W):
+    """ms_head_ce against fp64 math beyond test_heads' one shape: config 4's 64-channel / 2-class head (also grid-stride over a 320 x 320 plane), three classes, a ragged
+    7 x 9 plane."""
+    from maxstyle_amd import ops
+    from oracle import maxstyle_oracle as orc
+    h = _rand((N, C, H, W), 11)
+    w = _rand((K, C), 12, 0.3); b = _rand((K,), 13)
+    lab = torch.randint(0, K, (N, H, W), generator=torch.Generator().manual_seed(14))
+    hr = h.double().requires_grad_(True)
+    logits = F.conv2d(hr, w.double().view(K, C, 1, 1), b.double())
+    loss = -orc.cross_entropy_2d(logits, lab)
+    loss.backward()
+    lo, dh, lg = ops.head_ce(h.to(dev), w.to(dev), b.to(dev), lab.to(dev), loss_sign=-1.0, need_logits=True)
+    assert abs(float(lo) - float(loss)) < 2e-6 * abs(float(loss))
+    assert rel(lg, logits) < 2e-6
+    assert rel(dh, hr.grad) < 1e-5
+
+
 WIDE_CASES = [
     # N, Cin, Cout, H, W: rows >= 64 pixels wide take the wide-read kernel (ms_conv_wide.h)
     (2, 16, 16, 64, 64), (1, 16, 16, 9, 128), (2, 1, 16, 30, 72), (2, 20, 24, 13, 64), (1, 32, 48, 20, 192), (2, 64, 64, 64, 64), (1, 8, 33, 7, 100),
