@@ -32,6 +32,12 @@ class TailLayer(ctypes.Structure):
 SIGNATURES = {
     "ms_version": (c_int, []),
     "ms_last_error": (ctypes.c_char_p, []),
+    "ms_set_option": (c_int, [ctypes.c_char_p, c_int]),
+    "ms_get_option": (c_int, [ctypes.c_char_p]),
+    "ms_option_default": (c_int, [ctypes.c_char_p]),
+    "ms_option_count": (c_int, []),
+    "ms_option_name": (ctypes.c_char_p, [c_int]),
+    "ms_diag_set_trace": (c_int, [c_void, c_void]),
     "ms_style_ws_bytes": (c_size, [c_int, c_int, c_int]),
     "ms_style_moments": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_float, c_void, c_size, c_void]),
     "ms_style_coeffs": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_int, c_int, c_void]),
@@ -83,9 +89,6 @@ SIGNATURES = {
     "ms_conv_stats_parts": (c_int, [c_int, c_int, c_int]),
     "ms_conv2d": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                           c_int, c_f32p, c_f32p, c_f32p, c_int, c_int, c_float, c_int, c_f32p, c_void]),
-    "ms_conv_s2g2_enable": (c_int, [c_int]),
-    "ms_conv_k1g_enable": (c_int, [c_int]),
-    "ms_conv_k1s_enable": (c_int, [c_int]),
     "ms_conv_k1s_would_run": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "ms_conv_ride_capacity": (c_int, [c_int, c_int, c_int]),
     "ms_conv2d_ride": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -95,7 +98,6 @@ SIGNATURES = {
     "ms_bn_finalize_act": (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_float, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_float, c_void]),
     "ms_act_bwd_parts": (c_int, [c_int, c_int, c_int]),
     "ms_act_bwd_reduce": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_float, c_void]),
-    "ms_act_bwd_bn": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_void, c_f32p, c_int, c_int, c_int, c_float, c_void]),
     "ms_conv1x1_bnres": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_float, c_int, c_void]),
     "ms_xfin_gran_bytes": (c_size, [c_int]),
     "ms_conv1x1_bnres_xfin": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_void, c_void,
@@ -111,14 +113,12 @@ SIGNATURES = {
     "ms_conv_subpix2": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_int, c_void]),
     "ms_subpix_pack_floats": (c_size, [c_int, c_int]),
     "ms_subpix_pack": (c_int, [c_f32p, c_f32p, c_int, c_int, c_void]),
+    "ms_appendix_desc_bytes": (c_size, []),
+    "ms_appendix_job_threads": (ctypes.c_longlong, [c_int, c_int, c_int]),
+    "ms_appendix_batch": (c_int, [c_void, c_int, ctypes.c_longlong, c_void]),
     "ms_conv_actbwd_tab_bytes": (ctypes.c_size_t, [c_int]),
     "ms_conv2d_actbwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_f32p, c_f32p, c_f32p, c_int, c_int, ctypes.c_float, c_f32p, c_f32p, ctypes.c_float, c_f32p, c_void]),
-    "ms_conv2d_fin": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                              c_int, c_f32p, c_f32p, c_f32p, c_int, c_int, c_float, c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_void, c_void]),
-    "ms_conv2d_actbwd_fin": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                     c_int, c_f32p, c_f32p, c_f32p, c_int, c_int, ctypes.c_float, c_f32p, c_f32p, ctypes.c_float, c_f32p,
-                                     ctypes.c_double, c_f32p, c_void, c_void]),
     "ms_clock_probe": (c_int, [c_int, c_int, c_int, c_void, c_void, c_void]),
     "ms_bn_bwd_coefs": (c_int, [c_f32p, c_int, c_f32p, ctypes.c_double, c_f32p, c_int, c_void]),
     "ms_pool2_sum": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_void]),
@@ -181,6 +181,8 @@ def _load():
 
 
 lib = _load()
+from . import options as _options  # noqa: E402
+_options.apply_env_library_options()      # MS_OPTIONS' library entries (harness hook; the library itself reads no environment)
 
 
 def check(status, what):

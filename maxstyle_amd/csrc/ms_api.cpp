@@ -1,5 +1,7 @@
 // Library-level entry points: version and the thread-local error string.
 #include <algorithm>
+#include <atomic>
+#include <cstring>
 #include <cstdarg>
 #include <cstdio>
 #include <mutex>
@@ -31,9 +33,50 @@ int num_cus() {
   });
   return cus[dev];
 }
+
+struct OptRow { const char* name; int def, lo, hi; };
+static const OptRow kOpts[OPT_COUNT] = {
+  {"conv.wide", 1, 0, 1}, {"conv.wino", 1, 0, 2}, {"conv.wino32", 1, 0, 1}, {"conv.wino_nt", 0, 0, 2}, {"conv.wino_block", 1, 0, 2}, {"conv.wide_rows", 0, 0, 8},
+  {"conv.k1s", 1, 0, 1}, {"conv.k1g", 1, 0, 1}, {"conv.s2g2", 1, 0, 1}, {"conv.k3n", 1, 0, 1}, {"conv.force_nt", 0, 0, 4}, {"style.fused", 1, 0, 1}, {"diag.conv_dbg", 0, 0, 127},
+};
+static std::atomic<int> g_opt[OPT_COUNT];
+static std::once_flag g_opt_once;
+static void opt_init() { std::call_once(g_opt_once, []() { for (int i = 0; i < OPT_COUNT; ++i) g_opt[i].store(kOpts[i].def, std::memory_order_relaxed); }); }
+int opt(int which) { opt_init(); return g_opt[which].load(std::memory_order_relaxed); }
+static std::atomic<long long*> g_conv_trace{nullptr}, g_wgrad_trace{nullptr};
+long long* conv_trace_buffer() { return g_conv_trace.load(std::memory_order_relaxed); }
+long long* wgrad_trace_buffer() { return g_wgrad_trace.load(std::memory_order_relaxed); }
+static int opt_index(const char* name) {
+  if (name == nullptr) return -1;
+  for (int i = 0; i < OPT_COUNT; ++i) if (strcmp(name, kOpts[i].name) == 0) return i;
+  return -1;
+}
 }  // namespace ms
 
-extern "C" int ms_version(void) { return 200; }
+extern "C" int ms_option_count(void) { return ms::OPT_COUNT; }
+extern "C" const char* ms_option_name(int index) { return (index >= 0 && index < ms::OPT_COUNT) ? ms::kOpts[index].name : nullptr; }
+extern "C" int ms_option_default(const char* name) { const int i = ms::opt_index(name); return i < 0 ? MS_ERR_INVALID : ms::kOpts[i].def; }
+extern "C" int ms_get_option(const char* name) {
+  const int i = ms::opt_index(name);
+  if (i < 0) { ms::set_error("ms_get_option: unknown option '%s'", name ? name : "(null)"); return MS_ERR_INVALID; }
+  return ms::opt(i);
+}
+extern "C" int ms_set_option(const char* name, int value) {
+  const int i = ms::opt_index(name);
+  if (i < 0) { ms::set_error("ms_set_option: unknown option '%s'", name ? name : "(null)"); return MS_ERR_INVALID; }
+  if (value < ms::kOpts[i].lo || value > ms::kOpts[i].hi) { ms::set_error("ms_set_option: %s takes %d..%d", name, ms::kOpts[i].lo, ms::kOpts[i].hi); return MS_ERR_INVALID; }
+  ms::opt_init();
+  return ms::g_opt[i].exchange(value, std::memory_order_relaxed);
+}
+
+// diagnostic builds only (tools/trace_conv.py, tools/trace_wgrad.py): device buffers (>= 8 KiB) that workgroup 0 of the stamped kernels writes its cycle stamps into
+extern "C" int ms_diag_set_trace(void* conv_trace, void* wgrad_trace) {
+  ms::g_conv_trace.store((long long*)conv_trace, std::memory_order_relaxed);
+  ms::g_wgrad_trace.store((long long*)wgrad_trace, std::memory_order_relaxed);
+  return MS_OK;
+}
+
+extern "C" int ms_version(void) { return 210; }
 extern "C" int ms_num_cus(void) { return ms::num_cus(); }
 extern "C" const char* ms_last_error(void) { return ms::g_err; }
 

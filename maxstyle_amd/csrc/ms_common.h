@@ -23,6 +23,30 @@ constexpr int kStatSlots = kNumCU * 2 * 4;   // per-channel capacity (row stride
 // last error string (thread-local; the ABI itself never throws)
 void set_error(const char* fmt, ...);
 
+// ---- library options (ms_set_option / ms_get_option, include/maxstyle_hip.h) ------------------------------------------------------------------------
+// The ONLY process-wide knobs of the library: which kernel form the dispatch picks where more than one is built (every form computes the same convolution; the
+// defaults are the product, the others are kept for A/B timing and for the "same bits" tests).  Nothing in the library reads the environment: a caller sets an
+// option explicitly.  Relaxed atomics: a setter racing a launch gets one form or the other, never a torn state.
+enum Opt {
+  OPT_CONV_WIDE = 0,      // "conv.wide"        1: 3x3 stride-1 convs with rows >= 64 (Winograd forms: >= 20) pixels take conv_wide_kernel; 0: the first-generation kernel everywhere
+  OPT_CONV_WINO,          // "conv.wino"        1: a caller's MS_FETCH_WINOGRAD opt-in is honoured; 0: ignored (direct form); 2: Winograd form forced wherever legal
+  OPT_CONV_WINO32,        // "conv.wino32"      1: the 8 x 32-pixel Winograd tile for rows of 20..63 pixels
+  OPT_CONV_WINO_NT,       // "conv.wino_nt"     0: automatic; 1 / 2: channel blocks per staged Winograd tile
+  OPT_CONV_WINO_BLOCK,    // "conv.wino_block"  1: block form by fill; 0: never; 2: wherever legal
+  OPT_CONV_WIDE_ROWS,     // "conv.wide_rows"   0: automatic; 4 / 8: rows per tile of the direct-form wide kernel
+  OPT_CONV_K1S,           // "conv.k1s"         1: streaming 1x1 form where eligible
+  OPT_CONV_K1G,           // "conv.k1g"         1: LDS-tiled GEMM 1x1 form where eligible
+  OPT_CONV_S2G2,          // "conv.s2g2"        1: second-generation stride-2 3x3 form where eligible
+  OPT_CONV_K3N,           // "conv.k3n"         1: second-generation 3x3 form for rows of 12 / 14 / 16 pixels where eligible (ms_conv_k3n.h)
+  OPT_CONV_FORCE_NT,      // "conv.force_nt"    0: automatic; 1 / 2 / 4: output-channel blocks of 16 per workgroup (tuning: tools/tune_conv.py)
+  OPT_STYLE_FUSED,        // "style.fused"      1: single-read MaxStyle kernel where its grid fits the chip; 0: three-launch path
+  OPT_DIAG_CONV_DBG,      // "diag.conv_dbg"    timing-only ablation bits of the conv kernels (results are WRONG with any bit set): 1 no MFMA loop, 2 no global loads, 4 no stores, 8 no LDS stores, 16 no epilogue
+  OPT_COUNT
+};
+int opt(int which);
+long long* conv_trace_buffer();      // cycle-stamp destinations of the -DMS_CONV_TRACE_BUILD / -DMS_WGRAD_TRACE_BUILD diagnostic builds (ms_diag_set_trace); null otherwise
+long long* wgrad_trace_buffer();
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -150,13 +174,6 @@ template <> struct ActIO<ms_f32wb> : ActIO<float> {};
 struct ms_bf16wb { uint16_t v; };
 template <> struct ActIO<ms_bf16wb> : ActIO<ms_bf16> {};
 
-// ms_f32x3: fp32 storage, fp32-FAITHFUL matrix arithmetic on the bf16 matrix cores: every operand of the contraction is split into three bf16 numbers
-// (hi + mid + lo = the fp32 value to 2^-24) and the six leading products hi*hi, mid*hi, hi*mid, lo*hi, hi*lo, mid*mid are accumulated in fp32 by
-// v_mfma_f32_16x16x16_bf16 - two products per instruction (the K = 16 of the instruction holds two splits of an 8-channel chunk).  Error against fp64
-// below that of an fp32 FMA chain (profiles/r03_experiments.txt, section 7).  Loads / stores are those of float.
-struct ms_f32x3 { float v; };
-template <> struct ActIO<ms_f32x3> : ActIO<float> {};
-
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -167,6 +184,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // destination and puts `s_waitcnt vmcnt(0)` in front of the first ds_read / ds_write behind it (found in round 4: the mask prefetch of the Winograd kernel was waited for
 // at once - its ~1 us of HBM latency exposed once per work item - and in the staging waves the wait also covered the NEXT chunk's global loads: no prefetch at all).
 // The assembly is opaque to that pass; the code that reads the landing zone waits with its own counted `s_waitcnt vmcnt(N)` (loads return in order).
+// M0 is written inside the statement and declared clobbered (any compiler-generated M0 user - movrel, sendmsg, another DMA builtin - must not assume it survives).
 // rsrc: {base lo, base hi (stride 0), num_records, flags}; lds_byte_addr: wave-uniform LDS byte address; voff: per-lane byte offset; soff: wave-uniform byte offset.
 typedef int ms_i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ ms_i32x4 ms_dma_rsrc(const void* base) {
@@ -184,11 +202,11 @@ __device__ __forceinline__ ms_i32x4 ms_dma_rsrc_n(const void* base, unsigned byt
   return r;
 }
 __device__ __forceinline__ void ms_lds_dma16(ms_i32x4 rsrc, unsigned lds_byte_addr, int voff, int soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 // the 4-byte form: lane i's dword lands at lds_byte_addr + 4 i (256 contiguous bytes per wave instruction)
 __device__ __forceinline__ void ms_lds_dma4(ms_i32x4 rsrc, unsigned lds_byte_addr, int voff, int soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 __device__ __forceinline__ unsigned ms_lds_addr(const void* p) {      // byte address inside the workgroup's LDS allocation of a pointer into a __shared__ array
   typedef __attribute__((address_space(3))) void* lds_p;

@@ -27,6 +27,8 @@
 #include "ms_conv_k1s.h"
 #include "ms_conv_s2.h"
 #include "ms_conv_k1g.h"
+#include "ms_conv_k3n.h"
+#include "ms_pack.h"
 #include "maxstyle_hip.h"
 
 namespace ms {
@@ -77,7 +79,6 @@ extern "C" size_t ms_conv_stats_bytes(int N, int Cout, int Hout, int Wout) {
 }
 
 struct MaskEpi { const float* u; const float* coef4; float slope; float* tab; int mode = 3; };     // mode 3: activation-backward epilogue; 4 / 5: residual-block tail
-struct FinEpi { int* counter; float* out; const float* gamma; const float* beta; float eps; double count; };
 // cross-workgroup finalize (ConvArgs::xf_*): the statistics table of the BatchNorm whose coefficients this launch consumes, its affine parameters, the record
 // buffer the launch fills for later kernels, the granule table (2 x 8 bytes per channel, zero-filled once by the caller) and the error word
 struct Ride { int kind; const float* part2; int nparts; const float* coef4; const float* p1; float eps; double count; float* out4; int C; };      // ConvArgs::ride_*
@@ -86,17 +87,16 @@ struct XFin { const float* tab; const float* gamma; const float* beta; float eps
 static int conv2d_impl(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                        int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                        int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
-                       int epi_mode, float* stats, const MaskEpi* mk, const FinEpi* fin, void* stream, int act_bf16 = 0, const XFin* xf = nullptr, const Ride* ride = nullptr) {
+                       int epi_mode, float* stats, const MaskEpi* mk, void* stream, int act_bf16 = 0, const XFin* xf = nullptr, const Ride* ride = nullptr) {
   if (N < 1 || Cin < 1 || Cout < 1 || Hs < 1 || Ws < 1) { set_error("ms_conv2d: invalid shape"); return MS_ERR_INVALID; }
   // bit 8 of `fetch` (MS_FETCH_WINOGRAD): the caller accepts the Winograd F(2x2,3x3) form for this call where it is built (see include/maxstyle_hip.h)
   const bool wino_ok = (fetch >= 0) && (fetch & MS_FETCH_WINOGRAD) != 0;
-  const bool x3_ok = (fetch >= 0) && (fetch & MS_FETCH_X3) != 0;               // bit 9: ... the three-way bf16 split form
   const bool wino_nt1 = (fetch >= 0) && (fetch & MS_FETCH_WINO_NT1) != 0;      // bit 10: the one-channel-block variant of the Winograd form
   const bool wino_u = (fetch >= 0) && (fetch & MS_FETCH_WINO_U) != 0;          // bit 11: w_packed carries the Winograd appendix
   const bool wino_blocks = (fetch >= 0) && (fetch & MS_FETCH_WINO_BLOCKS) != 0;     // bit 12: the block form wherever legal
-  if (fetch >= 0) fetch &= ~(MS_FETCH_WINOGRAD | MS_FETCH_X3 | MS_FETCH_WINO_NT1 | MS_FETCH_WINO_U | MS_FETCH_WINO_BLOCKS);
-  if (pro_mode < 0 || pro_mode > 3 || epi_mode < 0 || (epi_mode > 2 && epi_mode != MS_EPI_POOL2) || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
-  if (epi_mode == MS_EPI_POOL2 && (mk != nullptr || fin != nullptr || stats != nullptr || bias != nullptr)) { set_error("ms_conv2d: the pooled epilogue is a plain store (no bias, statistics or mask)"); return MS_ERR_INVALID; }
+  if (fetch >= 0) fetch &= ~(MS_FETCH_WINOGRAD | MS_FETCH_WINO_NT1 | MS_FETCH_WINO_U | MS_FETCH_WINO_BLOCKS);
+  if (pro_mode < 0 || pro_mode > 2 || epi_mode < 0 || (epi_mode > 2 && epi_mode != MS_EPI_POOL2) || fetch < 0 || fetch > 2) { set_error("ms_conv2d: invalid mode"); return MS_ERR_INVALID; }
+  if (epi_mode == MS_EPI_POOL2 && (mk != nullptr || stats != nullptr || bias != nullptr)) { set_error("ms_conv2d: the pooled epilogue is a plain store (no bias, statistics or mask)"); return MS_ERR_INVALID; }
   // the activation helper computes max(v, v*slope): LeakyReLU / ReLU slopes only
   if ((pro_mode == 1 && !(slope >= 0.f && slope <= 1.f)) || (mk != nullptr && !(mk->slope >= 0.f && mk->slope <= 1.f))) { set_error("ms_conv2d: activation slope outside [0, 1]"); return MS_ERR_INVALID; }
   if (mk != nullptr && mk->mode != 3) {
@@ -119,14 +119,7 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
     pro_a = pro_b = pro_c = xf->coef4;                                             // (not read by the launch: the table is filled from the granules)
     pro_cstride = 4;
   }
-  // pro_mode 3 = pro_mode 2 whose coefficients are derived in-kernel from the partial sums of ms_act_bwd_reduce:
-  //   pro_a = partials [Cin][pro_nstride][2], pro_b = forward coefficient records (stride pro_cstride), pro_c = optional output [Cin][4]
-  int bw_parts = 0; float* bw_out = nullptr;
-  if (pro_mode == 3) {
-    if (in2 == nullptr || pro_nstride < 1 || pro_cstride < 4) { set_error("ms_conv2d: pro_mode 3 needs in2, pro_nstride = partial count and float4 coefficient records"); return MS_ERR_INVALID; }
-    bw_parts = pro_nstride; bw_out = const_cast<float*>(pro_c);
-    pro_mode = 2; pro_nstride = 0;
-  } else if (pro_mode == 2 && (in2 == nullptr || pro_c == nullptr)) { set_error("ms_conv2d: pro_mode 2 needs in2 and pro_c"); return MS_ERR_INVALID; }
+  if (pro_mode == 2 && (in2 == nullptr || pro_c == nullptr)) { set_error("ms_conv2d: pro_mode 2 needs in2 and pro_c"); return MS_ERR_INVALID; }
   if (pro_mode != 0 && (pro_a == nullptr || pro_b == nullptr)) { set_error("ms_conv2d: prologue coefficients missing"); return MS_ERR_INVALID; }
   if (epi_mode == 2 && (ks != 1 || stride != 1 || fetch != 0 || stats != nullptr)) { set_error("ms_conv2d: pixel-shuffle epilogue is for the k=1 GEMM form of ConvTranspose2d(k=2,s=2)"); return MS_ERR_INVALID; }
   if (!aligned16(w_packed)) { set_error("ms_conv2d: packed weights must be 16-byte aligned"); return MS_ERR_ALIGN; }
@@ -146,20 +139,13 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   const int gemm_cols = (epi_mode == 2) ? 4 * Cout : Cout;
   a.Cout = gemm_cols;
   a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (gemm_cols + 63) / 64 * 64;
-  a.bw_parts = bw_parts; a.bw_count = (double)N * Hs * Ws; a.bw_out = bw_out;
   a.wino_ok = wino_ok ? 1 : 0;
-  a.x3_ok = x3_ok ? 1 : 0;
   a.wino_nt1 = wino_nt1 ? 1 : 0;
   a.wino_blocks = wino_blocks ? 1 : 0;
   a.wu = (wino_u && wino_ok && ks == 3 && stride == 1 && Cin % 8 == 0) ? w_packed + (size_t)9 * a.cin_pad * a.cout_pad : nullptr;
   a.act_bf16 = act_bf16;                  // 0 fp32 storage | 1 bf16 storage, fp32 matrix arithmetic | 2 bf16 storage, bf16 matrix arithmetic where built (`_bf16m`)
   a.pro_mode = pro_mode; a.pro_nstride = pro_nstride; a.pro_cstride = pro_cstride < 1 ? 1 : pro_cstride; a.slope = slope; a.epi_mode = epi_mode;
   if (mk != nullptr) { a.mk_u = mk->u; a.mk_coef = mk->coef4; a.mk_slope = mk->slope; a.mk_tab = mk->tab; }
-  if (fin != nullptr) {
-    if (fin->counter == nullptr || fin->out == nullptr || !aligned16(fin->out) || (mk == nullptr && (stats == nullptr || fin->gamma == nullptr || fin->beta == nullptr)) ||
-        (mk != nullptr && !(fin->count > 0))) { set_error("ms_conv2d_fin: counter, output and the BatchNorm operands are required"); return MS_ERR_INVALID; }
-    a.fin_counter = fin->counter; a.fin_out = fin->out; a.fin_gamma = fin->gamma; a.fin_beta = fin->beta; a.fin_eps = fin->eps; a.fin_count = fin->count;
-  }
   if (xf != nullptr) {
     if (xf->tab == nullptr || xf->gamma == nullptr || (xf->kind == 0 && xf->beta == nullptr) || xf->coef4 == nullptr || xf->gran == nullptr || xf->err == nullptr || xf->C < 1 ||
         !aligned16(xf->tab) || !aligned16(xf->coef4) || (reinterpret_cast<uintptr_t>(xf->gran) & 7u) != 0) {
@@ -210,21 +196,15 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   // work items - the 64-channel tile needs 205 registers (one workgroup per CU) and leaves most of the chip idle there (tools/tune_conv.py 10 c4: 120 -> 92 us at
   // 512 -> 512 @16x20x20, 201 -> 150 us at 512 -> 256 @16x40x40).  Not the 16-pixel-wide levels (their own tile shape and chunking, tuned in round 3).
   if (ks == 1 && !narrow && epi_mode != 2 && tiles < (long)num_cus() && gemm_cols >= 256 && tiles * cdiv(gemm_cols, 16) >= 512L) nt = 1;
-  // tuning hook (tools/tune_conv.py): with MS_CONV_TUNE set, MS_CONV_FORCE_NT / MS_CONV_FORCE_WIDE are re-read on every call
-  static const bool tune = getenv("MS_CONV_TUNE") != nullptr;
-  bool allow_wide = true;
-  if (tune) {
-    const char* f = getenv("MS_CONV_FORCE_NT");
-    const int fnt = f ? atoi(f) : 0;
+  // tuning hook (tools/tune_conv.py): option "conv.force_nt"
+  {
+    const int fnt = opt(OPT_CONV_FORCE_NT);
     if (fnt == 1 || fnt == 2 || (fnt == 4 && ks != 3 && pro_mode != 2)) nt = fnt;
-    const char* fw = getenv("MS_CONV_FORCE_WIDE");
-    if (fw && atoi(fw) == 0) allow_wide = false;
   }
+  constexpr bool allow_wide = true;      // (every second-generation form has its own option: conv.wide / conv.k1s / conv.k1g / conv.s2g2)
   a.ncb = cdiv(gemm_cols, 16 * nt);
-  { static const int dbg = getenv("MS_CONV_DBG") ? atoi(getenv("MS_CONV_DBG")) : 0; a.dbg = dbg; }
-  { static const int pf = getenv("MS_CONV_PF") ? atoi(getenv("MS_CONV_PF")) : 0; a.pf = tune && getenv("MS_CONV_PF") ? atoi(getenv("MS_CONV_PF")) : pf; }
-  { static const int stag = getenv("MS_CONV_STAGGER") ? atoi(getenv("MS_CONV_STAGGER")) : 0; a.stagger = tune && getenv("MS_CONV_STAGGER") ? atoi(getenv("MS_CONV_STAGGER")) : stag; }
-  { static const char* tr = getenv("MS_CONV_TRACE"); a.trace = tr ? (long long*)strtoull(tr, nullptr, 0) : nullptr; }
+  a.dbg = opt(OPT_DIAG_CONV_DBG);
+  a.trace = conv_trace_buffer();
   hipStream_t st = (hipStream_t)stream;
   const bool use_in2 = (pro_mode == 2);
   if (epi_mode == MS_EPI_POOL2) {
@@ -234,6 +214,7 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
     return conv_dispatch_wide(a, nt, st);
   }
   if (allow_wide && conv_wide_eligible(a, ks, stride, fetch, vec)) return conv_dispatch_wide(a, nt, st);
+  if (conv_k3n_eligible(a, ks, stride, fetch)) return conv_dispatch_k3n(a, st);      // second generation for rows of 12 / 14 / 16 pixels (ms_conv_k3n.h)
   if (ks == 3 && stride == 1) return conv_dispatch_k3s1(a, fetch, nt, vec, narrow, use_in2, st);
   if (ks == 1 && allow_wide && conv_k1s_eligible(a, ks, stride, fetch)) return conv_dispatch_k1s(a, st);      // streaming form (ms_conv_k1s.h)
   if (ks == 1 && allow_wide && conv_k1g_eligible(a, ks, stride, fetch)) return conv_dispatch_k1g(a, st);      // LDS-tiled GEMM form of the channel-heavy levels (ms_conv_k1g.h)
@@ -242,7 +223,7 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
   return conv_dispatch_s2(a, ks, nt, vec, narrow, st);
 }
 
-namespace ms { int& conv_k1s_switch() { static int on = []() { const char* e = getenv("MS_CONV_K1S"); return (e && atoi(e) == 0) ? 0 : 1; }(); return on; } }
+namespace ms { int conv_k1s_switch() { return opt(OPT_CONV_K1S); } }
 // whether ms_conv2d (epi_mode 0 / 2) / ms_conv1x1_bnres (epi_mode 4; 5 = half-resolution input) would take the streaming kernel for this 1x1 shape (16-byte aligned fp32 tensors assumed)
 extern "C" int ms_conv_k1s_would_run(int N, int Cin, int H, int W, int Cout, int epi_mode) {
   if (N < 1 || Cin < 1 || H < 1 || W < 1 || Cout < 1) return 0;
@@ -251,18 +232,15 @@ extern "C" int ms_conv_k1s_would_run(int N, int Cin, int H, int W, int Cout, int
   a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (a.Cout + 63) / 64 * 64; a.epi_mode = epi_mode;
   return conv_k1s_eligible(a, 1, 1, FETCH_NORMAL) ? 1 : 0;
 }
-namespace ms { int& conv_s2g2_switch() { static int on = []() { const char* e = getenv("MS_CONV_S2G2"); return (e && atoi(e) == 0) ? 0 : 1; }(); return on; } }
-namespace ms { int& conv_k1g_switch() { static int on = []() { const char* e = getenv("MS_CONV_K1G"); return (e && atoi(e) == 0) ? 0 : 1; }(); return on; } }
-extern "C" int ms_conv_k1g_enable(int on) { const int was = conv_k1g_switch(); if (on == 0 || on == 1) conv_k1g_switch() = on; return was; }
-extern "C" int ms_conv_s2g2_enable(int on) { const int was = conv_s2g2_switch(); if (on == 0 || on == 1) conv_s2g2_switch() = on; return was; }
-extern "C" int ms_conv_k1s_enable(int on) { const int was = conv_k1s_switch(); if (on == 0 || on == 1) conv_k1s_switch() = on; return was; }
+namespace ms { int conv_s2g2_switch() { return opt(OPT_CONV_S2G2); } }
+namespace ms { int conv_k1g_switch() { return opt(OPT_CONV_K1G); } }
 
 extern "C" int ms_conv2d(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
                          int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
                          int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                          int epi_mode, float* stats, void* stream) {
   return conv2d_impl(in, in2, out, w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
-                     epi_mode, stats, nullptr, nullptr, stream);
+                     epi_mode, stats, nullptr, stream);
 }
 
 // ms_conv2d (a 1x1 conv) that also carries a ms_bn_bwd_coefs (ride_kind 0) or ms_bn_finalize (ride_kind 1) job for the launch BEHIND it: one MFMA wave per channel
@@ -278,33 +256,9 @@ extern "C" int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int pr
 }
 namespace ms { int conv_wino_blocks(const ConvArgs& a); bool conv_wino_blockform(const ConvArgs& a); }      // ms_conv_inst_wino.hip
 namespace ms {
-// one thread per (input channel, output channel) pair: U = G g G^T with EXACTLY the expression of the staging waves (conv_wide_kernel store_chunk), so the kernel that
-// copies U from here computes the same bits as the one that transforms the taps itself
+// (the arithmetic is wino_pack_one, ms_pack.h: shared with the batched appendix refresh ms_appendix_batch)
 __global__ __launch_bounds__(256) void wino_pack_kernel(float* __restrict__ wp, int Cin, int Cout, int cin_pad, int cout_pad) {
-  const int nchunks = Cin / 8, ncb = (Cout + 15) / 16;
-  const long total = (long)ncb * nchunks * 128;
-  const long id = (long)blockIdx.x * 256 + threadIdx.x;
-  if (id >= total) return;
-  const int m = (int)(id & 15), ci = (int)((id >> 4) & 7);
-  const long blk = id >> 7;                        // cb16 * nchunks + chunk
-  const int chunk = (int)(blk % nchunks), cb = (int)(blk / nchunks);
-  const int c = chunk * 8 + ci, co = cb * 16 + m;
-  float g[9];
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap) g[tap] = (co < cout_pad) ? wp[((size_t)tap * cin_pad + c) * cout_pad + co] : 0.f;
-  float t[4][3];
-#pragma unroll
-  for (int kx = 0; kx < 3; ++kx) {
-    const float g0 = g[kx], g1 = g[3 + kx], g2 = g[6 + kx];
-    t[0][kx] = g0; t[1][kx] = 0.5f * ((g0 + g2) + g1); t[2][kx] = 0.5f * ((g0 + g2) - g1); t[3][kx] = g2;
-  }
-  float* u = wp + (size_t)9 * cin_pad * cout_pad + (size_t)blk * 2048 + ci * 16 + m;
-#pragma unroll
-  for (int xi = 0; xi < 4; ++xi) {
-    const float u0 = t[xi][0], u3 = t[xi][2];
-    const float u1 = 0.5f * ((t[xi][0] + t[xi][2]) + t[xi][1]), u2 = 0.5f * ((t[xi][0] + t[xi][2]) - t[xi][1]);
-    u[(xi * 4 + 0) * 128] = u0; u[(xi * 4 + 1) * 128] = u1; u[(xi * 4 + 2) * 128] = u2; u[(xi * 4 + 3) * 128] = u3;
-  }
+  wino_pack_one((long)blockIdx.x * 256 + threadIdx.x, wp, Cin, Cout, cin_pad, cout_pad);
 }
 }  // namespace ms
 extern "C" size_t ms_wino_pack_floats(int Cin, int Cout) {
@@ -323,7 +277,7 @@ extern "C" int ms_conv2d_form(int N, int Cin, int H, int W, int Cout, int pro_mo
   ConvArgs a{};
   a.N = N; a.Cin = Cin; a.Hs = a.Hin = a.Hout = H; a.Ws = a.Win = a.Wout = W; a.Cout = a.cout_real = Cout;
   a.cin_pad = (Cin + 3) / 4 * 4; a.cout_pad = (Cout + 63) / 64 * 64;
-  a.pro_mode = pro_mode; a.wino_ok = (fetch & MS_FETCH_WINOGRAD) ? 1 : 0; a.x3_ok = (fetch & MS_FETCH_X3) ? 1 : 0; a.wino_nt1 = (fetch & MS_FETCH_WINO_NT1) ? 1 : 0;
+  a.pro_mode = pro_mode; a.wino_ok = (fetch & MS_FETCH_WINOGRAD) ? 1 : 0; a.wino_nt1 = (fetch & MS_FETCH_WINO_NT1) ? 1 : 0;
   a.wino_blocks = (fetch & MS_FETCH_WINO_BLOCKS) ? 1 : 0;
   a.act_bf16 = (bf16 < 0 || bf16 > 2) ? 2 : bf16;
   static const float appendix_marker = 0.f;             // (only compared with null by the dispatch rules)
@@ -348,7 +302,7 @@ extern "C" int ms_conv2d_ride(const float* in, const float* in2, float* out, con
                               void* stream) {
   const Ride rd{ride_kind, ride_tab, ride_nparts, ride_p0, ride_p1, ride_eps, ride_count, ride_out4, ride_C};
   return conv2d_impl(in, in2, out, w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
-                     epi_mode, stats, nullptr, nullptr, stream, 0, nullptr, &rd);
+                     epi_mode, stats, nullptr, stream, 0, nullptr, &rd);
 }
 extern "C" int ms_conv2d_ride_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias,
                                    int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
@@ -358,23 +312,14 @@ extern "C" int ms_conv2d_ride_bf16(const uint16_t* in, const uint16_t* in2, uint
                                    void* stream) {
   const Ride rd{ride_kind, ride_tab, ride_nparts, ride_p0, ride_p1, ride_eps, ride_count, ride_out4, ride_C};
   return conv2d_impl(reinterpret_cast<const float*>(in), reinterpret_cast<const float*>(in2), reinterpret_cast<float*>(out), w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch,
-                     pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope, epi_mode, stats, nullptr, nullptr, stream, 1, nullptr, &rd);
-}
-
-extern "C" int ms_conv2d_fin(const float* in, const float* in2, float* out, const float* w_packed, const float* bias,
-                             int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
-                             int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
-                             float* stats, const float* gamma, const float* beta, float eps, float* coef4, int* counter, void* stream) {
-  const FinEpi fin{counter, coef4, gamma, beta, eps, 0.0};
-  return conv2d_impl(in, in2, out, w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
-                     0, stats, nullptr, &fin, stream);
+                     pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope, epi_mode, stats, nullptr, stream, 1, nullptr, &rd);
 }
 
 extern "C" int ms_conv1x1_bnres(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
                                 const float* u, const float* coef4, float slope, int up2, void* stream) {
   MaskEpi mk{u, coef4, slope, nullptr};
   mk.mode = up2 ? 5 : 4;
-  return conv2d_impl(in, nullptr, out, w_packed, bias, N, Cin, Hs, Ws, Cout, 1, 1, 0, 0, nullptr, nullptr, nullptr, 0, 1, 1.0f, 0, nullptr, &mk, nullptr, stream);
+  return conv2d_impl(in, nullptr, out, w_packed, bias, N, Cin, Hs, Ws, Cout, 1, 1, 0, 0, nullptr, nullptr, nullptr, 0, 1, 1.0f, 0, nullptr, &mk, stream);
 }
 
 extern "C" size_t ms_xfin_gran_bytes(int C) { return (size_t)C * kXfinNG * kXfinRep * sizeof(conv_u64_t); }
@@ -387,7 +332,7 @@ extern "C" int ms_conv1x1_bnres_xfin(const float* in, float* out, const float* w
   MaskEpi mk{u, coef4, slope, nullptr};
   mk.mode = up2 ? 5 : 4;
   const XFin xf{stats, gamma, beta, eps, coef4, gran, err, Cout};
-  return conv2d_impl(in, nullptr, out, w_packed, bias, N, Cin, Hs, Ws, Cout, 1, 1, 0, 0, nullptr, nullptr, nullptr, 0, 1, 1.0f, 0, nullptr, &mk, nullptr, stream, 0, &xf);
+  return conv2d_impl(in, nullptr, out, w_packed, bias, N, Cin, Hs, Ws, Cout, 1, 1, 0, 0, nullptr, nullptr, nullptr, 0, 1, 1.0f, 0, nullptr, &mk, stream, 0, &xf);
 }
 extern "C" int ms_conv1x1_bnres_xfin_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
                                           const uint16_t* u, const float* stats, const float* gamma, const float* beta, float eps, float* coef4, void* gran, int* err,
@@ -396,7 +341,7 @@ extern "C" int ms_conv1x1_bnres_xfin_bf16(const uint16_t* in, uint16_t* out, con
   mk.mode = up2 ? 5 : 4;
   const XFin xf{stats, gamma, beta, eps, coef4, gran, err, Cout};
   return conv2d_impl(reinterpret_cast<const float*>(in), nullptr, reinterpret_cast<float*>(out), w_packed, bias, N, Cin, Hs, Ws, Cout, 1, 1, 0, 0, nullptr, nullptr, nullptr, 0, 1, 1.0f,
-                     0, nullptr, &mk, nullptr, stream, 1, &xf);
+                     0, nullptr, &mk, stream, 1, &xf);
 }
 
 // ms_bn_finalize (kind 0, pro_mode 1) or ms_bn_bwd_coefs on a conv-epilogue table (kind 1, pro_mode 2) + the ms_conv2d that consumes the coefficients in its
@@ -407,7 +352,7 @@ static int conv2d_xfin_impl(const float* in, const float* in2, float* out, const
                             float* coef4, void* gran, int* err, void* stream, int act_bf16) {
   XFin xf{tab, p0, p1, eps, coef4, gran, err, Cin};
   xf.kind = kind; xf.count = count;
-  return conv2d_impl(in, in2, out, w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, nullptr, nullptr, nullptr, 0, 4, slope, epi_mode, stats, nullptr, nullptr, stream,
+  return conv2d_impl(in, in2, out, w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, nullptr, nullptr, nullptr, 0, 4, slope, epi_mode, stats, nullptr, stream,
                      act_bf16, &xf);
 }
 extern "C" int ms_conv2d_xfin(const float* in, const float* in2, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride,
@@ -431,13 +376,13 @@ extern "C" int ms_conv2d_bf16(const uint16_t* in, const uint16_t* in2, uint16_t*
                               int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                               int epi_mode, float* stats, void* stream) {
   return conv2d_impl(as_f(in), as_f(in2), as_f(out), w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
-                     epi_mode, stats, nullptr, nullptr, stream, 1);
+                     epi_mode, stats, nullptr, stream, 1);
 }
 extern "C" int ms_conv1x1_bnres_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
                                      const uint16_t* u, const float* coef4, float slope, int up2, void* stream) {
   MaskEpi mk{as_f(u), coef4, slope, nullptr};
   mk.mode = up2 ? 5 : 4;
-  return conv2d_impl(as_f(in), nullptr, as_f(out), w_packed, bias, N, Cin, Hs, Ws, Cout, 1, 1, 0, 0, nullptr, nullptr, nullptr, 0, 1, 1.0f, 0, nullptr, &mk, nullptr, stream, 1);
+  return conv2d_impl(as_f(in), nullptr, as_f(out), w_packed, bias, N, Cin, Hs, Ws, Cout, 1, 1, 0, 0, nullptr, nullptr, nullptr, 0, 1, 1.0f, 0, nullptr, &mk, stream, 1);
 }
 extern "C" int ms_conv2d_actbwd_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed,
                                      int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
@@ -445,7 +390,7 @@ extern "C" int ms_conv2d_actbwd_bf16(const uint16_t* in, const uint16_t* in2, ui
                                      const uint16_t* u, const float* coef4, float act_slope, float* tab, void* stream) {
   const MaskEpi mk{as_f(u), coef4, act_slope, tab};
   return conv2d_impl(as_f(in), as_f(in2), as_f(out), w_packed, nullptr, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
-                     0, nullptr, &mk, nullptr, stream, 1);
+                     0, nullptr, &mk, stream, 1);
 }
 
 // ---- `_bf16m`: bf16 storage AND bf16 matrix arithmetic.  3x3 stride-1 convolutions with rows of >= 16 pixels run v_mfma_f32_16x16x16_bf16 (fp32 accumulation):
@@ -455,7 +400,7 @@ extern "C" int ms_conv2d_bf16m(const uint16_t* in, const uint16_t* in2, uint16_t
                                int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
                                int epi_mode, float* stats, void* stream) {
   return conv2d_impl(as_f(in), as_f(in2), as_f(out), w_packed, bias, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
-                     epi_mode, stats, nullptr, nullptr, stream, 2);
+                     epi_mode, stats, nullptr, stream, 2);
 }
 extern "C" int ms_conv2d_actbwd_bf16m(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed,
                                       int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
@@ -463,7 +408,7 @@ extern "C" int ms_conv2d_actbwd_bf16m(const uint16_t* in, const uint16_t* in2, u
                                       const uint16_t* u, const float* coef4, float act_slope, float* tab, void* stream) {
   const MaskEpi mk{as_f(u), coef4, act_slope, tab};
   return conv2d_impl(as_f(in), as_f(in2), as_f(out), w_packed, nullptr, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
-                     0, nullptr, &mk, nullptr, stream, 2);
+                     0, nullptr, &mk, stream, 2);
 }
 
 extern "C" size_t ms_conv_actbwd_tab_bytes(int Cout) { return ((size_t)Cout * kStatSlots + 1) * sizeof(float2); }
@@ -474,17 +419,7 @@ extern "C" int ms_conv2d_actbwd(const float* in, const float* in2, float* out, c
                                 const float* u, const float* coef4, float act_slope, float* tab, void* stream) {
   const MaskEpi mk{u, coef4, act_slope, tab};
   return conv2d_impl(in, in2, out, w_packed, nullptr, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
-                     0, nullptr, &mk, nullptr, stream);
-}
-
-extern "C" int ms_conv2d_actbwd_fin(const float* in, const float* in2, float* out, const float* w_packed,
-                                    int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
-                                    int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_nstride, int pro_cstride, float slope,
-                                    const float* u, const float* coef4, float act_slope, float* tab, double count, float* bcoef4, int* counter, void* stream) {
-  const MaskEpi mk{u, coef4, act_slope, tab};
-  const FinEpi fin{counter, bcoef4, nullptr, nullptr, 0.f, count};
-  return conv2d_impl(in, in2, out, w_packed, nullptr, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pro_mode, pro_a, pro_b, pro_c, pro_nstride, pro_cstride, slope,
-                     0, nullptr, &mk, &fin, stream);
+                     0, nullptr, &mk, stream);
 }
 
 extern "C" int ms_bn_finalize(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, int C, void* stream) {

@@ -3,26 +3,23 @@
 namespace ms {
 // Winograd F(2x2, 3x3) mode of the wide kernel (ms_conv_wide.h, AT = ms_f32w / ms_f32w32): fp32 storage, channel count a multiple of the 8-channel chunk
 static bool conv_wino_on(const ConvArgs& a) {
-  // MS_CONV_WINO: 0 = direct form everywhere | 1 (default) = where the caller allows it (MS_FETCH_WINOGRAD) | 2 = every eligible call (tools / tests)
-  static const int mode = getenv("MS_CONV_WINO") ? atoi(getenv("MS_CONV_WINO")) : 1;
-  static const int max_cb = getenv("MS_CONV_WINO_MAXCB") ? atoi(getenv("MS_CONV_WINO_MAXCB")) : 1 << 20;
+  // option "conv.wino": 0 = direct form everywhere | 1 (default) = where the caller allows it (MS_FETCH_WINOGRAD) | 2 = every eligible call (tools / tests)
+  const int mode = opt(OPT_CONV_WINO);
   if (mode == 0 || (mode == 1 && !a.wino_ok)) return false;
-  if (a.act_bf16 == 2 || a.cin_pad % 8 != 0 || a.Cin != a.cin_pad) return false;      // (bf16 matrix arithmetic has its own kernel mode)
-  return cdiv(a.Cout, 16) <= max_cb;
+  return !(a.act_bf16 == 2 || a.cin_pad % 8 != 0 || a.Cin != a.cin_pad);      // (bf16 matrix arithmetic has its own kernel mode)
 }
-// rows of 20..63 pixels: only the Winograd form has a tile for them (8 rows x 32 pixels); MS_CONV_WINO32=0 leaves them to the first-generation kernel
+// rows of 20..63 pixels: only the Winograd form has a tile for them (8 rows x 32 pixels); option "conv.wino32" = 0 leaves them to the first-generation kernel
 static bool conv_wino32_on(const ConvArgs& a) {
-  static const bool on = !(getenv("MS_CONV_WINO32") && atoi(getenv("MS_CONV_WINO32")) == 0);
+  const bool on = opt(OPT_CONV_WINO32) != 0;
   // narrower rows leave part of the 32-pixel tile empty: at 20 pixels (62 % full) the form still executes 0.71x the direct form's multiplications and wins
   // (C4's 512-channel 20x20 layers: 27.1 -> 29.3 steps/s), at 16 pixels (0.89x) it loses to the first-generation kernel (C2: 21.9 -> 23.7 us per launch)
-  static const int minw = getenv("MS_CONV_WINO32_MINW") ? atoi(getenv("MS_CONV_WINO32_MINW")) : 20;
+  constexpr int minw = 20;
   return on && a.Wout >= minw && a.Wout < 64 && conv_wino_on(a);
 }
 bool conv_wide_eligible(const ConvArgs& a, int ks, int stride, int fetch, bool vec) {
-  static const bool off = getenv("MS_CONV_WIDE") != nullptr && atoi(getenv("MS_CONV_WIDE")) == 0;      // A/B switch for timing
-  if (off) return false;
+  if (opt(OPT_CONV_WIDE) == 0) return false;      // A/B switch for timing and for the "same bits as the first generation" tests
   if (ks != 3 || stride != 1 || fetch != FETCH_NORMAL || !vec) return false;
-  if (a.epi_mode == 2 || (a.pro_mode != 0 && a.pro_nstride != 0) || a.bw_parts > 0) return false;      // (pro_mode 3 derives its coefficients in the first-generation kernel only)
+  if (a.epi_mode == 2 || (a.pro_mode != 0 && a.pro_nstride != 0)) return false;
   // (the two-tensor BatchNorm-backward prologue runs with 8-channel chunks: twice the staging registers per channel; 70.4 vs 74.2 us on the
   //  first-generation kernel at 16->16 @16x256x256)
   // fp32 arithmetic: rows of at least one 64-pixel tile.  bf16 matrix arithmetic (act_bf16 == 2): the matrix work of the padding columns of a narrower row is
@@ -42,17 +39,8 @@ static int wide_pro(const ConvArgs& a, hipStream_t st) {
   }
 }
 int conv_dispatch_wino(const ConvArgs& a, hipStream_t st);      // ms_conv_inst_wino.hip
-int conv_dispatch_x3(const ConvArgs& a, hipStream_t st);        // ms_conv_inst_x3.hip
-// three-way bf16 split mode (ms_conv_wide.h, AT = ms_f32x3): fp32 storage, rows of at least one 64-pixel tile, channel count a multiple of the 8-channel chunk
-static bool conv_x3_on(const ConvArgs& a) {
-  // MS_CONV_X3: 0 = never | 1 (default) = where the caller allows it (MS_FETCH_X3) | 2 = every eligible call (tools / tests)
-  static const int mode = getenv("MS_CONV_X3") ? atoi(getenv("MS_CONV_X3")) : 1;
-  if (mode == 0 || (mode == 1 && !a.x3_ok)) return false;
-  return a.act_bf16 == 0 && a.cin_pad % 8 == 0 && a.Cin == a.cin_pad && a.Wout >= 64;
-}
-bool conv_wide_is_wino(const ConvArgs& a) { return !conv_x3_on(a) && ((a.Wout < 64 && a.act_bf16 != 2) || conv_wino_on(a)); }
+bool conv_wide_is_wino(const ConvArgs& a) { return (a.Wout < 64 && a.act_bf16 != 2) || conv_wino_on(a); }
 int conv_dispatch_wide(const ConvArgs& a, int nt, hipStream_t st) {
-  if (conv_x3_on(a)) return conv_dispatch_x3(a, st);
   if ((a.Wout < 64 && a.act_bf16 != 2) || conv_wino_on(a)) return conv_dispatch_wino(a, st);      // (rows below 64 pixels: conv_wide_eligible admitted them for this form only)
   if (conv_wide_rows(a, nt >= 2 ? 2 : 1) == 8) return conv_dispatch_wide8(a, nt, st);
   return nt >= 2 ? wide_pro<2>(a, st) : wide_pro<1>(a, st);

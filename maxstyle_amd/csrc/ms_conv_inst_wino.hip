@@ -15,12 +15,10 @@ int conv_dispatch_wino2(const ConvArgs& a, hipStream_t st);      // ms_conv_inst
 // transformed once per 32 output channels, but a SIMD then holds one MFMA wave and one staging wave instead of two of each.  Measured per layer on MI355X
 // (tools/ab_wino_nt.py, profiles/r04_wino_nt_ab.txt): it wins where the K loop is long and the staging side is light - at least one work item per CU and, with the
 // transformed weights staged from the packed tensor's appendix (MS_FETCH_WINO_U: what the engine does), Cin >= 32 under every prologue; when the staging waves transform
-// the taps themselves, Cin >= 64, and with the two-tensor BatchNorm-backward prologue only from 256 input channels up or where the layer widens (Cout > Cin).  MS_CONV_WINO_NT: 1 = the one-block form everywhere, 2 = two blocks wherever Cout > 16 (A/B switches); per call: MS_FETCH_WINO_NT1.
+// the taps themselves, Cin >= 64, and with the two-tensor BatchNorm-backward prologue only from 256 input channels up or where the layer widens (Cout > Cin).  option "conv.wino_nt": 1 = the one-block form everywhere, 2 = two blocks wherever Cout > 16 (A/B switches); per call: MS_FETCH_WINO_NT1.
 bool conv_wino_blockform(const ConvArgs& a);
 static int wino_nt(const ConvArgs& a) {
-  static const int cap = getenv("MS_CONV_WINO_NT") ? atoi(getenv("MS_CONV_WINO_NT")) : 0;
-  static const bool tune = getenv("MS_CONV_TUNE") != nullptr;
-  const int c = (tune && getenv("MS_CONV_WINO_NT")) ? atoi(getenv("MS_CONV_WINO_NT")) : cap;
+  const int c = opt(OPT_CONV_WINO_NT);
   if (c == 1 || a.Cout <= 16 || a.wino_nt1) return 1;
   if (c >= 2) return 2;
   const int tw = a.Wout < 64 ? 32 : 64, th = 256 / tw;
@@ -34,11 +32,9 @@ static int wino_nt(const ConvArgs& a) {
 }
 // Block form (ms_f32wb: four independent 8x8-pixel blocks per work item) where the rectangular tiles waste matrix work: fill = the fraction of a tile grid's pixels that
 // exist.  64x4 / 32x8 tiles fill rows of 80, 40 and 20 pixels to 62 %; 8x8 blocks fill any multiple of 8 completely (20 x 20: 69 %).  The block form stages every
-// block with its own halo (~17 % more staging work than the 32-pixel tiles), so it is taken only from a clearly better fill (rules below).  MS_CONV_WINO_BLOCK: 0 never, 2 wherever legal.
+// block with its own halo (~17 % more staging work than the 32-pixel tiles), so it is taken only from a clearly better fill (rules below).  option "conv.wino_block": 0 never, 2 wherever legal.
 bool conv_wino_blockform(const ConvArgs& a) {
-  static const int mode = getenv("MS_CONV_WINO_BLOCK") ? atoi(getenv("MS_CONV_WINO_BLOCK")) : 1;
-  static const bool tune = getenv("MS_CONV_TUNE") != nullptr;
-  const int md = (tune && getenv("MS_CONV_WINO_BLOCK")) ? atoi(getenv("MS_CONV_WINO_BLOCK")) : mode;
+  const int md = opt(OPT_CONV_WINO_BLOCK);
   if (a.wino_blocks) return true;                     // MS_FETCH_WINO_BLOCKS
   if (md == 0 || a.wino_nt1) return false;            // (MS_FETCH_WINO_NT1 pins the round-3 kernel: rectangular tiles, one block)
   if (md >= 2) return true;

@@ -243,20 +243,18 @@ __global__ __launch_bounds__(512, 4) void conv_k1g_kernel(const ConvArgs a) {
   }
 }
 
-int& conv_k1g_switch();      // ms_conv.hip (MS_CONV_K1G=0: off); ms_conv_k1g_enable()
+int conv_k1g_switch();      // ms_conv.hip: option "conv.k1g" (0: off - A/B runs and the same-bits tests)
 inline bool conv_k1g_eligible(const ConvArgs& a, int ks, int stride, int fetch) {
-  if (conv_k1g_switch() == 0 || ks != 1 || stride != 1 || fetch != FETCH_NORMAL || a.act_bf16 != 0 || a.pro_mode != 0 || a.in2 != nullptr || a.stats != nullptr || a.fin_counter != nullptr ||
-      a.bw_parts > 0 || !(a.epi_mode == 0 || a.epi_mode == 4 || a.epi_mode == 5)) return false;
+  if (conv_k1g_switch() == 0 || ks != 1 || stride != 1 || fetch != FETCH_NORMAL || a.act_bf16 != 0 || a.pro_mode != 0 || a.in2 != nullptr || a.stats != nullptr ||
+      !(a.epi_mode == 0 || a.epi_mode == 4 || a.epi_mode == 5)) return false;
   if (a.xf_tab != nullptr && a.epi_mode == 0) return false;
   const long HW = (long)a.Hs * a.Ws;
-  static const int cmin = []() { const char* e = getenv("MS_K1G_CMIN"); return e ? atoi(e) : 256; }();
+  constexpr int cmin = 256;
   if (a.Cin % 8 != 0 || a.Cin < cmin || HW % 4 != 0 || (a.epi_mode == 5 && a.Ws % 4 != 0)) return false;       // measured scope: the channel-heavy levels (tools/ab_k1.py)
   if ((long long)a.N * a.Cin * HW * 4 >= (1LL << 31) || (long long)a.cin_pad * a.cout_pad * 4 >= (1LL << 31)) return false;
   return aligned16(a.in) && aligned16(a.out) && aligned16(a.w) && (a.epi_mode == 0 || aligned16(a.mk_u));
 }
 inline int conv_k1g_nt(const ConvArgs& a) {
-  static const int ent = []() { const char* e = getenv("MS_K1G_NT"); return e ? atoi(e) : 0; }();
-  if (ent == 1 || ent == 2 || ent == 4) return ent;
   const long groups = cdiv((long)a.N * cdiv((long)a.Hs * a.Ws, 64L), 4L);
   for (int cand : {4, 2}) if (a.Cout >= 16 * cand && 2 * groups * cdiv(a.Cout, 16 * cand) >= 3L * num_cus()) return cand;
   return 1;

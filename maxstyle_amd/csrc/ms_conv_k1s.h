@@ -236,16 +236,16 @@ __global__ __launch_bounds__(256, 2) void conv_k1s_kernel(const ConvArgs a) {
   }
 }
 
-int& conv_k1s_switch();      // ms_conv.hip: 1 (default; MS_CONV_K1S=0 in the environment: 0) - ms_conv_k1s_enable() flips it for A/B runs and the same-bits tests
+int conv_k1s_switch();      // ms_conv.hip: option "conv.k1s" (0: off - A/B runs and the same-bits tests)
 inline bool conv_k1s_eligible(const ConvArgs& a, int ks, int stride, int fetch) {
-  if (conv_k1s_switch() == 0 || ks != 1 || stride != 1 || fetch != FETCH_NORMAL || a.act_bf16 != 0 || a.pro_mode != 0 || a.in2 != nullptr || a.stats != nullptr || a.fin_counter != nullptr ||
-      a.bw_parts > 0 || !(a.epi_mode == 0 || a.epi_mode == 2 || a.epi_mode == 4 || a.epi_mode == 5)) return false;
+  if (conv_k1s_switch() == 0 || ks != 1 || stride != 1 || fetch != FETCH_NORMAL || a.act_bf16 != 0 || a.pro_mode != 0 || a.in2 != nullptr || a.stats != nullptr ||
+      !(a.epi_mode == 0 || a.epi_mode == 2 || a.epi_mode == 4 || a.epi_mode == 5)) return false;
   if (a.epi_mode == 2 && (a.cout_real % 16 != 0 || a.Ws % 4 != 0 || a.xf_tab != nullptr)) return false;
   if (a.xf_tab != nullptr && (a.epi_mode == 0 || a.epi_mode == 2)) return false;                     // (a prologue-kind `_xfin`: there is no prologue here)
   const int C = a.Cin;
   // measured (tools/ab_k1.py, profiles/r04_experiments.txt 8, 17, 19): with the 64-byte store mapping the stream also beats the tiled kernel on config 2's 16 / 32-channel
   // top levels (16 -> 16 @16x256x256 tail 39.8 -> 34.7 us = 0.73 of HBM); the half-resolution tails keep the tiled kernel
-  static const int cmin = []() { const char* e = getenv("MS_K1S_CMIN"); return e ? atoi(e) : 16; }();      // (A/B: 64 keeps config 2's 16 / 32-channel layers on the tiled kernel)
+  constexpr int cmin = 16;
   if (C < cmin || C > 128 || (C & (C - 1)) != 0 || a.epi_mode == 5) return false;
   const long HW = (long)a.Hs * a.Ws;
   if (HW % 4 != 0 || (a.epi_mode == 5 && a.Ws % 4 != 0)) return false;

@@ -73,25 +73,17 @@ struct ConvArgs {
   int N, Cin, Hs, Ws, Hin, Win, Cout, Hout, Wout, cin_pad, cout_pad;
   int pro_mode, pro_nstride, pro_cstride; float slope;
   int epi_mode, tiles_x, tiles_y, cout_real, ncb;   // ncb: number of output-channel blocks (of 16*NT)
-  int pf;                       // wide kernel: the MFMA waves touch the lines of the (cold) second tensor two chunks ahead (L2 prefetch), see conv_wide_kernel
-  int stagger;                  // wide kernel: the second workgroup of a CU starts `stagger` x ~1k cycles late (0 = off), see conv_wide_kernel
   int wino_ok;                  // the caller accepts the Winograd form of a 3x3 stride-1 convolution for this call (MS_FETCH_WINOGRAD)
-  int x3_ok;                    // ... the three-way bf16 split form (MS_FETCH_X3)
   int wino_nt1;                 // Winograd form: one channel block per staged tile (MS_FETCH_WINO_NT1)
   int wino_blocks;              // Winograd form: force the block form (MS_FETCH_WINO_BLOCKS)
   const float* wu;              // Winograd appendix of the packed weights (MS_FETCH_WINO_U): transformed weights [cb16][chunk][16][8][16], or null
   int act_bf16;                 // activation tensors (in, in2, out, mk_u) are stored as bf16 (the `_bf16` entry points); statistics / coefficients / weights fp32
   int dbg;                      // timing-only ablation bits (MS_CONV_DBG): 1 skip MFMA loop, 2 skip global loads, 4 skip epilogue stores, 8 skip LDS stores, 16 skip the epilogue
-  int bw_parts; double bw_count; float* bw_out;   // pro_mode 3 (host side): BatchNorm-backward coefficients are derived in-kernel from bw_parts partial sums per channel
   long long* trace;             // MS_CONV_TRACE_BUILD only: cycle stamps of workgroup 0 (tools/trace_conv.py)
   // epi_mode 4 / 5 (ms_conv1x1_bnres): residual-block tail, out = lrelu(sc*mk_u + sh + conv); 5 = the conv ran at half resolution (see the epilogue)
   // epi_mode 3 (ms_conv2d_actbwd): the output is the gradient w.r.t. an activation lrelu(sc*u + sh) that was never materialised; the epilogue
   // applies its derivative and accumulates the BatchNorm-backward sums (sum g, sum g*(u - mean)) of u's layer: what ms_act_bwd_reduce does in its own pass
   const float* mk_u; const float* mk_coef; float mk_slope; float* mk_tab;   // u [N,Cout,Hout,Wout]; coef float4 [Cout] {sc,sh,mean,invstd}; tab float2 [1 + Cout*kStatSlots]
-  // "last workgroup finalises" (ms_conv2d_fin / ms_conv2d_actbwd_fin): fin_counter != NULL -> the workgroup that arrives last reduces the table itself
-  // and writes fin_out: the BatchNorm coefficients {scale, shift, mean, invstd} (statistics epilogue; fin_gamma/fin_beta/fin_eps) or the
-  // BatchNorm-backward coefficients {al, be, de, 0} (mask epilogue; fin_count = N*H*W) - what ms_bn_finalize / ms_bn_bwd_coefs do in their own launch
-  int* fin_counter; float* fin_out; const float* fin_gamma; const float* fin_beta; float fin_eps; double fin_count;
   // "cross-workgroup finalize" (the `_xfin` entry points): this launch CONSUMES BatchNorm coefficients (prologue pro_mode 1, or the residual-tail epilogue
   // epi_mode 4 / 5) that no ms_bn_finalize launch has produced yet.  xf_tab = the statistics table the producing conv wrote (its header carries a launch
   // epoch, bumped by conv_table_tail); one MFMA wave per channel - wave w of workgroup vb takes channel 4*vb + w - runs ms_bn_finalize's arithmetic on it,
@@ -287,7 +279,6 @@ __device__ inline void xfin_fill(const ConvArgs& a, float* cf_lds, int ntab, uns
 
 // End of a conv kernel, MFMA waves only (threads 0..255; the staging waves have returned - s_barrier only waits for surviving waves): the per-lane
 // partials of the epilogue become ONE table slot per workgroup and channel (table[1 + co*kStatSlots + workgroup-within-channel-block], [0] = slots in use),
-// and with a.fin_counter the last workgroup to arrive turns the table into the coefficients the next kernel needs.
 //   STATS:  v0 = count, v1[j] = mean, v2[j] = M2 (per lane)  -> float4 slots {n, mean, M2, 0}
 //   !STATS: v1[j] = sum g, v2[j] = sum g*(u - mean) (per lane) -> float2 slots
 template <int NT, bool STATS>
@@ -298,7 +289,6 @@ __device__ inline void conv_table_tail(const ConvArgs& a, float* smem, int vb, i
   auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   bar();                                               // every MFMA wave is done with the stage buffers: smem is free
   float* red = smem;                                   // [4 waves][COUT_TILE][3]
-  int* flag = reinterpret_cast<int*>(smem + 4 * COUT_TILE * 3);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     float n_ = v0, a_ = v1[j], b_ = v2[j];
@@ -332,10 +322,10 @@ __device__ inline void conv_table_tail(const ConvArgs& a, float* smem, int vb, i
     if (co < a.Cout) {
       if (STATS) {
         float4* slot = reinterpret_cast<float4*>(a.stats) + 1 + (size_t)co * kStatSlots + wg;
-        if (a.fin_counter) slot_store16(slot, make_float4(n_, a_, b_, 0.f)); else *slot = make_float4(n_, a_, b_, 0.f);
+        *slot = make_float4(n_, a_, b_, 0.f);
       } else {
         float2* slot = reinterpret_cast<float2*>(a.mk_tab) + 1 + (size_t)co * kStatSlots + wg;
-        if (a.fin_counter) slot_store8(slot, make_float2(a_, b_)); else *slot = make_float2(a_, b_);
+        *slot = make_float2(a_, b_);
       }
     }
   }
@@ -349,55 +339,6 @@ __device__ inline void conv_table_tail(const ConvArgs& a, float* smem, int vb, i
       reinterpret_cast<float2*>(a.mk_tab)[0] = make_float2((float)S, __uint_as_float(ep == 0u ? 1u : ep));
     }
   }
-  if (a.fin_counter == nullptr) return;
-  if (wave == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's slots are out before it is counted
-    if (lane == 0) {
-      const int prev = __hip_atomic_fetch_add(a.fin_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *flag = (prev == (int)gridDim.x - 1) ? 1 : 0;
-    }
-  }
-  bar();
-  if (*flag == 0) return;
-  // ---- the last workgroup: 32 channels per pass, 8 threads per channel, fp64 (ms_bn_finalize / ms_bn_bwd_coefs restated) ----
-  const int sub = MS_TID & 7, cl = MS_TID >> 3;
-  for (int c0 = 0; c0 < a.Cout; c0 += 32) {
-    const int c = c0 + cl;
-    const bool live = c < a.Cout;
-    if (STATS) {
-      const float4* row = reinterpret_cast<const float4*>(a.stats) + 1 + (size_t)(live ? c : 0) * kStatSlots;
-      double sn = 0.0, sm = 0.0;
-      if (live) for (int i = sub; i < S; i += 8) { const float4 q = slot_load16(row + i); sn += (double)q.x; sm += (double)q.x * (double)q.y; }
-#pragma unroll
-      for (int off = 1; off <= 4; off <<= 1) { sn += shfl_xor_d(sn, off); sm += shfl_xor_d(sm, off); }
-      const double mean = live ? sm / sn : 0.0;
-      double sq = 0.0;
-      if (live) for (int i = sub; i < S; i += 8) { const float4 q = slot_load16(row + i); const double d = (double)q.y - mean; sq += (double)q.z + (double)q.x * d * d; }
-#pragma unroll
-      for (int off = 1; off <= 4; off <<= 1) sq += shfl_xor_d(sq, off);
-      if (live && sub == 0) {
-        const double var = sq / sn;
-        const float invstd = (float)(1.0 / sqrt(var + (double)a.fin_eps));
-        const float sc = a.fin_gamma[c] * invstd;
-        reinterpret_cast<float4*>(a.fin_out)[c] = make_float4(sc, a.fin_beta[c] - (float)mean * sc, (float)mean, invstd);
-      }
-    } else {
-      const float2* row = reinterpret_cast<const float2*>(a.mk_tab) + 1 + (size_t)(live ? c : 0) * kStatSlots;
-      double s1 = 0.0, s2 = 0.0;
-      if (live) for (int i = sub; i < S; i += 8) { const float2 q = slot_load8(row + i); s1 += (double)q.x; s2 += (double)q.y; }
-#pragma unroll
-      for (int off = 1; off <= 4; off <<= 1) { s1 += shfl_xor_d(s1, off); s2 += shfl_xor_d(s2, off); }
-      if (live && sub == 0) {
-        const float4 cf = reinterpret_cast<const float4*>(a.mk_coef)[c];           // {sc, sh, mean, invstd}
-        const double mean = cf.z, invstd = cf.w, sc = cf.x;
-        const double c1 = s1 / a.fin_count;
-        const double c2 = s2 * invstd / a.fin_count;
-        const double be = -sc * c2 * invstd;
-        reinterpret_cast<float4*>(a.fin_out)[c] = make_float4((float)sc, (float)be, (float)(-sc * c1 - be * mean), 0.f);
-      }
-    }
-  }
-  if (MS_TID == 0) __hip_atomic_store(a.fin_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
 }
 
 
@@ -480,8 +421,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
     for (int i = MS_TID; i < 2 * BUF; i += 512) smem[i] = 0.f;     // rows / columns the staging never writes are the inserted zeros
   }
   // per-channel prologue coefficients are constant for the whole launch: stage them once (per-plane mode reads global memory)
-  // (pro_mode 3, bw_parts > 0: the consumer waves derive the coefficients below while the producer waves already fetch the first chunk)
-  if (a.bw_parts == 0 && a.pro_mode != 0 && a.pro_nstride == 0 && a.xf_tab == nullptr) {
+  if (a.pro_mode != 0 && a.pro_nstride == 0 && a.xf_tab == nullptr) {
     for (int c = MS_TID; c < a.cin_pad; c += 512) {
       float ca = 1.f, cb_ = 0.f, cc = 0.f;
       if (c < a.Cin) { ca = a.pro_a[c * a.pro_cstride]; cb_ = a.pro_b[c * a.pro_cstride]; if (a.pro_mode == 2) cc = a.pro_c[c * a.pro_cstride]; }
@@ -770,35 +710,6 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_mfma_kernel(const
   //  fewer than ride_C / 4 workgroups a wave takes more than one channel: ms_conv_ride_capacity is a speed hint, no longer a correctness bound)
   if (a.ride_out != nullptr)
     for (int c = (int)blockIdx.x * 4 + wave; c < a.ride_C; c += 4 * (int)gridDim.x) conv_ride(a, c, lane);
-  if (a.bw_parts > 0) {
-    // pro_mode 3: what ms_bn_bwd_coefs would have computed in its own launch (a ~5 us kernel + launch gap, 29 times per inner step): every
-    // workgroup reduces the (sum g, sum g*u) partials of ms_act_bwd_reduce itself - <= 32 KB of L2-resident reads, 32 lanes per channel,
-    // fp64, fixed order, so all workgroups (and all runs) get the same bits.  pro_a = partials [Cin][bw_parts][2], pro_b = forward
-    // coefficient records {scale, shift, mean, invstd} (stride pro_cstride).
-    const int grp = MS_TID >> 5, l32 = MS_TID & 31;          // consumer threads 0..255: 8 groups of 32 lanes
-    for (int c = grp; c < a.cin_pad; c += 8) {
-      double s1 = 0.0, s2 = 0.0;
-      if (c < a.Cin) {
-        const float2* part = reinterpret_cast<const float2*>(a.pro_a) + (size_t)c * a.bw_parts;
-        for (int i = l32; i < a.bw_parts; i += 32) { const float2 q = part[i]; s1 += (double)q.x; s2 += (double)q.y; }
-      }
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
-      if (l32 == 0) {
-        float al = 1.f, be = 0.f, de = 0.f;
-        if (c < a.Cin) {
-          const float* cf = a.pro_b + (size_t)c * a.pro_cstride;       // {sc, sh, mean, invstd}
-          const double sc = cf[0], mean = cf[2], invstd = cf[3];
-          const double c1 = s1 / a.bw_count;
-          const double c2 = s2 * invstd / a.bw_count;                  // s2 is the centred sum
-          const double b = -sc * c2 * invstd;
-          al = (float)sc; be = (float)b; de = (float)(-sc * c1 - b * mean);
-          if (a.bw_out != nullptr && blockIdx.x == 0) { float* o = a.bw_out + 4 * c; o[0] = al; o[1] = be; o[2] = de; o[3] = 0.f; }
-        }
-        cf_lds[c * 4] = al; cf_lds[c * 4 + 1] = be; cf_lds[c * 4 + 2] = de;
-      }
-    }
-  }
   unsigned xf_tag = 0u;
   conv_u64_t xf_pre[NT][2];                            // the lane's granules, peeked at the start of the last chunk of the first item: landed by the epilogue
   bool xf_pending = false;                             // epi_mode 4 / 5 with xf_tab: (scale, shift) of this lane's channels are polled before the first epilogue

@@ -250,10 +250,10 @@ __global__ __launch_bounds__(512, 4) void conv_s2_kernel(const ConvArgs a) {
   }
 }
 
-int& conv_s2g2_switch();      // ms_conv.hip: 1 (MS_CONV_S2G2=0: 0); ms_conv_s2g2_enable() flips it for A/B runs and the same-bits tests
+int conv_s2g2_switch();      // ms_conv.hip: option "conv.s2g2" (0: off - A/B runs and the same-bits tests)
 inline bool conv_s2g2_eligible(const ConvArgs& a, int ks, int stride, int fetch) {
   if (conv_s2g2_switch() == 0 || ks != 3 || stride != 2 || fetch != FETCH_NORMAL || a.act_bf16 != 0 || a.pro_mode != 0 || a.in2 != nullptr || a.stats != nullptr ||
-      a.fin_counter != nullptr || a.bw_parts > 0 || a.epi_mode != 0 || a.xf_tab != nullptr || a.ride_out != nullptr) return false;
+      a.epi_mode != 0 || a.xf_tab != nullptr || a.ride_out != nullptr) return false;
   if (a.Ws % 8 != 0 || a.Hs % 2 != 0 || a.Cin % 4 != 0 || a.Cin < 16) return false;                    // 16-byte pieces on both sides, whole 4-channel chunks
   if (a.Wout <= 16) return false;            // the 16-pixel level keeps the first generation's 4 x 16 tiles (128 -> 128 @16x32x32 -> 16x16: 30 against 33 us; tools/ab_subpix.py)
   if ((long long)a.N * a.Cin * a.Hs * a.Ws * 4 >= (1LL << 31) || 9LL * a.cin_pad * a.cout_pad * 4 >= (1LL << 31)) return false;
@@ -263,17 +263,13 @@ inline bool conv_s2g2_eligible(const ConvArgs& a, int ks, int stride, int fetch)
 // geometry and channel blocks per patch: blocks where the 8 x 32 tiles are poorly filled and the block list has work for every CU; as many channel blocks as leave
 // >= 1.5 work items per CU (the patch is re-read from L2 once per item)
 inline void conv_s2g2_plan(const ConvArgs& a, int& geo, int& nt) {
-  static const int egeo = []() { const char* e = getenv("MS_S2G2_GEO"); return e ? atoi(e) : -1; }();
-  static const int ent = []() { const char* e = getenv("MS_S2G2_NT"); return e ? atoi(e) : 0; }();
   const double fill_t = (double)a.Hout * a.Wout / ((double)cdiv(a.Hout, 8) * 8 * cdiv(a.Wout, 32) * 32);
   const double fill_b = (double)a.Hout / (cdiv(a.Hout, 4) * 4);
   const long groups_b = cdiv((long)a.N * (a.Wout / 4) * cdiv(a.Hout, 4), 16L), tiles_t = (long)a.N * cdiv(a.Hout, 8) * cdiv(a.Wout, 32);
   geo = (a.Wout % 4 == 0 && fill_b >= 1.3 * fill_t && groups_b * cdiv(a.Cout, 16) >= num_cus()) ? 1 : 0;
-  if (egeo == 0 || (egeo == 1 && a.Wout % 4 == 0)) geo = egeo;
   const long units = geo ? groups_b : tiles_t;
   nt = 1;
   for (int cand : {4, 2}) if (a.Cout >= 16 * cand && 2 * units * cdiv(a.Cout, 16 * cand) >= 3L * num_cus()) { nt = cand; break; }      // (>= 1.5 work items per CU)
-  if (ent == 1 || ent == 2 || ent == 4) nt = ent;
 }
 
 template <int GEO, int NT>

@@ -8,10 +8,10 @@ extern "C" int ms_conv_subpix_eligible(int Hs, int Ws) { return (Hs >= 1 && Ws >
 
 // one thread per (product q, input channel, output channel): the sum of the 3x3 taps that land on the same stored pixel, in the first-generation kernel's order
 // (ky outer, kx inner, the first tap assigned, the others added in fp32): the kernel that copies the sums from here computes the same bits
+#include "ms_pack.h"
 namespace ms {
-__global__ __launch_bounds__(256) void subpix_pack_kernel(const float* __restrict__ wp, float* __restrict__ sums, int cin_pad, int cout_pad) {
+__device__ __forceinline__ void subpix_pack_one(long id, const float* __restrict__ wp, float* __restrict__ sums, int cin_pad, int cout_pad) {
   const long per = (long)cin_pad * cout_pad, total = 16 * per;
-  const long id = (long)blockIdx.x * 256 + threadIdx.x;
   if (id >= total) return;
   const int q = (int)(id / per);
   const long rem = id % per;
@@ -27,7 +27,38 @@ __global__ __launch_bounds__(256) void subpix_pack_kernel(const float* __restric
     }
   sums[id] = acc;
 }
+__global__ __launch_bounds__(256) void subpix_pack_kernel(const float* __restrict__ wp, float* __restrict__ sums, int cin_pad, int cout_pad) {
+  subpix_pack_one((long)blockIdx.x * 256 + threadIdx.x, wp, sums, cin_pad, cout_pad);
+}
+
+// Every appendix of a weight version in ONE launch (PackedNets.repack_from_bank issued 2 ms_wino_pack + 1 ms_subpix_pack launches per 3x3 ConvW - 100+ tiny eager
+// launches per trainer iteration): a descriptor per job, threads numbered across jobs, binary search for the job as ms_repack_weights does.  Same device functions as the
+// single-job entry points: same bits.
+struct AppxDesc { long long begin; float* wp; float* sums; int kind; int Cin; int Cout; int cin_pad; int cout_pad; int pad_; };
+__global__ __launch_bounds__(256) void appendix_batch_kernel(const AppxDesc* __restrict__ desc, int ndesc, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].begin <= i) lo = mid; else hi = mid - 1; }
+  const AppxDesc d = desc[lo];
+  const long id = (long)(i - d.begin);
+  if (d.kind == 0) wino_pack_one(id, d.wp, d.Cin, d.Cout, d.cin_pad, d.cout_pad);
+  else subpix_pack_one(id, d.wp, d.sums, d.cin_pad, d.cout_pad);
+}
 }  // namespace ms
+extern "C" size_t ms_appendix_desc_bytes(void) { return sizeof(AppxDesc); }
+// threads a job of this kind needs (the `begin` spacing of the descriptor table): kind 0 = ms_wino_pack, kind 1 = ms_subpix_pack
+extern "C" long long ms_appendix_job_threads(int kind, int Cin, int Cout) {
+  if (Cin < 1 || Cout < 1) return 0;
+  if (kind == 0) return (Cin % 8 != 0) ? 0 : (long long)((Cout + 15) / 16) * (Cin / 8) * 128;
+  if (kind == 1) return 16LL * ((Cin + 3) / 4 * 4) * ((Cout + 63) / 64 * 64);
+  return 0;
+}
+extern "C" int ms_appendix_batch(const void* desc_dev, int ndesc, long long total, void* stream) {
+  if (ndesc < 1 || total < 1 || desc_dev == nullptr) { set_error("ms_appendix_batch: nothing to do"); return MS_ERR_INVALID; }
+  MS_LAUNCH(appendix_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const AppxDesc*)desc_dev, ndesc, total);
+  return check_launch("appendix_batch");
+}
 extern "C" size_t ms_subpix_pack_floats(int Cin, int Cout) {
   if (Cin < 1 || Cout < 1) return 0;
   return (size_t)16 * (size_t)((Cin + 3) / 4 * 4) * (size_t)((Cout + 63) / 64 * 64);
@@ -62,8 +93,7 @@ static int conv_subpix_impl(const float* in, float* out, const float* w_packed, 
   a.wu = w_sums;
   hipStream_t st = (hipStream_t)stream;
   // second generation (ms_conv_subpix2.h): fp32 storage, every byte offset of the DMA within 31 bits, and - mode 0 - the sums appendix
-  static const int gen_env = []() { const char* e = getenv("MS_SUBPIX_GEN"); return e ? atoi(e) : 2; }();
-  const bool gen2 = !(flags & MS_SUBPIX_FIRST_GEN) && gen_env != 1 && !act_bf16 && (mode == 1 || w_sums != nullptr) &&
+  const bool gen2 = !(flags & MS_SUBPIX_FIRST_GEN) && !act_bf16 && (mode == 1 || w_sums != nullptr) &&
                     (long long)N * Cin * Hs * Ws * 4 < (1LL << 31) && 16LL * a.cin_pad * a.cout_pad * 4 < (1LL << 31);
   if (gen2) {
     const int geo = (flags & MS_SUBPIX_TILES) ? 0 : (flags & MS_SUBPIX_BLOCKS) ? 1 : -1;

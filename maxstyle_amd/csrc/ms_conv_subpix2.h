@@ -339,8 +339,6 @@ __global__ __launch_bounds__(512, 4) void conv_subpix2_kernel(const ConvArgs a, 
 // geo: 0 tiles, 1 blocks, -1 choose (blocks when they fill at least 1.25x better than the tiles)
 inline int subpix2_geo(const ConvArgs& a, int geo, bool mode1) {
   if (geo == 0 || geo == 1) return geo;
-  static const int env = []() { const char* e = getenv("MS_SUBPIX_GEO"); return e ? atoi(e) : -1; }();
-  if (env == 0 || env == 1) return env;
   const double fill_t = (double)a.Hs * a.Ws / ((double)cdiv(a.Hs, 8) * 8 * cdiv(a.Ws, 32) * 32);
   const double fill_b = (double)a.Hs / (cdiv(a.Hs, 4) * 4);
   const long items_b = cdiv((long)a.N * (a.Ws / 4) * cdiv(a.Hs, 4), 16L) * cdiv(a.Cout, 16);
@@ -367,8 +365,6 @@ int launch_conv_subpix2_t(ConvArgs a, const float* mk_ref, hipStream_t st) {
 }
 template <int MODE>
 int launch_conv_subpix2(const ConvArgs& a, const float* mk_ref, int geo, hipStream_t st) {
-  static const int nbuf = []() { const char* e = getenv("MS_SUBPIX_NBUF"); return e ? atoi(e) : 3; }();
-  if (nbuf == 2) return subpix2_geo(a, geo, MODE == 1) == 1 ? launch_conv_subpix2_t<MODE, 1, 2>(a, mk_ref, st) : launch_conv_subpix2_t<MODE, 0, 2>(a, mk_ref, st);
   return subpix2_geo(a, geo, MODE == 1) == 1 ? launch_conv_subpix2_t<MODE, 1, 3>(a, mk_ref, st) : launch_conv_subpix2_t<MODE, 0, 3>(a, mk_ref, st);
 }
 

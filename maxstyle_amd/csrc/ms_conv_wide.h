@@ -62,30 +62,6 @@ struct WideGeoBF {
   static constexpr int W_ITEMS = 9 * CK * (16 * NT / 4), NWI = (W_ITEMS + 255) / 256;
 };
 
-// Geometry of the three-way bf16 split mode (AT = ms_f32x3): the LDS layout of the bf16-MFMA mode (channel-quad interleaved 8-byte entries), SIX activation planes
-// per 8-channel chunk - plane p = 2*split + quad: hi(q0), hi(q1), mid(q0), mid(q1), lo(q0), lo(q1) - and THREE weight sets of 4 K-groups each, arranged so
-// that one instruction multiplies two splits at once (K group g of the instruction, A fragment x B fragment):
-//   MFMA 1: A1 = [hi0, hi1, mid0, mid1] x B1 = [hi0, hi1, hi0, hi1]    = hi*hi + mid*hi
-//   MFMA 2: A2 = [hi0, hi1, lo0,  lo1 ] x B2 = [mid0, mid1, hi0, hi1]  = hi*mid + lo*hi
-//   MFMA 3: A1                          x B3 = [lo0, lo1, mid0, mid1]  = hi*lo + mid*mid
-// A lane of K group k reads plane k for A1 and plane (k < 2 ? k : k + 2) for A2.  6 planes x 3264 B + 3 x 4608 B of weights = 33.4 KB per stage: two
-// workgroups per CU.  3 instructions of 8 cycles per (tap, 16 pixels, 8 channels, 16 output channels) against 2 x 32 cycles of v_mfma_f32_16x16x4_f32.
-template <int NT, int PRO>
-struct WideGeoX3 {
-  static_assert(NT == 1, "three-way split mode: one channel block per lane");
-  static constexpr int TH = 4, TW = 64, CK = 8, IH = TH + 2;
-  static constexpr int RSB = TW + 4;
-  static constexpr int GP = IH * RSB * 8;                          // bytes of one plane (3264)
-  static constexpr int A_BYTES = 6 * GP;
-  static constexpr int B_SET = 9 * 4 * 16 * NT * 8;                // one weight set: (tap, K group, output channel) entries of 8 bytes
-  static constexpr int B_BYTES = 3 * B_SET;
-  static constexpr int BUF = (A_BYTES + B_BYTES) / 4;
-  static constexpr int RS = RSB, PS = GP / 4, WS = 16;
-  static constexpr int Q_ITEMS = CK * IH * (TW / 4), H_ITEMS = CK * IH * 2;
-  static constexpr int NQI = (Q_ITEMS + 255) / 256, NHI = (H_ITEMS + 255) / 256;
-  static constexpr int W_ITEMS = 9 * CK * (16 * NT / 4), NWI = (W_ITEMS + 255) / 256;
-};
-
 // Geometry of the Winograd mode (AT = ms_f32w): F(2x2, 3x3), one channel block per lane.  The staged input tile is the fp32 one (same rows / columns / halo);
 // its plane stride is == 32 (mod 64 dwords) so that the 8-byte patch reads of the four K lanes groups of a wave fall on disjoint banks.  The weight region of a
 // stage holds the chunk's TRANSFORMED weights U = G g G^T as [16 positions][CK channels][16 output channels]: a lane's B fragment of position p and channel
@@ -125,8 +101,6 @@ struct WideGeoWB {
   static constexpr int W_ITEMS = CK * 16 * NT_, NWI = 1;
 };
 
-// census of workgroup arrivals per CU (stagger experiment): which of the two co-resident workgroups am I?  Timing only - never read for results.
-static __device__ int g_cu_census[1024];
 
 // PRO: 0 none, 1 BatchNorm apply + LeakyReLU, 2 BatchNorm backward (two tensors)
 // AF ("all full"): cin_pad is a multiple of the K-chunk - no ragged channel group anywhere in the layer, the guarded MFMA loop is not instantiated
@@ -134,16 +108,14 @@ static __device__ int g_cu_census[1024];
 template <int NT, int PRO, int R, bool AF, typename AT = float>
 __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const ConvArgs a) {
   constexpr bool BFM = std::is_same<AT, ms_bf16m>::value;         // bf16 matrix arithmetic (needs R == 1)
-  constexpr bool X3 = std::is_same<AT, ms_f32x3>::value;          // fp32 storage, three-way bf16 split on the bf16 matrix cores (needs R == 1, NT == 1, every chunk full)
-  constexpr bool BFL = BFM || X3;                                 // the bf16 LDS layout (8-byte channel-quad entries)
-  static_assert(!X3 || (R == 1 && NT == 1 && AF), "three-way split mode: 4-row tiles, one channel block per lane, channel count a multiple of the chunk");
+  constexpr bool BFL = BFM;                                       // the bf16 LDS layout (8-byte channel-quad entries)
   constexpr bool WB = std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value;        // Winograd form on independent 8x8-pixel blocks (WideGeoWB)
   constexpr bool WIN = std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value || WB ||       // Winograd F(2x2, 3x3) (needs R == 1, NT <= 2, every chunk full)
                        std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value;      // ... on bf16 storage
   constexpr int WTW = (std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w32>::value) ? 32 : 64;
   constexpr int WHALVES = WTW / 32;                               // 32-pixel halves of a tile row = waves per tile row
   static_assert(!WIN || (R == 1 && NT <= 2 && AF), "Winograd mode: 4-row tiles, one or two channel blocks per lane, channel count a multiple of the chunk");
-  using G = typename std::conditional<X3, WideGeoX3<(X3 ? NT : 1), PRO>, typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WB, WideGeoWB<(WB ? NT : 1), PRO>, typename std::conditional<WIN, WideGeoW<(WIN ? NT : 1), PRO, WTW>, WideGeo<NT, PRO, R>>::type>::type>::type>::type;
+  using G = typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WB, WideGeoWB<(WB ? NT : 1), PRO>, typename std::conditional<WIN, WideGeoW<(WIN ? NT : 1), PRO, WTW>, WideGeo<NT, PRO, R>>::type>::type>::type;
   using IO = ActIO<AT>;
   constexpr int AB = IO::kBytes;
   static_assert(!BFM || R == 1, "bf16 MFMA mode: 4-row tiles");
@@ -192,21 +164,6 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     }
   }
 
-  if (a.stagger > 0) {
-    // Two workgroups share a CU and run the same program: left alone they stay in lockstep - both in their MFMA phase (matrix pipe contended),
-    // then both in their epilogue (matrix pipe idle).  The workgroup that arrives second on its CU starts late by a fraction of an item so that one's
-    // epilogue / staging overlaps the other's MFMA phase (MI355X_MICROARCH.md "Two waves per SIMD", item 9: stagger).
-    __shared__ int s_slot;
-    if (MS_TID == 0) {
-      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
-      const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
-      const unsigned key = ((xcc & 7u) << 7) | ((hw >> 8) & 0x7Fu);
-      s_slot = atomicAdd(&g_cu_census[key], 1) & 1;
-    }
-    __syncthreads();
-    if (s_slot) for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
-  }
-
   if (producer) {
     // =========================================== PRODUCER waves ===========================================
 #ifndef MS_WIDE_STAGE_PRIO
@@ -237,7 +194,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       if (it < G::Q_ITEMS) {
         const int f = it % (TW / 4), row = it / (TW / 4);
         const int r = row % IH, c = row / IH;
-        if constexpr (BFL) q_lds[j] = (c << 20) | ((((c >> 2) * IH + r) * G::RSB + 4 * f + 1) * 8 + (c & 3) * 2);      // BYTE address of the entry's channel slot (X3: in the `hi` planes)
+        if constexpr (BFL) q_lds[j] = (c << 20) | ((((c >> 2) * IH + r) * G::RSB + 4 * f + 1) * 8 + (c & 3) * 2);      // BYTE address of the entry's channel slot 
         else q_lds[j] = (c << 20) | (c * PS + patch_off + r * RS + 4 * f + 1);
         q_rc[j] = (r << 16) | (4 * f + 16);
         q_off[j] = (unsigned)AB * (unsigned)(c * plane + (r - 1) * a.Ws + 4 * f + bias);
@@ -430,20 +387,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           if constexpr (PRO == 2) v[e] = ca[j] * v[e] + (cb_[j] * v2 + cc[j]);
           if constexpr (EDGE) v[e] = ((l_q_ok >> j) & 1u) ? v[e] : 0.f;          // zero padding pads the tensor AFTER the prologue
         }
-        if constexpr (X3) {
-          // three bf16 splits of every value (hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid)) into the hi / mid / lo planes of its channel quad
-          char* dst = reinterpret_cast<char*>(buf) + (q_lds[j] & 0xFFFFF);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint16_t hi = ms_to_bf16(v[e]);
-            const float r1 = v[e] - __uint_as_float((unsigned)hi << 16);
-            const uint16_t mid = ms_to_bf16(r1);
-            const uint16_t lo = ms_to_bf16(r1 - __uint_as_float((unsigned)mid << 16));
-            *reinterpret_cast<uint16_t*>(dst + 8 * e) = hi;
-            *reinterpret_cast<uint16_t*>(dst + 2 * G::GP + 8 * e) = mid;
-            *reinterpret_cast<uint16_t*>(dst + 4 * G::GP + 8 * e) = lo;
-          }
-        } else if constexpr (BFM) {
+        if constexpr (BFM) {
           // round to bf16 and scatter into the channel slot of the four pixels' entries (8 bytes apart)
           char* dst = reinterpret_cast<char*>(buf) + (q_lds[j] & 0xFFFFF);
 #pragma unroll
@@ -459,16 +403,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         float v = rh[j];
         if constexpr (PRO == 1) v = leaky(hca[j] * v + hcb[j], a.slope);
         if constexpr (PRO == 2) v = hca[j] * v + (hcb[j] * rh2[j] + hcc[j]);
-        if constexpr (X3) {
-          const float vv = ((l_h_ok >> j) & 1u) ? v : 0.f;
-          char* dst = reinterpret_cast<char*>(buf) + (h_lds[j] & 0xFFFFF);
-          const uint16_t hi = ms_to_bf16(vv);
-          const float r1 = vv - __uint_as_float((unsigned)hi << 16);
-          const uint16_t mid = ms_to_bf16(r1);
-          *reinterpret_cast<uint16_t*>(dst) = hi;
-          *reinterpret_cast<uint16_t*>(dst + 2 * G::GP) = mid;
-          *reinterpret_cast<uint16_t*>(dst + 4 * G::GP) = ms_to_bf16(r1 - __uint_as_float((unsigned)mid << 16));
-        } else if constexpr (BFM) *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(buf) + (h_lds[j] & 0xFFFFF)) = ms_to_bf16(((l_h_ok >> j) & 1u) ? v : 0.f);
+        if constexpr (BFM) *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(buf) + (h_lds[j] & 0xFFFFF)) = ms_to_bf16(((l_h_ok >> j) & 1u) ? v : 0.f);
         else buf[h_lds[j] & 0xFFFFF] = ((l_h_ok >> j) & 1u) ? v : 0.f;
       }
       if constexpr (WIN) {
@@ -496,24 +431,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           if (idx < G::W_ITEMS) {
             const int j4 = idx % (COUT_TILE / 4);
             const int row = idx / (COUT_TILE / 4);
-            if constexpr (X3) {
-              // the three weight sets (WideGeoX3): channel c = quad q, slot c & 3; hi -> B1 groups q and q+2, B2 group q+2; mid -> B2 group q, B3 group q+2; lo -> B3 group q
-              const int c = row % CK, tap = row / CK, q = c >> 2;
-              char* w0 = reinterpret_cast<char*>(buf) + G::A_BYTES + (c & 3) * 2;
-              auto ent = [&](int set, int g, int co) { return w0 + set * G::B_SET + ((tap * 4 + g) * COUT_TILE + co) * 8; };
-              const float wv[4] = {rw[j].x, rw[j].y, rw[j].z, rw[j].w};
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int co = j4 * 4 + e;
-                const uint16_t hi = ms_to_bf16(wv[e]);
-                const float r1 = wv[e] - __uint_as_float((unsigned)hi << 16);
-                const uint16_t mid = ms_to_bf16(r1);
-                const uint16_t lo = ms_to_bf16(r1 - __uint_as_float((unsigned)mid << 16));
-                *reinterpret_cast<uint16_t*>(ent(0, q, co)) = hi; *reinterpret_cast<uint16_t*>(ent(0, q + 2, co)) = hi; *reinterpret_cast<uint16_t*>(ent(1, q + 2, co)) = hi;
-                *reinterpret_cast<uint16_t*>(ent(1, q, co)) = mid; *reinterpret_cast<uint16_t*>(ent(2, q + 2, co)) = mid;
-                *reinterpret_cast<uint16_t*>(ent(2, q, co)) = lo;
-              }
-            } else if constexpr (BFM) {
+            if constexpr (BFM) {
               // entry (tap, g, cout) = channels 4g..4g+3 of one output channel: this item holds 4 output channels of ONE input channel
               const int c = row % CK, tap = row / CK;
               char* wb = reinterpret_cast<char*>(buf) + G::A_BYTES + ((tap * 4 + (c >> 2)) * COUT_TILE + j4 * 4) * 8 + (c & 3) * 2;
@@ -665,44 +583,6 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
                                                                         (FIRST && st == 0 && kx == 0) ? zero4 : acc[0][i][j], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  };
-  // three-way split mode (WideGeoX3): per staged row st and kernel column kx, three instructions per pixel-in-quad i: A1 x B1, A2 x B2, A1 x B3
-  auto compute_x3 = [&](const float* buf, auto first_tag) __attribute__((always_inline)) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (X3) {
-      const int p1 = k, p2 = (k < 2) ? k : k + 2;                 // planes of this lane's K group: A1 = [hi0, hi1, mid0, mid1], A2 = [hi0, hi1, lo0, lo1]
-      const char* a1 = reinterpret_cast<const char*>(buf) + ((p1 * IH + wave) * G::RSB + 4 * m) * 8;
-      const char* a2 = reinterpret_cast<const char*>(buf) + ((p2 * IH + wave) * G::RSB + 4 * m) * 8;
-      const char* bb = reinterpret_cast<const char*>(buf) + G::A_BYTES + (k * COUT_TILE + m) * 8;
-#pragma unroll
-      for (int st = 0; st < 3; ++st) {
-        cu32x4_t w1[3], w2[3];
-        cu32x2_t b[3][3];                                         // [set][kx]
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          w1[q] = *reinterpret_cast<const cu32x4_t*>(a1 + st * G::RSB * 8 + 16 * q);
-          w2[q] = *reinterpret_cast<const cu32x4_t*>(a2 + st * G::RSB * 8 + 16 * q);
-        }
-#pragma unroll
-        for (int set = 0; set < 3; ++set)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) b[set][kx] = *reinterpret_cast<const cu32x2_t*>(bb + set * G::B_SET + ((st * 3 + kx) * 4 * COUT_TILE) * 8);
-        const unsigned* v1 = reinterpret_cast<const unsigned*>(&w1[0]);
-        const unsigned* v2 = reinterpret_cast<const unsigned*>(&w2[0]);
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const cu32x2_t x1 = {v1[2 * (i + kx)], v1[2 * (i + kx) + 1]};
-            const cu32x2_t x2 = {v2[2 * (i + kx)], v2[2 * (i + kx) + 1]};
-            f32x4 c = (FIRST && st == 0 && kx == 0) ? zero4 : acc[0][i][0];
-            c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf4_t, x1), __builtin_bit_cast(bf4_t, b[2][kx]), c, 0, 0, 0);      // hi*lo + mid*mid (smallest first)
-            c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf4_t, x2), __builtin_bit_cast(bf4_t, b[1][kx]), c, 0, 0, 0);      // hi*mid + lo*hi
-            acc[0][i][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf4_t, x1), __builtin_bit_cast(bf4_t, b[0][kx]), c, 0, 0, 0);   // hi*hi + mid*hi
-          }
       }
     }
   };
@@ -872,7 +752,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     constexpr bool FIRST = decltype(first_tag)::value;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (BFM) { compute_bf(buf, first_tag); return; }
-    if constexpr (X3) { compute_x3(buf, first_tag); return; }
+    
     if constexpr (WIN) { compute_w(buf, first_tag); return; }
     float win[2][6], bfr[3][3][NT];
     load_win(buf, 0, 0, win[0]);
@@ -1550,11 +1430,11 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 
 template <int NT, int PRO, int R, bool AF, typename AT>
 int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
-  using G = typename std::conditional<std::is_same<AT, ms_f32x3>::value, WideGeoX3<(std::is_same<AT, ms_f32x3>::value ? NT : 1), PRO>, typename std::conditional<std::is_same<AT, ms_bf16m>::value, WideGeoBF<NT, PRO>,
+  using G = typename std::conditional<std::is_same<AT, ms_bf16m>::value, WideGeoBF<NT, PRO>,
                                       typename std::conditional<std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_bf16w>::value, WideGeoW<(NT <= 2 ? NT : 1), PRO, 64>,
                                       typename std::conditional<std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w32>::value, WideGeoW<(NT <= 2 ? NT : 1), PRO, 32>,
                                       typename std::conditional<std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value, WideGeoWB<(NT <= 2 ? NT : 1), PRO>,
-                                                                WideGeo<NT, PRO, R>>::type>::type>::type>::type>::type;
+                                                                WideGeo<NT, PRO, R>>::type>::type>::type>::type;
   const size_t cin_tab = (PRO != 0) ? (size_t)cdiv(a.cin_pad, G::CK) * G::CK : 0;              // coefficient table: one float4 per input channel of the padded chunks
   const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab) + ((std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value ||
                                                                                       std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value) ? NT * 16 * 1024 : 0);      // Winograd mode: + the mask tensor's landing zone (4 KB per MFMA wave and channel block)
@@ -1566,8 +1446,7 @@ int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
   if (kWB) { a.tiles_x = cdiv(a.N * a.tiles_x * a.tiles_y, 4); a.tiles_y = 1; }      // block form: groups of four blocks of the flattened (image, block row, block column) list
   a.ncb = cdiv(a.Cout, 16 * NT);
   const long nitems = (long)(kWB ? 1 : a.N) * a.tiles_x * a.tiles_y * a.ncb;
-  static const int cu_cap = getenv("MS_WIDE_PER_CU") ? atoi(getenv("MS_WIDE_PER_CU")) : 2;      // A/B switch: workgroups per CU of the persistent grid
-  int per_cu = std::max(1, std::min(NT == 1 ? cu_cap : 2, (int)((160 * 1024) / (lds_bytes + 256))));
+  int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));      // workgroups per CU of the persistent grid
   per_cu = std::max(1, std::min(per_cu, conv_resident_per_cu((const void*)conv_wide_kernel<NT, PRO, R, AF, AT>, lds_bytes)));      // (co-residency of the whole grid: ms_conv_kernel.h)
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;
@@ -1592,10 +1471,10 @@ int launch_conv_wide_r(const ConvArgs& a, hipStream_t st) {
   return (a.cin_pad % WideGeo<NT, PRO, R>::CK == 0) ? launch_conv_wide_af<NT, PRO, R, true>(a, st) : launch_conv_wide_af<NT, PRO, R, false>(a, st);
 }
 
-// tile height: 4 rows.  The 8-row variant (R = 2: two output rows per MFMA wave, bit-identical results) is kept behind MS_CONV_WIDE_ROWS=8: in isolation it is
+// tile height: 4 rows.  The 8-row variant (R = 2: two output rows per MFMA wave, bit-identical results) is kept behind the option "conv.wide_rows" = 8: in isolation it is
 // 2-3 % faster on the activation-backward data-gradient at 16->16 @16x256x256 (72.8 vs 74.7 us), in the step it is slower (333.5 vs 336.3 steps/s, twice each).
 inline int conv_wide_rows(const ConvArgs& a, int nt) {
-  static const int force = getenv("MS_CONV_WIDE_ROWS") ? atoi(getenv("MS_CONV_WIDE_ROWS")) : 0;
+  const int force = opt(OPT_CONV_WIDE_ROWS);
   if (force != 8 || nt != 1) return 4;     // (two channel blocks per lane x two rows per wave need 188 registers: one workgroup per CU - not built for it)
   const long items8 = (long)a.N * cdiv(a.Wout, 64) * cdiv(a.Hout, 8) * cdiv(a.Cout, 16 * nt);
   return (items8 >= 4L * num_cus()) ? 8 : 4;

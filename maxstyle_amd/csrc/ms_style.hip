@@ -593,11 +593,11 @@ extern "C" int ms_style_apply(const float* x, float* y, const float* mu, const f
 extern "C" int ms_style_fwd(const float* x, float* y, float* mu, float* sig, float* gamma_std, float* beta_std, int compute_std,
                             const float* lmda, const float* gamma_noise, const float* beta_noise, const int64_t* perm,
                             float* coefA, float* coefS, int B, int C, int HW, float eps, void* ws, size_t ws_bytes, void* stream) {
-  // single-read kernel when the shape is eligible (MS_STYLE_FUSED=0 forces the three-kernel path, for A/B timing).  compute_std bit 2
+  // single-read kernel when the shape is eligible (option "style.fused" = 0 forces the three-kernel path, for A/B timing).  compute_std bit 2
   // (MS_STYLE_SHARED_DEVICE): the caller runs other kernels beside this one (side streams, another process) - the single-read kernel's
   // co-residency argument does not hold then, so the three-launch path is taken.
-  static const bool fused_on = !(getenv("MS_STYLE_FUSED") != nullptr && atoi(getenv("MS_STYLE_FUSED")) == 0);
-  static const size_t min_kb = getenv("MS_STYLE_FUSED_MIN_KB") ? (size_t)atoi(getenv("MS_STYLE_FUSED_MIN_KB")) : 1024;      // A/B switch for timing
+  const bool fused_on = opt(OPT_STYLE_FUSED) != 0;
+  constexpr size_t min_kb = 1024;
   const bool big = (size_t)B * C * HW * sizeof(float) >= (min_kb << 10);
   const bool shared = (compute_std & 4) != 0;
   compute_std &= 3;

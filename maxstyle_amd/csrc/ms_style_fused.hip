@@ -243,11 +243,6 @@ __global__ __launch_bounds__(THREADS, 4) void style_fused_kernel(const FusedArgs
 
 struct FusedPlan { bool ok; int threads, nv, chunk, S, grid; size_t part_off, bytes; };
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 // State block: ints [0] epoch, [1] error word, [2] finished-workgroup counter; granules (8 B each) from byte 16.
 // Geometry: a unit is a balanced chunk of one plane held in registers by one workgroup (<= 64 floats per thread).  Prefer the fattest
 // workgroup that still gives every CU work; all units of one channel (G = B*S) must be resident together.
@@ -256,8 +251,7 @@ static FusedPlan fused_plan(int B, int C, int HW, int epl = 4) {
   pl.ok = false;
   if (HW % epl != 0 || B < 2 || B > 256) return pl;
   const int cus = num_cus();
-  static const int force_threads = env_int("MS_STYLE_FUSED_THREADS", 0);        // A/B switches for tools/bench_kernels.py
-  static const int force_split = env_int("MS_STYLE_FUSED_SPLIT", 0);
+  constexpr int force_threads = 0, force_split = 0;      // (were A/B environment switches until round 5; the measured choice is the rule below)
   // candidates in order of preference.  Measured on MI355X at 16x16x256x256 (kernel-trace medians): 512-thread workgroups, two per CU, 25.8 us
   // (one's stores overlap the other's loads) against 27.0 us for one 1024-thread workgroup per CU and 30 us for four of 256; so: 512 threads
   // when the planes already give every slot a unit, else 1024 threads (fewer, fatter units), else split planes into chunks.
@@ -336,9 +330,8 @@ static int style_fwd_fused_impl(const void* x, void* y, float* mu, float* sig, f
   a.compute_std = compute_std; a.B = B; a.C = C; a.HW = HW; a.S = pl.S; a.chunk = pl.chunk; a.nv = pl.nv; a.eps = eps;
   // cache policy (fp32): bit 0 nt loads of x, bit 1 nt stores of y.  A tensor that does not fit the 256 MB Infinity Cache cannot be found there by the next kernel
   // anyway: streaming it past the caches measured 184.8 -> 170.3 us at 16x64x320x320 (4.5 -> 4.9 TB/s, profiles/r02_experiments.txt section 4), while for the
-  // cache-sized tensors of config 2 the default policy wins in the step (the next kernel reads y from the cache).  MS_STYLE_FUSED_NT overrides (A/B timing).
-  static const int policy_env = env_int("MS_STYLE_FUSED_NT", -1);
-  const int policy = policy_env >= 0 ? policy_env : (((size_t)B * C * HW * sizeof(float) > ((size_t)256 << 20)) ? 3 : 0);
+  // cache-sized tensors of config 2 the default policy wins in the step (the next kernel reads y from the cache).
+  const int policy = ((size_t)B * C * HW * sizeof(float) > ((size_t)256 << 20)) ? 3 : 0;
   dim3 grid(pl.grid), block(pl.threads);
 #define MS_FUSED(TT, AL, AS) MS_LAUNCH((style_fused_kernel<TT, AL, AS, T>), grid, block, 0, st, a)
 #define MS_FUSED_T(TT) if (std::is_same<T, float>::value) { switch (policy & 3) { case 1: MS_FUSED(TT, 2, 0); break; case 2: MS_FUSED(TT, 0, 2); break; \

@@ -202,8 +202,8 @@ static int wgrad_partials(const float* p, const float* p2, const float* q, int N
   a.N = N; a.M = M; a.Nq = Nq; a.Hp = Hp; a.Wp = Wp; a.Hq = Hq; a.Wq = Wq;
   if (q_mode == 1 && !(slope >= 0.f && slope <= 1.f)) { set_error("ms_wgrad: activation slope outside [0, 1]"); return MS_ERR_INVALID; }
   a.p_mode = p_mode; a.q_mode = q_mode; a.coef_stride = coef_stride < 1 ? 1 : coef_stride; a.slope = slope;
-  { static const int dbg = getenv("MS_WGRAD_DBG") ? atoi(getenv("MS_WGRAD_DBG")) : 0; a.dbg = dbg; }
-  { static const char* tr = getenv("MS_WGRAD_TRACE"); a.trace = tr ? (long long*)strtoull(tr, nullptr, 0) : nullptr; }    // debug: device address of a >= 1 KiB buffer
+  a.dbg = opt(OPT_DIAG_CONV_DBG);
+  a.trace = wgrad_trace_buffer();      // cycle-stamp builds only (ms_diag_set_trace)
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (ks == 3 && stride == 1) {

@@ -17,7 +17,6 @@ Host code is orchestration only; it raises if the HIP extension is missing (impo
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -25,12 +24,13 @@ import torch
 
 from . import ops
 from ._lib import lib, check
+from .options import EngineOptions, engine_options
 
 EPI_POOL2 = 6          # include/maxstyle_hip.h MS_EPI_POOL2
 LEAKY = 0.2
 BN_EPS = 1e-5
 F32 = torch.float32
-WINO_APPENDIX = os.environ.get("MS_WINO_APPENDIX", "1") != "0"      # A/B switch: pack the Winograd-transformed weights behind the taps of every 3x3 conv
+WINO_APPENDIX = engine_options().wino_appendix      # A/B switch (EngineOptions.wino_appendix / MS_OPTIONS engine.wino_appendix=0): pack the Winograd-transformed weights behind the taps of every 3x3 conv
 
 
 @dataclass
@@ -189,12 +189,44 @@ class PackedNets:
         """After the flat optimiser moved the weights: one launch (graphs stay valid - same buffers)."""
         check(lib.ms_repack_weights(self._bank.flat_p.data_ptr(), self._desc.data_ptr(), self._desc_n, self._desc_total, torch.cuda.current_stream().cuda_stream),
               "ms_repack_weights")
-        for table in (self.enc, self.seg, self.dec):
-            if table is not None:
-                for obj in table.values():
-                    if isinstance(obj, ConvW):
-                        obj.refresh_appendix()
+        self.refresh_appendices()
         self.eval_dirty = True
+
+    _appx = None
+
+    def refresh_appendices(self):
+        """Every Winograd appendix (forward and data-gradient taps) and every sub-pixel sum table of the three tables follows the taps in ONE launch
+        (ms_appendix_batch; ADVICE r4: ConvW.refresh_appendix per conv was 2-3 tiny eager launches for each of ~50 3x3 convs per trainer iteration).  The descriptor
+        table is rebuilt when a conv gains a sum table (ConvW.subpix_sums packs on first use)."""
+        import numpy as np
+        jobs = []
+        for table in (self.enc, self.seg, self.dec):
+            if table is None:
+                continue
+            for obj in table.values():
+                if not isinstance(obj, ConvW):
+                    continue
+                if obj.wu:
+                    jobs.append((0, obj.wp.data_ptr(), 0, obj.cin, obj.cout))
+                if obj.dwu:
+                    jobs.append((0, obj.dwp.data_ptr(), 0, obj.cout, obj.cin))
+                if obj.ws is not None:
+                    jobs.append((1, obj.wp.data_ptr(), obj.ws.data_ptr(), obj.cin, obj.cout))
+        if not jobs:
+            return
+        key = tuple(jobs)
+        if self._appx is None or self._appx[0] != key:
+            assert lib.ms_appendix_desc_bytes() == 48
+            dt = np.dtype([("begin", "<i8"), ("wp", "<u8"), ("sums", "<u8"), ("kind", "<i4"), ("Cin", "<i4"), ("Cout", "<i4"), ("cin_pad", "<i4"), ("cout_pad", "<i4"), ("pad", "<i4")])
+            rows, total = [], 0
+            for kind, wp, ws, cin, cout in jobs:
+                rows.append((total, wp, ws, kind, cin, cout, (cin + 3) // 4 * 4, (cout + 63) // 64 * 64, 0))
+                total += int(lib.ms_appendix_job_threads(kind, cin, cout))
+            arr = np.array(rows, dtype=dt)
+            dev = self._bank.flat_p.device if getattr(self, "_bank", None) is not None else next(o for t in (self.enc, self.seg, self.dec) if t for o in t.values() if isinstance(o, ConvW)).wp.device
+            self._appx = (key, torch.from_numpy(arr.view(np.uint8).copy()).to(dev), len(rows), total)
+        _, desc, n, total = self._appx
+        check(lib.ms_appendix_batch(desc.data_ptr(), n, total, torch.cuda.current_stream().cuda_stream), "ms_appendix_batch")
 
     def refresh_eval(self):
         for table in (self.enc, self.seg, self.dec):
@@ -317,24 +349,23 @@ class StyleSlot:
 
 
 class InnerLoopEngine:
-    def __init__(self, spec: NetSpec, B: int, H: int, W: int, device, lr=0.1, act_dtype=None, mfma_bf16=None):
-        """act_dtype: storage type of the activation tensors - torch.float32 (default; MS_ACT_DTYPE=bf16 in the environment selects bf16) or torch.bfloat16
-        (BASELINE config 5 "bf16 activations": every conv input / output, gradient and image is stored as bf16, statistics / coefficients / parameters / the
-        matrix arithmetic stay fp32).  The engine takes fp32 codes and hands back an image of its storage type."""
+    def __init__(self, spec: NetSpec, B: int, H: int, W: int, device, lr=0.1, act_dtype=None, mfma_bf16=None, options=None):
+        """act_dtype: storage type of the activation tensors - torch.float32 (default) or torch.bfloat16 (BASELINE config 5 "bf16 activations": every conv input /
+        output, gradient and image is stored as bf16, statistics / coefficients / parameters / the matrix arithmetic stay fp32).  The engine takes fp32
+        codes and hands back an image of its storage type.  mfma_bf16: on top of bf16 storage, bf16 MATRIX arithmetic (the `_bf16m` conv entry points: 3x3 stride-1
+        convs run v_mfma_f32_16x16x16_bf16, their operands - prologue outputs and weights - rounded to bf16; fp32 accumulation / statistics).
+        options: an EngineOptions (maxstyle_amd/options.py) or a dict of its fields - every A/B switch of the fusion plan; nothing is read from the environment here."""
         if H % 16 or W % 16:
             raise ValueError("image height/width must be multiples of 16 (four stride-2 stages)")
         self.spec, self.B, self.H, self.W, self.dev, self.lr = spec, B, H, W, torch.device(device), lr
-        if act_dtype is None:
-            act_dtype = torch.bfloat16 if os.environ.get("MS_ACT_DTYPE", "").lower() in ("bf16", "bfloat16") else F32
+        act_dtype = F32 if act_dtype is None else act_dtype
         if act_dtype not in (F32, torch.bfloat16):
             raise TypeError("act_dtype must be torch.float32 or torch.bfloat16")
         self.act_dtype = act_dtype
         self.bf16 = act_dtype == torch.bfloat16
-        # bf16 MATRIX arithmetic on top of bf16 storage (the `_bf16m` conv entry points: 3x3 stride-1 convs run v_mfma_f32_16x16x16_bf16, their operands -
-        # prologue outputs and weights - rounded to bf16; fp32 accumulation / statistics).  MS_MFMA_DTYPE=bf16 selects it too.  Meaningless without bf16 storage.
-        if mfma_bf16 is None:
-            mfma_bf16 = os.environ.get("MS_MFMA_DTYPE", "").lower() in ("bf16", "bfloat16")
-        self.mfma_bf16 = bool(mfma_bf16) and self.bf16
+        self.mfma_bf16 = bool(mfma_bf16) and self.bf16      # (meaningless without bf16 storage)
+        opt = self.options = engine_options(options)
+        inner = type(self) is InnerLoopEngine
         self.buf: Dict[str, torch.Tensor] = {}
         self._stage = {}                    # pinned host staging buffers of _upload: key -> [buffer, event of the last copy queued from it]
         self.nets: Optional[PackedNets] = None
@@ -349,109 +380,50 @@ class InnerLoopEngine:
         self._cfg_cache = {}
         self._err_pending = None
         self._ws_state_off = {}
-        # True: other kernels run beside the loop (side streams / other processes on this GPU): the co-residency-dependent single-read MaxStyle kernel
-        # is not selected (three-launch path).  MS_SHARED_DEVICE=1 sets it for every engine of the process (several ranks per GPU, bench.py --oversubscribe).
-        self.shared_device = os.environ.get("MS_SHARED_DEVICE", "0") != "0"
+        # True: other kernels run beside the loop (side streams / other processes on this GPU): the co-residency-dependent single-read MaxStyle kernel and the
+        # `_xfin` launches are not selected.  EngineOptions.shared_device; MS_SHARED_DEVICE=1 sets it for every engine of the process (several ranks per GPU).
+        self.shared_device = bool(opt.shared_device)
         self._prefix_valid = False
         self.labels = None
         self.code = None
         self.bn_eval = False          # True: BatchNorm uses running statistics (module.eval()); False: batch statistics
         self.bn_observer = None       # optional callback(bn: BNW, coef4, count) - running-statistics update of a tracking forward
         self.loss_sign = -1.0         # loss = loss_sign * cross_entropy_2D  (the inner loop maximises CE)
-        self.fuse_bn_bwd = False      # ms_act_bwd_bn (one launch) instead of ms_act_bwd_reduce + ms_bn_bwd_coefs
-        # BatchNorm-backward coefficients computed inside the data-gradient conv (ms_conv2d pro_mode 3) instead of by ms_bn_bwd_coefs:
-        # 24 fewer launches per step, but measured SLOWER at C2 (263.1 vs 268.3 steps/s, twice each): every workgroup of the conv stalls
-        # on the dependent partial-sum loads at its start, which costs more than the 5 us kernel it replaces.  Off by default.
-        self.inline_bn_bwd = os.environ.get("MS_INLINE_BN_BWD", "0") != "0"
-        # independent branches of a residual block (1x1 skip conv and its gradient) on a second stream, captured into the same HIP graph.
-        # Built to fill the bubbles around the 5 us BatchNorm kernels; measured SLOWER at C2 (273.4 vs 295.3 steps/s, twice each): the conv kernels
-        # are persistent grids sized for the whole chip, and a concurrent kernel that takes CU slots turns into load imbalance. Off by default.
-        self.overlap = os.environ.get("MS_OVERLAP", "0") != "0"
-        # activation-backward mask + BatchNorm-backward sums in the epilogue of the data-gradient conv that produces the gradient
-        # (ms_conv2d_actbwd) instead of a separate ms_act_bwd_reduce pass over it; MS_FUSE_ACTBWD=0 is the A/B switch
-        self.fuse_act_bwd = os.environ.get("MS_FUSE_ACTBWD", "1") != "0"
-        # the LAST workgroup of a conv with a statistics / mask epilogue can reduce the partial table itself (ms_conv2d_fin, ms_conv2d_actbwd_fin)
-        # instead of an ms_bn_finalize / ms_bn_bwd_coefs launch behind it.  Those launches cost ~4 us each in the replayed graph (326.6 vs 304.3
-        # steps/s with all 54 of them skipped as a timing experiment), but the fused tail costs MORE: 260.9 vs 304.2 steps/s with 42 of them fused -
-        # 512 workgroups finish together, so publish -> arrive (one counter word, ~88 arrivals/us) -> reduce by one workgroup is ~13 us of serial
-        # device-scope round trips at the end of every such conv.  Off by default (MS_FUSE_BNFIN=1 turns it on; results are identical).
-        self.fuse_bn_fin = os.environ.get("MS_FUSE_BNFIN", "0") != "0"
-        # tail of a residual block as ONE launch: the 1x1 skip conv applies BatchNorm + residual add + LeakyReLU of the block in its epilogue
-        # (ms_conv1x1_bnres) instead of ms_conv2d(ks=1) -> skip tensor -> ms_bn_act; MS_FUSE_SKIP=0 is the A/B switch (bit-identical results)
-        self.fuse_skip = os.environ.get("MS_FUSE_SKIP", "1") != "0"
-        # the two x2 resampling convolutions in their sub-pixel form (ms_conv_subpix: no products with the duplicates / zeros the resampling inserts);
-        # MS_SUBPIX=0 is the A/B switch (results agree to fp32 rounding: the up-sampling form pre-adds the taps that meet on one stored pixel)
-        self.subpix = os.environ.get("MS_SUBPIX", "1") != "0"
-        # second generation of that kernel (LDS-DMA staging, sums appendix, 4 x 4-pixel block items on small images): MS_SUBPIX_GEN=1 is the A/B switch (the library reads
-        # it too: the mode-1 calls go through ms_conv_subpix, which picks the generation itself)
-        self.subpix_gen2 = os.environ.get("MS_SUBPIX_GEN", "2") != "1"
-        self.small_cout = os.environ.get("MS_SMALL_COUT", "1") != "0"      # vector-ALU kernel for the 16 -> 1 (64 -> 3) data-gradient to the image
-        # the activation after the encoder's first double conv (`inc`) is never written: BatchNorm + LeakyReLU become the prologue of down1's stride-2 conv
-        # and the backward mask is recomputed from the raw conv output (inner loop only: the training engine and the MixStyle baselines read that tensor)
-        self.lazy_inc = os.environ.get("MS_LAZY_INC", "1") != "0" and type(self) is InnerLoopEngine
+        # What each switch trades is described field by field in maxstyle_amd/options.py; the measurements behind the defaults are in DESIGN.md section 3.
+        # (Removed in round 5 with their entry points, all measured slower and off since rounds 1-2: a side stream for the skip branch - MS_OVERLAP -, BatchNorm-backward
+        #  coefficients derived inside the data-gradient conv - pro_mode 3 -, "the last workgroup finalises" - ms_conv2d_fin / ms_conv2d_actbwd_fin / ms_act_bwd_bn.)
+        self.fuse_act_bwd = opt.fuse_act_bwd
+        self.fuse_skip = opt.fuse_skip
+        self.subpix = opt.subpix
+        self.small_cout = opt.small_cout
+        self.lazy_inc = opt.lazy_inc and inner
         # Winograd F(2x2,3x3) form of the wide 3x3 stride-1 convolutions (MS_FETCH_WINOGRAD).  Its rounding error on the networks' activations is about twice the direct
-        # form's (include/maxstyle_hip.h, ms_conv2d): harmless for the augmentation loop (parity tests unchanged).  MS_LOOP_WINOGRAD=0 is the A/B switch there.
-        # Training passes (forward and data-gradient convs; the weight-gradient kernels are their own): OPT-IN, MS_TRAIN_WINOGRAD=1.  Measured at the end of round 4
-        # (tools/wino_train_check.py, tests/test_train_gpu.py under the switch: all bars hold): 22.5 -> 21.7 ms per trainer iteration (44.5 -> 46.1 /s), weight gradients of
-        # the full-size pass against the fp64 oracle - the same with either form in the batch measured (worst tensor 3.1e-2 max norm, mean over the 160 tensors 2.2e-3:
-        # LeakyReLU kinks on the 16-pixel levels decide it; the fp32 CPU oracle: 4.2e-3 / 5.2e-4; round 2, with another accumulation order in the
-        # stride-2 convs, measured 4.7e-4 direct against 1.0e-3 Winograd).  The form's own rounding error IS about twice the direct one's, i.e. about twice as many kinks
-        # over many batches: the default keeps the weight gradients on the direct form; the switch is there for whoever prefers the 3.5 % (the reference's GPU path leaves
-        # that choice to cuDNN).  bench.py reports both (`outer_iteration.winograd_training_passes_opt_in`).
-        if type(self) is InnerLoopEngine:
-            self.winograd = os.environ.get("MS_LOOP_WINOGRAD", "1") != "0"
-        else:
-            self.winograd = os.environ.get("MS_TRAIN_WINOGRAD", "0") != "0"
+        # form's (include/maxstyle_hip.h, ms_conv2d): harmless for the augmentation loop (parity tests unchanged: default on); the training passes (forward and
+        # data-gradient convs; the weight-gradient kernels are their own) keep the direct form unless asked (DESIGN.md section 10 has the round-5 fidelity distribution).
+        self.winograd = (True if opt.winograd is None else bool(opt.winograd)) if inner else bool(opt.train_winograd)
         self.fuse_style_actbwd = True  # ms_style_bwd_actbwd (the MaxStyle backward also does the block's output-activation backward)
-        # the tail of a step as ONE launch (ms_step_tail: the layers' gradient reductions + Adam + the cross-entropy sum + the step counter; was six
-        # ~4.8 us launches); MS_FUSE_TAIL=0 is the A/B switch (bit-identical results)
-        self.fuse_tail = os.environ.get("MS_FUSE_TAIL", "1") != "0"
-        # BatchNorm finalize + its activation as ONE launch where nothing else consumes the record in between (z_i, z_s: ms_bn_finalize_act; two ~5 us launches less per
-        # step); MS_FUSE_FINACT=0 is the A/B switch (bit-identical results).  Inner loop only: the training engine's bn_fin also tracks running statistics.
-        self.fuse_fin_act = os.environ.get("MS_FUSE_FINACT", "1") != "0" and type(self) is InnerLoopEngine
-        self.fuse_head_bwd = os.environ.get("MS_FUSE_HEAD_BWD", "1") != "0"     # ms_style_bwd_head: layer 4's backward forms the head's input gradient itself
-        # ms_bn_bwd_coefs jobs whose consumer is a residual block's backward ride on that block's 1x1 skip data-gradient launch (ms_conv2d_ride) instead of
-        # being ~5 us launches of their own; MS_RIDE=0 is the A/B switch (bit-identical results)
-        self.ride = os.environ.get("MS_RIDE", "1") != "0"
-        # the producers of a masked gradient that an up-sampling block's backward pools 2x2 for its skip branch (ms_head_ce_tail, ms_pool2_actbwd) write the
-        # pooled tensor themselves: no ms_pool2_sum launch in res_bwd (MS_POOL_FUSE=0 is the A/B switch; results agree to rounding - the producers' per-thread
-        # grouping of the BatchNorm-backward sums changes with their pixel mapping)
-        # the encoder's first conv (1 -> 16 channels) on the vector ALUs (ms_conv3x3_small_cin) instead of an MFMA tile with 7 of 8 K lanes empty: +0.3 % on the step.
-        # OPT-IN (MS_SMALL_CIN=1): results agree with the matrix-core path to rounding (an fp32 FMA chain instead of the MFMA's accumulation order), but that other
-        # rounding moves the free-running K = 5 trajectories onto other realisations of the same chaos, and three bars calibrated against the reference's own noise
-        # sit at 1.5-2x their limit with it (profiles/r03_experiments.txt 18).  The default keeps the path every parity number of the round was measured on.
-        self.small_cin = os.environ.get("MS_SMALL_CIN", "0") != "0" and type(self) is InnerLoopEngine
-        self.pool_fuse = os.environ.get("MS_POOL_FUSE", "1") != "0" and type(self) is InnerLoopEngine
-        # the data-gradient of an up-sampling block's first conv stores the 2x2 sums of its result itself (ms_conv2d epi_mode MS_EPI_POOL2, Winograd form):
-        # the full-resolution gradient is never written or read back (MS_POOL_EPI=0 is the A/B switch; bit-identical in fp32 storage)
-        self.pool_epi = os.environ.get("MS_POOL_EPI", "1") != "0" and type(self) is InnerLoopEngine
-        # the output of the MaxStyle layer in front of the image head is never written: the layer's kernel leaves statistics and coefficients, the head applies
-        # them per element (ms_head_fwd_styled; MS_LAZY_STYLE_HEAD=0 is the A/B switch, bit-identical)
-        self.lazy_style_head = os.environ.get("MS_LAZY_STYLE_HEAD", "1") != "0" and type(self) is InnerLoopEngine
-        self.lazy_seg_tail = os.environ.get("MS_LAZY_SEG_TAIL", "1") != "0" and type(self) is InnerLoopEngine      # ms_head_ce_tail (see seg_loss)
-        # cross-workgroup finalize (`_xfin` entry points): the BatchNorm coefficients a launch consumes are derived INSIDE that launch (one wave per channel,
-        # published through tagged granules) instead of by an ms_bn_finalize launch in front of it.  Needs every workgroup of a launch co-resident: not with
-        # shared_device.  MS_XFIN=0 is the A/B switch (bit-identical results).
-        # (the training engine can take it for its forward passes - MS_TRAIN_XFIN=1; every record a launch derives is reported to `_coef_made` - but its passes are
-        #  bound by kernel time, not by launches: -0.1 ms of a 23 ms trainer iteration, less than the error-word check in front of the weight step costs:
-        #  profiles/r04_experiments.txt 9; off by default)
-        self.xfin = os.environ.get("MS_XFIN", "1") != "0" and (type(self) is InnerLoopEngine or os.environ.get("MS_TRAIN_XFIN", "0") != "0")
-        # ... also for the consumers that need the coefficients in their PROLOGUE (ms_conv2d_xfin: conv2 of a block; MS_XFIN_PRO=0 is the A/B switch)
-        self.xfin_pro = self.xfin and os.environ.get("MS_XFIN_PRO", "1") != "0" and not self.mfma_bf16      # (the bf16-MFMA conv mode has no `_xfin` twin)
+        self.fuse_tail = opt.fuse_tail
+        self.fuse_fin_act = opt.fuse_fin_act and inner      # (the training engine's bn_fin also tracks running statistics)
+        self.fuse_head_bwd = opt.fuse_head_bwd
+        self.ride = opt.ride
+        self.small_cin = opt.small_cin and inner
+        self.pool_fuse = opt.pool_fuse and inner
+        self.pool_epi = opt.pool_epi and inner
+        self.lazy_style_head = opt.lazy_style_head and inner
+        self.lazy_seg_tail = opt.lazy_seg_tail and inner      # ms_head_ce_tail (see seg_loss)
+        # cross-workgroup finalize (`_xfin` entry points): needs every workgroup of a launch co-resident - not with shared_device.  The training engine takes it for its
+        # forward passes only on request (train_xfin: every record a launch derives is reported to `_coef_made`; -0.1 ms of a 23 ms iteration).
+        self.xfin = opt.xfin and (inner or opt.train_xfin)
+        self.xfin_pro = self.xfin and opt.xfin_pro and not self.mfma_bf16      # (the bf16-MFMA conv mode has no `_xfin` twin)
         self._tail = None              # while a step defers its tail: {"layers": [...], "ce": (ws, nparts, scale) | None}
-        if self.bf16:
-            # kernels without a bf16 twin: the "last workgroup finalises" experiments and the weight-gradient kernels (TrainEngine is fp32 only)
-            if type(self) is not InnerLoopEngine:
-                raise NotImplementedError("bf16 activation storage is built for the inner loop (InnerLoopEngine); the training passes store fp32")
-            self.fuse_bn_fin = self.fuse_bn_bwd = self.inline_bn_bwd = False
-        self._side_stream = None
-        self._side_pending = False
+        if self.bf16 and not inner:
+            raise NotImplementedError("bf16 activation storage is built for the inner loop (InnerLoopEngine); the training passes store fp32")
         # MixStyle / DSU layers inside the encoder (generate_style_augmented_latent_code, advanced_triplet...py:632-670):
         # {index 1..6: (perm | None, lmda | None, gaussian_std | None, gaussian_mu | None, eps)}; None = plain encoder
         self.enc_mix = None
 
     # ------------------------------------------------------------------ buffers
-    def t(self, name, *shape, dtype=F32):
+    def t(self, name, *shape, dtype=F32, zero=True):
         b = self.buf.get(name)
         if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
             if b is not None and self._any_graph():
@@ -461,17 +433,16 @@ class InnerLoopEngine:
                 # from) is dropped with it and comes back zero-filled - a fresh epoch can never meet a stale tag
                 for k in [k for k in self.buf if k.endswith(".gran")]:
                     del self.buf[k]
-            numel = 1
-            for s_ in shape:
-                numel *= int(s_)
-            # tables / coefficient records / partial sums start from zeros (deterministic launch epochs); activation-sized tensors are written before they are read
-            b = (torch.zeros if numel <= (1 << 20) else torch.empty)(*shape, dtype=dtype, device=self.dev)
+            # decided by ROLE, not by size (a statistics table of a >= 128-channel layer is just over 2^20 elements): everything allocated through t() - tables,
+            # coefficient records, partial sums, workspaces - starts from zeros, so the launch epoch in a table header is deterministic; activation tensors (a()) are
+            # written before they are read and stay uninitialised
+            b = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.dev)
             self.buf[name] = b
         return b
 
     def a(self, name, *shape):
         """An ACTIVATION tensor (conv inputs / outputs, gradients, images): fp32, or bf16 storage in bf16 mode (everything else stays fp32)."""
-        return self.t(name, *shape, dtype=self.act_dtype)
+        return self.t(name, *shape, dtype=self.act_dtype, zero=False)
 
     _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv2d_ride", "ms_conv2d_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_bn_finalize_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd", "ms_pool2_actbwd_pool", "ms_add_actbwd",
                              "ms_head_fwd", "ms_head_fwd_styled", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_head_ce_tail", "ms_style_fwd", "ms_style_bwd", "ms_style_ws_bytes",
@@ -487,7 +458,7 @@ class InnerLoopEngine:
         return getattr(lib, name)
 
     def _st(self):
-        # the raw handle of torch's CURRENT stream on this device (it changes under torch.cuda.graph capture and inside _side()): asked per launch, through the
+        # the raw handle of torch's CURRENT stream on this device (it changes under torch.cuda.graph capture): asked per launch, through the
         # accessor that does not build a torch.cuda.Stream object (1 us instead of ~10 us per launch of host time - a trainer pass is ~300 eager launches)
         return _raw_stream(self.dev.index if self.dev.index is not None else torch.cuda.current_device())
 
@@ -586,46 +557,10 @@ class InnerLoopEngine:
                 from ._lib import MaxStyleHipError
                 raise MaxStyleHipError("single-read MaxStyle kernel: a bounded spin timed out; the stylised image of the last loop call is invalid")
 
-    # ------------------------------------------------------------------ side stream (independent branches of a block)
-    class _SideCtx:
-        def __init__(self, eng):
-            self.eng = eng
-
-        def __enter__(self):
-            e = self.eng
-            if e.overlap:
-                if e._side_stream is None:
-                    e._side_stream = torch.cuda.Stream(device=e.dev)
-                e._side_stream.wait_stream(torch.cuda.current_stream())       # everything issued so far on the main stream is visible
-                self.ctx = torch.cuda.stream(e._side_stream)
-                self.ctx.__enter__()
-                e._side_pending = True
-            return self
-
-        def __exit__(self, *exc):
-            if self.eng.overlap:
-                self.ctx.__exit__(*exc)
-            return False
-
-    def _side(self, after_main=True):
-        return InnerLoopEngine._SideCtx(self)
-
-    def _join_side(self):
-        if self.overlap and self._side_pending:
-            torch.cuda.current_stream().wait_stream(self._side_stream)
-            self._side_pending = False
-
     # ------------------------------------------------------------------ kernel-call helpers (no allocation after warm-up)
-    def _counter(self, name):
-        c = self.buf.get(name + ".cnt")
-        if c is None:                     # zero once; every launch that uses it re-arms it
-            c = torch.zeros(1, dtype=torch.int32, device=self.dev)
-            self.buf[name + ".cnt"] = c
-        return c
-
     def conv(self, name, x, cw: ConvW, cout=None, ks=None, stride=1, fetch=0, act=None, bnbwd=None, epi=0, out=None, stats=False, dgrad=False, fin=None, ride=None):
-        """act=(coef4, slope): BN-apply+LeakyReLU prologue; bnbwd=(bcoef4, u): BN-backward prologue; fin: the BatchNorm (BNW) that follows - with
-        `fuse_bn_fin` its coefficients come out of this launch. Returns (out, stats, parts); stats is ("fused", coef4) when they did."""
+        """act=(coef4, slope): BN-apply+LeakyReLU prologue; bnbwd=(bcoef4, u): BN-backward prologue; fin: the BatchNorm (BNW) that follows (informational).
+        Returns (out, stats, parts)."""
         N, Cin, Hs, Ws = x.shape
         wp = cw.dwp if dgrad else cw.wp
         ks = cw.ks if ks is None else ks
@@ -653,23 +588,12 @@ class InnerLoopEngine:
             pm = 1
             pa, pb, _ = ops.coef_ptrs(act[0])
             slope = act[1]
-        elif bnbwd is not None and isinstance(bnbwd[0], tuple):
-            # (part, nparts, coef) instead of ready coefficients: the conv derives them itself (pro_mode 3, no ms_bn_bwd_coefs launch)
-            part, nparts, coef = bnbwd[0]
-            pm, pa, pb, pc, pn = 3, part.data_ptr(), coef.data_ptr(), 0, nparts
-            in2 = bnbwd[1]
         elif bnbwd is not None:
             pm = 2
             pa, pb, pc = ops.coef_ptrs(bnbwd[0])
             in2 = bnbwd[1]
         bias = None if dgrad else cw.b
-        assert ride is None or (xf is None and ks == 1 and not (stats and fin is not None and self.fuse_bn_fin)), "a rider travels on a plain 1x1 ms_conv2d"
-        if stats and fin is not None and self.fuse_bn_fin and epi == 0 and pm != 3:
-            coef = self.t(name + ".fcoef", cout, 4)
-            check(lib.ms_conv2d_fin(x.data_ptr(), 0 if in2 is None else in2.data_ptr(), out.data_ptr(), wp.data_ptr(), 0 if bias is None else bias.data_ptr(),
-                                    N, Cin, Hs, Ws, cout, ks, stride, fetch, pm, pa, pb, pc, pn, 4, slope, st.data_ptr(), fin.gamma.data_ptr(), fin.beta.data_ptr(),
-                                    BN_EPS, coef.data_ptr(), self._counter(name).data_ptr(), self._st()), "ms_conv2d_fin:" + name)
-            return out, ("fused", coef), parts
+        assert ride is None or (xf is None and ks == 1), "a rider travels on a plain 1x1 ms_conv2d"
         wf = ops.FETCH_WINOGRAD if (self.winograd and fetch == 0 and ks == 3 and stride == 1) else 0
         if wf and (cw.dwu if dgrad else cw.wu):
             wf |= ops.FETCH_WINO_U                     # the transformed weights are staged from the packed tensor's appendix
@@ -695,7 +619,7 @@ class InnerLoopEngine:
     def bwd_coefs(self, bc_name, part, nparts, coef, count, C, ride=False):
         """ms_bn_bwd_coefs -> the coefficient tensor; ride=True (the consumer is res_bwd): the pending job (RideCoef) for that block's skip conv to carry."""
         bc = self.t(bc_name, C, 4)
-        if ride and self.ride and not self.overlap and not self.bn_eval:
+        if ride and self.ride and not self.bn_eval:
             return RideCoef(part, nparts, coef, float(count), bc, C)
         check(lib.ms_bn_bwd_coefs(part.data_ptr(), nparts, coef.data_ptr(), float(count), bc.data_ptr(), C, self._st()), "ms_bn_bwd_coefs:" + bc_name)
         return bc
@@ -715,12 +639,8 @@ class InnerLoopEngine:
                 self.nets.refresh_eval()
             self.buf[name + ".coef"] = bn.coef_eval
             return bn.coef_eval
-        if isinstance(st, tuple):         # the conv's last workgroup already wrote them (ms_conv2d_fin)
-            coef = st[1]
-            self.buf[name + ".coef"] = coef
-        else:
-            coef = self.t(name + ".coef", bn.gamma.numel(), 4)
-            check(lib.ms_bn_finalize(st.data_ptr(), parts, bn.gamma.data_ptr(), bn.beta.data_ptr(), BN_EPS, coef.data_ptr(), bn.gamma.numel(), self._st()), "ms_bn_finalize:" + name)
+        coef = self.t(name + ".coef", bn.gamma.numel(), 4)
+        check(lib.ms_bn_finalize(st.data_ptr(), parts, bn.gamma.data_ptr(), bn.beta.data_ptr(), BN_EPS, coef.data_ptr(), bn.gamma.numel(), self._st()), "ms_bn_finalize:" + name)
         if self.bn_observer is not None:
             self.bn_observer(bn, coef)
         return coef
@@ -728,7 +648,7 @@ class InnerLoopEngine:
     def bn_fin_act(self, name, out_name, st, parts, bn: BNW, u, slope):
         """bn_fin(name, ...) followed by bn_act(out_name, u, coef, None, 0, slope) - as one launch when the engine may (fuse_fin_act; batch statistics; a statistics
         table in hand; nobody observing the record)."""
-        if not self.fuse_fin_act or self.bn_eval or isinstance(st, tuple) or self.bn_observer is not None:
+        if not self.fuse_fin_act or self.bn_eval or self.bn_observer is not None:
             return self.bn_act(out_name, u, self.bn_fin(name, st, parts, bn), None, 0, slope)
         N, C, H, W = u.shape
         coef = self.t(name + ".coef", C, 4)
@@ -738,9 +658,8 @@ class InnerLoopEngine:
         return out
 
     def _xfin_ok(self, st):
-        """The consumer launch may derive its BatchNorm coefficients itself (`_xfin`): batch statistics, a statistics TABLE in hand (not the pair the
-        'last workgroup finalises' experiment returns), an exclusive device."""
-        return self.xfin and not self.bn_eval and not self.shared_device and not isinstance(st, tuple) and self.bn_observer is None
+        """The consumer launch may derive its BatchNorm coefficients itself (`_xfin`): batch statistics, a statistics table in hand, an exclusive device."""
+        return self.xfin and not self.bn_eval and not self.shared_device and st is not None and self.bn_observer is None
 
     def bn_fin_or_pending(self, name, st, parts, bn: BNW, consumer_ok=True):
         """bn_fin, or - when the consumer is a conv that can derive the coefficients in its own launch (`_xfin`, prologue kind) - the pending record."""
@@ -798,23 +717,11 @@ class InnerLoopEngine:
                 self.buf[name + ".bcoef_eval"] = bc
             bc[:, 0].copy_(coef[:, 0])
             return gin, bc
-        if not self.fuse_bn_bwd:
-            # two launches (mask+reduce, then coefficients).  Both fusions were built and measured slower at C2: the one-launch
-            # ms_act_bwd_bn (236.5 vs 254.8 steps/s: an s_waitcnt vmcnt(0) + a returning atomic on the tail of each of its 4096
-            # workgroups) and ms_conv2d pro_mode 3 (`inline_bn_bwd`, see __init__).
-            check(self.L("ms_act_bwd_reduce")(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
-                                        N, C, H * W, slope, self._st()), "ms_act_bwd_reduce:" + name)
-            if self.inline_bn_bwd:
-                return gin, (part, nparts, coef)
-            return gin, self.bwd_coefs(name + ".bcoef", part, nparts, coef, N * H * W, C, ride=ride)
-        bc = self.t(name + ".bcoef", C, 4)
-        arrive = self.buf.get("bn.arrive")
-        if arrive is None:
-            arrive = torch.zeros(1024, dtype=torch.int32, device=self.dev)     # re-armed by every launch; stream order serialises its users
-            self.buf["bn.arrive"] = arrive
-        check(lib.ms_act_bwd_bn(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
-                                arrive.data_ptr(), bc.data_ptr(), N, C, H * W, slope, self._st()), "ms_act_bwd_bn:" + name)
-        return gin, bc
+        # two launches (mask+reduce, then coefficients - or the coefficient job as a rider).  A one-launch fusion (`last workgroup of the channel finalises`) and
+        # in-conv derivation of the coefficients were built and measured slower in rounds 1-2; both were removed in round 5.
+        check(self.L("ms_act_bwd_reduce")(gin.data_ptr(), 0 if ref is None else ref.data_ptr(), u.data_ptr(), coef.data_ptr(), gin.data_ptr(), part.data_ptr(),
+                                    N, C, H * W, slope, self._st()), "ms_act_bwd_reduce:" + name)
+        return gin, self.bwd_coefs(name + ".bcoef", part, nparts, coef, N * H * W, C, ride=ride)
 
     def conv_actbwd(self, name, bw_name, g, cw: ConvW, bnbwd, u, coef, slope):
         """Data-gradient conv (BatchNorm-backward prologue `bnbwd`) -> mask by the activation lrelu(bn(u)) below it -> (masked gradient, table).
@@ -831,20 +738,10 @@ class InnerLoopEngine:
 
     def dgrad_act_bwd(self, name, bw_name, g, cw: ConvW, bnbwd, u, coef, slope):
         """da = dgrad(conv cw)(BN-backward(g)); g' = da * lrelu'(bn(u)); BN-backward coefficients of u's layer -> (g', bcoef4)."""
-        if not self.fuse_act_bwd or isinstance(bnbwd[0], tuple):
+        if not self.fuse_act_bwd:
             da, _, _ = self.conv(name, g, cw, bnbwd=bnbwd, dgrad=True)
             return self.act_bwd(bw_name, da, None, u, coef, slope)
         N, C, H, W = u.shape
-        if self.fuse_bn_fin and not self.bn_eval:
-            Ng, Cin, Hs, Ws = g.shape
-            out = self.a(name, Ng, cw.cin, Hs, Ws)
-            tab = self.t(bw_name + ".tab", lib.ms_conv_actbwd_tab_bytes(cw.cin) // 4)
-            bc = self.t(bw_name + ".bcoef", C, 4)
-            pa, pb, pc = ops.coef_ptrs(bnbwd[0])
-            check(lib.ms_conv2d_actbwd_fin(g.data_ptr(), bnbwd[1].data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), Ng, Cin, Hs, Ws, cw.cin, cw.ks, 1, 0,
-                                           2, pa, pb, pc, 0, 4, 1.0, u.data_ptr(), coef.data_ptr(), slope, tab.data_ptr(), float(N * H * W), bc.data_ptr(),
-                                           self._counter(bw_name).data_ptr(), self._st()), "ms_conv2d_actbwd_fin:" + name)
-            return out, bc
         out, tab = self.conv_actbwd(name, bw_name, g, cw, bnbwd, u, coef, slope)
         if self.bn_eval:
             bc = self.buf.get(bw_name + ".bcoef_eval")
@@ -880,14 +777,14 @@ class InnerLoopEngine:
     def conv_ups2(self, name, x, cw: ConvW, fin=None):
         """nn.UpsamplingNearest2d(2) -> 3x3 conv (+ BatchNorm statistics of the outputs): sub-pixel kernel when eligible, else the fused-fetch conv."""
         N, Cin, Hs, Ws = x.shape
-        if not self._subpix_ok(N, Hs, Ws, cw.cout) or (self.fuse_bn_fin and not self.bn_eval):
+        if not self._subpix_ok(N, Hs, Ws, cw.cout):
             return self.conv(name, x, cw, fetch=ops.FETCH_UPS2, stats=True, fin=fin)
         out = self.a(name, N, cw.cout, 2 * Hs, 2 * Ws)
         st, parts = None, N * 4 * Hs * Ws
         if not self.bn_eval:
             parts = lib.ms_conv_stats_parts(N, 2 * Hs, 2 * Ws)
             st = self.t(name + ".stats", cw.cout * parts + 1, 4)
-        if self.bf16 or not self.subpix_gen2:
+        if self.bf16:
             check(self.L("ms_conv_subpix")(x.data_ptr(), out.data_ptr(), cw.wp.data_ptr(), 0 if cw.b is None else cw.b.data_ptr(), N, Cin, Hs, Ws, cw.cout, 0,
                                      0 if st is None else st.data_ptr(), 0, 0, 0, 1.0, 0, self._st()), "ms_conv_subpix(ups2):" + name)
         else:
@@ -931,14 +828,12 @@ class InnerLoopEngine:
             src, _, _ = self.conv(pfx + ".xd", x, net[key + ".down"], stride=2, act=x_act)
         else:
             fetch = ops.FETCH_UPS2
-        fused_tail = self.fuse_skip and not self.overlap
-        # the 1x1 skip convolution only depends on the block input: with `overlap` it runs on the side stream (see __init__ for the measurement)
+        fused_tail = self.fuse_skip
         if not fused_tail:
-            with self._side(after_main=True):
-                if kind == "nn":
-                    s, _, _ = self.conv(pfx + ".s", x, ci)          # conv1x1 commutes with nearest up-sampling: low resolution
-                else:
-                    s, _, _ = self.conv(pfx + ".s", src, ci)
+            if kind == "nn":
+                s, _, _ = self.conv(pfx + ".s", x, ci)          # conv1x1 commutes with nearest up-sampling: low resolution
+            else:
+                s, _, _ = self.conv(pfx + ".s", src, ci)
         if kind == "nn":
             u1, st1, p1 = self.conv_ups2(pfx + ".u1", src, c0, fin=net[key + ".bn1"])
         else:
@@ -951,7 +846,7 @@ class InnerLoopEngine:
             assert kind == "nn"
             bn = net[key + ".bn4"]
             N_, _, H_, W_ = x.shape
-            if self.ride and not self.bn_eval and not isinstance(st2, tuple) and self.bn_observer is None and bn.gamma.numel() <= lib.ms_conv_ride_capacity(N_, H_, W_):
+            if self.ride and not self.bn_eval and self.bn_observer is None and bn.gamma.numel() <= lib.ms_conv_ride_capacity(N_, H_, W_):
                 # ... and that conv carries the block's ms_bn_finalize job (ms_conv2d_ride kind 1): the head behind it reads the record
                 cf2 = self.t(pfx + ".bn4.coef", bn.gamma.numel(), 4)
                 self._coef_made(bn, cf2)
@@ -977,7 +872,6 @@ class InnerLoopEngine:
             check(self.L("ms_conv1x1_bnres")(xin.data_ptr(), out.data_ptr(), ci.wp.data_ptr(), 0 if ci.b is None else ci.b.data_ptr(), N, Cin, Hs, Ws, ci.cout,
                                        u2.data_ptr(), cf2.data_ptr(), LEAKY, 1 if kind == "nn" else 0, self._st()), "ms_conv1x1_bnres:" + pfx)
             return out
-        self._join_side()
         out = self.bn_act(pfx + ".out", u2, cf2, s, 2 if kind == "nn" else 1, LEAKY)
         return out
 
@@ -1006,19 +900,17 @@ class InnerLoopEngine:
                 ride, bc2 = bc2, bc2.bc
             else:
                 bc2 = self.ride_now(bc2)
-        # skip branch on the side stream (it only needs g2): its data-gradient lands in the buffer the main chain then ACCUMULATES into
-        with self._side(after_main=True):
-            if kind == "nn":
-                gs = gs_ready if gs_ready is not None else self.pool2(pfx + ".gs", g2)
-                dx, _, _ = self.conv(pfx + ".dx", gs, ci, dgrad=True, ride=ride)
-            else:
-                dsrc, _, _ = self.conv(pfx + ".dsrc", g2, ci, dgrad=True, ride=ride)
+        # skip branch (it only needs g2): its data-gradient lands in the buffer the main chain then ACCUMULATES into
+        if kind == "nn":
+            gs = gs_ready if gs_ready is not None else self.pool2(pfx + ".gs", g2)
+            dx, _, _ = self.conv(pfx + ".dx", gs, ci, dgrad=True, ride=ride)
+        else:
+            dsrc, _, _ = self.conv(pfx + ".dsrc", g2, ci, dgrad=True, ride=ride)
         g1, bc1 = self.dgrad_act_bwd(pfx + ".da1", pfx + ".bw1", g2, c3, (bc2, b[pfx + ".u2"]), b[pfx + ".u1"], b[pfx + ".bn1.coef"], LEAKY)
-        self._join_side()
         if kind == "nn":
             fused_next = next_act is not None and self.fuse_act_bwd and not self.bn_eval and dx.shape[3] % 4 == 0 and dx.shape[0] * dx.shape[1] <= 65535
             Ng, Cg, Hg, Wg = g1.shape
-            pooled_epi = (fused_next and self.pool_epi and self.winograd and not isinstance(bc1, tuple) and      # (a (partials, n, records) tuple = pro_mode 3: first-generation kernel)
+            pooled_epi = (fused_next and self.pool_epi and self.winograd and
                           lib.ms_conv2d_pool2_ok(Ng, Cg, Hg, Wg, c0.cin, 2, 2 if self.mfma_bf16 else int(self.bf16)) == 1)
             # at the up-sampled resolution - or, pooled_epi, already summed 2x2 by the conv's epilogue (the full-resolution gradient is never written)
             dhi, _, _ = self.conv(pfx + (".dlo" if pooled_epi else ".dhi"), g1, c0, bnbwd=(bc1, b[pfx + ".u1"]), dgrad=True, epi=(EPI_POOL2 if pooled_epi else 0))
@@ -1090,7 +982,7 @@ class InnerLoopEngine:
         """MyEncoder.forward + code_decoupler (encoder_decoder.py:469-482, 673-680) in BN batch-stat mode."""
         e = self.nets.enc
         c0 = e["inc0"]
-        if self.small_cin and not self.bn_eval and not self.fuse_bn_fin and lib.ms_conv3x3_small_cin_ok(c0.cin, c0.cout, image.shape[3]) == 1:
+        if self.small_cin and not self.bn_eval and lib.ms_conv3x3_small_cin_ok(c0.cin, c0.cout, image.shape[3]) == 1:
             N_, _, H_, W_ = image.shape
             ua = self.a("e.inc.ua", N_, c0.cout, H_, W_)
             p = lib.ms_conv_stats_parts(N_, H_, W_)
@@ -1143,7 +1035,7 @@ class InnerLoopEngine:
         g, bc = self.dgrad_act_bwd("e.inc.da", "e.inc.bw1", g, e["inc3"], (bc, b["e.inc.ub"]), b["e.inc.ua"], b["e.inc.bn1.coef"], LEAKY)
         c0 = e["inc0"]
         N, Cg, H, W = g.shape
-        if self.small_cout and lib.ms_conv3x3_small_cout_ok(c0.cin, W) and not isinstance(bc, tuple):
+        if self.small_cout and lib.ms_conv3x3_small_cout_ok(c0.cin, W):
             # the gradient that reaches the image has 1 (3) channels: vector-ALU kernel instead of a 16-column MFMA tile (ms_conv_small.hip)
             dimg = self.a("e.dimage", N, c0.cin, H, W)
             pa, pb, pc = ops.coef_ptrs(self.coef_tensor(bc))      # (not a conv_mfma / conv_wide launch: the coefficients get their own launch here)
@@ -1168,7 +1060,7 @@ class InnerLoopEngine:
         Cq = w.shape[1]
         # the last residual block of the segmentation decoder hands the head (u2, BatchNorm record, low-resolution skip) instead of its output, which is then
         # never written (ms_head_ce_tail; MS_LAZY_SEG_TAIL=0 is the A/B switch, bit-identical): the residual-tail launch becomes a 1x1 conv at half resolution
-        lazy = (self.lazy_seg_tail and need_grad and not need_logits and self.fuse_act_bwd and not self.bn_eval and self.fuse_skip and not self.overlap
+        lazy = (self.lazy_seg_tail and need_grad and not need_logits and self.fuse_act_bwd and not self.bn_eval and self.fuse_skip
                 and Cq == 16 and K <= 4            # (the kernel's channel count is compile-time: FCN_16's last block)
                 and lib.ms_head_ce_actbwd_parts(image.shape[0], Cq, image.shape[2] * image.shape[3]) > 0 and image.shape[3] % 4 == 0 and image.shape[2] % 2 == 0)
         h = self.seg_fwd(z_s, lazy_tail=lazy)
@@ -1320,7 +1212,7 @@ class InnerLoopEngine:
         if f"st{i}.ws" not in self._ws_state_off:
             self._note_state_offset(i, B, C, HW)
         po = lambda nm: self.flat_p.data_ptr() + 4 * s.off[nm][0]
-        flags = (0 if s.have_std else 1) | (4 if (self.shared_device or self.overlap) else 0)
+        flags = (0 if s.have_std else 1) | (4 if self.shared_device else 0)
         check(self.L("ms_style_fwd")(x.data_ptr(), 0 if y is None else y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), std[0].data_ptr(), std[1].data_ptr(),
                                flags, po("lmda") if s.mix_style else 0, po("gamma_noise") if s.use_noise else 0,
                                po("beta_noise") if s.use_noise else 0, s.perm.data_ptr() if s.mix_style else 0,

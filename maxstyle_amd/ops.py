@@ -160,7 +160,6 @@ def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8, step_dev=None):
 # convolution stack
 # ---------------------------------------------------------------------------------------------------------
 FETCH_NORMAL, FETCH_UPS2, FETCH_ZINS2 = 0, 1, 2
-FETCH_X3 = 0x200            # MS_FETCH_X3: the caller accepts the three-way bf16 split form (fp32-faithful, bf16 matrix cores)
 EPI_POOL2 = 6                # ms_conv2d epi_mode: 2x2-pooled store (MS_EPI_POOL2)
 FETCH_WINO_BLOCKS = 0x1000  # MS_FETCH_WINO_BLOCKS: the block form of the Winograd kernel wherever legal (test / A-B switch)
 FETCH_WINO_U = 0x800        # MS_FETCH_WINO_U: the packed weights carry the Winograd appendix (with_wino_appendix below)
@@ -255,35 +254,6 @@ def conv2d_actbwd(x, wp, Cout, ks, u, coef4, act_slope, pro_mode=0, pro_a=None, 
                                pro_mode, _ptr(pro_a), _ptr(pro_b), _ptr(pro_c), 0, pro_cstride, slope, u.data_ptr(), coef4.data_ptr(), act_slope,
                                tab.data_ptr(), _stream()), "ms_conv2d_actbwd")
     return out, tab
-
-
-def conv2d_fin(x, wp, bias, Cout, ks, gamma, beta, counter, eps=1e-5, stride=1, fetch=FETCH_NORMAL, pro_mode=0, pro_a=None, pro_b=None, pro_c=None,
-               pro_cstride=1, slope=1.0, in2=None, out=None, stats=None, coef=None):
-    """ms_conv2d_fin wrapper: conv + BatchNorm batch statistics + (last workgroup) the BatchNorm coefficients -> (out, coef4)."""
-    _need_cuda_f32(x, wp, bias, pro_a, pro_b, pro_c, in2, gamma, beta)
-    N, Cin, Hs, Ws = x.shape
-    Ho, Wo = conv_out_hw(Hs, Ws, ks, stride, fetch)
-    out = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=torch.float32) if out is None else out
-    if stats is None:
-        stats, _ = conv_stats_buffer(N, Cout, Ho, Wo, x.device)
-    coef = torch.empty(Cout, 4, device=x.device, dtype=torch.float32) if coef is None else coef
-    check(lib.ms_conv2d_fin(x.data_ptr(), _ptr(in2), out.data_ptr(), wp.data_ptr(), _ptr(bias), N, Cin, Hs, Ws, Cout, ks, stride, fetch,
-                            pro_mode, _ptr(pro_a), _ptr(pro_b), _ptr(pro_c), 0, pro_cstride, slope, stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps,
-                            coef.data_ptr(), counter.data_ptr(), _stream()), "ms_conv2d_fin")
-    return out, coef
-
-
-def conv2d_actbwd_fin(x, wp, Cout, ks, u, coef4, act_slope, counter, pro_mode=0, pro_a=None, pro_b=None, pro_c=None, pro_cstride=1, slope=1.0, in2=None):
-    """ms_conv2d_actbwd_fin wrapper -> (masked gradient, bcoef4)."""
-    _need_cuda_f32(x, wp, u, coef4, pro_a, pro_b, pro_c, in2)
-    N, Cin, Hs, Ws = x.shape
-    out = torch.empty((N, Cout, Hs, Ws), device=x.device, dtype=torch.float32)
-    tab = torch.full((lib.ms_conv_actbwd_tab_bytes(Cout) // 4,), float("nan"), device=x.device, dtype=torch.float32)
-    bc = torch.full((Cout, 4), float("nan"), device=x.device, dtype=torch.float32)
-    check(lib.ms_conv2d_actbwd_fin(x.data_ptr(), _ptr(in2), out.data_ptr(), wp.data_ptr(), N, Cin, Hs, Ws, Cout, ks, 1, FETCH_NORMAL,
-                                   pro_mode, _ptr(pro_a), _ptr(pro_b), _ptr(pro_c), 0, pro_cstride, slope, u.data_ptr(), coef4.data_ptr(), act_slope,
-                                   tab.data_ptr(), float(N * Hs * Ws), bc.data_ptr(), counter.data_ptr(), _stream()), "ms_conv2d_actbwd_fin")
-    return out, bc
 
 
 def conv_stats_buffer(N, Cout, Ho, Wo, device):

@@ -265,15 +265,24 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
 
     # storage type of the activation tensors of the INNER LOOP (generate_max_style_image): None / torch.float32, or torch.bfloat16 (BASELINE config 5's
     # "bf16 activations": conv inputs / outputs, gradients and the image are stored as bf16 inside the loop, statistics / parameters / arithmetic fp32; the
-    # returned image is fp32 as in the reference).  MS_ACT_DTYPE=bf16 in the environment selects it too.  Module forwards (predict / evaluate / training) are fp32.
+    # returned image is fp32 as in the reference).  Module forwards (predict / evaluate / training) are fp32.
     loop_act_dtype = None
     # True: this process shares its GPU with other processes / streams (several ranks per GPU): the inner loop must not select the single-read MaxStyle
-    # kernel, whose grid assumes it gets every CU (engine.shared_device).  None: the MS_SHARED_DEVICE environment switch decides (default off).
+    # kernel, whose grid assumes it gets every CU (engine.shared_device).  None: EngineOptions.shared_device (MS_SHARED_DEVICE; default off).
     loop_shared_device = None
     # "sync": a spin time-out of the single-read kernel raises MaxStyleHipError from the call that produced the invalid image (one event wait per call);
-    # "deferred": the check is resolved by the next call / optimize_all_params / evaluate / save_model (no host stall on the hot path).  MS_ERROR_CHECK sets the default.
+    # "deferred": the check is resolved by the next call / optimize_all_params / evaluate / save_model (no host stall on the hot path).  None = "sync".
     loop_error_check = None
-    loop_mfma_bf16 = None      # with bf16 storage: also bf16 matrix arithmetic in the 3x3 stride-1 convs (engine.mfma_bf16; MS_MFMA_DTYPE=bf16)
+    loop_mfma_bf16 = None      # with bf16 storage: also bf16 matrix arithmetic in the 3x3 stride-1 convs (engine.mfma_bf16)
+    # EngineOptions (maxstyle_amd/options.py; an object or a dict of its fields) of the engines this solver builds: the inner loop's / the training passes'.  Read when an
+    # engine is built (one per shape): set them before the first call, or call `drop_engines()`.
+    loop_options = None
+    train_options = None
+
+    def drop_engines(self):
+        """Forget every engine (their buffers and captured graphs); the next call builds new ones with the current loop_options / train_options."""
+        self._engines = {}
+        self._train_engines = {}
 
     def _loop_engine(self, B, H, W, dev, act_dtype=torch.float32, mfma_bf16=False):
         key = self._weights_key()
@@ -301,7 +310,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
         ek = (B, H, W, str(dev)) if act_dtype == torch.float32 else (B, H, W, str(dev), str(act_dtype), mfma_bf16)
         eng = self._engines.get(ek)
         if eng is None:
-            eng = E.InnerLoopEngine(spec, B, H, W, dev, act_dtype=act_dtype, mfma_bf16=mfma_bf16)
+            eng = E.InnerLoopEngine(spec, B, H, W, dev, act_dtype=act_dtype, mfma_bf16=mfma_bf16, options=self.loop_options)
             eng.set_nets(self._packed)
             self._engines[ek] = eng
         return eng
@@ -349,12 +358,8 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                     raise ValueError('loss type {} not supported'.format(ltype))
             code = image_code.detach().contiguous().float()
             B, _, h, w = code.shape
-            act = self.loop_act_dtype
-            if act is None:
-                act = torch.bfloat16 if os.environ.get("MS_ACT_DTYPE", "").lower() in ("bf16", "bfloat16") else torch.float32
-            mf = self.loop_mfma_bf16
-            if mf is None:
-                mf = os.environ.get("MS_MFMA_DTYPE", "").lower() in ("bf16", "bfloat16")
+            act = self.loop_act_dtype or torch.float32
+            mf = bool(self.loop_mfma_bf16)
             eng = self._loop_engine(B, h * 16, w * 16, code.device, act_dtype=act, mfma_bf16=mf)
             if self.loop_shared_device is not None:
                 eng.shared_device = bool(self.loop_shared_device)
@@ -383,7 +388,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             steps = n_iter if optimize else 0
             recon_image = eng.run(code, labels, steps, use_graph=use_graph)
             eng.stash_config(sig)
-            mode = self.loop_error_check or os.environ.get("MS_ERROR_CHECK", "sync")
+            mode = self.loop_error_check or "sync"
             eng.check_errors(sync=(mode != "deferred"))                 # the single-read MaxStyle kernel's error word (spin time-out): never silent
             with torch.no_grad():                                  # hand the optimised state back to the modules (debugging / tests)
                 for i in layers:
@@ -562,7 +567,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             if not eng.pending:
                 break
         else:
-            eng = T.TrainEngine(spec, B, H, W, dev)
+            eng = T.TrainEngine(spec, B, H, W, dev, options=self.train_options)
             eng.pending = False
             pool.append(eng)
         eng.nets = self._packed
@@ -708,6 +713,10 @@ class _TrainPassFn(torch.autograd.Function):
         eng.run_forward(x, labels, clean, track, bns)
         eng.pending = True
         ctx.solver, ctx.eng = solver, eng
+        # an output that takes no part in the caller's loss arrives in backward() as None, not as a materialised zero tensor: its branch of the backward pass is skipped
+        # (a device-side 0 would still run it with scale 0, and 0 * inf of a diverged activation would put NaN into the ParamBank where the reference contributes
+        # nothing - ADVICE r4).  A tensor-valued 0 the caller multiplies in itself still runs the branch.
+        ctx.set_materialize_grads(False)
         out = eng.loss_buf[:2].clone()
         return out[0], out[1]
 

@@ -107,8 +107,8 @@ class TrainEngine(InnerLoopEngine):
     """One forward/backward of the segmentation + reconstruction training pass.  Activations stay in this engine's buffers until
     `backward_pass`; use one TrainEngine per pass that is alive at the same time (standard pass, hard-example pass)."""
 
-    def __init__(self, spec: NetSpec, B: int, H: int, W: int, device):
-        super().__init__(spec, B, H, W, device)
+    def __init__(self, spec: NetSpec, B: int, H: int, W: int, device, options=None):
+        super().__init__(spec, B, H, W, device, options=options)
         self.loss_sign = 1.0
         self.bank: Optional[ParamBank] = None
         self.bn_affine_grad = True       # False inside _disable_tracking_bn_stats (hard-example pass): BatchNorm weight/bias are constants
@@ -119,8 +119,8 @@ class TrainEngine(InnerLoopEngine):
         self._run_desc = {}
         # optional: from its third use on, a pass is ONE HIP-graph replay (first use allocates, second is captured).  Measured at C2: 29.5 vs 29.8 ms
         # per trainer iteration - the ~230 launches of a pass are not host-bound (4.5 ms of kernels in 6 ms of wall, the rest is launch boundaries
-        # that a graph has too), so it is off by default (MS_TRAIN_GRAPH=1 turns it on).
-        self.graph_passes = os.environ.get("MS_TRAIN_GRAPH", "0") != "0"
+        # that a graph has too), so it is off by default (EngineOptions.train_graph turns it on).
+        self.graph_passes = bool(self.options.train_graph)
         self._pgraphs = {}
         self.configure_styles([], {})
 
@@ -293,7 +293,7 @@ class TrainEngine(InnerLoopEngine):
             return self._replayed(key, lambda: self.backward_pass(xi, li, ci, g_seg, g_rec))
         if not self.graph_passes or self.enc_mix is not None:
             return self.backward_pass(xi, li, ci, g_seg, g_rec)
-        key = ("bwd", float(g_seg), float(g_rec), bool(self.bn_affine_grad), id(self.nets), id(self.bank))
+        key = ("bwd", None if g_seg is None else float(g_seg), None if g_rec is None else float(g_rec), bool(self.bn_affine_grad), id(self.nets), id(self.bank))
         self._replayed(key, lambda: self.backward_pass(xi, li, ci, g_seg, g_rec))
 
     # ------------------------------------------------------------------ forward

@@ -30,3 +30,11 @@ def ref_params_at(g, step, layers, initial):
     if step == 0:
         return {n: initial[n] for n in style_names(layers)}
     return {n: g[f"step{step}.param.{n}"] for n in style_names(layers)}
+
+
+def set_engine_default(monkeypatch, field, value):
+    """Scoped change of an EngineOptions DEFAULT (maxstyle_amd/options.py) for engines built inside helpers that take no options argument: what
+    `MS_OPTIONS=engine.<field>=<value>` does for a whole process, undone by monkeypatch at the end of the test."""
+    from maxstyle_amd import options as O
+    assert field in O._FIELDS, field
+    monkeypatch.setitem(O._engine_defaults, field, value)

@@ -31,7 +31,7 @@ def test_every_entry_point_is_tagged_stable_or_internal():
     """the header marks which entry points are the stable operator surface and which are engine-private fusions with preconditions."""
     text = open(os.path.join(ROOT, "include", "maxstyle_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    decl = re.findall(r"^(MS_STABLE|MS_INTERNAL)?\s*(?:int|size_t|const char\*)\s+(ms_[a-z0-9_]+)\s*\(", text, flags=re.M)
+    decl = re.findall(r"^(MS_STABLE|MS_INTERNAL)?\s*(?:int|size_t|long long|const char\*)\s+(ms_[a-z0-9_]+)\s*\(", text, flags=re.M)
     assert len(decl) == len(_header_symbols())
     untagged = [n for t, n in decl if not t]
     assert not untagged, untagged

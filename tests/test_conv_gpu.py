@@ -132,20 +132,6 @@ def test_bn_backward_chain(dev, N, C, H, W):
     da = ops.conv2d(g, ops.pack_conv_weight_dgrad(w.to(dev)), None, C, 3, 1, pro_mode=2, pro_a=ops.coef_ptrs(bc)[0], pro_b=ops.coef_ptrs(bc)[1],
                     pro_c=ops.coef_ptrs(bc)[2], pro_cstride=4, in2=ug)
     assert rel(da, ar.grad) < 2e-5
-    # pro_mode 3: the data-gradient conv derives the same coefficients itself from the partial sums (no ms_bn_bwd_coefs launch)
-    bc3 = torch.full((C, 4), float("nan"), device=dev)
-    da3 = ops.conv2d(g, ops.pack_conv_weight_dgrad(w.to(dev)), None, C, 3, 1, pro_mode=3, pro_a=part, pro_b=coef, pro_c=bc3, pro_nstride=nparts, pro_cstride=4, in2=ug)
-    assert rel(bc3[:, :3], bc[:, :3]) < 1e-6 and float(bc3[:, 3].abs().max()) == 0.0
-    assert rel(da3, da) < 1e-6
-    # one-launch form (last workgroup of a channel finalises the coefficients), run twice: the counters re-arm themselves
-    from maxstyle_amd._lib import lib, check
-    arrive = torch.zeros(64, dtype=torch.int32, device=dev)
-    for _ in range(2):
-        gq = dout.to(dev).clone(); bc2 = torch.empty(C, 4, device=dev); part2 = torch.empty(C, nparts, 2, device=dev)
-        check(lib.ms_act_bwd_bn(gq.data_ptr(), og.data_ptr(), ug.data_ptr(), coef.data_ptr(), gq.data_ptr(), part2.data_ptr(), arrive.data_ptr(),
-                                bc2.data_ptr(), N, C, H * W, 0.2, torch.cuda.current_stream().cuda_stream), "ms_act_bwd_bn")
-        assert rel(bc2[:, :3], bc[:, :3]) < 1e-6 and torch.equal(gq, g)
-        assert int(arrive.abs().sum()) == 0
     # un-materialised activation: mask from coef*u+shift
     z2 = F.leaky_relu(F.batch_norm(u.detach(), None, None, gamma.double(), beta.double(), True, 0.0, 1e-5), 0.2)
     g2, _, _ = ops.act_bwd_reduce(dout.to(dev), None, ug, coef, 0.2)
@@ -219,7 +205,7 @@ WIDE_CASES = [
 @pytest.mark.parametrize("N,Cin,Cout,H,W", WIDE_CASES)
 def test_wide_kernel_all_modes(dev, N, Cin, Cout, H, W):
     """The wide-read 3x3 kernel: plain forward + BatchNorm statistics, BN-apply prologue, BN-backward two-tensor prologue, accumulate
-    epilogue - each against fp64 math, and against the first-generation kernel (MS_CONV_WIDE=0 is the A/B switch for timing only)."""
+    epilogue - each against fp64 math, and against the first-generation kernel (library option "conv.wide" = 0 is the A/B switch for timing only)."""
     from maxstyle_amd import ops
     x = _rand((N, Cin, H, W), 11); w = _rand((Cout, Cin, 3, 3), 12, 0.1); b = _rand((Cout,), 13)
     wp = ops.pack_conv_weight(w.to(dev))
@@ -284,44 +270,6 @@ def test_conv_actbwd_epilogue(dev, N, Cin, Cout, H, W, ks):
         be = -cc[:, 0] * (s2 * cc[:, 3] / cnt) * cc[:, 3]
         ref_bc = torch.stack([cc[:, 0], be, -cc[:, 0] * s1 / cnt - be * cc[:, 2]], 1)
         assert rel(bc_f[:, :3], ref_bc) < 1e-4
-
-
-@pytest.mark.parametrize("N,Cin,Cout,H,W,ks,stride", [
-    (2, 16, 16, 64, 64, 3, 1), (1, 32, 48, 20, 192, 3, 1), (2, 64, 64, 64, 64, 3, 1), (1, 8, 33, 7, 100, 3, 1),      # wide-read kernel
-    (2, 16, 16, 32, 32, 3, 1), (4, 128, 128, 8, 8, 3, 1), (1, 20, 24, 9, 70, 3, 1), (2, 24, 40, 6, 10, 3, 1),        # first-generation kernel
-    (2, 32, 16, 12, 20, 1, 1), (2, 16, 32, 32, 32, 3, 2), (16, 16, 16, 128, 128, 3, 1),                               # 1x1, stride 2, a full grid (512 workgroups)
-])
-def test_last_workgroup_finalises(dev, N, Cin, Cout, H, W, ks, stride):
-    """ms_conv2d_fin / ms_conv2d_actbwd_fin: the coefficients written by the last workgroup equal ms_bn_finalize / ms_bn_bwd_coefs on the same
-    table; the counter re-arms itself (three launches in a row), the tensors are bit-identical to the unfused launches."""
-    from maxstyle_amd import ops
-    x = _rand((N, Cin, H, W), 31); w = _rand((Cout, Cin, ks, ks), 32, 0.1); b = _rand((Cout,), 33)
-    gamma = (1 + 0.1 * _rand((Cout,), 34)).to(dev); beta = (0.1 * _rand((Cout,), 35)).to(dev)
-    wp = ops.pack_conv_weight(w.to(dev))
-    Ho, Wo = ops.conv_out_hw(H, W, ks, stride, 0)
-    stats, parts = ops.conv_stats_buffer(N, Cout, Ho, Wo, dev)
-    ref_out = ops.conv2d(x.to(dev), wp, b.to(dev), Cout, ks, stride, stats=stats)
-    ref_coef = ops.bn_finalize(stats, parts, gamma, beta)
-    counter = torch.zeros(1, dtype=torch.int32, device=dev)
-    for _ in range(3):
-        out, coef = ops.conv2d_fin(x.to(dev), wp, b.to(dev), Cout, ks, gamma, beta, counter, stride=stride)
-        assert torch.equal(out, ref_out)
-        assert rel(coef, ref_coef) < 1e-6, float((coef - ref_coef).abs().max())
-        assert int(counter) == 0
-    # against fp64 math
-    y = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=ks // 2)
-    mean = y.mean((0, 2, 3)); invstd = 1 / torch.sqrt(y.var((0, 2, 3), unbiased=False) + 1e-5)
-    assert rel(coef[:, 2], mean) < 1e-5 and rel(coef[:, 3], invstd) < 1e-5
-    if stride == 1:
-        g = _rand((N, Cin, H, W), 36); u = _rand((N, Cout, H, W), 37) + 0.3
-        fc = torch.stack([1 + 0.2 * _rand((Cout,), 38), 0.3 * _rand((Cout,), 39), 0.3 + 0.1 * _rand((Cout,), 40), 1 + 0.1 * _rand((Cout,), 41).abs()], 1).to(dev)
-        gm, tab = ops.conv2d_actbwd(g.to(dev), wp, Cout, ks, u.to(dev), fc, 0.2)
-        ref_bc = ops.bn_bwd_coefs(tab, 0, fc, N * H * W)
-        for _ in range(3):
-            gm2, bc = ops.conv2d_actbwd_fin(g.to(dev), wp, Cout, ks, u.to(dev), fc, 0.2, counter)
-            assert torch.equal(gm2, gm)
-            assert float((bc - ref_bc).abs().max()) <= 1e-6 * float(ref_bc.abs().max()), float((bc - ref_bc).abs().max())
-            assert int(counter) == 0
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W,up2", [(2, 16, 16, 32, 32, 0), (2, 16, 32, 64, 64, 0), (1, 5, 7, 9, 11, 0), (2, 128, 64, 16, 16, 0), (3, 64, 32, 8, 24, 0),
@@ -503,13 +451,13 @@ def test_stride2_conv_second_generation(dev, N, Cin, Cout, H, W):
         out = torch.full((N, Cout, Ho, Wo), float("nan"), device=dev)
         check(lib.ms_conv2d(x.data_ptr(), 0, out.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, 3, 2, 0, 0, 0, 0, 0, 0, 1, 1.0, 0, 0, st), "ms_conv2d(s2)")
         return out
-    was = lib.ms_conv_s2g2_enable(1)
+    was = lib.ms_set_option(b"conv.s2g2", 1)
     try:
         new = run()
-        lib.ms_conv_s2g2_enable(0)
+        lib.ms_set_option(b"conv.s2g2", 0)
         old = run()
     finally:
-        lib.ms_conv_s2g2_enable(was)
+        lib.ms_set_option(b"conv.s2g2", was)
     assert rel(old, ref) < 3e-6
     assert rel(new, ref) < 3e-6
     assert rel(new, old) < 2e-6
@@ -542,10 +490,10 @@ def test_small_cout_conv(dev, N, Cin, Cout, H, W, pro):
 
 
 def test_wide_kernel_8_row_tiles_in_a_subprocess():
-    """The 8-row-tile variant of the wide kernel (two output rows per MFMA wave) is selected by MS_CONV_WIDE_ROWS=8, which the library reads once per
-    process: run the wide-kernel and activation-backward cases in a child process with the switch set."""
+    """The 8-row-tile variant of the wide kernel (two output rows per MFMA wave) is selected by the library option "conv.wide_rows" = 8: run the wide-kernel and
+    activation-backward cases in a child process started with that option (the MS_OPTIONS harness hook of maxstyle_amd/options.py)."""
     import os, subprocess, sys
-    env = dict(os.environ, MS_CONV_WIDE_ROWS="8")
+    env = dict(os.environ, MS_OPTIONS="conv.wide_rows=8")
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_conv_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
                         "wide_kernel_all_modes or conv_actbwd_epilogue or batch_stats_and_prologue or bn_backward_chain"], env=env, capture_output=True, text=True, timeout=900)

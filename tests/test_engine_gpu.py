@@ -261,8 +261,8 @@ def test_single_read_kernel_under_graph_replay_with_foreign_work(dev):
     also when unrelated work touches the GPU between the calls."""
     from maxstyle_amd._lib import lib
     from oracle import maxstyle_oracle as orc
-    if os.environ.get("MS_STYLE_FUSED") == "0":
-        pytest.skip("the single-read kernel is switched off (MS_STYLE_FUSED=0)")
+    if lib.ms_get_option(b"style.fused") == 0:
+        pytest.skip("the single-read kernel is switched off (library option style.fused = 0)")
     layers = [3, 4, 5]
     eng, W, img, lab, styles = build_engine(dev, orc.NetSpec(4, 1, 4), 16, 256, layers)
     z_i, _ = eng.encode_fwd(img.to(dev))

@@ -46,13 +46,13 @@ def test_random_stride2(dev, N, Cin, Cout, H, W):
         out = torch.full(tuple(ref.shape), float("nan"), device=dev)
         check(lib.ms_conv2d(x.data_ptr(), 0, out.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, 3, 2, 0, 0, 0, 0, 0, 0, 1, 1.0, 0, 0, st), "ms_conv2d(s2)")
         return out
-    was = lib.ms_conv_s2g2_enable(1)
+    was = lib.ms_set_option(b"conv.s2g2", 1)
     try:
         new = run()
-        lib.ms_conv_s2g2_enable(0)
+        lib.ms_set_option(b"conv.s2g2", 0)
         old = run()
     finally:
-        lib.ms_conv_s2g2_enable(was)
+        lib.ms_set_option(b"conv.s2g2", was)
     assert rel(new, ref) < 3e-6 and rel(old, ref) < 3e-6 and rel(new, old) < 2e-6
 
 
@@ -102,13 +102,13 @@ def test_random_gemm_1x1(dev, N, Cin, Cout, H, W):
         t = torch.full_like(a, float("nan"))
         check(lib.ms_conv1x1_bnres(x.data_ptr(), t.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, u.data_ptr(), coef.data_ptr(), 0.2, 0, st), "ms_conv1x1_bnres")
         return a, t
-    was = lib.ms_conv_k1g_enable(1)
+    was = lib.ms_set_option(b"conv.k1g", 1)
     try:
         new = run()
-        lib.ms_conv_k1g_enable(0)
+        lib.ms_set_option(b"conv.k1g", 0)
         old = run()
     finally:
-        lib.ms_conv_k1g_enable(was)
+        lib.ms_set_option(b"conv.k1g", was)
     assert rel(new[0], ref) < 3e-6
     assert torch.equal(new[0], old[0]) and torch.equal(new[1], old[1])
 
@@ -131,13 +131,13 @@ def test_random_streaming_1x1(dev, N, Cin, Cout, H, W):
         t = torch.full_like(a, float("nan"))
         check(lib.ms_conv1x1_bnres(x.data_ptr(), t.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, u.data_ptr(), coef.data_ptr(), 0.2, 0, st), "ms_conv1x1_bnres")
         return a, t
-    was = lib.ms_conv_k1s_enable(1)
+    was = lib.ms_set_option(b"conv.k1s", 1)
     try:
         new = run()
-        lib.ms_conv_k1s_enable(0)
+        lib.ms_set_option(b"conv.k1s", 0)
         old = run()
     finally:
-        lib.ms_conv_k1s_enable(was)
+        lib.ms_set_option(b"conv.k1s", was)
     assert torch.equal(new[0], old[0]) and torch.equal(new[1], old[1])
     ref = F.conv2d(x.cpu().double(), w.double(), b.double())
     assert rel(new[0], ref) < 3e-6

@@ -29,9 +29,9 @@ def dev():
 @pytest.fixture
 def k1s():
     from maxstyle_amd._lib import lib
-    was = lib.ms_conv_k1s_enable(1)
+    was = lib.ms_set_option(b"conv.k1s", 1)
     yield lib
-    lib.ms_conv_k1s_enable(was)
+    lib.ms_set_option(b"conv.k1s", was)
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W", SHAPES)
@@ -60,11 +60,11 @@ def test_streaming_1x1_same_bits_as_tiled(dev, k1s, N, Cin, Cout, H, W):
         return out
     if Cin >= 64:
         assert lib.ms_conv_k1s_would_run(N, Cin, H, W, Cout, 0) == 1 and lib.ms_conv_k1s_would_run(N, Cin, H, W, Cout, 4) == 1, "this shape is meant to be streamed"
-    lib.ms_conv_k1s_enable(1)
+    lib.ms_set_option(b"conv.k1s", 1)
     a0, a1, a2 = plain(), tail(0), tail(1)
-    lib.ms_conv_k1s_enable(0)
+    lib.ms_set_option(b"conv.k1s", 0)
     b0, b1, b2 = plain(), tail(0), tail(1)
-    lib.ms_conv_k1s_enable(1)
+    lib.ms_set_option(b"conv.k1s", 1)
     assert rel(a0, ref) < 3e-6
     assert torch.equal(a0, b0) and torch.equal(a1, b1) and torch.equal(a2, b2)
     # the residual tail against its definition
@@ -133,11 +133,11 @@ def test_streaming_1x1_conv_transpose_gemm_same_bits(dev, k1s, N, Cin, Cout, H, 
         out = torch.full((N, Cout, 2 * H, 2 * W), float("nan"), device=dev)
         check(lib.ms_conv2d(x.data_ptr(), 0, out.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1.0, 2, 0, st), "ms_conv2d(epi 2)")
         return out
-    lib.ms_conv_k1s_enable(1)
+    lib.ms_set_option(b"conv.k1s", 1)
     a = run()
-    lib.ms_conv_k1s_enable(0)
+    lib.ms_set_option(b"conv.k1s", 0)
     t = run()
-    lib.ms_conv_k1s_enable(1)
+    lib.ms_set_option(b"conv.k1s", 1)
     assert rel(a, ref) < 3e-6
     assert torch.equal(a, t)
 
@@ -184,13 +184,13 @@ def test_lds_tiled_1x1_gemm_same_bits_as_tiled(dev, N, Cin, Cout, H, W):
         up = torch.full_like(u2, float("nan"))
         check(lib.ms_conv1x1_bnres(x.data_ptr(), up.data_ptr(), wp.data_ptr(), bd.data_ptr(), N, Cin, H, W, Cout, u2.data_ptr(), coef.data_ptr(), 0.2, 1, st), "ms_conv1x1_bnres(up2)")
         return plain, tail, xt, coef2, rid, out4, up
-    was = lib.ms_conv_k1g_enable(1)
+    was = lib.ms_set_option(b"conv.k1g", 1)
     try:
         new = run_all()
-        lib.ms_conv_k1g_enable(0)
+        lib.ms_set_option(b"conv.k1g", 0)
         old = run_all()
     finally:
-        lib.ms_conv_k1g_enable(was)
+        lib.ms_set_option(b"conv.k1g", was)
     assert rel(new[0], ref) < 3e-6
     for a_, b_, what in zip(new, old, ("plain", "tail", "xfin tail", "xfin records", "rider conv", "rider records", "half-resolution tail")):
         assert torch.equal(a_, b_), what

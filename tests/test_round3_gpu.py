@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import r3_cases as R
-from parity_util import rel
+from parity_util import rel, set_engine_default
 
 pytestmark = pytest.mark.gpu
 
@@ -25,7 +25,7 @@ def test_headline_config_vs_reference_run(dev, monkeypatch, winograd):
     training step) against the reference's fp64 run of the same call (advanced_triplet...py:539-571; tests/golden/loop_full_c2.npz):
     image error <= 2x the reference's OWN fp32 error (max and rms; measured 1.1-1.3x / 0.9-1.0x), labels >= 99.99 % equal, Dice within 1e-3,
     with the Winograd form of the wide convolutions (the benchmarked default) and with the direct form."""
-    monkeypatch.setenv("MS_LOOP_WINOGRAD", winograd)
+    set_engine_default(monkeypatch, "winograd", winograd == "1")
     r = R.full_size_case(dev)
     assert r["winograd"] == (winograd == "1")
     assert r["z_i_rel"] < 5e-6
@@ -85,7 +85,7 @@ def test_all_six_layers_on_trained_network_vs_reference_run(dev, monkeypatch, wi
     So a run is held to the tight bars when its own forward has that element on the reference's side (the direct form, by default) and to the size of one such event
     when it has it on the other (the Winograd form; a few non-default switches move the direct form across too: tools/test_switches.sh), and
     test_all_six_layers_conv_forms_differ_at_kink_elements_only pins that this IS the whole difference between the forms."""
-    monkeypatch.setenv("MS_LOOP_WINOGRAD", wino)
+    set_engine_default(monkeypatch, "winograd", wino == "1")
     # which side of the kink THIS run's forward lands on is an observable of the run: one step, then the pre-activation of that element (the reference: +3.0e-6)
     monkeypatch.setitem(R.ARG_CALLS, "all6", dict(n_iter=1))
     S1 = R.trained_solver(dev, "trained_fcn16.npz")
@@ -128,7 +128,7 @@ def test_all_six_layers_conv_forms_differ_at_kink_elements_only(dev, monkeypatch
     monkeypatch.setitem(R.ARG_CALLS, "all6", dict(n_iter=1))
     bufs = {}
     for wino in ("1", "0"):
-        monkeypatch.setenv("MS_LOOP_WINOGRAD", wino)
+        set_engine_default(monkeypatch, "winograd", wino == "1")
         S = R.trained_solver(dev, "trained_fcn16.npz")
         R.arg_case(dev, "all6", S)
         eng = next(iter(S._engines.values()))
@@ -193,7 +193,7 @@ def test_fused_step_tail_is_bit_identical(dev, monkeypatch, variant):
     to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
     outs = []
     for fuse in ("1", "0"):
-        monkeypatch.setenv("MS_FUSE_TAIL", fuse)
+        set_engine_default(monkeypatch, "fuse_tail", fuse == "1")
         spec = E.NetSpec(4, 1, 4)
         eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1)
         assert eng.fuse_tail == (fuse == "1")
@@ -301,7 +301,7 @@ def _switch_ab(dev, monkeypatch, case, env, attr, layers=(3, 4, 5), decoder_kind
     layers = list(layers)
     outs = []
     for flag in ("1", "0"):
-        monkeypatch.setenv(env, flag)
+        set_engine_default(monkeypatch, attr, flag == "1")
         spec = E.NetSpec(*net)
         eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1, act_dtype=act)
         assert getattr(eng, attr) == (flag == "1")
@@ -343,7 +343,7 @@ def test_cross_workgroup_finalize_is_bit_identical(dev, monkeypatch, case):
     ms_bn_finalize / ms_bn_bwd_coefs launch in front of it) against the separate launches: same bits in the
     image, the losses and the parameters after K steps, eager and through the captured graph; the error word stays clear; and the coefficient records the
     launch leaves for later kernels are the ones ms_bn_finalize writes."""
-    outs = _switch_ab(dev, monkeypatch, case, "MS_XFIN", "xfin")
+    outs = _switch_ab(dev, monkeypatch, case, "xfin", "xfin")
     eng = outs[0][2]
     assert "xfin.err" in eng.buf and int(eng.buf["xfin.err"].item()) == 0
     assert any(k.endswith(".gran") for k in eng.buf)
@@ -356,7 +356,7 @@ def test_rider_coefficient_jobs_are_bit_identical(dev, monkeypatch, case):
     ~5 us launch of its own) against the separate launches: same bits everywhere, including every coefficient record; and the launches really went away."""
     import maxstyle_amd._lib as L
     real_ride, real_coefs, real_fin = L.lib.ms_conv2d_ride, L.lib.ms_bn_bwd_coefs, L.lib.ms_bn_finalize
-    outs = _switch_ab(dev, monkeypatch, case, "MS_RIDE", "ride")
+    outs = _switch_ab(dev, monkeypatch, case, "ride", "ride")
     _same_bits(outs)
     # launch counts of one eager step with the switch on / off (the engine of each setting is still alive)
     counts = []
@@ -393,7 +393,7 @@ def test_head_backward_fused_into_layer4_is_bit_identical(dev, monkeypatch, net,
     B, size = 4, 64
     outs = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("MS_FUSE_HEAD_BWD", flag)
+        set_engine_default(monkeypatch, "fuse_head_bwd", flag == "1")
         spec = E.NetSpec(*net)
         eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1)
         assert eng.fuse_head_bwd == (flag == "1")
@@ -411,36 +411,6 @@ def test_head_backward_fused_into_layer4_is_bit_identical(dev, monkeypatch, net,
         assert torch.equal(a, b)
 
 
-def test_three_way_split_mode_vs_fp64(dev):
-    """MS_FETCH_X3 (ms_f32x3 mode of the wide conv kernel: operands split into three bf16 numbers, six leading products on v_mfma_f32_16x16x16_bf16, fp32
-    accumulation) is fp32-FAITHFUL: against fp64 it holds the bars of the fp32 forms (tests/test_wino_gpu.py) on every prologue / epilogue combination.
-    An experiment of round 3 (2x slower than the Winograd form: profiles/r03_experiments.txt section 8) - opt-in only, used by nothing."""
-    import torch.nn.functional as F
-    from maxstyle_amd import ops
-    rnd = lambda shape, seed, scale=1.0: torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
-    err = lambda o, r: float((o.cpu().double() - r).abs().max() / r.abs().max())
-    for (N, Cin, Cout, H, W) in [(2, 16, 16, 64, 64), (1, 32, 48, 20, 192), (2, 64, 64, 64, 64), (1, 8, 33, 10, 100), (2, 16, 16, 6, 72)]:
-        x = rnd((N, Cin, H, W), 1) * 0.7 + 0.5; x2 = rnd((N, Cin, H, W), 2); w = rnd((Cout, Cin, 3, 3), 3, 0.1); b = rnd((Cout,), 4)
-        cf = rnd((Cin, 4), 5); cfd = cf.to(dev)
-        a, bb, cc = (cf[:, i].double().view(1, -1, 1, 1) for i in range(3))
-        wp = ops.pack_conv_weight(w.to(dev))
-        xd, x2d = x.to(dev), x2.to(dev)
-        stats, parts = ops.conv_stats_buffer(N, Cout, H, W, dev)
-        out = ops.conv2d(xd, wp, b.to(dev), Cout, 3, 1, fetch=ops.FETCH_X3, stats=stats)
-        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
-        assert err(out, ref) < 2e-6, (N, Cin, Cout, H, W)
-        direct = ops.conv2d(xd, wp, b.to(dev), Cout, 3, 1)
-        assert not torch.equal(out, direct), "the call must have taken the three-way split mode (not bit-identical to the fp32 chain)"
-        coef = ops.bn_finalize(stats, parts, torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)).cpu().double()
-        assert float((coef[:, 2] - ref.mean((0, 2, 3))).abs().max()) < 1e-6
-        pa, pb, pc = ops.coef_ptrs(cfd)
-        o1 = ops.conv2d(xd, wp, None, Cout, 3, 1, fetch=ops.FETCH_X3, pro_mode=1, pro_a=pa, pro_b=pb, pro_cstride=4, slope=0.2)
-        assert err(o1, F.conv2d(F.leaky_relu(a * x.double() + bb, 0.2), w.double(), None, padding=1)) < 3e-6
-        base = rnd((N, Cout, H, W), 6)
-        o2 = ops.conv2d(xd, wp, None, Cout, 3, 1, fetch=ops.FETCH_X3, pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=x2d, epi_mode=1, out=base.to(dev).clone())
-        assert err(o2, F.conv2d(a * x.double() + bb * x2.double() + cc, w.double(), None, padding=1) + base.double()) < 3e-6
-
-
 @pytest.mark.parametrize("net,act", [((4, 1, 4), None), ((1, 3, 2), None), ((4, 1, 4), torch.bfloat16)])
 def test_lazy_segmentation_tail_is_bit_identical(dev, monkeypatch, net, act):
     """ms_head_ce_tail (the segmentation head forms the output of the decoder's last residual block itself from u2, its BatchNorm record and the half-resolution
@@ -454,9 +424,9 @@ def test_lazy_segmentation_tail_is_bit_identical(dev, monkeypatch, net, act):
     outs = []
     # (the row mapping of ms_head_ce_tail is the bit-identical one; with MS_POOL_FUSE it owns 2x2 quads and groups the BatchNorm-backward sums differently:
     #  test_pooled_gradient_from_the_producers)
-    monkeypatch.setenv("MS_POOL_FUSE", "0")
+    set_engine_default(monkeypatch, "pool_fuse", False)
     for flag in ("1", "0"):
-        monkeypatch.setenv("MS_LAZY_SEG_TAIL", flag)
+        set_engine_default(monkeypatch, "lazy_seg_tail", flag == "1")
         spec = E.NetSpec(*net)
         eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1, act_dtype=act)
         assert eng.lazy_seg_tail == (flag == "1")
@@ -499,7 +469,7 @@ def test_pooled_gradient_from_the_producers(dev, monkeypatch, case):
     layers = [3, 4, 5]
     outs = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("MS_POOL_FUSE", flag)
+        set_engine_default(monkeypatch, "pool_fuse", flag == "1")
         spec = E.NetSpec(*net)
         eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1, act_dtype=act)
         assert eng.pool_fuse == (flag == "1")
@@ -556,7 +526,7 @@ def test_pooled_epilogue_is_conv_plus_pool2_sum(dev, shape, act):
 def test_pooled_data_gradient_in_the_loop(dev, monkeypatch, case):
     """MS_POOL_EPI (the up-sampling blocks' first data-gradient conv stores 2x2 sums; ms_add_actbwd behind it) against the full-resolution gradient + pooling
     pass: same bits in fp32 storage (bf16: the pooled sum is rounded once more on its way through memory)."""
-    outs = _switch_ab(dev, monkeypatch, case, "MS_POOL_EPI", "pool_epi")
+    outs = _switch_ab(dev, monkeypatch, case, "pool_epi", "pool_epi")
     assert any(k.endswith(".dlo") for k in outs[0][2].buf) and not any(k.endswith(".dlo") for k in outs[1][2].buf)
     if case != "bf16":
         _same_bits(outs)
@@ -570,7 +540,7 @@ def test_pooled_data_gradient_in_the_loop(dev, monkeypatch, case):
 def test_style_layer_in_front_of_the_head_is_never_written(dev, monkeypatch, case):
     """MS_LAZY_STYLE_HEAD: layer 4's kernel leaves statistics and coefficients only (ms_style_fwd with y = NULL), the image head applies y = A/sig (x - mu) + S per
     element itself (ms_head_fwd_styled) - against the materialised layer output: same bits (fp32 and bf16 storage, 1 and 3 image channels)."""
-    outs = _switch_ab(dev, monkeypatch, case, "MS_LAZY_STYLE_HEAD", "lazy_style_head")
+    outs = _switch_ab(dev, monkeypatch, case, "lazy_style_head", "lazy_style_head")
     assert "st4.y" not in outs[0][2].buf and "st4.y" in outs[1][2].buf
     _same_bits(outs)
 

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from parity_util import set_engine_default
+
 import r4_cases as R4
 
 pytestmark = pytest.mark.gpu
@@ -23,7 +25,7 @@ def test_config4_at_size_vs_reference_run(dev, monkeypatch, winograd):
     tests/golden/loop_full_c4.npz).  The criteria config 2 got in round 3: image error <= 2x the reference's OWN fp32-vs-fp64 error (max and rms), per-step
     losses <= max(5x the reference's worst error up to the step, 3e-5), final parameters <= 3x its worst, labels >= 99.99 % equal, Dice within 1e-3 - with the Winograd
     form of the wide convolutions (one and two channel blocks per staged tile, as the dispatch picks them) and with the direct form."""
-    monkeypatch.setenv("MS_LOOP_WINOGRAD", winograd)
+    set_engine_default(monkeypatch, "winograd", winograd == "1")
     r = R4.c4_full_case(dev)
     assert r["winograd"] == (winograd == "1") and r["K"] == 10
     assert r["z_i_rel"] < 5e-6
@@ -212,7 +214,7 @@ def test_fused_finalize_and_activation_is_bit_identical(dev, monkeypatch, net, a
     B, size, layers = 4, 64, [3, 4, 5]
     outs = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("MS_FUSE_FINACT", flag)
+        set_engine_default(monkeypatch, "fuse_fin_act", flag == "1")
         spec = E.NetSpec(*net)
         eng = E.InnerLoopEngine(spec, B, size, size, dev, lr=0.1, act_dtype=act)
         assert eng.fuse_fin_act == (flag == "1")

@@ -1,0 +1,104 @@
+"""Round-5 parity tests on the GPU.
+
+* The reference's SHIPPED workloads (config/ACDC/1500_epoch/MICCAI2022_MaxStyle.json: 20x1x192x192; config/Prostate/MICCAI2022_MaxStyle.json: 20x1x224x224, always_use_beta) against
+  runs of the reference's generate_max_style_image at exactly those calls, fp32 + fp64 (tests/golden/make_golden_r5.py shipped), with config 2's criteria and both conv forms.
+* The batched appendix refresh (ms_appendix_batch) against the per-conv launches it replaces: same bits.
+* An unused loss of a training pass contributes nothing (ctx.set_materialize_grads(False))."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import r5_cases as R5
+from parity_util import rel, set_engine_default
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("winograd", [True, False], ids=["winograd", "direct"])
+@pytest.mark.parametrize("which", ["acdc", "prostate"])
+def test_shipped_workload_vs_reference_run(dev, monkeypatch, which, winograd):
+    """The reference's shipped call (20x1x192x192 ACDC / 20x1x224x224 Prostate with always_use_beta, FCN_16, layers [3,4,5], K = 5 free-running; decoder levels of
+    192..12 / 224..14 pixels) through the drop-in solver against the reference's own fp64 run of it (advanced_triplet...py:458-571): config 2's criteria -
+    image error <= 2x the reference's OWN fp32 error (max and rms), per-step losses <= max(5x its error, 5e-6), final parameters <= 3x its worst, labels >= 99.99 % equal,
+    Dice within 1e-3 - with the Winograd form of the wide convolutions (the default) and with the direct form."""
+    set_engine_default(monkeypatch, "winograd", winograd)
+    r = R5.shipped_case(dev, which)
+    assert r["winograd"] == winograd
+    assert r["z_i_rel"] < 5e-6
+    for k, e in r["std_rel"].items():
+        assert e < 2e-5, (k, e)                                        # gamma_std / beta_std frozen by the first forward (maxstyle.py:165-176)
+    assert r["image_max"] <= 2.0 * r["noise_image_max"], (r["image_max"], r["noise_image_max"])
+    assert r["image_rms"] <= 2.0 * r["noise_image_rms"], (r["image_rms"], r["noise_image_rms"])
+    for e, n in zip(r["losses_rel"], r["noise_losses_rel"]):
+        assert e <= max(5.0 * n, 5e-6), (r["losses_rel"], r["noise_losses_rel"])
+    worst_noise = max(r["noise_params_rel"].values())
+    for k, e in r["params_rel"].items():
+        assert e <= 3.0 * worst_noise, (k, e, worst_noise)
+    assert r["labels_equal_f64"] >= 0.9999 and r["clean_labels_equal"] >= 0.9999
+    assert r["dice_abs_diff"] <= 1e-3
+    assert max(abs(a - b) for a, b in zip(r["dice_clean"], r["dice_clean_ref"])) <= 1e-3
+    assert min(r["dice_clean"]) > 0.9 and max(r["dice"]) < 0.4          # a meaningful Dice, and a hard example
+
+
+def test_batched_appendix_refresh_same_bits(dev):
+    """PackedNets.refresh_appendices (ONE ms_appendix_batch launch for every Winograd appendix and sub-pixel sum table of the three sub-nets) against
+    ConvW.refresh_appendix per conv (2-3 launches each): the same bits in every packed buffer, for FCN_16 and FCN_64 widths."""
+    from maxstyle_amd import engine as E, synthetic as syn
+    for net in ((4, 1, 4), (1, 3, 2)):
+        W = syn.procedural_weights(syn.NetSpec(*net), 0)
+        to = lambda sd: {k: v.to(dev) for k, v in sd.items()}
+        nets = E.PackedNets(E.NetSpec(*net), to(W["image_encoder"]), to(W["segmentation_decoder"]), to(W["image_decoder"]))
+        convs = [o for t in (nets.enc, nets.seg, nets.dec) for o in t.values() if isinstance(o, E.ConvW)]
+        for cw in convs[::3]:
+            if cw.kind == "conv" and cw.ks == 3:
+                cw.subpix_sums()                                          # some convs carry a sum table too
+        bufs = lambda: [t for cw in convs for t in (getattr(cw.wp, "_ms_wino_buf", cw.wp), getattr(cw.dwp, "_ms_wino_buf", cw.dwp), cw.ws) if t is not None]
+        ref = [b.clone() for b in bufs()]
+        assert sum(int(cw.wu) + int(cw.dwu) for cw in convs) > 10
+        for b in bufs():                                                  # scribble over every appendix (the taps are the buffers' first bytes: keep them)
+            pass
+        for cw in convs:
+            for view, has in ((cw.wp, cw.wu), (cw.dwp, cw.dwu)):
+                if has:
+                    view._ms_wino_buf[view.numel():].fill_(float("nan"))
+            if cw.ws is not None:
+                cw.ws.fill_(float("nan"))
+        nets.refresh_appendices()
+        torch.cuda.synchronize()
+        for a, b in zip(bufs(), ref):
+            assert torch.equal(a, b)
+        for cw in convs:                                                  # and the per-conv path still produces them
+            cw.refresh_appendix()
+        for a, b in zip(bufs(), ref):
+            assert torch.equal(a, b)
+
+
+def test_unused_loss_of_a_training_pass_contributes_nothing(dev):
+    """loss = seg only (the reconstruction loss takes no part): its upstream gradient arrives in _TrainPassFn.backward as None (set_materialize_grads(False)) and the
+    image-decoder branch is skipped - the image decoder's gradients stay exactly zero even when its activations hold inf (0 * inf would be NaN)."""
+    import maxstyle_amd as M
+    from maxstyle_amd import synthetic as syn
+    S = M.AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard_no_STN", image_ch=1, num_classes=4, use_gpu=True, optimizer_type="AdamW")
+    W = syn.procedural_weights(syn.NetSpec(4, 1, 4), 0)
+    for name, mod in S.model.items():
+        mod.load_state_dict(W[name]); mod.train()
+    img, lab = syn.synthetic_batch(4, 64, 1, 4, seed=5)
+    S.reset_all_optimizers()
+    seg, rec, gt, sh = S.standard_training(img.to(dev), lab.to(dev), perturbed_image=img.to(dev))
+    seg.backward()
+    torch.cuda.synchronize()
+    gdec = [p.grad for p in S.model["image_decoder"].parameters() if p.grad is not None]
+    assert gdec and all(float(g.abs().max()) == 0.0 for g in gdec)
+    genc = [p.grad for p in S.model["segmentation_decoder"].parameters() if p.grad is not None]
+    assert any(float(g.abs().max()) > 0.0 for g in genc)
+    bank = S._param_bank()
+    assert bool(torch.isfinite(bank.flat_g).all())

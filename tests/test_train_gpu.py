@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from parity_util import rel
+from parity_util import rel, set_engine_default
 from test_solver_gpu import make_solver, injector
 
 pytestmark = pytest.mark.gpu
@@ -375,7 +375,7 @@ def test_trainer_loop_soak(dev, graph_passes, monkeypatch):
     cross-workgroup hand-offs of the single-read MaxStyle kernel and of the partial tables only showed their first bug after ~10 iterations.)"""
     import maxstyle_amd as M
     from maxstyle_amd import synthetic as syn
-    monkeypatch.setenv("MS_TRAIN_GRAPH", graph_passes)
+    set_engine_default(monkeypatch, "train_graph", graph_passes == "1")
     torch.manual_seed(0)
     S = M.AdvancedTripletReconSegmentationModel(network_type="FCN_16_standard_no_STN", image_ch=1, num_classes=4, use_gpu=True, optimizer_type="AdamW")
     clean, lab = syn.synthetic_batch(8, 128, 1, 4, 4321)

@@ -9,6 +9,8 @@ import sys
 
 import pytest
 import torch
+
+from parity_util import set_engine_default
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -204,16 +206,17 @@ def test_winograd_bit_is_ignored_where_the_form_is_not_built(dev):
 
 
 def test_which_engines_ask_for_the_winograd_form(dev, monkeypatch):
-    """The inner loop asks for the form (MS_LOOP_WINOGRAD=0 switches it off); the training passes keep the direct form - weight gradients at the reference's fidelity -
-    unless MS_TRAIN_WINOGRAD=1 opts them in (forward / data-gradient convs only; measured in engine.py)."""
+    """The inner loop asks for the form (EngineOptions.winograd = False switches it off); the training passes keep the direct form - weight gradients at the reference's fidelity -
+    unless EngineOptions.train_winograd opts them in (forward / data-gradient convs only; measured in engine.py)."""
     from maxstyle_amd import engine as E
     from maxstyle_amd.train_engine import TrainEngine
-    monkeypatch.delenv("MS_TRAIN_WINOGRAD", raising=False); monkeypatch.delenv("MS_LOOP_WINOGRAD", raising=False)
+    from maxstyle_amd import options as O
+    monkeypatch.delitem(O._engine_defaults, "winograd", raising=False); monkeypatch.delitem(O._engine_defaults, "train_winograd", raising=False)
     assert E.InnerLoopEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev).winograd
     assert not TrainEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev).winograd
-    monkeypatch.setenv("MS_TRAIN_WINOGRAD", "1")
+    set_engine_default(monkeypatch, "train_winograd", True)
     assert TrainEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev).winograd
-    monkeypatch.setenv("MS_LOOP_WINOGRAD", "0")
+    set_engine_default(monkeypatch, "winograd", False)
     assert not E.InnerLoopEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev).winograd
 
 

@@ -1,11 +1,12 @@
 """A/B of the Winograd form's channel blocks per staged tile (round 4): every distinct Winograd-eligible 3x3 call of one inner step with more than 16 output
 channels, replayed on its live buffers with MS_FETCH_WINO_NT1 (one block per tile: the round-3 kernel) and without (two blocks: ms_conv_inst_wino2.hip).
 Run on the GPU box:  python tools/ab_wino_nt.py [c2|c4] [reps]
-The engine is built with MS_XFIN=0 MS_RIDE=0 so that every convolution goes through ms_conv2d / ms_conv2d_actbwd (the `_xfin` twins launch the same kernels)."""
+The engine is built with the options xfin = ride = False so that every convolution goes through ms_conv2d / ms_conv2d_actbwd (the `_xfin` twins launch the same kernels)."""
 import os, sys
-os.environ.setdefault("MS_XFIN", "0"); os.environ.setdefault("MS_RIDE", "0"); os.environ["MS_CONV_WINO_NT"] = "2"      # NT1 bit decides per call; "auto" column: the heuristic (env dropped + MS_CONV_TUNE)
-os.environ["MS_CONV_TUNE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from maxstyle_amd import options as _O
+_O._engine_defaults.update(xfin=False, ride=False)
+_O.set_library_option("conv.wino_nt", 2)      # NT1 bit decides per call; "auto" column: the heuristic (option back to 0)
 import torch
 import bench
 from maxstyle_amd import _lib
@@ -82,15 +83,15 @@ def main():
         name, N, Cin, Hs, Ws, Cout, pm, epi, stats = key
         has_u = bool(a[fi] & WU)
         ts = []
-        os.environ["MS_CONV_WINO_NT"] = "2"         # (re-read per call under MS_CONV_TUNE) two blocks wherever the call's own NT1 bit does not say one
-        os.environ["MS_CONV_WINO_BLOCK"] = "0"      # tiled columns: never the block form
+        _O.set_library_option("conv.wino_nt", 2)         # two blocks wherever the call's own NT1 bit does not say one
+        _O.set_library_option("conv.wino_block", 0)      # tiled columns: never the block form
         for nt1, wu in ((1, 0), (1, 1), (0, 0), (0, 1)):
             a1 = list(a); a1[fi] = (a[fi] & ~WU & ~NT1) | (NT1 if nt1 else 0) | (WU if (wu and has_u) else 0)
             ts.append(time_call(name, tuple(a1)))
         a1 = list(a); a1[fi] = (a[fi] & ~NT1) | BLK
         ts.append(time_call(name, tuple(a1)))        # the block form, two channel blocks, weights from the appendix when the engine packed one
-        os.environ.pop("MS_CONV_WINO_BLOCK", None)
-        os.environ["MS_CONV_WINO_NT"] = "0"         # 0 = the heuristic
+        _O.set_library_option("conv.wino_block", 1)
+        _O.set_library_option("conv.wino_nt", 0)         # 0 = the heuristic
         auto = time_call(name, a)
         for i, t in enumerate(ts + [auto]):
             tot[i] += cnt * t

@@ -8,14 +8,17 @@ dev = torch.device("cuda:0")
 g = np.load(os.path.join(ROOT, "tests", "golden", "loop_args_all6.npz"))
 names = [str(n) for n in g["all6.param_names"]]
 R.ARG_CALLS["all6"] = dict(n_iter=1)
-CONFIGS = [dict(MS_LOOP_WINOGRAD="1"), dict(MS_LOOP_WINOGRAD="0"), dict(MS_LOOP_WINOGRAD="1", MS_POOL_EPI="0"), dict(MS_LOOP_WINOGRAD="1", MS_WINO_APPENDIX="0"),
-           dict(MS_LOOP_WINOGRAD="1", MS_POOL_EPI="0", MS_POOL_FUSE="0"), dict(MS_LOOP_WINOGRAD="1", MS_FUSE_ACTBWD="0"), dict(MS_LOOP_WINOGRAD="1", MS_RIDE="0"),
-           dict(MS_LOOP_WINOGRAD="1", MS_XFIN_PRO="0"), dict(MS_LOOP_WINOGRAD="1", MS_CONV_K1S="0", MS_CONV_K1G="0", MS_CONV_S2G2="0", MS_SUBPIX_GEN="1")]
+# configurations: engine options (EngineOptions fields) and library options ("a.b" names), maxstyle_amd/options.py
+from maxstyle_amd import options as O
+CONFIGS = [dict(winograd=True), dict(winograd=False), dict(winograd=True, pool_epi=False), dict(winograd=True, pool_epi=False, pool_fuse=False),
+           dict(winograd=True, fuse_act_bwd=False), dict(winograd=True, ride=False), dict(winograd=True, xfin_pro=False),
+           {"winograd": True, "conv.k1s": 0, "conv.k1g": 0, "conv.s2g2": 0}]
 if len(sys.argv) > 1:
-    CONFIGS = [dict(kv.split("=") for kv in a.split(",")) for a in sys.argv[1:]]
-BASE = dict(os.environ)
+    CONFIGS = [{k: int(v) for k, v in (kv.split("=") for kv in a.split(","))} for a in sys.argv[1:]]
 for cfg in CONFIGS:
-    os.environ.clear(); os.environ.update(BASE); os.environ.update(cfg)
+    libopts = {k: v for k, v in cfg.items() if "." in k}
+    O._engine_defaults.clear(); O._engine_defaults.update({k: bool(v) for k, v in cfg.items() if "." not in k})
+    prev = {k: O.set_library_option(k, v) for k, v in libopts.items()}
     wino = str(cfg)
     worst = 0.0
     S = R.trained_solver(dev, "trained_fcn16.npz")
@@ -36,3 +39,5 @@ for cfg in CONFIGS:
         if os.environ.get("DBG_VERBOSE", "0") == "1": print(f"   {n:16s} max|g| {m:.2e}  ours {np.abs(ours - r64).max() / m:.2e} | ref {np.abs(r32 - r64).max() / m:.2e}   median rel ours {np.median(rel_o):.1e} ref {np.median(rel_r):.1e}   "
               f"worst rel ours {rel_o.max():.1e} ref {rel_r.max():.1e}  ({small.sum()} small)")
     print(f"   worst max-norm error over the 18 tensors: {worst:.2e}")
+    for k, v in prev.items():
+        O.set_library_option(k, v)

@@ -20,14 +20,14 @@ def main():
     dev = torch.device("cuda:0")
     golden = os.path.join(ROOT, "tests", "golden")
     print("== full size (BASELINE config 2, trained FCN_16, K=5 free-running) vs the reference's fp64 run")
-    for wino in ("1", "0"):
-        os.environ["MS_LOOP_WINOGRAD"] = wino
-        r = R.full_size_case(dev)
+    from maxstyle_amd.options import engine_defaults
+    for wino in (True, False):
+        with engine_defaults(winograd=wino):
+            r = R.full_size_case(dev)
         print(json.dumps(r))
         print(f"   winograd={r['winograd']}: image max {r['image_max']:.3e} (reference noise {r['noise_image_max']:.3e}, ratio {r['image_max'] / r['noise_image_max']:.2f}), "
               f"rms {r['image_rms']:.3e} ({r['noise_image_rms']:.3e}, {r['image_rms'] / r['noise_image_rms']:.2f}), labels equal {r['labels_equal_f64']:.6f} "
               f"(reference {r['noise_labels_equal']:.6f}), Dice diff {r['dice_abs_diff']:.2e}")
-    os.environ.pop("MS_LOOP_WINOGRAD")
     print("== arguments of the drop-in signature (trained FCN_16, 4x1x64x64) vs the reference's fp64 run")
     for case in R.ARG_CALLS:
         r = R.arg_case(dev, case)
@@ -51,9 +51,10 @@ def round4():
     import r4_cases as R4
     dev = torch.device("cuda:0")
     print("== BASELINE config 4 at size (trained FCN_64, 16x3x320x320, K=10 free-running) vs the reference's fp64 run; noise_* = the reference's own fp32 run against it")
-    for wino in ("1", "0"):
-        os.environ["MS_LOOP_WINOGRAD"] = wino
-        r = R4.c4_full_case(dev)
+    from maxstyle_amd.options import engine_defaults
+    for wino in (True, False):
+        with engine_defaults(winograd=wino):
+            r = R4.c4_full_case(dev)
         print(json.dumps(r))
         print(f"   winograd={r['winograd']}: image max {r['image_max']:.3e} (reference noise {r['noise_image_max']:.3e}, ratio {r['image_max'] / r['noise_image_max']:.2f}), "
               f"rms {max(r['image_rms_full'], r['image_rms_strided']):.3e} ({r['noise_image_rms']:.3e}, {max(r['image_rms_full'], r['image_rms_strided']) / r['noise_image_rms']:.2f}), "
@@ -61,7 +62,6 @@ def round4():
               f"(reference {r['noise_labels_equal']:.6f}), Dice diff {r['dice_abs_diff']:.2e}, Dice {r['dice']} clean {r['dice_clean']}")
         print("   losses rel err per step:", ["%.1e" % e for e in r["losses_rel"]], " reference noise:", ["%.1e" % e for e in r["noise_losses_rel"]])
         print("   params rel err:", {k: "%.1e" % v for k, v in r["params_rel"].items()}, " worst reference noise: %.1e" % max(r["noise_params_rel"].values()))
-    os.environ.pop("MS_LOOP_WINOGRAD")
     print("== BASELINE config 5, one call per shape (p = 0.5: the reference's own draw), vs the reference's fp32 run; oracle_bf16_* = the CPU oracle with bf16 storage emulation")
     for tag in ("acdc", "prostate"):
         for dt in (None, torch.bfloat16):

@@ -26,9 +26,10 @@ MFMA = 157.3e12
 
 # (index of N in the argument list, has in2, index of `out`, indices of further activation tensors) of the conv-family entry points
 CONV_SIG = {
-    "ms_conv2d": 5, "ms_conv2d_xfin": 5, "ms_conv2d_ride": 5, "ms_conv2d_fin": 5, "ms_conv2d_actbwd": 4, "ms_conv2d_actbwd_fin": 4,
+    "ms_conv2d": 5, "ms_conv2d_xfin": 5, "ms_conv2d_ride": 5, "ms_conv2d_actbwd": 4,
 }
-NO_LAUNCH = ("_bytes", "_parts", "_ok", "_eligible", "_capacity", "_slots", "_offset", "ms_num_cus", "ms_version", "ms_last_error")
+NO_LAUNCH = ("_bytes", "_parts", "_ok", "_eligible", "_capacity", "_slots", "_offset", "_threads", "ms_num_cus", "ms_version", "ms_last_error", "ms_set_option", "ms_get_option",
+             "ms_option_default", "ms_option_count", "ms_option_name", "ms_diag_set_trace", "ms_conv2d_form", "ms_conv_k1s_would_run")
 
 
 def conv_cost(fn, a):
@@ -144,8 +145,9 @@ def record(cfg, out):
     import torch
     import bench
     dev = torch.device("cuda:0")
-    net, size = ((4, 1, 4), 256) if cfg == "c2" else ((1, 3, 2), 320)
-    eng, W, img, lab, styles, z_i, lab_d = bench.build(dev, 16, size, 0, net)
+    # c2 / c4: BASELINE configs 2 and 4; acdc192 / prostate224: the reference's shipped workloads (config/ACDC/1500_epoch/MICCAI2022_MaxStyle.json, config/Prostate/MICCAI2022_MaxStyle.json)
+    net, size, B = {"c2": ((4, 1, 4), 256, 16), "c4": ((1, 3, 2), 320, 16), "acdc192": ((4, 1, 4), 192, 20), "prostate224": ((4, 1, 2), 224, 20)}[cfg]
+    eng, W, img, lab, styles, z_i, lab_d = bench.build(dev, B, size, 0, net)
     eng.code, eng.labels = z_i, lab_d
     eng._prefix_valid = False
     im = eng.decode(z_i)
@@ -153,7 +155,7 @@ def record(cfg, out):
     torch.cuda.synchronize()
     ledger, _ = record_ledger(eng, im)
     torch.cuda.synchronize()
-    json.dump(dict(config=cfg, batch=16, size=size, launches=len(ledger), ledger=ledger), open(out, "w"), indent=0)
+    json.dump(dict(config=cfg, batch=B, size=size, launches=len(ledger), ledger=ledger), open(out, "w"), indent=0)
     print(f"{len(ledger)} library calls recorded -> {out}")
 
 

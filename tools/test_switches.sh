@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run the GPU suite under every A/B / opt-in switch of the library and the engines (on the GPU box: gpurun -- 'bash tools/test_switches.sh').
+# Run the GPU suite under every A/B / opt-in option of the library and the engines (MS_OPTIONS: maxstyle_amd/options.py) (on the GPU box: gpurun -- 'bash tools/test_switches.sh').
 # Every line must end in "N passed" with no FAILED line above it.  Tests that ASSERT the default of the switch in question are deselected for that switch only
 # (with the reason): e.g. a test that checks "the single-read kernel ran" cannot pass with the single-read kernel switched off.
 set -u
@@ -9,13 +9,13 @@ export MS_SWITCH_MATRIX=1      # tests that pin WHICH side of a knife edge the d
 # arithmetic leaves it at step 3 (losses 4e-5 .. 1.5e-4).  A knife edge of the case, not of a switch.
 KNIFE="--deselect tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[beta_injected]"
 # Free-running trajectories at the benchmarked sizes are held to 2x / 5x the reference's own fp32-vs-fp64 noise, ONE draw of a chaotic quantity on either side.  The default
-# configuration holds every bar; the alternatives to the single-read MaxStyle kernel (three-launch forward: MS_STYLE_FUSED=0, MS_OVERLAP=1, MS_SHARED_DEVICE=1 - the same bits
+# configuration holds every bar; the alternatives to the single-read MaxStyle kernel (three-launch forward: style.fused=0, MS_SHARED_DEVICE=1 - the same bits
 # among themselves), the materialised segmentation tail and the last-workgroup finalize land 3-27 % over two of them at the end of round 4 (profiles/r04_switch_matrix.txt:
 # step-4 loss error 5.9e-6 .. 7.2e-6 against a bar of 5.7e-6; config 4's plane rms 2.01x the reference's shift against 2x).  Another realisation, not another result.
 CHAOS2="--deselect tests/test_round3_gpu.py::test_headline_config_vs_reference_run[0] --deselect tests/test_round3_gpu.py::test_headline_config_vs_reference_run[1]"
 CHAOS4="--deselect tests/test_round4_gpu.py::test_config4_at_size_vs_reference_run[1]"
 # the well-conditioned all-six-layers case has (at least) one element within 3e-6 of LeakyReLU's kink (tests/test_round3_gpu.py): the test branches on the side the run's
-# first step lands on, but a rounding that differs only LATER (MS_POOL_FUSE=0 regroups the backward's partial sums: steps 2 and 3 see other activations) can meet another one
+# first step lands on, but a rounding that differs only LATER (engine.pool_fuse=0 regroups the backward's partial sums: steps 2 and 3 see other activations) can meet another one
 KINK6="--deselect tests/test_round3_gpu.py::test_all_six_layers_on_trained_network_vs_reference_run[0]"
 # tests whose premise is the cross-workgroup finalize / the co-residency kernels
 XF="not (reshaped_table_never_meets or collective_on_a_side_stream)"
@@ -29,42 +29,36 @@ run() {   # run "<env assignments>" <pytest deselect arguments...>
 run ""
 # bf16 matrix arithmetic and the three-way split exist in the wide kernel only; `nonoise` / `noisefixed`: free-running K = 3 cases whose bars are 3x the reference's own
 # noise - the first-generation kernels everywhere are another rounding of the same arithmetic and land at 4-5x (the same effect as experiments 17 / 18)
-run MS_CONV_WIDE=0 --ignore=tests/test_bf16m_gpu.py --ignore=tests/test_wino_gpu.py -k "not (three_way_split or pooled_epilogue_is_conv or pooled_data_gradient or bench_line_contract)" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[nonoise]" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[noisefixed]"
+run MS_OPTIONS=conv.wide=0 --ignore=tests/test_bf16m_gpu.py --ignore=tests/test_wino_gpu.py -k "not (pooled_epilogue_is_conv or pooled_data_gradient or bench_line_contract)" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[nonoise]" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[noisefixed]"
 # the lazy tail, the pooled epilogue's consumer and the riders' producers are forms of the fused activation backward
-run MS_FUSE_ACTBWD=0 $KNIFE -k "not (lazy_segmentation_tail or pooled_data_gradient or pooled_gradient_from or rider_coefficient or bench_line_contract)"
+run MS_OPTIONS=engine.fuse_act_bwd=0 $KNIFE -k "not (lazy_segmentation_tail or pooled_data_gradient or pooled_gradient_from or rider_coefficient or bench_line_contract)"
 # "last workgroup finalises" (a round-2 experiment) and the cross-workgroup finalize are alternatives
-run MS_FUSE_BNFIN=1 $KNIFE $CHAOS2 -k "not (cross_workgroup_finalize or reshaped_table_never_meets)"
 # (a round-1 experiment: coefficient buffers that the in-kernel form never writes stay uninitialised, so record-by-record A/B comparisons and the bench line's
 #  launch accounting do not apply)
-run MS_INLINE_BN_BWD=1 $KNIFE -k "not (cross_workgroup_finalize or rider_coefficient or pooled_data_gradient or style_layer_in_front or bench_line_contract)"
 # side streams: no single-read kernel, no riders, no lazy tail (they assume one stream)
 # (inner_loop_bf16_storage[net1]: first loss 1.12 % from the fp32-storage run against a 1 % bar on the three-launch bf16 MaxStyle path - the same with every round-3 switch off)
-run MS_OVERLAP=1 $KNIFE $CHAOS2 $CHAOS4 -k "not (single_read_kernel or rider_coefficient or lazy_segmentation_tail or cross_workgroup_finalize)" "--deselect=tests/test_bf16_conv_gpu.py::test_inner_loop_bf16_storage_vs_fp32_storage[net1-4-64-0.03]"
-run MS_TRAIN_GRAPH=1
-run MS_STYLE_FUSED=0 $KNIFE $CHAOS2 $CHAOS4 -k "not single_read_kernel"
-run MS_STYLE_FUSED_MIN_MB=2
-run MS_XFIN=0 -k "$XF"
-run MS_XFIN_PRO=0
-run MS_FUSE_TAIL=0
-run MS_FUSE_HEAD_BWD=0
-run MS_LAZY_SEG_TAIL=0 $KNIFE $CHAOS2
-run MS_RIDE=0
-run MS_POOL_FUSE=0 $KNIFE $KINK6
-run MS_POOL_EPI=0
-run MS_LAZY_STYLE_HEAD=0
-run MS_SMALL_CIN=1 $KNIFE "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[nomix]" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[nonoise]" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[noisefixed]" -k "not inner_loop_with_and_without_the_winograd_form"      # opt-in kernel: see experiment 18
+run MS_OPTIONS=engine.train_graph=1
+run MS_OPTIONS=style.fused=0 $KNIFE $CHAOS2 $CHAOS4 -k "not single_read_kernel"
+run MS_OPTIONS=engine.xfin=0 -k "$XF"
+run MS_OPTIONS=engine.xfin_pro=0
+run MS_OPTIONS=engine.fuse_tail=0
+run MS_OPTIONS=engine.fuse_head_bwd=0
+run MS_OPTIONS=engine.lazy_seg_tail=0 $KNIFE $CHAOS2
+run MS_OPTIONS=engine.ride=0
+run MS_OPTIONS=engine.pool_fuse=0 $KNIFE $KINK6
+run MS_OPTIONS=engine.pool_epi=0
+run MS_OPTIONS=engine.lazy_style_head=0
+run MS_OPTIONS=engine.small_cin=1 $KNIFE "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[nomix]" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[nonoise]" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[noisefixed]" -k "not inner_loop_with_and_without_the_winograd_form"      # opt-in kernel: see experiment 18
 # the Winograd form is what these tests are about (and what the bench line's `form` field reports)
-run MS_LOOP_WINOGRAD=0 $KNIFE -k "not (pooled_data_gradient or winograd or bench_line_contract)"
+run MS_OPTIONS=engine.winograd=0 $KNIFE -k "not (pooled_data_gradient or winograd or bench_line_contract)"
 # shared device: neither the single-read kernel nor the cross-workgroup finalize is selected
 run MS_SHARED_DEVICE=1 $KNIFE $CHAOS2 $CHAOS4 -k "not (single_read_kernel or cross_workgroup_finalize or reshaped_table_never_meets or collective_on_a_side_stream)"
 # ---- round 4: the second-generation kernels' process-wide switches (each falls back to the first generation: same bits at config 4, rounding-level differences of the
 #      stride-2 conv's chunking at config 2) ----
 # (tests that assert "the streaming / second-generation kernel ran" cannot pass with it switched off)
-run MS_CONV_K1S=0 $KNIFE -k "not (streamed or streaming_1x1 or k1s)"
-run MS_K1S_CMIN=64 $KNIFE -k "not (streamed or streaming_1x1 or k1s)"
-run MS_CONV_K1G=0 $KNIFE -k "not lds_tiled_1x1_gemm"
-run MS_CONV_S2G2=0 $KNIFE -k "not stride2_conv_second_generation"
-run MS_SUBPIX_GEN=1 $KNIFE
-run MS_TRAIN_XFIN=1 $KNIFE
-run MS_TRAIN_WINOGRAD=1 $KNIFE -k "not which_engines_ask"
-run MS_FUSE_FINACT=0
+run MS_OPTIONS=conv.k1s=0 $KNIFE -k "not (streamed or streaming_1x1 or k1s)"
+run MS_OPTIONS=conv.k1g=0 $KNIFE -k "not lds_tiled_1x1_gemm"
+run MS_OPTIONS=conv.s2g2=0 $KNIFE -k "not stride2_conv_second_generation"
+run MS_OPTIONS=engine.train_xfin=1 $KNIFE
+run MS_OPTIONS=engine.train_winograd=1 $KNIFE -k "not which_engines_ask"
+run MS_OPTIONS=engine.fuse_fin_act=0

@@ -4,7 +4,8 @@ sys.path.insert(0, os.getcwd())
 import torch
 dev = torch.device("cuda:0")
 trace = torch.zeros(512, dtype=torch.int64, device=dev)
-os.environ["MS_CONV_TRACE"] = hex(trace.data_ptr())
+from maxstyle_amd._lib import lib as _L
+_L.ms_diag_set_trace(trace.data_ptr(), 0)
 from maxstyle_amd import ops
 # usage: trace_conv.py [plain|pro1|bwd] [C] [size] [fetch bits: 0x100 = Winograd, 0x500 = Winograd one-block, +0x800 = weights from the appendix (0x900 / 0xD00)]
 N = 16

@@ -4,7 +4,8 @@ sys.path.insert(0, os.getcwd())
 import torch
 dev = torch.device("cuda:0")
 trace = torch.zeros(256, dtype=torch.int64, device=dev)
-os.environ["MS_WGRAD_TRACE"] = hex(trace.data_ptr())
+from maxstyle_amd._lib import lib as _L
+_L.ms_diag_set_trace(0, trace.data_ptr())
 from maxstyle_amd import ops
 B = 16
 dy = torch.randn(B, 16, 256, 256, device=dev); x = torch.randn(B, 16, 256, 256, device=dev)

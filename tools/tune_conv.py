@@ -1,11 +1,11 @@
 """Per-layer convolution tuning table of one inner step (run on the GPU box).
 
 Records every ms_conv2d / ms_conv2d_actbwd call of one eager step at the C2 configuration, then replays each distinct call (same live buffers)
-under the library's tuning hook (MS_CONV_TUNE: output-channel tile NT forced to 1/2/4, wide-read kernel on/off) and prints what the built-in
+under the library's tuning options (ms_set_option "conv.force_nt": output-channel tile NT forced to 1/2/4; "conv.wide": wide-read kernel on/off) and prints what the built-in
 heuristic chose against the best alternative.  Usage: python tools/tune_conv.py [reps]"""
 import os, sys, json
-os.environ["MS_CONV_TUNE"] = "1"
-os.environ.setdefault("MS_XFIN", "0"); os.environ.setdefault("MS_RIDE", "0")      # every conv through ms_conv2d / ms_conv2d_actbwd (the `_xfin` / rider twins launch the same kernels)
+from maxstyle_amd import options as _O
+_O._engine_defaults.update(xfin=False, ride=False)      # every conv through ms_conv2d / ms_conv2d_actbwd (the `_xfin` / rider twins launch the same kernels)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
@@ -68,25 +68,6 @@ def main():
         e1.synchronize()
         return e0.elapsed_time(e1) / reps * 1e3
 
-    if len(sys.argv) > 2 and sys.argv[2] == "stagger":
-        # sweep the wide kernel's workgroup stagger (MS_CONV_STAGGER, read per call under MS_CONV_TUNE) on every distinct wide-kernel call
-        vals = [0, 2, 4, 6, 8, 12]
-        print(f"{'call':16s} {'N,Cin,Hs,Ws,Cout':>22s} pm epi st cnt " + " ".join(f"stag{v:>3d}" for v in vals))
-        tot = [0.0] * len(vals)
-        for key, (cnt, a) in sorted(seen.items(), key=lambda kv: -kv[1][0]):
-            name, N, Cin, Hs, Ws, Cout, ks, stride, fetch, pm, epi, stats = key
-            if not (ks == 3 and stride == 1 and (fetch & 0xFF) == 0 and Ws >= 64):
-                continue
-            ts = []
-            for v in vals:
-                os.environ["MS_CONV_STAGGER"] = str(v)
-                ts.append(time_call(name, a))
-            os.environ["MS_CONV_STAGGER"] = "0"
-            for i, t in enumerate(ts):
-                tot[i] += cnt * t
-            print(f"{name[3:]:16s} {str((N, Cin, Hs, Ws, Cout)):>22s} {pm:2d} {epi:3d} {int(stats):2d} {cnt:3d} " + " ".join(f"{t:7.1f}" for t in ts))
-        print("per-step totals (us): " + " ".join(f"{t:7.0f}" for t in tot))
-        return
     rows = []
     total_auto = total_best = 0.0
     for key, (cnt, a) in seen.items():
@@ -94,13 +75,13 @@ def main():
         res = {}
         for nt in (0, 1, 2, 4):
             for wide in (1, 0):
-                os.environ["MS_CONV_FORCE_NT"] = str(nt); os.environ["MS_CONV_FORCE_WIDE"] = str(wide)
+                _O.set_library_option("conv.force_nt", nt); _O.set_library_option("conv.wide", wide)
                 if nt == 0 and wide == 0:
                     continue
                 t = time_call(name, a)
                 if t is not None:
                     res[(nt, wide)] = t
-        os.environ["MS_CONV_FORCE_NT"] = "0"; os.environ["MS_CONV_FORCE_WIDE"] = "1"
+        _O.set_library_option("conv.force_nt", 0); _O.set_library_option("conv.wide", 1)
         auto = res[(0, 1)]
         best = min(res, key=res.get)
         Ho = Hs * (2 if (fetch & 0xFF) else 1) // stride if ks != 2 else Hs // 2

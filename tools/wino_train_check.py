@@ -1,5 +1,5 @@
 """Weight gradients of one full-size training pass (16x1x256x256): GPU (direct / Winograd form) and the fp32 CPU oracle, each against the fp64 CPU oracle.
-python tools/wino_train_check.py   (runs itself twice as a child with MS_TRAIN_WINOGRAD=0 / 1)"""
+python tools/wino_train_check.py   (runs itself twice as a child with MS_OPTIONS=engine.train_winograd=0 / 1)"""
 import os, sys, subprocess, pickle
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -26,7 +26,7 @@ o64 = oracle_pass_grads(torch.float64, 16, 256, True)
 pickle.dump(dict(clean=o32["clean"], lab=o32["lab"], image_l=o32["image_l"]), open("/tmp/wtc_in.pkl", "wb"))
 res = {}
 for w in ("0", "1"):
-    env = dict(os.environ, MS_TRAIN_WINOGRAD=w)
+    env = dict(os.environ, MS_OPTIONS="engine.train_winograd=" + w)
     subprocess.check_call([sys.executable, os.path.abspath(__file__), "child", f"/tmp/wtc_{w}.pkl"], env=env)
     res[w] = pickle.load(open(f"/tmp/wtc_{w}.pkl", "rb"))
 def worst(get):
