@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--mfma", default="f32", choices=["f32", "bf16"],
                     help="with --act-dtype bf16: matrix arithmetic of the 3x3 stride-1 convs (bf16: v_mfma_f32_16x16x16_bf16 on bf16-rounded operands, fp32 accumulation)")
     ap.add_argument("--stream-calls", type=int, default=8, help="c5: generate_max_style_image calls per pass of the stream (alternating ACDC / Prostate shaped)")
+    ap.add_argument("--spinup-seconds", type=float, default=1.0, help="device spin-up (untimed replays of the step) in front of the W warm-up steps of the headline leg; 0 disables")
     ap.add_argument("--steady-seconds", type=float, default=2.0, help="length of the extra steady-state leg (graph replays, rank-local); 0 disables")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only: gloo on the CPU, stand-in step (CPU tests)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend of the real run (nccl = RCCL; gloo: validation of the N>1 path on a box with fewer GPUs than ranks)")
@@ -96,7 +97,10 @@ def build(dev, B, size, rank, net=(4, 1, 4), act_dtype=None, mfma_bf16=False):
     return eng, W, img, lab, styles, z_i, lab_d
 
 
-def timed_steps(eng, z_i, lab_d, steps, warmup, use_graph, dist_on):
+def timed_steps(eng, z_i, lab_d, steps, warmup, use_graph, dist_on, spinup_s=0.0):
+    """W untimed warm-up steps, then EXACTLY `steps` steps between barrier + synchronize on both sides.  spinup_s: before the warm-up steps the device is kept under the
+    same load for that long (untimed replays): a fresh box's first ~100 ms of kernels run at whatever clock / power state the idle GPU was in - one driver-style run of
+    round 5 measured 426.6 steps/s in its 50 timed steps and 455.2 in the 2 s steady-state leg right behind them (gpurun_out/r5_bench3.json)."""
     import torch.distributed as dist
     eng.code, eng.labels = z_i, lab_d
     eng._prefix_valid = False
@@ -116,6 +120,13 @@ def timed_steps(eng, z_i, lab_d, steps, warmup, use_graph, dist_on):
             torch.cuda.synchronize()
     run_one = (graph.replay if graph is not None else (lambda: eng.step(img)))
     eng._bench_img = img                      # (the in-place image buffer of the step: in_step_times re-captures prefixes of the step on it)
+    if spinup_s > 0:
+        t_sp = time.perf_counter()
+        while time.perf_counter() - t_sp < spinup_s:
+            for _ in range(40):
+                run_one()
+            eng.step_dev.zero_()
+            torch.cuda.synchronize()
     for _ in range(max(warmup - 1, 0)):
         run_one()
     eng.step_dev.zero_()                      # loss slots restart (the Adam moments keep evolving: same work per step)
@@ -1052,10 +1063,16 @@ def main():
             args.size = 320
     bf16 = args.act_dtype == "bf16"
     eng, W, img, lab, styles, z_i, lab_d = build(dev, args.batch, args.size, rank, net, torch.bfloat16 if bf16 else None, bf16 and args.mfma == "bf16")
-    dt, graphed, run_one = timed_steps(eng, z_i, lab_d, args.steps, args.warmup, not args.no_graph, dist_on)
+    dt, graphed, run_one = timed_steps(eng, z_i, lab_d, args.steps, args.warmup, not args.no_graph, dist_on, spinup_s=args.spinup_seconds)
+    coll = {}
     if dist_on:
         from maxstyle_amd import distributed as D
         dt = D.max_over_ranks(dt, dev)
+        # N > 1: every leg that contains a collective runs HERE, on all ranks, before rank 0 starts its rank-local extras (steady-state leg, in-step timing, kernel
+        # rooflines: ~20-30 s) - otherwise ranks 1..N-1 would sit inside RCCL kernels waiting for rank 0 all that time
+        coll["rccl"] = rccl_leg(dev, rank, run_one) if args.backend == "nccl" else None
+        if not args.no_outer and args.config == "c2" and args.act_dtype != "bf16":
+            coll["outer_iteration"] = outer_iteration(dev, args.batch, args.size, rank, world, dist_on=True)
     n_gpus = world
     value = n_gpus * args.steps / dt
     headline = (args.config, args.batch, args.size) == ("c2", 16, 256)
@@ -1078,6 +1095,7 @@ def main():
                        "global_batch": args.batch * n_gpus, "parallelism": f"dp{n_gpus}", "hip_graph": graphed, "world_seen": world,
                        **({"oversubscribed": True, "backend": args.backend} if (args.oversubscribe or args.backend != "nccl") else {})},
             "per_gpu_steps_s": value / n_gpus,
+            "device_spinup_s": args.spinup_seconds,
             "steady_state": steady,
             "conv_flops": ({"gflop_per_step_uncached": FLOP_PER_STEP_C2 / 1e9, "gflop_per_step_executed": FLOP_EXECUTED_C2 / 1e9,
                             "tflops_uncached_accounting": FLOP_PER_STEP_C2 / step_s / 1e12, "tflops_executed": FLOP_EXECUTED_C2 / step_s / 1e12,
@@ -1104,23 +1122,22 @@ def main():
     if rank == 0 and world == 1 and headline and not bf16 and not args.no_secondary:
         res["secondary"] = secondary_blocks(dev, args, rank)
     if dist_on:
-        rl = rccl_leg(dev, rank, run_one) if args.backend == "nccl" else None      # every rank: collectives
         if rank == 0:
-            res["rccl"] = rl
+            res.update(coll)
     elif rank == 0 and not args.no_rccl_selftest:
         res["rccl"] = rccl_selftest(dev, run_one)
-    if not args.no_outer and args.config == "c2" and not bf16:
+    if not dist_on and not args.no_outer and args.config == "c2" and not bf16:
         del eng, run_one
         torch.cuda.empty_cache()
-        oi = outer_iteration(dev, args.batch, args.size, rank, world, dist_on=dist_on)      # every rank: contains the collective
-        if not dist_on and rank == 0:
-            # side field: the same iteration with the training passes' forward / data-gradient convs in the Winograd form (opt-in EngineOptions.train_winograd);
-            # the headline of this block stays on the default (direct form: weight gradients at the reference's fidelity)
+        oi = outer_iteration(dev, args.batch, args.size, rank, world, dist_on=False)
+        if rank == 0:
+            # side field: the same iteration with the training passes' forward / data-gradient convs in the DIRECT form (the default until round 4; since round 5 they take the
+            # Winograd form: 20-seed weight-gradient fidelity equal, profiles/r05_train_fidelity.json)
             from maxstyle_amd.options import engine_defaults
-            with engine_defaults(train_winograd=True):
+            with engine_defaults(train_winograd=False):
                 torch.cuda.empty_cache()
-                ow = outer_iteration(dev, args.batch, args.size, rank, world, dist_on=dist_on)
-                oi["winograd_training_passes_opt_in"] = {"switch": "EngineOptions.train_winograd = True", "ms_per_iteration": ow["ms_per_iteration"], "value": ow["value"]}
+                ow = outer_iteration(dev, args.batch, args.size, rank, world, dist_on=False)
+                oi["direct_form_training_passes"] = {"switch": "EngineOptions.train_winograd = False", "ms_per_iteration": ow["ms_per_iteration"], "value": ow["value"]}
         if rank == 0:
             res["outer_iteration"] = oi
     if rank == 0:

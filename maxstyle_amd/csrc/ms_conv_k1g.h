@@ -249,8 +249,10 @@ inline bool conv_k1g_eligible(const ConvArgs& a, int ks, int stride, int fetch) 
       !(a.epi_mode == 0 || a.epi_mode == 4 || a.epi_mode == 5)) return false;
   if (a.xf_tab != nullptr && a.epi_mode == 0) return false;
   const long HW = (long)a.Hs * a.Ws;
-  constexpr int cmin = 256;
-  if (a.Cin % 8 != 0 || a.Cin < cmin || HW % 4 != 0 || (a.epi_mode == 5 && a.Ws % 4 != 0)) return false;       // measured scope: the channel-heavy levels (tools/ab_k1.py)
+  // measured scope: the channel-heavy levels (tools/ab_k1.py) - and, from 64 channels, rows that are not a multiple of 4 pixels (14 x 14: the deepest level of the
+  // reference's shipped 224-pixel Prostate workload), where the tiled kernel falls to its scalar staging path (27-33 us per launch against 9-11 us at 16 x 16)
+  const int cmin = (a.Ws % 4 != 0) ? 64 : 256;
+  if (a.Cin % 8 != 0 || a.Cin < cmin || HW % 4 != 0 || (a.epi_mode == 5 && a.Ws % 4 != 0)) return false;
   if ((long long)a.N * a.Cin * HW * 4 >= (1LL << 31) || (long long)a.cin_pad * a.cout_pad * 4 >= (1LL << 31)) return false;
   return aligned16(a.in) && aligned16(a.out) && aligned16(a.w) && (a.epi_mode == 0 || aligned16(a.mk_u));
 }

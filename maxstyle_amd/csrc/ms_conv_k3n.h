@@ -388,10 +388,13 @@ inline bool conv_k3n_eligible(const ConvArgs& a, int ks, int stride, int fetch) 
   return aligned16(a.in) && aligned16(a.out) && aligned16(a.w) && (a.in2 == nullptr || aligned16(a.in2)) && (a.epi_mode != 3 || aligned16(a.mk_u));
 }
 
-// M-tiles per MFMA wave: two (half the weight traffic and 25 % instead of 50 % halo rows per staged band) where that still leaves a work item for every CU
+// M-tiles per MFMA wave.  Two halve the weight traffic and stage 25 % instead of 50 % halo rows per band - taken where they leave a work item for every CU AND do not
+// cost matrix time: an image of HW pixels is ceil(HW / (64 MT)) items of MT units each (12 x 12 = 144 pixels: 3 x 1 units against 2 x 2; 14 x 14 and 16 x 16: equal)
 inline int conv_k3n_mt(const ConvArgs& a) {
-  const long items2 = (long)a.N * cdiv(a.Hs * a.Ws, 128) * cdiv(a.Cout, 16);
-  return items2 >= (long)num_cus() ? 2 : 1;
+  const int HW = a.Hs * a.Ws;
+  const long items2 = (long)a.N * cdiv(HW, 128) * cdiv(a.Cout, 16);
+  if (items2 < (long)num_cus()) return 1;
+  return (2 * cdiv(HW, 128) <= cdiv(HW, 64)) ? 2 : 1;
 }
 
 template <int W, int MT, int PRO>

@@ -376,6 +376,8 @@ class InnerLoopEngine:
         self.loss_buf = torch.zeros(64, dtype=F32, device=self.dev)
         self._graph = None
         self._graph_in = None
+        self._call_graphs = {}              # n_iter -> (captured graph of the WHOLE call: clean decode + n_iter steps, the image buffer it ends in)
+        self.call_graph = True              # run(): one graph launch per call from the second call of a (signature, n_iter) on (False: decode eagerly, one replay per step)
         self._cfg_sig = None
         self._cfg_cache = {}
         self._err_pending = None
@@ -398,9 +400,9 @@ class InnerLoopEngine:
         self.small_cout = opt.small_cout
         self.lazy_inc = opt.lazy_inc and inner
         # Winograd F(2x2,3x3) form of the wide 3x3 stride-1 convolutions (MS_FETCH_WINOGRAD).  Its rounding error on the networks' activations is about twice the direct
-        # form's (include/maxstyle_hip.h, ms_conv2d): harmless for the augmentation loop (parity tests unchanged: default on); the training passes (forward and
-        # data-gradient convs; the weight-gradient kernels are their own) keep the direct form unless asked (DESIGN.md section 10 has the round-5 fidelity distribution).
-        self.winograd = (True if opt.winograd is None else bool(opt.winograd)) if inner else bool(opt.train_winograd)
+        # form's (include/maxstyle_hip.h, ms_conv2d): harmless for the augmentation loop (parity tests unchanged: default on) and, by the 20-seed weight-gradient
+        # distribution of round 5 (options.py, profiles/r05_train_fidelity.json), for the training passes' forward / data-gradient convs too (default on since round 5).
+        self.winograd = (True if opt.winograd is None else bool(opt.winograd)) if inner else (True if opt.train_winograd is None else bool(opt.train_winograd))
         self.fuse_style_actbwd = True  # ms_style_bwd_actbwd (the MaxStyle backward also does the block's output-activation backward)
         self.fuse_tail = opt.fuse_tail
         self.fuse_fin_act = opt.fuse_fin_act and inner      # (the training engine's bn_fin also tracks running statistics)
@@ -464,10 +466,10 @@ class InnerLoopEngine:
 
     # ------------------------------------------------------------------ per-signature loop state (flat buffers + captured graph)
     CFG_CACHE_MAX = 16
-    _CFG_FIELDS = ("layers", "styles", "nparam", "flat_p", "flat_g", "flat_m", "flat_v", "learn_segments", "_graph", "_graph_in", "_cfg_sig")
+    _CFG_FIELDS = ("layers", "styles", "nparam", "flat_p", "flat_g", "flat_m", "flat_v", "learn_segments", "_graph", "_graph_in", "_call_graphs", "_cfg_sig")
 
     def _any_graph(self):
-        return self._graph is not None or any(ent.get("_graph") is not None for ent in self._cfg_cache.values())
+        return self._graph is not None or bool(self._call_graphs) or any(ent.get("_graph") is not None or ent.get("_call_graphs") for ent in self._cfg_cache.values())
 
     def stash_config(self, sig):
         """Remember the current style layout (flat parameter / gradient / moment buffers, the captured step) under `sig`.  A later call with the
@@ -480,6 +482,8 @@ class InnerLoopEngine:
             ent = self._cfg_cache.pop(old)
             g = ent.pop("_graph", None)
             del g
+            cg = ent.pop("_call_graphs", None)
+            del cg
             ent.clear()
 
     def restore_config(self, sig):
@@ -1145,6 +1149,7 @@ class InnerLoopEngine:
         self.flat_v = torch.zeros_like(self.flat_p)
         self.step_dev.zero_()
         self._graph = None
+        self._call_graphs = {}
         self._prefix_valid = False
         # learnable segments (merged where adjacent) for the Adam kernel
         segs = []
@@ -1459,11 +1464,15 @@ class InnerLoopEngine:
     def set_nets(self, nets: PackedNets):
         self.nets = nets
         self._graph = None
+        self._call_graphs = {}
         self._cfg_cache = {}          # captured steps hold the addresses of the previous tables
         self._prefix_valid = False
 
     def run(self, code, labels, n_iter, use_graph=True):
-        """K inner steps; returns the final stylised image (a view of an engine buffer - clone to keep)."""
+        """K inner steps; returns the final stylised image (a view of an engine buffer - clone to keep).
+        The reference's entry point is the CALL (advanced_triplet...py:503-571: clean decode, K steps), so from the second call of a (style signature, K) on the whole
+        call is ONE captured HIP graph - decode + K steps, one launch (round 5; `call_graph`) - instead of an eager decode and K replays of the step graph: no
+        inter-replay bubbles, ~20 fewer eager launches per call.  The first call of a signature runs eagerly / on the step graph and captures behind itself."""
         assert n_iter <= self.loss_buf.numel(), "n_iter exceeds the loss buffer"
         # inputs live in engine-owned buffers so that a captured graph (which holds addresses) stays valid across calls
         cb = self.a("in.code", *code.shape)
@@ -1474,33 +1483,67 @@ class InnerLoopEngine:
             lb.copy_(labels)
             labels = lb
         self.code, self.labels = code, labels
+        steps = n_iter if (n_iter > 0 and self.learn_segments) else 0
+        if use_graph and self.call_graph:
+            ent = self._call_graphs.get(steps)
+            if ent is not None and ent[2] == (code.data_ptr(), None if labels is None else labels.data_ptr()):
+                ent[0].replay()
+                self._prefix_valid = True
+                for sl in self.styles.values():
+                    sl.have_std = True
+                return ent[1]
         self._prefix_valid = False
         self.step_dev.zero_()
         img = self.decode(code)
-        if n_iter <= 0 or not self.learn_segments:
-            return img
-        k0 = 0
-        if use_graph and self._graph is None and n_iter >= 2:
-            img = self.step(img)                         # eager warm-up: allocates every buffer
-            k0 = 1
-            try:
-                g = torch.cuda.CUDAGraph()
-                self._graph_in = img
-                with torch.cuda.graph(g):
-                    out = self.step(self._graph_in)
-                assert out.data_ptr() == self._graph_in.data_ptr(), "decode must write the image in place for replay"
-                self._graph = g
-                # the captured launches did not execute: replay below performs step k0+1
-            except Exception as ex:                      # capture unsupported: stay eager, say so once
-                self._graph = None
-                self.graph_error = repr(ex)
-                torch.cuda.synchronize()
-        for _ in range(k0, n_iter):
-            if self._graph is not None and use_graph:
-                self._graph.replay()
-            else:
-                img = self.step(img)
+        if steps > 0:
+            k0 = 0
+            if use_graph and self._graph is None and steps >= 2:
+                img = self.step(img)                         # eager warm-up: allocates every buffer
+                k0 = 1
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    self._graph_in = img
+                    with torch.cuda.graph(g):
+                        out = self.step(self._graph_in)
+                    assert out.data_ptr() == self._graph_in.data_ptr(), "decode must write the image in place for replay"
+                    self._graph = g
+                    # the captured launches did not execute: replay below performs step k0+1
+                except Exception as ex:                      # capture unsupported: stay eager, say so once
+                    self._graph = None
+                    self.graph_error = repr(ex)
+                    torch.cuda.synchronize()
+            for _ in range(k0, steps):
+                if self._graph is not None and use_graph:
+                    self._graph.replay()
+                else:
+                    img = self.step(img)
+        if use_graph and self.call_graph and (steps == 0 or self._graph is not None) and steps not in self._call_graphs and not getattr(self, "graph_error", None):
+            self._capture_call(code, labels, steps, img)
         return img
+
+    def _capture_call(self, code, labels, steps, img_eager):
+        """Capture decode + `steps` steps as one graph for the NEXT call of this signature (nothing executes here; every buffer exists already: the eager call above
+        allocated them).  The Python-side flags a call starts from - prefix not cached, batch std not frozen - are restored around the capture."""
+        keep = self._prefix_valid, {i: sl.have_std for i, sl in self.styles.items()}
+        try:
+            self._prefix_valid = False
+            for sl in self.styles.values():
+                sl.have_std = False
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step_dev.zero_()
+                img = self.decode(code)
+                for _ in range(steps):
+                    img = self.step(img)
+            assert img.data_ptr() == img_eager.data_ptr(), "the captured call must end in the buffer the eager call ends in"
+            self._call_graphs[steps] = (g, img, (code.data_ptr(), None if labels is None else labels.data_ptr()))
+        except Exception as ex:                              # capture unsupported: keep the per-step path, say so once
+            self.graph_error = repr(ex)
+            torch.cuda.synchronize()
+        finally:
+            self._prefix_valid = keep[0]
+            for i, sl in self.styles.items():
+                sl.have_std = keep[1][i]
 
     def losses(self, n):
         return self.loss_buf[:n]

@@ -48,6 +48,9 @@ class _MaxStyleFunction(torch.autograd.Function):
         return dx, (dg if need_g else None), (db if need_b else None), (dl if need_l else None), None
 
 
+_CUDA, _CPU = torch.device('cuda'), torch.device('cpu')
+
+
 class MaxStyle(nn.Module):
     """MaxStyle layer (Chen et al., MICCAI 2022). See the reference docstring for argument meaning
     (/root/reference/src/advanced/maxstyle.py:14-30)."""
@@ -55,22 +58,11 @@ class MaxStyle(nn.Module):
     def __init__(self, batch_size, num_feature, p=0.5, mix_style=True, no_noise=False,
                  mix_learnable=True, noise_learnable=True, always_use_beta=False, alpha=0.1, eps=1e-6, use_gpu=True, debug=False):
         super().__init__()
-        self.batch_size = batch_size
-        self.num_feature = num_feature
-        self.p = p
-        self.mix_style = mix_style
-        self.no_noise = no_noise
-        self.mix_learnable = mix_learnable
-        self.noise_learnable = noise_learnable
-        self.always_use_beta = always_use_beta
-        self.alpha = alpha
-        self.eps = eps
-        self.use_gpu = use_gpu
-        self.debug = debug
-        self.device = torch.device('cuda') if use_gpu else torch.device('cpu')
-        self.data = None
-        self._perm_cache = None
-        self._last_stats = None
+        # plain (non-tensor) attributes: straight into __dict__ - nn.Module.__setattr__ walks its parameter / buffer / module tables for every assignment, and the
+        # trainer builds three of these layers per generate_max_style_image call (host time of the call: tools/prof_call_host.py)
+        self.__dict__.update(batch_size=batch_size, num_feature=num_feature, p=p, mix_style=mix_style, no_noise=no_noise, mix_learnable=mix_learnable,
+                             noise_learnable=noise_learnable, always_use_beta=always_use_beta, alpha=alpha, eps=eps, use_gpu=use_gpu, debug=debug,
+                             device=_CUDA if use_gpu else _CPU, data=None, _perm_cache=None, _last_stats=None)
         if batch_size <= 1:
             # the reference spins forever here (identity-permutation rejection loop, maxstyle.py:55-58)
             raise ValueError("MaxStyle needs batch_size >= 2 (a batch of one has no non-identity permutation)")
@@ -79,11 +71,10 @@ class MaxStyle(nn.Module):
     def init_parameters(self):
         """perm / rand_p from the CPU generator, noise / lmda from the device generator (maxstyle.py:48-122)."""
         B, C = self.batch_size, self.num_feature
-        self.perm = torch.randperm(B)
-        while torch.equal(self.perm, torch.arange(B)):
-            self.perm = torch.randperm(B)
-        self._perm_cache = None
-        self.rand_p = torch.rand(1)
+        perm = torch.randperm(B)
+        while torch.equal(perm, torch.arange(B)):
+            perm = torch.randperm(B)
+        self.__dict__.update(perm=perm, _perm_cache=None, rand_p=torch.rand(1))
         if self.rand_p >= self.p:
             for n in ("gamma_noise", "beta_noise", "lmda"):
                 if n in self._parameters:
@@ -114,8 +105,7 @@ class MaxStyle(nn.Module):
                     lmda = torch.rand(B, 1, 1, 1, dtype=torch.float32, device=self.device)
                 self.lmda = nn.Parameter(lmda.float())
                 self.lmda.requires_grad = bool(self.mix_learnable)
-        self.gamma_std = None
-        self.beta_std = None
+        self.__dict__.update(gamma_std=None, beta_std=None)
         if self.debug:
             print("lmda:", self.lmda); print("gamma_noise:", self.gamma_noise); print("beta_noise:", self.beta_noise); print("perm:", self.perm)
 

@@ -21,11 +21,14 @@ from typing import Optional
 
 @dataclass
 class EngineOptions:
-    # Winograd F(2x2,3x3) form of the wide 3x3 stride-1 convolutions (MS_FETCH_WINOGRAD): on for the inner loop (its parity tests
-    # hold either way), off for the training passes (weight gradients keep the direct form: the form's rounding error on the networks' activations is about twice the
-    # direct one's, i.e. about twice as many LeakyReLU kinks behind a backward pass; DESIGN.md section 3 "Round 2, last third", section 10)
+    # Winograd F(2x2,3x3) form of the wide 3x3 stride-1 convolutions (MS_FETCH_WINOGRAD): on for the inner loop (its parity tests hold either way) and - since round 5 -
+    # for the forward / data-gradient convs of the training passes (the weight-gradient kernels are their own).  Until round 4 the passes kept the direct form on a
+    # one-batch measurement ("the form's rounding error on these activations is about twice the direct one's": more LeakyReLU kinks behind a backward pass).  The 20-seed
+    # distribution of round 5 (tools/train_fidelity.py, profiles/r05_train_fidelity.json: weight gradients of the full-size pass against the fp64 oracle) shows no
+    # difference: worst tensor per seed in L2, median / max over the seeds - direct 2.8e-3 / 8.3e-3, Winograd 2.5e-3 / 8.0e-3, the fp32 CPU oracle itself 2.4e-3 / 7.3e-3;
+    # mean over tensors 7.1e-4 / 6.2e-4 / 5.2e-4.  -0.85 ms per trainer iteration (45.4 -> 47.3 iterations/s).
     winograd: Optional[bool] = None            # the inner loop's engines (and the module-forward engines); None = True
-    train_winograd: Optional[bool] = None      # the training passes' engines (TrainEngine); None = False
+    train_winograd: Optional[bool] = None      # the training passes' engines (TrainEngine); None = True
     wino_appendix: bool = True        # the transformed weights are packed once per weight version behind the taps (MS_FETCH_WINO_U) instead of being recomputed per work item
     shared_device: Optional[bool] = None      # other kernels run beside the engine's launches: no co-residency kernels (single-read MaxStyle, `_xfin`).  None: MS_SHARED_DEVICE
     fuse_act_bwd: bool = True         # activation backward + BatchNorm-backward sums in the epilogue of the data-gradient conv (ms_conv2d_actbwd) vs a separate ms_act_bwd_reduce pass

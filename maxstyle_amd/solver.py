@@ -270,8 +270,10 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
     # True: this process shares its GPU with other processes / streams (several ranks per GPU): the inner loop must not select the single-read MaxStyle
     # kernel, whose grid assumes it gets every CU (engine.shared_device).  None: EngineOptions.shared_device (MS_SHARED_DEVICE; default off).
     loop_shared_device = None
-    # "sync": a spin time-out of the single-read kernel raises MaxStyleHipError from the call that produced the invalid image (one event wait per call);
-    # "deferred": the check is resolved by the next call / optimize_all_params / evaluate / save_model (no host stall on the hot path).  None = "sync".
+    # "deferred" (the default since round 5; None): a spin time-out of the single-read kernel is reported by the NEXT call at the latest, and before anything lasting is
+    # done with the image - optimize_all_params / optimize_params / evaluate / save_model / save_snapshots flush it (flush_loop_errors) - so the host prepares the next
+    # call while the GPU still runs this one; "sync": MaxStyleHipError is raised by the very call that produced the invalid image (one event wait per call: the host
+    # cannot run ahead, +0.8 ms per K = 5 call at config 2).
     loop_error_check = None
     loop_mfma_bf16 = None      # with bf16 storage: also bf16 matrix arithmetic in the 3x3 stride-1 convs (engine.mfma_bf16)
     # EngineOptions (maxstyle_amd/options.py; an object or a dict of its fields) of the engines this solver builds: the inner loop's / the training passes'.  Read when an
@@ -388,7 +390,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             steps = n_iter if optimize else 0
             recon_image = eng.run(code, labels, steps, use_graph=use_graph)
             eng.stash_config(sig)
-            mode = self.loop_error_check or "sync"
+            mode = self.loop_error_check or "deferred"
             eng.check_errors(sync=(mode != "deferred"))                 # the single-read MaxStyle kernel's error word (spin time-out): never silent
             with torch.no_grad():                                  # hand the optimised state back to the modules (debugging / tests)
                 for i in layers:

@@ -87,7 +87,139 @@ def shipped_case(dev, which, options=None):
         "dice": dsty, "dice_ref_f64": g["f64.final_dice"].tolist(), "dice_ref_f32": g["f32.final_dice"].tolist(),
         "dice_clean": dclean, "dice_clean_ref": g["f64.clean_dice"].tolist(),
         "dice_abs_diff": max(abs(a - b) for a, b in zip(dsty, g["f64.final_dice"])),
+        # the reference's own fp32 evaluations of this call (tests/golden/make_golden_r5.py shipped_draws: oneDNN at 8 / 2 threads, ATen native), each against its fp64 run
+        "draws": {k[len("ref_draws."):]: g[k].tolist() for k in g.files if k.startswith("ref_draws.") and g[k].dtype.kind == "f"},
         "std_rel": {f"{i}.{nm}": rel(eng.buf[f"st{i}.std"][j].reshape(-1), g[f"f64.{i}.{nm}"].reshape(-1)) for i in layers for j, nm in enumerate(("gamma_std", "beta_std"))},
         "params_rel": {f"{i}.{nm}": rel(getattr(S.last_style_modules[str(i)], nm), g[f"f64.step{K}.param.{i}.{nm}"]) for i in layers for nm in PN},
         "noise_params_rel": {f"{i}.{nm}": rel(g[f"f32.step{K}.param.{i}.{nm}"], g[f"f64.step{K}.param.{i}.{nm}"]) for i in layers for nm in PN},
     }
+
+
+def shipped_step1_gradients(dev, which):
+    """The step-1 gradient of every style tensor (one evaluation at the injected parameters: nothing chaotic yet) against the reference's fp64 gradient at the same point;
+    `draws` = the same error for each of the reference's own fp32 evaluations, per tensor."""
+    g, spec, img, lab, styles, layers = shipped_inputs(which, dev)
+    S = shipped_solver(dev, which)
+
+    def hook(mods):
+        for k, m in mods.items():
+            st = styles[int(k)]
+            m.perm = st.perm.clone()
+            with torch.no_grad():
+                m.gamma_noise.data = st.gamma_noise.to(dev); m.beta_noise.data = st.beta_noise.to(dev); m.lmda.data = st.lmda.to(dev)
+    S.style_init_hook = hook
+    z_i, _ = S.encode_image(img.to(dev), disable_track_bn_stats=True)
+    S.generate_max_style_image(z_i.detach(), layers, spec.channel_num, p=1.5, n_iter=1, lr=0.1, always_use_beta=bool(SHIPPED[which]["beta"]),
+                               reference_image=img.to(dev), reference_segmentation=lab.to(dev))
+    eng = next(iter(S._engines.values()))
+    names = [str(n) for n in g["ref_draws.tensor_names"]]
+    ours = {}
+    for n in names:
+        i, nm = n.split(".")
+        r64 = g[f"f64.step1.grad.{n}"].reshape(-1)
+        ours[n] = float(np.abs(eng.grad(int(i), nm).detach().cpu().numpy().astype(np.float64).reshape(-1) - r64).max() / np.abs(r64).max())
+    return {"winograd": bool(eng.winograd), "ours": ours, "draws": {n: g["ref_draws.step1_grad_err"][:, j].tolist() for j, n in enumerate(names)},
+            "first_loss_rel": abs(float(S.last_losses[0]) - float(g["f64.losses"][0])) / abs(float(g["f64.losses"][0]))}
+
+
+# ------------------------------------------------------------------------------------------------------------- kink census at the benchmarked sizes
+def one_step_buffers(dev, which, winograd):
+    """ONE inner step (n_iter = 1) of the benchmarked call `which` ("c2": trained FCN_16 at 16x1x256x256 | "c4": trained FCN_64 at 16x3x320x320) with the given conv form
+    -> the encoder / segmentor buffers of the engine (raw conv outputs and BatchNorm records: everything a LeakyReLU mask of the backward pass is decided from)."""
+    from maxstyle_amd import synthetic as syn
+    from maxstyle_amd.options import engine_defaults
+    import r3_cases as R3
+    import r4_cases as R4
+    with engine_defaults(winograd=winograd):
+        if which == "c2":
+            spec, size = syn.NetSpec(4, 1, 4), 256
+            S = R3.trained_solver(dev, "trained_fcn16_256.npz")
+        else:
+            spec, size = syn.NetSpec(1, 3, 2), 320
+            S = R4.trained_solver64(dev)
+        B, layers = 16, [3, 4, 5]
+        img, lab = syn.synthetic_batch(B, size, spec.image_ch, spec.num_classes, seed=1234)
+        styles = {i: syn.random_style_state(B, spec.channel_num[i], 7 + i) for i in layers}
+        S.style_init_hook = R4._inject_all(styles, dev)
+        z_i, _ = S.encode_image(img.to(dev), disable_track_bn_stats=True)
+        S.generate_max_style_image(z_i.detach(), layers, spec.channel_num, p=1.5, n_iter=1, lr=0.1, reference_image=img.to(dev), reference_segmentation=lab.to(dev))
+        eng = next(iter(S._engines.values()))
+        assert eng.winograd == winograd
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in eng.buf.items() if torch.is_tensor(v) and v.is_floating_point() and (k.startswith("e.") or k.startswith("s."))}
+
+
+def kink_census(bufs_a, bufs_b, eps=2e-5):
+    """For every raw conv output u whose BatchNorm + LeakyReLU mask the backward pass uses (`*.u1` / `*.ua` with `*.bn1.coef`, `*.u` with `*.bn.coef`): the largest forward
+    difference between the two runs (relative to the tensor's range), the elements whose masks differ, whether each of them has |pre-activation| < eps in BOTH runs, and the
+    size of the kink set (elements within eps of zero in either run)."""
+    out = {"tensors": 0, "elements": 0, "flips": 0, "flips_outside_kink_set": 0, "kink_set": 0, "worst_forward_rel": 0.0, "worst_flip_pre": 0.0, "per_tensor": {}}
+    for k, a in bufs_a.items():
+        if not (k.endswith(".u1") or k.endswith(".ua") or k.endswith(".u")):
+            continue
+        ck = k.rsplit(".", 1)[0] + (".bn.coef" if k.endswith(".u") else ".bn1.coef")
+        if ck not in bufs_a or k not in bufs_b:
+            continue
+        b = bufs_b[k]
+        fwd = float((a - b).abs().max()) / float(b.abs().max())
+        pre = [c[:, 0].view(1, -1, 1, 1) * u + c[:, 1].view(1, -1, 1, 1) for u, c in ((a, bufs_a[ck]), (b, bufs_b[ck]))]
+        diff = (pre[0] > 0) != (pre[1] > 0)
+        nd = int(diff.sum())
+        near = (pre[0].abs() < eps) | (pre[1].abs() < eps)
+        outside = int((diff & ~((pre[0].abs() < eps) & (pre[1].abs() < eps))).sum())
+        out["tensors"] += 1; out["elements"] += a.numel(); out["flips"] += nd; out["flips_outside_kink_set"] += outside; out["kink_set"] += int(near.sum())
+        out["worst_forward_rel"] = max(out["worst_forward_rel"], fwd)
+        if nd:
+            out["worst_flip_pre"] = max(out["worst_flip_pre"], float(torch.maximum(pre[0][diff].abs(), pre[1][diff].abs()).max()))
+        out["per_tensor"][k] = {"elements": a.numel(), "forward_rel": fwd, "flips": nd, "kink_set": int(near.sum())}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------- config 5's calls against fp64 twins, config 4 against draws
+def c5_call_vs_f64(dev, tag):
+    """One call of BASELINE config 5's stream (fp32 storage; r4_cases.c5_call_case's call) against the reference's FP64 run of it (loop_c5_calls_f64.npz, round 5), with the
+    reference's own fp32 evaluations of the same call beside it (loop_ref_draws.npz: `draw_*` lists, one entry per evaluation)."""
+    from maxstyle_amd import synthetic as syn
+    from test_solver_gpu import injector
+    import r3_cases as R3
+    import r4_cases as R4
+    g32 = np.load(os.path.join(GOLDEN, "loop_c5_calls.npz"))
+    g = np.load(os.path.join(GOLDEN, "loop_c5_calls_f64.npz"))
+    dr = np.load(os.path.join(GOLDEN, "loop_ref_draws.npz"))
+    c = R4.C5_CALLS[tag]
+    spec = syn.NetSpec(*c["spec"])
+    B, layers, K = 16, [3, 4, 5], int(g32[f"{tag}.K"])
+    S = R3.trained_solver(dev, "trained_fcn16_256.npz") if tag == "acdc" else R4.trained_solver64(dev)
+    img, lab = syn.synthetic_batch(B, c["size"], spec.image_ch, spec.num_classes, seed=int(g32[f"{tag}.seed"]))
+    img_d, lab_d = img.to(dev), lab.to(dev)
+    styles = {}
+    for i, ap in zip(layers, [bool(v) for v in g32[f"{tag}.applied"]]):
+        st = syn.random_style_state(B, spec.channel_num[i], 7 + i)
+        st.perm = torch.from_numpy(g32[f"{tag}.{i}.perm"]).clone()
+        st.applied = ap
+        styles[i] = st
+    S.style_init_hook = injector(styles, dev)
+    z_i, _ = S.encode_image(img_d, disable_track_bn_stats=True)
+    out = S.generate_max_style_image(z_i.detach(), layers, spec.channel_num, p=0.5, n_iter=K, lr=0.1, reference_image=img_d, reference_segmentation=lab_d,
+                                     fix_seed=int(g32[f"{tag}.fix_seed"]))
+    losses = S.last_losses.cpu().numpy().astype(np.float64)
+    scale = float(g[f"{tag}.image_scale"])
+    o = out.cpu().double()
+    d = o[:, :, ::4, ::4] - torch.from_numpy(g[f"{tag}.image.strided"]).double()
+    pred = segment(S, out).argmax(1).cpu()
+    ds = dice(pred, lab, spec.num_classes)
+    return {"strided_max": float(d.abs().max()) / scale, "strided_rms": float(d.pow(2).mean().sqrt()) / scale,
+            "mean_max": float(np.abs(o.mean(dim=(2, 3)).numpy() - g[f"{tag}.image.mean"]).max()) / scale,
+            "rms_max": float(np.abs(o.pow(2).mean(dim=(2, 3)).sqrt().numpy() - g[f"{tag}.image.rms"]).max()) / scale,
+            "losses_rel": (np.abs(losses - g[f"{tag}.losses"]) / np.abs(g[f"{tag}.losses"])).tolist(),
+            "labels_equal": float((pred.numpy() == g[f"{tag}.final_pred"]).mean()),
+            "dice_abs_diff": max(abs(a - float(b)) for a, b in zip(ds, g[f"{tag}.final_dice"])),
+            "variants": [str(v) for v in dr["variants"]],
+            "draw_strided_max": dr[f"{tag}.strided_max"].tolist(), "draw_strided_rms": dr[f"{tag}.strided_rms"].tolist(), "draw_mean_max": dr[f"{tag}.mean_max"].tolist(),
+            "draw_rms_max": dr[f"{tag}.rms_max"].tolist(), "draw_losses_rel": dr[f"{tag}.losses_rel"].tolist(), "draw_labels_equal": dr[f"{tag}.labels_equal"].tolist()}
+
+
+def c4_draws():
+    """The reference's own fp32 evaluations of the config-4 call against its fp64 run (loop_ref_draws.npz `c4.*`), for the bars of the config-4 test."""
+    dr = np.load(os.path.join(GOLDEN, "loop_ref_draws.npz"))
+    return {k[3:]: dr[k].tolist() for k in dr.files if k.startswith("c4.")} | {"variants": [str(v) for v in dr["variants"]]}

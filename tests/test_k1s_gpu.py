@@ -142,7 +142,8 @@ def test_streaming_1x1_conv_transpose_gemm_same_bits(dev, k1s, N, Cin, Cout, H, 
     assert torch.equal(a, t)
 
 
-@pytest.mark.parametrize("N,Cin,Cout,H,W", [(16, 512, 512, 20, 20), (16, 256, 512, 40, 40), (3, 256, 80, 18, 22), (16, 512, 256, 20, 20), (2, 320, 48, 64, 64), (16, 256, 16, 8, 8)])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(16, 512, 512, 20, 20), (16, 256, 512, 40, 40), (3, 256, 80, 18, 22), (16, 512, 256, 20, 20), (2, 320, 48, 64, 64), (16, 256, 16, 8, 8),
+                                               (20, 128, 128, 14, 14), (20, 128, 64, 14, 14), (3, 64, 40, 10, 14)])      # rows of 14 pixels: from 64 channels (round 5)
 def test_lds_tiled_1x1_gemm_same_bits_as_tiled(dev, N, Cin, Cout, H, W):
     """LDS-tiled GEMM form of the channel-heavy 1x1 convolutions (csrc/ms_conv_k1g.h) against the tiled kernel: same bits for the plain conv and the residual tail, the
     rider's records and the in-launch BatchNorm finalize of the tail unchanged; against fp64 math.  Shapes: ragged units (H W % 64 != 0), channel counts that are not

@@ -27,26 +27,63 @@ def dev():
 @pytest.mark.parametrize("which", ["acdc", "prostate"])
 def test_shipped_workload_vs_reference_run(dev, monkeypatch, which, winograd):
     """The reference's shipped call (20x1x192x192 ACDC / 20x1x224x224 Prostate with always_use_beta, FCN_16, layers [3,4,5], K = 5 free-running; decoder levels of
-    192..12 / 224..14 pixels) through the drop-in solver against the reference's own fp64 run of it (advanced_triplet...py:458-571): config 2's criteria -
-    image error <= 2x the reference's OWN fp32 error (max and rms), per-step losses <= max(5x its error, 5e-6), final parameters <= 3x its worst, labels >= 99.99 % equal,
-    Dice within 1e-3 - with the Winograd form of the wide convolutions (the default) and with the direct form."""
+    192..12 / 224..14 pixels) through the drop-in solver against the reference's own fp64 run of it (advanced_triplet...py:458-571), with the Winograd form of the wide
+    convolutions (the default) and with the direct form.
+    Calibration: the K = 5 trajectory is chaotic, and ONE fp32 run of the reference is one draw of its noise - its three fp32 evaluations of the ACDC call (oneDNN at 8 and
+    at 2 threads, ATen's native convolutions; `ref_draws.*` of the fixture) land 8.7e-5, 2.9e-4 and 5.9e-4 of the image range from its fp64 run.  Bars: image error <= 2x
+    the MEDIAN of the reference's draws (max and rms), per-step losses <= max(5x the largest draw at that step, 5e-6), final parameters <= 3x the largest draw,
+    labels >= 99.99 % equal, Dice within 1e-3; the non-chaotic quantities (code, frozen batch std) at fp32 rounding."""
     set_engine_default(monkeypatch, "winograd", winograd)
     r = R5.shipped_case(dev, which)
+    d = r["draws"]
     assert r["winograd"] == winograd
     assert r["z_i_rel"] < 5e-6
     for k, e in r["std_rel"].items():
         assert e < 2e-5, (k, e)                                        # gamma_std / beta_std frozen by the first forward (maxstyle.py:165-176)
-    assert r["image_max"] <= 2.0 * r["noise_image_max"], (r["image_max"], r["noise_image_max"])
-    assert r["image_rms"] <= 2.0 * r["noise_image_rms"], (r["image_rms"], r["noise_image_rms"])
-    for e, n in zip(r["losses_rel"], r["noise_losses_rel"]):
-        assert e <= max(5.0 * n, 5e-6), (r["losses_rel"], r["noise_losses_rel"])
-    worst_noise = max(r["noise_params_rel"].values())
+    assert len(d["image_max"]) >= 3
+    assert r["image_max"] <= 2.0 * float(np.median(d["image_max"])), (r["image_max"], d["image_max"])
+    assert r["image_rms"] <= 2.0 * float(np.median(d["image_rms"])), (r["image_rms"], d["image_rms"])
+    for s_, e in enumerate(r["losses_rel"]):
+        assert e <= max(5.0 * max(dr[s_] for dr in d["losses_rel"]), 5e-6), (s_, r["losses_rel"], d["losses_rel"])
+    worst_noise = max(max(dr) for dr in d["params_rel"])
     for k, e in r["params_rel"].items():
         assert e <= 3.0 * worst_noise, (k, e, worst_noise)
     assert r["labels_equal_f64"] >= 0.9999 and r["clean_labels_equal"] >= 0.9999
     assert r["dice_abs_diff"] <= 1e-3
     assert max(abs(a - b) for a, b in zip(r["dice_clean"], r["dice_clean_ref"])) <= 1e-3
     assert min(r["dice_clean"]) > 0.9 and max(r["dice"]) < 0.4          # a meaningful Dice, and a hard example
+
+
+@pytest.mark.parametrize("winograd", [True, False], ids=["winograd", "direct"])
+@pytest.mark.parametrize("which", ["acdc", "prostate"])
+def test_shipped_workload_first_step_gradients(dev, monkeypatch, which, winograd):
+    """Before anything chaotic happens: the gradient of -CE w.r.t. every style tensor at the injected parameters (step 1) against the reference's fp64 gradient at the
+    same point.  Direct conv form: per tensor within 3x the LARGEST error of the reference's own fp32 evaluations (measured 0.3-1.1x: the same LeakyReLU masks flip).
+    Winograd form (the loop's default; its rounding error on these activations is about twice the direct form's): within one kink event - a single flipped LeakyReLU
+    element moves a gradient by 1e-3 .. 4.5e-3 of its max norm here (tools/shipped_grad.py) - 1e-2."""
+    set_engine_default(monkeypatch, "winograd", winograd)
+    r = R5.shipped_step1_gradients(dev, which)
+    assert r["winograd"] == winograd and r["first_loss_rel"] < 2e-6
+    for n, e in r["ours"].items():
+        bar = 3.0 * max(r["draws"][n])
+        assert e <= (max(bar, 1e-2) if winograd else max(bar, 1e-4)), (n, e, r["draws"][n])
+
+
+@pytest.mark.parametrize("which", ["c2", "c4"])
+def test_kink_census_at_benchmarked_size(dev, which):
+    """the claim "every excess of the Winograd form over the direct form is a LeakyReLU kink event" asserted at the BENCHMARKED sizes (trained FCN_16 at
+    16x1x256x256; trained FCN_64 at 16x3x320x320), one step, both conv forms: every raw conv output of the encoder / segmentation decoder agrees between the forms to 1e-5
+    of its range, and every element whose LeakyReLU mask differs has a pre-activation within 2e-5 of zero in BOTH runs - i.e. lies in the kink set, whose size is reported
+    (the forms disagree on a few of its tens of millions of elements, and on nothing outside it)."""
+    a = R5.one_step_buffers(dev, which, True)
+    b = R5.one_step_buffers(dev, which, False)
+    c = R5.kink_census(a, b)
+    print(f"kink census {which}: {c['tensors']} mask-bearing tensors, {c['elements']} elements; forward agreement {c['worst_forward_rel']:.1e}; masks differ at {c['flips']} elements "
+          f"(largest |pre-activation| among them {c['worst_flip_pre']:.1e}), {c['flips_outside_kink_set']} of them outside the kink set; kink set (|pre| < 2e-5 in either run): {c['kink_set']}")
+    assert c["tensors"] >= 10 and c["elements"] > (30_000_000 if which == "c2" else 200_000_000)
+    assert c["worst_forward_rel"] <= 1e-5
+    assert c["flips_outside_kink_set"] == 0, c
+    assert c["flips"] <= c["kink_set"] and c["flips"] <= 2000          # measured: tens
 
 
 def test_batched_appendix_refresh_same_bits(dev):

@@ -329,15 +329,21 @@ def test_no_grad_forward_and_double_backward_guard(dev):
 def test_training_pass_full_size_vs_oracle(dev):
     """BASELINE config-2 batch (16x1x256x256): standard_training forward + backward against the CPU oracle (autograd over the functional forward) in fp32 AND fp64
     (about half a minute of host time).  Forward quantities: tight.  Parameter gradients: every fp32 forward is ~5e-6 away from the fp64 one at the top level (the fp32
-    oracle too), ~13 LeakyReLU masks per 16.7 M-element tensor flip, and a flipped mask changes that element's gradient by 80 % - WHICH masks flip depends on the order in
-    which the forward accumulates its products.  Measured over six input seeds x the two accumulation orders of the stride-2 convs (8- and 4-channel chunks, both in the
-    first-generation kernel; tools/dbg_train_seeds.py, profiles/r04_experiments.txt 12): worst parameter in the max norm 3.3e-3 .. 3.1e-2 (outliers on the 16 x 16-pixel
-    layers: down4, code_decoupler), in the L2 norm 1.7e-3 .. 7.7e-3; the fp32 ORACLE against the fp64 one: 1.9e-3 .. 5.2e-3 / 0.9e-3 .. 2.5e-3.  So the bar on the L2
-    norm is 2e-2 (2.6x the worst draw seen, 8x the reference side's own worst) and 8e-2 on the max norm; the backward kernels themselves are held to fp64 at a size where
-    no mask flips (test_training_pass_gradients_vs_oracle) and one by one (test_conv_gpu, test_wgrad_gpu)."""
+    oracle too), a handful of LeakyReLU masks per 16.7 M-element tensor flip, and a flipped mask changes that element's gradient by 80 % - WHICH masks flip depends on the
+    order in which the forward accumulates its products.  So the bar is calibrated on the reference side's OWN noise: the fp32 CPU
+    oracle against the fp64 one over 20 input seeds (tools/train_fidelity.py -> tests/golden/train_fidelity_oracle32.npz: per tensor its worst L2 / max-norm error), and
+    the GPU pass over the same 20 seeds (profiles/r05_train_fidelity.json): per tensor the GPU's worst L2 error is 1.3x (median) and at most 2.7x the fp32 oracle's worst,
+    with the direct AND with the Winograd conv form; worst tensor per seed in L2: oracle median 2.4e-3 / max 7.3e-3, GPU 2.8e-3 / 8.3e-3.
+    Bars: every tensor's L2 error <= 4x the fp32 oracle's worst for THAT tensor (this seed is the GPU's worst of the 20 in the max norm); the mean L2 error over the
+    tensors <= 2x the oracle's worst per-seed mean; the max norm - one flipped element moves it, 20 seeds do not sample its tail: oracle 2.5e-3 .. 1.7e-2, GPU up to
+    3.2e-2 - keeps the loose absolute backstop 8e-2.  The backward kernels themselves are held to fp64 at a size where no mask flips
+    (test_training_pass_gradients_vs_oracle) and one by one (test_conv_gpu, test_wgrad_gpu, test_k3n_gpu)."""
+    import numpy as np
     from oracle import maxstyle_oracle as orc
     from oracle import outer_oracle as outer
     torch.set_num_threads(min(32, os.cpu_count() or 1))
+    cal = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_fidelity_oracle32.npz"))
+    cal_l2 = {str(k): float(v) for k, v in zip(cal["keys"], cal["worst_l2"])}
     o32 = oracle_pass_grads(torch.float32, 16, 256, True)
     o64 = oracle_pass_grads(torch.float64, 16, 256, True)
     S, W = make_solver(dev, orc.NetSpec(4, 1, 4))
@@ -351,7 +357,8 @@ def test_training_pass_full_size_vs_oracle(dev):
     for got, key in ((S.z_i, "z_i"), (recon, "recon"), (y0, "logits")):
         assert rel(got.cpu().double(), o64[key]) < 3.0 * rel(o32[key].double(), o64[key]) + 1e-6, key
     (seg + rec).backward()
-    worst_max, worst_l2 = ("", 0.0), ("", 0.0)
+    worst_max, worst_l2, worst_ratio = ("", 0.0), ("", 0.0), ("", 0.0)
+    l2s = []
     for net in outer.NETS:
         for k, p in S.model[net].named_parameters():
             key = f"{net}/{k}"
@@ -360,12 +367,15 @@ def test_training_pass_full_size_vs_oracle(dev):
                 continue
             g = p.grad.detach().cpu().double()
             e_max, e_l2 = rel(g, ref), float((g - ref).norm() / ref.norm())
-            if e_max > worst_max[1]:
-                worst_max = (key, e_max)
-            if e_l2 > worst_l2[1]:
-                worst_l2 = (key, e_l2)
-            assert e_l2 < 2e-2 and e_max < 8e-2, (key, e_l2, e_max)
-    print("worst gradient error at full size vs fp64: max norm", worst_max, " L2", worst_l2)
+            l2s.append(e_l2)
+            worst_max = max(worst_max, (key, e_max), key=lambda t: t[1])
+            worst_l2 = max(worst_l2, (key, e_l2), key=lambda t: t[1])
+            worst_ratio = max(worst_ratio, (key, e_l2 / cal_l2[key]), key=lambda t: t[1])
+            assert e_l2 <= 4.0 * cal_l2[key], (key, e_l2, cal_l2[key])
+            assert e_max < 8e-2, (key, e_max)
+    assert len(l2s) == len(cal_l2)
+    assert sum(l2s) / len(l2s) <= 2.0 * float(cal["per_seed_mean_l2"].max()), (sum(l2s) / len(l2s), float(cal["per_seed_mean_l2"].max()))
+    print("worst gradient error at full size vs fp64: max norm", worst_max, " L2", worst_l2, " L2 / the fp32 oracle's worst over 20 seeds", worst_ratio)
 
 
 @pytest.mark.parametrize("graph_passes", ["0", "1"], ids=["eager_passes", "graph_passes"])

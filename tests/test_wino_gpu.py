@@ -206,16 +206,16 @@ def test_winograd_bit_is_ignored_where_the_form_is_not_built(dev):
 
 
 def test_which_engines_ask_for_the_winograd_form(dev, monkeypatch):
-    """The inner loop asks for the form (EngineOptions.winograd = False switches it off); the training passes keep the direct form - weight gradients at the reference's fidelity -
-    unless EngineOptions.train_winograd opts them in (forward / data-gradient convs only; measured in engine.py)."""
+    """Both engines ask for the form by default - the inner loop since round 2, the training passes' forward / data-gradient convs since round 5 (their weight-gradient
+    fidelity over 20 seeds equals the direct form's: profiles/r05_train_fidelity.json) - and EngineOptions.winograd / .train_winograd = False switch it off per engine."""
     from maxstyle_amd import engine as E
-    from maxstyle_amd.train_engine import TrainEngine
     from maxstyle_amd import options as O
+    from maxstyle_amd.train_engine import TrainEngine
     monkeypatch.delitem(O._engine_defaults, "winograd", raising=False); monkeypatch.delitem(O._engine_defaults, "train_winograd", raising=False)
     assert E.InnerLoopEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev).winograd
-    assert not TrainEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev).winograd
-    set_engine_default(monkeypatch, "train_winograd", True)
     assert TrainEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev).winograd
+    assert not TrainEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev, options={"train_winograd": False}).winograd
+    assert TrainEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev, options={"winograd": False}).winograd              # (the loop's switch is not the passes')
     set_engine_default(monkeypatch, "winograd", False)
     assert not E.InnerLoopEngine(E.NetSpec(4, 1, 4), 2, 64, 64, dev).winograd
 

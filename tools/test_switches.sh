@@ -60,5 +60,5 @@ run MS_OPTIONS=conv.k1s=0 $KNIFE -k "not (streamed or streaming_1x1 or k1s)"
 run MS_OPTIONS=conv.k1g=0 $KNIFE -k "not lds_tiled_1x1_gemm"
 run MS_OPTIONS=conv.s2g2=0 $KNIFE -k "not stride2_conv_second_generation"
 run MS_OPTIONS=engine.train_xfin=1 $KNIFE
-run MS_OPTIONS=engine.train_winograd=1 $KNIFE -k "not which_engines_ask"
+run MS_OPTIONS=engine.train_winograd=0 $KNIFE -k "not which_engines_ask"
 run MS_OPTIONS=engine.fuse_fin_act=0
