@@ -52,6 +52,8 @@ MS_STABLE const char* ms_last_error(void);
  *   "conv.k1s" "conv.k1g" "conv.s2g2"   1   0: the streaming / GEMM 1x1 forms, the second-generation stride-2 form are not chosen
  *   "conv.k3n"         1        0: 3x3 stride-1 convs on rows of 12 / 14 / 16 pixels stay on the first-generation kernel (csrc/ms_conv_k3n.h is the second generation:
  *                               flattened-pixel M-tiles, LDS-DMA / hoisted-offset staging; the same bits in `out` where the first generation runs 16-channel chunks)
+ *   "conv.k9"          1        ms_conv3x3_small_cin at Cin = 1, rows of whole 16-pixel M-tiles: the nine taps are the K dimension of the matrix instruction (3 MFMAs per
+ *                               16 pixels; the same bits in `out` as ms_conv2d on that layer) | 0: the vector-ALU form (another rounding)
  *   "conv.force_nt"    0        1 / 2 / 4: output-channel blocks of 16 per workgroup of the first-generation kernel (tuning)
  *   "style.fused"      1        0: ms_style_fwd never takes the single-read kernel (three-launch path)
  *   "diag.conv_dbg"    0        timing-only ablation bits of the conv kernels - results are WRONG with any bit set
@@ -64,6 +66,11 @@ MS_STABLE int ms_option_count(void);
 MS_STABLE const char* ms_option_name(int index);
 /* diagnostic builds only (-DMS_CONV_TRACE_BUILD / -DMS_WGRAD_TRACE_BUILD): device buffers (>= 8 KiB each, or NULL) for the in-kernel cycle stamps */
 MS_INTERNAL int ms_diag_set_trace(void* conv_trace, void* wgrad_trace);
+/* Layer-chain probe (tools/chain_probe.py): L plain 3x3 layers C -> C on N images of H x 16 pixels as ONE persistent launch with a grid barrier
+ * between layers (layer l reads a_buf / b_buf alternately and writes the other).  layers_dev: ms_diag_k3n_chain_bytes(L) bytes of device scratch; arrive: two device
+ * words, zero before the first call, owned by the probe afterwards; err: set to 1 if a barrier times out.  Not used by any product path. */
+MS_INTERNAL size_t ms_diag_k3n_chain_bytes(int L);
+MS_INTERNAL int ms_diag_k3n_chain(const float* a_buf, float* b_buf, const float* w_packed, int N, int C, int H, int L, void* layers_dev, unsigned* arrive, int* err, void* stream);
 /* bit of the `fetch` argument of the convolution entry points: the caller accepts the Winograd form for this call (see ms_conv2d) */
 #define MS_FETCH_WINOGRAD 0x100
 /* (bit 9, 0x200, was MS_FETCH_X3 - the three-way bf16 split form, built and measured 2x slower than the Winograd form in round 3, removed in round 5; the bit is rejected) */

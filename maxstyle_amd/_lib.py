@@ -38,6 +38,8 @@ SIGNATURES = {
     "ms_option_count": (c_int, []),
     "ms_option_name": (ctypes.c_char_p, [c_int]),
     "ms_diag_set_trace": (c_int, [c_void, c_void]),
+    "ms_diag_k3n_chain_bytes": (c_size, [c_int]),
+    "ms_diag_k3n_chain": (c_int, [c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_void, c_void, c_void, c_void]),
     "ms_style_ws_bytes": (c_size, [c_int, c_int, c_int]),
     "ms_style_moments": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_float, c_void, c_size, c_void]),
     "ms_style_coeffs": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_int, c_int, c_void]),

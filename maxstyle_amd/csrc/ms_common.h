@@ -38,6 +38,7 @@ enum Opt {
   OPT_CONV_K1G,           // "conv.k1g"         1: LDS-tiled GEMM 1x1 form where eligible
   OPT_CONV_S2G2,          // "conv.s2g2"        1: second-generation stride-2 3x3 form where eligible
   OPT_CONV_K3N,           // "conv.k3n"         1: second-generation 3x3 form for rows of 12 / 14 / 16 pixels where eligible (ms_conv_k3n.h)
+  OPT_CONV_K9,            // "conv.k9"          ms_conv3x3_small_cin at Cin = 1: 1: the nine taps as the K dimension of the MFMA (3 per 16 pixels, ms_conv2d's bits); 0: the vector-ALU form
   OPT_CONV_FORCE_NT,      // "conv.force_nt"    0: automatic; 1 / 2 / 4: output-channel blocks of 16 per workgroup (tuning: tools/tune_conv.py)
   OPT_STYLE_FUSED,        // "style.fused"      1: single-read MaxStyle kernel where its grid fits the chip; 0: three-launch path
   OPT_DIAG_CONV_DBG,      // "diag.conv_dbg"    timing-only ablation bits of the conv kernels (results are WRONG with any bit set): 1 no MFMA loop, 2 no global loads, 4 no stores, 8 no LDS stores, 16 no epilogue

@@ -45,11 +45,10 @@ struct K3nGeo {
 };
 
 // PRO: 0 none | 1 v = lrelu(a[c] v + b[c]) | 2 v = a[c] v + b[c] v2 + c[c]
-template <int W, int MT, int PRO>
-__global__ __launch_bounds__(512, 4) void conv_k3n_kernel(const ConvArgs a) {
+template <int W, int MT, int PRO, bool CHAINED = false>
+__device__ __forceinline__ void conv_k3n_body(const ConvArgs& a, float* smem) {
   using G = K3nGeo<W, MT>;
   constexpr int CK = G::CK, RS = G::RS, PS = G::PS, PIX = G::PIX, BUF = G::BUF, NJ = G::NJ, NWJ = G::NWJ, NE = G::NE, OOB = G::OOB;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* cf_lds = smem + 3 * BUF;                        // [cin_pad][4] prologue coefficients
   const int wave = MS_TID >> 6, lane = MS_TID & 63;
   const bool producer = wave >= 4;
@@ -371,8 +370,47 @@ __global__ __launch_bounds__(512, 4) void conv_k3n_kernel(const ConvArgs a) {
     }
     if (p + 1 < T) lds_barrier();
   }
-  if (a.stats != nullptr) conv_table_tail<1, true>(a, smem, vb, ncb, st_n, st_mean, st_m2);
-  else if (a.epi_mode == 3) conv_table_tail<1, false>(a, smem, vb, ncb, 0.f, st_mean, st_m2);
+  if constexpr (!CHAINED) {      // (the table tail synchronises the MFMA waves only: the staging waves of a stand-alone launch have returned)
+    if (a.stats != nullptr) conv_table_tail<1, true>(a, smem, vb, ncb, st_n, st_mean, st_m2);
+    else if (a.epi_mode == 3) conv_table_tail<1, false>(a, smem, vb, ncb, 0.f, st_mean, st_m2);
+  }
+}
+
+template <int W, int MT, int PRO>
+__global__ __launch_bounds__(512, 4) void conv_k3n_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  conv_k3n_body<W, MT, PRO>(a, smem);
+}
+
+// ---- go / no-go probe for a LAYER-CHAIN launch: L plain 3x3 layers (prologue-free, plain store) walked by ONE persistent
+// launch - the body above per layer, then a grid barrier (every wave drains its stores, one agent-scope release + arrival per workgroup, a bounded spin on the arrival
+// counter, an agent-scope acquire) instead of a launch boundary.  Diagnostics only (ms_diag_k3n_chain, tools/chain_probe.py): no product path launches it.
+template <int W, int MT>
+__global__ __launch_bounds__(512, 4) void conv_k3n_chain_kernel(const ConvArgs* __restrict__ layers, int L, unsigned* __restrict__ arrive, int* __restrict__ err) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const unsigned base = __hip_atomic_load(arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // arrivals of earlier launches (the host never resets the counter)
+  for (int l = 0; l < L; ++l) {
+    const ConvArgs a = layers[l];
+    conv_k3n_body<W, MT, 0, true>(a, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (MS_TID == 0) {
+      __atomic_thread_fence(__ATOMIC_RELEASE);            // (agent scope: the workgroup's stores leave this XCD's L2)
+      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned want = base + (unsigned)(l + 1) * gridDim.x;
+      for (unsigned spins = 0;; ++spins) {
+        if ((int)(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) break;
+        if (spins > (1u << 20)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && MS_TID == 0) {
+    // the last workgroup through would be cleaner; block 0 has seen every arrival of the last barrier: publish the new base for the next launch
+    __hip_atomic_store(arrive + 1, base + (unsigned)L * gridDim.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // Eligible: 3x3 stride 1, plain fetch, fp32 storage, rows of 12 / 14 / 16 pixels, whole 16-channel chunks, per-channel coefficients, 16-byte pixel quads

@@ -10,7 +10,11 @@
 //   * NT = 1, 2 or 4 sixteen-channel output blocks per staged patch (the deep layers re-read their patch from L2 once per 64 output channels, not once per 32);
 //   * GEO 0: 8 x 32-pixel output tiles.  GEO 1: sixteen independent 4 x 4-pixel output blocks per work item from a flattened (image, block row, block column) list, each
 //     with its own 9 x 12 patch: every output size that is a multiple of 4 fills its MFMA rows (20 x 20: 52 % -> 100 %).
-// fp32 storage, no prologue (the block-input convs of down2 .. down4; down1's input is the never-materialised `inc` activation: first generation), bias, no statistics.
+// fp32 storage, bias, no statistics.  PRO 0: no prologue (the block-input convs of down2 .. down4).  PRO 1 (round 5; GEO 0 only): v = lrelu(a[c] v + b[c]) per input channel
+// - down1's input is the never-materialised `inc` activation (37.8 us at config 2 on the first generation, profiles/r05_step_budget_c2.txt) - applied by the MFMA waves to
+// the fragments they read (the patch still travels by DMA; a staged value is activated once per output pixel that uses it, 2.25 x on average: 3 vector instructions per
+// element next to the MFMA it feeds), the coefficients from a table in LDS (given, or derived in the launch: `_xfin` kind 0); zero padding pads the ACTIVATED tensor:
+// with an even input only kernel row 0 of output row 0 and kernel column 0 of output column 0 leave the image - one wave-uniform and one per-lane select.
 #pragma once
 #include <cstdlib>
 #include <map>
@@ -44,8 +48,9 @@ struct S2Geo {
   static constexpr int OOB = (int)0x80000000;
 };
 
-template <int GEO, int NT>
+template <int GEO, int NT, int PRO>
 __global__ __launch_bounds__(512, 4) void conv_s2_kernel(const ConvArgs a) {
+  static_assert(PRO == 0 || GEO == 0, "the prologue form is built for the tile geometry");
   using G = S2Geo<GEO, NT>;
   constexpr int CK = G::CK, WSW = G::WSW, RS = G::RS, PS = G::PS, BSB = G::BSB, BUF = G::BUF, NJ = G::NJ, NWJ = G::NWJ, OOB = G::OOB, NBUF = G::NBUF;
   constexpr int COUT_TILE = 16 * NT;
@@ -63,6 +68,15 @@ __global__ __launch_bounds__(512, 4) void conv_s2_kernel(const ConvArgs a) {
   const int plane = a.Hs * a.Ws;
   auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   auto decode = [&](int it, int& n, int& tile, int& cb) { cb = it % ncb; const int t2 = it / ncb; tile = t2 % ntiles; n = t2 / ntiles; };
+  float* cf_lds = smem + NBUF * BUF;                     // PRO 1: [cin_pad][4] prologue coefficients
+
+  if (PRO != 0 && a.xf_tab == nullptr) {
+    for (int c = MS_TID; c < a.cin_pad; c += 512) {
+      float ca = 1.f, cb_ = 0.f;
+      if (c < a.Cin) { ca = a.pro_a[c * a.pro_cstride]; cb_ = a.pro_b[c * a.pro_cstride]; }
+      reinterpret_cast<float4*>(cf_lds)[c] = make_float4(ca, cb_, 0.f, 0.f);
+    }
+  }
 
   if (producer) {
     // =========================================== STAGING waves: LDS-DMA only ===========================================
@@ -159,6 +173,14 @@ __global__ __launch_bounds__(512, 4) void conv_s2_kernel(const ConvArgs a) {
   }
 
   // =========================================== MFMA waves ===========================================
+  if (PRO != 0 && a.xf_tab != nullptr) {
+    // the coefficients feed this launch's PROLOGUE: in LDS before the first chunk is read (barrier #0 / #1)
+    unsigned xf_tag = 0u;
+    int xf_nparts = 0;
+    xfin_header(a, xf_tag, xf_nparts);
+    if (!xfin_produce(a, xf_tag, xf_nparts)) __builtin_amdgcn_s_sleep(30);
+    xfin_fill<2>(a, cf_lds, a.cin_pad, xf_tag, vb & (kXfinRep - 1), MS_TID, 256, 1.f, 0.f);
+  }
   const int m = lane & 15, k = lane >> 4;
   f32x4 acc[4][NT];
 #pragma unroll
@@ -171,7 +193,9 @@ __global__ __launch_bounds__(512, 4) void conv_s2_kernel(const ConvArgs a) {
   auto mt_off = [](int i) { return (GEO == 0) ? (2 * (i >> 1) * RS + (i & 1) * 32) : (i * BSB); };
   const int b_lane = G::IN_FLOATS + k * WSW + m;
 
-  auto compute = [&](const float* buf) {
+  bool pad_top = false, pad_left = false;                // PRO 1: this tile holds output row 0 / output column 0
+  auto set_tile = [&](int tile) { pad_top = (tile / a.tiles_x == 0) && (wave == 0); pad_left = (tile % a.tiles_x == 0) && (m == 0); };
+  auto compute = [&](const float* buf, int chunk) {
     float bf[9][NT];
 #pragma unroll
     for (int q = 0; q < 9; ++q)
@@ -184,6 +208,18 @@ __global__ __launch_bounds__(512, 4) void conv_s2_kernel(const ConvArgs a) {
       for (int ky = 0; ky < 3; ++ky) {
         const float2 v = *reinterpret_cast<const float2*>(buf + a_lane + mt_off(i) + ky * RS);
         af[ky][0] = buf[a_lane + mt_off(i) + ky * RS - 1]; af[ky][1] = v.x; af[ky][2] = v.y;
+      }
+      if constexpr (PRO == 1) {
+        const float4 cf = reinterpret_cast<const float4*>(cf_lds)[chunk * CK + k];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            float v = leaky(cf.x * af[ky][kx] + cf.y, a.slope);
+            if (ky == 0 && (i >> 1) == 0) v = pad_top ? 0.f : v;          // input row -1
+            if (kx == 0 && (i & 1) == 0) v = pad_left ? 0.f : v;         // input column -1
+            af[ky][kx] = v;
+          }
       }
       __builtin_amdgcn_sched_barrier(0);
       // first generation's order: taps ascending (ky outer, kx inner)
@@ -234,15 +270,16 @@ __global__ __launch_bounds__(512, 4) void conv_s2_kernel(const ConvArgs a) {
   int item = vb, chunk = 0, n, tile, cb, ring = 0;
   decode(item, n, tile, cb);
   load_bias(cb);
+  set_tile(tile);
   lds_barrier();                                      // barrier #0
   lds_barrier();                                      // barrier #1: chunk 0 is in buffer 0
   for (int p = 0; p < T; ++p) {
-    compute(smem + ring * BUF);
+    compute(smem + ring * BUF, chunk);
     if (++ring == NBUF) ring = 0;
     if (chunk + 1 == nchunks) {
       epilogue(n, tile, cb);
       chunk = 0; item += gridDim.x;
-      if (p + 1 < T) { decode(item, n, tile, cb); load_bias(cb); }
+      if (p + 1 < T) { decode(item, n, tile, cb); load_bias(cb); set_tile(tile); }
     } else {
       ++chunk;
     }
@@ -251,9 +288,16 @@ __global__ __launch_bounds__(512, 4) void conv_s2_kernel(const ConvArgs a) {
 }
 
 int conv_s2g2_switch();      // ms_conv.hip: option "conv.s2g2" (0: off - A/B runs and the same-bits tests)
+inline void conv_s2g2_plan(const ConvArgs& a, int& geo, int& nt);
 inline bool conv_s2g2_eligible(const ConvArgs& a, int ks, int stride, int fetch) {
-  if (conv_s2g2_switch() == 0 || ks != 3 || stride != 2 || fetch != FETCH_NORMAL || a.act_bf16 != 0 || a.pro_mode != 0 || a.in2 != nullptr || a.stats != nullptr ||
-      a.epi_mode != 0 || a.xf_tab != nullptr || a.ride_out != nullptr) return false;
+  if (conv_s2g2_switch() == 0 || ks != 3 || stride != 2 || fetch != FETCH_NORMAL || a.act_bf16 != 0 || a.pro_mode > 1 || a.in2 != nullptr || a.stats != nullptr ||
+      a.epi_mode != 0 || a.ride_out != nullptr) return false;
+  if (a.pro_mode == 0 && a.xf_tab != nullptr) return false;
+  if (a.pro_mode == 1) {                     // per-channel coefficients, the tile geometry, a BatchNorm-apply record when derived in the launch
+    int geo, nt;
+    conv_s2g2_plan(a, geo, nt);
+    if (geo != 0 || a.pro_nstride != 0 || (a.xf_tab != nullptr && a.xf_kind != 0) || a.Hs != 2 * a.Hout || a.Ws != 2 * a.Wout) return false;
+  }
   if (a.Ws % 8 != 0 || a.Hs % 2 != 0 || a.Cin % 4 != 0 || a.Cin < 16) return false;                    // 16-byte pieces on both sides, whole 4-channel chunks
   if (a.Wout <= 16) return false;            // the 16-pixel level keeps the first generation's 4 x 16 tiles (128 -> 128 @16x32x32 -> 16x16: 30 against 33 us; tools/ab_subpix.py)
   if ((long long)a.N * a.Cin * a.Hs * a.Ws * 4 >= (1LL << 31) || 9LL * a.cin_pad * a.cout_pad * 4 >= (1LL << 31)) return false;
@@ -272,12 +316,12 @@ inline void conv_s2g2_plan(const ConvArgs& a, int& geo, int& nt) {
   for (int cand : {4, 2}) if (a.Cout >= 16 * cand && 2 * units * cdiv(a.Cout, 16 * cand) >= 3L * num_cus()) { nt = cand; break; }      // (>= 1.5 work items per CU)
 }
 
-template <int GEO, int NT>
+template <int GEO, int NT, int PRO>
 int launch_conv_s2_t(ConvArgs a, hipStream_t st) {
   using G = S2Geo<GEO, NT>;
-  const size_t lds_bytes = sizeof(float) * G::NBUF * (size_t)G::BUF;
+  const size_t lds_bytes = sizeof(float) * (G::NBUF * (size_t)G::BUF + (PRO ? 4 * (size_t)a.cin_pad : 0));
   static std::once_flag attr_once;
-  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_s2_kernel<GEO, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
+  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_s2_kernel<GEO, NT, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
   a.ncb = cdiv(a.Cout, 16 * NT);
   long nitems;
   if (GEO == 0) { a.tiles_x = cdiv(a.Wout, 32); a.tiles_y = cdiv(a.Hout, 8); nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb; }
@@ -285,7 +329,7 @@ int launch_conv_s2_t(ConvArgs a, hipStream_t st) {
   const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;
-  MS_LAUNCH((conv_s2_kernel<GEO, NT>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
+  MS_LAUNCH((conv_s2_kernel<GEO, NT, PRO>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
   return check_launch("conv_s2");
 }
 

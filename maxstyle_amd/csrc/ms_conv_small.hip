@@ -336,21 +336,124 @@ extern "C" int ms_conv3x3_small_cout_bf16(const uint16_t* in, const uint16_t* in
   return small_cout_impl<ms_bf16>(in, in2, out, w_packed, N, Cin, H, W, Cout, pro_mode, pro_a, pro_b, pro_c, pro_cstride, stream);
 }
 
-// 1: the entry point takes the shape AND is the faster choice (measured at Cin = 1 only: 30 vs 34 us at 16x1x256x256; with 2..4 input channels the kernel is
-// correct but its 300..600 weights no longer fit the scalar registers); 0: use ms_conv2d
+// 1: the entry point takes the shape AND is the faster choice (Cin = 1: rows of whole 16-pixel M-tiles take the taps-as-K matrix form - ms_conv2d's bits; other
+// rows the vector form, 30 vs 34 us at 16x1x256x256, ANOTHER rounding; with 2..4 input channels the vector kernel is correct but its 300..600 weights no longer fit the
+// scalar registers); 0: use ms_conv2d
 extern "C" int ms_conv3x3_small_cin_ok(int Cin, int Cout, int W) { return (Cin == 1 && Cout == kSciCout && W % 4 == 0) ? 1 : 0; }
 
 // out [N,16,H,W] = conv3x3(in [N,Cin,H,W], w) + bias, Cin <= 4, stride 1, padding 1; w = packed forward weights [9][cin_pad][cout_pad] (ms_conv2d's layout).
 // stats (may be NULL): the statistics table of ms_conv2d ([1 + 16 * ms_conv_stats_parts()] float4, header {slots, epoch}) for ms_bn_finalize / the `_xfin` consumers.
+// Third form (round 5), Cin = 1: the nine TAPS are the K dimension of the matrix instruction.  A lane (m, k) of MFMA j holds tap 4 j + k of pixel m of a 16-pixel
+// M-tile - read straight from the (L2-resident, 4 MB at config 2) image with buffer loads whose out-of-image offsets return the conv's zero padding - against the
+// weight of that tap for output channel m: 3 MFMAs per 16 pixels x 16 channels (the padded 8-channel chunk of the general kernels issues 18, the vector form above
+// ~800 FMAs per thread).  No LDS, no staging waves: a wave walks strips of 64 pixels of one image row (4 M-tiles: 12 loads, 12 MFMAs, 4 x 16-byte stores per lane),
+// keeps the per-lane running (count, mean, M2) of its output channel and ends in the conv kernels' table tail (one slot per workgroup).  What remains is the 67 MB
+// write.  The matrix instruction adds its four K products to the accumulator one after the other, in K order (measured: the output has the BITS of the general kernels,
+// which feed the same taps one per instruction - tests/test_k9_gpu.py), so the layer's rounding does not depend on which kernel ran it.
+__global__ __launch_bounds__(256) void conv3x3_k9_kernel(const ConvArgs a, int nsx) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 3];
+  constexpr int NJ = 3;
+  constexpr int OOB = (int)0x80000000;
+  const int wave = MS_TID >> 6, lane = MS_TID & 63, m = lane & 15, k = lane >> 4;
+  const int H = a.Hs, W = a.Ws;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((unsigned)a.N * H * W * 4u), 0x00020000);
+  // lane constants: tap of MFMA j, its weight, its (dy, dx)
+  float bw[NJ];
+  int dy[NJ], dx[NJ], loff[NJ];
+  bool tv[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int tap = 4 * j + k;
+    tv[j] = tap < 9;
+    const int tp = min(tap, 8);
+    dy[j] = tp / 3 - 1; dx[j] = tp % 3 - 1;
+    loff[j] = (dy[j] * W + dx[j] + m) * 4;
+    bw[j] = tv[j] ? a.w[(size_t)tp * a.cin_pad * a.cout_pad + m] : 0.f;
+  }
+  const float bias_v = (a.bias != nullptr) ? a.bias[m] : 0.f;
+  const int nstrips = a.N * H * nsx;
+  float st_n = 0.f, st_mean[1] = {0.f}, st_m2[1] = {0.f};
+  for (int s = (int)blockIdx.x * 4 + wave; s < nstrips; s += (int)gridDim.x * 4) {
+    const int sx = s % nsx, row = s / nsx;              // row = n * H + y
+    const int y = row % H;
+    const int x0 = sx * 64;
+    const int base = (row * W + x0) * 4;
+    float av[4][NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const bool rok = tv[j] && ((unsigned)(y + dy[j]) < (unsigned)H);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool ok = rok && ((unsigned)(x0 + 16 * t + m + dx[j]) < (unsigned)W);
+        av[t][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, ok ? (base + 64 * t + loff[j]) : OOB, 0, 0));
+      }
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][j], bw[j], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] += bias_v;
+    }
+    // D layout: this lane holds output channel m of pixels x0 + 16 t + 4 k .. + 3 (W % 16 == 0: an M-tile is inside the row or outside it)
+    const int nt_ok = min(4, (W - x0) >> 4);
+    if (a.stats != nullptr) {
+      const float cnt = 4.f * (float)nt_ok;
+      const float rc = __builtin_amdgcn_rcpf(cnt);
+      const float ntot = st_n + cnt;
+      const float wgt = cnt * __builtin_amdgcn_rcpf(ntot);
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum += (t < nt_ok) ? acc[t][r] : 0.f;
+      const float mean = sum * rc;
+      float q = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = acc[t][r] - mean; q += (t < nt_ok) ? d * d : 0.f; }
+      const float d = mean - st_mean[0];
+      st_mean[0] += d * wgt;
+      st_m2[0] += q + d * d * st_n * wgt;
+      st_n = ntot;
+    }
+    const int n = row / H;
+    float* op = a.out + ((size_t)(n * 16 + m) * H + y) * W + x0 + 4 * k;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < nt_ok) *reinterpret_cast<float4*>(op + 16 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  }
+  if (a.stats != nullptr) conv_table_tail<1, true>(a, red, (int)blockIdx.x, 1, st_n, st_mean, st_m2);
+}
+
+static int conv_k9_launch(const float* in, float* out, const float* w_packed, const float* bias, int N, int H, int W, float* stats, hipStream_t st) {
+  ConvArgs a{};
+  a.in = in; a.out = out; a.w = w_packed; a.bias = bias; a.stats = stats;
+  a.N = N; a.Cin = 1; a.Hs = H; a.Ws = W; a.Hin = H; a.Win = W; a.Cout = kSciCout; a.Hout = H; a.Wout = W;
+  a.cin_pad = 4; a.cout_pad = 64; a.cout_real = kSciCout; a.ncb = 1;
+  const int nsx = cdiv(W, 64);
+  const long nstrips = (long)N * H * nsx;
+  const int grid = (int)std::min<long>(cdiv(nstrips, 4L), std::min<long>(8L * num_cus(), kStatSlots));
+  MS_LAUNCH(conv3x3_k9_kernel, dim3(grid), dim3(256), 0, st, a, nsx);
+  return check_launch("conv3x3_k9");
+}
+
 template <typename AT>
 static int small_cin_impl(const void* in, void* out, const float* w_packed, const float* bias, int N, int Cin, int H, int W, int Cout, float* stats, void* stream) {
   if (N < 1 || H < 1 || W < 1 || Cin < 1 || Cin > 4 || Cout != kSciCout || W % 4 != 0) { set_error("ms_conv3x3_small_cin: Cin <= 4, Cout == 16, W %% 4 == 0"); return MS_ERR_INVALID; }
   if (!aligned16(in) || !aligned16(out) || (stats != nullptr && !aligned16(stats))) { set_error("ms_conv3x3_small_cin: tensors must be 16-byte aligned"); return MS_ERR_ALIGN; }
+  hipStream_t st = (hipStream_t)stream;
+  if constexpr (sizeof(AT) == 4) {           // Cin = 1, rows of whole M-tiles, fp32 storage: the taps-as-K matrix form (option "conv.k9"; 0: the vector form)
+    if (Cin == 1 && W % 16 == 0 && opt(OPT_CONV_K9) != 0 && (long long)N * H * W * 4 < (1LL << 31) && aligned16(w_packed))
+      return conv_k9_launch((const float*)in, (float*)out, w_packed, bias, N, H, W, stats, st);
+  }
   const int tiles_x = cdiv(W, kSmTW), tiles_y = cdiv(H, kSmTH);
   const long ntiles = (long)N * tiles_x * tiles_y;
   const int cin_pad = (Cin + 3) / 4 * 4, cout_pad = (Cout + 63) / 64 * 64;
   const int grid = (int)std::min<long>(ntiles, std::min<long>((Cin == 1 ? 3L : 2L) * num_cus(), kStatSlots));      // resident workgroups per CU: 143 VGPRs at Cin = 1
-  hipStream_t st = (hipStream_t)stream;
 #define MS_SCI(CI) MS_LAUNCH((conv3x3_small_cin_kernel<CI, AT>), dim3(grid), dim3(256), 0, st, in, out, w_packed, bias, (float4*)stats, N, H, W, cin_pad, cout_pad, tiles_x, tiles_x * tiles_y)
   switch (Cin) { case 1: MS_SCI(1); break; case 2: MS_SCI(2); break; case 3: MS_SCI(3); break; default: MS_SCI(4); }
 #undef MS_SCI

@@ -423,6 +423,7 @@ struct TailArgs {
 };
 __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs a) {
   __shared__ double redd[16];
+  __shared__ float2 stage[1024];
   // (every global load below misses the caches - the data was just written by kernels on other XCDs - so a block is a chain of ~2 us round trips: the
   //  independent ones are issued together up front, and the cross-entropy sum has its own block row instead of queueing behind a layer's work)
   const int slot = *a.step_dev;                    // every block reads the counter before it arrives below
@@ -452,12 +453,20 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const TailArgs a) {
         a.p[i] = a.p[i] - step_size * (mi / denom);
       };
       double acc = 0.0;
+      // the S partial records of the block's C channels: one load per thread where they fit (a 16-channel layer kept 16 threads busy with S dependent ~2 us
+      // round trips each), parked in LDS and summed per channel in the order s = 0, 1, ... as before (the same bits)
+      const bool staged = (C * S <= 1024);
+      if (staged) {
+        for (int i = threadIdx.x; i < C * S; i += blockDim.x) stage[i] = part[(size_t)b * C * S + i];
+        __syncthreads();
+      }
       for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const int p = b * C + c;
         const int q = pb * C + c;
         const double dsig = (double)L.sig[q] - (double)L.sig[p], dmu = (double)L.mu[q] - (double)L.mu[p];
         double s1 = 0.0, s2 = 0.0;
-        for (int s = 0; s < S; ++s) { const float2 v2 = part[(size_t)p * S + s]; s1 += (double)v2.x; s2 += (double)v2.y; }
+        if (staged) { for (int s = 0; s < S; ++s) { const float2 v2 = stage[c * S + s]; s1 += (double)v2.x; s2 += (double)v2.y; } }
+        else { for (int s = 0; s < S; ++s) { const float2 v2 = part[(size_t)p * S + s]; s1 += (double)v2.x; s2 += (double)v2.y; } }
         if (L.off_gamma >= 0) {
           const float dg = (float)((double)L.gamma_std[c] * s2), db = (float)((double)L.beta_std[c] * s1);
           a.g[L.off_gamma + p] = dg; a.g[L.off_beta + p] = db;

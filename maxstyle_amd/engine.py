@@ -986,7 +986,8 @@ class InnerLoopEngine:
         """MyEncoder.forward + code_decoupler (encoder_decoder.py:469-482, 673-680) in BN batch-stat mode."""
         e = self.nets.enc
         c0 = e["inc0"]
-        if self.small_cin and not self.bn_eval and lib.ms_conv3x3_small_cin_ok(c0.cin, c0.cout, image.shape[3]) == 1:
+        # (rows of whole 16-pixel tiles in fp32 storage take the taps-as-K matrix form - ms_conv2d's bits; the vector form behind the same entry point rounds differently)
+        if self.small_cin and not self.bn_eval and not self.bf16 and image.shape[3] % 16 == 0 and lib.ms_conv3x3_small_cin_ok(c0.cin, c0.cout, image.shape[3]) == 1:
             N_, _, H_, W_ = image.shape
             ua = self.a("e.inc.ua", N_, c0.cout, H_, W_)
             p = lib.ms_conv_stats_parts(N_, H_, W_)

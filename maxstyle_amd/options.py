@@ -35,7 +35,7 @@ class EngineOptions:
     fuse_skip: bool = True            # residual-block tail as one launch (ms_conv1x1_bnres) vs ms_conv2d(ks=1) + ms_bn_act
     subpix: bool = True               # sub-pixel form of the two x2 resampling convolutions (results agree to fp32 rounding with the fused-fetch form)
     small_cout: bool = True           # vector-ALU kernel for the data-gradient that reaches the image
-    small_cin: bool = False           # vector-ALU kernel for the encoder's first conv (another rounding: DESIGN.md section 7)
+    small_cin: bool = True            # ms_conv3x3_small_cin for the encoder's first conv (taps-as-K matrix form: ms_conv2d's bits on rows of whole 16-pixel tiles)
     lazy_inc: bool = True             # the activation after the encoder's first double conv is never written (inner loop only)
     fuse_tail: bool = True            # ms_step_tail: the six launches that end a step as one
     fuse_fin_act: bool = True         # ms_bn_finalize_act for z_i / z_s (inner loop only)

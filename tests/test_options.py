@@ -50,7 +50,7 @@ def test_option_table_round_trip():
 def test_engine_options_object():
     from maxstyle_amd import options as O
     d = O.engine_options()
-    assert d.winograd is None and d.train_winograd is None and d.ride and d.xfin and not d.small_cin and d.shared_device is False
+    assert d.winograd is None and d.train_winograd is None and d.ride and d.xfin and d.small_cin and d.shared_device is False
     assert len(O._FIELDS) <= 24
     assert O.engine_options({"ride": False}).ride is False
     assert O.engine_options(O.EngineOptions(xfin=False)).xfin is False

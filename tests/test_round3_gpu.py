@@ -65,10 +65,13 @@ def test_drop_in_arguments_vs_reference_run(dev, case):
     # gradient is scaled by 0.2 instead of 1 and every style gradient moves by ~1e-4 .. 1e-3; profiles/r04_all6_flip.txt takes one apart).  Measured, image / parameters
     # (profiles/r04_parity_report.txt): without an event 6e-7 .. 2e-6 / 6e-7 .. 6e-5 here and 4e-7 .. 2e-6 / 1e-6 .. 3e-5 in the reference's own fp32 run; with one
     # 1.1e-5 .. 5.5e-5 / 1.7e-4 .. 1.5e-3 here (nomix, mixfixed, lw05) and 4e-5 .. 2.9e-4 / 5.6e-4 .. 2.1e-3 in the reference's (mixfixed, lw05, twoterms, lr003).
+    # WHICH cases meet an event changes with every legitimate re-rounding of a kernel: round 5's stride-2 prologue kernel (another chunk order in e.d1.xd) moved one into
+    # `nonoise` / `noisefixed` (3.lmda 8.3e-4; image 4.7e-5).  The parameter floor is therefore the largest single event the REFERENCE's own fp32 run shows on these
+    # cases (2.1e-3 -> 2.5e-3), the image floor stays north_star's 1e-4.
     assert r["image_rel"] <= max(3.0 * r["noise_image_rel"], 1e-4), (r["image_rel"], r["noise_image_rel"])     # 1e-4: north_star's stated tolerance
     worst_noise = max(list(r["noise_params_rel"].values()) + [0.0])
     for k, e in r["params_rel"].items():
-        assert e <= max(3.0 * worst_noise, 5e-4), (k, e, worst_noise)
+        assert e <= max(3.0 * worst_noise, 2.5e-3), (k, e, worst_noise)
     assert r["labels_equal"] >= 0.9998 and r["dice_abs_diff"] <= 5e-3   # 16384 pixels: one flipped label is 6e-5 / up to 3e-3 of a class's Dice
 
 
