@@ -1204,6 +1204,15 @@ class InnerLoopEngine:
         self._upload(f"st{i}.gamma_noise", gamma_noise, self.param(i, "gamma_noise"))
         self._upload(f"st{i}.beta_noise", beta_noise, self.param(i, "beta_noise"))
 
+    def preset_style_std(self, i, gamma_std, beta_std):
+        """maxstyle.py:165-168: a layer that already holds gamma_std / beta_std keeps them (`if self.gamma_std is None: ...`) - the call starts with the batch std frozen
+        at the given values instead of deriving it from its first forward.  After configure_styles / restore_config; the caller runs such a call without graphs."""
+        s = self.styles[i]
+        std = self.t(f"st{i}.std", 2, s.C)
+        std[0].copy_(gamma_std.detach().reshape(-1).to(device=self.dev, dtype=F32))
+        std[1].copy_(beta_std.detach().reshape(-1).to(device=self.dev, dtype=F32))
+        s.have_std = True
+
     def style_fwd(self, i, x, store=True):
         """store=False: statistics and coefficients only (y = NULL) - the caller's next kernel applies the layer itself; returns None then."""
         s = self.styles[i]

@@ -378,9 +378,13 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             if not eng.restore_config(sig):
                 eng.configure_styles(layers, slots)
             eng._cfg_sig = sig
+            preset_std = False
             for i in layers:
                 m = mods[i]
                 eng.set_style_state(i, m.perm, m.lmda.detach(), m.gamma_noise.detach(), m.beta_noise.detach())
+                if m.gamma_std is not None and m.beta_std is not None:       # (only a style_init_hook can have set them: maxstyle.py:165-168 keeps a std it already holds)
+                    eng.preset_style_std(i, m.gamma_std, m.beta_std)
+                    preset_std = True
             eng.lr = lr_
             eng.loss_sign = loss_sign
             eng.bn_eval = bn_eval
@@ -388,7 +392,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             if optimize and n_iter > 0:
                 labels = reference_segmentation.to(device=code.device, dtype=torch.int64).contiguous()
             steps = n_iter if optimize else 0
-            recon_image = eng.run(code, labels, steps, use_graph=use_graph)
+            recon_image = eng.run(code, labels, steps, use_graph=use_graph and not preset_std)
             eng.stash_config(sig)
             mode = self.loop_error_check or "deferred"
             eng.check_errors(sync=(mode != "deferred"))                 # the single-read MaxStyle kernel's error word (spin time-out): never silent

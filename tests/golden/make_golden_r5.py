@@ -1,6 +1,6 @@
 """Round-5 golden vectors, produced by running the REFERENCE here (needs /root/reference; older fixtures are left untouched).
 
-    python tests/golden/make_golden_r5.py [train_p224] [train_a192] [shipped] [shipped_draws] [c5f64] [draws]
+    python tests/golden/make_golden_r5.py [train_p224] [train_a192] [shipped] [shipped_draws] [shipped_forced] [forced_full] [c5f64] [draws]
 
 The reference's SHIPPED workloads (the only sizes a user of the reference actually runs; VERDICT r4 missing 2):
   config/ACDC/1500_epoch/MICCAI2022_MaxStyle.json:24-28,40-43,51,56-76    crop 192x192x1, FCN_16, 4 classes, batch 20, K = 5, layers [3,4,5], lr 0.1, always_use_beta false
@@ -13,6 +13,15 @@ shipped    -> loop_shipped_acdc.npz, loop_shipped_prostate.npz : the reference's
               20x1x192x192 / 20x1x224x224, layers [3,4,5], K = 5, lr 0.1, always_use_beta as the JSON says - in fp32 and fp64 on the trained weights; state injected
               (perm / noise from orc.random_style_state; lmda for the Prostate call = Beta(0.1, 0.1) draws, stored as `initial.{i}.lmda`): losses, per-step parameters,
               gamma_std / beta_std, the fp64 image, labels, Dice and the reference's OWN fp32-vs-fp64 noise - the same keys as loop_full_c2.npz.
+shipped_forced -> adds `forced.*` to both shipped fixtures: TEACHER-FORCED evaluations.  The K = 5 free-running loop is chaotic (Adam's first steps are sign-like:
+              an element whose gradient is below the fp32 noise of the pass moves by +-lr whichever way the noise points), so a free-running comparison measures a draw.
+              Here the reference evaluates ONE step at the parameters its own fp64 run held before step k (k = 2..K; k = 1 is `f64.step1.grad.*`): loss and the gradient of every
+              style tensor in fp64 (`forced.f64.step{k}.loss`, `forced.f64.step{k}.grad.{i}.{name}`), plus the max-norm error of its fp32 evaluations at the same point
+              (oneDNN and ATen native; `forced.draws.grad_err[draw, k-2, tensor]`, `forced.draws.loss_rel[draw, k-2]`).  Nothing chaotic: a smooth map evaluated at given points.
+forced_full -> loop_forced_full.npz : the same teacher-forced evaluations for the BENCHMARKED calls - config 2 (loop_full_c2.npz: trained FCN_16, 16x1x256x256, K = 5) and
+              config 4 (loop_full_c4.npz: trained FCN_64, 16x3x320x320, K = 10): for k = 1..K the reference's fp64 loss and style gradients at the parameters (and frozen batch
+              std) its fp64 run held before step k (`c2.step{k}.loss`, `c2.step{k}.grad.{i}.{name}`, `c4....`), and the errors of two fp32 evaluations of the reference at
+              the same points (`c2.draws.grad_err[draw, k-1, tensor]`, `c2.draws.loss_rel[draw, k-1]`).
 c5f64      -> loop_c5_calls_f64.npz : fp64 twins of BOTH calls of loop_c5_calls.npz (VERDICT r4 missing 4 / next 6a): same batch, same fix_seed draw (checked: the fp64 run
               applies the same layers with the same perm), same injected state cast to fp64: losses, per-plane moments, a strided image sample, labels, Dice, plus the
               distance of the COMMITTED fp32 fixture from it (`ref_noise.*`).
@@ -210,7 +219,7 @@ def shipped_draws(solver_mod):
         ref = torch.from_numpy(g["f64.image"]).double()
         scale = float(g["image_scale"])
         names = [f"{i}.{n}" for i in layers for n in PNAMES]
-        acc = {k: [] for k in ("image_max", "image_rms", "losses_rel", "step1_grad_err", "params_rel", "labels_equal")}
+        acc = {k: [] for k in ("image_max", "image_rms", "image_max_per_sample", "image_rms_per_sample", "losses_rel", "step1_grad_err", "params_rel", "labels_equal")}
         for vname, nt, mkl in DRAW_VARIANTS:
             with torch.backends.mkldnn.flags(enabled=mkl):
                 torch.set_num_threads(nt)
@@ -231,12 +240,14 @@ def shipped_draws(solver_mod):
                 pred = segment(R, out).argmax(1).numpy().astype(np.uint8)
             d = out.double() - ref
             acc["image_max"].append(float(d.abs().max()) / scale); acc["image_rms"].append(float(d.pow(2).mean().sqrt()) / scale)
+            acc["image_max_per_sample"].append((d.abs().amax(dim=(1, 2, 3)) / scale).numpy()); acc["image_rms_per_sample"].append((d.pow(2).mean(dim=(1, 2, 3)).sqrt() / scale).numpy())
             acc["losses_rel"].append(np.abs(np.array(spy.losses) - g["f64.losses"]) / np.abs(g["f64.losses"]))
             acc["step1_grad_err"].append(np.array([float(np.abs(gr.numpy().astype(np.float64).reshape(-1) - g[f"f64.step1.grad.{n}"].reshape(-1)).max()
                                                          / np.abs(g[f"f64.step1.grad.{n}"]).max()) for n, gr in zip(names, spy.grads[0])]))
             acc["params_rel"].append(np.array([float(np.abs(p_.numpy().astype(np.float64).reshape(-1) - g[f"f64.step{K}.param.{n}"].reshape(-1)).max()
                                                      / np.abs(g[f"f64.step{K}.param.{n}"]).max()) for n, p_ in zip(names, spy.params[-1])]))
             acc["labels_equal"].append(float((pred == g["f64.final_pred"]).mean()))
+            print(tag, vname, "per-sample rms", " ".join("%.1e" % v for v in acc["image_rms_per_sample"][-1]), flush=True)
             print(tag, vname, "image max %.3e rms %.3e" % (acc["image_max"][-1], acc["image_rms"][-1]), "losses", ["%.1e" % e for e in acc["losses_rel"][-1]],
                   "step-1 gradients", ["%.1e" % e for e in acc["step1_grad_err"][-1]], flush=True)
         # (the fixture keeps the fp64 image as fp32: the distances here are against that copy - equal to the fixture's own ref_noise.* to ~1e-3 of their value)
@@ -247,6 +258,124 @@ def shipped_draws(solver_mod):
             g["ref_draws." + k] = np.array(v)
         np.savez_compressed(path, **g)
         print(name, os.path.getsize(path), flush=True)
+
+
+FORCED_VARIANTS = (("mkldnn_t8", 8, True), ("native_t8", 8, False))
+
+
+def shipped_forced(solver_mod):
+    """See the module docstring: one step of the reference at the parameters its fp64 run held before step k, k = 2..K, in fp64 and in two fp32 evaluations."""
+    for tag, mk, spec, size, beta, name in (("acdc192", lambda dt: trained_reference(solver_mod, dt, "trained_fcn16_192.npz"), SPEC_A, 192, False, "loop_shipped_acdc.npz"),
+                                            ("prostate224", lambda dt: reference_p224(solver_mod, dt), SPEC_P, 224, True, "loop_shipped_prostate.npz")):
+        path = os.path.join(HERE, name)
+        g = dict(np.load(path))
+        B, K, layers = int(g["B"]), int(g["K"]), [3, 4, 5]
+        img, lab = orc.synthetic_batch(B, size, spec.image_ch, spec.num_classes, seed=1234)
+        names = [f"{i}.{n}" for i in layers for n in PNAMES]
+
+        def one_step(dtype, k):
+            R = mk(dtype)
+            x = img.to(dtype)
+            states = {i: orc.random_style_state(B, spec.channel_num[i], 7 + i, dtype) for i in layers}
+            for i in layers:                      # the parameters before step k = after step k - 1 of the fp64 run
+                for n in PNAMES:
+                    setattr(states[i], n, torch.from_numpy(g[f"f64.step{k - 1}.param.{i}.{n}"]).to(dtype))
+            with torch.no_grad():
+                z_i, _ = R.encode_image(x, disable_track_bn_stats=True)
+            Cpu = solver_mod.CpuMaxStyle
+            Cpu.created = []
+            def hook(layer, idx):
+                inject(layer, states[layers[idx]].clone(), dtype)
+                # the batch std was frozen by the run's FIRST forward (maxstyle.py:165-168) - part of the state of step k, restored from the fp64 run's record
+                layer.gamma_std = torch.from_numpy(g[f"f64.{layers[idx]}.gamma_std"]).to(dtype).reshape(1, -1, 1, 1)
+                layer.beta_std = torch.from_numpy(g[f"f64.{layers[idx]}.beta_std"]).to(dtype).reshape(1, -1, 1, 1)
+            Cpu.post_init_hook = staticmethod(hook)
+            torch.manual_seed(5000)
+            with Spy(solver_mod) as spy, contextlib.redirect_stdout(io.StringIO()):
+                R.generate_max_style_image(z_i, decoder_layers_indexes=list(layers), channel_num=spec.channel_num, p=1.5, n_iter=1, lr=0.1, mix_style=True, no_noise=False,
+                                           mix_learnable=True, noise_learnable=True, loss_types=["seg"], loss_weights=[1], always_use_beta=bool(beta),
+                                           reference_image=x, reference_segmentation=lab)
+            return spy.losses[0], [gr.numpy().astype(np.float64) for gr in spy.grads[0]]
+        gerr = np.zeros((len(FORCED_VARIANTS), K - 1, len(names))); lerr = np.zeros((len(FORCED_VARIANTS), K - 1))
+        for k in range(2, K + 1):
+            t0 = time.time()
+            torch.set_num_threads(NTHREADS)
+            l64, g64 = one_step(torch.float64, k)
+            # the forced loss IS the free-running fp64 run's loss of step k (same parameters): a consistency check of the injection
+            assert abs(l64 - float(g["f64.losses"][k - 1])) <= 1e-9 * abs(l64), (k, l64, float(g["f64.losses"][k - 1]))
+            g[f"forced.f64.step{k}.loss"] = np.array(l64)
+            for n, gr in zip(names, g64):
+                g[f"forced.f64.step{k}.grad.{n}"] = gr
+            for v, (vname, nt, mkl) in enumerate(FORCED_VARIANTS):
+                with torch.backends.mkldnn.flags(enabled=mkl):
+                    torch.set_num_threads(nt)
+                    l32, g32 = one_step(torch.float32, k)
+                lerr[v, k - 2] = abs(l32 - l64) / abs(l64)
+                gerr[v, k - 2] = [float(np.abs(a.reshape(-1) - b.reshape(-1)).max() / np.abs(b).max()) for a, b in zip(g32, g64)]
+            print(tag, "forced step", k, f"({time.time() - t0:.0f} s) loss", l64, "fp32 loss errors", lerr[:, k - 2], "fp32 gradient errors (max over tensors)", gerr[:, k - 2].max(axis=1), flush=True)
+        g["forced.draws.variants"] = np.array([v[0] for v in FORCED_VARIANTS])
+        g["forced.draws.grad_err"] = gerr
+        g["forced.draws.loss_rel"] = lerr
+        np.savez_compressed(path, **g)
+        print(name, os.path.getsize(path), flush=True)
+
+
+def forced_full(solver_mod):
+    """See the module docstring (forced_full)."""
+    from make_golden_r4 import trained_reference64, SPEC4
+    res = {"variants": np.array([v[0] for v in FORCED_VARIANTS])}
+    for tag, mk, spec, size, fixture in (("c2", lambda dt: trained_reference(solver_mod, dt, "trained_fcn16_256.npz"), SPEC_A, 256, "loop_full_c2.npz"),
+                                         ("c4", lambda dt: trained_reference64(solver_mod, dt), SPEC4, 320, "loop_full_c4.npz")):
+        g = np.load(os.path.join(HERE, fixture))
+        B, K, layers = 16, int(g["K"]), [3, 4, 5]
+        img, lab = orc.synthetic_batch(B, size, spec.image_ch, spec.num_classes, seed=1234)
+        names = [f"{i}.{n}" for i in layers for n in PNAMES]
+        res[f"{tag}.tensor_names"] = np.array(names)
+
+        def one_step(dtype, k):
+            R = mk(dtype)
+            x = img.to(dtype)
+            states = {i: orc.random_style_state(B, spec.channel_num[i], 7 + i, dtype) for i in layers}
+            if k > 1:
+                for i in layers:
+                    for n in PNAMES:
+                        setattr(states[i], n, torch.from_numpy(g[f"f64.step{k - 1}.param.{i}.{n}"]).to(dtype))
+            with torch.no_grad():
+                z_i, _ = R.encode_image(x, disable_track_bn_stats=True)
+            Cpu = solver_mod.CpuMaxStyle
+            Cpu.created = []
+
+            def hook(layer, idx):
+                inject(layer, states[layers[idx]].clone(), dtype)
+                if k > 1:          # the batch std frozen by the run's first forward (maxstyle.py:165-168)
+                    layer.gamma_std = torch.from_numpy(g[f"f64.{layers[idx]}.gamma_std"]).to(dtype).reshape(1, -1, 1, 1)
+                    layer.beta_std = torch.from_numpy(g[f"f64.{layers[idx]}.beta_std"]).to(dtype).reshape(1, -1, 1, 1)
+            Cpu.post_init_hook = staticmethod(hook)
+            with Spy(solver_mod) as spy, contextlib.redirect_stdout(io.StringIO()):
+                R.generate_max_style_image(z_i, decoder_layers_indexes=list(layers), channel_num=spec.channel_num, p=1.5, n_iter=1, lr=0.1,
+                                           reference_image=x, reference_segmentation=lab)
+            return spy.losses[0], [gr.numpy().astype(np.float64) for gr in spy.grads[0]]
+        gerr = np.zeros((len(FORCED_VARIANTS), K, len(names))); lerr = np.zeros((len(FORCED_VARIANTS), K))
+        for k in range(1, K + 1):
+            t0 = time.time()
+            torch.set_num_threads(NTHREADS)
+            l64, g64 = one_step(torch.float64, k)
+            assert abs(l64 - float(g["f64.losses"][k - 1])) <= 1e-9 * abs(l64), (tag, k, l64, float(g["f64.losses"][k - 1]))      # the forced evaluation IS the fp64 run's step k
+            res[f"{tag}.step{k}.loss"] = np.array(l64)
+            for n, gr in zip(names, g64):
+                res[f"{tag}.step{k}.grad.{n}"] = gr
+            for v, (vname, nt, mkl) in enumerate(FORCED_VARIANTS):
+                with torch.backends.mkldnn.flags(enabled=mkl):
+                    torch.set_num_threads(nt)
+                    l32, g32 = one_step(torch.float32, k)
+                lerr[v, k - 1] = abs(l32 - l64) / abs(l64)
+                gerr[v, k - 1] = [float(np.abs(a.reshape(-1) - b.reshape(-1)).max() / np.abs(b).max()) for a, b in zip(g32, g64)]
+            print(tag, "forced step", k, f"({time.time() - t0:.0f} s) loss", l64, "fp32 loss errors", lerr[:, k - 1], "fp32 gradient errors (max over tensors)", gerr[:, k - 1].max(axis=1), flush=True)
+            res[f"{tag}.draws.grad_err"] = gerr
+            res[f"{tag}.draws.loss_rel"] = lerr
+            res[f"{tag}.steps_done"] = np.array(k)
+            np.savez_compressed(os.path.join(HERE, "loop_forced_full.npz"), **res)          # (kept current: config 4's ten steps take half an hour)
+    print("loop_forced_full.npz", os.path.getsize(os.path.join(HERE, "loop_forced_full.npz")), flush=True)
 
 
 def shipped(solver_mod):
@@ -394,7 +523,7 @@ def draws(solver_mod, variants=DRAW_VARIANTS):
 
 
 def main():
-    what = sys.argv[1:] or ["train_a192", "train_p224", "shipped", "shipped_draws", "c5f64", "draws"]
+    what = sys.argv[1:] or ["train_a192", "train_p224", "shipped", "shipped_draws", "shipped_forced", "forced_full", "c5f64", "draws"]
     solver_mod = ref_harness.load_solver_module()
     if "train_a192" in what:
         train_a192(solver_mod)
@@ -404,6 +533,10 @@ def main():
         shipped(solver_mod)
     if "shipped_draws" in what:
         shipped_draws(solver_mod)
+    if "shipped_forced" in what:
+        shipped_forced(solver_mod)
+    if "forced_full" in what:
+        forced_full(solver_mod)
     if "c5f64" in what:
         c5_f64(solver_mod)
     if "draws" in what:

@@ -80,6 +80,7 @@ def shipped_case(dev, which, options=None):
         "z_i_rel": rel(zf[idx], g["f64.z_i.sample"]),
         "image_max": float(d.abs().max()) / scale, "noise_image_max": float(g["ref_noise.image_max"]),
         "image_rms": float(d.pow(2).mean().sqrt()) / scale, "noise_image_rms": float(g["ref_noise.image_rms"]),
+        "image_max_per_sample": (d.abs().amax(dim=(1, 2, 3)) / scale).tolist(), "image_rms_per_sample": (d.pow(2).mean(dim=(1, 2, 3)).sqrt() / scale).tolist(),
         "losses_rel": (np.abs(losses - g["f64.losses"]) / np.abs(g["f64.losses"])).tolist(), "noise_losses_rel": g["ref_noise.losses_rel"].tolist(),
         "losses": losses.tolist(),
         "labels_equal_f64": float((pred.numpy() == g["f64.final_pred"]).mean()), "noise_labels_equal": float(g["ref_noise.labels_equal"]),
@@ -120,6 +121,97 @@ def shipped_step1_gradients(dev, which):
         ours[n] = float(np.abs(eng.grad(int(i), nm).detach().cpu().numpy().astype(np.float64).reshape(-1) - r64).max() / np.abs(r64).max())
     return {"winograd": bool(eng.winograd), "ours": ours, "draws": {n: g["ref_draws.step1_grad_err"][:, j].tolist() for j, n in enumerate(names)},
             "first_loss_rel": abs(float(S.last_losses[0]) - float(g["f64.losses"][0])) / abs(float(g["f64.losses"][0]))}
+
+
+def shipped_teacher_forced(dev, which):
+    """TEACHER-FORCED steps of the shipped call (fixture keys `forced.*`, tests/golden/make_golden_r5.py shipped_forced): for k = 1..K the style parameters are set to what the
+    reference's fp64 run held BEFORE its step k, one step is evaluated, and its loss and the gradient of every style tensor are compared with the reference's fp64 evaluation at
+    the same point.  Nothing chaotic: five points of the reference's own trajectory, a smooth map at each.  -> per step: loss error, per-tensor gradient error (max norm over
+    max|g|), and the same errors of the reference's own fp32 evaluations at that point (`draws`)."""
+    g, spec, img, lab, styles, layers = shipped_inputs(which, dev)
+    K = int(g["K"])
+    S = shipped_solver(dev, which)
+    names = [str(n) for n in g["ref_draws.tensor_names"]]
+    img_d, lab_d = img.to(dev), lab.to(dev)
+    z_i, _ = S.encode_image(img_d, disable_track_bn_stats=True)
+    steps = []
+    for k in range(1, K + 1):
+        def hook(mods, k=k):
+            for key, m in mods.items():
+                st = styles[int(key)]
+                m.perm = st.perm.clone()
+                with torch.no_grad():
+                    for nm in PN:
+                        v = getattr(st, nm) if k == 1 else torch.from_numpy(g[f"f64.step{k - 1}.param.{key}.{nm}"]).float()
+                        getattr(m, nm).data = v.to(dev)
+                if k > 1:      # the batch std frozen by the run's first forward is part of the state of step k (maxstyle.py:165-168)
+                    m.gamma_std = torch.from_numpy(g[f"f64.{key}.gamma_std"]).float().reshape(1, -1, 1, 1).to(dev)
+                    m.beta_std = torch.from_numpy(g[f"f64.{key}.beta_std"]).float().reshape(1, -1, 1, 1).to(dev)
+        S.style_init_hook = hook
+        S.generate_max_style_image(z_i.detach(), layers, spec.channel_num, p=1.5, n_iter=1, lr=0.1, always_use_beta=bool(SHIPPED[which]["beta"]),
+                                   reference_image=img_d, reference_segmentation=lab_d)
+        eng = next(iter(S._engines.values()))
+        l64 = float(g["f64.losses"][k - 1])
+        if k > 1:
+            assert abs(float(g[f"forced.f64.step{k}.loss"]) - l64) <= 1e-9 * abs(l64)      # the forced evaluation IS the free-running fp64 run's step k
+        ours, draws = {}, {}
+        for j, n in enumerate(names):
+            i, nm = n.split(".")
+            r64 = (g[f"f64.step1.grad.{n}"] if k == 1 else g[f"forced.f64.step{k}.grad.{n}"]).reshape(-1)
+            ours[n] = float(np.abs(eng.grad(int(i), nm).detach().cpu().numpy().astype(np.float64).reshape(-1) - r64).max() / np.abs(r64).max())
+            draws[n] = (g["ref_draws.step1_grad_err"][:, j] if k == 1 else g["forced.draws.grad_err"][:, k - 2, j]).tolist()
+        steps.append({"k": k, "loss_rel": abs(float(S.last_losses[0]) - l64) / abs(l64),
+                      "draw_loss_rel": (g["ref_draws.losses_rel"][:, 0] if k == 1 else g["forced.draws.loss_rel"][:, k - 2]).tolist(), "ours": ours, "draws": draws})
+    return {"winograd": bool(eng.winograd), "steps": steps}
+
+
+def full_teacher_forced(dev, which):
+    """shipped_teacher_forced's method at the BENCHMARKED calls (`which` = "c2": trained FCN_16 at 16x1x256x256, K = 5, loop_full_c2.npz | "c4": trained FCN_64 at
+    16x3x320x320, K = 10, loop_full_c4.npz): for k = 1..K one step from the parameters and frozen batch std the reference's fp64 run held before its step k, against the
+    reference's fp64 evaluation at that point and next to its own fp32 evaluations there (tests/golden/loop_forced_full.npz, make_golden_r5.py forced_full)."""
+    from maxstyle_amd import synthetic as syn
+    import r3_cases as R3
+    import r4_cases as R4
+    g = np.load(os.path.join(GOLDEN, "loop_full_c2.npz" if which == "c2" else "loop_full_c4.npz"))
+    f = np.load(os.path.join(GOLDEN, "loop_forced_full.npz"))
+    if which == "c2":
+        spec, size = syn.NetSpec(4, 1, 4), 256
+        S = R3.trained_solver(dev, "trained_fcn16_256.npz")
+    else:
+        spec, size = syn.NetSpec(1, 3, 2), 320
+        S = R4.trained_solver64(dev)
+    B, layers, K = 16, [3, 4, 5], int(g["K"])
+    assert int(f[f"{which}.steps_done"]) == K
+    names = [str(n) for n in f[f"{which}.tensor_names"]]
+    img, lab = syn.synthetic_batch(B, size, spec.image_ch, spec.num_classes, seed=1234)
+    styles = {i: syn.random_style_state(B, spec.channel_num[i], 7 + i) for i in layers}
+    img_d, lab_d = img.to(dev), lab.to(dev)
+    z_i, _ = S.encode_image(img_d, disable_track_bn_stats=True)
+    steps = []
+    for k in range(1, K + 1):
+        def hook(mods, k=k):
+            for key, m in mods.items():
+                st = styles[int(key)]
+                m.perm = st.perm.clone()
+                with torch.no_grad():
+                    for nm in PN:
+                        v = getattr(st, nm) if k == 1 else torch.from_numpy(g[f"f64.step{k - 1}.param.{key}.{nm}"]).float()
+                        getattr(m, nm).data = v.to(dev)
+                if k > 1:
+                    m.gamma_std = torch.from_numpy(g[f"f64.{key}.gamma_std"]).float().reshape(1, -1, 1, 1).to(dev)
+                    m.beta_std = torch.from_numpy(g[f"f64.{key}.beta_std"]).float().reshape(1, -1, 1, 1).to(dev)
+        S.style_init_hook = hook
+        S.generate_max_style_image(z_i.detach(), layers, spec.channel_num, p=1.5, n_iter=1, lr=0.1, reference_image=img_d, reference_segmentation=lab_d)
+        eng = next(iter(S._engines.values()))
+        l64 = float(f[f"{which}.step{k}.loss"])
+        ours, draws = {}, {}
+        for j, n in enumerate(names):
+            i, nm = n.split(".")
+            r64 = f[f"{which}.step{k}.grad.{n}"].reshape(-1)
+            ours[n] = float(np.abs(eng.grad(int(i), nm).detach().cpu().numpy().astype(np.float64).reshape(-1) - r64).max() / np.abs(r64).max())
+            draws[n] = f[f"{which}.draws.grad_err"][:, k - 1, j].tolist()
+        steps.append({"k": k, "loss_rel": abs(float(S.last_losses[0]) - l64) / abs(l64), "draw_loss_rel": f[f"{which}.draws.loss_rel"][:, k - 1].tolist(), "ours": ours, "draws": draws})
+    return {"winograd": bool(eng.winograd), "steps": steps}
 
 
 # ------------------------------------------------------------------------------------------------------------- kink census at the benchmarked sizes

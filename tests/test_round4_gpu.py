@@ -22,24 +22,35 @@ def dev():
 def test_config4_at_size_vs_reference_run(dev, monkeypatch, winograd):
     """BASELINE config 4 as benchmarked - FCN_64, 16x3x320x320, MaxStyle after blocks [3,4,5], K = 10 free-running Adam steps - on FCN_64 weights trained by the
     reference's own training step (tests/golden/trained_fcn64_320.npz), against the reference's fp64 run of the same call (advanced_triplet...py:539-571;
-    tests/golden/loop_full_c4.npz).  The criteria config 2 got in round 3: image error <= 2x the reference's OWN fp32-vs-fp64 error (max and rms), per-step
-    losses <= max(5x the reference's worst error up to the step, 3e-5), final parameters <= 3x its worst, labels >= 99.99 % equal, Dice within 1e-3 - with the Winograd
-    form of the wide convolutions (one and two channel blocks per staged tile, as the dispatch picks them) and with the direct form."""
+    tests/golden/loop_full_c4.npz) - with the Winograd form of the wide convolutions (one and two channel blocks per staged tile, as the dispatch picks them) and with
+    the direct form.
+    Calibration (round 5): the reference's fp32 run of this call is NOT run-to-run reproducible (its fp32 backward at 320x320 differs from step 1 on
+    between evaluations), so the bars no longer rest on the one fp32 leg stored with the fixture: tests/golden/loop_ref_draws.npz holds three more evaluations (oneDNN at 8
+    and 2 threads, ATen native), each against the same fp64 run, and the bars take the SMALLEST of the four: image rms and per-plane moments <= 2x, image max norm <= 3x
+    (a maximum over 4.9 M pixels of a heavy-tailed quantity: the four draws themselves span 5.2e-4 .. 1.9e-3), per-step losses <= max(5x the reference's worst error up to
+    the step over its draws, 3e-5), final parameters <= 3x its worst, labels >= 99.99 % equal, Dice within 1e-3."""
     set_engine_default(monkeypatch, "winograd", winograd == "1")
     r = R4.c4_full_case(dev)
+    import r5_cases as R5
+    d = R5.c4_draws()
     assert r["winograd"] == (winograd == "1") and r["K"] == 10
     assert r["z_i_rel"] < 5e-6
-    assert r["image_max"] <= 2.0 * r["noise_image_max"], (r["image_max"], r["noise_image_max"])
-    assert max(r["image_rms_full"], r["image_rms_strided"]) <= 2.0 * r["noise_image_rms"], (r["image_rms_full"], r["image_rms_strided"], r["noise_image_rms"])
-    # per-(sample, channel) mean / rms of ALL 16 samples (the full image is stored for 4 of them): inside 2x the reference's own shift of the same moments
-    assert r["mean_rel"] <= 2.0 * r["noise_plane_mean"] and r["rms_rel"] <= 2.0 * r["noise_plane_rms"], (r["mean_rel"], r["noise_plane_mean"], r["rms_rel"], r["noise_plane_rms"])
+    assert len(d["variants"]) >= 3
+    noise_max = min([r["noise_image_max"]] + [max(a, b) for a, b in zip(d["strided_max"], d["full4_max"])])
+    noise_rms = min([r["noise_image_rms"]] + [max(a, b) for a, b in zip(d["strided_rms"], d["full4_rms"])])
+    print(f"config 4 {'winograd' if winograd == '1' else 'direct'}: image max {r['image_max']:.2e} rms {max(r['image_rms_full'], r['image_rms_strided']):.2e}; smallest of the reference's draws: {noise_max:.2e} / {noise_rms:.2e}")
+    assert r["image_max"] <= 3.0 * noise_max, (r["image_max"], noise_max)
+    assert max(r["image_rms_full"], r["image_rms_strided"]) <= 2.0 * noise_rms, (r["image_rms_full"], r["image_rms_strided"], noise_rms)
+    # per-(sample, channel) mean / rms of ALL 16 samples (the full image is stored for 4 of them): inside 2x the reference's own shift of the same moments (smallest draw)
+    nm, nr = min([r["noise_plane_mean"]] + d["mean_max"]), min([r["noise_plane_rms"]] + d["rms_max"])
+    assert r["mean_rel"] <= 2.0 * nm and r["rms_rel"] <= 2.0 * nr, (r["mean_rel"], nm, r["rms_rel"], nr)
     # per-step losses: the error of a free-running trajectory accumulates, and the reference's own fp32 error at ONE step is one draw of a chaotic quantity (6e-8 at step 1,
     # 2.9e-5 at step 4, 7e-6 at step 8, 4.6e-5 at step 10) - so a step is held to 5x the reference's WORST error up to that step, floor 3e-5 (the fp32 forward bar every
     # loss test of this repo holds; the trained FCN_64's loss is 0.013 .. 0.12).  Measured: 7e-6 .. 1.8e-4 against bars 3e-5 .. 2.3e-4 (profiles/r04_parity_report.txt).
     worst = 0.0
-    for e, n in zip(r["losses_rel"], r["noise_losses_rel"]):
-        worst = max(worst, n)
-        assert e <= max(5.0 * worst, 3e-5), (r["losses_rel"], r["noise_losses_rel"])
+    for s_, (e, n) in enumerate(zip(r["losses_rel"], r["noise_losses_rel"])):
+        worst = max([worst, n] + [dr[s_] for dr in d["losses_rel"]])
+        assert e <= max(5.0 * worst, 3e-5), (r["losses_rel"], r["noise_losses_rel"], d["losses_rel"])
     worst_noise = max(r["noise_params_rel"].values())
     for k, e in r["params_rel"].items():
         assert e <= 3.0 * worst_noise, (k, e, worst_noise)
