@@ -844,13 +844,16 @@ def shipped_blocks(dev, rank):
             torch.cuda.synchronize()
             blk["step_roofline"] = step_roofline(ledger, dt / 20)
             forms = {}
-            names = {0: "first_generation", 1: "wide_direct", 2: "winograd_1block", 3: "winograd_2blocks", 4: "winograd_8x8_1block", 5: "winograd_8x8_2blocks"}
+            names = {0: "first_generation", 1: "wide_direct", 2: "winograd_1block", 3: "winograd_2blocks", 4: "winograd_8x8_1block", 5: "winograd_8x8_2blocks",
+                     6: "narrow_rows_second_generation"}
             for e in ledger:
                 cv = e["conv"]
                 if cv is None:
                     continue
                 fn = e["fn"]
-                if cv.get("vector_alu"):
+                if fn.startswith("ms_conv3x3_small_cin"):
+                    kind = "k3_taps_as_k_first_conv"
+                elif cv.get("vector_alu"):
                     kind = "vector_alu"
                 elif fn.startswith("ms_conv_subpix"):
                     kind = "subpixel"

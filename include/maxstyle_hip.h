@@ -96,7 +96,8 @@ MS_INTERNAL int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int p
 /* Which kernel form ms_conv2d(ks 3, stride 1, fetch) takes for this shape (16-byte aligned tensors assumed) - what the measurement tools print and price, asked of the
  * dispatch itself instead of re-deriving its rules: 0 first-generation kernel (conv_mfma_kernel) | 1 wide direct form (conv_wide_kernel) | 2 Winograd F(2x2,3x3), one
  * 16-channel block per staged tile (conv_wide_kernel<1, ..., ms_f32w*>) | 3 Winograd, two blocks (conv_wide_kernel<2, ...>: round 4) | 4 / 5 the same on independent
- * 8x8-pixel blocks instead of 4x64 / 8x32 tiles (ms_f32wb: rows that are not multiples of 32 / 64 pixels).  fetch = the call's fetch argument
+ * 8x8-pixel blocks instead of 4x64 / 8x32 tiles (ms_f32wb: rows that are not multiples of 32 / 64 pixels) | 6 the narrow-rows second generation (conv_k3n_kernel:
+ * rows of 12 / 14 / 16 pixels, round 5).  fetch = the call's fetch argument
  * (MS_FETCH_WINOGRAD / MS_FETCH_WINO_NT1 bits); a fused-fetch call (fetch & 0xFF != 0) is always 0. */
 MS_INTERNAL int ms_conv2d_form(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16, int fetch);
 /* The Winograd appendix of a packed 3x3 weight tensor (MS_FETCH_WINO_U): layout [ceil(Cout/16)][Cin/8][16 positions][8 input channels][16 output channels] fp32
@@ -316,7 +317,8 @@ MS_INTERNAL int ms_conv3x3_small_cout(const float* in, const float* in2, float* 
                           int pro_mode, const float* pro_a, const float* pro_b, const float* pro_c, int pro_cstride, void* stream);
 
 /* Sub-pixel form of the two x2 resampling convolutions (csrc/ms_conv_subpix.h): same results as ms_conv2d with fetch = 1 / 2 to fp32 rounding, without
- * multiplying the duplicates / zeros the resampling inserts (2.25x / 4x fewer matrix instructions).  in [N,Cin,Hs,Ws] (Ws % 4 == 0), out [N,Cout,2Hs,2Ws].
+ * multiplying the duplicates / zeros the resampling inserts (2.25x / 4x fewer matrix instructions).  in [N,Cin,Hs,Ws], out [N,Cout,2Hs,2Ws]; ms_conv_subpix_eligible:
+ * 1 = Ws % 4 == 0 (every form), 2 = Ws even (14-pixel rows of the shipped 224-pixel workload: the second generation's block geometry only - fp32 storage, mode 0 with w_sums).
  *   mode 0: nn.UpsamplingNearest2d(2) -> nn.Conv2d(3x3,p=1) (encoder_decoder.py:298-300, 323-337); w_packed = the FORWARD packed weights, bias optional,
  *           stats = optional BatchNorm statistics table of the outputs (ms_conv_stats_bytes);
  *   mode 1: data-gradient of nn.Conv2d(3x3,s=2,p=1) (res_convdown.down, encoder_decoder.py:40); `in` = dY [N,Cout_fwd,Hs,Ws], w_packed = the

@@ -214,7 +214,7 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
     return conv_dispatch_wide(a, nt, st);
   }
   if (allow_wide && conv_wide_eligible(a, ks, stride, fetch, vec)) return conv_dispatch_wide(a, nt, st);
-  if (conv_k3n_eligible(a, ks, stride, fetch)) return conv_dispatch_k3n(a, st);      // second generation for rows of 12 / 14 / 16 pixels (ms_conv_k3n.h)
+  if (conv_k3n_eligible(a, ks, stride, fetch)) return conv_dispatch_k3n(a, ks, st);      // second generation for rows of 12 / 14 / 16 pixels (ms_conv_k3n.h)
   if (ks == 3 && stride == 1) return conv_dispatch_k3s1(a, fetch, nt, vec, narrow, use_in2, st);
   if (ks == 1 && allow_wide && conv_k1s_eligible(a, ks, stride, fetch)) return conv_dispatch_k1s(a, st);      // streaming form (ms_conv_k1s.h)
   if (ks == 1 && allow_wide && conv_k1g_eligible(a, ks, stride, fetch)) return conv_dispatch_k1g(a, st);      // LDS-tiled GEMM form of the channel-heavy levels (ms_conv_k1g.h)
@@ -282,7 +282,7 @@ extern "C" int ms_conv2d_form(int N, int Cin, int H, int W, int Cout, int pro_mo
   a.act_bf16 = (bf16 < 0 || bf16 > 2) ? 2 : bf16;
   static const float appendix_marker = 0.f;             // (only compared with null by the dispatch rules)
   a.wu = ((fetch & MS_FETCH_WINO_U) && a.wino_ok && Cin % 8 == 0) ? &appendix_marker : nullptr;
-  if (!conv_wide_eligible(a, 3, 1, FETCH_NORMAL, W % 4 == 0)) return 0;
+  if (!conv_wide_eligible(a, 3, 1, FETCH_NORMAL, W % 4 == 0)) return conv_k3n_eligible(a, 3, 1, FETCH_NORMAL) ? 6 : 0;
   if (!conv_wide_is_wino(a)) return 1;
   return 1 + conv_wino_blocks(a) + (conv_wino_blockform(a) ? 2 : 0);
 }

@@ -24,9 +24,10 @@
 
 namespace ms {
 
-template <int W, int MT>
+template <int W, int MT, int KS = 3>
 struct K3nGeo {
   static constexpr int CK = 16;
+  static constexpr int TAPS = KS * KS;                                  // 9 | 1 (round 5: the 1x1 convs on 14-pixel rows share the kernel - same band, centre tap only)
   static constexpr int RS = W + 2;
   static constexpr int PIX = 64 * MT;                                   // pixels of a work item: 4 MFMA waves x MT M-tiles x 16
   static constexpr int SPAN = (PIX % W == 0) ? PIX / W : (W - 1 + PIX - 1) / W + 1;      // image rows PIX consecutive pixels can touch (item starts are multiples of PIX)
@@ -36,7 +37,7 @@ struct K3nGeo {
   static constexpr int IN_FLOATS = CK * PS;
   static constexpr int NJ = (IN_FLOATS + 255) / 256;                    // dword DMA pieces per staging wave and chunk
   static constexpr int IN_REGION = NJ * 256;
-  static constexpr int W_FLOATS = 9 * CK * 16;                          // [tap][channel][16 output channels]
+  static constexpr int W_FLOATS = TAPS * CK * 16;                       // [tap][channel][16 output channels]
   static constexpr int NWJ = (W_FLOATS / 4 + 255) / 256;                // 16-byte DMA pieces per staging wave and chunk (3; the last round half used)
   static constexpr int W_REGION = NWJ * 1024;
   static constexpr int BUF = IN_REGION + W_REGION;                      // floats per stage buffer
@@ -45,9 +46,9 @@ struct K3nGeo {
 };
 
 // PRO: 0 none | 1 v = lrelu(a[c] v + b[c]) | 2 v = a[c] v + b[c] v2 + c[c]
-template <int W, int MT, int PRO, bool CHAINED = false>
+template <int W, int MT, int PRO, bool CHAINED = false, int KS = 3>
 __device__ __forceinline__ void conv_k3n_body(const ConvArgs& a, float* smem) {
-  using G = K3nGeo<W, MT>;
+  using G = K3nGeo<W, MT, KS>;
   constexpr int CK = G::CK, RS = G::RS, PS = G::PS, PIX = G::PIX, BUF = G::BUF, NJ = G::NJ, NWJ = G::NWJ, NE = G::NE, OOB = G::OOB;
   float* cf_lds = smem + 3 * BUF;                        // [cin_pad][4] prologue coefficients
   const int wave = MS_TID >> 6, lane = MS_TID & 63;
@@ -75,7 +76,7 @@ __device__ __forceinline__ void conv_k3n_body(const ConvArgs& a, float* smem) {
     // =========================================== STAGING waves ===========================================
     __builtin_amdgcn_s_setprio(3);
     const int sw = __builtin_amdgcn_readfirstlane(wave) - 4;
-    const ms_i32x4 rs_w = ms_dma_rsrc_n(a.w, (unsigned)9 * a.cin_pad * a.cout_pad * 4u);
+    const ms_i32x4 rs_w = ms_dma_rsrc_n(a.w, (unsigned)G::TAPS * a.cin_pad * a.cout_pad * 4u);
     const unsigned lds0 = ms_lds_addr(smem);
     // weights: 16-byte piece q = (sw + 4 j) * 64 + lane -> row (tap, c) = q / 4, part = q % 4
     int w_voff[NWJ];
@@ -261,13 +262,14 @@ __device__ __forceinline__ void conv_k3n_body(const ConvArgs& a, float* smem) {
   };
   auto compute = [&](const float* buf) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < G::TAPS; ++tap) {
 #pragma unroll
       for (int cg = 0; cg < CK / 4; ++cg) {
         const float bf = buf[b_lane + (tap * CK + cg * 4) * 16];
         float af[MT];
+        constexpr int HO = (3 - KS) / 2;                 // (KS 1: the centre of the 3 x 3 window the band is laid out for)
 #pragma unroll
-        for (int t = 0; t < MT; ++t) af[t] = buf[a_off[t] + cg * 4 * PS + (tap / 3) * RS + (tap % 3)];
+        for (int t = 0; t < MT; ++t) af[t] = buf[a_off[t] + cg * 4 * PS + (tap / KS + HO) * RS + (tap % KS + HO)];
 #pragma unroll
         for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t], bf, acc[t], 0, 0, 0);
       }
@@ -376,10 +378,10 @@ __device__ __forceinline__ void conv_k3n_body(const ConvArgs& a, float* smem) {
   }
 }
 
-template <int W, int MT, int PRO>
+template <int W, int MT, int PRO, int KS = 3>
 __global__ __launch_bounds__(512, 4) void conv_k3n_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  conv_k3n_body<W, MT, PRO>(a, smem);
+  conv_k3n_body<W, MT, PRO, false, KS>(a, smem);
 }
 
 // ---- go / no-go probe for a LAYER-CHAIN launch: L plain 3x3 layers (prologue-free, plain store) walked by ONE persistent
@@ -415,7 +417,10 @@ __global__ __launch_bounds__(512, 4) void conv_k3n_chain_kernel(const ConvArgs* 
 
 // Eligible: 3x3 stride 1, plain fetch, fp32 storage, rows of 12 / 14 / 16 pixels, whole 16-channel chunks, per-channel coefficients, 16-byte pixel quads
 inline bool conv_k3n_eligible(const ConvArgs& a, int ks, int stride, int fetch) {
-  if (opt(OPT_CONV_K3N) == 0 || ks != 3 || stride != 1 || fetch != FETCH_NORMAL || a.act_bf16 != 0) return false;
+  if (opt(OPT_CONV_K3N) == 0 || !(ks == 3 || ks == 1) || stride != 1 || fetch != FETCH_NORMAL || a.act_bf16 != 0) return false;
+  // 1x1: only rows of 14 pixels (not a multiple of 4: the tiled first-generation 1x1 falls to its scalar staging there - 28-33 us per launch at the shipped Prostate shape
+  // against ~8 us at 12 / 16 pixels) and only the plain / statistics / two-tensor-prologue calls (the residual tails and riders have the GEMM kernel, ms_conv_k1g.h)
+  if (ks == 1 && (a.Ws != 14 || a.epi_mode == 3 || a.Cin < 64)) return false;
   if (!(a.Ws == 12 || a.Ws == 14 || a.Ws == 16) || a.Hs < 1 || (a.Hs * a.Ws) % 4 != 0) return false;
   if (a.Cin % 16 != 0 || a.cin_pad != a.Cin || a.Cin < 16) return false;
   if (a.pro_mode != 0 && a.pro_nstride != 0) return false;
@@ -427,7 +432,9 @@ inline bool conv_k3n_eligible(const ConvArgs& a, int ks, int stride, int fetch) 
 }
 
 // M-tiles per MFMA wave.  Two halve the weight traffic and stage 25 % instead of 50 % halo rows per band - taken where they leave a work item for every CU AND do not
-// cost matrix time: an image of HW pixels is ceil(HW / (64 MT)) items of MT units each (12 x 12 = 144 pixels: 3 x 1 units against 2 x 2; 14 x 14 and 16 x 16: equal)
+// cost matrix time: an image of HW pixels is ceil(HW / (64 MT)) items of MT units each (12 x 12 = 144 pixels: 3 x 1 units against 2 x 2; 14 x 14 and 16 x 16: equal).
+// (Measured and NOT adopted, round 5: one tile at 20 x 128 @14x14, where two tiles mean 320 items = two rounds on 256 CUs against 640 half-size items = three - the
+//  launches went from 30-32 to 32-35 us: the doubled weight and halo traffic costs more than the idle quarter of the second round.)
 inline int conv_k3n_mt(const ConvArgs& a) {
   const int HW = a.Hs * a.Ws;
   const long items2 = (long)a.N * cdiv(HW, 128) * cdiv(a.Cout, 16);
@@ -435,21 +442,21 @@ inline int conv_k3n_mt(const ConvArgs& a) {
   return (2 * cdiv(HW, 128) <= cdiv(HW, 64)) ? 2 : 1;
 }
 
-template <int W, int MT, int PRO>
+template <int W, int MT, int PRO, int KS = 3>
 int launch_conv_k3n_t(ConvArgs a, hipStream_t st) {
-  using G = K3nGeo<W, MT>;
+  using G = K3nGeo<W, MT, KS>;
   const size_t lds_bytes = sizeof(float) * (3 * (size_t)G::BUF + 4 * (size_t)a.cin_pad);
   static std::once_flag attr_once;
-  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_k3n_kernel<W, MT, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
+  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_k3n_kernel<W, MT, PRO, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
   a.ncb = cdiv(a.Cout, 16);
   const long nitems = (long)a.N * cdiv(a.Hs * a.Ws, G::PIX) * a.ncb;
-  const int per_cu = std::max(1, std::min(conv_resident_per_cu((const void*)conv_k3n_kernel<W, MT, PRO>, lds_bytes), 2));
+  const int per_cu = std::max(1, std::min(conv_resident_per_cu((const void*)conv_k3n_kernel<W, MT, PRO, KS>, lds_bytes), 2));
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;
-  MS_LAUNCH((conv_k3n_kernel<W, MT, PRO>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
+  MS_LAUNCH((conv_k3n_kernel<W, MT, PRO, KS>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
   return check_launch("conv_k3n");
 }
 
-int conv_dispatch_k3n(const ConvArgs& a, hipStream_t st);      // ms_conv_inst_k3n.hip
+int conv_dispatch_k3n(const ConvArgs& a, int ks, hipStream_t st);      // ms_conv_inst_k3n.hip
 
 }  // namespace ms

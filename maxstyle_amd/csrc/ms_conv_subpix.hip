@@ -4,7 +4,8 @@
 
 using namespace ms;
 
-extern "C" int ms_conv_subpix_eligible(int Hs, int Ws) { return (Hs >= 1 && Ws >= 4 && Ws % 4 == 0) ? 1 : 0; }
+// 1: every form | 2: an even width that is not a multiple of 4 - the second generation's block geometry only (fp32 storage; mode 0 with the sums appendix) | 0: no
+extern "C" int ms_conv_subpix_eligible(int Hs, int Ws) { return (Hs >= 1 && Ws >= 4 && Ws % 4 == 0) ? 1 : ((Hs >= 1 && Ws >= 2 && Ws % 2 == 0) ? 2 : 0); }
 
 // one thread per (product q, input channel, output channel): the sum of the 3x3 taps that land on the same stored pixel, in the first-generation kernel's order
 // (ky outer, kx inner, the first tap assigned, the others added in fp32): the kernel that copies the sums from here computes the same bits
@@ -75,7 +76,7 @@ static int conv_subpix_impl(const float* in, float* out, const float* w_packed, 
                             float* stats, const float* ref, const float* u, const float* coef4, float act_slope, float* tab, void* stream, int act_bf16,
                             const float* w_sums = nullptr, int flags = 0) {
   if (N < 1 || Cin < 1 || Cout < 1 || !ms_conv_subpix_eligible(Hs, Ws) || (mode != 0 && mode != 1)) {
-    set_error("ms_conv_subpix: invalid shape / mode (stored width must be a multiple of 4)"); return MS_ERR_INVALID;
+    set_error("ms_conv_subpix: invalid shape / mode (stored width must be even)"); return MS_ERR_INVALID;
   }
   if (!aligned16(in) || !aligned16(out) || !aligned16(w_packed) || !aligned16(w_sums)) { set_error("ms_conv_subpix: in, out and the packed weights must be 16-byte aligned"); return MS_ERR_ALIGN; }
   const bool mask = (ref != nullptr) || (u != nullptr);        // ref == NULL with u given: the mask is recomputed from sc*u + sh (activation never materialised)
@@ -95,6 +96,7 @@ static int conv_subpix_impl(const float* in, float* out, const float* w_packed, 
   // second generation (ms_conv_subpix2.h): fp32 storage, every byte offset of the DMA within 31 bits, and - mode 0 - the sums appendix
   const bool gen2 = !(flags & MS_SUBPIX_FIRST_GEN) && !act_bf16 && (mode == 1 || w_sums != nullptr) &&
                     (long long)N * Cin * Hs * Ws * 4 < (1LL << 31) && 16LL * a.cin_pad * a.cout_pad * 4 < (1LL << 31);
+  if (!gen2 && Ws % 4 != 0) { set_error("ms_conv_subpix: a stored width that is not a multiple of 4 needs the second generation (fp32 storage; mode 0: the sums appendix)"); return MS_ERR_INVALID; }
   if (gen2) {
     const int geo = (flags & MS_SUBPIX_TILES) ? 0 : (flags & MS_SUBPIX_BLOCKS) ? 1 : -1;
     return mode == 0 ? launch_conv_subpix2<0>(a, ref, geo, st) : launch_conv_subpix2<1>(a, ref, geo, st);

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(512, 4) void conv_subpix2_kernel(const ConvArgs a, 
   const int ntiles = a.tiles_x * a.tiles_y;
   const int nitems = (GEO == 0 ? a.N : 1) * ntiles * ncb;
   const int nchunks = (a.cin_pad + CK - 1) / CK;
-  const int nbx = a.Ws >> 2, nby = (a.Hs + 3) >> 2, NB = a.N * nbx * nby;       // (GEO 1)
+  const int nbx = (a.Ws + 3) >> 2, nby = (a.Hs + 3) >> 2, NB = a.N * nbx * nby;       // (GEO 1; an even width that is not a multiple of 4 ends in a half block)
   const int vb = ((int)gridDim.x % 8 == 0) ? (((int)blockIdx.x % 8) * ((int)gridDim.x / 8) + (int)blockIdx.x / 8) : (int)blockIdx.x;
   const int my_items = (nitems - vb + (int)gridDim.x - 1) / (int)gridDim.x;
   const int T = my_items * nchunks;
@@ -233,9 +233,12 @@ __global__ __launch_bounds__(512, 4) void conv_subpix2_kernel(const ConvArgs a, 
   };
   auto epilogue = [&](int n_item, int tile, int co0) {
     const int co = co0 + m;
-    int qn[4], qy[4], qx[4]; bool qok[4];
+    int qn[4], qy[4], qx[4], qnr[4]; bool qok[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) qok[i] = quad(n_item, tile, i, qn[i], qy[i], qx[i]);
+    for (int i = 0; i < 4; ++i) {
+      qok[i] = quad(n_item, tile, i, qn[i], qy[i], qx[i]);
+      qnr[i] = (GEO == 1) ? min(4, a.Ws - qx[i]) : 4;       // stored columns of the quad inside the image (GEO 1, Ws % 4 == 2: the last block of a row holds 2)
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(512, 4) void conv_subpix2_kernel(const ConvArgs a, 
       // per-lane running (count, mean, M2) over the outputs this lane produced (<= 64 per item), Chan-merged item by item (ms_conv_kernel.h)
       float cnt = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) if (qok[i]) cnt += 16.f;
+      for (int i = 0; i < 4; ++i) if (qok[i]) cnt += 4.f * (float)qnr[i];
       if (cnt > 0.f) {
         const float rc = __builtin_amdgcn_rcpf(cnt);
         float s = 0.f;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(512, 4) void conv_subpix2_kernel(const ConvArgs a, 
 #pragma unroll
           for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s += qok[i] ? acc[i][p][r] : 0.f;
+            for (int r = 0; r < 4; ++r) s += (qok[i] && r < qnr[i]) ? acc[i][p][r] : 0.f;
         }
         const float mean = s * rc;
         float qq = 0.f;
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(512, 4) void conv_subpix2_kernel(const ConvArgs a, 
 #pragma unroll
           for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float d = acc[i][p][r] - mean; qq += qok[i] ? d * d : 0.f; }
+            for (int r = 0; r < 4; ++r) { const float d = acc[i][p][r] - mean; qq += (qok[i] && r < qnr[i]) ? d * d : 0.f; }
         }
         const float nt_ = st_n + cnt;
         const float wgt = cnt * __builtin_amdgcn_rcpf(nt_);
@@ -287,22 +290,24 @@ __global__ __launch_bounds__(512, 4) void conv_subpix2_kernel(const ConvArgs a, 
           const size_t off = pb + (size_t)(2 * qy[i] + py) * Wo + 2 * qx[i];
           const f32x4 e = acc[i][py * 2], o = acc[i][py * 2 + 1];
           float4 v0 = make_float4(e[0], o[0], e[1], o[1]), v1 = make_float4(e[2], o[2], e[3], o[3]);
+          const bool full = (qnr[i] == 4);                // (else 2 stored columns = the first four outputs of the row: v0)
           if (a.epi_mode == 3) {
-            const float4 u0 = *reinterpret_cast<const float4*>(a.mk_u + off), u1 = *reinterpret_cast<const float4*>(a.mk_u + off + 4);
+            const float4 u0 = *reinterpret_cast<const float4*>(a.mk_u + off), u1 = full ? *reinterpret_cast<const float4*>(a.mk_u + off + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 r0, r1;
-            if (have_ref) { r0 = *reinterpret_cast<const float4*>(mk_ref + off); r1 = *reinterpret_cast<const float4*>(mk_ref + off + 4); }
+            if (have_ref) { r0 = *reinterpret_cast<const float4*>(mk_ref + off); r1 = full ? *reinterpret_cast<const float4*>(mk_ref + off + 4) : make_float4(0.f, 0.f, 0.f, 0.f); }
             else {
               r0 = make_float4(mk_sc * u0.x + mk_sh, mk_sc * u0.y + mk_sh, mk_sc * u0.z + mk_sh, mk_sc * u0.w + mk_sh);
               r1 = make_float4(mk_sc * u1.x + mk_sh, mk_sc * u1.y + mk_sh, mk_sc * u1.z + mk_sh, mk_sc * u1.w + mk_sh);
             }
             v0.x *= (r0.x > 0.f) ? 1.f : a.mk_slope; v0.y *= (r0.y > 0.f) ? 1.f : a.mk_slope; v0.z *= (r0.z > 0.f) ? 1.f : a.mk_slope; v0.w *= (r0.w > 0.f) ? 1.f : a.mk_slope;
             v1.x *= (r1.x > 0.f) ? 1.f : a.mk_slope; v1.y *= (r1.y > 0.f) ? 1.f : a.mk_slope; v1.z *= (r1.z > 0.f) ? 1.f : a.mk_slope; v1.w *= (r1.w > 0.f) ? 1.f : a.mk_slope;
+            if (!full) v1 = make_float4(0.f, 0.f, 0.f, 0.f);
             s1 += ((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w));
             s2 += ((v0.x * (u0.x - mk_mu) + v0.y * (u0.y - mk_mu)) + (v0.z * (u0.z - mk_mu) + v0.w * (u0.w - mk_mu))) +
                   ((v1.x * (u1.x - mk_mu) + v1.y * (u1.y - mk_mu)) + (v1.z * (u1.z - mk_mu) + v1.w * (u1.w - mk_mu)));
           }
           *reinterpret_cast<float4*>(a.out + off) = v0;
-          *reinterpret_cast<float4*>(a.out + off + 4) = v1;
+          if (full) *reinterpret_cast<float4*>(a.out + off + 4) = v1;
         }
       }
       if (a.epi_mode == 3) { st_mean[0] += s1; st_m2[0] += s2; }
@@ -338,10 +343,15 @@ __global__ __launch_bounds__(512, 4) void conv_subpix2_kernel(const ConvArgs a, 
 
 // geo: 0 tiles, 1 blocks, -1 choose (blocks when they fill at least 1.25x better than the tiles)
 inline int subpix2_geo(const ConvArgs& a, int geo, bool mode1) {
+  if (a.Ws % 4 != 0) return 1;                 // (rows of 16-byte pieces only where the width is a multiple of 4: an even width takes the blocks)
   if (geo == 0 || geo == 1) return geo;
   const double fill_t = (double)a.Hs * a.Ws / ((double)cdiv(a.Hs, 8) * 8 * cdiv(a.Ws, 32) * 32);
   const double fill_b = (double)a.Hs / (cdiv(a.Hs, 4) * 4);
   const long items_b = cdiv((long)a.N * (a.Ws / 4) * cdiv(a.Hs, 4), 16L) * cdiv(a.Cout, 16);
+  const long items_t = (long)a.N * cdiv(a.Hs, 8) * cdiv(a.Ws, 32) * cdiv(a.Cout, 16);
+  // (round 5, the 12 / 24-pixel levels of the reference's shipped 192-pixel workload) few, full blocks against MORE THAN ONE ROUND of mostly empty tiles: an item costs
+  // the same matrix time in both geometries, two co-resident items share their SIMDs - 20 x 128 @12x12: 96 block items 100 % full against 320 tile items 28 % full
+  if (items_b < num_cus() && items_t > num_cus() && fill_b >= 2.0 * fill_t) return 1;
   // measured (tools/ab_subpix.py, profiles/r04_experiments.txt 7): the blocks pay their 2.25x patch traffic in single-float DMA pieces; with mode 1's 9 products per
   // M-tile (mode 0: 16) that is worth it only where the tiles are half empty, and never when the blocks leave compute units without a work item
   return (items_b >= num_cus() && fill_b >= (mode1 ? 1.8 : 1.4) * fill_t) ? 1 : 0;
@@ -356,7 +366,7 @@ int launch_conv_subpix2_t(ConvArgs a, const float* mk_ref, hipStream_t st) {
   a.ncb = cdiv(a.Cout, 16);
   long nitems;
   if (GEO == 0) { a.tiles_x = cdiv(a.Ws, G::TLW); a.tiles_y = cdiv(a.Hs, G::TLH); nitems = (long)a.N * a.tiles_x * a.tiles_y * a.ncb; }
-  else { const long nb = (long)a.N * (a.Ws / 4) * cdiv(a.Hs, 4); a.tiles_x = (int)cdiv(nb, 16L); a.tiles_y = 1; nitems = (long)a.tiles_x * a.ncb; }
+  else { const long nb = (long)a.N * cdiv(a.Ws, 4) * cdiv(a.Hs, 4); a.tiles_x = (int)cdiv(nb, 16L); a.tiles_y = 1; nitems = (long)a.tiles_x * a.ncb; }
   const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;

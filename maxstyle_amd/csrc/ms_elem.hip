@@ -374,13 +374,14 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_kernel(const void* __res
     float se = 0.f;
 #pragma unroll
     for (int k = 0; k < kMaxHeadK; ++k) if (k < K) se += expf(z[k] - mx);
-    const float lse = mx + logf(se);
+    const float lg = logf(se);
+    const float lse = mx + lg;
     const int lab = (int)labels[(size_t)n * HW + i];
     float d[kMaxHeadK];
 #pragma unroll
     for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
       const float pk = expf(z[k] - lse);
-      if (k == lab) picked += (double)(z[k] - lse);
+      if (k == lab) picked += (double)(z[k] - mx) - (double)lg;      // log_softmax as (z - max) - log(sum): no cancellation against the rounded max + log (ulp(max) per pixel)
       d[k] = grad_scale * (pk - (k == lab ? 1.f : 0.f));
       if (logits_out) logits_out[((size_t)n * K + k) * HW + i] = z[k];
     }
@@ -469,12 +470,13 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const void
       float se = 0.f;
 #pragma unroll
       for (int k = 0; k < kMaxHeadK; ++k) if (k < K) se += expf(z[k][e] - mx);
-      const float lse = mx + logf(se);
+      const float lg = logf(se);
+      const float lse = mx + lg;
       const int lab = labv[e];
 #pragma unroll
       for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
         const float pk = expf(z[k][e] - lse);
-        if (k == lab) picked += (double)(z[k][e] - lse);
+        if (k == lab) picked += (double)(z[k][e] - mx) - (double)lg;
         d[k][e] = grad_scale * (pk - (k == lab ? 1.f : 0.f));
       }
     }
@@ -602,12 +604,13 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_tail_kernel(const void* 
       float se = 0.f;
 #pragma unroll
       for (int k = 0; k < K; ++k) se += expf(z[k][e] - mx);
-      const float lse = mx + logf(se);
+      const float lg = logf(se);
+      const float lse = mx + lg;
       const int lab = labv[e];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const float pk_ = expf(z[k][e] - lse);
-        if (k == lab) picked += (double)(z[k][e] - lse);
+        if (k == lab) picked += (double)(z[k][e] - mx) - (double)lg;
         d[k][e] = grad_scale * (pk_ - (k == lab ? 1.f : 0.f));
       }
     }

@@ -769,19 +769,25 @@ class InnerLoopEngine:
         check(self.L("ms_pool2_sum")(x.data_ptr(), out.data_ptr(), N * C, H // 2, W // 2, 1 if accumulate else 0, self._st()), "ms_pool2_sum:" + name)
         return out
 
-    def _subpix_ok(self, N, Hs, Ws, cout):
-        """The sub-pixel kernel works on 8 x 32 stored-pixel tiles x 16 output channels: it pays once there is a work item for every CU (measured at C2:
-        128 ch @16^2 -> 64 ch @32^2 = 128 items took 74.8 us against 32.9 us for the fused-fetch kernel with its 4 x 16 tiles; 16 ch @128^2 = 1024 items
-        37.3 against 55.8 us)."""
-        if not (self.subpix and lib.ms_conv_subpix_eligible(Hs, Ws)):
+    def _subpix_ok(self, N, Hs, Ws, cout, mode):
+        """Sub-pixel kernel (mode 0: up-sampling + conv | 1: data-gradient of the stride-2 conv) or the fused-fetch first-generation conv?
+        fp32 storage (second generation, ms_conv_subpix2.h; isolated timings of tools/ab_subpix_small.py, profiles/r05_ab_subpix_small.txt): the data-gradient form wins at
+        every size of the shipped and benchmarked workloads (20 x 128 @14^2: 38.9 against 100.9 us; 20 x 64 @24^2: 20.4 against 58.3; 16 x 128 @16^2: 29.0 against 56.6);
+        the up-sampling form (16 products per pixel instead of 9) from rows of 20 pixels on (20 x 64 @28^2 -> 32: 29.0 against 58.7; 16 x 64 @32^2: 28.7 against 36.3); at
+        12 / 14 / 16 pixels the fused-fetch conv stays (40 against 44-53 us; at 14 pixels 52.6 against 58.7 isolated but 51.9 against 49.4 inside the step).
+        bf16 storage (first generation: 8 x 32 stored-pixel tiles only): once there is a work item for every CU (round 2: 128 items 74.8 against 32.9 us)."""
+        el = lib.ms_conv_subpix_eligible(Hs, Ws) if self.subpix else 0
+        if el == 0 or (el == 2 and self.bf16):           # (2: an even width that is not a multiple of 4 - the fp32 second generation only)
             return False
+        if not self.bf16:
+            return mode == 1 or Ws >= 20
         items = N * ((Hs + 7) // 8) * ((Ws + 31) // 32) * ((cout + 15) // 16)
         return items >= lib.ms_num_cus()
 
     def conv_ups2(self, name, x, cw: ConvW, fin=None):
         """nn.UpsamplingNearest2d(2) -> 3x3 conv (+ BatchNorm statistics of the outputs): sub-pixel kernel when eligible, else the fused-fetch conv."""
         N, Cin, Hs, Ws = x.shape
-        if not self._subpix_ok(N, Hs, Ws, cw.cout):
+        if not self._subpix_ok(N, Hs, Ws, cw.cout, 0):
             return self.conv(name, x, cw, fetch=ops.FETCH_UPS2, stats=True, fin=fin)
         out = self.a(name, N, cw.cout, 2 * Hs, 2 * Ws)
         st, parts = None, N * 4 * Hs * Ws
@@ -800,7 +806,7 @@ class InnerLoopEngine:
     def dgrad_s2(self, name, g, cw: ConvW):
         """Data-gradient of the 3x3 stride-2 conv `cw` (res_convdown.down): sub-pixel kernel when eligible, else the zero-insertion conv."""
         N, Cg, Hs, Ws = g.shape
-        if not self._subpix_ok(N, Hs, Ws, cw.cin):
+        if not self._subpix_ok(N, Hs, Ws, cw.cin, 1):
             dx, _, _ = self.conv(name, g, cw, ks=3, stride=1, fetch=ops.FETCH_ZINS2, dgrad=True)
             return dx
         out = self.a(name, N, cw.cin, 2 * Hs, 2 * Ws)
@@ -947,7 +953,7 @@ class InnerLoopEngine:
             dx, _, _ = self.conv(pfx + ".dx", dsrc, net[key + ".up"], ks=2, stride=2, dgrad=True)
         else:
             down = net[key + ".down"]
-            if next_act is not None and self.fuse_act_bwd and not self.bn_eval and self._subpix_ok(dsrc.shape[0], dsrc.shape[2], dsrc.shape[3], down.cin):
+            if next_act is not None and self.fuse_act_bwd and not self.bn_eval and self._subpix_ok(dsrc.shape[0], dsrc.shape[2], dsrc.shape[3], down.cin, 1):
                 bw_name, act_out, u, coef, slope = next_act
                 return self.dgrad_s2_actbwd(pfx + ".dx", dsrc, down, bw_name, act_out, u, coef, slope, ride=ride_next)
             dx = self.dgrad_s2(pfx + ".dx", dsrc, down)

@@ -325,7 +325,10 @@ def test_subpixel_upsample_conv(dev, N, Cin, Cout, H, W):
     assert rel(out, old) < 2e-6
 
 
-@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 16, 16, 32, 32), (2, 32, 64, 16, 16), (1, 128, 128, 10, 24), (3, 24, 20, 18, 72), (16, 16, 16, 256, 256)])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 16, 16, 32, 32), (2, 32, 64, 16, 16), (1, 128, 128, 10, 24), (3, 24, 20, 18, 72), (16, 16, 16, 256, 256),
+                                            # stored gradients whose width is even but not a multiple of 4 (round 5: the 14-pixel level of the shipped 224-pixel workload;
+                                            # the block geometry with a half block at the end of every row)
+                                            (20, 128, 128, 28, 28), (3, 24, 20, 18, 36), (1, 16, 16, 4, 4), (2, 40, 8, 6, 12)])
 def test_subpixel_stride2_data_gradient(dev, N, Cin, Cout, H, W):
     """ms_conv_subpix mode 1 == d/dx of Conv2d(3x3, s=2, p=1)(x) (res_convdown.down), plain and with the activation-backward epilogue
     (== ms_act_bwd_reduce on the plain result: masked gradient bit for bit, BatchNorm-backward coefficients to rounding)."""

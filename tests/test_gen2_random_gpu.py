@@ -84,6 +84,45 @@ def test_random_subpixel(dev, N, Cin, Cout, Hs, Ws, mode):
         assert torch.equal(outs[flags], outs[1]), flags
 
 
+@pytest.mark.parametrize("N,Cin,Cout,Hs,Ws", [(20, 128, 64, 14, 14), (3, 24, 20, 9, 18), (1, 16, 16, 2, 2), (2, 40, 8, 5, 6), (4, 64, 32, 7, 10), (2, 8, 33, 3, 22)])
+def test_subpixel_upsampling_conv_on_even_widths(dev, N, Cin, Cout, Hs, Ws):
+    """Mode 0 of the sub-pixel kernel on stored widths that are even but not a multiple of 4 (ms_conv_subpix_eligible == 2: the block geometry with a half block at the end
+    of every row; the 14-pixel level of the reference's shipped 224-pixel workload): against fp64 math, against the fused-fetch conv, and its statistics table through
+    ms_bn_finalize - bias, channel tails, one-block rows."""
+    from maxstyle_amd import ops
+    from maxstyle_amd._lib import lib, check
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.ms_conv_subpix_eligible(Hs, Ws) == 2 and lib.ms_conv_subpix_eligible(Hs, Ws + 1) == 0 and lib.ms_conv_subpix_eligible(Hs, Ws + 2) == 1
+    x = _rand((N, Cin, Hs, Ws), 1); w = _rand((Cout, Cin, 3, 3), 2, 0.1); b = _rand((Cout,), 3)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+    xd, bd = x.to(dev), b.to(dev)
+    wp = ops.pack_conv_weight(w.to(dev))
+    sums = torch.empty(int(lib.ms_subpix_pack_floats(Cin, Cout)), device=dev)
+    check(lib.ms_subpix_pack(wp.data_ptr(), sums.data_ptr(), Cin, Cout, st), "ms_subpix_pack")
+    parts = lib.ms_conv_stats_parts(N, 2 * Hs, 2 * Ws)
+    outs = []
+    for rep in range(2):
+        out = torch.full((N, Cout, 2 * Hs, 2 * Ws), float("nan"), device=dev)
+        stats = torch.zeros(Cout * parts + 1, 4, device=dev)
+        check(lib.ms_conv_subpix2(xd.data_ptr(), out.data_ptr(), wp.data_ptr(), sums.data_ptr(), bd.data_ptr(), N, Cin, Hs, Ws, Cout, 0, stats.data_ptr(), 0, 0, 0, 1.0, 0, 0, st), "ms_conv_subpix2")
+        outs.append((out, stats))
+    out, stats = outs[0]
+    assert torch.equal(out, outs[1][0]) and torch.equal(stats, outs[1][1])
+    assert rel(out, ref) < 3e-6
+    st2 = torch.zeros_like(stats)
+    old = ops.conv2d(xd, wp, bd, Cout, 3, 1, fetch=ops.FETCH_UPS2, stats=st2)
+    assert rel(out, old) < 3e-6
+    gamma, beta = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev)
+    cf1, cf2 = torch.empty(Cout, 4, device=dev), torch.empty(Cout, 4, device=dev)
+    check(lib.ms_bn_finalize(stats.data_ptr(), parts, gamma.data_ptr(), beta.data_ptr(), 1e-5, cf1.data_ptr(), Cout, st), "bn_finalize")
+    check(lib.ms_bn_finalize(st2.data_ptr(), parts, gamma.data_ptr(), beta.data_ptr(), 1e-5, cf2.data_ptr(), Cout, st), "bn_finalize")
+    o64 = out.double()
+    assert float((cf1[:, 2].double() - o64.mean(dim=(0, 2, 3))).abs().max()) < 2e-6 * float(ref.abs().max())
+    assert rel(cf1, cf2) < 3e-5
+    # the first generation cannot take these rows: a clear error, not a wrong result
+    assert lib.ms_conv_subpix2(xd.data_ptr(), out.data_ptr(), wp.data_ptr(), sums.data_ptr(), bd.data_ptr(), N, Cin, Hs, Ws, Cout, 0, 0, 0, 0, 0, 1.0, 0, 1, st) != 0
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W", _shapes(13, 12, [256, 264, 320, 384, 512], 300, (1, 4), 44, nmax=16))
 def test_random_gemm_1x1(dev, N, Cin, Cout, H, W):
     from maxstyle_amd import ops

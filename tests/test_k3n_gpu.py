@@ -163,3 +163,47 @@ def test_cross_workgroup_finalize_prologue_on_narrow_rows(dev):
         check(lib.ms_conv2d_xfin(u1.data_ptr(), 0, out.data_ptr(), wp2.data_ptr(), 0, N, C, H, W, C, 3, 1, 0, 1, 0.2, 0, 0, 0, stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                  1e-5, 0.0, coef_x.data_ptr(), gran.data_ptr(), err.data_ptr(), st), "ms_conv2d_xfin")
         assert torch.equal(out, ref) and torch.equal(coef_x, coef) and int(err) == 0
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H", [(20, 128, 128, 14), (3, 64, 40, 10), (1, 80, 16, 2)])
+def test_one_by_one_convs_on_14_pixel_rows(dev, N, Cin, Cout, H):
+    """The 1x1 convs of the 14-pixel level (final_conv forward with BatchNorm statistics, its data-gradient behind a BatchNorm-backward prologue; encoder_decoder.py:441-445)
+    on the narrow-rows kernel (KS = 1 variant: centre tap of the same band) - against fp64 math and against the first-generation kernel they leave (rounding level)."""
+    from maxstyle_amd import ops
+    W = 14
+    lib = _lib()
+    x = _rand((N, Cin, H, W), 31) * 0.7 + 0.2; w = _rand((Cout, Cin, 1, 1), 32, 0.1); b = _rand((Cout,), 33)
+    x2 = _rand((N, Cin, H, W), 34); cf = _rand((Cin, 4), 35)
+    xd, x2d, cfd = x.to(dev), x2.to(dev), cf.to(dev)
+    wp = ops.pack_conv_weight(w.to(dev))
+    pa, pb, pc = ops.coef_ptrs(cfd)
+    v = lambda i: cf[:, i].double().view(1, -1, 1, 1)
+
+    def run():
+        res = {}
+        stats, parts = ops.conv_stats_buffer(N, Cout, H, W, dev)
+        stats.fill_(0.0)
+        res["stats"] = ops.conv2d(xd, wp, b.to(dev), Cout, 1, 1, stats=stats)
+        res["coef"] = ops.bn_finalize(stats, parts, torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev))
+        res["plain"] = ops.conv2d(xd, wp, None, Cout, 1, 1)
+        res["pro1"] = ops.conv2d(xd, wp, None, Cout, 1, 1, pro_mode=1, pro_a=pa, pro_b=pb, pro_cstride=4, slope=0.2)
+        res["pro2"] = ops.conv2d(xd, wp, None, Cout, 1, 1, pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=x2d)
+        base = _rand((N, Cout, H, W), 36).to(dev)
+        res["pro2_acc"] = ops.conv2d(xd, wp, None, Cout, 1, 1, pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=x2d, epi_mode=1, out=base.clone())
+        res["base"] = base
+        return res
+    new = run()
+    was = lib.ms_set_option(b"conv.k3n", 0)
+    try:
+        old = run()
+    finally:
+        lib.ms_set_option(b"conv.k3n", was)
+    r0 = F.conv2d(x.double(), w.double(), b.double())
+    assert rel(new["stats"], r0) < 3e-6 and rel(new["plain"], F.conv2d(x.double(), w.double())) < 3e-6
+    assert rel(new["coef"][:, 2], r0.mean((0, 2, 3))) < 1e-5
+    assert rel(new["pro1"], F.conv2d(F.leaky_relu(v(0) * x.double() + v(1), 0.2), w.double())) < 4e-6
+    r2 = F.conv2d(v(0) * x.double() + v(1) * x2.double() + v(2), w.double())
+    assert rel(new["pro2"], r2) < 4e-6 and rel(new["pro2_acc"], r2 + new["base"].cpu().double()) < 4e-6
+    for k in ("stats", "plain", "pro1", "pro2", "pro2_acc"):
+        assert rel(new[k], old[k]) < 3e-6, k
+    assert rel(new["coef"][:, :3], old["coef"][:, :3]) < 2e-5
