@@ -243,7 +243,7 @@ def in_step_times(eng, img, wanted, reps=15):
 
 def step_roofline(ledger, step_s):
     """sum over the launches of one step of max(bytes / 8 TB/s, executed flop / 157.3 TFLOP/s) against the measured step time (accounting rules: tools/step_budget.py);
-    the per-launch table with in-step durations from a kernel trace is committed as profiles/r04_step_budget_<config>.txt / .json."""
+    the per-launch table with in-step durations from a kernel trace is committed as profiles/r05_step_budget_<config>.txt / .json."""
     sb = _step_budget()
     tot = hb = mf = 0.0
     for e in ledger:
@@ -283,7 +283,7 @@ def _traffic_table(B, H, W):
     if (B, H, W) != (16, 256, 256):
         return {}
     tab = {}
-    for name in ("r01_traffic.json", "r02_traffic.json", "r03_traffic.json", "r04_traffic.json"):
+    for name in ("r01_traffic.json", "r02_traffic.json", "r03_traffic.json", "r04_traffic.json", "r05_traffic.json"):
         try:
             tab.update(json.load(open(os.path.join(ROOT, "profiles", name))))
             tab["_source"] = f"profiles/{name}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (tools/profile_round.sh), NOT collected in this run"
@@ -813,18 +813,18 @@ def whole_call(dev, args, rank):
             best = dt_ if best is None else min(best, dt_)
         return best
     t_call, t_dec = timed(K, 20), timed(0, 20)
-    # the same call with the DEFERRED error protocol (solver.loop_error_check): the single-read kernel's error word is resolved by the next call / at
-    # optimize_all_params instead of by an event wait inside this call, so the host prepares the next call while the GPU still runs this one
-    S.loop_error_check = "deferred"
-    t_call_d, t_dec_d = timed(K, 20), timed(0, 20)
+    # the same call with the SYNCHRONOUS error protocol (solver.loop_error_check = "sync"): the single-read kernel's error word is resolved by an event wait inside the
+    # call that produced the image instead of by the next call / optimize_all_params (the default since round 5), so the host cannot prepare the next call meanwhile
     S.flush_loop_errors()
+    S.loop_error_check = "sync"
+    t_call_s, t_dec_s = timed(K, 20), timed(0, 20)
     S.loop_error_check = None
-    return {"what": "generate_max_style_image through the drop-in API, C2 workload, K=5, every layer applied (p forced), captured graph replayed per call; default = "
-                    "the call waits for its own error check (a spin time-out of the single-read kernel raises from the call that produced the image)",
+    return {"what": "generate_max_style_image through the drop-in API, C2 workload, K=5, every layer applied (p forced); from its second issue the whole call (decode + K steps) "
+                    "replays as ONE captured graph; default error protocol = deferred (a spin time-out of the single-read kernel raises from the next call / the weight step at the latest)",
             "ms_per_call": t_call * 1e3, "ms_decode_only_call": t_dec * 1e3, "whole_call_steps_s": K / t_call,
             "steps_s_excluding_decode": K / max(t_call - t_dec, 1e-9),
-            "deferred_error_check": {"ms_per_call": t_call_d * 1e3, "ms_decode_only_call": t_dec_d * 1e3, "whole_call_steps_s": K / t_call_d,
-                                     "steps_s_excluding_decode": K / max(t_call_d - t_dec_d, 1e-9)}}
+            "sync_error_check": {"ms_per_call": t_call_s * 1e3, "ms_decode_only_call": t_dec_s * 1e3, "whole_call_steps_s": K / t_call_s,
+                                 "steps_s_excluding_decode": K / max(t_call_s - t_dec_s, 1e-9)}}
 
 
 def shipped_blocks(dev, rank):
@@ -906,7 +906,7 @@ def secondary_blocks(dev, args, rank):
     roof = kernel_rooflines(eng, dev, "c4", ins)
     out["c4"] = {"workload": f"C4: FCN_64 dual-branch, batch {args.batch}x3x320x320, MaxStyle layers [3,4,5], Adam lr 0.1, fp32", "steps_s": 10 / dt, "ms_per_step": dt / 10 * 1e3,
                  "hip_graph": graphed, "roofline": roof["dominant"], "roofline_conv_fwd": roof["conv_fwd"], "roofline_maxstyle": roof["style"], "roofline_maxstyle_bwd": roof["style_bwd"],
-                 "step_roofline": (step_roofline(ledger, dt / 10) if ledger else None), "step_roofline_per_launch": "profiles/r04_step_budget_c4.txt"}
+                 "step_roofline": (step_roofline(ledger, dt / 10) if ledger else None), "step_roofline_per_launch": "profiles/r05_step_budget_c4.txt"}
     del eng
     torch.cuda.empty_cache()
     out["shipped"] = shipped_blocks(dev, rank)
@@ -1107,7 +1107,7 @@ def main():
             "roofline": roof["dominant"], "roofline_dgrad_plain": roof["dgrad_plain"], "roofline_conv_fwd": roof["conv_fwd"],
             "roofline_maxstyle": roof["style"], "roofline_maxstyle_bwd": roof["style_bwd"], "roofline_maxstyle_bf16": roof["style_bf16"], "loss_check": loss_last,
             "step_roofline": (step_roofline(ledger, step_s) if ledger else None),
-            "step_roofline_per_launch": f"profiles/r04_step_budget_{args.config}.txt (every launch of the step: bytes, executed flop, bound, in-step duration from a rocprofv3 kernel trace)",
+            "step_roofline_per_launch": f"profiles/r05_step_budget_{args.config}.txt (every launch of the step: bytes, executed flop, bound, in-step duration from a rocprofv3 kernel trace)",
         }
         if world == 1 and not args.no_cpu_baseline and args.config == "c2" and not bf16:
             res["cpu_baseline"], _ = cpu_baseline(W, img, lab, styles, args.cpu_steps, z_gpu=z_i.cpu())

@@ -479,7 +479,7 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             v.step()
 
     def flush_loop_errors(self):
-        """Resolve the deferred error check of every inner-loop engine (loop_error_check = "deferred"); a no-op in the default "sync" mode."""
+        """Resolve the deferred error check of every inner-loop engine (loop_error_check = "deferred", the default); a no-op in "sync" mode."""
         for eng in self._engines.values():
             eng.flush_errors()
         # the training engines' `_xfin` launches (cross-workgroup BatchNorm finalize in the forward passes) have an error word too: a weight step must not follow a

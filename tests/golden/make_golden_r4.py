@@ -105,7 +105,9 @@ def _train_phase(S, iters, B, size, seed0, every):
 
 
 def train_64(solver_mod, it64=300, it320=90, more=0):
-    """more > 0: continue from the checkpoint of an earlier call (MS_R4_CKPT) for `more` iterations at 320x320 (fresh AdamW moments, seeds 27000+)."""
+    """more > 0: continue from the checkpoint of an earlier call (MS_R4_CKPT) for `more` iterations at 320x320 (fresh AdamW moments, seeds 27000+).
+    Every call appends what it ran to tests/golden/trained_fcn64_320.provenance.json (the continuation arguments behind the committed file were
+    not recorded in round 4 - the sidecar says what is known; the fixture IS the network, both sides of every test load it, so parity does not depend on regenerating it)."""
     torch.set_num_threads(NTHREADS)
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -128,6 +130,17 @@ def train_64(solver_mod, it64=300, it320=90, more=0):
                 gr["lr"] = 5e-4
         _train_phase(S, it320, 2, 320, 26000, 10)
     torch.save({n: S.model[n].state_dict() for n in NETS}, CKPT)
+    import json
+    prov_path = os.path.join(HERE, "trained_fcn64_320.provenance.json")
+    prov = json.load(open(prov_path)) if (more and os.path.exists(prov_path)) else {"file": "trained_fcn64_320.npz", "phases": []}
+    if more:
+        prov["phases"].append({"command": f"make_golden_r4.py more={more}", "size": 320, "iterations": more, "batch": 2, "lr": 5e-4, "seed0": 27000 + int(os.environ.get("MS_R4_SEED_OFF", "0")),
+                               "MS_R4_SEED_OFF": os.environ.get("MS_R4_SEED_OFF", "0"), "adamw_moments": "fresh"})
+    else:
+        prov["phases"] = [{"command": "make_golden_r4.py train64", "size": 64, "iterations": it64, "batch": 8, "lr": 1e-3, "seed0": 21000, "init": "orc.procedural_weights(SPEC4, seed=0)"},
+                          {"command": "(same call)", "size": 320, "iterations": it320, "batch": 2, "lr": 5e-4, "seed0": 26000}]
+    prov["threads"] = NTHREADS
+    json.dump(prov, open(prov_path, "w"), indent=1)
     store = quantise_state(S.model)
     path = os.path.join(HERE, "trained_fcn64_320.npz")
     np.savez_compressed(path, **store)

@@ -49,6 +49,13 @@ python tools/train_timeline.py 10 > $O/${R}_train_timeline.txt 2>&1
 bash tools/traffic_by_kernel.sh c2 $O/${R}_step_budget_c2.json > $O/${R}_traffic_by_kernel_c2.txt 2>&1
 bash tools/traffic_by_kernel.sh c4 $O/${R}_step_budget_c4.json > $O/${R}_traffic_by_kernel_c4.txt 2>&1
 { python tools/one_small.py c2; python tools/one_small.py c4; bash tools/pmc_cmd.sh $O/pmc_small small_cout tools/one_small.py c2; bash tools/pmc_cache.sh $O/pmc_small2 small_cout tools/one_small.py c2; } 2>&1 | grep -v amdgpu > $O/${R}_small_cout_pmc.txt
+# 5f. round 5: the shipped workloads' step budgets, the small-image resampling A/B, the layer-chain probe, configs 4 / 5 against the reference's draws
+bash tools/step_budget_shipped.sh > /dev/null 2>&1
+for c in acdc192 prostate224; do cp gpurun_out/sb/step_budget_$c.txt $O/${R}_step_budget_$c.txt; cp gpurun_out/sb/step_budget_$c.json $O/${R}_step_budget_$c.json; done
+python tools/ab_subpix_small.py 20 2>&1 | grep -v amdgpu > $O/${R}_ab_subpix_small.txt
+timeout 300 python tools/chain_probe.py 2>&1 | grep -v amdgpu > $O/${R}_chain_probe.txt; cp gpurun_out/chain_probe.json $O/${R}_chain_probe.json
+python tools/draws_report.py 2>&1 | grep -E "^c4|^c5" > $O/${R}_draws_report.txt
+python tools/shipped_report.py 2>&1 | grep -E "^acdc|^prostate|per sample" > $O/${R}_shipped_report.txt
 # 6. un-profiled bench lines
 python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
 python bench.py --config c4 --steps 10 --warmup 2 > $O/${R}_bench_c4.json 2> $O/bench_c4.err

@@ -24,7 +24,7 @@ run() {   # run "<env assignments>" <pytest deselect arguments...>
   local sw=$1; shift
   if [ -n "$ONLY" ] && ! echo "${sw:-default}" | grep -qE "$ONLY"; then return; fi
   echo -n "${sw:-default}: "
-  env $sw timeout 1200 python -m pytest tests -q -m gpu --maxfail=8 -rf "$@" 2>&1 | grep -E "^FAILED|passed|failed" | cut -c1-220
+  env $sw timeout 1200 python -m pytest tests -q -m gpu --maxfail=8 -rf ${MS_MATRIX_EXTRA:-} "$@" 2>&1 | grep -E "^FAILED|passed|failed" | cut -c1-220
 }
 run ""
 # bf16 matrix arithmetic and the three-way split exist in the wide kernel only; `nonoise` / `noisefixed`: free-running K = 3 cases whose bars are 3x the reference's own
@@ -48,7 +48,11 @@ run MS_OPTIONS=engine.ride=0
 run MS_OPTIONS=engine.pool_fuse=0 $KNIFE $KINK6
 run MS_OPTIONS=engine.pool_epi=0
 run MS_OPTIONS=engine.lazy_style_head=0
-run MS_OPTIONS=engine.small_cin=1 $KNIFE "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[nomix]" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[nonoise]" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[noisefixed]" -k "not inner_loop_with_and_without_the_winograd_form"      # opt-in kernel: see experiment 18
+# the first conv on the general kernels (engine.small_cin=0: the same output bits, another statistics grouping) and on the vector-ALU form (conv.k9=0: another rounding)
+run MS_OPTIONS=engine.small_cin=0 $KNIFE
+run MS_OPTIONS=conv.k9=0 $KNIFE "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[nomix]" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[nonoise]" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[noisefixed]" -k "not inner_loop_with_and_without_the_winograd_form"      # opt-in kernel: see experiment 18 -k "not taps_as_k"
+# the narrow-rows second generation off: the first-generation kernel on rows of 12 / 14 / 16 pixels
+run MS_OPTIONS=conv.k3n=0 $KNIFE -k "not (narrow_rows or second_generation_is_taken or one_by_one_convs_on_14)"
 # the Winograd form is what these tests are about (and what the bench line's `form` field reports)
 run MS_OPTIONS=engine.winograd=0 $KNIFE -k "not (pooled_data_gradient or winograd or bench_line_contract)"
 # shared device: neither the single-read kernel nor the cross-workgroup finalize is selected
