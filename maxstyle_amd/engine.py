@@ -1210,6 +1210,24 @@ class InnerLoopEngine:
         self._upload(f"st{i}.gamma_noise", gamma_noise, self.param(i, "gamma_noise"))
         self._upload(f"st{i}.beta_noise", beta_noise, self.param(i, "beta_noise"))
 
+    def set_style_states(self, states):
+        """set_style_state for every layer of a call ({i: (perm, lmda, gamma_noise, beta_noise)}): device-resident parameters (what MaxStyle.__init__ creates) travel in
+        ONE multi-tensor copy instead of three launches per layer (host time and tiny launches of a generate_max_style_image call: tools/prof_call_host.py)."""
+        dsts, srcs = [], []
+        for i, (perm, lmda, gamma_noise, beta_noise) in states.items():
+            s = self.styles[i]
+            s.perm = self.t(f"st{i}.perm", s.B, dtype=torch.int64)      # engine-owned: a captured graph keeps its address
+            self._upload(f"st{i}.perm", perm, s.perm)
+            for nm, src in (("lmda", lmda), ("gamma_noise", gamma_noise), ("beta_noise", beta_noise)):
+                dst = self.param(i, nm)
+                src = torch.as_tensor(src)
+                if src.is_cuda and src.dtype == dst.dtype and src.device == dst.device and src.numel() == dst.numel():
+                    dsts.append(dst); srcs.append(src.detach().reshape(dst.shape))
+                else:
+                    self._upload(f"st{i}.{nm}", src, dst)
+        if dsts:
+            torch._foreach_copy_(dsts, srcs)
+
     def preset_style_std(self, i, gamma_std, beta_std):
         """maxstyle.py:165-168: a layer that already holds gamma_std / beta_std keeps them (`if self.gamma_std is None: ...`) - the call starts with the batch std frozen
         at the given values instead of deriving it from its first forward.  After configure_styles / restore_config; the caller runs such a call without graphs."""

@@ -379,9 +379,9 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
                 eng.configure_styles(layers, slots)
             eng._cfg_sig = sig
             preset_std = False
+            eng.set_style_states({i: (mods[i].perm, mods[i].lmda.detach(), mods[i].gamma_noise.detach(), mods[i].beta_noise.detach()) for i in layers})
             for i in layers:
                 m = mods[i]
-                eng.set_style_state(i, m.perm, m.lmda.detach(), m.gamma_noise.detach(), m.beta_noise.detach())
                 if m.gamma_std is not None and m.beta_std is not None:       # (only a style_init_hook can have set them: maxstyle.py:165-168 keeps a std it already holds)
                     eng.preset_style_std(i, m.gamma_std, m.beta_std)
                     preset_std = True
@@ -396,14 +396,22 @@ class AdvancedTripletReconSegmentationModel(nn.Module):
             eng.stash_config(sig)
             mode = self.loop_error_check or "deferred"
             eng.check_errors(sync=(mode != "deferred"))                 # the single-read MaxStyle kernel's error word (spin time-out): never silent
-            with torch.no_grad():                                  # hand the optimised state back to the modules (debugging / tests)
+            with torch.no_grad():                                  # hand the optimised state back to the modules (debugging / tests): two multi-tensor copies
+                dsts, srcs = [], []
                 for i in layers:
                     m = mods[i]
                     for nm in ("gamma_noise", "beta_noise", "lmda"):
-                        getattr(m, nm).data.copy_(eng.param(i, nm))
+                        d_, s_ = getattr(m, nm).data, eng.param(i, nm)
+                        if d_.is_cuda and d_.dtype == s_.dtype and d_.shape == s_.shape:
+                            dsts.append(d_); srcs.append(s_)
+                        else:
+                            d_.copy_(s_)
                     std = eng.buf.get(f"st{i}.std")
                     if std is not None:
-                        m.gamma_std = std[0].clone().view(1, -1, 1, 1); m.beta_std = std[1].clone().view(1, -1, 1, 1)
+                        m.gamma_std = torch.empty(1, std.shape[1], 1, 1, dtype=std.dtype, device=std.device); m.beta_std = torch.empty_like(m.gamma_std)
+                        dsts += [m.gamma_std.view(-1), m.beta_std.view(-1)]; srcs += [std[0], std[1]]
+                if dsts:
+                    torch._foreach_copy_(dsts, srcs)
             self.last_style_modules = nn_style_augmentor_dict
             self.last_losses = eng.losses(steps).clone() if steps > 0 else None
             out = recon_image.detach().float().clone() if recon_image.dtype != torch.float32 else recon_image.detach().clone()
