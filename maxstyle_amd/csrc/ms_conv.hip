@@ -214,7 +214,7 @@ static int conv2d_impl(const float* in, const float* in2, float* out, const floa
     return conv_dispatch_wide(a, nt, st);
   }
   if (allow_wide && conv_wide_eligible(a, ks, stride, fetch, vec)) return conv_dispatch_wide(a, nt, st);
-  if (conv_k3n_eligible(a, ks, stride, fetch)) return conv_dispatch_k3n(a, ks, st);      // second generation for rows of 12 / 14 / 16 pixels (ms_conv_k3n.h)
+  if (conv_k3n_eligible(a, ks, stride, fetch)) return conv_dispatch_k3n(a, ks, st, stride);      // second generation for rows of 12 / 14 / 16 pixels (ms_conv_k3n.h)
   if (ks == 3 && stride == 1) return conv_dispatch_k3s1(a, fetch, nt, vec, narrow, use_in2, st);
   if (ks == 1 && allow_wide && conv_k1s_eligible(a, ks, stride, fetch)) return conv_dispatch_k1s(a, st);      // streaming form (ms_conv_k1s.h)
   if (ks == 1 && allow_wide && conv_k1g_eligible(a, ks, stride, fetch)) return conv_dispatch_k1g(a, st);      // LDS-tiled GEMM form of the channel-heavy levels (ms_conv_k1g.h)

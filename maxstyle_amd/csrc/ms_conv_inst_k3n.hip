@@ -8,8 +8,10 @@ static int k3n_w(const ConvArgs& a, int mt, hipStream_t st) {
   return mt == 2 ? launch_conv_k3n_t<W, 2, 1>(a, st) : launch_conv_k3n_t<W, 1, 1>(a, st);
 }
 int conv_dispatch_k3n_k1(const ConvArgs& a, int mt, hipStream_t st);      // ms_conv_inst_k3n2.hip: the 1x1 variants (rows of 14 pixels)
-int conv_dispatch_k3n(const ConvArgs& a, int ks, hipStream_t st) {
+int conv_dispatch_k3n_s2(const ConvArgs& a, int mt, hipStream_t st);      // ms_conv_inst_k3n2.hip: the stride-2 variants
+int conv_dispatch_k3n(const ConvArgs& a, int ks, hipStream_t st, int stride) {
   const int mt = conv_k3n_mt(a);
+  if (stride == 2) return conv_dispatch_k3n_s2(a, mt, st);
   if (ks == 1) return conv_dispatch_k3n_k1(a, mt, st);
   if (a.pro_mode == 2) return conv_dispatch_k3n_p2(a, mt, st);
   switch (a.Ws) {

@@ -24,14 +24,15 @@
 
 namespace ms {
 
-template <int W, int MT, int KS = 3>
+template <int W, int MT, int KS = 3, int S = 1>
 struct K3nGeo {
-  static constexpr int CK = 16;
+  static constexpr int CK = (S == 1) ? 16 : 8;                          // (stride 2: the band is four times the pixels - 8-channel chunks keep three stage buffers in LDS)
   static constexpr int TAPS = KS * KS;                                  // 9 | 1 (round 5: the 1x1 convs on 14-pixel rows share the kernel - same band, centre tap only)
-  static constexpr int RS = W + 2;
+  static constexpr int WI = S * W;                                      // input row width (S = 2: the stride-2 conv onto rows of W pixels, round 5)
+  static constexpr int RS = WI + 2;
   static constexpr int PIX = 64 * MT;                                   // pixels of a work item: 4 MFMA waves x MT M-tiles x 16
   static constexpr int SPAN = (PIX % W == 0) ? PIX / W : (W - 1 + PIX - 1) / W + 1;      // image rows PIX consecutive pixels can touch (item starts are multiples of PIX)
-  static constexpr int BR = SPAN + 2;                                   // ... plus the halo rows
+  static constexpr int BR = S * (SPAN - 1) + 3;                         // input rows of the band: S (SPAN - 1) + 1 plus the halo rows
   static constexpr int BASE = BR * RS;
   static constexpr int PS = BASE + ((16 - BASE % 32 + 32) % 32);        // plane stride == 16 (mod 32 banks)
   static constexpr int IN_FLOATS = CK * PS;
@@ -46,15 +47,17 @@ struct K3nGeo {
 };
 
 // PRO: 0 none | 1 v = lrelu(a[c] v + b[c]) | 2 v = a[c] v + b[c] v2 + c[c]
-template <int W, int MT, int PRO, bool CHAINED = false, int KS = 3>
+template <int W, int MT, int PRO, bool CHAINED = false, int KS = 3, int S = 1>
 __device__ __forceinline__ void conv_k3n_body(const ConvArgs& a, float* smem) {
-  using G = K3nGeo<W, MT, KS>;
+  static_assert(S == 1 || (PRO == 0 && KS == 3), "the stride-2 form is the prologue-free 3x3 conv");
+  using G = K3nGeo<W, MT, KS, S>;
+  constexpr int WI = G::WI;
   constexpr int CK = G::CK, RS = G::RS, PS = G::PS, PIX = G::PIX, BUF = G::BUF, NJ = G::NJ, NWJ = G::NWJ, NE = G::NE, OOB = G::OOB;
   float* cf_lds = smem + 3 * BUF;                        // [cin_pad][4] prologue coefficients
   const int wave = MS_TID >> 6, lane = MS_TID & 63;
   const bool producer = wave >= 4;
   const int ncb = a.ncb;
-  const int HW = a.Hs * a.Ws;
+  const int HW = a.Hout * a.Wout, HWI = a.Hs * a.Ws;     // output / input plane (equal at stride 1)
   const int gpi = (HW + PIX - 1) / PIX;                  // pixel groups per image
   const int nitems = a.N * gpi * ncb;
   const int nchunks = a.cin_pad / CK;
@@ -96,29 +99,29 @@ __device__ __forceinline__ void conv_k3n_body(const ConvArgs& a, float* smem) {
 
     if constexpr (PRO == 0) {
       // ---- LDS-DMA: dword piece (sw + 4 j): LDS dwords L = ((sw + 4 j) * 64 + lane) of the [CK][PS] band image
-      const ms_i32x4 rs_in = ms_dma_rsrc_n(a.in, (unsigned)a.N * a.Cin * HW * 4u);
+      const ms_i32x4 rs_in = ms_dma_rsrc_n(a.in, (unsigned)a.N * a.Cin * HWI * 4u);
       int i_sb[NJ], i_br[NJ], i_voff[NJ];        // static byte offset (channel, band row, column) | band row (or -1000: no element) | per-item offset
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int L = (sw + 4 * j) * 64 + lane;
         const int c = L / PS, rem = L - c * PS, br = rem / RS, bc = rem - br * RS;
-        const bool ok = (c < CK) && (rem < G::BASE) && (bc >= 1) && (bc <= W);
-        i_sb[j] = (c * HW + br * W + (bc - 1)) * 4;
+        const bool ok = (c < CK) && (rem < G::BASE) && (bc >= 1) && (bc <= WI);
+        i_sb[j] = (c * HWI + br * WI + (bc - 1)) * 4;
         i_br[j] = ok ? br : -1000;
         i_voff[j] = OOB;
       }
       auto set_item = [&](int grp_) {
-        const int r0 = (grp_ * PIX) / W;                    // image row of the item's first pixel; band row 0 = image row r0 - 1
+        const int r0 = (grp_ * PIX) / W;                    // output row of the item's first pixel; band row 0 = input row S r0 - 1
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int row = r0 - 1 + i_br[j];
-          i_voff[j] = ((unsigned)row < (unsigned)a.Hs) ? (i_sb[j] + (r0 - 1) * W * 4) : OOB;
+          const int row = S * r0 - 1 + i_br[j];
+          i_voff[j] = ((unsigned)row < (unsigned)a.Hs) ? (i_sb[j] + (S * r0 - 1) * WI * 4) : OOB;
         }
       };
       auto issue = [&](int buf, int n_, int cb_, int chunk_) {
         issue_w(buf, cb_, chunk_);
         const unsigned lb = lds0 + (unsigned)buf * (BUF * 4);
-        const int soff = (n_ * a.Cin + chunk_ * CK) * HW * 4;
+        const int soff = (n_ * a.Cin + chunk_ * CK) * HWI * 4;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) ms_lds_dma4(rs_in, lb + (unsigned)(sw + 4 * j) * 256, i_voff[j], soff);
       };
@@ -257,7 +260,7 @@ __device__ __forceinline__ void conv_k3n_body(const ConvArgs& a, float* smem) {
     for (int t = 0; t < MT; ++t) {
       const int pix = min(p0 + (wave * MT + t) * 16 + m, HW - 1);
       const int y = pix / W, x = pix - y * W;
-      a_off[t] = k * PS + (y - r0) * RS + x;
+      a_off[t] = k * PS + S * (y - r0) * RS + S * x;
     }
   };
   auto compute = [&](const float* buf) {
@@ -378,10 +381,10 @@ __device__ __forceinline__ void conv_k3n_body(const ConvArgs& a, float* smem) {
   }
 }
 
-template <int W, int MT, int PRO, int KS = 3>
+template <int W, int MT, int PRO, int KS = 3, int S = 1>
 __global__ __launch_bounds__(512, 4) void conv_k3n_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  conv_k3n_body<W, MT, PRO, false, KS>(a, smem);
+  conv_k3n_body<W, MT, PRO, false, KS, S>(a, smem);
 }
 
 // ---- go / no-go probe for a LAYER-CHAIN launch: L plain 3x3 layers (prologue-free, plain store) walked by ONE persistent
@@ -416,7 +419,18 @@ __global__ __launch_bounds__(512, 4) void conv_k3n_chain_kernel(const ConvArgs* 
 }
 
 // Eligible: 3x3 stride 1, plain fetch, fp32 storage, rows of 12 / 14 / 16 pixels, whole 16-channel chunks, per-channel coefficients, 16-byte pixel quads
+// stride 2 (round 5: res_convdown.down onto rows of 12 / 14 / 16 pixels - encoder_decoder.py:40 at the deepest level; the DMA-staged stride-2 kernel needs 16-byte output
+// quads and 32-pixel tiles, the first generation ran it on its scalar path at 14 pixels: 44.9 us at the shipped Prostate shape): prologue-free, bias, plain store
+inline bool conv_k3n_s2_eligible(const ConvArgs& a, int ks, int stride, int fetch) {
+  if (opt(OPT_CONV_K3N) == 0 || ks != 3 || stride != 2 || fetch != FETCH_NORMAL || a.act_bf16 != 0 || a.pro_mode != 0 || a.in2 != nullptr || a.stats != nullptr ||
+      a.epi_mode != 0 || a.xf_tab != nullptr || a.ride_out != nullptr) return false;
+  if (!(a.Wout == 12 || a.Wout == 14 || a.Wout == 16) || a.Ws != 2 * a.Wout || a.Hs != 2 * a.Hout || (a.Hout * a.Wout) % 4 != 0) return false;
+  if (a.Cin % 8 != 0 || a.cin_pad != a.Cin || a.Cin < 16) return false;
+  if ((long long)a.N * a.Cin * a.Hs * a.Ws * 4 >= (1LL << 31) || 9LL * a.cin_pad * a.cout_pad * 4 >= (1LL << 31)) return false;
+  return aligned16(a.in) && aligned16(a.out) && aligned16(a.w);
+}
 inline bool conv_k3n_eligible(const ConvArgs& a, int ks, int stride, int fetch) {
+  if (stride == 2) return conv_k3n_s2_eligible(a, ks, stride, fetch);
   if (opt(OPT_CONV_K3N) == 0 || !(ks == 3 || ks == 1) || stride != 1 || fetch != FETCH_NORMAL || a.act_bf16 != 0) return false;
   // 1x1: only rows of 14 pixels (not a multiple of 4: the tiled first-generation 1x1 falls to its scalar staging there - 28-33 us per launch at the shipped Prostate shape
   // against ~8 us at 12 / 16 pixels) and only the plain / statistics / two-tensor-prologue calls (the residual tails and riders have the GEMM kernel, ms_conv_k1g.h)
@@ -436,27 +450,27 @@ inline bool conv_k3n_eligible(const ConvArgs& a, int ks, int stride, int fetch) 
 // (Measured and NOT adopted, round 5: one tile at 20 x 128 @14x14, where two tiles mean 320 items = two rounds on 256 CUs against 640 half-size items = three - the
 //  launches went from 30-32 to 32-35 us: the doubled weight and halo traffic costs more than the idle quarter of the second round.)
 inline int conv_k3n_mt(const ConvArgs& a) {
-  const int HW = a.Hs * a.Ws;
+  const int HW = a.Hout * a.Wout;
   const long items2 = (long)a.N * cdiv(HW, 128) * cdiv(a.Cout, 16);
   if (items2 < (long)num_cus()) return 1;
   return (2 * cdiv(HW, 128) <= cdiv(HW, 64)) ? 2 : 1;
 }
 
-template <int W, int MT, int PRO, int KS = 3>
+template <int W, int MT, int PRO, int KS = 3, int S = 1>
 int launch_conv_k3n_t(ConvArgs a, hipStream_t st) {
-  using G = K3nGeo<W, MT, KS>;
+  using G = K3nGeo<W, MT, KS, S>;
   const size_t lds_bytes = sizeof(float) * (3 * (size_t)G::BUF + 4 * (size_t)a.cin_pad);
   static std::once_flag attr_once;
-  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_k3n_kernel<W, MT, PRO, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
+  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_k3n_kernel<W, MT, PRO, KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
   a.ncb = cdiv(a.Cout, 16);
-  const long nitems = (long)a.N * cdiv(a.Hs * a.Ws, G::PIX) * a.ncb;
-  const int per_cu = std::max(1, std::min(conv_resident_per_cu((const void*)conv_k3n_kernel<W, MT, PRO, KS>, lds_bytes), 2));
+  const long nitems = (long)a.N * cdiv(a.Hout * a.Wout, G::PIX) * a.ncb;
+  const int per_cu = std::max(1, std::min(conv_resident_per_cu((const void*)conv_k3n_kernel<W, MT, PRO, KS, S>, lds_bytes), 2));
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;
-  MS_LAUNCH((conv_k3n_kernel<W, MT, PRO, KS>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
+  MS_LAUNCH((conv_k3n_kernel<W, MT, PRO, KS, S>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
   return check_launch("conv_k3n");
 }
 
-int conv_dispatch_k3n(const ConvArgs& a, int ks, hipStream_t st);      // ms_conv_inst_k3n.hip
+int conv_dispatch_k3n(const ConvArgs& a, int ks, hipStream_t st, int stride = 1);      // ms_conv_inst_k3n.hip
 
 }  // namespace ms

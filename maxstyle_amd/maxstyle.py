@@ -86,10 +86,18 @@ class MaxStyle(nn.Module):
         else:
             if self.noise_learnable:
                 assert self.no_noise is False, 'turn no_noise=False to enable the optimization of noise'
-                self.gamma_noise = nn.Parameter(torch.empty(B, C, 1, 1, device=self.device))
-                self.beta_noise = nn.Parameter(torch.empty(B, C, 1, 1, device=self.device))
-                nn.init.normal_(self.gamma_noise)
-                nn.init.normal_(self.beta_noise)
+                if self.device.type == "cuda":
+                    # both N(0,1) tensors from ONE draw of the device generator (the reference draws them one after the other from its CUDA generator, whose stream this
+                    # hardware cannot reproduce anyway: the same distribution, one launch instead of two per layer of a generate_max_style_image call)
+                    gb = torch.empty(2, B, C, 1, 1, device=self.device).normal_()
+                    self.gamma_noise = nn.Parameter(gb[0])
+                    self.beta_noise = nn.Parameter(gb[1])
+                else:
+                    # CPU generator: the reference's draw order, number for number (tests/golden/kat_ramp.npz)
+                    self.gamma_noise = nn.Parameter(torch.empty(B, C, 1, 1, device=self.device))
+                    self.beta_noise = nn.Parameter(torch.empty(B, C, 1, 1, device=self.device))
+                    nn.init.normal_(self.gamma_noise)
+                    nn.init.normal_(self.beta_noise)
             else:
                 # NB (reference quirk kept): fixed noise is N(0,1) only when no_noise=True, zeros otherwise (maxstyle.py:75-80)
                 mk = torch.randn if self.no_noise else torch.zeros

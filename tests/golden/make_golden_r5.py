@@ -1,6 +1,6 @@
 """Round-5 golden vectors, produced by running the REFERENCE here (needs /root/reference; older fixtures are left untouched).
 
-    python tests/golden/make_golden_r5.py [train_p224] [train_a192] [shipped] [shipped_draws] [shipped_forced] [forced_full] [c5f64] [draws]
+    python tests/golden/make_golden_r5.py [train_p224] [train_a192] [shipped] [shipped_draws] [shipped_forced] [forced_full] [c5f64] [draws] [draws_c2]
 
 The reference's SHIPPED workloads (the only sizes a user of the reference actually runs; VERDICT r4 missing 2):
   config/ACDC/1500_epoch/MICCAI2022_MaxStyle.json:24-28,40-43,51,56-76    crop 192x192x1, FCN_16, 4 classes, batch 20, K = 5, layers [3,4,5], lr 0.1, always_use_beta false
@@ -522,8 +522,52 @@ def draws(solver_mod, variants=DRAW_VARIANTS):
     print("loop_ref_draws.npz", os.path.getsize(path), flush=True)
 
 
+def draws_c2(solver_mod, variants=DRAW_VARIANTS):
+    """Adds `c2.*` to loop_ref_draws.npz: the reference's fp32 run of the HEADLINE call (loop_full_c2.npz: trained FCN_16, 16x1x256x256, K = 5) under every DRAW_VARIANTS
+    setting, each against the fixture's fp64 run - image max / rms (+ per sample), per-step loss errors, final-parameter errors per tensor, labels."""
+    path = os.path.join(HERE, "loop_ref_draws.npz")
+    res = dict(np.load(path))
+    g = np.load(os.path.join(HERE, "loop_full_c2.npz"))
+    B, size, layers, K = 16, 256, [3, 4, 5], int(g["K"])
+    img, lab = orc.synthetic_batch(B, size, 1, 4, seed=1234)
+    ref = torch.from_numpy(g["f64.image"]).double()
+    scale = float(g["image_scale"])
+    names = [f"{i}.{n}" for i in layers for n in PNAMES]
+    acc = {}
+    for vname, nt, mkl in variants:
+        with torch.backends.mkldnn.flags(enabled=mkl):
+            torch.set_num_threads(nt)
+            R = trained_reference(solver_mod, torch.float32, "trained_fcn16_256.npz")
+            states = {i: orc.random_style_state(B, SPEC_A.channel_num[i], 7 + i, torch.float32) for i in layers}
+            with torch.no_grad():
+                z_i, _ = R.encode_image(img, disable_track_bn_stats=True)
+            Cpu = solver_mod.CpuMaxStyle
+            Cpu.created = []
+            Cpu.post_init_hook = staticmethod(lambda layer, idx: inject(layer, states[layers[idx]].clone(), torch.float32))
+            with Spy(solver_mod) as spy, contextlib.redirect_stdout(io.StringIO()):
+                out = R.generate_max_style_image(z_i, decoder_layers_indexes=list(layers), channel_num=SPEC_A.channel_num, p=1.5, n_iter=K, lr=0.1,
+                                                 reference_image=img, reference_segmentation=lab)
+            pred = segment(R, out).argmax(1).numpy().astype(np.uint8)
+        d = out.double() - ref
+        acc.setdefault("c2.image_max", []).append(float(d.abs().max()) / scale); acc.setdefault("c2.image_rms", []).append(float(d.pow(2).mean().sqrt()) / scale)
+        acc.setdefault("c2.image_rms_per_sample", []).append((d.pow(2).mean(dim=(1, 2, 3)).sqrt() / scale).numpy())
+        acc.setdefault("c2.losses_rel", []).append(np.abs(np.array(spy.losses) - g["f64.losses"]) / np.abs(g["f64.losses"]))
+        acc.setdefault("c2.params_rel", []).append(np.array([float(np.abs(p_.numpy().astype(np.float64).reshape(-1) - g[f"f64.step{K}.param.{n}"].reshape(-1)).max()
+                                                                   / np.abs(g[f"f64.step{K}.param.{n}"]).max()) for n, p_ in zip(names, spy.params[-1])]))
+        acc.setdefault("c2.labels_equal", []).append(float((pred == g["f64.final_pred"]).mean()))
+        print("draw", vname, "c2: image max %.3e rms %.3e" % (acc["c2.image_max"][-1], acc["c2.image_rms"][-1]), "losses", ["%.1e" % e for e in acc["c2.losses_rel"][-1]],
+              "params worst %.2e" % acc["c2.params_rel"][-1].max(), "labels", acc["c2.labels_equal"][-1], flush=True)
+    # draw 0 (oneDNN, 8 threads) is the configuration the fixture's own fp32 leg ran under
+    assert abs(acc["c2.image_max"][0] - float(g["ref_noise.image_max"])) <= 1e-2 * float(g["ref_noise.image_max"]), (acc["c2.image_max"][0], float(g["ref_noise.image_max"]))
+    for k, v in acc.items():
+        res[k] = np.array(v)
+    res["c2.tensor_names"] = np.array(names)
+    np.savez_compressed(path, **res)
+    print("loop_ref_draws.npz", os.path.getsize(path), flush=True)
+
+
 def main():
-    what = sys.argv[1:] or ["train_a192", "train_p224", "shipped", "shipped_draws", "shipped_forced", "forced_full", "c5f64", "draws"]
+    what = sys.argv[1:] or ["train_a192", "train_p224", "shipped", "shipped_draws", "shipped_forced", "forced_full", "c5f64", "draws", "draws_c2"]
     solver_mod = ref_harness.load_solver_module()
     if "train_a192" in what:
         train_a192(solver_mod)
@@ -541,6 +585,8 @@ def main():
         c5_f64(solver_mod)
     if "draws" in what:
         draws(solver_mod)
+    if "draws_c2" in what:
+        draws_c2(solver_mod)
 
 
 if __name__ == "__main__":

@@ -311,6 +311,12 @@ def c5_call_vs_f64(dev, tag):
             "draw_rms_max": dr[f"{tag}.rms_max"].tolist(), "draw_losses_rel": dr[f"{tag}.losses_rel"].tolist(), "draw_labels_equal": dr[f"{tag}.labels_equal"].tolist()}
 
 
+def c4_draws_all():
+    """Every key of loop_ref_draws.npz as lists (`c2.*`, `c4.*`, `acdc.*`, `prostate.*`)."""
+    dr = np.load(os.path.join(GOLDEN, "loop_ref_draws.npz"))
+    return {k: dr[k].tolist() for k in dr.files if dr[k].dtype.kind == "f"}
+
+
 def c4_draws():
     """The reference's own fp32 evaluations of the config-4 call against its fp64 run (loop_ref_draws.npz `c4.*`), for the bars of the config-4 test."""
     dr = np.load(os.path.join(GOLDEN, "loop_ref_draws.npz"))

@@ -207,3 +207,24 @@ def test_one_by_one_convs_on_14_pixel_rows(dev, N, Cin, Cout, H):
     for k in ("stats", "plain", "pro1", "pro2", "pro2_acc"):
         assert rel(new[k], old[k]) < 3e-6, k
     assert rel(new["coef"][:, :3], old["coef"][:, :3]) < 2e-5
+
+
+@pytest.mark.parametrize("N,Cin,Cout,Ho,Wo", [(16, 128, 128, 16, 16), (20, 128, 128, 14, 14), (20, 128, 128, 12, 12), (3, 24, 40, 5, 12), (1, 16, 16, 2, 14), (2, 64, 33, 9, 16)])
+def test_stride2_conv_onto_narrow_rows(dev, N, Cin, Cout, Ho, Wo):
+    """res_convdown.down of the deepest encoder block (encoder_decoder.py:40: 3x3, stride 2, padding 1) onto rows of 12 / 14 / 16 pixels on the narrow-rows kernel
+    (S = 2 variant: the band holds input rows 2 r0 - 1 .. of the flattened output pixels) against fp64 math and the first-generation kernel it leaves."""
+    from maxstyle_amd import ops
+    lib = _lib()
+    x = _rand((N, Cin, 2 * Ho, 2 * Wo), 41); w = _rand((Cout, Cin, 3, 3), 42, 0.08); b = _rand((Cout,), 43)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    xd, wp, bd = x.to(dev), ops.pack_conv_weight(w.to(dev)), b.to(dev)
+    run = lambda: ops.conv2d(xd, wp, bd, Cout, 3, 2)
+    new = run()
+    was = lib.ms_set_option(b"conv.k3n", 0)
+    try:
+        old = run()
+    finally:
+        lib.ms_set_option(b"conv.k3n", was)
+    assert tuple(new.shape) == (N, Cout, Ho, Wo)
+    assert rel(new, ref) < 3e-6 and rel(old, ref) < 3e-6 and rel(new, old) < 3e-6
+    assert torch.equal(new, run())
