@@ -264,7 +264,7 @@ def conv_in_step(eng):
         C, H = eng.nets.seg["u4.c3"].cout, eng.H
         top = lambda e: e["conv"] is not None and e["conv"]["ks"] == 3 and e["conv"]["stride"] == 1 and (e["conv"]["fetch"] & 0xFF) == 0 and \
             e["conv"]["Cin"] == C and e["conv"]["Cout"] == C and e["conv"]["Hs"] == H
-        wanted = {"dgrad_actbwd": lambda e: top(e) and e["fn"].startswith("ms_conv2d_actbwd") and e["conv"]["pm"] == 2,
+        wanted = {"dgrad_actbwd": lambda e: top(e) and e["fn"].startswith("ms_conv2d_actbwd") and "xfin" not in e["fn"] and e["conv"]["pm"] == 2,
                   "dgrad_plain": lambda e: top(e) and not e["fn"].startswith("ms_conv2d_actbwd") and e["conv"]["pm"] == 2 and e["conv"]["epi"] == 0,
                   "conv_fwd": lambda e: top(e) and not e["fn"].startswith("ms_conv2d_actbwd") and e["conv"]["pm"] == 0 and e["conv"]["epi"] == 0}
         ts, ledger, idx = in_step_times(eng, eng._bench_img, wanted)

@@ -375,6 +375,12 @@ MS_INTERNAL int ms_conv2d_xfin(const float* in, const float* in2, float* out, co
 MS_INTERNAL int ms_conv1x1_bnres_xfin(const float* in, float* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
                           const float* u, const float* stats, const float* gamma, const float* beta, float eps, float* coef4, void* gran, int* err,
                           float slope, int up2, void* stream);
+/* ms_conv2d_actbwd (pro_mode 2) whose prologue coefficients are derived in the launch like ms_conv2d_xfin kind 1 does: xf_tab = the float2 table of the activation-backward
+ * epilogue that produced `in`, xf_p0 = the forward records [Cin][4] of the BatchNorm being back-propagated, count = N*H*W; xf_coef4 [Cin][4] receives the records.  The same
+ * bits in `out` and `tab` as ms_bn_bwd_coefs + ms_conv2d_actbwd (round 5: two launches of the encoder's backward per step). */
+MS_INTERNAL int ms_conv2d_actbwd_xfin(const float* in, const float* in2, float* out, const float* w_packed, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                          const float* u, const float* coef4, float act_slope, float* tab, const float* xf_tab, const float* xf_p0, double count, float* xf_coef4,
+                          void* gran, int* err, void* stream);
 
 /* ms_conv2d whose output is the gradient w.r.t. an activation LeakyReLU_act_slope(coef4[c].scale*u + coef4[c].shift) that the forward pass
  * never materialised (it was folded into the next convolution's prologue: encoder_decoder.py:44-46, 62-64): the epilogue multiplies by the
@@ -618,6 +624,9 @@ MS_INTERNAL int ms_conv2d_ride_bf16(const uint16_t* in, const uint16_t* in2, uin
 MS_INTERNAL int ms_conv2d_xfin_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride,
                         int fetch, int pro_mode, float slope, int epi_mode, float* stats, int kind, const float* tab, const float* p0, const float* p1, float eps, double count,
                         float* coef4, void* gran, int* err, void* stream);
+MS_INTERNAL int ms_conv2d_actbwd_xfin_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride,
+                               int fetch, const uint16_t* u, const float* coef4, float act_slope, float* tab, const float* xf_tab, const float* xf_p0, double count,
+                               float* xf_coef4, void* gran, int* err, void* stream);
 MS_INTERNAL int ms_conv1x1_bnres_xfin_bf16(const uint16_t* in, uint16_t* out, const float* w_packed, const float* bias, int N, int Cin, int Hs, int Ws, int Cout,
                                const uint16_t* u, const float* stats, const float* gamma, const float* beta, float eps, float* coef4, void* gran, int* err,
                                float slope, int up2, void* stream);

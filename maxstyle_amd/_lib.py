@@ -106,6 +106,8 @@ SIGNATURES = {
                                       c_float, c_int, c_void]),
     "ms_conv2d_xfin": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_f32p,
                                c_int, c_f32p, c_f32p, c_f32p, c_float, ctypes.c_double, c_f32p, c_void, c_void, c_void]),
+    "ms_conv2d_actbwd_xfin": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_float, c_f32p,
+                                      c_f32p, c_f32p, ctypes.c_double, c_f32p, c_void, c_void, c_void]),
     "ms_conv3x3_small_cout_ok": (c_int, [c_int, c_int]),
     "ms_conv3x3_small_cin_ok": (c_int, [c_int, c_int, c_int]),
     "ms_conv3x3_small_cin": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_f32p, c_void]),
@@ -158,7 +160,7 @@ SIGNATURES = {
                            c_void, c_size, c_void]),
 }
 # bf16 activation storage for the conv stack: same argument lists as the fp32 entry points (device pointers travel as integers either way)
-for _n in ("ms_conv2d", "ms_conv2d_ride", "ms_conv2d_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_bn_finalize_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd", "ms_pool2_actbwd_pool", "ms_add_actbwd",
+for _n in ("ms_conv2d", "ms_conv2d_ride", "ms_conv2d_xfin", "ms_conv2d_actbwd_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_bn_finalize_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd", "ms_pool2_actbwd_pool", "ms_add_actbwd",
            "ms_head_fwd", "ms_head_fwd_styled", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_head_ce_tail", "ms_conv_subpix", "ms_conv3x3_small_cout", "ms_conv3x3_small_cin", "ms_style_bwd_actbwd", "ms_style_bwd_actbwd_parts"):
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]
 for _n in ("ms_conv2d", "ms_conv2d_actbwd"):           # bf16 storage + bf16 matrix arithmetic (v_mfma_f32_16x16x16_bf16) where built

@@ -422,6 +422,30 @@ extern "C" int ms_conv2d_actbwd(const float* in, const float* in2, float* out, c
                      0, nullptr, &mk, stream);
 }
 
+// ms_conv2d_actbwd whose two-tensor (BatchNorm-backward) PROLOGUE coefficients are derived inside the launch from the table of the activation-backward epilogue that
+// produced `in` (`_xfin` kind 1: xf_tab = that table, xf_p0 = the forward records {sc, sh, mean, invstd} [Cin][4] of the layer being back-propagated, count = N*H*W):
+// ms_bn_bwd_coefs + ms_conv2d_actbwd in one launch (round 5: the chains e.cd.da -> e.dz_i and e.d1.dx -> e.inc.da of the encoder's backward; the same bits in `out` and `tab`
+// as the two launches, the records land in xf_coef4 for whoever reads them later).
+static int conv2d_actbwd_xfin_impl(const float* in, const float* in2, float* out, const float* w_packed, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                                   const float* u, const float* coef4, float act_slope, float* tab, const float* xf_tab, const float* xf_p0, double count, float* xf_coef4,
+                                   void* gran, int* err, void* stream, int act_bf16) {
+  const MaskEpi mk{u, coef4, act_slope, tab};
+  XFin xf{xf_tab, xf_p0, nullptr, 0.f, xf_coef4, gran, err, Cin};
+  xf.kind = 1; xf.count = count;
+  return conv2d_impl(in, in2, out, w_packed, nullptr, N, Cin, Hs, Ws, Cout, ks, stride, fetch, 2, nullptr, nullptr, nullptr, 0, 4, 1.0f, 0, nullptr, &mk, stream, act_bf16, &xf);
+}
+extern "C" int ms_conv2d_actbwd_xfin(const float* in, const float* in2, float* out, const float* w_packed, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride, int fetch,
+                                     const float* u, const float* coef4, float act_slope, float* tab, const float* xf_tab, const float* xf_p0, double count, float* xf_coef4,
+                                     void* gran, int* err, void* stream) {
+  return conv2d_actbwd_xfin_impl(in, in2, out, w_packed, N, Cin, Hs, Ws, Cout, ks, stride, fetch, u, coef4, act_slope, tab, xf_tab, xf_p0, count, xf_coef4, gran, err, stream, 0);
+}
+extern "C" int ms_conv2d_actbwd_xfin_bf16(const uint16_t* in, const uint16_t* in2, uint16_t* out, const float* w_packed, int N, int Cin, int Hs, int Ws, int Cout, int ks, int stride,
+                                          int fetch, const uint16_t* u, const float* coef4, float act_slope, float* tab, const float* xf_tab, const float* xf_p0, double count,
+                                          float* xf_coef4, void* gran, int* err, void* stream) {
+  return conv2d_actbwd_xfin_impl(as_f(in), as_f(in2), as_f(out), w_packed, N, Cin, Hs, Ws, Cout, ks, stride, fetch, as_f(u), coef4, act_slope, tab, xf_tab, xf_p0, count, xf_coef4, gran,
+                                 err, stream, 1);
+}
+
 extern "C" int ms_bn_finalize(const float* stats, int nparts, const float* gamma, const float* beta, float eps, float* coef4, int C, void* stream) {
   if (C < 1 || nparts != kStatSlots) { set_error("ms_bn_finalize: invalid shape (nparts must be ms_conv_stats_parts())"); return MS_ERR_INVALID; }
   MS_LAUNCH(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float4*)stats, gamma, beta, eps, (float4*)coef4);

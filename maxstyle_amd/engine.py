@@ -409,6 +409,7 @@ class InnerLoopEngine:
         self.fuse_head_bwd = opt.fuse_head_bwd
         self.ride = opt.ride
         self.small_cin = opt.small_cin and inner
+        self.xfin_actbwd = inner                               # pending BatchNorm-backward records may reach an activation-backward conv (ms_conv2d_actbwd_xfin): the inner loop's backward only
         self.pool_fuse = opt.pool_fuse and inner
         self.pool_epi = opt.pool_epi and inner
         self.lazy_style_head = opt.lazy_style_head and inner
@@ -446,7 +447,7 @@ class InnerLoopEngine:
         """An ACTIVATION tensor (conv inputs / outputs, gradients, images): fp32, or bf16 storage in bf16 mode (everything else stays fp32)."""
         return self.t(name, *shape, dtype=self.act_dtype, zero=False)
 
-    _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv2d_ride", "ms_conv2d_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_bn_finalize_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd", "ms_pool2_actbwd_pool", "ms_add_actbwd",
+    _BF16_TWINS = frozenset(("ms_conv2d", "ms_conv2d_ride", "ms_conv2d_xfin", "ms_conv2d_actbwd_xfin", "ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin", "ms_conv2d_actbwd", "ms_bn_act", "ms_bn_finalize_act", "ms_act_bwd_reduce", "ms_pool2_sum", "ms_pool2_actbwd", "ms_pool2_actbwd_pool", "ms_add_actbwd",
                              "ms_head_fwd", "ms_head_fwd_styled", "ms_head_bwd", "ms_head_ce", "ms_head_ce_actbwd", "ms_head_ce_tail", "ms_style_fwd", "ms_style_bwd", "ms_style_ws_bytes",
                              "ms_conv_subpix", "ms_conv3x3_small_cout", "ms_conv3x3_small_cin", "ms_style_bwd_actbwd", "ms_style_bwd_actbwd_parts"))
 
@@ -734,6 +735,17 @@ class InnerLoopEngine:
         cout = cw.cin
         out = self.a(name, N, cout, Hs, Ws)
         tab = self.t(bw_name + ".tab", lib.ms_conv_actbwd_tab_bytes(cout) // 4)
+        if isinstance(bnbwd[0], XfCoef) and not self.mfma_bf16:
+            # the BatchNorm-backward coefficients of the prologue are still a table of the producing launch's epilogue: derived inside this launch (`_xfin` kind 1)
+            xf = bnbwd[0]
+            assert xf.kind == 1 and xf.C == Cin
+            wf = (ops.FETCH_WINOGRAD | (ops.FETCH_WINO_U if cw.dwu else 0)) if (self.winograd and cw.ks == 3) else 0
+            check(self.L("ms_conv2d_actbwd_xfin")(g.data_ptr(), bnbwd[1].data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), N, Cin, Hs, Ws, cout, cw.ks, 1, wf,
+                                            u.data_ptr(), coef.data_ptr(), slope, tab.data_ptr(), xf.tab.data_ptr(), xf.p0.data_ptr(), xf.count, xf.coef.data_ptr(),
+                                            xf.gran.data_ptr(), xf.err.data_ptr(), self._st()), "ms_conv2d_actbwd_xfin:" + name)
+            return out, tab
+        if isinstance(bnbwd[0], XfCoef):
+            bnbwd = (self.coef_tensor(bnbwd[0]), bnbwd[1])
         pa, pb, pc = ops.coef_ptrs(bnbwd[0])
         check(self.L("ms_conv2d_actbwd")(g.data_ptr(), bnbwd[1].data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), N, Cin, Hs, Ws, cout, cw.ks, 1,
                                    (ops.FETCH_WINOGRAD | (ops.FETCH_WINO_U if cw.dwu else 0)) if (self.winograd and cw.ks == 3) else 0,
@@ -823,6 +835,10 @@ class InnerLoopEngine:
         tab = self.t(bw_name + ".tab", lib.ms_conv_actbwd_tab_bytes(C) // 4)
         check(self.L("ms_conv_subpix")(g.data_ptr(), out.data_ptr(), cw.dwp.data_ptr(), 0, N, Cg, Hs, Ws, C, 1, 0, 0 if act_out is None else act_out.data_ptr(), u.data_ptr(),
                                  coef.data_ptr(), slope, tab.data_ptr(), self._st()), "ms_conv_subpix(s2 dgrad + act bwd):" + name)
+        if not ride and self.xfin_actbwd and self.fuse_act_bwd and self.xfin_pro and self._xfin_ok(tab):
+            # nobody to carry the coefficient job: the consumer (the activation-backward conv of the layer below, ms_conv2d_actbwd_xfin) derives the records itself
+            bc, gran, err = self._xfin_bufs(bw_name + ".b", C, coef_name=bw_name + ".bcoef")
+            return out, XfCoef(1, tab, coef, None, float(N * 4 * Hs * Ws), bc, gran, err, C)
         return out, self.bwd_coefs(bw_name + ".bcoef", tab, 0, coef, N * 4 * Hs * Ws, C, ride=ride)
 
     # ------------------------------------------------------------------ residual blocks
@@ -1032,8 +1048,13 @@ class InnerLoopEngine:
         e, b = self.nets.enc, self.buf
         g, bc = pre if pre is not None else self.act_bwd("e.cd.bw2", dz_s, b["e.z_s"], b["e.cd.u2"], b["e.cd.bn4.coef"], 0.0)
         g, bc = self.dgrad_act_bwd("e.cd.da", "e.cd.bw1", g, e["cd3"], (bc, b["e.cd.u2"]), b["e.cd.u1"], b["e.cd.bn1.coef"], LEAKY)
-        dz_i, _, _ = self.conv("e.dz_i", g, e["cd0"], bnbwd=(bc, b["e.cd.u1"]), dgrad=True)
-        g, bc = self.act_bwd("e.fc.bw", dz_i, b["e.z_i"], b["e.fc.u"], b["e.fc.bn.coef"], 0.0)
+        if self.xfin_actbwd and self.fuse_act_bwd and not self.bn_eval and self.enc_mix is None:
+            # the ReLU backward of z_i = relu(bn(fc.u)) in the epilogue of the conv that produces dz_i (the mask recomputed from fc.u: the same expression bn_finalize_act
+            # evaluated), its BatchNorm-backward sums in the conv's table: no ms_act_bwd_reduce launch, and e.fc.dh derives the records itself (`_xfin` kind 1)
+            g, bc = self.dgrad_act_bwd("e.dz_i", "e.fc.bw", g, e["cd0"], (bc, b["e.cd.u1"]), b["e.fc.u"], b["e.fc.bn.coef"], 0.0)
+        else:
+            dz_i, _, _ = self.conv("e.dz_i", g, e["cd0"], bnbwd=(bc, b["e.cd.u1"]), dgrad=True)
+            g, bc = self.act_bwd("e.fc.bw", dz_i, b["e.z_i"], b["e.fc.u"], b["e.fc.bn.coef"], 0.0)
         dh, _, _ = self.conv("e.fc.dh", g, e["fc0"], bnbwd=(bc, b["e.fc.u"]), dgrad=True)
         pre = None
         for i in range(4, 0, -1):

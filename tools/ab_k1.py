@@ -52,7 +52,7 @@ def main():
                 check(lib.ms_conv1x1_bnres(x.data_ptr(), out.data_ptr(), wp.data_ptr(), b.data_ptr(), N, Cin, H, W, Cout, u.data_ptr(), coef.data_ptr(), 0.2, 1 if kind == "up2" else 0, st), "bnres")
         line, outs = f"{kind:5s} {Cin:4d}->{Cout:4d} @{H}x{W}  {nbytes / 1e6:8.1f} MB ", []
         for on in (0, 1, 0, 1):
-            lib.ms_conv_k1s_enable(on); lib.ms_conv_k1g_enable(on)
+            lib.ms_set_option(b"conv.k1s", int(on)); lib.ms_set_option(b"conv.k1g", int(on))
             for _ in range(5):
                 run()
             torch.cuda.synchronize()
@@ -65,7 +65,7 @@ def main():
             us = ts[len(ts) // 2]
             outs.append(out.clone())
             line += f" | {'stream' if on else 'tiled '} {us:7.1f} us {nbytes / 8e12 / (us * 1e-6):.2f}"
-        lib.ms_conv_k1s_enable(1); lib.ms_conv_k1g_enable(1)
+        lib.ms_set_option(b"conv.k1s", 1); lib.ms_set_option(b"conv.k1g", 1)
         print(line + ("   same bits" if torch.equal(outs[0], outs[1]) else "   DIFFERENT BITS"), flush=True)
 
 

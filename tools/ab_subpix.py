@@ -89,7 +89,7 @@ def main():
         sums0 = None
         for vname, flags in variants:
             if flags < 0:                      # the stride-2 forward: a process-wide switch, not a per-call flag
-                lib.ms_conv_s2g2_enable(1 if flags == -2 else 0)
+                lib.ms_set_option(b"conv.s2g2", 1 if flags == -2 else 0)
             out.zero_()
             for _ in range(3):
                 run(flags)
@@ -107,7 +107,7 @@ def main():
             if sums0 is None:
                 sums0 = cs
             line += f" | {vname} {us:7.1f} us {flop / PEAK / (us * 1e-6):.3f}{same}"
-        lib.ms_conv_s2g2_enable(1)
+        lib.ms_set_option(b"conv.s2g2", 1)
         print(line + f"   out {sums0:012x}", flush=True)
 
 

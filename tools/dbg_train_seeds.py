@@ -16,7 +16,7 @@ for seed in (100, 101, 102, 103, 104, 105):
     line = "seed %d  oracle32 worst max-norm %.1e L2 %.1e" % (seed, max(rel(o32["grads"][k].double(), o64["grads"][k]) for k in ks),
                                                              max(float((o32["grads"][k].double() - o64["grads"][k]).norm() / o64["grads"][k].norm()) for k in ks))
     for on in (0, 1):
-        lib.ms_conv_s2g2_enable(on)
+        lib.ms_set_option(b"conv.s2g2", int(on))
         S, W = make_solver(dev, orc.NetSpec(4, 1, 4))
         S.reset_all_optimizers()
         out = S.standard_training(o32["clean"].to(dev), o32["lab"].to(dev), perturbed_image=o32["image_l"].to(dev), disable_track_bn_stats=False, return_output=True)

@@ -60,4 +60,7 @@ python tools/shipped_report.py 2>&1 | grep -E "^acdc|^prostate|per sample" > $O/
 python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
 python bench.py --config c4 --steps 10 --warmup 2 > $O/${R}_bench_c4.json 2> $O/bench_c4.err
 python tools/tune_conv.py 20 > $O/${R}_conv_tuning_table.txt 2>&1
+# the raw traces and counter dumps stay on the box (gpurun copies back at most 64 MiB): keep the summaries
+rm -rf $O/trace $O/trace_c4 $O/trace_train $O/pmc_* gpurun_out/pmc_conv_$R/*/ gpurun_out/tbk_* gpurun_out/sb/trace* 2>/dev/null
+du -sh gpurun_out | tail -1
 ls -la $O

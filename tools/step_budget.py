@@ -43,6 +43,9 @@ def conv_cost(fn, a):
         Ho, Wo = (Hs * up + (2 if ks == 3 else 0) - ks) // stride + 1, (Ws * up + (2 if ks == 3 else 0) - ks) // stride + 1
         cols = 4 * Cout if epi == 2 else Cout
         return dict(N=N, Cin=Cin, Hs=Hs, Ws=Ws, Cout=Cout, ks=ks, stride=stride, fetch=fetch, pm=pm, epi=epi, flop=2.0 * N * Ho * Wo * cols * Cin * ks * ks)
+    if base == "ms_conv2d_actbwd_xfin":      # (in, in2, out, w, N, Cin, Hs, Ws, Cout, ks, stride, fetch, ...): always the two-tensor prologue and the activation-backward epilogue
+        N, Cin, Hs, Ws, Cout, ks, stride, fetch = a[4:12]
+        return dict(N=N, Cin=Cin, Hs=Hs, Ws=Ws, Cout=Cout, ks=ks, stride=stride, fetch=fetch, pm=2, epi=3, flop=2.0 * N * Hs * Ws * Cout * Cin * ks * ks)
     if base in ("ms_conv1x1_bnres", "ms_conv1x1_bnres_xfin"):
         N, Cin, Hs, Ws, Cout = a[4:9]
         return dict(N=N, Cin=Cin, Hs=Hs, Ws=Ws, Cout=Cout, ks=1, stride=1, fetch=0, pm=0, epi=4, flop=2.0 * N * Hs * Ws * Cout * Cin)
