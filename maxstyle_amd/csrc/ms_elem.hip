@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_kernel(const void* __res
 #pragma unroll
     for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
       const float pk = expf(z[k] - lse);
-      if (k == lab) picked += (double)(z[k] - mx) - (double)lg;      // log_softmax as (z - max) - log(sum): no cancellation against the rounded max + log (ulp(max) per pixel)
+      if (k == lab) picked += (double)((z[k] - mx) - lg);      // log_softmax as (z - max) - log(sum): no cancellation against the rounded max + log (ulp(max) per pixel)
       d[k] = grad_scale * (pk - (k == lab ? 1.f : 0.f));
       if (logits_out) logits_out[((size_t)n * K + k) * HW + i] = z[k];
     }
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const void
 #pragma unroll
       for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
         const float pk = expf(z[k][e] - lse);
-        if (k == lab) picked += (double)(z[k][e] - mx) - (double)lg;
+        if (k == lab) picked += (double)((z[k][e] - mx) - lg);
         d[k][e] = grad_scale * (pk - (k == lab ? 1.f : 0.f));
       }
     }
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_tail_kernel(const void* 
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const float pk_ = expf(z[k][e] - lse);
-        if (k == lab) picked += (double)(z[k][e] - mx) - (double)lg;
+        if (k == lab) picked += (double)((z[k][e] - mx) - lg);
         d[k][e] = grad_scale * (pk_ - (k == lab ? 1.f : 0.f));
       }
     }
