@@ -377,11 +377,18 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_kernel(const void* __res
     const float lg = logf(se);
     const float lse = mx + lg;
     const int lab = (int)labels[(size_t)n * HW + i];
+    {
+      // picked log-softmax as (z_label - max) - log(sum): no cancellation against the rounded max + log(sum) (ulp(max) per pixel; config 4's first loss 7e-6 -> 9e-8 from
+      // fp64).  Selected here so that max and log(sum) die before the class loop (two more live registers there halve head_ce_tail's occupancy: 46 -> 67 us)
+      float zl = z[0];
+#pragma unroll
+      for (int k = 1; k < kMaxHeadK; ++k) if (k < K) zl = (k == lab) ? z[k] : zl;
+      picked += (double)((zl - mx) - lg);
+    }
     float d[kMaxHeadK];
 #pragma unroll
     for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
       const float pk = expf(z[k] - lse);
-      if (k == lab) picked += (double)((z[k] - mx) - lg);      // log_softmax as (z - max) - log(sum): no cancellation against the rounded max + log (ulp(max) per pixel)
       d[k] = grad_scale * (pk - (k == lab ? 1.f : 0.f));
       if (logits_out) logits_out[((size_t)n * K + k) * HW + i] = z[k];
     }
@@ -473,10 +480,15 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const void
       const float lg = logf(se);
       const float lse = mx + lg;
       const int lab = labv[e];
+      {
+        float zl = z[0][e];
+#pragma unroll
+        for (int k = 1; k < kMaxHeadK; ++k) if (k < K) zl = (k == lab) ? z[k][e] : zl;
+        picked += (double)((zl - mx) - lg);
+      }
 #pragma unroll
       for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
         const float pk = expf(z[k][e] - lse);
-        if (k == lab) picked += (double)((z[k][e] - mx) - lg);
         d[k][e] = grad_scale * (pk - (k == lab ? 1.f : 0.f));
       }
     }
@@ -607,10 +619,15 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_tail_kernel(const void* 
       const float lg = logf(se);
       const float lse = mx + lg;
       const int lab = labv[e];
+      {
+        float zl = z[0][e];
+#pragma unroll
+        for (int k = 1; k < K; ++k) zl = (k == lab) ? z[k][e] : zl;
+        picked += (double)((zl - mx) - lg);
+      }
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const float pk_ = expf(z[k][e] - lse);
-        if (k == lab) picked += (double)((z[k][e] - mx) - lg);
         d[k][e] = grad_scale * (pk_ - (k == lab ? 1.f : 0.f));
       }
     }
