@@ -321,3 +321,67 @@ def c4_draws():
     """The reference's own fp32 evaluations of the config-4 call against its fp64 run (loop_ref_draws.npz `c4.*`), for the bars of the config-4 test."""
     dr = np.load(os.path.join(GOLDEN, "loop_ref_draws.npz"))
     return {k[3:]: dr[k].tolist() for k in dr.files if k.startswith("c4.")} | {"variants": [str(v) for v in dr["variants"]]}
+
+
+# ------------------------------------------------------------------------------------------------------------- the argument cases, teacher-forced
+def arg_case_teacher_forced(dev, case):
+    """Every step k of a drop-in argument case (tests/golden/loop_args.npz; "all6": loop_args_all6.npz) evaluated at the parameters and frozen batch std the reference's fp64
+    run held before that step - its stored per-step gradients ARE fp64 evaluations at those points - so nothing free-running enters: per step the loss error and the gradient
+    error of every learnable tensor (max norm over max|g|), beside the reference's own fp32 error at step 1 (the one step where its fp32 and fp64 runs share a point)."""
+    from maxstyle_amd import synthetic as syn
+    import r3_cases as R3
+    g = np.load(os.path.join(GOLDEN, "loop_args_all6.npz" if case == "all6" else "loop_args.npz"))
+    kw = dict(R3.ARG_CALLS.get(case, {}))
+    B, layers = 4, ([0, 1, 2, 3, 4, 5] if case == "all6" else [3, 4, 5])
+    spec = syn.NetSpec(4, 1, 4)
+    S = R3.trained_solver(dev, "trained_fcn16.npz")
+    img, lab = syn.synthetic_batch(B, 64, 1, 4, seed=777)
+    img_d, lab_d = img.to(dev), lab.to(dev)
+    drawn = case == "beta_drawn"
+    names = [str(n) for n in g[f"{case}.param_names"]]
+    per = len(kw.get("loss_weights", [1]))
+    lw = float(sum(kw.get("loss_weights", [1])))
+    K = len(g[f"{case}.f64.losses"]) // per
+    z_i, _ = S.encode_image(img_d, disable_track_bn_stats=True)
+    steps = []
+    for k in range(1, K + 1):
+        def hook(mods, k=k):
+            for key, m in mods.items():
+                i = int(key)
+                if not drawn:
+                    st = syn.random_style_state(B, spec.channel_num[i], 7 + i)
+                    m.perm = st.perm.clone()
+                    with torch.no_grad():
+                        if isinstance(m.gamma_noise, torch.nn.Parameter):
+                            m.gamma_noise.data = st.gamma_noise.to(dev); m.beta_noise.data = st.beta_noise.to(dev)
+                        if isinstance(m.lmda, torch.nn.Parameter):
+                            m.lmda.data = torch.from_numpy(g[f"{case}.initial.{i}.lmda"]).to(dev)
+                if k > 1:
+                    with torch.no_grad():
+                        for nm in PN:
+                            pk = f"{case}.f64.step{k - 1}.param.{i}.{nm}"
+                            if pk in g.files and isinstance(getattr(m, nm), torch.nn.Parameter):
+                                getattr(m, nm).data = torch.from_numpy(g[pk]).float().reshape(getattr(m, nm).shape).to(dev)
+                    sk = f"{case}.f64.{i}.gamma_std"
+                    if sk in g.files and bool(m.rand_p < m.p):
+                        m.gamma_std = torch.from_numpy(g[sk]).float().reshape(1, -1, 1, 1).to(dev)
+                        m.beta_std = torch.from_numpy(g[f"{case}.f64.{i}.beta_std"]).float().reshape(1, -1, 1, 1).to(dev)
+        S.style_init_hook = hook
+        call = dict(decoder_layers_indexes=list(layers), channel_num=spec.channel_num, p=1.5, lr=0.1, reference_image=img_d, reference_segmentation=lab_d)
+        call.update(kw)
+        call["n_iter"] = 1
+        S.generate_max_style_image(z_i.detach(), **call)
+        eng = next(iter(S._engines.values()))
+        l64 = float(g[f"{case}.f64.losses"][::per][k - 1])
+        ours, noise1 = {}, {}
+        for n in names:
+            gk = f"{case}.f64.step{k}.grad.{n}"
+            if gk not in g.files:
+                continue                                    # a Parameter without gradient (mix_learnable / noise_learnable False)
+            i, nm = n.split(".")
+            r64 = g[gk].astype(np.float64).reshape(-1)
+            ours[n] = float(np.abs(eng.grad(int(i), nm).detach().cpu().numpy().astype(np.float64).reshape(-1) - r64).max() / max(np.abs(r64).max(), 1e-30))
+            r1_64, r1_32 = g[f"{case}.f64.step1.grad.{n}"].astype(np.float64).reshape(-1), g[f"{case}.f32.step1.grad.{n}"].astype(np.float64).reshape(-1)
+            noise1[n] = float(np.abs(r1_32 - r1_64).max() / max(np.abs(r1_64).max(), 1e-30))
+        steps.append({"k": k, "loss_rel": abs(float(S.last_losses[0]) / lw - l64) / abs(l64), "ours": ours, "noise_step1": noise1})
+    return {"winograd": bool(eng.winograd), "steps": steps}
