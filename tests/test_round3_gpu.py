@@ -96,7 +96,10 @@ def test_all_six_layers_on_trained_network_vs_reference_run(dev, monkeypatch, wi
     2e-7 from fp64 on those inputs).  The reference's own fp32 run is hit the same way in 4 of the 10 argument cases above (its image error jumps from 5e-7 to 3e-4 there).
     So a run is held to the tight bars when its own forward has that element on the reference's side (the direct form, by default) and to the size of one such event
     when it has it on the other (the Winograd form; a few non-default switches move the direct form across too: tools/test_switches.sh), and
-    test_all_six_layers_conv_forms_differ_at_kink_elements_only pins that this IS the whole difference between the forms."""
+    test_all_six_layers_conv_forms_differ_at_kink_elements_only pins that this IS the whole difference between the forms.
+    (Round 5: the statement that needs NO branch on an observable of the run is tests/test_round5_gpu.py::test_drop_in_arguments_teacher_forced[all6-*] - every step of this
+    case at the reference's fp64 parameters, both conv forms under the same bars: median gradient error 1.7x / 1.4x the reference's own fp32 error.  This free-running test
+    stays as the end-to-end check of the K = 3 trajectory.)"""
     set_engine_default(monkeypatch, "winograd", wino == "1")
     # which side of the kink THIS run's forward lands on is an observable of the run: one step, then the pre-activation of that element (the reference: +3.0e-6)
     monkeypatch.setitem(R.ARG_CALLS, "all6", dict(n_iter=1))
