@@ -5,9 +5,9 @@ namespace ms {
 template <typename WT>
 static int wide_wino(const ConvArgs& a, hipStream_t st) {
   switch (a.pro_mode) {
-    case 0: return launch_conv_wide_t<1, 0, 1, true, WT>(a, st);
-    case 1: return launch_conv_wide_t<1, 1, 1, true, WT>(a, st);
-    default: return launch_conv_wide_t<1, 2, 1, true, WT>(a, st);
+    case 0: return launch_wino_fx<1, 0, WT>(a, st);
+    case 1: return launch_wino_fx<1, 1, WT>(a, st);
+    default: return launch_wino_fx<1, 2, WT>(a, st);
   }
 }
 int conv_dispatch_wino2(const ConvArgs& a, hipStream_t st);      // ms_conv_inst_wino2.hip: two channel blocks per staged tile

@@ -6,9 +6,9 @@ namespace ms {
 template <typename WT>
 static int wide_wino2(const ConvArgs& a, hipStream_t st) {
   switch (a.pro_mode) {
-    case 0: return launch_conv_wide_t<2, 0, 1, true, WT>(a, st);
-    case 1: return launch_conv_wide_t<2, 1, 1, true, WT>(a, st);
-    default: return launch_conv_wide_t<2, 2, 1, true, WT>(a, st);
+    case 0: return launch_wino_fx<2, 0, WT>(a, st);
+    case 1: return launch_wino_fx<2, 1, WT>(a, st);
+    default: return launch_wino_fx<2, 2, WT>(a, st);
   }
 }
 int conv_dispatch_wino2(const ConvArgs& a, hipStream_t st) {

@@ -6,9 +6,9 @@ namespace ms {
 template <int NT, typename WT>
 static int wide_winob(const ConvArgs& a, hipStream_t st) {
   switch (a.pro_mode) {
-    case 0: return launch_conv_wide_t<NT, 0, 1, true, WT>(a, st);
-    case 1: return launch_conv_wide_t<NT, 1, 1, true, WT>(a, st);
-    default: return launch_conv_wide_t<NT, 2, 1, true, WT>(a, st);
+    case 0: return launch_wino_fx<NT, 0, WT>(a, st);
+    case 1: return launch_wino_fx<NT, 1, WT>(a, st);
+    default: return launch_wino_fx<NT, 2, WT>(a, st);
   }
 }
 int conv_dispatch_winob(const ConvArgs& a, int nt, hipStream_t st) {

@@ -105,8 +105,21 @@ struct WideGeoWB {
 // PRO: 0 none, 1 BatchNorm apply + LeakyReLU, 2 BatchNorm backward (two tensors)
 // AF ("all full"): cin_pad is a multiple of the K-chunk - no ragged channel group anywhere in the layer, the guarded MFMA loop is not instantiated
 // AT = storage type of the activation tensors (float | ms_bf16, ms_common.h ActIO)
-template <int NT, int PRO, int R, bool AF, typename AT = float>
+// FX ("fixed launch facts", round 6): -1 = everything below is read from ConvArgs at run time (the generic instantiation: also the only one that honours the timing-only
+// ablation bits a_dbg).  FX >= 0 = the epilogue kind (bits 0-2 = epi_mode), statistics (bit 3), bias (bit 4) and the Winograd appendix (bit 5) are COMPILE-TIME facts: the
+// hot instantiations carry no branch on them.  Found with tools/isa_census.py on the dominant launch of the C2 step (two-tensor prologue + activation backward): with
+// run-time flags the MFMA waves executed, per work item, 36 v_mov that zero the accumulators for the ablation path (hoisted in front of its branch), 16 bias additions +
+// 16 v_mov selecting between the biased / unbiased transform (no bias in a data-gradient), the 64-bit address arithmetic of the border epilogue in front of the branch that
+// skips it, and ~200 scalar instructions of mode dispatch.  Same arithmetic in the same order: bit-identical results (tests/test_wino_gpu.py).
+constexpr int kFxStats = 8, kFxBias = 16, kFxWu = 32;
+template <int NT, int PRO, int R, bool AF, typename AT = float, int FX = -1>
 __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const ConvArgs a) {
+  constexpr bool FIXED = FX >= 0;
+  const int a_dbg = FIXED ? 0 : a.dbg;
+  const int a_epi = FIXED ? (FX & 7) : a.epi_mode;
+  const bool a_has_stats = FIXED ? ((FX & kFxStats) != 0) : (a.stats != nullptr);
+  const bool a_has_bias = FIXED ? ((FX & kFxBias) != 0) : (a.bias != nullptr);
+  const bool a_has_wu = FIXED ? ((FX & kFxWu) != 0) : (a.wu != nullptr);
   constexpr bool BFM = std::is_same<AT, ms_bf16m>::value;         // bf16 matrix arithmetic (needs R == 1)
   constexpr bool BFL = BFM;                                       // the bf16 LDS layout (8-byte channel-quad entries)
   constexpr bool WB = std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value;        // Winograd form on independent 8x8-pixel blocks (WideGeoWB)
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(img2, 0, 0x7FFFFFFF, 0x00020000);
       const int soff = AB * (c0 * plane + t_base);
       const bool ragged = (c0 + CK > a.Cin);          // last chunk of a layer whose channel count is not a multiple of CK
-      l_q_ok = q_ok; l_h_ok = h_ok; l_edge = edge || ragged || (a.dbg & 2);
+      l_q_ok = q_ok; l_h_ok = h_ok; l_edge = edge || ragged || (a_dbg & 2);
       mask_t qm = q_ok, hm = h_ok;
       if (ragged) {
 #pragma unroll
@@ -332,12 +345,12 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         for (int j = 0; j < NHI; ++j) if (c0 + (h_lds[j] >> 20) >= a.Cin) hm &= ~(1u << j);
         l_q_ok = qm; l_h_ok = hm;
       }
-      if (a.dbg & 2) { qm = 0; hm = 0; }                // timing-only: every lane reads the tile origin
+      if (a_dbg & 2) { qm = 0; hm = 0; }                // timing-only: every lane reads the tile origin
       if (l_edge) load_data(r1, r2, soff, qm, hm, std::true_type{}); else load_data(r1, r2, soff, qm, hm, std::false_type{});
       if (coefs) load_coefs(c0);
       have_w = load_w;
       if constexpr (WIN) {
-        if (load_w && tid < G::W_ITEMS && a.wu == nullptr) {
+        if (load_w && tid < G::W_ITEMS && !a_has_wu) {
           {
             // buffer addressing: resource = the packed weights, scalar offset = (tap, first channel of the chunk, channel block), vector offset = the
             // thread's hoisted (channel-in-chunk, output channel) - nine loads, no vector address arithmetic (layers with many chunks re-stage per chunk)
@@ -407,7 +420,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         else buf[h_lds[j] & 0xFFFFF] = ((l_h_ok >> j) & 1u) ? v : 0.f;
       }
       if constexpr (WIN) {
-        if (have_w && tid < G::W_ITEMS && a.wu == nullptr) {
+        if (have_w && tid < G::W_ITEMS && !a_has_wu) {
           // U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: position p = 4*xi + nu (xi along ky, nu along kx)
           float t[4][3];
 #pragma unroll
@@ -485,9 +498,9 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     constexpr int kDataLoads = (PRO == 2 ? 2 : 1) * (NQI + NHI);      // vector-memory loads load_chunk issues for one chunk's activations
     for (int p = 0; p < T; ++p) {
       if (tr && p < 16) a.trace[128 + p * 4 + 0] = clock64();
-      const bool dma_now = WIN && (a.wu != nullptr) && have_w;      // (have_w / cb / chunk describe chunk p here: they move on below)
+      const bool dma_now = WIN && (a_has_wu) && have_w;      // (have_w / cb / chunk describe chunk p here: they move on below)
       const int dma_cb = cb, dma_chunk = chunk;
-      if (!(a.dbg & 8)) {
+      if (!(a_dbg & 8)) {
         if (l_edge) store_chunk(smem + (p & 1) * BUF, std::true_type{}); else store_chunk(smem + (p & 1) * BUF, std::false_type{});
       }
       if (tr && p < 16) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); a.trace[128 + p * 4 + 1] = clock64(); }
@@ -804,8 +817,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int co = co0 + j * 16 + m;
-      bias_v[j] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
-      if (a.epi_mode == 3) {
+      bias_v[j] = (a_has_bias && co < a.Cout) ? a.bias[co] : 0.f;
+      if (a_epi == 3) {
         const float4 cf = (co < a.Cout) ? reinterpret_cast<const float4*>(a.mk_coef)[co] : make_float4(0.f, 0.f, 0.f, 0.f);
         mk_sc[j] = cf.x; mk_sh[j] = cf.y; mk_mu[j] = cf.z;
       }
@@ -831,7 +844,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     }
   };
   auto epilogue = [&](int n, int tile, int co0) __attribute__((always_inline)) {
-    if (a.dbg & 16) {                                    // timing-only: no epilogue at all (upper bound of what hiding it can gain)
+    if (a_dbg & 16) {                                    // timing-only: no epilogue at all (upper bound of what hiding it can gain)
 #pragma unroll
       for (int rr = 0; rr < R; ++rr)
 #pragma unroll
@@ -845,7 +858,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     // epi_mode 3 without the early prefetch (8-row tiles: no registers to park 2 x 16 values across the MFMA loop): request the u values of EVERY
     // row of this wave up front, so that their latency is paid once per item and overlaps the first row's arithmetic
     float4 ulate[(!UPRE && NT == 1) ? R : 1][4];
-    if (!UPRE && NT == 1 && a.epi_mode == 3) {
+    if (!UPRE && NT == 1 && a_epi == 3) {
       const int co = co0 + m;
 #pragma unroll
       for (int rr = 0; rr < R; ++rr) {
@@ -869,7 +882,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[rr][i][j][r] += bias_v[j];
-      if (a.stats != nullptr && nvalid > 0) {
+      if (a_has_stats && nvalid > 0) {
         // PER-LANE running (count, mean, M2) of this lane's 16-pixel groups, Chan-merged group by group; the four lanes that share a channel are
         // merged once, at the end of the kernel.  (The first version reduced every tile across those lanes: six dependent ds_bpermute round trips
         // and two IEEE divisions per tile = ~2 k cycles of epilogue per item on an idle CU - tools/trace_conv.py with MS_CONV_DBG=15.)
@@ -900,7 +913,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         }
         st_n = nt_;
       }
-      if (a.epi_mode == 3) {
+      if (a_epi == 3) {
         // g = acc * lrelu'(sc*u + sh); running sums of g and g*(u - mean) per channel in st_mean / st_m2 (act_bwd_reduce_kernel<1>)
         if (row_ok) {
 #pragma unroll
@@ -932,7 +945,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
             st_mean[j] += s1; st_m2[j] += s2;
           }
         }
-      } else if (row_ok && !(a.dbg & 4)) {
+      } else if (row_ok && !(a_dbg & 4)) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int co = co0 + j * 16 + m;
@@ -942,7 +955,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           for (int r = 0; r < 4; ++r) {
             if (4 * r < nvalid) {
               float4 v = make_float4(acc[rr][0][j][r], acc[rr][1][j][r], acc[rr][2][j][r], acc[rr][3][j][r]);
-              if (a.epi_mode == 1) { const float4 p = IO::ld4(a.out, op + 4 * r); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+              if (a_epi == 1) { const float4 p = IO::ld4(a.out, op + 4 * r); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
               IO::st4(a.out, op + 4 * r, v);
             }
           }
@@ -999,9 +1012,9 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   // and read back by the epilogue: 4 KB per MFMA wave behind the coefficient table.
   float* u_lds = smem + 2 * BUF + (PRO != 0 ? 4 * (nchunks * CK) : 0) + wave * (1024 * WNT);      // (+ 1024 floats per channel block j)
   auto wino_interior = [&](int tile, int co0) {
-    if constexpr (WB) return wb_live && (wb_x0 + 8 <= a.Wout) && (wb_y0 + 8 <= a.Hout) && (co0 + 16 <= a.Cout) && !(a.dbg & 32);
+    if constexpr (WB) return wb_live && (wb_x0 + 8 <= a.Wout) && (wb_y0 + 8 <= a.Hout) && (co0 + 16 <= a.Cout) && !(a_dbg & 32);
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    return (tx * TW + TW <= a.Wout) && (ty * TH + TH <= a.Hout) && (co0 + 16 <= a.Cout) && !(a.dbg & 32);
+    return (tx * TW + TW <= a.Wout) && (ty * TH + TH <= a.Hout) && (co0 + 16 <= a.Cout) && !(a_dbg & 32);
   };
   auto prefetch_u_w = [&](int n, int tile, int cob) __attribute__((always_inline)) {
     if constexpr (WIN) {
@@ -1050,10 +1063,10 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   auto epilogue_w = [&](int n, int tile, int co0, int j, float (&o)[2][8], float& stn_next, auto interior_tag) __attribute__((always_inline)) {
     constexpr bool INT = decltype(interior_tag)::value;
     if constexpr (WIN) {
-      if (a.dbg & 16) return;
+      if (a_dbg & 16) return;
       int xb, y0; wino_geo(tile, xb, y0);
       const int co = co0 + m;
-      if (a.bias != nullptr) {
+      if (a_has_bias) {
 #pragma unroll
         for (int row = 0; row < 2; ++row)
 #pragma unroll
@@ -1065,7 +1078,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       for (int row = 0; row < 2; ++row)
 #pragma unroll
         for (int q = 0; q < 2; ++q) ok[row][q] = INT || ((y0 + row < a.Hout) && (4 * q < nvx));
-      if (a.stats != nullptr) {
+      if (a_has_stats) {
         // per-lane running (count, mean, M2): this item's group = the valid quads of the lane's 2 x 8 pixels (see the generic epilogue)
         int cnt_i = 0; float sm = 0.f;
 #pragma unroll
@@ -1096,7 +1109,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       }
       if (!INT && co >= a.Cout) return;
       const __amdgpu_buffer_rsrc_t ro = w_rsrc(a.out, n);
-      if (a.epi_mode == 3) {
+      if (a_epi == 3) {
         float4 um[2][2];
         if constexpr (INT) {
           // (the item's LDS-destined loads have landed: the caller waits ONCE per item, in front of the first block's epilogue)
@@ -1140,7 +1153,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           }
         }
         st_mean[j] += s1; st_m2[j] += s2;
-      } else if (a.epi_mode == 1) {
+      } else if (a_epi == 1) {
         float4 pv[2][2];
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
@@ -1164,7 +1177,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
             }
           }
         }
-      } else if (a.epi_mode == 6) {
+      } else if (a_epi == 6) {
         // 2x2-POOLED store (MS_EPI_POOL2): out is [N, Cout, Hout/2, Wout/2] and receives the sum of every 2x2 block of the result - the lane's 2 rows x 8 pixels
         // are four such blocks (the Winograd output tiles themselves), summed in ms_pool2_sum's order (a.x + a.y) + (b.x + b.y) over the values as they would
         // have been STORED (bf16 storage: rounded first): the same bits as ms_conv2d + ms_pool2_sum, a quarter of the bytes written and none read back.
@@ -1178,7 +1191,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
             IO::st2(a.out, offp + 2 * q, make_float2(p0, p1));
           }
         }
-      } else if (!(a.dbg & 4)) {
+      } else if (!(a_dbg & 4)) {
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
           const size_t off = (((size_t)n * a.Cout + co) * a.Hout + (y0 + row)) * a.Wout + xb;
@@ -1244,9 +1257,9 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     for (int r = 0; r < 4; ++r) upre[0][r] = bload4(ru, ep_voff + QB * r, so);
   };
   auto epilogue_fast = [&](int n, int tile, int co0) __attribute__((always_inline)) {
-    if (a.dbg & 16) return;                              // timing-only: no epilogue at all
+    if (a_dbg & 16) return;                              // timing-only: no epilogue at all
     const __amdgpu_buffer_rsrc_t ro = img_rsrc(a.out, n);
-    if (a.bias != nullptr) {
+    if (a_has_bias) {
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -1254,7 +1267,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[0][i][j][r] += bias_v[j];
     }
-    if (a.stats != nullptr) {
+    if (a_has_stats) {
       const float nt_ = st_n + 16.f;
       const float wgt = 16.f * __builtin_amdgcn_rcpf(nt_);
 #pragma unroll
@@ -1275,7 +1288,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       }
       st_n = nt_;
     }
-    if (a.epi_mode == 3) {
+    if (a_epi == 3) {
       const __amdgpu_buffer_rsrc_t ru = img_rsrc(a.mk_u, n);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -1298,7 +1311,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         }
         st_mean[j] += s1; st_m2[j] += s2;
       }
-    } else if (a.epi_mode == 1) {
+    } else if (a_epi == 1) {
       // accumulate into the tensor: its own block - merged with the plain store the compiler guards the adds with selects and a vmcnt wait that, on
       // gfx9, also waits for the STORES of the previous item (measured: +3 us per launch on the plain epilogue)
 #pragma unroll
@@ -1312,7 +1325,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         for (int r = 0; r < 4; ++r)
           bstore4(ro, st_voff + QB * r, make_float4(acc[0][0][j][r] + prev[r].x, acc[0][1][j][r] + prev[r].y, acc[0][2][j][r] + prev[r].z, acc[0][3][j][r] + prev[r].w));
       }
-    } else if (!(a.dbg & 4)) {
+    } else if (!(a_dbg & 4)) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int st_voff = ep_voff + row_soff(tile, co0 + 16 * j);
@@ -1355,7 +1368,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       else {
       const int ncg = AF ? CK / 4 : min(CK / 4, (a.cin_pad - ch * CK) / 4);
       if (tr && p < 16) a.trace[p * 4 + 0] = clock64();
-      if (a.dbg & 1) {
+      if (a_dbg & 1) {
         if constexpr (WIN) { if (decltype(first_tag)::value) { for (int j = 0; j < WNT; ++j) for (int q = 0; q < 16; ++q) accw[j][q] = f32x4{0.f, 0.f, 0.f, 0.f}; } }
         if (decltype(first_tag)::value) {
 #pragma unroll
@@ -1376,18 +1389,18 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     for (int it = 0; it < my_items; ++it) {
       const int co0 = cb * COUT_TILE;
       constexpr bool FAST = (NT == 1 && R == 1 && !WIN);      // (two channel blocks per lane: the fast epilogue's extra live values push the kernel past 128 registers = one workgroup per CU)
-      const bool interior = FAST && !(a.dbg & 32) && tile_interior(tile, co0);      // (dbg bit 32: generic epilogue everywhere - A/B switch)
+      const bool interior = FAST && !(a_dbg & 32) && tile_interior(tile, co0);      // (dbg bit 32: generic epilogue everywhere - A/B switch)
       auto pre_u = [&]() __attribute__((always_inline)) {
-        if constexpr (FAST) { if (interior && !(a.dbg & 64)) { prefetch_u_fast(n, tile, co0); return; } }
+        if constexpr (FAST) { if (interior && !(a_dbg & 64)) { prefetch_u_fast(n, tile, co0); return; } }
         if constexpr (WIN) { prefetch_u_w(n, tile, co0); return; }
         else prefetch_u(n, tile, co0);
       };
       // direct form: at the START of the item (the registers are reserved anyway, and in a step the mask tensor is cold).  Winograd form (LDS-DMA): BEHIND the first
       // chunk - the accumulator set-up of an item waits for vmcnt(0) (the previous item's stores still hold their data registers), and a prefetch issued in front of
       // that wait is simply waited for: its HBM latency was exposed once per item until round 4 (found in the ISA; the remaining chunks now cover it)
-      if (UPRE && !WIN && a.epi_mode == 3) pre_u();
+      if (UPRE && !WIN && a_epi == 3) pre_u();
       mfma_chunk(0, std::true_type{});
-      if (WIN && a.epi_mode == 3) pre_u();
+      if (WIN && a_epi == 3) pre_u();
       for (int ch = 1; ch < nchunks; ++ch) {
         if constexpr (!W2) lds_barrier();              // (two-block Winograd form: the chunk barrier sits inside the previous chunk - w2_cg)
         if (!W2 && tr && p < 16) a.trace[p * 4 + 3] = clock64();
@@ -1397,7 +1410,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       bool done = false;
       if constexpr (FAST) { if (interior) { epilogue_fast(n, tile, co0); done = true; } }
       if constexpr (WIN) {
-        if (a.epi_mode == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the item's LDS-destined mask values have landed (once, not per block: vmcnt also counts the previous block's stores)
+        if (a_epi == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the item's LDS-destined mask values have landed (once, not per block: vmcnt also counts the previous block's stores)
         float stn_next = st_n;
 #pragma unroll
         for (int j = 0; j < WNT; ++j) {
@@ -1424,11 +1437,11 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #ifdef MS_CONV_TRACE_BUILD
   if (tr) { a.trace[502] = clock64(); a.trace[503] = (long long)__builtin_amdgcn_s_memrealtime(); }
 #endif
-  if (a.stats != nullptr) conv_table_tail<NT, true>(a, smem, vb, ncb, st_n, st_mean, st_m2);
-  else if (a.epi_mode == 3) conv_table_tail<NT, false>(a, smem, vb, ncb, 0.f, st_mean, st_m2);
+  if (a_has_stats) conv_table_tail<NT, true>(a, smem, vb, ncb, st_n, st_mean, st_m2);
+  else if (a_epi == 3) conv_table_tail<NT, false>(a, smem, vb, ncb, 0.f, st_mean, st_m2);
 }
 
-template <int NT, int PRO, int R, bool AF, typename AT>
+template <int NT, int PRO, int R, bool AF, typename AT, int FX = -1>
 int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
   using G = typename std::conditional<std::is_same<AT, ms_bf16m>::value, WideGeoBF<NT, PRO>,
                                       typename std::conditional<std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_bf16w>::value, WideGeoW<(NT <= 2 ? NT : 1), PRO, 64>,
@@ -1440,18 +1453,44 @@ int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
                                                                                       std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value) ? NT * 16 * 1024 : 0);      // Winograd mode: + the mask tensor's landing zone (4 KB per MFMA wave and channel block)
   if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
   static std::once_flag attr_once;                     // one flag per instantiation; the attribute itself is immutable afterwards
-  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO, R, AF, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
+  std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO, R, AF, AT, FX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
   constexpr bool kWB = std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value;
   a.tiles_x = cdiv(a.Wout, G::TW); a.tiles_y = cdiv(a.Hout, G::TH);
   if (kWB) { a.tiles_x = cdiv(a.N * a.tiles_x * a.tiles_y, 4); a.tiles_y = 1; }      // block form: groups of four blocks of the flattened (image, block row, block column) list
   a.ncb = cdiv(a.Cout, 16 * NT);
   const long nitems = (long)(kWB ? 1 : a.N) * a.tiles_x * a.tiles_y * a.ncb;
   int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));      // workgroups per CU of the persistent grid
-  per_cu = std::max(1, std::min(per_cu, conv_resident_per_cu((const void*)conv_wide_kernel<NT, PRO, R, AF, AT>, lds_bytes)));      // (co-residency of the whole grid: ms_conv_kernel.h)
+  per_cu = std::max(1, std::min(per_cu, conv_resident_per_cu((const void*)conv_wide_kernel<NT, PRO, R, AF, AT, FX>, lds_bytes)));      // (co-residency of the whole grid: ms_conv_kernel.h)
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
   if (nblocks > a.ncb) nblocks -= nblocks % a.ncb;
-  MS_LAUNCH((conv_wide_kernel<NT, PRO, R, AF, AT>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
+  MS_LAUNCH((conv_wide_kernel<NT, PRO, R, AF, AT, FX>), dim3((unsigned)nblocks), dim3(512), lds_bytes, st, a);
   return check_launch("conv_wide");
+}
+// the "fixed launch facts" code of a call (conv_wide_kernel's FX), for dispatchers that instantiate the hot combinations: epilogue kind | statistics | bias | appendix
+inline int conv_wide_fx(const ConvArgs& a) {
+  if (a.dbg != 0 || a.epi_mode < 0 || a.epi_mode > 7) return -1;
+  return a.epi_mode | (a.stats != nullptr ? kFxStats : 0) | (a.bias != nullptr ? kFxBias : 0) | (a.wu != nullptr ? kFxWu : 0);
+}
+// Winograd form: the combinations of (prologue, epilogue kind, statistics, bias) the engines launch are instantiated with compile-time launch facts (fp32 storage, weights
+// from the appendix); anything else - and every call under an ablation bit - takes the generic instantiation.  Forward convs: bias + statistics, plain store.  Data-gradients:
+// no bias, no statistics; plain / accumulate / activation-backward / 2x2-pooled store.
+template <int NT, int PRO, typename WT>
+int launch_wino_fx(const ConvArgs& a, hipStream_t st) {
+  constexpr bool F32 = std::is_same<WT, ms_f32w>::value || std::is_same<WT, ms_f32w32>::value || std::is_same<WT, ms_f32wb>::value;
+  if constexpr (F32) {
+    const int fx = conv_wide_fx(a);
+    constexpr int FWD = 0 | kFxStats | kFxBias | kFxWu;
+    if constexpr (PRO != 2) { if (fx == FWD) return launch_conv_wide_t<NT, PRO, 1, true, WT, FWD>(a, st); }
+    if constexpr (PRO != 1) {
+      if (fx == (0 | kFxWu)) return launch_conv_wide_t<NT, PRO, 1, true, WT, (0 | kFxWu)>(a, st);
+      if (fx == (1 | kFxWu)) return launch_conv_wide_t<NT, PRO, 1, true, WT, (1 | kFxWu)>(a, st);
+    }
+    if constexpr (PRO == 2) {
+      if (fx == (3 | kFxWu)) return launch_conv_wide_t<NT, PRO, 1, true, WT, (3 | kFxWu)>(a, st);
+      if (fx == (6 | kFxWu)) return launch_conv_wide_t<NT, PRO, 1, true, WT, (6 | kFxWu)>(a, st);
+    }
+  }
+  return launch_conv_wide_t<NT, PRO, 1, true, WT>(a, st);
 }
 template <int NT, int PRO, int R, bool AF>
 int launch_conv_wide_af(const ConvArgs& a, hipStream_t st) {

@@ -7,7 +7,7 @@ trace = torch.zeros(512, dtype=torch.int64, device=dev)
 from maxstyle_amd._lib import lib as _L
 _L.ms_diag_set_trace(trace.data_ptr(), 0)
 from maxstyle_amd import ops
-# usage: trace_conv.py [plain|pro1|bwd] [C] [size] [fetch bits: 0x100 = Winograd, 0x500 = Winograd one-block, +0x800 = weights from the appendix (0x900 / 0xD00)]
+# usage: trace_conv.py [plain|pro1|bwd|actbwd] [C] [size] [fetch bits: 0x100 = Winograd, 0x500 = Winograd one-block, +0x800 = weights from the appendix (0x900 / 0xD00)]
 N = 16
 mode = sys.argv[1] if len(sys.argv) > 1 else "plain"
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 16
@@ -26,8 +26,14 @@ if mode == "pro1":
 if mode == "bwd":
     bc = torch.randn(C, 4, device=dev); pa, pb, pc = ops.coef_ptrs(bc)
     kw = dict(pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=torch.randn_like(x))
-for _ in range(3):
-    ops.conv2d(x, wp, b, C, 3, 1, out=out, fetch=FETCH, **kw)
+if mode == "actbwd":                                # the dominant launch of the C2 step: two-tensor prologue + activation-backward epilogue (ms_conv2d_actbwd)
+    bc = torch.randn(C, 4, device=dev); pa, pb, pc = ops.coef_ptrs(bc)
+    u = torch.randn_like(x); c4 = torch.randn(C, 4, device=dev); x2 = torch.randn_like(x)
+    for _ in range(3):
+        ops.conv2d_actbwd(x, wp, C, 3, u, c4, 0.2, pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=x2, fetch=FETCH)
+else:
+    for _ in range(3):
+        ops.conv2d(x, wp, b, C, 3, 1, out=out, fetch=FETCH, **kw)
 torch.cuda.synchronize()
 t = trace.cpu().tolist()
 t0 = min(t[0], t[128])
