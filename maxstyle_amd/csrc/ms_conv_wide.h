@@ -120,6 +120,10 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   const bool a_has_stats = FIXED ? ((FX & kFxStats) != 0) : (a.stats != nullptr);
   const bool a_has_bias = FIXED ? ((FX & kFxBias) != 0) : (a.bias != nullptr);
   const bool a_has_wu = FIXED ? ((FX & kFxWu) != 0) : (a.wu != nullptr);
+#ifdef MS_CONV_TRACE_BUILD
+  // per-workgroup wall-clock stamps (s_memrealtime, 100 MHz): entry, first MFMA chunk, exit - where a launch spends the time outside its steady state (tools/trace_conv.py)
+  if (a.trace != nullptr && threadIdx.x == 0 && blockIdx.x < 1024) a.trace[1024 + 4 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   constexpr bool BFM = std::is_same<AT, ms_bf16m>::value;         // bf16 matrix arithmetic (needs R == 1)
   constexpr bool BFL = BFM;                                       // the bf16 LDS layout (8-byte channel-quad entries)
   constexpr bool WB = std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value;        // Winograd form on independent 8x8-pixel blocks (WideGeoWB)
@@ -179,6 +183,9 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 
   if (producer) {
     // =========================================== PRODUCER waves ===========================================
+#ifndef MS_WIDE_PRIO_SHIFT
+#define MS_WIDE_PRIO_SHIFT 8
+#endif
 #ifndef MS_WIDE_STAGE_PRIO
 #define MS_WIDE_STAGE_PRIO 3
 #endif
@@ -498,6 +505,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     constexpr int kDataLoads = (PRO == 2 ? 2 : 1) * (NQI + NHI);      // vector-memory loads load_chunk issues for one chunk's activations
     for (int p = 0; p < T; ++p) {
       if (tr && p < 16) a.trace[128 + p * 4 + 0] = clock64();
+      if (tr && p < 16) { a.trace[256 + p * 8 + 0] = clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.trace[256 + p * 8 + 1] = clock64(); }      // (stamps: wait for the chunk's loads, separated from the arithmetic)
       const bool dma_now = WIN && (a_has_wu) && have_w;      // (have_w / cb / chunk describe chunk p here: they move on below)
       const int dma_cb = cb, dma_chunk = chunk;
       if (!(a_dbg & 8)) {
@@ -508,9 +516,11 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       // the weights of chunk p by LDS-DMA: behind this iteration's LDS stores (the consumers left the buffer at the previous barrier), in front of the next chunk's
       // data loads - so the compiler's own counted waits for THOSE never include a DMA piece, and the counted wait below leaves them in flight
       if constexpr (WIN) { if (dma_now) dma_u(smem + (p & 1) * BUF, dma_cb, dma_chunk); }
+      if (tr && p < 16) a.trace[256 + p * 8 + 2] = clock64();
       if (p + 1 < T) {
         if (++chunk == nchunks) { chunk = 0; item += gridDim.x; decode(item, n, tile, cb); }
         if (tile != tile_set) { set_tile(tile); tile_set = tile; }
+        if (tr && p < 16) a.trace[256 + p * 8 + 3] = clock64();
         const int b = (p + 1) & 1;
         load_chunk(n, cb * COUT_TILE, chunk * CK, !(key_cb[b] == cb && key_c0[b] == chunk * CK));
       }
@@ -521,6 +531,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
       }
+      if (tr && p < 16) a.trace[256 + p * 8 + 4] = clock64();
       lds_barrier();                                  // barrier #(p+1): chunk p visible; consumers done with chunk p-1
       if (tr && p < 16) a.trace[128 + p * 4 + 3] = clock64();
     }
@@ -531,6 +542,24 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   // (no s_setprio here: the STAGING waves get the priority - measured 290.7 -> 295.2 steps/s against the opposite choice; a staging wave that
   //  loses issue arbitration to back-to-back MFMAs is what the MFMA waves end up waiting for at the barrier)
   const int m = lane & 15, k = lane >> 4;
+#ifdef MS_CONV_TRACE_BUILD
+  if (a.trace != nullptr && MS_TID == 0 && blockIdx.x < 1024) a.trace[1024 + 4096 + blockIdx.x] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#endif
+#ifdef MS_WIDE_PRIO_EXP
+  // experiment (round 6): the two workgroups of a CU do not progress at the same rate (per-workgroup wall-clock stamps: the first-placed one finishes its 8 items in
+  // ~41 us, the second in ~50 us, alone on the CU at the end).  1: static priority for the odd thread-group slot; 2: priority alternates between the slots in time windows
+  const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+  const int tg_slot = (hw_id >> 16) & 1;
+  if (MS_WIDE_PRIO_EXP == 1 && tg_slot) __builtin_amdgcn_s_setprio(1);
+  auto prio_tick = [&]() {
+    if (MS_WIDE_PRIO_EXP == 2) {
+      const int win = (int)((__builtin_amdgcn_s_memrealtime() >> MS_WIDE_PRIO_SHIFT) & 1);
+      if (win == tg_slot) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
+  };
+#else
+  auto prio_tick = [&]() {};
+#endif
   f32x4 acc[R][4][NT];                                  // [row of this wave][pixel-in-quad i][channel block j]: rows = lane-local pixel quads
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -1352,6 +1381,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #ifdef MS_CONV_TRACE_BUILD
   const bool tr = (a.trace != nullptr) && (blockIdx.x == 0) && (MS_TID == 0);
   if (tr) { a.trace[500] = clock64(); a.trace[501] = (long long)__builtin_amdgcn_s_memrealtime(); }     // shader clock vs the 100 MHz constant clock
+  if (a.trace != nullptr && threadIdx.x == 0 && blockIdx.x < 1024) a.trace[1024 + 4 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();
 #else
   constexpr bool tr = false;
 #endif
@@ -1364,6 +1394,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   {
     int p = 0;
     auto mfma_chunk = [&](int ch, auto first_tag) __attribute__((always_inline)) {
+      prio_tick();
       if constexpr (W2) { w2_chunk(p, first_tag); return; }
       else {
       const int ncg = AF ? CK / 4 : min(CK / 4, (a.cin_pad - ch * CK) / 4);
@@ -1436,9 +1467,13 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   }
 #ifdef MS_CONV_TRACE_BUILD
   if (tr) { a.trace[502] = clock64(); a.trace[503] = (long long)__builtin_amdgcn_s_memrealtime(); }
+  if (a.trace != nullptr && threadIdx.x == 0 && blockIdx.x < 1024) a.trace[1024 + 4 * blockIdx.x + 2] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
   if (a_has_stats) conv_table_tail<NT, true>(a, smem, vb, ncb, st_n, st_mean, st_m2);
   else if (a_epi == 3) conv_table_tail<NT, false>(a, smem, vb, ncb, 0.f, st_mean, st_m2);
+#ifdef MS_CONV_TRACE_BUILD
+  if (a.trace != nullptr && threadIdx.x == 0 && blockIdx.x < 1024) a.trace[1024 + 4 * blockIdx.x + 3] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int NT, int PRO, int R, bool AF, typename AT, int FX = -1>

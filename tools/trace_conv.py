@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 dev = torch.device("cuda:0")
-trace = torch.zeros(512, dtype=torch.int64, device=dev)
+trace = torch.zeros(8192, dtype=torch.int64, device=dev)
 from maxstyle_amd._lib import lib as _L
 _L.ms_diag_set_trace(trace.data_ptr(), 0)
 from maxstyle_amd import ops
@@ -45,6 +45,39 @@ print("producer: p  [store_start, store_end, loads_issued, after_barrier]   stor
 for p in range(12):
     c = t[128 + p * 4:128 + (p + 1) * 4]
     print(p, [v - t0 for v in c], c[1] - c[0], c[2] - c[1], c[3] - c[2])
+if t[256] != 0:
+    print("producer, fine: p  wait-for-loads / prologue+LDS stores / U DMA issue / advance+set_tile / load issue + coefficient reads / DMA wait")
+    for p in range(12):
+        c = t[256 + p * 8:256 + p * 8 + 5]; c0 = t[128 + p * 4 + 1]
+        print(p, c[1] - c[0], c0 - c[1], c[2] - c0, c[3] - c[2], t[128 + p * 4 + 2] - c[3], c[4] - t[128 + p * 4 + 2])
 dc, dr = t[502] - t[500], t[503] - t[501]
 if dr > 0:
     print(f"workgroup 0 main loop: {dc} shader cycles in {dr * 10} ns (s_memrealtime, 100 MHz) -> shader clock {dc / (dr * 10):.3f} GHz")
+
+# per-workgroup wall-clock stamps (100 MHz): entry / first MFMA chunk / end of the item loop / exit, relative to the earliest entry
+import numpy as np
+w = np.array(t[1024:1024 + 4096], dtype=np.int64).reshape(-1, 4)
+w = w[w[:, 0] != 0]
+if len(w):
+    t00 = w[:, 0].min()
+    r = (w - t00) * 10 / 1000.0          # us
+    q = lambda a: "min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f" % (a.min(), np.percentile(a, 10), np.median(a), np.percentile(a, 90), a.max())
+    print(f"{len(w)} workgroups, us since the first workgroup's entry:")
+    print("  entry        ", q(r[:, 0]))
+    print("  first MFMA   ", q(r[:, 1]))
+    print("  loop end     ", q(r[:, 2]))
+    print("  exit         ", q(r[:, 3]))
+    print("  loop duration", q(r[:, 2] - r[:, 1]), "  entry -> first MFMA", q(r[:, 1] - r[:, 0]))
+    if os.environ.get("MS_TRACE_DUMP"):
+        np.save(os.environ["MS_TRACE_DUMP"], np.concatenate([r, np.array(t[1024 + 4096:1024 + 4096 + len(r)], dtype=np.float64).reshape(-1, 1)], axis=1))
+    # by XCD (workgroup b runs on XCD b % 8) and by position inside the XCD: where do the slow workgroups sit?
+    nb = len(r)
+    for x in range(8):
+        sel = r[np.arange(nb) % 8 == x]
+        print(f"  XCD {x}: loop duration median {np.median(sel[:, 2] - sel[:, 1]):.1f}  min {np.min(sel[:, 2] - sel[:, 1]):.1f}  max {np.max(sel[:, 2] - sel[:, 1]):.1f}   exit max {sel[:, 3].max():.1f}")
+    hw = np.array(t[1024 + 4096:1024 + 4096 + nb], dtype=np.int64)
+    if hw.any():
+        hw = hw & 0xFFFFFFFF; tg = (hw >> 16) & 15; cu = (hw >> 8) & 15; se = (hw >> 13) & 7
+        d = r[:, 2] - r[:, 1]
+        for g in sorted(set(tg.tolist())):
+            print(f"  thread-group slot {g}: {int((tg == g).sum())} workgroups, loop duration median {np.median(d[tg == g]):.1f}")
