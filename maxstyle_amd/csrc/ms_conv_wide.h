@@ -165,21 +165,14 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   float* cf_lds = smem + 2 * BUF;
   if constexpr (BFM) {                               // K groups 2, 3 (activation planes and weight entries) stay zero for the whole launch
     for (int i = MS_TID; i < 2 * BUF; i += 512) smem[i] = 0.f;
-    if constexpr (PRO == 0) __syncthreads();
+    __syncthreads();
   }
   // cross-workgroup finalize (`_xfin`, ms_conv_kernel.h): the table is filled by the MFMA waves from granules published inside this launch - in front of
   // barrier #0, while the staging waves already have their first chunk's global loads in flight (they read their coefficients behind that barrier)
+  // (round 6: the table is ALWAYS filled by the MFMA waves in front of barrier #0 - from the coefficient arrays, or `_xfin` from the granules - while the staging waves
+  //  have their first chunk's global loads in flight; until round 5 the array form was filled by all 512 threads behind a __syncthreads in FRONT of those loads:
+  //  entry -> first MFMA 3.8 us (BatchNorm-apply prologue) / 4.8 us (two-tensor) against 2.9 us without a prologue, per-workgroup wall-clock stamps)
   const bool xf_pro = (PRO != 0) && (a.xf_tab != nullptr);
-  if constexpr (PRO != 0) {
-    if (!xf_pro) {
-      for (int c = MS_TID; c < nchunks * CK; c += 512) {
-        float4 cf = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < a.Cin) { cf.x = a.pro_a[c * a.pro_cstride]; cf.y = a.pro_b[c * a.pro_cstride]; if constexpr (PRO == 2) cf.z = a.pro_c[c * a.pro_cstride]; }
-        reinterpret_cast<float4*>(cf_lds)[c] = cf;
-      }
-      __syncthreads();
-    }
-  }
 
   if (producer) {
     // =========================================== PRODUCER waves ===========================================
@@ -470,9 +463,9 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     int item = vb, chunk = 0, n, tile, cb, tile_set = -1;
     decode(item, n, tile, cb);
     set_tile(tile); tile_set = tile;
-    load_chunk(n, cb * COUT_TILE, 0, true, !xf_pro);
-    lds_barrier();                                    // barrier #0 (matched by the consumers); `_xfin`: the coefficient table is complete behind it
-    if (xf_pro) load_coefs(0);
+    load_chunk(n, cb * COUT_TILE, 0, true, false);
+    lds_barrier();                                    // barrier #0 (matched by the consumers): the coefficient table is complete behind it
+    load_coefs(0);
 #ifdef MS_CONV_TRACE_BUILD
     const bool tr = (a.trace != nullptr) && (blockIdx.x == 0) && (MS_TID == 256);
 #else
@@ -1374,6 +1367,12 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       xfin_header(a, xf_tag, xf_nparts);
       if (!xfin_produce(a, xf_tag, xf_nparts)) __builtin_amdgcn_s_sleep(30);
       xfin_fill<(PRO == 2 ? 3 : 2)>(a, cf_lds, nchunks * CK, xf_tag, vb & (kXfinRep - 1), MS_TID, 256, 0.f, 0.f);
+    } else {
+      for (int c = MS_TID; c < nchunks * CK; c += 256) {
+        float4 cf = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < a.Cin) { cf.x = a.pro_a[c * a.pro_cstride]; cf.y = a.pro_b[c * a.pro_cstride]; if constexpr (PRO == 2) cf.z = a.pro_c[c * a.pro_cstride]; }
+        reinterpret_cast<float4*>(cf_lds)[c] = cf;
+      }
     }
   }
   lds_barrier();                                      // barrier #0

@@ -383,13 +383,15 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_kernel(const void* __res
       float zl = z[0];
 #pragma unroll
       for (int k = 1; k < kMaxHeadK; ++k) if (k < K) zl = (k == lab) ? z[k] : zl;
-      picked += (double)((zl - mx) - lg);
+      // a label outside [0, K) contributes nothing - neither to the loss nor (grad_scale below) to the gradient: F.nll_loss's ignore_index semantics (the reference
+      // passes no such labels; until round 5 the class-0 term was picked for them.  ADVICE r5)
+      picked += ((unsigned)lab < (unsigned)K) ? (double)((zl - mx) - lg) : 0.0;
     }
     float d[kMaxHeadK];
 #pragma unroll
     for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
       const float pk = expf(z[k] - lse);
-      d[k] = grad_scale * (pk - (k == lab ? 1.f : 0.f));
+      d[k] = ((unsigned)lab < (unsigned)K ? grad_scale : 0.f) * (pk - (k == lab ? 1.f : 0.f));
       if (logits_out) logits_out[((size_t)n * K + k) * HW + i] = z[k];
     }
     if (dh) {
@@ -484,12 +486,12 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_actbwd_kernel(const void
         float zl = z[0][e];
 #pragma unroll
         for (int k = 1; k < kMaxHeadK; ++k) if (k < K) zl = (k == lab) ? z[k][e] : zl;
-        picked += (double)((zl - mx) - lg);
+        picked += ((unsigned)lab < (unsigned)K) ? (double)((zl - mx) - lg) : 0.0;      // (labels outside [0, K) are ignored: see head_ce_kernel)
       }
 #pragma unroll
       for (int k = 0; k < kMaxHeadK; ++k) if (k < K) {
         const float pk = expf(z[k][e] - lse);
-        d[k][e] = grad_scale * (pk - (k == lab ? 1.f : 0.f));
+        d[k][e] = ((unsigned)lab < (unsigned)K ? grad_scale : 0.f) * (pk - (k == lab ? 1.f : 0.f));
       }
     }
 #pragma unroll
@@ -623,12 +625,12 @@ __global__ __launch_bounds__(kElemThreads) void head_ce_tail_kernel(const void* 
         float zl = z[0][e];
 #pragma unroll
         for (int k = 1; k < K; ++k) zl = (k == lab) ? z[k][e] : zl;
-        picked += (double)((zl - mx) - lg);
+        picked += ((unsigned)lab < (unsigned)K) ? (double)((zl - mx) - lg) : 0.0;      // (labels outside [0, K) are ignored: see head_ce_kernel)
       }
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const float pk_ = expf(z[k][e] - lse);
-        d[k][e] = grad_scale * (pk_ - (k == lab ? 1.f : 0.f));
+        d[k][e] = ((unsigned)lab < (unsigned)K ? grad_scale : 0.f) * (pk_ - (k == lab ? 1.f : 0.f));
       }
     }
 #pragma unroll
