@@ -1,5 +1,11 @@
 #!/bin/bash
-# Run the GPU suite under every A/B / opt-in option of the library and the engines (MS_OPTIONS: maxstyle_amd/options.py) (on the GPU box: gpurun -- 'bash tools/test_switches.sh').
+# The GPU tests under the A/B / opt-in options of the library and the engines (MS_OPTIONS: maxstyle_amd/options.py) (on the GPU box: gpurun -- 'bash tools/test_switches.sh').
+# Round 6 (the 29-line matrix of whole-suite runs cost ~75 GPU-minutes a pass): two tiers.
+#   TIER A - the WHOLE suite under the settings a user can reach in a supported configuration (EngineOptions fields / library options README.md documents, and the shared-device
+#            deployment): 9 lines.
+#   TIER B - every remaining A/B switch (each guards a "same bits" / "to rounding" test of its own in the default run) under the parity tests that bind the numbers without
+#            chaos: the teacher-forced image, loss and gradient tests at every full size and the kink census (tests/test_round6_gpu.py, tests/test_round5_gpu.py -k ...): ~1 minute
+#            a line.
 # Every line must end in "N passed" with no FAILED line above it.  Tests that ASSERT the default of the switch in question are deselected for that switch only
 # (with the reason): e.g. a test that checks "the single-read kernel ran" cannot pass with the single-read kernel switched off.
 set -u
@@ -22,51 +28,36 @@ KINK6="--deselect tests/test_round3_gpu.py::test_all_six_layers_on_trained_netwo
 # tests whose premise is the cross-workgroup finalize / the co-residency kernels
 XF="not (reshaped_table_never_meets or collective_on_a_side_stream)"
 ONLY=${1:-}      # optional: a regular expression - only the switches that match it are run
-run() {   # run "<env assignments>" <pytest deselect arguments...>
+run() {   # run "<env assignments>" <pytest deselect arguments...>      (whole suite)
   local sw=$1; shift
   if [ -n "$ONLY" ] && ! echo "${sw:-default}" | grep -qE "$ONLY"; then return; fi
-  echo -n "${sw:-default}: "
+  echo -n "A ${sw:-default}: "
   env $sw timeout 1200 python -m pytest tests -q -m gpu --maxfail=8 -rf ${MS_MATRIX_EXTRA:-} "$@" 2>&1 | grep -E "^FAILED|passed|failed" | cut -c1-220
 }
+runb() {  # runb "<env assignments>" <pytest arguments...>             (teacher-forced tests + kink census)
+  local sw=$1; shift
+  if [ -n "$ONLY" ] && ! echo "${sw:-default}" | grep -qE "$ONLY"; then return; fi
+  echo -n "B ${sw}: "
+  env $sw timeout 900 python -m pytest tests/test_round6_gpu.py tests/test_round5_gpu.py -q -m gpu --maxfail=8 -rf -k "teacher_forced or kink" "$@" 2>&1 | grep -E "^FAILED|passed|failed" | cut -c1-220
+}
+# ---------------------------------------------------------------------------------------------------------------- TIER A: whole suite
 run ""
+# the Winograd form is what these tests are about (and what the bench line's `form` field reports)
+run MS_OPTIONS=engine.winograd=0 $KNIFE -k "not (pooled_data_gradient or winograd or bench_line_contract)"
+run MS_OPTIONS=engine.train_winograd=0 $KNIFE -k "not which_engines_ask"
+# shared device: neither the single-read kernel nor the cross-workgroup finalize is selected
+run MS_SHARED_DEVICE=1 $KNIFE $CHAOS2 $CHAOS4 -k "not (single_read_kernel or cross_workgroup_finalize or reshaped_table_never_meets or collective_on_a_side_stream)"
+run MS_OPTIONS=style.fused=0 $KNIFE $CHAOS2 $CHAOS4 -k "not single_read_kernel"
+run MS_OPTIONS=engine.xfin=0 -k "$XF"
 # bf16 matrix arithmetic and the three-way split exist in the wide kernel only; `nonoise` / `noisefixed`: free-running K = 3 cases whose bars are 3x the reference's own
 # noise - the first-generation kernels everywhere are another rounding of the same arithmetic and land at 4-5x (the same effect as experiments 17 / 18)
 run MS_OPTIONS=conv.wide=0 $CHAOS4 --ignore=tests/test_bf16m_gpu.py --ignore=tests/test_wino_gpu.py -k "not (pooled_epilogue_is_conv or pooled_data_gradient or bench_line_contract)" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[nonoise]" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[noisefixed]"
-# the lazy tail, the pooled epilogue's consumer and the riders' producers are forms of the fused activation backward
-run MS_OPTIONS=engine.fuse_act_bwd=0 $KNIFE $CHAOS5 -k "not (lazy_segmentation_tail or pooled_data_gradient or pooled_gradient_from or rider_coefficient or bench_line_contract)"
-# "last workgroup finalises" (a round-2 experiment) and the cross-workgroup finalize are alternatives
-# (a round-1 experiment: coefficient buffers that the in-kernel form never writes stay uninitialised, so record-by-record A/B comparisons and the bench line's
-#  launch accounting do not apply)
-# side streams: no single-read kernel, no riders, no lazy tail (they assume one stream)
-# (inner_loop_bf16_storage[net1]: first loss 1.12 % from the fp32-storage run against a 1 % bar on the three-launch bf16 MaxStyle path - the same with every round-3 switch off)
-run MS_OPTIONS=engine.train_graph=1
-run MS_OPTIONS=style.fused=0 $KNIFE $CHAOS2 $CHAOS4 -k "not single_read_kernel"
-run MS_OPTIONS=engine.xfin=0 -k "$XF"
-run MS_OPTIONS=engine.xfin_pro=0
-run MS_OPTIONS=engine.fuse_tail=0
-run MS_OPTIONS=engine.fuse_head_bwd=0
-run MS_OPTIONS=engine.lazy_seg_tail=0 $KNIFE $CHAOS2 $CHAOS5
-run MS_OPTIONS=engine.ride=0
-run MS_OPTIONS=engine.pool_fuse=0 $KNIFE $KINK6
-run MS_OPTIONS=engine.pool_epi=0
-run MS_OPTIONS=engine.lazy_style_head=0
-# the first conv on the general kernels (engine.small_cin=0: the same output bits, another statistics grouping) and on the vector-ALU form (conv.k9=0: another rounding)
-# (another statistics grouping of the first conv = another realisation of the free-running cases: step-4 loss 6.2e-6 against a bar of 5.7e-6 in the direct-form headline case,
-#  one kink event in the Winograd all-six-layers case and in the Winograd-on/off loop comparison - round 5, profiles/r05_switch_matrix.txt)
-run MS_OPTIONS=engine.small_cin=0 $KNIFE "--deselect=tests/test_round3_gpu.py::test_headline_config_vs_reference_run[0]" "--deselect=tests/test_round3_gpu.py::test_all_six_layers_on_trained_network_vs_reference_run[1]" -k "not inner_loop_with_and_without_the_winograd_form"
-run MS_OPTIONS=conv.k9=0 $KNIFE "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[nomix]" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[nonoise]" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[noisefixed]" -k "not (inner_loop_with_and_without_the_winograd_form or taps_as_k)"      # the vector-ALU form: another rounding (r03 experiment 18)
 # the narrow-rows second generation off: the first-generation kernel on rows of 12 / 14 / 16 pixels
 run MS_OPTIONS=conv.k3n=0 $KNIFE -k "not (narrow_rows or second_generation_is_taken or one_by_one_convs_on_14)"
-# the Winograd form is what these tests are about (and what the bench line's `form` field reports)
-run MS_OPTIONS=engine.winograd=0 $KNIFE -k "not (pooled_data_gradient or winograd or bench_line_contract)"
-# shared device: neither the single-read kernel nor the cross-workgroup finalize is selected
-run MS_SHARED_DEVICE=1 $KNIFE $CHAOS2 $CHAOS4 -k "not (single_read_kernel or cross_workgroup_finalize or reshaped_table_never_meets or collective_on_a_side_stream)"
-# ---- round 4: the second-generation kernels' process-wide switches (each falls back to the first generation: same bits at config 4, rounding-level differences of the
-#      stride-2 conv's chunking at config 2) ----
-# (tests that assert "the streaming / second-generation kernel ran" cannot pass with it switched off)
 run MS_OPTIONS=conv.k1s=0 $KNIFE -k "not (streamed or streaming_1x1 or k1s)"
-run MS_OPTIONS=conv.k1g=0 $KNIFE -k "not lds_tiled_1x1_gemm"
-run MS_OPTIONS=conv.s2g2=0 $KNIFE -k "not (stride2_conv_second_generation or stride2_prologue)"
-run MS_OPTIONS=engine.train_xfin=1 $KNIFE
-run MS_OPTIONS=engine.train_winograd=0 $KNIFE -k "not which_engines_ask"
-run MS_OPTIONS=engine.fuse_fin_act=0
+# ---------------------------------------------------------------------------------------------------------------- TIER B: teacher-forced tests + kink census
+for sw in engine.fuse_act_bwd=0 engine.train_graph=1 engine.xfin_pro=0 engine.fuse_tail=0 engine.fuse_head_bwd=0 engine.lazy_seg_tail=0 engine.ride=0 engine.pool_fuse=0 engine.pool_epi=0 \
+          engine.lazy_style_head=0 engine.small_cin=0 conv.k9=0 conv.k1g=0 conv.s2g2=0 engine.train_xfin=1 engine.fuse_fin_act=0 engine.subpix=0 engine.small_cout=0 engine.lazy_inc=0 \
+          engine.fuse_skip=0 engine.wino_appendix=0 conv.wino_nt=1 conv.wino_block=0 conv.wino32=0; do
+  runb MS_OPTIONS=$sw
+done
