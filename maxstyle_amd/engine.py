@@ -30,7 +30,13 @@ EPI_POOL2 = 6          # include/maxstyle_hip.h MS_EPI_POOL2
 LEAKY = 0.2
 BN_EPS = 1e-5
 F32 = torch.float32
-WINO_APPENDIX = engine_options().wino_appendix      # A/B switch (EngineOptions.wino_appendix / MS_OPTIONS engine.wino_appendix=0): pack the Winograd-transformed weights behind the taps of every 3x3 conv
+
+
+def wino_appendix_default() -> bool:
+    """A/B switch `wino_appendix`: pack the Winograd-transformed weights behind the taps of every 3x3 conv.  It acts where the WEIGHTS are packed (ConvW / PackedNets), so it
+    is read from the process defaults at that moment - MS_OPTIONS engine.wino_appendix=0, `with engine_defaults(wino_appendix=False):` around the code that builds the
+    solver / PackedNets - not from the `options=` of an engine built later on those weights."""
+    return bool(engine_options().wino_appendix)
 
 
 @dataclass
@@ -71,7 +77,7 @@ class ConvW:
             self.cout, self.cin, self.ks = w.shape[0], w.shape[1], w.shape[2]
             self.wp = ops.pack_conv_weight(w)
             self.dwp = ops.pack_conv_weight_dgrad(w)
-            if self.ks == 3 and w.is_cuda and WINO_APPENDIX:
+            if self.ks == 3 and w.is_cuda and wino_appendix_default():
                 self.wp, self.wu = ops.with_wino_appendix(self.wp, self.cin, self.cout)
                 self.dwp, self.dwu = ops.with_wino_appendix(self.dwp, self.cout, self.cin)
         else:  # ConvTranspose2d k2 s2: weight [Cin, Cout, 2, 2]
@@ -516,8 +522,8 @@ class InnerLoopEngine:
 
     def check_errors(self, sync=True):
         """A bounded spin of the single-read kernel that timed out leaves its statistics invalid and sets an error word in the layer's state block.
-        Product code must never return such a result: sync=True (the default, what the solver uses) copies the words and WAITS for the copy, so the
-        error is raised by the very call that produced the invalid image.  sync=False is the deferred protocol for callers that must not stall the
+        Product code must never return such a result: sync=True copies the words and WAITS for the copy, so the
+        error is raised by the very call that produced the invalid image.  sync=False (what the solver uses by default since round 5: `loop_error_check = "deferred"`) is the deferred protocol for callers that must not stall the
         host: it queues the copy (pinned buffer + event) and resolves the copy queued by the previous call; such a caller flushes with
         `flush_errors()` before it uses results for anything lasting (the solver does at optimize_all_params / evaluate / save).  Once reported,
         the device words are cleared - the kernel's epoch / arrival state stays consistent through a time-out (every workgroup still finishes) - so
@@ -1257,6 +1263,7 @@ class InnerLoopEngine:
         std[0].copy_(gamma_std.detach().reshape(-1).to(device=self.dev, dtype=F32))
         std[1].copy_(beta_std.detach().reshape(-1).to(device=self.dev, dtype=F32))
         s.have_std = True
+        s.std_preset = True                              # (run() keeps it for the one call that follows)
 
     def style_fwd(self, i, x, store=True):
         """store=False: statistics and coefficients only (y = NULL) - the caller's next kernel applies the layer itself; returns None then."""
@@ -1548,6 +1555,13 @@ class InnerLoopEngine:
                     sl.have_std = True
                 return ent[1]
         self._prefix_valid = False
+        # a CALL is the unit (advanced_triplet...py:503-537 builds fresh MaxStyle modules: their first forward derives the batch std): the eager / step-graph path starts
+        # every call the way the whole-call graph was captured - batch std not frozen - unless the caller preset it for this call (preset_style_std).  Until round 5 a
+        # second direct run() without restore_config kept the first call's std on this path only (the solver always went through restore_config).
+        for sl in self.styles.values():
+            if not getattr(sl, "std_preset", False):
+                sl.have_std = False
+            sl.std_preset = False
         self.step_dev.zero_()
         img = self.decode(code)
         if steps > 0:

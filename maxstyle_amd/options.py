@@ -29,7 +29,8 @@ class EngineOptions:
     # mean over tensors 7.1e-4 / 6.2e-4 / 5.2e-4.  -0.85 ms per trainer iteration (45.4 -> 47.3 iterations/s).
     winograd: Optional[bool] = None            # the inner loop's engines (and the module-forward engines); None = True
     train_winograd: Optional[bool] = None      # the training passes' engines (TrainEngine); None = True
-    wino_appendix: bool = True        # the transformed weights are packed once per weight version behind the taps (MS_FETCH_WINO_U) instead of being recomputed per work item
+    wino_appendix: bool = True        # the transformed weights are packed once per weight version behind the taps (MS_FETCH_WINO_U) instead of being recomputed per work item.
+                                      # Acts where the weights are PACKED (engine.ConvW): the process default at that moment counts (MS_OPTIONS / engine_defaults), not an engine's own `options=`
     shared_device: Optional[bool] = None      # other kernels run beside the engine's launches: no co-residency kernels (single-read MaxStyle, `_xfin`).  None: MS_SHARED_DEVICE
     fuse_act_bwd: bool = True         # activation backward + BatchNorm-backward sums in the epilogue of the data-gradient conv (ms_conv2d_actbwd) vs a separate ms_act_bwd_reduce pass
     fuse_skip: bool = True            # residual-block tail as one launch (ms_conv1x1_bnres) vs ms_conv2d(ks=1) + ms_bn_act
@@ -84,14 +85,30 @@ def _parse_env(text: str):
             pv = _parse_value(val)
             _engine_defaults[f] = None if pv is None else bool(pv)
         else:
+            if name.startswith("diag."):
+                raise ValueError(f"MS_OPTIONS: '{name}' is a timing-only ablation option (results are WRONG with it set): not accepted from the environment - a diagnostic "
+                                 "tool sets it in its own process (set_library_option; tools/replay_conv.py <which> <reps> <dbg bits>)")
             _library_from_env[name] = int(val)
 
 
 _parse_env(os.environ.get("MS_OPTIONS", ""))
 
+# The 65 MS_* switches of rounds 1-4 are gone (round 5): a leftover in the environment would now be ignored without a word - MS_ACT_DTYPE=bf16 would run an fp32 loop,
+# MS_TRAIN_WINOGRAD=0 a Winograd training pass.  Say so once at import.
+_KNOWN_ENV = {"MS_OPTIONS", "MS_LIB", "MS_SHARED_DEVICE", "MS_SWITCH_MATRIX", "MS_MATRIX_EXTRA", "MS_TRACE_DUMP", "MS_R5_THREADS"}
+_legacy = sorted(k for k in os.environ if k.startswith("MS_") and k not in _KNOWN_ENV)
+if _legacy:
+    import warnings
+    warnings.warn("maxstyle_amd ignores the environment variable(s) " + ", ".join(_legacy) + ": the MS_* switches were replaced by MS_OPTIONS=\"engine.<field>=v,<library option>=v\", "
+                  "EngineOptions objects and ms_set_option (maxstyle_amd/options.py); activation storage / bf16 arithmetic are solver attributes (loop_act_dtype, loop_mfma_dtype)",
+                  RuntimeWarning, stacklevel=2)
+
 
 def engine_options(given=None, **overrides) -> EngineOptions:
-    """EngineOptions from: the class defaults, then MS_OPTIONS' `engine.*` entries, then `given` (an EngineOptions or a dict of fields), then keyword overrides."""
+    """EngineOptions from: the class defaults, then the process defaults (MS_OPTIONS' `engine.*` entries, engine_defaults / set_engine_default), then `given`, then keyword
+    overrides.  `given` as a DICT names the fields to change on top of the process defaults; `given` as an EngineOptions OBJECT is taken verbatim - every field of it, the
+    process defaults do not reach such an engine (a caller who builds the object owns all of it; tools/test_switches.sh therefore reaches only engines built from dicts /
+    defaults, which is every engine the solver builds unless loop_options / train_options hold an object)."""
     if isinstance(given, EngineOptions):
         opt = dataclasses.replace(given)
     else:

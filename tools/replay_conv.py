@@ -1,6 +1,6 @@
 """Replay ONE convolution launch of the C2 inner step on its live buffers, N times back to back (for rocprofv3 --pmc / --kernel-trace).
 
-    python tools/replay_conv.py <which> [reps]
+    python tools/replay_conv.py <which> [reps] [timing-only ablation bits of the conv kernels: diag.conv_dbg, results WRONG]
 which: dgrad_actbwd | dgrad_plain | dgrad_acc | dgrad_nt2 | fwd_pro1 | fwd_pro0        (all at their dominant shape of the step)
 The launch sequence of one eager step is recorded exactly as tools/tune_conv.py does; the selected call is then re-issued with the same arguments."""
 import os, sys
@@ -60,6 +60,7 @@ def describe(name, a):
 def main():
     which = sys.argv[1]
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    dbg = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0
     dev = torch.device("cuda:0")
     eng, calls, orig = record_step(dev)
     ep, cin, hs, pm, epi, stats = WHICH[which]
@@ -67,6 +68,9 @@ def main():
         d = describe(name, a)
         if name == ep and d["Cin"] == cin and d["Hs"] == hs and d["pm"] == pm and d["epi"] == epi and d["stats"] == stats and d["ks"] == 3 and d["stride"] == 1 and (d["fetch"] & 0xFF) == 0 \
                 and d["Cout"] == cin:
+            if dbg:
+                from maxstyle_amd.options import set_library_option
+                set_library_option("diag.conv_dbg", dbg)
             for _ in range(reps):
                 rc = orig[name](*a)
                 assert rc == 0
