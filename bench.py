@@ -283,7 +283,7 @@ def _traffic_table(B, H, W):
     if (B, H, W) != (16, 256, 256):
         return {}
     tab = {}
-    for name in ("r01_traffic.json", "r02_traffic.json", "r03_traffic.json", "r04_traffic.json", "r05_traffic.json"):
+    for name in ("r01_traffic.json", "r02_traffic.json", "r03_traffic.json", "r04_traffic.json", "r05_traffic.json", "r06_traffic.json"):
         try:
             tab.update(json.load(open(os.path.join(ROOT, "profiles", name))))
             tab["_source"] = f"profiles/{name}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (tools/profile_round.sh), NOT collected in this run"
@@ -383,7 +383,7 @@ def kernel_rooflines(eng, dev, config, instep=None):
         if hf > mf:
             blk = {"bound": "hbm", "achieved": nbytes / t_use / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hf, "frac_isolated": hfi}
         blk.update({"traffic": traffic.get(tkey), "traffic_source": traffic.get("_source") if traffic.get(tkey) else None, "traffic_fresh": (traffic.get("_fresh") if traffic.get(tkey) else None),
-                    "kernel": FORMS[form].replace("PRO", str(pro)) + " " + what + " " + shape,
+                    "kernel": FORMS[form].replace("PRO", str(pro)) + (" [the hot combinations are instantiated with compile-time launch facts: template argument FX, ms_conv_wide.h] " if form >= 2 else " ") + what + " " + shape,
                     "us_per_launch": t_use * 1e6, "us_per_launch_source": ("in-step (two cut-off captures of the step, difference)" if key in instep else "isolated back-to-back replay"),
                     "us_per_launch_isolated": t_iso * 1e6, "algorithmic_bytes": nbytes, "hbm_GBps": nbytes / t_use / 1e9, "hbm_frac": hf, "hbm_frac_isolated": hfi,
                     "flop_per_launch_executed": exf, "executed_tflops": exf / t_use / 1e12, "executed_mfma_frac": mf, "executed_mfma_frac_isolated": mfi,
@@ -652,6 +652,19 @@ def outer_iteration(dev, batch, size, rank=0, world=1, iters=6, dist_on=None):
                     "weights_max_abs_diff_across_ranks": float(dev_max.item())})
     out["value"] = world / dt
     out["per_gpu"] = 1.0 / dt
+    # the roofline of the training passes around the inner loop (round 6): priced per launch family by tools/train_budget.py from a kernel trace of eager
+    # iterations - a committed profile, NOT collected in this run (the live figure of this leg is `ms_per_iteration`)
+    for name in ("r06_step_budget_train.json",):
+        try:
+            sm = json.load(open(os.path.join(ROOT, "profiles", name)))["summary"]
+            tp = sm["training_passes"]
+            out["step_roofline"] = {"source": f"profiles/{name} (tools/train_budget.py: rocprofv3 --kernel-trace of eager trainer iterations; committed, not collected in this run)",
+                                    "training_passes_sum_bound_us": tp["sum_bound_us"], "training_passes_kernel_us": tp["lib_kernel_us"] + tp["torch_kernel_us"],
+                                    "training_passes_wall_us": tp["wall_us"], "frac": tp["sum_bound_us"] / tp["wall_us"], "frac_of_kernel_time": tp["frac_of_kernel_time"],
+                                    "inner_loop_wall_us": sm["inner_loop_wall_us"],
+                                    "phases": {k: {kk: v.get(kk) for kk in ("sum_bound_us", "lib_us", "wall_us", "lib_launches")} for k, v in sm["phases"].items()}}
+        except Exception:  # noqa: BLE001
+            pass
     return out
 
 

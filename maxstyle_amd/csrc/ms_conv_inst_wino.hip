@@ -33,20 +33,39 @@ static int wino_nt(const ConvArgs& a) {
 // Block form (ms_f32wb: four independent 8x8-pixel blocks per work item) where the rectangular tiles waste matrix work: fill = the fraction of a tile grid's pixels that
 // exist.  64x4 / 32x8 tiles fill rows of 80, 40 and 20 pixels to 62 %; 8x8 blocks fill any multiple of 8 completely (20 x 20: 69 %).  The block form stages every
 // block with its own halo (~17 % more staging work than the 32-pixel tiles), so it is taken only from a clearly better fill (rules below).  option "conv.wino_block": 0 never, 2 wherever legal.
+static int wino_nt_for(const ConvArgs& a, bool blocks) {      // wino_nt's rule for a given form (no recursion into the form choice)
+  const int c = opt(OPT_CONV_WINO_NT);
+  if (c == 1 || a.Cout <= 16 || a.wino_nt1) return 1;
+  if (c >= 2) return 2;
+  const int tw = a.Wout < 64 ? 32 : 64, th = 256 / tw;
+  long items2 = (long)a.N * cdiv(a.Wout, tw) * cdiv(a.Hout, th) * cdiv(a.Cout, 32);
+  if (blocks) items2 = cdiv((long)a.N * cdiv(a.Wout, 8) * cdiv(a.Hout, 8), 4L) * cdiv(a.Cout, 32);
+  if (items2 < (long)num_cus()) return 1;
+  if (a.wu != nullptr) return a.Cin >= 32 ? 2 : 1;
+  if (a.Cin < 64) return 1;
+  if (a.pro_mode == 2 && a.Cin < 256 && a.Cout <= a.Cin) return 1;
+  return 2;
+}
 bool conv_wino_blockform(const ConvArgs& a) {
   const int md = opt(OPT_CONV_WINO_BLOCK);
   if (a.wino_blocks) return true;                     // MS_FETCH_WINO_BLOCKS
   if (md == 0 || a.wino_nt1) return false;            // (MS_FETCH_WINO_NT1 pins the round-3 kernel: rectangular tiles, one block)
   if (md >= 2) return true;
+  if (a.Wout < 32) return false;                      // rows of 20 / 24 / 28 pixels lose either way (three partial blocks per row: 281 vs 251 us at 20 x 20)
+  // Round 6: the choice by ROUNDS of the persistent grid, not by fill alone.  A launch runs ceil(items / resident workgroups) rounds of work items; an item of the
+  // block form costs ~1.15x a tile item under the one-tensor prologues and ~1.3x under the two-tensor prologue (private halos: 2.5 scalar loads per lane and chunk
+  // instead of 0.6).  The fill rule of round 4 (blocks from a 1.15x / 1.5x better fill) is this rule on long launches, where rounds ~ items; on the reference's SHIPPED
+  // shapes (batch 20, 1-5 rounds) the integer matters: 64 -> 64 @20x56x56 is 560 tile items = 3 rounds against 490 block items = 2 (41.3 -> 32.5 us), while
+  // 64 -> 64 @20x48x48 is 2 rounds either way and the blocks' better fill loses (29.1 vs 32.4 us) - tools/ab_wino_nt.py acdc192 / prostate224, profiles/r06_wino_ab_*.txt.
   const int tw = a.Wout < 64 ? 32 : 64, th = 256 / tw;
-  const double fill_t = (double)a.Wout * a.Hout / ((double)cdiv(a.Wout, tw) * tw * cdiv(a.Hout, th) * th);
-  const long nb = (long)a.N * cdiv(a.Wout, 8) * cdiv(a.Hout, 8);
-  const double fill_b = (double)a.N * a.Wout * a.Hout / ((double)cdiv(nb, 4) * 4 * 64);
-  // measured (tools/ab_wino_nt.py c4, profiles/r04_wino_nt_ab.txt): the blocks win from a 1.15x better fill under the one-tensor prologues (128 -> 128 @160^2: 713 -> 674 us),
-  // from 1.5x under the two-tensor prologue (its staging is twice as heavy, and the blocks' private halos add ~20 % to it: 160^2 loses, 80^2 / 40^2 win by 10-25 %);
-  // rows of 20 pixels lose either way (three partial blocks per row: 281 vs 251 us)
-  if (a.Wout < 32) return false;
-  return fill_b >= (a.pro_mode == 2 ? 1.5 : 1.15) * fill_t;
+  const int nt_t = wino_nt_for(a, false), nt_b = wino_nt_for(a, true);
+  const long items_t = (long)a.N * cdiv(a.Wout, tw) * cdiv(a.Hout, th) * cdiv(a.Cout, 16 * nt_t);
+  const long items_b = cdiv((long)a.N * cdiv(a.Wout, 8) * cdiv(a.Hout, 8), 4L) * cdiv(a.Cout, 16 * nt_b);
+  const long slots_t = (long)num_cus() * (nt_t == 1 ? 2 : 1), slots_b = (long)num_cus() * (nt_b == 1 ? 2 : 1);
+  // (a round = every CU works through 32 output channels of one tile: one two-block workgroup, or two one-block workgroups sharing the CU - ~1.1x as long)
+  const double cost_t = (double)cdiv(items_t, slots_t) * (nt_t == 1 ? 1.1 : 1.0);
+  const double cost_b = (double)cdiv(items_b, slots_b) * (nt_b == 1 ? 1.1 : 1.0) * (a.pro_mode == 2 ? 1.3 : 1.15);
+  return cost_b < cost_t;
 }
 int conv_wino_blocks(const ConvArgs& a) { return wino_nt(a); }
 int conv_dispatch_winob(const ConvArgs& a, int nt, hipStream_t st);      // ms_conv_inst_winob.hip: the block form

@@ -46,7 +46,7 @@ def test_bench_line_contract():
                 assert 0.0 < v <= 1.0, (b.get("kernel"), k, v)
     assert n_blocks >= 8
     assert r["us_per_launch_source"].startswith("in-step") and r["us_per_launch"] >= 0.9 * r["us_per_launch_isolated"] and r["frac_isolated"] >= r["frac"] * 0.9
-    assert "conv_wide_kernel<1,2,1,true,ms_f32w>" in r["kernel"] and r["form"].startswith("winograd") and r["channel_blocks_per_tile"] == 1
+    assert "conv_wide_kernel<1,2,1,true,ms_f32w>" in r["kernel"] and "FX" in r["kernel"] and r["form"].startswith("winograd") and r["channel_blocks_per_tile"] == 1
     sr = d["step_roofline"]
     assert sr["launches"] >= 60 and 0.1 < sr["frac"] < 1.0 and abs(sr["frac"] - sr["sum_bound_us"] / sr["step_us"]) < 1e-9
     assert abs(sr["hbm_bound_us"] + sr["mfma_bound_us"] - sr["sum_bound_us"]) < 1e-6 * sr["sum_bound_us"]
@@ -67,3 +67,6 @@ def test_bench_line_contract():
     assert sec["c4"]["step_roofline"]["launches"] >= 60 and 0.1 < sec["c4"]["step_roofline"]["frac"] < 1.0
     assert "error" not in d["rccl"] and d["rccl"]["backend"] == "nccl" and d["rccl"]["fcn16_6MB"]["mean_ok"]
     assert d["roofline"].get("traffic_source") is None or d["roofline"]["traffic_source"].startswith("profiles/")
+    # round 6: the outer iteration carries the roofline of its training passes (tools/train_budget.py; a committed profile, named as such)
+    osr = d["outer_iteration"]["step_roofline"]
+    assert osr["source"].startswith("profiles/") and 0.05 < osr["frac"] < 1.0 and osr["training_passes_sum_bound_us"] < osr["training_passes_wall_us"]

@@ -15,6 +15,9 @@ SHAPES = {
            ("convT", 64, 64, 160, 160), ("plain", 64, 64, 320, 320), ("plain", 128, 64, 160, 160), ("plain", 64, 64, 160, 160), ("plain", 64, 128, 80, 80), ("plain", 128, 256, 40, 40),
            # the channel-heavy levels (LDS-tiled GEMM form, csrc/ms_conv_k1g.h)
            ("tail", 256, 512, 40, 40), ("tail", 512, 512, 20, 20), ("plain", 512, 512, 20, 20), ("plain", 512, 256, 40, 40), ("plain", 256, 128, 80, 80), ("plain", 256, 512, 20, 20)],
+    # (round 6) the 1x1 convolutions of config 2 on images of <= 32 x 32 pixels: the first-generation kernel's launches of the step (profiles/r05_step_budget_c2.txt)
+    "c2small": [("tail", 64, 128, 32, 32), ("tail", 128, 128, 16, 16), ("plain", 128, 128, 16, 16), ("up2", 128, 64, 8, 8), ("up2", 64, 32, 16, 16), ("up2", 32, 16, 32, 32),
+                ("plain", 32, 64, 32, 32), ("plain", 64, 128, 16, 16), ("plain", 128, 64, 32, 32)],
     "c2": [("tail", 16, 16, 256, 256), ("tail", 16, 32, 128, 128), ("tail", 32, 64, 64, 64), ("tail", 64, 128, 32, 32), ("up2", 32, 16, 64, 64), ("up2", 64, 32, 32, 32),
            ("plain", 16, 16, 256, 256), ("plain", 16, 16, 128, 128), ("plain", 32, 16, 128, 128), ("plain", 64, 32, 64, 64), ("plain", 16, 32, 64, 64)],
 }
