@@ -64,7 +64,7 @@ MS_STABLE int ms_get_option(const char* name);
 MS_STABLE int ms_option_default(const char* name);
 MS_STABLE int ms_option_count(void);
 MS_STABLE const char* ms_option_name(int index);
-/* diagnostic builds only (-DMS_CONV_TRACE_BUILD / -DMS_WGRAD_TRACE_BUILD): device buffers (conv: >= 64 KiB, wgrad: >= 8 KiB, or NULL) for the in-kernel cycle stamps */
+/* diagnostic builds only (-DMS_CONV_TRACE_BUILD / -DMS_WGRAD_TRACE_BUILD): device buffers (conv: >= 128 KiB, wgrad: >= 8 KiB, or NULL) for the in-kernel cycle stamps */
 MS_INTERNAL int ms_diag_set_trace(void* conv_trace, void* wgrad_trace);
 /* Layer-chain probe (tools/chain_probe.py): L plain 3x3 layers C -> C on N images of H x 16 pixels as ONE persistent launch with a grid barrier
  * between layers (layer l reads a_buf / b_buf alternately and writes the other).  layers_dev: ms_diag_k3n_chain_bytes(L) bytes of device scratch; arrive: two device

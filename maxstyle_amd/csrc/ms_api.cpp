@@ -69,7 +69,7 @@ extern "C" int ms_set_option(const char* name, int value) {
   return ms::g_opt[i].exchange(value, std::memory_order_relaxed);
 }
 
-// diagnostic builds only (tools/trace_conv.py, tools/trace_wgrad.py): device buffers (conv: >= 64 KiB, wgrad: >= 8 KiB) that the stamped kernels write their cycle stamps into (workgroup 0; conv_wide_kernel also one wall-clock record per workgroup)
+// diagnostic builds only (tools/trace_conv.py, tools/trace_wgrad.py): device buffers (conv: >= 128 KiB, wgrad: >= 8 KiB) that the stamped kernels write their cycle stamps into (workgroup 0; conv_wide_kernel also one wall-clock record per workgroup)
 extern "C" int ms_diag_set_trace(void* conv_trace, void* wgrad_trace) {
   ms::g_conv_trace.store((long long*)conv_trace, std::memory_order_relaxed);
   ms::g_wgrad_trace.store((long long*)wgrad_trace, std::memory_order_relaxed);

@@ -188,6 +188,30 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     const int itid = WB ? (tid & 63) : tid;        // item numbering: per workgroup (256 staging threads), or per patch (64 lanes) in the block form
     constexpr int ISTR = WB ? 64 : 256;
     const int patch_off = WB ? sw_ * (IH * RS) : 0;
+    // Winograd appendix (a.wu, MS_FETCH_WINO_U): the chunk's transformed weights come straight from HBM / L2 into the stage's weight region by LDS-DMA
+    // (buffer_load_dwordx4 ... lds: 1 KB per wave-instruction, no vector register, no vector arithmetic) - 2 * NT instructions per staging wave instead of nine tap loads,
+    // ~37 vector instructions and 16 LDS stores per thread.  Issued FIRST in the iteration that stores the chunk (the consumers left this buffer at the previous
+    // barrier), covered by a counted vmcnt in front of this iteration's barrier: the next chunk's data loads, issued later, stay in flight.
+    int wu_voff = 0;
+    if constexpr (WIN) {
+      const int pl = tid & 63;
+      // lane -> (block j, channel-in-chunk, 4 output channels) inside one position's UP floats of the stage (see WideGeoW)
+      if constexpr (NT == 2) wu_voff = 4 * ((pl >> 5) * nchunks * 2048 + ((pl & 31) >> 2) * 16 + (pl & 3) * 4);
+      else wu_voff = 4 * ((pl >> 5) * 128 + ((pl & 31) >> 2) * 16 + (pl & 3) * 4);
+    }
+    auto dma_u = [&](float* buf, int cbi, int chunk_i) __attribute__((always_inline)) {
+      if constexpr (WIN) {
+        const ms_i32x4 ru = ms_dma_rsrc(a.wu);
+        const int sw = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const unsigned dst = ms_lds_addr(buf + CK * PS);
+#pragma unroll
+        for (int q = 0; q < 2 * NT; ++q) {
+          const int piece = q * 4 + sw;                 // 256 floats of the weight region each
+          const int so = (NT == 2) ? 4 * ((cbi * 2 * nchunks + chunk_i) * 2048 + piece * 128) : 4 * ((cbi * nchunks + chunk_i) * 2048 + piece * 256);
+          ms_lds_dma16(ru, dst + 1024u * (unsigned)piece, wu_voff, __builtin_amdgcn_readfirstlane(so));
+        }
+      }
+    };
     int pb_n = 0;                                  // block form: the image of this wave's patch
     const int plane = a.Hs * a.Ws;                 // host checks Cin*plane < 2^31
     typedef unsigned mask_t;
@@ -461,40 +485,26 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 
     int key_cb[2] = {-1, -1}, key_c0[2] = {-1, -1};
     int item = vb, chunk = 0, n, tile, cb, tile_set = -1;
+#ifdef MS_CONV_TRACE_BUILD
+    const bool wtr = (a.trace != nullptr) && (MS_TID == 256) && (blockIdx.x < 1024);
+    if (wtr) a.trace[1024 + 4096 + 1024 + 4 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();          // hoisted set-up done
+#endif
     decode(item, n, tile, cb);
     set_tile(tile); tile_set = tile;
     load_chunk(n, cb * COUT_TILE, 0, true, false);
+#ifdef MS_CONV_TRACE_BUILD
+    if (wtr) a.trace[1024 + 4096 + 1024 + 4 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();      // first chunk's loads issued
+#endif
     lds_barrier();                                    // barrier #0 (matched by the consumers): the coefficient table is complete behind it
+#ifdef MS_CONV_TRACE_BUILD
+    if (wtr) a.trace[1024 + 4096 + 1024 + 4 * blockIdx.x + 2] = (long long)__builtin_amdgcn_s_memrealtime();      // behind barrier #0
+#endif
     load_coefs(0);
 #ifdef MS_CONV_TRACE_BUILD
     const bool tr = (a.trace != nullptr) && (blockIdx.x == 0) && (MS_TID == 256);
 #else
     constexpr bool tr = false;
 #endif
-    // Winograd appendix (a.wu, MS_FETCH_WINO_U): the chunk's transformed weights come straight from HBM / L2 into the stage's weight region by LDS-DMA
-    // (buffer_load_dwordx4 ... lds: 1 KB per wave-instruction, no vector register, no vector arithmetic) - 2 * NT instructions per staging wave instead of nine tap loads,
-    // ~37 vector instructions and 16 LDS stores per thread.  Issued FIRST in the iteration that stores the chunk (the consumers left this buffer at the previous
-    // barrier), covered by a counted vmcnt in front of this iteration's barrier: the next chunk's data loads, issued later, stay in flight.
-    int wu_voff = 0;
-    if constexpr (WIN) {
-      const int pl = tid & 63;
-      // lane -> (block j, channel-in-chunk, 4 output channels) inside one position's UP floats of the stage (see WideGeoW)
-      if constexpr (NT == 2) wu_voff = 4 * ((pl >> 5) * nchunks * 2048 + ((pl & 31) >> 2) * 16 + (pl & 3) * 4);
-      else wu_voff = 4 * ((pl >> 5) * 128 + ((pl & 31) >> 2) * 16 + (pl & 3) * 4);
-    }
-    auto dma_u = [&](float* buf, int cbi, int chunk_i) __attribute__((always_inline)) {
-      if constexpr (WIN) {
-        const ms_i32x4 ru = ms_dma_rsrc(a.wu);
-        const int sw = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const unsigned dst = ms_lds_addr(buf + CK * PS);
-#pragma unroll
-        for (int q = 0; q < 2 * NT; ++q) {
-          const int piece = q * 4 + sw;                 // 256 floats of the weight region each
-          const int so = (NT == 2) ? 4 * ((cbi * 2 * nchunks + chunk_i) * 2048 + piece * 128) : 4 * ((cbi * nchunks + chunk_i) * 2048 + piece * 256);
-          ms_lds_dma16(ru, dst + 1024u * (unsigned)piece, wu_voff, __builtin_amdgcn_readfirstlane(so));
-        }
-      }
-    };
     constexpr int kDataLoads = (PRO == 2 ? 2 : 1) * (NQI + NHI);      // vector-memory loads load_chunk issues for one chunk's activations
     for (int p = 0; p < T; ++p) {
       if (tr && p < 16) a.trace[128 + p * 4 + 0] = clock64();
@@ -505,6 +515,9 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         if (l_edge) store_chunk(smem + (p & 1) * BUF, std::true_type{}); else store_chunk(smem + (p & 1) * BUF, std::false_type{});
       }
       if (tr && p < 16) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); a.trace[128 + p * 4 + 1] = clock64(); }
+#ifdef MS_CONV_TRACE_BUILD
+      if (wtr && p == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); a.trace[1024 + 4096 + 1024 + 4 * blockIdx.x + 3] = (long long)__builtin_amdgcn_s_memrealtime(); }      // first chunk stored
+#endif
       key_cb[p & 1] = cb; key_c0[p & 1] = chunk * CK;
       // the weights of chunk p by LDS-DMA: behind this iteration's LDS stores (the consumers left the buffer at the previous barrier), in front of the next chunk's
       // data loads - so the compiler's own counted waits for THOSE never include a DMA piece, and the counted wait below leaves them in flight

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 dev = torch.device("cuda:0")
-trace = torch.zeros(8192, dtype=torch.int64, device=dev)
+trace = torch.zeros(16384, dtype=torch.int64, device=dev)
 from maxstyle_amd._lib import lib as _L
 _L.ms_diag_set_trace(trace.data_ptr(), 0)
 from maxstyle_amd import ops
@@ -81,3 +81,8 @@ if len(w):
         d = r[:, 2] - r[:, 1]
         for g in sorted(set(tg.tolist())):
             print(f"  thread-group slot {g}: {int((tg == g).sum())} workgroups, loop duration median {np.median(d[tg == g]):.1f}")
+    pw = np.array(t[1024 + 4096 + 1024:1024 + 4096 + 1024 + 4 * nb], dtype=np.int64).reshape(-1, 4)
+    if pw.any():
+        e = (pw - (np.array(t[1024:1024 + 4 * nb], dtype=np.int64).reshape(-1, 4)[:, :1])) * 10 / 1000.0          # us since the workgroup's own entry
+        print("  staging wave 0, us since its workgroup's entry (median over workgroups): set-up done %.2f | first loads issued %.2f | behind barrier #0 %.2f | first chunk stored %.2f | first MFMA %.2f"
+              % (np.median(e[:, 0]), np.median(e[:, 1]), np.median(e[:, 2]), np.median(e[:, 3]), np.median(r[:, 1] - r[:, 0])))
