@@ -56,6 +56,18 @@ python tools/ab_subpix_small.py 20 2>&1 | grep -v amdgpu > $O/${R}_ab_subpix_sma
 timeout 300 python tools/chain_probe.py 2>&1 | grep -v amdgpu > $O/${R}_chain_probe.txt; cp gpurun_out/chain_probe.json $O/${R}_chain_probe.json
 python tools/draws_report.py 2>&1 | grep -E "^c4|^c5" > $O/${R}_draws_report.txt
 python tools/shipped_report.py 2>&1 | grep -E "^acdc|^prostate|per sample" > $O/${R}_shipped_report.txt
+# 5g. round 6: the trainer's roofline budget (tools/train_budget.py), the Winograd forms per layer at the shipped shapes, the wide kernel's per-workgroup wall-clock stamps
+python tools/train_budget.py record $O/train_ledger.json > $O/train_budget.log 2>&1
+rm -rf /tmp/ktt; rocprofv3 --kernel-trace --output-format csv -d /tmp/ktt -- python tools/train_budget.py trace >> $O/train_budget.log 2>&1
+python tools/train_budget.py merge $O/train_ledger.json /tmp/ktt $O/${R}_step_budget_train >> $O/train_budget.log 2>&1
+rm -rf /tmp/ktt
+python tools/ab_wino_nt.py acdc192 10 2>&1 | grep -v amdgpu > $O/${R}_wino_ab_acdc192.txt
+python tools/ab_wino_nt.py prostate224 10 2>&1 | grep -v amdgpu > $O/${R}_wino_ab_prostate224.txt
+if [ -f maxstyle_amd/lib/trace/libmaxstyle_hip.so ]; then
+  for spec in "actbwd 16 256 0x900" "pro1 16 256 0x900" "plain 16 256 0x900" "actbwd 64 320 0x900"; do
+    echo "== tools/trace_conv.py $spec"; MS_LIB=$GRAFT_REPO_ROOT/maxstyle_amd/lib/trace/libmaxstyle_hip.so python tools/trace_conv.py $spec 2>&1 | grep -v amdgpu; echo
+  done > $O/${R}_conv_wide_stamps.txt
+fi
 # 6. un-profiled bench lines
 python bench.py > $O/${R}_bench_line.json 2> $O/bench.err
 python bench.py --config c4 --steps 10 --warmup 2 > $O/${R}_bench_c4.json 2> $O/bench_c4.err
