@@ -4,9 +4,9 @@ Records every ms_conv2d / ms_conv2d_actbwd call of one eager step at the C2 conf
 under the library's tuning options (ms_set_option "conv.force_nt": output-channel tile NT forced to 1/2/4; "conv.wide": wide-read kernel on/off) and prints what the built-in
 heuristic chose against the best alternative.  Usage: python tools/tune_conv.py [reps]"""
 import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maxstyle_amd import options as _O
 _O._engine_defaults.update(xfin=False, ride=False)      # every conv through ms_conv2d / ms_conv2d_actbwd (the `_xfin` / rider twins launch the same kernels)
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from maxstyle_amd import _lib
