@@ -28,7 +28,10 @@ def test_headline_config_vs_reference_run(dev, monkeypatch, winograd):
     oneDNN at 8 / 2 threads, ATen native; draw 0 reproduces the fp32 leg stored with the fixture) land 1.0e-4 / 1.0e-4 / 1.6e-4 (max) and 1.9e-5 / 1.9e-5 / 2.5e-5 (rms)
     of the image range from its fp64 run, their step-4 loss errors 1.1e-6 / 1.1e-6 / 4e-8.  Bars: image error <= 2x the LARGEST draw (max and rms; measured 0.7-1.3x of
     the fixture's own draw), per-step losses <= max(5x the reference's worst error up to the step over its draws, 5e-6), final parameters <= 3x its worst, labels
-    >= 99.99 % equal, Dice within 1e-3.  The smooth part of the map is pinned separately at every step (tests/test_round5_gpu.py::test_benchmarked_calls_teacher_forced)."""
+    >= 99.99 % equal, Dice within 1e-3.  The smooth part of the map is pinned separately at every step (tests/test_round5_gpu.py::test_benchmarked_calls_teacher_forced).
+    (Round 6: the image bar OF RECORD is tests/test_round6_gpu.py::test_augmented_image_teacher_forced - one decode at the reference's fp64 parameters, max <= 1e-4 / rms <= 1e-5 of the
+    image range, no calibration; the image assertions here measure one draw of a chaotic loop against the reference's own fp32 evaluations - two distinct ones: oneDNN and ATen native.)
+    """
     import r5_cases as R5
     set_engine_default(monkeypatch, "winograd", winograd == "1")
     r = R.full_size_case(dev)

@@ -38,7 +38,10 @@ def test_shipped_workload_vs_reference_run(dev, monkeypatch, which, winograd):
         direct form / 1e-3 for either form, the non-chaotic quantities (code, frozen batch std) at fp32 rounding;
       * the image: max norm <= 1e-2 and batch rms <= 2e-3 of the image range - 2.5 and 0.5 grey levels of the 8-bit scans the trainer's inputs come from - for either
         form; the DIRECT form, whose forward rounding is the reference's own, also within 3x the largest of the reference's draws in batch rms (measured 0.9-1.7x);
-        the Winograd form (about twice the forward rounding error, hence more sign flips) measures 1-4x, printed below and recorded in DESIGN.md section 10."""
+        the Winograd form (about twice the forward rounding error, hence more sign flips) measures 1-4x, printed below and recorded in DESIGN.md section 10.
+    (Round 6: the image bar OF RECORD is tests/test_round6_gpu.py::test_augmented_image_teacher_forced - one decode at the reference's fp64 parameters, max <= 1e-4 / rms <= 1e-5 of the
+    image range, no calibration; the image assertions here measure one draw of a chaotic loop against the reference's own fp32 evaluations - two distinct ones: oneDNN and ATen native.)
+    """
     set_engine_default(monkeypatch, "winograd", winograd)
     r = R5.shipped_case(dev, which)
     d = r["draws"]
