@@ -363,7 +363,9 @@ def kernel_rooflines(eng, dev, config, instep=None):
              2: "conv_wide_kernel<1,PRO,1,true,ms_f32w%s> (Winograd F(2x2,3x3), one 16-channel block per staged tile)" % ("32" if W < 64 else ""),
              3: "conv_wide_kernel<2,PRO,1,true,ms_f32w%s> (Winograd F(2x2,3x3), two 16-channel blocks per staged tile)" % ("32" if W < 64 else ""),
              4: "conv_wide_kernel<1,PRO,1,true,ms_f32wb> (Winograd F(2x2,3x3) on 8x8-pixel blocks, one 16-channel block)",
-             5: "conv_wide_kernel<2,PRO,1,true,ms_f32wb> (Winograd F(2x2,3x3) on 8x8-pixel blocks, two 16-channel blocks)"}
+             5: "conv_wide_kernel<2,PRO,1,true,ms_f32wb> (Winograd F(2x2,3x3) on 8x8-pixel blocks, two 16-channel blocks)",
+             6: "conv_k3n_kernel (narrow rows, direct form)",
+             7: "conv_wide_kernel<2,PRO,1,true,ms_f32wf> (Winograd F(2x2,3x3) on the flattened tile list of 20-pixel images, two 16-channel blocks)"}
 
     def conv_block(key, what, pro, nbytes, tkey):
         # Both roofs are priced with what the launch EXECUTES: the Winograd form multiplies 16/36 of the direct form's products on the same fp32 matrix instruction, so its
@@ -371,7 +373,7 @@ def kernel_rooflines(eng, dev, config, instep=None):
         # launch is closer to.  `frac` / `achieved` use the IN-STEP duration of the launch (in_step_times: measured live inside the replayed step) when the caller measured
         # it; the isolated back-to-back replay (warm caches, no neighbours) is `frac_isolated`.
         form = int(_lib.lib.ms_conv2d_form(B, C, H, W, C, pro, 0, wino))
-        exf = flops * (16.0 / 36.0 if form >= 2 else 1.0)
+        exf = flops * (16.0 / 36.0 if (form >= 2 and form != 6) else 1.0)
         t_iso = t[key]
         t_use = instep.get(key, t_iso)
 
@@ -387,8 +389,8 @@ def kernel_rooflines(eng, dev, config, instep=None):
                     "us_per_launch": t_use * 1e6, "us_per_launch_source": ("in-step (two cut-off captures of the step, difference)" if key in instep else "isolated back-to-back replay"),
                     "us_per_launch_isolated": t_iso * 1e6, "algorithmic_bytes": nbytes, "hbm_GBps": nbytes / t_use / 1e9, "hbm_frac": hf, "hbm_frac_isolated": hfi,
                     "flop_per_launch_executed": exf, "executed_tflops": exf / t_use / 1e12, "executed_mfma_frac": mf, "executed_mfma_frac_isolated": mfi,
-                    "form": "winograd F(2x2,3x3)" if form >= 2 else "direct", "channel_blocks_per_tile": ((form - 2) % 2 + 1 if form >= 2 else None)})
-        if form >= 2:
+                    "form": "winograd F(2x2,3x3)" if (form >= 2 and form != 6) else "direct", "channel_blocks_per_tile": (2 if form == 7 else ((form - 2) % 2 + 1 if 2 <= form <= 5 else None))})
+        if form >= 2 and form != 6:
             blk["direct_form_flop_per_launch"] = flops
             blk["direct_form_equivalent_tflops"] = flops / t_use / 1e12      # (work of the direct form per second: can pass the pipe's peak, NOT a roofline fraction)
         return blk

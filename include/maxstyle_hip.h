@@ -56,6 +56,7 @@ MS_STABLE const char* ms_last_error(void);
  *                               16 pixels; the same bits in `out` as ms_conv2d on that layer) | 0: the vector-ALU form (another rounding)
  *   "conv.force_nt"    0        1 / 2 / 4: output-channel blocks of 16 per workgroup of the first-generation kernel (tuning)
  *   "style.fused"      1        0: ms_style_fwd never takes the single-read kernel (three-launch path)
+ *   "conv.wino_flat"   1        0: no flattened-tile Winograd form on images of 20 x 20 pixels (the 8 x 32-pixel tiles instead: the same bits in `out`)
  *   "diag.conv_dbg"    0        timing-only ablation bits of the conv kernels - results are WRONG with any bit set
  * ms_set_option returns the previous value (>= 0) or MS_ERR_INVALID for an unknown name / a value out of range; ms_get_option the current value.  Setting an option
  * while launches of other threads are in flight is safe (relaxed atomics): such a launch takes one form or the other.  ms_option_count / ms_option_name enumerate. */
@@ -97,7 +98,8 @@ MS_INTERNAL int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int p
  * dispatch itself instead of re-deriving its rules: 0 first-generation kernel (conv_mfma_kernel) | 1 wide direct form (conv_wide_kernel) | 2 Winograd F(2x2,3x3), one
  * 16-channel block per staged tile (conv_wide_kernel<1, ..., ms_f32w*>) | 3 Winograd, two blocks (conv_wide_kernel<2, ...>: round 4) | 4 / 5 the same on independent
  * 8x8-pixel blocks instead of 4x64 / 8x32 tiles (ms_f32wb: rows that are not multiples of 32 / 64 pixels) | 6 the narrow-rows second generation (conv_k3n_kernel:
- * rows of 12 / 14 / 16 pixels, round 5).  fetch = the call's fetch argument
+ * rows of 12 / 14 / 16 pixels, round 5) | 7 Winograd on the flattened tile list of 20-pixel images, two blocks (conv_wide_kernel<2, ..., ms_f32wf>: round 6; needs the
+ * MS_FETCH_WINO_U appendix).  fetch = the call's fetch argument
  * (MS_FETCH_WINOGRAD / MS_FETCH_WINO_NT1 bits); a fused-fetch call (fetch & 0xFF != 0) is always 0. */
 MS_INTERNAL int ms_conv2d_form(int N, int Cin, int H, int W, int Cout, int pro_mode, int bf16, int fetch);
 /* The Winograd appendix of a packed 3x3 weight tensor (MS_FETCH_WINO_U): layout [ceil(Cout/16)][Cin/8][16 positions][8 input channels][16 output channels] fp32

@@ -254,7 +254,7 @@ extern "C" int ms_conv2d_pool2_ok(int N, int Cin, int H, int W, int Cout, int pr
   a.pro_mode = pro_mode; a.epi_mode = MS_EPI_POOL2; a.wino_ok = 1; a.act_bf16 = (bf16 < 0 || bf16 > 2) ? 2 : bf16;
   return (conv_wide_eligible(a, 3, 1, FETCH_NORMAL, true) && conv_wide_is_wino(a)) ? 1 : 0;
 }
-namespace ms { int conv_wino_blocks(const ConvArgs& a); bool conv_wino_blockform(const ConvArgs& a); }      // ms_conv_inst_wino.hip
+namespace ms { int conv_wino_blocks(const ConvArgs& a); bool conv_wino_blockform(const ConvArgs& a); bool conv_wino_flat(const ConvArgs& a); }      // ms_conv_inst_wino.hip / ms_conv_inst_winof.hip
 namespace ms {
 // (the arithmetic is wino_pack_one, ms_pack.h: shared with the batched appendix refresh ms_appendix_batch)
 __global__ __launch_bounds__(256) void wino_pack_kernel(float* __restrict__ wp, int Cin, int Cout, int cin_pad, int cout_pad) {
@@ -284,6 +284,7 @@ extern "C" int ms_conv2d_form(int N, int Cin, int H, int W, int Cout, int pro_mo
   a.wu = ((fetch & MS_FETCH_WINO_U) && a.wino_ok && Cin % 8 == 0) ? &appendix_marker : nullptr;
   if (!conv_wide_eligible(a, 3, 1, FETCH_NORMAL, W % 4 == 0)) return conv_k3n_eligible(a, 3, 1, FETCH_NORMAL) ? 6 : 0;
   if (!conv_wide_is_wino(a)) return 1;
+  if (conv_wino_flat(a)) return 7;                      // (the flat form needs the appendix and one of its epilogues: asked here with epi_mode 0)
   return 1 + conv_wino_blocks(a) + (conv_wino_blockform(a) ? 2 : 0);
 }
 // Channels a rider should have at most on a conv launch with this output shape so that every MFMA wave takes ONE channel: 4 x (an estimate of) the workgroup count.

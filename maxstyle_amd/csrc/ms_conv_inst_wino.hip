@@ -69,7 +69,10 @@ bool conv_wino_blockform(const ConvArgs& a) {
 }
 int conv_wino_blocks(const ConvArgs& a) { return wino_nt(a); }
 int conv_dispatch_winob(const ConvArgs& a, int nt, hipStream_t st);      // ms_conv_inst_winob.hip: the block form
+bool conv_wino_flat(const ConvArgs& a);                                  // ms_conv_inst_winof.hip: the flat form (20-pixel rows)
+int conv_dispatch_winof(const ConvArgs& a, hipStream_t st);
 int conv_dispatch_wino(const ConvArgs& a, hipStream_t st) {
+  if (conv_wino_flat(a)) return conv_dispatch_winof(a, st);
   if (conv_wino_blockform(a)) return conv_dispatch_winob(a, wino_nt(a), st);
   if (wino_nt(a) == 2) return conv_dispatch_wino2(a, st);
   if (a.Wout < 64) return a.act_bf16 ? wide_wino<ms_bf16w32>(a, st) : wide_wino<ms_f32w32>(a, st);

@@ -101,6 +101,28 @@ struct WideGeoWB {
   static constexpr int W_ITEMS = CK * 16 * NT_, NWI = 1;
 };
 
+// Flat form of the Winograd mode (AT = ms_f32wf, round 6): images of W = 20 pixels per row (config 4's deepest levels).  The 2x2-output tiles of the whole
+// batch form ONE list (image, tile row, tile column: 10 tiles per row); a work item = 64 consecutive tiles of it x 32 output channels, MFMA wave w multiplies tiles
+// 16 w .. 16 w + 15 - every MFMA row is a real tile (the 8-row x 32-pixel tile fills 62 % x 83 % of its rows here).  Staged per chunk: the BAND of image rows the item's tiles
+// touch - of one image, or (the list runs across images) the last rows of one and the first rows of the next: band row r = image row 2 ty0 - 1 + r of the first image up to
+// and including the row BELOW it (zero), then rows -1 (zero), 0, 1 .. of the next.  64 tiles touch at most 8 tile rows in all: 16 pixel rows + 2 halo rows + 2 at an image
+// boundary = 20 band rows of 22 floats (column 0 / 21 = the left / right halo: always outside the image, always zero); plane stride 480 == 32 (mod 64).
+// A lane's 4 x 4 patch starts at an even column (8-byte reads), its base offset is per lane and per item (tile -> band row, column); after the MFMAs a lane holds four
+// consecutive tiles of the list, stored tile by tile (8-byte stores).  Per output element the K loop is the tiled form's: the same bits in `out`.
+template <int NT_, int PRO>
+struct WideGeoWF {
+  static constexpr int W = 20, TXR = W / 2;
+  static constexpr int TW = W, TH = 4, CK = 8, IH = 20;
+  static constexpr int RS = W + 2, PS = 480;
+  static_assert(IH * RS <= PS && PS % 64 == 32, "plane stride");
+  static constexpr int WS = 16;
+  static constexpr int UP = CK * 16 * NT_;
+  static constexpr int BUF = CK * PS + 16 * UP;
+  static constexpr int Q_ITEMS = CK * IH * (TW / 4), H_ITEMS = CK * IH * 2;      // (the halo items are never inside the image: they store the zeros of columns 0 / 21)
+  static constexpr int NQI = (Q_ITEMS + 255) / 256, NHI = (H_ITEMS + 255) / 256;
+  static constexpr int W_ITEMS = CK * 16 * NT_, NWI = 1;
+};
+
 
 // PRO: 0 none, 1 BatchNorm apply + LeakyReLU, 2 BatchNorm backward (two tensors)
 // AF ("all full"): cin_pad is a multiple of the K-chunk - no ragged channel group anywhere in the layer, the guarded MFMA loop is not instantiated
@@ -127,12 +149,15 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   constexpr bool BFM = std::is_same<AT, ms_bf16m>::value;         // bf16 matrix arithmetic (needs R == 1)
   constexpr bool BFL = BFM;                                       // the bf16 LDS layout (8-byte channel-quad entries)
   constexpr bool WB = std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value;        // Winograd form on independent 8x8-pixel blocks (WideGeoWB)
-  constexpr bool WIN = std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value || WB ||       // Winograd F(2x2, 3x3) (needs R == 1, NT <= 2, every chunk full)
+  constexpr bool WFL = std::is_same<AT, ms_f32wf>::value;                                               // Winograd form on the flattened tile list of 20-pixel images (WideGeoWF)
+  static_assert(!WFL || NT == 2, "flat form: two channel blocks per lane");
+  constexpr bool WIN = std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value || WB || WFL ||       // Winograd F(2x2, 3x3) (needs R == 1, NT <= 2, every chunk full)
                        std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value;      // ... on bf16 storage
   constexpr int WTW = (std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w32>::value) ? 32 : 64;
   constexpr int WHALVES = WTW / 32;                               // 32-pixel halves of a tile row = waves per tile row
   static_assert(!WIN || (R == 1 && NT <= 2 && AF), "Winograd mode: 4-row tiles, one or two channel blocks per lane, channel count a multiple of the chunk");
-  using G = typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WB, WideGeoWB<(WB ? NT : 1), PRO>, typename std::conditional<WIN, WideGeoW<(WIN ? NT : 1), PRO, WTW>, WideGeo<NT, PRO, R>>::type>::type>::type;
+  using G = typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WB, WideGeoWB<(WB ? NT : 1), PRO>, typename std::conditional<WFL, WideGeoWF<(WFL ? NT : 1), PRO>,
+            typename std::conditional<WIN, WideGeoW<(WIN ? NT : 1), PRO, WTW>, WideGeo<NT, PRO, R>>::type>::type>::type>::type;
   using IO = ActIO<AT>;
   constexpr int AB = IO::kBytes;
   static_assert(!BFM || R == 1, "bf16 MFMA mode: 4-row tiles");
@@ -142,7 +167,9 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   const int wave = __builtin_amdgcn_readfirstlane((int)(MS_TID >> 6)), lane = MS_TID & 63;      // wave-uniform by construction: keep it in a scalar register
   const bool producer = wave >= 4;
   const int ntiles = a.tiles_x * a.tiles_y, ncb = a.ncb;
-  const int nitems = (WB ? 1 : a.N) * ntiles * ncb;          // (block form: a "tile" is a group of four blocks of the flattened (image, block row, block column) list)
+  const int nitems = ((WB || WFL) ? 1 : a.N) * ntiles * ncb;          // (block form: a "tile" is a group of four blocks of the flattened (image, block row, block column) list; flat form: 64 tiles of the flattened tile list)
+  // flat form: tiles per image, per batch; group g = tiles 64 g .. 64 g + 63 of the batch's list
+  const int wf_T = (a.Hout >> 1) * (WFL ? G::TW / 2 : 1), wf_total = a.N * wf_T;
   const int nchunks = (a.cin_pad + CK - 1) / CK;
   // block form: block b of the flattened list -> (image, first row, first column); b beyond the list -> an empty block (rows beyond the image: nothing loaded or stored)
   const int wb_bx = (a.Wout + 7) >> 3, wb_by = (a.Hout + 7) >> 3, wb_total = a.N * wb_bx * wb_by;
@@ -258,7 +285,32 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     mask_t q_ok = 0, h_ok = 0;
     bool edge = false;
     int t_base = 0;
+    unsigned q_offd[WFL ? NQI : 1];                // flat form: the item's own load offsets (band rows of the NEXT image sit a constant further)
     auto set_tile = [&](int tile) {
+      if constexpr (WFL) {
+        // band row r: first image n0 rows 2 ty0 - 1 + r for r < rows_a (the last of them is the row below the image), then image n0 + 1 rows r - rows_a - 1.
+        // The hoisted offsets are linear in r from the band's first row; a row of the next image is (Cin * plane - (H + 2) * W) elements further, whatever the item.
+        const int t0 = tile * 64, n0 = t0 / wf_T, l0 = t0 - n0 * wf_T, ty0 = l0 / (G::TW / 2);
+        pb_n = n0;
+        const int y0 = 2 * ty0;
+        t_base = y0 * a.Ws;
+        const int rows_a = a.Hin - y0 + 2;
+        const bool live_b = n0 + 1 < a.N;
+        const unsigned d_next = (unsigned)AB * (unsigned)(a.Cin * plane - (a.Hin + 2) * a.Ws);
+        edge = true;
+        q_ok = 0; h_ok = 0;
+#pragma unroll
+        for (int j = 0; j < NQI; ++j) {
+          const int r = q_rc[j] >> 16;
+          const bool part_b = r >= rows_a;
+          const int y = part_b ? r - rows_a - 1 : y0 - 1 + r;
+          const bool ok = (y >= 0) && (y < a.Hin) && (!part_b || live_b);
+          q_ok |= (ok ? 1u : 0u) << j;
+          q_offd[j] = q_off[j] + (part_b ? d_next : 0u);
+        }
+        q_ok &= q_all;
+        return;
+      }
       int y0, x0;
       bool live = true;
       if constexpr (WB) { live = wb_decode(tile * 4 + sw_, pb_n, y0, x0); }
@@ -297,7 +349,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       const int origin = AB * bias;                     // masked items read the (valid) tile origin and are zeroed at the LDS store
 #pragma unroll
       for (int j = 0; j < NQI; ++j) {
-        int off = (int)q_off[j];
+        int off = WFL ? (int)q_offd[WFL ? j : 0] : (int)q_off[j];
         if constexpr (EDGE) off = ((qm >> j) & 1u) ? off : origin;
         if constexpr (AB == 4) {
           const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r1, off, soff, 0);
@@ -352,7 +404,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     auto load_chunk = [&](int n, int co0, int c0, bool load_w, bool coefs = true) {
       // buffer addressing: resource base = image n, biased back (scalar arithmetic); soffset = chunk + tile origin (scalar); voffset = the hoisted item offset:
       // `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen` - no vector address arithmetic per chunk (the host checks Cin*plane*4 < 2^31)
-      if constexpr (WB) n = pb_n;                                                             // (block form: this wave's patch has its own image)
+      if constexpr (WB || WFL) n = pb_n;                                                      // (block form: this wave's patch has its own image; flat form: the item's first image)
       const ptrdiff_t img_off = ((ptrdiff_t)n * a.Cin * plane - bias) * AB;                  // bytes
       char* img = const_cast<char*>(reinterpret_cast<const char*>(a.in)) + img_off;
       const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(img, 0, 0x7FFFFFFF, 0x00020000);
@@ -716,7 +768,17 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   int w2_p = 0;                                        // (cycle stamps only) running chunk number
   w2f2 w2d[4][2];
   float w2u[4][WNT][4], w2va[4], w2vb[4];
-  const int w2_aoff = WB ? k * PS + wave * (IH * RS) + (2 * (m >> 2)) * RS + 2 * (m & 3) : k * PS + (2 * (wave / WHALVES)) * RS + 32 * (wave % WHALVES) + 2 * m;
+  // flat form: the lane's patch offset depends on the item (tile -> band row, column): w2_aoff = the current item's, w2_aoff_pf = the one the cross-chunk prefetch of
+  // the LAST chunk of an item uses (the next item's); every other form: one constant
+  auto wf_aoff = [&](int grp) {
+    const int t0 = grp * 64, n0 = t0 / wf_T, l0 = t0 - n0 * wf_T, ty0 = l0 / (G::TW / 2);
+    const int t = min(t0 + 16 * wave + m, wf_total - 1);
+    const int n = t / wf_T, l = t - n * wf_T, ty = l / (G::TW / 2), tx = l - ty * (G::TW / 2);
+    const int top = (n == n0) ? 2 * (ty - ty0) : (a.Hin - 2 * ty0 + 2) + 2 * ty;      // band row of the patch's first row (image row 2 ty - 1)
+    return k * PS + top * RS + 2 * tx;
+  };
+  int w2_aoff = WB ? k * PS + wave * (IH * RS) + (2 * (m >> 2)) * RS + 2 * (m & 3) : k * PS + (2 * (wave / WHALVES)) * RS + 32 * (wave % WHALVES) + 2 * m;
+  int w2_aoff_pf = w2_aoff;
   auto w2_ldrow = [&](const float* pa, int r) __attribute__((always_inline)) {
     w2d[r][0] = *reinterpret_cast<const w2f2*>(pa + r * RS);
     w2d[r][1] = *reinterpret_cast<const w2f2*>(pa + r * RS + 2);
@@ -733,15 +795,16 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     const w2f2 w = ta - tb;
     v[0] = w.x; v[3] = w.y; v[1] = ta.y + tb.x; v[2] = tb.x - ta.y;
   };
-  auto w2_pre_a = [&](const float* buf, int cg) __attribute__((always_inline)) {
-    const float* pa = buf + w2_aoff + cg * 4 * PS;
+  auto w2_pre_a = [&](const float* buf, int cg, int aoff) __attribute__((always_inline)) {
+    const float* pa = buf + aoff + cg * 4 * PS;
     w2_ldrow(pa, 0); w2_ldrow(pa, 2); w2_ldu(buf + CK * PS + lane + cg * 64, 0);
   };
-  auto w2_pre_b = [&](const float* buf, int cg) __attribute__((always_inline)) {
-    w2_ldrow(buf + w2_aoff + cg * 4 * PS, 1); w2_ldu(buf + CK * PS + lane + cg * 64, 1);
+  auto w2_pre_b = [&](const float* buf, int cg, int aoff) __attribute__((always_inline)) {
+    w2_ldrow(buf + aoff + cg * 4 * PS, 1); w2_ldu(buf + CK * PS + lane + cg * 64, 1);
     w2_vrow(w2d[0][0] - w2d[2][0], w2d[0][1] - w2d[2][1], w2va);
   };
-  auto w2_cg = [&](const float* buf, int cg, auto zero_tag, const float* nbuf, int ncg, auto barrier_tag) __attribute__((always_inline)) {
+  // aoff_n: the patch offset of the NEXT group's operands (the same item's, or - behind the early barrier of an item's last chunk, flat form - the next item's)
+  auto w2_cg = [&](const float* buf, int cg, auto zero_tag, const float* nbuf, int ncg, auto barrier_tag, int aoff_n) __attribute__((always_inline)) {
     constexpr bool ZERO = decltype(zero_tag)::value, BAR = decltype(barrier_tag)::value;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (WIN) {
@@ -771,11 +834,11 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
         if (w2_tr && w2_p < 16) a.trace[w2_p * 4 + 2] = clock64();
         __builtin_amdgcn_sched_barrier(0);
       }
-      w2_pre_a(nbuf, ncg);
+      w2_pre_a(nbuf, ncg, aoff_n);
       __builtin_amdgcn_sched_barrier(0);
       mm(2, w2va); w2_vrow(w2d[1][0] - w2d[3][0], w2d[1][1] - w2d[3][1], w2vb);
       __builtin_amdgcn_sched_barrier(0);
-      w2_ldrow(nbuf + w2_aoff + ncg * 4 * PS, 1); w2_ldu(nbuf + CK * PS + lane + ncg * 64, 1);
+      w2_ldrow(nbuf + aoff_n + ncg * 4 * PS, 1); w2_ldu(nbuf + CK * PS + lane + ncg * 64, 1);
       __builtin_amdgcn_sched_barrier(0);
       mm(3, w2vb); w2_vrow(w2d[0][0] - w2d[2][0], w2d[0][1] - w2d[2][1], w2va);
       __builtin_amdgcn_sched_barrier(0);
@@ -788,8 +851,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     static_assert(!WIN || CK == 8, "two channel groups per chunk");
     w2_p = p;
     if (w2_tr && p < 16) a.trace[p * 4 + 0] = clock64();
-    w2_cg(buf, 0, first_tag, buf, 1, std::false_type{});
-    w2_cg(buf, 1, std::false_type{}, nbuf, 0, std::true_type{});
+    w2_cg(buf, 0, first_tag, buf, 1, std::false_type{}, w2_aoff);
+    w2_cg(buf, 1, std::false_type{}, nbuf, 0, std::true_type{}, w2_aoff_pf);
     if (w2_tr && p < 16) a.trace[p * 4 + 3] = clock64();
   };
 
@@ -1243,6 +1306,83 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     }
   };
 
+  // ---- flat form: the lane holds four CONSECUTIVE tiles of the batch's tile list (64 grp + 16 wave + 4 k + r, r = 0..3: o[row][2 r], o[row][2 r + 1]) for channel co0 + m -
+  // each its own (image, tile row, tile column): 8-byte loads / stores tile by tile.  Same epilogue arithmetic as epilogue_w; the statistics / activation-backward sums
+  // group the lane's values differently (per tile list, not per image row): the tables agree with the tiled form's to summation order, `out` bit for bit.
+  int wf_po[4];                                         // element offset of (image, channel 0, row 2 ty, column 2 tx) of the lane's four tiles; -1: beyond the list
+  auto wf_set = [&](int grp) {
+    if constexpr (WFL) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = grp * 64 + 16 * wave + 4 * k + r;
+        const int n = t / wf_T, l = t - n * wf_T, ty = l / (G::TW / 2), tx = l - ty * (G::TW / 2);
+        wf_po[r] = (t < wf_total) ? (n * a.Cout * a.Hout + 2 * ty) * a.Wout + 2 * tx : -1;      // (the host checks N * Cout * H * W < 2^31)
+      }
+    }
+  };
+  auto epilogue_wf = [&](int co0, int j, float (&o)[2][8], float& stn_next) __attribute__((always_inline)) {
+    if constexpr (WFL) {
+      const int co = co0 + m;
+      if (a_has_bias) {
+#pragma unroll
+        for (int row = 0; row < 2; ++row)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[row][e] += bias_v[j];
+      }
+      bool tv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tv[r] = wf_po[r] >= 0;
+      if (a_has_stats) {
+        int cnt_i = 0; float sm = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (tv[r]) { cnt_i += 4; sm += (o[0][2 * r] + o[0][2 * r + 1]) + (o[1][2 * r] + o[1][2 * r + 1]); }
+        if (cnt_i > 0) {
+          const float cnt = (float)cnt_i;
+          const float rc = (cnt_i == 16) ? 0.0625f : __builtin_amdgcn_rcpf(cnt);
+          const float mean = sm * rc;
+          float qq = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (tv[r]) {
+              const float d0 = o[0][2 * r] - mean, d1 = o[0][2 * r + 1] - mean, d2 = o[1][2 * r] - mean, d3 = o[1][2 * r + 1] - mean;
+              qq += __builtin_fmaf(d1, d1, d0 * d0) + __builtin_fmaf(d3, d3, d2 * d2);
+            }
+          const float nt_ = st_n + cnt;
+          const float wgt = cnt * __builtin_amdgcn_rcpf(nt_);
+          const float dd = mean - st_mean[j];
+          st_mean[j] += dd * wgt;
+          st_m2[j] += qq + dd * dd * st_n * wgt;
+          stn_next = nt_;
+        }
+      }
+      if (co >= a.Cout) return;
+      const int cpl = co * a.Hout * a.Wout;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (!tv[r]) continue;
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+          const size_t off = (size_t)(wf_po[r] + cpl + row * a.Wout);
+          float2 v = make_float2(o[row][2 * r], o[row][2 * r + 1]);
+          if (a_epi == 3) {
+            const float2 uu = IO::ld2(a.mk_u, off);
+            v.x *= ((mk_sc[j] * uu.x + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+            v.y *= ((mk_sc[j] * uu.y + mk_sh[j] > 0.f) ? 1.f : a.mk_slope);
+            s1 += v.x + v.y;
+            s2 += __builtin_fmaf(v.y, uu.y - mk_mu[j], v.x * (uu.x - mk_mu[j]));
+          } else if (a_epi == 1) {
+            const float2 pv = IO::ld2(a.out, off);
+            v.x += pv.x; v.y += pv.y;
+          }
+          if (!(a_dbg & 4)) IO::st2(a.out, off, v);
+        }
+      }
+      if (a_epi == 3) { st_mean[j] += s1; st_m2[j] += s2; }
+    }
+  };
+
   // ---- interior items (every pixel, row and channel of the tile exists; 4-row tiles): no masks, and buffer addressing - resource base = image n,
   // scalar offset = (channel block, row, tile column), vector offset = the lane's hoisted (channel m, pixel group k) offset: the 64-bit address arithmetic
   // of the generic epilogue (~15 vector instructions per row) and its per-quad selects are gone.  Same arithmetic, same order: bit-identical results.
@@ -1402,7 +1542,8 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   // Item loop with the first K-chunk peeled (its MFMAs start from a zero C operand).  With AF the guarded MFMA loop is not instantiated, so the
   // accumulators keep one register assignment across the whole loop (no copies where the variants used to join).
   constexpr bool W2 = WIN && NT == 2;
-  if constexpr (W2) { w2_pre_a(smem, 0); w2_pre_b(smem, 0); }      // the first group's operands of chunk 0
+  if constexpr (WFL) { w2_aoff = wf_aoff(tile); w2_aoff_pf = w2_aoff; }
+  if constexpr (W2) { w2_pre_a(smem, 0, w2_aoff); w2_pre_b(smem, 0, w2_aoff); }      // the first group's operands of chunk 0
   {
     int p = 0;
     auto mfma_chunk = [&](int ch, auto first_tag) __attribute__((always_inline)) {
@@ -1442,12 +1583,21 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
       // chunk - the accumulator set-up of an item waits for vmcnt(0) (the previous item's stores still hold their data registers), and a prefetch issued in front of
       // that wait is simply waited for: its HBM latency was exposed once per item until round 4 (found in the ISA; the remaining chunks now cover it)
       if (UPRE && !WIN && a_epi == 3) pre_u();
+      // flat form: the cross-chunk prefetch inside an item's LAST chunk fetches the NEXT item's first operands - at that item's patch offsets
+      auto wf_next = [&]() __attribute__((always_inline)) {
+        if constexpr (WFL) {
+          if (it + 1 < my_items) { int nn, nt, ncb_; decode(item + (int)gridDim.x, nn, nt, ncb_); w2_aoff_pf = wf_aoff(nt); }
+          else w2_aoff_pf = w2_aoff;
+        }
+      };
+      if constexpr (WFL) { wf_set(tile); if (nchunks == 1) wf_next(); }
       mfma_chunk(0, std::true_type{});
-      if (WIN && a_epi == 3) pre_u();
+      if (WIN && !WFL && a_epi == 3) pre_u();
       for (int ch = 1; ch < nchunks; ++ch) {
         if constexpr (!W2) lds_barrier();              // (two-block Winograd form: the chunk barrier sits inside the previous chunk - w2_cg)
         if (!W2 && tr && p < 16) a.trace[p * 4 + 3] = clock64();
         ++p;
+        if constexpr (WFL) { if (ch == nchunks - 1) wf_next(); }
         mfma_chunk(ch, std::false_type{});
       }
       bool done = false;
@@ -1460,9 +1610,11 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           float o[2][8];
           wino_out(j, o);
           __builtin_amdgcn_sched_barrier(0);
-          if (wino_interior(tile, co0 + 16 * j)) epilogue_w(n, tile, co0 + 16 * j, j, o, stn_next, std::true_type{}); else epilogue_w(n, tile, co0 + 16 * j, j, o, stn_next, std::false_type{});
+          if constexpr (WFL) epilogue_wf(co0 + 16 * j, j, o, stn_next);
+          else if (wino_interior(tile, co0 + 16 * j)) epilogue_w(n, tile, co0 + 16 * j, j, o, stn_next, std::true_type{}); else epilogue_w(n, tile, co0 + 16 * j, j, o, stn_next, std::false_type{});
         }
         st_n = stn_next;
+        if constexpr (WFL) w2_aoff = w2_aoff_pf;
         done = true;
       }
       if (!done) epilogue(n, tile, co0);
@@ -1494,18 +1646,21 @@ int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
                                       typename std::conditional<std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_bf16w>::value, WideGeoW<(NT <= 2 ? NT : 1), PRO, 64>,
                                       typename std::conditional<std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w32>::value, WideGeoW<(NT <= 2 ? NT : 1), PRO, 32>,
                                       typename std::conditional<std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value, WideGeoWB<(NT <= 2 ? NT : 1), PRO>,
-                                                                WideGeo<NT, PRO, R>>::type>::type>::type>::type;
+                                      typename std::conditional<std::is_same<AT, ms_f32wf>::value, WideGeoWF<(NT <= 2 ? NT : 1), PRO>,
+                                                                WideGeo<NT, PRO, R>>::type>::type>::type>::type>::type;
   const size_t cin_tab = (PRO != 0) ? (size_t)cdiv(a.cin_pad, G::CK) * G::CK : 0;              // coefficient table: one float4 per input channel of the padded chunks
   const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab) + ((std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value ||
-                                                                                      std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value) ? NT * 16 * 1024 : 0);      // Winograd mode: + the mask tensor's landing zone (4 KB per MFMA wave and channel block)
+                                                                                      std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value) ? NT * 16 * 1024 : 0);      // (flat form: no landing zone - its mask values are read tile by tile in the epilogue)      // Winograd mode: + the mask tensor's landing zone (4 KB per MFMA wave and channel block)
   if (lds_bytes > 160 * 1024) { set_error("ms_conv2d: %d input channels exceed the LDS coefficient table", a.Cin); return MS_ERR_INVALID; }
   static std::once_flag attr_once;                     // one flag per instantiation; the attribute itself is immutable afterwards
   std::call_once(attr_once, []() { (void)hipFuncSetAttribute((const void*)conv_wide_kernel<NT, PRO, R, AF, AT, FX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); });
   constexpr bool kWB = std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value;
   a.tiles_x = cdiv(a.Wout, G::TW); a.tiles_y = cdiv(a.Hout, G::TH);
   if (kWB) { a.tiles_x = cdiv(a.N * a.tiles_x * a.tiles_y, 4); a.tiles_y = 1; }      // block form: groups of four blocks of the flattened (image, block row, block column) list
+  constexpr bool kWF = std::is_same<AT, ms_f32wf>::value;
+  if (kWF) { a.tiles_x = cdiv(a.N * (a.Hout / 2) * (a.Wout / 2), 64); a.tiles_y = 1; }      // flat form: groups of 64 tiles of the batch's tile list
   a.ncb = cdiv(a.Cout, 16 * NT);
-  const long nitems = (long)(kWB ? 1 : a.N) * a.tiles_x * a.tiles_y * a.ncb;
+  const long nitems = (long)((kWB || kWF) ? 1 : a.N) * a.tiles_x * a.tiles_y * a.ncb;
   int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / (lds_bytes + 256))));      // workgroups per CU of the persistent grid
   per_cu = std::max(1, std::min(per_cu, conv_resident_per_cu((const void*)conv_wide_kernel<NT, PRO, R, AF, AT, FX>, lds_bytes)));      // (co-residency of the whole grid: ms_conv_kernel.h)
   long nblocks = std::min<long>(nitems, (long)num_cus() * per_cu);
@@ -1523,7 +1678,7 @@ inline int conv_wide_fx(const ConvArgs& a) {
 // no bias, no statistics; plain / accumulate / activation-backward / 2x2-pooled store.
 template <int NT, int PRO, typename WT>
 int launch_wino_fx(const ConvArgs& a, hipStream_t st) {
-  constexpr bool F32 = std::is_same<WT, ms_f32w>::value || std::is_same<WT, ms_f32w32>::value || std::is_same<WT, ms_f32wb>::value;
+  constexpr bool F32 = std::is_same<WT, ms_f32w>::value || std::is_same<WT, ms_f32w32>::value || std::is_same<WT, ms_f32wb>::value || std::is_same<WT, ms_f32wf>::value;
   if constexpr (F32) {
     const int fx = conv_wide_fx(a);
     constexpr int FWD = 0 | kFxStats | kFxBias | kFxWu;

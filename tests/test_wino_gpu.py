@@ -168,6 +168,58 @@ def test_block_form_same_bits_as_the_tiled_form(dev, N, Cin, Cout, H, W, bf16):
         assert torch.equal(ops.conv2d(x, wpu, b, Cout, 3, 1, fetch=BL | ops.FETCH_WINO_U), o1)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H", [(16, 64, 64, 20), (3, 32, 48, 20), (1, 64, 64, 20), (2, 16, 32, 14), (5, 24, 40, 18), (16, 16, 96, 20), (7, 8, 33, 26)])
+def test_flat_form_same_bits_as_the_tiled_form(dev, N, Cin, Cout, H):
+    """Round 6: the FLAT form of the Winograd kernel (ms_f32wf: the 2x2-output tiles of a batch of 20-pixel-wide images as ONE list, 64 consecutive tiles per work item, the band
+    of image rows they touch staged per chunk - of one image or across an image boundary; ms_conv2d_form 7) against the 8-row x 32-pixel tiles it replaces (option
+    "conv.wino_flat" = 0): per output element the same accumulation order, so every stored tensor is bit-identical - all three prologues, the plain / accumulate /
+    activation-backward epilogues, statistics; tile lists that end inside a group, groups that span two images, a batch of one (no next image), channel tails, heights from
+    14 rows; the BatchNorm tables agree to rounding (another grouping of the per-lane sums)."""
+    from maxstyle_amd import ops
+    from maxstyle_amd.options import library_option
+    W = 20
+    U = ops.FETCH_WINOGRAD | ops.FETCH_WINO_U
+    x = _rand((N, Cin, H, W), 1).to(dev); x2 = _rand((N, Cin, H, W), 2).to(dev); w = _rand((Cout, Cin, 3, 3), 3, 0.1); b = _rand((Cout,), 4).to(dev)
+    cfd = _rand((Cin, 4), 5).to(dev)
+    pa, pb, pc = ops.coef_ptrs(cfd)[:3]
+    wp, has = ops.with_wino_appendix(ops.pack_conv_weight(w.to(dev)), Cin, Cout)
+    assert has
+    base = _rand((N, Cout, H, W), 6).to(dev)
+    u = (_rand((N, Cout, H, W), 24) + 0.3).to(dev)
+    coef4 = torch.stack([1 + 0.2 * _rand((Cout,), 26), 0.3 * _rand((Cout,), 27), 0.3 + 0.1 * _rand((Cout,), 28), 1 + 0.1 * _rand((Cout,), 29).abs()], 1).to(dev)
+    one, zero = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+
+    def run():
+        r = {}
+        st, parts = ops.conv_stats_buffer(N, Cout, H, W, dev)
+        r["fwd"] = ops.conv2d(x, wp, b, Cout, 3, 1, fetch=U, stats=st)
+        r["fwd.coef"] = ops.bn_finalize(st, parts, one, zero)
+        st1, _ = ops.conv_stats_buffer(N, Cout, H, W, dev)
+        r["pro1"] = ops.conv2d(x, wp, b, Cout, 3, 1, fetch=U, stats=st1, pro_mode=1, pro_a=pa, pro_b=pb, pro_cstride=4, slope=0.2)
+        r["pro1.coef"] = ops.bn_finalize(st1, parts, one, zero)
+        kw = dict(pro_mode=2, pro_a=pa, pro_b=pb, pro_c=pc, pro_cstride=4, in2=x2)
+        r["pro2"] = ops.conv2d(x, wp, None, Cout, 3, 1, fetch=U, **kw)
+        r["acc"] = ops.conv2d(x, wp, None, Cout, 3, 1, fetch=U, out=base.clone(), epi_mode=1, **kw)
+        r["acc0"] = ops.conv2d(x, wp, None, Cout, 3, 1, fetch=U, out=base.clone(), epi_mode=1)
+        g, t = ops.conv2d_actbwd(x, wp, Cout, 3, u, coef4, 0.2, fetch=U, **kw)
+        r["actbwd"] = g; r["actbwd.coef"] = ops.bn_bwd_coefs(t, 0, coef4, N * H * W)
+        torch.cuda.synchronize()
+        return r
+    with library_option("conv.wino_nt", 2):
+        assert ops.lib.ms_conv2d_form(N, Cin, H, W, Cout, 0, 0, U) == 7
+        flat = run()
+        with library_option("conv.wino_flat", 0):
+            assert ops.lib.ms_conv2d_form(N, Cin, H, W, Cout, 0, 0, U) == 3
+            tiled = run()
+    for k in ("fwd", "pro1", "pro2", "acc", "acc0", "actbwd"):
+        assert torch.equal(flat[k], tiled[k]), (k, float((flat[k] - tiled[k]).abs().max()))
+    for k, tol in (("fwd.coef", 2e-6), ("pro1.coef", 2e-6), ("actbwd.coef", 1e-5)):
+        assert float((flat[k] - tiled[k]).abs().max()) < tol * float(tiled[k].abs().max()), k
+    # and against fp64 (the form's own error: 1-5e-7 of the output range on random data, as the tiled form's)
+    ref = torch.nn.functional.conv2d(x.double().cpu(), w.double(), b.double().cpu(), padding=1)
+    assert float((flat["fwd"].double().cpu() - ref).abs().max()) < 2e-6 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 16, 16, 64, 64), (2, 64, 64, 64, 64), (1, 32, 48, 20, 192), (2, 64, 64, 32, 32), (1, 128, 64, 20, 40), (1, 8, 33, 10, 100), (1, 256, 256, 40, 40)])
 def test_winograd_appendix_same_bits(dev, N, Cin, Cout, H, W):
     """MS_FETCH_WINO_U: the transformed weights staged by LDS-DMA from the packed tensor's appendix (ms_wino_pack: the in-kernel expression, evaluated once per weight

@@ -51,7 +51,9 @@ run MS_OPTIONS=style.fused=0 $KNIFE $CHAOS2 $CHAOS4 -k "not single_read_kernel"
 run MS_OPTIONS=engine.xfin=0 -k "$XF"
 # bf16 matrix arithmetic and the three-way split exist in the wide kernel only; `nonoise` / `noisefixed`: free-running K = 3 cases whose bars are 3x the reference's own
 # noise - the first-generation kernels everywhere are another rounding of the same arithmetic and land at 4-5x (the same effect as experiments 17 / 18)
-run MS_OPTIONS=conv.wide=0 $CHAOS4 --ignore=tests/test_bf16m_gpu.py --ignore=tests/test_wino_gpu.py -k "not (pooled_epilogue_is_conv or pooled_data_gradient or bench_line_contract)" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[nonoise]" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[noisefixed]"
+# (the bf16 loop on the trained networks is a free-running K = 5 trajectory whose bars were measured on the default kernels: on the first-generation kernels everywhere it is another
+#  draw, over them since round 4 - profiles/r04_switch_matrix.txt, r05_switch_matrix.txt)
+run MS_OPTIONS=conv.wide=0 $CHAOS4 "--deselect=tests/test_bf16_conv_gpu.py::test_bf16_loop_on_trained_networks_vs_reference" --ignore=tests/test_bf16m_gpu.py --ignore=tests/test_wino_gpu.py -k "not (pooled_epilogue_is_conv or pooled_data_gradient or bench_line_contract)" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[nonoise]" "--deselect=tests/test_round3_gpu.py::test_drop_in_arguments_vs_reference_run[noisefixed]"
 # the narrow-rows second generation off: the first-generation kernel on rows of 12 / 14 / 16 pixels
 run MS_OPTIONS=conv.k3n=0 $KNIFE -k "not (narrow_rows or second_generation_is_taken or one_by_one_convs_on_14)"
 run MS_OPTIONS=conv.k1s=0 $KNIFE -k "not (streamed or streaming_1x1 or k1s)"
