@@ -56,7 +56,8 @@ MS_STABLE const char* ms_last_error(void);
  *                               16 pixels; the same bits in `out` as ms_conv2d on that layer) | 0: the vector-ALU form (another rounding)
  *   "conv.force_nt"    0        1 / 2 / 4: output-channel blocks of 16 per workgroup of the first-generation kernel (tuning)
  *   "style.fused"      1        0: ms_style_fwd never takes the single-read kernel (three-launch path)
- *   "conv.wino_flat"   1        0: no flattened-tile Winograd form on images of 20 x 20 pixels (the 8 x 32-pixel tiles instead: the same bits in `out`)
+ *   "conv.wino_flat"   1        0: no flattened-tile Winograd form on images of 20 / 24 / 28-pixel rows (the 8 x 32-pixel tiles instead: the same bits in `out`) | 1: where it
+ *                               saves a round of the persistent grid | 2: wherever legal
  *   "diag.conv_dbg"    0        timing-only ablation bits of the conv kernels - results are WRONG with any bit set
  * ms_set_option returns the previous value (>= 0) or MS_ERR_INVALID for an unknown name / a value out of range; ms_get_option the current value.  Setting an option
  * while launches of other threads are in flight is safe (relaxed atomics): such a launch takes one form or the other.  ms_option_count / ms_option_name enumerate. */

@@ -37,7 +37,7 @@ int num_cus() {
 struct OptRow { const char* name; int def, lo, hi; };
 static const OptRow kOpts[OPT_COUNT] = {
   {"conv.wide", 1, 0, 1}, {"conv.wino", 1, 0, 2}, {"conv.wino32", 1, 0, 1}, {"conv.wino_nt", 0, 0, 2}, {"conv.wino_block", 1, 0, 2}, {"conv.wide_rows", 0, 0, 8},
-  {"conv.k1s", 1, 0, 1}, {"conv.k1g", 1, 0, 1}, {"conv.s2g2", 1, 0, 1}, {"conv.k3n", 1, 0, 1}, {"conv.k9", 1, 0, 1}, {"conv.force_nt", 0, 0, 4}, {"style.fused", 1, 0, 1}, {"conv.wino_flat", 1, 0, 1}, {"diag.conv_dbg", 0, 0, 127},
+  {"conv.k1s", 1, 0, 1}, {"conv.k1g", 1, 0, 1}, {"conv.s2g2", 1, 0, 1}, {"conv.k3n", 1, 0, 1}, {"conv.k9", 1, 0, 1}, {"conv.force_nt", 0, 0, 4}, {"style.fused", 1, 0, 1}, {"conv.wino_flat", 1, 0, 2}, {"diag.conv_dbg", 0, 0, 127},
 };
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::once_flag g_opt_once;

@@ -41,7 +41,7 @@ enum Opt {
   OPT_CONV_K9,            // "conv.k9"          ms_conv3x3_small_cin at Cin = 1: 1: the nine taps as the K dimension of the MFMA (3 per 16 pixels, ms_conv2d's bits); 0: the vector-ALU form
   OPT_CONV_FORCE_NT,      // "conv.force_nt"    0: automatic; 1 / 2 / 4: output-channel blocks of 16 per workgroup (tuning: tools/tune_conv.py)
   OPT_STYLE_FUSED,        // "style.fused"      1: single-read MaxStyle kernel where its grid fits the chip; 0: three-launch path
-  OPT_CONV_WINO_FLAT,     // "conv.wino_flat"   1: the flattened-tile Winograd form on images of 20 x 20 pixels where eligible (ms_f32wf); 0: the 8 x 32-pixel tiles
+  OPT_CONV_WINO_FLAT,     // "conv.wino_flat"   1: the flattened-tile Winograd form on images of 20 / 24 / 28-pixel rows where it saves a round of the grid (ms_f32wf_t); 0: never; 2: wherever legal
   OPT_DIAG_CONV_DBG,      // "diag.conv_dbg"    timing-only ablation bits of the conv kernels (results are WRONG with any bit set): 1 no MFMA loop, 2 no global loads, 4 no stores, 8 no LDS stores, 16 no epilogue
   OPT_COUNT
 };
@@ -176,11 +176,14 @@ template <> struct ActIO<ms_f32wb> : ActIO<float> {};
 struct ms_bf16wb { uint16_t v; };
 template <> struct ActIO<ms_bf16wb> : ActIO<ms_bf16> {};
 
-// ms_f32wf (round 6): the Winograd form on FLATTENED TILES for images of 20 x 20 pixels (config 4's deepest levels: encoder_decoder.py:22-74, 650-653 at FCN_64 widths) - the
+// ms_f32wf_t<W> (round 6): the Winograd form on FLATTENED TILES for images of W = 20 / 24 / 28 pixels per row (config 4's deepest levels: encoder_decoder.py:22-74, 650-653 at FCN_64 widths) - the
 // 2x2-output tiles of the whole batch form one list (image, tile row, tile column); a work item = 64 consecutive tiles (16 per MFMA wave) and the band of image rows they touch
 // (of one image, or of the end of one and the start of the next): every MFMA row is a real tile (the 8-row x 32-pixel tile fills 52 % of its rows at 20 x 20)
-struct ms_f32wf { float v; };
-template <> struct ActIO<ms_f32wf> : ActIO<float> {};
+template <int W> struct ms_f32wf_t { float v; };      // W = pixels per image row: 20 (config 4's deepest levels), 24 / 28 (the deep levels of the reference's shipped 192 / 224-pixel workloads)
+template <int W> struct ActIO<ms_f32wf_t<W>> : ActIO<float> {};
+typedef ms_f32wf_t<20> ms_f32wf;
+template <typename T> struct ms_wf_width { static constexpr int value = 0; };
+template <int W> struct ms_wf_width<ms_f32wf_t<W>> { static constexpr int value = W; };
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -109,10 +109,12 @@ struct WideGeoWB {
 // boundary = 20 band rows of 22 floats (column 0 / 21 = the left / right halo: always outside the image, always zero); plane stride 480 == 32 (mod 64).
 // A lane's 4 x 4 patch starts at an even column (8-byte reads), its base offset is per lane and per item (tile -> band row, column); after the MFMAs a lane holds four
 // consecutive tiles of the list, stored tile by tile (8-byte stores).  Per output element the K loop is the tiled form's: the same bits in `out`.
-template <int NT_, int PRO>
+template <int NT_, int PRO, int W_ = 20>
 struct WideGeoWF {
-  static constexpr int W = 20, TXR = W / 2;
-  static constexpr int TW = W, TH = 4, CK = 8, IH = 20;
+  static constexpr int W = W_, TXR = W / 2;      // (W = 24 / 28: 64 tiles touch 7 / 6 tile rows at most - 18 / 16 band rows of 26 / 30 floats: the same 20-row, 480-float plane)
+  static_assert(W == 20 || W == 24 || W == 28, "flat form: rows of 20 / 24 / 28 pixels");
+  static constexpr int TW = W, TH = 4, CK = 8;
+  static constexpr int IH = 2 * ((64 + TXR - 1 + TXR - 1) / TXR) + 4;      // band rows: 64 consecutive tiles starting anywhere in a tile row touch ceil((64 + TXR - 1) / TXR) tile rows, + 2 halo rows, + 2 at an image boundary: 20 / 18 / 16
   static constexpr int RS = W + 2, PS = 480;
   static_assert(IH * RS <= PS && PS % 64 == 32, "plane stride");
   static constexpr int WS = 16;
@@ -149,14 +151,15 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
   constexpr bool BFM = std::is_same<AT, ms_bf16m>::value;         // bf16 matrix arithmetic (needs R == 1)
   constexpr bool BFL = BFM;                                       // the bf16 LDS layout (8-byte channel-quad entries)
   constexpr bool WB = std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value;        // Winograd form on independent 8x8-pixel blocks (WideGeoWB)
-  constexpr bool WFL = std::is_same<AT, ms_f32wf>::value;                                               // Winograd form on the flattened tile list of 20-pixel images (WideGeoWF)
+  constexpr int WFW = ms_wf_width<AT>::value;                                                          // (flat form: pixels per image row, else 0)
+  constexpr bool WFL = WFW != 0;                                                                        // Winograd form on the flattened tile list of 20 / 24 / 28-pixel images (WideGeoWF)
   static_assert(!WFL || NT == 2, "flat form: two channel blocks per lane");
   constexpr bool WIN = std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value || WB || WFL ||       // Winograd F(2x2, 3x3) (needs R == 1, NT <= 2, every chunk full)
                        std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value;      // ... on bf16 storage
   constexpr int WTW = (std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w32>::value) ? 32 : 64;
   constexpr int WHALVES = WTW / 32;                               // 32-pixel halves of a tile row = waves per tile row
   static_assert(!WIN || (R == 1 && NT <= 2 && AF), "Winograd mode: 4-row tiles, one or two channel blocks per lane, channel count a multiple of the chunk");
-  using G = typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WB, WideGeoWB<(WB ? NT : 1), PRO>, typename std::conditional<WFL, WideGeoWF<(WFL ? NT : 1), PRO>,
+  using G = typename std::conditional<BFM, WideGeoBF<NT, PRO>, typename std::conditional<WB, WideGeoWB<(WB ? NT : 1), PRO>, typename std::conditional<WFL, WideGeoWF<(WFL ? NT : 1), PRO, (WFL ? WFW : 20)>,
             typename std::conditional<WIN, WideGeoW<(WIN ? NT : 1), PRO, WTW>, WideGeo<NT, PRO, R>>::type>::type>::type>::type;
   using IO = ActIO<AT>;
   constexpr int AB = IO::kBytes;
@@ -371,8 +374,10 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
           }
         }
       }
+      // (flat form: the halo columns are never inside the image - NO loads, stated here and not left to dead-code elimination: the counted wait behind the weights'
+      //  LDS-DMA below - kDataLoads - counts the loads this function issues)
 #pragma unroll
-      for (int j = 0; j < NHI; ++j) {
+      for (int j = 0; j < (WFL ? 0 : NHI); ++j) {
         const int off = ((hm >> j) & 1u) ? (int)h_off[j] : origin;       // the halo columns of the first / last tile of a row are outside the image
         if constexpr (AB == 4) {
           rh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, off, soff, 0));
@@ -489,6 +494,7 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #pragma unroll
       for (int j = 0; j < NHI; ++j) {
         if (h_lds[j] < 0) continue;
+        if constexpr (WFL) { buf[h_lds[j] & 0xFFFFF] = 0.f; continue; }      // flat form: columns 0 / W + 1 of the band are the zero padding, every chunk
         float v = rh[j];
         if constexpr (PRO == 1) v = leaky(hca[j] * v + hcb[j], a.slope);
         if constexpr (PRO == 2) v = hca[j] * v + (hcb[j] * rh2[j] + hcc[j]);
@@ -557,7 +563,11 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
 #else
     constexpr bool tr = false;
 #endif
-    constexpr int kDataLoads = (PRO == 2 ? 2 : 1) * (NQI + NHI);      // vector-memory loads load_chunk issues for one chunk's activations
+    // vector-memory loads load_chunk issues for one chunk's activations - EXACTLY: the counted wait behind the weights' LDS-DMA relies on it.  Round 6, found as a
+    // run-to-run difference of ~1e-5 in one work item of a config-4 call: in the flat form the halo loads are dead (their mask is the constant 0), the compiler removed
+    // them, and vmcnt(NQI + NHI) left the last NHI pieces of the DMA unwaited - staged weights read before they had landed, rarely, on a cold first call
+    // (tools/check_dma_wait.py checks the built ISA: loads issued behind the DMA >= the count waited for)
+    constexpr int kDataLoads = (PRO == 2 ? 2 : 1) * (NQI + (WFL ? 0 : NHI));
     for (int p = 0; p < T; ++p) {
       if (tr && p < 16) a.trace[128 + p * 4 + 0] = clock64();
       if (tr && p < 16) { a.trace[256 + p * 8 + 0] = clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.trace[256 + p * 8 + 1] = clock64(); }      // (stamps: wait for the chunk's loads, separated from the arithmetic)
@@ -1646,7 +1656,7 @@ int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
                                       typename std::conditional<std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_bf16w>::value, WideGeoW<(NT <= 2 ? NT : 1), PRO, 64>,
                                       typename std::conditional<std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w32>::value, WideGeoW<(NT <= 2 ? NT : 1), PRO, 32>,
                                       typename std::conditional<std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value, WideGeoWB<(NT <= 2 ? NT : 1), PRO>,
-                                      typename std::conditional<std::is_same<AT, ms_f32wf>::value, WideGeoWF<(NT <= 2 ? NT : 1), PRO>,
+                                      typename std::conditional<(ms_wf_width<AT>::value != 0), WideGeoWF<(NT <= 2 ? NT : 1), PRO, (ms_wf_width<AT>::value != 0 ? ms_wf_width<AT>::value : 20)>,
                                                                 WideGeo<NT, PRO, R>>::type>::type>::type>::type>::type;
   const size_t cin_tab = (PRO != 0) ? (size_t)cdiv(a.cin_pad, G::CK) * G::CK : 0;              // coefficient table: one float4 per input channel of the padded chunks
   const size_t lds_bytes = sizeof(float) * (2 * (size_t)G::BUF + 4 * cin_tab) + ((std::is_same<AT, ms_f32w>::value || std::is_same<AT, ms_f32w32>::value || std::is_same<AT, ms_bf16w>::value || std::is_same<AT, ms_bf16w32>::value ||
@@ -1657,7 +1667,7 @@ int launch_conv_wide_t(ConvArgs a, hipStream_t st) {
   constexpr bool kWB = std::is_same<AT, ms_f32wb>::value || std::is_same<AT, ms_bf16wb>::value;
   a.tiles_x = cdiv(a.Wout, G::TW); a.tiles_y = cdiv(a.Hout, G::TH);
   if (kWB) { a.tiles_x = cdiv(a.N * a.tiles_x * a.tiles_y, 4); a.tiles_y = 1; }      // block form: groups of four blocks of the flattened (image, block row, block column) list
-  constexpr bool kWF = std::is_same<AT, ms_f32wf>::value;
+  constexpr bool kWF = ms_wf_width<AT>::value != 0;
   if (kWF) { a.tiles_x = cdiv(a.N * (a.Hout / 2) * (a.Wout / 2), 64); a.tiles_y = 1; }      // flat form: groups of 64 tiles of the batch's tile list
   a.ncb = cdiv(a.Cout, 16 * NT);
   const long nitems = (long)((kWB || kWF) ? 1 : a.N) * a.tiles_x * a.tiles_y * a.ncb;
@@ -1678,7 +1688,7 @@ inline int conv_wide_fx(const ConvArgs& a) {
 // no bias, no statistics; plain / accumulate / activation-backward / 2x2-pooled store.
 template <int NT, int PRO, typename WT>
 int launch_wino_fx(const ConvArgs& a, hipStream_t st) {
-  constexpr bool F32 = std::is_same<WT, ms_f32w>::value || std::is_same<WT, ms_f32w32>::value || std::is_same<WT, ms_f32wb>::value || std::is_same<WT, ms_f32wf>::value;
+  constexpr bool F32 = std::is_same<WT, ms_f32w>::value || std::is_same<WT, ms_f32w32>::value || std::is_same<WT, ms_f32wb>::value || ms_wf_width<WT>::value != 0;
   if constexpr (F32) {
     const int fx = conv_wide_fx(a);
     constexpr int FWD = 0 | kFxStats | kFxBias | kFxWu;

@@ -53,7 +53,7 @@ def main():
         else:
             N, Cin, Hs, Ws, Cout, ks, stride, fetch, pm = a[4:13]
             epi, stats = 3, False
-        if not (ks == 3 and stride == 1 and (fetch & 0x100) and (fetch & 0xFF) == 0 and Cout > 16 and Ws >= 20 and Cin % 8 == 0):
+        if not (ks == 3 and stride == 1 and (fetch & 0x100) and (fetch & 0xFF) == 0 and Cout > 16 and Ws >= 20 and Cin % 8 == 0):      # (Cout > 16: the one-block-only layers have nothing to choose)
             continue
         key = (name, N, Cin, Hs, Ws, Cout, pm, epi, stats)
         seen.setdefault(key, [0, a, fi])[0] += 1
@@ -94,12 +94,17 @@ def main():
         ts.append(time_call(name, tuple(a1)))        # the block form, one channel block
         _O.set_library_option("conv.wino_block", 1)
         _O.set_library_option("conv.wino_nt", 0)         # 0 = the heuristic
+        _O.set_library_option("conv.wino_flat", 2)       # (round 6) the flat form wherever legal ...
+        flat = time_call(name, a)
+        _O.set_library_option("conv.wino_flat", 0)       # ... never ...
+        noflat = time_call(name, a)
+        _O.set_library_option("conv.wino_flat", 1)       # ... by its rounds rule (the default)
         auto = time_call(name, a)
         for i, t in enumerate(ts + [auto]):
             tot[i] += cnt * t
         # executed matrix work: 16 MFMAs of 16x16x4 per (2x2 tile group of 16, 4 channels, 16 output channels): 16/36 of the direct form's flops
         ex = 2.0 * N * Hs * Ws * Cout * Cin * 9 * 16 / 36 / 157.3e12 * 1e6
-        print(f"{name[3:]:12s} {str((N, Cin, Hs, Ws, Cout)):>24s} {pm:2d} {epi:3d} {int(stats):2d} {cnt:3d} {ts[0]:8.1f} {ts[1]:8.1f} {ts[2]:8.1f} {ts[3]:8.1f} {ts[4]:8.1f} {ts[5]:8.1f}     {ex / ts[0]:5.2f} -> {ex / min(ts):5.2f}    {auto:8.1f}")
+        print(f"{name[3:]:12s} {str((N, Cin, Hs, Ws, Cout)):>24s} {pm:2d} {epi:3d} {int(stats):2d} {cnt:3d} {ts[0]:8.1f} {ts[1]:8.1f} {ts[2]:8.1f} {ts[3]:8.1f} {ts[4]:8.1f} {ts[5]:8.1f}     {ex / ts[0]:5.2f} -> {ex / min(ts):5.2f}    {auto:8.1f}   flat forced / off {flat:7.1f} / {noflat:7.1f}")
     print(f"per step: nt1 {tot[0]:.0f} us, nt1+U {tot[1]:.0f} us, nt2 {tot[2]:.0f} us, nt2+U {tot[3]:.0f} us, blocks {tot[4]:.0f} us, one-block blocks {tot[5]:.0f} us; the dispatch's own choice {tot[6]:.0f} us")
 
 
