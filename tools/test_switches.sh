@@ -60,6 +60,6 @@ run MS_OPTIONS=conv.k1s=0 $KNIFE -k "not (streamed or streaming_1x1 or k1s)"
 # ---------------------------------------------------------------------------------------------------------------- TIER B: teacher-forced tests + kink census
 for sw in engine.fuse_act_bwd=0 engine.train_graph=1 engine.xfin_pro=0 engine.fuse_tail=0 engine.fuse_head_bwd=0 engine.lazy_seg_tail=0 engine.ride=0 engine.pool_fuse=0 engine.pool_epi=0 \
           engine.lazy_style_head=0 engine.small_cin=0 conv.k9=0 conv.k1g=0 conv.s2g2=0 engine.train_xfin=1 engine.fuse_fin_act=0 engine.subpix=0 engine.small_cout=0 engine.lazy_inc=0 \
-          engine.fuse_skip=0 engine.wino_appendix=0 conv.wino_nt=1 conv.wino_block=0 conv.wino32=0; do
+          engine.fuse_skip=0 engine.wino_appendix=0 conv.wino_nt=1 conv.wino_block=0 conv.wino32=0 conv.wino_flat=0; do
   runb MS_OPTIONS=$sw
 done
