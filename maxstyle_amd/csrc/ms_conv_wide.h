@@ -232,13 +232,18 @@ __global__ __launch_bounds__(512, (NT == 1 ? 4 : 2)) void conv_wide_kernel(const
     auto dma_u = [&](float* buf, int cbi, int chunk_i) __attribute__((always_inline)) {
       if constexpr (WIN) {
         const ms_i32x4 ru = ms_dma_rsrc(a.wu);
+        // the appendix holds ceil(Cout / 16) blocks: with two blocks per item and an odd count the last item's second block does not exist.  Its lanes (bit 5 of the
+        // lane index) take an offset beyond the resource's range - the pieces read as zeros (the buffer range check looks at the VECTOR offset only) instead of whatever
+        // lies behind the weights (round 6: a rare memory fault when the buffer ended its memory segment; Cout = 33 / 40 / 48 in the tests)
+        const bool odd_tail = (NT == 2) && (2 * cbi + 1 >= ((a.Cout + 15) >> 4));
+        const int u_voff = (odd_tail && (tid & 32)) ? (int)0x80000000 : wu_voff;
         const int sw = __builtin_amdgcn_readfirstlane(tid >> 6);
         const unsigned dst = ms_lds_addr(buf + CK * PS);
 #pragma unroll
         for (int q = 0; q < 2 * NT; ++q) {
           const int piece = q * 4 + sw;                 // 256 floats of the weight region each
           const int so = (NT == 2) ? 4 * ((cbi * 2 * nchunks + chunk_i) * 2048 + piece * 128) : 4 * ((cbi * nchunks + chunk_i) * 2048 + piece * 256);
-          ms_lds_dma16(ru, dst + 1024u * (unsigned)piece, wu_voff, __builtin_amdgcn_readfirstlane(so));
+          ms_lds_dma16(ru, dst + 1024u * (unsigned)piece, u_voff, __builtin_amdgcn_readfirstlane(so));
         }
       }
     };

@@ -32,13 +32,21 @@ run() {   # run "<env assignments>" <pytest deselect arguments...>      (whole s
   local sw=$1; shift
   if [ -n "$ONLY" ] && ! echo "${sw:-default}" | grep -qE "$ONLY"; then return; fi
   echo -n "A ${sw:-default}: "
-  env $sw timeout 1200 python -m pytest tests -q -m gpu --maxfail=8 -rf ${MS_MATRIX_EXTRA:-} "$@" 2>&1 | grep -E "^FAILED|passed|failed" | cut -c1-220
+  local log; log=$(mktemp)
+  env $sw timeout 1200 python -m pytest tests -q -m gpu --maxfail=8 -rf ${MS_MATRIX_EXTRA:-} "$@" > "$log" 2>&1; local rc=$?
+  summarise "$log" $rc
+}
+summarise() {   # the FAILED lines and pytest's summary; a run that ended without one (killed, crashed, timed out) says so with its exit code and last lines
+  if grep -qE "passed|failed" "$1"; then grep -E "^FAILED|passed|failed" "$1" | cut -c1-220; else echo "NO SUMMARY (exit code $2):"; tail -5 "$1" | cut -c1-220; fi
+  rm -f "$1"
 }
 runb() {  # runb "<env assignments>" <pytest arguments...>             (teacher-forced tests + kink census)
   local sw=$1; shift
   if [ -n "$ONLY" ] && ! echo "${sw:-default}" | grep -qE "$ONLY"; then return; fi
   echo -n "B ${sw}: "
-  env $sw timeout 900 python -m pytest tests/test_round6_gpu.py tests/test_round5_gpu.py -q -m gpu --maxfail=8 -rf -k "teacher_forced or kink" "$@" 2>&1 | grep -E "^FAILED|passed|failed" | cut -c1-220
+  local log; log=$(mktemp)
+  env $sw timeout 900 python -m pytest tests/test_round6_gpu.py tests/test_round5_gpu.py -q -m gpu --maxfail=8 -rf -k "teacher_forced or kink" "$@" > "$log" 2>&1; local rc=$?
+  summarise "$log" $rc
 }
 # ---------------------------------------------------------------------------------------------------------------- TIER A: whole suite
 run ""
