@@ -169,13 +169,15 @@ def test_block_form_same_bits_as_the_tiled_form(dev, N, Cin, Cout, H, W, bf16):
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W", [(16, 64, 64, 20, 20), (3, 32, 48, 20, 20), (1, 64, 64, 20, 20), (2, 16, 32, 14, 20), (5, 24, 40, 18, 20), (16, 16, 96, 20, 20), (7, 8, 33, 26, 20),
-                                            (20, 32, 64, 24, 24), (3, 16, 48, 12, 24), (1, 64, 32, 24, 24), (20, 32, 64, 28, 28), (2, 24, 40, 10, 28), (5, 16, 33, 28, 28)])
+                                            (20, 32, 64, 24, 24), (3, 16, 48, 12, 24), (1, 64, 32, 24, 24), (20, 32, 64, 28, 28), (2, 24, 40, 10, 28), (5, 16, 33, 28, 28),
+                                            (64, 16, 256, 20, 20), (48, 8, 256, 28, 28)])
 def test_flat_form_same_bits_as_the_tiled_form(dev, N, Cin, Cout, H, W):
     """Round 6: the FLAT form of the Winograd kernel (ms_f32wf_t<W>: the 2x2-output tiles of a batch of 20 / 24 / 28-pixel-wide images as ONE list, 64 consecutive tiles per work item, the band
     of image rows they touch staged per chunk - of one image or across an image boundary; ms_conv2d_form 7) against the 8-row x 32-pixel tiles it replaces (option
     "conv.wino_flat" = 0): per output element the same accumulation order, so every stored tensor is bit-identical - all three prologues, the plain / accumulate /
-    activation-backward epilogues, statistics; tile lists that end inside a group, groups that span two images, a batch of one (no next image), channel tails, the smallest
-    legal heights (64 tiles per image); the BatchNorm tables agree to rounding (another grouping of the per-lane sums)."""
+    activation-backward epilogues, statistics; tile lists that end inside a group, groups that span two images, a batch of one (no next image), channel tails (an odd number of 16-channel blocks: the
+    second block of the last item does not exist), the smallest legal heights (64 tiles per image), launches of three to five rounds of the persistent grid (every workgroup runs several items:
+    the cross-item operand prefetch); the BatchNorm tables agree to rounding (another grouping of the per-lane sums)."""
     from maxstyle_amd import ops
     from maxstyle_amd.options import library_option
     U = ops.FETCH_WINOGRAD | ops.FETCH_WINO_U
