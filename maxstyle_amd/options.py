@@ -95,7 +95,7 @@ _parse_env(os.environ.get("MS_OPTIONS", ""))
 
 # The 65 MS_* switches of rounds 1-4 are gone (round 5): a leftover in the environment would now be ignored without a word - MS_ACT_DTYPE=bf16 would run an fp32 loop,
 # MS_TRAIN_WINOGRAD=0 a Winograd training pass.  Say so once at import.
-_KNOWN_ENV = {"MS_OPTIONS", "MS_LIB", "MS_SHARED_DEVICE", "MS_SWITCH_MATRIX", "MS_MATRIX_EXTRA", "MS_TRACE_DUMP", "MS_R5_THREADS"}
+_KNOWN_ENV = {"MS_OPTIONS", "MS_LIB", "MS_SHARED_DEVICE", "MS_SWITCH_MATRIX", "MS_MATRIX_EXTRA", "MS_TRACE_DUMP", "MS_R5_THREADS", "MS_GUARD_PAGES"}
 _legacy = sorted(k for k in os.environ if k.startswith("MS_") and k not in _KNOWN_ENV)
 if _legacy:
     import warnings
