@@ -9,7 +9,7 @@ section 3); this makes the search deliberate.
     MS_GUARD_PAGES=end|start PYTORCH_NO_CUDA_MEMORY_CACHING=1 python -m pytest tests/... -m gpu        (tests/conftest.py installs it; tests/test_guard_pages_gpu.py runs it)
 
 What is guarded: every torch.empty / zeros / ones / full / *_like call made from inside maxstyle_amd (engine buffers, op outputs, packed weights with their appendix,
-tables, workspaces) and the tests' own device tensors created through `guarded(t)`.  `end`: the tensor's last byte is within 15 bytes of the block's end (16-byte
+tables, workspaces) and every host-to-device `Tensor.to` copy (the tests' inputs).  `end`: the tensor's last byte is within 15 bytes of the block's end (16-byte
 alignment of the start is kept - the kernels' vector paths check it); `start`: the tensor starts the block (a 2 MiB-aligned address whose preceding page belongs to
 no allocation of this process)."""
 import importlib
@@ -93,8 +93,20 @@ class _TorchProxy:
         return self.empty_like(t, **kw).zero_()
 
 
+_orig_to = torch.Tensor.to
+
+
+def _guarded_to(self, *args, **kw):
+    """Tensor.to under the guard: a fresh host-to-device copy (the tests' `_rand(...).to(dev)` inputs) lands in a guarded block too."""
+    r = _orig_to(self, *args, **kw)
+    if r.is_cuda and not self.is_cuda and r.numel() > 0 and r.is_contiguous() and not r.requires_grad and type(r) is torch.Tensor:
+        return guarded(r)
+    return r
+
+
 def install():
-    """Swap the `torch` name inside every maxstyle_amd module for the proxy (idempotent)."""
+    """Swap the `torch` name inside every maxstyle_amd module for the proxy, and Tensor.to for the guarded copy (idempotent)."""
+    torch.Tensor.to = _guarded_to
     if os.environ.get("PYTORCH_NO_CUDA_MEMORY_CACHING") != "1":
         raise RuntimeError("MS_GUARD_PAGES needs PYTORCH_NO_CUDA_MEMORY_CACHING=1 (every allocation its own hipMalloc)")
     import maxstyle_amd
